@@ -1,0 +1,100 @@
+"""ctypes loader for libaukit_hip.so (the C ABI of include/aukit_hip.h).
+
+There is deliberately NO CPU fallback: if the HIP library is missing, or no MI355X is
+visible when a context is created, this module raises.  The CPU oracle under oracle/ is
+test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["runtime.hip", "resample.hip", "api_resample.hip", "codecs.hip", "effects.hip", "flac.hip", "stubs.hip"]
+HEADERS = ["common.h", "resample.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
+
+OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
+F64, F32, I8 = 0, 1, 2
+INTERP = {"none": 0, "linear": 1, "cubic": 2, "sinc": 3}
+PCM_TYPE = {"signed": 0, "unsigned": 1, "float": 2}
+CODEC_PCM, CODEC_G711, CODEC_ADPCM, CODEC_ADPCM_WAV, CODEC_MSADPCM, CODEC_DFPWM, CODEC_MDFPWM, CODEC_QOA, CODEC_FLAC = range(9)
+FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center": 5, "trim": 6, "delay": 7, "echo": 8, "reverb": 9,
+      "lowpass": 10, "highpass": 11}
+MAX_CH = 8
+
+# every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "aukit_abi_version", "aukit_last_error", "aukit_ctx_create", "aukit_ctx_destroy", "aukit_ctx_set_stream", "aukit_ctx_get_stream",
+    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end",
+    "aukit_ctx_set_kernel_timing", "aukit_ctx_last_kernel",
+    "aukit_batch_upload", "aukit_batch_wrap_device", "aukit_batch_info", "aukit_batch_offsets", "aukit_batch_device_ptr",
+    "aukit_batch_download", "aukit_batch_free",
+    "aukit_audio_upload", "aukit_audio_info", "aukit_audio_layout", "aukit_audio_device_ptr", "aukit_audio_download",
+    "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
+    "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode",
+    "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
+]
+
+
+class CodecDesc(C.Structure):
+    _fields_ = [("codec", C.c_int32), ("channels", C.c_int32), ("sample_rate", C.c_double), ("bit_depth", C.c_int32),
+                ("data_type", C.c_int32), ("big_endian", C.c_int32), ("interleaved", C.c_int32), ("ulaw", C.c_int32),
+                ("top_first", C.c_int32), ("block_align", C.c_int32), ("ncoef", C.c_int32), ("coef1", C.c_int16 * 32),
+                ("coef2", C.c_int16 * 32), ("predictor", C.c_int32 * MAX_CH), ("step_index", C.c_int32 * MAX_CH)]
+
+
+class AukitError(RuntimeError):
+    """Raised for every non-zero aukit_status; `.code` is the status, `.msg` the reference's error text."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+        self.msg = msg
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 all of csrc/ into aukit_amd/libaukit_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(aukit_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.aukit_last_error.restype = C.c_char_p
+    L.aukit_ctx_get_stream.restype = C.c_void_p
+    L.aukit_batch_device_ptr.restype = C.c_void_p
+    L.aukit_audio_device_ptr.restype = C.c_void_p
+    L.aukit_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.aukit_batch_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    for name in ("aukit_ctx_destroy", "aukit_batch_free", "aukit_audio_free", "aukit_chunks_free"):
+        getattr(L, name).restype = None
+        getattr(L, name).argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise AukitError(rc, lib().aukit_last_error().decode(errors="replace"))

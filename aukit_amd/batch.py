@@ -1,0 +1,309 @@
+"""Batch-level host API over the C ABI: N independent streams per call.
+
+This is the MI355X-shaped face of the hot path (one call = one fused kernel over the whole batch);
+`aukit_amd.aukit` mirrors the reference's single-stream Lua API on top of it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def make_desc(codec, channels=1, sample_rate=48000.0, bit_depth=8, data_type="signed", big_endian=False, interleaved=True,
+              ulaw=True, top_first=True, block_align=0, coefficients=None, predictor=None, step_index=None):
+    d = N.CodecDesc()
+    d.codec = codec
+    d.channels = int(channels)
+    d.sample_rate = float(sample_rate)
+    d.bit_depth = int(bit_depth)
+    d.data_type = N.PCM_TYPE[data_type] if isinstance(data_type, str) else int(data_type)
+    d.big_endian = int(bool(big_endian))
+    d.interleaved = int(bool(interleaved))
+    d.ulaw = int(bool(ulaw))
+    d.top_first = int(bool(top_first))
+    d.block_align = int(block_align)
+    if coefficients:
+        d.ncoef = len(coefficients[0])
+        for i, v in enumerate(coefficients[0]):
+            d.coef1[i] = int(v)
+        for i, v in enumerate(coefficients[1]):
+            d.coef2[i] = int(v)
+    if predictor is not None:
+        for i, v in enumerate(predictor):
+            d.predictor[i] = int(v)
+    if step_index is not None:
+        for i, v in enumerate(step_index):
+            d.step_index[i] = int(v)
+    return d
+
+
+class Context:
+    """One GPU + one HIP stream (aukit_ctx)."""
+
+    def __init__(self, device=0, dtype=N.F64):
+        self._h = C.c_void_p()
+        N.check(N.lib().aukit_ctx_create(C.byref(self._h), int(device)))
+        self.device = device
+        self.dtype = dtype
+        N.check(N.lib().aukit_ctx_set_dtype(self._h, dtype))
+
+    def close(self):
+        if self._h:
+            N.lib().aukit_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        N.check(N.lib().aukit_ctx_set_stream(self._h, C.c_void_p(int(hip_stream_ptr))))
+
+    def sync(self):
+        N.check(N.lib().aukit_ctx_sync(self._h))
+
+    def timer_begin(self):
+        N.check(N.lib().aukit_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        N.check(N.lib().aukit_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_kernel_timing(self, on=True):
+        N.check(N.lib().aukit_ctx_set_kernel_timing(self._h, int(on)))
+
+    def last_kernel(self):
+        name = C.c_char_p()
+        ms = C.c_float()
+        nb = C.c_uint64()
+        N.check(N.lib().aukit_ctx_last_kernel(self._h, C.byref(name), C.byref(ms), C.byref(nb)))
+        return (name.value or b"").decode(), ms.value, nb.value
+
+    def set_sinc_window(self, w):
+        N.check(N.lib().aukit_ctx_set_sinc_window(self._h, int(w)))
+
+
+class Batch:
+    """N byte strings resident on the device (aukit_batch)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._keep = None
+
+    @classmethod
+    def upload(cls, ctx, streams):
+        streams = [bytes(s) if not isinstance(s, (bytes, bytearray, memoryview)) else s for s in streams]
+        offs = np.zeros(len(streams) + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in streams], out=offs[1:])
+        blob = b"".join(streams)
+        buf = (C.c_uint8 * max(len(blob), 1)).from_buffer_copy(blob if blob else b"\0")
+        h = C.c_void_p()
+        N.check(N.lib().aukit_batch_upload(ctx._h, C.byref(h), buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(streams))))
+        return cls(ctx, h)
+
+    @classmethod
+    def wrap(cls, ctx, device_ptr, offsets, keep=None):
+        """Zero-copy view of bytes already on this GPU (e.g. a torch uint8 tensor's data_ptr())."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        N.check(N.lib().aukit_batch_wrap_device(ctx._h, C.byref(h), C.c_void_p(int(device_ptr)), offs.ctypes.data_as(C.c_void_p), C.c_uint32(len(offs) - 1)))
+        b = cls(ctx, h)
+        b._keep = keep
+        return b
+
+    def info(self):
+        n = C.c_uint32()
+        tot = C.c_uint64()
+        N.check(N.lib().aukit_batch_info(self._h, C.byref(n), C.byref(tot)))
+        return n.value, tot.value
+
+    def offsets(self):
+        n, _ = self.info()
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        N.check(N.lib().aukit_batch_offsets(self._h, offs.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return offs
+
+    def device_ptr(self):
+        return N.lib().aukit_batch_device_ptr(self._h)
+
+    def download(self):
+        n, tot = self.info()
+        buf = np.zeros(max(tot, 1), dtype=np.uint8)
+        N.check(N.lib().aukit_batch_download(self.ctx._h, self._h, buf.ctypes.data_as(C.POINTER(C.c_uint8))))
+        offs = self.offsets()
+        return [bytes(buf[int(offs[i]):int(offs[i + 1])]) for i in range(n)]
+
+    def free(self):
+        if self._h:
+            N.lib().aukit_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class AudioBatch:
+    """N aukit.Audio objects (same channel count and sample rate) resident on the device (aukit_audio)."""
+
+    def __init__(self, ctx, handle=None):
+        self.ctx = ctx
+        self._h = handle if handle is not None else C.c_void_p()
+
+    @classmethod
+    def upload(cls, ctx, streams, sample_rate, dtype=None):
+        """streams: list (per stream) of list (per channel) of 1-D arrays of equal length."""
+        dtype = ctx.dtype if dtype is None else dtype
+        channels = len(streams[0])
+        lens = np.array([len(s[0]) for s in streams], dtype=np.uint64)
+        flat = np.concatenate([np.asarray(ch, dtype=np.float64).ravel() for s in streams for ch in s]) if len(streams) else np.zeros(0)
+        flat = np.ascontiguousarray(flat, dtype=np.float64)
+        if flat.size == 0:
+            flat = np.zeros(1)
+        h = C.c_void_p()
+        N.check(N.lib().aukit_audio_upload(ctx._h, C.byref(h), flat.ctypes.data_as(C.POINTER(C.c_double)), lens.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           C.c_uint32(len(streams)), channels, C.c_double(sample_rate), dtype))
+        return cls(ctx, h)
+
+    def info(self):
+        n = C.c_uint32()
+        ch = C.c_int()
+        rate = C.c_double()
+        dt = C.c_int()
+        tot = C.c_uint64()
+        N.check(N.lib().aukit_audio_info(self._h, C.byref(n), C.byref(ch), C.byref(rate), C.byref(dt), C.byref(tot)))
+        return dict(n=n.value, channels=ch.value, sample_rate=rate.value, dtype=dt.value, total_elems=tot.value)
+
+    def layout(self):
+        n = self.info()["n"]
+        lens = np.zeros(n, dtype=np.uint64)
+        off = np.zeros(n, dtype=np.uint64)
+        stride = np.zeros(n, dtype=np.uint64)
+        N.check(N.lib().aukit_audio_layout(self._h, lens.ctypes.data_as(C.POINTER(C.c_uint64)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           stride.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return lens, off, stride
+
+    def device_ptr(self):
+        return N.lib().aukit_audio_device_ptr(self._h)
+
+    def download(self):
+        """→ list (per stream) of list (per channel) of float64 arrays (exact for every storage dtype)."""
+        inf = self.info()
+        lens, _, _ = self.layout()
+        total = int(lens.sum()) * inf["channels"]
+        buf = np.zeros(max(total, 1), dtype=np.float64)
+        N.check(N.lib().aukit_audio_download(self.ctx._h, self._h, buf.ctypes.data_as(C.POINTER(C.c_double))))
+        out, p = [], 0
+        for s in range(inf["n"]):
+            chs = []
+            for _ in range(inf["channels"]):
+                chs.append(buf[p:p + int(lens[s])].copy())
+                p += int(lens[s])
+            out.append(chs)
+        return out
+
+    def clone(self):
+        h = C.c_void_p()
+        N.check(N.lib().aukit_audio_clone(self.ctx._h, self._h, C.byref(h)))
+        return AudioBatch(self.ctx, h)
+
+    def free(self):
+        if self._h:
+            N.lib().aukit_audio_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Chunks:
+    """Per-stream chunk metadata of a stream.* run (lengths and the iterator's position values)."""
+
+    def __init__(self, handle):
+        n = C.c_uint32()
+        mx = C.c_uint32()
+        N.check(N.lib().aukit_chunks_info(handle, C.byref(n), C.byref(mx)))
+        self.n, self.max_chunks = n.value, mx.value
+        m = max(self.max_chunks, 1)
+        self.nchunks = np.zeros(self.n, dtype=np.uint32)
+        self.lens = np.zeros((self.n, m), dtype=np.uint32)
+        self.pos = np.zeros((self.n, m), dtype=np.float64)
+        self.status = np.zeros(self.n, dtype=np.int32)
+        self.length_seconds = np.zeros(self.n, dtype=np.float64)
+        N.check(N.lib().aukit_chunks_get(handle, self.nchunks.ctypes.data_as(C.POINTER(C.c_uint32)), self.lens.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         self.pos.ctypes.data_as(C.POINTER(C.c_double)), self.status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         self.length_seconds.ctypes.data_as(C.POINTER(C.c_double))))
+        N.lib().aukit_chunks_free(handle)
+
+
+def _interp(i):
+    return N.INTERP[i] if isinstance(i, str) else int(i)
+
+
+def decode(ctx, batch, desc, dtype=None, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_decode(ctx._h, batch._h, C.byref(desc), ctx.dtype if dtype is None else dtype, C.byref(out._h)))
+    return out
+
+
+def decode_resample(ctx, batch, desc, new_rate, interp, dtype=None, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_decode_resample(ctx._h, batch._h, C.byref(desc), C.c_double(new_rate), _interp(interp),
+                                          ctx.dtype if dtype is None else dtype, C.byref(out._h)))
+    return out
+
+
+def resample(ctx, audio, new_rate, interp, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_resample(ctx._h, audio._h, C.c_double(new_rate), _interp(interp), C.byref(out._h)))
+    return out
+
+
+def mono(ctx, audio, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_mono(ctx._h, audio._h, C.byref(out._h)))
+    return out
+
+
+def mix(ctx, audios, amplifier=1.0, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    arr = (C.c_void_p * len(audios))(*[a._h for a in audios])
+    N.check(N.lib().aukit_mix(ctx._h, arr, len(audios), C.c_double(amplifier), C.byref(out._h)))
+    return out
+
+
+def effect(ctx, audio, name, *args):
+    a = (C.c_double * max(len(args), 1))(*[float(x) for x in args])
+    N.check(N.lib().aukit_effect(ctx._h, audio._h, N.FX[name], a, len(args)))
+    return audio
+
+
+def dfpwm_encode(ctx, audio, interleaved=True, out=None):
+    out = out if out is not None else Batch(ctx, C.c_void_p())
+    N.check(N.lib().aukit_dfpwm_encode(ctx._h, audio._h, int(bool(interleaved)), C.byref(out._h)))
+    return out
+
+
+def encode_pcm(ctx, audio, bit_depth=8, data_type="signed", interleaved=True, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_encode_pcm(ctx._h, audio._h, int(bit_depth), N.PCM_TYPE[data_type] if isinstance(data_type, str) else int(data_type),
+                                     int(bool(interleaved)), C.byref(out._h)))
+    return out
+
+
+def stream_decode(ctx, batch, desc, interp, mono=False, dtype=None, out=None):
+    out = out if out is not None else AudioBatch(ctx)
+    ch = C.c_void_p()
+    N.check(N.lib().aukit_stream_decode(ctx._h, batch._h, C.byref(desc), _interp(interp), int(bool(mono)),
+                                        ctx.dtype if dtype is None else dtype, C.byref(out._h), C.byref(ch)))
+    return out, Chunks(ch)

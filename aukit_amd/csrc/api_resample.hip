@@ -1,0 +1,408 @@
+// api_resample.hip — host planners that expand C-ABI calls into segments for the fused resample engine:
+//   aukit_decode / aukit_decode_resample  (PCM, G.711)        aukit.lua:1049-1171, :1361-1384, :653-673
+//   aukit_resample                        (Audio:resample)    aukit.lua:653-673
+//   aukit_stream_decode                   (stream.pcm, stream.g711)  aukit.lua:2228-2424, :2850-2913
+// Block codecs (ADPCM, MS-ADPCM, DFPWM, QOA, FLAC) are routed to codecs.hip.
+#include <algorithm>
+#include "resample.h"
+
+namespace aukit {
+
+int decode_block_codec(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample,
+                       int dtype, aukit_audio **out);
+int stream_block_codec(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype,
+                       aukit_audio **out, aukit_chunks **chunks);
+
+static int check_pcm_desc(const aukit_codec_desc *d) {
+    if (d->bit_depth != 8 && d->bit_depth != 16 && d->bit_depth != 24 && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
+    if (d->data_type < 0 || d->data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
+    if (d->data_type == AUKIT_FLOAT && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
+    if (d->channels < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
+    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #5 (number outside of range)");
+    if (d->channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_CHANNELS);
+    return AUKIT_OK;
+}
+
+static void fill_source(ResampleParams &P, const aukit_batch *in, const aukit_codec_desc *d) {
+    P.src = in->data();
+    P.src_off = reinterpret_cast<const unsigned long long *>(in->d_off);
+    P.src_frames = nullptr;
+    P.safe_lo = in->base;
+    P.safe_hi = in->base + (in->cap & ~(size_t)15);
+    P.channels = d->channels;
+    P.bit_depth = d->bit_depth;
+    P.data_type = d->data_type;
+    P.big_endian = d->big_endian;
+    P.planar = 0;
+    P.ulaw = d->ulaw;
+    P.premix_mono = 0;
+    P.mix_mono = 0;
+    P.lp_alpha = 0;
+    P.norm_pos = P.norm_neg = 1;
+    P.g711_scale = 1.0 / 8192.0;
+}
+
+static bool all_even(const aukit_batch *in) {
+    if (((uintptr_t)in->data()) & 1) return false;
+    for (uint32_t s = 0; s < in->n; s++)
+        if (in->off[s] & 1) return false;
+    return true;
+}
+
+static int pick_pcm_source(const aukit_batch *in, const aukit_codec_desc *d, bool planar, bool premix) {
+    if (d->bit_depth == 16 && d->data_type == AUKIT_SIGNED && !d->big_endian && d->channels == 1 && !planar && !premix && all_even(in)) return SRC_PCM_S16LE_MONO;
+    return SRC_PCM_GENERIC;
+}
+
+// number of outputs of Audio:resample: `for i = 1, #data * ratio`  aukit.lua:659-664
+static inline uint64_t resample_count(uint64_t n_in, double ratio) {
+    double newlen = (double)n_in * ratio;
+    return newlen >= 1 ? (uint64_t)std::floor(newlen) : 0;
+}
+
+// fused  aukit.pcm/g711(data, ...):resample(new_rate, interp)  (ratio == 1 → plain decode)
+static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample,
+                                int dtype, aukit_audio **out) {
+    const int C = d->channels;
+    int rc;
+    bool planar = false;
+    if (d->codec == AUKIT_CODEC_PCM) {
+        if ((rc = check_pcm_desc(d))) return rc;
+        planar = !(d->interleaved && C > 1) && C > 1;  // aukit.lua:1156-1169
+    } else {
+        if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
+    }
+    const size_t frame_bytes = d->codec == AUKIT_CODEC_PCM ? (size_t)(d->bit_depth / 8) * C : (size_t)C;
+    const double ratio = do_resample ? new_rate / d->sample_rate : 1.0;  // :658
+    if (!(ratio > 0)) return fail(AUKIT_E_ARG, "bad sample rate");
+    std::vector<uint64_t> frames(in->n), lens(in->n);
+    uint64_t in_bytes = 0, out_elems = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        uint64_t nb = in->off[s + 1] - in->off[s];
+        if (nb % frame_bytes != 0) {
+            if (d->codec == AUKIT_CODEC_PCM) return fail(AUKIT_E_ARG, "bad argument #1 (uneven amount of data per channel)");  // :1064
+            return fail(AUKIT_E_UNSUPPORTED, "G.711 data length is not a multiple of the channel count (stream %u)", s);
+        }
+        frames[s] = nb / frame_bytes;
+        lens[s] = do_resample ? resample_count(frames[s], ratio) : frames[s];
+        if (lens[s]) {
+            double xl = host_pos(lens[s] - 1, ratio);
+            if (std::floor(xl) > (double)frames[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        }
+        in_bytes += nb;
+        out_elems += lens[s] * (uint64_t)C;
+    }
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, C, do_resample ? new_rate : d->sample_rate, dtype, lens.data()))) return rc;
+    *out = a;
+    std::vector<Seg> segs(in->n);
+    for (uint32_t s = 0; s < in->n; s++) {
+        Seg &g = segs[s];
+        g.src_base = -1;  // table index 1 ↔ frame 0
+        g.w_lo = 1;
+        g.w_hi = (int)frames[s];
+        g.n_out = (unsigned)lens[s];
+        g.stream = s;
+        g.out_off = a->row_off[s];
+        g.out_stride = (unsigned)a->row_stride[s];
+        g.pad = 0;
+        if (frames[s] > 0x7FFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "stream too long");
+    }
+    ResampleParams P;
+    memset(&P, 0, sizeof P);
+    fill_source(P, in, d);
+    int src;
+    if (d->codec == AUKIT_CODEC_PCM) {
+        src = pick_pcm_source(in, d, planar, false);
+        P.planar = planar ? 1 : 0;
+        if (planar) {
+            if ((rc = upload_table(ctx, ctx->misc_buf, frames.data(), frames.size() * sizeof(uint64_t)))) return rc;
+            P.src_frames = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        }
+    } else {
+        src = C == 1 ? SRC_G711_MONO : SRC_G711;
+        P.g711_scale = 1.0 / 8192.0;  // m / 0x2000  :1379
+    }
+    P.out = a->dev;
+    size_t lds;
+    if ((rc = plan_tiles(ctx, segs, ratio, do_resample ? interp : AUKIT_INTERP_NONE, C, P, &lds))) return rc;
+    return launch_resample(ctx, src, do_resample ? interp : AUKIT_INTERP_NONE, EPI_AUDIO, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
+}
+
+// ---------------------------------------------------------------- stream.pcm  aukit.lua:2228-2424
+struct ChunkPlan {
+    double ratio;
+    int interp;
+    long K;                        // table re-base per full chunk (Q1)
+    std::vector<int> acc, req;     // per output j (1-based → [j-1]): highest index touched so far / index that must be non-nil
+};
+
+static int build_chunk_plan(double sample_rate, int interp, ChunkPlan &cp) {
+    static const int iend[4] = {1, 2, 3, 0};
+    cp.ratio = 48000 / sample_rate;  // :2364
+    cp.interp = interp;
+    cp.acc.resize(48000);
+    cp.req.resize(48000);
+    int mx = iend[interp];
+    for (int j = 1; j <= 48000; j++) {
+        double x = ((double)(j - 1) / cp.ratio) + 1;
+        double ffx = std::floor(x);
+        bool isint = x == ffx;
+        int top = isint ? (int)x : (int)ffx + (interp == AUKIT_INTERP_CUBIC ? 2 : (interp == AUKIT_INTERP_LINEAR ? 1 : 0));
+        if (top > mx) mx = top;
+        cp.acc[j - 1] = mx;
+        cp.req[j - 1] = (int)ffx;
+    }
+    cp.K = mx;
+    return AUKIT_OK;
+}
+
+static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
+                      aukit_chunks **chunks_out) {
+    int rc;
+    if ((rc = check_pcm_desc(d))) return rc;
+    if (interp == AUKIT_INTERP_SINC) return fail(AUKIT_E_UNSUPPORTED, "stream.pcm with sinc interpolation reads its lazy table out of order (not reproduced on the GPU)");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
+    if (d->sample_rate > 48000) return fail(AUKIT_E_UNSUPPORTED, "stream.pcm above 48 kHz is ill-defined in the reference (lazy table read out of order, SURVEY Q3)");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.pcm output must be AUKIT_F64 or AUKIT_F32");
+    const int C = d->channels;
+    if (C == 1) mono = 0;  // :2243
+    const int nd = mono ? 1 : C;
+    const int bd = d->bit_depth / 8;
+    static const int istart[4] = {1, 1, 0, 0}, iend[4] = {1, 2, 3, 0};  // :283-284
+    ChunkPlan cp;
+    build_chunk_plan(d->sample_rate, interp, cp);
+    const bool is_float = d->data_type == AUKIT_FLOAT;
+
+    aukit_chunks *ck = new aukit_chunks();
+    ck->n = in->n;
+    ck->nchunks.assign(in->n, 0);
+    ck->status.assign(in->n, 0);
+    ck->length_seconds.assign(in->n, 0);
+    std::vector<std::vector<uint32_t>> clens(in->n);
+    std::vector<uint64_t> lens(in->n, 0);
+    std::vector<Seg> segs;
+    uint64_t in_bytes = 0, out_elems = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        uint64_t nb = in->off[s + 1] - in->off[s];
+        if (nb % ((size_t)bd * C) != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream.pcm: data is not a whole number of frames (stream %u)", s); }
+        const long long nframes = (long long)(nb / ((size_t)bd * C));
+        ck->length_seconds[s] = ((double)nb / bd) / C / d->sample_rate;  // :2245, :2423
+        in_bytes += nb;
+        for (long c = 0;; c++) {
+            const long long src_base = (long long)c * cp.K - istart[interp];  // frame of table index 0
+            // prefill :2376-2386 reads eagerly up to index iend
+            if (src_base + iend[interp] > nframes - 1) { ck->status[s] = is_float ? 0 : AUKIT_E_LUA; break; }
+            const long long w_avail = nframes - 1 - src_base;
+            const std::vector<int> &need = is_float ? cp.req : cp.acc;
+            uint32_t n_out = (uint32_t)(std::upper_bound(need.begin(), need.end(), (int)std::min<long long>(w_avail, 0x7FFFFFFF)) - need.begin());
+            if (n_out == 0) break;  // :2407
+            Seg g;
+            g.src_base = src_base;
+            g.w_lo = c == 0 ? istart[interp] : -1;
+            g.w_hi = (int)std::min<long long>(w_avail, 0x7FFFFFF0);
+            g.n_out = n_out;
+            g.stream = s;
+            g.out_off = lens[s];  // patched with the row offset below
+            g.out_stride = 0;
+            g.pad = 0;
+            segs.push_back(g);
+            clens[s].push_back(n_out);
+            lens[s] += n_out;
+            if (n_out < 48000) break;  // ok = false → next call returns nil
+        }
+        ck->nchunks[s] = (uint32_t)clens[s].size();
+        ck->max_chunks = std::max<uint32_t>(ck->max_chunks, ck->nchunks[s]);
+        out_elems += lens[s] * (uint64_t)nd;
+    }
+    ck->lens.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
+    ck->pos.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
+    for (uint32_t s = 0; s < in->n; s++) {
+        double nacc = 0;
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
+            ck->lens[(size_t)s * ck->max_chunks + k] = clens[s][k];
+            ck->pos[(size_t)s * ck->max_chunks + k] = nacc / 48000;  // (n - #chunk[1]) / 48000  :2422
+            nacc += clens[s][k];
+        }
+    }
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
+    *out = a;
+    for (Seg &g : segs) {
+        g.out_off += a->row_off[g.stream];
+        g.out_stride = (unsigned)a->row_stride[g.stream];
+    }
+    ResampleParams P;
+    memset(&P, 0, sizeof P);
+    fill_source(P, in, d);
+    P.premix_mono = mono ? 1 : 0;
+    P.lp_alpha = 1 - std::exp(-(d->sample_rate / 96000) * 2 * M_PI);  // :2365
+    P.out = a->dev;
+    int src = pick_pcm_source(in, d, false, mono != 0);
+    size_t lds;
+    if ((rc = plan_tiles(ctx, segs, cp.ratio, interp, nd, P, &lds))) { delete ck; return rc; }
+    rc = launch_resample(ctx, src, interp, EPI_STREAM_PCM, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
+    if (rc) { delete ck; return rc; }
+    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+    return AUKIT_OK;
+}
+
+// ---------------------------------------------------------------- stream.g711  aukit.lua:2850-2913
+static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
+                       aukit_chunks **chunks_out) {
+    const int C = d->channels;
+    if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
+    if (d->sample_rate != std::floor(d->sample_rate) || d->sample_rate < 1) return fail(AUKIT_E_UNSUPPORTED, "stream.g711 needs an integer sample rate");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
+    if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.g711 output must be AUKIT_I8 or AUKIT_F64");
+    const double ratio = 48000 / d->sample_rate;
+    const uint64_t per_call = (uint64_t)d->sample_rate * (uint64_t)C;
+    const int nd = mono ? 1 : C;
+    aukit_chunks *ck = new aukit_chunks();
+    ck->n = in->n;
+    ck->nchunks.assign(in->n, 0);
+    ck->status.assign(in->n, 0);
+    ck->length_seconds.assign(in->n, 0);
+    std::vector<uint64_t> lens(in->n, 0);
+    std::vector<Seg> segs;
+    uint64_t in_bytes = 0, out_elems = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        uint64_t nb = in->off[s + 1] - in->off[s];
+        if (nb % (uint64_t)C != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "G.711 data length is not a multiple of the channel count (stream %u)", s); }
+        ck->length_seconds[s] = (double)nb / d->sample_rate / C;
+        in_bytes += nb;
+        uint32_t calls = (uint32_t)((nb + per_call - 1) / per_call);  // calls that see data; the reference then returns {{}} forever (Q13)
+        ck->nchunks[s] = calls;
+        ck->max_chunks = std::max(ck->max_chunks, calls);
+    }
+    ck->lens.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
+    ck->pos.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
+    for (uint32_t s = 0; s < in->n; s++) {
+        uint64_t nb = in->off[s + 1] - in->off[s];
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
+            uint64_t pos = (uint64_t)k * per_call;
+            uint64_t cnt = std::min<uint64_t>(per_call, nb - pos);
+            uint64_t m = cnt / C;                                       // #retval[1]
+            uint32_t n_out = (uint32_t)std::floor((double)m * ratio);   // :2897
+            Seg g;
+            g.src_base = (long long)(pos / C) - 1;
+            g.w_lo = 1;
+            g.w_hi = (int)m;
+            g.n_out = n_out;
+            g.stream = s;
+            g.out_off = lens[s];
+            g.out_stride = 0;
+            g.pad = 0;
+            segs.push_back(g);
+            ck->lens[(size_t)s * ck->max_chunks + k] = n_out;
+            ck->pos[(size_t)s * ck->max_chunks + k] = ((double)(pos + 1) - 1) / d->sample_rate / C;  // (lp - 1) / sampleRate / channels
+            lens[s] += n_out;
+        }
+        out_elems += lens[s] * (uint64_t)nd;
+    }
+    int rc;
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
+    *out = a;
+    for (Seg &g : segs) {
+        g.out_off += a->row_off[g.stream];
+        g.out_stride = (unsigned)a->row_stride[g.stream];
+    }
+    ResampleParams P;
+    memset(&P, 0, sizeof P);
+    fill_source(P, in, d);
+    P.g711_scale = 1.0 / 64.0;  // m / 0x40  :2891
+    P.mix_mono = mono ? 1 : 0;
+    P.out = a->dev;
+    size_t lds;
+    if ((rc = plan_tiles(ctx, segs, ratio, interp, C, P, &lds))) { delete ck; return rc; }
+    rc = launch_resample(ctx, C == 1 ? SRC_G711_MONO : SRC_G711, interp, EPI_STREAM_FLOOR, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
+    if (rc) { delete ck; return rc; }
+    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+    return AUKIT_OK;
+}
+
+}  // namespace aukit
+
+using namespace aukit;
+
+extern "C" {
+
+int aukit_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int dtype, aukit_audio **out) {
+    if (!ctx || !in || !desc || !out) return fail(AUKIT_E_ARG, "null argument");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "dtype must be AUKIT_F64 or AUKIT_F32");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (desc->codec == AUKIT_CODEC_PCM || desc->codec == AUKIT_CODEC_G711) return decode_resample_flat(ctx, in, desc, desc->sample_rate, AUKIT_INTERP_NONE, false, dtype, out);
+    return decode_block_codec(ctx, in, desc, 0, 0, false, dtype, out);
+}
+
+int aukit_decode_resample(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, double new_rate, int interp, int dtype,
+                          aukit_audio **out) {
+    if (!ctx || !in || !desc || !out) return fail(AUKIT_E_ARG, "null argument");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "dtype must be AUKIT_F64 or AUKIT_F32");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "bad argument #2 (invalid interpolation type)");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (desc->codec == AUKIT_CODEC_PCM || desc->codec == AUKIT_CODEC_G711) return decode_resample_flat(ctx, in, desc, new_rate, interp, true, dtype, out);
+    return decode_block_codec(ctx, in, desc, new_rate, interp, true, dtype, out);
+}
+
+int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int interp, aukit_audio **out) {
+    if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "bad argument #2 (invalid interpolation type)");
+    if (in->dtype != AUKIT_F64 && in->dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "resample needs a float audio");
+    if (*out == in) return fail(AUKIT_E_ARG, "resample cannot run in place");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    const double ratio = new_rate / in->rate;  // :658
+    if (!(ratio > 0)) return fail(AUKIT_E_ARG, "bad sample rate");
+    const int C = in->channels;
+    std::vector<uint64_t> lens(in->n);
+    uint64_t in_elems = 0, out_elems = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        lens[s] = resample_count(in->len[s], ratio);
+        if (lens[s] && std::floor(host_pos(lens[s] - 1, ratio)) > (double)in->len[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        in_elems += in->len[s] * (uint64_t)C;
+        out_elems += lens[s] * (uint64_t)C;
+    }
+    aukit_audio *a = *out;
+    int rc;
+    if ((rc = audio_prepare(ctx, &a, in->n, C, new_rate, in->dtype, lens.data()))) return rc;
+    *out = a;
+    std::vector<Seg> segs((size_t)in->n * C);
+    std::vector<uint64_t> rows((size_t)in->n * C);
+    for (uint32_t s = 0; s < in->n; s++)
+        for (int c = 0; c < C; c++) {
+            size_t r = (size_t)s * C + c;
+            rows[r] = in->row_off[s] + (uint64_t)c * in->row_stride[s];
+            Seg &g = segs[r];
+            g.src_base = -1;
+            g.w_lo = 1;
+            g.w_hi = (int)in->len[s];
+            g.n_out = (unsigned)lens[s];
+            g.stream = (unsigned)r;
+            g.out_off = a->row_off[s] + (uint64_t)c * a->row_stride[s];
+            g.out_stride = 0;
+            g.pad = 0;
+        }
+    if ((rc = upload_table(ctx, ctx->misc_buf, rows.data(), rows.size() * sizeof(uint64_t)))) return rc;
+    ResampleParams P;
+    memset(&P, 0, sizeof P);
+    P.src = reinterpret_cast<const unsigned char *>(in->dev);
+    P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+    P.channels = 1;
+    P.out = a->dev;
+    size_t lds;
+    if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) return rc;
+    return launch_resample(ctx, in->dtype == AUKIT_F64 ? SRC_AUDIO_F64 : SRC_AUDIO_F32, interp, EPI_AUDIO, in->dtype, P, lds,
+                           (in_elems + out_elems) * dtype_size(in->dtype), nullptr);
+}
+
+int aukit_stream_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int interp, int mono, int dtype,
+                        aukit_audio **out, aukit_chunks **chunks) {
+    if (!ctx || !in || !desc || !out) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (desc->codec == AUKIT_CODEC_PCM) return stream_pcm(ctx, in, desc, interp, mono, dtype, out, chunks);
+    if (desc->codec == AUKIT_CODEC_G711) return stream_g711(ctx, in, desc, interp, mono, dtype, out, chunks);
+    return stream_block_codec(ctx, in, desc, interp, mono, dtype, out, chunks);
+}
+
+}  // extern "C"

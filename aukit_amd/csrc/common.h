@@ -1,0 +1,140 @@
+// common.h — host-side object model and device-side exact-arithmetic helpers of libaukit_hip.so.
+// gfx950 (MI355X) only.  Compiled with -ffp-contract=off: every fused multiply-add in this library
+// is an explicit __builtin_fma, because the reference's arithmetic (Lua doubles, aukit.lua) has none.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/aukit_hip.h"
+
+namespace aukit {
+
+// ---------------------------------------------------------------- errors
+int fail(int code, const char *fmt, ...);
+#define AUKIT_HIP_CHECK(expr)                                                                          \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return ::aukit::fail(AUKIT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------- device buffers
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);  // grows (never shrinks); contents are NOT preserved
+    void release();
+};
+
+}  // namespace aukit
+
+// ---------------------------------------------------------------- opaque handle bodies
+struct aukit_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int dtype = AUKIT_F64;
+    int sinc_w = 10;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // user timer
+    hipEvent_t kev0 = nullptr, kev1 = nullptr;  // per-kernel timing
+    bool ktiming = false;
+    std::string last_kernel;
+    float last_ms = 0.f;
+    uint64_t last_bytes = 0;
+    int num_cus = 256;
+    // scratch tables (segment/tile/stream descriptors); plan_key caches the last uploaded plan
+    aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2;
+    std::string plan_key;
+    // verified range of the reciprocal-based exact division per ratio (see exact_div_verified)
+    std::map<double, uint64_t> div_ok;
+};
+
+struct aukit_batch {
+    uint32_t n = 0;
+    std::vector<uint64_t> off;  // n+1, relative to data()
+    uint8_t *base = nullptr;    // allocation (owned) or wrapped pointer
+    size_t front_pad = 0, cap = 0;
+    bool own = true;
+    uint64_t *d_off = nullptr;  // device copy of off (n+1)
+    uint64_t version = 0;       // bumped whenever contents/layout change (plan cache key)
+    uint8_t *data() const { return base + front_pad; }
+    uint64_t total() const { return off.empty() ? 0 : off.back(); }
+};
+
+struct aukit_audio {
+    uint32_t n = 0;
+    int channels = 1;
+    double rate = 48000;
+    int dtype = AUKIT_F64;
+    std::vector<uint64_t> len, row_off, row_stride;
+    uint64_t total = 0;  // elements
+    void *dev = nullptr;
+    size_t cap_bytes = 0;
+    uint64_t *d_meta = nullptr;  // device: len[n], row_off[n], row_stride[n]
+    size_t meta_cap = 0;
+    uint64_t version = 0;
+};
+
+struct aukit_chunks {
+    uint32_t n = 0, max_chunks = 0;
+    std::vector<uint32_t> nchunks, lens;
+    std::vector<double> pos, length_seconds;
+    std::vector<int32_t> status;
+};
+
+namespace aukit {
+
+static inline size_t dtype_size(int dt) { return dt == AUKIT_F64 ? 8 : (dt == AUKIT_F32 ? 4 : 1); }
+static inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// (re)shape *out for n streams of the given lengths; reuses its buffers when they are large enough.
+int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, double rate, int dtype, const uint64_t *lens);
+int ctx_begin_kernel(aukit_ctx *ctx);
+int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes);
+// uploads a host table into a ctx scratch buffer on the ctx stream
+int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes);
+// q = RN(n / d) computed as fma(fma(-d, n*r, n), r, n*r) with r = RN(1/d) is exact for the integers
+// n in [0, count): verified on the host once per (d, count) and cached in ctx->div_ok.
+bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count);
+
+// ---------------------------------------------------------------- device helpers
+#define AUKIT_DEV __device__ __forceinline__
+
+// Lua clamp(n, min, max)  aukit.lua:228-232 (NaN falls through unchanged, like the Lua)
+AUKIT_DEV double lua_clamp(double n, double mn, double mx) { return n < mn ? mn : (n > mx ? mx : n); }
+
+// correctly rounded a / b from r = RN(1/b): Markstein's correction step (two fmas)
+AUKIT_DEV double div_rcp(double a, double b, double r) {
+    double q0 = a * r;
+    double e = __builtin_fma(-b, q0, a);
+    return __builtin_fma(e, r, q0);
+}
+
+// correctly rounded fx^3 (what an exact pow(fx, 3) returns): double-double product
+AUKIT_DEV double pow3_rn(double fx) {
+    double hi = fx * fx;
+    double lo = __builtin_fma(fx, fx, -hi);
+    double p = hi * fx;
+    double pl = __builtin_fma(hi, fx, -p);
+    double t = __builtin_fma(lo, fx, pl);
+    return p + t;
+}
+
+// interpolate.cubic  aukit.lua:261-266 — same operation order, no contraction
+AUKIT_DEV double cubic_exact(double p0, double p1, double p2, double p3, double fx) {
+    double f2 = fx * fx;       // fx^2: pow(fx, 2) is exactly RN(fx*fx)
+    double f3 = pow3_rn(fx);   // fx^3
+    double c3 = -0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3;
+    double c2 = p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3;
+    double c1 = -0.5 * p0 + 0.5 * p2;
+    return c3 * f3 + c2 * f2 + c1 * fx + p1;
+}
+// interpolate.linear  aukit.lua:257-260
+AUKIT_DEV double linear_exact(double a, double b, double fx) { return a + (b - a) * fx; }
+
+}  // namespace aukit

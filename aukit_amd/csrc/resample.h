@@ -1,0 +1,76 @@
+// resample.h — the segment-based fused "stage → interpolate → epilogue" engine.
+//
+// Every resampling loop of the reference has the same shape (aukit.lua:662-671, :2395-2405,
+// :2818-2828, :2900-2910 ...): a Lua table `d` with valid indices w_lo..w_hi, and outputs
+// i = 1..n_out at position x = (i-1)/ratio + 1, `if x % 1 == 0 then d[x] else interp(d, x)`.
+// A *segment* is one such (table, output line) pair; the host expands an API call into segments
+// (one per stream for the Audio path, one per stream × chunk for stream.pcm / stream.g711 ...),
+// and one kernel walks tiles of segments: stage the needed window of the table into LDS as fp64
+// (decoding PCM / G.711 bytes on the way, so decoded samples never touch HBM), interpolate with the
+// reference's fp64 operation order, apply the epilogue, store coalesced.
+#pragma once
+#include "common.h"
+
+namespace aukit {
+
+struct Seg {
+    long long src_base;   // source frame index (within the stream / row) of table index 0
+    int w_lo, w_hi;       // valid table indices (anything else reads as nil)
+    unsigned n_out;       // number of outputs
+    unsigned stream;      // source stream (batch sources) or source row (audio sources)
+    unsigned long long out_off;  // element offset of output channel 0, output index 0
+    unsigned out_stride;  // element stride between output channels
+    unsigned pad;
+};
+static_assert(sizeof(Seg) == 40, "Seg layout");
+
+enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7 };
+enum EpiKind {
+    EPI_AUDIO = 0,       // Audio:resample  :666-668  (integer x copies unclamped, else clamp ±1)
+    EPI_STREAM_PCM = 1,  // stream.pcm      :2397-2403 (no clamp of interp, 2-tap FIR, ×127/128, clamp ±128/127)
+    EPI_STREAM_FLOOR = 2 // stream.g711/adpcm/msadpcm :2900-2910 (optional mono mean, floor, clamp)
+};
+
+struct ResampleParams {
+    // tiling
+    const Seg *segs;
+    const unsigned *tile_seg;   // tile → segment (ragged batches), or null
+    const unsigned *seg_tile0;  // segment → its first tile (ragged batches)
+    unsigned tiles_per_seg;     // != 0: uniform batch, tile → (tile / tps, tile % tps)
+    unsigned n_tiles;
+    int tile_out;               // outputs per tile
+    int cap;                    // LDS doubles per staged channel
+    // position arithmetic: x = (i-1)/ratio + 1
+    double ratio, rcp;
+    int exact_rcp;              // 1: RN((i-1)/ratio) via rcp + two fmas is verified exact for this launch
+    int halo_l, halo_r;         // taps below / above floor(x)
+    int sinc_w;
+    // source
+    const unsigned char *src;
+    const unsigned long long *src_off;     // per stream: byte offset (batch) / element offset (audio rows)
+    const unsigned long long *src_frames;  // per stream: frames per channel (planar PCM)
+    const unsigned char *safe_lo, *safe_hi; // 16-byte vector loads allowed in [safe_lo, safe_hi)
+    int channels;      // channels in the source data
+    int stage_channels;// channels staged per tile (1 when the source is pre-mixed or planar rows)
+    int bit_depth, data_type, big_endian, planar, ulaw;
+    int premix_mono;   // stream.pcm mono: mean of the channels at read time (:2368)
+    double norm_pos, norm_neg;  // SRC_I16 / SRC_I8: v / (v < 0 ? norm_neg : norm_pos)
+    double g711_scale;          // 1/0x2000 (aukit.g711) or 1/0x40 (stream.g711): exact power of two
+    // epilogue
+    void *out;
+    double lp_alpha;
+    int mix_mono;      // EPI_STREAM_FLOOR: mean over channels after interpolation (:2905-2908)
+};
+
+// launches the right instantiation; `name` receives a static string naming the kernel
+int launch_resample(aukit_ctx *ctx, int src_kind, int interp, int epi, int out_dtype, const ResampleParams &P, size_t lds_bytes,
+                    uint64_t algorithmic_bytes, const char **name);
+
+// host-side tiling helper: fills the tile tables for a list of segments, uploads segs/tiles to ctx scratch
+// and completes P.{segs,tile_seg,seg_tile0,tiles_per_seg,n_tiles,tile_out,cap,halo_*,ratio,rcp,exact_rcp}.
+int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int interp, int stage_channels, ResampleParams &P, size_t *lds_bytes);
+
+// position of output o (0-based) exactly as the reference computes it on the host
+static inline double host_pos(uint64_t o, double ratio) { return ((double)o) / ratio + 1; }
+
+}  // namespace aukit

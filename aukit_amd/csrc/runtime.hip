@@ -1,0 +1,390 @@
+// runtime.hip — contexts, batches, audio objects, scratch tables, timers (host side of the C ABI).
+#include <algorithm>
+#include "common.h"
+
+namespace aukit {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return AUKIT_OK;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    cap = want;
+    return AUKIT_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes) {
+    int rc = buf.ensure(std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    if (bytes) AUKIT_HIP_CHECK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AUKIT_OK;
+}
+
+bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count) {
+    auto it = ctx->div_ok.find(d);
+    if (it != ctx->div_ok.end()) {
+        if (it->second == 0) return false;          // known counter-example
+        if (it->second >= count) return true;
+    }
+    const double r = 1.0 / d;
+    uint64_t from = (it != ctx->div_ok.end()) ? it->second : 0;
+    for (uint64_t n = from; n < count; n++) {
+        double a = (double)n;
+        double q0 = a * r;
+        double e = std::fma(-d, q0, a);
+        double q = std::fma(e, r, q0);
+        if (q != a / d) { ctx->div_ok[d] = 0; return false; }
+    }
+    ctx->div_ok[d] = count;
+    return true;
+}
+
+int ctx_begin_kernel(aukit_ctx *ctx) {
+    if (ctx->ktiming) AUKIT_HIP_CHECK(hipEventRecord(ctx->kev0, ctx->stream));
+    return AUKIT_OK;
+}
+int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes) {
+    ctx->last_kernel = name ? name : "";
+    ctx->last_bytes = algorithmic_bytes;
+    if (ctx->ktiming) {
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->kev1, ctx->stream));
+        AUKIT_HIP_CHECK(hipEventSynchronize(ctx->kev1));
+        AUKIT_HIP_CHECK(hipEventElapsedTime(&ctx->last_ms, ctx->kev0, ctx->kev1));
+    }
+    return AUKIT_OK;
+}
+
+int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, double rate, int dtype, const uint64_t *lens) {
+    if (!out) return fail(AUKIT_E_ARG, "out is null");
+    if (channels < 1) return fail(AUKIT_E_ARG, "channels out of range");
+    aukit_audio *a = *out;
+    if (!a) a = new aukit_audio();
+    a->n = n; a->channels = channels; a->rate = rate; a->dtype = dtype;
+    a->len.assign(lens, lens + n);
+    a->row_off.resize(n);
+    a->row_stride.resize(n);
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        a->row_stride[s] = round_up(std::max<uint64_t>(lens[s], 1), 16);
+        a->row_off[s] = tot;
+        tot += a->row_stride[s] * (uint64_t)channels;
+    }
+    a->total = tot;
+    size_t need = (size_t)tot * dtype_size(dtype) + 64;
+    if (need > a->cap_bytes || !a->dev) {
+        if (a->dev) (void)hipFree(a->dev);
+        a->dev = nullptr; a->cap_bytes = 0;
+        hipError_t e = hipMalloc(&a->dev, need);
+        if (e != hipSuccess) { if (!*out) delete a; return fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
+        a->cap_bytes = need;
+    }
+    size_t mbytes = (size_t)n * 3 * sizeof(uint64_t);
+    if (mbytes > a->meta_cap || !a->d_meta) {
+        if (a->d_meta) (void)hipFree(a->d_meta);
+        a->d_meta = nullptr; a->meta_cap = 0;
+        hipError_t e = hipMalloc((void **)&a->d_meta, std::max<size_t>(mbytes, 64));
+        if (e != hipSuccess) { if (!*out) delete a; return fail(AUKIT_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+        a->meta_cap = std::max<size_t>(mbytes, 64);
+    }
+    if (n) {
+        std::vector<uint64_t> m(3 * (size_t)n);
+        std::copy(a->len.begin(), a->len.end(), m.begin());
+        std::copy(a->row_off.begin(), a->row_off.end(), m.begin() + n);
+        std::copy(a->row_stride.begin(), a->row_stride.end(), m.begin() + 2 * (size_t)n);
+        AUKIT_HIP_CHECK(hipMemcpyAsync(a->d_meta, m.data(), mbytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    a->version++;
+    *out = a;
+    return AUKIT_OK;
+}
+
+}  // namespace aukit
+
+using namespace aukit;
+
+extern "C" {
+
+int aukit_abi_version(void) { return AUKIT_ABI_VERSION; }
+const char *aukit_last_error(void) { return g_err; }
+
+int aukit_ctx_create(aukit_ctx **out, int device) {
+    if (!out) return fail(AUKIT_E_ARG, "out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(AUKIT_E_HIP, "no HIP device available (%s): libaukit_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    if (device < 0 || device >= count) return fail(AUKIT_E_ARG, "device %d out of range (0..%d)", device, count - 1);
+    AUKIT_HIP_CHECK(hipSetDevice(device));
+    aukit_ctx *c = new aukit_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    AUKIT_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    AUKIT_HIP_CHECK(hipEventCreate(&c->ev0));
+    AUKIT_HIP_CHECK(hipEventCreate(&c->ev1));
+    AUKIT_HIP_CHECK(hipEventCreate(&c->kev0));
+    AUKIT_HIP_CHECK(hipEventCreate(&c->kev1));
+    *out = c;
+    return AUKIT_OK;
+}
+
+void aukit_ctx_destroy(aukit_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->kev0) (void)hipEventDestroy(c->kev0);
+    if (c->kev1) (void)hipEventDestroy(c->kev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int aukit_ctx_set_stream(aukit_ctx *c, void *s) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    AUKIT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return AUKIT_OK;
+}
+void *aukit_ctx_get_stream(aukit_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int aukit_ctx_sync(aukit_ctx *c) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    AUKIT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return AUKIT_OK;
+}
+int aukit_ctx_set_dtype(aukit_ctx *c, int dtype) {
+    if (!c || (dtype != AUKIT_F64 && dtype != AUKIT_F32)) return fail(AUKIT_E_ARG, "dtype must be AUKIT_F64 or AUKIT_F32");
+    c->dtype = dtype;
+    return AUKIT_OK;
+}
+int aukit_ctx_set_sinc_window(aukit_ctx *c, int w) {
+    if (!c || w < 1 || w > 30) return fail(AUKIT_E_ARG, "sinc window out of range");
+    c->sinc_w = w;
+    return AUKIT_OK;
+}
+int aukit_timer_begin(aukit_ctx *c) {
+    AUKIT_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    return AUKIT_OK;
+}
+int aukit_timer_end(aukit_ctx *c, float *ms) {
+    AUKIT_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    AUKIT_HIP_CHECK(hipEventSynchronize(c->ev1));
+    AUKIT_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return AUKIT_OK;
+}
+int aukit_ctx_set_kernel_timing(aukit_ctx *c, int enabled) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    c->ktiming = enabled != 0;
+    return AUKIT_OK;
+}
+int aukit_ctx_last_kernel(aukit_ctx *c, const char **name, float *ms, uint64_t *bytes) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    if (name) *name = c->last_kernel.c_str();
+    if (ms) *ms = c->last_ms;
+    if (bytes) *bytes = c->last_bytes;
+    return AUKIT_OK;
+}
+
+// ---------------------------------------------------------------- batches
+static int batch_set_offsets(aukit_ctx *ctx, aukit_batch *b, const uint64_t *offsets, uint32_t n) {
+    b->n = n;
+    b->off.assign(offsets, offsets + n + 1);
+    for (uint32_t i = 0; i < n; i++)
+        if (b->off[i + 1] < b->off[i]) return fail(AUKIT_E_ARG, "offsets must be non-decreasing");
+    if (b->d_off) (void)hipFree(b->d_off);
+    b->d_off = nullptr;
+    AUKIT_HIP_CHECK(hipMalloc((void **)&b->d_off, ((size_t)n + 1) * sizeof(uint64_t)));
+    AUKIT_HIP_CHECK(hipMemcpyAsync(b->d_off, b->off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    b->version++;
+    return AUKIT_OK;
+}
+
+int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, const uint64_t *offsets, uint32_t n) {
+    if (!ctx || !out || !offsets) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    aukit_batch *b = new aukit_batch();
+    uint64_t total = offsets[n] - offsets[0];
+    b->front_pad = 64;
+    b->cap = (size_t)total + 128;
+    b->own = true;
+    hipError_t e = hipMalloc((void **)&b->base, b->cap);
+    if (e != hipSuccess) { delete b; return fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed: %s", b->cap, hipGetErrorString(e)); }
+    std::vector<uint64_t> rel(n + 1);
+    for (uint32_t i = 0; i <= n; i++) rel[i] = offsets[i] - offsets[0];
+    int rc = batch_set_offsets(ctx, b, rel.data(), n);
+    if (rc) { aukit_batch_free(b); return rc; }
+    if (total) {
+        hipError_t e2 = hipMemcpyAsync(b->data(), bytes + offsets[0], total, hipMemcpyHostToDevice, ctx->stream);
+        if (e2 != hipSuccess) { aukit_batch_free(b); return fail(AUKIT_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e2)); }
+    }
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may free `bytes` right away
+    *out = b;
+    return AUKIT_OK;
+}
+
+int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_bytes, const uint64_t *offsets, uint32_t n) {
+    if (!ctx || !out || !offsets) return fail(AUKIT_E_ARG, "null argument");
+    aukit_batch *b = new aukit_batch();
+    b->base = (uint8_t *)const_cast<void *>(dev_bytes);
+    b->front_pad = 0;
+    b->cap = (size_t)offsets[n];
+    b->own = false;
+    int rc = batch_set_offsets(ctx, b, offsets, n);
+    if (rc) { aukit_batch_free(b); return rc; }
+    *out = b;
+    return AUKIT_OK;
+}
+
+int aukit_batch_info(const aukit_batch *b, uint32_t *n, uint64_t *total) {
+    if (!b) return fail(AUKIT_E_ARG, "batch is null");
+    if (n) *n = b->n;
+    if (total) *total = b->total();
+    return AUKIT_OK;
+}
+int aukit_batch_offsets(const aukit_batch *b, uint64_t *offsets) {
+    if (!b || !offsets) return fail(AUKIT_E_ARG, "null argument");
+    std::copy(b->off.begin(), b->off.end(), offsets);
+    return AUKIT_OK;
+}
+const void *aukit_batch_device_ptr(const aukit_batch *b) { return b ? b->data() : nullptr; }
+int aukit_batch_download(aukit_ctx *ctx, const aukit_batch *b, uint8_t *dst) {
+    if (!ctx || !b || !dst) return fail(AUKIT_E_ARG, "null argument");
+    if (b->total()) AUKIT_HIP_CHECK(hipMemcpyAsync(dst, b->data(), b->total(), hipMemcpyDeviceToHost, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AUKIT_OK;
+}
+void aukit_batch_free(aukit_batch *b) {
+    if (!b) return;
+    if (b->own && b->base) (void)hipFree(b->base);
+    if (b->d_off) (void)hipFree(b->d_off);
+    delete b;
+}
+
+// ---------------------------------------------------------------- audio objects
+int aukit_audio_info(const aukit_audio *a, uint32_t *n, int *channels, double *rate, int *dtype, uint64_t *total) {
+    if (!a) return fail(AUKIT_E_ARG, "audio is null");
+    if (n) *n = a->n;
+    if (channels) *channels = a->channels;
+    if (rate) *rate = a->rate;
+    if (dtype) *dtype = a->dtype;
+    if (total) *total = a->total;
+    return AUKIT_OK;
+}
+int aukit_audio_layout(const aukit_audio *a, uint64_t *lens, uint64_t *row_off, uint64_t *row_stride) {
+    if (!a) return fail(AUKIT_E_ARG, "audio is null");
+    if (lens) std::copy(a->len.begin(), a->len.end(), lens);
+    if (row_off) std::copy(a->row_off.begin(), a->row_off.end(), row_off);
+    if (row_stride) std::copy(a->row_stride.begin(), a->row_stride.end(), row_stride);
+    return AUKIT_OK;
+}
+void *aukit_audio_device_ptr(const aukit_audio *a) { return a ? a->dev : nullptr; }
+
+int aukit_audio_download_raw(aukit_ctx *ctx, const aukit_audio *a, void *dst) {
+    if (!ctx || !a || !dst) return fail(AUKIT_E_ARG, "null argument");
+    if (a->total) AUKIT_HIP_CHECK(hipMemcpyAsync(dst, a->dev, (size_t)a->total * dtype_size(a->dtype), hipMemcpyDeviceToHost, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AUKIT_OK;
+}
+
+int aukit_audio_download(aukit_ctx *ctx, const aukit_audio *a, double *dst) {
+    if (!ctx || !a || !dst) return fail(AUKIT_E_ARG, "null argument");
+    std::vector<unsigned char> raw((size_t)a->total * dtype_size(a->dtype) + 8);
+    int rc = aukit_audio_download_raw(ctx, a, raw.data());
+    if (rc) return rc;
+    size_t w = 0;
+    for (uint32_t s = 0; s < a->n; s++)
+        for (int c = 0; c < a->channels; c++) {
+            size_t base = (size_t)a->row_off[s] + (size_t)c * a->row_stride[s];
+            for (uint64_t i = 0; i < a->len[s]; i++) {
+                double v;
+                if (a->dtype == AUKIT_F64) v = reinterpret_cast<const double *>(raw.data())[base + i];
+                else if (a->dtype == AUKIT_F32) v = (double)reinterpret_cast<const float *>(raw.data())[base + i];
+                else v = (double)reinterpret_cast<const signed char *>(raw.data())[base + i];
+                dst[w++] = v;
+            }
+        }
+    return AUKIT_OK;
+}
+
+int aukit_audio_upload(aukit_ctx *ctx, aukit_audio **out, const double *samples, const uint64_t *lens, uint32_t n, int channels,
+                       double rate, int dtype) {
+    if (!ctx || !out || !lens) return fail(AUKIT_E_ARG, "null argument");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32 && dtype != AUKIT_I8) return fail(AUKIT_E_ARG, "bad dtype");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    aukit_audio *a = *out;
+    int rc = audio_prepare(ctx, &a, n, channels, rate, dtype, lens);
+    if (rc) return rc;
+    std::vector<unsigned char> raw((size_t)a->total * dtype_size(dtype) + 8, 0);
+    size_t r = 0;
+    for (uint32_t s = 0; s < n; s++)
+        for (int c = 0; c < channels; c++) {
+            size_t base = (size_t)a->row_off[s] + (size_t)c * a->row_stride[s];
+            for (uint64_t i = 0; i < lens[s]; i++) {
+                double v = samples[r++];
+                if (dtype == AUKIT_F64) reinterpret_cast<double *>(raw.data())[base + i] = v;
+                else if (dtype == AUKIT_F32) reinterpret_cast<float *>(raw.data())[base + i] = (float)v;
+                else reinterpret_cast<signed char *>(raw.data())[base + i] = (signed char)(int)v;
+            }
+        }
+    if (a->total) AUKIT_HIP_CHECK(hipMemcpyAsync(a->dev, raw.data(), (size_t)a->total * dtype_size(dtype), hipMemcpyHostToDevice, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = a;
+    return AUKIT_OK;
+}
+
+int aukit_audio_clone(aukit_ctx *ctx, const aukit_audio *a, aukit_audio **out) {
+    if (!ctx || !a || !out) return fail(AUKIT_E_ARG, "null argument");
+    aukit_audio *b = *out;
+    int rc = audio_prepare(ctx, &b, a->n, a->channels, a->rate, a->dtype, a->len.data());
+    if (rc) return rc;
+    if (a->total) AUKIT_HIP_CHECK(hipMemcpyAsync(b->dev, a->dev, (size_t)a->total * dtype_size(a->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+    *out = b;
+    return AUKIT_OK;
+}
+
+void aukit_audio_free(aukit_audio *a) {
+    if (!a) return;
+    if (a->dev) (void)hipFree(a->dev);
+    if (a->d_meta) (void)hipFree(a->d_meta);
+    delete a;
+}
+
+int aukit_chunks_info(const aukit_chunks *c, uint32_t *n, uint32_t *max_chunks) {
+    if (!c) return fail(AUKIT_E_ARG, "chunks is null");
+    if (n) *n = c->n;
+    if (max_chunks) *max_chunks = c->max_chunks;
+    return AUKIT_OK;
+}
+int aukit_chunks_get(const aukit_chunks *c, uint32_t *nchunks, uint32_t *lens, double *pos, int32_t *status, double *length_seconds) {
+    if (!c) return fail(AUKIT_E_ARG, "chunks is null");
+    if (nchunks) std::copy(c->nchunks.begin(), c->nchunks.end(), nchunks);
+    if (lens) std::copy(c->lens.begin(), c->lens.end(), lens);
+    if (pos) std::copy(c->pos.begin(), c->pos.end(), pos);
+    if (status) std::copy(c->status.begin(), c->status.end(), status);
+    if (length_seconds) std::copy(c->length_seconds.begin(), c->length_seconds.end(), length_seconds);
+    return AUKIT_OK;
+}
+void aukit_chunks_free(aukit_chunks *c) { delete c; }
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+/* aukit_hip.h — C ABI of libaukit_hip.so, the MI355X (gfx950) implementation of AUKit's batched
+ * decode → resample-to-48 kHz → effects/mixdown → DFPWM re-encode hot path.
+ *
+ * The reference (MCJack123/AUKit 1.10.0, /root/reference/aukit.lua) is a pure-Lua module with no
+ * FFI/plugin interface: its boundary is the table returned by `require "aukit"` (aukit.lua:97-113,
+ * :3620).  This header is the native face a Lua host binds instead (LuaJIT `ffi.cdef` of this file —
+ * see INTEGRATION.md and aukit_amd/lua/aukit.lua); each entry point cites the reference function(s)
+ * whose per-sample loops it replaces.  Plain C: opaque handles, pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 (AUKIT_OK) or a negative aukit_status; aukit_last_error() returns a
+ *     thread-local message.  AUKIT_E_LUA means "the reference raises a Lua error here"; the message
+ *     is the reference's own string where it has one, so a Lua shim can `error(msg, 2)`.
+ *   - a *batch* is N independent byte strings (the `data` argument of the reference functions, N times);
+ *     an *audio* is N independent aukit.Audio objects with a common channel count and sample rate.
+ *     Streams never interact (no reference function reads another stream), so a batch shards across
+ *     GPUs by stream index with no collective.
+ *   - one aukit_ctx = one GPU + one HIP stream; use one ctx per thread (the reference is single-threaded).
+ *     All work is enqueued on the ctx stream; download/sync calls wait for it.
+ *   - sample storage (`aukit_dtype`): AUKIT_F64 mirrors the reference's Lua doubles exactly;
+ *     AUKIT_F32 stores fp64 arithmetic results as float (1e-6 RMS tolerance);
+ *     AUKIT_I8 is used for the integer-valued stream outputs of stream.{g711,adpcm,msadpcm,mdfpwm}.
+ *   - layout of an audio on the device: row (stream s, channel c) starts at element
+ *     row_off[s] + c * row_stride[s], rows are padded to a multiple of 16 elements.
+ */
+#ifndef AUKIT_HIP_H
+#define AUKIT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUKIT_ABI_VERSION 1
+#define AUKIT_MAX_CHANNELS 8
+
+typedef struct aukit_ctx aukit_ctx;
+typedef struct aukit_batch aukit_batch;
+typedef struct aukit_audio aukit_audio;
+
+typedef enum { AUKIT_OK = 0, AUKIT_E_ARG = -1, AUKIT_E_LUA = -2, AUKIT_E_NOMEM = -3, AUKIT_E_UNSUPPORTED = -4, AUKIT_E_HIP = -5 } aukit_status;
+typedef enum { AUKIT_F64 = 0, AUKIT_F32 = 1, AUKIT_I8 = 2 } aukit_dtype;
+/* aukit.defaultInterpolation / the `interpolation` argument (aukit.lua:96-99, :253-284) */
+typedef enum { AUKIT_INTERP_NONE = 0, AUKIT_INTERP_LINEAR = 1, AUKIT_INTERP_CUBIC = 2, AUKIT_INTERP_SINC = 3 } aukit_interp;
+typedef enum { AUKIT_SIGNED = 0, AUKIT_UNSIGNED = 1, AUKIT_FLOAT = 2 } aukit_pcm_type;
+
+typedef enum {
+    AUKIT_CODEC_PCM = 0,     /* aukit.pcm / stream.pcm        aukit.lua:1049, :2228 */
+    AUKIT_CODEC_G711 = 1,    /* aukit.g711 / stream.g711      aukit.lua:1361, :2850 */
+    AUKIT_CODEC_ADPCM = 2,   /* aukit.adpcm (raw nibbles)     aukit.lua:1183        */
+    AUKIT_CODEC_ADPCM_WAV = 3, /* IMA blocks: aukit.wav splitter :1509-1548 / stream.adpcm :2753 */
+    AUKIT_CODEC_MSADPCM = 4, /* aukit.msadpcm / stream.msadpcm aukit.lua:1283, :2588 */
+    AUKIT_CODEC_DFPWM = 5,   /* aukit.dfpwm / stream.dfpwm    aukit.lua:1392, :2439 */
+    AUKIT_CODEC_MDFPWM = 6,  /* aukit.mdfpwm / stream.mdfpwm  aukit.lua:1420, :2507 */
+    AUKIT_CODEC_QOA = 7,     /* aukit.qoa / stream.qoa        aukit.lua:1706, :3202 */
+    AUKIT_CODEC_FLAC = 8     /* aukit.flac / stream.flac      aukit.lua:311-619, :1657, :3124 */
+} aukit_codec;
+
+/* Arguments of the reference loader / stream factory for one codec (unused fields are ignored). */
+typedef struct {
+    int32_t codec;         /* aukit_codec */
+    int32_t channels;      /* `channels` (PCM, G711, ADPCM*, MSADPCM, DFPWM)                */
+    double sample_rate;    /* `sampleRate`                                                   */
+    int32_t bit_depth;     /* PCM: 8/16/24/32                                                */
+    int32_t data_type;     /* PCM: aukit_pcm_type                                            */
+    int32_t big_endian;    /* PCM: `bigEndian`                                               */
+    int32_t interleaved;   /* PCM/ADPCM: `interleaved` (default true in the reference)       */
+    int32_t ulaw;          /* G711: `ulaw`                                                   */
+    int32_t top_first;     /* ADPCM: `topFirst`                                              */
+    int32_t block_align;   /* ADPCM_WAV / MSADPCM: `blockAlign`                              */
+    int32_t ncoef;         /* MSADPCM: number of coefficient pairs (0 → the 7 defaults :1304) */
+    int16_t coef1[32];     /* MSADPCM `coefficients[1]`                                      */
+    int16_t coef2[32];     /* MSADPCM `coefficients[2]`                                      */
+    int32_t predictor[AUKIT_MAX_CHANNELS];  /* ADPCM: initial predictor(s)                   */
+    int32_t step_index[AUKIT_MAX_CHANNELS]; /* ADPCM: initial step index(es)                 */
+} aukit_codec_desc;
+
+/* ids for aukit_effect(); args in the reference's argument order after `audio` (aukit.lua:3356-3618) */
+typedef enum {
+    AUKIT_FX_AMPLIFY = 0,   /* (multiplier)                                      :3356 */
+    AUKIT_FX_SPEED = 1,     /* (multiplier, default_interp)                      :3376 */
+    AUKIT_FX_FADE = 2,      /* (startTime, startAmplitude, endTime, endAmplitude) :3394 */
+    AUKIT_FX_INVERT = 3,    /* ()                                                :3417 */
+    AUKIT_FX_NORMALIZE = 4, /* (peakAmplitude=1, independent=0)                  :3431 */
+    AUKIT_FX_CENTER = 5,    /* ()                                                :3464 */
+    AUKIT_FX_TRIM = 6,      /* (threshold) — always AUKIT_E_LUA like the reference (:3495) */
+    AUKIT_FX_DELAY = 7,     /* (delay, multiplier=0.5)                           :3505 */
+    AUKIT_FX_ECHO = 8,      /* (delay=1, multiplier=0.5)                         :3524 */
+    AUKIT_FX_REVERB = 9,    /* (delay=100, decay=0.3, wet=1, dry=0)              :3546 */
+    AUKIT_FX_LOWPASS = 10,  /* (frequency)                                       :3586 */
+    AUKIT_FX_HIGHPASS = 11  /* (frequency)                                       :3604 */
+} aukit_effect_id;
+
+/* ---- library / context ---- */
+int aukit_abi_version(void);
+const char *aukit_last_error(void);
+int aukit_ctx_create(aukit_ctx **out, int device);
+void aukit_ctx_destroy(aukit_ctx *ctx);
+/* enqueue on an existing hipStream_t (e.g. torch's current stream) instead of the ctx's own */
+int aukit_ctx_set_stream(aukit_ctx *ctx, void *hip_stream);
+void *aukit_ctx_get_stream(aukit_ctx *ctx);
+int aukit_ctx_sync(aukit_ctx *ctx);
+/* default storage type of float results (AUKIT_F64 on creation) */
+int aukit_ctx_set_dtype(aukit_ctx *ctx, int dtype);
+/* sincWindowSize (aukit.lua:129): 10, or 30 to mirror LuaJIT hosts */
+int aukit_ctx_set_sinc_window(aukit_ctx *ctx, int w);
+/* hipEvent pair on the ctx stream: begin(); ...launches...; end() → elapsed milliseconds */
+int aukit_timer_begin(aukit_ctx *ctx);
+int aukit_timer_end(aukit_ctx *ctx, float *ms);
+/* name and duration (ms, hipEvents around the launch) of the most recent kernel launched through
+ * aukit_decode_resample / aukit_stream_decode when profiling is enabled */
+int aukit_ctx_set_kernel_timing(aukit_ctx *ctx, int enabled);
+int aukit_ctx_last_kernel(aukit_ctx *ctx, const char **name, float *ms, uint64_t *algorithmic_bytes);
+
+/* ---- batches of byte strings ---- */
+int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, const uint64_t *offsets /* n+1 */, uint32_t n);
+/* zero-copy: bytes already on this device (e.g. received by RCCL); the caller keeps ownership */
+int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_bytes, const uint64_t *offsets /* host, n+1 */, uint32_t n);
+int aukit_batch_info(const aukit_batch *b, uint32_t *n, uint64_t *total_bytes);
+int aukit_batch_offsets(const aukit_batch *b, uint64_t *offsets /* n+1 */);
+const void *aukit_batch_device_ptr(const aukit_batch *b);
+int aukit_batch_download(aukit_ctx *ctx, const aukit_batch *b, uint8_t *dst);
+void aukit_batch_free(aukit_batch *b);
+
+/* ---- audio objects ---- */
+int aukit_audio_upload(aukit_ctx *ctx, aukit_audio **out, const double *samples /* packed [s][c][len_s] */,
+                       const uint64_t *lens /* n */, uint32_t n, int channels, double sample_rate, int dtype);
+int aukit_audio_info(const aukit_audio *a, uint32_t *n, int *channels, double *sample_rate, int *dtype, uint64_t *total_elems);
+int aukit_audio_layout(const aukit_audio *a, uint64_t *lens /* n */, uint64_t *row_off /* n */, uint64_t *row_stride /* n */);
+void *aukit_audio_device_ptr(const aukit_audio *a);
+/* packed [s][c][len_s] as doubles (exact for every dtype) */
+int aukit_audio_download(aukit_ctx *ctx, const aukit_audio *a, double *dst);
+/* raw padded device buffer in its own dtype (total_elems elements) */
+int aukit_audio_download_raw(aukit_ctx *ctx, const aukit_audio *a, void *dst);
+int aukit_audio_clone(aukit_ctx *ctx, const aukit_audio *a, aukit_audio **out);
+void aukit_audio_free(aukit_audio *a);
+
+/* ---- loaders: aukit.<codec>(data, ...) → Audio   (aukit.lua:1049-1777) ----
+ * `*out` may point to an audio returned by an earlier identical call: its buffers are reused. */
+int aukit_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int dtype, aukit_audio **out);
+/* fused aukit.<codec>(data, ...):resample(new_rate, interp): decoded samples never touch HBM for
+ * PCM and G.711; block codecs decode to a compact integer intermediate first.  Same results as
+ * aukit_decode followed by aukit_resample. */
+int aukit_decode_resample(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, double new_rate, int interp,
+                          int dtype, aukit_audio **out);
+
+/* ---- Audio methods ---- */
+int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int interp, aukit_audio **out); /* Audio:resample :653 */
+int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out);                                  /* Audio:mono :677 */
+/* Audio:mix(amplifier, ...) :804 — audios[0] is `self`; all at the same sample rate (resample first) */
+int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, double amplifier, aukit_audio **out);
+/* aukit.effects.<name>(audio, ...) in place :3356-3618 */
+int aukit_effect(aukit_ctx *ctx, aukit_audio *inout, int effect_id, const double *args, int nargs);
+/* Audio:dfpwm(interleaved) :1005 → one byte string per stream */
+int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, aukit_batch **out);
+/* Audio:pcm(bitDepth, dataType, interleaved) :901 → unfloored numbers, packed per stream */
+int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out);
+
+/* ---- aukit.stream.<codec>(data, ...) with string input, every call of the iterator at once ----
+ * out audio: per stream the concatenation of all chunks (`channels` = number of chunk tables);
+ * chunk metadata is read back with aukit_stream_chunks(). */
+typedef struct aukit_chunks aukit_chunks;
+int aukit_stream_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int interp, int mono,
+                        int dtype, aukit_audio **out, aukit_chunks **chunks);
+/* per stream s: nchunks[s]; chunk k of stream s: length and the iterator's second return value.
+ * status[s]: 0 = iterator ended with nil, AUKIT_E_LUA = the reference iterator raises after the last chunk. */
+int aukit_chunks_info(const aukit_chunks *c, uint32_t *n, uint32_t *max_chunks);
+int aukit_chunks_get(const aukit_chunks *c, uint32_t *nchunks /* n */, uint32_t *lens /* n*max */, double *pos /* n*max */,
+                     int32_t *status /* n */, double *length_seconds /* n */);
+void aukit_chunks_free(aukit_chunks *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

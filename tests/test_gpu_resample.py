@@ -1,0 +1,232 @@
+"""GPU parity: fused decode → resample kernels vs the CPU oracle (same seeded inputs, through the C ABI).
+
+Bars: integer-valued stream outputs bit-exact; float stages ≤ 1e-6 RMS on the [-1,1]
+scale (un-floored stream outputs are divided by 128 first).  With AUKIT_F64 storage the kernels use the
+reference's fp64 operation order, so the tests additionally demand ≤ 1 ulp-level agreement there.
+"""
+import numpy as np
+import pytest
+
+from tests.util import pcm16, rms, signal
+
+pytestmark = pytest.mark.gpu
+
+RATES = [8000, 11025, 22050, 44100, 48000]
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+@pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
+@pytest.mark.parametrize("rate", [8000, 22050, 44100])
+def test_pcm16_mono_resample_f64(ctx, oracle, rate, interp):
+    B, N = _B(), _N()
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate([rate, rate // 3 + 7, 5, 2000])]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed")
+    out = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    for s, got in zip(streams, out):
+        ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, rate), 48000, oracle.INTERP[interp])
+        assert len(got[0]) == len(ref.data[0])
+        assert np.max(np.abs(got[0] - ref.data[0]), initial=0) <= 4e-16  # fp64 op order is reproduced; pow(fx,3) may differ by 1 ulp
+
+
+def test_pcm16_mono_resample_f32_tolerance(ctx, oracle):
+    B, N = _B(), _N()
+    s = pcm16(44100, 44100, 1, 0).tobytes()
+    bt = B.Batch.upload(ctx, [s])
+    out = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), 48000, "cubic", dtype=N.F32).download()
+    ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
+    assert rms(out[0][0], ref.data[0]) <= 1e-6
+
+
+def test_decode_is_exact(ctx, oracle):
+    B, N = _B(), _N()
+    s = pcm16(10000, 44100, 1, 3).tobytes()
+    bt = B.Batch.upload(ctx, [s, s[:200]])
+    out = B.decode(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), dtype=N.F64).download()
+    ref = oracle.pcm(s, 16, oracle.SIGNED, 1, 44100)
+    assert np.array_equal(out[0][0], ref.data[0])
+    assert np.array_equal(out[1][0], ref.data[0][:100])
+
+
+@pytest.mark.parametrize("bits,dtype,be,ch,interleaved", [
+    (8, "signed", False, 1, True), (8, "unsigned", False, 2, True), (16, "unsigned", True, 1, True), (16, "signed", True, 2, True),
+    (24, "signed", False, 2, True), (24, "unsigned", True, 1, True), (32, "signed", False, 1, True), (32, "float", False, 2, True),
+    (32, "float", True, 1, True), (16, "signed", False, 2, False), (16, "signed", False, 3, True),
+])
+def test_pcm_formats(ctx, oracle, bits, dtype, be, ch, interleaved):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(77 + bits + ch))
+    frames = 3001
+    if dtype == "float":
+        raw = rng.uniform(-1, 1, frames * ch).astype(">f4" if be else "<f4").tobytes()
+    else:
+        raw = rng.integers(0, 256, frames * ch * (bits // 8), dtype=np.uint8).tobytes()
+    bt = B.Batch.upload(ctx, [raw])
+    desc = B.make_desc(N.CODEC_PCM, ch, 22050, bits, dtype, big_endian=be, interleaved=interleaved)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()[0]
+    ref = oracle.pcm(raw, bits, oracle.DTYPE[dtype], ch, 22050, interleaved, be)
+    for c in range(ch):
+        assert np.array_equal(got[c], ref.data[c]), f"channel {c}"
+    got = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F64).download()[0]
+    ref = oracle.resample(ref, 48000, oracle.CUBIC)
+    for c in range(ch):
+        assert np.max(np.abs(got[c] - ref.data[c])) <= 4e-16
+
+
+def test_pcm_uneven_data_is_an_error(ctx):
+    B, N = _B(), _N()
+    bt = B.Batch.upload(ctx, [b"\0" * 7])
+    with pytest.raises(N.AukitError) as e:
+        B.decode(ctx, bt, B.make_desc(N.CODEC_PCM, 2, 44100, 16, "signed"))
+    assert "uneven amount of data per channel" in str(e.value)
+
+
+@pytest.mark.parametrize("ulaw", [True, False])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_g711_audio_path(ctx, oracle, ulaw, ch):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(5))
+    streams = [rng.integers(0, 256, n * ch, dtype=np.uint8).tobytes() for n in (8000, 8000 * 2 + 1234, 17)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_G711, ch, 8000, ulaw=ulaw)
+    dec = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    res = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F64).download()
+    for s, d, r in zip(streams, dec, res):
+        ref = oracle.g711(s, ulaw, ch, 8000)
+        refr = oracle.resample(ref, 48000, oracle.CUBIC)
+        for c in range(ch):
+            assert np.array_equal(d[c], ref.data[c])
+            assert np.max(np.abs(r[c] - refr.data[c])) <= 4e-16
+
+
+def test_g711_all_bytes_match_itu_tables(ctx):
+    """Independent KAT: every µ-law / A-law code point against the ITU-T G.711 expansion."""
+    B, N = _B(), _N()
+    codes = bytes(range(256))
+    bt = B.Batch.upload(ctx, [codes])
+    for ulaw in (True, False):
+        got = B.decode(ctx, bt, B.make_desc(N.CODEC_G711, 1, 8000, ulaw=ulaw), dtype=N.F64).download()[0][0]
+        exp = np.array([_itu_ulaw(b) / 32768.0 if ulaw else _itu_alaw(b) / 32768.0 for b in range(256)])
+        assert np.array_equal(got, exp)
+
+
+def _itu_ulaw(u):
+    u = ~u & 0xFF
+    t = (((u & 0x0F) << 3) + 0x84) << ((u & 0x70) >> 4)
+    return (0x84 - t) if (u & 0x80) else (t - 0x84)
+
+
+def _itu_alaw(a):
+    a ^= 0x55
+    t = (a & 0x0F) << 4
+    seg = (a & 0x70) >> 4
+    if seg == 0:
+        t += 8
+    elif seg == 1:
+        t += 0x108
+    else:
+        t = (t + 0x108) << (seg - 1)
+    return t if (a & 0x80) else -t
+
+
+def test_audio_resample_matches_fused(ctx, oracle):
+    B, N = _B(), _N()
+    a = [[signal(5000, 22050, 2, 0), signal(5000, 22050, 2, 1)], [signal(1234, 22050, 2, 2), signal(1234, 22050, 2, 3)]]
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    for interp in ("none", "linear", "cubic"):
+        got = B.resample(ctx, ab, 48000, interp).download()
+        for s in range(2):
+            ref = oracle.resample(oracle.Audio(a[s], 22050), 48000, oracle.INTERP[interp])
+            for c in range(2):
+                assert np.max(np.abs(got[s][c] - ref.data[c])) <= 4e-16
+    # downsampling too (ratio < 1)
+    got = B.resample(ctx, ab, 8000, "cubic").download()
+    ref = oracle.resample(oracle.Audio(a[0], 22050), 8000, oracle.CUBIC)
+    assert np.max(np.abs(got[0][0] - ref.data[0])) <= 4e-16
+
+
+@pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
+@pytest.mark.parametrize("rate", RATES)
+def test_stream_pcm_mono16(ctx, oracle, rate, interp):
+    B, N = _B(), _N()
+    nsamp = [int(rate * 2.5), rate, rate + 3, 10, int(rate * 1.0001) + 2]
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate(nsamp)]
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed"), interp, dtype=N.F64)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, rate, False, False, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks, (i, ck.nchunks[i], ref.nchunks)
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        assert np.allclose(ck.pos[i][:ref.nchunks], ref.chunk_pos, rtol=0, atol=0)
+        assert ck.status[i] == ref.final_status
+        assert abs(ck.length_seconds[i] - ref.length_seconds) == 0
+        assert np.max(np.abs(got[i][0] - ref.data[0]), initial=0) <= 1e-13  # values up to 128: 1 ulp = 2.8e-14
+
+
+def test_stream_pcm_stereo_and_mono_mix(ctx, oracle):
+    B, N = _B(), _N()
+    st = np.stack([pcm16(30000, 22050, 1, 0), pcm16(30000, 22050, 1, 1)], 1).tobytes()
+    bt = B.Batch.upload(ctx, [st])
+    desc = B.make_desc(N.CODEC_PCM, 2, 22050, 16, "signed")
+    for mono in (False, True):
+        out, ck = B.stream_decode(ctx, bt, desc, "cubic", mono=mono, dtype=N.F64)
+        got = out.download()[0]
+        ref = oracle.stream_pcm(st, 16, oracle.SIGNED, 2, 22050, False, mono, oracle.CUBIC)
+        assert len(got) == ref.channels
+        assert ck.nchunks[0] == ref.nchunks
+        for c in range(ref.channels):
+            assert np.max(np.abs(got[c] - ref.data[c])) <= 1e-13
+
+
+def test_stream_pcm_f32_tolerance_and_float_input(ctx, oracle):
+    B, N = _B(), _N()
+    s = pcm16(44100 * 2, 44100, 1, 9).tobytes()
+    bt = B.Batch.upload(ctx, [s])
+    out, _ = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), "cubic", dtype=N.F32)
+    ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, 44100, False, False, oracle.CUBIC)
+    assert rms(out.download()[0][0] / 128, ref.data[0] / 128) <= 1e-6
+    f = signal(30000, 32000, 1, 4).astype("<f4").tobytes()  # float input ends with nil reads, not an error
+    bt = B.Batch.upload(ctx, [f])
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 32000, 32, "float"), "cubic", dtype=N.F64)
+    ref = oracle.stream_pcm(f, 32, oracle.FLOAT, 1, 32000, False, False, oracle.CUBIC)
+    assert ck.nchunks[0] == ref.nchunks and list(ck.lens[0][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+    assert np.max(np.abs(out.download()[0][0] - ref.data[0])) <= 1e-13
+
+
+@pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
+@pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
+def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(11))
+    streams = [oracle.gen_g711(pcm16(n * ch, 8000, 2, i), True) for i, n in enumerate([8000 * 3, 8000 * 2 + 4000, 100])]
+    streams.append(rng.integers(0, 256, 8000 * ch, dtype=np.uint8).tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_G711, ch, 8000, ulaw=True), interp, mono=mono, dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_g711(s, True, ch, 8000, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        for c in range(ref.channels):
+            assert np.array_equal(got[i][c], ref.data[c]), (i, c)
+
+
+def test_empty_and_ragged_batches(ctx, oracle):
+    B, N = _B(), _N()
+    streams = [b"", pcm16(3, 44100, 1, 0).tobytes(), b"", pcm16(50000, 44100, 1, 1).tobytes()]
+    bt = B.Batch.upload(ctx, streams)
+    out = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), 48000, "cubic", dtype=N.F64).download()
+    for s, got in zip(streams, out):
+        ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
+        assert len(got[0]) == len(ref.data[0])
+        assert np.max(np.abs(got[0] - ref.data[0]), initial=0) <= 4e-16
