@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "api_resample.hip", "codecs.hip", "effects.hip", "flac.hip", "stubs.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "api_resample.hip", "codecs.hip", "effects.hip", "flac.hip", "stubs.hip"]
 HEADERS = ["common.h", "resample.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -23,11 +23,12 @@ CODEC_PCM, CODEC_G711, CODEC_ADPCM, CODEC_ADPCM_WAV, CODEC_MSADPCM, CODEC_DFPWM,
 FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center": 5, "trim": 6, "delay": 7, "echo": 8, "reverb": 9,
       "lowpass": 10, "highpass": 11}
 MAX_CH = 8
+OPT_EXACT_MATH, OPT_STORE_X4 = 0, 1
 
 # every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aukit_abi_version", "aukit_last_error", "aukit_ctx_create", "aukit_ctx_destroy", "aukit_ctx_set_stream", "aukit_ctx_get_stream",
-    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end",
+    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_option", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end",
     "aukit_ctx_set_kernel_timing", "aukit_ctx_last_kernel",
     "aukit_batch_upload", "aukit_batch_wrap_device", "aukit_batch_info", "aukit_batch_offsets", "aukit_batch_device_ptr",
     "aukit_batch_download", "aukit_batch_free",

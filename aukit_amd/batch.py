@@ -83,6 +83,9 @@ class Context:
         N.check(N.lib().aukit_ctx_last_kernel(self._h, C.byref(name), C.byref(ms), C.byref(nb)))
         return (name.value or b"").decode(), ms.value, nb.value
 
+    def set_option(self, option, value):
+        N.check(N.lib().aukit_ctx_set_option(self._h, int(option), int(value)))
+
     def set_sinc_window(self, w):
         N.check(N.lib().aukit_ctx_set_sinc_window(self._h, int(w)))
 

@@ -124,6 +124,10 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         P.g711_scale = 1.0 / 8192.0;  // m / 0x2000  :1379
     }
     P.out = a->dev;
+    if (do_resample && dtype == AUKIT_F32 && C == 1) {  // HBM-bound tolerance path (fast.hip)
+        int frc = AUKIT_OK;
+        if (fast_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
+    }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, do_resample ? interp : AUKIT_INTERP_NONE, C, P, &lds))) return rc;
     return launch_resample(ctx, src, do_resample ? interp : AUKIT_INTERP_NONE, EPI_AUDIO, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
@@ -390,6 +394,10 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
     P.channels = 1;
     P.out = a->dev;
+    if (in->dtype == AUKIT_F32) {
+        int frc = AUKIT_OK;
+        if (fast_try(ctx, SRC_AUDIO_F32, interp, in->rate, new_rate, segs, P, (in_elems + out_elems) * 4, &frc)) return frc;
+    }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) return rc;
     return launch_resample(ctx, in->dtype == AUKIT_F64 ? SRC_AUDIO_F64 : SRC_AUDIO_F32, interp, EPI_AUDIO, in->dtype, P, lds,

@@ -43,6 +43,8 @@ struct aukit_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // user timer
     hipEvent_t kev0 = nullptr, kev1 = nullptr;  // per-kernel timing
     bool ktiming = false;
+    bool exact_math = false;    // AUKIT_OPT_EXACT_MATH: F32 storage also uses the fp64 reference-order kernels
+    bool fast_store_x4 = true;  // AUKIT_OPT_STORE_X4: LDS-transposed 16-byte stores in the fast kernels
     std::string last_kernel;
     float last_ms = 0.f;
     uint64_t last_bytes = 0;

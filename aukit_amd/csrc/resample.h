@@ -70,6 +70,13 @@ int launch_resample(aukit_ctx *ctx, int src_kind, int interp, int epi, int out_d
 // and completes P.{segs,tile_seg,seg_tile0,tiles_per_seg,n_tiles,tile_out,cap,halo_*,ratio,rcp,exact_rcp}.
 int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int interp, int stage_channels, ResampleParams &P, size_t *lds_bytes);
 
+int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out, ResampleParams &P);
+
+// fast.hip: f32 tolerance path (exact rational positions, f32 FMA taps, 16-byte stores)
+struct FastParams;
+bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
+              uint64_t algorithmic_bytes, int *rc);
+
 // position of output o (0-based) exactly as the reference computes it on the host
 static inline double host_pos(uint64_t o, double ratio) { return ((double)o) / ratio + 1; }
 

@@ -383,7 +383,15 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
     P.tile_out = tile_out;
     P.cap = (cap_for(tile_out) + 1) & ~1;
     *lds_bytes = (size_t)P.cap * 8 * stage_channels;
+    uint64_t max_out = 0;
+    for (const Seg &g : segs) max_out = std::max<uint64_t>(max_out, g.n_out);
+    P.exact_rcp = exact_div_verified(ctx, ratio, max_out + 1) ? 1 : 0;
+    return plan_tiles_sized(ctx, segs, tile_out, P);
+}
 
+// tile tables for a given tile size: uploads segs (+ tile → segment tables for ragged batches)
+int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out, ResampleParams &P) {
+    P.tile_out = tile_out;
     uint64_t max_out = 0;
     std::vector<unsigned> tile0(segs.size() + 1, 0);
     bool uniform = true;
@@ -398,7 +406,6 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
     }
     if (nt > 0xFFFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "too many tiles");
     P.n_tiles = (unsigned)nt;
-    P.exact_rcp = exact_div_verified(ctx, ratio, max_out + 1) ? 1 : 0;
     int rc = upload_table(ctx, ctx->seg_buf, segs.data(), segs.size() * sizeof(Seg));
     if (rc) return rc;
     P.segs = reinterpret_cast<const Seg *>(ctx->seg_buf.p);

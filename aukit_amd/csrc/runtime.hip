@@ -183,6 +183,13 @@ int aukit_ctx_set_sinc_window(aukit_ctx *c, int w) {
     c->sinc_w = w;
     return AUKIT_OK;
 }
+int aukit_ctx_set_option(aukit_ctx *c, int option, int value) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    if (option == AUKIT_OPT_EXACT_MATH) c->exact_math = value != 0;
+    else if (option == AUKIT_OPT_STORE_X4) c->fast_store_x4 = value != 0;
+    else return fail(AUKIT_E_ARG, "unknown option %d", option);
+    return AUKIT_OK;
+}
 int aukit_timer_begin(aukit_ctx *c) {
     AUKIT_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     return AUKIT_OK;

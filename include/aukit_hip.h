@@ -105,6 +105,13 @@ int aukit_ctx_sync(aukit_ctx *ctx);
 int aukit_ctx_set_dtype(aukit_ctx *ctx, int dtype);
 /* sincWindowSize (aukit.lua:129): 10, or 30 to mirror LuaJIT hosts */
 int aukit_ctx_set_sinc_window(aukit_ctx *ctx, int w);
+/* tuning / fidelity switches */
+typedef enum {
+    AUKIT_OPT_EXACT_MATH = 0, /* 1: AUKIT_F32 results are computed by the fp64 reference-order kernels too (default 0:
+                                 f32 FMA arithmetic with exact rational positions, ≤ 1e-6 RMS from the reference) */
+    AUKIT_OPT_STORE_X4 = 1    /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
+} aukit_option;
+int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 /* hipEvent pair on the ctx stream: begin(); ...launches...; end() → elapsed milliseconds */
 int aukit_timer_begin(aukit_ctx *ctx);
 int aukit_timer_end(aukit_ctx *ctx, float *ms);
