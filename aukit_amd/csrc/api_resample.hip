@@ -394,6 +394,8 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
     P.channels = 1;
     P.out = a->dev;
+    P.safe_lo = reinterpret_cast<const unsigned char *>(in->dev);
+    P.safe_hi = P.safe_lo + (in->cap_bytes & ~(size_t)15);
     if (in->dtype == AUKIT_F32) {
         int frc = AUKIT_OK;
         if (fast_try(ctx, SRC_AUDIO_F32, interp, in->rate, new_rate, segs, P, (in_elems + out_elems) * 4, &frc)) return frc;

@@ -16,15 +16,6 @@
 
 namespace aukit {
 
-struct FastParams {
-    unsigned a, b;       // x - 1 = o * a / b
-    unsigned magic;      // ceil(2^32 / b): q = mulhi(n, magic) exact for n * b < 2^32
-    float inv_b;
-    int tile_out;        // multiple of 1024
-    int cap;             // LDS floats for the staged window
-    float scale_pos, scale_neg;  // s16: 1/32767, 1/32768
-};
-
 AUKIT_DEV float g711_f32(unsigned byte, int ulaw, float scale) {
     unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
     int m = b & 15, e = (b >> 4) & 7;
@@ -221,6 +212,7 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
     a /= x; b /= x;
     if (b < 2) return false;  // ratio 1/b with b == 1: every x is an integer, nothing to interpolate — exact path
     F.tile_out = 4096;
+    if (const char *e = getenv("AUKIT_FAST_TILE")) { int v = atoi(e); if (v >= 1024 && v % 1024 == 0) F.tile_out = v; }  // tuning knob
     while (F.tile_out > 1024 && ((double)F.tile_out * (double)a / (double)b + 64) * 4 > 40 * 1024) F.tile_out -= 1024;
     if (((double)F.tile_out * (double)a / (double)b + 64) * 4 > 60 * 1024) return false;
     if (((double)b + (double)F.tile_out * (double)a) * (double)b >= 4294967296.0) return false;  // magic division exactness
@@ -251,6 +243,7 @@ int launch_fast(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg>
     const bool x4 = ctx->fast_store_x4;
     size_t lds = (size_t)F.cap * 4 + (x4 ? 4 * 256 * 4 : 0);
     unsigned per_cu = (unsigned)std::min<size_t>(8, (160 * 1024) / lds);
+    if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }  // tuning knob
     unsigned grid = std::min<unsigned>(P.n_tiles, (unsigned)ctx->num_cus * std::max(per_cu, 1u));
     if ((rc = ctx_begin_kernel(ctx))) return rc;
 #define AUKIT_FAST_CASE(S)                                                                                   \
@@ -277,6 +270,11 @@ bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double 
     if (!fast_eligible(src_kind, interp, old_rate, new_rate, F)) return false;
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
+    if (!getenv("AUKIT_FAST_V1")) {  // wave-private pipelined kernel (fast2.hip); v1 kept for A/B and odd ratios
+        bool taken = false;
+        int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
+        if (taken) { *rc = r2; return true; }
+    }
     *rc = launch_fast(ctx, src_kind, interp, segs, P, F, algorithmic_bytes);
     return true;
 }

@@ -72,8 +72,18 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
 
 int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out, ResampleParams &P);
 
-// fast.hip: f32 tolerance path (exact rational positions, f32 FMA taps, 16-byte stores)
-struct FastParams;
+// fast.hip / fast2.hip: f32 tolerance path (exact rational positions, f32 FMA taps)
+struct FastParams {
+    unsigned a, b;       // x - 1 = o * a / b
+    unsigned magic;      // ceil(2^32 / b): q = mulhi(n, magic) exact for n * b < 2^32
+    float inv_b;
+    int tile_out;        // v1: outputs per workgroup tile (multiple of 1024)
+    int cap;             // LDS floats per staged window (v1: per workgroup, v2: per wave)
+    float scale_pos, scale_neg;  // s16: 1/32767, 1/32768
+    unsigned wc, wd;     // v2: (1024 * a) = wc * b + wd  (one wave tile = 1024 outputs)
+};
+int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
+                     uint64_t algorithmic_bytes, bool *taken);
 bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
               uint64_t algorithmic_bytes, int *rc);
 

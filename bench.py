@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-streams", type=int, default=256, help="streams timed on the CPU oracle (0 disables)")
+    ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the fast kernel")
+    ap.add_argument("--exact-math", type=int, default=0, help="1: fp64 reference-order kernel even for f32 storage")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +97,8 @@ def main():
 
     ctx = B.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launch on torch's current stream
+    ctx.set_option(N.OPT_STORE_X4, args.store_x4)
+    ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
     offs = [i * n_samples * 2 for i in range(args.streams + 1)]
     bt = B.Batch.wrap(ctx, x.data_ptr(), offs, keep=x)
     desc = B.make_desc(N.CODEC_PCM, 1, SRC_RATE, 16, "signed")
@@ -147,7 +151,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            # arithmetic type of the path: the f32-store fast kernels use exact integer positions + f32 FMA taps,
+            # the reference-order kernels (f64 store or --exact-math 1) compute in fp64
+            "dtype": "f32" if name.startswith("k_fast") else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.streams}x s16le 44.1kHz mono {args.seconds:g}s per GPU -> aukit.pcm:resample(48000,'cubic'), "
                                    f"{args.dtype} store (SURVEY 8d config T)",
