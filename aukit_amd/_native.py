@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "api_resample.hip", "codecs.hip", "effects.hip", "flac.hip", "stubs.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "effects.hip", "flac.hip", "stubs.hip"]
 HEADERS = ["common.h", "resample.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -34,7 +34,7 @@ EXPORTS = [
     "aukit_batch_download", "aukit_batch_free",
     "aukit_audio_upload", "aukit_audio_info", "aukit_audio_layout", "aukit_audio_device_ptr", "aukit_audio_download",
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
-    "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode",
+    "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
 ]
 

@@ -297,6 +297,13 @@ def dfpwm_encode(ctx, audio, interleaved=True, out=None):
     return out
 
 
+def dfpwm_transcode_mono(ctx, batch, channels, out=None):
+    """Fused aukit.dfpwm(d, channels, sr):mono():dfpwm() over a batch."""
+    out = out if out is not None else Batch(ctx, C.c_void_p())
+    N.check(N.lib().aukit_dfpwm_transcode_mono(ctx._h, batch._h, int(channels), C.byref(out._h)))
+    return out
+
+
 def encode_pcm(ctx, audio, bit_depth=8, data_type="signed", interleaved=True, out=None):
     out = out if out is not None else AudioBatch(ctx)
     N.check(N.lib().aukit_encode_pcm(ctx._h, audio._h, int(bit_depth), N.PCM_TYPE[data_type] if isinstance(data_type, str) else int(data_type),

@@ -326,6 +326,59 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
     return AUKIT_OK;
 }
 
+// Block codecs decode to compact integer rows (int16 predictors / int8 DFPWM samples) in a scratch buffer; this turns
+// those rows into an Audio: v / (v < 0 and norm_neg or norm_pos), optionally resampled in the same pass
+// (`loader(...):resample(new_rate, interp)`).  Row r = stream r / channels, channel r % channels.
+int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len,
+                        uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
+                        double norm_neg, aukit_audio **out) {
+    const double ratio = do_resample ? new_rate / rate : 1.0;
+    if (!(ratio > 0)) return fail(AUKIT_E_ARG, "bad sample rate");
+    std::vector<uint64_t> lens(n);
+    uint64_t in_elems = 0, out_elems = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t L = row_len[(size_t)s * channels];
+        lens[s] = do_resample ? resample_count(L, ratio) : L;  // newlen uses #data[1]  :659
+        for (int c = 0; c < channels; c++) {
+            if (row_len[(size_t)s * channels + c] < L && lens[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+            in_elems += row_len[(size_t)s * channels + c];
+        }
+        if (lens[s] && std::floor(host_pos(lens[s] - 1, ratio)) > (double)L) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        out_elems += lens[s] * (uint64_t)channels;
+    }
+    aukit_audio *a = *out;
+    int rc;
+    if ((rc = audio_prepare(ctx, &a, n, channels, do_resample ? new_rate : rate, dtype, lens.data()))) return rc;
+    *out = a;
+    std::vector<Seg> segs((size_t)n * channels);
+    for (uint32_t s = 0; s < n; s++)
+        for (int c = 0; c < channels; c++) {
+            const size_t r = (size_t)s * channels + c;
+            Seg &g = segs[r];
+            g.src_base = -1;
+            g.w_lo = 1;
+            g.w_hi = (int)row_len[r];
+            g.n_out = (unsigned)lens[s];
+            g.stream = (unsigned)r;
+            g.out_off = a->row_off[s] + (uint64_t)c * a->row_stride[s];
+            g.out_stride = 0;
+            g.pad = 0;
+        }
+    if ((rc = upload_table(ctx, ctx->misc_buf, row_off.data(), row_off.size() * sizeof(uint64_t)))) return rc;
+    ResampleParams P;
+    memset(&P, 0, sizeof P);
+    P.src = reinterpret_cast<const unsigned char *>(rows_dev);
+    P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+    P.channels = 1;
+    P.norm_pos = norm_pos;
+    P.norm_neg = norm_neg;
+    P.out = a->dev;
+    const int ip = do_resample ? interp : AUKIT_INTERP_NONE;
+    size_t lds;
+    if ((rc = plan_tiles(ctx, segs, ratio, ip, 1, P, &lds))) return rc;
+    return launch_resample(ctx, src_kind, ip, EPI_AUDIO, dtype, P, lds, in_elems * (src_kind == SRC_I16 ? 2 : 1) + out_elems * dtype_size(dtype), nullptr);
+}
+
 }  // namespace aukit
 
 using namespace aukit;

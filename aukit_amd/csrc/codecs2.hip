@@ -1,0 +1,656 @@
+// codecs2.hip — MS-ADPCM, QOA, MDFPWM loaders and the remaining stream.* factories (dfpwm, mdfpwm, msadpcm, qoa).
+//
+// MS-ADPCM (aukit.lua:1321-1328) and the QOA LMS (aukit.lua:1686-1701) have a floor / wrap inside the recurrence, so they
+// are sequential per block / frame: one lane per (block, channel) resp. (frame, channel); parallelism comes from
+// blocks × streams.  MS-ADPCM is evaluated in fp64 exactly like the Lua (its `delta` can leave the integer range on
+// adversarial data); QOA in int64 with the int32 wrap of bit32.arshift.  None of these is on a BASELINE config.
+#include <algorithm>
+#include "resample.h"
+#include "dfpwm_dev.h"
+
+namespace aukit {
+
+int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len,
+                        uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
+                        double norm_neg, aukit_audio **out);
+
+AUKIT_DEV double lclamp(double n, double mn, double mx) { return n < mn ? mn : (n > mx ? mx : n); }
+
+// ================================================================= MS-ADPCM
+__constant__ int c_ms_adapt[16] = {230, 230, 230, 230, 307, 409, 512, 614, 768, 614, 512, 409, 307, 230, 230, 230};  // [0..7], [-8..-1]  :173-176
+
+struct MsJob {
+    unsigned long long blk_off;   // byte offset of the block
+    unsigned long long hdr_off;   // byte offset of the header to use (mono: always the stream's first block, Q9)
+    unsigned long long out_off;   // element offset (doubles) of this block's first sample, channel 0
+    unsigned long long out_off_r; // channel 1
+};
+struct MsParams {
+    const unsigned char *src;
+    const MsJob *jobs;
+    unsigned long long njobs;
+    int C, block_align, ncoef;
+    int coef1[32], coef2[32];
+    double div_neg, div_pos;      // 32768/32767 (aukit.msadpcm) or 128/127 (stream.msadpcm)
+    int floor_all;                // stream stereo: every sample floored (:2648-2662); stream mono / Audio path: not
+    double *out;
+    int *err;
+};
+AUKIT_DEV double ms_step(double &s1, double &s2, double &delta, double c1, double c2, int nib) {
+    const double predictor = lclamp(floor((s1 * c1 + s2 * c2) / 256) + nib * delta, -32768, 32767);  // :1321
+    s2 = s1; s1 = predictor;
+    const double nd = floor(c_ms_adapt[nib & 15] * delta / 256);                                      // :1324
+    delta = nd < 16 ? 16 : nd;  // math.max(nd, 16): PUC math.max keeps the first argument unless the next is greater
+    return predictor;
+}
+AUKIT_DEV int rd16(const unsigned char *p) { return (short)(p[0] | p[1] << 8); }
+
+__global__ __launch_bounds__(64) void k_msadpcm(const MsParams P) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (j >= P.njobs) return;
+    const MsJob job = P.jobs[j];
+    const unsigned char *blk = P.src + job.blk_off, *h = P.src + job.hdr_off;
+    auto emit = [&](double *o, unsigned long long i, double p) {
+        double v = p / (p < 0 ? P.div_neg : P.div_pos);
+        o[i] = P.floor_all ? floor(v) : v;
+    };
+    if (P.C == 2) {
+        const int piL = h[0], piR = h[1];
+        if (piL >= P.ncoef || piR >= P.ncoef) { atomicCAS(P.err, 0, 1); return; }
+        double dL = rd16(h + 2), dR = rd16(h + 4), s1L = rd16(h + 6), s1R = rd16(h + 8), s2L = rd16(h + 10), s2R = rd16(h + 12);
+        const double c1L = P.coef1[piL], c2L = P.coef2[piL], c1R = P.coef1[piR], c2R = P.coef2[piR];
+        double *oL = P.out + job.out_off, *oR = P.out + job.out_off_r;
+        emit(oL, 0, s2L); emit(oL, 1, s1L); emit(oR, 0, s2R); emit(oR, 1, s1R);
+        unsigned long long w = 2;
+        for (int i = 14; i < P.block_align; i++) {
+            const int b = blk[i];
+            int hi = b >> 4, lo = b & 15;
+            if (hi >= 8) hi -= 16;
+            if (lo >= 8) lo -= 16;
+            emit(oL, w, ms_step(s1L, s2L, dL, c1L, c2L, hi));
+            emit(oR, w, ms_step(s1R, s2R, dR, c1R, c2R, lo));
+            w++;
+        }
+    } else {
+        const int pi = h[0];
+        if (pi >= P.ncoef) { atomicCAS(P.err, 0, 1); return; }
+        double d = rd16(h + 1), s1 = rd16(h + 3), s2 = rd16(h + 5);
+        const double c1 = P.coef1[pi], c2 = P.coef2[pi];
+        double *o = P.out + job.out_off;
+        // stream mono leaves the two header samples unfloored too (:2708-2709)
+        emit(o, 0, s2); emit(o, 1, s1);
+        unsigned long long w = 2;
+        for (int i = 7; i < P.block_align; i++) {
+            const int b = blk[i];
+            int hi = b >> 4, lo = b & 15;
+            if (hi >= 8) hi -= 16;
+            if (lo >= 8) lo -= 16;
+            emit(o, w++, ms_step(s1, s2, d, c1, c2, hi));
+            emit(o, w++, ms_step(s1, s2, d, c1, c2, lo));
+        }
+    }
+}
+
+static const int ms_c1_default[7] = {256, 512, 0, 192, 240, 460, 392}, ms_c2_default[7] = {0, -256, 0, 64, 0, -208, -232};  // :1304
+
+// decodes every block of every stream into fp64 rows in ctx->tmp_buf; rows are per (stream, channel), blocks back to back
+static int msadpcm_rows(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, bool stream_mode, std::vector<uint64_t> &row_off,
+                        std::vector<uint64_t> &row_len, std::vector<uint64_t> &nblocks, uint64_t *spb_out) {
+    const int C = d->channels;
+    if (C != 1 && C != 2) return fail(AUKIT_E_LUA, "Unsupported number of channels: %d", C);
+    const uint64_t ba = (uint64_t)d->block_align;
+    if (d->block_align < (C == 2 ? 15 : 8)) return fail(AUKIT_E_ARG, "bad blockAlign");
+    const uint64_t spb = C == 2 ? (ba - 14) + 2 : (ba - 7) * 2 + 2;  // samples decoded per block per channel
+    *spb_out = spb;
+    std::vector<MsJob> jobs;
+    row_off.assign((size_t)in->n * C, 0);
+    row_len.assign((size_t)in->n * C, 0);
+    nblocks.assign(in->n, 0);
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        const uint64_t nblk = (nb + ba - 1) / ba;  // for n = 1, #data, blockAlign
+        if (nblk && nb % ba != 0) return fail(AUKIT_E_LUA, stream_mode ? "bad argument #1 to 'rshift' (number expected, got nil)" : "bad argument #1 to 'rshift' (number expected, got nil)");
+        nblocks[s] = nblk;
+        const uint64_t L = nblk * spb, stride = round_up(std::max<uint64_t>(L, 1), 2);
+        for (int c = 0; c < C; c++) { row_off[(size_t)s * C + c] = tot + (uint64_t)c * stride; row_len[(size_t)s * C + c] = L; }
+        for (uint64_t b = 0; b < nblk; b++) {
+            MsJob j;
+            j.blk_off = in->off[s] + b * ba;
+            j.hdr_off = C == 1 ? in->off[s] : j.blk_off;
+            j.out_off = tot + b * spb;
+            j.out_off_r = tot + stride + b * spb;
+            jobs.push_back(j);
+        }
+        tot += stride * C;
+    }
+    int rc = ctx->tmp_buf.ensure((size_t)tot * 8 + 64);
+    if (rc) return rc;
+    const size_t jbytes = jobs.size() * sizeof(MsJob);
+    if ((rc = ctx->tmp_buf2.ensure(jbytes + 16))) return rc;
+    if (jbytes) AUKIT_HIP_CHECK(hipMemcpyAsync(ctx->tmp_buf2.p, jobs.data(), jbytes, hipMemcpyHostToDevice, ctx->stream));
+    int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->tmp_buf2.p) + jbytes);
+    AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
+    if (jobs.empty()) return AUKIT_OK;
+    MsParams P{};
+    P.src = in->data(); P.jobs = reinterpret_cast<const MsJob *>(ctx->tmp_buf2.p); P.njobs = jobs.size();
+    P.C = C; P.block_align = d->block_align;
+    if (d->ncoef > 0) { P.ncoef = std::min(d->ncoef, 32); for (int i = 0; i < P.ncoef; i++) { P.coef1[i] = d->coef1[i]; P.coef2[i] = d->coef2[i]; } }
+    else { P.ncoef = 7; for (int i = 0; i < 7; i++) { P.coef1[i] = ms_c1_default[i]; P.coef2[i] = ms_c2_default[i]; } }
+    P.div_neg = stream_mode ? 128 : 32768; P.div_pos = stream_mode ? 127 : 32767;
+    P.floor_all = (stream_mode && C == 2) ? 1 : 0;
+    P.out = reinterpret_cast<double *>(ctx->tmp_buf.p);
+    P.err = err;
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
+    hipLaunchKernelGGL(k_msadpcm, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, ctx->stream, P);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    if ((rc = ctx_end_kernel(ctx, "k_msadpcm", in->total() + tot * 8))) return rc;
+    int herr = 0;
+    AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (herr) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (local 'c1')");  // predictor index beyond the coefficient table
+    return AUKIT_OK;
+}
+
+int decode_msadpcm_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample, int dtype,
+                         aukit_audio **out) {
+    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
+    std::vector<uint64_t> row_off, row_len, nblocks;
+    uint64_t spb;
+    int rc = msadpcm_rows(ctx, in, d, false, row_off, row_len, nblocks, &spb);
+    if (rc) return rc;
+    return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, row_off, row_len, in->n, d->channels, d->sample_rate, new_rate, interp, do_resample, dtype, 1, 1, out);
+}
+
+// aukit.stream.msadpcm  aukit.lua:2588-2736
+static int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
+                          aukit_chunks **chunks_out) {
+    const int C = d->channels;
+    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
+    if (interp == AUKIT_INTERP_SINC && C == 2) return fail(AUKIT_E_UNSUPPORTED, "stream.msadpcm stereo + sinc reads the previous block through a shifted history (not reproduced)");
+    if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.msadpcm output must be AUKIT_I8 or AUKIT_F64");
+    std::vector<uint64_t> row_off, row_len, nblocks;
+    uint64_t spb_dec;
+    int rc = msadpcm_rows(ctx, in, d, true, row_off, row_len, nblocks, &spb_dec);
+    if (rc) return rc;
+    const uint64_t ba = (uint64_t)d->block_align;
+    const double ratio = 48000 / d->sample_rate;
+    const double samplesPerBlock = C == 2 ? (double)(ba - 14) : (double)(ba - 7) * 2;  // :2617 / :2682 (2 short, Q9)
+    const double ips_d = std::ceil(d->sample_rate / samplesPerBlock);
+    const double bytesPerSecond = (double)ba * ips_d;
+    const uint32_t newlen = (uint32_t)std::max(0.0, std::floor(samplesPerBlock * ratio));
+    const uint64_t ips = (uint64_t)ips_d;
+    const int nd = (C == 2 && !mono) ? 2 : 1;
+    aukit_chunks *ck = new aukit_chunks();
+    ck->n = in->n;
+    ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
+    std::vector<uint64_t> lens(in->n, 0);
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        ck->length_seconds[s] = (double)nb / (double)ba * samplesPerBlock / d->sample_rate;
+        ck->nchunks[s] = newlen ? (uint32_t)((nblocks[s] + ips - 1) / ips) : 0;
+        ck->max_chunks = std::max(ck->max_chunks, ck->nchunks[s]);
+        lens[s] = nblocks[s] * newlen;
+    }
+    const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
+    ck->lens.assign((size_t)ck->n * mc, 0);
+    ck->pos.assign((size_t)ck->n * mc, 0);
+    for (uint32_t s = 0; s < in->n; s++)
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
+            const uint64_t done = std::min<uint64_t>((uint64_t)(k + 1) * ips, nblocks[s]), first = (uint64_t)k * ips;
+            ck->lens[(size_t)s * mc + k] = (uint32_t)((done - first) * newlen);
+            ck->pos[(size_t)s * mc + k] = ((double)(done * ba + 1)) / bytesPerSecond;  // (n + pos) / bytesPerSecond
+        }
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
+    *out = a;
+    // one segment per block; its C source rows are consecutive entries of the row table
+    std::vector<Seg> segs;
+    std::vector<uint64_t> blkrows;
+    uint64_t out_elems = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        for (uint64_t b = 0; b < nblocks[s]; b++) {
+            Seg g;
+            g.src_base = -1; g.w_lo = 1; g.w_hi = (int)spb_dec; g.n_out = newlen;
+            g.stream = (unsigned)(blkrows.size() / C);
+            g.out_off = a->row_off[s] + b * newlen;
+            g.out_stride = (unsigned)a->row_stride[s];
+            g.pad = 0;
+            for (int c = 0; c < C; c++) blkrows.push_back(row_off[(size_t)s * C + c] + b * spb_dec);
+            segs.push_back(g);
+        }
+        out_elems += lens[s] * nd;
+    }
+    if (!segs.empty() && newlen) {
+        if ((rc = upload_table(ctx, ctx->misc_buf, blkrows.data(), blkrows.size() * 8))) { delete ck; return rc; }
+        ResampleParams P;
+        memset(&P, 0, sizeof P);
+        P.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
+        P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        P.channels = C;
+        P.mix_mono = (C == 2 && mono) ? 2 : 0;
+        P.out = a->dev;
+        size_t lds;
+        if ((rc = plan_tiles(ctx, segs, ratio, interp, C, P, &lds))) { delete ck; return rc; }
+        rc = launch_resample(ctx, SRC_AUDIO_F64, interp, EPI_STREAM_FLOOR, dtype, P, lds, in->total() + out_elems * dtype_size(dtype), nullptr);
+        if (rc) { delete ck; return rc; }
+    }
+    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+    return AUKIT_OK;
+}
+
+// ================================================================= QOA
+__constant__ int c_qoa_dequant[16][8] = {
+    {1, -1, 3, -3, 5, -5, 7, -7}, {5, -5, 18, -18, 32, -32, 49, -49}, {16, -16, 53, -53, 95, -95, 147, -147},
+    {34, -34, 113, -113, 203, -203, 315, -315}, {63, -63, 210, -210, 378, -378, 588, -588}, {104, -104, 345, -345, 621, -621, 966, -966},
+    {158, -158, 528, -528, 950, -950, 1477, -1477}, {228, -228, 760, -760, 1368, -1368, 2128, -2128},
+    {316, -316, 1053, -1053, 1895, -1895, 2947, -2947}, {422, -422, 1405, -1405, 2529, -2529, 3934, -3934},
+    {548, -548, 1828, -1828, 3290, -3290, 5117, -5117}, {696, -696, 2320, -2320, 4176, -4176, 6496, -6496},
+    {868, -868, 2893, -2893, 5207, -5207, 8099, -8099}, {1064, -1064, 3548, -3548, 6386, -6386, 9933, -9933},
+    {1286, -1286, 4288, -4288, 7718, -7718, 12005, -12005}, {1536, -1536, 5120, -5120, 9216, -9216, 14336, -14336}};  // :1662-1679
+
+struct QoaJob {
+    unsigned long long frame_off;  // byte offset of the frame header
+    unsigned long long out_off;    // element offset (int16) of sample_pos + 1 in this channel's row
+    int c, channels, samples, emit;  // emit: how many samples to store (20 * slices for the last frame of a table, `samples` otherwise)
+};
+AUKIT_DEV unsigned rdbe32(const unsigned char *p) { return (unsigned)p[0] << 24 | (unsigned)p[1] << 16 | (unsigned)p[2] << 8 | p[3]; }
+AUKIT_DEV int rdbe16s(const unsigned char *p) { return (short)(p[0] << 8 | p[1]); }
+
+__global__ __launch_bounds__(64) void k_qoa(const unsigned char *src, const QoaJob *jobs, unsigned long long njobs, short *out, int shift8) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (j >= njobs) return;
+    const QoaJob job = jobs[j];
+    const unsigned char *f = src + job.frame_off;
+    const unsigned char *l = f + 8 + 16 * job.c;
+    long long h[4], w[4];
+    for (int k = 0; k < 4; k++) { h[k] = rdbe16s(l + 2 * k); w[k] = rdbe16s(l + 8 + 2 * k); }
+    const unsigned char *sl = f + 8 + 16 * job.channels;
+    short *o = out + job.out_off;
+    for (int si0 = 0; si0 < job.samples; si0 += 20) {
+        const unsigned char *p = sl + 8 * ((size_t)(si0 / 20) * job.channels + job.c);
+        unsigned hi = rdbe32(p), lo = rdbe32(p + 4);
+        const int sf = hi >> 28;
+        for (int k = 0; k < 20; k++) {
+            const long long sum = w[0] * h[0] + w[1] * h[1] + w[2] * h[2] + w[3] * h[3];
+            const int predicted = ((int)(unsigned)(unsigned long long)sum) >> 13;         // signed_rshift: wrap to int32, arithmetic shift :1681-1689
+            const int deq = c_qoa_dequant[sf][(hi >> 25) & 7];
+            int rec = predicted + deq;
+            rec = rec < -32768 ? -32768 : (rec > 32767 ? 32767 : rec);
+            if (si0 + k < job.emit) o[si0 + k] = (short)(shift8 ? (rec >> 8) : rec);       // stream.qoa: math.floor(reconstructed / 256) :3299
+            hi = (hi << 3) | (lo >> 29);
+            lo <<= 3;
+            const int delta = deq >> 4;                                                    // signed_rshift(residual, 4)
+            for (int q = 0; q < 4; q++) w[q] += h[q] < 0 ? -delta : delta;                 // :1694-1699
+            h[0] = h[1]; h[1] = h[2]; h[2] = h[3]; h[3] = rec;
+        }
+    }
+}
+
+struct QoaFrame { uint64_t off; int samples; };
+// walks the frame headers exactly like the reference loops; `audio_mode` adds aukit.qoa's extra checks (:1720, :1735)
+static int qoa_scan(const uint8_t *hdr, uint64_t nb, bool audio_mode, int *file_channels, double *file_rate, double *file_samples,
+                    std::vector<QoaFrame> &frames, bool *raised) {
+    *raised = false;
+    if (nb < 8) return fail(AUKIT_E_LUA, audio_mode ? "data string too short" : "Not a QOA file");
+    if (memcmp(hdr, "qoaf", 4) != 0) return fail(AUKIT_E_ARG, "Not a QOA file");
+    *file_samples = (double)((uint32_t)hdr[4] << 24 | (uint32_t)hdr[5] << 16 | (uint32_t)hdr[6] << 8 | hdr[7]);
+    if (nb < 12) return fail(AUKIT_E_LUA, nb == 8 && !audio_mode ? "Not a QOA file" : "data string too short");
+    *file_channels = hdr[8];
+    *file_rate = (double)((uint32_t)hdr[9] << 16 | (uint32_t)hdr[10] << 8 | hdr[11]);
+    if (*file_channels < 1 || *file_channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", *file_channels);
+    uint64_t pos = 8;
+    double sample_pos = 0;
+    for (;;) {
+        if (audio_mode) { if (!(pos + 1 + 16 * (uint64_t)*file_channels + 8 <= nb && sample_pos < *file_samples)) break; }
+        else { if (pos >= nb) break; if (pos + 8 > nb) { *raised = true; break; } }
+        const uint8_t *f = hdr + pos;
+        const int channels = f[0];
+        const double rate = (double)((uint32_t)f[1] << 16 | (uint32_t)f[2] << 8 | f[3]);
+        const int samples = f[4] << 8 | f[5], frame_size = f[6] << 8 | f[7];
+        const int data_size = frame_size - 8 - 16 * channels;
+        const int num_slices = (int)std::floor((double)data_size / 8);
+        if (channels != *file_channels || rate != *file_rate || samples * channels > num_slices * 20) break;
+        if (audio_mode && (double)frame_size > (double)nb - (double)(pos + 8)) break;  // frame_size > #data - pos + 1, pos after the header (drops the last frame)
+        const uint64_t need = 8 + 16 * (uint64_t)channels + 8 * (uint64_t)((samples + 19) / 20) * channels;
+        if (pos + need > nb) { *raised = true; break; }  // "data string too short" / assert(read(8))
+        frames.push_back(QoaFrame{pos, samples});
+        pos += need;
+        sample_pos += samples;
+        (void)sample_pos;
+    }
+    return AUKIT_OK;
+}
+
+int decode_qoa_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
+                     aukit_audio **out) {
+    // headers are parsed on the host (8 bytes per 5120-sample frame); the batch is read back once for that
+    std::vector<uint8_t> host(in->total() + 16);
+    if (in->total()) AUKIT_HIP_CHECK(hipMemcpyAsync(host.data(), in->data(), in->total(), hipMemcpyDeviceToHost, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int C = 0;
+    double rate = 0;
+    std::vector<QoaJob> jobs;
+    std::vector<uint64_t> row_off, row_len;
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        int fc; double fr, fs; bool raised;
+        std::vector<QoaFrame> frames;
+        int rc = qoa_scan(host.data() + in->off[s], in->off[s + 1] - in->off[s], true, &fc, &fr, &fs, frames, &raised);
+        if (rc) return rc;
+        if (raised) return fail(AUKIT_E_LUA, "data string too short");
+        if (s == 0) { C = fc; rate = fr; }
+        else if (fc != C || fr != rate) return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate");
+        uint64_t L = 0, sp = 0;
+        for (size_t k = 0; k < frames.size(); k++) { L = std::max<uint64_t>(L, sp + (uint64_t)((frames[k].samples + 19) / 20) * 20); sp += frames[k].samples; }
+        const uint64_t stride = round_up(std::max<uint64_t>(L, 1), 8);
+        sp = 0;
+        for (size_t k = 0; k < frames.size(); k++) {
+            const bool lastf = k + 1 == frames.size();
+            for (int c = 0; c < C; c++) {
+                QoaJob j;
+                j.frame_off = in->off[s] + frames[k].off; j.out_off = tot + (uint64_t)c * stride + sp;
+                j.c = c; j.channels = C; j.samples = frames[k].samples;
+                j.emit = lastf ? ((frames[k].samples + 19) / 20) * 20 : frames[k].samples;  // Q15: the ≤19-sample tail survives only after the last frame
+                jobs.push_back(j);
+            }
+            sp += frames[k].samples;
+        }
+        for (int c = 0; c < C; c++) { row_off.push_back(tot + (uint64_t)c * stride); row_len.push_back(L); }
+        tot += stride * C;
+    }
+    if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
+    int rc = ctx->tmp_buf.ensure((size_t)tot * 2 + 64);
+    if (rc) return rc;
+    if ((rc = upload_table(ctx, ctx->tmp_buf2, jobs.data(), jobs.size() * sizeof(QoaJob)))) return rc;
+    if (!jobs.empty()) {
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        hipLaunchKernelGGL(k_qoa, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const QoaJob *>(ctx->tmp_buf2.p),
+                           (unsigned long long)jobs.size(), reinterpret_cast<short *>(ctx->tmp_buf.p), 0);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        if ((rc = ctx_end_kernel(ctx, "k_qoa", in->total() + tot * 2))) return rc;
+    }
+    return audio_from_int_rows(ctx, SRC_I16, ctx->tmp_buf.p, row_off, row_len, in->n, C, rate, new_rate, interp, do_resample, dtype, 32767, 32768, out);
+}
+
+// ================================================================= MDFPWM  aukit.lua:1420-1448
+__global__ __launch_bounds__(64) void k_mdfpwm_decode(const unsigned char *src, const unsigned long long *payload_off, const unsigned long long *payload_len,
+                                                     unsigned n, signed char *out, const unsigned long long *row_off) {
+    const unsigned r = blockIdx.x * 64 + threadIdx.x;  // row = stream * 2 + channel: decoderL / decoderR are independent
+    if (r >= 2 * n) return;
+    const unsigned s = r >> 1, c = r & 1;
+    const unsigned char *p = src + payload_off[s];
+    const unsigned long long nb = payload_len[s];
+    signed char *o = out + row_off[r];
+    DfDec d{};
+    unsigned long long w = 0;
+    for (unsigned long long pos = 6000ull * c; pos < nb; pos += 12000) {
+        const unsigned long long cnt = nb - pos < 6000 ? nb - pos : 6000;
+        for (unsigned long long b = 0; b < cnt; b++) {
+            unsigned byte = p[pos + b];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { o[w++] = (signed char)df_decode_bit(d, byte & 1); byte >>= 1; }
+        }
+    }
+}
+
+struct MdHeader { uint64_t payload, length; };
+static int mdfpwm_header(const uint8_t *h, uint64_t nb, MdHeader *out, const char *badmsg) {
+    if (nb < 7 || memcmp(h, "MDFPWM\3", 7) != 0) return fail(AUKIT_E_ARG, "%s", badmsg);
+    uint64_t pos = 7;
+    if (pos + 4 > nb) return fail(AUKIT_E_LUA, "data string too short");
+    out->length = (uint64_t)h[pos] | (uint64_t)h[pos + 1] << 8 | (uint64_t)h[pos + 2] << 16 | (uint64_t)h[pos + 3] << 24;
+    pos += 4;
+    for (int k = 0; k < 3; k++) {
+        if (pos + 1 > nb) return fail(AUKIT_E_LUA, "data string too short");
+        pos += 1 + (uint64_t)h[pos];
+        if (pos > nb) return fail(AUKIT_E_LUA, "data string too short");
+    }
+    out->payload = pos;
+    return AUKIT_OK;
+}
+
+// decodes both channels of every stream into int8 rows in ctx->tmp_buf; returns per-row offsets / decoded lengths
+static int mdfpwm_rows(aukit_ctx *ctx, const aukit_batch *in, const char *badmsg, std::vector<MdHeader> &hdrs, std::vector<uint64_t> &row_off,
+                       std::vector<uint64_t> &row_len) {
+    std::vector<uint8_t> head(300);
+    hdrs.resize(in->n);
+    row_off.assign((size_t)in->n * 2, 0);
+    row_len.assign((size_t)in->n * 2, 0);
+    std::vector<uint64_t> tab((size_t)in->n * 4, 0);
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s], take = std::min<uint64_t>(nb, 300);
+        if (take) AUKIT_HIP_CHECK(hipMemcpyAsync(head.data(), in->data() + in->off[s], take, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int rc = mdfpwm_header(head.data(), take == nb ? nb : std::max<uint64_t>(take, 300), &hdrs[s], badmsg);
+        if (rc) return rc;
+        if (hdrs[s].payload > nb) return fail(AUKIT_E_LUA, "data string too short");
+        const uint64_t pl = nb - hdrs[s].payload;
+        // bytes seen by decoderL / decoderR
+        uint64_t bl = 0, br = 0;
+        for (uint64_t pos = 0; pos < pl; pos += 12000) {
+            bl += std::min<uint64_t>(6000, pl - pos);
+            if (pos + 6000 < pl) br += std::min<uint64_t>(6000, pl - pos - 6000);
+        }
+        if (bl != br) return fail(AUKIT_E_UNSUPPORTED, "MDFPWM payload is not a whole number of L/R block pairs (the reference builds a table with holes)");
+        const uint64_t stride = round_up(std::max<uint64_t>(bl * 8, 1), 16);
+        row_off[(size_t)s * 2] = tot; row_off[(size_t)s * 2 + 1] = tot + stride;
+        row_len[(size_t)s * 2] = row_len[(size_t)s * 2 + 1] = bl * 8;
+        tab[s] = in->off[s] + hdrs[s].payload;
+        tab[in->n + s] = pl;
+        tab[2 * (size_t)in->n + 2 * s] = tot; tab[2 * (size_t)in->n + 2 * s + 1] = tot + stride;
+        tot += 2 * stride;
+    }
+    int rc = ctx->tmp_buf.ensure((size_t)tot + 64);
+    if (rc) return rc;
+    if ((rc = upload_table(ctx, ctx->tmp_buf2, tab.data(), tab.size() * 8))) return rc;
+    if (in->n) {
+        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->tmp_buf2.p);
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        hipLaunchKernelGGL(k_mdfpwm_decode, dim3((2 * in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), t, t + in->n, in->n,
+                           reinterpret_cast<signed char *>(ctx->tmp_buf.p), t + 2 * (size_t)in->n);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        if ((rc = ctx_end_kernel(ctx, "k_mdfpwm_decode", in->total() + tot))) return rc;
+    }
+    return AUKIT_OK;
+}
+
+int decode_mdfpwm_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
+                        aukit_audio **out) {
+    std::vector<MdHeader> hdrs;
+    std::vector<uint64_t> row_off, row_len;
+    int rc = mdfpwm_rows(ctx, in, "bad argument #1 (not a MDFPWM file)", hdrs, row_off, row_len);
+    if (rc) return rc;
+    for (uint32_t s = 0; s < in->n; s++) {  // for i = length * 8 + 1, #audio do audio[i] = nil  :1444 (interleaved table)
+        const uint64_t inter = row_len[(size_t)s * 2] * 2, keep = std::min<uint64_t>(inter, hdrs[s].length * 8);
+        row_len[(size_t)s * 2] = row_len[(size_t)s * 2 + 1] = keep / 2;
+        if (keep % 2) return fail(AUKIT_E_ARG, "bad argument #1 (uneven amount of data per channel)");
+    }
+    return audio_from_int_rows(ctx, SRC_I8, ctx->tmp_buf.p, row_off, row_len, in->n, 2, 48000, new_rate, interp, do_resample, dtype, 127, 128, out);
+}
+
+// ================================================================= stream.dfpwm  aukit.lua:2439-2496
+__global__ __launch_bounds__(64) void k_dfpwm_stream_rows(const unsigned char *src, const unsigned long long *off, unsigned n, unsigned long long adv,
+                                                         signed char *out, const unsigned long long *row_off) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const unsigned char *p = src + off[s];
+    const unsigned long long nb = off[s + 1] - off[s];
+    signed char *o = out + row_off[s];
+    DfDec d{};
+    unsigned long long w = 0;
+    o[w++] = 0;  // audio[0] of the first chunk = `last` = 0
+    for (unsigned long long pos = 0; pos < nb; pos += adv) {  // str_sub(data, pos, pos + 6000 * channels): one byte of overlap
+        const unsigned long long cnt = nb - pos < adv + 1 ? nb - pos : adv + 1;
+        for (unsigned long long b = 0; b < cnt; b++) {
+            unsigned byte = p[pos + b];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { o[w++] = (signed char)df_decode_bit(d, byte & 1); byte >>= 1; }
+        }
+    }
+}
+
+static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
+                        aukit_chunks **chunks_out) {
+    const int C = d->channels;
+    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
+    if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "bad argument #3 (number outside of range)");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.dfpwm output must be AUKIT_F64 or AUKIT_F32");
+    if (C == 1) mono = 0;
+    const uint64_t adv = 6000ull * C, slice = adv + 1;
+    const double ratio = 48000 / d->sample_rate;
+    const int nd = mono ? 1 : C;
+    aukit_chunks *ck = new aukit_chunks();
+    ck->n = in->n;
+    ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
+    std::vector<uint64_t> lens(in->n, 0), rowo(in->n, 0);
+    std::vector<Seg> segs;
+    std::vector<std::vector<uint32_t>> clen(in->n);
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        ck->length_seconds[s] = (double)nb * 8 / d->sample_rate / C;
+        rowo[s] = tot;
+        uint64_t fed = 0;
+        for (uint64_t pos = 0; pos < nb; pos += adv) {
+            const uint64_t cnt = std::min<uint64_t>(slice, nb - pos), na = cnt * 8;
+            const double newlen = (double)na * ratio;                         // :2474
+            const uint32_t m = newlen >= 1 ? (uint32_t)(std::floor((newlen - 1) / C) + 1) : 0;  // for i = 1, newlen, channels
+            Seg g;
+            g.src_base = (long long)fed;  // row[fed] = audio[0] (previous chunk's last sample, or the leading 0)
+            g.w_lo = 0; g.w_hi = (int)na; g.n_out = m; g.stream = s;
+            g.out_off = lens[s]; g.out_stride = 0; g.pad = 0;
+            segs.push_back(g);
+            clen[s].push_back(m);
+            lens[s] += m;
+            fed += na;
+        }
+        ck->nchunks[s] = (uint32_t)clen[s].size();
+        ck->max_chunks = std::max(ck->max_chunks, ck->nchunks[s]);
+        tot += round_up(fed + 1, 16);
+    }
+    const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
+    ck->lens.assign((size_t)ck->n * mc, 0);
+    ck->pos.assign((size_t)ck->n * mc, 0);
+    for (uint32_t s = 0; s < in->n; s++)
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
+            ck->lens[(size_t)s * mc + k] = clen[s][k];
+            ck->pos[(size_t)s * mc + k] = (double)(k * adv + 1) * 8 / d->sample_rate / C;  // p * 8 / sampleRate / channels :2494
+        }
+    int rc;
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
+    *out = a;
+    for (Seg &g : segs) { g.out_off += a->row_off[g.stream]; g.out_stride = (unsigned)a->row_stride[g.stream]; }
+    if (in->n && !segs.empty()) {
+        if ((rc = ctx->tmp_buf.ensure((size_t)tot + 64))) { delete ck; return rc; }
+        if ((rc = upload_table(ctx, ctx->misc_buf, rowo.data(), rowo.size() * 8))) { delete ck; return rc; }
+        hipLaunchKernelGGL(k_dfpwm_stream_rows, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
+                           in->n, (unsigned long long)adv, reinterpret_cast<signed char *>(ctx->tmp_buf.p), reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        ResampleParams P;
+        memset(&P, 0, sizeof P);
+        P.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
+        P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        P.channels = 1;
+        P.norm_pos = P.norm_neg = 1;
+        P.pos_mul = C;
+        P.mix_mono = mono ? 1 : 0;
+        P.out_channels = C;
+        P.out = a->dev;
+        size_t lds;
+        if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) { delete ck; return rc; }
+        uint64_t oe = 0;
+        for (uint64_t l : lens) oe += l * nd;
+        rc = launch_resample(ctx, SRC_I8, interp, EPI_STREAM_DFPWM, dtype, P, lds, in->total() + oe * dtype_size(dtype), nullptr);
+        if (rc) { delete ck; return rc; }
+    }
+    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+    return AUKIT_OK;
+}
+
+// ================================================================= stream.mdfpwm  aukit.lua:2507-2572
+__global__ __launch_bounds__(256) void k_mdfpwm_chunks(const signed char *rows, const unsigned long long *row_off, const unsigned long long *nsamp, unsigned n, int mono,
+                                                      signed char *out, const unsigned long long *ooff, const unsigned long long *ostride) {
+    const unsigned s = blockIdx.y;
+    const unsigned long long L = nsamp[s];
+    const signed char *l = rows + row_off[2 * s], *r = rows + row_off[2 * s + 1];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < L; i += (unsigned long long)gridDim.x * 256) {
+        if (mono) {
+            const double v = floor((double)l[i] + (double)r[i] / 2);  // clamp(floor(audioL[i] + audioR[i] / 2))  :2563
+            out[ooff[s] + i] = (signed char)(int)(v < -128 ? -128 : (v > 127 ? 127 : v));
+        } else {
+            out[ooff[s] + i] = l[i];
+            out[ooff[s] + ostride[s] + i] = r[i];
+        }
+    }
+}
+
+static int stream_mdfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
+    if (dtype != AUKIT_I8) return fail(AUKIT_E_ARG, "stream.mdfpwm output must be AUKIT_I8");
+    std::vector<MdHeader> hdrs;
+    std::vector<uint64_t> row_off, row_len;
+    int rc = mdfpwm_rows(ctx, in, "bad argument #1 (invalid MDFPWM data)", hdrs, row_off, row_len);
+    if (rc) return rc;
+    aukit_chunks *ck = new aukit_chunks();
+    ck->n = in->n;
+    ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
+    std::vector<uint64_t> lens(in->n, 0);
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t pl = in->off[s + 1] - in->off[s] - hdrs[s].payload;
+        ck->length_seconds[s] = (double)hdrs[s].length / 12000;
+        // chunk k (12000-byte pair at payload offset 12000k) is delivered intact unless `pos - headerSize + 12000 > length` (Q12)
+        uint32_t good = 0;
+        for (uint64_t pos = 0; pos < pl; pos += 12000) {
+            const bool full = pos + 12000 <= pl;
+            const bool trimmed = (double)(pos + 1) + 12000 > (double)hdrs[s].length;
+            if (!full || trimmed) { ck->status[s] = mono ? AUKIT_E_LUA : AUKIT_E_UNSUPPORTED; break; }
+            good++;
+        }
+        ck->nchunks[s] = good;
+        ck->max_chunks = std::max(ck->max_chunks, good);
+        lens[s] = (uint64_t)good * 48000;
+    }
+    const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
+    ck->lens.assign((size_t)ck->n * mc, 0);
+    ck->pos.assign((size_t)ck->n * mc, 0);
+    for (uint32_t s = 0; s < in->n; s++)
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = 48000; ck->pos[(size_t)s * mc + k] = (double)(12000ull * k + 1) / 12000; }
+    aukit_audio *a = *out;
+    if ((rc = audio_prepare(ctx, &a, in->n, mono ? 1 : 2, 48000, AUKIT_I8, lens.data()))) { delete ck; return rc; }
+    *out = a;
+    if (in->n) {
+        std::vector<uint64_t> tab(row_off);
+        tab.insert(tab.end(), lens.begin(), lens.end());
+        if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) { delete ck; return rc; }
+        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        const unsigned long long *m = reinterpret_cast<const unsigned long long *>(a->d_meta);
+        hipLaunchKernelGGL(k_mdfpwm_chunks, dim3(64, in->n), dim3(256), 0, ctx->stream, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), t, t + 2 * (size_t)in->n,
+                           in->n, mono ? 1 : 0, reinterpret_cast<signed char *>(a->dev), m + in->n, m + 2 * (size_t)in->n);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        ctx->last_kernel = "k_mdfpwm_chunks";
+    }
+    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+    return AUKIT_OK;
+}
+
+int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
+int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
+
+int stream_more_codecs(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
+                       aukit_chunks **chunks) {
+    switch (d->codec) {
+    case AUKIT_CODEC_DFPWM: return stream_dfpwm(ctx, in, d, interp, mono, dtype, out, chunks);
+    case AUKIT_CODEC_MDFPWM: return stream_mdfpwm(ctx, in, d, mono, dtype, out, chunks);
+    case AUKIT_CODEC_MSADPCM: return stream_msadpcm(ctx, in, d, interp, mono, dtype, out, chunks);
+    case AUKIT_CODEC_QOA: return stream_qoa(ctx, in, d, interp, mono, dtype, out, chunks);
+    case AUKIT_CODEC_FLAC: return stream_flac(ctx, in, d, interp, mono, dtype, out, chunks);
+    case AUKIT_CODEC_ADPCM: return fail(AUKIT_E_ARG, "aukit.stream.adpcm takes WAV-style blocks: use AUKIT_CODEC_ADPCM_WAV");
+    }
+    return fail(AUKIT_E_ARG, "unknown stream codec %d", d->codec);
+}
+
+}  // namespace aukit

@@ -1,0 +1,559 @@
+// effects.hip — Audio:mono / Audio:mix / Audio:pcm and aukit.effects.* on device-resident audio batches.
+//
+// All of these are HBM-bound fp64 (or f32-stored) element-wise maps, reductions, or linear recurrences:
+//   * maps (amplify, invert, fade, normalize-scale, delay, mono, mix, encodePCM): one coalesced pass;
+//   * reductions (normalize peak, center mean): wave shuffles + LDS, atomicMax on the bit pattern;
+//   * first-order recurrences (lowpass, highpass): affine-map scan — each thread owns 8 consecutive samples,
+//     wave64 shuffle scan of the (A, B) composites, cross-wave scan in LDS, carry across tiles;
+//   * lag-`samples` recurrences (echo, reverb combs / all-pass): the `samples` residue chains are independent,
+//     so chains map to lanes (coalesced) and only the chain direction is sequential.
+// Arithmetic is fp64 in the reference's operation order wherever the algorithm is a map (bit-identical to the
+// Lua with AUKIT_F64 storage); the scans re-associate products and are tolerance-level (≤ 1e-12 observed).
+#include <algorithm>
+#include "common.h"
+
+namespace aukit {
+
+struct RowMeta {  // device view of an audio's layout
+    const unsigned long long *len, *off, *stride;
+    int channels;
+    unsigned n;
+};
+static RowMeta meta_of(const aukit_audio *a) {
+    RowMeta m;
+    m.len = reinterpret_cast<const unsigned long long *>(a->d_meta);
+    m.off = m.len + a->n;
+    m.stride = m.len + 2 * (size_t)a->n;
+    m.channels = a->channels;
+    m.n = a->n;
+    return m;
+}
+AUKIT_DEV void row_of(const RowMeta &m, unsigned r, unsigned long long *base, unsigned long long *len) {
+    unsigned s = r / (unsigned)m.channels, c = r - s * (unsigned)m.channels;
+    *base = m.off[s] + (unsigned long long)c * m.stride[s];
+    *len = m.len[s];
+}
+
+enum MapOp { MAP_AMPLIFY, MAP_INVERT, MAP_FADE, MAP_SCALE_ROWMAX, MAP_DELAY };
+struct MapArgs {
+    double a0, a1, a2, a3;       // op-specific scalars
+    const double *rowmax;        // MAP_SCALE_ROWMAX: max |x| per stream (or per row when `independent`)
+    int independent;
+    const void *aux;             // MAP_DELAY: copy of the original samples
+    unsigned long long lag;
+};
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void k_map(T *data, RowMeta m, MapArgs A) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    T *row = data + base;
+    double mult = 0;
+    if constexpr (OP == MAP_SCALE_ROWMAX) mult = A.a0 / A.rowmax[A.independent ? r : r / (unsigned)m.channels];  // peak / max  :3444
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
+        double x = (double)row[i];
+        if constexpr (OP == MAP_AMPLIFY) row[i] = (T)lua_clamp(x * A.a0, -1, 1);                       // :3365
+        else if constexpr (OP == MAP_INVERT) row[i] = (T)(-x);                                           // :3421
+        else if constexpr (OP == MAP_SCALE_ROWMAX) row[i] = (T)lua_clamp(x * mult, -1, 1);              // :3455
+        else if constexpr (OP == MAP_FADE) {  // Lua index li = i + 1 in [start, limit]  :3406-3408
+            double li = (double)(i + 1);
+            if (li >= A.a0 && li <= A.a1) row[i] = (T)lua_clamp(x * (A.a2 * (li - A.a0) + A.a3), -1, 1);
+        } else if constexpr (OP == MAP_DELAY) {  // o[i] = clamp(o[i] + original[i - samples] * multiplier)  :3514
+            if (i >= A.lag) row[i] = (T)lua_clamp(x + (double)reinterpret_cast<const T *>(A.aux)[base + i - A.lag] * A.a0, -1, 1);
+        }
+    }
+}
+
+// max |x| per row → atomicMax on the (non-negative) bit pattern; NaNs are skipped like math.max does
+template <typename T>
+__global__ __launch_bounds__(256) void k_rowmax(const T *data, RowMeta m, unsigned long long *out, int independent) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    const T *row = data + base;
+    double mx = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
+        double v = fabs((double)row[i]);
+        mx = mx < v ? v : mx;
+    }
+    for (int o = 32; o; o >>= 1) { double t = __shfl_xor(mx, o); mx = mx < t ? t : mx; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out + (independent ? r : r / (unsigned)m.channels), (unsigned long long)__double_as_longlong(mx));
+}
+
+// Audio:mono  :682-687  (s = 0 + c1 + c2 ...; s / cn)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mono(const T *in, RowMeta mi, T *out, RowMeta mo) {
+    const unsigned s = blockIdx.y;
+    const unsigned long long len = mi.len[s], ib = mi.off[s], st = mi.stride[s], ob = mo.off[s];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
+        double acc = 0;
+        for (int c = 0; c < mi.channels; c++) acc = acc + (double)in[ib + (unsigned long long)c * st + i];
+        out[ob + i] = (T)(acc / mi.channels);
+    }
+}
+
+// Audio:mix  :823-833
+struct MixSrc { const void *data[8]; RowMeta m[8]; int count; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_mix(MixSrc S, T *out, RowMeta mo, double amplifier) {
+    const unsigned r = blockIdx.y;
+    const unsigned s = r / (unsigned)mo.channels, c = r - s * (unsigned)mo.channels;
+    const unsigned long long len = mo.len[s], ob = mo.off[s] + (unsigned long long)c * mo.stride[s];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
+        double acc = 0;
+        for (int a = 0; a < S.count; a++)
+            if ((int)c < S.m[a].channels) {
+                const RowMeta &m = S.m[a];
+                acc = acc + (i < m.len[s] ? (double)reinterpret_cast<const T *>(S.data[a])[m.off[s] + (unsigned long long)c * m.stride[s] + i] : 0.0);
+            }
+        out[ob + i] = (T)lua_clamp(acc * amplifier, -1, 1);
+    }
+}
+
+// encodePCM  :874-892 : d * (d < 0 and maxValue or maxValue-1) + add, laid out interleaved or channel-after-channel
+template <typename T>
+__global__ __launch_bounds__(256) void k_encode_pcm(const T *in, RowMeta mi, double *out, RowMeta mo, double maxValue, double add, int is_float, int interleaved) {
+    const unsigned s = blockIdx.y;
+    const unsigned long long len = mi.len[s], ib = mi.off[s], st = mi.stride[s], ob = mo.off[s];
+    const int nc = mi.channels;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < len * nc; k += (unsigned long long)gridDim.x * 256) {
+        unsigned long long i, c;
+        if (interleaved) { i = k / nc; c = k - i * nc; } else { c = k / len; i = k - c * len; }
+        double d = (double)in[ib + c * st + i];
+        out[ob + k] = is_float ? d : d * (d < 0 ? maxValue : maxValue - 1) + add;
+    }
+}
+
+// effects.center  :3468-3474 : per 1 s window, subtract the mean
+template <typename T>
+__global__ __launch_bounds__(256) void k_center(T *data, RowMeta m, unsigned long long win) {
+    __shared__ double red[4];
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    T *row = data + base;
+    const unsigned long long nwin = (len + win - 1) / win;
+    for (unsigned long long w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const unsigned long long i0 = w * win, l = (len - i0) < win ? (len - i0) : win;
+        double acc = 0;
+        for (unsigned long long j = threadIdx.x; j < l; j += 256) acc += (double)row[i0 + j];
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        const double avg = (red[0] + red[1] + red[2] + red[3]) / (double)l;
+        for (unsigned long long j = threadIdx.x; j < l; j += 256) row[i0 + j] = (T)lua_clamp((double)row[i0 + j] - avg, -1, 1);
+    }
+}
+
+// ---------------------------------------------------------------- first-order recurrences (lowpass / highpass)
+// y_out = A * y_in + B composites; compose(f then g) = (gA * fA, gA * fB + gB)
+struct Aff { double A, B; };
+AUKIT_DEV Aff aff_then(const Aff &f, const Aff &g) { return Aff{g.A * f.A, __builtin_fma(g.A, f.B, g.B)}; }
+
+template <typename T, bool HIGHPASS>
+__global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a) {
+    constexpr int PER = 8, TILE = 256 * PER;
+    __shared__ Aff wave_tot[4];
+    __shared__ double carry_y, carry_x;
+    const unsigned r = blockIdx.x;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    if (len < 2) return;
+    T *row = data + base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry_y = (double)row[0]; carry_x = (double)row[0]; }  // y[1] = x[1]
+    __syncthreads();
+    // elements 1 .. len-1 (0-based) are produced by the recurrence
+    for (unsigned long long t0 = 1; t0 < len; t0 += TILE) {
+        const unsigned long long i0 = t0 + (unsigned long long)threadIdx.x * PER;
+        double x[PER], xprev = 0;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { x[k] = 0; if (i0 + k < len) { x[k] = (double)row[i0 + k]; cnt = k + 1; } }
+        if (HIGHPASS && cnt) xprev = (double)row[i0 - 1];  // ORIGINAL x[i-1]: read before anyone overwrites it
+        __syncthreads();
+        if (HIGHPASS && threadIdx.x == 0) xprev = carry_x;  // the tile's first predecessor was overwritten by the previous tile
+        // local composite of this thread's samples
+        Aff f{1.0, 0.0};
+        double xp = xprev;
+        for (int k = 0; k < cnt; k++) {
+            Aff g = HIGHPASS ? Aff{a, a * (x[k] - xp)} : Aff{1.0 - a, a * x[k]};
+            f = aff_then(f, g);
+            xp = x[k];
+        }
+        // inclusive scan across the wave
+        Aff inc = f;
+        for (int o = 1; o < 64; o <<= 1) {
+            Aff p{__shfl_up(inc.A, o), __shfl_up(inc.B, o)};
+            if (lane >= o) inc = aff_then(p, inc);
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        Aff pre{1.0, 0.0};  // composite of everything before this thread within the tile
+        for (int w = 0; w < wave; w++) pre = aff_then(pre, wave_tot[w]);
+        Aff exc{__shfl_up(inc.A, 1), __shfl_up(inc.B, 1)};
+        if (lane > 0) pre = aff_then(pre, exc);
+        const double cy = carry_y;
+        double y = __builtin_fma(pre.A, cy, pre.B);  // value entering this thread's first sample
+        xp = xprev;
+        double lastx = 0;
+        for (int k = 0; k < cnt; k++) {
+            if (HIGHPASS) y = a * (y + x[k] - xp);      // d[i] = a * (d[i-1] + llx - lx)  :3613
+            else y = y + a * (x[k] - y);                // d[i] = l + a * (d[i] - l)      :3594
+            xp = x[k];
+            lastx = x[k];
+            row[i0 + k] = (T)y;
+        }
+        __syncthreads();
+        const unsigned long long tile_last = (t0 + TILE <= len ? t0 + TILE : len) - 1;
+        if (cnt && i0 + cnt - 1 == tile_last) { carry_y = y; carry_x = lastx; }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- lag recurrences
+// effects.echo :3531  o[i] = clamp(o[i] + o[i - L] * mult)  — chain r: i = r + k*L
+template <typename T>
+__global__ __launch_bounds__(256) void k_echo(T *data, RowMeta m, unsigned long long L, double mult) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    T *row = data + base;
+    for (unsigned long long c = (unsigned long long)blockIdx.x * 256 + threadIdx.x; c < L && c < len; c += (unsigned long long)gridDim.x * 256) {
+        double prev = (double)row[c];
+        for (unsigned long long i = c + L; i < len; i += L) {
+            prev = lua_clamp((double)row[i] + prev * mult, -1, 1);
+            row[i] = (T)prev;
+        }
+    }
+}
+// one reverb comb :3560-3568, accumulated into sum in comb order
+template <typename T>
+__global__ __launch_bounds__(256) void k_comb(const T *data, RowMeta m, double *sum, unsigned long long L, double mult, int first) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    const T *row = data + base;
+    double *srow = sum + base;
+    for (unsigned long long c = (unsigned long long)blockIdx.x * 256 + threadIdx.x; c < L && c < len; c += (unsigned long long)gridDim.x * 256) {
+        double comb = (double)row[c];
+        srow[c] = (first ? 0.0 : srow[c]) + comb;
+        for (unsigned long long i = c + L; i < len; i += L) {
+            comb = (double)row[i] + comb * mult;
+            srow[i] = (first ? 0.0 : srow[i]) + comb;
+        }
+    }
+}
+// wet/dry mix :3571
+template <typename T>
+__global__ __launch_bounds__(256) void k_wetdry(const T *data, RowMeta m, double *sum, double wet, double dry) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256)
+        sum[base + i] = sum[base + i] * wet + (double)data[base + i] * dry;
+}
+// in-place all-pass :3574-3575: sum[i] = sum[i] - 0.131*sum[i-S] + 0.131*sum[i+20-S], i >= S+2 (1-based).
+// Element i depends on i-S and i-S+20, both at least S-20 behind: blocks of S-20 elements are internally independent.
+__global__ __launch_bounds__(1024) void k_allpass(double *sum, RowMeta m, long long S) {
+    const unsigned r = blockIdx.x;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    double *s = sum + base;  // s[i-1] = sum[i]
+    const long long n = (long long)len, W = S - 20;
+    if (threadIdx.x == 0) s[S] = s[S] - 0.131 * s[0];  // sum[S+1] -= 0.131 * sum[1]
+    __threadfence();
+    __syncthreads();
+    for (long long b0 = S + 2; b0 <= n; b0 += W) {
+        const long long b1 = (b0 + W - 1 < n) ? b0 + W - 1 : n;
+        for (long long i = b0 + threadIdx.x; i <= b1; i += blockDim.x) s[i - 1] = s[i - 1] - 0.131 * s[i - S - 1] + 0.131 * s[i + 20 - S - 1];
+        __threadfence();
+        __syncthreads();
+    }
+}
+// :3576-3577
+template <typename T>
+__global__ __launch_bounds__(256) void k_allpass_out(T *data, RowMeta m, const double *sum, long long S) {
+    const unsigned r = blockIdx.y;
+    unsigned long long base, len;
+    row_of(m, r, &base, &len);
+    const double *s = sum + base;
+    for (long long i = S + 1 + (long long)blockIdx.x * 256 + threadIdx.x; i <= (long long)len; i += (long long)gridDim.x * 256) {
+        double v = (i == S + 1) ? s[S] - 0.131 * s[0] : s[i - 1] - 0.131 * s[i - S - 1] + 0.131 * s[i + 20 - S - 1];
+        data[base + i - 1] = (T)lua_clamp(v, -1, 1);
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static unsigned xblocks(const aukit_audio *a, unsigned per_thread = 4) {
+    uint64_t mx = 1;
+    for (uint64_t l : a->len) mx = std::max(mx, l);
+    uint64_t b = (mx + 256ull * per_thread - 1) / (256ull * per_thread);
+    return (unsigned)std::min<uint64_t>(std::max<uint64_t>(b, 1), 1024);
+}
+static uint64_t audio_bytes(const aukit_audio *a) {
+    uint64_t e = 0;
+    for (uint64_t l : a->len) e += l * (uint64_t)a->channels;
+    return e * dtype_size(a->dtype);
+}
+#define AUKIT_FLOAT_ONLY(a)                                                                              \
+    if ((a)->dtype != AUKIT_F64 && (a)->dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "this operation needs an AUKIT_F64 / AUKIT_F32 audio")
+#define AUKIT_DISPATCH_T(a, CALL)                        \
+    do {                                                 \
+        if ((a)->dtype == AUKIT_F64) { using T = double; CALL; } \
+        else { using T = float; CALL; }                  \
+    } while (0)
+
+template <int OP>
+static int run_map(aukit_ctx *ctx, aukit_audio *a, const MapArgs &A, const char *name) {
+    if (a->n == 0) return AUKIT_OK;
+    dim3 grid(xblocks(a), a->n * a->channels);
+    int rc = ctx_begin_kernel(ctx);
+    if (rc) return rc;
+    AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_map<T, OP>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), A));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, name, 2 * audio_bytes(a));
+}
+
+static int fx_normalize(aukit_ctx *ctx, aukit_audio *a, double peak, int independent) {
+    if (a->n == 0) return AUKIT_OK;
+    size_t cnt = (size_t)a->n * (independent ? a->channels : 1);
+    int rc = ctx->tmp_buf.ensure(cnt * 8);
+    if (rc) return rc;
+    AUKIT_HIP_CHECK(hipMemsetAsync(ctx->tmp_buf.p, 0, cnt * 8, ctx->stream));
+    dim3 grid(xblocks(a), a->n * a->channels);
+    AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_rowmax<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(a->dev), meta_of(a),
+                                           reinterpret_cast<unsigned long long *>(ctx->tmp_buf.p), independent));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    MapArgs A{};
+    A.a0 = peak;
+    A.rowmax = reinterpret_cast<const double *>(ctx->tmp_buf.p);
+    A.independent = independent;
+    return run_map<MAP_SCALE_ROWMAX>(ctx, a, A, "k_map<normalize>");
+}
+
+static int fx_onepole(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass) {
+    if (a->n == 0) return AUKIT_OK;
+    int rc = ctx_begin_kernel(ctx);
+    if (rc) return rc;
+    dim3 grid(a->n * a->channels);
+    if (highpass) AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef));
+    else AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, false>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, highpass ? "k_onepole<highpass>" : "k_onepole<lowpass>", 2 * audio_bytes(a));
+}
+
+static int fx_reverb(aukit_ctx *ctx, aukit_audio *a, double delay, double decay, double wet, double dry) {
+    static const double dshift[4] = {0, -11.73, 19.31, -7.97}, cshift[4] = {0, 0.1313, 0.2743, 0.31};  // :3536-3537
+    if (a->n == 0) return AUKIT_OK;
+    const long long S = (long long)std::floor(0.08927 * a->rate);  // :3573
+    long long lag[4];
+    for (int k = 0; k < 4; k++) {
+        double sf = std::floor((delay + dshift[k]) / 1000 * a->rate);
+        if (sf < 1) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        lag[k] = (long long)sf;
+    }
+    for (uint64_t l : a->len)
+        if ((long long)l < S + 1 || S < 20) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+    int rc = ctx->tmp_buf.ensure((size_t)a->total * 8);
+    if (rc) return rc;
+    double *sum = reinterpret_cast<double *>(ctx->tmp_buf.p);
+    dim3 grid(xblocks(a), a->n * a->channels);
+    for (int k = 0; k < 4; k++) {
+        AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_comb<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(a->dev), meta_of(a), sum,
+                                               (unsigned long long)lag[k], decay - cshift[k], k == 0 ? 1 : 0));
+        AUKIT_HIP_CHECK(hipGetLastError());
+    }
+    AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_wetdry<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(a->dev), meta_of(a), sum, wet, dry));
+    hipLaunchKernelGGL(k_allpass, dim3(a->n * a->channels), dim3(1024), 0, ctx->stream, sum, meta_of(a), S);
+    AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_allpass_out<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), sum, S));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    ctx->last_kernel = "reverb(k_comb x4, k_wetdry, k_allpass, k_allpass_out)";
+    return AUKIT_OK;
+}
+
+}  // namespace aukit
+
+using namespace aukit;
+
+extern "C" {
+
+int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
+    if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_FLOAT_ONLY(in);
+    if (*out == in) return fail(AUKIT_E_ARG, "mono cannot run in place");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    aukit_audio *o = *out;
+    int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, in->dtype, in->len.data());
+    if (rc) return rc;
+    *out = o;
+    if (in->n == 0) return AUKIT_OK;
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
+    dim3 grid(xblocks(in), in->n);
+    AUKIT_DISPATCH_T(in, hipLaunchKernelGGL((k_mono<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(in->dev), meta_of(in),
+                                            reinterpret_cast<T *>(o->dev), meta_of(o)));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, "k_mono", audio_bytes(in) + audio_bytes(o));
+}
+
+int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, double amplifier, aukit_audio **out) {
+    if (!ctx || !audios || !out || count < 1 || !audios[0]) return fail(AUKIT_E_ARG, "null argument");
+    if (count > 8) return fail(AUKIT_E_UNSUPPORTED, "at most 8 audios per mix call");
+    const aukit_audio *self = audios[0];
+    AUKIT_FLOAT_ONLY(self);
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    int cn = self->channels;
+    std::vector<uint64_t> lens(self->len);
+    for (int a = 1; a < count; a++) {
+        if (!audios[a] || audios[a]->n != self->n) return fail(AUKIT_E_ARG, "all audios of a mix must hold the same number of streams");
+        if (audios[a]->dtype != self->dtype) return fail(AUKIT_E_ARG, "all audios of a mix must share a dtype");
+        if (audios[a]->rate != self->rate) return fail(AUKIT_E_ARG, "mix: resample to a common sample rate first (Audio:mix does this with the default interpolation)");
+        cn = std::max(cn, audios[a]->channels);
+        for (uint32_t s = 0; s < self->n; s++) lens[s] = std::max(lens[s], audios[a]->len[s]);
+    }
+    for (int a = 0; a < count; a++)
+        if (*out == audios[a]) return fail(AUKIT_E_ARG, "mix cannot run in place");
+    aukit_audio *o = *out;
+    int rc = audio_prepare(ctx, &o, self->n, cn, self->rate, self->dtype, lens.data());
+    if (rc) return rc;
+    *out = o;
+    if (self->n == 0) return AUKIT_OK;
+    MixSrc S;
+    S.count = count;
+    uint64_t bytes = audio_bytes(o);
+    for (int a = 0; a < count; a++) { S.data[a] = audios[a]->dev; S.m[a] = meta_of(audios[a]); bytes += audio_bytes(audios[a]); }
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
+    dim3 grid(xblocks(o), o->n * o->channels);
+    AUKIT_DISPATCH_T(o, hipLaunchKernelGGL((k_mix<T>), grid, dim3(256), 0, ctx->stream, S, reinterpret_cast<T *>(o->dev), meta_of(o), amplifier));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, "k_mix", bytes);
+}
+
+int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out) {
+    if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_FLOAT_ONLY(in);
+    if (bit_depth != 8 && bit_depth != 16 && bit_depth != 24 && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
+    if (data_type < 0 || data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
+    if (data_type == AUKIT_FLOAT && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> lens(in->n);
+    for (uint32_t s = 0; s < in->n; s++) lens[s] = in->len[s] * (uint64_t)in->channels;
+    aukit_audio *o = *out;
+    int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, AUKIT_F64, lens.data());
+    if (rc) return rc;
+    *out = o;
+    if (in->n == 0) return AUKIT_OK;
+    const double maxValue = std::ldexp(1.0, bit_depth - 1);
+    dim3 grid(xblocks(o), in->n);
+    AUKIT_DISPATCH_T(in, hipLaunchKernelGGL((k_encode_pcm<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(in->dev), meta_of(in),
+                                            reinterpret_cast<double *>(o->dev), meta_of(o), maxValue, data_type == AUKIT_UNSIGNED ? maxValue : 0.0,
+                                            data_type == AUKIT_FLOAT ? 1 : 0, interleaved));
+    AUKIT_HIP_CHECK(hipGetLastError());
+    ctx->last_kernel = "k_encode_pcm";
+    return AUKIT_OK;
+}
+
+int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int nargs) {
+    if (!ctx || !a) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_FLOAT_ONLY(a);
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    auto arg = [&](int i, double def) { return (args && i < nargs) ? args[i] : def; };
+    auto need = [&](int k) { return nargs >= k && args; };
+    MapArgs A{};
+    switch (id) {
+    case AUKIT_FX_AMPLIFY:
+        if (!need(1)) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");
+        if (args[0] == 1) return AUKIT_OK;  // :3359
+        A.a0 = args[0];
+        return run_map<MAP_AMPLIFY>(ctx, a, A, "k_map<amplify>");
+    case AUKIT_FX_INVERT:
+        return run_map<MAP_INVERT>(ctx, a, A, "k_map<invert>");
+    case AUKIT_FX_FADE: {
+        if (!need(4)) return fail(AUKIT_E_ARG, "bad argument #5 (expected number, got nil)");
+        const double startTime = args[0], startAmp = args[1], endTime = args[2], endAmp = args[3];
+        if (startAmp == 1 && endAmp == 1) return AUKIT_OK;  // :3400
+        const double start = startTime * a->rate, limit = endTime * a->rate;
+        if (start <= limit) {  // the loop runs at least once: ch[i] must exist for every visited i (Q17)
+            if (start != std::floor(start) || start < 1) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+            const double last = start + std::floor(limit - start);
+            for (uint64_t l : a->len)
+                if (last > (double)l) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        }
+        A.a0 = start;
+        A.a1 = limit;
+        A.a2 = (endAmp - startAmp) / ((endTime - startTime) * a->rate);  // :3405
+        A.a3 = startAmp;
+        return run_map<MAP_FADE>(ctx, a, A, "k_map<fade>");
+    }
+    case AUKIT_FX_NORMALIZE:
+        return fx_normalize(ctx, a, arg(0, 1.0), arg(1, 0.0) != 0);
+    case AUKIT_FX_CENTER: {
+        if (a->rate != std::floor(a->rate) || a->rate < 1) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        if (a->n == 0) return AUKIT_OK;
+        uint64_t mx = 1;
+        for (uint64_t l : a->len) mx = std::max(mx, l);
+        unsigned nw = (unsigned)std::min<uint64_t>((mx + (uint64_t)a->rate - 1) / (uint64_t)a->rate, 4096);
+        dim3 grid(std::max(nw, 1u), a->n * a->channels);
+        AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_center<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), (unsigned long long)a->rate));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        ctx->last_kernel = "k_center";
+        return AUKIT_OK;
+    }
+    case AUKIT_FX_TRIM:
+        return fail(AUKIT_E_LUA, "bad argument #1 to 'sub' (string expected, got table)");  // :3495 (Q17)
+    case AUKIT_FX_DELAY: {
+        if (!need(1)) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");
+        const double sd = std::floor(args[0] * a->rate);
+        if (sd < 0) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        int rc = ctx->tmp_buf.ensure((size_t)a->total * dtype_size(a->dtype) + 64);
+        if (rc) return rc;
+        if (a->total) AUKIT_HIP_CHECK(hipMemcpyAsync(ctx->tmp_buf.p, a->dev, (size_t)a->total * dtype_size(a->dtype), hipMemcpyDeviceToDevice, ctx->stream));
+        A.a0 = arg(1, 0.5);
+        A.aux = ctx->tmp_buf.p;
+        A.lag = sd > 1.8e19 ? ~0ull : (unsigned long long)sd;
+        return run_map<MAP_DELAY>(ctx, a, A, "k_map<delay>");
+    }
+    case AUKIT_FX_ECHO: {
+        const double sd = std::floor(arg(0, 1.0) * a->rate);
+        if (sd < 0) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        if (a->n == 0) return AUKIT_OK;
+        if (sd == 0) return fail(AUKIT_E_UNSUPPORTED, "echo with a zero-sample delay");
+        const unsigned long long L = sd > 1.8e19 ? ~0ull : (unsigned long long)sd;
+        dim3 grid((unsigned)std::min<unsigned long long>((L + 255) / 256, 1024), a->n * a->channels);
+        AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_echo<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), L, arg(1, 0.5)));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        ctx->last_kernel = "k_echo";
+        return AUKIT_OK;
+    }
+    case AUKIT_FX_REVERB:
+        return fx_reverb(ctx, a, arg(0, 100.0), arg(1, 0.3), arg(2, 1.0), arg(3, 0.0));
+    case AUKIT_FX_LOWPASS:
+        if (!need(1)) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");
+        return fx_onepole(ctx, a, 1 - std::exp(-(args[0] / a->rate) * 2 * M_PI), false);  // :3589
+    case AUKIT_FX_HIGHPASS:
+        if (!need(1)) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");
+        return fx_onepole(ctx, a, 1 / (2 * M_PI * (args[0] / a->rate) + 1), true);          // :3607
+    case AUKIT_FX_SPEED: {
+        if (!need(1)) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");
+        if (args[0] == 1) return AUKIT_OK;  // :3379
+        const double rate = a->rate;
+        aukit_audio *tmp = nullptr;
+        a->rate = rate * args[0];  // :3381
+        int rc = aukit_resample(ctx, a, rate, (int)arg(1, AUKIT_INTERP_LINEAR), &tmp);
+        a->rate = rate;
+        if (rc) { if (tmp) aukit_audio_free(tmp); return rc; }
+        // audio.data = new.data: adopt the resampled buffers
+        std::swap(a->dev, tmp->dev); std::swap(a->cap_bytes, tmp->cap_bytes); std::swap(a->d_meta, tmp->d_meta); std::swap(a->meta_cap, tmp->meta_cap);
+        a->len = tmp->len; a->row_off = tmp->row_off; a->row_stride = tmp->row_stride; a->total = tmp->total;
+        a->version++;
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        aukit_audio_free(tmp);
+        return AUKIT_OK;
+    }
+    }
+    return fail(AUKIT_E_ARG, "unknown effect id %d", id);
+}
+
+}  // extern "C"

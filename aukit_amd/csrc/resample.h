@@ -28,7 +28,8 @@ enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G7
 enum EpiKind {
     EPI_AUDIO = 0,       // Audio:resample  :666-668  (integer x copies unclamped, else clamp ±1)
     EPI_STREAM_PCM = 1,  // stream.pcm      :2397-2403 (no clamp of interp, 2-tap FIR, ×127/128, clamp ±128/127)
-    EPI_STREAM_FLOOR = 2 // stream.g711/adpcm/msadpcm :2900-2910 (optional mono mean, floor, clamp)
+    EPI_STREAM_FLOOR = 2,// stream.g711/adpcm/msadpcm :2900-2910 (optional mono mean, floor, clamp)
+    EPI_STREAM_DFPWM = 3 // stream.dfpwm :2478-2489 (interp clamped to ±128/127, same sample to every channel)
 };
 
 struct ResampleParams {
@@ -59,7 +60,9 @@ struct ResampleParams {
     // epilogue
     void *out;
     double lp_alpha;
-    int mix_mono;      // EPI_STREAM_FLOOR: mean over channels after interpolation (:2905-2908)
+    int mix_mono;      // EPI_STREAM_FLOOR: 1 = mean over channels after interpolation (:2905-2908), 2 = l + r/2 (:2672)
+    int pos_mul;       // x = ((i-1) * pos_mul) / ratio + 1 (stream.dfpwm steps i by `channels`); 0 means 1
+    int out_channels;  // EPI_STREAM_DFPWM: rows written per output
 };
 
 // launches the right instantiation; `name` receives a static string naming the kernel

@@ -7,18 +7,9 @@
 // LDS bank row (conflict-free ds_read_b64); (3) the epilogue result is stored coalesced.
 // The path is HBM-bound by design (no MFMA): algorithmic bytes are input bytes + output bytes.
 #include "resample.h"
+#include "resample_dev.h"
 
 namespace aukit {
-
-template <int INTERP> struct HaloOf { static constexpr int L = 0, R = 0; };
-template <> struct HaloOf<AUKIT_INTERP_LINEAR> { static constexpr int L = 0, R = 1; };
-template <> struct HaloOf<AUKIT_INTERP_CUBIC> { static constexpr int L = 1, R = 2; };
-
-AUKIT_DEV double pos_of(const ResampleParams &P, unsigned o) {
-    double n = (double)o;  // (i - 1)
-    double q = P.exact_rcp ? div_rcp(n, P.ratio, P.rcp) : n / P.ratio;
-    return q + 1.0;
-}
 
 // ------------------------------------------------------------------ sample decoding
 AUKIT_DEV double pcm_raw(const unsigned char *p, int bd, int dt, int be) {
@@ -147,62 +138,26 @@ AUKIT_DEV int stage(const ResampleParams &P, const Seg &sg, int k_lo, int n_stag
             sm[c * P.cap + rel] = g711_value(base[(size_t)g * C + c], P.ulaw) * P.g711_scale;
         }
         return 0;
-    } else if constexpr (SRC == SRC_AUDIO_F64) {
-        const double *row = reinterpret_cast<const double *>(P.src) + P.src_off[sg.stream];
-        for (int rel = tid; rel < n_stage; rel += 256) sm[rel] = row[g0 + rel];
-        return 0;
-    } else if constexpr (SRC == SRC_AUDIO_F32) {
-        const float *row = reinterpret_cast<const float *>(P.src) + P.src_off[sg.stream];
-        for (int rel = tid; rel < n_stage; rel += 256) sm[rel] = (double)row[g0 + rel];
-        return 0;
-    } else if constexpr (SRC == SRC_I16) {
-        const short *row = reinterpret_cast<const short *>(P.src) + P.src_off[sg.stream];
-        for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; sm[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
-        return 0;
-    } else {  // SRC_I8
-        const signed char *row = reinterpret_cast<const signed char *>(P.src) + P.src_off[sg.stream];
-        for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; sm[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
-        return 0;
-    }
-}
-
-// ------------------------------------------------------------------ one interpolated sample
-// `tab` points at the LDS slot of table index k_lo for this channel.  Returns
-// `if x % 1 == 0 then d[x] else interp(d, x)`; *isint tells the caller which branch was taken.
-template <int INTERP>
-AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const double *tab, int k_lo, unsigned o, bool *isint) {
-    double x = pos_of(P, o);
-    double ffx = floor(x);
-    int k = (int)ffx;
-    k = k < sg.w_lo ? sg.w_lo : (k > sg.w_hi ? sg.w_hi : k);  // host guarantees w_lo <= k <= w_hi; keeps LDS reads in range
-    int idx = k - k_lo;
-    *isint = (x == ffx);  // x % 1 == 0
-    double p1 = tab[idx];
-    if (*isint) return p1;
-    double fx = x - ffx;
-    if constexpr (INTERP == AUKIT_INTERP_NONE) {
-        return p1;  // data[math.floor(x)]  :254-256
-    } else if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-        int i1 = (k + 1 <= sg.w_hi) ? idx + 1 : idx;  // data[ffx+1] or data[ffx]
-        return linear_exact(p1, tab[i1], fx);
-    } else if constexpr (INTERP == AUKIT_INTERP_CUBIC) {
-        int i0 = (k - 1 >= sg.w_lo) ? idx - 1 : idx;      // p0 or p1
-        int i2 = (k + 1 <= sg.w_hi) ? idx + 1 : idx;      // p2 or p1
-        int i3 = (k + 2 <= sg.w_hi) ? idx + 2 : i2;       // p3 or p2 or p1
-        return cubic_exact(tab[i0], p1, tab[i2], tab[i3], fx);
-    } else {  // sinc  :267-281 (sin() is libm-dependent: tolerance-level parity only)
-        double sum = 0;
-        const double pi = 3.14159265358979323846;
-        for (int n = -P.sinc_w; n <= P.sinc_w; n++) {
-            int w = k + n;
-            if (w >= sg.w_lo && w <= sg.w_hi) {
-                double d = tab[idx + n];
-                double px = pi * (fx - n);
-                if (px == 0) sum = sum + d;
-                else sum = sum + d * sin(px) / px;
+    } else {  // planar rows: SRC_AUDIO_F64 / SRC_AUDIO_F32 / SRC_I16 / SRC_I8; channel c of a segment is row sg.stream * SC + c
+        const int SC = P.stage_channels;
+        for (int c = 0; c < SC; c++) {
+            const unsigned long long ro = P.src_off[(size_t)sg.stream * SC + c];
+            double *dst = sm + c * P.cap;
+            if constexpr (SRC == SRC_AUDIO_F64) {
+                const double *row = reinterpret_cast<const double *>(P.src) + ro;
+                for (int rel = tid; rel < n_stage; rel += 256) dst[rel] = row[g0 + rel];
+            } else if constexpr (SRC == SRC_AUDIO_F32) {
+                const float *row = reinterpret_cast<const float *>(P.src) + ro;
+                for (int rel = tid; rel < n_stage; rel += 256) dst[rel] = (double)row[g0 + rel];
+            } else if constexpr (SRC == SRC_I16) {
+                const short *row = reinterpret_cast<const short *>(P.src) + ro;
+                for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; dst[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
+            } else {
+                const signed char *row = reinterpret_cast<const signed char *>(P.src) + ro;
+                for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; dst[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
             }
         }
-        return sum;
+        return 0;
     }
 }
 
@@ -247,7 +202,10 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleParams P) {
                 if (j >= cnt) break;
                 const unsigned o = o0 + j;
                 bool isint;
-                if (P.mix_mono) {
+                if (P.mix_mono == 2) {  // stream.msadpcm stereo→mono: floor(l + r / 2)  :2672 (Q9)
+                    const double l = eval_at<INTERP>(P, sg, sm + shift, k_lo, o, &isint), r2 = eval_at<INTERP>(P, sg, sm + P.cap + shift, k_lo, o, &isint);
+                    store_val<OUT_T>(out + sg.out_off + o, lua_clamp(floor(l + r2 / 2), -128, 127));
+                } else if (P.mix_mono) {
                     double acc = 0;
                     for (int c = 0; c < SC; c++) acc = acc + eval_at<INTERP>(P, sg, sm + c * P.cap + shift, k_lo, o, &isint);
                     store_val<OUT_T>(out + sg.out_off + o, lua_clamp(floor(acc / SC), -128, 127));  // :2908
@@ -277,6 +235,16 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleParams P) {
                     double s = eval_at<INTERP>(P, sg, tab, k_lo, o, &isint);
                     if constexpr (EPI == EPI_AUDIO) {
                         if (active) store_val<OUT_T>(orow + o, isint ? s : lua_clamp(s, -1, 1));  // :667-668
+                    } else if constexpr (EPI == EPI_STREAM_DFPWM) {  // stream.dfpwm :2481-2488: every channel gets the same sample (Q11)
+                        if (active) {
+                            const double v = isint ? s : lua_clamp(s, -128, 127);
+                            if (P.mix_mono) {
+                                double acc = 0;
+                                for (int cc = 0; cc < P.out_channels; cc++) acc = acc + v;
+                                store_val<OUT_T>(orow + o, acc / P.out_channels);
+                            } else
+                                for (int cc = 0; cc < P.out_channels; cc++) store_val<OUT_T>(orow + (size_t)cc * sg.out_stride + o, v);
+                        }
                     } else {
                         double prev = __shfl_up(s, 1);
                         if (lane == 0) prev = carry;
@@ -319,8 +287,13 @@ static int launch_src(aukit_ctx *ctx, int interp, int epi, int out_dtype, const 
             if (out_dtype == AUKIT_F64) return launch_interp<SRC, EPI_STREAM_PCM, double>(ctx, interp, P, lds, grid);
             if (out_dtype == AUKIT_F32) return launch_interp<SRC, EPI_STREAM_PCM, float>(ctx, interp, P, lds, grid);
         }
+    } else if (epi == EPI_STREAM_DFPWM) {
+        if constexpr (SRC == SRC_I8) {
+            if (out_dtype == AUKIT_F64) return launch_interp<SRC, EPI_STREAM_DFPWM, double>(ctx, interp, P, lds, grid);
+            if (out_dtype == AUKIT_F32) return launch_interp<SRC, EPI_STREAM_DFPWM, float>(ctx, interp, P, lds, grid);
+        }
     } else if (epi == EPI_STREAM_FLOOR) {
-        if constexpr (SRC == SRC_G711 || SRC == SRC_G711_MONO || SRC == SRC_I16) {
+        if constexpr (SRC == SRC_G711 || SRC == SRC_G711_MONO || SRC == SRC_AUDIO_F64) {
             if (out_dtype == AUKIT_I8) return launch_interp<SRC, EPI_STREAM_FLOOR, signed char>(ctx, interp, P, lds, grid);
             if (out_dtype == AUKIT_F64) return launch_interp<SRC, EPI_STREAM_FLOOR, double>(ctx, interp, P, lds, grid);
         }
@@ -331,7 +304,7 @@ static int launch_src(aukit_ctx *ctx, int interp, int epi, int out_dtype, const 
 static const char *kernel_name(int src, int interp, int epi) {
     static const char *srcn[] = {"pcm", "pcm_s16le_mono", "g711", "g711_mono", "audio_f64", "audio_f32", "i16", "i8"};
     static const char *intn[] = {"none", "linear", "cubic", "sinc"};
-    static const char *epin[] = {"audio", "stream_pcm", "stream_floor"};
+    static const char *epin[] = {"audio", "stream_pcm", "stream_floor", "stream_dfpwm"};
     static thread_local char buf[96];
     snprintf(buf, sizeof buf, "k_resample<%s,%s,%s>", srcn[src], intn[interp], epin[epi]);
     return buf;
@@ -374,7 +347,8 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
     P.stage_channels = stage_channels;
     // tile size: the staged window (tile_out / ratio + halo) must fit the LDS budget
     const int slack = hl + hr + 2 + 32;  // +32: alignment head of the vector-load paths, FIR look-back
-    auto cap_for = [&](int to) { return (int)std::ceil((double)to / ratio) + slack; };
+    const double eff_ratio = ratio / (double)(P.pos_mul > 1 ? P.pos_mul : 1);  // outputs advance pos_mul table steps at a time
+    auto cap_for = [&](int to) { return (int)std::ceil((double)to / eff_ratio) + slack; };
     int tile_out = 2048;
     const size_t budget = 24 * 1024, hard = 64 * 1024;
     while (tile_out > 256 && (size_t)cap_for(tile_out) * 8 * stage_channels > budget) tile_out -= 256;
@@ -385,7 +359,7 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
     *lds_bytes = (size_t)P.cap * 8 * stage_channels;
     uint64_t max_out = 0;
     for (const Seg &g : segs) max_out = std::max<uint64_t>(max_out, g.n_out);
-    P.exact_rcp = exact_div_verified(ctx, ratio, max_out + 1) ? 1 : 0;
+    P.exact_rcp = exact_div_verified(ctx, ratio, (max_out + 1) * (uint64_t)(P.pos_mul > 0 ? P.pos_mul : 1)) ? 1 : 0;
     return plan_tiles_sized(ctx, segs, tile_out, P);
 }
 

@@ -161,6 +161,9 @@ int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, doubl
 int aukit_effect(aukit_ctx *ctx, aukit_audio *inout, int effect_id, const double *args, int nargs);
 /* Audio:dfpwm(interleaved) :1005 → one byte string per stream */
 int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, aukit_batch **out);
+/* fused pipeline  aukit.dfpwm(data, channels, sr):mono():dfpwm()  (:1392, :677, :1005) — one lane per stream, the decoded
+ * samples never leave registers.  Same bytes as aukit_decode(DFPWM) → aukit_mono → aukit_dfpwm_encode with AUKIT_F64. */
+int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channels, aukit_batch **out);
 /* Audio:pcm(bitDepth, dataType, interleaved) :901 → unfloored numbers, packed per stream */
 int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out);
 

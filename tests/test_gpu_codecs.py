@@ -1,0 +1,258 @@
+"""GPU parity for the sequential codecs (DFPWM, IMA / MS ADPCM, QOA, MDFPWM) vs the CPU oracle, through the C ABI.
+
+Integer decode stages and floored stream outputs are compared bit-exactly; DFPWM re-encoded bytes bit-exactly.
+"""
+import numpy as np
+import pytest
+
+from tests.util import pcm16, rms, signal
+
+pytestmark = pytest.mark.gpu
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+def _dfpwm_bytes(oracle, n, cfg, stream):
+    return oracle.dfpwm_encode(np.round(signal(n, 48000, cfg, stream) * 100))
+
+
+# ---------------------------------------------------------------- DFPWM
+@pytest.mark.parametrize("ch", [1, 2])
+def test_dfpwm_decode(ctx, oracle, ch):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(3))
+    streams = [_dfpwm_bytes(oracle, 48000 * 2, 4, 0), _dfpwm_bytes(oracle, 6000 * 8, 4, 1), _dfpwm_bytes(oracle, 6001 * 8 * 2, 4, 2),
+               rng.integers(0, 256, 12002, dtype=np.uint8).tobytes(), b"\x55" * 2]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_DFPWM, ch, 48000)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.dfpwm(s, ch, 48000)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c])
+    res = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_DFPWM, ch, 32000), 48000, "cubic", dtype=N.F64).download()
+    ref = oracle.resample(oracle.dfpwm(streams[0], ch, 32000), 48000, oracle.CUBIC)
+    assert np.max(np.abs(res[0][0] - ref.data[0])) <= 1e-15
+
+
+def test_dfpwm_uneven_channels_is_an_error(ctx):
+    B, N = _B(), _N()
+    bt = B.Batch.upload(ctx, [b"\x55" * 7])  # 56 samples over 3 channels
+    with pytest.raises(N.AukitError) as e:
+        B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 3, 48000))
+    assert "uneven amount of data per channel" in str(e.value)
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_dfpwm_encode_bit_exact(ctx, oracle, interleaved):
+    B, N = _B(), _N()
+    a = [[signal(n, 48000, 4, 10 * i + c) * 0.9 for c in range(2)] for i, n in enumerate((48000, 1001, 8, 3))]
+    ab = B.AudioBatch.upload(ctx, a, 48000, dtype=N.F64)
+    got = B.dfpwm_encode(ctx, ab, interleaved).download()
+    for s in range(len(a)):
+        assert got[s] == oracle.audio_dfpwm(oracle.Audio(a[s], 48000), interleaved)
+
+
+def test_dfpwm_encode_out_of_range_raises(ctx):
+    B, N = _B(), _N()
+    ab = B.AudioBatch.upload(ctx, [[np.array([0.0, 0.5, 1.5, 0.0])]], 48000, dtype=N.F64)
+    with pytest.raises(N.AukitError):
+        B.dfpwm_encode(ctx, ab, True)
+
+
+def test_config4_pipeline_and_fused_transcode(ctx, oracle):
+    """BASELINE config 4: a = aukit.dfpwm(d, 2, 48000); m = a:mono(); out = m:dfpwm() — unfused and fused, bit-exact."""
+    B, N = _B(), _N()
+    streams = []
+    for i, n in enumerate((120000, 24000, 6000, 6002)):
+        l, r = np.round(signal(n * 4, 48000, 4, 2 * i) * 100), np.round(signal(n * 4, 48000, 4, 2 * i + 1) * 90)
+        streams.append(oracle.dfpwm_encode(np.stack([l, r], 1).ravel()))
+    bt = B.Batch.upload(ctx, streams)
+    au = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F64)
+    unfused = B.dfpwm_encode(ctx, B.mono(ctx, au), True).download()
+    fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    for s, u, f in zip(streams, unfused, fused):
+        ref = oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(s, 2, 48000)), True)
+        assert u == ref
+        assert f == ref
+    assert len(fused[0]) == 60010  # Q10: 120 000 B → 960 152 samples → 480 076 mono samples → 60 010 B
+
+
+@pytest.mark.parametrize("ch,mono,rate", [(1, False, 48000), (2, False, 48000), (2, True, 48000), (1, False, 24000), (2, True, 32000)])
+def test_stream_dfpwm(ctx, oracle, ch, mono, rate):
+    B, N = _B(), _N()
+    streams = [_dfpwm_bytes(oracle, 48000 * 2 + 16, 4, 3), _dfpwm_bytes(oracle, 6000 * 8 * ch, 4, 4), b"\xaa" * 13]
+    bt = B.Batch.upload(ctx, streams)
+    for interp in ("linear", "cubic"):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, ch, rate), interp, mono=mono, dtype=N.F64)
+        got = out.download()
+        for i, s in enumerate(streams):
+            ref = oracle.stream_dfpwm(s, rate, ch, mono, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks
+            assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            assert np.array_equal(ck.pos[i][:ref.nchunks], ref.chunk_pos)
+            for c in range(ref.channels):
+                assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-13, (i, c)
+
+
+def test_mdfpwm(ctx, oracle):
+    B, N = _B(), _N()
+    e1, e2 = _dfpwm_bytes(oracle, 48000 * 3, 4, 5), _dfpwm_bytes(oracle, 48000 * 3, 4, 6)
+    md = oracle.gen_mdfpwm(e1, e2, b"artist", b"title", b"album")
+    bt = B.Batch.upload(ctx, [md, md[:len(md) - 12000]])
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), dtype=N.F64).download()
+    ref = oracle.mdfpwm(md)
+    for c in range(2):
+        assert np.array_equal(got[0][c], ref.data[c])
+    for mono in (False, True):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), "linear", mono=mono, dtype=N.I8)
+        o = oracle.stream_mdfpwm(md, mono)
+        assert ck.nchunks[0] == o.nchunks and ck.status[0] == o.final_status
+        g = out.download()[0]
+        for c in range(o.channels):
+            assert np.array_equal(g[c], o.data[c])
+    with pytest.raises(N.AukitError) as e:
+        B.decode(ctx, B.Batch.upload(ctx, [b"RIFFxxxxWAVE"]), B.make_desc(N.CODEC_MDFPWM))
+    assert "not a MDFPWM file" in str(e.value)
+
+
+# ---------------------------------------------------------------- IMA ADPCM
+@pytest.mark.parametrize("ch,ba", [(1, 512), (2, 1024), (1, 36), (2, 2048), (1, 2052)])
+def test_ima_wav_audio_path(ctx, oracle, ch, ba):
+    B, N = _B(), _N()
+    spb = (ba - 4 * ch) * 2 // ch
+    streams = [oracle.gen_ima(np.stack([pcm16(spb * nb, 22050, 3, 4 * i + c) for c in range(ch)], 1).ravel(), ch, ba, 15) for i, nb in enumerate((20, 1, 3))]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_ADPCM_WAV, ch, 22050, block_align=ba)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.wav_adpcm(s, ba, ch, 22050)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c])
+    res = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F64)
+    B.effect(ctx, res, "lowpass", 11025.0)  # config 3b: aukit.wav → :resample(48000,"cubic") → effects.lowpass(a, 11025)
+    ref = oracle.fx_lowpass(oracle.resample(oracle.wav_adpcm(streams[0], ba, ch, 22050), 48000, oracle.CUBIC), 11025.0)
+    assert np.max(np.abs(res.download()[0][0] - ref.data[0])) <= 1e-12
+
+
+def test_ima_wav_mono_masks_header_index_and_partial_block(ctx, oracle):
+    B, N = _B(), _N()
+    s = oracle.gen_ima(pcm16(1016 * 6, 22050, 3, 9), 1, 512, 88)  # full-range header step indices: masked with 0x0F by aukit.wav (Q8)
+    s2 = s[:512 * 3 + 100]                                        # partial last block (mono: str_sub is just shorter)
+    bt = B.Batch.upload(ctx, [s, s2])
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), dtype=N.F64).download()
+    assert np.array_equal(got[0][0], oracle.wav_adpcm(s, 512, 1, 22050).data[0])
+    assert np.array_equal(got[1][0], oracle.wav_adpcm(s2, 512, 1, 22050).data[0])
+
+
+@pytest.mark.parametrize("ch,interleaved,top_first", [(1, True, True), (1, True, False), (2, True, True), (2, False, False), (3, True, True)])
+def test_ima_raw_adpcm(ctx, oracle, ch, interleaved, top_first):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(17 + ch))
+    streams = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (6000, 3, 1025)]
+    pred, idx = [100 * (c + 1) for c in range(ch)], [10 * c + 3 for c in range(ch)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_ADPCM, ch, 22050, interleaved=interleaved, top_first=top_first, predictor=pred, step_index=idx)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.adpcm(s, ch, 22050, top_first, interleaved, pred, idx)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c]), c
+
+
+@pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
+@pytest.mark.parametrize("ch,mono,ba", [(1, False, 512), (2, False, 1024), (2, True, 1024), (1, False, 260)])
+def test_stream_adpcm_bit_exact(ctx, oracle, interp, ch, mono, ba):
+    """BASELINE config 3a: stream.adpcm incl. the junk word after every non-final block and the dropped last word (Q6)."""
+    B, N = _B(), _N()
+    spb = (ba - 4 * ch) * 2 // ch
+    streams = [oracle.gen_ima(np.stack([pcm16(spb * nb, 22050, 3, 4 * i + c) for c in range(ch)], 1).ravel(), ch, ba, 88) for i, nb in enumerate((50, 1, 23, 22))]
+    streams.append(streams[0][: ba * 7 + 40])  # ragged tail: short final block
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, ch, 22050, block_align=ba), interp, mono=mono, dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_adpcm(s, ba, ch, 22050, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks, (i, ck.nchunks[i], ref.nchunks)
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        assert np.array_equal(ck.pos[i][:ref.nchunks], ref.chunk_pos)
+        for c in range(ref.channels):
+            assert np.array_equal(got[i][c], ref.data[c]), (i, c)
+
+
+def test_stream_adpcm_config3_shape(ctx, oracle):
+    """220 × 512-byte mono blocks @22 050 Hz → 219×2211 + 2194 = 486 403 outputs."""
+    B, N = _B(), _N()
+    s = oracle.gen_ima(pcm16(1016 * 220, 22050, 3, 0), 1, 512, 88)
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [s]), B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", dtype=N.I8)
+    assert int(ck.lens[0].sum()) == 219 * 2211 + 2194 == 486403
+    ref = oracle.stream_adpcm(s, 512, 1, 22050, False, oracle.CUBIC)
+    assert np.array_equal(out.download()[0][0], ref.data[0])
+
+
+# ---------------------------------------------------------------- MS ADPCM
+@pytest.mark.parametrize("ch,ba", [(2, 1024), (1, 512), (2, 64)])
+def test_msadpcm(ctx, oracle, ch, ba):
+    B, N = _B(), _N()
+    spb = (ba - 14) + 2 if ch == 2 else (ba - 7) * 2 + 2
+    streams = [oracle.gen_msadpcm(np.stack([pcm16(spb * nb, 44100, 6, 4 * i + c) for c in range(ch)], 1).ravel(), ch, ba) for i, nb in enumerate((12, 1, 60))]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_MSADPCM, ch, 44100, block_align=ba)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.msadpcm(s, ba, ch, 44100)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c])
+    for mono in ((False, True) if ch == 2 else (False,)):
+        for interp in ("linear", "cubic"):
+            out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.I8)
+            g = out.download()
+            for i, s in enumerate(streams):
+                ref = oracle.stream_msadpcm(s, ba, ch, 44100, mono, None, oracle.INTERP[interp])
+                assert ck.nchunks[i] == ref.nchunks
+                assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+                assert np.array_equal(ck.pos[i][:ref.nchunks], ref.chunk_pos)
+                for c in range(ref.channels):
+                    assert np.array_equal(g[i][c], ref.data[c]), (i, c, mono, interp)
+
+
+def test_msadpcm_random_bytes_follow_fp64_semantics(ctx, oracle):
+    """Adversarial data drives `delta` out of the integer range; the reference computes in doubles, so do we."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(99))
+    raw = bytearray(rng.integers(0, 256, 256 * 4, dtype=np.uint8).tobytes())
+    for b in range(4):
+        raw[256 * b] %= 7
+        raw[256 * b + 1] %= 7
+    bt = B.Batch.upload(ctx, [bytes(raw)])
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_MSADPCM, 2, 44100, block_align=256), dtype=N.F64).download()[0]
+    ref = oracle.msadpcm(bytes(raw), 256, 2, 44100)
+    for c in range(2):
+        assert np.array_equal(got[c], ref.data[c], equal_nan=True)
+
+
+# ---------------------------------------------------------------- QOA
+@pytest.mark.parametrize("ch", [1, 2])
+def test_qoa_audio_path(ctx, oracle, ch):
+    B, N = _B(), _N()
+    streams = [oracle.gen_qoa(np.stack([pcm16(n, 44100, 8, 4 * i + c) for c in range(ch)], 1).ravel(), ch, 44100) for i, n in enumerate((5120 * 3 + 777, 5120, 100))]
+    streams = [s + b"\0" * 8 for s in streams]  # 8 trailing bytes: otherwise aukit.qoa drops the last frame (frame_size check, Q18)
+    streams.append(streams[0][:-8])              # ... and here it does drop it
+    bt = B.Batch.upload(ctx, streams)
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_QOA), dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.qoa(s)
+        assert len(g) == ref.channels
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c])
+    res = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_QOA), 48000, "cubic", dtype=N.F64).download()
+    ref = oracle.resample(oracle.qoa(streams[0]), 48000, oracle.CUBIC)
+    assert np.max(np.abs(res[0][0] - ref.data[0])) <= 1e-15

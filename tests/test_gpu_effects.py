@@ -1,0 +1,154 @@
+"""GPU parity: Audio:mono / :mix / :pcm and aukit.effects.* vs the CPU oracle (through the C ABI).
+
+Maps are evaluated in the reference's fp64 order → bit-identical with AUKIT_F64 storage.  Scans (lowpass,
+highpass) and tree reductions (center) re-associate → ≤ 1e-12; everything is ≤ 1e-6 RMS with AUKIT_F32.
+"""
+import numpy as np
+import pytest
+
+from tests.util import rms, signal
+
+pytestmark = pytest.mark.gpu
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+def _audios(rate=22050, lens=(30000, 777, 4097), ch=2, cfg=7):
+    return [[signal(n, rate, cfg, 10 * i + c) for c in range(ch)] for i, n in enumerate(lens)]
+
+
+CASES = [
+    ("amplify", (1.5,), lambda O, a: O.fx_amplify(a, 1.5), 0.0),
+    ("amplify", (1.0,), lambda O, a: O.fx_amplify(a, 1.0), 0.0),
+    ("invert", (), lambda O, a: O.fx_invert(a), 0.0),
+    ("normalize", (0.8,), lambda O, a: O.fx_normalize(a, 0.8), 0.0),
+    ("normalize", (1.0, 1.0), lambda O, a: O.fx_normalize(a, 1.0, True), 0.0),
+    ("center", (), lambda O, a: O.fx_center(a), 1e-13),
+    ("delay", (0.01, 0.5), lambda O, a: O.fx_delay(a, 0.01, 0.5), 0.0),
+    ("delay", (0.0, 0.25), lambda O, a: O.fx_delay(a, 0.0, 0.25), 0.0),
+    ("echo", (0.01, 0.5), lambda O, a: O.fx_echo(a, 0.01, 0.5), 0.0),
+    ("echo", (0.0005, 0.9), lambda O, a: O.fx_echo(a, 0.0005, 0.9), 0.0),
+    ("lowpass", (11025.0,), lambda O, a: O.fx_lowpass(a, 11025.0), 1e-12),
+    ("lowpass", (200.0,), lambda O, a: O.fx_lowpass(a, 200.0), 1e-12),
+    ("highpass", (20.0,), lambda O, a: O.fx_highpass(a, 20.0), 1e-11),
+    ("highpass", (3000.0,), lambda O, a: O.fx_highpass(a, 3000.0), 1e-12),
+    ("fade", (0.1, 1.0, 0.2, 0.0), lambda O, a: O.fx_fade(a, 0.1, 1.0, 0.2, 0.0), 0.0),
+]
+
+
+@pytest.mark.parametrize("name,args,ref_fn,tol", CASES)
+def test_effect_f64(ctx, oracle, name, args, ref_fn, tol):
+    B, N = _B(), _N()
+    lens = (30000, 4410, 5000) if name == "fade" else (30000, 777, 4097)
+    a = _audios(lens=lens)
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    B.effect(ctx, ab, name, *args)
+    got = ab.download()
+    for s in range(len(a)):
+        ref = ref_fn(oracle, oracle.Audio(a[s], 22050))
+        for c in range(2):
+            err = np.max(np.abs(got[s][c] - ref.data[c]))
+            assert err <= tol, (name, s, c, err)
+
+
+def test_effects_f32_tolerance(ctx, oracle):
+    B, N = _B(), _N()
+    a = _audios(lens=(48000, 5000))
+    for name, args, ref_fn, _ in CASES:
+        if name == "fade":
+            continue
+        ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F32)
+        B.effect(ctx, ab, name, *args)
+        got = ab.download()
+        for s in range(len(a)):
+            ref = ref_fn(oracle, oracle.Audio([x.astype(np.float32).astype(np.float64) for x in a[s]], 22050))
+            for c in range(2):
+                assert rms(got[s][c], ref.data[c]) <= 1e-6, name
+
+
+def test_reverb(ctx, oracle):
+    B, N = _B(), _N()
+    a = _audios(rate=22050, lens=(30000, 9000), ch=2)
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    B.effect(ctx, ab, "reverb", 100.0, 0.3, 1.0, 0.0)
+    got = ab.download()
+    for s in range(2):
+        ref = oracle.fx_reverb(oracle.Audio(a[s], 22050), 100.0, 0.3, 1.0, 0.0)
+        for c in range(2):
+            assert np.max(np.abs(got[s][c] - ref.data[c])) <= 1e-13
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    B.effect(ctx, ab, "reverb", 60.0, 0.4, 0.7, 0.3)
+    ref = oracle.fx_reverb(oracle.Audio(a[0], 22050), 60.0, 0.4, 0.7, 0.3)
+    assert np.max(np.abs(ab.download()[0][1] - ref.data[1])) <= 1e-13
+
+
+def test_speed_and_trim(ctx, oracle):
+    B, N = _B(), _N()
+    a = _audios(lens=(20000, 3000))
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    B.effect(ctx, ab, "speed", 1.25, 1)  # default interpolation = linear
+    got = ab.download()
+    for s in range(2):
+        ref = oracle.fx_speed(oracle.Audio(a[s], 22050), 1.25, oracle.LINEAR)
+        assert len(got[s][0]) == len(ref.data[0])
+        assert np.max(np.abs(got[s][1] - ref.data[1])) <= 1e-15
+    assert ab.info()["sample_rate"] == 22050
+    with pytest.raises(N.AukitError) as e:  # the reference always raises here (Q17)
+        B.effect(ctx, ab, "trim", 1 / 65536)
+    assert "string expected, got table" in str(e.value)
+
+
+def test_fade_error_cases_match_reference(ctx):
+    B, N = _B(), _N()
+    ab = B.AudioBatch.upload(ctx, _audios(lens=(1000,)), 22050, dtype=N.F64)
+    with pytest.raises(N.AukitError):  # startTime = 0 indexes ch[0] (nil)
+        B.effect(ctx, ab, "fade", 0.0, 1.0, 0.01, 0.0)
+    with pytest.raises(N.AukitError):  # runs past the end
+        B.effect(ctx, ab, "fade", 0.01, 1.0, 1.0, 0.0)
+    B.effect(ctx, ab, "fade", 0.01, 1.0, 0.02, 1.0)  # both amplitudes 1: no-op, no error
+
+
+def test_mono_mix_encode_pcm(ctx, oracle):
+    B, N = _B(), _N()
+    a = _audios(lens=(5000, 123), ch=3)
+    b = [[signal(n, 22050, 8, 5 * i + c) for c in range(2)] for i, n in enumerate((7000, 50))]
+    ab, bb = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64), B.AudioBatch.upload(ctx, b, 22050, dtype=N.F64)
+    mono = B.mono(ctx, ab).download()
+    mixed = B.mix(ctx, [ab, bb], 0.7).download()
+    for s in range(2):
+        oa, ob = oracle.Audio(a[s], 22050), oracle.Audio(b[s], 22050)
+        assert np.array_equal(mono[s][0], oracle.mono(oa).data[0])
+        ref = oracle.mix([oa, ob], 0.7)
+        assert len(mixed[s]) == 3
+        for c in range(3):
+            assert np.array_equal(mixed[s][c], ref.data[c])
+    for bits, dt, inter in ((8, "signed", True), (16, "unsigned", False), (32, "float", True)):
+        got = B.encode_pcm(ctx, ab, bits, dt, inter).download()
+        for s in range(2):
+            ref = oracle.encode_pcm(oracle.Audio(a[s], 22050), bits, oracle.DTYPE[dt], inter)
+            assert np.array_equal(got[s][0], ref)
+
+
+def test_auplay_pipeline(ctx, oracle):
+    """auplay.lua:20-31: resample(48000) → mono → normalize(0.8) → lowpass(sr/2), default (linear) interpolation."""
+    B, N = _B(), _N()
+    from tests.util import pcm16
+    st = np.stack([pcm16(20000, 44100, 5, 0), pcm16(20000, 44100, 5, 1)], 1).tobytes()
+    bt = B.Batch.upload(ctx, [st])
+    desc = B.make_desc(N.CODEC_PCM, 2, 44100, 16, "signed")
+    au = B.decode(ctx, bt, desc, dtype=N.F64)
+    rs = B.resample(ctx, au, 48000, "linear")
+    mo = B.mono(ctx, rs)
+    B.effect(ctx, mo, "normalize", 0.8)
+    B.effect(ctx, mo, "lowpass", 44100 / 2)
+    got = mo.download()[0][0]
+    ref = oracle.fx_lowpass(oracle.fx_normalize(oracle.mono(oracle.resample(oracle.pcm(st, 16, oracle.SIGNED, 2, 44100), 48000, oracle.LINEAR)), 0.8), 22050.0)
+    assert np.max(np.abs(got - ref.data[0])) <= 1e-12
