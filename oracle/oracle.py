@@ -29,7 +29,7 @@ class OracleError(RuntimeError):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("ork_core.c", "ork_codecs.c", "ork_stream.c", "ork_gen.c", "ork.h", "ork_internal.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ork_core.c", "ork_codecs.c", "ork_stream.c", "ork_gen.c", "ork_check.c", "ork.h", "ork_internal.h")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB

@@ -1,0 +1,99 @@
+"""CPU: the exact-arithmetic shortcuts of the kernels, the sharding helpers, and the host-side chunk logic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_reciprocal_division_is_exact_for_common_rates(oracle):
+    """x = (i-1)/ratio is computed on the GPU as fma(fma(-d, n*r, n), r, n*r) with r = RN(1/d): must equal n/d for every output."""
+    L = oracle.lib()
+    L.ork_check_div_rcp.restype = C.c_uint64
+    for sr in (8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 192000, 37800, 7333):
+        assert L.ork_check_div_rcp(C.c_double(48000 / sr), C.c_uint64(1 << 21)) == 0, sr
+    for new in (44100, 8000, 22050):  # arbitrary target rates
+        assert L.ork_check_div_rcp(C.c_double(new / 48000), C.c_uint64(1 << 20)) == 0
+
+
+def test_sample_normalisation_by_reciprocal_is_exact(oracle):
+    L = oracle.lib()
+    L.ork_check_div_rcp.restype = C.c_uint64
+    assert L.ork_check_div_rcp(C.c_double(32767.0), C.c_uint64(32768)) == 0   # s16: s / 32767
+    assert L.ork_check_div_rcp(C.c_double(127.0), C.c_uint64(128)) == 0       # s8
+
+
+def test_pow3_double_double_is_correctly_rounded(oracle):
+    L = oracle.lib()
+    L.ork_check_pow3.restype = C.c_uint64
+    assert L.ork_check_pow3(C.c_uint64(1_000_000), C.c_uint64(7)) == 0
+
+
+def test_rational_positions_agree_with_reference_doubles():
+    """fast kernels: floor(x) and frac from (o*a) divmod b vs the reference's double x = o/ratio + 1 (differences ≤ 1e-10)."""
+    for sr, new in ((44100, 48000), (8000, 48000), (22050, 48000), (48000, 44100), (11025, 48000)):
+        g = np.gcd(sr, new)
+        a, b = sr // g, new // g
+        o = np.arange(0, 600000, dtype=np.int64)
+        x = o.astype(np.float64) / (new / sr) + 1
+        k, r = np.divmod(o * a, b)
+        xr = k + 1 + r / b
+        assert np.max(np.abs(x - xr)) < 1e-9
+        magic = (2 ** 32 + b - 1) // b
+        n = (r[:5000] + np.arange(5000) * a).astype(np.uint64)
+        assert np.array_equal((n * np.uint64(magic)) >> np.uint64(32), n // np.uint64(b))
+
+
+def test_partition_is_contiguous_and_balanced():
+    from aukit_amd.shard import partition
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 7, 4096):
+            sizes = rng.integers(1, 100000, n)
+            parts = partition(sizes, world)
+            assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[g][1] == parts[g + 1][0] for g in range(world - 1))
+            if n >= 64 * world:
+                loads = [int(sizes[a:b].sum()) for a, b in parts]
+                assert max(loads) - min(loads) <= 2 * int(sizes.max())
+    assert partition([5, 5, 5, 5], 2) == [(0, 2), (2, 4)]
+    assert partition(np.zeros(6), 3) == [(0, 2), (2, 4), (4, 6)]
+
+
+def _worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aukit_amd import shard
+    from oracle import oracle as O
+    from tests.util import pcm16
+    streams = [pcm16(2000 + 300 * i, 44100, 1, i).tobytes() for i in range(9)] if rank == 0 else None
+    mine, (lo, hi) = shard.scatter_streams(streams, src=0)
+    # stand-in for the per-GPU path: the CPU oracle (tests may use it as the checker and as the shard worker)
+    outs = []
+    for s in mine:
+        r = O.resample(O.pcm(s, 16, O.SIGNED, 1, 44100), 48000, O.CUBIC)
+        outs.append(r.data[0].astype(np.float32).tobytes())
+    gathered = shard.gather_streams(outs, dst=0)
+    if rank == 0:
+        ref = [O.resample(O.pcm(s, 16, O.SIGNED, 1, 44100), 48000, O.CUBIC).data[0].astype(np.float32).tobytes() for s in streams]
+        q.put((gathered == ref, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_process_gather_world2_gloo():
+    """N > 1 path: gather(process(scatter(batch))) == process(batch), two processes over gloo on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_worker, args=(r, 2, int(port), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, lo, hi = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and lo == 0 and 0 < hi < 9

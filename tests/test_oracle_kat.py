@@ -1,0 +1,303 @@
+"""CPU tests that pin the ORACLE with checks that do not depend on the restatement being right.
+
+The reference ships no tests, fixtures or golden vectors, and no Lua interpreter exists in the
+build image, so the oracle cannot be compared with the reference's own output.  These known-answer tests are
+the independent anchors named in SURVEY.md §8c:
+  * ITU-T G.711 expansion tables (µ-law / A-law), every code point;
+  * FLAC is lossless: decode(encode(pcm)) == pcm for every subframe type / stereo mode / partition layout;
+  * QOA: a straight int32 decoder written from the qoaformat.org specification agrees sample for sample;
+  * DFPWM: encoder and decoder track the input (lossy), and the 1-bit stream round-trips through both states;
+  * hand-computed micro-vectors for the reference quirks (§8.0).
+"""
+import numpy as np
+import pytest
+
+from tests.util import pcm16, signal
+
+
+def _itu_ulaw(u):
+    u = ~u & 0xFF
+    t = (((u & 0x0F) << 3) + 0x84) << ((u & 0x70) >> 4)
+    return (0x84 - t) if (u & 0x80) else (t - 0x84)
+
+
+def _itu_alaw(a):
+    a ^= 0x55
+    t = (a & 0x0F) << 4
+    seg = (a & 0x70) >> 4
+    if seg == 0:
+        t += 8
+    elif seg == 1:
+        t += 0x108
+    else:
+        t = (t + 0x108) << (seg - 1)
+    return t if (a & 0x80) else -t
+
+
+def test_g711_matches_itu_tables(oracle):
+    codes = bytes(range(256))
+    u = oracle.g711(codes, True, 1, 8000).data[0]
+    a = oracle.g711(codes, False, 1, 8000).data[0]
+    assert np.array_equal(u, np.array([_itu_ulaw(b) / 32768.0 for b in range(256)]))
+    assert np.array_equal(a, np.array([_itu_alaw(b) / 32768.0 for b in range(256)]))
+
+
+def test_g711_encoder_decoder_roundtrip(oracle):
+    x = pcm16(8000, 8000, 2, 0)
+    for ulaw in (True, False):
+        y = oracle.g711(oracle.gen_g711(x, ulaw), ulaw, 1, 8000).data[0] * 32768
+        assert np.sqrt(np.mean((y - x) ** 2)) < 400  # companding error of a ±24 000 signal
+
+
+@pytest.mark.parametrize("depth", [8, 16, 24])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_flac_is_lossless(oracle, depth, ch):
+    rng = np.random.Generator(np.random.PCG64(depth * 10 + ch))
+    n = 4096 * 12 + 1234  # 13 frames: every (frame % 4) stereo mode, every subframe variant, a short explicit-size last frame
+    base = (signal(n, 44100, 5, ch) * (2 ** (depth - 1) - 1) * 0.9).astype(np.int64)
+    cols = [base]
+    if ch == 2:
+        cols.append((base * 0.5 + rng.integers(-40, 40, n)).astype(np.int64))
+    pcm = np.stack(cols, 1)
+    pcm[4096:8192] = 1234 if depth > 8 else 12        # CONSTANT subframes
+    pcm[8192:12288] = (pcm[8192:12288] >> 3) << 3      # wasted bits
+    pcm[12288:16384] = rng.integers(-(2 ** (depth - 1)), 2 ** (depth - 1), (4096, ch))  # incompressible → escape partitions
+    data = oracle.gen_flac(pcm.ravel(), ch, depth, 44100, 4096)
+    dec = oracle.flac(data)
+    assert dec.channels == ch and dec.sample_rate == 44100
+    got = np.stack([np.round(dec.data[c] * 2 ** depth) for c in range(ch)], 1).astype(np.int64)  # Q14: / 2^depth
+    assert np.array_equal(got, pcm)
+
+
+def test_flac_other_blocksizes(oracle):
+    pcm = np.stack([pcm16(5000, 44100, 5, 0), pcm16(5000, 44100, 5, 1)], 1).astype(np.int64)
+    for bs in (192, 576, 1152, 256, 1024, 1000):
+        dec = oracle.flac(oracle.gen_flac(pcm.ravel(), 2, 16, 44100, bs))
+        got = np.stack([np.round(dec.data[c] * 65536) for c in range(2)], 1).astype(np.int64)
+        assert np.array_equal(got, pcm), bs
+
+
+# ---- QOA: straight decoder from the specification (int32 arithmetic) ----
+_QOA_DEQUANT = [[1, -1, 3, -3, 5, -5, 7, -7], [5, -5, 18, -18, 32, -32, 49, -49], [16, -16, 53, -53, 95, -95, 147, -147],
+                [34, -34, 113, -113, 203, -203, 315, -315], [63, -63, 210, -210, 378, -378, 588, -588],
+                [104, -104, 345, -345, 621, -621, 966, -966], [158, -158, 528, -528, 950, -950, 1477, -1477],
+                [228, -228, 760, -760, 1368, -1368, 2128, -2128], [316, -316, 1053, -1053, 1895, -1895, 2947, -2947],
+                [422, -422, 1405, -1405, 2529, -2529, 3934, -3934], [548, -548, 1828, -1828, 3290, -3290, 5117, -5117],
+                [696, -696, 2320, -2320, 4176, -4176, 6496, -6496], [868, -868, 2893, -2893, 5207, -5207, 8099, -8099],
+                [1064, -1064, 3548, -3548, 6386, -6386, 9933, -9933], [1286, -1286, 4288, -4288, 7718, -7718, 12005, -12005],
+                [1536, -1536, 5120, -5120, 9216, -9216, 14336, -14336]]
+
+
+def _qoa_spec_decode(data):
+    import struct
+    assert data[:4] == b"qoaf"
+    pos, out = 8, None
+    while pos + 8 <= len(data):
+        ch, = struct.unpack(">B", data[pos:pos + 1])
+        samples, fsize = struct.unpack(">HH", data[pos + 4:pos + 8])
+        if pos + fsize > len(data) or ch == 0:
+            break
+        if out is None:
+            out = [[] for _ in range(ch)]
+        p = pos + 8
+        lms = []
+        for _ in range(ch):
+            h = list(struct.unpack(">4h", data[p:p + 8]))
+            w = list(struct.unpack(">4h", data[p + 8:p + 16]))
+            lms.append((h, w))
+            p += 16
+        frame = [[] for _ in range(ch)]
+        for s0 in range(0, samples, 20):
+            for c in range(ch):
+                sl, = struct.unpack(">Q", data[p:p + 8])
+                p += 8
+                sf = sl >> 60
+                h, w = lms[c]
+                for k in range(min(20, samples - s0)):
+                    q = (sl >> (57 - 3 * k)) & 7
+                    pred = sum(a * b for a, b in zip(h, w)) >> 13
+                    deq = _QOA_DEQUANT[sf][q]
+                    rec = max(-32768, min(32767, pred + deq))
+                    frame[c].append(rec)
+                    d = deq >> 4
+                    for i in range(4):
+                        w[i] += -d if h[i] < 0 else d
+                    h[:] = h[1:] + [rec]
+        for c in range(ch):
+            out[c] += frame[c]
+        pos += fsize
+    return out
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_qoa_matches_spec_decoder(oracle, ch):
+    pcm = np.stack([pcm16(5120 * 2 + 20 * 17, 44100, 8, c) for c in range(ch)], 1)
+    data = oracle.gen_qoa(pcm.ravel(), ch, 44100) + b"\0" * 8  # trailing bytes keep aukit.qoa's last frame (Q18)
+    ref = _qoa_spec_decode(data)
+    got = oracle.qoa(data)
+    for c in range(ch):
+        r = np.array(ref[c], dtype=np.float64)
+        exp = np.where(r < 0, r / 32768, r / 32767)
+        assert np.array_equal(got.data[c], exp)
+    # the stream decoder emits floor(reconstructed / 256) of the same integers
+    s = oracle.stream_qoa(data[:-8], False, oracle.NONE)
+    assert s.nchunks >= 1
+
+
+def test_qoa_last_frame_is_dropped_without_trailing_bytes(oracle):
+    """aukit.lua:1735 compares frame_size with the bytes AFTER the 8-byte frame header, so the final frame never passes."""
+    pcm = pcm16(5120 * 3, 44100, 8, 0)
+    data = oracle.gen_qoa(pcm, 1, 44100)
+    assert len(oracle.qoa(data).data[0]) == 5120 * 2
+    assert len(oracle.qoa(data + b"\0" * 8).data[0]) == 5120 * 3
+
+
+def test_dfpwm_roundtrip_and_state(oracle):
+    x = np.round(signal(48000, 48000, 4, 0) * 100)
+    enc = oracle.dfpwm_encode(x)
+    assert len(enc) == 6000
+    dec = oracle.DfpwmDecoder()(enc)
+    assert np.sqrt(np.mean((dec - x) ** 2)) < 25           # lossy 1-bit codec tracks the input
+    d2 = oracle.DfpwmDecoder()
+    assert np.array_equal(np.concatenate([d2(enc[:1000]), d2(enc[1000:])]), dec)  # decoder state carries across calls
+    e2 = oracle.DfpwmEncoder()
+    assert e2(x[:8000]) + e2(x[8000:]) == enc               # encoder state too
+    assert oracle.dfpwm_encode(np.zeros(3)) != b""         # a partial byte is padded with zero samples
+    with pytest.raises(oracle.OracleError):
+        oracle.dfpwm_encode(np.array([0.0, 200.0]))
+
+
+def test_dfpwm_first_bits_by_hand(oracle):
+    """DFPWM1a from charge = 0, strength = 0: bit 1 → target 127: next = 0 + floor((0·127 + 512)/1024) = 0 → nudged to 1;
+    strength 0 → z = 0 (bit ≠ prev=false) → stays 0 → floor 8.  Decoder: antijerk (bit ≠ prevbit=false): floor((1+0+1)/2) = 1;
+    lpf += floor((1·140 + 128)/256) = 1."""
+    out = oracle.DfpwmDecoder()(bytes([0x01]))
+    assert out[0] == 1
+    # second bit 0: target -128, charge 1, strength 8: next = 1 + floor((8·(-129) + 512)/1024) = 1 + floor(-520/1024) = 0
+    # antijerk: bit ≠ prev → floor((0 + 1 + 1)/2) = 1; lpf = 1 + floor(((1-1)·140 + 128)/256) = 1
+    assert out[1] == 1
+
+
+# ---- quirk micro-vectors ----
+def test_q10_dfpwm_6001_byte_slices(oracle):
+    data = bytes(range(256)) * 24  # 6144 bytes → slices [0,6001) and [6000,6144): byte 6000 is decoded twice
+    a = oracle.dfpwm(data, 1, 48000)
+    assert len(a.data[0]) == (6001 + 144) * 8
+    d = oracle.DfpwmDecoder()
+    exp = np.concatenate([d(data[:6001]), d(data[6000:])]).astype(np.float64)
+    assert np.array_equal(a.data[0], np.where(exp < 0, exp / 128, exp / 127))
+
+
+def test_q1_q2_stream_pcm_rebase_and_fir(oracle):
+    rate = 44100
+    x = pcm16(rate * 3, rate, 1, 0)
+    s = oracle.stream_pcm(x.tobytes(), 16, oracle.SIGNED, 1, rate, False, False, oracle.LINEAR)
+    assert list(s.chunk_len[:2, 0]) == [48000, 48000]
+    v = np.where(x < 0, x / 32768.0, x / 32767.0)
+    alpha = 1 - np.exp(-(rate / 96000) * 2 * np.pi)
+    # first output of every chunk is alpha * s (ls restarts at 0); chunk c starts at input offset c * 44101 (linear)
+    for c in range(2):
+        ns = alpha * v[c * 44101]
+        exp = max(-128.0, min(127.0, ns * (128 if ns < 0 else 127)))
+        assert s.data[0][c * 48000] == exp
+    sc = oracle.stream_pcm(x.tobytes(), 16, oracle.SIGNED, 1, rate, False, False, oracle.CUBIC)
+    ns = alpha * v[1]  # cubic puts the FIRST sample at index 0, so output 1 is the 2nd sample
+    assert sc.data[0][0] == ns * (128 if ns < 0 else 127)
+    ns = alpha * v[44102 + 1]  # and re-bases by K = 44102
+    assert sc.data[0][48000] == ns * (128 if ns < 0 else 127)
+
+
+def test_q4_unsigned_normalisation(oracle):
+    a = oracle.pcm(bytes([0, 127, 128, 255]), 8, oracle.UNSIGNED, 1, 8000)
+    assert np.array_equal(a.data[0], np.array([-128 / 128, -1 / 128, 0 / 127, 127 / 127]))
+    b = oracle.pcm(np.array([0, 200, 65535], dtype="<u2").tobytes(), 16, oracle.UNSIGNED, 1, 8000)
+    assert np.array_equal(b.data[0], np.array([(0 - 128) / 32768, (200 - 128) / 32767, (65535 - 128) / 32767]))  # only right for 8 bit
+
+
+def test_q5_ima_nibble_expansion(oracle):
+    # predictor 0, step index 0 (step 7): nibble 7 → diff = (7*7 >> 2) + (7 >> 3) = 12 (standard IMA would give 11)
+    a = oracle.adpcm(bytes([0x70]), 1, 8000, True, True, [0], [0])
+    assert a.data[0][0] == 12 / 32767
+    # nibble 0xF → -12, index moved 0 → 8 (step 16) by the first nibble: diff = (7*16 >> 2) + 2 = 30
+    a = oracle.adpcm(bytes([0x7F]), 1, 8000, True, True, [0], [0])
+    assert a.data[0][1] == (12 - 30) / 32768
+
+
+def test_q6_stream_adpcm_junk_word_and_dropped_word(oracle):
+    s = oracle.gen_ima(pcm16(1016 * 2, 22050, 3, 0), 1, 512, 88)
+    r = oracle.stream_adpcm(s, 512, 1, 22050, False, oracle.CUBIC)
+    assert int(r.chunk_len.sum()) == 2211 + int(np.floor(1008 * 48000 / 22050))  # block 1: 1016 real + 8 junk; block 2 loses its last word
+    r1 = oracle.stream_adpcm(s[:512], 512, 1, 22050, False, oracle.CUBIC)
+    n = int(np.floor(1008 * 48000 / 22050))
+    # the junk nibbles only influence the interpolation look-ahead at the very end of block 1
+    assert np.array_equal(r.data[0][:2000], oracle.stream_adpcm(s[:512] + s[512:516] + b"\0" * 508, 512, 1, 22050, False, oracle.CUBIC).data[0][:2000])
+    assert len(r1.data[0]) == n
+
+
+def test_q9_msadpcm_mono_reads_first_header_for_every_block(oracle):
+    x = pcm16(1012 * 2, 44100, 6, 0)
+    s = bytearray(oracle.gen_msadpcm(x, 1, 512))
+    a = oracle.msadpcm(bytes(s), 512, 1, 44100)
+    s2 = bytearray(s)
+    s2[512:519] = b"\x06\x10\x00\x11\x11\x22\x22"  # rewrite block 2's header: ignored by the reference
+    assert np.array_equal(oracle.msadpcm(bytes(s2), 512, 1, 44100).data[0], a.data[0])
+    assert a.data[0][1012] == a.data[0][0] and a.data[0][1013] == a.data[0][1]  # block 2 starts from block 1's header samples
+
+
+def test_q13_stream_g711_chunks_are_independent(oracle):
+    g = oracle.gen_g711(pcm16(16000, 8000, 2, 0), True)
+    full = oracle.stream_g711(g, True, 1, 8000, False, oracle.CUBIC)
+    second = oracle.stream_g711(g[8000:], True, 1, 8000, False, oracle.CUBIC)
+    assert np.array_equal(full.data[0][48000:], second.data[0])
+    extra = oracle.stream_g711(g, True, 1, 8000, False, oracle.CUBIC, max_calls=4)
+    assert list(extra.chunk_len[:, 0]) == [48000, 48000, 0, 0]  # never returns nil: empty chunks forever
+
+
+def test_q14_flac_normalised_by_2_pow_depth(oracle):
+    pcm = np.array([[32767, -32768], [1, -1]], dtype=np.int64)
+    dec = oracle.flac(oracle.gen_flac(pcm.ravel(), 2, 16, 44100, 4096))
+    assert dec.data[0][0] == 32767 / 65536 and dec.data[1][0] == -32768 / 65536
+
+
+def test_q16_resample_integer_positions_copy_unclamped(oracle):
+    a = oracle.Audio([np.array([0.0, 2.0, -3.0, 0.5])], 24000)
+    r = oracle.resample(a, 48000, oracle.LINEAR)
+    assert list(r.data[0][[0, 2, 4, 6]]) == [0.0, 2.0, -3.0, 0.5]  # x integer → copied as is
+    assert r.data[0][1] == 1.0 and r.data[0][3] == -0.5             # interpolated → clamped to ±1
+
+
+def test_q17_effects_that_raise(oracle):
+    a = oracle.Audio([signal(1000, 8000, 1, 0)], 8000)
+    with pytest.raises(oracle.OracleError):
+        oracle.fx_trim(a)
+    with pytest.raises(oracle.OracleError):
+        oracle.fx_fade(a, 0.0, 1.0, 0.01, 0.0)
+    z = oracle.fx_normalize(oracle.Audio([np.zeros(4)], 8000), 1.0)
+    assert np.all(np.isnan(z.data[0]))  # peak / 0 = inf; 0 * inf = nan
+
+
+def test_effects_against_direct_numpy(oracle):
+    x = signal(5000, 22050, 7, 0)
+    a = 1 - np.exp(-(3000 / 22050) * 2 * np.pi)
+    y = x.copy()
+    for i in range(1, len(y)):
+        y[i] = y[i - 1] + a * (y[i] - y[i - 1])
+    assert np.array_equal(oracle.fx_lowpass(oracle.Audio([x], 22050), 3000.0).data[0], y)
+    ah = 1 / (2 * np.pi * (20 / 22050) + 1)
+    z = x.copy()
+    lx = z[0]
+    for i in range(1, len(z)):
+        llx = z[i]
+        z[i] = ah * (z[i - 1] + llx - lx)
+        lx = llx
+    assert np.array_equal(oracle.fx_highpass(oracle.Audio([x], 22050), 20.0).data[0], z)
+
+
+def test_cubic_interpolation_by_hand(oracle):
+    d = np.array([0.0, 1.0, 4.0, 9.0, 16.0])
+    # x = 2.5: p0..p3 = d[1..4]
+    p0, p1, p2, p3, fx = 0.0, 1.0, 4.0, 9.0, 0.5
+    exp = (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+    assert oracle.interp(oracle.CUBIC, d, 2.5) == exp
+    assert oracle.interp(oracle.CUBIC, d, 1.5) == (-0.5 * 0 + 1.5 * 0 - 1.5 * 1 + 0.5 * 4) * 0.125 + (0 - 0 + 2 - 2) * 0.25 + (0 + 0.5) * 0.5 + 0  # p0 := p1 at the left edge
+    assert oracle.interp(oracle.LINEAR, d, 5.25) == 16.0  # data[ffx+1] or data[ffx]
