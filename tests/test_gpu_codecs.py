@@ -256,3 +256,21 @@ def test_qoa_audio_path(ctx, oracle, ch):
     res = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_QOA), 48000, "cubic", dtype=N.F64).download()
     ref = oracle.resample(oracle.qoa(streams[0]), 48000, oracle.CUBIC)
     assert np.max(np.abs(res[0][0] - ref.data[0])) <= 1e-15
+
+
+@pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
+@pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
+def test_stream_qoa(ctx, oracle, ch, mono, interp):
+    B, N = _B(), _N()
+    streams = [oracle.gen_qoa(np.stack([pcm16(n, 44100, 8, 4 * i + c) for c in range(ch)], 1).ravel(), ch, 44100) for i, n in enumerate((44100 * 2 + 1234, 5120 * 9, 777))]
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F64)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_qoa(s, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks, (i, ck.nchunks[i], ref.nchunks)
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        assert np.array_equal(ck.pos[i][:ref.nchunks], ref.chunk_pos)
+        assert ck.status[i] == ref.final_status
+        for c in range(ref.channels):
+            assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-12, (i, c)
