@@ -1,0 +1,569 @@
+"""Host-side mirror of the reference's Lua module table (`require "aukit"`, aukit.lua:97-113) over the HIP C ABI.
+
+Same names, argument order, defaults and error strings as the reference so that tests read like its own API:
+
+    import aukit_amd.aukit as aukit
+    aukit.defaultInterpolation = "cubic"
+    audio = aukit.pcm(data, 16, "signed", 1, 44100):  ->  aukit.pcm(data, 16, "signed", 1, 44100)
+    audio.resample(48000).mono()                           (Lua `:` calls become Python methods)
+    aukit.effects.normalize(audio, 0.8)                    (mutates and returns the same object, aukit.lua:3356-3618)
+    for chunk, pos in aukit.stream.wav(data, mono):        (iterator of (chunk tables, position), aukit.lua:2927)
+
+Every per-sample loop runs on the GPU; this file only parses container headers (host-side bytes),
+checks arguments the way cc.expect does, and moves handles around.  Lua `data` strings are Python `bytes`.
+Batch use (N streams per call) goes through `aukit_amd.batch` directly.
+"""
+import math
+import struct
+
+import numpy as np
+
+from . import _native as N
+from . import batch as B
+
+_VERSION = "1.10.0"
+defaultInterpolation = "linear"  # aukit.lua:99
+
+_ctx = None
+
+
+def context():
+    """The process-wide GPU context (created on first use; raises without an MI355X — there is no CPU path)."""
+    global _ctx
+    if _ctx is None:
+        _ctx = B.Context(0, dtype=N.F64)
+    return _ctx
+
+
+class LuaError(RuntimeError):
+    """A Lua `error(...)` the reference would raise (message text preserved)."""
+
+
+def _wrap(fn, *a, **k):
+    try:
+        return fn(*a, **k)
+    except N.AukitError as e:
+        raise LuaError(e.msg) from None
+
+
+def _expect(n, v, *types):
+    names = {"string": (bytes, bytearray, memoryview), "number": (int, float), "boolean": (bool,), "table": (list, tuple), "nil": (type(None),)}
+    for t in types:
+        if t == "number" and isinstance(v, bool):
+            continue
+        if isinstance(v, names[t]):
+            return v
+    got = "nil" if v is None else ("boolean" if isinstance(v, bool) else ("number" if isinstance(v, (int, float)) else ("string" if isinstance(v, (bytes, str)) else type(v).__name__)))
+    want = " or ".join(types) if len(types) < 3 else ", ".join(types[:-1]) + ", or " + types[-1]
+    raise LuaError(f"bad argument #{n} (expected {want}, got {got})")
+
+
+def _interp(name, argn=2):
+    if name not in N.INTERP:
+        raise LuaError(f"bad argument #{argn} (invalid interpolation type)")
+    return N.INTERP[name]
+
+
+class Audio:
+    """aukit.Audio (aukit.lua:116-123, methods :631-1024) backed by a device-resident audio batch of one stream."""
+
+    def __init__(self, handle, metadata=None, info=None):
+        self._h = handle  # batch.AudioBatch with n == 1
+        self.metadata = dict(metadata or {})
+        self.info = dict(info or {})
+
+    # -- data access (what `audio.data[c][i]` / `audio.sampleRate` are in Lua)
+    @property
+    def sampleRate(self):
+        return self._h.info()["sample_rate"]
+
+    @property
+    def data(self):
+        return self._h.download()[0]
+
+    def len(self):  # Audio:len  :638
+        lens, _, _ = self._h.layout()
+        return int(lens[0]) / self.sampleRate
+
+    def channels(self):  # Audio:channels  :644
+        return self._h.info()["channels"]
+
+    @classmethod
+    def from_arrays(cls, channels, sample_rate):
+        """Build an Audio from host arrays (what Lua code does by filling `data` tables by hand)."""
+        return cls(B.AudioBatch.upload(context(), [[np.asarray(c, dtype=np.float64) for c in channels]], sample_rate, dtype=N.F64))
+
+    # -- methods on the hot path
+    def resample(self, sampleRate, interpolation=None):  # :653
+        _expect(1, sampleRate, "number")
+        interpolation = interpolation if interpolation is not None else defaultInterpolation
+        ip = _interp(interpolation)
+        return Audio(_wrap(B.resample, context(), self._h, float(sampleRate), ip), self.metadata, self.info)
+
+    def mono(self):  # :677
+        return Audio(_wrap(B.mono, context(), self._h), self.metadata, self.info)
+
+    def mix(self, amplifier, *others):  # :804
+        audios = [self] + list(others)
+        if not isinstance(amplifier, (int, float)):
+            if not isinstance(amplifier, Audio):
+                raise LuaError("bad argument #1 (expected Audio, got " + type(amplifier).__name__ + ")")
+            audios.insert(1, amplifier)
+            amplifier = 1
+        hs = []
+        for a in audios:
+            if not isinstance(a, Audio):
+                raise LuaError("bad argument (expected Audio)")
+            if a.sampleRate != self.sampleRate:  # :810 resamples with the default interpolation
+                a = a.resample(self.sampleRate)
+            hs.append(a._h)
+        return Audio(_wrap(B.mix, context(), hs, float(amplifier)), self.metadata, self.info)
+
+    def pcm(self, bitDepth=None, dataType=None, interleaved=None):  # :901 → table of numbers (unfloored, like the Lua)
+        bitDepth = 8 if bitDepth is None else bitDepth
+        dataType = "signed" if dataType is None else dataType
+        interleaved = True if interleaved is None else interleaved
+        if bitDepth not in (8, 16, 24, 32):
+            raise LuaError("bad argument #2 (invalid bit depth)")
+        if dataType not in ("signed", "unsigned", "float"):
+            raise LuaError("bad argument #3 (invalid data type)")
+        if dataType == "float" and bitDepth != 32:
+            raise LuaError("bad argument #2 (float audio must have 32-bit depth)")
+        return _wrap(B.encode_pcm, context(), self._h, bitDepth, dataType, interleaved).download()[0][0]
+
+    def dfpwm(self, interleaved=None):  # :1005
+        interleaved = True if interleaved is None else interleaved
+        return _wrap(B.dfpwm_encode, context(), self._h, interleaved).download()[0]
+
+    def stream(self, chunkSize=None, bitDepth=None, dataType=None):  # :921 → iterator of (chunk tables, seconds)
+        chunkSize = 131072 if chunkSize is None else int(chunkSize)
+        bitDepth = 8 if bitDepth is None else bitDepth
+        dataType = "signed" if dataType is None else dataType
+        planar = self.pcm(bitDepth, dataType, False)
+        nc = self.channels()
+        per = len(planar) // max(nc, 1)
+        rate = self.sampleRate
+
+        def it():
+            pos = 1
+            while pos <= per:
+                yield [planar[c * per + pos - 1: c * per + pos - 1 + chunkSize] for c in range(nc)], pos / rate
+                pos += chunkSize
+        return it(), per / rate
+
+    def __str__(self):
+        return f"Audio: {self.sampleRate} Hz, {self.channels()} channels, {self.len()} seconds"
+
+
+def _load(desc, data, dtype=None):
+    ctx = context()
+    bt = _wrap(B.Batch.upload, ctx, [data])
+    return _wrap(B.decode, ctx, bt, desc, ctx.dtype if dtype is None else dtype)
+
+
+# ---------------------------------------------------------------- loaders  (aukit.lua:1049-1777)
+def pcm(data, bitDepth=None, dataType=None, channels=None, sampleRate=None, interleaved=None, bigEndian=None):
+    _expect(1, data, "string")
+    bitDepth = 8 if bitDepth is None else bitDepth
+    dataType = "signed" if dataType is None else dataType
+    channels = 1 if channels is None else channels
+    sampleRate = 48000 if sampleRate is None else sampleRate
+    interleaved = True if interleaved is None else interleaved
+    if dataType not in ("signed", "unsigned", "float"):
+        raise LuaError("bad argument #3 (invalid data type)")
+    d = B.make_desc(N.CODEC_PCM, channels, sampleRate, bitDepth, dataType, bool(bigEndian), interleaved)
+    return Audio(_load(d, data), {}, {"bitDepth": bitDepth, "dataType": dataType})
+
+
+def adpcm(data, channels=None, sampleRate=None, topFirst=None, interleaved=None, predictor=None, step_index=None):
+    _expect(1, data, "string")
+    channels = 1 if channels is None else channels
+    sampleRate = 48000 if sampleRate is None else sampleRate
+    pred = [predictor] if isinstance(predictor, (int, float)) else predictor
+    idx = [step_index] if isinstance(step_index, (int, float)) else step_index
+    if pred is not None and channels > len(pred):
+        raise LuaError("bad argument #6 (table too short)")
+    if idx is not None and channels > len(idx):
+        raise LuaError("bad argument #7 (table too short)")
+    d = B.make_desc(N.CODEC_ADPCM, channels, sampleRate, top_first=True if topFirst is None else topFirst,
+                    interleaved=True if interleaved is None else interleaved, predictor=pred, step_index=idx)
+    return Audio(_load(d, data), {}, {"bitDepth": 16, "dataType": "signed"})
+
+
+def msadpcm(data, blockAlign, channels=None, sampleRate=None, coefficients=None):
+    _expect(1, data, "string")
+    _expect(2, blockAlign, "number")
+    d = B.make_desc(N.CODEC_MSADPCM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, block_align=blockAlign, coefficients=coefficients)
+    return Audio(_load(d, data), {}, {"bitDepth": 16, "dataType": "signed"})
+
+
+def g711(data, ulaw, channels=None, sampleRate=None):
+    _expect(1, data, "string")
+    _expect(2, ulaw, "boolean")
+    d = B.make_desc(N.CODEC_G711, 1 if channels is None else channels, 8000 if sampleRate is None else sampleRate, ulaw=ulaw)
+    return Audio(_load(d, data), {"bitDepth": 14 if ulaw else 13, "dataType": "signed"}, {})
+
+
+def dfpwm(data, channels=None, sampleRate=None):
+    _expect(1, data, "string")
+    d = B.make_desc(N.CODEC_DFPWM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate)
+    return Audio(_load(d, data), {}, {"bitDepth": 8, "dataType": "signed"})
+
+
+def mdfpwm(data, head=None):
+    _expect(1, data, "string")
+    if bytes(data[:7]) != b"MDFPWM\x03":
+        raise LuaError("bad argument #1 (not a MDFPWM file)")
+    pos = 11
+    meta = []
+    for _ in range(3):
+        ln = data[pos]
+        meta.append(bytes(data[pos + 1:pos + 1 + ln]))
+        pos += 1 + ln
+    a = Audio(_load(B.make_desc(N.CODEC_MDFPWM), data), {}, {"bitDepth": 8, "dataType": "signed"})
+    a.metadata = {"artist": meta[0], "title": meta[1], "album": meta[2]}
+    return a
+
+
+def qoa(data):
+    _expect(1, data, "string")
+    return Audio(_load(B.make_desc(N.CODEC_QOA), data), {}, {"bitDepth": 16, "dataType": "signed"})
+
+
+def flac(data, head=None):
+    _expect(1, data, "string")
+    return Audio(_load(B.make_desc(N.CODEC_FLAC), data), {}, {"dataType": "signed"})
+
+
+# ---- container parsers: host-side header walking only (aukit.lua:1456-1651, :2927-3113) ----
+_WAV_GUID = {
+    bytes.fromhex("0100000000001000800000aa00389b71"): "pcm", bytes.fromhex("0200000000001000800000aa00389b71"): "msadpcm",
+    bytes.fromhex("0300000000001000800000aa00389b71"): "float", bytes.fromhex("0600000000001000800000aa00389b71"): "alaw",
+    bytes.fromhex("0700000000001000800000aa00389b71"): "ulaw", bytes.fromhex("1100000000001000800000aa00389b71"): "adpcm",
+    bytes.fromhex("3ac1fa38811d4361a40dce53ca607cd1"): "dfpwm",
+}
+
+
+def _parse_wav(data):
+    """→ dict(dataType, channels, sampleRate, bitDepth, blockAlign, coefficients, payload) per aukit.lua:1459-1507 / :2932-2979."""
+    if bytes(data[:4]) != b"RIFF" or bytes(data[8:12]) != b"WAVE":
+        raise LuaError("bad argument #1 (not a WAV file)")
+    pos, fmt = 12, None
+    while pos + 8 <= len(data):
+        tag, size = bytes(data[pos:pos + 4]), struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        pos += 8
+        if tag == b"fmt ":
+            chunk = bytes(data[pos:pos + size])
+            f, ch, sr, ba, bd = struct.unpack("<HHIxxxxHH", chunk[:16])
+            coeffs = None
+            if f == 1:
+                dt = "unsigned" if bd == 8 else "signed"
+            elif f == 2:
+                dt = "msadpcm"
+                nco = struct.unpack("<H", chunk[20:22])[0]
+                if nco > 0:
+                    coeffs = [[], []]
+                    for i in range(1, nco + 1):
+                        a, b = struct.unpack("<hh", chunk[i * 4 + 18:i * 4 + 22])
+                        coeffs[0].append(a)
+                        coeffs[1].append(b)
+            elif f == 3:
+                dt = "float"
+            elif f == 6:
+                dt = "alaw"
+            elif f == 7:
+                dt = "ulaw"
+            elif f == 0x11:
+                dt = "adpcm"
+            elif f == 0xFFFE:
+                bd = struct.unpack("<H", chunk[18:20])[0]
+                kind = _WAV_GUID.get(chunk[24:40])
+                if kind is None:
+                    raise LuaError("unsupported WAV file")
+                dt = {"pcm": "unsigned" if bd == 8 else "signed"}.get(kind, kind)
+            else:
+                raise LuaError("unsupported WAV file")
+            fmt = dict(dataType=dt, channels=ch, sampleRate=sr, bitDepth=bd, blockAlign=ba, coefficients=coeffs)
+            pos += size
+        elif tag == b"data":
+            if fmt is None:
+                raise LuaError("invalid WAV file")
+            payload = bytes(data[pos:pos + size])
+            if len(payload) < size:
+                raise LuaError("invalid WAV file")
+            fmt["payload"] = payload
+            fmt["size"] = size
+            return fmt
+        else:
+            pos += size
+    raise LuaError("invalid WAV file")
+
+
+def _aiff_rate(e, m):
+    s = -1 if e & 0x8000 else 1
+    e = ((e & 0x7FFF) - 0x3FFE) % 0x800
+    return math.ldexp(m * s / 0x100000000000000, e)  # aukit.lua:1603-1605
+
+
+def _parse_aiff(data):
+    if bytes(data[:4]) != b"FORM":
+        raise LuaError("bad argument #1 (not an AIFF file)")
+    kind = bytes(data[8:12])
+    if kind not in (b"AIFF", b"AIFC"):
+        raise LuaError("bad argument #1 (not an AIFF file)")
+    pos, comm = 12, None
+    while pos + 8 <= len(data):
+        tag, size = bytes(data[pos:pos + 4]), struct.unpack(">I", data[pos + 4:pos + 8])[0]
+        pos += 8
+        if tag == b"COMM":
+            ch, length, bd, e = struct.unpack(">hIhH", data[pos:pos + 10])
+            m = struct.unpack(">Q", data[pos + 10:pos + 18])[0] >> 8  # ">I7" reads 7 bytes
+            p = pos + 18
+            comp = None
+            if kind == b"AIFC":
+                comp = bytes(data[p:p + 4])
+                ln = data[p + 4]
+                p += 5 + ln
+                if ln % 2 == 0:
+                    p += 1
+            comm = dict(channels=ch, length=length * ch * (bd // 8), bitDepth=bd, sampleRate=_aiff_rate(e, m), compression=comp)
+            pos = p
+        elif tag == b"SSND":
+            if comm is None:
+                raise LuaError("invalid AIFF file")
+            offset = struct.unpack(">I", data[pos:pos + 4])[0]
+            pos += 8
+            comm["payload"] = bytes(data[pos + offset:pos + offset + comm["length"]])
+            return comm
+        else:
+            pos += size
+    raise LuaError("invalid AIFF file")
+
+
+def _parse_au(data):
+    magic, offset, size, enc, sr, ch = struct.unpack(">4sIIIII", data[:24])
+    if magic != b".snd":
+        raise LuaError("invalid AU file")
+    payload = bytes(data[offset - 1:]) if size == 0xFFFFFFFF else bytes(data[offset - 1:offset - 1 + size])  # str_sub(data, offset, ...) is 1-based
+    return dict(encoding=enc, sampleRate=sr, channels=ch, payload=payload, size=size)
+
+
+def wav(data, head=None):  # aukit.lua:1456
+    _expect(1, data, "string")
+    f = _parse_wav(data)
+    dt, p = f["dataType"], f["payload"]
+    if dt == "adpcm":
+        a = Audio(_load(B.make_desc(N.CODEC_ADPCM_WAV, f["channels"], f["sampleRate"], block_align=f["blockAlign"]), p))
+    elif dt == "msadpcm":
+        a = msadpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], f["coefficients"])
+    elif dt in ("alaw", "ulaw"):
+        a = g711(p, dt == "ulaw", f["channels"], f["sampleRate"])
+    elif dt == "dfpwm":
+        a = dfpwm(p, f["channels"], f["sampleRate"])
+    else:
+        a = pcm(p, f["bitDepth"], dt, f["channels"], f["sampleRate"], True, False)
+    a.metadata = {}
+    a.info = {"dataType": dt, "bitDepth": f["bitDepth"]}
+    return a
+
+
+def aiff(data, head=None):  # aukit.lua:1580
+    _expect(1, data, "string")
+    f = _parse_aiff(data)
+    c, p = f["compression"], f["payload"]
+    if c in (None, b"NONE"):
+        return pcm(p, f["bitDepth"], "signed", f["channels"], f["sampleRate"], True, True)
+    if c == b"sowt":
+        return pcm(p, f["bitDepth"], "signed", f["channels"], f["sampleRate"], True, False)
+    if c in (b"fl32", b"FL32"):
+        return pcm(p, 32, "float", f["channels"], f["sampleRate"], True, True)
+    if c in (b"alaw", b"ulaw", b"ALAW", b"ULAW"):
+        return g711(p, c in (b"ulaw", b"ULAW"), f["channels"], f["sampleRate"])
+    raise LuaError("Unsupported compression scheme " + c.decode(errors="replace"))
+
+
+def au(data):  # aukit.lua:1639
+    _expect(1, data, "string")
+    f = _parse_au(data)
+    e, p, ch, sr = f["encoding"], f["payload"], f["channels"], f["sampleRate"]
+    if e == 1:
+        return g711(p, True, ch, sr)
+    if e in (2, 3, 4, 5):
+        return pcm(p, {2: 8, 3: 16, 4: 24, 5: 32}[e], "signed", ch, sr, True, True)
+    if e == 6:
+        return pcm(p, 32, "float", ch, sr, True, True)
+    if e == 27:
+        return g711(p, False, ch, sr)
+    raise LuaError(f"unsupported encoding type {e}")
+
+
+# ---------------------------------------------------------------- aukit.stream.*  (aukit.lua:2207-3337)
+class _StreamNS:
+    """Iterator factories: `it, length = aukit.stream.pcm(...)`; `for chunk, pos in it` (chunk = list of per-channel arrays)."""
+
+    @staticmethod
+    def _run(desc, data, mono, dtype, length_override=None, endless_empty=False):
+        ctx = context()
+        bt = _wrap(B.Batch.upload, ctx, [data])
+        out, ck = _wrap(B.stream_decode, ctx, bt, desc, _interp(defaultInterpolation, 0), bool(mono), dtype)
+        chans = out.download()[0]
+        n = int(ck.nchunks[0])
+        lens, poss, status = ck.lens[0][:n], ck.pos[0][:n], int(ck.status[0])
+
+        def it():
+            off = 0
+            for k in range(n):
+                yield [c[off:off + int(lens[k])] for c in chans], float(poss[k])
+                off += int(lens[k])
+            if status == N.E_LUA:
+                raise LuaError("the reference iterator raises a Lua error here (end of data inside the prefill / a malformed block)")
+            while endless_empty:  # stream.g711 never returns nil with string input (Q13)
+                yield [np.zeros(0) for _ in chans], float("nan")
+        return it(), (float(ck.length_seconds[0]) if length_override is None else length_override)
+
+    def pcm(self, data, bitDepth=None, dataType=None, channels=None, sampleRate=None, bigEndian=None, mono=None):
+        _expect(1, data, "string")
+        bitDepth = 8 if bitDepth is None else bitDepth
+        dataType = "signed" if dataType is None else dataType
+        if dataType not in ("signed", "unsigned", "float"):
+            raise LuaError("bad argument #3 (invalid data type)")
+        d = B.make_desc(N.CODEC_PCM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, bitDepth, dataType, bool(bigEndian))
+        return self._run(d, data, mono, N.F64)
+
+    def dfpwm(self, data, sampleRate=None, channels=None, mono=None):
+        _expect(1, data, "string")
+        d = B.make_desc(N.CODEC_DFPWM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate)
+        return self._run(d, data, mono, N.F64)
+
+    def mdfpwm(self, data, mono=None):
+        _expect(1, data, "string")
+        if bytes(data[:7]) != b"MDFPWM\x03":
+            raise LuaError("bad argument #1 (invalid MDFPWM data)")
+        return self._run(B.make_desc(N.CODEC_MDFPWM), data, mono, N.I8)
+
+    def msadpcm(self, input, blockAlign, channels=None, sampleRate=None, mono=None, coefficients=None):
+        _expect(1, input, "string")
+        _expect(2, blockAlign, "number")
+        d = B.make_desc(N.CODEC_MSADPCM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, block_align=blockAlign, coefficients=coefficients)
+        return self._run(d, input, mono, N.I8)
+
+    def adpcm(self, input, blockAlign, channels=None, sampleRate=None, mono=None):
+        _expect(1, input, "string")
+        _expect(2, blockAlign, "number")
+        d = B.make_desc(N.CODEC_ADPCM_WAV, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, block_align=blockAlign)
+        return self._run(d, input, mono, N.I8)
+
+    def g711(self, input, ulaw, channels=None, sampleRate=None, mono=None):
+        _expect(1, input, "string")
+        _expect(2, ulaw, "boolean")
+        d = B.make_desc(N.CODEC_G711, 1 if channels is None else channels, 8000 if sampleRate is None else sampleRate, ulaw=ulaw)
+        return self._run(d, input, mono, N.I8, endless_empty=True)
+
+    def flac(self, data, mono=None):
+        _expect(1, data, "string")
+        return self._run(B.make_desc(N.CODEC_FLAC), data, mono, N.F64)
+
+    def qoa(self, data, mono=None):
+        _expect(1, data, "string")
+        return self._run(B.make_desc(N.CODEC_QOA), data, mono, N.F64)
+
+    def wav(self, data, mono=None, ignoreHeader=None):  # :2927: header parse + dispatch (:2992-2996)
+        _expect(1, data, "string")
+        f = _parse_wav(data)
+        dt, p = f["dataType"], f["payload"]
+        if dt == "adpcm":
+            return self.adpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], mono)
+        if dt == "msadpcm":
+            return self.msadpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], mono, f["coefficients"])
+        if dt == "dfpwm":
+            return self.dfpwm(p, f["sampleRate"], f["channels"], mono)[0], f["size"] / f["channels"] / (f["bitDepth"] / 8) / f["sampleRate"]
+        if dt in ("alaw", "ulaw"):
+            return self.g711(p, dt == "ulaw", f["channels"], f["sampleRate"], mono)
+        return self.pcm(p, f["bitDepth"], dt, f["channels"], f["sampleRate"], False, mono)[0], f["size"] / f["channels"] / (f["bitDepth"] / 8) / f["sampleRate"]
+
+    def aiff(self, data, mono=None, ignoreHeader=None):  # :3016
+        _expect(1, data, "string")
+        f = _parse_aiff(data)
+        c, p, ch, sr, bd, ln = f["compression"], f["payload"], f["channels"], f["sampleRate"], f["bitDepth"], f["length"]
+        if c in (None, b"NONE", b"sowt"):
+            return self.pcm(p, bd, "signed", ch, sr, True, mono)[0], ln / ch / (bd / 8) / sr  # :3064-3065 (both big-endian in the reference)
+        if c in (b"fl32", b"FL32"):
+            return self.pcm(p, 32, "float", ch, sr, True, mono)[0], ln / ch / 4 / sr
+        if c in (b"alaw", b"ulaw", b"ALAW", b"ULAW"):
+            return self.g711(p, c in (b"ulaw", b"ULAW"), ch, sr, mono)[0], ln / ch / sr
+        raise LuaError("Unsupported compression scheme " + c.decode(errors="replace"))
+
+    def au(self, data, mono=None, ignoreHeader=None):  # :3086
+        _expect(1, data, "string")
+        f = _parse_au(data)
+        e, p, ch, sr, size = f["encoding"], f["payload"], f["channels"], f["sampleRate"], f["size"]
+        if e == 1:
+            return self.g711(p, True, ch, sr, mono)[0], size / ch / sr
+        if e in (2, 3, 4, 5):
+            bd = {2: 8, 3: 16, 4: 24, 5: 32}[e]
+            return self.pcm(p, bd, "signed", ch, sr, True, mono)[0], size / ch / (bd // 8) / sr
+        if e == 6:
+            return self.pcm(p, 32, "float", ch, sr, True, mono)[0], size / ch / 4 / sr
+        if e == 27:
+            return self.g711(p, False, ch, sr, mono)[0], size / ch / sr
+        raise LuaError(f"unsupported encoding type {e}")
+
+
+stream = _StreamNS()
+
+
+# ---------------------------------------------------------------- aukit.effects.*  (aukit.lua:3349-3618)
+class _EffectsNS:
+    @staticmethod
+    def _fx(audio, name, *args):
+        if not isinstance(audio, Audio):
+            raise LuaError("bad argument #1 (expected Audio, got " + type(audio).__name__ + ")")
+        _wrap(B.effect, context(), audio._h, name, *args)
+        return audio  # in place, returns the same object
+
+    def amplify(self, audio, multiplier):
+        _expect(2, multiplier, "number")
+        return self._fx(audio, "amplify", multiplier)
+
+    def speed(self, audio, multiplier):
+        _expect(2, multiplier, "number")
+        return self._fx(audio, "speed", multiplier, N.INTERP[defaultInterpolation])
+
+    def fade(self, audio, startTime, startAmplitude, endTime, endAmplitude):
+        for i, v in enumerate((startTime, startAmplitude, endTime, endAmplitude)):
+            _expect(i + 2, v, "number")
+        return self._fx(audio, "fade", startTime, startAmplitude, endTime, endAmplitude)
+
+    def invert(self, audio):
+        return self._fx(audio, "invert")
+
+    def normalize(self, audio, peakAmplitude=None, independent=None):
+        return self._fx(audio, "normalize", 1 if peakAmplitude is None else peakAmplitude, 1.0 if independent else 0.0)
+
+    def center(self, audio):
+        return self._fx(audio, "center")
+
+    def trim(self, audio, threshold=None):
+        return self._fx(audio, "trim", 1 / 65536 if threshold is None else threshold)
+
+    def delay(self, audio, delay, multiplier=None):
+        _expect(2, delay, "number")
+        return self._fx(audio, "delay", delay, 0.5 if multiplier is None else multiplier)
+
+    def echo(self, audio, delay=None, multiplier=None):
+        return self._fx(audio, "echo", 1 if delay is None else delay, 0.5 if multiplier is None else multiplier)
+
+    def reverb(self, audio, delay=None, decay=None, wetMultiplier=None, dryMultiplier=None):
+        return self._fx(audio, "reverb", 100 if delay is None else delay, 0.3 if decay is None else decay, 1 if wetMultiplier is None else wetMultiplier,
+                        0 if dryMultiplier is None else dryMultiplier)
+
+    def lowpass(self, audio, frequency):
+        _expect(2, frequency, "number")
+        return self._fx(audio, "lowpass", frequency)
+
+    def highpass(self, audio, frequency):
+        _expect(2, frequency, "number")
+        return self._fx(audio, "highpass", frequency)
+
+
+effects = _EffectsNS()
