@@ -203,16 +203,36 @@ AUKIT_DEV unsigned nib_get(const NibSeq &s, unsigned long long q) {
 // (pred, idx) enter as the state before nibble q0 and leave as the state after the chunk.  emit(q, predictor) per nibble.
 template <class Emit>
 AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned long long nb, int lane, int &pred, int &idx, Emit emit) {
+    // straight-line code on purpose: conditional stores into the unrolled register arrays make hipcc copy the whole
+    // array per iteration (1000+ v_mov_b64 in the first version of this kernel)
     unsigned nibs[16];
     const unsigned long long qa = q0 + 16ull * lane;
-    int valid = 0;
+    const int valid = qa >= nb ? 0 : (nb - qa >= 16 ? 16 : (int)(nb - qa));
+    if (seq.mode == 0) {  // WAV words: this lane's 16 nibbles are two 4-byte words of channel c, low nibble first
 #pragma unroll
-    for (int k = 0; k < 16; k++) { nibs[k] = 0; if (qa + k < nb) { nibs[k] = nib_get(seq, qa + k); valid = k + 1; } }
+        for (int j = 0; j < 2; j++) {
+            const bool ok = 8 * j < valid;
+            const unsigned char *wp = seq.base + (((qa >> 3) + (ok ? j : 0)) * seq.C + seq.c) * 4;
+            const unsigned w = ok ? ((unsigned)wp[0] | (unsigned)wp[1] << 8 | (unsigned)wp[2] << 16 | (unsigned)wp[3] << 24) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) nibs[8 * j + k] = (w >> (4 * k)) & 15u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool ok = k < valid;
+            const unsigned v = nib_get(seq, ok ? qa + k : 0);
+            nibs[k] = ok ? v : 0u;
+        }
+    }
     // step index: composite of this lane's clamp-adds, exclusive scan, then replay
     Sat f = sat_id();
 #pragma unroll
-    for (int k = 0; k < 16; k++) if (k < valid) f = sat_then(f, Sat{ima_index_delta(nibs[k]), 0, 88});
-    Sat inc = wave_scan_incl(f, lane);
+    for (int k = 0; k < 16; k++) {
+        const Sat g = k < valid ? Sat{ima_index_delta(nibs[k]), 0, 88} : sat_id();
+        f = sat_then(f, g);
+    }
+    const Sat inc = wave_scan_incl(f, lane);
     Sat exc = sat_shfl_up(inc, 1);
     if (lane == 0) exc = sat_id();
     int si = sat_apply(exc, idx);
@@ -221,23 +241,25 @@ AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned
     Sat g = sat_id();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        delta[k] = 0;
-        if (k < valid) {
-            const int step = c_ima_step[si];                                              // :2807
-            si = clampi(si + ima_index_delta(nibs[k]), 0, 88);                            // :2808
-            const int diff = (int)(((nibs[k] & 7) * (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
-            delta[k] = (nibs[k] & 8) ? -diff : diff;
-            g = sat_then(g, Sat{delta[k], -32768, 32767});                                // :2810-2811
-        }
+        const bool ok = k < valid;
+        const int step = c_ima_step[si];                                              // :2807 (si stays a valid index when !ok)
+        const int nsi = clampi(si + ima_index_delta(nibs[k]), 0, 88);                 // :2808
+        si = ok ? nsi : si;
+        const int diff = (int)(((nibs[k] & 7) * (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
+        const int d = (nibs[k] & 8) ? -diff : diff;
+        delta[k] = ok ? d : 0;
+        g = sat_then(g, ok ? Sat{d, -32768, 32767} : sat_id());                       // :2810-2811
     }
-    Sat ginc = wave_scan_incl(g, lane);
+    const Sat ginc = wave_scan_incl(g, lane);
     Sat gexc = sat_shfl_up(ginc, 1);
     if (lane == 0) gexc = sat_id();
     int p = sat_apply(gexc, pred);
     const int pred_end = sat_apply(Sat{__shfl(ginc.a, 63), __shfl(ginc.lo, 63), __shfl(ginc.hi, 63)}, pred);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (k < valid) { p = clampi(p + delta[k], -32768, 32767); emit(qa + k, p); }
+    for (int k = 0; k < 16; k++) {
+        p = clampi(p + delta[k], -32768, 32767);
+        if (k < valid) emit(qa + k, p);
+    }
     pred = pred_end;
     idx = idx_end;
 }
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
             NibSeq seq{blk + 4 * P.C, 0, P.C, c, 0, 1, 0};
             double *ch = sm + (size_t)c * P.cap;
             for (unsigned long long q0 = 0; q0 < nb; q0 += 1024)
-                ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { ch[q] = (double)p / (p < 0 ? 128 : 127); });  // :2812
+                ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { ch[q + (q >> 4)] = p < 0 ? (double)p * (1.0 / 128) : div_rcp((double)p, 127.0, 1.0 / 127.0); });  // :2812, skewed slots
         }
         if (bad) { if (lane == 0) atomicCAS(P.err, 0, 3); continue; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -358,12 +380,12 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
             bool isint;
             if (P.mono) {
                 double acc = 0;
-                for (int c = 0; c < P.C; c++) acc = acc + eval_at<INTERP>(RP, sg, sm + (size_t)c * P.cap, 1, j, &isint);
+                for (int c = 0; c < P.C; c++) acc = acc + eval_at<INTERP, true>(RP, sg, sm + (size_t)c * P.cap, 1, j, &isint);
                 const double v = lua_clamp(floor(acc / P.C), -128, 127);
                 obase[j] = (OUT_T)(int)v;
             } else {
                 for (int c = 0; c < P.C; c++) {
-                    const double v = lua_clamp(floor(eval_at<INTERP>(RP, sg, sm + (size_t)c * P.cap, 1, j, &isint)), -128, 127);
+                    const double v = lua_clamp(floor(eval_at<INTERP, true>(RP, sg, sm + (size_t)c * P.cap, 1, j, &isint)), -128, 127);
                     obase[(unsigned long long)c * ostride + j] = (OUT_T)(int)v;
                 }
             }
@@ -533,6 +555,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         P.newlen_full = newlen_full; P.ratio = ratio; P.rcp = 1.0 / ratio;
         P.exact_rcp = exact_div_verified(ctx, ratio, (uint64_t)newlen_full + 2) ? 1 : 0;
         P.cap = (int)((ba - 4ull * C) * 2 / C + 8 + 8);
+        P.cap += P.cap / 16 + 2;  // skewed LDS slots
         P.out = a->dev; P.err = err;
         unsigned nwv = 4;
         while (nwv > 1 && (size_t)P.cap * C * 8 * nwv > 64 * 1024) nwv >>= 1;

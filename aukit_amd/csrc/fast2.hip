@@ -193,11 +193,26 @@ __global__ __launch_bounds__(256) void k_fast_wave(const ResampleParams P, const
         }
         const float *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
         float *orow = cur.orow;
-        if (cur.cnt == (unsigned)WT) {
+        if (cur.cnt == (unsigned)WT && P.nt_store == 2) {  // experiment: 4 rows transposed through LDS → one 16-byte store per lane
+            float *so = smf + 4u * (unsigned)F.cap + wave * 256u;
+            unsigned n = cur.r0 + lane_a;
+#pragma unroll
+            for (int g = 0; g < WT / 256; g++) {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) { so[rr * 64 + lane] = interp_row<INTERP>(F, tab, n); n += row_a; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float4 val = *reinterpret_cast<const float4 *>(so + 4 * lane);
+                *reinterpret_cast<float4 *>(orow + g * 256 + 4 * lane) = val;
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (cur.cnt == (unsigned)WT) {
             unsigned n = cur.r0 + lane_a;
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
-                orow[r * 64 + lane] = interp_row<INTERP>(F, tab, n);
+                const float v = interp_row<INTERP>(F, tab, n);
+                if (P.nt_store) __builtin_nontemporal_store(v, &orow[r * 64 + lane]);  // outputs are never re-read by this kernel
+                else orow[r * 64 + lane] = v;
                 n += row_a;
             }
         } else {
@@ -250,7 +265,8 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     if (rc) return rc;
     *taken = true;
     if (P.n_tiles == 0) return AUKIT_OK;
-    size_t lds = (size_t)F.cap * 4 * 4;
+    if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
+    size_t lds = (size_t)F.cap * 4 * 4 + 4 * 256 * 4;  // 4 wave windows + 4 × 1 KiB of store-transpose staging
     unsigned per_cu = 16;  // 2x the resident workgroups: measured +3.5 % over 8 (better tail balance across XCDs)
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     unsigned nblk_needed = (P.n_tiles + 3) / 4;

@@ -63,6 +63,7 @@ struct ResampleParams {
     int mix_mono;      // EPI_STREAM_FLOOR: 1 = mean over channels after interpolation (:2905-2908), 2 = l + r/2 (:2672)
     int pos_mul;       // x = ((i-1) * pos_mul) / ratio + 1 (stream.dfpwm steps i by `channels`); 0 means 1
     int out_channels;  // EPI_STREAM_DFPWM: rows written per output
+    int nt_store;      // fast kernels: non-temporal output stores (tuning knob AUKIT_NT_STORE)
 };
 
 // launches the right instantiation; `name` receives a static string naming the kernel

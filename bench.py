@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: Msamples/s decoded + resampled to 48 kHz on a 4096-stream batch.
 
-Workload (BASELINE.json metric): per GPU, 4096 independent 1-channel s16le
+Default workload (BASELINE.json metric): per GPU, 4096 independent 1-channel s16le
 44.1 kHz streams of 10 s (441 000 samples = 882 000 B each, 3.61 GB of input resident in HBM) →
 `aukit.pcm(d,16,"signed",1,44100):resample(48000,"cubic")` as ONE fused launch of aukit_decode_resample
-(fp64 arithmetic in the reference's operation order, f32 store) → 4096 × 480 000 output samples.
-One step = one pass over the whole batch.  Streams are independent, so N GPUs = N shards with no
-data-path collective (weak scaling: every rank owns a 4096-stream shard; value is the whole-job rate).
+(f32 store) → 4096 × 480 000 output samples.  One step = one pass over the whole batch.  Streams are independent,
+so N GPUs = N shards with no data-path collective (weak scaling: every rank owns a 4096-stream shard; value is the
+whole-job rate).  Other BASELINE configs are parity-test cases; `--workload` times them too (not the driver's line).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -25,12 +25,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 SRC_RATE, DST_RATE = 44100, 48000
 
 
-def make_inputs(torch, dev, n_streams, n_samples, rank):
-    """Synthetic s16le streams generated on the device: 0.5*sine(440 Hz) + uniform noise ±0.25."""
+def _sine_noise_s16(torch, dev, n_streams, n_samples, rate, seed):
+    """0.5*sine(440 Hz) + uniform noise ±0.25, quantised to s16, generated on the device."""
     g = torch.Generator(device=dev)
-    g.manual_seed(0xA0C17 + 1000 * 1 + rank)
+    g.manual_seed(seed)
     out = torch.empty(n_streams * n_samples, dtype=torch.int16, device=dev)
-    t = torch.arange(n_samples, device=dev, dtype=torch.float32) / SRC_RATE
+    t = torch.arange(n_samples, device=dev, dtype=torch.float32) / rate
     sine = 0.5 * torch.sin(2 * torch.pi * 440.0 * t)
     step = 256
     for s0 in range(0, n_streams, step):
@@ -40,25 +40,107 @@ def make_inputs(torch, dev, n_streams, n_samples, rank):
     return out
 
 
-def cpu_baseline(n_streams, n_samples):
-    """The CPU oracle (scalar fp64 C restatement of the reference's Lua loops) timed on a bounded sample of the
-    same workload, 1 thread.  A reported baseline, not the target."""
-    import numpy as np
-    from oracle import oracle as O
-    O.build()
-    rng = np.random.Generator(np.random.PCG64(0xA0C17 + 1000))
-    t = np.arange(n_samples) / SRC_RATE
-    sig = 0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, n_samples)
-    data = np.round(sig * 32767).astype(np.int16).tobytes()
-    done = 0
-    t0 = time.perf_counter()
-    for _ in range(n_streams):
-        a = O.pcm(data, 16, O.SIGNED, 1, SRC_RATE)
-        r = O.resample(a, DST_RATE, O.CUBIC)
-        done += len(r.data[0])
-    dt = time.perf_counter() - t0
-    return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"{n_streams} of the 4096 streams ({n_samples} samples each), scalar fp64 C oracle, {dt:.1f} s"}
+def _random_bytes(torch, dev, n, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8)
+
+
+class Workload:
+    """setup(torch, dev, ctx, args, rank) → self; step() runs one pass; out_samples = units per pass on this rank."""
+    name = unit = desc = ""
+
+    def cpu_baseline(self, args):
+        return None
+
+
+class Pcm16Cubic(Workload):
+    name, unit = "pcm16_cubic", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.n_samples = int(round(args.seconds * SRC_RATE))
+        self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples, SRC_RATE, 0xA0C17 + 1000 + rank)
+        offs = [i * self.n_samples * 2 for i in range(args.streams + 1)]
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_PCM, 1, SRC_RATE, 16, "signed")
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.step = lambda: B.decode_resample(ctx, self.bt, self.d, DST_RATE, args.interp, dtype=self.dtype, out=self.out)
+        self.desc = (f"{args.streams}x s16le 44.1kHz mono {args.seconds:g}s per GPU -> aukit.pcm:resample(48000,'cubic'), "
+                     f"{args.dtype} store (SURVEY 8d config T)")
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+    def cpu_baseline(self, args):
+        import numpy as np
+        from oracle import oracle as O
+        O.build()
+        rng = np.random.Generator(np.random.PCG64(0xA0C17 + 1000))
+        t = np.arange(self.n_samples) / SRC_RATE
+        data = np.round((0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, self.n_samples)) * 32767).astype(np.int16).tobytes()
+        done, t0 = 0, time.perf_counter()
+        for _ in range(args.cpu_streams):
+            done += len(O.resample(O.pcm(data, 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
+        dt = time.perf_counter() - t0
+        return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": f"{args.cpu_streams} of the {args.streams} streams ({self.n_samples} samples each), scalar fp64 C oracle, {dt:.1f} s"}
+
+
+class G711Cubic(Workload):
+    name, unit = "g711_cubic", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        n = int(round(args.seconds * 8000))
+        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 2000 + rank)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        self.d = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
+        self.out = B.AudioBatch(ctx)
+        self.step = lambda: B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=N.F32, out=self.out)
+        self.desc = f"{args.streams}x G.711 u-law 8kHz {args.seconds:g}s -> aukit.g711:resample(48000,'cubic'), f32 store (config 2a)"
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+
+class ImaStream(Workload):
+    name, unit = "ima_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        blocks = int(round(args.seconds * 22))  # 220 blocks of 512 B ≈ 10.1 s @22 050 Hz
+        n = blocks * 512
+        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 3000 + rank)
+        self.x.view(-1, 512)[:, 2] %= 89  # header step index <= 88
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
+        self.out = B.AudioBatch(ctx)
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, "cubic", dtype=N.I8, out=self.out)
+        self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B -> stream.adpcm cubic, int8 out (config 3a)"
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+
+class DfpwmTranscode(Workload):
+    name, unit = "dfpwm_transcode", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        n = int(round(args.seconds * 12000))  # 120 000 B = 10 s of 2-channel interleaved DFPWM @48 kHz
+        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 4000 + rank)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        self.outb = B.Batch(ctx, __import__("ctypes").c_void_p())
+        self.step = lambda: B.dfpwm_transcode_mono(ctx, self.bt, 2, out=self.outb)
+        self.desc = f"{args.streams}x DFPWM 48kHz stereo {args.seconds:g}s -> aukit.dfpwm:mono():dfpwm() fused (config 4); unit = mono samples"
+        return self
+
+    def out_samples(self):
+        return int(self.outb.info()[1]) * 8
+
+
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, G711Cubic, ImaStream, DfpwmTranscode)}
 
 
 def main():
@@ -66,13 +148,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=4096)
+    ap.add_argument("--workload", default="pcm16_cubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default 4096; 16384 for dfpwm_transcode)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-streams", type=int, default=256, help="streams timed on the CPU oracle (0 disables)")
-    ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the fast kernel")
+    ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the v1 fast kernel")
     ap.add_argument("--exact-math", type=int, default=0, help="1: fp64 reference-order kernel even for f32 storage")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 16384 if args.workload == "dfpwm_transcode" else 4096
 
     import torch
     import torch.distributed as dist
@@ -84,39 +171,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: aukit_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    n_samples = int(round(args.seconds * SRC_RATE))
-    dtype = N.F32 if args.dtype == "f32" else N.F64
-    x = make_inputs(torch, dev, args.streams, n_samples, rank)
-    torch.cuda.synchronize()
-
-    ctx = B.Context(local_rank)
+    ctx = B.Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launch on torch's current stream
     ctx.set_option(N.OPT_STORE_X4, args.store_x4)
     ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
-    offs = [i * n_samples * 2 for i in range(args.streams + 1)]
-    bt = B.Batch.wrap(ctx, x.data_ptr(), offs, keep=x)
-    desc = B.make_desc(N.CODEC_PCM, 1, SRC_RATE, 16, "signed")
-    out = B.AudioBatch(ctx)
-
-    def step():
-        B.decode_resample(ctx, bt, desc, DST_RATE, "cubic", dtype=dtype, out=out)
+    wl = WORKLOADS[args.workload]().setup(torch, dev, ctx, args, rank, N, B)
+    torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.timer_begin()  # HIP events on the stream the kernel is launched on
+    ctx.timer_begin()  # HIP events on the stream the kernels are launched on
     for _ in range(args.steps):
-        step()
+        wl.step()
     ev_ms = ctx.timer_end()
     torch.cuda.synchronize()
     if world > 1:
@@ -124,14 +206,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
-    lens, _, _ = out.layout()
-    out_samples = int(lens.sum())
+    out_samples = wl.out_samples()
     name, _, alg_bytes = ctx.last_kernel()
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ts = torch.tensor([out_samples], device=dev, dtype=torch.float64)
+        ts = torch.tensor([float(out_samples)], device=rdev, dtype=torch.float64)
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         total_samples = float(ts.item())
     else:
@@ -140,10 +221,11 @@ def main():
     if rank == 0:
         kernel_ms = ev_ms / args.steps
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        headline = args.workload == "pcm16_cubic"
         line = {
-            "metric": "Msamples/s decoded+resampled to 48kHz, 4096-stream batch",
+            "metric": "Msamples/s decoded+resampled to 48kHz, 4096-stream batch" if headline else f"Msamples/s ({args.workload})",
             "value": total_samples * args.steps / dt / 1e6,
-            "unit": "Msamples/s",
+            "unit": wl.unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -152,19 +234,19 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             # arithmetic type of the path: the f32-store fast kernels use exact integer positions + f32 FMA taps,
-            # the reference-order kernels (f64 store or --exact-math 1) compute in fp64
-            "dtype": "f32" if name.startswith("k_fast") else "f64",
+            # the reference-order kernels (f64 store or --exact-math 1) compute in fp64; DFPWM / ADPCM decode is int32
+            "dtype": "f32" if name.startswith("k_fast") else ("i32" if "dfpwm" in name else "f64"),
             "data": "synthetic",
-            "config": {"workload": f"{args.streams}x s16le 44.1kHz mono {args.seconds:g}s per GPU -> aukit.pcm:resample(48000,'cubic'), "
-                                   f"{args.dtype} store (SURVEY 8d config T)",
-                       "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds, "interpolation": "cubic",
-                       "store": args.dtype, "parallelism": f"shard{world}"},
+            "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds,
+                       "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_out_sample": alg_bytes / max(out_samples, 1)},
         }
         if world == 1 and args.cpu_streams > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_streams, n_samples)
+            cb = wl.cpu_baseline(args)
+            if cb:
+                line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
