@@ -117,6 +117,78 @@ __global__ __launch_bounds__(64) void k_dfpwm_transcode_mono(const unsigned char
     }
 }
 
+// Stereo specialisation of the fused transcode.  Profile of the generic kernel (profiles/r01_r1_dfpwm_*): 68 VALU
+// instructions per decoded bit at 6.7 cycles each — one wave per CU, a single dependent chain, nothing to overlap.
+// Here (a) the fp64 part  floor(m * (m<0 and 128 or 127)),  m = ((0 + L/(128|127)) + R/(128|127)) / 2  is a pure function
+// of the two int8 decoder outputs, so it is tabulated once per workgroup (65 536 entries of int8 in LDS, computed with the
+// reference's own fp64 operations) and the inner loop is integer-only; (b) input arrives as 16-byte vectors with the next
+// vector already in flight; (c) the decoder of the next sample pair and the encoder of the previous one are independent
+// chains inside one loop body, which the scheduler interleaves.
+__global__ __launch_bounds__(64) void k_dfpwm_transcode_stereo(const unsigned char *src, const unsigned long long *off, unsigned n,
+                                                              unsigned char *out, const unsigned long long *ooff) {
+    __shared__ signed char lut[65536];
+    for (int i = threadIdx.x; i < 65536; i += 64) {
+        const double l = (double)((i >> 8) - 128), r = (double)((i & 255) - 128);
+        double acc = 0;
+        acc = acc + l / (l < 0 ? 128 : 127);   // aukit.pcm table input :1082 (left), Audio:mono :685
+        acc = acc + r / (r < 0 ? 128 : 127);
+        const double m = acc / 2;               // :686
+        lut[i] = (signed char)(int)floor(m * (m < 0 ? 128 : 127));  // encodePCM :874 + the encoder's floor
+    }
+    __syncthreads();
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const unsigned char *p = src + off[s];  // 16-byte aligned (checked on the host)
+    const unsigned long long nb = off[s + 1] - off[s];
+    unsigned char *o = out + ooff[s];
+    DfDec d{};
+    DfEnc e{};
+    int nbits = 0, have_l = 0, vl = 0;
+    unsigned byte_out = 0;
+    unsigned long long w = 0;
+    const unsigned long long nvec = (nb + 15) >> 4;
+    uint4 cur = nvec ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0), nxt = cur;
+    unsigned long long cur_vec = 0;
+    auto feed = [&](unsigned byte) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = df_decode_bit(d, byte & 1);
+            byte >>= 1;
+            if (!have_l) { vl = v; have_l = 1; }
+            else {
+                have_l = 0;
+                const int pv = lut[((vl + 128) << 8) | (v + 128)];
+                byte_out = (byte_out >> 1) | (df_encode_sample(e, pv) ? 128u : 0u);
+                if (++nbits == 8) { o[w++] = (unsigned char)byte_out; nbits = 0; byte_out = 0; }
+            }
+        }
+    };
+    for (unsigned long long pos = 0; pos < nb; pos += 6000) {  // 6001-byte slices advanced by 6000 (Q10); 6000 = 375 vectors
+        const unsigned long long cnt = nb - pos < 6001 ? nb - pos : 6001;
+        for (unsigned long long b = 0; b < cnt; b += 16) {
+            const unsigned long long vi = (pos + b) >> 4;
+            if (vi != cur_vec) { cur = nxt; cur_vec = vi; }
+            if (vi + 1 < nvec) nxt = *reinterpret_cast<const uint4 *>(p + 16 * (vi + 1));  // in flight while `cur` is decoded
+            const unsigned words[4] = {cur.x, cur.y, cur.z, cur.w};
+            const unsigned long long take = cnt - b < 16 ? cnt - b : 16;
+#pragma unroll
+            for (int wi = 0; wi < 4; wi++) {
+                unsigned wv = words[wi];
+#pragma unroll 1
+                for (int jb = 0; jb < 4; jb++) {  // not unrolled: keeps the loop body inside the instruction cache
+                    if ((unsigned long long)(4 * wi + jb) < take) feed(wv & 0xFF);
+                    wv >>= 8;
+                }
+            }
+        }
+        // the 6001st byte of a slice is the first byte of the next vector, which the next slice starts from again
+    }
+    if (nbits) {  // pad the last byte with samples of value 0
+        while (nbits < 8) { byte_out = (byte_out >> 1) | (df_encode_sample(e, 0) ? 128u : 0u); nbits++; }
+        o[w++] = (unsigned char)byte_out;
+    }
+}
+
 // fed bytes of aukit.dfpwm's slice loop (Q10): Σ min(6001, nb - 6000k)
 static uint64_t dfpwm_fed_bytes(uint64_t nb) {
     uint64_t f = 0;
@@ -695,11 +767,18 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
     if (in->n == 0) return AUKIT_OK;
     int rc = ctx_begin_kernel(ctx);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dfpwm_transcode_mono, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
-                       in->n, channels, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off));
+    bool aligned = (reinterpret_cast<uintptr_t>(in->data()) & 15) == 0;
+    for (uint32_t s = 0; s < in->n && aligned; s++) aligned = (in->off[s] & 15) == 0;
+    const bool stereo = channels == 2 && aligned && !getenv("AUKIT_DFPWM_GENERIC");
+    if (stereo)
+        hipLaunchKernelGGL(k_dfpwm_transcode_stereo, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
+                           in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off));
+    else
+        hipLaunchKernelGGL(k_dfpwm_transcode_mono, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
+                           in->n, channels, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off));
     AUKIT_HIP_CHECK(hipGetLastError());
     (void)samples_total;
-    return ctx_end_kernel(ctx, "k_dfpwm_transcode_mono", in->total() + off[in->n]);
+    return ctx_end_kernel(ctx, stereo ? "k_dfpwm_transcode_stereo" : "k_dfpwm_transcode_mono", in->total() + off[in->n]);
 }
 
 }  // extern "C"

@@ -84,6 +84,12 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle):
         assert u == ref
         assert f == ref
     assert len(fused[0]) == 60010  # Q10: 120 000 B → 960 152 samples → 480 076 mono samples → 60 010 B
+    assert ctx.last_kernel()[0] == "k_dfpwm_transcode_stereo"
+    # a batch whose streams are not 16-byte aligned takes the generic kernel: same bytes
+    bt2 = B.Batch.upload(ctx, [b"\x5a"] + streams)
+    fused2 = B.dfpwm_transcode_mono(ctx, bt2, 2).download()
+    assert ctx.last_kernel()[0] == "k_dfpwm_transcode_mono"
+    assert fused2[1:] == fused
 
 
 @pytest.mark.parametrize("ch,mono,rate", [(1, False, 48000), (2, False, 48000), (2, True, 48000), (1, False, 24000), (2, True, 32000)])
