@@ -21,7 +21,8 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         double norm_neg, aukit_audio **out);
 
 enum FlacErr { FE_OK = 0, FE_EOF_START = 1 /* readByte() == nil at a frame start: clean end */, FE_NIL = 2, FE_SYNC = 3, FE_BLOCKSIZE = 4,
-               FE_CHAN = 5, FE_SUBTYPE = 6, FE_RESMETHOD = 7, FE_PARTITION = 8 };
+               FE_CHAN = 5, FE_SUBTYPE = 6, FE_RESMETHOD = 7, FE_PARTITION = 8,
+               FE_LIMIT = 9 /* parse pass only: the candidate ran past its bit budget; re-parsed without a budget if the chain needs it */ };
 static const char *flac_err_msg(int e) {
     switch (e) {
     case FE_NIL: return "attempt to perform arithmetic on a nil value";
@@ -35,15 +36,41 @@ static const char *flac_err_msg(int e) {
     return "FLAC decode error";
 }
 
-// MSB-first bit reader over [first_bit, end_bit) of the batch buffer, 8-byte aligned loads + funnel shift
+// MSB-first bit reader over [first_bit, end_bit) of the batch buffer.  Three big-endian 64-bit words are kept in
+// registers (current, next, next-but-one): a Rice-coded sample consumes ≈15 bits, so one 8-byte load is issued every
+// ≈4 samples and it is not needed until the following word crossing — the load latency stays off the decode chain
+// (the first version re-loaded 16 bytes for every bit-field: 72 + 82 ms per 3.6 GB batch, see profiles/).
 struct Bits {
     const unsigned long long *w0;   // 8-byte aligned base at or below the batch data
     unsigned long long first, end;  // bit offsets (relative to w0) of the BitInputStream start and of the end of the string
     unsigned long long pos;
+    unsigned long long cur, nxt, nxt2, wi;
+    unsigned long long limit;       // parse pass: give up (FE_LIMIT) beyond this bit — bounds the work of false sync candidates
+    int kind;                       // parse pass: code-path class of the last subframe (0 const, 1 verbatim, 2/3/4 order <= 4/12/32, 5 wide)
     int eof;
 };
 AUKIT_DEV unsigned long long be64(unsigned long long v) { return __builtin_bswap64(v); }
-AUKIT_DEV unsigned long long peek64(const Bits &b, unsigned long long pos) {
+AUKIT_DEV void bits_seek(Bits &b, unsigned long long pos) {
+    b.pos = pos;
+    b.wi = pos >> 6;
+    b.cur = be64(b.w0[b.wi]);
+    b.nxt = be64(b.w0[b.wi + 1]);
+    b.nxt2 = be64(b.w0[b.wi + 2]);
+}
+AUKIT_DEV unsigned long long peek(const Bits &b) {
+    const unsigned s = (unsigned)b.pos & 63;
+    return s ? (b.cur << s) | (b.nxt >> (64 - s)) : b.cur;
+}
+AUKIT_DEV void skip(Bits &b, unsigned n) {  // n <= 64
+    b.pos += n;
+    if ((b.pos >> 6) != b.wi) {
+        b.wi++;
+        b.cur = b.nxt;
+        b.nxt = b.nxt2;
+        b.nxt2 = be64(b.w0[b.wi + 2]);
+    }
+}
+AUKIT_DEV unsigned long long peek_at(const Bits &b, unsigned long long pos) {  // uncached, any position
     const unsigned long long wi = pos >> 6;
     const unsigned s = (unsigned)pos & 63;
     const unsigned long long hi = be64(b.w0[wi]);
@@ -55,8 +82,8 @@ AUKIT_DEV long long read_uint(Bits &b, int n) {
     if (n == 0) return 0;
     if (b.pos + (unsigned long long)n > b.end) { b.eof = 1; return 0; }  // str_byte → nil
     if (n < 32) {
-        const unsigned long long v = peek64(b, b.pos) >> (64 - n);
-        b.pos += n;
+        const unsigned long long v = peek(b) >> (64 - n);
+        skip(b, (unsigned)n);
         return (long long)v;
     }
     const unsigned long long after = b.pos + n;
@@ -64,8 +91,8 @@ AUKIT_DEV long long read_uint(Bits &b, int n) {
     int width = 44 - L;
     unsigned long long s = after - (unsigned long long)width;
     if (after < b.first + (unsigned long long)width) { width = (int)(after - b.first); s = b.first; }
-    const unsigned long long v = peek64(b, s) >> (64 - width);
-    b.pos = after;
+    const unsigned long long v = peek_at(b, s) >> (64 - width);
+    skip(b, (unsigned)n);
     return (long long)v;
 }
 AUKIT_DEV long long read_sint(Bits &b, int n) {  // :365-369
@@ -77,13 +104,13 @@ AUKIT_DEV long long read_rice(Bits &b, int param) {  // :370-376
     long long val = 0;
     for (;;) {
         if (b.pos >= b.end) { b.eof = 1; return 0; }
-        const unsigned long long w = peek64(b, b.pos);
+        const unsigned long long w = peek(b);
         const unsigned long long avail = b.end - b.pos;
         int z = w ? __builtin_clzll(w) : 64;
         if ((unsigned long long)z >= avail) { b.eof = 1; return 0; }  // ran off the end inside the unary prefix
-        if (z < 64) { val += z; b.pos += (unsigned)z + 1; break; }
+        if (z < 64) { val += z; skip(b, (unsigned)z + 1); break; }
         val += 64;
-        b.pos += 64;
+        skip(b, 64);
     }
     val = (val << param) + read_uint(b, param);
     return (val & 1) ? -(val >> 1) - 1 : (val >> 1);
@@ -94,6 +121,7 @@ struct FrameInfo {                 // result of parsing one candidate
     unsigned long long end_bit;    // first bit after the frame's CRC-16 (byte aligned)
     unsigned long long sub_bit[AUKIT_MAX_CHANNELS];
     int blocksize, chan_asgn, status, pad;
+    unsigned char kind[AUKIT_MAX_CHANNELS];
 };
 
 struct FlacStreamInfo { unsigned long long first_byte; double rate, nsamples; int channels, depth, status, pad; };
@@ -134,6 +162,27 @@ __global__ __launch_bounds__(64) void k_flac_header(const unsigned char *src, co
     out[s] = r;
 }
 
+// frame-header length as decodeFrame walks it (:518-553) and CRC-8 (poly 0x07) over it; false when the header does not fit
+AUKIT_DEV bool flac_header_crc_ok(const unsigned char *src, unsigned long long p, unsigned long long end) {
+    if (p + 6 > end) return false;
+    const unsigned b2 = src[p + 2];
+    const unsigned bsc = b2 >> 4, src_code = b2 & 15;
+    unsigned long long idx = p + 4;
+    const unsigned t = src[idx];
+    int lead = 0;
+    for (int i = 7; i >= 0; i--) { if (!(t & (1u << i))) break; lead++; }
+    idx += 1 + (lead > 1 ? lead - 1 : 0);
+    if (bsc == 6) idx += 1; else if (bsc == 7) idx += 2;
+    if (src_code == 12) idx += 1; else if (src_code == 13 || src_code == 14) idx += 2;
+    if (idx >= end) return false;
+    unsigned crc = 0;
+    for (unsigned long long q = p; q < idx; q++) {
+        crc ^= src[q];
+        for (int k = 0; k < 8; k++) crc = (crc & 0x80) ? ((crc << 1) ^ 0x07) & 0xFF : (crc << 1) & 0xFF;
+    }
+    return crc == src[idx];
+}
+
 struct Cand { unsigned stream; unsigned pad; unsigned long long byte; };  // byte: absolute in the batch
 
 __global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, const unsigned long long *off, const FlacStreamInfo *info, unsigned n,
@@ -143,6 +192,9 @@ __global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, con
     const unsigned long long b0 = off[s] + info[s].first_byte, b1 = off[s + 1];
     for (unsigned long long p = b0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; p + 1 < b1; p += (unsigned long long)gridDim.x * 256) {
         if (src[p] == 0xFF && (src[p + 1] & 0xFC) == 0xF8) {  // temp * 64 + readUint(6) == 0x3FFE  :518
+            // Speed-only filter: keep candidates whose header CRC-8 checks out.  The reference ignores the CRC (:553), so a
+            // real frame with a damaged CRC is still decoded: the host parses any chain position that is not in this list on demand.
+            if (!flac_header_crc_ok(src, p, b1)) continue;
             const unsigned long long k = atomicAdd(count, 1ull);
             if (k < cap) cands[k] = Cand{s, 0, p};
         }
@@ -168,6 +220,7 @@ AUKIT_DEV int flac_residuals(Bits &b, int order, int blocksize, int lshift, H *h
         const bool esc = param >= escape;
         if (esc) nbits = (int)read_uint(b, 5);
         if (b.eof) return FE_NIL;
+        if (!STORE && b.pos > b.limit) return FE_LIMIT;
         for (int j = start; j < endd; j++) {
             const long long r = esc ? read_sint(b, nbits) : read_rice(b, param);
             if constexpr (STORE) {
@@ -236,13 +289,16 @@ AUKIT_DEV int flac_subframe(Bits &b, int depth, int blocksize, double *out) {
     if (depth < 0 || depth > 57) return FE_NIL;  // 2^(n-1) with a negative n misbehaves in the Lua too; treat as malformed
     const long long mul = 1ll << shift;
     if (type == 0) {
+        b.kind = 0;
         const long long c = read_sint(b, depth);
         if (b.eof) return FE_NIL;
         if (STORE) for (int i = 0; i < blocksize; i++) out[i] = (double)(c * mul);
         return FE_OK;
     }
     if (type == 1) {
+        b.kind = 1;
         for (int i = 0; i < blocksize; i++) {
+            if (!STORE && (i & 255) == 0 && b.pos > b.limit) return FE_LIMIT;
             const long long v = read_sint(b, depth);
             if (STORE) out[i] = (double)(v * mul);
         }
@@ -253,6 +309,7 @@ AUKIT_DEV int flac_subframe(Bits &b, int depth, int blocksize, double *out) {
     else if (type >= 32 && type <= 63) order = type - 31;
     else return FE_SUBTYPE;
     if (!STORE) {  // parse only: consume warm-up, coefficients and residuals
+        b.kind = depth > 31 ? 5 : (order <= 4 ? 2 : (order <= 12 ? 3 : 4));
         for (int i = 0; i < order; i++) read_sint(b, depth);
         if (type >= 32) {
             const int precision = (int)read_uint(b, 4) + 1;
@@ -280,7 +337,7 @@ struct FlacGlobals {
 };
 
 // decodeFrame header + parse-only subframes  :510-557
-__global__ __launch_bounds__(64) void k_flac_parse(const FlacGlobals G, const Cand *cands, unsigned long long ncand, FrameInfo *out) {
+__global__ __launch_bounds__(64) void k_flac_parse(const FlacGlobals G, const Cand *cands, unsigned long long ncand, FrameInfo *out, int limit_factor) {
     const unsigned long long ci = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
     if (ci >= ncand) return;
     const Cand c = cands[ci];
@@ -289,8 +346,10 @@ __global__ __launch_bounds__(64) void k_flac_parse(const FlacGlobals G, const Ca
     b.w0 = G.w0;
     b.first = G.base_bit + 8 * (G.off[c.stream] + si.first_byte);
     b.end = G.base_bit + 8 * G.off[c.stream + 1];
-    b.pos = G.base_bit + 8 * c.byte;
     b.eof = 0;
+    b.limit = ~0ull;
+    b.kind = 0;
+    bits_seek(b, G.base_bit + 8 * c.byte);
     FrameInfo f{};
     f.start_bit = b.pos;
     f.status = FE_OK;
@@ -320,16 +379,19 @@ __global__ __launch_bounds__(64) void k_flac_parse(const FlacGlobals G, const Ca
     read_uint(b, 8);  // CRC-8, ignored :553
     if (b.eof) { f.status = FE_NIL; out[ci] = f; return; }
     f.blocksize = bs;
+    // bit budget: `limit_factor` times the size of an all-VERBATIM frame (no encoder emits a bigger one; the chain re-parses without it if needed)
+    b.limit = limit_factor > 0 ? b.pos + (unsigned long long)limit_factor * (unsigned long long)bs * (unsigned long long)si.channels * (unsigned long long)(si.depth + 2) + 4096 : ~0ull;
     const int nch = si.channels, depth = si.depth;
     int st = FE_OK;
     if (f.chan_asgn <= 7) {
-        for (int ch = 0; ch < nch && st == FE_OK; ch++) { f.sub_bit[ch] = b.pos; st = flac_subframe<false>(b, depth, bs, nullptr); }
+        for (int ch = 0; ch < nch && st == FE_OK; ch++) { f.sub_bit[ch] = b.pos; st = flac_subframe<false>(b, depth, bs, nullptr); f.kind[ch] = (unsigned char)b.kind; }
     } else if (f.chan_asgn <= 10) {
         if (nch < 2) st = FE_NIL;
         else {
             f.sub_bit[0] = b.pos;
             st = flac_subframe<false>(b, depth + (f.chan_asgn == 9 ? 1 : 0), bs, nullptr);
-            if (st == FE_OK) { f.sub_bit[1] = b.pos; st = flac_subframe<false>(b, depth + (f.chan_asgn == 9 ? 0 : 1), bs, nullptr); }
+            f.kind[0] = (unsigned char)b.kind;
+            if (st == FE_OK) { f.sub_bit[1] = b.pos; st = flac_subframe<false>(b, depth + (f.chan_asgn == 9 ? 0 : 1), bs, nullptr); f.kind[1] = (unsigned char)b.kind; }
         }
     } else st = FE_CHAN;
     if (st != FE_OK) { f.status = st; out[ci] = f; return; }
@@ -351,8 +413,10 @@ __global__ __launch_bounds__(64) void k_flac_subframe(const FlacGlobals G, const
     b.w0 = G.w0;
     b.first = G.base_bit + 8 * (G.off[job.stream] + si.first_byte);
     b.end = G.base_bit + 8 * G.off[job.stream + 1];
-    b.pos = job.bit;
     b.eof = 0;
+    b.limit = ~0ull;
+    b.kind = 0;
+    bits_seek(b, job.bit);
     const int st = flac_subframe<true>(b, job.depth, job.blocksize, out + job.out_off);
     if (st != FE_OK) atomicCAS(err, 0, st);
 }
@@ -444,11 +508,11 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     G.base_bit = 8 * (dptr & 7);
     G.off = reinterpret_cast<const unsigned long long *>(in->d_off);
     G.info = reinterpret_cast<const FlacStreamInfo *>(hb.p);
-    if ((rc = cb.ensure(ncand * (sizeof(Cand) + sizeof(FrameInfo)) + 64))) return rc;
+    if ((rc = cb.ensure((ncand + 1) * (sizeof(Cand) + sizeof(FrameInfo)) + 64))) return rc;  // +1: scratch slot for on-demand parses
     AUKIT_HIP_CHECK(hipMemcpyAsync(cb.p, cands.data(), ncand * sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
-    FrameInfo *d_fi = reinterpret_cast<FrameInfo *>(reinterpret_cast<char *>(cb.p) + ncand * sizeof(Cand));
+    FrameInfo *d_fi = reinterpret_cast<FrameInfo *>(reinterpret_cast<char *>(cb.p) + (ncand + 1) * sizeof(Cand));
     if ((rc = ctx_begin_kernel(ctx))) return rc;
-    hipLaunchKernelGGL(k_flac_parse, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p), ncand, d_fi);
+    hipLaunchKernelGGL(k_flac_parse, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p), ncand, d_fi, 4);
     AUKIT_HIP_CHECK(hipGetLastError());
     if ((rc = ctx_end_kernel(ctx, "k_flac_parse", in->total()))) return rc;
     std::vector<FrameInfo> fi(ncand);
@@ -475,7 +539,23 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
             if (at >= endb) break;  // readByte() → nil → decodeFrame returns false
             size_t a = lo, b = hi;
             while (a < b) { size_t m = (a + b) / 2; if (cands[m].byte < at) a = m + 1; else b = m; }
-            if (a >= hi || cands[a].byte != at) { D.status[s] = (at + 2 > endb) ? FE_NIL : FE_SYNC; break; }  // no sync code at the expected position
+            if (a >= hi || cands[a].byte != at) {
+                // not in the pre-parsed list (failed the CRC filter, or no sync pattern here): parse this one position now —
+                // k_flac_parse reports "Sync code expected" / nil arithmetic exactly like decodeFrame would
+                const Cand one{s, 0, at};
+                AUKIT_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<Cand *>(cb.p) + ncand, &one, sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_flac_parse, dim3(1), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p) + ncand, 1ull, d_fi + ncand, 0);
+                FrameInfo extra;
+                AUKIT_HIP_CHECK(hipMemcpyAsync(&extra, d_fi + ncand, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                fi.push_back(extra);
+                a = fi.size() - 1;
+            }
+            if (fi[a].status == FE_LIMIT) {  // a real frame larger than the budget: parse it again without one
+                hipLaunchKernelGGL(k_flac_parse, dim3(1), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p) + a, 1ull, d_fi + a, 0);
+                AUKIT_HIP_CHECK(hipMemcpyAsync(&fi[a], d_fi + a, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            }
             const FrameInfo &f = fi[a];
             if (f.status == FE_EOF_START) break;
             if (f.status != FE_OK) { D.status[s] = f.status; break; }
@@ -496,7 +576,7 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
                     if (c >= 2) break;  // only subframes[1], [2] exist in the decorrelated modes; extra channels would be nil
                     if (c == 0) dep += (f.chan_asgn == 9 ? 1 : 0); else dep += (f.chan_asgn == 9 ? 0 : 1);
                 }
-                sub.push_back(SubJob{f.sub_bit[c], tot + (uint64_t)c * stride + sp, s, dep, f.blocksize, 0});
+                sub.push_back(SubJob{f.sub_bit[c], tot + (uint64_t)c * stride + sp, s, dep, f.blocksize, (int)f.kind[c]});
             }
             if (f.chan_asgn >= 8) {
                 if (D.channels != 2) { D.status[s] = FE_NIL; }
@@ -510,6 +590,8 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     // -- 5/6. decode the chained frames
     if ((rc = ctx->tmp_buf.ensure((size_t)tot * 8 + 64))) return rc;
     if (!sub.empty()) {
+        // lanes of a wave run in lock-step: group subframes that take the same code path (constant / verbatim / order class)
+        std::stable_sort(sub.begin(), sub.end(), [](const SubJob &x, const SubJob &y) { return x.pad < y.pad; });
         DevBuf &jb = ctx->seg_buf;
         const size_t sb = sub.size() * sizeof(SubJob), fb = fin.size() * sizeof(FinJob);
         if ((rc = jb.ensure(sb + fb + 64))) return rc;

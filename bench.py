@@ -140,7 +140,42 @@ class DfpwmTranscode(Workload):
         return int(self.outb.info()[1]) * 8
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, G711Cubic, ImaStream, DfpwmTranscode)}
+class FlacPipeline(Workload):
+    name, unit = "flac_pipeline", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        import numpy as np
+        from oracle import oracle as O  # the oracle's FLAC *encoder* only generates the synthetic input (the reference has none)
+        n = int(round(args.seconds * SRC_RATE))
+        rng = np.random.Generator(np.random.PCG64(0xA0C17 + 5000 + rank))
+        t = np.arange(n) / SRC_RATE
+        chans = [np.round((0.5 * np.sin(2 * np.pi * f * t) + rng.uniform(-0.25, 0.25, n)) * 32767 * 0.9) for f in (440.0, 330.0)]
+        one = O.gen_flac(np.stack(chans, 1).astype(np.int32).ravel(), 2, 16, SRC_RATE, 4096)
+        self.flac_bytes = len(one)
+        blob = torch.frombuffer(bytearray(one), dtype=torch.uint8).to(dev)
+        self.x = blob.repeat(args.streams)  # identical streams back to back (throughput does not depend on the content)
+        offs = [i * len(one) for i in range(args.streams + 1)]
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_FLAC)
+        self.a = B.AudioBatch(ctx)
+        self.m = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+
+        def step():
+            B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=self.dtype, out=self.a)
+            B.effect(ctx, self.a, "highpass", 20.0)
+            B.effect(ctx, self.a, "normalize", 0.8)
+            B.mono(ctx, self.a, out=self.m)
+        self.step = step
+        self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each) -> aukit.flac:resample(48000,'cubic') "
+                     f"-> highpass(20) -> normalize(0.8) -> mono, {args.dtype} store (config 5); unit = mono out-samples")
+        return self
+
+    def out_samples(self):
+        return int(self.m.layout()[0].sum())
+
+
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, G711Cubic, ImaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def main():
@@ -159,7 +194,7 @@ def main():
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = 16384 if args.workload == "dfpwm_transcode" else 4096
+        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048}.get(args.workload, 4096)
 
     import torch
     import torch.distributed as dist
