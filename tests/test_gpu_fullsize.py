@@ -1,0 +1,119 @@
+"""GPU: BASELINE.json's full batch sizes, checked through size-independent properties (the oracle only sees samples).
+
+  * config T (4096 × s16le 44.1 kHz 10 s → cubic → 48 kHz f32): every stream is one of 8 distinct signals, so the 4096
+    outputs must fall into 8 classes of bit-identical rows (catches any tile / segment / stream-offset mistake at scale);
+    one row per class is compared with the oracle (≤ 1e-6 RMS) and with the fp64 reference-order kernel.
+  * config 2 (4096 × µ-law 8 kHz → cubic): same construction.
+  * config 3 (4096 × 220 IMA blocks → stream.adpcm cubic): same, bit-exact vs oracle.
+  * config 4 (16384 × 120 000 B DFPWM stereo → mono → DFPWM): encode→decode round trip property + class identity + oracle bytes.
+Sizes are the BASELINE ones unless AUKIT_FULLSIZE_SCALE (default 1.0) shrinks the stream count.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import pcm16, rms, signal
+
+pytestmark = pytest.mark.gpu
+SCALE = float(os.environ.get("AUKIT_FULLSIZE_SCALE", "1.0"))
+K = 8  # distinct signals per batch
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+def _row_classes(out, n, ch_len, k):
+    """out: AudioBatch with n streams, 1 channel of length ch_len → (n, ch_len) view of the raw buffer as numpy."""
+    import ctypes as C
+    from aukit_amd import _native as N
+    inf = out.info()
+    lens, off, stride = out.layout()
+    assert np.all(lens == ch_len)
+    dt = {N.F64: np.float64, N.F32: np.float32, N.I8: np.int8}[inf["dtype"]]
+    raw = np.zeros(inf["total_elems"], dtype=dt)
+    N.check(N.lib().aukit_audio_download_raw(out.ctx._h, out._h, raw.ctypes.data_as(C.c_void_p)))
+    rows = raw.reshape(n, int(stride[0]))[:, :ch_len]
+    for c in range(k):
+        cls = rows[c::k]
+        assert np.array_equal(cls, np.broadcast_to(cls[0], cls.shape)), f"class {c}: rows differ"
+    return rows
+
+
+def test_config_T_full_batch(ctx, oracle):
+    B, N = _B(), _N()
+    n = max(K, int(4096 * SCALE) // K * K)
+    base = [pcm16(441000, 44100, 1, i).tobytes() for i in range(K)]
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    out = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave")
+    rows = _row_classes(out, n, 480000, K)
+    for c in (0, K - 1):
+        ref = oracle.resample(oracle.pcm(base[c], 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
+        assert rms(rows[c].astype(np.float64), ref.data[0]) <= 1e-6
+    # the fp64 reference-order kernel on the same batch: identical classes, ≤ 1e-6 RMS from the fast path, f32-rounded oracle values
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        out2 = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+        rows2 = _row_classes(out2, n, 480000, K)
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
+    ref = oracle.resample(oracle.pcm(base[0], 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
+    assert np.max(np.abs(rows2[0].astype(np.float64) - ref.data[0])) <= 1.2e-7  # f32 rounding of the exact value (± a pow3 ulp)
+    assert rms(rows[0].astype(np.float64), rows2[0].astype(np.float64)) <= 1e-6
+
+
+def test_config_2_full_batch(ctx, oracle):
+    B, N = _B(), _N()
+    n = max(K, int(4096 * SCALE) // K * K)
+    base = [oracle.gen_g711(pcm16(80000, 8000, 2, i), True) for i in range(K)]
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    desc = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
+    rows = _row_classes(B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32), n, 480000, K)
+    ref = oracle.resample(oracle.g711(base[3], True, 1, 8000), 48000, oracle.CUBIC)
+    assert rms(rows[3].astype(np.float64), ref.data[0]) <= 1e-6
+    out, ck = B.stream_decode(ctx, bt, desc, "cubic", dtype=N.I8)  # (b) stream.g711 ×10 calls, bit-exact incl. floor
+    assert np.all(ck.nchunks == 10) and np.all(ck.lens == 48000)
+    rows = _row_classes(out, n, 480000, K)
+    assert np.array_equal(rows[5], oracle.stream_g711(base[5], True, 1, 8000, False, oracle.CUBIC).data[0])
+
+
+def test_config_3_full_batch(ctx, oracle):
+    B, N = _B(), _N()
+    n = max(K, int(4096 * SCALE) // K * K)
+    base = [oracle.gen_ima(pcm16(1016 * 220, 22050, 3, i), 1, 512, 88) for i in range(K)]
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", dtype=N.I8)
+    assert np.all(ck.nchunks == 10) and np.all(ck.lens.sum(axis=1) == 486403)  # 219×2211 + 2194
+    rows = _row_classes(out, n, 486403, K)
+    for c in (0, 6):
+        assert np.array_equal(rows[c], oracle.stream_adpcm(base[c], 512, 1, 22050, False, oracle.CUBIC).data[0])
+
+
+def test_config_4_full_batch(ctx, oracle):
+    B, N = _B(), _N()
+    n = max(K, int(16384 * SCALE) // K * K)
+    base = []
+    for i in range(K):
+        l, r = np.round(signal(480000, 48000, 4, 2 * i) * 100), np.round(signal(480000, 48000, 4, 2 * i + 1) * 90)
+        base.append(oracle.dfpwm_encode(np.stack([l, r], 1).ravel()))
+    assert len(base[0]) == 120000
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    assert all(len(g) == 60010 for g in got)
+    for c in range(K):
+        assert all(g == got[c] for g in got[c::K])
+    for c in (0, K - 1):
+        assert got[c] == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(base[c], 2, 48000)), True)
+    # encode → decode round trip (lossy codec): the re-encoded mono stream still tracks the mono mix of the decoded input
+    a = oracle.mono(oracle.dfpwm(base[0], 2, 48000)).data[0]
+    back = oracle.DfpwmDecoder()(got[0]).astype(np.float64)[:len(a)] / 127  # plain decoder: no 6001-byte slicing, so no new duplicates
+    assert np.corrcoef(back, a)[0, 1] > 0.8

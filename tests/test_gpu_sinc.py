@@ -1,0 +1,45 @@
+"""GPU: interpolate.sinc (aukit.lua:267-281).  sin() comes from the device libm, so parity is tolerance-level (≤ 1e-12 on
+[-1,1] data); floored stream outputs may flip by one unit where the interpolated value is an integer to within 1e-13."""
+import numpy as np
+import pytest
+
+from tests.util import pcm16, signal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_audio_resample_sinc(ctx, oracle):
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    a = [[signal(6000, 22050, 9, 0)], [signal(333, 22050, 9, 1)]]
+    ab = B.AudioBatch.upload(ctx, a, 22050, dtype=N.F64)
+    for new_rate in (48000, 16000):
+        got = B.resample(ctx, ab, new_rate, "sinc").download()
+        for s in range(2):
+            ref = oracle.resample(oracle.Audio(a[s], 22050), new_rate, oracle.SINC)
+            assert len(got[s][0]) == len(ref.data[0])
+            assert np.max(np.abs(got[s][0] - ref.data[0])) <= 1e-12
+    ctx.set_sinc_window(30)  # LuaJIT hosts use a ±30 window (aukit.lua:129)
+    oracle.set_sinc_window(30)
+    try:
+        got = B.resample(ctx, ab, 48000, "sinc").download()
+        ref = oracle.resample(oracle.Audio(a[0], 22050), 48000, oracle.SINC)
+        assert np.max(np.abs(got[0][0] - ref.data[0])) <= 1e-12
+    finally:
+        ctx.set_sinc_window(10)
+        oracle.set_sinc_window(10)
+
+
+def test_fused_and_stream_sinc(ctx, oracle):
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    s = pcm16(9000, 44100, 1, 2).tobytes()
+    bt = B.Batch.upload(ctx, [s])
+    got = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), 48000, "sinc", dtype=N.F64).download()[0][0]
+    ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.SINC)
+    assert np.max(np.abs(got - ref.data[0])) <= 1e-12
+    g = oracle.gen_g711(pcm16(12000, 8000, 2, 3), True)
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [g]), B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True), "sinc", dtype=N.I8)
+    ref = oracle.stream_g711(g, True, 1, 8000, False, oracle.SINC)
+    d = out.download()[0][0] - ref.data[0]
+    assert np.max(np.abs(d)) <= 1 and np.count_nonzero(d) <= 2

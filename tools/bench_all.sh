@@ -1,11 +1,17 @@
 #!/bin/bash
-# runs every bench workload once and prints a compact summary (GPU box)
-for w in pcm16_cubic g711_cubic ima_stream dfpwm_transcode; do
-  python bench.py --workload $w --steps ${STEPS:-10} --warmup 2 --cpu-streams 0 2>&1 | tail -1 | python -c "
-import sys,json
-try:
-    d=json.loads(sys.stdin.read()); r=d['roofline']
-    print('$w', 'Gsamples/s=%.1f'%(d['value']/1e3), 'ms=%.3f'%r['kernel_ms'], 'GB/s=%.0f'%r['achieved'], r['kernel'])
-except Exception as e: print('$w FAILED', e)
-"
+# runs every bench workload once, appends the JSON lines to gpurun_out/bench_lines.jsonl and prints a compact summary (GPU box)
+mkdir -p gpurun_out
+: > gpurun_out/bench_lines.jsonl
+python bench.py 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
+for w in g711_cubic ima_stream dfpwm_transcode flac_pipeline; do
+  python bench.py --workload $w --steps ${STEPS:-5} --warmup 1 --cpu-streams 0 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
 done
+python - <<'PY'
+import json
+for l in open("gpurun_out/bench_lines.jsonl"):
+    try:
+        d = json.loads(l); r = d["roofline"]
+        print("%-70s %9.1f Gsamples/s  %8.3f ms/step  last kernel %s (%.0f GB/s)" % (d["config"]["workload"][:70], d["value"] / 1e3, d["ms_per_step"], r["kernel"], r["achieved"]))
+    except Exception as e:
+        print("bad line", e)
+PY
