@@ -11,7 +11,10 @@
 
 namespace aukit {
 
-constexpr int WT = 1024;  // outputs per wave tile = 16 rows of 64
+#ifndef AUKIT_WT
+#define AUKIT_WT 1024
+#endif
+constexpr int WT = AUKIT_WT;  // outputs per wave tile = 16 rows of 64
 
 template <int SRC> struct SrcTraits;
 template <> struct SrcTraits<SRC_PCM_S16LE_MONO> { static constexpr int BYTES = 2, SPV = 8; };
@@ -266,7 +269,8 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     *taken = true;
     if (P.n_tiles == 0) return AUKIT_OK;
     if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
-    size_t lds = (size_t)F.cap * 4 * 4 + 4 * 256 * 4;  // 4 wave windows + 4 × 1 KiB of store-transpose staging
+    if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
+    size_t lds = (size_t)F.cap * 4 * 4 + (P.nt_store == 2 ? 4 * 256 * 4 : 0);  // 4 wave windows (+ 4 × 1 KiB of store-transpose staging in the x4 experiment)
     unsigned per_cu = 16;  // 2x the resident workgroups: measured +3.5 % over 8 (better tail balance across XCDs)
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     unsigned nblk_needed = (P.n_tiles + 3) / 4;
