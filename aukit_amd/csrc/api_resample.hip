@@ -376,7 +376,7 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     const int ip = do_resample ? interp : AUKIT_INTERP_NONE;
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, ip, 1, P, &lds))) return rc;
-    return launch_resample(ctx, src_kind, ip, EPI_AUDIO, dtype, P, lds, in_elems * (src_kind == SRC_I16 ? 2 : 1) + out_elems * dtype_size(dtype), nullptr);
+    return launch_resample(ctx, src_kind, ip, EPI_AUDIO, dtype, P, lds, in_elems * (src_kind == SRC_I16 ? 2 : src_kind == SRC_I32 || src_kind == SRC_AUDIO_F32 ? 4 : src_kind == SRC_AUDIO_F64 ? 8 : 1) + out_elems * dtype_size(dtype), nullptr);
 }
 
 }  // namespace aukit

@@ -50,7 +50,7 @@ struct aukit_ctx {
     uint64_t last_bytes = 0;
     int num_cus = 256;
     // scratch tables (segment/tile/stream descriptors); plan_key caches the last uploaded plan
-    aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2;
+    aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2, tmp_buf3;
     std::string plan_key;
     // verified range of the reciprocal-based exact division per ratio (see exact_div_verified)
     std::map<double, uint64_t> div_ok;

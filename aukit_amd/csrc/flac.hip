@@ -3,15 +3,24 @@
 // FLAC frames carry no length, and the reference simply decodes them one after another (aukit.lua:615), ignoring
 // the CRCs (:553, :557).  To decode frames in parallel without changing which bytes are treated as frames:
 //   1. k_flac_header   one lane per stream walks the metadata blocks (:573-606) → STREAMINFO + first frame byte;
-//   2. k_flac_find     every byte position that starts with the 14-bit sync code 0x3FFE (:518) is a candidate;
-//   3. k_flac_parse    one lane per candidate parses the frame exactly like decodeFrame (Rice prefix by clz on a
-//                      64-bit window) WITHOUT storing samples → end position, block size, subframe bit offsets, status;
-//   4. host            follows end → start links from the first frame: precisely the frames the serial decoder visits;
-//   5. k_flac_subframe one lane per (frame, subframe): residual decode + LPC restore on the fly (history in VGPRs);
-//   6. k_flac_finish   stereo decorrelation (:482-497), wrap and / 2^depth (:501-507, Q14).
-// Integer work throughout (exact); only the final division produces the reference's doubles.
+//   2. k_flac_find     every byte position that starts with the 14-bit sync code 0x3FFE (:518) and carries a valid
+//                      header CRC-8 is a candidate; candidates go into a list and a byte-position hash table;
+//   3. k_flac_extract  one lane per candidate walks the frame exactly like decodeFrame does and writes, per subframe,
+//                      the warm-up samples + Rice residuals (integers, :380-409) to a scratch array and the predictor
+//                      (order, coefficients, shifts) to a descriptor — no prediction yet, so every lane of a wave runs
+//                      the same bit-reading code whatever the subframe types are;
+//   4. k_flac_chain    one lane per stream follows end → start links through the hash table from the first frame:
+//                      precisely the frames the serial decoder visits; positions that are not in the table (CRC filter,
+//                      no sync) are extracted on demand by the host loop, so the filter never changes the result;
+//   5. k_flac_jobs     chained subframes → job list grouped by predictor-order class;
+//   6. k_flac_restore  restoreLinearPrediction (:411-419) + wasted-bits shift (:467-469), one lane per subframe;
+//   7. k_flac_finish   stereo decorrelation (:482-497) and wrap (:501-507, Q14) in place.
+// Steps 3 and 6 stage everything through LDS so that global loads/stores are contiguous 128-byte runs per subframe
+// (round 1 had each lane walk its own bytes from global memory: 48 + 36 ms per 3.6 GB batch, both latency-bound).
+// Rows are int32 when the bit depth is ≤ 24 and no value overflows (checked everywhere; a flagged batch is redone with
+// double rows and the Lua's own floating-point prediction, so even absurd values round the way the reference rounds them).  The division by 2^depth (:505) happens in the consumer.
 #include <algorithm>
-#include <map>
+#include <type_traits>
 #include "resample.h"
 
 namespace aukit {
@@ -20,9 +29,11 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
                         double norm_neg, aukit_audio **out);
 
+typedef unsigned long long u64;
+
 enum FlacErr { FE_OK = 0, FE_EOF_START = 1 /* readByte() == nil at a frame start: clean end */, FE_NIL = 2, FE_SYNC = 3, FE_BLOCKSIZE = 4,
                FE_CHAN = 5, FE_SUBTYPE = 6, FE_RESMETHOD = 7, FE_PARTITION = 8,
-               FE_LIMIT = 9 /* parse pass only: the candidate ran past its bit budget; re-parsed without a budget if the chain needs it */ };
+               FE_LIMIT = 9 /* the candidate ran past its bit budget; extracted again without a budget if the chain needs it */ };
 static const char *flac_err_msg(int e) {
     switch (e) {
     case FE_NIL: return "attempt to perform arithmetic on a nil value";
@@ -35,29 +46,50 @@ static const char *flac_err_msg(int e) {
     }
     return "FLAC decode error";
 }
+enum { FLAG_OVERFLOW = 1, FLAG_INTERNAL = 2 };
 
-// MSB-first bit reader over [first_bit, end_bit) of the batch buffer.  Three big-endian 64-bit words are kept in
-// registers (current, next, next-but-one): a Rice-coded sample consumes ≈15 bits, so one 8-byte load is issued every
-// ≈4 samples and it is not needed until the following word crossing — the load latency stays off the decode chain
-// (the first version re-loaded 16 bytes for every bit-field: 72 + 82 ms per 3.6 GB batch, see profiles/).
+constexpr int WN = 16;    // 64-bit words of bit-stream window per lane in LDS (128 bytes)
+constexpr int WSTR = 17;  // row stride of the window array (words): lanes L and L+32 share a bank pair, nothing worse
+constexpr int NC = 32;    // values a lane produces (extract) / restores (restore) per round
+constexpr int OSTR = 33;  // row stride of the value array
+
+struct FlacStreamInfo { u64 first_byte; double rate, nsamples; int channels, depth, status, pad; };
+
+struct FlacGlobals {
+    const unsigned char *src;  // batch data
+    const u64 *w0;             // 16-byte aligned base at or below src
+    u64 base_bit;              // bit offset of src relative to w0
+    u64 safe_words;            // even; 16-byte vectors [w0 + 2k, w0 + 2k + 2) with 2k < safe_words touch the batch (same page as a valid byte)
+    const u64 *off;
+    const FlacStreamInfo *info;
+};
+
+// MSB-first bit reader over [first, end) of the batch buffer.  Three big-endian 64-bit words are kept in registers
+// (current, next, next-but-one); they are refilled from the lane's LDS window, or from global memory when a field
+// reaches outside the window (long warm-up / coefficient runs, the 44-bit look-back of readUint(n >= 32)).
 struct Bits {
-    const unsigned long long *w0;   // 8-byte aligned base at or below the batch data
-    unsigned long long first, end;  // bit offsets (relative to w0) of the BitInputStream start and of the end of the string
-    unsigned long long pos;
-    unsigned long long cur, nxt, nxt2, wi;
-    unsigned long long limit;       // parse pass: give up (FE_LIMIT) beyond this bit — bounds the work of false sync candidates
-    int kind;                       // parse pass: code-path class of the last subframe (0 const, 1 verbatim, 2/3/4 order <= 4/12/32, 5 wide)
+    const u64 *w0;
+    const u64 *lw;      // this lane's window row: lw[d] = big-endian word win_lo + d
+    u64 safe_words;
+    u64 first, end;     // bit offsets (relative to w0) of the BitInputStream start and of the end of the string
+    u64 pos, limit;
+    u64 cur, nxt, nxt2, wi, win_lo;
     int eof;
 };
-AUKIT_DEV unsigned long long be64(unsigned long long v) { return __builtin_bswap64(v); }
-AUKIT_DEV void bits_seek(Bits &b, unsigned long long pos) {
+AUKIT_DEV u64 be64(u64 v) { return __builtin_bswap64(v); }
+AUKIT_DEV u64 fetch(const Bits &b, u64 wi) {
+    const u64 d = wi - b.win_lo;
+    if (d < (u64)WN) return b.lw[d];
+    return wi < b.safe_words ? be64(b.w0[wi]) : 0ull;
+}
+AUKIT_DEV void bits_seek(Bits &b, u64 pos) {
     b.pos = pos;
     b.wi = pos >> 6;
-    b.cur = be64(b.w0[b.wi]);
-    b.nxt = be64(b.w0[b.wi + 1]);
-    b.nxt2 = be64(b.w0[b.wi + 2]);
+    b.cur = fetch(b, b.wi);
+    b.nxt = fetch(b, b.wi + 1);
+    b.nxt2 = fetch(b, b.wi + 2);
 }
-AUKIT_DEV unsigned long long peek(const Bits &b) {
+AUKIT_DEV u64 peek(const Bits &b) {
     const unsigned s = (unsigned)b.pos & 63;
     return s ? (b.cur << s) | (b.nxt >> (64 - s)) : b.cur;
 }
@@ -67,31 +99,31 @@ AUKIT_DEV void skip(Bits &b, unsigned n) {  // n <= 64
         b.wi++;
         b.cur = b.nxt;
         b.nxt = b.nxt2;
-        b.nxt2 = be64(b.w0[b.wi + 2]);
+        b.nxt2 = fetch(b, b.wi + 2);
     }
 }
-AUKIT_DEV unsigned long long peek_at(const Bits &b, unsigned long long pos) {  // uncached, any position
-    const unsigned long long wi = pos >> 6;
+AUKIT_DEV u64 peek_at(const Bits &b, u64 pos) {  // uncached, any position
+    const u64 wi = pos >> 6;
     const unsigned s = (unsigned)pos & 63;
-    const unsigned long long hi = be64(b.w0[wi]);
+    const u64 hi = fetch(b, wi);
     if (s == 0) return hi;
-    return (hi << s) | (be64(b.w0[wi + 1]) >> (64 - s));
+    return (hi << s) | (fetch(b, wi + 1) >> (64 - s));
 }
 // BitInputStream.readUint(n)  :351-364, n <= 57.  n >= 32 keeps the stale high bits of the 44-bit buffer like the Lua does.
 AUKIT_DEV long long read_uint(Bits &b, int n) {
     if (n == 0) return 0;
-    if (b.pos + (unsigned long long)n > b.end) { b.eof = 1; return 0; }  // str_byte → nil
+    if (b.pos + (u64)n > b.end) { b.eof = 1; return 0; }  // str_byte → nil
     if (n < 32) {
-        const unsigned long long v = peek(b) >> (64 - n);
+        const u64 v = peek(b) >> (64 - n);
         skip(b, (unsigned)n);
         return (long long)v;
     }
-    const unsigned long long after = b.pos + n;
+    const u64 after = b.pos + n;
     const int L = (int)((8 - ((after - b.first) & 7)) & 7);  // bits left in the buffer after this read
     int width = 44 - L;
-    unsigned long long s = after - (unsigned long long)width;
-    if (after < b.first + (unsigned long long)width) { width = (int)(after - b.first); s = b.first; }
-    const unsigned long long v = peek_at(b, s) >> (64 - width);
+    u64 s = after - (u64)width;
+    if (after < b.first + (u64)width) { width = (int)(after - b.first); s = b.first; }
+    const u64 v = peek_at(b, s) >> (64 - width);
     skip(b, (unsigned)n);
     return (long long)v;
 }
@@ -104,10 +136,10 @@ AUKIT_DEV long long read_rice(Bits &b, int param) {  // :370-376
     long long val = 0;
     for (;;) {
         if (b.pos >= b.end) { b.eof = 1; return 0; }
-        const unsigned long long w = peek(b);
-        const unsigned long long avail = b.end - b.pos;
+        const u64 w = peek(b);
+        const u64 avail = b.end - b.pos;
         int z = w ? __builtin_clzll(w) : 64;
-        if ((unsigned long long)z >= avail) { b.eof = 1; return 0; }  // ran off the end inside the unary prefix
+        if ((u64)z >= avail) { b.eof = 1; return 0; }  // ran off the end inside the unary prefix
         if (z < 64) { val += z; skip(b, (unsigned)z + 1); break; }
         val += 64;
         skip(b, 64);
@@ -116,34 +148,24 @@ AUKIT_DEV long long read_rice(Bits &b, int param) {  // :370-376
     return (val & 1) ? -(val >> 1) - 1 : (val >> 1);
 }
 
-struct FrameInfo {                 // result of parsing one candidate
-    unsigned long long start_bit;  // relative to w0
-    unsigned long long end_bit;    // first bit after the frame's CRC-16 (byte aligned)
-    unsigned long long sub_bit[AUKIT_MAX_CHANNELS];
-    int blocksize, chan_asgn, status, pad;
-    unsigned char kind[AUKIT_MAX_CHANNELS];
-};
-
-struct FlacStreamInfo { unsigned long long first_byte; double rate, nsamples; int channels, depth, status, pad; };
-
 // decodeFLAC header + metadata blocks  :569-606
-__global__ __launch_bounds__(64) void k_flac_header(const unsigned char *src, const unsigned long long *off, unsigned n, FlacStreamInfo *out) {
+__global__ __launch_bounds__(64) void k_flac_header(const unsigned char *src, const u64 *off, unsigned n, FlacStreamInfo *out) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     const unsigned char *p = src + off[s];
-    const unsigned long long nb = off[s + 1] - off[s];
+    const u64 nb = off[s + 1] - off[s];
     FlacStreamInfo r{};
     r.status = 0;
     if (nb < 4) { r.status = 1; out[s] = r; return; }                                                    // nil arithmetic in intunpack
     if (!(p[0] == 0x66 && p[1] == 0x4C && p[2] == 0x61 && p[3] == 0x43)) { r.status = 2; out[s] = r; return; }  // "Invalid magic string"
-    unsigned long long pos = 4;
+    u64 pos = 4;
     bool last = false, have = false;
     while (!last) {
         if (pos + 4 > nb) { r.status = 1; out[s] = r; return; }
         const int t = p[pos];
         last = (t & 0x80) != 0;
         const int type = t & 0x7F;
-        const unsigned long long length = (unsigned long long)p[pos + 1] << 16 | (unsigned long long)p[pos + 2] << 8 | p[pos + 3];
+        const u64 length = (u64)p[pos + 1] << 16 | (u64)p[pos + 2] << 8 | p[pos + 3];
         pos += 4;
         if (type == 0) {
             if (pos + 34 > nb) { r.status = 1; out[s] = r; return; }
@@ -163,11 +185,11 @@ __global__ __launch_bounds__(64) void k_flac_header(const unsigned char *src, co
 }
 
 // frame-header length as decodeFrame walks it (:518-553) and CRC-8 (poly 0x07) over it; false when the header does not fit
-AUKIT_DEV bool flac_header_crc_ok(const unsigned char *src, unsigned long long p, unsigned long long end) {
+AUKIT_DEV bool flac_header_crc_ok(const unsigned char *src, u64 p, u64 end) {
     if (p + 6 > end) return false;
     const unsigned b2 = src[p + 2];
     const unsigned bsc = b2 >> 4, src_code = b2 & 15;
-    unsigned long long idx = p + 4;
+    u64 idx = p + 4;
     const unsigned t = src[idx];
     int lead = 0;
     for (int i = 7; i >= 0; i--) { if (!(t & (1u << i))) break; lead++; }
@@ -176,291 +198,729 @@ AUKIT_DEV bool flac_header_crc_ok(const unsigned char *src, unsigned long long p
     if (src_code == 12) idx += 1; else if (src_code == 13 || src_code == 14) idx += 2;
     if (idx >= end) return false;
     unsigned crc = 0;
-    for (unsigned long long q = p; q < idx; q++) {
+    for (u64 q = p; q < idx; q++) {
         crc ^= src[q];
         for (int k = 0; k < 8; k++) crc = (crc & 0x80) ? ((crc << 1) ^ 0x07) & 0xFF : (crc << 1) & 0xFF;
     }
     return crc == src[idx];
 }
 
-struct Cand { unsigned stream; unsigned pad; unsigned long long byte; };  // byte: absolute in the batch
+struct Cand { unsigned stream; unsigned nolimit; u64 byte; };  // byte: absolute in the batch
 
-__global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, const unsigned long long *off, const FlacStreamInfo *info, unsigned n,
-                                                  Cand *cands, unsigned long long cap, unsigned long long *count) {
+// byte position → candidate index (open addressing, linear probing; empty key = ~0)
+struct CandHash { u64 *keys; unsigned *vals; unsigned shift; u64 mask; };
+AUKIT_DEV u64 hash_slot(const CandHash &H, u64 key) { return (key * 0x9E3779B97F4A7C15ull) >> H.shift; }
+AUKIT_DEV void hash_insert(const CandHash &H, u64 key, unsigned val) {
+    u64 h = hash_slot(H, key);
+    for (;;) {
+        const u64 prev = atomicCAS(&H.keys[h], ~0ull, key);
+        if (prev == ~0ull) { H.vals[h] = val; return; }
+        if (prev == key) return;
+        h = (h + 1) & H.mask;
+    }
+}
+AUKIT_DEV unsigned hash_lookup(const CandHash &H, u64 key) {
+    u64 h = hash_slot(H, key);
+    for (;;) {
+        const u64 k = H.keys[h];
+        if (k == key) return H.vals[h];
+        if (k == ~0ull) return ~0u;
+        h = (h + 1) & H.mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, const u64 *off, const FlacStreamInfo *info, unsigned n,
+                                                  Cand *cands, u64 cap, u64 *count, CandHash H) {
     const unsigned s = blockIdx.y;
     if (info[s].status) return;
-    const unsigned long long b0 = off[s] + info[s].first_byte, b1 = off[s + 1];
-    for (unsigned long long p = b0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; p + 1 < b1; p += (unsigned long long)gridDim.x * 256) {
+    const u64 b0 = off[s] + info[s].first_byte, b1 = off[s + 1];
+    for (u64 p = b0 + (u64)blockIdx.x * 256 + threadIdx.x; p + 1 < b1; p += (u64)gridDim.x * 256) {
         if (src[p] == 0xFF && (src[p + 1] & 0xFC) == 0xF8) {  // temp * 64 + readUint(6) == 0x3FFE  :518
             // Speed-only filter: keep candidates whose header CRC-8 checks out.  The reference ignores the CRC (:553), so a
-            // real frame with a damaged CRC is still decoded: the host parses any chain position that is not in this list on demand.
+            // real frame with a damaged CRC is still decoded: the chain asks for any position that is not in the table.
             if (!flac_header_crc_ok(src, p, b1)) continue;
-            const unsigned long long k = atomicAdd(count, 1ull);
-            if (k < cap) cands[k] = Cand{s, 0, p};
+            const u64 k = atomicAdd(count, 1ull);
+            if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
         }
     }
 }
-
-// decodeResiduals (:380-409) + restoreLinearPrediction (:411-419) fused: every residual is turned into a sample at once,
-// with the last MAXO samples in registers (hist[j] = result[i-1-j]).  STORE = false only advances the bit reader.
-template <bool STORE, int MAXO, typename H>
-AUKIT_DEV int flac_residuals(Bits &b, int order, int blocksize, int lshift, H *hist, const H *coef, long long mul, double *out) {
-    const int method = (int)read_uint(b, 2);
-    if (b.eof) return FE_NIL;
-    if (method >= 2) return FE_RESMETHOD;
-    const int param_bits = method == 0 ? 4 : 5, escape = method == 0 ? 0xF : 0x1F;
-    const int porder = (int)read_uint(b, 4);
-    const int nparts = 1 << porder;
-    if (blocksize % nparts != 0) return FE_PARTITION;
-    const int psize = blocksize / nparts;
-    for (int pi = 0; pi < nparts; pi++) {
-        const int start = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
-        const int param = (int)read_uint(b, param_bits);
-        int nbits = 0;
-        const bool esc = param >= escape;
-        if (esc) nbits = (int)read_uint(b, 5);
-        if (b.eof) return FE_NIL;
-        if (!STORE && b.pos > b.limit) return FE_LIMIT;
-        for (int j = start; j < endd; j++) {
-            const long long r = esc ? read_sint(b, nbits) : read_rice(b, param);
-            if constexpr (STORE) {
-                long long sum = 0;
-#pragma unroll
-                for (int q = 0; q < MAXO; q++) sum += (long long)hist[q] * (long long)coef[q];
-                const long long pred = lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));  // floor(sum / 2^shift)
-                const long long v = r + pred;
-                out[j] = (double)(v * mul);
-#pragma unroll
-                for (int q = MAXO - 1; q > 0; q--) hist[q] = hist[q - 1];
-                hist[0] = (H)v;
-            }
-        }
-        if (b.eof) return FE_NIL;
-    }
-    return FE_OK;
+__global__ __launch_bounds__(64) void k_flac_hash_insert(const Cand *cands, unsigned first, unsigned count, CandHash H) {
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    if (i < count) hash_insert(H, cands[first + i].byte, first + i);
 }
 
-template <int MAXO, typename H>
-AUKIT_DEV int flac_predict(Bits &b, int type, int order, int depth, int blocksize, long long mul, double *out) {
-    H hist[MAXO], coef[MAXO];
-#pragma unroll
-    for (int j = 0; j < MAXO; j++) { hist[j] = 0; coef[j] = 0; }
-    for (int i = 0; i < order; i++) {  // warm-up samples :422-424 / :430-432
-        const long long v = read_sint(b, depth);
-        if (i < blocksize) out[i] = (double)(v * mul);
-#pragma unroll
-        for (int j = MAXO - 1; j > 0; j--) hist[j] = hist[j - 1];
-        hist[0] = (H)v;
-    }
-    int lshift = 0;
-    if (type >= 32) {
-        const int precision = (int)read_uint(b, 4) + 1;
-        lshift = (int)read_sint(b, 5);
-        for (int i = 0; i < order; i++) {
-            const long long c = read_sint(b, precision);
-#pragma unroll
-            for (int j = 0; j < MAXO; j++) if (j == i) coef[j] = (H)c;
-        }
-    } else {  // FIXED_PREDICTION_COEFFICIENTS  :334-340
-        const int fc[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (j < MAXO) coef[j] = (H)fc[order][j];
-    }
-    if (b.eof) return FE_NIL;
-    return flac_residuals<true, MAXO, H>(b, order, blocksize, lshift, hist, coef, mul, out);
-}
+struct CandInfo {
+    u64 end_byte;     // absolute byte after the frame's CRC-16
+    u64 scratch;      // element offset of subframe 0 in the scratch array; subframe c at + c * blocksize
+    u64 sample_off;   // chain: samples of the stream before this frame
+    int blocksize, chan_asgn, status, nsub;
+    unsigned seq, used;
+};
+struct SubDesc { int order, lshift, wasted, kind; short coef[32]; };  // kind: 0 = no prediction, 1/2/3 = order <= 4/12/32
 
-// decodeSubframe (:443-470) on a bit reader.  STORE = false: parse only; STORE = true: residual + prediction restored on the fly.
-template <bool STORE>
-AUKIT_DEV int flac_subframe(Bits &b, int depth, int blocksize, double *out) {
-    read_uint(b, 1);
-    const int type = (int)read_uint(b, 6);
-    int shift = (int)read_uint(b, 1);
-    if (shift == 1) {  // unary wasted-bits count  :447-449
-        for (;;) {
-            const long long bit = read_uint(b, 1);
-            if (b.eof) return FE_NIL;
-            if (bit) break;
-            shift++;
-        }
-    }
-    if (b.eof) return FE_NIL;
-    depth -= shift;
-    if (depth < 0 || depth > 57) return FE_NIL;  // 2^(n-1) with a negative n misbehaves in the Lua too; treat as malformed
-    const long long mul = 1ll << shift;
-    if (type == 0) {
-        b.kind = 0;
-        const long long c = read_sint(b, depth);
-        if (b.eof) return FE_NIL;
-        if (STORE) for (int i = 0; i < blocksize; i++) out[i] = (double)(c * mul);
-        return FE_OK;
-    }
-    if (type == 1) {
-        b.kind = 1;
-        for (int i = 0; i < blocksize; i++) {
-            if (!STORE && (i & 255) == 0 && b.pos > b.limit) return FE_LIMIT;
-            const long long v = read_sint(b, depth);
-            if (STORE) out[i] = (double)(v * mul);
-        }
-        return b.eof ? FE_NIL : FE_OK;
-    }
-    int order, lshift = 0;
-    if (type >= 8 && type <= 12) order = type - 8;
-    else if (type >= 32 && type <= 63) order = type - 31;
-    else return FE_SUBTYPE;
-    if (!STORE) {  // parse only: consume warm-up, coefficients and residuals
-        b.kind = depth > 31 ? 5 : (order <= 4 ? 2 : (order <= 12 ? 3 : 4));
-        for (int i = 0; i < order; i++) read_sint(b, depth);
-        if (type >= 32) {
-            const int precision = (int)read_uint(b, 4) + 1;
-            read_sint(b, 5);
-            for (int i = 0; i < order; i++) read_sint(b, precision);
-        }
-        if (b.eof) return FE_NIL;
-        return flac_residuals<false, 1, int>(b, order, blocksize, 0, nullptr, nullptr, 1, nullptr);
-    }
-    // 8/16/24-bit audio: history and coefficients fit int32 (one v_mad_i64_i32 per tap); 32-bit audio takes the int64 path
-    if (depth <= 31) {
-        if (order <= 4) return flac_predict<4, int>(b, type, order, depth, blocksize, mul, out);
-        if (order <= 12) return flac_predict<12, int>(b, type, order, depth, blocksize, mul, out);
-        return flac_predict<32, int>(b, type, order, depth, blocksize, mul, out);
-    }
-    return flac_predict<32, long long>(b, type, order, depth, blocksize, mul, out);
-}
+enum { ST_FRAME = 0, ST_SUB, ST_WARM, ST_CONST, ST_COEF, ST_PART, ST_CODES, ST_SUBEND, ST_FRAMEEND, ST_DIRECT_WAIT, ST_DONE };
 
-struct FlacGlobals {
-    const unsigned char *src;           // batch data
-    const unsigned long long *w0;       // aligned base
-    unsigned long long base_bit;        // bit offset of src relative to w0
-    const unsigned long long *off;
-    const FlacStreamInfo *info;
+template <typename R> struct ExtractArgs {
+    FlacGlobals G;
+    const Cand *cands;
+    unsigned first, count;  // candidates [first, first + count)
+    CandInfo *ci;
+    SubDesc *sd;
+    int C;                  // channels of the batch = descriptors per candidate
+    R *scratch;
+    u64 scratch_cap;        // elements
+    u64 *scratch_cursor;
+    unsigned *flags;
+    int limit_factor;
 };
 
-// decodeFrame header + parse-only subframes  :510-557
-__global__ __launch_bounds__(64) void k_flac_parse(const FlacGlobals G, const Cand *cands, unsigned long long ncand, FrameInfo *out, int limit_factor) {
-    const unsigned long long ci = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
-    if (ci >= ncand) return;
-    const Cand c = cands[ci];
-    const FlacStreamInfo si = G.info[c.stream];
+// decodeFrame (:510-557) without prediction: header, per-subframe warm-up / residual values → scratch, predictor → SubDesc.
+template <typename R>
+__global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
+    __shared__ u64 s_win[64 * WSTR];
+    __shared__ R s_out[64 * OSTR];
+    __shared__ u64 s_ptr[64];
+    __shared__ int s_cnt[64];
+    const int lane = threadIdx.x;
+    const unsigned rel = blockIdx.x * 64 + lane;
+    const bool valid = rel < A.count;
+    const unsigned idx = A.first + (valid ? rel : 0);
+    const Cand c = A.cands[idx];
+    const FlacStreamInfo si = A.G.info[c.stream];
+    const int C = A.C, depth = si.depth;
     Bits b;
-    b.w0 = G.w0;
-    b.first = G.base_bit + 8 * (G.off[c.stream] + si.first_byte);
-    b.end = G.base_bit + 8 * G.off[c.stream + 1];
+    b.w0 = A.G.w0;
+    b.lw = s_win + lane * WSTR;
+    b.safe_words = A.G.safe_words;
+    b.first = A.G.base_bit + 8 * (A.G.off[c.stream] + si.first_byte);
+    b.end = A.G.base_bit + 8 * A.G.off[c.stream + 1];
     b.eof = 0;
     b.limit = ~0ull;
-    b.kind = 0;
-    bits_seek(b, G.base_bit + 8 * c.byte);
-    FrameInfo f{};
-    f.start_bit = b.pos;
-    f.status = FE_OK;
-    const long long t0 = read_uint(b, 8);
-    if (b.eof) { f.status = FE_EOF_START; out[ci] = f; return; }
-    const long long sync = t0 * 64 + read_uint(b, 6);
-    if (b.eof) { f.status = FE_NIL; out[ci] = f; return; }
-    if (sync != 0x3FFE) { f.status = FE_SYNC; out[ci] = f; return; }
-    read_uint(b, 2);
-    const int bsc = (int)read_uint(b, 4), src_code = (int)read_uint(b, 4);
-    f.chan_asgn = (int)read_uint(b, 4);
-    read_uint(b, 4);
-    const int t = (int)read_uint(b, 8);
-    if (b.eof) { f.status = FE_NIL; out[ci] = f; return; }
-    int t2 = -1;
-    for (int i = 7; i >= 0; i--) { if (!(t & (1 << i))) break; t2++; }
-    for (int i = 1; i <= t2; i++) read_uint(b, 8);
-    int bs;
-    if (bsc == 1) bs = 192;
-    else if (bsc >= 2 && bsc <= 5) bs = 576 << (bsc - 2);
-    else if (bsc == 6) bs = (int)read_uint(b, 8) + 1;
-    else if (bsc == 7) bs = (int)read_uint(b, 16) + 1;
-    else if (bsc >= 8) bs = 256 << (bsc - 8);
-    else { f.status = FE_BLOCKSIZE; out[ci] = f; return; }
-    if (src_code == 12) read_uint(b, 8);
-    else if (src_code == 13 || src_code == 14) read_uint(b, 16);
-    read_uint(b, 8);  // CRC-8, ignored :553
-    if (b.eof) { f.status = FE_NIL; out[ci] = f; return; }
-    f.blocksize = bs;
-    // bit budget: `limit_factor` times the size of an all-VERBATIM frame (no encoder emits a bigger one; the chain re-parses without it if needed)
-    b.limit = limit_factor > 0 ? b.pos + (unsigned long long)limit_factor * (unsigned long long)bs * (unsigned long long)si.channels * (unsigned long long)(si.depth + 2) + 4096 : ~0ull;
-    const int nch = si.channels, depth = si.depth;
-    int st = FE_OK;
-    if (f.chan_asgn <= 7) {
-        for (int ch = 0; ch < nch && st == FE_OK; ch++) { f.sub_bit[ch] = b.pos; st = flac_subframe<false>(b, depth, bs, nullptr); f.kind[ch] = (unsigned char)b.kind; }
-    } else if (f.chan_asgn <= 10) {
-        if (nch < 2) st = FE_NIL;
-        else {
-            f.sub_bit[0] = b.pos;
-            st = flac_subframe<false>(b, depth + (f.chan_asgn == 9 ? 1 : 0), bs, nullptr);
-            f.kind[0] = (unsigned char)b.kind;
-            if (st == FE_OK) { f.sub_bit[1] = b.pos; st = flac_subframe<false>(b, depth + (f.chan_asgn == 9 ? 0 : 1), bs, nullptr); f.kind[1] = (unsigned char)b.kind; }
+    b.pos = A.G.base_bit + 8 * c.byte;
+    b.wi = b.pos >> 6;
+    b.win_lo = 0; b.cur = b.nxt = b.nxt2 = 0;
+    int st = valid ? ST_FRAME : ST_DONE;
+    bool fresh = true;
+    int status = FE_OK, bs = 0, chan_asgn = 0, nsub = 0, ch = 0;
+    int order = 0, type = 0, wasted = 0, sdepth = 0, lshift = 0, after = ST_SUBEND, resume = ST_SUB;
+    int nparts = 0, psize = 0, pi = 0, param = 0, nbits = 0, param_bits = 4, escape = 15, remaining = 0, jpos = 0;
+    bool esc = false, direct = false, store_ok = false, ovf = false;
+    long long cval = 0;
+    u64 cand_scratch = 0, gcur = 0, end_byte = 0;
+    SubDesc *sd = A.sd + (size_t)idx * C;
+    R *const orow = s_out + lane * OSTR;
+
+    for (;;) {
+        // ---- slide the LDS windows of the lanes that have used half of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
+        {
+            const bool want = st != ST_DONE && (fresh || (b.wi - b.win_lo) >= (u64)(WN / 2));
+            const u64 new_lo = b.wi & ~1ull;
+            if (want) b.win_lo = new_lo;
+            const int sub8 = lane & 7, grp = lane >> 3;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int s = i * 8 + grp;
+                const int w = __shfl((int)want, s);
+                const u64 ws = __shfl(new_lo, s);
+                if (w) {
+                    const u64 wj = ws + 2 * (u64)sub8;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (wj < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + wj);
+                    s_win[s * WSTR + 2 * sub8] = be64((u64)v.x | (u64)v.y << 32);
+                    s_win[s * WSTR + 2 * sub8 + 1] = be64((u64)v.z | (u64)v.w << 32);
+                }
+            }
+            __syncthreads();
+            if (fresh && st != ST_DONE) { bits_seek(b, b.pos); fresh = false; }
         }
-    } else st = FE_CHAN;
-    if (st != FE_OK) { f.status = st; out[ci] = f; return; }
-    b.pos = b.first + (((b.pos - b.first) + 7) & ~7ull);  // alignToByte
-    // readUint(16): a nil here is discarded, the NEXT readByte then returns nil  :557
-    b.pos = (b.pos + 16 <= b.end) ? b.pos + 16 : b.end;
-    f.end_bit = b.pos;
-    out[ci] = f;
+        // ---- every lane advances its own frame until it has produced NC values or its window runs low
+        int cnt = 0;
+        if (st == ST_DIRECT_WAIT) { __threadfence(); direct = true; st = resume; }
+        while (st != ST_DONE && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+            if (st == ST_CODES) {
+                while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                    const long long v = esc ? read_sint(b, nbits) : read_rice(b, param);
+                    if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
+                    if (direct) { if (store_ok) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
+                    else orow[cnt++] = (R)v;
+                    jpos++;
+                    remaining--;
+                }
+                if (b.eof) { status = FE_NIL; st = ST_DONE; }
+                else if (remaining == 0) { pi++; st = pi < nparts ? ST_PART : ST_SUBEND; }
+            } else if (st == ST_WARM) {  // warm-up samples (:422-424, :430-432) or a VERBATIM subframe (:456-458)
+                while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                    const long long v = read_sint(b, sdepth);
+                    if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
+                    if (direct) { if (store_ok && jpos < bs) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
+                    else orow[cnt++] = (R)v;
+                    jpos++;
+                    remaining--;
+                    if ((jpos & 255) == 0 && b.pos > b.limit) { status = FE_LIMIT; st = ST_DONE; break; }
+                }
+                if (st != ST_DONE) {
+                    if (b.eof) { status = FE_NIL; st = ST_DONE; }
+                    else if (remaining == 0) st = after;
+                }
+            } else if (st == ST_CONST) {  // :453-454
+                if constexpr (sizeof(R) == 4) { if (cval != (long long)(R)cval) ovf = true; }
+                while (remaining > 0 && cnt < NC) { orow[cnt++] = (R)cval; remaining--; }
+                if (remaining == 0) st = ST_SUBEND;
+            } else if (st == ST_PART) {  // :394-406
+                param = (int)read_uint(b, param_bits);
+                esc = param >= escape;
+                nbits = 0;
+                if (esc) nbits = (int)read_uint(b, 5);
+                if (b.eof) { status = FE_NIL; st = ST_DONE; }
+                else if (b.pos > b.limit) { status = FE_LIMIT; st = ST_DONE; }
+                else {
+                    const int start = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
+                    remaining = endd > start ? endd - start : 0;
+                    jpos = start;
+                    if (remaining > 0) st = ST_CODES;
+                    else { pi++; st = pi < nparts ? ST_PART : ST_SUBEND; }
+                }
+            } else if (st == ST_SUB) {  // decodeSubframe  :443-465
+                read_uint(b, 1);
+                type = (int)read_uint(b, 6);
+                wasted = (int)read_uint(b, 1);
+                if (wasted == 1) {  // unary wasted-bits count  :447-449
+                    for (;;) {
+                        const long long bit = read_uint(b, 1);
+                        if (b.eof || bit) break;
+                        wasted++;
+                    }
+                }
+                sdepth = depth - wasted;
+                if (chan_asgn >= 8) sdepth += ((chan_asgn == 9) == (ch == 0)) ? 1 : 0;  // the side channel has one more bit  :483-497
+                direct = false;
+                order = 0; lshift = 0; jpos = 0;
+                if (b.eof || sdepth < 0 || sdepth > 57) { status = FE_NIL; st = ST_DONE; }  // 2^(n-1) with a negative n misbehaves in the Lua too
+                else if (type == 0) {
+                    cval = read_sint(b, sdepth);
+                    if (b.eof) { status = FE_NIL; st = ST_DONE; }
+                    else { remaining = bs; st = ST_CONST; }
+                } else if (type == 1) { remaining = bs; after = ST_SUBEND; st = ST_WARM; }
+                else if ((type >= 8 && type <= 12) || (type >= 32 && type <= 63)) {
+                    order = type <= 12 ? type - 8 : type - 31;
+                    remaining = order;
+                    after = ST_COEF;
+                    st = order > 0 ? ST_WARM : ST_COEF;
+                    // more warm-up samples than the block holds: the Lua table simply grows past blockSize; take the explicit-index path
+                    if (order > bs) { resume = st; st = ST_DIRECT_WAIT; break; }
+                } else { status = FE_SUBTYPE; st = ST_DONE; }
+            } else if (st == ST_COEF) {  // :433-438 / FIXED_PREDICTION_COEFFICIENTS :334-340, then the residual header :381-391
+                if (type >= 32) {
+                    const int precision = (int)read_uint(b, 4) + 1;
+                    lshift = (int)read_sint(b, 5);
+                    for (int i = 0; i < order; i++) sd[ch].coef[i] = (short)read_sint(b, precision);
+                } else {
+                    const short fc[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+                    for (int i = 0; i < order; i++) sd[ch].coef[i] = fc[order][i];
+                }
+                const int method = (int)read_uint(b, 2);
+                param_bits = method == 0 ? 4 : 5;
+                escape = method == 0 ? 0xF : 0x1F;
+                const int porder = (int)read_uint(b, 4);
+                nparts = 1 << porder;
+                if (b.eof) { status = FE_NIL; st = ST_DONE; }
+                else if (method >= 2) { status = FE_RESMETHOD; st = ST_DONE; }
+                else if (bs % nparts != 0) { status = FE_PARTITION; st = ST_DONE; }
+                else {
+                    psize = bs / nparts;
+                    pi = 0;
+                    st = ST_PART;
+                    // a partition smaller than the predictor order makes later partitions overwrite warm-up entries (:400): explicit-index path
+                    if (!direct && nparts > 1 && psize < order) { resume = ST_PART; st = ST_DIRECT_WAIT; break; }
+                }
+            } else if (st == ST_SUBEND) {
+                sd[ch].order = order;
+                sd[ch].lshift = lshift;
+                sd[ch].wasted = wasted;
+                sd[ch].kind = order == 0 ? 0 : (order <= 4 ? 1 : (order <= 12 ? 2 : 3));
+                if (direct) { gcur = cand_scratch + (u64)(ch + 1) * bs; direct = false; }  // cnt == 0 here: direct mode starts at a round boundary
+                ch++;
+                st = ch < nsub ? ST_SUB : ST_FRAMEEND;
+            } else if (st == ST_FRAME) {  // decodeFrame header  :510-553
+                const long long t0 = read_uint(b, 8);
+                if (b.eof) { status = FE_EOF_START; st = ST_DONE; continue; }
+                const long long sync = t0 * 64 + read_uint(b, 6);
+                if (b.eof) { status = FE_NIL; st = ST_DONE; continue; }
+                if (sync != 0x3FFE) { status = FE_SYNC; st = ST_DONE; continue; }
+                read_uint(b, 2);
+                const int bsc = (int)read_uint(b, 4), src_code = (int)read_uint(b, 4);
+                chan_asgn = (int)read_uint(b, 4);
+                read_uint(b, 4);
+                const int t = (int)read_uint(b, 8);
+                if (b.eof) { status = FE_NIL; st = ST_DONE; continue; }
+                int t2 = -1;
+                for (int i = 7; i >= 0; i--) { if (!(t & (1 << i))) break; t2++; }
+                for (int i = 1; i <= t2; i++) read_uint(b, 8);
+                if (bsc == 1) bs = 192;
+                else if (bsc >= 2 && bsc <= 5) bs = 576 << (bsc - 2);
+                else if (bsc == 6) bs = (int)read_uint(b, 8) + 1;
+                else if (bsc == 7) bs = (int)read_uint(b, 16) + 1;
+                else if (bsc >= 8) bs = 256 << (bsc - 8);
+                else { status = FE_BLOCKSIZE; st = ST_DONE; continue; }
+                if (src_code == 12) read_uint(b, 8);
+                else if (src_code == 13 || src_code == 14) read_uint(b, 16);
+                read_uint(b, 8);  // CRC-8, ignored :553
+                if (b.eof) { status = FE_NIL; st = ST_DONE; continue; }
+                if (chan_asgn <= 7) nsub = C;
+                else if (chan_asgn <= 10) {
+                    nsub = 2;
+                    if (C != 2) { status = FE_NIL; st = ST_DONE; continue; }  // result[ch] of a missing / extra channel is nil (:482-507)
+                } else { status = FE_CHAN; st = ST_DONE; continue; }
+                // bit budget: `limit_factor` times the size of an all-VERBATIM frame (no encoder emits a bigger one)
+                b.limit = (A.limit_factor > 0 && !c.nolimit) ? b.pos + (u64)A.limit_factor * (u64)bs * (u64)C * (u64)(depth + 2) + 4096 : ~0ull;
+                const u64 need = (u64)nsub * (u64)bs;
+                cand_scratch = atomicAdd(A.scratch_cursor, (need + 3) & ~3ull);
+                store_ok = cand_scratch + need <= A.scratch_cap;
+                gcur = cand_scratch;
+                ch = 0;
+                st = ST_SUB;
+            } else if (st == ST_FRAMEEND) {  // :555-557
+                b.pos = b.first + (((b.pos - b.first) + 7) & ~7ull);  // alignToByte
+                // readUint(16): a nil here is discarded, the NEXT readByte then returns nil  :557
+                b.pos = (b.pos + 16 <= b.end) ? b.pos + 16 : b.end;
+                end_byte = (b.pos - A.G.base_bit) >> 3;
+                st = ST_DONE;
+            } else break;  // ST_DIRECT_WAIT: resume after this round's flush
+        }
+        // ---- flush: the values of stream s go to 128 contiguous bytes; two streams per store instruction
+        s_cnt[lane] = store_ok ? cnt : 0;
+        s_ptr[lane] = gcur;
+        gcur += (u64)cnt;
+        __syncthreads();
+        {
+            const int half = lane >> 5, k = lane & 31;
+            for (int i = 0; i < 32; i++) {
+                const int s = 2 * i + half;
+                if (k < s_cnt[s]) A.scratch[s_ptr[s] + k] = s_out[s * OSTR + k];
+            }
+        }
+        __syncthreads();
+        if (__ballot(st != ST_DONE) == 0) break;
+    }
+    if (valid) {
+        CandInfo f;
+        f.end_byte = end_byte;
+        f.scratch = cand_scratch;
+        f.sample_off = 0;
+        f.blocksize = bs; f.chan_asgn = chan_asgn; f.status = status; f.nsub = nsub;
+        f.seq = 0; f.used = 0;
+        A.ci[idx] = f;
+        if (ovf && status == FE_OK) atomicOr(A.flags, (unsigned)FLAG_OVERFLOW);
+    }
 }
 
-struct SubJob { unsigned long long bit; unsigned long long out_off; unsigned stream; int depth, blocksize, pad; };
+struct ChainOut { u64 L, miss_at; unsigned nframes; int status; int miss_kind; unsigned miss_ci; };  // miss_kind: 1 = no candidate at miss_at, 2 = candidate miss_ci hit its bit budget
 
-__global__ __launch_bounds__(64) void k_flac_subframe(const FlacGlobals G, const SubJob *jobs, unsigned long long njobs, double *out, int *err) {
-    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
-    if (j >= njobs) return;
-    const SubJob job = jobs[j];
-    const FlacStreamInfo si = G.info[job.stream];
-    Bits b;
-    b.w0 = G.w0;
-    b.first = G.base_bit + 8 * (G.off[job.stream] + si.first_byte);
-    b.end = G.base_bit + 8 * G.off[job.stream + 1];
-    b.eof = 0;
-    b.limit = ~0ull;
-    b.kind = 0;
-    bits_seek(b, job.bit);
-    const int st = flac_subframe<true>(b, job.depth, job.blocksize, out + job.out_off);
-    if (st != FE_OK) atomicCAS(err, 0, st);
-}
-
-struct FinJob { unsigned long long off0, off1; int blocksize, chan_asgn; };  // off0/off1: the frame's first two channel blocks
-// decodeSubframes tail  :482-507: decorrelate, wrap, / 2^depth.  rows[] lists every (frame, channel) block for the plain wrap pass.
-__global__ __launch_bounds__(256) void k_flac_finish(const FinJob *jobs, unsigned long long njobs, double *data, int depth) {
-    const FinJob job = jobs[blockIdx.x];
-    const double half = ldexp(1.0, depth - 1), full = ldexp(1.0, depth);
-    for (int i = threadIdx.x; i < job.blocksize; i += 256) {
-        if (job.chan_asgn >= 8) {
-            double a = data[job.off0 + i], s = data[job.off1 + i];
-            if (job.chan_asgn == 8) s = a - s;                                   // left/side
-            else if (job.chan_asgn == 9) a = a + s;                              // side/right
-            else { const double side = s; const double right = a - floor(side / 2); s = right; a = right + side; }  // mid/side
-            if (a >= half) a -= full;
-            if (s >= half) s -= full;
-            data[job.off0 + i] = a / full;
-            data[job.off1 + i] = s / full;
-        } else {
-            double a = data[job.off0 + i];
-            if (a >= half) a -= full;
-            data[job.off0 + i] = a / full;
+// decodeFLAC's frame loop (:615): follow end → start links from the first frame
+__global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned n, CandHash H, CandInfo *ci, const SubDesc *sd, int C, ChainOut *out, u64 *kind_count) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    ChainOut r{};
+    u64 at = G.off[s] + G.info[s].first_byte;
+    const u64 endb = G.off[s + 1];
+    u64 sp = 0;
+    unsigned nf = 0;
+    unsigned kc[4] = {0, 0, 0, 0};
+    int stream_status = FE_OK;
+    bool go = at < endb;  // readByte() → nil → decodeFrame returns false
+    while (go) {          // (single-exit loop: the multi-break form of this walk was miscompiled by hipcc 7.2 — status lost)
+        const unsigned k = hash_lookup(H, at);
+        if (k == ~0u) { r.miss_kind = 1; r.miss_at = at; go = false; }
+        else {
+            const CandInfo f = ci[k];
+            if (f.status == FE_OK) {
+                ci[k].sample_off = sp;
+                ci[k].seq = nf;
+                ci[k].used = 1;
+                for (int c = 0; c < f.nsub; c++) kc[sd[(size_t)k * C + c].kind & 3]++;
+                sp += (u64)f.blocksize;
+                nf++;
+                at = f.end_byte;
+                go = at < endb;
+            } else {
+                if (f.status == FE_LIMIT) { r.miss_kind = 2; r.miss_ci = k; }
+                else if (f.status != FE_EOF_START) stream_status = f.status;
+                go = false;
+            }
         }
     }
+    r.L = sp;
+    r.nframes = nf;
+    r.status = stream_status;
+    out[s] = r;
+    for (int q = 0; q < 4; q++) if (kc[q]) atomicAdd(&kind_count[q], (u64)kc[q]);
+}
+
+struct SubJob { u64 src, dst; unsigned desc; int bs; };
+struct FrameRec { u64 sample_off; int bs, chan_asgn; unsigned stream, pad; };
+
+__global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const CandInfo *ci, const SubDesc *sd, unsigned ncand, int C, const u64 *row_off,
+                                                  const u64 *frame_base, const u64 *kind_base, u64 *kind_fill, SubJob *jobs, FrameRec *frames) {
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ncand) return;
+    const CandInfo f = ci[k];
+    if (!f.used) return;
+    const unsigned s = cands[k].stream;
+    for (int c = 0; c < f.nsub; c++) {
+        const int kind = sd[(size_t)k * C + c].kind & 3;
+        const u64 slot = kind_base[kind] + atomicAdd(&kind_fill[kind], 1ull);
+        jobs[slot] = SubJob{f.scratch + (u64)c * f.blocksize, row_off[(size_t)s * C + c] + f.sample_off, k * (unsigned)C + c, f.blocksize};
+    }
+    frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
+}
+
+// restoreLinearPrediction (:411-419) + result[i] * 2^shift (:467-469).  One lane per subframe; 32 values per lane and round
+// travel global → LDS → lane → LDS → global so that both directions move 128 contiguous bytes per subframe.
+template <typename R, int MAXO>
+__global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njobs, const SubDesc *sd, const R *scratch, R *rows, unsigned *flags) {
+    constexpr bool INT = std::is_same<R, int>::value;  // int32 rows: exact integer prediction with overflow detection; double rows: the Lua's own arithmetic
+    __shared__ R s_v[64 * OSTR];
+    __shared__ u64 s_src[64], s_dst[64];
+    __shared__ int s_bs[64];
+    const int lane = threadIdx.x;
+    const u64 j = (u64)blockIdx.x * 64 + lane;
+    SubJob job{0, 0, 0, 0};
+    if (j < njobs) job = jobs[j];
+    int order = 0, lshift = 0, wasted = 0;
+    R coef[MAXO > 0 ? MAXO : 1], hist[MAXO > 0 ? MAXO : 1];
+#pragma unroll
+    for (int q = 0; q < (MAXO > 0 ? MAXO : 1); q++) { coef[q] = 0; hist[q] = 0; }
+    if (j < njobs) {
+        const SubDesc &d = sd[job.desc];
+        order = d.order; lshift = d.lshift; wasted = d.wasted;
+#pragma unroll
+        for (int q = 0; q < MAXO; q++) if (q < order) coef[q] = (R)d.coef[q];
+    }
+    const double div = ldexp(1.0, lshift), mul = ldexp(1.0, wasted);
+    s_src[lane] = job.src; s_dst[lane] = job.dst; s_bs[lane] = job.bs;
+    int maxbs = job.bs;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) maxbs = max(maxbs, __shfl_xor(maxbs, m));
+    __syncthreads();
+    bool ovf = false;
+    const int half = lane >> 5, k32 = lane & 31;
+    for (int base = 0; base < maxbs; base += NC) {
+        for (int i = 0; i < 32; i++) {
+            const int s = 2 * i + half;
+            if (base + k32 < s_bs[s]) s_v[s * OSTR + k32] = scratch[s_src[s] + base + k32];
+        }
+        __syncthreads();
+        const int nmine = min(NC, job.bs - base);
+        for (int k = 0; k < nmine; k++) {
+            const int i = base + k;
+            if constexpr (INT) {
+                long long v = (long long)s_v[lane * OSTR + k];
+                if constexpr (MAXO > 0) {
+                    if (i >= order) {
+                        long long sum = 0;
+#pragma unroll
+                        for (int q = 0; q < MAXO; q++) sum += (long long)hist[q] * (long long)coef[q];
+                        v += lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));  // floor(sum / 2^shift)
+                    }
+                    if (v != (long long)(int)v) ovf = true;
+#pragma unroll
+                    for (int q = MAXO - 1; q > 0; q--) hist[q] = hist[q - 1];
+                    hist[0] = (int)v;
+                }
+                const long long o = v << wasted;
+                if (o != (long long)(int)o) ovf = true;
+                s_v[lane * OSTR + k] = (int)o;
+            } else {
+                double v = s_v[lane * OSTR + k];
+                if constexpr (MAXO > 0) {
+                    if (i >= order) {
+                        double sum = 0;  // sum = sum + result[i - j] * coefs[j + 1], j = 0 ..  :413-416 (padded taps add exact zeros)
+#pragma unroll
+                        for (int q = 0; q < MAXO; q++) sum = sum + hist[q] * coef[q];
+                        v = v + floor(sum / div);
+                    }
+#pragma unroll
+                    for (int q = MAXO - 1; q > 0; q--) hist[q] = hist[q - 1];
+                    hist[0] = v;
+                }
+                s_v[lane * OSTR + k] = v * mul;
+            }
+        }
+        __syncthreads();
+        for (int i = 0; i < 32; i++) {
+            const int s = 2 * i + half;
+            if (base + k32 < s_bs[s]) rows[s_dst[s] + base + k32] = s_v[s * OSTR + k32];
+        }
+        __syncthreads();
+    }
+    if (ovf) atomicOr(flags, (unsigned)FLAG_OVERFLOW);
+}
+
+// decodeSubframes tail  :482-507: decorrelate and wrap, in place, one workgroup per chained frame.  int32 rows keep the
+// integer (the consumer divides by 2^depth); double rows get the reference's doubles, computed the way the Lua does.
+template <typename R>
+__global__ __launch_bounds__(256) void k_flac_finish(const FrameRec *frames, const u64 *row_off, int C, R *data, int depth, unsigned *flags) {
+    const FrameRec fr = frames[blockIdx.x];
+    bool ovf = false;
+    if constexpr (std::is_same<R, int>::value) {
+        const long long half = 1ll << (depth - 1), full = 1ll << depth;
+        auto put = [&](u64 at, long long v) {
+            if (v >= half) v -= full;
+            if (v != (long long)(int)v) ovf = true;
+            data[at] = (int)v;
+        };
+        if (fr.chan_asgn >= 8) {
+            const u64 o0 = row_off[(size_t)fr.stream * C] + fr.sample_off, o1 = row_off[(size_t)fr.stream * C + 1] + fr.sample_off;
+            for (int i = threadIdx.x; i < fr.bs; i += 256) {
+                long long a = (long long)data[o0 + i], s = (long long)data[o1 + i];
+                if (fr.chan_asgn == 8) s = a - s;                                   // left/side
+                else if (fr.chan_asgn == 9) a = a + s;                              // side/right
+                else { const long long side = s; const long long right = a - (side >> 1); s = right; a = right + side; }  // mid/side, floor(side / 2)
+                put(o0 + i, a);
+                put(o1 + i, s);
+            }
+        } else {
+            for (int c = 0; c < C; c++) {
+                const u64 o = row_off[(size_t)fr.stream * C + c] + fr.sample_off;
+                for (int i = threadIdx.x; i < fr.bs; i += 256) put(o + i, (long long)data[o + i]);
+            }
+        }
+    } else {
+        const double half = ldexp(1.0, depth - 1), full = ldexp(1.0, depth);
+        if (fr.chan_asgn >= 8) {
+            const u64 o0 = row_off[(size_t)fr.stream * C] + fr.sample_off, o1 = row_off[(size_t)fr.stream * C + 1] + fr.sample_off;
+            for (int i = threadIdx.x; i < fr.bs; i += 256) {
+                double a = data[o0 + i], s = data[o1 + i];
+                if (fr.chan_asgn == 8) s = a - s;
+                else if (fr.chan_asgn == 9) a = a + s;
+                else { const double side = s; const double right = a - floor(side / 2); s = right; a = right + side; }
+                if (a >= half) a -= full;
+                if (s >= half) s -= full;
+                data[o0 + i] = a / full;
+                data[o1 + i] = s / full;
+            }
+        } else {
+            for (int c = 0; c < C; c++) {
+                const u64 o = row_off[(size_t)fr.stream * C + c] + fr.sample_off;
+                for (int i = threadIdx.x; i < fr.bs; i += 256) { double a = data[o + i]; if (a >= half) a -= full; data[o + i] = a / full; }
+            }
+        }
+    }
+    if (ovf) atomicOr(flags, (unsigned)FLAG_OVERFLOW);
 }
 
 struct FlacDecoded {
     std::vector<FlacStreamInfo> info;
     std::vector<std::vector<std::pair<uint64_t, int>>> frames;  // per stream: (sample offset, blocksize) of every decoded frame, in order
     std::vector<int> status;                                     // per stream: 0 = clean end, else FlacErr of the frame that failed
-    std::vector<uint64_t> row_off, row_len;                      // (stream, channel) rows of doubles in ctx->tmp_buf
+    std::vector<uint64_t> row_off, row_len;                      // (stream, channel) rows in ctx->tmp_buf
     int channels = 0, depth = 0;
     double rate = 0;
+    bool wide = false;  // rows are doubles (already / 2^depth) instead of int32
 };
 
-static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D) {
+struct Carve {
+    size_t at = 0;
+    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
+};
+struct Counters { u64 ncand, scratch_cursor, kind_count[4], kind_fill[4]; unsigned flags, pad; };
+
+static bool g_flac_force_wide() { const char *e = getenv("AUKIT_FLAC_WIDE"); return e && atoi(e) != 0; }
+
+// returns AUKIT_OK, an error, or 1 = "int32 rows overflowed, run again with R = double"
+template <typename R>
+static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
+    const uint32_t n = in->n;
+    const int C = D.channels;
+    int rc;
+    const FlacStreamInfo *d_info = reinterpret_cast<const FlacStreamInfo *>(ctx->misc_buf.p);
+    const uintptr_t dptr = reinterpret_cast<uintptr_t>(in->data());
+    FlacGlobals G;
+    G.src = in->data();
+    G.w0 = reinterpret_cast<const u64 *>(dptr & ~(uintptr_t)15);
+    G.base_bit = 8 * (dptr & 15);
+    G.safe_words = (((dptr & 15) + in->total() + 15) / 16) * 2;
+    G.off = reinterpret_cast<const u64 *>(in->d_off);
+    G.info = d_info;
+
+    uint64_t capc = in->total() / 2048 + n + 4096;  // candidate slots (grown on demand)
+    uint64_t guess = 0;
+    for (uint32_t s = 0; s < n; s++) guess += (uint64_t)D.info[s].nsamples * C;
+    uint64_t scap = std::max<uint64_t>(guess + guess / 16 + 65536, ctx->tmp_buf3.cap / sizeof(R));  // scratch elements (grown on demand)
+    uint64_t maxlen = 1;
+    for (uint32_t s = 0; s < n; s++) maxlen = std::max<uint64_t>(maxlen, in->off[s + 1] - in->off[s]);
+
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) return fail(AUKIT_E_HIP, "internal: FLAC candidate tables keep overflowing");
+        // ---- carve tmp_buf2
+        uint64_t hs = 1; unsigned hbits = 0;
+        while (hs < 2 * capc) { hs <<= 1; hbits++; }
+        Carve cv;
+        const size_t o_cnt = cv.take(sizeof(Counters)), o_chain = cv.take((size_t)n * sizeof(ChainOut)), o_cand = cv.take(capc * sizeof(Cand)),
+                     o_ci = cv.take(capc * sizeof(CandInfo)), o_sd = cv.take(capc * C * sizeof(SubDesc)), o_keys = cv.take(hs * 8), o_vals = cv.take(hs * 4),
+                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8), o_kbase = cv.take(4 * 8);
+        if ((rc = ctx->tmp_buf2.ensure(cv.at))) return rc;
+        char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+        Counters *d_cnt = reinterpret_cast<Counters *>(B + o_cnt);
+        ChainOut *d_chain = reinterpret_cast<ChainOut *>(B + o_chain);
+        Cand *d_cand = reinterpret_cast<Cand *>(B + o_cand);
+        CandInfo *d_ci = reinterpret_cast<CandInfo *>(B + o_ci);
+        SubDesc *d_sd = reinterpret_cast<SubDesc *>(B + o_sd);
+        CandHash H{reinterpret_cast<u64 *>(B + o_keys), reinterpret_cast<unsigned *>(B + o_vals), 64 - hbits, hs - 1};
+        u64 *d_rowoff = reinterpret_cast<u64 *>(B + o_rowoff), *d_fbase = reinterpret_cast<u64 *>(B + o_fbase), *d_kbase = reinterpret_cast<u64 *>(B + o_kbase);
+        AUKIT_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), ctx->stream));
+        AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, ctx->stream));
+        // ---- 2. sync candidates
+        const uint64_t cand_room = capc - n - 64;  // the tail is kept for positions the chain asks for
+        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((maxlen + 255) / 256, 2048), n), dim3(256), 0, ctx->stream, in->data(), G.off, d_info, n,
+                           d_cand, cand_room, &d_cnt->ncand, H);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        Counters hc;
+        AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (hc.ncand > cand_room) { capc = hc.ncand + hc.ncand / 8 + n + 4096; continue; }
+        unsigned ncand = (unsigned)hc.ncand;
+
+        // ---- 3. extract every candidate
+        auto extract = [&](unsigned first, unsigned count, int limit_factor) -> int {
+            if (!count) return AUKIT_OK;
+            ExtractArgs<R> A;
+            A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.sd = d_sd; A.C = C;
+            A.scratch = reinterpret_cast<R *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
+            A.limit_factor = limit_factor;
+            hipLaunchKernelGGL((k_flac_extract<R>), dim3((count + 63) / 64), dim3(64), 0, ctx->stream, A);
+            AUKIT_HIP_CHECK(hipGetLastError());
+            return AUKIT_OK;
+        };
+        std::vector<ChainOut> chain(n);
+        bool restart = false;
+        for (int pass = 0;; pass++) {
+            if (pass == 0) {
+                if ((rc = ctx->tmp_buf3.ensure(scap * sizeof(R) + 256))) return rc;
+                AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->scratch_cursor, 0, 8, ctx->stream));
+                if ((rc = ctx_begin_kernel(ctx))) return rc;
+                if ((rc = extract(0, ncand, 4))) return rc;
+                if ((rc = ctx_end_kernel(ctx, "k_flac_extract", in->total() + guess * sizeof(R)))) return rc;
+            }
+            // ---- 4. follow the chains
+            AUKIT_HIP_CHECK(hipMemsetAsync(d_cnt->kind_count, 0, sizeof hc.kind_count + sizeof hc.kind_fill, ctx->stream));
+            hipLaunchKernelGGL(k_flac_chain, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, G, n, H, d_ci, d_sd, C, d_chain, d_cnt->kind_count);
+            AUKIT_HIP_CHECK(hipGetLastError());
+            AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipMemcpyAsync(chain.data(), d_chain, (size_t)n * sizeof(ChainOut), hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (getenv("AUKIT_FLAC_DEBUG")) {
+                std::vector<CandInfo> hci(ncand);
+                (void)hipMemcpy(hci.data(), d_ci, ncand * sizeof(CandInfo), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[flac] pass %d ncand %u cursor %llu scap %llu flags %u\n", pass, ncand, (u64)hc.scratch_cursor, (u64)scap, hc.flags);
+                for (unsigned k = 0; k < ncand && k < 16; k++)
+                    fprintf(stderr, "  cand %u end %llu bs %d asgn %d status %d nsub %d used %u seq %u\n", k, hci[k].end_byte, hci[k].blocksize, hci[k].chan_asgn, hci[k].status, hci[k].nsub, hci[k].used, hci[k].seq);
+                for (uint32_t s = 0; s < n && s < 4; s++)
+                    fprintf(stderr, "  chain %u L %llu nfr %u status %d miss %d at %llu ci %u\n", s, chain[s].L, chain[s].nframes, chain[s].status, chain[s].miss_kind, chain[s].miss_at, chain[s].miss_ci);
+            }
+            if (hc.scratch_cursor > scap) {  // some frames had no room for their values: grow and extract everything again
+                scap = hc.scratch_cursor + hc.scratch_cursor / 16 + 65536;
+                pass = -1;
+                continue;
+            }
+            // positions the serial decoder would visit that are not (fully) extracted yet
+            std::vector<Cand> extra;
+            std::vector<unsigned> redo;
+            for (uint32_t s = 0; s < n; s++) {
+                if (chain[s].miss_kind == 1) extra.push_back(Cand{s, 1, chain[s].miss_at});
+                else if (chain[s].miss_kind == 2) redo.push_back(chain[s].miss_ci);
+            }
+            if (extra.empty() && redo.empty()) break;
+            if (pass > 1000000) return fail(AUKIT_E_HIP, "internal: FLAC chain does not converge");
+            if ((uint64_t)ncand + extra.size() > capc) { capc = (uint64_t)ncand + extra.size() * 2 + n + 4096; restart = true; break; }
+            if (!extra.empty()) {
+                AUKIT_HIP_CHECK(hipMemcpyAsync(d_cand + ncand, extra.data(), extra.size() * sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_flac_hash_insert, dim3((unsigned)((extra.size() + 63) / 64)), dim3(64), 0, ctx->stream, d_cand, ncand, (unsigned)extra.size(), H);
+                if ((rc = extract(ncand, (unsigned)extra.size(), 0))) return rc;
+                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `extra` is read by the async copy
+                ncand += (unsigned)extra.size();
+            }
+            for (unsigned k : redo) if ((rc = extract(k, 1, 0))) return rc;
+        }
+        if (restart) continue;
+
+        // ---- rows, frame lists, job ranges
+        D.status.assign(n, 0);
+        D.row_off.assign((size_t)n * C, 0);
+        D.row_len.assign((size_t)n * C, 0);
+        std::vector<uint64_t> fbase(n);
+        uint64_t tot = 0, nfr = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            const uint64_t L = chain[s].L, stride = round_up(std::max<uint64_t>(L, 1), 4);
+            for (int c = 0; c < C; c++) { D.row_off[(size_t)s * C + c] = tot + (uint64_t)c * stride; D.row_len[(size_t)s * C + c] = L; }
+            tot += stride * C;
+            fbase[s] = nfr;
+            nfr += chain[s].nframes;
+            D.status[s] = chain[s].status;
+        }
+        uint64_t kbase[4], njobs = 0;
+        for (int q = 0; q < 4; q++) { kbase[q] = njobs; njobs += hc.kind_count[q]; }
+        if ((rc = ctx->tmp_buf.ensure((size_t)tot * sizeof(R) + 256))) return rc;
+        Carve cj;
+        const size_t o_jobs = cj.take(njobs * sizeof(SubJob)), o_frames = cj.take(nfr * sizeof(FrameRec));
+        if ((rc = ctx->seg_buf.ensure(cj.at + 256))) return rc;
+        ctx->plan_key.clear();  // seg_buf no longer holds a cached resample plan
+        SubJob *d_jobs = reinterpret_cast<SubJob *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_jobs);
+        FrameRec *d_frames = reinterpret_cast<FrameRec *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_frames);
+        AUKIT_HIP_CHECK(hipMemcpyAsync(d_rowoff, D.row_off.data(), (size_t)n * C * 8, hipMemcpyHostToDevice, ctx->stream));
+        AUKIT_HIP_CHECK(hipMemcpyAsync(d_fbase, fbase.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        AUKIT_HIP_CHECK(hipMemcpyAsync(d_kbase, kbase, sizeof kbase, hipMemcpyHostToDevice, ctx->stream));
+        R *rows = reinterpret_cast<R *>(ctx->tmp_buf.p);
+        const R *scratch = reinterpret_cast<const R *>(ctx->tmp_buf3.p);
+        if (njobs) {
+            hipLaunchKernelGGL(k_flac_jobs, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, d_cand, d_ci, d_sd, ncand, C, d_rowoff, d_fbase, d_kbase, d_cnt->kind_fill,
+                               d_jobs, d_frames);
+            AUKIT_HIP_CHECK(hipGetLastError());
+            // ---- 6. prediction, grouped by order class so that the lanes of a wave run the same number of taps
+            if ((rc = ctx_begin_kernel(ctx))) return rc;
+#define AUKIT_RESTORE(Q, MAXO)                                                                                                                    \
+    if (hc.kind_count[Q])                                                                                                                         \
+        hipLaunchKernelGGL((k_flac_restore<R, MAXO>), dim3((unsigned)((hc.kind_count[Q] + 63) / 64)), dim3(64), 0, ctx->stream, d_jobs + kbase[Q], \
+                           (u64)hc.kind_count[Q], d_sd, scratch, rows, &d_cnt->flags)
+            AUKIT_RESTORE(0, 0);
+            AUKIT_RESTORE(1, 4);
+            AUKIT_RESTORE(2, 12);
+            AUKIT_RESTORE(3, 32);
+#undef AUKIT_RESTORE
+            AUKIT_HIP_CHECK(hipGetLastError());
+            if ((rc = ctx_end_kernel(ctx, "k_flac_restore", 2 * tot * sizeof(R)))) return rc;
+            // ---- 7. decorrelate + wrap
+            hipLaunchKernelGGL((k_flac_finish<R>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, d_frames, d_rowoff, C, rows, D.depth, &d_cnt->flags);
+            AUKIT_HIP_CHECK(hipGetLastError());
+        }
+        std::vector<FrameRec> hfr;
+        if (want_frames && nfr) {
+            hfr.resize(nfr);
+            AUKIT_HIP_CHECK(hipMemcpyAsync(hfr.data(), d_frames, nfr * sizeof(FrameRec), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        unsigned flags = 0;
+        AUKIT_HIP_CHECK(hipMemcpyAsync(&flags, &d_cnt->flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (flags & FLAG_OVERFLOW) return 1;  // only the int32 instantiation raises it
+        D.frames.assign(n, {});
+        if (want_frames)
+            for (uint32_t s = 0; s < n; s++) {
+                D.frames[s].reserve(chain[s].nframes);
+                for (unsigned f = 0; f < chain[s].nframes; f++) D.frames[s].push_back({hfr[fbase[s] + f].sample_off, hfr[fbase[s] + f].bs});
+            }
+        D.wide = sizeof(R) == 8;
+        return AUKIT_OK;
+    }
+}
+
+static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
     const uint32_t n = in->n;
     if (n == 0) return fail(AUKIT_E_ARG, "empty batch");
     int rc;
     // -- 1. stream headers
     DevBuf &hb = ctx->misc_buf;
     if ((rc = hb.ensure((size_t)n * sizeof(FlacStreamInfo)))) return rc;
-    hipLaunchKernelGGL(k_flac_header, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), n,
+    hipLaunchKernelGGL(k_flac_header, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const u64 *>(in->d_off), n,
                        reinterpret_cast<FlacStreamInfo *>(hb.p));
     AUKIT_HIP_CHECK(hipGetLastError());
     D.info.resize(n);
@@ -478,173 +938,48 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
         else if (D.info[s].channels != D.channels || D.info[s].depth != D.depth || D.info[s].rate != D.rate)
             return fail(AUKIT_E_ARG, "all FLAC streams of a batch must share channel count, bit depth and sample rate");
     }
-    // -- 2. sync candidates
-    const uint64_t cap = in->total() / 32 + 4096;
-    DevBuf &cb = ctx->tmp_buf2;
-    if ((rc = cb.ensure(cap * sizeof(Cand) + 64))) return rc;
-    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(cb.p) + cap * sizeof(Cand));
-    AUKIT_HIP_CHECK(hipMemsetAsync(d_count, 0, 8, ctx->stream));
-    uint64_t maxlen = 1;
-    for (uint32_t s = 0; s < n; s++) maxlen = std::max<uint64_t>(maxlen, in->off[s + 1] - in->off[s]);
-    hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((maxlen + 255) / 256, 2048), n), dim3(256), 0, ctx->stream, in->data(),
-                       reinterpret_cast<const unsigned long long *>(in->d_off), reinterpret_cast<const FlacStreamInfo *>(hb.p), n, reinterpret_cast<Cand *>(cb.p), cap, d_count);
-    AUKIT_HIP_CHECK(hipGetLastError());
-    unsigned long long ncand = 0;
-    AUKIT_HIP_CHECK(hipMemcpyAsync(&ncand, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (ncand > cap) return fail(AUKIT_E_UNSUPPORTED, "too many FLAC sync candidates (%llu)", ncand);
-    std::vector<Cand> cands(ncand);
-    if (ncand) AUKIT_HIP_CHECK(hipMemcpy(cands.data(), cb.p, ncand * sizeof(Cand), hipMemcpyDeviceToHost));
-    // the first frame position of every stream is a chain root even if it does not look like a sync code
-    for (uint32_t s = 0; s < n; s++) cands.push_back(Cand{s, 0, in->off[s] + D.info[s].first_byte});
-    std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.stream != b.stream ? a.stream < b.stream : a.byte < b.byte; });
-    cands.erase(std::unique(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.stream == b.stream && a.byte == b.byte; }), cands.end());
-    ncand = cands.size();
-    // -- 3. parse every candidate
-    const uintptr_t dptr = reinterpret_cast<uintptr_t>(in->data());
-    FlacGlobals G;
-    G.src = in->data();
-    G.w0 = reinterpret_cast<const unsigned long long *>(dptr & ~(uintptr_t)7);
-    G.base_bit = 8 * (dptr & 7);
-    G.off = reinterpret_cast<const unsigned long long *>(in->d_off);
-    G.info = reinterpret_cast<const FlacStreamInfo *>(hb.p);
-    if ((rc = cb.ensure((ncand + 1) * (sizeof(Cand) + sizeof(FrameInfo)) + 64))) return rc;  // +1: scratch slot for on-demand parses
-    AUKIT_HIP_CHECK(hipMemcpyAsync(cb.p, cands.data(), ncand * sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
-    FrameInfo *d_fi = reinterpret_cast<FrameInfo *>(reinterpret_cast<char *>(cb.p) + (ncand + 1) * sizeof(Cand));
-    if ((rc = ctx_begin_kernel(ctx))) return rc;
-    hipLaunchKernelGGL(k_flac_parse, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p), ncand, d_fi, 4);
-    AUKIT_HIP_CHECK(hipGetLastError());
-    if ((rc = ctx_end_kernel(ctx, "k_flac_parse", in->total()))) return rc;
-    std::vector<FrameInfo> fi(ncand);
-    AUKIT_HIP_CHECK(hipMemcpyAsync(fi.data(), d_fi, ncand * sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    // -- 4. follow the chain per stream
-    D.frames.assign(n, {});
-    D.status.assign(n, 0);
-    D.row_off.assign((size_t)n * D.channels, 0);
-    D.row_len.assign((size_t)n * D.channels, 0);
-    std::vector<SubJob> sub;
-    std::vector<FinJob> fin;
-    uint64_t tot = 0;
-    size_t ci = 0;
-    for (uint32_t s = 0; s < n; s++) {
-        size_t lo = ci;
-        while (ci < ncand && cands[ci].stream == s) ci++;
-        const size_t hi = ci;
-        // first pass over the chain to size the rows
-        std::vector<size_t> chain;
-        uint64_t at = in->off[s] + D.info[s].first_byte;
-        const uint64_t endb = in->off[s + 1];
-        for (;;) {
-            if (at >= endb) break;  // readByte() → nil → decodeFrame returns false
-            size_t a = lo, b = hi;
-            while (a < b) { size_t m = (a + b) / 2; if (cands[m].byte < at) a = m + 1; else b = m; }
-            if (a >= hi || cands[a].byte != at) {
-                // not in the pre-parsed list (failed the CRC filter, or no sync pattern here): parse this one position now —
-                // k_flac_parse reports "Sync code expected" / nil arithmetic exactly like decodeFrame would
-                const Cand one{s, 0, at};
-                AUKIT_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<Cand *>(cb.p) + ncand, &one, sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL(k_flac_parse, dim3(1), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p) + ncand, 1ull, d_fi + ncand, 0);
-                FrameInfo extra;
-                AUKIT_HIP_CHECK(hipMemcpyAsync(&extra, d_fi + ncand, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                fi.push_back(extra);
-                a = fi.size() - 1;
-            }
-            if (fi[a].status == FE_LIMIT) {  // a real frame larger than the budget: parse it again without one
-                hipLaunchKernelGGL(k_flac_parse, dim3(1), dim3(64), 0, ctx->stream, G, reinterpret_cast<const Cand *>(cb.p) + a, 1ull, d_fi + a, 0);
-                AUKIT_HIP_CHECK(hipMemcpyAsync(&fi[a], d_fi + a, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            }
-            const FrameInfo &f = fi[a];
-            if (f.status == FE_EOF_START) break;
-            if (f.status != FE_OK) { D.status[s] = f.status; break; }
-            chain.push_back(a);
-            at = (f.end_bit - G.base_bit) / 8;
-        }
-        uint64_t L = 0;
-        for (size_t a : chain) L += (uint64_t)fi[a].blocksize;
-        const uint64_t stride = round_up(std::max<uint64_t>(L, 1), 2);
-        for (int c = 0; c < D.channels; c++) { D.row_off[(size_t)s * D.channels + c] = tot + (uint64_t)c * stride; D.row_len[(size_t)s * D.channels + c] = L; }
-        uint64_t sp = 0;
-        for (size_t a : chain) {
-            const FrameInfo &f = fi[a];
-            D.frames[s].push_back({sp, f.blocksize});
-            for (int c = 0; c < D.channels; c++) {
-                int dep = D.depth;
-                if (f.chan_asgn >= 8) {
-                    if (c >= 2) break;  // only subframes[1], [2] exist in the decorrelated modes; extra channels would be nil
-                    if (c == 0) dep += (f.chan_asgn == 9 ? 1 : 0); else dep += (f.chan_asgn == 9 ? 0 : 1);
-                }
-                sub.push_back(SubJob{f.sub_bit[c], tot + (uint64_t)c * stride + sp, s, dep, f.blocksize, (int)f.kind[c]});
-            }
-            if (f.chan_asgn >= 8) {
-                if (D.channels != 2) { D.status[s] = FE_NIL; }
-                fin.push_back(FinJob{tot + sp, tot + stride + sp, f.blocksize, f.chan_asgn});
-            } else
-                for (int c = 0; c < D.channels; c++) fin.push_back(FinJob{tot + (uint64_t)c * stride + sp, 0, f.blocksize, 0});
-            sp += (uint64_t)f.blocksize;
-        }
-        tot += stride * D.channels;
+    if (D.depth <= 24 && !g_flac_force_wide()) {
+        rc = flac_run<int>(ctx, in, D, want_frames);
+        if (rc != 1) return rc;
     }
-    // -- 5/6. decode the chained frames
-    if ((rc = ctx->tmp_buf.ensure((size_t)tot * 8 + 64))) return rc;
-    if (!sub.empty()) {
-        // lanes of a wave run in lock-step: group subframes that take the same code path (constant / verbatim / order class)
-        std::stable_sort(sub.begin(), sub.end(), [](const SubJob &x, const SubJob &y) { return x.pad < y.pad; });
-        DevBuf &jb = ctx->seg_buf;
-        const size_t sb = sub.size() * sizeof(SubJob), fb = fin.size() * sizeof(FinJob);
-        if ((rc = jb.ensure(sb + fb + 64))) return rc;
-        AUKIT_HIP_CHECK(hipMemcpyAsync(jb.p, sub.data(), sb, hipMemcpyHostToDevice, ctx->stream));
-        AUKIT_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(jb.p) + sb, fin.data(), fb, hipMemcpyHostToDevice, ctx->stream));
-        int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(jb.p) + sb + fb);
-        AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
-        if ((rc = ctx_begin_kernel(ctx))) return rc;
-        hipLaunchKernelGGL(k_flac_subframe, dim3((unsigned)((sub.size() + 63) / 64)), dim3(64), 0, ctx->stream, G, reinterpret_cast<const SubJob *>(jb.p),
-                           (unsigned long long)sub.size(), reinterpret_cast<double *>(ctx->tmp_buf.p), err);
-        AUKIT_HIP_CHECK(hipGetLastError());
-        if ((rc = ctx_end_kernel(ctx, "k_flac_subframe", in->total() + tot * 8))) return rc;
-        hipLaunchKernelGGL(k_flac_finish, dim3((unsigned)fin.size()), dim3(256), 0, ctx->stream, reinterpret_cast<const FinJob *>(reinterpret_cast<char *>(jb.p) + sb),
-                           (unsigned long long)fin.size(), reinterpret_cast<double *>(ctx->tmp_buf.p), D.depth);
-        AUKIT_HIP_CHECK(hipGetLastError());
-        int herr = 0;
-        AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (herr) return fail(AUKIT_E_HIP, "internal: FLAC subframe decode disagreed with the parse pass (%d)", herr);
-    }
-    return AUKIT_OK;
+    return flac_run<double>(ctx, in, D, want_frames);
 }
 
 // aukit.flac(data)  aukit.lua:1657-1660
 int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
                       aukit_audio **out) {
     FlacDecoded D;
-    int rc = flac_decode_rows(ctx, in, D);
+    int rc = flac_decode_rows(ctx, in, D, false);
     if (rc) return rc;
     for (uint32_t s = 0; s < in->n; s++)
         if (D.status[s]) return fail(AUKIT_E_LUA, "%s", flac_err_msg(D.status[s]));  // decodeFLAC raises: the whole load fails
-    return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, 1, 1, out);
+    const double full = std::ldexp(1.0, D.depth);  // :505
+    if (D.wide) return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, 1, 1, out);
+    return audio_from_int_rows(ctx, SRC_I32, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, full, full, out);
 }
 
 // ================================================================= stream.flac  aukit.lua:3124-3191
 struct FsJob {
-    unsigned long long src_off;   // element offset of this (frame, channel) block in the decoded rows
-    unsigned long long last_off;  // element offset of the previous (frame, channel) block's LAST sample (src[0]); ~0 → {0, 0}
-    unsigned long long out_off;
+    u64 src_off;   // element offset of this (frame, channel) block in the decoded rows
+    u64 last_off;  // element offset of the previous (frame, channel) block's LAST sample (src[0]); ~0 → {0, 0}
+    u64 out_off;
     int blocksize, nout;
 };
-template <int INTERP, typename OUT_T>
-__global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, unsigned long long njobs, const double *rows, OUT_T *out, double ratio, double rcp, int exact,
+template <typename R> AUKIT_DEV double flac_row_value(const R *rows, u64 at, double full) {
+    if constexpr (sizeof(R) == 4) return (double)rows[at] / full;
+    else return rows[at];
+}
+template <int INTERP, typename OUT_T, typename R>
+__global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs, const R *rows, double full, OUT_T *out, double ratio, double rcp, int exact,
                                                    double lp_alpha) {
-    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    const u64 j = (u64)blockIdx.x * 64 + threadIdx.x;
     if (j >= njobs) return;
     const FsJob job = jobs[j];
-    const double *src = rows + job.src_off;  // src[k-1] = table index k
     double m1 = 0, z0 = 0;                   // src[-1], src[0] = last[1], last[2]  :3170-3171
-    if (job.last_off != ~0ull) { z0 = rows[job.last_off]; m1 = rows[job.last_off - 1]; }
+    if (job.last_off != ~0ull) { z0 = flac_row_value(rows, job.last_off, full); m1 = flac_row_value(rows, job.last_off - 1, full); }
     double ls = z0 / (z0 < 0 ? 128 : 127);   // :3172
     const int n = job.blocksize;
-    auto tap = [&](int k) -> double { return k >= 1 ? src[k - 1] : (k == 0 ? z0 : m1); };
+    auto tap = [&](int k) -> double { return k >= 1 ? flac_row_value(rows, job.src_off + (u64)(k - 1), full) : (k == 0 ? z0 : m1); };  // table index k
     for (int i = 0; i < job.nout; i++) {
         const double nn = (double)i;
         const double x = (exact ? div_rcp(nn, ratio, rcp) : nn / ratio) + 1.0;
@@ -671,7 +1006,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.flac: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.flac output must be AUKIT_F64 or AUKIT_F32");
     FlacDecoded D;
-    int rc = flac_decode_rows(ctx, in, D);
+    int rc = flac_decode_rows(ctx, in, D, true);
     if (rc) return rc;
     const int C = D.channels;
     const double ratio = 48000 / D.rate;                                      // :3154
@@ -715,7 +1050,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     uint64_t nouts = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t op = 0;
-        unsigned long long prev_last = ~0ull;
+        u64 prev_last = ~0ull;
         for (auto &fr : D.frames[s]) {
             const int nout = (int)std::floor((double)fr.second * ratio);
             for (int c = 0; c < C; c++) {
@@ -738,12 +1073,14 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
         const int exact = exact_div_verified(ctx, ratio, maxn) ? 1 : 0;
         const unsigned grid = (unsigned)((jobs.size() + 63) / 64);
         const FsJob *dj = reinterpret_cast<const FsJob *>(ctx->seg_buf.p);
-        const double *rows = reinterpret_cast<const double *>(ctx->tmp_buf.p);
+        const double full = std::ldexp(1.0, D.depth);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
-#define AUKIT_FS(I, T) hipLaunchKernelGGL((k_flac_stream<I, T>), dim3(grid), dim3(64), 0, ctx->stream, dj, (unsigned long long)jobs.size(), rows, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
+#define AUKIT_FS2(I, T, R) hipLaunchKernelGGL((k_flac_stream<I, T, R>), dim3(grid), dim3(64), 0, ctx->stream, dj, (u64)jobs.size(), reinterpret_cast<const R *>(ctx->tmp_buf.p), full, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
+#define AUKIT_FS(I, T) do { if (D.wide) AUKIT_FS2(I, T, double); else AUKIT_FS2(I, T, int); } while (0)
         if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_FS(0, double); else if (interp == 1) AUKIT_FS(1, double); else AUKIT_FS(2, double); }
         else { if (interp == 0) AUKIT_FS(0, float); else if (interp == 1) AUKIT_FS(1, float); else AUKIT_FS(2, float); }
 #undef AUKIT_FS
+#undef AUKIT_FS2
         AUKIT_HIP_CHECK(hipGetLastError());
         if ((rc = ctx_end_kernel(ctx, "k_flac_stream", in->total() + nouts * dtype_size(dtype)))) { delete ck; return rc; }
     }

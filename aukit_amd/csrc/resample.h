@@ -24,7 +24,7 @@ struct Seg {
 };
 static_assert(sizeof(Seg) == 40, "Seg layout");
 
-enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7 };
+enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7, SRC_I32 = 8 };
 enum EpiKind {
     EPI_AUDIO = 0,       // Audio:resample  :666-668  (integer x copies unclamped, else clamp ±1)
     EPI_STREAM_PCM = 1,  // stream.pcm      :2397-2403 (no clamp of interp, 2-tap FIR, ×127/128, clamp ±128/127)
@@ -55,7 +55,7 @@ struct ResampleParams {
     int stage_channels;// channels staged per tile (1 when the source is pre-mixed or planar rows)
     int bit_depth, data_type, big_endian, planar, ulaw;
     int premix_mono;   // stream.pcm mono: mean of the channels at read time (:2368)
-    double norm_pos, norm_neg;  // SRC_I16 / SRC_I8: v / (v < 0 ? norm_neg : norm_pos)
+    double norm_pos, norm_neg;  // SRC_I16 / SRC_I8 / SRC_I32: v / (v < 0 ? norm_neg : norm_pos)
     double g711_scale;          // 1/0x2000 (aukit.g711) or 1/0x40 (stream.g711): exact power of two
     // epilogue
     void *out;

@@ -138,7 +138,7 @@ AUKIT_DEV int stage(const ResampleParams &P, const Seg &sg, int k_lo, int n_stag
             sm[c * P.cap + rel] = g711_value(base[(size_t)g * C + c], P.ulaw) * P.g711_scale;
         }
         return 0;
-    } else {  // planar rows: SRC_AUDIO_F64 / SRC_AUDIO_F32 / SRC_I16 / SRC_I8; channel c of a segment is row sg.stream * SC + c
+    } else {  // planar rows: SRC_AUDIO_F64 / SRC_AUDIO_F32 / SRC_I16 / SRC_I8 / SRC_I32; channel c of a segment is row sg.stream * SC + c
         const int SC = P.stage_channels;
         for (int c = 0; c < SC; c++) {
             const unsigned long long ro = P.src_off[(size_t)sg.stream * SC + c];
@@ -151,6 +151,9 @@ AUKIT_DEV int stage(const ResampleParams &P, const Seg &sg, int k_lo, int n_stag
                 for (int rel = tid; rel < n_stage; rel += 256) dst[rel] = (double)row[g0 + rel];
             } else if constexpr (SRC == SRC_I16) {
                 const short *row = reinterpret_cast<const short *>(P.src) + ro;
+                for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; dst[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
+            } else if constexpr (SRC == SRC_I32) {
+                const int *row = reinterpret_cast<const int *>(P.src) + ro;
                 for (int rel = tid; rel < n_stage; rel += 256) { double v = (double)row[g0 + rel]; dst[rel] = v / (v < 0 ? P.norm_neg : P.norm_pos); }
             } else {
                 const signed char *row = reinterpret_cast<const signed char *>(P.src) + ro;
@@ -302,7 +305,7 @@ static int launch_src(aukit_ctx *ctx, int interp, int epi, int out_dtype, const 
 }
 
 static const char *kernel_name(int src, int interp, int epi) {
-    static const char *srcn[] = {"pcm", "pcm_s16le_mono", "g711", "g711_mono", "audio_f64", "audio_f32", "i16", "i8"};
+    static const char *srcn[] = {"pcm", "pcm_s16le_mono", "g711", "g711_mono", "audio_f64", "audio_f32", "i16", "i8", "i32"};
     static const char *intn[] = {"none", "linear", "cubic", "sinc"};
     static const char *epin[] = {"audio", "stream_pcm", "stream_floor", "stream_dfpwm"};
     static thread_local char buf[96];
@@ -327,6 +330,7 @@ int launch_resample(aukit_ctx *ctx, int src_kind, int interp, int epi, int out_d
     case SRC_AUDIO_F32: rc = launch_src<SRC_AUDIO_F32>(ctx, interp, epi, out_dtype, P, lds_bytes, grid); break;
     case SRC_I16: rc = launch_src<SRC_I16>(ctx, interp, epi, out_dtype, P, lds_bytes, grid); break;
     case SRC_I8: rc = launch_src<SRC_I8>(ctx, interp, epi, out_dtype, P, lds_bytes, grid); break;
+    case SRC_I32: rc = launch_src<SRC_I32>(ctx, interp, epi, out_dtype, P, lds_bytes, grid); break;
     default: rc = fail(AUKIT_E_ARG, "bad source kind");
     }
     if (rc) return rc;

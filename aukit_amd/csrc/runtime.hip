@@ -150,7 +150,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release();
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->kev0) (void)hipEventDestroy(c->kev0);

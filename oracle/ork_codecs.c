@@ -753,7 +753,7 @@ int ork__flac_frame(ork_flac_dec *d, double **out, size_t *block_size) {
     int nch = d->numChannels, sampleDepth = d->sampleDepth, rc = ORK_OK;
     double *sub[ORK_MAX_CH] = {0};
     for (int c = 0; c < nch; c++) {
-        sub[c] = (double *)calloc((size_t)blockSize, sizeof(double));
+        sub[c] = (double *)calloc((size_t)blockSize + 32, sizeof(double)); /* +32: warm-up entries past blockSize (a Lua table just grows) */
         if (!sub[c]) { rc = ork__fail(ORK_E_NOMEM, "out of memory"); goto fail; }
     }
     if (0 <= chanAsgn && chanAsgn <= 7) { /* :475-478 */
