@@ -746,7 +746,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
     uint64_t capc = in->total() / 2048 + n + 4096;  // candidate slots (grown on demand)
     uint64_t guess = 0;
     for (uint32_t s = 0; s < n; s++) guess += (uint64_t)D.info[s].nsamples * C;
-    uint64_t scap = std::max<uint64_t>(guess + guess / 16 + 65536, ctx->tmp_buf3.cap / sizeof(R));  // scratch elements (grown on demand)
+    uint64_t scap = std::max<uint64_t>(guess + guess / 16 + 65536, ctx->tmp_buf3.cap > 256 ? (ctx->tmp_buf3.cap - 256) / sizeof(R) : 0);  // scratch elements (grown on demand)
     uint64_t maxlen = 1;
     for (uint32_t s = 0; s < n; s++) maxlen = std::max<uint64_t>(maxlen, in->off[s + 1] - in->off[s]);
 
