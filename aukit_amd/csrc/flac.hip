@@ -49,7 +49,8 @@ static const char *flac_err_msg(int e) {
 enum { FLAG_OVERFLOW = 1, FLAG_INTERNAL = 2 };
 
 constexpr int WN = 16;    // 64-bit words of bit-stream window per lane in LDS (128 bytes)
-constexpr int WSTR = 17;  // row stride of the window array (words): lanes L and L+32 share a bank pair, nothing worse
+constexpr int WSTR = 2 * WN + 1;  // row stride of the window array in 32-bit words (odd: lanes at the same offset hit distinct banks)
+constexpr unsigned LOW_BITS = (WN - 4) * 64;  // a lane stops for a refill once it is this far into its window
 constexpr int NC = 32;    // values a lane produces (extract) / restores (restore) per round
 constexpr int OSTR = 33;  // row stride of the value array
 
@@ -69,7 +70,7 @@ struct FlacGlobals {
 // reaches outside the window (long warm-up / coefficient runs, the 44-bit look-back of readUint(n >= 32)).
 struct Bits {
     const u64 *w0;
-    const u64 *lw;      // this lane's window row: lw[d] = big-endian word win_lo + d
+    const unsigned *lw; // this lane's window row: lw[k] = big-endian 32-bit word k of the stream, counted from 64-bit word win_lo
     u64 safe_words;
     u64 first, end;     // bit offsets (relative to w0) of the BitInputStream start and of the end of the string
     u64 pos, limit;
@@ -79,7 +80,7 @@ struct Bits {
 AUKIT_DEV u64 be64(u64 v) { return __builtin_bswap64(v); }
 AUKIT_DEV u64 fetch(const Bits &b, u64 wi) {
     const u64 d = wi - b.win_lo;
-    if (d < (u64)WN) return b.lw[d];
+    if (d < (u64)WN) return (u64)b.lw[2 * d] << 32 | b.lw[2 * d + 1];
     return wi < b.safe_words ? be64(b.w0[wi]) : 0ull;
 }
 AUKIT_DEV void bits_seek(Bits &b, u64 pos) {
@@ -184,11 +185,19 @@ __global__ __launch_bounds__(64) void k_flac_header(const unsigned char *src, co
     out[s] = r;
 }
 
-// frame-header length as decodeFrame walks it (:518-553) and CRC-8 (poly 0x07) over it; false when the header does not fit
-AUKIT_DEV bool flac_header_crc_ok(const unsigned char *src, u64 p, u64 end) {
+// Speed-only plausibility filter for sync candidates: the header fields a real encoder writes for this stream (reserved bits
+// clear, channel assignment and sample size matching STREAMINFO) and the header CRC-8 (poly 0x07) over the bytes decodeFrame
+// walks (:518-553).  The reference checks none of this, so nothing here may change results: see k_flac_chain's miss path.
+AUKIT_DEV bool flac_header_plausible(const unsigned char *src, u64 p, u64 end, int channels, int depth) {
     if (p + 6 > end) return false;
-    const unsigned b2 = src[p + 2];
+    if (src[p + 1] & 2) return false;
+    const unsigned b2 = src[p + 2], b3 = src[p + 3];
     const unsigned bsc = b2 >> 4, src_code = b2 & 15;
+    if (bsc == 0 || src_code == 15 || (b3 & 1)) return false;
+    const unsigned asgn = b3 >> 4, ssc = (b3 >> 1) & 7;
+    if (asgn <= 7 ? (int)asgn != channels - 1 : (asgn > 10 || channels != 2)) return false;
+    const int ssd = ssc == 1 ? 8 : ssc == 2 ? 12 : ssc == 4 ? 16 : ssc == 5 ? 20 : ssc == 6 ? 24 : ssc == 7 ? 32 : 0;
+    if (ssc == 3 || (ssc != 0 && ssd != depth)) return false;
     u64 idx = p + 4;
     const unsigned t = src[idx];
     int lead = 0;
@@ -236,9 +245,8 @@ __global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, con
     const u64 b0 = off[s] + info[s].first_byte, b1 = off[s + 1];
     for (u64 p = b0 + (u64)blockIdx.x * 256 + threadIdx.x; p + 1 < b1; p += (u64)gridDim.x * 256) {
         if (src[p] == 0xFF && (src[p + 1] & 0xFC) == 0xF8) {  // temp * 64 + readUint(6) == 0x3FFE  :518
-            // Speed-only filter: keep candidates whose header CRC-8 checks out.  The reference ignores the CRC (:553), so a
-            // real frame with a damaged CRC is still decoded: the chain asks for any position that is not in the table.
-            if (!flac_header_crc_ok(src, p, b1)) continue;
+            // Speed-only filter: a frame that fails it is still decoded — the chain asks for any position that is not in the table.
+            if (!flac_header_plausible(src, p, b1, info[s].channels, info[s].depth)) continue;
             const u64 k = atomicAdd(count, 1ull);
             if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
         }
@@ -277,7 +285,7 @@ template <typename R> struct ExtractArgs {
 // decodeFrame (:510-557) without prediction: header, per-subframe warm-up / residual values → scratch, predictor → SubDesc.
 template <typename R>
 __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
-    __shared__ u64 s_win[64 * WSTR];
+    __shared__ unsigned s_win[64 * WSTR];
     __shared__ R s_out[64 * OSTR];
     __shared__ u64 s_ptr[64];
     __shared__ int s_cnt[64];
@@ -304,16 +312,16 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     int status = FE_OK, bs = 0, chan_asgn = 0, nsub = 0, ch = 0;
     int order = 0, type = 0, wasted = 0, sdepth = 0, lshift = 0, after = ST_SUBEND, resume = ST_SUB;
     int nparts = 0, psize = 0, pi = 0, param = 0, nbits = 0, param_bits = 4, escape = 15, remaining = 0, jpos = 0;
-    bool esc = false, direct = false, store_ok = false, ovf = false;
+    bool esc = false, direct = false, store_ok = false, ovf = false, gen_once = false, gen_part = false;
     long long cval = 0;
     u64 cand_scratch = 0, gcur = 0, end_byte = 0;
     SubDesc *sd = A.sd + (size_t)idx * C;
     R *const orow = s_out + lane * OSTR;
 
     for (;;) {
-        // ---- slide the LDS windows of the lanes that have used half of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
+        // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
         {
-            const bool want = st != ST_DONE && (fresh || (b.wi - b.win_lo) >= (u64)(WN / 2));
+            const bool want = st != ST_DONE && (fresh || (b.wi - b.win_lo) >= (u64)(WN / 4));
             const u64 new_lo = b.wi & ~1ull;
             if (want) b.win_lo = new_lo;
             const int sub8 = lane & 7, grp = lane >> 3;
@@ -326,8 +334,9 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     const u64 wj = ws + 2 * (u64)sub8;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (wj < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + wj);
-                    s_win[s * WSTR + 2 * sub8] = be64((u64)v.x | (u64)v.y << 32);
-                    s_win[s * WSTR + 2 * sub8 + 1] = be64((u64)v.z | (u64)v.w << 32);
+                    unsigned *wrow = s_win + s * WSTR + 4 * sub8;
+                    wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
+                    wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
                 }
             }
             __syncthreads();
@@ -337,7 +346,60 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         int cnt = 0;
         if (st == ST_DIRECT_WAIT) { __threadfence(); direct = true; st = resume; }
         while (st != ST_DONE && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
-            if (st == ST_CODES) {
+            if (!direct && !gen_once && ((st == ST_CODES && !esc && !gen_part) || st == ST_PART)) {
+                // ---- fast path: Rice-coded partitions (:393-401) on a 64-bit shift register fed from the LDS window.  One loop, one
+                // exit condition, selects instead of branches (hipcc's exec-mask bookkeeping for a loop with many exits cost more
+                // than the decoding).  An iteration reads either a partition header or one residual; anything unusual (escape
+                // partition, Rice parameter > 26, 32+ zero bits of unary prefix) stops the loop and is left to the generic reader.
+                const u64 wbase = b.win_lo << 6;
+                unsigned rp = (unsigned)(b.pos - wbase);
+                const unsigned end_rel = (unsigned)min(b.end - wbase, (u64)1 << 30);
+                const unsigned limit_rel = (unsigned)min(b.limit > wbase ? b.limit - wbase : 0ull, (u64)1 << 30);
+                unsigned wd = (rp >> 5) + 2;  // next 32-bit word of the window to shift in
+                u64 buf = ((u64)b.lw[wd - 2] << 32 | b.lw[wd - 1]) << (rp & 31);
+                int avail = 64 - (int)(rp & 31);  // valid bits at the top of buf; >= 32 at the top of every iteration
+                unsigned wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];  // loaded one iteration ahead: LDS latency stays off the dependency chain
+                int why = 0;  // 1: hand over to the generic reader, 2: ran off the end of the data, 3: over the bit budget
+                bool go = true;
+                while (go) {
+                    const bool hdr = remaining == 0;
+                    const unsigned hi = (unsigned)(buf >> 32);
+                    const int z = __builtin_clz(hi | 1u);
+                    const int pv = (int)(hi >> (32 - param_bits));
+                    const int total = hdr ? param_bits : z + 1 + param;  // bits of this header / residual
+                    const unsigned low = ((((hi << z) << 1) >> 1) >> (31 - param));  // the `param` bits after the unary prefix
+                    const unsigned nrp = rp + (unsigned)total;
+                    const bool b_gen = hdr ? ((pv >= escape) | (pv > 26)) : ((hi == 0) | (total > 32));
+                    const bool b_eof = nrp > end_rel, b_lim = hdr & (nrp > limit_rel);
+                    const int bad = b_gen ? 1 : (b_eof ? 2 : (b_lim ? 3 : 0));
+                    const bool good = bad == 0;
+                    why = bad;
+                    const int tot = good ? total : 0;
+                    buf <<= tot;
+                    avail -= tot;
+                    rp += (unsigned)tot;
+                    const bool need = avail < 32;
+                    buf |= need ? (u64)wnext << (32 - avail) : 0ull;
+                    avail += need ? 32 : 0;
+                    wd += need ? 1u : 0u;
+                    wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];
+                    // a header sets the parameter and the number of residuals of partition pi (:394-395); a residual is stored
+                    const int count = psize - (pi == 0 ? min(order, psize) : 0);
+                    const unsigned u = ((unsigned)z << param) | low;
+                    orow[min(cnt, NC - 1)] = (R)((int)(u >> 1) ^ -(int)(u & 1));
+                    cnt += (good & !hdr) ? 1 : 0;
+                    param = (good & hdr) ? pv : param;
+                    remaining = good ? (hdr ? count : remaining - 1) : remaining;
+                    pi += (good & (remaining == 0)) ? 1 : 0;  // a finished (or empty) partition
+                    go = good & (cnt < NC) & (rp < LOW_BITS) & ((remaining > 0) | (pi < nparts));
+                }
+                esc = false; nbits = 0;
+                bits_seek(b, wbase + rp);
+                if (why == 1) gen_once = true;
+                else if (why == 2) { b.eof = 1; status = FE_NIL; st = ST_DONE; }
+                else if (why == 3) { status = FE_LIMIT; st = ST_DONE; }
+                if (why <= 1) st = remaining > 0 ? ST_CODES : (pi < nparts ? ST_PART : ST_SUBEND);
+            } else if (st == ST_CODES) {
                 while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = esc ? read_sint(b, nbits) : read_rice(b, param);
                     if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
@@ -345,9 +407,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     else orow[cnt++] = (R)v;
                     jpos++;
                     remaining--;
+                    if (gen_once) { gen_once = false; break; }
                 }
                 if (b.eof) { status = FE_NIL; st = ST_DONE; }
-                else if (remaining == 0) { pi++; st = pi < nparts ? ST_PART : ST_SUBEND; }
+                else if (remaining == 0) { pi++; gen_part = false; st = pi < nparts ? ST_PART : ST_SUBEND; }
             } else if (st == ST_WARM) {  // warm-up samples (:422-424, :430-432) or a VERBATIM subframe (:456-458)
                 while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = read_sint(b, sdepth);
@@ -367,6 +430,8 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 while (remaining > 0 && cnt < NC) { orow[cnt++] = (R)cval; remaining--; }
                 if (remaining == 0) st = ST_SUBEND;
             } else if (st == ST_PART) {  // :394-406
+                gen_once = false;
+                gen_part = false;
                 param = (int)read_uint(b, param_bits);
                 esc = param >= escape;
                 nbits = 0;
@@ -377,6 +442,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     const int start = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
                     remaining = endd > start ? endd - start : 0;
                     jpos = start;
+                    gen_part = !esc && param > 26;
                     if (remaining > 0) st = ST_CODES;
                     else { pi++; st = pi < nparts ? ST_PART : ST_SUBEND; }
                 }
@@ -471,8 +537,9 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     nsub = 2;
                     if (C != 2) { status = FE_NIL; st = ST_DONE; continue; }  // result[ch] of a missing / extra channel is nil (:482-507)
                 } else { status = FE_CHAN; st = ST_DONE; continue; }
-                // bit budget: `limit_factor` times the size of an all-VERBATIM frame (no encoder emits a bigger one)
-                b.limit = (A.limit_factor > 0 && !c.nolimit) ? b.pos + (u64)A.limit_factor * (u64)bs * (u64)C * (u64)(depth + 2) + 4096 : ~0ull;
+                // bit budget: `limit_factor` quarters of the size of an all-VERBATIM frame (no encoder emits a bigger one); a false
+                // candidate crawling through garbage on one lane would otherwise hold its whole wave for tens of milliseconds
+                b.limit = (A.limit_factor > 0 && !c.nolimit) ? b.pos + (u64)A.limit_factor * (u64)bs * (u64)C * (u64)(depth + 2) / 4 + 4096 : ~0ull;
                 const u64 need = (u64)nsub * (u64)bs;
                 cand_scratch = atomicAdd(A.scratch_cursor, (need + 3) & ~3ull);
                 store_ok = cand_scratch + need <= A.scratch_cap;
@@ -799,7 +866,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
                 if ((rc = ctx->tmp_buf3.ensure(scap * sizeof(R) + 256))) return rc;
                 AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->scratch_cursor, 0, 8, ctx->stream));
                 if ((rc = ctx_begin_kernel(ctx))) return rc;
-                if ((rc = extract(0, ncand, 4))) return rc;
+                if ((rc = extract(0, ncand, 5))) return rc;
                 if ((rc = ctx_end_kernel(ctx, "k_flac_extract", in->total() + guess * sizeof(R)))) return rc;
             }
             // ---- 4. follow the chains
