@@ -346,11 +346,12 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         int cnt = 0;
         if (st == ST_DIRECT_WAIT) { __threadfence(); direct = true; st = resume; }
         while (st != ST_DONE && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
-            if (!direct && !gen_once && ((st == ST_CODES && !esc && !gen_part) || st == ST_PART)) {
-                // ---- fast path: Rice-coded partitions (:393-401) on a 64-bit shift register fed from the LDS window.  One loop, one
-                // exit condition, selects instead of branches (hipcc's exec-mask bookkeeping for a loop with many exits cost more
-                // than the decoding).  An iteration reads either a partition header or one residual; anything unusual (escape
-                // partition, Rice parameter > 26, 32+ zero bits of unary prefix) stops the loop and is left to the generic reader.
+            if (!direct && !gen_once && !gen_part && (st == ST_CODES || st == ST_PART || (st == ST_WARM && sdepth < 32))) {
+                // ---- fast path for everything that is a run of bit fields: Rice partitions incl. their headers and escape-coded
+                // partitions (:393-407), warm-up samples and VERBATIM subframes (:422-424, :456-458).  A 64-bit shift register is fed
+                // from the LDS window one 32-bit word ahead; one loop, one exit condition, selects instead of branches (hipcc's
+                // exec-mask bookkeeping for a loop with many exits cost more than the decoding).  One iteration = one field.  The
+                // rare cases (Rice parameter > 26, a residual longer than 32 bits) stop the loop and go to the generic reader.
                 const u64 wbase = b.win_lo << 6;
                 unsigned rp = (unsigned)(b.pos - wbase);
                 const unsigned end_rel = (unsigned)min(b.end - wbase, (u64)1 << 30);
@@ -359,21 +360,32 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 u64 buf = ((u64)b.lw[wd - 2] << 32 | b.lw[wd - 1]) << (rp & 31);
                 int avail = 64 - (int)(rp & 31);  // valid bits at the top of buf; >= 32 at the top of every iteration
                 unsigned wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];  // loaded one iteration ahead: LDS latency stays off the dependency chain
+                const bool warm = st == ST_WARM;
                 int why = 0;  // 1: hand over to the generic reader, 2: ran off the end of the data, 3: over the bit budget
                 bool go = true;
                 while (go) {
-                    const bool hdr = remaining == 0;
+                    const bool hdr = !warm & (remaining == 0);
+                    const bool fixed = warm | esc;
+                    const int nfix = warm ? sdepth : nbits;
                     const unsigned hi = (unsigned)(buf >> 32);
                     const int z = __builtin_clz(hi | 1u);
+                    // partition header: Rice parameter, or the escape code followed by a 5-bit field width
                     const int pv = (int)(hi >> (32 - param_bits));
-                    const int total = hdr ? param_bits : z + 1 + param;  // bits of this header / residual
-                    const unsigned low = ((((hi << z) << 1) >> 1) >> (31 - param));  // the `param` bits after the unary prefix
+                    const bool is_esc = pv >= escape;
+                    const int nb5 = (int)((hi << param_bits) >> 27);
+                    const int total = hdr ? param_bits + (is_esc ? 5 : 0) : (fixed ? nfix : z + 1 + param);
                     const unsigned nrp = rp + (unsigned)total;
-                    const bool b_gen = hdr ? ((pv >= escape) | (pv > 26)) : ((hi == 0) | (total > 32));
+                    const bool b_gen = hdr ? (!is_esc & (pv > 26)) : (!fixed & ((hi == 0) | (total > 32)));
                     const bool b_eof = nrp > end_rel, b_lim = hdr & (nrp > limit_rel);
                     const int bad = b_gen ? 1 : (b_eof ? 2 : (b_lim ? 3 : 0));
                     const bool good = bad == 0;
                     why = bad;
+                    // the value: `param` bits after the unary prefix (zig-zag), or a sign-extended nfix-bit field
+                    const unsigned low = ((((hi << z) << 1) >> 1) >> (31 - param));
+                    const unsigned u = ((unsigned)z << param) | low;
+                    const int v_rice = (int)(u >> 1) ^ -(int)(u & 1);
+                    const int v_fix = nfix ? ((int)hi >> (32 - nfix)) : 0;
+                    orow[min(cnt, NC - 1)] = (R)(fixed ? v_fix : v_rice);
                     const int tot = good ? total : 0;
                     buf <<= tot;
                     avail -= tot;
@@ -383,22 +395,25 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     avail += need ? 32 : 0;
                     wd += need ? 1u : 0u;
                     wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];
-                    // a header sets the parameter and the number of residuals of partition pi (:394-395); a residual is stored
+                    // a header sets the coding of partition pi and its number of residuals (:394-395, :403); a value is stored
                     const int count = psize - (pi == 0 ? min(order, psize) : 0);
-                    const unsigned u = ((unsigned)z << param) | low;
-                    orow[min(cnt, NC - 1)] = (R)((int)(u >> 1) ^ -(int)(u & 1));
+                    const bool gh = good & hdr;
                     cnt += (good & !hdr) ? 1 : 0;
-                    param = (good & hdr) ? pv : param;
+                    param = gh ? pv : param;
+                    esc = gh ? is_esc : esc;
+                    nbits = gh ? (is_esc ? nb5 : 0) : nbits;
                     remaining = good ? (hdr ? count : remaining - 1) : remaining;
-                    pi += (good & (remaining == 0)) ? 1 : 0;  // a finished (or empty) partition
-                    go = good & (cnt < NC) & (rp < LOW_BITS) & ((remaining > 0) | (pi < nparts));
+                    pi += (good & !warm & (remaining == 0)) ? 1 : 0;  // a finished (or empty) partition
+                    go = good & (cnt < NC) & (rp < LOW_BITS) & ((remaining > 0) | (!warm & (pi < nparts)));
                 }
-                esc = false; nbits = 0;
                 bits_seek(b, wbase + rp);
                 if (why == 1) gen_once = true;
                 else if (why == 2) { b.eof = 1; status = FE_NIL; st = ST_DONE; }
-                else if (why == 3) { status = FE_LIMIT; st = ST_DONE; }
-                if (why <= 1) st = remaining > 0 ? ST_CODES : (pi < nparts ? ST_PART : ST_SUBEND);
+                else if (why == 3 || (warm && rp > limit_rel)) { status = FE_LIMIT; st = ST_DONE; }
+                if (st != ST_DONE) {
+                    if (warm) st = remaining == 0 ? after : ST_WARM;
+                    else st = remaining > 0 ? ST_CODES : (pi < nparts ? ST_PART : ST_SUBEND);
+                }
             } else if (st == ST_CODES) {
                 while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = esc ? read_sint(b, nbits) : read_rice(b, param);
