@@ -238,15 +238,38 @@ AUKIT_DEV unsigned hash_lookup(const CandHash &H, u64 key) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_flac_find(const unsigned char *src, const u64 *off, const FlacStreamInfo *info, unsigned n,
-                                                  Cand *cands, u64 cap, u64 *count, CandHash H) {
-    const unsigned s = blockIdx.y;
-    if (info[s].status) return;
-    const u64 b0 = off[s] + info[s].first_byte, b1 = off[s + 1];
-    for (u64 p = b0 + (u64)blockIdx.x * 256 + threadIdx.x; p + 1 < b1; p += (u64)gridDim.x * 256) {
-        if (src[p] == 0xFF && (src[p + 1] & 0xFC) == 0xF8) {  // temp * 64 + readUint(6) == 0x3FFE  :518
+// One 16-byte vector (+ the first byte of the next one) per thread and step: 16 byte positions are tested for the sync code
+// (round 1 read two bytes per thread and launched 4 M workgroups: 6 ms for 3.6 GB; this is one pass at HBM speed).
+__global__ __launch_bounds__(256) void k_flac_find(const FlacGlobals G, u64 total, unsigned n, Cand *cands, u64 cap, u64 *count, CandHash H) {
+    const u64 base_off = G.base_bit >> 3;  // G.src = (bytes of G.w0) + base_off
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(G.w0);
+    const u64 nvec = G.safe_words >> 1;
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < nvec; c += (u64)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(wb + 16 * c);
+        const unsigned nxt = (c + 1 < nvec) ? *reinterpret_cast<const unsigned *>(wb + 16 * c + 16) : 0u;
+        const unsigned w[5] = {v.x, v.y, v.z, v.w, nxt};
+        unsigned hits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 x = (u64)w[q] | (u64)w[q + 1] << 32;
+#pragma unroll
+            for (int i = 0; i < 4; i++)  // byte 0 = 0xFF, byte 1 = 0xF8 / 0xF9 (0x3FFE :518, reserved bit clear)
+                hits |= ((((unsigned)(x >> (8 * i))) & 0xFEFFu) == 0xF8FFu) ? 1u << (4 * q + i) : 0u;
+        }
+        while (hits) {
+            const int i = __builtin_ctz(hits);
+            hits &= hits - 1;
+            const u64 pa = 16 * c + (u64)i;
+            if (pa < base_off || pa - base_off + 1 >= total) continue;
+            const u64 p = pa - base_off;  // byte position in the batch
+            unsigned lo = 0, hi = n;      // stream: off[s] <= p < off[s + 1]
+            while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (G.off[m] <= p) lo = m; else hi = m; }
+            const unsigned s = lo;
+            const FlacStreamInfo si = G.info[s];
+            const u64 b1 = G.off[s + 1];
+            if (si.status || p < G.off[s] + si.first_byte || p + 1 >= b1) continue;
             // Speed-only filter: a frame that fails it is still decoded — the chain asks for any position that is not in the table.
-            if (!flac_header_plausible(src, p, b1, info[s].channels, info[s].depth)) continue;
+            if (!flac_header_plausible(G.src, p, b1, si.channels, si.depth)) continue;
             const u64 k = atomicAdd(count, 1ull);
             if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
         }
@@ -829,8 +852,6 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
     uint64_t guess = 0;
     for (uint32_t s = 0; s < n; s++) guess += (uint64_t)D.info[s].nsamples * C;
     uint64_t scap = std::max<uint64_t>(guess + guess / 16 + 65536, ctx->tmp_buf3.cap > 256 ? (ctx->tmp_buf3.cap - 256) / sizeof(R) : 0);  // scratch elements (grown on demand)
-    uint64_t maxlen = 1;
-    for (uint32_t s = 0; s < n; s++) maxlen = std::max<uint64_t>(maxlen, in->off[s + 1] - in->off[s]);
 
     for (int attempt = 0;; attempt++) {
         if (attempt > 8) return fail(AUKIT_E_HIP, "internal: FLAC candidate tables keep overflowing");
@@ -854,8 +875,8 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, ctx->stream));
         // ---- 2. sync candidates
         const uint64_t cand_room = capc - n - 64;  // the tail is kept for positions the chain asks for
-        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((maxlen + 255) / 256, 2048), n), dim3(256), 0, ctx->stream, in->data(), G.off, d_info, n,
-                           d_cand, cand_room, &d_cnt->ncand, H);
+        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 16)), dim3(256), 0, ctx->stream, G,
+                           (u64)in->total(), n, d_cand, cand_room, &d_cnt->ncand, H);
         AUKIT_HIP_CHECK(hipGetLastError());
         Counters hc;
         AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
