@@ -374,6 +374,12 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     P.norm_neg = norm_neg;
     P.out = a->dev;
     const int ip = do_resample ? interp : AUKIT_INTERP_NONE;
+    if (src_kind == SRC_I32 && dtype == AUKIT_F32 && do_resample && rows_dev == ctx->tmp_buf.p) {  // F32 pipelines: tolerance path
+        P.safe_lo = reinterpret_cast<const unsigned char *>(rows_dev);
+        P.safe_hi = P.safe_lo + (ctx->tmp_buf.cap & ~(size_t)15);
+        int frc = AUKIT_OK;
+        if (fast_try(ctx, SRC_I32, ip, rate, new_rate, segs, P, in_elems * 4 + out_elems * 4, &frc)) return frc;
+    }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, ip, 1, P, &lds))) return rc;
     return launch_resample(ctx, src_kind, ip, EPI_AUDIO, dtype, P, lds, in_elems * (src_kind == SRC_I16 ? 2 : src_kind == SRC_I32 || src_kind == SRC_AUDIO_F32 ? 4 : src_kind == SRC_AUDIO_F64 ? 8 : 1) + out_elems * dtype_size(dtype), nullptr);

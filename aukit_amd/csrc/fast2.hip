@@ -20,6 +20,7 @@ template <int SRC> struct SrcTraits;
 template <> struct SrcTraits<SRC_PCM_S16LE_MONO> { static constexpr int BYTES = 2, SPV = 8; };
 template <> struct SrcTraits<SRC_G711_MONO> { static constexpr int BYTES = 1, SPV = 16; };
 template <> struct SrcTraits<SRC_AUDIO_F32> { static constexpr int BYTES = 4, SPV = 4; };
+template <> struct SrcTraits<SRC_I32> { static constexpr int BYTES = 4, SPV = 4; };  // integer rows (FLAC): v * 2^-depth, exact in f32 for |v| < 2^24
 
 AUKIT_DEV float g711_f32b(unsigned byte, int ulaw, float scale) {
     unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
@@ -59,7 +60,7 @@ AUKIT_DEV WaveTile describe(const ResampleParams &P, const FastParams &F, unsign
     w.n_stage = (int)klast + 1 + HL + HR;
     w.w_lo = sg.w_lo;
     w.w_hi = sg.w_hi;
-    if constexpr (SRC == SRC_AUDIO_F32) w.base = P.src + 4 * (size_t)P.src_off[sg.stream] + 4 * sg.src_base;
+    if constexpr (SRC == SRC_AUDIO_F32 || SRC == SRC_I32) w.base = P.src + 4 * (size_t)P.src_off[sg.stream] + 4 * sg.src_base;
     else w.base = P.src + (size_t)P.src_off[sg.stream] + (long long)T::BYTES * sg.src_base;
     const unsigned char *a0 = w.base + (long long)T::BYTES * w.k_lo;
     w.al = (const unsigned char *)((uintptr_t)a0 & ~(uintptr_t)15);
@@ -87,6 +88,8 @@ AUKIT_DEV float sample_at(const ResampleParams &P, const FastParams &F, const un
         return (float)s * (s < 0 ? F.scale_neg : F.scale_pos);
     } else if constexpr (SRC == SRC_G711_MONO) {
         return g711_f32b(*q, P.ulaw, (float)P.g711_scale);
+    } else if constexpr (SRC == SRC_I32) {
+        return (float)*reinterpret_cast<const int *>(q) * F.scale_pos;
     } else {
         return *reinterpret_cast<const float *>(q);
     }
@@ -120,6 +123,8 @@ AUKIT_DEV void write_lds(const ResampleParams &P, const FastParams &F, const Wav
             for (int e = 0; e < 4; e++)
                 o[e] = make_float4(g711_f32b(ww[e] & 0xFF, P.ulaw, sc), g711_f32b((ww[e] >> 8) & 0xFF, P.ulaw, sc),
                                    g711_f32b((ww[e] >> 16) & 0xFF, P.ulaw, sc), g711_f32b(ww[e] >> 24, P.ulaw, sc));
+        } else if constexpr (SRC == SRC_I32) {
+            *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4((float)(int)u.x * F.scale_pos, (float)(int)u.y * F.scale_pos, (float)(int)u.z * F.scale_pos, (float)(int)u.w * F.scale_pos);
         } else {
             *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         }
@@ -269,7 +274,7 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     *taken = true;
     if (P.n_tiles == 0) return AUKIT_OK;
     if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
-    if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
+    if (src_kind == SRC_I32) F.scale_pos = F.scale_neg = (float)(1.0 / P.norm_pos);  // a power of two (checked by fast_try)
     size_t lds = (size_t)F.cap * 4 * 4 + (P.nt_store == 2 ? 4 * 256 * 4 : 0);  // 4 wave windows (+ 4 × 1 KiB of store-transpose staging in the x4 experiment)
     unsigned per_cu = 16;  // 2x the resident workgroups: measured +3.5 % over 8 (better tail balance across XCDs)
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
@@ -280,11 +285,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     case SRC_PCM_S16LE_MONO: rc = launch_src2<SRC_PCM_S16LE_MONO>(ctx, interp, nv, P, F, lds, grid); break;
     case SRC_G711_MONO: rc = launch_src2<SRC_G711_MONO>(ctx, interp, nv, P, F, lds, grid); break;
     case SRC_AUDIO_F32: rc = launch_src2<SRC_AUDIO_F32>(ctx, interp, nv, P, F, lds, grid); break;
+    case SRC_I32: rc = launch_src2<SRC_I32>(ctx, interp, nv, P, F, lds, grid); break;
     default: rc = fail(AUKIT_E_ARG, "bad fast source");
     }
     if (rc) return rc;
     static thread_local char nm[96];
-    static const char *srcn[] = {"", "pcm_s16le_mono", "", "g711_mono", "", "audio_f32"};
+    static const char *srcn[] = {"", "pcm_s16le_mono", "", "g711_mono", "", "audio_f32", "", "", "i32"};
     snprintf(nm, sizeof nm, "k_fast_wave<%s,%s,nv%d>", srcn[src_kind], interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
     return ctx_end_kernel(ctx, nm, algorithmic_bytes);
 }

@@ -61,6 +61,14 @@ def test_flac_blocksizes_and_config5_pipeline(ctx, oracle):
     ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(s), 48000, oracle.CUBIC), 20.0), 0.8))
     assert np.max(np.abs(m[0][0] - ref.data[0])) <= 1e-11 and np.array_equal(m[0][0], m[1][0])
     a32 = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_FLAC), 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave<i32")  # F32 pipelines resample the int32 rows with the f32 tolerance kernel
+    assert rms(a32.download()[0][1], oracle.resample(oracle.flac(s), 48000, oracle.CUBIC).data[1]) <= 1e-6
+    for depth, interp in ((24, "linear"), (8, "cubic")):
+        p = _pcm(30000, 2, depth, 5, 3)
+        sd = oracle.gen_flac(p.ravel(), 2, depth, 44100, 4096)
+        g = B.decode_resample(ctx, B.Batch.upload(ctx, [sd]), B.make_desc(N.CODEC_FLAC), 48000, interp, dtype=N.F32).download()[0]
+        r = oracle.resample(oracle.flac(sd), 48000, oracle.INTERP[interp])
+        assert rms(g[0], r.data[0]) <= 1e-6 and rms(g[1], r.data[1]) <= 1e-6
     B.effect(ctx, a32, "highpass", 20.0)
     B.effect(ctx, a32, "normalize", 0.8)
     assert rms(B.mono(ctx, a32).download()[0][0], ref.data[0]) <= 1e-6
