@@ -667,16 +667,28 @@ struct FrameRec { u64 sample_off; int bs, chan_asgn; unsigned stream, pad; };
 __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const CandInfo *ci, const SubDesc *sd, unsigned ncand, int C, const u64 *row_off,
                                                   const u64 *frame_base, const u64 *kind_base, u64 *kind_fill, SubJob *jobs, FrameRec *frames) {
     const unsigned k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= ncand) return;
-    const CandInfo f = ci[k];
-    if (!f.used) return;
-    const unsigned s = cands[k].stream;
-    for (int c = 0; c < f.nsub; c++) {
-        const int kind = sd[(size_t)k * C + c].kind & 3;
-        const u64 slot = kind_base[kind] + atomicAdd(&kind_fill[kind], 1ull);
-        jobs[slot] = SubJob{f.scratch + (u64)c * f.blocksize, row_off[(size_t)s * C + c] + f.sample_off, k * (unsigned)C + c, f.blocksize};
+    CandInfo f{};
+    if (k < ncand) f = ci[k];
+    const bool used = k < ncand && f.used;
+    const unsigned s = used ? cands[k].stream : 0;
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < C; c++) {  // wave-uniform trip count; one atomic per wave and order class instead of one per subframe
+        const bool have = used && c < f.nsub;
+        const int kind = have ? (sd[(size_t)k * C + c].kind & 3) : -1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 m = __ballot(kind == q);
+            if (!m) continue;
+            u64 base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(&kind_fill[q], (u64)__builtin_popcountll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+            if (kind == q) {
+                const u64 slot = kind_base[q] + base + (u64)__builtin_popcountll(m & ((1ull << lane) - 1));
+                jobs[slot] = SubJob{f.scratch + (u64)c * f.blocksize, row_off[(size_t)s * C + c] + f.sample_off, k * (unsigned)C + c, f.blocksize};
+            }
+        }
     }
-    frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
+    if (used) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
 }
 
 // restoreLinearPrediction (:411-419) + result[i] * 2^shift (:467-469).  One lane per subframe; 32 values per lane and round
@@ -709,12 +721,37 @@ __global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njo
     __syncthreads();
     bool ovf = false;
     const int half = lane >> 5, k32 = lane & 31;
-    for (int base = 0; base < maxbs; base += NC) {
-        for (int i = 0; i < 32; i++) {
-            const int s = 2 * i + half;
-            if (base + k32 < s_bs[s]) s_v[s * OSTR + k32] = scratch[s_src[s] + base + k32];
+    // 16-byte path: 8 lanes × 4 values per subframe and round, 8 subframes per instruction; the next round's loads are in flight
+    // while this round is predicted.  Needs 4-element alignment of every subframe of the wave (block sizes are multiples of 4 but for
+    // a stream's last frame); otherwise 4-byte accesses, two subframes per instruction.
+    const bool vec = INT && __all((job.src & 3) == 0 && (job.dst & 3) == 0 && (job.bs & 3) == 0);
+    const int grp = lane >> 3, sub4 = 4 * (lane & 7);
+    uint4 pre[8];
+    auto prefetch = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int s = 8 * i + grp;
+            pre[i] = make_uint4(0, 0, 0, 0);
+            if (base + sub4 < s_bs[s]) pre[i] = *reinterpret_cast<const uint4 *>(scratch + s_src[s] + base + sub4);
         }
-        __syncthreads();
+    };
+    if (vec) prefetch(0);
+    for (int base = 0; base < maxbs; base += NC) {
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                R *d = s_v + (8 * i + grp) * OSTR + sub4;
+                d[0] = (R)(int)pre[i].x; d[1] = (R)(int)pre[i].y; d[2] = (R)(int)pre[i].z; d[3] = (R)(int)pre[i].w;
+            }
+            __syncthreads();
+            if (base + NC < maxbs) prefetch(base + NC);
+        } else {
+            for (int i = 0; i < 32; i++) {
+                const int s = 2 * i + half;
+                if (base + k32 < s_bs[s]) s_v[s * OSTR + k32] = scratch[s_src[s] + base + k32];
+            }
+            __syncthreads();
+        }
         const int nmine = min(NC, job.bs - base);
         for (int k = 0; k < nmine; k++) {
             const int i = base + k;
@@ -752,9 +789,18 @@ __global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njo
             }
         }
         __syncthreads();
-        for (int i = 0; i < 32; i++) {
-            const int s = 2 * i + half;
-            if (base + k32 < s_bs[s]) rows[s_dst[s] + base + k32] = s_v[s * OSTR + k32];
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int s = 8 * i + grp;
+                const R *d = s_v + s * OSTR + sub4;
+                if (base + sub4 < s_bs[s]) *reinterpret_cast<uint4 *>(rows + s_dst[s] + base + sub4) = make_uint4((unsigned)(int)d[0], (unsigned)(int)d[1], (unsigned)(int)d[2], (unsigned)(int)d[3]);
+            }
+        } else {
+            for (int i = 0; i < 32; i++) {
+                const int s = 2 * i + half;
+                if (base + k32 < s_bs[s]) rows[s_dst[s] + base + k32] = s_v[s * OSTR + k32];
+            }
         }
         __syncthreads();
     }
