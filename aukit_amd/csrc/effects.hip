@@ -158,64 +158,100 @@ __global__ __launch_bounds__(256) void k_center(T *data, RowMeta m, unsigned lon
 struct Aff { double A, B; };
 AUKIT_DEV Aff aff_then(const Aff &f, const Aff &g) { return Aff{g.A * f.A, __builtin_fma(g.A, f.B, g.B)}; }
 
+// One workgroup per row, 64 bytes per thread and tile (rows start on 64-byte boundaries and are padded to 16 elements,
+// audio_prepare).  Per tile: every thread composes the affine maps of its own samples, a wave scan + one LDS exchange give the
+// value entering each thread, the recurrence is then run for real in the reference's operation order.  The next tile's vector
+// loads are issued before the scan, and carries / wave totals are double-buffered so that one barrier per tile is enough
+// (round 1: scalar strided accesses, no prefetch, 4 barriers per tile — 1.9 TB/s; see profiles/).
 template <typename T, bool HIGHPASS>
 __global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a) {
-    constexpr int PER = 8, TILE = 256 * PER;
-    __shared__ Aff wave_tot[4];
-    __shared__ double carry_y, carry_x;
+    constexpr int PER = 64 / (int)sizeof(T), TILE = 256 * PER, NV = PER * (int)sizeof(T) / 16;
+    __shared__ Aff wave_tot[2][4];
+    __shared__ double carry_y[2], carry_x[2];
     const unsigned r = blockIdx.x;
     unsigned long long base, len;
     row_of(m, r, &base, &len);
     if (len < 2) return;
     T *row = data + base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { carry_y = (double)row[0]; carry_x = (double)row[0]; }  // y[1] = x[1]
-    __syncthreads();
-    // elements 1 .. len-1 (0-based) are produced by the recurrence
-    for (unsigned long long t0 = 1; t0 < len; t0 += TILE) {
+    if (threadIdx.x == 0) { carry_y[0] = 0; carry_x[0] = 0; }
+    uint4 raw[NV], nraw[NV];
+    T xb = 0, nxb = 0;  // HIGHPASS: the ORIGINAL sample before this thread's first one, for the first lane of waves 1..3
+    auto fetch = [&](unsigned long long t0, uint4 (&dst)[NV], T &before) {
         const unsigned long long i0 = t0 + (unsigned long long)threadIdx.x * PER;
-        double x[PER], xprev = 0;
-        int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { x[k] = 0; if (i0 + k < len) { x[k] = (double)row[i0 + k]; cnt = k + 1; } }
-        if (HIGHPASS && cnt) xprev = (double)row[i0 - 1];  // ORIGINAL x[i-1]: read before anyone overwrites it
-        __syncthreads();
-        if (HIGHPASS && threadIdx.x == 0) xprev = carry_x;  // the tile's first predecessor was overwritten by the previous tile
-        // local composite of this thread's samples
+        for (int v = 0; v < NV; v++) {
+            dst[v] = make_uint4(0, 0, 0, 0);
+            if (i0 + (unsigned long long)v * (16 / sizeof(T)) < len) dst[v] = *reinterpret_cast<const uint4 *>(row + i0 + v * (16 / sizeof(T)));  // padded rows: whole vectors are readable
+        }
+        if (HIGHPASS && lane == 0 && wave > 0 && i0 < len) before = row[i0 - 1];
+    };
+    fetch(0, raw, xb);
+    int ph = 0;
+    for (unsigned long long t0 = 0; t0 < len; t0 += TILE, ph ^= 1) {
+        const unsigned long long i0 = t0 + (unsigned long long)threadIdx.x * PER;
+        double x[PER];
+        const T *rt = reinterpret_cast<const T *>(raw);
+#pragma unroll
+        for (int k = 0; k < PER; k++) x[k] = (double)rt[k];
+        const int cnt = i0 >= len ? 0 : (int)(len - i0 < (unsigned long long)PER ? len - i0 : PER);
+        const double xb_d = (double)xb;
+        if (t0 + TILE < len) fetch(t0 + TILE, nraw, nxb);  // in flight during the scan
+        const unsigned long long tile_last = (t0 + TILE <= len ? t0 + TILE : len) - 1;
+        double xprev = 0;
+        if (HIGHPASS) {
+            const double up = __shfl_up(x[PER - 1], 1);
+            xprev = lane > 0 ? up : (wave > 0 ? xb_d : carry_x[ph]);  // thread 0: the previous tile's last ORIGINAL sample (LDS: its owner has stored over it)
+        }
+        // local composite of this thread's samples; sample 0 of the row is the constant map y = x  (:3589, :3607)
         Aff f{1.0, 0.0};
         double xp = xprev;
-        for (int k = 0; k < cnt; k++) {
-            Aff g = HIGHPASS ? Aff{a, a * (x[k] - xp)} : Aff{1.0 - a, a * x[k]};
-            f = aff_then(f, g);
-            xp = x[k];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (k < cnt) {
+                Aff g = HIGHPASS ? Aff{a, a * (x[k] - xp)} : Aff{1.0 - a, a * x[k]};
+                if (i0 + k == 0) g = Aff{0.0, x[k]};
+                f = aff_then(f, g);
+                xp = x[k];
+            }
         }
-        // inclusive scan across the wave
+        if (HIGHPASS && cnt && i0 + cnt - 1 == tile_last) carry_x[ph ^ 1] = xp;  // xp = this thread's last ORIGINAL sample
         Aff inc = f;
+#pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             Aff p{__shfl_up(inc.A, o), __shfl_up(inc.B, o)};
             if (lane >= o) inc = aff_then(p, inc);
         }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        Aff pre{1.0, 0.0};  // composite of everything before this thread within the tile
-        for (int w = 0; w < wave; w++) pre = aff_then(pre, wave_tot[w]);
+        if (lane == 63) wave_tot[ph][wave] = inc;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the prefetched vectors stay in flight across the barrier
+        __builtin_amdgcn_s_barrier();        // also publishes the carries written during the previous tile
+        Aff pre{1.0, 0.0};
+        for (int w = 0; w < wave; w++) pre = aff_then(pre, wave_tot[ph][w]);
         Aff exc{__shfl_up(inc.A, 1), __shfl_up(inc.B, 1)};
         if (lane > 0) pre = aff_then(pre, exc);
-        const double cy = carry_y;
-        double y = __builtin_fma(pre.A, cy, pre.B);  // value entering this thread's first sample
+        double y = __builtin_fma(pre.A, carry_y[ph], pre.B);  // value entering this thread's first sample
         xp = xprev;
-        double lastx = 0;
-        for (int k = 0; k < cnt; k++) {
-            if (HIGHPASS) y = a * (y + x[k] - xp);      // d[i] = a * (d[i-1] + llx - lx)  :3613
-            else y = y + a * (x[k] - y);                // d[i] = l + a * (d[i] - l)      :3594
+        T out[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (i0 + k == 0) y = x[k];
+            else if (HIGHPASS) y = a * (y + x[k] - xp);  // d[i] = a * (d[i-1] + llx - lx)  :3613
+            else y = y + a * (x[k] - y);                 // d[i] = l + a * (d[i] - l)      :3594
             xp = x[k];
-            lastx = x[k];
-            row[i0 + k] = (T)y;
+            out[k] = (T)y;
+            if (k == cnt - 1 && i0 + k == tile_last) carry_y[ph ^ 1] = y;
         }
-        __syncthreads();
-        const unsigned long long tile_last = (t0 + TILE <= len ? t0 + TILE : len) - 1;
-        if (cnt && i0 + cnt - 1 == tile_last) { carry_y = y; carry_x = lastx; }
-        __syncthreads();
+        const uint4 *ov = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const unsigned long long e = i0 + (unsigned long long)v * (16 / sizeof(T));
+            if (e + 16 / sizeof(T) <= len) *reinterpret_cast<uint4 *>(row + e) = ov[v];
+            else
+                for (int q = 0; q < (int)(16 / sizeof(T)); q++) if (e + q < len) row[e + q] = out[v * (16 / sizeof(T)) + q];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) raw[v] = nraw[v];
+        xb = nxb;
     }
 }
 
