@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip"]
 HEADERS = ["common.h", "resample.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -24,6 +24,8 @@ FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center"
       "lowpass": 10, "highpass": 11}
 MAX_CH = 8
 OPT_EXACT_MATH, OPT_STORE_X4 = 0, 1
+WAVE_NONE, WAVE_SINE, WAVE_TRIANGLE, WAVE_SAWTOOTH, WAVE_SQUARE = 0, 1, 2, 3, 4
+PACK_TRUNC, PACK_FLOOR, PACK_STRICT = 0, 1, 2
 
 # every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -36,6 +38,7 @@ EXPORTS = [
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
     "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
+    "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
 ]
 
 

@@ -151,6 +151,64 @@ class Audio:
                 pos += chunkSize
         return it(), per / rate
 
+    # -- structural methods (either side of the hot path): device-side row copies
+    def _others(self, others, first_arg=1):
+        hs = [self._h]
+        for i, a in enumerate(others):
+            if not isinstance(a, Audio):
+                raise LuaError(f"bad argument #{first_arg + i} (expected Audio, got {type(a).__name__})")
+            if a.sampleRate != self.sampleRate:  # :702 / :756 resample with the default interpolation
+                a = a.resample(self.sampleRate)
+            hs.append(a._h)
+        return hs
+
+    def concat(self, *others):  # :695
+        return Audio(_wrap(B.concat, context(), self._others(others)), self.metadata, self.info)
+
+    def sub(self, start=None, last=None):  # :725
+        _expect(1, start, "number", "nil")
+        _expect(2, last, "number", "nil")
+        return Audio(_wrap(B.sub, context(), self._h, float(start or 0), float(last or 0)), self.metadata, self.info)
+
+    def combine(self, *others):  # :751
+        return Audio(_wrap(B.combine, context(), self._others(others)), self.metadata, self.info)
+
+    def split(self, *lists):  # :781 → one Audio per channel list
+        res = []
+        for n, cl in enumerate(lists, 1):
+            _expect(n, cl, "table")
+            if len(cl) == 0:
+                raise LuaError(f"bad argument #{n} (cannot use empty table)")
+            for cs in cl:
+                if not (1 <= cs <= self.channels()):
+                    raise LuaError(f"channel {cs} (in argument {n}) out of range")
+            res.append(Audio(_wrap(B.split, context(), self._h, list(cl)), self.metadata, self.info))
+        return tuple(res)
+
+    def rep(self, count):  # :839
+        _expect(1, count, "number")
+        return Audio(_wrap(B.rep, context(), self._h, float(count)), self.metadata, self.info)
+
+    def reverse(self):  # :856
+        return Audio(_wrap(B.reverse, context(), self._h), self.metadata, self.info)
+
+    def wav(self, bitDepth=None, int_mode=N.PACK_TRUNC):  # :947 (metadata LIST chunk not written: self.metadata must be empty)
+        bitDepth = 16 if bitDepth is None else _expect(1, bitDepth, "number")
+        nc, rate, n = self.channels(), self.sampleRate, int(self._h.layout()[0][0])
+        if self.metadata:
+            raise LuaError("Audio:wav with metadata is not supported by this mirror")
+        if bitDepth == 1:  # DFPWM in WAVE_FORMAT_EXTENSIBLE  :952-961, :981-985
+            body = self.dfpwm(True)
+            guid = bytes([0x3A, 0xC1, 0xFA, 0x38, 0x81, 0x1D, 0x43, 0x61, 0xA4, 0x0D, 0xCE, 0x53, 0xCA, 0x60, 0x7C, 0xD1])  # wavExtensible.dfpwm  :137
+            chmask = {1: 0x04, 2: 0x03, 3: 0x07, 4: 0x33, 5: 0x37, 6: 0x3F, 7: 0x637, 8: 0x63F}.get(nc, 0)  # wavExtensibleChannels  :141-149
+            return (struct.pack("<4sI4s4sIHHIIHHHHI16s4sII4sI", b"RIFF", len(body) + 72, b"WAVE", b"fmt ", 40, 0xFFFE, nc, int(rate), int(rate * nc / 8),
+                                int(math.ceil(nc / 8)), 1, 22, 1, chmask, guid, b"fact", 4, n, b"data", len(body)) + body)
+        if bitDepth not in (8, 16, 24, 32):
+            raise LuaError("bad argument #2 (invalid bit depth)")
+        body = _wrap(B.pack_pcm, context(), self._h, bitDepth, "unsigned" if bitDepth == 8 else "signed", False, True, int_mode).download()[0]
+        return struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", len(body) + 36, b"WAVE", b"fmt ", 16, 1, nc, int(rate), int(rate * nc * bitDepth / 8),
+                           int(nc * bitDepth / 8), bitDepth, b"data", len(body)) + body
+
     def __str__(self):
         return f"Audio: {self.sampleRate} Hz, {self.channels()} channels, {self.len()} seconds"
 
@@ -159,6 +217,54 @@ def _load(desc, data, dtype=None):
     ctx = context()
     bt = _wrap(B.Batch.upload, ctx, [data])
     return _wrap(B.decode, ctx, bt, desc, ctx.dtype if dtype is None else dtype)
+
+
+# ---------------------------------------------------------------- generators and packing  (aukit.lua:1779-1878)
+def new(duration, channels=None, sampleRate=None):  # :1783
+    _expect(1, duration, "number")
+    channels = 1 if channels is None else _expect(2, channels, "number")
+    sampleRate = 48000 if sampleRate is None else _expect(3, sampleRate, "number")
+    return Audio(_wrap(B.tone, context(), 1, 0.0, float(duration), 1.0, "none", 0.5, int(channels), float(sampleRate), N.F64))
+
+
+def tone(frequency, duration, amplitude=None, waveType=None, duty=None, channels=None, sampleRate=None):  # :1808
+    _expect(1, frequency, "number")
+    _expect(2, duration, "number")
+    amplitude = 1 if amplitude is None else _expect(3, amplitude, "number")
+    waveType = "sine" if waveType is None else waveType
+    duty = 0.5 if duty is None else _expect(5, duty, "number")
+    channels = 1 if channels is None else _expect(6, channels, "number")
+    sampleRate = 48000 if sampleRate is None else _expect(7, sampleRate, "number")
+    if waveType not in ("sine", "triangle", "sawtooth", "square"):
+        raise LuaError("bad argument #4 (invalid wave type)")
+    return Audio(_wrap(B.tone, context(), 1, float(frequency), float(duration), float(amplitude), waveType, float(duty), int(channels), float(sampleRate), N.F64))
+
+
+def noise(duration, amplitude=None, channels=None, sampleRate=None):  # :1840 draws from the host VM's math.random: not reproducible
+    raise LuaError("aukit.noise depends on the host VM's math.random and has no reproducible counterpart here")
+
+
+def pack(data, bitDepth=None, dataType=None, bigEndian=None, int_mode=N.PACK_TRUNC):  # :1861 on a table of numbers
+    _expect(1, data, "string", "table")
+    bitDepth = 8 if bitDepth is None else bitDepth
+    dataType = "signed" if dataType is None else dataType
+    if bitDepth not in (8, 16, 24, 32):
+        raise LuaError("bad argument #2 (invalid bit depth)")
+    if dataType not in ("signed", "unsigned", "float"):
+        raise LuaError("bad argument #3 (invalid data type)")
+    if dataType == "float" and bitDepth != 32:
+        raise LuaError("bad argument #2 (float audio must have 32-bit depth)")
+    if dataType == "float":
+        tmp = Audio.from_arrays([np.asarray(data, dtype=np.float64)], 48000)
+        return _wrap(B.pack_pcm, context(), tmp._h, 32, "float", bool(bigEndian), True, int_mode).download()[0]
+    # integers: pack() receives already-encoded numbers, so undo nothing — convert and lay out the bytes (the device packer works on [-1, 1] audio)
+    v = np.asarray(data, dtype=np.float64)
+    if int_mode == N.PACK_STRICT and np.any(v != np.floor(v)):
+        raise LuaError("bad argument #2 to 'pack' (number has no integer representation)")
+    q = (np.floor(v) if int_mode == N.PACK_FLOOR else np.trunc(v)).astype(np.int64).view(np.uint64)
+    nb = bitDepth // 8
+    raw = np.stack([((q >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8) for b in range(nb)], 1)
+    return bytes((raw[:, ::-1] if bigEndian else raw).ravel())
 
 
 # ---------------------------------------------------------------- loaders  (aukit.lua:1049-1777)

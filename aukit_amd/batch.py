@@ -311,6 +311,66 @@ def encode_pcm(ctx, audio, bit_depth=8, data_type="signed", interleaved=True, ou
     return out
 
 
+def _group(audios):
+    return (C.c_void_p * len(audios))(*[a._h for a in audios])
+
+
+def concat(ctx, audios, out=None):  # Audio:concat  aukit.lua:695
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_concat(ctx._h, _group(audios), len(audios), C.byref(out._h)))
+    return out
+
+
+def sub(ctx, audio, start=0.0, last=0.0, out=None):  # Audio:sub  aukit.lua:725
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_sub(ctx._h, audio._h, C.c_double(start), C.c_double(last), C.byref(out._h)))
+    return out
+
+
+def combine(ctx, audios, out=None):  # Audio:combine  aukit.lua:751
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_combine(ctx._h, _group(audios), len(audios), C.byref(out._h)))
+    return out
+
+
+def split(ctx, audio, channels, out=None):  # one result of Audio:split  aukit.lua:781 (1-based channel numbers)
+    out = out if out is not None else AudioBatch(ctx)
+    arr = (C.c_int32 * max(len(channels), 1))(*[int(c) for c in channels])
+    N.check(N.lib().aukit_split(ctx._h, audio._h, arr, len(channels), C.byref(out._h)))
+    return out
+
+
+def rep(ctx, audio, count, out=None):  # Audio:rep  aukit.lua:839
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_rep(ctx._h, audio._h, C.c_double(count), C.byref(out._h)))
+    return out
+
+
+def reverse(ctx, audio, out=None):  # Audio:reverse  aukit.lua:856
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_reverse(ctx._h, audio._h, C.byref(out._h)))
+    return out
+
+
+WAVES = {"none": N.WAVE_NONE, "sine": N.WAVE_SINE, "triangle": N.WAVE_TRIANGLE, "sawtooth": N.WAVE_SAWTOOTH, "square": N.WAVE_SQUARE}
+
+
+def tone(ctx, n, frequency, duration, amplitude=1.0, wave="sine", duty=0.5, channels=1, sample_rate=48000.0, dtype=None, out=None):
+    """aukit.tone (aukit.lua:1808); wave="none" is aukit.new (:1783).  `n` identical audios."""
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_tone(ctx._h, int(n), C.c_double(frequency), C.c_double(duration), C.c_double(amplitude), WAVES[wave] if isinstance(wave, str) else int(wave),
+                               C.c_double(duty), int(channels), C.c_double(sample_rate), ctx.dtype if dtype is None else dtype, C.byref(out._h)))
+    return out
+
+
+def pack_pcm(ctx, audio, bit_depth=8, data_type="signed", big_endian=False, interleaved=True, int_mode=N.PACK_TRUNC, out=None):
+    """aukit.pack(audio:pcm(...), ...) (aukit.lua:901, :1861) → Batch of byte strings."""
+    out = out if out is not None else Batch(ctx, C.c_void_p())
+    N.check(N.lib().aukit_pack_pcm(ctx._h, audio._h, int(bit_depth), N.PCM_TYPE[data_type] if isinstance(data_type, str) else int(data_type),
+                                   int(bool(big_endian)), int(bool(interleaved)), int(int_mode), C.byref(out._h)))
+    return out
+
+
 def stream_decode(ctx, batch, desc, interp, mono=False, dtype=None, out=None):
     out = out if out is not None else AudioBatch(ctx)
     ch = C.c_void_p()

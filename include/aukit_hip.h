@@ -167,6 +167,29 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
 /* Audio:pcm(bitDepth, dataType, interleaved) :901 → unfloored numbers, packed per stream */
 int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out);
 
+/* ---- either side of the hot path: structural Audio methods, generators, string packing ----
+ * Group calls take `count` audios with the same stream count, dtype and sample rate (the reference resamples mismatched
+ * rates first, :702 / :756 — do that with aukit_resample); stream i of the result is built from stream i of every input. */
+int aukit_concat(aukit_ctx *ctx, const aukit_audio *const *audios, uint32_t count, aukit_audio **out);   /* Audio:concat :695 */
+int aukit_sub(aukit_ctx *ctx, const aukit_audio *in, double start, double last, aukit_audio **out);      /* Audio:sub :725 (0 = default) */
+int aukit_combine(aukit_ctx *ctx, const aukit_audio *const *audios, uint32_t count, aukit_audio **out);  /* Audio:combine :751 */
+/* one result of Audio:split :781 — `channels` = 1-based channel numbers of the new object */
+int aukit_split(aukit_ctx *ctx, const aukit_audio *in, const int32_t *channels, uint32_t count, aukit_audio **out);
+int aukit_rep(aukit_ctx *ctx, const aukit_audio *in, double count, aukit_audio **out);                   /* Audio:rep :839 */
+int aukit_reverse(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out);                             /* Audio:reverse :856 */
+typedef enum { AUKIT_WAVE_NONE = 0 /* aukit.new: silence */, AUKIT_WAVE_SINE = 1, AUKIT_WAVE_TRIANGLE = 2, AUKIT_WAVE_SAWTOOTH = 3, AUKIT_WAVE_SQUARE = 4 } aukit_wave;
+/* aukit.new(duration, channels, sampleRate) :1783 / aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)
+ * :1808 — `n` identical audios (aukit.noise draws from the host VM's math.random and cannot be reproduced) */
+int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels,
+               double sample_rate, int dtype, aukit_audio **out);
+/* What string.pack does with a sample that has no integer representation is the host VM's business, not aukit.lua's
+ * (Audio:pcm hands it unfloored numbers, :875): truncate like a Java (long) cast (CC: Tweaked's VM), floor, or raise like PUC Lua 5.3. */
+typedef enum { AUKIT_PACK_TRUNC = 0, AUKIT_PACK_FLOOR = 1, AUKIT_PACK_STRICT = 2 } aukit_pack_mode;
+/* aukit.pack(audio:pcm(bitDepth, dataType, interleaved), bitDepth, dataType, bigEndian) :901 + :1861 → one byte string per
+ * stream; with (bitDepth, bitDepth == 8 ? unsigned : signed, little-endian, interleaved) these are the sample bytes of Audio:wav :966-971 */
+int aukit_pack_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode,
+                   aukit_batch **out);
+
 /* ---- aukit.stream.<codec>(data, ...) with string input, every call of the iterator at once ----
  * out audio: per stream the concatenation of all chunks (`channels` = number of chunk tables);
  * chunk metadata is read back with aukit_stream_chunks(). */
