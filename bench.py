@@ -46,6 +46,19 @@ def _random_bytes(torch, dev, n, seed):
     return torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.uint8)
 
 
+def _measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes), recorded in profiles/traffic.json; None when no matching measurement is committed."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
+            for e in json.load(fh)["entries"]:
+                if e["kernel"] == kernel and e["streams"] == args.streams and e["seconds"] == args.seconds:
+                    return e["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 class Workload:
     """setup(torch, dev, ctx, args, rank) → self; step() runs one pass; out_samples = units per pass on this rank."""
     name = unit = desc = ""
@@ -84,8 +97,19 @@ class Pcm16Cubic(Workload):
         for _ in range(args.cpu_streams):
             done += len(O.resample(O.pcm(data, 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
         dt = time.perf_counter() - t0
+        # (ii) every host core, one stream per task; ctypes releases the GIL around the C calls
+        import concurrent.futures
+        import os
+        cores = os.cpu_count() or 1
+        one = lambda _: len(O.resample(O.pcm(data, 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
+        t1 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(cores) as ex:
+            n_all = max(args.cpu_streams, min(args.streams, 16 * cores))
+            done_all = sum(ex.map(one, range(n_all)))
+        dt_all = time.perf_counter() - t1
         return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                "sample": f"{args.cpu_streams} of the {args.streams} streams ({self.n_samples} samples each), scalar fp64 C oracle, {dt:.1f} s"}
+                "sample": f"{args.cpu_streams} of the {args.streams} streams ({self.n_samples} samples each), scalar fp64 C oracle, {dt:.1f} s",
+                "all_cores": {"value": done_all / dt_all / 1e6, "unit": "Msamples/s", "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
 
 
 class G711Cubic(Workload):
@@ -116,7 +140,8 @@ class ImaStream(Workload):
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
         self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
         self.out = B.AudioBatch(ctx)
-        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, "cubic", dtype=N.I8, out=self.out)
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=N.I8, out=self.out)
+        self.arith = "i32 decode + f64 resample"
         self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B -> stream.adpcm cubic, int8 out (config 3a)"
         return self
 
@@ -160,6 +185,7 @@ class FlacPipeline(Workload):
         self.a = B.AudioBatch(ctx)
         self.m = B.AudioBatch(ctx)
         self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.arith = "i32 decode + " + args.dtype + " resample/effects"
 
         def step():
             B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=self.dtype, out=self.a)
@@ -187,7 +213,7 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default 4096; 16384 for dfpwm_transcode)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--cpu-streams", type=int, default=256, help="streams timed on the CPU oracle (0 disables)")
+    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams timed on the CPU oracle (0 disables)")
     ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the v1 fast kernel")
     ap.add_argument("--exact-math", type=int, default=0, help="1: fp64 reference-order kernel even for f32 storage")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -270,12 +296,12 @@ def main():
             "vs_baseline": None,
             # arithmetic type of the path: the f32-store fast kernels use exact integer positions + f32 FMA taps,
             # the reference-order kernels (f64 store or --exact-math 1) compute in fp64; DFPWM / ADPCM decode is int32
-            "dtype": "f32" if name.startswith("k_fast") else ("i32" if "dfpwm" in name else "f64"),
+            "dtype": getattr(wl, "arith", None) or ("f32" if name.startswith("k_fast") else ("i32" if "dfpwm" in name else "f64")),
             "data": "synthetic",
             "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": _measured_traffic(name, args), "kernel": name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_out_sample": alg_bytes / max(out_samples, 1)},
         }
         if world == 1 and args.cpu_streams > 0:
