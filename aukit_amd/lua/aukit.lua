@@ -27,6 +27,14 @@ int aukit_mix(aukit_ctx *, const aukit_audio *const *audios, int count, double a
 int aukit_effect(aukit_ctx *, aukit_audio *inout, int effect_id, const double *args, int nargs);
 int aukit_dfpwm_encode(aukit_ctx *, const aukit_audio *, int interleaved, aukit_batch **out);
 int aukit_encode_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_type, int interleaved, aukit_audio **out);
+int aukit_concat(aukit_ctx *, const aukit_audio *const *audios, uint32_t count, aukit_audio **out);
+int aukit_sub(aukit_ctx *, const aukit_audio *, double start, double last, aukit_audio **out);
+int aukit_combine(aukit_ctx *, const aukit_audio *const *audios, uint32_t count, aukit_audio **out);
+int aukit_split(aukit_ctx *, const aukit_audio *, const int32_t *channels, uint32_t count, aukit_audio **out);
+int aukit_rep(aukit_ctx *, const aukit_audio *, double count, aukit_audio **out);
+int aukit_reverse(aukit_ctx *, const aukit_audio *, aukit_audio **out);
+int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
+int aukit_pack_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode, aukit_batch **out);
 int aukit_stream_decode(aukit_ctx *, const aukit_batch *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_chunks_info(const aukit_chunks *, uint32_t *n, uint32_t *max_chunks);
 int aukit_chunks_get(const aukit_chunks *, uint32_t *nchunks, uint32_t *lens, double *pos, int32_t *status, double *length_seconds); void aukit_chunks_free(aukit_chunks *);
@@ -127,6 +135,81 @@ function Audio:dfpwm(interleaved)
     C.aukit_batch_free(b[0])
     return ffi.string(buf, tot[0])
 end
+
+-- structural methods (aukit.lua:690-866): device-side row copies, the source objects are never touched
+local function group(self, ...)
+    local audios = {self, ...}
+    local arr = ffi.new("const aukit_audio*[?]", #audios)
+    for i, a in ipairs(audios) do
+        if a.sampleRate ~= self.sampleRate then a = a:resample(self.sampleRate) audios[i] = a end  -- :702, :756
+        arr[i - 1] = a._h
+    end
+    return arr, #audios, audios  -- `audios` keeps the resampled temporaries alive across the call
+end
+function Audio:concat(...)
+    local arr, n, keep = group(self, ...)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_concat(ctx(), arr, n, o))
+    return wrap(o[0], self.metadata, self.info), keep and nil
+end
+function Audio:combine(...)
+    local arr, n, keep = group(self, ...)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_combine(ctx(), arr, n, o))
+    return wrap(o[0], self.metadata, self.info), keep and nil
+end
+function Audio:sub(start, last)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_sub(ctx(), self._h, start or 0, last or 0, o))
+    return wrap(o[0], self.metadata, self.info)
+end
+function Audio:split(...)
+    local res = {}
+    for n, cl in ipairs {...} do
+        if #cl == 0 then error("bad argument #" .. n .. " (cannot use empty table)") end
+        local ch = ffi.new("int32_t[?]", #cl, cl)
+        local o = ffi.new("aukit_audio*[1]")
+        check(C.aukit_split(ctx(), self._h, ch, #cl, o))
+        res[#res + 1] = wrap(o[0], self.metadata, self.info)
+    end
+    return table.unpack(res)
+end
+function Audio:rep(count)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_rep(ctx(), self._h, count, o))
+    return wrap(o[0], self.metadata, self.info)
+end
+function Audio:reverse()
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_reverse(ctx(), self._h, o))
+    return wrap(o[0], self.metadata, self.info)
+end
+local WAVE = {sine = 1, triangle = 2, sawtooth = 3, square = 4}
+function aukit.new(duration, channels, sampleRate)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_tone(ctx(), 1, 0, duration, 1, 0, 0.5, channels or 1, sampleRate or 48000, F64, o))
+    return wrap(o[0], {}, {})
+end
+function aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)
+    local w = WAVE[waveType or "sine"]
+    if not w then error("bad argument #4 (invalid wave type)", 2) end
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_tone(ctx(), 1, frequency, duration, amplitude or 1, w, duty or 0.5, channels or 1, sampleRate or 48000, F64, o))
+    return wrap(o[0], {}, {})
+end
+-- the sample bytes of Audio:wav (aukit.lua:966-971); the RIFF header is string.pack'ed around them exactly as :993-996 does.
+-- int_mode 0 = truncate like the CC: Tweaked VM's string.pack (a Java long cast); see include/aukit_hip.h
+local function wav_body(self, bitDepth)
+    local b = ffi.new("aukit_batch*[1]")
+    check(C.aukit_pack_pcm(ctx(), self._h, bitDepth, bitDepth == 8 and 1 or 0, 0, 1, 0, b))
+    local n, tot = ffi.new("uint32_t[1]"), ffi.new("uint64_t[1]")
+    check(C.aukit_batch_info(b[0], n, tot))
+    local buf = ffi.new("uint8_t[?]", math.max(tonumber(tot[0]), 1))
+    check(C.aukit_batch_download(ctx(), b[0], buf))
+    C.aukit_batch_free(b[0])
+    return ffi.string(buf, tot[0])
+end
+aukit._wav_body = wav_body
 
 local function loader(d, data, info)
     local o = ffi.new("aukit_audio*[1]")
