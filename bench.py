@@ -133,10 +133,20 @@ class ImaStream(Workload):
     name, unit = "ima_stream", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
+        import numpy as np
+        from oracle import oracle as O  # the oracle's IMA *encoder* only generates the synthetic input (the reference has none)
         blocks = int(round(args.seconds * 22))  # 220 blocks of 512 B ≈ 10.1 s @22 050 Hz
         n = blocks * 512
-        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 3000 + rank)
-        self.x.view(-1, 512)[:, 2] %= 89  # header step index <= 88
+        # the config-1 style signal through the AUKit-variant encoder; 8 distinct streams, repeated
+        kinds = []
+        for i in range(8):
+            rng = np.random.Generator(np.random.PCG64(0xA0C17 + 3000 + 8 * rank + i))
+            t = np.arange(1016 * blocks) / 22050.0
+            pcm = np.round((0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, len(t))) * 32767).astype(np.int16)
+            enc = O.gen_ima(pcm, 1, 512, 88)
+            assert len(enc) == n, (len(enc), n)
+            kinds.append(torch.frombuffer(bytearray(enc), dtype=torch.uint8))
+        self.x = torch.cat(kinds).to(dev).repeat((args.streams + 7) // 8)[: args.streams * n].contiguous()
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
         self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
         self.out = B.AudioBatch(ctx)
