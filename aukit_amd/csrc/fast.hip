@@ -223,6 +223,8 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
     F.cap = (((int)std::ceil((double)F.tile_out * (double)a / (double)b) + 64) + 3) & ~3;
     F.scale_pos = 1.0f / 32767.0f;
     F.scale_neg = 1.0f / 32768.0f;
+    F.epi = 0;
+    F.alpha = 0.f;
     return true;
 }
 
@@ -264,12 +266,21 @@ int launch_fast(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg>
 
 // returns true when the fast kernel took the launch (*rc holds its status)
 bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
-              uint64_t algorithmic_bytes, int *rc) {
+              uint64_t algorithmic_bytes, int *rc, int epi, double alpha) {
     if (ctx->exact_math) return false;
     FastParams F;
     if (!fast_eligible(src_kind, interp, old_rate, new_rate, F)) return false;
+    F.epi = epi;
+    F.alpha = (float)alpha;
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
+    if (epi) {  // epilogues other than Audio:resample exist as wave kernels only (fast_stream.hip)
+        if (src_kind != SRC_PCM_S16LE_MONO) return false;
+        bool taken = false;
+        int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
+        if (taken) *rc = r2;
+        return taken;
+    }
     if (src_kind == SRC_I32) {  // integer rows: only the wave kernel, and only when v / norm is an exact f32 operation
         int e = 0;
         if (P.norm_pos != P.norm_neg || std::frexp(P.norm_pos, &e) != 0.5 || P.norm_pos > 16777216.0) return false;

@@ -1,0 +1,75 @@
+// fast_stream.hip — the wave-private f32 resampler (fast2.hip) with the stream.pcm epilogue (aukit.lua:2397-2403), for
+// aukit.stream.pcm on s16le mono input with AUKIT_F32 output:
+//   s = raw interpolated sample (not clamped); ns = ls + alpha * (s - ls) with ls the RAW previous sample of the same iterator
+//   call (0 for its first output, Q2); output clamp(ns * (ns < 0 and 128 or 127), -128, 127).
+// The previous sample of a row's first lane comes from lane 63 of the row before (one readlane); that of a tile's first output
+// is evaluated once more from the window, which therefore reaches one tap further left than the Audio:resample kernel's.
+// Its own translation unit: see fast_wave_dev.h.
+#include <algorithm>
+#include "fast_wave_dev.h"
+
+namespace aukit {
+
+template <int INTERP, int NV>
+__global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P, const FastParams F) {
+    extern __shared__ float smf[];
+    constexpr int SRC = SRC_PCM_S16LE_MONO;
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *const sm = smf + wave * (unsigned)F.cap;
+    const unsigned nwaves = gridDim.x * 4u;
+    const float alpha = F.alpha;
+
+    unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    if (t >= P.n_tiles) return;
+    uint4 pre[NV];
+    WaveTile cur = describe<SRC, HL, HR>(P, F, t);
+    issue_loads<NV>(P, cur, lane, pre);
+    for (;;) {
+        write_lds<SRC, NV>(P, F, cur, lane, pre, sm);
+        const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - P.seg_tile0[P.tile_seg[t]]) == 0;  // first tile of its iterator call
+        const unsigned tn = t + nwaves;
+        const bool more = tn < P.n_tiles;
+        WaveTile nxt = cur;
+        if (more) {  // wave-uniform
+            nxt = describe<SRC, HL, HR>(P, F, tn);
+            issue_loads<NV>(P, nxt, lane, pre);  // in flight while this tile is interpolated
+        }
+        const float *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
+        float *orow = cur.orow;
+        float carry = 0.f;  // the raw sample before the tile's first output: position n = r0 - a, one table step back when that is negative
+        if (!first) carry = cur.r0 >= F.a ? interp_row<INTERP, false>(F, tab, cur.r0 - F.a) : interp_row<INTERP, false>(F, tab - 1, cur.r0 + F.b - F.a);
+        for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+            const unsigned j = rb + lane;
+            const float s = interp_row<INTERP, false>(F, tab, cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a);
+            float prev = __shfl_up(s, 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(s, 63);
+            const float ns = fmaf(alpha, s - prev, prev);                                                // :2401
+            if (j < cur.cnt) orow[j] = fminf(fmaxf(ns * (ns < 0.f ? 128.f : 127.f), -128.f), 127.f);  // :2402
+        }
+        if (!more) break;
+        cur = nxt;
+        t = tn;
+    }
+}
+
+template <int INTERP>
+static int launch_nv_stream(aukit_ctx *ctx, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid) {
+    switch (nv) {
+    case 1: hipLaunchKernelGGL((k_fast_wave_stream<INTERP, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
+    case 2: hipLaunchKernelGGL((k_fast_wave_stream<INTERP, 2>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
+    case 4: hipLaunchKernelGGL((k_fast_wave_stream<INTERP, 4>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
+    default: return fail(AUKIT_E_ARG, "bad NV");
+    }
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+
+int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid) {
+    if (interp == AUKIT_INTERP_LINEAR) return launch_nv_stream<AUKIT_INTERP_LINEAR>(ctx, nv, P, F, lds, grid);
+    return launch_nv_stream<AUKIT_INTERP_CUBIC>(ctx, nv, P, F, lds, grid);
+}
+
+}  // namespace aukit

@@ -1,0 +1,174 @@
+// fast_wave_dev.h — device helpers of the wave-private f32 resampler, shared by its translation units: fast2.hip (Audio:resample
+// epilogue — the headline kernel) and fast_stream.hip (stream.pcm epilogue).  The epilogues live in separate translation units on
+// purpose: adding the second epilogue as a template parameter of the one kernel changed the register allocation of the headline
+// instantiation and cost it 18 % (A/B on one box, tools/ab_lib.sh) although its source path was untouched.
+#pragma once
+#include "resample.h"
+
+namespace aukit {
+
+#ifndef AUKIT_WT
+#define AUKIT_WT 1024
+#endif
+constexpr int WT = AUKIT_WT;  // outputs per wave tile = 16 rows of 64
+
+template <int SRC> struct SrcTraits;
+template <> struct SrcTraits<SRC_PCM_S16LE_MONO> { static constexpr int BYTES = 2, SPV = 8; };
+template <> struct SrcTraits<SRC_G711_MONO> { static constexpr int BYTES = 1, SPV = 16; };
+template <> struct SrcTraits<SRC_AUDIO_F32> { static constexpr int BYTES = 4, SPV = 4; };
+template <> struct SrcTraits<SRC_I32> { static constexpr int BYTES = 4, SPV = 4; };  // integer rows (FLAC): v * 2^-depth, exact in f32 for |v| < 2^24
+
+AUKIT_DEV float g711_f32b(unsigned byte, int ulaw, float scale) {
+    unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
+    int m = b & 15, e = (b >> 4) & 7;
+    if (!ulaw && e == 0) m = m * 4 + 2;
+    else m = (m * 2 + 33) << e;
+    if (ulaw) m -= 33;
+    bool neg = ((b & 0x80) != 0) == (ulaw != 0);
+    return (float)(neg ? -m : m) * scale;
+}
+
+struct WaveTile {
+    const unsigned char *al;   // 16-byte aligned address of the first vector
+    float *orow;               // output of the tile's first sample
+    unsigned cnt, r0;
+    int k_lo, n_stage, head, nvec;
+    int w_lo, w_hi;
+    const unsigned char *base; // address of table index 0 (for edge replication)
+};
+
+template <int SRC, int HL, int HR>
+AUKIT_DEV WaveTile describe(const ResampleParams &P, const FastParams &F, unsigned t) {
+    using T = SrcTraits<SRC>;
+    unsigned sidx, tin;
+    if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
+    else { sidx = P.tile_seg[t]; tin = t - P.seg_tile0[sidx]; }
+    const Seg sg = P.segs[sidx];
+    WaveTile w;
+    const unsigned o0 = tin * (unsigned)WT;
+    w.cnt = o0 < sg.n_out ? min((unsigned)WT, sg.n_out - o0) : 0u;
+    const unsigned td = tin * F.wd;                    // (o0 * a) = (tin * wc + td / b) * b + td % b
+    const unsigned tq = td / F.b;
+    const unsigned kb = tin * F.wc + tq;
+    w.r0 = td - tq * F.b;
+    const unsigned klast = w.cnt ? (w.r0 + (w.cnt - 1) * F.a) / F.b : 0u;
+    w.k_lo = 1 + (int)kb - HL;
+    w.n_stage = (int)klast + 1 + HL + HR;
+    w.w_lo = sg.w_lo;
+    w.w_hi = sg.w_hi;
+    if constexpr (SRC == SRC_AUDIO_F32 || SRC == SRC_I32) w.base = P.src + 4 * (size_t)P.src_off[sg.stream] + 4 * sg.src_base;
+    else w.base = P.src + (size_t)P.src_off[sg.stream] + (long long)T::BYTES * sg.src_base;
+    const unsigned char *a0 = w.base + (long long)T::BYTES * w.k_lo;
+    w.al = (const unsigned char *)((uintptr_t)a0 & ~(uintptr_t)15);
+    w.head = (int)(a0 - w.al) / T::BYTES;
+    w.nvec = (w.head + w.n_stage + T::SPV - 1) / T::SPV;
+    w.orow = reinterpret_cast<float *>(P.out) + sg.out_off + o0;
+    return w;
+}
+
+template <int NV>
+AUKIT_DEV void issue_loads(const ResampleParams &P, const WaveTile &w, int lane, uint4 (&pre)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int v = lane + 64 * i;
+        const unsigned char *p = w.al + 16 * (size_t)v;
+        pre[i] = make_uint4(0, 0, 0, 0);
+        if (v < w.nvec && p >= P.safe_lo && p + 16 <= P.safe_hi) pre[i] = *reinterpret_cast<const uint4 *>(p);
+    }
+}
+
+template <int SRC>
+AUKIT_DEV float sample_at(const ResampleParams &P, const FastParams &F, const unsigned char *q) {
+    if constexpr (SRC == SRC_PCM_S16LE_MONO) {
+        short s = (short)(q[0] | q[1] << 8);
+        return (float)s * (s < 0 ? F.scale_neg : F.scale_pos);
+    } else if constexpr (SRC == SRC_G711_MONO) {
+        return g711_f32b(*q, P.ulaw, (float)P.g711_scale);
+    } else if constexpr (SRC == SRC_I32) {
+        return (float)*reinterpret_cast<const int *>(q) * F.scale_pos;
+    } else {
+        return *reinterpret_cast<const float *>(q);
+    }
+}
+
+template <int SRC, int NV>
+AUKIT_DEV void write_lds(const ResampleParams &P, const FastParams &F, const WaveTile &w, int lane, const uint4 (&pre)[NV], float *sm) {
+    using T = SrcTraits<SRC>;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int v = lane + 64 * i;
+        if (v >= w.nvec) continue;
+        const uint4 u = pre[i];
+        if constexpr (SRC == SRC_PCM_S16LE_MONO) {
+            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                short lo = (short)(ww[e] & 0xFFFF), hi = (short)(ww[e] >> 16);
+                d[2 * e] = (float)lo * (lo < 0 ? F.scale_neg : F.scale_pos);
+                d[2 * e + 1] = (float)hi * (hi < 0 ? F.scale_neg : F.scale_pos);
+            }
+            float4 *o = reinterpret_cast<float4 *>(sm + 8 * v);
+            o[0] = make_float4(d[0], d[1], d[2], d[3]);
+            o[1] = make_float4(d[4], d[5], d[6], d[7]);
+        } else if constexpr (SRC == SRC_G711_MONO) {
+            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
+            const float sc = (float)P.g711_scale;
+            float4 *o = reinterpret_cast<float4 *>(sm + 16 * v);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = make_float4(g711_f32b(ww[e] & 0xFF, P.ulaw, sc), g711_f32b((ww[e] >> 8) & 0xFF, P.ulaw, sc),
+                                   g711_f32b((ww[e] >> 16) & 0xFF, P.ulaw, sc), g711_f32b(ww[e] >> 24, P.ulaw, sc));
+        } else if constexpr (SRC == SRC_I32) {
+            *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4((float)(int)u.x * F.scale_pos, (float)(int)u.y * F.scale_pos, (float)(int)u.z * F.scale_pos, (float)(int)u.w * F.scale_pos);
+        } else {
+            *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+    }
+    // vectors that straddle the safe range were zero-filled: patch them sample by sample (first/last stream of a wrapped buffer)
+    {
+        const unsigned char *lo = w.al, *hi = w.al + 16 * (size_t)w.nvec;
+        if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare
+            for (int idx = lane; idx < w.nvec * T::SPV; idx += 64) {
+                const unsigned char *q = w.al + (size_t)idx * T::BYTES;
+                const unsigned char *vb = w.al + 16 * (size_t)(idx / T::SPV);
+                if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q + T::BYTES <= P.safe_hi) ? sample_at<SRC>(P, F, q) : 0.f;
+            }
+        }
+    }
+    // nil fall-backs of interpolate.{linear,cubic} (aukit.lua:259, :264) = replicated edge samples
+    const int k_hi = w.k_lo + w.n_stage - 1;
+    if (w.k_lo < w.w_lo) {
+        const float e_lo = sample_at<SRC>(P, F, w.base + (long long)T::BYTES * w.w_lo);
+        for (int idx = lane; idx < w.w_lo - w.k_lo; idx += 64) sm[w.head + idx] = e_lo;
+    }
+    if (k_hi > w.w_hi) {
+        const float e_hi = sample_at<SRC>(P, F, w.base + (long long)T::BYTES * w.w_hi);
+        const int first = w.w_hi + 1 - w.k_lo;
+        for (int idx = lane; idx < k_hi - w.w_hi; idx += 64) sm[w.head + first + idx] = e_hi;
+    }
+}
+
+template <int INTERP, bool CLAMP = true>
+AUKIT_DEV float interp_row(const FastParams &F, const float *tab, unsigned n) {
+    const unsigned q = __umulhi(n, F.magic);
+    const unsigned rem = n - q * F.b;
+    float fx = (float)rem * F.inv_b;
+    fx = fmaf(fmaf(-fx, (float)F.b, (float)rem), F.inv_b, fx);
+    const float p1 = tab[q];
+    float v;
+    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+        const float p2 = tab[q + 1];
+        v = fmaf(p2 - p1, fx, p1);
+    } else {
+        const float p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
+        const float c3 = fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
+        const float c2 = fmaf(-0.5f, p3, fmaf(2.0f, p2, fmaf(-2.5f, p1, p0)));
+        const float c1 = 0.5f * (p2 - p0);
+        v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
+    }
+    if constexpr (!CLAMP) return rem == 0 ? p1 : v;            // stream.pcm uses the interpolated sample as is (aukit.lua:2397-2400)
+    else return rem == 0 ? p1 : fminf(fmaxf(v, -1.0f), 1.0f);  // aukit.lua:667-668
+}
+
+}  // namespace aukit

@@ -85,11 +85,14 @@ struct FastParams {
     int cap;             // LDS floats per staged window (v1: per workgroup, v2: per wave)
     float scale_pos, scale_neg;  // s16: 1/32767, 1/32768
     unsigned wc, wd;     // v2: (1024 * a) = wc * b + wd  (one wave tile = 1024 outputs)
+    int epi;             // wave kernel epilogue: 0 = Audio:resample, 1 = stream.pcm (fast_stream.hip); appended last so that the
+    float alpha;         //   kernel-argument offsets the headline kernel reads stay what they were.  alpha: stream.pcm's low-pass weight
 };
+int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken);
 bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
-              uint64_t algorithmic_bytes, int *rc);
+              uint64_t algorithmic_bytes, int *rc, int epi = 0, double alpha = 0);
 
 // position of output o (0-based) exactly as the reference computes it on the host
 static inline double host_pos(uint64_t o, double ratio) { return ((double)o) / ratio + 1; }

@@ -112,6 +112,27 @@ class Pcm16Cubic(Workload):
                 "all_cores": {"value": done_all / dt_all / 1e6, "unit": "Msamples/s", "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
 
 
+class Pcm16Stream(Workload):
+    """config T through the stream path: aukit.stream.pcm(data, 16, "signed", 1, 44100) with defaultInterpolation = cubic, every iterator call."""
+    name, unit = "pcm16_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.n_samples = int(round(args.seconds * SRC_RATE))
+        self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples, SRC_RATE, 0xA0C17 + 1000 + rank)
+        offs = [i * self.n_samples * 2 for i in range(args.streams + 1)]
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_PCM, 1, SRC_RATE, 16, "signed")
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=self.dtype, out=self.out)
+        self.desc = (f"{args.streams}x s16le 44.1kHz mono {args.seconds:g}s per GPU -> aukit.stream.pcm ({args.interp}), all iterator calls, "
+                     f"{args.dtype} store (config T, stream path)")
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+
 class G711Cubic(Workload):
     name, unit = "g711_cubic", "Msamples/s"
 
@@ -211,7 +232,7 @@ class FlacPipeline(Workload):
         return int(self.m.layout()[0].sum())
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, G711Cubic, ImaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stream, G711Cubic, ImaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def main():

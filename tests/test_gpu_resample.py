@@ -173,6 +173,36 @@ def test_stream_pcm_mono16(ctx, oracle, rate, interp):
         assert np.max(np.abs(got[i][0] - ref.data[0]), initial=0) <= 1e-13  # values up to 128: 1 ulp = 2.8e-14
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate", [44100, 22050, 8000, 32000])
+def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
+    """F32 storage takes the f32 wave kernel with the stream.pcm epilogue: same chunking, ≤ 1e-6 RMS on the [-1,1] scale, and ≤ 1e-6
+    RMS from the fp64 reference-order kernel on the same batch (ragged streams: chunk boundaries, tile boundaries, short tails)."""
+    B, N = _B(), _N()
+    nsamp = [int(rate * 2.5), rate, rate + 3, 10, int(rate * 1.0001) + 2, 1100, 2]
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate(nsamp)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed")
+    out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave_stream<pcm_s16le_mono") and ctx.last_kernel()[0].endswith("stream_pcm>") and "k_fast_wave_stream" in ctx.last_kernel()[0]
+    got = out.download()
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        out2, ck2 = B.stream_decode(ctx, bt, desc, interp, dtype=N.F32)
+        assert ctx.last_kernel()[0].startswith("k_resample<")
+        got2 = out2.download()
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, rate, False, False, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        assert len(got[i][0]) == len(ref.data[0])
+        if len(ref.data[0]):
+            assert rms(got[i][0] / 128, ref.data[0] / 128) <= 1e-6, i
+            assert np.max(np.abs(got[i][0] - ref.data[0])) <= 2e-4, i  # absolute, on the [-128, 127] scale
+            assert rms(got[i][0] / 128, got2[i][0] / 128) <= 1e-6, i
+
+
 def test_stream_pcm_stereo_and_mono_mix(ctx, oracle):
     B, N = _B(), _N()
     st = np.stack([pcm16(30000, 22050, 1, 0), pcm16(30000, 22050, 1, 1)], 1).tobytes()
