@@ -260,6 +260,7 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
 }
 
 // ---------------------------------------------------------------- stream.g711  aukit.lua:2850-2913
+bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype, uint64_t algorithmic_bytes, int *rc);
 static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                        aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -326,10 +327,18 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
     P.g711_scale = 1.0 / 64.0;  // m / 0x40  :2891
     P.mix_mono = mono ? 1 : 0;
     P.out = a->dev;
-    size_t lds;
-    if ((rc = plan_tiles(ctx, segs, ratio, interp, C, P, &lds))) { delete ck; return rc; }
-    rc = launch_resample(ctx, C == 1 ? SRC_G711_MONO : SRC_G711, interp, EPI_STREAM_FLOOR, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
-    if (rc) { delete ck; return rc; }
+    bool done = false;
+    if (C == 1 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // guarded short-cut under the floor(), bit-exact (floor_wave.hip)
+        int frc = AUKIT_OK;
+        done = floor_wave_g711_try(ctx, interp, d->sample_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &frc);
+        if (done && frc) { delete ck; return frc; }
+    }
+    if (!done) {
+        size_t lds;
+        if ((rc = plan_tiles(ctx, segs, ratio, interp, C, P, &lds))) { delete ck; return rc; }
+        rc = launch_resample(ctx, C == 1 ? SRC_G711_MONO : SRC_G711, interp, EPI_STREAM_FLOOR, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
+        if (rc) { delete ck; return rc; }
+    }
     if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
     return AUKIT_OK;
 }

@@ -1,0 +1,173 @@
+// floor_wave.hip — aukit.stream.g711 (mono) on the wave-private tile engine of fast2.hip, bit-exact.
+//
+// The stream outputs are floor()ed and clamped (aukit.lua:2909-2910), so all that matters of the interpolated value is which
+// integer interval it falls into.  The reference-order evaluation costs ≈41 fp64 instructions per output (exact division for the
+// position, pow() emulation, the polynomial term by term); this kernel evaluates the same polynomial from the same fp64 samples
+// with exact rational positions and FMA Horner form (≈14 fp64 instructions) and takes the result only when it lies more than
+// 1e-6 away from an integer.  Margin: the reference's x = (i-1)/ratio + 1 carries at most 48000 * 2^-53 = 5.3e-12 of rounding
+// error, the spline's slope is below 3 * 1004 (samples are < 512 in magnitude), so the two values differ by < 2e-8; their own
+// evaluation errors are ~1e-12.  Otherwise — and at positions
+// that are mathematically integers, where the reference's own `x % 1 == 0` test decides between copy and interpolation — the
+// lane runs the reference-order code (resample_dev.h) on the same LDS window.  Bit-exact either way; the tests compare every
+// output with the oracle and with the k_resample path.
+#include <algorithm>
+#include "fast_wave_dev.h"
+#include "resample_dev.h"
+
+namespace aukit {
+
+AUKIT_DEV double g711_f64b(unsigned byte, int ulaw, double scale) {  // same integers as g711_f32b / resample.hip's g711_value
+    unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
+    int m = b & 15, e = (b >> 4) & 7;
+    if (!ulaw && e == 0) m = m * 4 + 2;
+    else m = (m * 2 + 33) << e;
+    if (ulaw) m -= 33;
+    const bool neg = ((b & 0x80) != 0) == (ulaw != 0);
+    return (double)(neg ? -m : m) * scale;
+}
+
+AUKIT_DEV void store_floor(signed char *p, double v) { *p = (signed char)(int)v; }
+AUKIT_DEV void store_floor(double *p, double v) { *p = v; }
+
+template <int INTERP, int NV, typename OUT_T>
+__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F) {
+    extern __shared__ double smd[];
+    constexpr int SRC = SRC_G711_MONO;
+    // one more tap to the left than the polynomial needs: at a mathematically integer position the reference's x may round to just
+    // below the integer, and its floor(x) is then one table index lower
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *const sm = smd + wave * (unsigned)F.cap;
+    const unsigned nwaves = gridDim.x * 4u;
+    const double inv_b = 1.0 / (double)F.b;
+    const bool int_ratio = F.a == 1;  // ratio = b: (i-1)/ratio is an integer exactly when b divides i-1, in floating point too
+    OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
+
+    unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    if (t >= P.n_tiles) return;
+    uint4 pre[NV];
+    WaveTile cur = describe<SRC, HL, HR>(P, F, t);
+    issue_loads<NV>(P, cur, lane, pre);
+    for (;;) {
+        // ---- window → LDS as the reference's doubles (m / 0x40, :2891); slots below / above the table replicate its ends,
+        // which is what the nil fall-backs of interpolate.linear / cubic read (:259, :264)
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = lane + 64 * i;
+            if (v >= cur.nvec) continue;
+            const unsigned ww[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+            for (int e = 0; e < 16; e++) sm[16 * v + e] = g711_f64b((ww[e >> 2] >> (8 * (e & 3))) & 0xFF, P.ulaw, P.g711_scale);
+        }
+        {
+            const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
+            if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare: vectors that straddle the allocation were zero-filled
+                for (int idx = lane; idx < cur.nvec * 16; idx += 64) {
+                    const unsigned char *q = cur.al + idx;
+                    const unsigned char *vb = cur.al + 16 * (size_t)(idx / 16);
+                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q < P.safe_hi) ? g711_f64b(*q, P.ulaw, P.g711_scale) : 0.0;
+                }
+            }
+            const int k_hi = cur.k_lo + cur.n_stage - 1;
+            if (cur.k_lo < cur.w_lo) {
+                const double e_lo = g711_f64b(cur.base[cur.w_lo], P.ulaw, P.g711_scale);
+                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) sm[cur.head + idx] = e_lo;
+            }
+            if (k_hi > cur.w_hi) {
+                const double e_hi = g711_f64b(cur.base[cur.w_hi], P.ulaw, P.g711_scale);
+                const int first = cur.w_hi + 1 - cur.k_lo;
+                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) sm[cur.head + first + idx] = e_hi;
+            }
+        }
+        // the tile's segment, for the reference-order fallback
+        unsigned sidx, tin;
+        if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
+        else { sidx = P.tile_seg[t]; tin = t - P.seg_tile0[sidx]; }
+        const Seg sg = P.segs[sidx];
+        const unsigned tn = t + nwaves;
+        const bool more = tn < P.n_tiles;
+        WaveTile nxt = cur;
+        if (more) {  // wave-uniform
+            nxt = describe<SRC, HL, HR>(P, F, tn);
+            issue_loads<NV>(P, nxt, lane, pre);  // in flight while this tile is interpolated
+        }
+        const double *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
+        const double *tab_klo = sm + cur.head;   // slot of table index cur.k_lo
+        OUT_T *orow = out + sg.out_off + (size_t)tin * WT;
+        for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+            const unsigned j = rb + lane;
+            if (j >= cur.cnt) break;
+            const unsigned n = cur.r0 + j * F.a;
+            const unsigned q = __umulhi(n, F.magic);
+            const unsigned rem = n - q * F.b;
+            const double p1 = tab[q];
+            double v = p1;
+            bool ok = rem != 0 || int_ratio;
+            if (rem != 0) {
+                const double fx = (double)rem * inv_b;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    v = __builtin_fma(tab[q + 1] - p1, fx, p1);
+                } else {
+                    const double p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
+                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                    const double c1 = 0.5 * (p2 - p0);
+                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+                }
+                const double fr = v - floor(v);
+                ok = fr > 1e-6 && fr < 1 - 1e-6;
+            }
+            if (!ok) {  // reference-order evaluation on the same window
+                bool isint;
+                v = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT + j, &isint);
+            }
+            store_floor(orow + j, lua_clamp(floor(v), -128, 127));  // :2909
+        }
+        if (!more) break;
+        cur = nxt;
+        t = tn;
+    }
+}
+
+bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
+
+// returns true when this kernel took the launch (*rc = its status).  Needs: mono, linear / cubic, integer rates, a window of one
+// vector per lane (up-sampling by >= ~1.06), and the reciprocal-based exact division verified for the fallback path.
+bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype, uint64_t algorithmic_bytes, int *rc) {
+    if (ctx->exact_math) return false;
+    FastParams F;
+    if (!fast_eligible(SRC_G711_MONO, interp, old_rate, 48000, F)) return false;
+    for (const Seg &g : segs)
+        if (g.w_hi < g.w_lo && g.n_out) return false;
+    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;
+    if (win + 2 * 16 > 64 * 16) return false;  // one 16-byte vector per lane
+    uint64_t max_tiles = 0, max_out = 0;
+    for (const Seg &g : segs) { max_tiles = std::max<uint64_t>(max_tiles, (g.n_out + WT - 1) / WT); max_out = std::max<uint64_t>(max_out, g.n_out); }
+    F.wc = (unsigned)(((unsigned long long)WT * F.a) / F.b);
+    F.wd = (unsigned)(((unsigned long long)WT * F.a) % F.b);
+    if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return false;
+    if (((double)F.b + (double)WT * (double)F.a) * (double)F.b >= 4294967296.0) return false;
+    F.cap = 64 * 16;  // doubles per wave window
+    P.ratio = 48000 / old_rate;
+    P.rcp = 1.0 / P.ratio;
+    P.exact_rcp = exact_div_verified(ctx, P.ratio, max_out + 2) ? 1 : 0;
+    P.halo_l = hl; P.halo_r = hr; P.sinc_w = ctx->sinc_w;
+    if ((*rc = plan_tiles_sized(ctx, segs, WT, P))) return true;
+    if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
+    const size_t lds = (size_t)F.cap * 8 * 4;
+    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 8);
+    if ((*rc = ctx_begin_kernel(ctx))) return true;
+#define AUKIT_FW(I, T) hipLaunchKernelGGL((k_floor_wave_g711<I, 1, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F)
+    if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, signed char); else AUKIT_FW(AUKIT_INTERP_CUBIC, signed char); }
+    else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, double); else AUKIT_FW(AUKIT_INTERP_CUBIC, double); }
+#undef AUKIT_FW
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_floor_wave_g711 launch failed"); return true; }
+    static thread_local char nm[96];
+    snprintf(nm, sizeof nm, "k_floor_wave_g711<%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic");
+    *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
+    return true;
+}
+
+}  // namespace aukit

@@ -150,6 +150,25 @@ class G711Cubic(Workload):
         return int(self.out.layout()[0].sum())
 
 
+class G711Stream(Workload):
+    """config 2(b): aukit.stream.g711(d, true, 1, 8000, false), every iterator call, int8 out."""
+    name, unit = "g711_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        n = int(round(args.seconds * 8000))
+        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 2000 + rank)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        self.d = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
+        self.out = B.AudioBatch(ctx)
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=N.I8, out=self.out)
+        self.arith = "int decode + f64 resample"
+        self.desc = f"{args.streams}x G.711 u-law 8kHz {args.seconds:g}s -> aukit.stream.g711 ({args.interp}), all iterator calls, int8 out (config 2b)"
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+
 class ImaStream(Workload):
     name, unit = "ima_stream", "Msamples/s"
 
@@ -232,7 +251,7 @@ class FlacPipeline(Workload):
         return int(self.m.layout()[0].sum())
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stream, G711Cubic, ImaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def main():

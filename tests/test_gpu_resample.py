@@ -251,6 +251,37 @@ def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):
             assert np.array_equal(got[i][c], ref.data[c]), (i, c)
 
 
+@pytest.mark.parametrize("alaw", [False, True])
+@pytest.mark.parametrize("rate", [8000, 11025, 16000, 22050, 44100])
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_stream_g711_guarded_wave_kernel(ctx, oracle, interp, rate, alaw):
+    """Mono stream.g711 takes the guarded short-cut kernel (floor_wave.hip): every output equal to the oracle's and to the
+    reference-order kernel's, for integer (8 k, 16 k → 48 k) and non-integer ratios, both laws, I8 and F64 outputs.  The byte
+    patterns include runs of equal samples and full-scale steps: interpolated values that are exact integers (guard → fallback)."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(rate + (1 if alaw else 0)))
+    flat = np.repeat(rng.integers(0, 256, 400, dtype=np.uint8), 25)  # plateaus: value == integer between equal samples
+    streams = [oracle.gen_g711(pcm16(int(rate * 2.3), rate, 2, 5), not alaw), rng.integers(0, 256, rate + 17, dtype=np.uint8).tobytes(), flat.tobytes(), b"\x00\xff" * 700, b"\x7f"]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_G711, 1, rate, ulaw=not alaw)
+    for dt in (N.I8, N.F64):
+        out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=dt)
+        assert ctx.last_kernel()[0].startswith("k_floor_wave_g711"), ctx.last_kernel()
+        got = out.download()
+        ctx.set_option(N.OPT_EXACT_MATH, 1)
+        try:
+            out2, _ = B.stream_decode(ctx, bt, desc, interp, dtype=dt)
+            assert ctx.last_kernel()[0].startswith("k_resample<")
+            got2 = out2.download()
+        finally:
+            ctx.set_option(N.OPT_EXACT_MATH, 0)
+        for i, s in enumerate(streams):
+            ref = oracle.stream_g711(s, not alaw, 1, rate, False, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            assert np.array_equal(got[i][0], ref.data[0]), (i, dt)
+            assert np.array_equal(got[i][0], got2[i][0]), (i, dt)
+
+
 def test_empty_and_ragged_batches(ctx, oracle):
     B, N = _B(), _N()
     streams = [b"", pcm16(3, 44100, 1, 0).tobytes(), b"", pcm16(50000, 44100, 1, 1).tobytes()]
