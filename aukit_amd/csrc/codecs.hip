@@ -403,6 +403,11 @@ struct ImaStreamParams {
     int cap;                             // LDS doubles per channel
     void *out;
     int *err;
+    // mono, linear / cubic, integer sample rate: guarded short-cut under the floor() (same argument as floor_wave.hip):
+    // x - 1 = j * fa / fb exactly; fmagic = ceil(2^32 / fb)
+    int fast;
+    unsigned fa, fb, fmagic;
+    double inv_fb;
 };
 
 template <int INTERP, typename OUT_T>
@@ -448,6 +453,44 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
         sg.w_lo = 1; sg.w_hi = (int)nb;
         OUT_T *obase = reinterpret_cast<OUT_T *>(P.out) + P.out_off[s] + bi * (unsigned long long)P.newlen_full;
         const unsigned long long ostride = P.out_stride[s];
+        if constexpr (INTERP == AUKIT_INTERP_LINEAR || INTERP == AUKIT_INTERP_CUBIC) {
+            if (P.fast) {  // wave-uniform: one channel.  The output is floor()ed (:2823): evaluate the polynomial with exact rational
+                // positions and FMA Horner form, keep the result unless it is within 1e-6 of an integer (then, and at the table's
+                // ends where the nil fall-backs apply, run the reference-order code).  Bit-exact: see floor_wave.hip for the margin.
+                const int nbi = (int)nb;
+                for (unsigned j = lane; j < newlen; j += 64) {
+                    const unsigned n = j * P.fa;
+                    const unsigned q0 = __umulhi(n, P.fmagic);  // floor(n / fb), exact: (newlen * fa + fb) * fb < 2^32
+                    const unsigned rem = n - q0 * P.fb;
+                    const int k = (int)q0 + 1;                  // floor(x)
+                    double v = 0;
+                    bool ok = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi);  // one spare tap on the left (x may round below an integer)
+                    if (ok) {
+                        const int s1 = k - 1;  // slot of table index k (skewed: one pad per 16)
+                        const double p1 = sm[s1 + (s1 >> 4)];
+                        v = p1;
+                        if (rem != 0) {
+                            const double fx = (double)rem * P.inv_fb;
+                            const double p2 = sm[s1 + 1 + ((s1 + 1) >> 4)];
+                            if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
+                            else {
+                                const double p0 = sm[s1 - 1 + ((s1 - 1) >> 4)], p3 = sm[s1 + 2 + ((s1 + 2) >> 4)];
+                                const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                                const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                                const double c1 = 0.5 * (p2 - p0);
+                                v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+                            }
+                        }
+                        const double fr = v - floor(v);
+                        ok = fr > 1e-6 && fr < 1 - 1e-6;
+                    }
+                    if (!ok) { bool isint; v = eval_at<INTERP, true>(RP, sg, sm, 1, j, &isint); }
+                    obase[j] = (OUT_T)(int)lua_clamp(floor(v), -128, 127);
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
         for (unsigned j = lane; j < newlen; j += 64) {  // :2818-2828
             bool isint;
             if (P.mono) {
@@ -629,6 +672,14 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         P.cap = (int)((ba - 4ull * C) * 2 / C + 8 + 8);
         P.cap += P.cap / 16 + 2;  // skewed LDS slots
         P.out = a->dev; P.err = err;
+        if (C == 1 && !ctx->exact_math && d->sample_rate == std::floor(d->sample_rate) && d->sample_rate <= 4e9) {
+            unsigned long long x = 48000, y = (unsigned long long)d->sample_rate;
+            while (y) { const unsigned long long tq = x % y; x = y; y = tq; }
+            const unsigned long long fa = (unsigned long long)d->sample_rate / x, fb = 48000 / x;  // x - 1 = (i - 1) / ratio = (i - 1) * fa / fb
+            if (fb >= 2 && ((double)newlen_full * (double)fa + (double)fb) * (double)fb < 4294967296.0) {
+                P.fast = 1; P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb); P.inv_fb = 1.0 / (double)fb;
+            }
+        }
         unsigned nwv = 4;
         while (nwv > 1 && (size_t)P.cap * C * 8 * nwv > 64 * 1024) nwv >>= 1;
         const size_t lds = (size_t)P.cap * C * 8 * nwv;
