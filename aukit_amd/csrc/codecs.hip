@@ -617,15 +617,17 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         const uint64_t nb = in->off[s + 1] - in->off[s];
         ck->length_seconds[s] = (double)nb / (double)ba * spb / d->sample_rate;   // :2834
         // blocks processed: while n + 4C <= #data (1-based n)  :2794
-        uint64_t nblk = 0;
-        while (nblk * ba + 4ull * C + 1 <= nb) nblk++;
+        const uint64_t nblk = nb >= 4ull * C + 1 ? (nb - 4ull * C - 1) / ba + 1 : 0;
         blk0[s + 1] = blk0[s] + nblk;
         uint64_t done = 0;
         for (;;) {  // one iterator call = up to iterPerSecond blocks
             const uint64_t take = std::min<uint64_t>(ips, nblk - done);
-            uint64_t produced = 0;
-            for (uint64_t b = done; b < done + take; b++) {
-                const uint64_t rem = nb - b * ba;
+            // every block but the stream's last sees at least blockAlign + 4C more bytes — all its word groups plus the junk word (Q6) —
+            // and yields newlen_full outputs; only the last block needs the arithmetic of :2800-2802 / :2817
+            uint64_t full = take, produced = 0;
+            if (take && done + take == nblk) {
+                full = take - 1;
+                const uint64_t rem = nb - (nblk - 1) * ba;
                 long long ng = (long long)((rem - 1) / (4ull * C)) - 1;
                 const long long nwr = (long long)((ba - 4ull * C) / (4ull * C));
                 if (ng > nwr + 1) ng = nwr + 1;
@@ -633,6 +635,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 const uint64_t nbn = (uint64_t)ng * 8;
                 produced += ((double)nbn < spb) ? (uint64_t)std::floor((double)nbn * ratio) : newlen_full;
             }
+            produced += full * newlen_full;
             // a short block is always the last one (n advances past #data), so block b's outputs start at b * newlen_full
             done += take;
             if (produced == 0) break;  // #retval[1] == 0 → nil
