@@ -56,6 +56,15 @@ def main():
     # MS-ADPCM and QOA
     ms = O.gen_msadpcm(np.stack([pcm16(1012 * 3, 44100, 6, 0), pcm16(1012 * 3, 44100, 6, 1)], 1).ravel(), 2, 1024)
     save("msadpcm_stereo", data=u8(ms), decoded_l=O.msadpcm(ms, 1024, 2, 44100).data[0], stream_cubic_mono=O.stream_msadpcm(ms, 1024, 2, 44100, True, None, O.CUBIC).data[0])
+    # callers either side of the path: structural methods, tone, packing — from oracle/oracle_ops.py
+    from oracle import oracle_ops as OPS
+    xa = ([signal(300, 4800, 9, 0), signal(300, 4800, 9, 1)], 4800)
+    xb = ([signal(120, 4800, 9, 2)], 4800)
+    enc = OPS.encode_pcm(xa, 16, "signed", True)
+    save("ops", a0=xa[0][0], a1=xa[0][1], b0=xb[0][0],
+         concat0=OPS.concat([xa, xb])[0][0], concat1=OPS.concat([xa, xb])[0][1], combine2=OPS.combine([xa, xb])[0][2],
+         rep_rev=OPS.reverse(OPS.rep(xb, 2))[0][0], tone_tri=OPS.tone(441, 0.01, 0.7, "triangle", 0.5, 1, 48000)[0][0],
+         pack16_trunc=u8(OPS.pack(enc, 16, "signed", False, OPS.TRUNC)), pack16_floor_be=u8(OPS.pack(enc, 16, "signed", True, OPS.FLOOR)))
     q = O.gen_qoa(pcm16(5120 + 600, 44100, 8, 0), 1, 44100) + b"\0" * 8
     save("qoa_mono", data=u8(q), decoded=O.qoa(q).data[0], stream_cubic=O.stream_qoa(q[:-8], False, O.CUBIC).data[0])
     for f in sorted(os.listdir(OUT)):
