@@ -225,6 +225,7 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
     F.scale_neg = 1.0f / 32768.0f;
     F.epi = 0;
     F.alpha = 0.f;
+    F.dq64 = F.dr64 = 0;
     return true;
 }
 

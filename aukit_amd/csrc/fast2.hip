@@ -52,13 +52,19 @@ __global__ __launch_bounds__(256) void k_fast_wave(const ResampleParams P, const
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (cur.cnt == (unsigned)WT) {
-            unsigned n = cur.r0 + lane_a;
+            const unsigned n0 = cur.r0 + lane_a;
+            unsigned q = __umulhi(n0, F.magic);
+            unsigned rem = n0 - q * F.b;
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
-                const float v = interp_row<INTERP>(F, tab, n);
+                const float v = interp_qr<SRC, INTERP>(F, tab, q, rem);
                 if (P.nt_store) __builtin_nontemporal_store(v, &orow[r * 64 + lane]);  // outputs are never re-read by this kernel
                 else orow[r * 64 + lane] = v;
-                n += row_a;
+                rem += F.dr64;  // the same lane, one row (64 outputs) further
+                q += F.dq64;
+                const bool wrap = rem >= F.b;
+                rem -= wrap ? F.b : 0u;
+                q += wrap ? 1u : 0u;
             }
         } else {
             for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
@@ -106,6 +112,8 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return AUKIT_OK;
     if (((double)F.b + (double)WT * (double)F.a) * (double)F.b >= 4294967296.0) return AUKIT_OK;
     F.cap = ((nv * 64 * spv) + 15) & ~15;  // every lane may write a full vector
+    F.dq64 = (unsigned)((64ull * F.a) / F.b);
+    F.dr64 = (unsigned)((64ull * F.a) % F.b);
     int rc = plan_tiles_sized(ctx, segs, WT, P);
     if (rc) return rc;
     *taken = true;

@@ -149,6 +149,30 @@ AUKIT_DEV void write_lds(const ResampleParams &P, const FastParams &F, const Wav
     }
 }
 
+// The full-tile path of k_fast_wave: the wave is VALU-issue-bound (profiles/: 32 VALU instructions per 64 outputs, two of them
+// quarter-rate integer multiplies), so the position arrives as (q, rem) kept by additions, fx is one multiply (|error| <= 6e-8,
+// the tolerance path allows 1e-6 RMS), the clamp is one v_med3, and for sources whose samples lie in [-1, 1] the `x % 1 == 0`
+// copy (:666) needs no select: rem == 0 makes fx == 0 and the Horner form returns p1 exactly.
+template <int SRC, int INTERP>
+AUKIT_DEV float interp_qr(const FastParams &F, const float *tab, unsigned q, unsigned rem) {
+    const float fx = (float)rem * F.inv_b;
+    const float p1 = tab[q];
+    float v;
+    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+        const float p2 = tab[q + 1];
+        v = fmaf(p2 - p1, fx, p1);
+    } else {
+        const float p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
+        const float c3 = fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
+        const float c2 = fmaf(-0.5f, p3, fmaf(2.0f, p2, fmaf(-2.5f, p1, p0)));
+        const float c1 = 0.5f * (p2 - p0);
+        v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
+    }
+    const float c = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);  // aukit.lua:667-668
+    if constexpr (SRC == SRC_PCM_S16LE_MONO || SRC == SRC_G711_MONO) return c;
+    else return rem == 0 ? p1 : c;
+}
+
 template <int INTERP, bool CLAMP = true>
 AUKIT_DEV float interp_row(const FastParams &F, const float *tab, unsigned n) {
     const unsigned q = __umulhi(n, F.magic);

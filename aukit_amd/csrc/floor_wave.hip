@@ -150,6 +150,7 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return false;
     if (((double)F.b + (double)WT * (double)F.a) * (double)F.b >= 4294967296.0) return false;
     F.cap = 64 * 16;  // doubles per wave window
+    F.dq64 = F.dr64 = 0;
     P.ratio = 48000 / old_rate;
     P.rcp = 1.0 / P.ratio;
     P.exact_rcp = exact_div_verified(ctx, P.ratio, max_out + 2) ? 1 : 0;

@@ -87,6 +87,7 @@ struct FastParams {
     unsigned wc, wd;     // v2: (1024 * a) = wc * b + wd  (one wave tile = 1024 outputs)
     int epi;             // wave kernel epilogue: 0 = Audio:resample, 1 = stream.pcm (fast_stream.hip); appended last so that the
     float alpha;         //   kernel-argument offsets the headline kernel reads stay what they were.  alpha: stream.pcm's low-pass weight
+    unsigned dq64, dr64; // 64 * a = dq64 * b + dr64: one row of a wave tile further down, (q, rem) advance by (dq64, dr64) with one carry
 };
 int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
