@@ -132,6 +132,13 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
         snprintf(nms, sizeof nms, "k_fast_wave_stream<pcm_s16le_mono,%s,nv%d,stream_pcm>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
         return ctx_end_kernel(ctx, nms, algorithmic_bytes);
     }
+    if (F.b >= 2 * F.a && nv <= 2 && (src_kind == SRC_PCM_S16LE_MONO || src_kind == SRC_G711_MONO) && !getenv("AUKIT_FAST_NOCOEF")) {
+        // up-sampling by 2x and more: per-source-sample coefficient table (fast_coef.hip)
+        if ((rc = launch_fast_wave_coef(ctx, src_kind, interp, nv, win, P, F, grid))) return rc;
+        static thread_local char nmc[96];
+        snprintf(nmc, sizeof nmc, "k_fast_wave_coef<%s,%s,nv%d>", src_kind == SRC_PCM_S16LE_MONO ? "pcm_s16le_mono" : "g711_mono", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+        return ctx_end_kernel(ctx, nmc, algorithmic_bytes);
+    }
     switch (src_kind) {
     case SRC_PCM_S16LE_MONO: rc = launch_src2<SRC_PCM_S16LE_MONO>(ctx, interp, nv, P, F, lds, grid); break;
     case SRC_G711_MONO: rc = launch_src2<SRC_G711_MONO>(ctx, interp, nv, P, F, lds, grid); break;

@@ -1,0 +1,79 @@
+// write-bandwidth micro-benchmark: which store pattern reaches torch.fill's rate?  (hipcc --offload-arch=gfx950 -O3 wr_probe.hip -o wr_probe)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// A: persistent waves, each tile = 1024 floats written as 16 rows of 64 dwords (the resampler's pattern)
+__global__ __launch_bounds__(256) void k_tile_dword(float *out, unsigned ntiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        float *o = out + (size_t)t * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r * 64 + lane] = (float)(t + r);
+    }
+}
+// B: same tiles, 4 rows of 64 float4
+__global__ __launch_bounds__(256) void k_tile_x4(float *out, unsigned ntiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)t * 1024);
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r * 64 + lane] = make_float4((float)t, (float)r, 0.f, 1.f);
+    }
+}
+// C: grid-stride float4 fill (what a fill kernel does)
+__global__ __launch_bounds__(256) void k_fill_x4(float4 *out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+// D: one tile per wave, non-persistent (grid = ntiles / 4)
+__global__ __launch_bounds__(256) void k_tile_dword_np(float *out, unsigned ntiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned t = blockIdx.x * 4 + wave;
+    if (t >= ntiles) return;
+    float *o = out + (size_t)t * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r * 64 + lane] = (float)(t + r);
+}
+// E: read 2 B + write 4 B per output (the headline's byte mix), no math: persistent tiles
+__global__ __launch_bounds__(256) void k_tile_rw(const short *in, float *out, unsigned ntiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(in + (size_t)t * 1024);
+        const uint4 a = ip[lane], b = ip[64 + lane];  // 2 KiB of int16 per tile
+        float *o = out + (size_t)t * 1024;
+        const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r * 64 + lane] = (float)(short)(w[r >> 1] >> (16 * (r & 1)));
+    }
+}
+
+int main(int argc, char **argv) {
+    const size_t nfl = (size_t)4096 * 480000;  // the headline's output
+    float *out; short *in;
+    CK(hipMalloc(&out, nfl * 4)); CK(hipMalloc(&in, nfl * 2)); CK(hipMemset(in, 1, nfl * 2));
+    const unsigned ntiles = (unsigned)(nfl / 1024);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char *name, auto launch, double bytes) {
+        for (int i = 0; i < 3; i++) launch();
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; i++) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s %8.3f ms  %7.0f GB/s\n", name, ms / 10, bytes / (ms / 10 * 1e-3) / 1e9);
+    };
+    for (int percu : {8, 16, 32}) {
+        const unsigned grid = 256 * percu;
+        char nm[64];
+        snprintf(nm, sizeof nm, "A tile dword persistent, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_tile_dword, dim3(grid), dim3(256), 0, 0, out, ntiles); }, nfl * 4.0);
+        snprintf(nm, sizeof nm, "B tile float4 persistent, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_tile_x4, dim3(grid), dim3(256), 0, 0, out, ntiles); }, nfl * 4.0);
+        snprintf(nm, sizeof nm, "C grid-stride float4 fill, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_fill_x4, dim3(grid), dim3(256), 0, 0, reinterpret_cast<float4 *>(out), nfl / 4); }, nfl * 4.0);
+        snprintf(nm, sizeof nm, "E tile read s16 + write f32, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_tile_rw, dim3(grid), dim3(256), 0, 0, in, out, ntiles); }, nfl * 6.0);
+    }
+    run("D tile dword, one tile per wave", [&] { hipLaunchKernelGGL(k_tile_dword_np, dim3((ntiles + 3) / 4), dim3(256), 0, 0, out, ntiles); }, nfl * 4.0);
+    return 0;
+}
