@@ -128,6 +128,12 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int frc = AUKIT_OK;
         if (fast_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
+    if (do_resample && dtype == AUKIT_F32 && C == 2 && d->codec == AUKIT_CODEC_PCM && !planar && d->bit_depth == 16 && d->data_type == AUKIT_SIGNED && !d->big_endian) {
+        bool aligned4 = (((uintptr_t)in->data()) & 3) == 0;  // frames must not straddle dwords
+        for (uint32_t s = 0; s < in->n && aligned4; s++) aligned4 = (in->off[s] & 3) == 0;
+        int frc = AUKIT_OK;
+        if (aligned4 && fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
+    }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, do_resample ? interp : AUKIT_INTERP_NONE, C, P, &lds))) return rc;
     return launch_resample(ctx, src, do_resample ? interp : AUKIT_INTERP_NONE, EPI_AUDIO, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);

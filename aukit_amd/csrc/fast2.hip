@@ -99,7 +99,7 @@ static int launch_src2(aukit_ctx *ctx, int interp, int nv, const ResampleParams 
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken) {
     *taken = false;
-    const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : (src_kind == SRC_G711_MONO ? 16 : 4);
+    const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : (src_kind == SRC_G711_MONO ? 16 : 4);  // source elements (frames for stereo) per 16-byte vector
     const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi == 1 ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;  // staged samples per wave tile (upper bound)
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
@@ -131,6 +131,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
         static thread_local char nms[96];
         snprintf(nms, sizeof nms, "k_fast_wave_stream<pcm_s16le_mono,%s,nv%d,stream_pcm>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
         return ctx_end_kernel(ctx, nms, algorithmic_bytes);
+    }
+    if (src_kind == SRC_PCM_S16LE_STEREO) {
+        if ((rc = launch_fast_wave_s16x2(ctx, interp, nv, P, F, grid))) return rc;
+        static thread_local char nm2[96];
+        snprintf(nm2, sizeof nm2, "k_fast_wave_s16x2<%s,nv%d>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+        return ctx_end_kernel(ctx, nm2, algorithmic_bytes);
     }
     if (F.b >= 2 * F.a && nv <= 2 && (src_kind == SRC_PCM_S16LE_MONO || src_kind == SRC_G711_MONO) && !getenv("AUKIT_FAST_NOCOEF")) {
         // up-sampling by 2x and more: per-source-sample coefficient table (fast_coef.hip)

@@ -24,7 +24,8 @@ struct Seg {
 };
 static_assert(sizeof(Seg) == 40, "Seg layout");
 
-enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7, SRC_I32 = 8 };
+enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7, SRC_I32 = 8,
+               SRC_PCM_S16LE_STEREO = 9 /* fast path only (fast_s16x2.hip): interleaved 16-bit stereo frames */ };
 enum EpiKind {
     EPI_AUDIO = 0,       // Audio:resample  :666-668  (integer x copies unclamped, else clamp ±1)
     EPI_STREAM_PCM = 1,  // stream.pcm      :2397-2403 (no clamp of interp, 2-tap FIR, ×127/128, clamp ±128/127)
@@ -90,6 +91,7 @@ struct FastParams {
     unsigned dq64, dr64; // 64 * a = dq64 * b + dr64: one row of a wave tile further down, (q, rem) advance by (dq64, dr64) with one carry
 };
 int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);
+int launch_fast_wave_s16x2(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, unsigned grid);
 int launch_fast_wave_coef(aukit_ctx *ctx, int src_kind, int interp, int nv, int win, const ResampleParams &P, const FastParams &F, unsigned grid);
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken);

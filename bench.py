@@ -112,6 +112,26 @@ class Pcm16Cubic(Workload):
                 "all_cores": {"value": done_all / dt_all / 1e6, "unit": "Msamples/s", "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
 
 
+class Pcm16Stereo(Workload):
+    """The WAV-file case: 16-bit stereo 44.1 kHz → 48 kHz through the Audio path (not a BASELINE config; same byte mix as config T)."""
+    name, unit = "pcm16_stereo", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.n_samples = int(round(args.seconds * SRC_RATE))
+        self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples * 2, SRC_RATE, 0xA0C17 + 6000 + rank)
+        offs = [i * self.n_samples * 4 for i in range(args.streams + 1)]
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_PCM, 2, SRC_RATE, 16, "signed")
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.step = lambda: B.decode_resample(ctx, self.bt, self.d, DST_RATE, args.interp, dtype=self.dtype, out=self.out)
+        self.desc = f"{args.streams}x s16le 44.1kHz STEREO {args.seconds:g}s -> aukit.pcm:resample(48000,'{args.interp}'), {args.dtype} store; unit = out-samples of both channels"
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum()) * 2
+
+
 class Pcm16Stream(Workload):
     """config T through the stream path: aukit.stream.pcm(data, 16, "signed", 1, 44100) with defaultInterpolation = cubic, every iterator call."""
     name, unit = "pcm16_stream", "Msamples/s"
@@ -251,7 +271,7 @@ class FlacPipeline(Workload):
         return int(self.m.layout()[0].sum())
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stereo, Pcm16Stream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def main():
@@ -270,7 +290,7 @@ def main():
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048}.get(args.workload, 4096)
+        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048}.get(args.workload, 4096)
 
     import torch
     import torch.distributed as dist
