@@ -189,6 +189,11 @@ __global__ __launch_bounds__(64) void k_dfpwm_transcode_stereo(const unsigned ch
     }
 }
 
+bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
+                           const unsigned long long *d_out_stride, int *rc);
+int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const unsigned long long *d_in_off, const unsigned long long *d_count, uint32_t n, unsigned char *out,
+                    const unsigned long long *d_ooff);
+
 // fed bytes of aukit.dfpwm's slice loop (Q10): Σ min(6001, nb - 6000k)
 static uint64_t dfpwm_fed_bytes(uint64_t nb) {
     uint64_t f = 0;
@@ -216,10 +221,16 @@ static int dfpwm_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit
     if (rc) return rc;
     std::vector<uint64_t> tab(soff);
     tab.insert(tab.end(), sstride.begin(), sstride.end());
-    if ((rc = upload_table(ctx, ctx->tmp_buf2, tab.data(), tab.size() * 8))) return rc;
+    if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;
     if (in->n) {
-        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->tmp_buf2.p);
+        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
         if ((rc = ctx_begin_kernel(ctx))) return rc;
+        int prc = AUKIT_OK;
+        if (dfpwm_decode_parallel(ctx, in, 0, C, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, t + in->n, &prc)) {  // chunk-parallel, bit-exact (dfpwm_par.hip)
+            if (prc) return prc;
+            if ((rc = ctx_end_kernel(ctx, "k_df_chunks(parallel dfpwm decode)", in->total() + tot))) return rc;
+            return audio_from_int_rows(ctx, SRC_I8, ctx->tmp_buf.p, row_off, row_len, in->n, C, d->sample_rate, new_rate, interp, do_resample, dtype, 127, 128, out);
+        }
         hipLaunchKernelGGL(k_dfpwm_decode, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
                            in->n, C, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, t + in->n);
         AUKIT_HIP_CHECK(hipGetLastError());
@@ -824,6 +835,25 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
     bool aligned = (reinterpret_cast<uintptr_t>(in->data()) & 15) == 0;
     for (uint32_t s = 0; s < in->n && aligned; s++) aligned = (in->off[s] & 15) == 0;
     const bool stereo = channels == 2 && aligned && !getenv("AUKIT_DFPWM_GENERIC");
+    if (channels == 2) {  // decode + mono mix in parallel chunks (exact), then one encoder lane per stream (dfpwm_par.hip)
+        std::vector<uint64_t> tab(2 * (size_t)in->n);
+        uint64_t mtot = 0;
+        for (uint32_t s = 0; s < in->n; s++) {
+            const uint64_t pairs = dfpwm_fed_bytes(in->off[s + 1] - in->off[s]) * 4;
+            tab[s] = mtot;
+            tab[in->n + s] = pairs;
+            mtot += round_up(std::max<uint64_t>(pairs, 1), 16);
+        }
+        if ((rc = ctx->tmp_buf.ensure((size_t)mtot + 64))) return rc;
+        if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;
+        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        int prc = AUKIT_OK;
+        if (dfpwm_decode_parallel(ctx, in, 1, 2, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, nullptr, &prc)) {
+            if (prc) return prc;
+            if ((rc = dfpwm_encode_i8(ctx, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), t, t + in->n, in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off)))) return rc;
+            return ctx_end_kernel(ctx, "k_df_chunks+k_dfpwm_encode_i8", in->total() + off[in->n]);
+        }
+    }
     if (stereo)
         hipLaunchKernelGGL(k_dfpwm_transcode_stereo, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
                            in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off));

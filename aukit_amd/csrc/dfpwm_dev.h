@@ -11,14 +11,18 @@ namespace aukit {
 struct DfPred { int charge, strength, prev; };
 // math.floor(a / 2^sh) on two's-complement ints is an arithmetic shift
 AUKIT_DEV int df_predict(DfPred &p, int bit) {
-    const int target = bit ? 127 : -128;
-    int next = p.charge + ((p.strength * (target - p.charge) + 512) >> 10);
-    if (next == p.charge && next != target) next += bit ? 1 : -1;
-    const int z = (bit == p.prev) ? 1023 : 0;
-    int ns = p.strength;
-    if (ns != z) ns += (bit == p.prev) ? 1 : -1;
-    if (ns < 8) ns = 8;
-    p.charge = next; p.strength = ns; p.prev = bit;
+    // branch-free form of:  target = bit ? 127 : -128;  next = charge + floor((strength * (target - charge) + 512) / 1024);
+    //   if next == charge and next ~= target then next = next + (bit ? 1 : -1);
+    //   z = (bit == prev) ? 1023 : 0;  if strength ~= z then strength += (bit == prev) ? 1 : -1;  strength = max(strength, 8)
+    // (for strength >= 8, and for the reset value 0, the last line is max(min(strength ± 1, 1023), 8))
+    const int diff = bit * 255 - 128 - p.charge;
+    const int step = (p.strength * diff + 512) >> 10;
+    const int nudge = (step == 0 && diff != 0) ? 2 * bit - 1 : 0;
+    const int next = p.charge + step + nudge;
+    const int ns = p.strength + (bit == p.prev ? 1 : -1);
+    p.strength = max(min(ns, 1023), 8);
+    p.charge = next;
+    p.prev = bit;
     return next;
 }
 struct DfDec { DfPred p; int lpf, pcharge, pbit; };

@@ -1,0 +1,372 @@
+// dfpwm_par.hip — chunk-parallel DFPWM *decoding*, bit-exact (the encoder stays one lane per stream: its bits depend on its state).
+//
+// aukit.dfpwm feeds one decoder per stream, serially (aukit.lua:1399-1412).  One lane per stream leaves most of the GPU idle for
+// batches below ~10^5 streams, and speculation on the whole state does not work: the strength counter only forgets its start at
+// its floor, which noisy input rarely touches.  But the decoder's strength is a saturating ±1 counter driven by
+// the INPUT bits alone (bit == previous bit ? min(s + 1, 1023) : max(s - 1, 8)), i.e. a composition of clamp-add maps
+// (a, lo, hi) — associative, so it is known exactly at any position after a scan:
+//   1. k_df_blockmaps   lane per (stream, 1 KiB block): the block's composite clamp-add map;
+//   2. k_df_blockscan   lane per stream: strength at every block start;
+//   3. k_df_chunks      lane per (stream, chunk): starts one block early with the exact strength and previous bit, charge and
+//                       filter state zero — the charge update is a contraction towards the target ((1 - s/1024) per step, plus
+//                       a nudge) and the low-pass forgets at 116/256 per step, so after the 8192 warm-up steps the state is the
+//                       true one in practice — records the state it reached, decodes its chunk, records the end state;
+//   4. k_df_verify      lane per stream: where a chunk's recorded start state differs from the true end state of the chunk
+//                       before it, that chunk is decoded again serially from the true state.  Exactness therefore never rests
+//                       on the convergence argument; only the speed does (AUKIT_DFPWM_STATS=1 prints the redo count).
+// Output: de-interleaved int8 rows (the loader), or the stereo → mono mix of aukit.pcm ∘ Audio:mono ∘ encodePCM as int8 (transcode).
+#include <algorithm>
+#include "common.h"
+#include "dfpwm_dev.h"
+
+namespace aukit {
+
+typedef unsigned long long u64;
+
+struct SatMap { int a, lo, hi; };
+AUKIT_DEV int sm_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+AUKIT_DEV SatMap sm_then(const SatMap &f, const SatMap &g) { return SatMap{f.a + g.a, sm_clamp(f.lo + g.a, g.lo, g.hi), sm_clamp(f.hi + g.a, g.lo, g.hi)}; }
+AUKIT_DEV int sm_apply(const SatMap &f, int x) { return sm_clamp(x + f.a, f.lo, f.hi); }
+
+// bytes fed to the decoder by aukit.dfpwm's slice loop (Q10): slice k = source bytes [6000k, 6000k + min(6001, nb - 6000k))
+AUKIT_DEV u64 dfp_fed_total(u64 nb) { return nb ? nb + (nb + 5999) / 6000 - 1 : 0; }
+AUKIT_DEV u64 dfp_src_index(u64 f, u64 nb) {  // fed byte f → source byte
+    const u64 nsl = (nb + 5999) / 6000;
+    u64 k = f / 6001;
+    if (k >= nsl) k = nsl - 1;
+    return f - k;  // 6000 k + (f - 6001 k)
+}
+
+// Sequential reader of the fed byte sequence starting at fed index f0: source bytes are contiguous except that every slice of
+// 6001 fed bytes is followed by a step back of one source byte (its last byte is fed again as the first byte of the next slice).
+// Aligned dword loads, one per four bytes.
+struct FedReader {
+    const unsigned char *p;
+    u64 src;        // next source byte
+    unsigned left;  // fed bytes left in the current slice
+    unsigned dw;    // aligned dword holding source byte `src` (valid when have)
+    bool have;
+};
+AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 nb, u64 f0) {
+    FedReader r;
+    const u64 nsl = (nb + 5999) / 6000;
+    u64 k = f0 / 6001;
+    if (nsl && k >= nsl) k = nsl - 1;
+    const u64 base = 6000 * k, cnt = nb - base < 6001 ? nb - base : 6001, off = f0 - 6001 * k;
+    r.p = p; r.src = base + off; r.left = (unsigned)(cnt - off); r.dw = 0; r.have = false;
+    return r;
+}
+AUKIT_DEV unsigned fed_next(FedReader &r) {
+    const unsigned sh = (unsigned)((uintptr_t)(r.p + r.src) & 3);
+    if (!r.have || sh == 0) { r.dw = *reinterpret_cast<const unsigned *>((uintptr_t)(r.p + r.src) & ~(uintptr_t)3); r.have = true; }
+    const unsigned byte = (r.dw >> (8 * sh)) & 0xFF;
+    r.src++;
+    if (--r.left == 0) { r.src--; r.left = 6001; r.have = false; }  // next slice starts on the byte just read (the last slice simply ends)
+    return byte;
+}
+
+struct DfParParams {
+    const unsigned char *src;
+    const u64 *off;
+    unsigned n;
+    unsigned nblk;      // 1 KiB blocks per stream (max over the batch)
+    unsigned bpc;       // blocks per chunk
+    unsigned nchunk;    // chunks per stream
+    u64 W;              // block size in fed bytes
+    SatMap *maps;       // [n][nblk]
+    int *s_start;       // [n][nblk + 1] strength at block starts
+    int *st_start, *st_end;  // [n][nchunk][6] decoder state after warm-up / at chunk end (charge, strength, prev, lpf, pcharge, pbit); strength -1 = no such chunk
+    // output
+    int mode;           // 0: rows (C channels), 1: stereo → mono mix
+    int C;
+    signed char *out;
+    const u64 *out_off, *out_stride;  // rows: element offset of channel 0 / channel stride per stream; mix: element offset per stream
+    unsigned *stats;
+};
+
+// The eight clamp-add steps of one byte, given the bit before it, compose to one clamp-add map: 512 table entries per workgroup.
+__global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
+    __shared__ SatMap bm[512];
+    for (int e = threadIdx.x; e < 512; e += 256) {
+        unsigned byte = e & 255;
+        int prev = e >> 8;
+        SatMap f{0, -(1 << 28), 1 << 28};
+        for (int k = 0; k < 8; k++) {
+            const int bit = byte & 1;
+            byte >>= 1;
+            f = sm_then(f, SatMap{bit == prev ? 1 : -1, 8, 1023});
+            prev = bit;
+        }
+        bm[e] = f;
+    }
+    __syncthreads();
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const unsigned blk = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)blk * P.n);
+    if (blk >= P.nblk) return;
+    const unsigned char *p = P.src + P.off[s];
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb);
+    const u64 f0 = (u64)blk * P.W, f1 = f0 + P.W < fed ? f0 + P.W : fed;
+    SatMap f{0, -(1 << 28), 1 << 28};
+    if (f0 < fed) {
+        int prev = f0 ? (p[dfp_src_index(f0 - 1, nb)] >> 7) & 1 : 0;
+        FedReader rd = fed_open(p, nb, f0);
+        u64 b = f0;
+        if (b == 0) {  // from the reset state (strength 0) the first step lands on 8 either way: do the stream's first byte bit by bit
+            unsigned byte = fed_next(rd);
+            for (int k = 0; k < 8; k++) {
+                const int bit = byte & 1;
+                byte >>= 1;
+                f = sm_then(f, k == 0 ? SatMap{0, 8, 8} : SatMap{bit == prev ? 1 : -1, 8, 1023});
+                prev = bit;
+            }
+            b = 1;
+        }
+        for (; b < f1; b++) {
+            const unsigned byte = fed_next(rd);
+            f = sm_then(f, bm[(prev << 8) | byte]);
+            prev = byte >> 7;
+        }
+    }
+    P.maps[(size_t)s * P.nblk + blk] = f;
+}
+
+__global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= P.n) return;
+    int st = 0;
+    int *o = P.s_start + (size_t)s * (P.nblk + 1);
+    o[0] = 0;
+    for (unsigned b = 0; b < P.nblk; b++) { st = sm_apply(P.maps[(size_t)s * P.nblk + b], st); o[b + 1] = st; }
+}
+
+struct DfOut {  // where decoded samples go
+    int mode, C;
+    signed char *base;   // rows: channel 0 of the stream; mix: the stream's mono samples
+    u64 stride;
+    const signed char *lut;
+};
+
+// decode fed bytes [f0, f1) of one stream; EMIT = false: state only
+template <bool EMIT>
+AUKIT_DEV void dfp_run(const unsigned char *p, u64 nb, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
+    u64 i = 8 * f0;  // index of the next decoded sample in the fed order
+    FedReader rd = fed_open(p, nb, f0);
+    for (u64 b = f0; b < f1; b++) {
+        unsigned byte = fed_next(rd);
+        if (!EMIT) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { df_decode_bit(d, byte & 1); byte >>= 1; }
+        } else if (O.mode == 1) {  // stereo frames → one mono int8 each (4 per fed byte: one dword store)
+            unsigned packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
+                byte >>= 2;
+                packed |= ((unsigned)(unsigned char)O.lut[((l + 128) << 8) | (r + 128)]) << (8 * k);
+            }
+            *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = packed;
+            i += 8;
+        } else if (O.C == 1) {
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { lo |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k); byte >>= 1; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hi |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k); byte >>= 1; }
+            *reinterpret_cast<uint2 *>(O.base + i) = make_uint2(lo, hi);
+            i += 8;
+        } else if (O.C == 2) {
+            unsigned c0 = 0, c1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c0 |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k);
+                c1 |= ((unsigned)(unsigned char)df_decode_bit(d, (byte >> 1) & 1)) << (8 * k);
+                byte >>= 2;
+            }
+            *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = c0;
+            *reinterpret_cast<unsigned *>(O.base + O.stride + (i >> 1)) = c1;
+            i += 8;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int v = df_decode_bit(d, byte & 1);
+                byte >>= 1;
+                const u64 fr = i / (u64)O.C;
+                O.base[(i - fr * (u64)O.C) * O.stride + fr] = (signed char)v;
+                i++;
+            }
+        }
+    }
+}
+
+AUKIT_DEV void dfp_pack(const DfDec &d, int *o) { o[0] = d.p.charge; o[1] = d.p.strength; o[2] = d.p.prev; o[3] = d.lpf; o[4] = d.pcharge; o[5] = d.pbit; }
+AUKIT_DEV void dfp_unpack(const int *o, DfDec &d) { d.p.charge = o[0]; d.p.strength = o[1]; d.p.prev = o[2]; d.lpf = o[3]; d.pcharge = o[4]; d.pbit = o[5]; }
+
+AUKIT_DEV int dfp_mix(int l, int r) {  // aukit.pcm table input :1082, Audio:mono :685-686, encodePCM :874 + the encoder's floor
+    double acc = 0;
+    acc = acc + (double)l / (l < 0 ? 128 : 127);
+    acc = acc + (double)r / (r < 0 ? 128 : 127);
+    const double m = acc / 2;
+    return (int)floor(m * (m < 0 ? 128 : 127));
+}
+
+AUKIT_DEV DfOut dfp_out(const DfParParams &P, unsigned s, const signed char *lut) {
+    DfOut O;
+    O.mode = P.mode; O.C = P.C; O.lut = lut;
+    O.base = P.out + P.out_off[s];
+    O.stride = P.mode == 0 ? P.out_stride[s] : 0;
+    return O;
+}
+
+__global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
+    __shared__ signed char lut[65536];
+    if (P.mode == 1) {
+        for (int i = threadIdx.x; i < 65536; i += 256) lut[i] = (signed char)dfp_mix((i >> 8) - 128, (i & 255) - 128);
+        __syncthreads();
+    }
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
+    if (c >= P.nchunk) return;
+    const unsigned char *p = P.src + P.off[s];
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb);
+    const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+    int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6, *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
+    if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
+    const DfOut O = dfp_out(P, s, lut);
+    DfDec d{};
+    if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
+        const u64 fw = f0 - P.W;
+        d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + (size_t)c * P.bpc - 1];
+        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, nb)] >> 7) & 1 : 0;
+        dfp_run<false>(p, nb, fw, f0, d, O);
+    }
+    dfp_pack(d, ss);
+    dfp_run<true>(p, nb, f0, f1, d, O);
+    dfp_pack(d, se);
+}
+
+__global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= P.n) return;
+    const unsigned char *p = P.src + P.off[s];
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb), CH = (u64)P.bpc * P.W;
+    const DfOut O = dfp_out(P, s, nullptr);
+    int truth[6];
+    for (int i = 0; i < 6; i++) truth[i] = P.st_end[(size_t)s * P.nchunk * 6 + i];
+    unsigned redone = 0, chunks = 1;
+    for (unsigned c = 1; c < P.nchunk; c++) {
+        const int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6;
+        int *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
+        if (ss[1] < 0) break;
+        chunks++;
+        bool same = true;
+        for (int i = 0; i < 6; i++) same = same && ss[i] == truth[i];
+        if (same) { for (int i = 0; i < 6; i++) truth[i] = se[i]; continue; }
+        DfDec d;
+        dfp_unpack(truth, d);
+        const u64 f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+        if (P.mode == 1) {  // no table in this kernel: mix computed on the spot
+            u64 i = 4 * f0;
+            for (u64 b = f0; b < f1; b++) {
+                unsigned byte = p[dfp_src_index(b, nb)];
+                for (int k = 0; k < 4; k++) {
+                    const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
+                    byte >>= 2;
+                    O.base[i++] = (signed char)dfp_mix(l, r);
+                }
+            }
+        } else dfp_run<true>(p, nb, f0, f1, d, O);
+        dfp_pack(d, truth);
+        for (int i = 0; i < 6; i++) se[i] = truth[i];
+        redone++;
+    }
+    if (redone) atomicAdd(&P.stats[0], redone);
+    atomicAdd(&P.stats[1], chunks);
+}
+
+// Audio:dfpwm on int8 mono samples (the transcode's second half): one encoder per stream, serial (its bits depend on its state)
+__global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, const u64 *in_off, const u64 *count, unsigned n, unsigned char *out, const u64 *ooff) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const signed char *p = in + in_off[s];  // 16-byte aligned (host)
+    const u64 L = count[s];
+    unsigned char *o = out + ooff[s];
+    DfEnc e{};
+    u64 w = 0;
+    uint4 cur = L ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
+    for (u64 i = 0; i < L; i += 16) {
+        uint4 nxt = cur;
+        if (i + 16 < L) nxt = *reinterpret_cast<const uint4 *>(p + i + 16);  // in flight while `cur` is encoded
+        const unsigned words[4] = {cur.x, cur.y, cur.z, cur.w};
+        if (i + 16 <= L) {  // two whole output bytes
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) byte |= (unsigned)df_encode_sample(e, (int)(signed char)(words[2 * h + (k >> 2)] >> (8 * (k & 3)))) << k;
+                o[w++] = (unsigned char)byte;
+            }
+        } else {
+            for (int h = 0; h < 2 && i + 8 * h < L; h++) {
+                unsigned byte = 0;
+                for (int k = 0; k < 8; k++) {
+                    const u64 idx = i + 8 * h + k;
+                    const int v = idx < L ? (int)(signed char)(words[2 * h + (k >> 2)] >> (8 * (k & 3))) : 0;  // the last byte is padded with samples of value 0
+                    byte |= (unsigned)df_encode_sample(e, v) << k;
+                }
+                o[w++] = (unsigned char)byte;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// host: plan + launch.  `out`: rows (mode 0, C channels, per-stream row offsets / strides as device arrays of n entries) or mono
+// mix (mode 1, per-stream element offsets).  Returns false (nothing launched) when the batch is better served one lane per stream.
+bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc) {
+    const uint32_t n = in->n;
+    uint64_t fed_max = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        fed_max = std::max<uint64_t>(fed_max, nb ? nb + (nb + 5999) / 6000 - 1 : 0);
+    }
+    uint64_t W = 1024;
+    if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(2, strtoull(e, nullptr, 10) & ~1ull);
+    const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
+    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 1024 / std::max<uint32_t>(n, 1));  // chunks per stream for ~1024 lanes per CU
+    if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
+    unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 6u);  // warm-up (1 block) <= 1/6 of a chunk
+    const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
+    if (nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
+    // scratch: maps, strengths, states, stats
+    const size_t b_maps = (size_t)n * nblk * sizeof(SatMap), b_ss = (size_t)n * (nblk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
+    if ((*rc = ctx->tmp_buf2.ensure(b_maps + b_ss + 2 * b_st + 256))) return true;
+    char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+    DfParParams P{};
+    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(in->d_off); P.n = n; P.nblk = nblk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+    P.maps = reinterpret_cast<SatMap *>(B); P.s_start = reinterpret_cast<int *>(B + b_maps);
+    P.st_start = reinterpret_cast<int *>(B + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_maps + b_ss + b_st);
+    P.stats = reinterpret_cast<unsigned *>(B + b_maps + b_ss + 2 * b_st);
+    P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride;
+    if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
+    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
+    if (getenv("AUKIT_DFPWM_STATS")) {
+        unsigned h[2] = {0, 0};
+        (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[dfpwm] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone serially\n", n, nchunk, bpc, (unsigned long long)W, h[0], h[1]);
+    }
+    *rc = AUKIT_OK;
+    return true;
+}
+
+int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const u64 *d_in_off, const u64 *d_count, uint32_t n, unsigned char *out, const u64 *d_ooff) {
+    hipLaunchKernelGGL(k_dfpwm_encode_i8, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in, d_in_off, d_count, n, out, d_ooff);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+
+}  // namespace aukit

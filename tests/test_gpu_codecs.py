@@ -68,7 +68,7 @@ def test_dfpwm_encode_out_of_range_raises(ctx):
         B.dfpwm_encode(ctx, ab, True)
 
 
-def test_config4_pipeline_and_fused_transcode(ctx, oracle):
+def test_config4_pipeline_and_fused_transcode(ctx, oracle, monkeypatch):
     """BASELINE config 4: a = aukit.dfpwm(d, 2, 48000); m = a:mono(); out = m:dfpwm() — unfused and fused, bit-exact."""
     B, N = _B(), _N()
     streams = []
@@ -84,11 +84,38 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle):
         assert u == ref
         assert f == ref
     assert len(fused[0]) == 60010  # Q10: 120 000 B → 960 152 samples → 480 076 mono samples → 60 010 B
+    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfpwm_encode_i8"  # chunk-parallel exact decode + one encoder lane per stream
+    # the same bytes through every schedule: one lane per stream; 2-byte blocks (a warm-up of 16 steps: most recorded start states
+    # are wrong and the verify pass redoes the chunks); chunk and Q10 slice boundaries in odd positions
+    for env in ({"AUKIT_DFPWM_SERIAL": "1"}, {"AUKIT_DFPWM_BLOCK": "2", "AUKIT_DFPWM_CHUNKS": "1000"}, {"AUKIT_DFPWM_BLOCK": "6002", "AUKIT_DFPWM_CHUNKS": "50"},
+                {"AUKIT_DFPWM_BLOCK": "250", "AUKIT_DFPWM_CHUNKS": "7"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        again = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        dec = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F64).download()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert again == fused, env
+        for x, y in zip(dec, au.download()):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), env
+    monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
+    B.dfpwm_transcode_mono(ctx, bt, 2)
     assert ctx.last_kernel()[0] == "k_dfpwm_transcode_stereo"
+    monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
+    # mono and 3-channel DFPWM through the parallel loader
+    for ch in (1, 3):
+        sx = oracle.dfpwm_encode(np.round(signal(47976 if ch == 3 else 100000, 48000, 4, 40 + ch) * 100))  # 5997 B: fed bytes * 8 divisible by 3
+        got = B.decode(ctx, B.Batch.upload(ctx, [sx]), B.make_desc(N.CODEC_DFPWM, ch, 48000), dtype=N.F64).download()[0]
+        refx = oracle.dfpwm(sx, ch, 48000)
+        for c in range(ch):
+            assert np.array_equal(got[c], refx.data[c]), (ch, c)
     # a batch whose streams are not 16-byte aligned takes the generic kernel: same bytes
     bt2 = B.Batch.upload(ctx, [b"\x5a"] + streams)
+    monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
     fused2 = B.dfpwm_transcode_mono(ctx, bt2, 2).download()
     assert ctx.last_kernel()[0] == "k_dfpwm_transcode_mono"
+    monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
+    assert B.dfpwm_transcode_mono(ctx, bt2, 2).download() == fused2
     assert fused2[1:] == fused
 
 
