@@ -16,7 +16,7 @@ AUKIT_DEV int df_predict(DfPred &p, int bit) {
     //   z = (bit == prev) ? 1023 : 0;  if strength ~= z then strength += (bit == prev) ? 1 : -1;  strength = max(strength, 8)
     // (for strength >= 8, and for the reset value 0, the last line is max(min(strength ± 1, 1023), 8))
     const int diff = bit * 255 - 128 - p.charge;
-    const int step = (p.strength * diff + 512) >> 10;
+    const int step = (__mul24(p.strength, diff) + 512) >> 10;  // |strength * diff| < 2^18: the 24-bit multiply is exact and full-rate
     const int nudge = (step == 0 && diff != 0) ? 2 * bit - 1 : 0;
     const int next = p.charge + step + nudge;
     const int ns = p.strength + (bit == p.prev ? 1 : -1);
