@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void k_dfpwm_transcode_stereo(const unsigned ch
 }
 
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
-                           const unsigned long long *d_out_stride, int *rc);
+                           const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0);
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const unsigned long long *d_in_off, const unsigned long long *d_count, uint32_t n, unsigned char *out,
                     const unsigned long long *d_ooff);
 

@@ -492,6 +492,13 @@ __global__ __launch_bounds__(64) void k_dfpwm_stream_rows(const unsigned char *s
     }
 }
 
+bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
+                           const unsigned long long *d_out_stride, int *rc, uint64_t adv, uint64_t lead);
+__global__ __launch_bounds__(256) void k_row_heads_zero(signed char *out, const unsigned long long *row_off, unsigned n) {
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) out[row_off[s]] = 0;
+}
+
 static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                         aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -548,6 +555,12 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
     if (in->n && !segs.empty()) {
         if ((rc = ctx->tmp_buf.ensure((size_t)tot + 64))) { delete ck; return rc; }
         if ((rc = upload_table(ctx, ctx->misc_buf, rowo.data(), rowo.size() * 8))) { delete ck; return rc; }
+        int prc = AUKIT_OK;
+        const unsigned long long *d_rowo = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        if (dfpwm_decode_parallel(ctx, in, 0, 1, reinterpret_cast<signed char *>(ctx->tmp_buf.p), d_rowo, nullptr, &prc, (uint64_t)adv, 1)) {  // chunk-parallel, exact (dfpwm_par.hip)
+            if (prc) { delete ck; return prc; }
+            hipLaunchKernelGGL(k_row_heads_zero, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<signed char *>(ctx->tmp_buf.p), d_rowo, in->n);  // audio[0] of the first chunk = `last` = 0
+        } else
         hipLaunchKernelGGL(k_dfpwm_stream_rows, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
                            in->n, (unsigned long long)adv, reinterpret_cast<signed char *>(ctx->tmp_buf.p), reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p));
         AUKIT_HIP_CHECK(hipGetLastError());

@@ -29,12 +29,13 @@ AUKIT_DEV SatMap sm_then(const SatMap &f, const SatMap &g) { return SatMap{f.a +
 AUKIT_DEV int sm_apply(const SatMap &f, int x) { return sm_clamp(x + f.a, f.lo, f.hi); }
 
 // bytes fed to the decoder by aukit.dfpwm's slice loop (Q10): slice k = source bytes [6000k, 6000k + min(6001, nb - 6000k))
-AUKIT_DEV u64 dfp_fed_total(u64 nb) { return nb ? nb + (nb + 5999) / 6000 - 1 : 0; }
-AUKIT_DEV u64 dfp_src_index(u64 f, u64 nb) {  // fed byte f → source byte
-    const u64 nsl = (nb + 5999) / 6000;
-    u64 k = f / 6001;
+// (stream.dfpwm slices by 6000 * channels + 1 bytes advanced by 6000 * channels, :2449-2451: `adv` is the advance)
+AUKIT_DEV u64 dfp_fed_total(u64 nb, u64 adv) { return nb ? nb + (nb + adv - 1) / adv - 1 : 0; }
+AUKIT_DEV u64 dfp_src_index(u64 f, u64 nb, u64 adv) {  // fed byte f → source byte
+    const u64 nsl = (nb + adv - 1) / adv;
+    u64 k = f / (adv + 1);
     if (k >= nsl) k = nsl - 1;
-    return f - k;  // 6000 k + (f - 6001 k)
+    return f - k;  // adv k + (f - (adv + 1) k)
 }
 
 // Sequential reader of the fed byte sequence starting at fed index f0: source bytes are contiguous except that every slice of
@@ -44,16 +45,17 @@ struct FedReader {
     const unsigned char *p;
     u64 src;        // next source byte
     unsigned left;  // fed bytes left in the current slice
+    unsigned adv1;  // fed bytes per full slice
     unsigned dw;    // aligned dword holding source byte `src` (valid when have)
     bool have;
 };
-AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 nb, u64 f0) {
+AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 nb, u64 f0, u64 adv) {
     FedReader r;
-    const u64 nsl = (nb + 5999) / 6000;
-    u64 k = f0 / 6001;
+    const u64 nsl = (nb + adv - 1) / adv;
+    u64 k = f0 / (adv + 1);
     if (nsl && k >= nsl) k = nsl - 1;
-    const u64 base = 6000 * k, cnt = nb - base < 6001 ? nb - base : 6001, off = f0 - 6001 * k;
-    r.p = p; r.src = base + off; r.left = (unsigned)(cnt - off); r.dw = 0; r.have = false;
+    const u64 base = adv * k, cnt = nb - base < adv + 1 ? nb - base : adv + 1, off = f0 - (adv + 1) * k;
+    r.p = p; r.src = base + off; r.left = (unsigned)(cnt - off); r.adv1 = (unsigned)(adv + 1); r.dw = 0; r.have = false;
     return r;
 }
 AUKIT_DEV unsigned fed_next(FedReader &r) {
@@ -61,7 +63,7 @@ AUKIT_DEV unsigned fed_next(FedReader &r) {
     if (!r.have || sh == 0) { r.dw = *reinterpret_cast<const unsigned *>((uintptr_t)(r.p + r.src) & ~(uintptr_t)3); r.have = true; }
     const unsigned byte = (r.dw >> (8 * sh)) & 0xFF;
     r.src++;
-    if (--r.left == 0) { r.src--; r.left = 6001; r.have = false; }  // next slice starts on the byte just read (the last slice simply ends)
+    if (--r.left == 0) { r.src--; r.left = r.adv1; r.have = false; }  // next slice starts on the byte just read (the last slice simply ends)
     return byte;
 }
 
@@ -73,6 +75,8 @@ struct DfParParams {
     unsigned bpc;       // blocks per chunk
     unsigned nchunk;    // chunks per stream
     u64 W;              // block size in fed bytes
+    u64 adv;            // slice advance of the feeding loop (6000 for aukit.dfpwm, 6000 * channels for stream.dfpwm)
+    u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
     SatMap *maps;       // [n][nblk]
     int *s_start;       // [n][nblk + 1] strength at block starts
     int *st_start, *st_end;  // [n][nchunk][6] decoder state after warm-up / at chunk end (charge, strength, prev, lpf, pcharge, pbit); strength -1 = no such chunk
@@ -104,12 +108,12 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     const unsigned blk = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)blk * P.n);
     if (blk >= P.nblk) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb);
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv);
     const u64 f0 = (u64)blk * P.W, f1 = f0 + P.W < fed ? f0 + P.W : fed;
     SatMap f{0, -(1 << 28), 1 << 28};
     if (f0 < fed) {
-        int prev = f0 ? (p[dfp_src_index(f0 - 1, nb)] >> 7) & 1 : 0;
-        FedReader rd = fed_open(p, nb, f0);
+        int prev = f0 ? (p[dfp_src_index(f0 - 1, nb, P.adv)] >> 7) & 1 : 0;
+        FedReader rd = fed_open(p, nb, f0, P.adv);
         u64 b = f0;
         if (b == 0) {  // from the reset state (strength 0) the first step lands on 8 either way: do the stream's first byte bit by bit
             unsigned byte = fed_next(rd);
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
 struct DfOut {  // where decoded samples go
     int mode, C;
     signed char *base;   // rows: channel 0 of the stream; mix: the stream's mono samples
-    u64 stride;
+    u64 stride, adv, lead;
     const signed char *lut;
 };
 
@@ -150,7 +154,7 @@ struct DfOut {  // where decoded samples go
 template <bool EMIT>
 AUKIT_DEV void dfp_run(const unsigned char *p, u64 nb, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
     u64 i = 8 * f0;  // index of the next decoded sample in the fed order
-    FedReader rd = fed_open(p, nb, f0);
+    FedReader rd = fed_open(p, nb, f0, O.adv);
     for (u64 b = f0; b < f1; b++) {
         unsigned byte = fed_next(rd);
         if (!EMIT) {
@@ -165,6 +169,10 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 nb, u64 f0, u64 f1, DfDec &d,
                 packed |= ((unsigned)(unsigned char)O.lut[((l + 128) << 8) | (r + 128)]) << (8 * k);
             }
             *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = packed;
+            i += 8;
+        } else if (O.C == 1 && O.lead) {  // row shifted by `lead` elements: byte stores
+#pragma unroll
+            for (int k = 0; k < 8; k++) { O.base[O.lead + i + k] = (signed char)df_decode_bit(d, byte & 1); byte >>= 1; }
             i += 8;
         } else if (O.C == 1) {
             unsigned lo = 0, hi = 0;
@@ -213,7 +221,8 @@ AUKIT_DEV DfOut dfp_out(const DfParParams &P, unsigned s, const signed char *lut
     DfOut O;
     O.mode = P.mode; O.C = P.C; O.lut = lut;
     O.base = P.out + P.out_off[s];
-    O.stride = P.mode == 0 ? P.out_stride[s] : 0;
+    O.stride = (P.mode == 0 && P.out_stride) ? P.out_stride[s] : 0;
+    O.adv = P.adv; O.lead = P.lead;
     return O;
 }
 
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
     if (c >= P.nchunk) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb);
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv);
     const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
     int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6, *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
     if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + (size_t)c * P.bpc - 1];
-        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, nb)] >> 7) & 1 : 0;
+        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, nb, P.adv)] >> 7) & 1 : 0;
         dfp_run<false>(p, nb, fw, f0, d, O);
     }
     dfp_pack(d, ss);
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb), CH = (u64)P.bpc * P.W;
+    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv), CH = (u64)P.bpc * P.W;
     const DfOut O = dfp_out(P, s, nullptr);
     int truth[6];
     for (int i = 0; i < 6; i++) truth[i] = P.st_end[(size_t)s * P.nchunk * 6 + i];
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
         if (P.mode == 1) {  // no table in this kernel: mix computed on the spot
             u64 i = 4 * f0;
             for (u64 b = f0; b < f1; b++) {
-                unsigned byte = p[dfp_src_index(b, nb)];
+                unsigned byte = p[dfp_src_index(b, nb, P.adv)];
                 for (int k = 0; k < 4; k++) {
                     const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
                     byte >>= 2;
@@ -322,14 +331,15 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
 
 // host: plan + launch.  `out`: rows (mode 0, C channels, per-stream row offsets / strides as device arrays of n entries) or mono
 // mix (mode 1, per-stream element offsets).  Returns false (nothing launched) when the batch is better served one lane per stream.
-bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc) {
+bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc,
+                           uint64_t adv, uint64_t lead) {
     const uint32_t n = in->n;
     uint64_t fed_max = 0;
     for (uint32_t s = 0; s < n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
-        fed_max = std::max<uint64_t>(fed_max, nb ? nb + (nb + 5999) / 6000 - 1 : 0);
+        fed_max = std::max<uint64_t>(fed_max, nb ? nb + (nb + adv - 1) / adv - 1 : 0);
     }
-    uint64_t W = 1024;
+    uint64_t W = n >= 4096 ? 1024 : 512;  // small batches: more, shorter chunks
     if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(2, strtoull(e, nullptr, 10) & ~1ull);
     const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
     unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 1024 / std::max<uint32_t>(n, 1));  // chunks per stream for ~1024 lanes per CU
@@ -346,7 +356,7 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
     P.maps = reinterpret_cast<SatMap *>(B); P.s_start = reinterpret_cast<int *>(B + b_maps);
     P.st_start = reinterpret_cast<int *>(B + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_maps + b_ss + b_st);
     P.stats = reinterpret_cast<unsigned *>(B + b_maps + b_ss + 2 * b_st);
-    P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride;
+    P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.adv = adv; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
