@@ -227,7 +227,7 @@ AUKIT_DEV DfOut dfp_out(const DfParParams &P, unsigned s, const signed char *lut
 }
 
 __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
-    __shared__ signed char lut[65536];
+    extern __shared__ signed char lut[];  // 64 KiB in mix mode only (rows mode runs at full occupancy)
     if (P.mode == 1) {
         for (int i = threadIdx.x; i < 65536; i += 256) lut[i] = (signed char)dfp_mix((i >> 8) - 128, (i & 255) - 128);
         __syncthreads();
@@ -360,7 +360,7 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
-    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), mode == 1 ? 65536 : 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
     if (getenv("AUKIT_DFPWM_STATS")) {
