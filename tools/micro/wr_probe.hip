@@ -48,6 +48,43 @@ __global__ __launch_bounds__(256) void k_tile_rw(const short *in, float *out, un
     }
 }
 
+// F: E + the window goes through LDS (write 2 x 8 floats per lane, read 4 neighbours per output) — no arithmetic worth the name
+__global__ __launch_bounds__(256) void k_tile_rw_lds(const short *in, float *out, unsigned ntiles) {
+    __shared__ float sm[4][1040];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+    float *w = sm[wave];
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(in + (size_t)t * 1024);
+        const uint4 a = ip[lane], b = ip[64 + lane];
+        const unsigned ww[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) { w[16 * lane + 2 * e] = (float)(short)ww[e]; w[16 * lane + 2 * e + 1] = (float)(short)(ww[e] >> 16); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float *o = out + (size_t)t * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const unsigned q = (r * 59 + lane * 15 / 16) & 1023; o[r * 64 + lane] = w[q] + w[q + 1] + w[q + 2] + w[q + 3]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// G: E + ~20 dependent-free FMAs per output, no LDS
+__global__ __launch_bounds__(256) void k_tile_rw_valu(const short *in, float *out, unsigned ntiles, float k) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+    for (unsigned t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        const uint4 *ip = reinterpret_cast<const uint4 *>(in + (size_t)t * 1024);
+        const uint4 a = ip[lane], b = ip[64 + lane];
+        float *o = out + (size_t)t * 1024;
+        const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = (float)(short)(w[r >> 1] >> (16 * (r & 1))), u = v * k;
+#pragma unroll
+            for (int i = 0; i < 10; i++) { v = fmaf(v, k, u); u = fmaf(u, k, v); }
+            o[r * 64 + lane] = v + u;
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     const size_t nfl = (size_t)4096 * 480000;  // the headline's output
     float *out; short *in;
@@ -73,6 +110,10 @@ int main(int argc, char **argv) {
         run(nm, [&] { hipLaunchKernelGGL(k_fill_x4, dim3(grid), dim3(256), 0, 0, reinterpret_cast<float4 *>(out), nfl / 4); }, nfl * 4.0);
         snprintf(nm, sizeof nm, "E tile read s16 + write f32, %d blocks/CU", percu);
         run(nm, [&] { hipLaunchKernelGGL(k_tile_rw, dim3(grid), dim3(256), 0, 0, in, out, ntiles); }, nfl * 6.0);
+        snprintf(nm, sizeof nm, "F  = E + window through LDS, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_tile_rw_lds, dim3(grid), dim3(256), 0, 0, in, out, ntiles); }, nfl * 6.0);
+        snprintf(nm, sizeof nm, "G  = E + 20 FMAs per output, %d blocks/CU", percu);
+        run(nm, [&] { hipLaunchKernelGGL(k_tile_rw_valu, dim3(grid), dim3(256), 0, 0, in, out, ntiles, 0.999f); }, nfl * 6.0);
     }
     run("D tile dword, one tile per wave", [&] { hipLaunchKernelGGL(k_tile_dword_np, dim3((ntiles + 3) / 4), dim3(256), 0, 0, out, ntiles); }, nfl * 4.0);
     return 0;
