@@ -395,6 +395,9 @@ __global__ __launch_bounds__(64) void k_mdfpwm_decode(const unsigned char *src, 
     }
 }
 
+bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const std::vector<uint64_t> &h_off, const std::vector<uint64_t> &h_fed, uint64_t run,
+                                uint64_t stride, int mode, int C, signed char *out, const unsigned long long *d_out_off, const unsigned long long *d_out_stride,
+                                uint64_t lead, int *rc);
 struct MdHeader { uint64_t payload, length; };
 static int mdfpwm_header(const uint8_t *h, uint64_t nb, MdHeader *out, const char *badmsg) {
     if (nb < 7 || memcmp(h, "MDFPWM\3", 7) != 0) return fail(AUKIT_E_ARG, "%s", badmsg);
@@ -445,10 +448,21 @@ static int mdfpwm_rows(aukit_ctx *ctx, const aukit_batch *in, const char *badmsg
     }
     int rc = ctx->tmp_buf.ensure((size_t)tot + 64);
     if (rc) return rc;
-    if ((rc = upload_table(ctx, ctx->tmp_buf2, tab.data(), tab.size() * 8))) return rc;
+    if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;  // tmp_buf2 is the parallel decoder's scratch
     if (in->n) {
-        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->tmp_buf2.p);
+        const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
         if ((rc = ctx_begin_kernel(ctx))) return rc;
+        // decoderL / decoderR of a file are two independent decoders fed alternate 6000-byte blocks: 2n pseudo-streams for the
+        // chunk-parallel exact decoder (dfpwm_par.hip)
+        std::vector<uint64_t> p_off((size_t)in->n * 2), p_fed((size_t)in->n * 2);
+        for (uint32_t s = 0; s < in->n; s++)
+            for (int c = 0; c < 2; c++) { p_off[(size_t)s * 2 + c] = tab[s] + 6000ull * c; p_fed[(size_t)s * 2 + c] = row_len[(size_t)s * 2 + c] / 8; }
+        int prc = AUKIT_OK;
+        if (dfpwm_decode_parallel_feed(ctx, in->data(), p_off, p_fed, 6000, 12000, 0, 1, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t + 2 * (size_t)in->n, nullptr, 0,
+                                       &prc)) {
+            if (prc) return prc;
+            return ctx_end_kernel(ctx, "k_df_chunks", in->total() + tot);
+        }
         hipLaunchKernelGGL(k_mdfpwm_decode, dim3((2 * in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), t, t + in->n, in->n,
                            reinterpret_cast<signed char *>(ctx->tmp_buf.p), t + 2 * (size_t)in->n);
         AUKIT_HIP_CHECK(hipGetLastError());

@@ -28,34 +28,29 @@ AUKIT_DEV int sm_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? h
 AUKIT_DEV SatMap sm_then(const SatMap &f, const SatMap &g) { return SatMap{f.a + g.a, sm_clamp(f.lo + g.a, g.lo, g.hi), sm_clamp(f.hi + g.a, g.lo, g.hi)}; }
 AUKIT_DEV int sm_apply(const SatMap &f, int x) { return sm_clamp(x + f.a, f.lo, f.hi); }
 
-// bytes fed to the decoder by aukit.dfpwm's slice loop (Q10): slice k = source bytes [6000k, 6000k + min(6001, nb - 6000k))
-// (stream.dfpwm slices by 6000 * channels + 1 bytes advanced by 6000 * channels, :2449-2451: `adv` is the advance)
-AUKIT_DEV u64 dfp_fed_total(u64 nb, u64 adv) { return nb ? nb + (nb + adv - 1) / adv - 1 : 0; }
-AUKIT_DEV u64 dfp_src_index(u64 f, u64 nb, u64 adv) {  // fed byte f → source byte
-    const u64 nsl = (nb + adv - 1) / adv;
-    u64 k = f / (adv + 1);
-    if (k >= nsl) k = nsl - 1;
-    return f - k;  // adv k + (f - (adv + 1) k)
-}
+// The byte sequence a decoder is fed is described by (run, stride): fed byte f is source byte (f / run) * stride + f % run of the
+// (pseudo-)stream, and `fed` bytes are fed in all:
+//   aukit.dfpwm   slices of 6001 bytes advanced by 6000 (Q10: every 6001st byte is fed twice)   run 6001, stride 6000
+//   stream.dfpwm  slices of 6000 C + 1 bytes advanced by 6000 C (:2449-2451)                     run 6000 C + 1, stride 6000 C
+//   MDFPWM        decoderL / decoderR see alternate 6000-byte blocks (:1432-1436)                run 6000, stride 12000
+struct Feed { u64 run, stride; };
+AUKIT_DEV u64 dfp_src_index(u64 f, const Feed &fd) { const u64 k = f / fd.run; return k * fd.stride + (f - k * fd.run); }
 
-// Sequential reader of the fed byte sequence starting at fed index f0: source bytes are contiguous except that every slice of
-// 6001 fed bytes is followed by a step back of one source byte (its last byte is fed again as the first byte of the next slice).
-// Aligned dword loads, one per four bytes.
+// Sequential reader of the fed byte sequence starting at fed index f0.  Aligned dword loads, one per four bytes.
 struct FedReader {
     const unsigned char *p;
     u64 src;        // next source byte
-    unsigned left;  // fed bytes left in the current slice
-    unsigned adv1;  // fed bytes per full slice
+    unsigned left;  // fed bytes left in the current run
+    unsigned run;
+    long long skip; // stride - run: what to add to src at the end of a run (-1 for the overlapping slices)
     unsigned dw;    // aligned dword holding source byte `src` (valid when have)
     bool have;
 };
-AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 nb, u64 f0, u64 adv) {
+AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 f0, const Feed &fd) {
     FedReader r;
-    const u64 nsl = (nb + adv - 1) / adv;
-    u64 k = f0 / (adv + 1);
-    if (nsl && k >= nsl) k = nsl - 1;
-    const u64 base = adv * k, cnt = nb - base < adv + 1 ? nb - base : adv + 1, off = f0 - (adv + 1) * k;
-    r.p = p; r.src = base + off; r.left = (unsigned)(cnt - off); r.adv1 = (unsigned)(adv + 1); r.dw = 0; r.have = false;
+    const u64 k = f0 / fd.run, off = f0 - k * fd.run;
+    r.p = p; r.src = k * fd.stride + off; r.left = (unsigned)(fd.run - off); r.run = (unsigned)fd.run; r.skip = (long long)fd.stride - (long long)fd.run;
+    r.dw = 0; r.have = false;
     return r;
 }
 AUKIT_DEV unsigned fed_next(FedReader &r) {
@@ -63,19 +58,20 @@ AUKIT_DEV unsigned fed_next(FedReader &r) {
     if (!r.have || sh == 0) { r.dw = *reinterpret_cast<const unsigned *>((uintptr_t)(r.p + r.src) & ~(uintptr_t)3); r.have = true; }
     const unsigned byte = (r.dw >> (8 * sh)) & 0xFF;
     r.src++;
-    if (--r.left == 0) { r.src--; r.left = r.adv1; r.have = false; }  // next slice starts on the byte just read (the last slice simply ends)
+    if (--r.left == 0) { r.src = (u64)((long long)r.src + r.skip); r.left = r.run; r.have = false; }
     return byte;
 }
 
 struct DfParParams {
     const unsigned char *src;
-    const u64 *off;
+    const u64 *off;     // [n] first source byte of each (pseudo-)stream
+    const u64 *fed;     // [n] bytes fed to its decoder
+    Feed feed;
     unsigned n;
     unsigned nblk;      // 1 KiB blocks per stream (max over the batch)
     unsigned bpc;       // blocks per chunk
     unsigned nchunk;    // chunks per stream
     u64 W;              // block size in fed bytes
-    u64 adv;            // slice advance of the feeding loop (6000 for aukit.dfpwm, 6000 * channels for stream.dfpwm)
     u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
     SatMap *maps;       // [n][nblk]
     int *s_start;       // [n][nblk + 1] strength at block starts
@@ -108,12 +104,12 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     const unsigned blk = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)blk * P.n);
     if (blk >= P.nblk) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv);
+    const u64 fed = P.fed[s];
     const u64 f0 = (u64)blk * P.W, f1 = f0 + P.W < fed ? f0 + P.W : fed;
     SatMap f{0, -(1 << 28), 1 << 28};
     if (f0 < fed) {
-        int prev = f0 ? (p[dfp_src_index(f0 - 1, nb, P.adv)] >> 7) & 1 : 0;
-        FedReader rd = fed_open(p, nb, f0, P.adv);
+        int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
+        FedReader rd = fed_open(p, f0, P.feed);
         u64 b = f0;
         if (b == 0) {  // from the reset state (strength 0) the first step lands on 8 either way: do the stream's first byte bit by bit
             unsigned byte = fed_next(rd);
@@ -146,15 +142,16 @@ __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
 struct DfOut {  // where decoded samples go
     int mode, C;
     signed char *base;   // rows: channel 0 of the stream; mix: the stream's mono samples
-    u64 stride, adv, lead;
+    u64 stride, lead;
+    Feed feed;
     const signed char *lut;
 };
 
 // decode fed bytes [f0, f1) of one stream; EMIT = false: state only
 template <bool EMIT>
-AUKIT_DEV void dfp_run(const unsigned char *p, u64 nb, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
+AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
     u64 i = 8 * f0;  // index of the next decoded sample in the fed order
-    FedReader rd = fed_open(p, nb, f0, O.adv);
+    FedReader rd = fed_open(p, f0, O.feed);
     for (u64 b = f0; b < f1; b++) {
         unsigned byte = fed_next(rd);
         if (!EMIT) {
@@ -222,7 +219,7 @@ AUKIT_DEV DfOut dfp_out(const DfParParams &P, unsigned s, const signed char *lut
     O.mode = P.mode; O.C = P.C; O.lut = lut;
     O.base = P.out + P.out_off[s];
     O.stride = (P.mode == 0 && P.out_stride) ? P.out_stride[s] : 0;
-    O.adv = P.adv; O.lead = P.lead;
+    O.feed = P.feed; O.lead = P.lead;
     return O;
 }
 
@@ -236,7 +233,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
     if (c >= P.nchunk) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv);
+    const u64 fed = P.fed[s];
     const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
     int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6, *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
     if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
@@ -245,11 +242,11 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + (size_t)c * P.bpc - 1];
-        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, nb, P.adv)] >> 7) & 1 : 0;
-        dfp_run<false>(p, nb, fw, f0, d, O);
+        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, P.feed)] >> 7) & 1 : 0;
+        dfp_run<false>(p, fw, f0, d, O);
     }
     dfp_pack(d, ss);
-    dfp_run<true>(p, nb, f0, f1, d, O);
+    dfp_run<true>(p, f0, f1, d, O);
     dfp_pack(d, se);
 }
 
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 nb = P.off[s + 1] - P.off[s], fed = dfp_fed_total(nb, P.adv), CH = (u64)P.bpc * P.W;
+    const u64 fed = P.fed[s], CH = (u64)P.bpc * P.W;
     const DfOut O = dfp_out(P, s, nullptr);
     int truth[6];
     for (int i = 0; i < 6; i++) truth[i] = P.st_end[(size_t)s * P.nchunk * 6 + i];
@@ -276,14 +273,14 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
         if (P.mode == 1) {  // no table in this kernel: mix computed on the spot
             u64 i = 4 * f0;
             for (u64 b = f0; b < f1; b++) {
-                unsigned byte = p[dfp_src_index(b, nb, P.adv)];
+                unsigned byte = p[dfp_src_index(b, P.feed)];
                 for (int k = 0; k < 4; k++) {
                     const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
                     byte >>= 2;
                     O.base[i++] = (signed char)dfp_mix(l, r);
                 }
             }
-        } else dfp_run<true>(p, nb, f0, f1, d, O);
+        } else dfp_run<true>(p, f0, f1, d, O);
         dfp_pack(d, truth);
         for (int i = 0; i < 6; i++) se[i] = truth[i];
         redone++;
@@ -329,16 +326,14 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
     }
 }
 
-// host: plan + launch.  `out`: rows (mode 0, C channels, per-stream row offsets / strides as device arrays of n entries) or mono
-// mix (mode 1, per-stream element offsets).  Returns false (nothing launched) when the batch is better served one lane per stream.
-bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc,
-                           uint64_t adv, uint64_t lead) {
-    const uint32_t n = in->n;
+// host: plan + launch for `n` (pseudo-)streams given by their first source byte and fed byte count.  `out`: rows (mode 0, C
+// channels, per-stream row offsets / strides as device arrays) or mono mix (mode 1, per-stream element offsets).  Returns false
+// (nothing launched) when the batch is better served one lane per stream.
+bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const std::vector<uint64_t> &h_off, const std::vector<uint64_t> &h_fed, uint64_t run,
+                                uint64_t stride, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, uint64_t lead, int *rc) {
+    const uint32_t n = (uint32_t)h_off.size();
     uint64_t fed_max = 0;
-    for (uint32_t s = 0; s < n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s];
-        fed_max = std::max<uint64_t>(fed_max, nb ? nb + (nb + adv - 1) / adv - 1 : 0);
-    }
+    for (uint64_t f : h_fed) fed_max = std::max(fed_max, f);
     uint64_t W = n >= 4096 ? 1024 : 512;  // small batches: more, shorter chunks
     if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(2, strtoull(e, nullptr, 10) & ~1ull);
     const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
@@ -346,17 +341,21 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
     if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 6u);  // warm-up (1 block) <= 1/6 of a chunk
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
-    if (nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
-    // scratch: maps, strengths, states, stats
-    const size_t b_maps = (size_t)n * nblk * sizeof(SatMap), b_ss = (size_t)n * (nblk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
-    if ((*rc = ctx->tmp_buf2.ensure(b_maps + b_ss + 2 * b_st + 256))) return true;
+    if (n == 0 || nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
+    // scratch: stream table, maps, strengths, states, stats
+    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nblk * sizeof(SatMap), b_ss = (size_t)n * (nblk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
+    if ((*rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + 2 * b_st + 256))) return true;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+    if (hipMemcpyAsync(B, h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(B + (size_t)n * 8, h_fed.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "upload of the DFPWM stream table failed"); return true; }
     DfParParams P{};
-    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(in->d_off); P.n = n; P.nblk = nblk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
-    P.maps = reinterpret_cast<SatMap *>(B); P.s_start = reinterpret_cast<int *>(B + b_maps);
-    P.st_start = reinterpret_cast<int *>(B + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_maps + b_ss + b_st);
-    P.stats = reinterpret_cast<unsigned *>(B + b_maps + b_ss + 2 * b_st);
-    P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.adv = adv; P.lead = lead;
+    P.src = src; P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{run, stride};
+    P.n = n; P.nblk = nblk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+    P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
+    P.st_start = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss + b_st);
+    P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + 2 * b_st);
+    P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
@@ -371,6 +370,17 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
     }
     *rc = AUKIT_OK;
     return true;
+}
+
+// aukit.dfpwm / stream.dfpwm on a batch: overlapping slices advanced by `adv`
+bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc,
+                           uint64_t adv, uint64_t lead) {
+    std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + in->n), h_fed(in->n);
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        h_fed[s] = nb ? nb + (nb + adv - 1) / adv - 1 : 0;  // Σ min(adv + 1, nb - adv k)
+    }
+    return dfpwm_decode_parallel_feed(ctx, in->data(), h_off, h_fed, adv + 1, adv, mode, C, out, d_out_off, d_out_stride, lead, rc);
 }
 
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const u64 *d_in_off, const u64 *d_count, uint32_t n, unsigned char *out, const u64 *d_ooff) {

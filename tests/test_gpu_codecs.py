@@ -136,7 +136,7 @@ def test_stream_dfpwm(ctx, oracle, ch, mono, rate):
                 assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-13, (i, c)
 
 
-def test_mdfpwm(ctx, oracle):
+def test_mdfpwm(ctx, oracle, monkeypatch):
     B, N = _B(), _N()
     e1, e2 = _dfpwm_bytes(oracle, 48000 * 3, 4, 5), _dfpwm_bytes(oracle, 48000 * 3, 4, 6)
     md = oracle.gen_mdfpwm(e1, e2, b"artist", b"title", b"album")
@@ -145,6 +145,17 @@ def test_mdfpwm(ctx, oracle):
     ref = oracle.mdfpwm(md)
     for c in range(2):
         assert np.array_equal(got[0][c], ref.data[c])
+    # decoderL / decoderR go through the chunk-parallel exact decoder (run 6000, stride 12000): every schedule gives the same rows
+    for env in ({"AUKIT_DFPWM_BLOCK": "2", "AUKIT_DFPWM_CHUNKS": "500"}, {"AUKIT_DFPWM_BLOCK": "6000", "AUKIT_DFPWM_CHUNKS": "3"},
+                {"AUKIT_DFPWM_BLOCK": "1000", "AUKIT_DFPWM_CHUNKS": "7"}, {"AUKIT_DFPWM_SERIAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = B.decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), dtype=N.F64).download()
+        for k in env:
+            monkeypatch.delenv(k)
+        for i in range(2):
+            for c in range(2):
+                assert np.array_equal(alt[i][c], got[i][c]), (env, i, c)
     for mono in (False, True):
         out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), "linear", mono=mono, dtype=N.I8)
         o = oracle.stream_mdfpwm(md, mono)
