@@ -75,7 +75,7 @@ struct DfParParams {
     u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
     SatMap *maps;       // [n][nblk]
     int *s_start;       // [n][nblk + 1] strength at block starts
-    int *st_start, *st_end;  // [n][nchunk][6] decoder state after warm-up / at chunk end (charge, strength, prev, lpf, pcharge, pbit); strength -1 = no such chunk
+    int *st_start, *st_end;  // [n][nchunk][6] decoder state after warm-up / at chunk end (n, strength, pb, lpf, pn, -: dfpwm_dev.h); strength -1 = no such chunk
     // output
     int mode;           // 0: rows (C channels), 1: stereo → mono mix
     int C;
@@ -154,38 +154,38 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
     FedReader rd = fed_open(p, f0, O.feed);
     for (u64 b = f0; b < f1; b++) {
         unsigned byte = fed_next(rd);
+        const unsigned nb = ~byte;
         if (!EMIT) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { df_decode_bit(d, byte & 1); byte >>= 1; }
+            for (int k = 0; k < 8; k++) df_decode_b(d, df_pm1(nb, k));
         } else if (O.mode == 1) {  // stereo frames → one mono int8 each (4 per fed byte: one dword store)
+            const signed char *lutc = O.lut + 128 * 257;  // indexed by signed (l, r)
             unsigned packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
-                byte >>= 2;
-                packed |= ((unsigned)(unsigned char)O.lut[((l + 128) << 8) | (r + 128)]) << (8 * k);
+                const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+                packed |= ((unsigned)(unsigned char)lutc[l * 256 + r]) << (8 * k);
             }
             *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = packed;
             i += 8;
         } else if (O.C == 1 && O.lead) {  // row shifted by `lead` elements: byte stores
 #pragma unroll
-            for (int k = 0; k < 8; k++) { O.base[O.lead + i + k] = (signed char)df_decode_bit(d, byte & 1); byte >>= 1; }
+            for (int k = 0; k < 8; k++) O.base[O.lead + i + k] = (signed char)df_decode_b(d, df_pm1(nb, k));
             i += 8;
         } else if (O.C == 1) {
             unsigned lo = 0, hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { lo |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k); byte >>= 1; }
+            for (int k = 0; k < 4; k++) lo |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, k))) << (8 * k);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { hi |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k); byte >>= 1; }
+            for (int k = 0; k < 4; k++) hi |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 4 + k))) << (8 * k);
             *reinterpret_cast<uint2 *>(O.base + i) = make_uint2(lo, hi);
             i += 8;
         } else if (O.C == 2) {
             unsigned c0 = 0, c1 = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                c0 |= ((unsigned)(unsigned char)df_decode_bit(d, byte & 1)) << (8 * k);
-                c1 |= ((unsigned)(unsigned char)df_decode_bit(d, (byte >> 1) & 1)) << (8 * k);
-                byte >>= 2;
+                c0 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k))) << (8 * k);
+                c1 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k + 1))) << (8 * k);
             }
             *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = c0;
             *reinterpret_cast<unsigned *>(O.base + O.stride + (i >> 1)) = c1;
@@ -203,8 +203,8 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
     }
 }
 
-AUKIT_DEV void dfp_pack(const DfDec &d, int *o) { o[0] = d.p.charge; o[1] = d.p.strength; o[2] = d.p.prev; o[3] = d.lpf; o[4] = d.pcharge; o[5] = d.pbit; }
-AUKIT_DEV void dfp_unpack(const int *o, DfDec &d) { d.p.charge = o[0]; d.p.strength = o[1]; d.p.prev = o[2]; d.lpf = o[3]; d.pcharge = o[4]; d.pbit = o[5]; }
+AUKIT_DEV void dfp_pack(const DfDec &d, int *o) { o[0] = d.p.n; o[1] = d.p.strength; o[2] = d.p.pb; o[3] = d.lpf; o[4] = d.pn; o[5] = 0; }
+AUKIT_DEV void dfp_unpack(const int *o, DfDec &d) { d.p.n = o[0]; d.p.strength = o[1]; d.p.pb = o[2]; d.lpf = o[3]; d.pn = o[4]; }
 
 AUKIT_DEV int dfp_mix(int l, int r) {  // aukit.pcm table input :1082, Audio:mono :685-686, encodePCM :874 + the encoder's floor
     double acc = 0;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + (size_t)c * P.bpc - 1];
-        d.p.prev = d.pbit = fw ? (p[dfp_src_index(fw - 1, P.feed)] >> 7) & 1 : 0;
+        d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
         dfp_run<false>(p, fw, f0, d, O);
     }
     dfp_pack(d, ss);
@@ -302,13 +302,13 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
     for (u64 i = 0; i < L; i += 16) {
         uint4 nxt = cur;
         if (i + 16 < L) nxt = *reinterpret_cast<const uint4 *>(p + i + 16);  // in flight while `cur` is encoded
-        const unsigned words[4] = {cur.x, cur.y, cur.z, cur.w};
+        const unsigned words[4] = {cur.x ^ 0x80808080u, cur.y ^ 0x80808080u, cur.z ^ 0x80808080u, cur.w ^ 0x80808080u};  // u = v + 128
         if (i + 16 <= L) {  // two whole output bytes
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 unsigned byte = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) byte |= (unsigned)df_encode_sample(e, (int)(signed char)(words[2 * h + (k >> 2)] >> (8 * (k & 3)))) << k;
+                for (int k = 0; k < 8; k++) byte |= df_encode_u(e, (words[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xFF) & (1u << k);
                 o[w++] = (unsigned char)byte;
             }
         } else {
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
                 unsigned byte = 0;
                 for (int k = 0; k < 8; k++) {
                     const u64 idx = i + 8 * h + k;
-                    const int v = idx < L ? (int)(signed char)(words[2 * h + (k >> 2)] >> (8 * (k & 3))) : 0;  // the last byte is padded with samples of value 0
-                    byte |= (unsigned)df_encode_sample(e, v) << k;
+                    const unsigned u = idx < L ? (words[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xFF : 128u;  // the last byte is padded with samples of value 0
+                    byte |= df_encode_u(e, u) & (1u << k);
                 }
                 o[w++] = (unsigned char)byte;
             }
