@@ -36,30 +36,38 @@ AUKIT_DEV int sm_apply(const SatMap &f, int x) { return sm_clamp(x + f.a, f.lo, 
 struct Feed { u64 run, stride; };
 AUKIT_DEV u64 dfp_src_index(u64 f, const Feed &fd) { const u64 k = f / fd.run; return k * fd.stride + (f - k * fd.run); }
 
-// Sequential reader of the fed byte sequence starting at fed index f0.  Aligned dword loads, one per four bytes.
-struct FedReader {
-    const unsigned char *p;
-    u64 src;        // next source byte
-    unsigned left;  // fed bytes left in the current run
-    unsigned run;
-    long long skip; // stride - run: what to add to src at the end of a run (-1 for the overlapping slices)
-    unsigned dw;    // aligned dword holding source byte `src` (valid when have)
-    bool have;
-};
-AUKIT_DEV FedReader fed_open(const unsigned char *p, u64 f0, const Feed &fd) {
-    FedReader r;
-    const u64 k = f0 / fd.run, off = f0 - k * fd.run;
-    r.p = p; r.src = k * fd.stride + off; r.left = (unsigned)(fd.run - off); r.run = (unsigned)fd.run; r.skip = (long long)fd.stride - (long long)fd.run;
-    r.dw = 0; r.have = false;
-    return r;
-}
-AUKIT_DEV unsigned fed_next(FedReader &r) {
-    const unsigned sh = (unsigned)((uintptr_t)(r.p + r.src) & 3);
-    if (!r.have || sh == 0) { r.dw = *reinterpret_cast<const unsigned *>((uintptr_t)(r.p + r.src) & ~(uintptr_t)3); r.have = true; }
-    const unsigned byte = (r.dw >> (8 * sh)) & 0xFF;
-    r.src++;
-    if (--r.left == 0) { r.src = (u64)((long long)r.src + r.skip); r.left = r.run; r.have = false; }
-    return byte;
+// Calls fn(byte) for the fed bytes [f0, f1) in order.  Inside a run the source is contiguous: aligned 16-byte loads (the next one
+// in flight while the current one is consumed), single bytes up to the first aligned address and around the end of a run.
+template <typename F>
+AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn) {
+    if (f0 >= f1) return;
+    const u64 k0 = f0 / fd.run, o0 = f0 - k0 * fd.run;
+    const unsigned char *a = p + k0 * fd.stride + o0;  // next source byte
+    const unsigned run = (unsigned)fd.run;
+    const long long skip = (long long)fd.stride - (long long)fd.run;  // added at the end of a run (-1 for the overlapping slices)
+    unsigned left = (unsigned)(fd.run - o0);                          // fed bytes left in the current run
+    u64 rem = f1 - f0;
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    bool have = false;
+    while (rem) {
+        if (((uintptr_t)a & 15) == 0 && left >= 16 && rem >= 16) {
+            const uint4 q = have ? pre : *reinterpret_cast<const uint4 *>(a);
+            have = left >= 32 && rem >= 32;
+            if (have) pre = *reinterpret_cast<const uint4 *>(a + 16);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll 1
+            for (int w = 0; w < 4; w++) {
+                const unsigned word = w4[w];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fn((word >> (8 * j)) & 0xFF);
+            }
+            a += 16; left -= 16; rem -= 16;
+        } else {
+            fn((unsigned)*a);
+            a++; left--; rem--;
+        }
+        if (left == 0) { a += skip; left = run; have = false; }
+    }
 }
 
 struct DfParParams {
@@ -109,10 +117,9 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     SatMap f{0, -(1 << 28), 1 << 28};
     if (f0 < fed) {
         int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
-        FedReader rd = fed_open(p, f0, P.feed);
         u64 b = f0;
         if (b == 0) {  // from the reset state (strength 0) the first step lands on 8 either way: do the stream's first byte bit by bit
-            unsigned byte = fed_next(rd);
+            unsigned byte = p[0];
             for (int k = 0; k < 8; k++) {
                 const int bit = byte & 1;
                 byte >>= 1;
@@ -121,11 +128,10 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             }
             b = 1;
         }
-        for (; b < f1; b++) {
-            const unsigned byte = fed_next(rd);
+        fed_for_each(p, b, f1, P.feed, [&](unsigned byte) {
             f = sm_then(f, bm[(prev << 8) | byte]);
             prev = byte >> 7;
-        }
+        });
     }
     P.maps[(size_t)s * P.nblk + blk] = f;
 }
@@ -151,9 +157,7 @@ struct DfOut {  // where decoded samples go
 template <bool EMIT>
 AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
     u64 i = 8 * f0;  // index of the next decoded sample in the fed order
-    FedReader rd = fed_open(p, f0, O.feed);
-    for (u64 b = f0; b < f1; b++) {
-        unsigned byte = fed_next(rd);
+    fed_for_each(p, f0, f1, O.feed, [&](unsigned byte) {
         const unsigned nb = ~byte;
         if (!EMIT) {
 #pragma unroll
@@ -200,7 +204,7 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
                 i++;
             }
         }
-    }
+    });
 }
 
 AUKIT_DEV void dfp_pack(const DfDec &d, int *o) { o[0] = d.p.n; o[1] = d.p.strength; o[2] = d.p.pb; o[3] = d.lpf; o[4] = d.pn; o[5] = 0; }
@@ -226,10 +230,10 @@ AUKIT_DEV DfOut dfp_out(const DfParParams &P, unsigned s, const signed char *lut
 __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     extern __shared__ signed char lut[];  // 64 KiB in mix mode only (rows mode runs at full occupancy)
     if (P.mode == 1) {
-        for (int i = threadIdx.x; i < 65536; i += 256) lut[i] = (signed char)dfp_mix((i >> 8) - 128, (i & 255) - 128);
+        for (int i = threadIdx.x; i < 65536; i += blockDim.x) lut[i] = (signed char)dfp_mix((i >> 8) - 128, (i & 255) - 128);
         __syncthreads();
     }
-    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
     if (c >= P.nchunk) return;
     const unsigned char *p = P.src + P.off[s];
@@ -337,7 +341,8 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     uint64_t W = n >= 4096 ? 1024 : 512;  // small batches: more, shorter chunks
     if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(2, strtoull(e, nullptr, 10) & ~1ull);
     const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
-    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 1024 / std::max<uint32_t>(n, 1));  // chunks per stream for ~1024 lanes per CU
+    // chunks per stream for one full round of lanes: 1024 per CU, 512 in mix mode (two workgroups per CU next to their 64 KiB tables)
+    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * (mode == 1 ? 512 : 1024) / std::max<uint32_t>(n, 1));
     if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 6u);  // warm-up (1 block) <= 1/6 of a chunk
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
@@ -359,7 +364,8 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
-    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), mode == 1 ? 65536 : 0, ctx->stream, P);
+    const unsigned cb = 256;  // (1024 lanes sharing one table, 8 waves per SIMD instead of 2: 7 % slower — the kernel is issue-bound)
+    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + cb - 1) / cb)), dim3(cb), mode == 1 ? 65536 : 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
     if (getenv("AUKIT_DFPWM_STATS")) {
