@@ -10,6 +10,12 @@
 // that are mathematically integers, where the reference's own `x % 1 == 0` test decides between copy and interpolation — the
 // lane runs the reference-order code (resample_dev.h) on the same LDS window.  Bit-exact either way; the tests compare every
 // output with the oracle and with the k_resample path.
+//
+// In front of that sits the same test in f32 (fp64 instructions issue at half rate): G.711 samples are multiples of 1/64 below
+// 126 in magnitude, so the spline coefficients (multiples of 1/128 below 1400) are exact in f32 and the three Horner FMAs round
+// at magnitudes below 2048 (half an ulp = 6.1e-5 each); with the position fraction good to one ulp (4.5e-5 after the slope of
+// < 750) the f32 value is within 2.3e-4 of the exact one and is taken when it lies more than 1e-3 away from an integer.  About
+// one output in 500 goes on to the fp64 test.
 #include <algorithm>
 #include "fast_wave_dev.h"
 #include "resample_dev.h"
@@ -28,8 +34,12 @@ AUKIT_DEV double g711_f64b(unsigned byte, int ulaw, double scale) {  // same int
 
 AUKIT_DEV void store_floor(signed char *p, double v) { *p = (signed char)(int)v; }
 AUKIT_DEV void store_floor(double *p, double v) { *p = v; }
+AUKIT_DEV void store_floor(signed char *p, float v) { *p = (signed char)(int)v; }
+AUKIT_DEV void store_floor(double *p, float v) { *p = (double)v; }
 
-template <int INTERP, int NV, typename OUT_T>
+// DW: the window is at most 16 vectors (up-sampling by > ~4.6, e.g. 8 kHz -> 48 kHz): every lane stages one dword of it instead
+// of the first few lanes staging 16 bytes each
+template <int INTERP, bool DW, typename OUT_T>
 __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F) {
     extern __shared__ double smd[];
     constexpr int SRC = SRC_G711_MONO;
@@ -39,26 +49,49 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *const sm = smd + wave * (unsigned)F.cap;
+    float *const smf = reinterpret_cast<float *>(smd + 4 * (unsigned)F.cap) + wave * (unsigned)F.cap;  // the same window in f32 (exact)
     const unsigned nwaves = gridDim.x * 4u;
     const double inv_b = 1.0 / (double)F.b;
+    const float bf = (float)F.b, inv_bf = 1.0f / bf;
     const bool int_ratio = F.a == 1;  // ratio = b: (i-1)/ratio is an integer exactly when b divides i-1, in floating point too
     OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
 
     unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
     if (t >= P.n_tiles) return;
+    constexpr int NV = 1;
     uint4 pre[NV];
+    unsigned pre1 = 0;
+    auto load_window = [&](const WaveTile &w) {
+        if constexpr (DW) {
+            const unsigned char *vb = w.al + 16 * (size_t)(lane >> 2);  // same rule as issue_loads: a vector that straddles the allocation reads as zero
+            pre1 = 0;
+            if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *reinterpret_cast<const unsigned *>(w.al + 4 * (size_t)lane);
+        } else issue_loads<NV>(P, w, lane, pre);
+    };
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);
-    issue_loads<NV>(P, cur, lane, pre);
+    load_window(cur);
     for (;;) {
         // ---- window → LDS as the reference's doubles (m / 0x40, :2891); slots below / above the table replicate its ends,
         // which is what the nil fall-backs of interpolate.linear / cubic read (:259, :264)
+        if constexpr (DW) {
+            if ((lane >> 2) < cur.nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double d = g711_f64b((pre1 >> (8 * e)) & 0xFF, P.ulaw, P.g711_scale);
+                    sm[4 * lane + e] = d; smf[4 * lane + e] = (float)d;
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int v = lane + 64 * i;
             if (v >= cur.nvec) continue;
             const unsigned ww[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
 #pragma unroll
-            for (int e = 0; e < 16; e++) sm[16 * v + e] = g711_f64b((ww[e >> 2] >> (8 * (e & 3))) & 0xFF, P.ulaw, P.g711_scale);
+            for (int e = 0; e < 16; e++) {
+                const double d = g711_f64b((ww[e >> 2] >> (8 * (e & 3))) & 0xFF, P.ulaw, P.g711_scale);
+                sm[16 * v + e] = d; smf[16 * v + e] = (float)d;
+            }
         }
         {
             const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
@@ -66,18 +99,18 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
                 for (int idx = lane; idx < cur.nvec * 16; idx += 64) {
                     const unsigned char *q = cur.al + idx;
                     const unsigned char *vb = cur.al + 16 * (size_t)(idx / 16);
-                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q < P.safe_hi) ? g711_f64b(*q, P.ulaw, P.g711_scale) : 0.0;
+                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) { sm[idx] = (q >= P.safe_lo && q < P.safe_hi) ? g711_f64b(*q, P.ulaw, P.g711_scale) : 0.0; smf[idx] = (float)sm[idx]; }
                 }
             }
             const int k_hi = cur.k_lo + cur.n_stage - 1;
             if (cur.k_lo < cur.w_lo) {
                 const double e_lo = g711_f64b(cur.base[cur.w_lo], P.ulaw, P.g711_scale);
-                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) sm[cur.head + idx] = e_lo;
+                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) { sm[cur.head + idx] = e_lo; smf[cur.head + idx] = (float)e_lo; }
             }
             if (k_hi > cur.w_hi) {
                 const double e_hi = g711_f64b(cur.base[cur.w_hi], P.ulaw, P.g711_scale);
                 const int first = cur.w_hi + 1 - cur.k_lo;
-                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) sm[cur.head + first + idx] = e_hi;
+                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) { sm[cur.head + first + idx] = e_hi; smf[cur.head + first + idx] = (float)e_hi; }
             }
         }
         // the tile's segment, for the reference-order fallback
@@ -90,17 +123,48 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
         WaveTile nxt = cur;
         if (more) {  // wave-uniform
             nxt = describe<SRC, HL, HR>(P, F, tn);
-            issue_loads<NV>(P, nxt, lane, pre);  // in flight while this tile is interpolated
+            load_window(nxt);  // in flight while this tile is interpolated
         }
         const double *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
         const double *tab_klo = sm + cur.head;   // slot of table index cur.k_lo
+        const float *tabf = smf + cur.head + HL;
         OUT_T *orow = out + sg.out_off + (size_t)tin * WT;
-        for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+        // (q, rem) of the lane's first output by the verified reciprocal, then advanced by additions: 64 outputs further is
+        // 64 a = dq64 b + dr64 input positions further
+        unsigned q, rem;
+        {
+            const unsigned n0 = cur.r0 + (unsigned)lane * F.a;
+            q = __umulhi(n0, F.magic);
+            rem = n0 - q * F.b;
+        }
+        for (unsigned rb = 0; rb < cur.cnt; rb += 64, q += F.dq64, rem += F.dr64) {
             const unsigned j = rb + lane;
             if (j >= cur.cnt) break;
-            const unsigned n = cur.r0 + j * F.a;
-            const unsigned q = __umulhi(n, F.magic);
-            const unsigned rem = n - q * F.b;
+            if (rem >= F.b) { rem -= F.b; q++; }
+            if (rem == 0 && int_ratio) {  // the reference's copy branch; exact in f32
+                store_floor(orow + j, fminf(fmaxf(floorf(tabf[q]), -128.0f), 127.0f));
+                continue;
+            }
+            if (rem != 0) {  // f32 first
+                const float *tf = tabf + q;
+                const float remf = (float)rem;
+                float fx = remf * inv_bf;
+                fx = __builtin_fmaf(__builtin_fmaf(-fx, bf, remf), inv_bf, fx);  // rem / b to one ulp
+                const float p1 = tf[0];
+                float w;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    w = __builtin_fmaf(tf[1] - p1, fx, p1);
+                } else {
+                    const float p0 = tf[-1], p2 = tf[1], p3 = tf[2];
+                    const float c3 = __builtin_fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
+                    const float c2 = __builtin_fmaf(-2.5f, p1, p0) + __builtin_fmaf(2.0f, p2, -0.5f * p3);
+                    const float c1 = 0.5f * (p2 - p0);
+                    w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, p1);
+                }
+                const float fl = floorf(w), fr = w - fl;
+                if (fr > 1e-3f && fr < 1 - 1e-3f) { store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f)); continue; }  // :2909
+            }
+            // the same in fp64, margin 1e-6
             const double p1 = tab[q];
             double v = p1;
             bool ok = rem != 0 || int_ratio;
@@ -149,18 +213,21 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     F.wd = (unsigned)(((unsigned long long)WT * F.a) % F.b);
     if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return false;
     if (((double)F.b + (double)WT * (double)F.a) * (double)F.b >= 4294967296.0) return false;
-    F.cap = 64 * 16;  // doubles per wave window
-    F.dq64 = F.dr64 = 0;
+    const bool dw = win + 2 * 16 <= 16 * 16;
+    F.cap = dw ? 16 * 16 : 64 * 16;  // window slots per wave (the kernel is latency-bound: a small window keeps 8 workgroups per CU resident)
+    F.dq64 = (unsigned)((64ull * F.a) / F.b);
+    F.dr64 = (unsigned)((64ull * F.a) % F.b);
     P.ratio = 48000 / old_rate;
     P.rcp = 1.0 / P.ratio;
     P.exact_rcp = exact_div_verified(ctx, P.ratio, max_out + 2) ? 1 : 0;
     P.halo_l = hl; P.halo_r = hr; P.sinc_w = ctx->sinc_w;
     if ((*rc = plan_tiles_sized(ctx, segs, WT, P))) return true;
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
-    const size_t lds = (size_t)F.cap * 8 * 4;
+    const size_t lds = (size_t)F.cap * (8 + 4) * 4;  // per wave: the window as doubles and as floats
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 8);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-#define AUKIT_FW(I, T) hipLaunchKernelGGL((k_floor_wave_g711<I, 1, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F)
+#define AUKIT_FW(I, T) do { if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F); \
+                            else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F); } while (0)
     if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, signed char); else AUKIT_FW(AUKIT_INTERP_CUBIC, signed char); }
     else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, double); else AUKIT_FW(AUKIT_INTERP_CUBIC, double); }
 #undef AUKIT_FW
