@@ -10,6 +10,22 @@
 
 namespace aukit {
 
+// interp_qr of fast_wave_dev.h without Audio:resample's clamp (the stream's interpolated sample is not clamped, Q2)
+template <int INTERP>
+AUKIT_DEV float interp_qr_raw(const FastParams &F, const float *tab, unsigned q, unsigned rem) {
+    const float fx = (float)rem * F.inv_b;
+    const float p1 = tab[q];
+    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+        return fmaf(tab[q + 1] - p1, fx, p1);
+    } else {
+        const float p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
+        const float c3 = fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
+        const float c2 = fmaf(-0.5f, p3, fmaf(2.0f, p2, fmaf(-2.5f, p1, p0)));
+        const float c1 = 0.5f * (p2 - p0);
+        return fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
+    }
+}
+
 template <int INTERP, int NV>
 __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P, const FastParams F) {
     extern __shared__ float smf[];
@@ -40,6 +56,25 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
         float *orow = cur.orow;
         float carry = 0.f;  // the raw sample before the tile's first output: position n = r0 - a, one table step back when that is negative
         if (!first) carry = cur.r0 >= F.a ? interp_row<INTERP, false>(F, tab, cur.r0 - F.a) : interp_row<INTERP, false>(F, tab - 1, cur.r0 + F.b - F.a);
+        if (cur.cnt == (unsigned)WT) {  // whole tile: (q, rem) advanced by additions, as in k_fast_wave
+            const unsigned n0 = cur.r0 + (unsigned)lane * F.a;
+            unsigned q = __umulhi(n0, F.magic);
+            unsigned rem = n0 - q * F.b;
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) {
+                const float s = interp_qr_raw<INTERP>(F, tab, q, rem);
+                float prev = __shfl_up(s, 1);
+                if (lane == 0) prev = carry;
+                carry = __shfl(s, 63);
+                const float ns = fmaf(alpha, s - prev, prev);                                                   // :2401
+                orow[r * 64 + lane] = __builtin_amdgcn_fmed3f(ns * (ns < 0.f ? 128.f : 127.f), -128.f, 127.f);  // :2402
+                rem += F.dr64;
+                q += F.dq64;
+                const bool wrap = rem >= F.b;
+                rem -= wrap ? F.b : 0u;
+                q += wrap ? 1u : 0u;
+            }
+        } else
         for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
             const unsigned j = rb + lane;
             const float s = interp_row<INTERP, false>(F, tab, cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a);
