@@ -419,6 +419,7 @@ struct ImaStreamParams {
     int fast;
     unsigned fa, fb, fmagic;
     double inv_fb;
+    unsigned fdq, fdr;                   // 64 fa = fdq fb + fdr
 };
 
 template <int INTERP, typename OUT_T>
@@ -469,10 +470,12 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
                 // positions and FMA Horner form, keep the result unless it is within 1e-6 of an integer (then, and at the table's
                 // ends where the nil fall-backs apply, run the reference-order code).  Bit-exact: see floor_wave.hip for the margin.
                 const int nbi = (int)nb;
-                for (unsigned j = lane; j < newlen; j += 64) {
-                    const unsigned n = j * P.fa;
-                    const unsigned q0 = __umulhi(n, P.fmagic);  // floor(n / fb), exact: (newlen * fa + fb) * fb < 2^32
-                    const unsigned rem = n - q0 * P.fb;
+                // floor(j fa / fb) and the remainder: by the reciprocal for the lane's first output (exact: (newlen * fa + fb) * fb
+                // < 2^32), then advanced by additions — 64 outputs further is 64 fa = dq fb + dr
+                unsigned q0 = __umulhi((unsigned)lane * P.fa, P.fmagic);
+                unsigned rem = (unsigned)lane * P.fa - q0 * P.fb;
+                for (unsigned j = lane; j < newlen; j += 64, q0 += P.fdq, rem += P.fdr) {
+                    if (rem >= P.fb) { rem -= P.fb; q0++; }
                     const int k = (int)q0 + 1;                  // floor(x)
                     double v = 0;
                     bool ok = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi);  // one spare tap on the left (x may round below an integer)
@@ -692,6 +695,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             const unsigned long long fa = (unsigned long long)d->sample_rate / x, fb = 48000 / x;  // x - 1 = (i - 1) / ratio = (i - 1) * fa / fb
             if (fb >= 2 && ((double)newlen_full * (double)fa + (double)fb) * (double)fb < 4294967296.0) {
                 P.fast = 1; P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb); P.inv_fb = 1.0 / (double)fb;
+                P.fdq = (unsigned)((64ull * fa) / fb); P.fdr = (unsigned)((64ull * fa) % fb);
             }
         }
         unsigned nwv = 4;

@@ -302,31 +302,41 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
     unsigned char *o = out + ooff[s];
     DfEnc e{};
     u64 w = 0;
-    uint4 cur = L ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
-    for (u64 i = 0; i < L; i += 16) {
-        uint4 nxt = cur;
-        if (i + 16 < L) nxt = *reinterpret_cast<const uint4 *>(p + i + 16);  // in flight while `cur` is encoded
-        const unsigned words[4] = {cur.x ^ 0x80808080u, cur.y ^ 0x80808080u, cur.z ^ 0x80808080u, cur.w ^ 0x80808080u};  // u = v + 128
-        if (i + 16 <= L) {  // two whole output bytes
+    // 64 samples per round, the next 64 in flight meanwhile: a lone wave per SIMD has nothing else to hide the load latency with,
+    // and 16 samples are only ~900 cycles of work
+    uint4 cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = 16u * k < L ? *reinterpret_cast<const uint4 *>(p + 16 * k) : make_uint4(0, 0, 0, 0);
+    u64 i = 0;
+    for (; i + 64 <= L; i += 64) {
+        uint4 nxt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = i + 64 + 16 * k < L ? *reinterpret_cast<const uint4 *>(p + i + 64 + 16 * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned words[4] = {cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u, cur[k].z ^ 0x80808080u, cur[k].w ^ 0x80808080u};  // u = v + 128
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 unsigned byte = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) byte |= df_encode_u(e, (words[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xFF) & (1u << k);
-                o[w++] = (unsigned char)byte;
-            }
-        } else {
-            for (int h = 0; h < 2 && i + 8 * h < L; h++) {
-                unsigned byte = 0;
-                for (int k = 0; k < 8; k++) {
-                    const u64 idx = i + 8 * h + k;
-                    const unsigned u = idx < L ? (words[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xFF : 128u;  // the last byte is padded with samples of value 0
-                    byte |= df_encode_u(e, u) & (1u << k);
-                }
+                for (int b = 0; b < 8; b++) byte |= df_encode_u(e, (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF) & (1u << b);
                 o[w++] = (unsigned char)byte;
             }
         }
-        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+    for (int k = 0; k < 4 && i < L; k++, i += 16) {  // the last < 64 samples
+        const unsigned words[4] = {cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u, cur[k].z ^ 0x80808080u, cur[k].w ^ 0x80808080u};
+        for (int h = 0; h < 2 && i + 8 * h < L; h++) {
+            unsigned byte = 0;
+            for (int b = 0; b < 8; b++) {
+                const u64 idx = i + 8 * h + b;
+                const unsigned u = idx < L ? (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF : 128u;  // the last byte is padded with samples of value 0
+                byte |= df_encode_u(e, u) & (1u << b);
+            }
+            o[w++] = (unsigned char)byte;
+        }
     }
 }
 
