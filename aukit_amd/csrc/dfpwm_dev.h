@@ -12,7 +12,8 @@
 //     z = (bit == prev) ? 1023 : 0;  if strength ~= z then strength += (bit == prev) ? 1 : -1;  strength = max(strength, 8)
 // and both forms used here are algebraically the same integers:
 //   * the nudge: with diff = target - charge, step = floor((strength * diff + 512) / 1024) has the sign of diff (or is 0) and
-//     |step| <= |diff| for strength <= 1023, so "step, or ±1 if step is 0 and diff is not" = median(step, clamp(diff, -1, 1), diff)
+//     |step| <= |diff| for strength <= 1023, so "step, or ±1 if step is 0 and diff is not" = median(step, ±1, diff) with the
+//     ±1 of the bit (diff = 0 gives step = 0 and median(0, ±1, 0) = 0)
 //   * the strength: for strength >= 8, and for the reset value 0, the last line is clamp(strength ± 1, 8, 1023), and with bits
 //     kept as b = ±1 the ± 1 is b * prev_b
 //   * the decoder keeps n = -(2 charge + 1): 2 (target - charge) = 255 b + n, floor((s diff + 512) / 1024) =
@@ -23,11 +24,6 @@
 namespace aukit {
 
 AUKIT_DEV int df_med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }  // one v_med3_i32
-AUKIT_DEV int df_sign(int x) {  // clamp(x, -1, 1); as an instruction, or the compiler rewrites it into two compares and two selects on x's operands
-    int r;
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
-    return r;
-}
 
 // ---- decoder side: bits are given
 struct DfPred { int n = -1, strength = 0, pb = -1; };  // charge 0, strength 0, previous bit 0
@@ -37,7 +33,7 @@ AUKIT_DEV void df_set(DfPred &p, int charge, int strength, int prev_bit) { p.n =
 AUKIT_DEV int df_predict(DfPred &p, int b) {
     const int diff2 = __mul24(b, 255) + p.n;
     int step = (__mul24(p.strength, diff2) + 1024) >> 11;  // |strength * diff2| < 2^20: the 24-bit multiply is exact and full-rate
-    step = df_med3(step, df_sign(diff2), diff2);
+    step = df_med3(step, b, diff2);
     asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(p.n) : "v"(step), "v"(p.n));  // n -= 2 step in one instruction (the compiler makes it a shift and a subtract)
     p.strength = df_med3(__mul24(b, p.pb) + p.strength, 8, 1023);
     p.pb = b;
@@ -52,7 +48,12 @@ AUKIT_DEV int df_decode_b(DfDec &d, int b) {  // b = ±1
     const int n = df_predict(d.p, b);
     const int q = (n + (same ? n : pn) + 3) >> 2;  // = -(anti-jerked charge: the mean with the previous charge when the bit flipped)
     d.pn = n;
-    d.lpf += (__mul24(q + d.lpf, -140) + 0x80) >> 8;  // lpf += floor(((aj - lpf) * 140 + 128) / 256)
+    // lpf += floor(((aj - lpf) * 140 + 128) / 256) with the lpf moved inside the floor: two multiply-adds and a shift.  The 128
+    // sits in a VGPR: gfx9 VOP3 takes one scalar operand and no literal, and left to itself the compiler emits mul, mul, add3.
+    int t, u;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(q), "s"(-140), "v"(128));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(u) : "v"(d.lpf), "s"(116), "v"(t));
+    d.lpf = u >> 8;
     return d.lpf;
 }
 AUKIT_DEV int df_decode_bit(DfDec &d, int bit) { return df_decode_b(d, 2 * bit - 1); }
@@ -66,7 +67,7 @@ AUKIT_DEV unsigned df_encode_u(DfEnc &e, unsigned u) {
     const int target = bit ? 255 : 0, b = bit ? 1 : -1;
     const int diff = target - e.cu;
     int step = (__mul24(e.strength, diff) + 512) >> 10;
-    step = df_med3(step, df_sign(diff), diff);
+    step = df_med3(step, b, diff);
     e.cu += step;
     e.strength = df_med3(__mul24(b, e.pb) + e.strength, 8, 1023);
     e.pb = b;
