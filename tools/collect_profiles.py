@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile_all.sh left in gpurun_out/ into profiles/ (r1_<tag>_* -> r<NN>_<tag>_*), and rebuild
+profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes (first dispatch of the dominant kernel of each tag).
+
+usage: python tools/collect_profiles.py [round=01]
+"""
+import csv, glob, json, os, shutil, sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
+n = 0
+for f in sorted(glob.glob(os.path.join(src, "r1_*.csv"))):
+    shutil.copy(f, os.path.join(dst, "r%s_%s" % (rnd, os.path.basename(f)[3:])))
+    n += 1
+shutil.copy(os.path.join(root, "gpurun_out", "bench_lines.jsonl"), os.path.join(dst, "r%s_bench_lines.jsonl" % rnd))
+
+# kernel name as bench.py reports it (ctx.last_kernel) -> (tag, substring of the rocprofv3 kernel name)
+DOMINANT = [("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<"),
+            ("k_fast_wave_stream<pcm_s16le_mono,cubic,nv2,stream_pcm>", "pcmstream", "k_fast_wave_stream<"),
+            ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<"),
+            ("k_ima_stream", "ima", "k_ima_stream<")]
+
+
+def first(tag, which, pat, col):
+    with open(os.path.join(dst, "r%s_%s_pmc_%s.csv" % (rnd, tag, which))) as fh:
+        for row in csv.DictReader(fh):
+            if pat in row["kernel"] and row.get(col):
+                return float(row[col])
+    return None
+
+
+entries = []
+for kernel, tag, pat in DOMINANT:
+    try:
+        fk, wk = first(tag, "fetch", pat, "FETCH_SIZE"), first(tag, "write", pat, "WRITE_SIZE")
+    except OSError:
+        continue
+    if fk is None or wk is None:
+        continue
+    entries.append({"kernel": kernel, "streams": 4096, "seconds": 10.0, "tag": tag, "fetch_kb": fk, "write_kb": wk,
+                    "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)})
+note = ("HBM bytes per launch from rocprofv3 PMC passes of `python3 bench.py --steps 5 --warmup 1 --cpu-streams 0 [--workload W]` "
+        "(tools/profile_bench.sh, separate passes for FETCH_SIZE and WRITE_SIZE): FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports wide "
+        "coalesced reads as 64-B requests: MI355X_MICROARCH.md, HBM/rocprofv3 section) + WRITE_SIZE [KB] x 1024. Source rows: "
+        "profiles/r%s_<tag>_pmc_fetch.csv / _pmc_write.csv; rebuilt by tools/collect_profiles.py." % rnd)
+with open(os.path.join(dst, "traffic.json"), "w") as fh:
+    json.dump({"note": note, "entries": entries}, fh, indent=1)
+print("copied %d csv files, %d traffic entries" % (n, len(entries)))
+for e in entries:
+    print("  %-60s %.3f GB" % (e["kernel"], e["hbm_bytes_per_launch"] / 1e9))
