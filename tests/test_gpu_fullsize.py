@@ -6,6 +6,8 @@
   * config 2 (4096 × µ-law 8 kHz → cubic): same construction.
   * config 3 (4096 × 220 IMA blocks → stream.adpcm cubic): same, bit-exact vs oracle.
   * config 4 (16384 × 120 000 B DFPWM stereo → mono → DFPWM): encode→decode round trip property + class identity + oracle bytes.
+  * config 5 (2048 × FLAC 44.1 kHz stereo 10 s → cubic → highpass → normalize → mono): losslessness of the decode (every decoded
+    row equals the PCM that was encoded, exactly), class identity of the pipeline output, one class against the oracle pipeline.
 Sizes are the BASELINE ones unless AUKIT_FULLSIZE_SCALE (default 1.0) shrinks the stream count.
 """
 import os
@@ -117,3 +119,31 @@ def test_config_4_full_batch(ctx, oracle):
     a = oracle.mono(oracle.dfpwm(base[0], 2, 48000)).data[0]
     back = oracle.DfpwmDecoder()(got[0]).astype(np.float64)[:len(a)] / 127  # plain decoder: no 6001-byte slicing, so no new duplicates
     assert np.corrcoef(back, a)[0, 1] > 0.8
+
+
+def test_config_5_full_batch(ctx, oracle):
+    B, N = _B(), _N()
+    k5 = 4
+    n = max(k5, int(2048 * SCALE) // k5 * k5)
+    pcm = [np.stack([pcm16(441000, 44100, 5, 2 * i), pcm16(441000, 44100, 5, 2 * i + 1)], 1).astype(np.int64) for i in range(k5)]
+    base = [oracle.gen_flac(p.ravel(), 2, 16, 44100, 4096) for p in pcm]
+    bt = B.Batch.upload(ctx, [base[i % k5] for i in range(n)])
+    desc = B.make_desc(N.CODEC_FLAC)
+    # the decode alone is lossless: sample / 2^16 (Q14) is exact in f32 for 16-bit audio
+    dec = B.decode(ctx, bt, desc, dtype=N.F32)
+    lens, off, stride = dec.layout()
+    assert np.all(lens == 441000)
+    import ctypes as C
+    raw = np.zeros(dec.info()["total_elems"], dtype=np.float32)
+    N.check(N.lib().aukit_audio_download_raw(ctx._h, dec._h, raw.ctypes.data_as(C.c_void_p)))
+    for s_i in list(range(0, n, max(1, n // 64))) + [n - 1]:  # a spread of streams, both channels, every sample
+        for c in range(2):
+            row = raw[int(off[s_i]) + c * int(stride[s_i]): int(off[s_i]) + c * int(stride[s_i]) + 441000]
+            assert np.array_equal(row, (pcm[s_i % k5][:, c] / 65536.0).astype(np.float32)), (s_i, c)
+    del raw, dec
+    a = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+    B.effect(ctx, a, "highpass", 20.0)
+    B.effect(ctx, a, "normalize", 0.8)
+    rows = _row_classes(B.mono(ctx, a), n, 480000, k5)
+    ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(base[1]), 48000, oracle.CUBIC), 20.0), 0.8))
+    assert rms(rows[1].astype(np.float64), ref.data[0]) <= 1e-6
