@@ -139,54 +139,57 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
         }
         for (unsigned rb = 0; rb < cur.cnt; rb += 64, q += F.dq64, rem += F.dr64) {
             const unsigned j = rb + lane;
-            if (j >= cur.cnt) break;
-            if (rem >= F.b) { rem -= F.b; q++; }
-            if (rem == 0 && int_ratio) {  // the reference's copy branch; exact in f32
-                store_floor(orow + j, fminf(fmaxf(floorf(tabf[q]), -128.0f), 127.0f));
-                continue;
+            const bool active = j < cur.cnt;  // lanes past the end of a short tile compute on (their taps are still inside the window table)
+            const bool wrap = rem >= F.b;
+            rem -= wrap ? F.b : 0u;
+            q += wrap ? 1u : 0u;
+            // f32 first, straight-line for the whole wave.  rem == 0 gives fx = 0 and w = p1 exactly: with an integer ratio that is
+            // the reference's copy branch (accepted whatever the guard says); otherwise the reference's own `x % 1 == 0` decides
+            // between copy and interpolation and the lane goes to the reference-order code.
+            const float *tf = tabf + q;
+            const float remf = (float)rem;
+            float fx = remf * inv_bf;
+            fx = __builtin_fmaf(__builtin_fmaf(-fx, bf, remf), inv_bf, fx);  // rem / b to one ulp
+            const float f1 = tf[0];
+            float w;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                w = __builtin_fmaf(tf[1] - f1, fx, f1);
+            } else {
+                const float f0 = tf[-1], f2 = tf[1], f3 = tf[2];
+                const float c3 = __builtin_fmaf(1.5f, f1 - f2, 0.5f * (f3 - f0));
+                const float c2 = __builtin_fmaf(-2.5f, f1, f0) + __builtin_fmaf(2.0f, f2, -0.5f * f3);
+                const float c1 = 0.5f * (f2 - f0);
+                w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, f1);
             }
-            if (rem != 0) {  // f32 first
-                const float *tf = tabf + q;
-                const float remf = (float)rem;
-                float fx = remf * inv_bf;
-                fx = __builtin_fmaf(__builtin_fmaf(-fx, bf, remf), inv_bf, fx);  // rem / b to one ulp
-                const float p1 = tf[0];
-                float w;
-                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                    w = __builtin_fmaf(tf[1] - p1, fx, p1);
-                } else {
-                    const float p0 = tf[-1], p2 = tf[1], p3 = tf[2];
-                    const float c3 = __builtin_fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
-                    const float c2 = __builtin_fmaf(-2.5f, p1, p0) + __builtin_fmaf(2.0f, p2, -0.5f * p3);
-                    const float c1 = 0.5f * (p2 - p0);
-                    w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, p1);
+            float fl = floorf(w);
+            const float fr = w - fl;
+            const bool accept = rem == 0 ? int_ratio : (fr > 1e-3f && fr < 1 - 1e-3f);
+            if (active && !accept) {  // about one wave row in eight has such a lane
+                // the same in fp64, margin 1e-6
+                const double p1 = tab[q];
+                double v = p1;
+                bool ok = false;
+                if (rem != 0) {
+                    const double fxd = (double)rem * inv_b;
+                    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                        v = __builtin_fma(tab[q + 1] - p1, fxd, p1);
+                    } else {
+                        const double p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
+                        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                        const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                        const double c1 = 0.5 * (p2 - p0);
+                        v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fxd, c2), fxd, c1), fxd, p1);
+                    }
+                    const double frd = v - floor(v);
+                    ok = frd > 1e-6 && frd < 1 - 1e-6;
                 }
-                const float fl = floorf(w), fr = w - fl;
-                if (fr > 1e-3f && fr < 1 - 1e-3f) { store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f)); continue; }  // :2909
-            }
-            // the same in fp64, margin 1e-6
-            const double p1 = tab[q];
-            double v = p1;
-            bool ok = rem != 0 || int_ratio;
-            if (rem != 0) {
-                const double fx = (double)rem * inv_b;
-                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                    v = __builtin_fma(tab[q + 1] - p1, fx, p1);
-                } else {
-                    const double p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
-                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                    const double c1 = 0.5 * (p2 - p0);
-                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+                if (!ok) {  // reference-order evaluation on the same window
+                    bool isint;
+                    v = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT + j, &isint);
                 }
-                const double fr = v - floor(v);
-                ok = fr > 1e-6 && fr < 1 - 1e-6;
+                fl = (float)lua_clamp(floor(v), -128, 127);
             }
-            if (!ok) {  // reference-order evaluation on the same window
-                bool isint;
-                v = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT + j, &isint);
-            }
-            store_floor(orow + j, lua_clamp(floor(v), -128, 127));  // :2909
+            if (active) store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f));  // :2909
         }
         if (!more) break;
         cur = nxt;
