@@ -477,27 +477,24 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
                 for (unsigned j = lane; j < newlen; j += 64, q0 += P.fdq, rem += P.fdr) {
                     if (rem >= P.fb) { rem -= P.fb; q0++; }
                     const int k = (int)q0 + 1;                  // floor(x)
-                    double v = 0;
+                    // straight-line for the whole wave (branches cost more than the arithmetic they skip): taps outside the table are
+                    // read from a safe slot and the lane is sent to the reference-order code; rem == 0 gives fx = 0 and v = p1 exactly
                     bool ok = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi);  // one spare tap on the left (x may round below an integer)
-                    if (ok) {
-                        const int s1 = k - 1;  // slot of table index k (skewed: one pad per 16)
-                        const double p1 = sm[s1 + (s1 >> 4)];
-                        v = p1;
-                        if (rem != 0) {
-                            const double fx = (double)rem * P.inv_fb;
-                            const double p2 = sm[s1 + 1 + ((s1 + 1) >> 4)];
-                            if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
-                            else {
-                                const double p0 = sm[s1 - 1 + ((s1 - 1) >> 4)], p3 = sm[s1 + 2 + ((s1 + 2) >> 4)];
-                                const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                                const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                                const double c1 = 0.5 * (p2 - p0);
-                                v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
-                            }
-                        }
-                        const double fr = v - floor(v);
-                        ok = fr > 1e-6 && fr < 1 - 1e-6;
+                    const int s1 = ok ? k - 1 : 2;  // slot of table index k (skewed: one pad per 16)
+                    const double p1 = sm[s1 + (s1 >> 4)];
+                    const double fx = (double)rem * P.inv_fb;
+                    const double p2 = sm[s1 + 1 + ((s1 + 1) >> 4)];
+                    double v;
+                    if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
+                    else {
+                        const double p0 = sm[s1 - 1 + ((s1 - 1) >> 4)], p3 = sm[s1 + 2 + ((s1 + 2) >> 4)];
+                        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                        const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                        const double c1 = 0.5 * (p2 - p0);
+                        v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
                     }
+                    const double fr = v - floor(v);
+                    ok = ok && fr > 1e-6 && fr < 1 - 1e-6;
                     if (!ok) { bool isint; v = eval_at<INTERP, true>(RP, sg, sm, 1, j, &isint); }
                     obase[j] = (OUT_T)(int)lua_clamp(floor(v), -128, 127);
                 }
