@@ -2,58 +2,53 @@
 //
 // The stream outputs are floor()ed and clamped (aukit.lua:2909-2910), so all that matters of the interpolated value is which
 // integer interval it falls into.  The reference-order evaluation costs ≈41 fp64 instructions per output (exact division for the
-// position, pow() emulation, the polynomial term by term); this kernel evaluates the same polynomial from the same fp64 samples
-// with exact rational positions and FMA Horner form (≈14 fp64 instructions) and takes the result only when it lies more than
-// 1e-6 away from an integer.  Margin: the reference's x = (i-1)/ratio + 1 carries at most 48000 * 2^-53 = 5.3e-12 of rounding
-// error, the spline's slope is below 3 * 1004 (samples are < 512 in magnitude), so the two values differ by < 2e-8; their own
-// evaluation errors are ~1e-12.  Otherwise — and at positions
-// that are mathematically integers, where the reference's own `x % 1 == 0` test decides between copy and interpolation — the
-// lane runs the reference-order code (resample_dev.h) on the same LDS window.  Bit-exact either way; the tests compare every
-// output with the oracle and with the k_resample path.
+// position, pow() emulation, the polynomial term by term).  Three tiers, each taken only when it is certain:
+//   1. f32, straight-line for the whole wave.  G.711 samples are multiples of 1/64 up to 126 in magnitude (m / 0x40, :2891), so
+//      they and the spline coefficients (multiples of 1/128 below 1400) are exact in f32; the three Horner FMAs round at
+//      magnitudes below 2048 (half an ulp = 6.1e-5 each) and the position fraction is good to one ulp (4.5e-5 after the slope of
+//      < 750): the f32 value is within 2.3e-4 of the exact one and is taken when it lies more than 1e-3 away from an integer.
+//   2. (about one output in 500) the same polynomial in fp64 with exact rational positions and FMA Horner form, taken when more
+//      than 1e-6 away from an integer.  Margin: the reference's x = (i-1)/ratio + 1 carries at most 48000 * 2^-53 = 5.3e-12 of
+//      rounding error, the spline's slope is below 3 * 1004 (samples are < 512 in magnitude), so the two values differ by
+//      < 2e-8; their own evaluation errors are ~1e-12.
+//   3. otherwise — and at positions that are mathematically integers, where the reference's own `x % 1 == 0` test decides between
+//      copy and interpolation (with an integer ratio that test is exact and the copy is taken in tier 1) — the reference-order
+//      code (resample_dev.h) on the same window.
+// Bit-exact whichever tier answers; the tests compare every output with the oracle and with the k_resample path.
 //
-// In front of that sits the same test in f32 (fp64 instructions issue at half rate): G.711 samples are multiples of 1/64 below
-// 126 in magnitude, so the spline coefficients (multiples of 1/128 below 1400) are exact in f32 and the three Horner FMAs round
-// at magnitudes below 2048 (half an ulp = 6.1e-5 each); with the position fraction good to one ulp (4.5e-5 after the slope of
-// < 750) the f32 value is within 2.3e-4 of the exact one and is taken when it lies more than 1e-3 away from an integer.  About
-// one output in 500 goes on to the fp64 test.
+// What the speed came from (same box, config 2b): fp64-only tier 2 with branches 488 G samples/s; + f32 tier, window staged one
+// dword per lane into 256 slots (more resident waves), positions advanced by additions 519; tier 1 straight-line with ONE rare
+// branch for tiers 2-3 734; + per-source-sample coefficient table for up-sampling by > 4.6 (six outputs share a polynomial) and
+// no fp64 copy of the window (tiers 2-3 convert the exact f32 samples on read) 778.  Four outputs per lane with packed stores on
+// top of that changed nothing (771): what is left is per-tile work (describe, staging, the coefficient pass, LDS round trips).
 #include <algorithm>
 #include "fast_wave_dev.h"
 #include "resample_dev.h"
 
 namespace aukit {
 
-AUKIT_DEV double g711_f64b(unsigned byte, int ulaw, double scale) {  // same integers as g711_f32b / resample.hip's g711_value
-    unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
-    int m = b & 15, e = (b >> 4) & 7;
-    if (!ulaw && e == 0) m = m * 4 + 2;
-    else m = (m * 2 + 33) << e;
-    if (ulaw) m -= 33;
-    const bool neg = ((b & 0x80) != 0) == (ulaw != 0);
-    return (double)(neg ? -m : m) * scale;
-}
-
-AUKIT_DEV void store_floor(signed char *p, double v) { *p = (signed char)(int)v; }
-AUKIT_DEV void store_floor(double *p, double v) { *p = v; }
 AUKIT_DEV void store_floor(signed char *p, float v) { *p = (signed char)(int)v; }
 AUKIT_DEV void store_floor(double *p, float v) { *p = (double)v; }
 
 // DW: the window is at most 16 vectors (up-sampling by > ~4.6, e.g. 8 kHz -> 48 kHz): every lane stages one dword of it instead
-// of the first few lanes staging 16 bytes each
+// of the first few lanes staging 16 bytes each, and the polynomial coefficients are tabulated per source sample (ccap entries).
 template <int INTERP, bool DW, typename OUT_T>
-__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F) {
-    extern __shared__ double smd[];
+__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F, const unsigned ccap) {
+    extern __shared__ float smf[];
     constexpr int SRC = SRC_G711_MONO;
     // one more tap to the left than the polynomial needs: at a mathematically integer position the reference's x may round to just
     // below the integer, and its floor(x) is then one table index lower
     constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    constexpr int CW = INTERP == AUKIT_INTERP_CUBIC ? 4 : 2;  // floats per coefficient entry
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *const sm = smd + wave * (unsigned)F.cap;
-    float *const smf = reinterpret_cast<float *>(smd + 4 * (unsigned)F.cap) + wave * (unsigned)F.cap;  // the same window in f32 (exact)
+    float *const sm = smf + wave * ((unsigned)F.cap + ccap * CW);  // the window (exact in f32), then the coefficient table
+    float *const cf = sm + F.cap;                                  // 16-byte aligned: F.cap is a multiple of 16
     const unsigned nwaves = gridDim.x * 4u;
     const double inv_b = 1.0 / (double)F.b;
     const float bf = (float)F.b, inv_bf = 1.0f / bf;
     const bool int_ratio = F.a == 1;  // ratio = b: (i-1)/ratio is an integer exactly when b divides i-1, in floating point too
+    const float sc = (float)P.g711_scale;
     OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
 
     unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
@@ -71,48 +66,24 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);
     load_window(cur);
     for (;;) {
-        // ---- window → LDS as the reference's doubles (m / 0x40, :2891); slots below / above the table replicate its ends,
-        // which is what the nil fall-backs of interpolate.linear / cubic read (:259, :264)
+        // ---- window → LDS (write_lds also patches vectors that straddle the allocation and replicates the table's ends into the
+        // slots below / above it, which is what the nil fall-backs of interpolate.linear / cubic read (:259, :264))
         if constexpr (DW) {
-            if ((lane >> 2) < cur.nvec) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double d = g711_f64b((pre1 >> (8 * e)) & 0xFF, P.ulaw, P.g711_scale);
-                    sm[4 * lane + e] = d; smf[4 * lane + e] = (float)d;
-                }
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const int v = lane + 64 * i;
-            if (v >= cur.nvec) continue;
-            const unsigned ww[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const double d = g711_f64b((ww[e >> 2] >> (8 * (e & 3))) & 0xFF, P.ulaw, P.g711_scale);
-                sm[16 * v + e] = d; smf[16 * v + e] = (float)d;
-            }
-        }
-        {
+            if ((lane >> 2) < cur.nvec)
+                *reinterpret_cast<float4 *>(sm + 4 * lane) = make_float4(g711_f32b(pre1 & 0xFF, P.ulaw, sc), g711_f32b((pre1 >> 8) & 0xFF, P.ulaw, sc),
+                                                                         g711_f32b((pre1 >> 16) & 0xFF, P.ulaw, sc), g711_f32b(pre1 >> 24, P.ulaw, sc));
             const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
-            if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare: vectors that straddle the allocation were zero-filled
+            if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare
                 for (int idx = lane; idx < cur.nvec * 16; idx += 64) {
                     const unsigned char *q = cur.al + idx;
                     const unsigned char *vb = cur.al + 16 * (size_t)(idx / 16);
-                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) { sm[idx] = (q >= P.safe_lo && q < P.safe_hi) ? g711_f64b(*q, P.ulaw, P.g711_scale) : 0.0; smf[idx] = (float)sm[idx]; }
+                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q < P.safe_hi) ? sample_at<SRC>(P, F, q) : 0.f;
                 }
             }
-            const int k_hi = cur.k_lo + cur.n_stage - 1;
-            if (cur.k_lo < cur.w_lo) {
-                const double e_lo = g711_f64b(cur.base[cur.w_lo], P.ulaw, P.g711_scale);
-                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) { sm[cur.head + idx] = e_lo; smf[cur.head + idx] = (float)e_lo; }
-            }
-            if (k_hi > cur.w_hi) {
-                const double e_hi = g711_f64b(cur.base[cur.w_hi], P.ulaw, P.g711_scale);
-                const int first = cur.w_hi + 1 - cur.k_lo;
-                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) { sm[cur.head + first + idx] = e_hi; smf[cur.head + first + idx] = (float)e_hi; }
-            }
-        }
+            WaveTile edges = cur;
+            edges.nvec = 0;  // write_lds: nothing to convert, only the replicated edge samples
+            write_lds<SRC, NV>(P, F, edges, lane, pre, sm);
+        } else write_lds<SRC, NV>(P, F, cur, lane, pre, sm);
         // the tile's segment, for the reference-order fallback
         unsigned sidx, tin;
         if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
@@ -125,9 +96,27 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             nxt = describe<SRC, HL, HR>(P, F, tn);
             load_window(nxt);  // in flight while this tile is interpolated
         }
-        const double *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
-        const double *tab_klo = sm + cur.head;   // slot of table index cur.k_lo
-        const float *tabf = smf + cur.head + HL;
+        const float *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
+        const float *tab_klo = sm + cur.head;   // slot of table index cur.k_lo
+        if constexpr (DW) {  // the polynomial between source samples q and q + 1, once for the ~6 outputs that fall there
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int ncoef = cur.n_stage - HL - HR;
+            for (int q = lane; q < ncoef; q += 64) {
+                const float f1 = tab[q], f2 = tab[q + 1];
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    *reinterpret_cast<float2 *>(cf + 2 * q) = make_float2(f2 - f1, f1);
+                } else {
+                    const float f0 = tab[q - 1], f3 = tab[q + 2];
+                    const float c3 = __builtin_fmaf(1.5f, f1 - f2, 0.5f * (f3 - f0));
+                    const float c2 = __builtin_fmaf(-2.5f, f1, f0) + __builtin_fmaf(2.0f, f2, -0.5f * f3);
+                    const float c1 = 0.5f * (f2 - f0);
+                    *reinterpret_cast<float4 *>(cf + 4 * q) = make_float4(c3, c2, c1, f1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         OUT_T *orow = out + sg.out_off + (size_t)tin * WT;
         // (q, rem) of the lane's first output by the verified reciprocal, then advanced by additions: 64 outputs further is
         // 64 a = dq64 b + dr64 input positions further
@@ -137,60 +126,71 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             q = __umulhi(n0, F.magic);
             rem = n0 - q * F.b;
         }
+        // tiers 2 and 3 for one output (rare): returns the floored, clamped value
+        auto slow = [&](unsigned q, unsigned rem, unsigned j) -> float {
+            const double p1 = (double)tab[q];  // the same samples (exact in f32, converted on read)
+            double v = p1;
+            bool ok = false;
+            if (rem != 0) {
+                const double fxd = (double)rem * inv_b;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    v = __builtin_fma((double)tab[q + 1] - p1, fxd, p1);
+                } else {
+                    const double p0 = (double)tab[(int)q - 1], p2 = (double)tab[q + 1], p3 = (double)tab[q + 2];
+                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                    const double c1 = 0.5 * (p2 - p0);
+                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fxd, c2), fxd, c1), fxd, p1);
+                }
+                const double frd = v - floor(v);
+                ok = frd > 1e-6 && frd < 1 - 1e-6;
+            }
+            if (!ok) {  // tier 3
+                bool isint;
+                v = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT + j, &isint);
+            }
+            return (float)lua_clamp(floor(v), -128, 127);
+        };
         for (unsigned rb = 0; rb < cur.cnt; rb += 64, q += F.dq64, rem += F.dr64) {
             const unsigned j = rb + lane;
-            const bool active = j < cur.cnt;  // lanes past the end of a short tile compute on (their taps are still inside the window table)
+            const bool active = j < cur.cnt;  // lanes past the end of a short tile compute on (their taps are still inside the tables)
             const bool wrap = rem >= F.b;
             rem -= wrap ? F.b : 0u;
             q += wrap ? 1u : 0u;
-            // f32 first, straight-line for the whole wave.  rem == 0 gives fx = 0 and w = p1 exactly: with an integer ratio that is
-            // the reference's copy branch (accepted whatever the guard says); otherwise the reference's own `x % 1 == 0` decides
-            // between copy and interpolation and the lane goes to the reference-order code.
-            const float *tf = tabf + q;
+            // tier 1.  rem == 0 gives fx = 0 and w = p1 exactly: with an integer ratio that is the reference's copy branch (accepted
+            // whatever the guard says); otherwise the reference's own `x % 1 == 0` decides and the lane goes to tier 3.
             const float remf = (float)rem;
             float fx = remf * inv_bf;
             fx = __builtin_fmaf(__builtin_fmaf(-fx, bf, remf), inv_bf, fx);  // rem / b to one ulp
-            const float f1 = tf[0];
             float w;
-            if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                w = __builtin_fmaf(tf[1] - f1, fx, f1);
+            if constexpr (DW) {
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    const float2 c = *reinterpret_cast<const float2 *>(cf + 2 * q);
+                    w = __builtin_fmaf(c.x, fx, c.y);
+                } else {
+                    const float4 c = *reinterpret_cast<const float4 *>(cf + 4 * q);
+                    w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.x, fx, c.y), fx, c.z), fx, c.w);
+                }
             } else {
-                const float f0 = tf[-1], f2 = tf[1], f3 = tf[2];
-                const float c3 = __builtin_fmaf(1.5f, f1 - f2, 0.5f * (f3 - f0));
-                const float c2 = __builtin_fmaf(-2.5f, f1, f0) + __builtin_fmaf(2.0f, f2, -0.5f * f3);
-                const float c1 = 0.5f * (f2 - f0);
-                w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, f1);
+                const float *tf = tab + q;
+                const float f1 = tf[0];
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    w = __builtin_fmaf(tf[1] - f1, fx, f1);
+                } else {
+                    const float f0 = tf[-1], f2 = tf[1], f3 = tf[2];
+                    const float c3 = __builtin_fmaf(1.5f, f1 - f2, 0.5f * (f3 - f0));
+                    const float c2 = __builtin_fmaf(-2.5f, f1, f0) + __builtin_fmaf(2.0f, f2, -0.5f * f3);
+                    const float c1 = 0.5f * (f2 - f0);
+                    w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, f1);
+                }
             }
             float fl = floorf(w);
             const float fr = w - fl;
             const bool accept = rem == 0 ? int_ratio : (fr > 1e-3f && fr < 1 - 1e-3f);
-            if (active && !accept) {  // about one wave row in eight has such a lane
-                // the same in fp64, margin 1e-6
-                const double p1 = tab[q];
-                double v = p1;
-                bool ok = false;
-                if (rem != 0) {
-                    const double fxd = (double)rem * inv_b;
-                    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                        v = __builtin_fma(tab[q + 1] - p1, fxd, p1);
-                    } else {
-                        const double p0 = tab[(int)q - 1], p2 = tab[q + 1], p3 = tab[q + 2];
-                        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                        const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                        const double c1 = 0.5 * (p2 - p0);
-                        v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fxd, c2), fxd, c1), fxd, p1);
-                    }
-                    const double frd = v - floor(v);
-                    ok = frd > 1e-6 && frd < 1 - 1e-6;
-                }
-                if (!ok) {  // reference-order evaluation on the same window
-                    bool isint;
-                    v = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT + j, &isint);
-                }
-                fl = (float)lua_clamp(floor(v), -128, 127);
-            }
+            if (active && !accept) fl = slow(q, rem, j);  // about one wave row in eight has such a lane
             if (active) store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f));  // :2909
         }
+        if (DW) __builtin_amdgcn_wave_barrier();  // the next tile's staging overwrites both tables
         if (!more) break;
         cur = nxt;
         t = tn;
@@ -217,7 +217,9 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return false;
     if (((double)F.b + (double)WT * (double)F.a) * (double)F.b >= 4294967296.0) return false;
     const bool dw = win + 2 * 16 <= 16 * 16;
-    F.cap = dw ? 16 * 16 : 64 * 16;  // window slots per wave (the kernel is latency-bound: a small window keeps 8 workgroups per CU resident)
+    F.cap = dw ? 16 * 16 : 64 * 16;  // window slots per wave
+    const unsigned ccap = dw ? (unsigned)((win + 3) & ~3) : 0u;
+    F.scale_pos = F.scale_neg = 0.f;
     F.dq64 = (unsigned)((64ull * F.a) / F.b);
     F.dr64 = (unsigned)((64ull * F.a) % F.b);
     P.ratio = 48000 / old_rate;
@@ -226,11 +228,11 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     P.halo_l = hl; P.halo_r = hr; P.sinc_w = ctx->sinc_w;
     if ((*rc = plan_tiles_sized(ctx, segs, WT, P))) return true;
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
-    const size_t lds = (size_t)F.cap * (8 + 4) * 4;  // per wave: the window as doubles and as floats
+    const size_t lds = ((size_t)F.cap + (size_t)ccap * (interp == AUKIT_INTERP_CUBIC ? 4 : 2)) * 4 * 4;  // per wave: window + coefficient table
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 8);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-#define AUKIT_FW(I, T) do { if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F); \
-                            else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F); } while (0)
+#define AUKIT_FW(I, T) do { if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap); \
+                            else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap); } while (0)
     if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, signed char); else AUKIT_FW(AUKIT_INTERP_CUBIC, signed char); }
     else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, double); else AUKIT_FW(AUKIT_INTERP_CUBIC, double); }
 #undef AUKIT_FW

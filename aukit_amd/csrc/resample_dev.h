@@ -20,9 +20,10 @@ AUKIT_DEV double pos_of(const ResampleParams &P, unsigned o) {
 // `if x % 1 == 0 then d[x] else interp(d, x)`; *isint tells the caller which branch was taken.
 // SKEW16: the table is stored with one pad slot per 16 entries (slot(i) = i + i/16) so that lanes which each own 16
 // consecutive entries write to distinct LDS banks (k_ima_stream).
-template <int INTERP, bool SKEW16 = false>
-AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const double *tabp, int k_lo, unsigned o, bool *isint) {
-    struct { const double *p; AUKIT_DEV double operator[](int i) const { return SKEW16 ? p[i + (i >> 4)] : p[i]; } } tab{tabp};
+// TAB_T: double, or float for tables whose samples are exact in f32 (G.711: multiples of 1/64) — converted on read.
+template <int INTERP, bool SKEW16 = false, typename TAB_T = double>
+AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const TAB_T *tabp, int k_lo, unsigned o, bool *isint) {
+    struct { const TAB_T *p; AUKIT_DEV double operator[](int i) const { return (double)(SKEW16 ? p[i + (i >> 4)] : p[i]); } } tab{tabp};
     double x = pos_of(P, o);
     double ffx = floor(x);
     int k = (int)ffx;
