@@ -255,6 +255,14 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         done = fast_try(ctx, src, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, 1, P.lp_alpha);
         if (done && frc) { delete ck; return frc; }
     }
+    if (!done && dtype == AUKIT_F32 && C == 2 && bd == 2 && d->data_type == AUKIT_SIGNED && !d->big_endian && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+        // interleaved 16-bit stereo (nearly every WAV file): both channels, or averaged as they are read when `mono`
+        bool aligned4 = (((uintptr_t)in->data()) & 3) == 0;  // frames must not straddle dwords
+        for (uint32_t s = 0; s < in->n && aligned4; s++) aligned4 = (in->off[s] & 3) == 0;
+        int frc = AUKIT_OK;
+        if (aligned4) done = fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, mono ? 2 : 1, P.lp_alpha);
+        if (done && frc) { delete ck; return frc; }
+    }
     if (!done) {
         size_t lds;
         if ((rc = plan_tiles(ctx, segs, cp.ratio, interp, nd, P, &lds))) { delete ck; return rc; }

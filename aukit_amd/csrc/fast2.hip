@@ -100,7 +100,7 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
                      uint64_t algorithmic_bytes, bool *taken) {
     *taken = false;
     const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : (src_kind == SRC_G711_MONO ? 16 : 4);  // source elements (frames for stereo) per 16-byte vector
-    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi == 1 ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
+    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;  // staged samples per wave tile (upper bound)
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
     nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
@@ -126,6 +126,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     unsigned nblk_needed = (P.n_tiles + 3) / 4;
     unsigned grid = std::min<unsigned>(nblk_needed, (unsigned)ctx->num_cus * std::max(per_cu, 1u));
     if ((rc = ctx_begin_kernel(ctx))) return rc;
+    if (F.epi && src_kind == SRC_PCM_S16LE_STEREO) {  // stream.pcm on interleaved stereo (fast_stream_s16x2.hip)
+        if ((rc = launch_fast_wave_stream_s16x2(ctx, interp, nv, P, F, grid))) return rc;
+        static thread_local char nmx[96];
+        snprintf(nmx, sizeof nmx, "k_fast_wave_stream_s16x2<%s,nv%d,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, F.epi == 2 ? "mono" : "stereo");
+        return ctx_end_kernel(ctx, nmx, algorithmic_bytes);
+    }
     if (F.epi == 1) {
         if ((rc = launch_fast_wave_stream(ctx, interp, nv, P, F, lds, grid))) return rc;
         static thread_local char nms[96];

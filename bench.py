@@ -153,6 +153,27 @@ class Pcm16Stream(Workload):
         return int(self.out.layout()[0].sum())
 
 
+class Pcm16StereoStream(Workload):
+    """The austream case: a 16-bit stereo 44.1 kHz WAV through aukit.stream.pcm (both channels; not a BASELINE config)."""
+    name, unit = "pcm16_stereo_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.n_samples = int(round(args.seconds * SRC_RATE))
+        self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples * 2, SRC_RATE, 0xA0C17 + 7000 + rank)
+        offs = [i * self.n_samples * 4 for i in range(args.streams + 1)]
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_PCM, 2, SRC_RATE, 16, "signed")
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=self.dtype, out=self.out)
+        self.desc = (f"{args.streams}x s16le 44.1kHz STEREO {args.seconds:g}s -> aukit.stream.pcm ({args.interp}), all iterator calls, "
+                     f"{args.dtype} store; unit = out-samples of both channels")
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum()) * 2
+
+
 class G711Cubic(Workload):
     name, unit = "g711_cubic", "Msamples/s"
 
@@ -271,7 +292,7 @@ class FlacPipeline(Workload):
         return int(self.m.layout()[0].sum())
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stereo, Pcm16Stream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def main():
@@ -290,7 +311,7 @@ def main():
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048}.get(args.workload, 4096)
+        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048}.get(args.workload, 4096)
 
     import torch
     import torch.distributed as dist

@@ -203,6 +203,40 @@ def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
             assert rms(got[i][0] / 128, got2[i][0] / 128) <= 1e-6, i
 
 
+@pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate", [44100, 32000, 22050, 8000])
+def test_stream_pcm_stereo16_f32_wave_kernel(ctx, oracle, rate, interp, mono):
+    """Interleaved 16-bit stereo (the WAV layout) with F32 storage takes the stereo wave kernel with the stream.pcm epilogue — both
+    channels, or the channels averaged as they are read (`mono`): same chunking as the oracle, ≤ 1e-6 RMS on the [-1,1] scale, and
+    ≤ 1e-6 RMS from the fp64 reference-order kernel on the same batch (ragged streams, a batch offset that is not 16-byte aligned)."""
+    B, N = _B(), _N()
+    nfr = [int(rate * 2.5), rate, rate + 3, 10, int(rate * 1.0001) + 2, 1100, 2]
+    streams = [np.stack([pcm16(n, rate, 1, 2 * i), pcm16(n, rate, 1, 2 * i + 1)], 1).tobytes() for i, n in enumerate(nfr)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 2, rate, 16, "signed")
+    out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave_stream_s16x2<") and ctx.last_kernel()[0].endswith(("mono>" if mono else "stereo>")), ctx.last_kernel()
+    got = out.download()
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        out2, ck2 = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
+        assert ctx.last_kernel()[0].startswith("k_resample<")
+        got2 = out2.download()
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 2, rate, False, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        assert len(got[i]) == ref.channels == (1 if mono else 2)
+        for c in range(ref.channels):
+            assert len(got[i][c]) == len(ref.data[c])
+            if len(ref.data[c]):
+                assert rms(got[i][c] / 128, ref.data[c] / 128) <= 1e-6, (i, c)
+                assert np.max(np.abs(got[i][c] - ref.data[c])) <= 2e-4, (i, c)  # absolute, on the [-128, 127] scale
+                assert rms(got[i][c] / 128, got2[i][c] / 128) <= 1e-6, (i, c)
+
+
 def test_stream_pcm_stereo_and_mono_mix(ctx, oracle):
     B, N = _B(), _N()
     st = np.stack([pcm16(30000, 22050, 1, 0), pcm16(30000, 22050, 1, 1)], 1).tobytes()
