@@ -53,6 +53,11 @@ constexpr int WSTR = 2 * WN + 1;  // row stride of the window array in 32-bit wo
 constexpr unsigned LOW_BITS = (WN - 4) * 64;  // a lane stops for a refill once it is this far into its window
 constexpr int NC = 32;    // values a lane produces (extract) / restores (restore) per round
 constexpr int OSTR = 33;  // row stride of the value array
+#ifndef AUKIT_FLAC_NCX
+#define AUKIT_FLAC_NCX 32
+#endif
+constexpr int NCX = AUKIT_FLAC_NCX;  // values a lane extracts per round (k_flac_extract); a power of two <= 64
+constexpr int OSTRX = NCX + 1;
 
 struct FlacStreamInfo { u64 first_byte; double rate, nsamples; int channels, depth, status, pad; };
 
@@ -309,7 +314,7 @@ template <typename R> struct ExtractArgs {
 template <typename R>
 __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     __shared__ unsigned s_win[64 * WSTR];
-    __shared__ R s_out[64 * OSTR];
+    __shared__ R s_out[64 * OSTRX];
     __shared__ u64 s_ptr[64];
     __shared__ int s_cnt[64];
     const int lane = threadIdx.x;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     long long cval = 0;
     u64 cand_scratch = 0, gcur = 0, end_byte = 0;
     SubDesc *sd = A.sd + (size_t)idx * C;
-    R *const orow = s_out + lane * OSTR;
+    R *const orow = s_out + lane * OSTRX;
 
     for (;;) {
         // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
@@ -365,10 +370,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
             __syncthreads();
             if (fresh && st != ST_DONE) { bits_seek(b, b.pos); fresh = false; }
         }
-        // ---- every lane advances its own frame until it has produced NC values or its window runs low
+        // ---- every lane advances its own frame until it has produced NCX values or its window runs low
         int cnt = 0;
         if (st == ST_DIRECT_WAIT) { __threadfence(); direct = true; st = resume; }
-        while (st != ST_DONE && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+        while (st != ST_DONE && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
             if (!direct && !gen_once && !gen_part && (st == ST_CODES || st == ST_PART || (st == ST_WARM && sdepth < 32))) {
                 // ---- fast path for everything that is a run of bit fields: Rice partitions incl. their headers and escape-coded
                 // partitions (:393-407), warm-up samples and VERBATIM subframes (:422-424, :456-458).  A 64-bit shift register is fed
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     const unsigned u = ((unsigned)z << param) | low;
                     const int v_rice = (int)(u >> 1) ^ -(int)(u & 1);
                     const int v_fix = nfix ? ((int)hi >> (32 - nfix)) : 0;
-                    orow[min(cnt, NC - 1)] = (R)(fixed ? v_fix : v_rice);
+                    orow[min(cnt, NCX - 1)] = (R)(fixed ? v_fix : v_rice);
                     const int tot = good ? total : 0;
                     buf <<= tot;
                     avail -= tot;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     nbits = gh ? (is_esc ? nb5 : 0) : nbits;
                     remaining = good ? (hdr ? count : remaining - 1) : remaining;
                     pi += (good & !warm & (remaining == 0)) ? 1 : 0;  // a finished (or empty) partition
-                    go = good & (cnt < NC) & (rp < LOW_BITS) & ((remaining > 0) | (!warm & (pi < nparts)));
+                    go = good & (cnt < NCX) & (rp < LOW_BITS) & ((remaining > 0) | (!warm & (pi < nparts)));
                 }
                 bits_seek(b, wbase + rp);
                 if (why == 1) gen_once = true;
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     else st = remaining > 0 ? ST_CODES : (pi < nparts ? ST_PART : ST_SUBEND);
                 }
             } else if (st == ST_CODES) {
-                while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                while (remaining > 0 && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = esc ? read_sint(b, nbits) : read_rice(b, param);
                     if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
                     if (direct) { if (store_ok) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 if (b.eof) { status = FE_NIL; st = ST_DONE; }
                 else if (remaining == 0) { pi++; gen_part = false; st = pi < nparts ? ST_PART : ST_SUBEND; }
             } else if (st == ST_WARM) {  // warm-up samples (:422-424, :430-432) or a VERBATIM subframe (:456-458)
-                while (remaining > 0 && cnt < NC && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                while (remaining > 0 && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = read_sint(b, sdepth);
                     if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
                     if (direct) { if (store_ok && jpos < bs) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 }
             } else if (st == ST_CONST) {  // :453-454
                 if constexpr (sizeof(R) == 4) { if (cval != (long long)(R)cval) ovf = true; }
-                while (remaining > 0 && cnt < NC) { orow[cnt++] = (R)cval; remaining--; }
+                while (remaining > 0 && cnt < NCX) { orow[cnt++] = (R)cval; remaining--; }
                 if (remaining == 0) st = ST_SUBEND;
             } else if (st == ST_PART) {  // :394-406
                 gen_once = false;
@@ -598,10 +603,11 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         gcur += (u64)cnt;
         __syncthreads();
         {
-            const int half = lane >> 5, k = lane & 31;
-            for (int i = 0; i < 32; i++) {
-                const int s = 2 * i + half;
-                if (k < s_cnt[s]) A.scratch[s_ptr[s] + k] = s_out[s * OSTR + k];
+            constexpr int PER = 64 / NCX;  // streams per store instruction
+            const int part = lane / NCX, k = lane % NCX;
+            for (int i = 0; i < NCX; i++) {
+                const int s = PER * i + part;
+                if (k < s_cnt[s]) A.scratch[s_ptr[s] + k] = s_out[s * OSTRX + k];
             }
         }
         __syncthreads();
