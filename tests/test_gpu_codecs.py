@@ -61,6 +61,34 @@ def test_dfpwm_encode_bit_exact(ctx, oracle, interleaved):
         assert got[s] == oracle.audio_dfpwm(oracle.Audio(a[s], 48000), interleaved)
 
 
+def test_dfpwm_saturating_inputs(ctx, oracle):
+    """The corners of the step functions (dfpwm_dev.h): charge pinned at 127 / -128 (the encoder's `v == charge and v == 127`
+    clause, the nudge with diff == 0), strength at its floor and at its ceiling, long runs and strict alternation — decoder, encoder
+    and the fused transcode against the oracle, bit for bit."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(99))
+    pats = [b"\xff" * 12000, b"\x00" * 12000, b"\xaa" * 12000, b"\x55" * 12004, b"\xff" * 3000 + b"\x00" * 3000 + b"\xaa" * 6000,
+            bytes(rng.integers(0, 256, 12000, dtype=np.uint8)), b"\x0f" * 12000, b"\xfe\x01" * 6000]
+    bt = B.Batch.upload(ctx, pats)
+    for ch in (1, 2):
+        got = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, ch, 48000), dtype=N.F64).download()
+        for s, g in zip(pats, got):
+            ref = oracle.dfpwm(s, ch, 48000)
+            for c in range(ch):
+                assert np.array_equal(g[c], ref.data[c]), (s[:2], ch, c)
+    fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    for s, f in zip(pats, fused):
+        assert f == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(s, 2, 48000)), True), s[:2]
+    # the encoder on signals that sit on the rails, step between them, and dither around them
+    n = 48000
+    sq = np.where((np.arange(n) // 500) % 2 == 0, 1.0, -1.0)
+    sigs = [np.full(n, 1.0), np.full(n, -1.0), sq, np.clip(sq + rng.uniform(-0.02, 0.02, n), -1, 1), np.zeros(n), np.full(n, 126 / 127), np.full(n, -127 / 128)]
+    ab = B.AudioBatch.upload(ctx, [[x] for x in sigs], 48000, dtype=N.F64)
+    enc = B.dfpwm_encode(ctx, ab, True).download()
+    for x, e in zip(sigs, enc):
+        assert e == oracle.audio_dfpwm(oracle.Audio([x], 48000), True)
+
+
 def test_dfpwm_encode_out_of_range_raises(ctx):
     B, N = _B(), _N()
     ab = B.AudioBatch.upload(ctx, [[np.array([0.0, 0.5, 1.5, 0.0])]], 48000, dtype=N.F64)

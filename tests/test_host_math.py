@@ -43,6 +43,45 @@ def test_rational_positions_agree_with_reference_doubles():
         assert np.array_equal((n * np.uint64(magic)) >> np.uint64(32), n // np.uint64(b))
 
 
+def test_dfpwm_step_algebra_is_the_published_step_for_every_state():
+    """dfpwm_dev.h rewrites the DFPWM1a step for instruction count (median-of-three nudge, ±1 bits, n = -(2 charge + 1), low-pass
+    with the lpf inside the floor, biased charge in the encoder).  Every identity it claims, checked exhaustively in integer numpy
+    against the published form — independent of the GPU and of the C oracle."""
+    def med3(a, b, c):
+        return np.maximum(np.minimum(a, b), np.minimum(np.maximum(a, b), c))
+
+    charge, strength, bit, prev = np.meshgrid(np.arange(-128, 128), np.concatenate([[0], np.arange(8, 1024)]), [0, 1], [0, 1], indexing="ij")
+    charge, strength, bit, prev = [x.ravel().astype(np.int64) for x in (charge, strength, bit, prev)]
+    # published predictor
+    target = np.where(bit == 1, 127, -128)
+    nxt = charge + ((strength * (target - charge) + 512) >> 10)
+    nxt = np.where((nxt == charge) & (nxt != target), nxt + np.where(bit == 1, 1, -1), nxt)
+    z = np.where(bit == prev, 1023, 0)
+    ns = np.where(strength != z, strength + np.where(bit == prev, 1, -1), strength)
+    ns = np.maximum(ns, 8)
+    # decoder form
+    b, pb, n = 2 * bit - 1, 2 * prev - 1, -(2 * charge + 1)
+    diff2 = 255 * b + n
+    assert np.array_equal(diff2, 2 * (target - charge))
+    step = med3((strength * diff2 + 1024) >> 11, b, diff2)
+    n2 = n - 2 * step
+    assert np.array_equal((~n2) >> 1, nxt)
+    assert np.array_equal(med3(b * pb + strength, 8, 1023), ns)
+    # encoder form: biased charge, unsigned samples
+    cu, diff = charge + 128, np.where(bit == 1, 255, 0) - (charge + 128)
+    assert np.array_equal(cu + med3((strength * diff + 512) >> 10, b, diff) - 128, nxt)
+    v, c = [x.ravel().astype(np.int64) for x in np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), indexing="ij")]
+    assert np.array_equal((v > c) | ((v == c) & (v == 127)), (v + 128) > np.minimum(c + 128, 254))
+    # anti-jerk + low-pass: q = ceil((n + (same ? n : previous n)) / 4) = -(anti-jerked charge); lpf' = (116 lpf - 140 aj + 128) >> 8
+    c1, c0, lpf, same = [x.ravel().astype(np.int64) for x in np.meshgrid(np.arange(-128, 128), np.arange(-128, 128), np.arange(-128, 128, 3), [0, 1], indexing="ij")]
+    aj = np.where(same == 1, c1, (c1 + c0 + 1) >> 1)
+    ref = lpf + (((aj - lpf) * 140 + 0x80) >> 8)
+    n1, n0 = -(2 * c1 + 1), -(2 * c0 + 1)
+    q = (n1 + np.where(same == 1, n1, n0) + 3) >> 2
+    assert np.array_equal(q, -aj)
+    assert np.array_equal((116 * lpf + (-140 * q + 128)) >> 8, ref)
+
+
 def test_partition_is_contiguous_and_balanced():
     from aukit_amd.shard import partition
     rng = np.random.default_rng(0)
