@@ -1,0 +1,130 @@
+"""GPU: seeded random sweeps over the fast paths against the CPU oracle — odd sample rates, ragged and tiny streams, full-scale
+random samples, plateaus.  Every case goes through the C ABI twice: the f32 tolerance path
+(≤ 1e-6 RMS, the bar of SURVEY §8d) and the reference-order path (exact / 1e-13), and the chunk bookkeeping of the stream paths
+must equal the oracle's.  Seeds are fixed: the sweep is the same on every run.
+"""
+import numpy as np
+import pytest
+
+from tests.util import rms
+
+pytestmark = pytest.mark.gpu
+
+RATES = [4000, 6000, 8000, 11025, 12000, 16000, 22050, 24000, 32000, 37800, 44100, 47999, 8001, 44056, 30000]
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+def _lens(rng, rate, k):
+    """k stream lengths (frames): around chunk and tile boundaries, tiny, and a long one"""
+    picks = [1, 2, 3, 5, 17, 1023, 1024, 1025, rate - 1, rate, rate + 1, int(rate * 1.5) + int(rng.integers(0, 50)), int(rate * 2.2)]
+    return [int(picks[i]) for i in rng.choice(len(picks), k, replace=False)]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_pcm16_audio_and_stream(ctx, oracle, seed):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    rate = int(RATES[rng.integers(0, len(RATES))])
+    ch = int(rng.integers(1, 3))
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    lens = _lens(rng, rate, 6)
+    # full-scale random samples (worst case for the interpolators), a few constant runs
+    streams = []
+    for n in lens:
+        x = rng.integers(-32768, 32768, n * ch, dtype=np.int64).astype(np.int16)
+        if n > 40:
+            x[10 * ch:30 * ch] = x[10 * ch]
+        streams.append(x.tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, 16, "signed")
+    oi = oracle.INTERP[interp]
+    # Audio path
+    g32 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32).download()
+    g64 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    for i, s in enumerate(streams):
+        if len(s) % (2 * ch):
+            continue
+        ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, ch, rate), 48000, oi)
+        for c in range(ch):
+            assert len(g32[i][c]) == len(ref.data[c]) == len(g64[i][c]), (rate, ch, interp, i)
+            assert np.max(np.abs(g64[i][c] - ref.data[c]), initial=0) <= 1e-15, (rate, ch, interp, i, c)
+            assert rms(g32[i][c], ref.data[c]) <= 1e-6, (rate, ch, interp, i, c)
+    # stream path (whole frames only)
+    ok = [s for s in streams if len(s) % (2 * ch) == 0 and len(s)]
+    bts = B.Batch.upload(ctx, ok)
+    for mono in ([False, True] if ch == 2 else [False]):
+        o32, ck32 = B.stream_decode(ctx, bts, desc, interp, mono=mono, dtype=N.F32)
+        o64, ck64 = B.stream_decode(ctx, bts, desc, interp, mono=mono, dtype=N.F64)
+        a32, a64 = o32.download(), o64.download()
+        for i, s in enumerate(ok):
+            ref = oracle.stream_pcm(s, 16, oracle.SIGNED, ch, rate, False, mono, oi)
+            for ck in (ck32, ck64):
+                assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (rate, ch, interp, mono, i)
+                assert ck.status[i] == ref.final_status
+            for c in range(ref.channels):
+                assert np.max(np.abs(a64[i][c] - ref.data[c]), initial=0) <= 1e-13, (rate, ch, interp, mono, i, c)
+                assert rms(a32[i][c] / 128, ref.data[c] / 128) <= 1e-6, (rate, ch, interp, mono, i, c)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_g711_audio_and_stream(ctx, oracle, seed):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    rate = int(RATES[rng.integers(0, len(RATES))])
+    ulaw = bool(rng.integers(0, 2))
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    lens = _lens(rng, rate, 6)
+    streams = []
+    for n in lens:
+        x = rng.integers(0, 256, n, dtype=np.uint8)
+        if n > 64:
+            x[20:50] = x[20]  # a plateau: interpolated values that are exact multiples of 1/64 (and, in the stream, exact integers)
+        streams.append(x.tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_G711, 1, rate, ulaw=ulaw)
+    oi = oracle.INTERP[interp]
+    g32 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32).download()
+    g64 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=N.I8)
+    st = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.resample(oracle.g711(s, ulaw, 1, rate), 48000, oi)
+        assert len(g32[i][0]) == len(ref.data[0])
+        assert np.max(np.abs(g64[i][0] - ref.data[0]), initial=0) <= 1e-15, (rate, ulaw, interp, i)
+        assert rms(g32[i][0], ref.data[0]) <= 1e-6, (rate, ulaw, interp, i)
+        rs = oracle.stream_g711(s, ulaw, 1, rate, False, oi)
+        assert ck.nchunks[i] == rs.nchunks and list(ck.lens[i][:rs.nchunks]) == list(rs.chunk_len[:, 0]), (rate, ulaw, interp, i)
+        assert np.array_equal(st[i][0], rs.data[0]), (rate, ulaw, interp, i)  # floored outputs: bit-exact
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_dfpwm_paths(ctx, oracle, seed):
+    """random DFPWM byte streams of odd lengths through the loader (1-3 channels where the sample count divides), stream.dfpwm and
+    the fused stereo → mono → DFPWM transcode, bit-exact"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    lens = [int(v) for v in rng.choice([1, 2, 7, 599, 6000, 6001, 6002, 11999, 12000, 12001, 18003, 30000, 48001], 6, replace=False)]
+    streams = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+    bt = B.Batch.upload(ctx, streams)
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 1, 48000), dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        assert np.array_equal(g[0], oracle.dfpwm(s, 1, 48000).data[0]), len(s)
+    fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    for s, f in zip(streams, fused):
+        assert f == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(s, 2, 48000)), True), len(s)
+    rate = [48000, 24000, 32000, 44100][seed % 4]
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 1, rate), "linear", dtype=N.F64)
+    a = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_dfpwm(s, rate, 1, False, oracle.LINEAR)
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (rate, len(s))
+        assert np.max(np.abs(a[i][0] - ref.data[0]), initial=0) <= 1e-13, (rate, len(s))
