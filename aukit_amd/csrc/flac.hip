@@ -1116,7 +1116,9 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
 // ================================================================= stream.flac  aukit.lua:3124-3191
 struct FsJob {
     u64 src_off;   // element offset of this (frame, channel) block in the decoded rows
-    u64 last_off;  // element offset of the previous (frame, channel) block's LAST sample (src[0]); ~0 → {0, 0}
+    u64 last_off;  // element offset of src[0] = last[2], the previous (frame, channel) block's last sample; ~0 → 0
+    u64 m1_off;    // element offset of src[-1] = last[1]: the sample before it, or — after a one-sample block, whose src[#src-1] is its
+                   // own src[0] (:3183) — the last sample of the block before that one; ~0 → 0
     u64 out_off;
     int blocksize, nout;
 };
@@ -1131,7 +1133,8 @@ __global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs
     if (j >= njobs) return;
     const FsJob job = jobs[j];
     double m1 = 0, z0 = 0;                   // src[-1], src[0] = last[1], last[2]  :3170-3171
-    if (job.last_off != ~0ull) { z0 = flac_row_value(rows, job.last_off, full); m1 = flac_row_value(rows, job.last_off - 1, full); }
+    if (job.last_off != ~0ull) z0 = flac_row_value(rows, job.last_off, full);
+    if (job.m1_off != ~0ull) m1 = flac_row_value(rows, job.m1_off, full);
     double ls = z0 / (z0 < 0 ? 128 : 127);   // :3172
     const int n = job.blocksize;
     auto tap = [&](int k) -> double { return k >= 1 ? flac_row_value(rows, job.src_off + (u64)(k - 1), full) : (k == 0 ? z0 : m1); };  // table index k
@@ -1205,18 +1208,21 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     uint64_t nouts = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t op = 0;
-        u64 prev_last = ~0ull;
+        u64 l1 = ~0ull, l2 = ~0ull;  // where last[1], last[2] live in the decoded rows (~0: the initial 0)
         for (auto &fr : D.frames[s]) {
             const int nout = (int)std::floor((double)fr.second * ratio);
             for (int c = 0; c < C; c++) {
                 FsJob j;
                 j.src_off = D.row_off[(size_t)s * C + c] + fr.first;
-                j.last_off = prev_last;
+                j.last_off = l2;
+                j.m1_off = l1;
                 j.out_off = a->row_off[s] + (uint64_t)c * a->row_stride[s] + op;
                 j.blocksize = fr.second;
                 j.nout = nout;
                 jobs.push_back(j);
-                prev_last = (fr.second >= 2) ? j.src_off + (uint64_t)fr.second - 1 : prev_last;  // last = {src[#src-1], src[#src]}, shared across channels (Q14)
+                // last = {src[#src-1], src[#src]}, shared across channels (Q14); for a one-sample block src[#src-1] is src[0] = the old last[2]
+                if (fr.second >= 2) { l1 = j.src_off + (uint64_t)fr.second - 2; l2 = l1 + 1; }
+                else if (fr.second == 1) { l1 = l2; l2 = j.src_off; }
             }
             op += (uint64_t)nout;
             nouts += (uint64_t)nout * C;

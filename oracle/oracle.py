@@ -428,7 +428,10 @@ def gen_g711(pcm16, ulaw=True):
 def gen_ima(pcm16_interleaved, channels=1, block_align=512, max_index=88):
     p = np.ascontiguousarray(pcm16_interleaved, dtype=np.int16)
     frames = len(p) // channels
-    out = np.zeros(frames // 2 * channels + block_align * 4 + 64, dtype=np.uint8)
+    if block_align <= 4 * channels or (block_align - 4 * channels) % (4 * channels):
+        raise ValueError("block_align must be 4*channels + a whole number of 4-byte words per channel")
+    spb = (block_align - 4 * channels) * 2 // channels  # samples per block: small blocks spend most of their bytes on headers
+    out = np.zeros((frames // spb + 2) * block_align + 64, dtype=np.uint8)
     f = lib().ork_gen_ima
     f.restype = C.c_size_t
     n = f(p.ctypes.data_as(C.POINTER(C.c_int16)), C.c_size_t(frames), channels, block_align, max_index, out.ctypes.data_as(C.POINTER(C.c_uint8)))

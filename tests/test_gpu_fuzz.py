@@ -128,3 +128,72 @@ def test_fuzz_dfpwm_paths(ctx, oracle, seed):
         ref = oracle.stream_dfpwm(s, rate, 1, False, oracle.LINEAR)
         assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (rate, len(s))
         assert np.max(np.abs(a[i][0] - ref.data[0]), initial=0) <= 1e-13, (rate, len(s))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_ima_stream(ctx, oracle, seed):
+    """stream.adpcm over random block sizes / channel counts / rates, full-scale random PCM (saturating predictors), ragged tails:
+    chunk bookkeeping and every floored output equal to the oracle's"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(4000 + seed))
+    ch = int(rng.integers(1, 3))
+    ba = int(rng.choice([36, 68, 260, 512, 1024, 2048] if ch == 1 else [72, 264, 512, 1024, 2048]))  # 4 ch + whole words per channel
+    rate = int(rng.choice([8000, 11025, 16000, 22050, 32000, 44100]))
+    interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+    mono = bool(ch == 2 and rng.integers(0, 2))
+    spb = (ba - 4 * ch) * 2 // ch
+    streams = []
+    for nb in (int(rng.integers(1, 4)), int(rng.integers(20, 60)), 1):
+        amp = [32767, 3000, 300][int(rng.integers(0, 3))]
+        x = rng.integers(-amp, amp + 1, spb * nb * ch, dtype=np.int64).astype(np.int16)
+        streams.append(oracle.gen_ima(x, ch, ba, 88))
+    streams.append(streams[1][: ba * 5 + int(rng.integers(4 * ch + 1, ba))])  # short final block
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, ch, rate, block_align=ba), interp, mono=mono, dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_adpcm(s, ba, ch, rate, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks, (ba, ch, rate, interp, mono, i)
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ba, ch, rate, interp, mono, i)
+        for c in range(ref.channels):
+            assert np.array_equal(got[i][c], ref.data[c]), (ba, ch, rate, interp, mono, i, c)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_flac(ctx, oracle, seed):
+    """FLAC files of random depth / channels / block size / length (the oracle's encoder picks predictor orders and Rice parameters
+    per block) through the loader (lossless), the resampled f32 pipeline and stream.flac"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(5000 + seed))
+    depth = int(rng.choice([8, 16, 24]))
+    ch = int(rng.integers(1, 3))
+    bs = int(rng.choice([192, 576, 1000, 1152, 4096, 4608]))
+    rate = int(rng.choice([22050, 32000, 44100, 48000]))
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    streams, pcms = [], []
+    for n in (int(rng.integers(1, 50)), bs, bs + 1, int(rng.integers(3 * bs, 6 * bs)), rate + 17):
+        lim = 1 << (depth - 1)
+        t = np.arange(n)[:, None] / rate
+        x = 0.6 * lim * np.sin(2 * np.pi * np.array([440.0, 557.0][:ch]) * t) + rng.integers(-lim // 8, lim // 8 + 1, (n, ch))
+        x = np.clip(np.round(x), -lim, lim - 1).astype(np.int64)
+        pcms.append(x)
+        streams.append(oracle.gen_flac(x.ravel(), ch, depth, rate, bs))
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_FLAC)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for x, g in zip(pcms, got):
+        for c in range(ch):
+            assert np.array_equal(np.round(g[c] * (1 << depth)).astype(np.int64), x[:, c]), (depth, ch, bs, len(x))
+    if rate != 48000:
+        g32 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32).download()
+        for s, g in zip(streams, g32):
+            ref = oracle.resample(oracle.flac(s), 48000, oracle.INTERP[interp])
+            for c in range(ch):
+                assert rms(g[c], ref.data[c]) <= 1e-6, (depth, ch, bs, rate, interp)
+    out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=N.F64)
+    a = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_flac(s, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (depth, ch, bs, rate, i)
+        for c in range(ref.channels):
+            assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-12, (depth, ch, bs, rate, i, c)
