@@ -197,3 +197,106 @@ def test_fuzz_flac(ctx, oracle, seed):
         assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (depth, ch, bs, rate, i)
         for c in range(ref.channels):
             assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-12, (depth, ch, bs, rate, i, c)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_msadpcm(ctx, oracle, seed):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(6000 + seed))
+    ch = int(rng.integers(1, 3))
+    ba = int(rng.choice([64, 256, 1024, 2048])) * ch
+    rate = int(rng.choice([8000, 11025, 22050, 44100]))
+    interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+    mono = bool(ch == 2 and rng.integers(0, 2))
+    spb = (ba - 14) + 2 if ch == 2 else (ba - 7) * 2 + 2
+    streams = []
+    for nb in (1, int(rng.integers(2, 9)), int(rng.integers(10, 50))):
+        amp = [32767, 4000, 200][int(rng.integers(0, 3))]
+        x = rng.integers(-amp, amp + 1, spb * nb * ch, dtype=np.int64).astype(np.int16)
+        streams.append(oracle.gen_msadpcm(x, ch, ba))
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_MSADPCM, ch, rate, block_align=ba)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.msadpcm(s, ba, ch, rate)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c], equal_nan=True), (ba, ch, rate)  # full-scale noise can drive `delta` to inf / nan, as in Lua
+    out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.I8)
+    g = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_msadpcm(s, ba, ch, rate, mono, None, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ba, ch, rate, interp, mono, i)
+        for c in range(ref.channels):
+            ok = ~np.isnan(ref.data[c])  # where `delta` overflowed the Lua number is nan, which an int8 chunk cannot hold
+            assert np.array_equal(g[i][c][ok], ref.data[c][ok]), (ba, ch, rate, interp, mono, i, c)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_qoa(ctx, oracle, seed):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    ch = int(rng.integers(1, 3))
+    rate = int(rng.choice([8000, 22050, 44100, 48000]))
+    interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+    mono = bool(ch == 2 and rng.integers(0, 2))
+    streams = []
+    for n in (int(rng.integers(1, 40)), 20, 5120, 5121, int(rng.integers(5120 * 2, 5120 * 5)), rate + int(rng.integers(0, 300))):
+        amp = [32767, 5000][int(rng.integers(0, 2))]
+        x = rng.integers(-amp, amp + 1, n * ch, dtype=np.int64).astype(np.int16)
+        streams.append(oracle.gen_qoa(x, ch, rate) + b"\0" * (8 if rng.integers(0, 2) else 0))  # with / without the trailing bytes of Q18
+    bt = B.Batch.upload(ctx, streams)
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_QOA), dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.qoa(s)
+        assert len(g) == ref.channels
+        for c in range(ref.channels):
+            assert np.array_equal(g[c], ref.data[c]), (ch, rate, len(s))
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F64)
+    a = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_qoa(s, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ch, rate, interp, mono, i)
+        assert ck.status[i] == ref.final_status
+        for c in range(ref.channels):
+            assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-12, (ch, rate, interp, mono, i, c)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_pcm_formats(ctx, oracle, seed):
+    """the generic PCM source: 8/16/24/32-bit signed / unsigned / float, either endianness, 1-3 channels, interleaved or planar,
+    through aukit.pcm (exact), :resample (fp64 order) and stream.pcm (rates <= 48 kHz)"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(8000 + seed))
+    bits = int(rng.choice([8, 16, 24, 32]))
+    dt = ["signed", "unsigned", "float"][int(rng.integers(0, 3 if bits == 32 else 2))]
+    be = bool(rng.integers(0, 2))
+    ch = int(rng.integers(1, 4))
+    rate = int(rng.choice([8000, 12000, 22050, 44100, 48000]))
+    interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+    odt = {"signed": oracle.SIGNED, "unsigned": oracle.UNSIGNED, "float": oracle.FLOAT}[dt]
+    streams = []
+    for n in (1, 3, int(rng.integers(100, 3000)), rate + int(rng.integers(1, 99))):
+        if dt == "float":
+            raw = rng.uniform(-1, 1, n * ch).astype(">f4" if be else "<f4").tobytes()
+        else:
+            raw = bytes(rng.integers(0, 256, n * ch * (bits // 8), dtype=np.uint8))
+        streams.append(raw)
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dt, big_endian=be)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    res = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    for s, g, r in zip(streams, got, res):
+        ref = oracle.pcm(s, bits, odt, ch, rate, True, be)
+        rr = oracle.resample(ref, 48000, oracle.INTERP[interp])
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c]), (bits, dt, be, ch)
+            assert len(r[c]) == len(rr.data[c]) and np.max(np.abs(r[c] - rr.data[c]), initial=0) <= 1e-15, (bits, dt, be, ch, rate, interp)
+    if interp != "none":
+        mono = bool(ch > 1 and rng.integers(0, 2))
+        out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F64)
+        a = out.download()
+        for i, s in enumerate(streams):
+            ref = oracle.stream_pcm(s, bits, odt, ch, rate, be, mono, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (bits, dt, be, ch, rate, interp, mono, i)
+            for c in range(ref.channels):
+                assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-13, (bits, dt, be, ch, rate, interp, mono, i, c)
