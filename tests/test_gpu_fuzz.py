@@ -300,3 +300,50 @@ def test_fuzz_pcm_formats(ctx, oracle, seed):
             assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (bits, dt, be, ch, rate, interp, mono, i)
             for c in range(ref.channels):
                 assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-13, (bits, dt, be, ch, rate, interp, mono, i, c)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_effects_and_audio_methods(ctx, oracle, seed):
+    """random audio (1-3 channels, ragged lengths, values over the full [-1, 1] range incl. exact ±1 and 0) through a random effect
+    with random parameters, then :mono / :mix / :resample — F64 storage against the oracle (maps exact, scans 1e-11)"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    ch = int(rng.integers(1, 4))
+    rate = int(rng.choice([8000, 22050, 44100, 48000]))
+    lens = [int(rng.integers(1, 40)), int(rng.integers(900, 1200)), int(rng.integers(rate // 2, rate * 2))]
+    a = []
+    for n in lens:
+        chans = []
+        for _ in range(ch):
+            x = rng.uniform(-1, 1, n)
+            x[rng.integers(0, n, max(1, n // 50))] = rng.choice([-1.0, 0.0, 1.0], max(1, n // 50))
+            chans.append(x)
+        a.append(chans)
+    choices = [
+        ("amplify", (float(rng.uniform(0, 3)),), lambda O, au, p: O.fx_amplify(au, *p), 0.0),
+        ("invert", (), lambda O, au, p: O.fx_invert(au), 0.0),
+        ("normalize", (float(rng.uniform(0.1, 1)), float(rng.integers(0, 2))), lambda O, au, p: O.fx_normalize(au, p[0], bool(p[1])), 0.0),
+        ("center", (), lambda O, au, p: O.fx_center(au), 1e-12),
+        ("delay", (float(rng.uniform(0, 0.02)), float(rng.uniform(0, 1))), lambda O, au, p: O.fx_delay(au, *p), 0.0),
+        ("echo", (float(rng.uniform(0.0003, 0.02)), float(rng.uniform(0, 0.95))), lambda O, au, p: O.fx_echo(au, *p), 0.0),
+        ("lowpass", (float(rng.uniform(50, rate / 2)),), lambda O, au, p: O.fx_lowpass(au, *p), 1e-11),
+        ("highpass", (float(rng.uniform(10, rate / 4)),), lambda O, au, p: O.fx_highpass(au, *p), 1e-11),
+    ]
+    name, params, ref_fn, tol = choices[int(rng.integers(0, len(choices)))]
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F64)
+    B.effect(ctx, ab, name, *params)
+    got = ab.download()
+    refs = [ref_fn(oracle, oracle.Audio(x, rate), params) for x in a]
+    for s in range(len(a)):
+        for c in range(ch):
+            assert np.max(np.abs(got[s][c] - refs[s].data[c]), initial=0) <= tol, (name, params, ch, rate, s, c)
+    m = B.mono(ctx, ab).download()
+    for s in range(len(a)):
+        assert np.max(np.abs(m[s][0] - oracle.mono(refs[s]).data[0]), initial=0) <= max(tol, 1e-15), (name, s)
+    if rate != 48000:
+        interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+        r = B.resample(ctx, ab, 48000, interp).download()
+        for s in range(len(a)):
+            rr = oracle.resample(refs[s], 48000, oracle.INTERP[interp])
+            for c in range(ch):
+                assert len(r[s][c]) == len(rr.data[c]) and np.max(np.abs(r[s][c] - rr.data[c]), initial=0) <= max(4 * tol, 1e-15), (name, interp, s, c)
