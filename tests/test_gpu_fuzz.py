@@ -347,3 +347,43 @@ def test_fuzz_effects_and_audio_methods(ctx, oracle, seed):
             rr = oracle.resample(refs[s], 48000, oracle.INTERP[interp])
             for c in range(ch):
                 assert len(r[s][c]) == len(rr.data[c]) and np.max(np.abs(r[s][c] - rr.data[c]), initial=0) <= max(4 * tol, 1e-15), (name, interp, s, c)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_mdfpwm(ctx, oracle, seed):
+    """MDFPWM files with random payloads (1-9 L/R block pairs), random metadata lengths and a length field at, below and above the
+    payload size: aukit.mdfpwm (trim at length * 8 samples, :1444) and stream.mdfpwm (Q12) against the oracle"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9500 + seed))
+    files = []
+    for pairs in (1, int(rng.integers(2, 5)), int(rng.integers(5, 10))):
+        l = bytes(rng.integers(0, 256, 6000 * pairs, dtype=np.uint8))
+        r = bytes(rng.integers(0, 256, 6000 * pairs, dtype=np.uint8))
+        md = bytearray(oracle.gen_mdfpwm(l, r, bytes(rng.integers(65, 91, int(rng.integers(0, 40)), dtype=np.uint8)), b"t" * int(rng.integers(0, 20)), b""))
+        if rng.integers(0, 2):  # shrink the length field: the loader trims, the stream stops early (Q12)
+            newlen = int(rng.integers(1, 12000 * pairs))
+            md[7:11] = newlen.to_bytes(4, "little")
+        files.append(bytes(md))
+    bt = B.Batch.upload(ctx, files)
+    try:
+        got = B.decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), dtype=N.F64).download()
+        loader_err = None
+    except N.AukitError as e:
+        loader_err = str(e)
+    for i, f in enumerate(files):
+        try:
+            ref = oracle.mdfpwm(f)
+        except Exception as e:  # an odd trimmed length is an error in the reference ("uneven amount of data per channel")
+            assert loader_err is not None, (i, e)
+            continue
+        if loader_err is None:
+            for c in range(2):
+                assert np.array_equal(got[i][c], ref.data[c]), (i, c)
+    for mono in (False, True):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_MDFPWM), "linear", mono=mono, dtype=N.I8)
+        g = out.download()
+        for i, f in enumerate(files):
+            o = oracle.stream_mdfpwm(f, mono)
+            assert ck.nchunks[i] == o.nchunks and ck.status[i] == o.final_status, (i, mono)
+            for c in range(o.channels):
+                assert np.array_equal(g[i][c], o.data[c]), (i, mono, c)
