@@ -102,3 +102,70 @@ def test_mix_dfpwm_and_pcm_methods(ctx, oracle):
     assert np.array_equal(a.pcm(16, "signed"), oracle.encode_pcm(oa, 16, oracle.SIGNED, True))
     d = oracle.dfpwm_encode(np.round(np.sin(np.arange(48000) / 20) * 90))
     assert np.array_equal(aukit.dfpwm(d, 1, 48000).data[0], oracle.dfpwm(d, 1, 48000).data[0])
+
+
+def _ext80(rate):
+    """IEEE 754 80-bit extended big-endian, as AIFF stores the sample rate"""
+    import math
+    m, e = math.frexp(rate)  # rate = m * 2^e, 0.5 <= m < 1
+    return struct.pack(">HQ", 16382 + e, int(m * (1 << 64)))
+
+
+def _aiff(ch, frames, bits, rate, payload, comp=None, ssnd_offset=0, extra_chunks=b""):
+    comm = struct.pack(">hIh", ch, frames, bits) + _ext80(rate)
+    if comp is not None:
+        name = b"not compressed"  # pascal string, even length → one pad byte
+        comm += comp + bytes([len(name)]) + name + b"\0"
+    body = (b"AIFC" if comp is not None else b"AIFF") + extra_chunks + b"COMM" + struct.pack(">I", len(comm)) + comm + \
+        b"SSND" + struct.pack(">III", 8 + ssnd_offset + len(payload), ssnd_offset, 0) + b"\x55" * ssnd_offset + payload
+    return b"FORM" + struct.pack(">I", len(body)) + body
+
+
+def test_aiff_aifc_and_au_containers(ctx, oracle):
+    """aukit.aiff (:1580-1633: COMM with the 80-bit rate, AIFC compression ids, SSND offset) and aukit.au (:1639-1651: 1-based data
+    offset, encodings 1-6 and 27) hand the right bytes and descriptors to the codecs"""
+    import aukit_amd.aukit as aukit
+    rng = np.random.Generator(np.random.PCG64(5))
+    n, ch = 500, 2
+    for rate in (22050, 44100, 8000, 48000, 11025):
+        x = rng.integers(-32768, 32768, n * ch, dtype=np.int64).astype(">i2").tobytes()
+        a = aukit.aiff(_aiff(ch, n, 16, rate, x, ssnd_offset=rate % 7, extra_chunks=b"NAME" + struct.pack(">I", 4) + b"abcd"))
+        assert a.sampleRate == rate and a.channels() == ch
+        ref = oracle.pcm(x, 16, oracle.SIGNED, ch, rate, True, True)
+        for c in range(ch):
+            assert np.array_equal(a.data[c], ref.data[c])
+    x24 = bytes(rng.integers(0, 256, n * 3, dtype=np.uint8))
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 24, 32000, x24)).data[0], oracle.pcm(x24, 24, oracle.SIGNED, 1, 32000, True, True).data[0])
+    le = rng.integers(-32768, 32768, n, dtype=np.int64).astype("<i2").tobytes()
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 16, 44100, le, b"sowt")).data[0], oracle.pcm(le, 16, oracle.SIGNED, 1, 44100, True, False).data[0])
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 16, 44100, x[:2 * n], b"NONE")).data[0], oracle.pcm(x[:2 * n], 16, oracle.SIGNED, 1, 44100, True, True).data[0])
+    fl = rng.uniform(-1, 1, n).astype(">f4").tobytes()
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 32, 48000, fl, b"fl32")).data[0], oracle.pcm(fl, 32, oracle.FLOAT, 1, 48000, True, True).data[0])
+    g = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 8, 8000, g, b"ulaw")).data[0], oracle.g711(g, True, 1, 8000).data[0])
+    assert np.array_equal(aukit.aiff(_aiff(1, n, 8, 8000, g, b"ALAW")).data[0], oracle.g711(g, False, 1, 8000).data[0])
+    with pytest.raises(aukit.LuaError, match="Unsupported compression scheme"):
+        aukit.aiff(_aiff(1, n, 8, 8000, g, b"ima4"))
+    with pytest.raises(aukit.LuaError, match="not an AIFF file"):
+        aukit.aiff(b"RIFF" + b"\0" * 40)
+    # AU: header 24 bytes (+ annotation); the offset field is used as a 1-based index (a file written with offset = 24 loses no byte
+    # only if the writer meant 25), size 0xFFFFFFFF = to the end
+    for enc, bits, dt in ((2, 8, oracle.SIGNED), (3, 16, oracle.SIGNED), (4, 24, oracle.SIGNED), (5, 32, oracle.SIGNED), (6, 32, oracle.FLOAT)):
+        raw = rng.uniform(-1, 1, n * 2).astype(">f4").tobytes() if enc == 6 else bytes(rng.integers(0, 256, n * 2 * (bits // 8), dtype=np.uint8))
+        for size in (len(raw), 0xFFFFFFFF):
+            au = b".snd" + struct.pack(">IIIII", 29, size, enc, 16000, 2) + b"anno" + raw
+            a = aukit.au(au)
+            ref = oracle.pcm(raw, bits, dt, 2, 16000, True, True)
+            for c in range(2):
+                assert np.array_equal(a.data[c], ref.data[c]), (enc, size)
+    for enc, ul in ((1, True), (27, False)):
+        a = aukit.au(b".snd" + struct.pack(">IIIII", 25, len(g), enc, 8000, 1) + g)
+        assert np.array_equal(a.data[0], oracle.g711(g, ul, 1, 8000).data[0])
+    with pytest.raises(aukit.LuaError, match="unsupported encoding type 23"):
+        aukit.au(b".snd" + struct.pack(">IIIII", 25, 4, 23, 8000, 1) + b"\0" * 4)
+    # stream.aiff / stream.au dispatch to the same stream kernels
+    aukit.defaultInterpolation = "linear"
+    it, length = aukit.stream.aiff(_aiff(1, n, 16, 22050, x[:2 * n]))
+    got = np.concatenate([c[0] for c, _ in it])
+    ref = oracle.stream_pcm(x[:2 * n], 16, oracle.SIGNED, 1, 22050, True, False, oracle.LINEAR)
+    assert np.max(np.abs(got - ref.data[0])) <= 1e-13
