@@ -387,3 +387,34 @@ def test_fuzz_mdfpwm(ctx, oracle, seed):
             assert ck.nchunks[i] == o.nchunks and ck.status[i] == o.final_status, (i, mono)
             for c in range(o.channels):
                 assert np.array_equal(g[i][c], o.data[c]), (i, mono, c)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_multichannel_streams(ctx, oracle, seed):
+    """stream.g711 and stream.dfpwm with 2-3 channels, with and without `mono` (Q11, Q13: the reference-order kernels)"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9700 + seed))
+    ch = int(rng.integers(2, 4))
+    mono = bool(rng.integers(0, 2))
+    interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
+    rate = int(rng.choice([8000, 11025, 16000, 24000, 48000]))
+    ulaw = bool(rng.integers(0, 2))
+    streams = [bytes(rng.integers(0, 256, n * ch, dtype=np.uint8)) for n in (1, 7, rate // 2 + 3, rate + 11, 2 * rate + 1)]
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_G711, ch, rate, ulaw=ulaw), interp, mono=mono, dtype=N.I8)
+    g = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_g711(s, ulaw, ch, rate, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ch, mono, interp, rate, i)
+        for c in range(ref.channels):
+            assert np.array_equal(g[i][c], ref.data[c]), (ch, mono, interp, rate, i, c)
+    dstreams = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (3 * ch, 6000 * ch, 6000 * ch + ch, 13000 * ch)]
+    bd = B.Batch.upload(ctx, dstreams)
+    drate = int(rng.choice([48000, 24000, 44100]))
+    out, ck = B.stream_decode(ctx, bd, B.make_desc(N.CODEC_DFPWM, ch, drate), "linear" if interp == "none" else interp, mono=mono, dtype=N.F64)
+    a = out.download()
+    for i, s in enumerate(dstreams):
+        ref = oracle.stream_dfpwm(s, drate, ch, mono, oracle.INTERP["linear" if interp == "none" else interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ch, mono, drate, i)
+        for c in range(ref.channels):
+            assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-13, (ch, mono, drate, i, c)
