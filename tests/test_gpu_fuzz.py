@@ -130,7 +130,7 @@ def test_fuzz_dfpwm_paths(ctx, oracle, seed):
         assert np.max(np.abs(a[i][0] - ref.data[0]), initial=0) <= 1e-13, (rate, len(s))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(24))
 def test_fuzz_ima_stream(ctx, oracle, seed):
     """stream.adpcm over random block sizes / channel counts / rates, full-scale random PCM (saturating predictors), ragged tails:
     chunk bookkeeping and every floored output equal to the oracle's"""
@@ -159,7 +159,7 @@ def test_fuzz_ima_stream(ctx, oracle, seed):
             assert np.array_equal(got[i][c], ref.data[c]), (ba, ch, rate, interp, mono, i, c)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(24))
 def test_fuzz_flac(ctx, oracle, seed):
     """FLAC files of random depth / channels / block size / length (the oracle's encoder picks predictor orders and Rice parameters
     per block) through the loader (lossless), the resampled f32 pipeline and stream.flac"""
@@ -199,7 +199,7 @@ def test_fuzz_flac(ctx, oracle, seed):
             assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-12, (depth, ch, bs, rate, i, c)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(20))
 def test_fuzz_msadpcm(ctx, oracle, seed):
     B, N = _B(), _N()
     rng = np.random.Generator(np.random.PCG64(6000 + seed))
@@ -231,7 +231,7 @@ def test_fuzz_msadpcm(ctx, oracle, seed):
             assert np.array_equal(g[i][c][ok], ref.data[c][ok]), (ba, ch, rate, interp, mono, i, c)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(16))
 def test_fuzz_qoa(ctx, oracle, seed):
     B, N = _B(), _N()
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
