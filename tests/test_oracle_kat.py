@@ -301,3 +301,53 @@ def test_cubic_interpolation_by_hand(oracle):
     assert oracle.interp(oracle.CUBIC, d, 2.5) == exp
     assert oracle.interp(oracle.CUBIC, d, 1.5) == (-0.5 * 0 + 1.5 * 0 - 1.5 * 1 + 0.5 * 4) * 0.125 + (0 - 0 + 2 - 2) * 0.25 + (0 + 0.5) * 0.5 + 0  # p0 := p1 at the left edge
     assert oracle.interp(oracle.LINEAR, d, 5.25) == 16.0  # data[ffx+1] or data[ffx]
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_q14_stream_flac_history_is_shared_across_channels_and_one_sample_blocks(oracle, interp):
+    """stream.flac (aukit.lua:3157-3188) transliterated line by line in Python and run next to the C oracle on a stereo file whose
+    last frame holds ONE sample: `last` is shared by the channels (channel 2 of a frame sees channel 1's tail) and for a block with
+    #src == 1, `last = {src[#src-1], src[#src]}` picks up the block's own injected src[0].  (The random sweeps on the GPU found the
+    HIP path wrong exactly here; this pins the oracle it was checked against.)"""
+    import math
+    rng = np.random.Generator(np.random.PCG64(77))
+    rate, bs, ch, depth = 22050, 192, 2, 16
+    n = 3 * bs + 1
+    x = rng.integers(-20000, 20000, (n, ch)).astype(np.int64)
+    ref = oracle.stream_flac(oracle.gen_flac(x.ravel(), ch, depth, rate, bs), oracle.INTERP[interp])
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def interpolate(src, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "linear":
+            a, b = src.get(ffx), src.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx                                     # :257-260
+        p0, p1, p2, p3 = src.get(ffx - 1), src.get(ffx), src.get(ffx + 1), src.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1  # :261-266
+
+    ratio = 48000 / rate
+    alpha = 1 - math.exp(-(rate / 96000) * 2 * math.pi)
+    last, out, pos = [0, 0], [[] for _ in range(ch)], 0
+    while pos < n:
+        nfr = min(bs, n - pos)
+        for c in range(ch):
+            src = {i + 1: float(x[pos + i, c]) / (1 << depth) for i in range(nfr)}                   # :505 (Q14)
+            src[0], src[-1] = last[1], last[0]                                                       # :3170-3171
+            ls = last[1] / (128 if last[1] < 0 else 127)
+            for i in range(1, math.floor(nfr * ratio) + 1):
+                xx = ((i - 1) / ratio) + 1
+                s = src[int(xx)] if xx % 1 == 0 else interpolate(src, xx)
+                s = ls + alpha * (s - ls)
+                ls = s
+                out[c].append(clamp(s * (128 if s < 0 else 127), -128, 127))
+            last = [src[nfr - 1], src[nfr]]                                                          # :3183
+        pos += nfr
+    for c in range(ch):
+        assert len(out[c]) == len(ref.data[c])
+        assert np.max(np.abs(np.array(out[c]) - ref.data[c])) <= 1e-12
