@@ -351,3 +351,99 @@ def test_q14_stream_flac_history_is_shared_across_channels_and_one_sample_blocks
     for c in range(ch):
         assert len(out[c]) == len(ref.data[c])
         assert np.max(np.abs(np.array(out[c]) - ref.data[c])) <= 1e-12
+
+
+_IMA_INDEX = [-1, -1, -1, -1, 2, 4, 6, 8] * 2
+_IMA_STEP = [7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97, 107, 118, 130, 143, 157, 173, 190, 209,
+             230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060, 1166, 1282, 1411, 1552, 1707, 1878, 2066, 2272, 2499, 2749,
+             3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484, 7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385,
+             24623, 27086, 29794, 32767]  # the standard IMA tables (aukit.lua:156-171)
+
+
+@pytest.mark.parametrize("ch,ba,mono,interp", [(1, 36, False, "cubic"), (1, 68, False, "linear"), (2, 72, False, "cubic"), (2, 72, True, "linear"), (2, 136, True, "cubic")])
+def test_q6_stream_adpcm_transliterated(oracle, ch, ba, mono, interp):
+    """stream.adpcm in string mode (aukit.lua:2771-2831) transliterated line by line — inclusive word loop (junk word after every
+    non-final block, last word of the final block dropped), history written to the outer table (no effect), upvalue `newlen` that
+    stays shrunk, unmasked header index, Q5 nibble expansion, Q7 scaling — next to the C oracle, chunk for chunk."""
+    import math
+    import struct as st
+    rng = np.random.Generator(np.random.PCG64(ba + ch))
+    rate = 22050
+    spb = (ba - 4 * ch) * 2 // ch
+    pcm = rng.integers(-9000, 9000, spb * 9 * ch).astype(np.int16)
+    data = oracle.gen_ima(pcm, ch, ba, 88)
+    data = data[: ba * 8 + ba // 2]  # a short final block
+    ref = oracle.stream_adpcm(data, ba, ch, rate, mono, oracle.INTERP[interp])
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def length(t):  # Lua's # on a table filled from 1 upwards
+        k = 0
+        while (k + 1) in t:
+            k += 1
+        return k
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "linear":
+            a, b = t.get(ffx), t.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx
+        p0, p1, p2, p3 = t.get(ffx - 1), t.get(ffx), t.get(ffx + 1), t.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    ratio = 48000 / rate
+    n = 1
+    samples_per_block = (ba - 4 * ch) * 2 / ch
+    bytes_per_second = ba * math.ceil(rate / samples_per_block)
+    newlen = math.floor(samples_per_block * ratio)
+    chunks = []
+    while True:
+        target = n + bytes_per_second
+        retval = [[] for _ in range(1 if mono else ch)]
+        while n < target:
+            if n + ch * 4 > len(data):
+                break
+            d = [dict() for _ in range(ch)]
+            predictor = [st.unpack_from("<h", data, n - 1 + i * 4)[0] for i in range(ch)]
+            step_index = [data[n - 1 + i * 4 + 2] for i in range(ch)]
+            i = ch * 4
+            while i <= ba:
+                p = (i - ch * 4) // ch * 2 + 1
+                if len(data) < n + i + ch * 4:
+                    break
+                for j in range(ch):
+                    num = st.unpack_from("<I", data, n - 1 + i + j * 4)[0]
+                    for k in range(8):
+                        nibble = (num >> (4 * k)) & 15
+                        step = _IMA_STEP[step_index[j]]
+                        step_index[j] = clamp(step_index[j] + _IMA_INDEX[nibble], 0, 88)
+                        diff = (((nibble % 8) * step) >> 2) + (step >> 3)
+                        predictor[j] = clamp(predictor[j] - diff, -32768, 32767) if nibble >= 8 else clamp(predictor[j] + diff, -32768, 32767)
+                        d[j][p + k] = predictor[j] / (128 if predictor[j] < 0 else 127)
+                i += ch * 4
+            if length(d[0]) < samples_per_block:
+                newlen = math.floor(length(d[0]) * ratio)
+            for i in range(1, newlen + 1):
+                xx = (i - 1) / ratio + 1
+                c = [d[j][int(xx)] if xx % 1 == 0 else interpolate(d[j], xx) for j in range(ch)]
+                if mono:
+                    acc = 0
+                    for j in range(ch):
+                        acc = acc + c[j]
+                    retval[0].append(clamp(math.floor(acc / ch), -128, 127))
+                else:
+                    for j in range(ch):
+                        retval[j].append(clamp(math.floor(c[j]), -128, 127))
+            n += ba
+        if not retval[0]:
+            break
+        chunks.append(retval)
+    assert len(chunks) == ref.nchunks
+    assert [len(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
+    for c in range(ref.channels):
+        assert np.array_equal(np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks]), ref.data[c]), c
