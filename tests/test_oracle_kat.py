@@ -447,3 +447,110 @@ def test_q6_stream_adpcm_transliterated(oracle, ch, ba, mono, interp):
     assert [len(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
     for c in range(ref.channels):
         assert np.array_equal(np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks]), ref.data[c]), c
+
+
+@pytest.mark.parametrize("ch,mono,interp,rate", [(1, False, "cubic", 44100), (1, False, "linear", 8000), (2, False, "cubic", 22050), (2, True, "linear", 44100), (2, True, "cubic", 32000)])
+def test_q1_q2_q3_stream_pcm_transliterated(oracle, ch, mono, interp, rate):
+    """aukit.stream.pcm on a 16-bit signed string (aukit.lua:2228-2424) transliterated line by line: the lazy `__index` tables that
+    hand out the NEXT stream sample whatever index is asked (Q3), the eager prefill, the 2-tap low-pass on the raw previous sample
+    with `ls` restarting at 0 (Q2), the window re-base that keeps d[-1], d[0] (Q1), end of data as an error inside pcall (truncated
+    last chunk) or in the prefill (the iterator raises) — next to the C oracle, chunk for chunk."""
+    import math
+    rng = np.random.Generator(np.random.PCG64(rate + ch))
+    nfr = rate * 2 + 100
+    pcm = rng.integers(-32768, 32768, nfr * ch).astype("<i2")
+    ref = oracle.stream_pcm(pcm.tobytes(), 16, oracle.SIGNED, ch, rate, False, mono, oracle.INTERP[interp])
+
+    class LuaError(Exception):
+        pass
+
+    state = {"pos": 0}
+
+    def read():
+        if state["pos"] >= len(pcm):
+            raise LuaError("attempt to compare nil with number")  # s = tmp[pos] is nil, `s < 0` raises
+        s = int(pcm[state["pos"]])
+        state["pos"] += 1
+        return s / (32768 if s < 0 else 32767)
+
+    if ch == 1:
+        mono = False  # :2243
+
+    class Lazy(dict):
+        def __missing__(self, i):  # the __index metamethod :2367-2371
+            if mono:
+                v = 0
+                for _ in range(ch):
+                    v = v + read()
+                v = v / ch
+            else:
+                v = read()
+            self[i] = v
+            return v
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        if interp == "linear":
+            a = t[ffx]
+            b = t[ffx + 1]
+            return a + (b - a) * (xx - ffx)
+        p0, p1, p2, p3, fx = t[ffx - 1], t[ffx], t[ffx + 1], t[ffx + 2], xx - ffx  # in this order: each miss reads the stream
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    def length(t):
+        k = 0
+        while (k + 1) in t:
+            k += 1
+        return k
+
+    nd = 1 if mono else ch
+    d = [Lazy() for _ in range(nd)]
+    ratio = 48000 / rate
+    alpha = 1 - math.exp(-(rate / 96000) * 2 * math.pi)
+    istart, iend = {"linear": (1, 2), "cubic": (0, 3)}[interp]
+    n, ok, chunks, raised = 0, True, [], False
+    while ok:
+        try:
+            for i in range(istart if n == 0 else 1, iend + 1):  # the prefill :2376-2386 (outside pcall)
+                if mono:
+                    s = 0
+                    for _ in range(ch):
+                        s = s + read()
+                    dict.__setitem__(d[0], i, s / ch)
+                else:
+                    for j in range(nd):
+                        dict.__setitem__(d[j], i, read())
+        except LuaError:
+            raised = True
+            break
+        chunk = [dict() for _ in range(nd)]
+        try:
+            ls = [0.0] * nd  # chunk[y][0] is always nil
+            for i in range(1, 48001):
+                for y in range(nd):
+                    xx = ((i - 1) / ratio) + 1
+                    s = d[y][int(xx)] if xx % 1 == 0 else interpolate(d[y], xx)
+                    ns = ls[y] + alpha * (s - ls[y])
+                    chunk[y][i] = clamp(ns * (128 if ns < 0 else 127), -128, 127)
+                    ls[y] = s
+        except LuaError:
+            ok = False
+        if length(chunk[0]) == 0:
+            break
+        n += length(chunk[0])
+        for y in range(nd):
+            l = length(d[y])
+            l2, l1 = d[y].get(l - 1), d[y].get(l)
+            d[y] = Lazy()
+            dict.__setitem__(d[y], -1, l2)
+            dict.__setitem__(d[y], 0, l1)
+        chunks.append(chunk)
+    assert len(chunks) == ref.nchunks
+    assert [length(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
+    assert raised == (ref.final_status != 0)
+    for y in range(nd):
+        got = np.array([c[y][i] for c in chunks for i in range(1, length(c[y]) + 1)])
+        assert np.max(np.abs(got - ref.data[y][:len(got)])) <= 1e-12, y
