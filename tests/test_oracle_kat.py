@@ -554,3 +554,65 @@ def test_q1_q2_q3_stream_pcm_transliterated(oracle, ch, mono, interp, rate):
     for y in range(nd):
         got = np.array([c[y][i] for c in chunks for i in range(1, length(c[y]) + 1)])
         assert np.max(np.abs(got - ref.data[y][:len(got)])) <= 1e-12, y
+
+
+@pytest.mark.parametrize("ch,mono,ulaw,interp,rate", [(1, False, True, "cubic", 8000), (1, False, False, "linear", 11025), (2, True, True, "cubic", 8000), (3, False, False, "linear", 16000), (2, True, False, "none", 8000)])
+def test_q13_stream_g711_transliterated(oracle, ch, mono, ulaw, interp, rate):
+    """aukit.stream.g711 on a string (aukit.lua:2863-2911) transliterated: per-call slices of sampleRate * channels bytes, the G.711
+    expansion with its ±0x40 divisor, independent chunks (the history copy lands in the outer table), floor + clamp, mono mean."""
+    import math
+    rng = np.random.Generator(np.random.PCG64(rate + 10 * ch))
+    data = bytes(rng.integers(0, 256, rate * ch * 2 + 37 * ch, dtype=np.uint8))
+    ref = oracle.stream_g711(data, ulaw, ch, rate, mono, oracle.INTERP[interp])
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "none":
+            return t.get(ffx)
+        if interp == "linear":
+            a, b = t.get(ffx), t.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx
+        p0, p1, p2, p3 = t.get(ffx - 1), t.get(ffx), t.get(ffx + 1), t.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    xor = 0xFF if ulaw else 0x55
+    ratio = 48000 / rate
+    pos, outs = 1, [[] for _ in range(1 if mono else ch)]
+    lens = []
+    for _ in range(ref.nchunks):
+        sl = data[pos - 1: pos - 1 + rate * ch]
+        pos += rate * ch
+        tabs = [dict() for _ in range(ch)]
+        for k, byte in enumerate(sl):  # k = i + j - 2
+            b = byte ^ xor
+            m, e = b & 0x0F, (b >> 4) & 7
+            m = m * 4 + 2 if (not ulaw and e == 0) else (m * 2 + 33) << e
+            if ulaw:
+                m -= 33
+            tabs[k % ch][k // ch + 1] = m / (-0x40 if (bool(b & 0x80) == ulaw) else 0x40)
+        n1 = 0
+        while (n1 + 1) in tabs[0]:
+            n1 += 1
+        newlen = math.floor(n1 * ratio)
+        lens.append(newlen)
+        for i in range(1, newlen + 1):
+            xx = (i - 1) / ratio + 1
+            c = [tabs[j][int(xx)] if xx % 1 == 0 else interpolate(tabs[j], xx) for j in range(ch)]
+            if mono:
+                acc = 0
+                for j in range(ch):
+                    acc = acc + c[j]
+                outs[0].append(clamp(math.floor(acc / ch), -128, 127))
+            else:
+                for j in range(ch):
+                    outs[j].append(clamp(math.floor(c[j]), -128, 127))
+    assert lens == list(ref.chunk_len[:, 0])
+    for c in range(len(outs)):
+        assert np.array_equal(np.array(outs[c], dtype=np.float64), ref.data[c]), c
