@@ -616,3 +616,67 @@ def test_q13_stream_g711_transliterated(oracle, ch, mono, ulaw, interp, rate):
     assert lens == list(ref.chunk_len[:, 0])
     for c in range(len(outs)):
         assert np.array_equal(np.array(outs[c], dtype=np.float64), ref.data[c]), c
+
+
+@pytest.mark.parametrize("ch,mono,interp,rate", [(1, False, "linear", 48000), (1, False, "cubic", 24000), (2, False, "linear", 44100), (2, True, "cubic", 32000), (3, True, "linear", 48000)])
+def test_q10_q11_stream_dfpwm_transliterated(oracle, ch, mono, interp, rate):
+    """aukit.stream.dfpwm on a string (aukit.lua:2446-2493) transliterated around the oracle's decoder object (the codec arithmetic
+    itself is the unpinned part): slices of 6000 * channels + 1 bytes advanced by 6000 * channels (Q10), audio[0] = the previous
+    slice's last sample, `x` that ignores the channel index and the stride of `channels` over a fractional `newlen` (Q11), clamp on
+    the interpolated branch only, mono mean."""
+    import math
+    rng = np.random.Generator(np.random.PCG64(rate + ch))
+    data = bytes(rng.integers(0, 256, 6000 * ch * 2 + 777 * ch, dtype=np.uint8))
+    ref = oracle.stream_dfpwm(data, rate, ch, mono, oracle.INTERP[interp])
+    if ch == 1:
+        mono = False
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "linear":
+            a, b = t.get(ffx), t.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx
+        p0, p1, p2, p3 = t.get(ffx - 1), t.get(ffx), t.get(ffx + 1), t.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    dec = oracle.DfpwmDecoder()
+    pos, last, chunks, positions = 1, 0, [], []
+    while pos <= len(data):
+        d = data[pos - 1: pos + 6000 * ch]
+        a = dec(d)
+        if len(a) == 0:
+            break
+        audio = {i + 1: float(v) for i, v in enumerate(a)}
+        audio[0], last = last, audio[len(a)]
+        ratio = 48000 / rate
+        newlen = len(a) * ratio
+        lines = [dict() for _ in range(1 if mono else ch)]
+        i = 1
+        while i <= newlen:
+            n = 0
+            for j in range(ch):
+                xx = (i - 1) / ratio + 1
+                s = audio[int(xx)] if xx % 1 == 0 else clamp(interpolate(audio, xx), -128, 127)
+                if mono:
+                    n = n + s
+                else:
+                    lines[j][math.ceil(i / ch)] = s
+            if mono:
+                lines[0][math.ceil(i / ch)] = n / ch
+            i += ch
+        chunks.append(lines)
+        positions.append(pos * 8 / rate / ch)
+        pos += 6000 * ch
+    assert len(chunks) == ref.nchunks
+    assert np.array_equal(np.array(positions), ref.chunk_pos)
+    for c in range(ref.channels):
+        got = np.array([k[c][i] for k in chunks for i in range(1, len(k[c]) + 1)])
+        assert [len(k[c]) for k in chunks] == list(ref.chunk_len[:, 0])
+        assert np.max(np.abs(got - ref.data[c]), initial=0) <= 1e-12, c
