@@ -680,3 +680,49 @@ def test_q10_q11_stream_dfpwm_transliterated(oracle, ch, mono, interp, rate):
         got = np.array([k[c][i] for k in chunks for i in range(1, len(k[c]) + 1)])
         assert [len(k[c]) for k in chunks] == list(ref.chunk_len[:, 0])
         assert np.max(np.abs(got - ref.data[c]), initial=0) <= 1e-12, c
+
+
+def test_dfpwm_codec_against_the_published_text(oracle):
+    """DFPWM1a written out from the published description (SURVEY §8c: PREC = 10, strength floor 8, anti-jerk, low-pass 140/256;
+    encoder bit = v > charge or (v == charge and v == 127)) in plain Python, next to the C oracle's decoder and encoder on random
+    bytes / random samples — the arithmetic stays "parity unpinned" (no reference copy of cc.audio.dfpwm exists here), but the three
+    statements of it (this one, ork_codecs.c, dfpwm_dev.h via tests/test_host_math.py) agree."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+
+    class Pred:
+        def __init__(self):
+            self.charge, self.strength, self.prev = 0, 0, False
+
+        def step(self, bit):
+            target = 127 if bit else -128
+            nxt = self.charge + ((self.strength * (target - self.charge) + 512) >> 10)
+            if nxt == self.charge and nxt != target:
+                nxt += 1 if bit else -1
+            z = 1023 if bit == self.prev else 0
+            if self.strength != z:
+                self.strength += 1 if bit == self.prev else -1
+            if self.strength < 8:
+                self.strength = 8
+            self.charge, self.prev = nxt, bit
+            return nxt
+
+    data = bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"\xff" * 40 + b"\x00" * 40 + b"\xaa" * 40
+    p, lpf, pcharge, pbit, out = Pred(), 0, 0, False, []
+    for byte in data:
+        for k in range(8):
+            bit = bool((byte >> k) & 1)
+            charge = p.step(bit)
+            aj = (charge + pcharge + 1) >> 1 if bit != pbit else charge
+            pcharge, pbit = charge, bit
+            lpf += ((aj - lpf) * 140 + 0x80) >> 8
+            out.append(lpf)
+    assert np.array_equal(np.array(out, dtype=np.int8), oracle.DfpwmDecoder()(data))
+
+    samples = np.concatenate([rng.integers(-128, 128, 8000), np.full(200, 127), np.full(200, -128), np.zeros(200, dtype=np.int64)])
+    e, bits = Pred(), []
+    for v in samples:
+        bit = bool(v > e.charge or (v == e.charge and v == 127))
+        e.step(bit)
+        bits.append(bit)
+    packed = bytes(sum(int(b) << k for k, b in enumerate(bits[i:i + 8])) for i in range(0, len(bits), 8))
+    assert packed == oracle.dfpwm_encode(samples.astype(np.float64))
