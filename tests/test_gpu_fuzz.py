@@ -418,3 +418,40 @@ def test_fuzz_multichannel_streams(ctx, oracle, seed):
         assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (ch, mono, drate, i)
         for c in range(ref.channels):
             assert np.max(np.abs(a[i][c] - ref.data[c]), initial=0) <= 1e-13, (ch, mono, drate, i, c)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_mix_encode_dfpwm(ctx, oracle, seed):
+    """Audio:mix over 2-4 audios of different lengths and channel counts (zero padding, clamp of sum * amplifier), Audio:pcm in every
+    depth / type / layout and Audio:dfpwm (interleaved or channel after channel) on the result — exact"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9900 + seed))
+    k = int(rng.integers(2, 5))
+    nstreams = 3
+    auds, refs = [], [[] for _ in range(nstreams)]
+    for _ in range(k):
+        ch = int(rng.integers(1, 4))
+        per_stream = []
+        for s in range(nstreams):
+            n = int(rng.integers(1, 3000))
+            per_stream.append([rng.uniform(-1, 1, n) for _ in range(ch)])
+            refs[s].append(oracle.Audio(per_stream[-1], 48000))
+        auds.append(B.AudioBatch.upload(ctx, per_stream, 48000, dtype=N.F64))
+    amp = float(rng.uniform(0.1, 1.5))
+    m = B.mix(ctx, auds, amp)
+    got = m.download()
+    mixed = [oracle.mix(refs[s], amp) for s in range(nstreams)]
+    for s in range(nstreams):
+        assert len(got[s]) == mixed[s].channels
+        for c in range(mixed[s].channels):
+            assert np.array_equal(got[s][c], mixed[s].data[c]), (k, amp, s, c)
+    bits = int(rng.choice([8, 16, 24, 32]))
+    dt = ["signed", "unsigned"][int(rng.integers(0, 2))]
+    inter = bool(rng.integers(0, 2))
+    enc = B.encode_pcm(ctx, m, bits, dt, inter).download()
+    for s in range(nstreams):
+        ref = oracle.encode_pcm(mixed[s], bits, {"signed": oracle.SIGNED, "unsigned": oracle.UNSIGNED}[dt], inter)
+        assert np.array_equal(np.asarray(enc[s][0]), ref), (bits, dt, inter, s)
+    df = B.dfpwm_encode(ctx, m, inter).download()
+    for s in range(nstreams):
+        assert df[s] == oracle.audio_dfpwm(mixed[s], inter), (inter, s)
