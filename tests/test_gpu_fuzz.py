@@ -455,3 +455,52 @@ def test_fuzz_mix_encode_dfpwm(ctx, oracle, seed):
     df = B.dfpwm_encode(ctx, m, inter).download()
     for s in range(nstreams):
         assert df[s] == oracle.audio_dfpwm(mixed[s], inter), (inter, s)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_flac_corrupted(ctx, oracle, seed):
+    """FLAC files with a few random bytes overwritten or cut short after the metadata: whatever decodeFLAC does with them — decode
+    garbage, lose sync, raise — the stream (errors swallowed, it just ends) must deliver the same chunks as the oracle, and the
+    loader must raise exactly when the oracle does, with the same samples otherwise"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9950 + seed))
+    ch = int(rng.integers(1, 3))
+    bs = int(rng.choice([192, 576, 1152, 4096]))
+    n = int(rng.integers(2 * bs, 6 * bs))
+    t = np.arange(n)[:, None] / 44100
+    x = np.clip(np.round(9000 * np.sin(2 * np.pi * np.array([440.0, 557.0][:ch]) * t) + rng.integers(-900, 900, (n, ch))), -32768, 32767).astype(np.int64)
+    good = oracle.gen_flac(x.ravel(), ch, 16, 44100, bs)
+    files = []
+    for _ in range(4):
+        b = bytearray(good)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:    # overwrite 1-3 bytes somewhere in the frames
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(60, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 1:  # cut the file short
+            b = b[: int(rng.integers(60, len(b)))]
+        else:            # flip one bit
+            p = int(rng.integers(60, len(b)))
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        files.append(bytes(b))
+    desc = B.make_desc(N.CODEC_FLAC)
+    for f in files:  # one file per call: a loader error concerns the whole batch
+        bt = B.Batch.upload(ctx, [f])
+        try:
+            ref = oracle.flac(f)
+        except Exception:
+            ref = None
+        try:
+            got = B.decode(ctx, bt, desc, dtype=N.F64).download()[0]
+        except N.AukitError:
+            got = None
+        assert (ref is None) == (got is None), (ch, bs, len(f))
+        if ref is not None:
+            for c in range(ref.channels):
+                assert np.array_equal(got[c], ref.data[c]), (ch, bs, c)
+        rs = oracle.stream_flac(f, oracle.LINEAR)
+        out, ck = B.stream_decode(ctx, bt, desc, "linear", dtype=N.F64)
+        a = out.download()[0]
+        assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0]), (ch, bs, len(f))
+        for c in range(rs.channels):
+            assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (ch, bs, c)
