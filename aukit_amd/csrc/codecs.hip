@@ -600,6 +600,29 @@ static int launch_ima_stream(aukit_ctx *ctx, int interp, const ImaStreamParams &
 }
 
 // aukit.stream.adpcm(input, blockAlign, channels, sampleRate, mono)  aukit.lua:2753-2835
+// First block of every stream whose header carries a step index above 88 and that decodes at least one word: the reference
+// indexes ima_step_table with it unmasked (:2799, :2807) and the iterator call that reaches the block dies with "attempt to perform
+// arithmetic on a nil value" — the chunks of earlier calls were delivered, that call's is not.  One wave per stream.
+__global__ __launch_bounds__(64) void k_ima_scan_headers(const unsigned char *src, const unsigned long long *off, unsigned n, int C, unsigned long long ba,
+                                                        unsigned *first_bad) {
+    const unsigned s = blockIdx.x;
+    if (s >= n) return;
+    const unsigned long long nbytes = off[s + 1] - off[s];
+    const unsigned long long nblk = nbytes >= 4ull * C + 1 ? (nbytes - 4ull * C - 1) / ba + 1 : 0;
+    unsigned best = 0xFFFFFFFFu;
+    for (unsigned long long bi = threadIdx.x; bi < nblk && bi < 0xFFFFFFFFull; bi += 64) {
+        const unsigned long long b0 = bi * ba, rem = nbytes - b0;
+        const long long ng = (long long)((rem - 1) / (4ull * C)) - 1;  // word groups decoded (:2800-2802), capped elsewhere; > 0 is all that matters here
+        if (ng <= 0) continue;
+        const unsigned char *blk = src + off[s] + b0;
+        bool bad = false;
+        for (int c = 0; c < C; c++) bad = bad || blk[4 * c + 2] > 88;
+        if (bad) best = min(best, (unsigned)bi);
+    }
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    if (threadIdx.x == 0) first_bad[s] = best;
+}
+
 static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                       aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -624,14 +647,28 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     std::vector<uint64_t> lens(in->n, 0), blk0(in->n + 1, 0);
     std::vector<std::vector<uint32_t>> clen(in->n);
     std::vector<std::vector<double>> cpos(in->n);
+    std::vector<unsigned> first_bad(in->n, 0xFFFFFFFFu);
+    if (in->n) {  // which streams die on a header index above 88, and where
+        int rc0 = ctx->misc_buf.ensure((size_t)in->n * 4 + 16);
+        if (rc0) { delete ck; return rc0; }
+        unsigned *dfb = reinterpret_cast<unsigned *>(ctx->misc_buf.p);
+        hipLaunchKernelGGL(k_ima_scan_headers, dim3(in->n), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), in->n, C,
+                           (unsigned long long)ba, dfb);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(first_bad.data(), dfb, (size_t)in->n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "stream.adpcm header scan failed"); }
+    }
     for (uint32_t s = 0; s < in->n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
         ck->length_seconds[s] = (double)nb / (double)ba * spb / d->sample_rate;   // :2834
         // blocks processed: while n + 4C <= #data (1-based n)  :2794
         const uint64_t nblk = nb >= 4ull * C + 1 ? (nb - 4ull * C - 1) / ba + 1 : 0;
-        blk0[s + 1] = blk0[s] + nblk;
+        // a bad header kills the iterator call that reaches it: only the calls before that one deliver
+        const uint64_t calls_ok = first_bad[s] == 0xFFFFFFFFu ? ~0ull : (uint64_t)first_bad[s] / std::max<uint64_t>(ips, 1);
+        if (calls_ok != ~0ull) ck->status[s] = AUKIT_E_LUA;  // "attempt to perform arithmetic on a nil value (field '?')"
+        blk0[s + 1] = blk0[s] + (calls_ok == ~0ull ? nblk : std::min<uint64_t>(nblk, calls_ok * ips));
         uint64_t done = 0;
-        for (;;) {  // one iterator call = up to iterPerSecond blocks
+        for (uint64_t call = 0;; call++) {  // one iterator call = up to iterPerSecond blocks
+            if (call == calls_ok) break;
             const uint64_t take = std::min<uint64_t>(ips, nblk - done);
             // every block but the stream's last sees at least blockAlign + 4C more bytes — all its word groups plus the junk word (Q6) —
             // and yields newlen_full outputs; only the last block needs the arithmetic of :2800-2802 / :2817

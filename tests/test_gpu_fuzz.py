@@ -504,3 +504,46 @@ def test_fuzz_flac_corrupted(ctx, oracle, seed):
         assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0]), (ch, bs, len(f))
         for c in range(rs.channels):
             assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (ch, bs, c)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_ima_random_bytes(ctx, oracle, seed):
+    """stream.adpcm / aukit.wav's IMA path on RANDOM bytes: header step indices above 88 (the stream uses them unmasked and dies with a
+    Lua error in the middle of a call, aukit.wav masks mono ones with 0x0F), saturating predictors, partial blocks"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9990 + seed))
+    ch = int(rng.integers(1, 3))
+    ba = int(rng.choice([36, 260, 512] if ch == 1 else [72, 264, 512]))
+    rate = int(rng.choice([11025, 22050, 44100]))
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    mono = bool(ch == 2 and rng.integers(0, 2))
+    streams = []
+    for nb in (1, 3, int(rng.integers(5, 40))):
+        raw = bytearray(rng.integers(0, 256, ba * nb + int(rng.integers(0, ba)), dtype=np.uint8).tobytes())
+        if rng.integers(0, 2):  # keep most header indices legal so that some streams survive for a while
+            for b in range(0, len(raw) - 4 * ch, ba):
+                for c in range(ch):
+                    raw[b + 4 * c + 2] %= 89
+        streams.append(bytes(raw))
+    desc = B.make_desc(N.CODEC_ADPCM_WAV, ch, rate, block_align=ba)
+    for s in streams:  # one stream per call: statuses are per stream, loader errors per batch
+        bt = B.Batch.upload(ctx, [s])
+        ref = oracle.stream_adpcm(s, ba, ch, rate, mono, oracle.INTERP[interp])
+        out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.I8)
+        g = out.download()[0]
+        assert ck.nchunks[0] == ref.nchunks and ck.status[0] == ref.final_status, (ba, ch, rate, len(s))
+        assert list(ck.lens[0][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        for c in range(ref.channels):
+            assert np.array_equal(g[c], ref.data[c]), (ba, ch, rate, c)
+        try:
+            ra = oracle.wav_adpcm(s, ba, ch, rate)
+        except Exception:
+            ra = None
+        try:
+            ga = B.decode(ctx, bt, desc, dtype=N.F64).download()[0]
+        except N.AukitError:
+            ga = None
+        assert (ra is None) == (ga is None), (ba, ch, len(s))
+        if ra is not None:
+            for c in range(ch):
+                assert np.array_equal(ga[c], ra.data[c]), (ba, ch, c)
