@@ -547,3 +547,60 @@ def test_fuzz_ima_random_bytes(ctx, oracle, seed):
         if ra is not None:
             for c in range(ch):
                 assert np.array_equal(ga[c], ra.data[c]), (ba, ch, c)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_qoa_corrupted(ctx, oracle, seed):
+    """QOA files with overwritten bytes (slices, LMS state, now and then a frame header) or cut short: aukit.qoa raises exactly when
+    the oracle does and decodes the same samples otherwise; stream.qoa delivers the same chunks and ends with the same status"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(9960 + seed))
+    ch = int(rng.integers(1, 3))
+    n = int(rng.integers(5120, 5120 * 4))
+    x = rng.integers(-20000, 20000, n * ch).astype(np.int16)
+    good = oracle.gen_qoa(x, ch, 44100) + b"\0" * 8
+    files = []
+    for _ in range(4):
+        b = bytearray(good)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(16, len(b)))] = int(rng.integers(0, 256))  # payload of the first frame onwards
+        elif kind == 1:
+            b = b[: int(rng.integers(9, len(b)))]
+        elif kind == 2:
+            p = int(rng.integers(8, len(b)))
+            b[p] ^= 1 << int(rng.integers(0, 8))
+        else:
+            b[int(rng.integers(8, 16))] = int(rng.integers(0, 256))  # the first frame header: channels / rate / samples / size
+        files.append(bytes(b))
+    desc = B.make_desc(N.CODEC_QOA)
+    for f in files:
+        bt = B.Batch.upload(ctx, [f])
+        try:
+            ref = oracle.qoa(f)
+        except Exception:
+            ref = None
+        try:
+            got = B.decode(ctx, bt, desc, dtype=N.F64).download()[0]
+        except N.AukitError:
+            got = None
+        assert (ref is None) == (got is None), (ch, len(f))
+        if ref is not None:
+            assert len(got) == ref.channels
+            for c in range(ref.channels):
+                assert np.array_equal(got[c], ref.data[c]), (ch, c)
+        try:
+            rs = oracle.stream_qoa(f, False, oracle.LINEAR)
+        except Exception:
+            rs = None
+        try:
+            out, ck = B.stream_decode(ctx, bt, desc, "linear", dtype=N.F64)
+            a = out.download()[0]
+        except N.AukitError:
+            a = None
+        assert (rs is None) == (a is None), (ch, len(f))
+        if rs is not None:
+            assert ck.nchunks[0] == rs.nchunks and ck.status[0] == rs.final_status and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0]), (ch, len(f))
+            for c in range(rs.channels):
+                assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (ch, c)
