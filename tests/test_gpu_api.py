@@ -169,3 +169,63 @@ def test_aiff_aifc_and_au_containers(ctx, oracle):
     got = np.concatenate([c[0] for c, _ in it])
     ref = oracle.stream_pcm(x[:2 * n], 16, oracle.SIGNED, 1, 22050, True, False, oracle.LINEAR)
     assert np.max(np.abs(got - ref.data[0])) <= 1e-13
+
+
+def test_wav_formats_through_loader_and_stream(ctx, oracle):
+    """every `fmt ` the reference understands (:1473-1503, :2941-2975) through aukit.wav and aukit.stream.wav: MS-ADPCM with its
+    coefficient table, IEEE float, A-law / µ-law, unsigned 8-bit, and WAVE_FORMAT_EXTENSIBLE with the PCM and the DFPWM GUID"""
+    import aukit_amd.aukit as aukit
+    rng = np.random.Generator(np.random.PCG64(11))
+    aukit.defaultInterpolation = "linear"
+
+    def stream_all(w, mono=None):
+        import itertools
+        it, _ = aukit.stream.wav(w, mono)
+        chunks = []
+        for c in itertools.islice(it, 50):  # stream.g711 on a string never returns nil (Q13): stop at the first empty chunk
+            if len(c[0][0]) == 0:
+                break
+            chunks.append(c)
+        return [np.concatenate([c[0][k] for c in chunks]) for k in range(len(chunks[0][0]))]
+
+    # MS-ADPCM, stereo, the standard 7 coefficient pairs in the header
+    ba, ch = 256, 2
+    spb = (ba - 14) + 2
+    ms = oracle.gen_msadpcm(np.stack([pcm16(spb * 20, 22050, 6, c) for c in range(ch)], 1).ravel(), ch, ba)
+    co = [(256, 0), (512, -256), (0, 0), (192, 64), (240, 0), (460, -208), (392, -232)]
+    extra = struct.pack("<HHH", 32, spb, 7) + b"".join(struct.pack("<hh", a, b) for a, b in co)
+    w = _wav(2, ch, 22050, ba, 4, ms, extra)
+    a = aukit.wav(w)
+    ref = oracle.msadpcm(ms, ba, ch, 22050, [[c[0] for c in co], [c[1] for c in co]])
+    for c in range(ch):
+        assert np.array_equal(a.data[c], ref.data[c])
+    rs = oracle.stream_msadpcm(ms, ba, ch, 22050, False, [[c[0] for c in co], [c[1] for c in co]], oracle.LINEAR)
+    got = stream_all(w)
+    for c in range(ch):
+        assert np.array_equal(got[c], rs.data[c])
+    # IEEE float 32, mono
+    fl = rng.uniform(-1, 1, 3000).astype("<f4").tobytes()
+    w = _wav(3, 1, 32000, 4, 32, fl)
+    assert np.array_equal(aukit.wav(w).data[0], oracle.pcm(fl, 32, oracle.FLOAT, 1, 32000).data[0])
+    assert np.max(np.abs(stream_all(w)[0] - oracle.stream_pcm(fl, 32, oracle.FLOAT, 1, 32000, False, False, oracle.LINEAR).data[0])) <= 1e-13
+    # A-law (6) and µ-law (7), stereo, with the mono mix in the stream
+    g = bytes(rng.integers(0, 256, 8000 * 2 + 10, dtype=np.uint8))
+    for fmt, ul in ((6, False), (7, True)):
+        w = _wav(fmt, 2, 8000, 2, 8, g)
+        a = aukit.wav(w)
+        r = oracle.g711(g, ul, 2, 8000)
+        assert np.array_equal(a.data[0], r.data[0]) and np.array_equal(a.data[1], r.data[1])
+        sg = stream_all(w, True)[0]
+        rg = oracle.stream_g711(g, ul, 2, 8000, True, oracle.LINEAR).data[0]
+        assert len(sg) == len(rg) and np.array_equal(sg, rg)
+    # extensible: PCM 16 and DFPWM
+    x = pcm16(2000, 44100, 1, 3).tobytes()
+    ext_pcm = struct.pack("<HHI", 22, 16, 4) + bytes.fromhex("0100000000001000800000aa00389b71")
+    assert np.array_equal(aukit.wav(_wav(0xFFFE, 1, 44100, 2, 16, x, ext_pcm)).data[0], oracle.pcm(x, 16, oracle.SIGNED, 1, 44100).data[0])
+    d = oracle.dfpwm_encode(np.round(np.sin(np.arange(48000) / 17) * 100))
+    ext_df = struct.pack("<HHI", 22, 1, 4) + bytes.fromhex("3ac1fa38811d4361a40dce53ca607cd1")
+    w = _wav(0xFFFE, 1, 48000, 1, 1, d, ext_df)
+    assert np.array_equal(aukit.wav(w).data[0], oracle.dfpwm(d, 1, 48000).data[0])
+    assert np.max(np.abs(stream_all(w)[0] - oracle.stream_dfpwm(d, 48000, 1, False, oracle.LINEAR).data[0])) <= 1e-13
+    with pytest.raises(aukit.LuaError, match="unsupported WAV file"):
+        aukit.wav(_wav(0xFFFE, 1, 48000, 1, 1, d, struct.pack("<HHI", 22, 1, 4) + b"\x55" * 16))
