@@ -26,6 +26,13 @@ AUKIT_DEV float interp_qr_raw(const FastParams &F, const float *tab, unsigned q,
     }
 }
 
+// the previous lane's value (lane 0: `carry`) and lane 63's value without going through the LDS crossbar: __shfl_up / __shfl
+// compile to ds_bpermute_b32; a wave-wide DPP shift (invalid source lane keeps `old`) and a v_readlane do the same in the VALU
+AUKIT_DEV float prev_lane(float s, float carry) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+AUKIT_DEV float last_lane(float s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63)); }
+
 template <int INTERP, int NV>
 __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P, const FastParams F) {
     extern __shared__ float smf[];
@@ -63,9 +70,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
                 const float s = interp_qr_raw<INTERP>(F, tab, q, rem);
-                float prev = __shfl_up(s, 1);
-                if (lane == 0) prev = carry;
-                carry = __shfl(s, 63);
+                const float prev = prev_lane(s, carry);
+                carry = last_lane(s);
                 const float ns = fmaf(alpha, s - prev, prev);                                                   // :2401
                 orow[r * 64 + lane] = __builtin_amdgcn_fmed3f(ns * (ns < 0.f ? 128.f : 127.f), -128.f, 127.f);  // :2402
                 rem += F.dr64;
@@ -78,9 +84,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
         for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
             const unsigned j = rb + lane;
             const float s = interp_row<INTERP, false>(F, tab, cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a);
-            float prev = __shfl_up(s, 1);
-            if (lane == 0) prev = carry;
-            carry = __shfl(s, 63);
+            const float prev = prev_lane(s, carry);
+            carry = last_lane(s);
             const float ns = fmaf(alpha, s - prev, prev);                                                // :2401
             if (j < cur.cnt) orow[j] = fminf(fmaxf(ns * (ns < 0.f ? 128.f : 127.f), -128.f), 127.f);  // :2402
         }

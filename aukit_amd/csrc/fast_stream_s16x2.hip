@@ -35,6 +35,13 @@ AUKIT_DEV float stream_out(float s, float prev, float alpha) {
     return __builtin_amdgcn_fmed3f(ns * (ns < 0.f ? 128.f : 127.f), -128.f, 127.f);     // :2402
 }
 
+// the previous lane's value (lane 0: `carry`) and lane 63's value without going through the LDS crossbar: __shfl_up / __shfl
+// compile to ds_bpermute_b32; a wave-wide DPP shift (invalid source lane keeps `old`) and a v_readlane do the same in the VALU
+AUKIT_DEV float prev_lane(float s, float carry) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(s), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+AUKIT_DEV float last_lane(float s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63)); }
+
 template <int INTERP, int NV, bool MONO>
 __global__ __launch_bounds__(256) void k_fast_wave_stream_s16x2(const ResampleParams P, const FastParams F) {
     extern __shared__ float smf[];
@@ -126,16 +133,14 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream_s16x2(const ResamplePa
         }
         auto row = [&](unsigned q, unsigned rem, unsigned j, bool active) {
             const float sl = interp_raw2<INTERP>(F, tabL, q, rem);
-            float pl = __shfl_up(sl, 1);
-            if (lane == 0) pl = carryL;
-            carryL = __shfl(sl, 63);
+            const float pl = prev_lane(sl, carryL);
+            carryL = last_lane(sl);
             const float ol = stream_out(sl, pl, alpha);
             if (active) orowL[j] = ol;
             if constexpr (!MONO) {
                 const float sr = interp_raw2<INTERP>(F, tabR, q, rem);
-                float pr = __shfl_up(sr, 1);
-                if (lane == 0) pr = carryR;
-                carryR = __shfl(sr, 63);
+                const float pr = prev_lane(sr, carryR);
+                carryR = last_lane(sr);
                 const float orr = stream_out(sr, pr, alpha);
                 if (active) orowR[j] = orr;
             }
