@@ -134,6 +134,10 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int frc = AUKIT_OK;
         if (aligned4 && fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
+    if (do_resample && C == 1 && src == SRC_PCM_S16LE_MONO) {  // reference-order fp64 on wave tiles (exact_wave.hip)
+        int erc = AUKIT_OK;
+        if (exact_wave_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc)) return erc;
+    }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, do_resample ? interp : AUKIT_INTERP_NONE, C, P, &lds))) return rc;
     return launch_resample(ctx, src, do_resample ? interp : AUKIT_INTERP_NONE, EPI_AUDIO, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
@@ -489,6 +493,10 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     if (in->dtype == AUKIT_F32) {
         int frc = AUKIT_OK;
         if (fast_try(ctx, SRC_AUDIO_F32, interp, in->rate, new_rate, segs, P, (in_elems + out_elems) * 4, &frc)) return frc;
+    }
+    if (in->dtype == AUKIT_F64) {  // reference-order fp64 on wave tiles (exact_wave.hip)
+        int erc = AUKIT_OK;
+        if (exact_wave_try(ctx, SRC_AUDIO_F64, interp, in->rate, new_rate, segs, P, AUKIT_F64, (in_elems + out_elems) * 8, &erc)) return erc;
     }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) return rc;

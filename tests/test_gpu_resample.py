@@ -409,8 +409,53 @@ def test_exact_math_option_uses_fp64_kernel(ctx, oracle):
     ctx.set_option(N.OPT_EXACT_MATH, 1)
     try:
         out = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), 48000, "cubic", dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith("k_resample<")
+        assert ctx.last_kernel()[0].startswith("k_exact_wave<")  # reference-order fp64, wave tiles (exact_wave.hip)
         ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
         assert np.array_equal(out.download()[0][0], ref.data[0].astype(np.float32).astype(np.float64)) or rms(out.download()[0][0], ref.data[0]) <= 5e-8
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate,new_rate", [(44100, 48000), (8000, 48000), (22050, 48000), (48000, 44100), (32000, 8000), (47999, 48000), (11025, 22050)])
+def test_exact_wave_kernel_is_bit_identical_to_the_tiled_one(ctx, oracle, monkeypatch, rate, new_rate, interp):
+    """AUKIT_F64 storage: the fused s16 decode + resample and Audio:resample on f64 rows run the reference-order code on wave tiles
+    (exact_wave.hip) — every output bit-identical to the workgroup-tiled k_resample (AUKIT_EXACT_TILED=1) and within 1e-15 of the
+    oracle, on ragged batches (tiny streams, tile boundaries, 3 channels), up- and down-sampling."""
+    B, N = _B(), _N()
+    lens = [int(rate * 1.3), 1, 2, 1023, 1024, 1025, 5000, rate + 7]
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate(lens)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed")
+    out = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F64)
+    wave = new_rate >= rate and rate != 47999  # down-sampling may need a longer window than a wave stages, 47999 / 48000 does not reduce: k_resample runs
+    if wave:
+        assert ctx.last_kernel()[0].startswith("k_exact_wave<pcm_s16le_mono"), ctx.last_kernel()
+    got = out.download()
+    monkeypatch.setenv("AUKIT_EXACT_TILED", "1")
+    out2 = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F64)
+    assert ctx.last_kernel()[0].startswith("k_resample<")
+    got2 = out2.download()
+    monkeypatch.delenv("AUKIT_EXACT_TILED")
+    for i, s in enumerate(streams):
+        ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, rate), new_rate, oracle.INTERP[interp])
+        assert len(got[i][0]) == len(ref.data[0])
+        assert np.array_equal(got[i][0], got2[i][0]), i
+        assert np.max(np.abs(got[i][0] - ref.data[0]), initial=0) <= 1e-15, i
+    # Audio:resample on f64 rows, 3 channels
+    rng = np.random.Generator(np.random.PCG64(rate + new_rate))
+    a = [[rng.uniform(-1, 1, n) for _ in range(3)] for n in (4000, 1, 1025, rate // 2 + 3)]
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F64)
+    r = B.resample(ctx, ab, new_rate, interp)
+    if wave:
+        assert ctx.last_kernel()[0].startswith("k_exact_wave<audio_f64"), ctx.last_kernel()
+    g = r.download()
+    monkeypatch.setenv("AUKIT_EXACT_TILED", "1")
+    g2 = B.resample(ctx, ab, new_rate, interp).download()
+    monkeypatch.delenv("AUKIT_EXACT_TILED")
+    for i in range(len(a)):
+        ref = oracle.resample(oracle.Audio(a[i], rate), new_rate, oracle.INTERP[interp])
+        for c in range(3):
+            assert len(g[i][c]) == len(ref.data[c])
+            assert np.array_equal(g[i][c], g2[i][c]), (i, c)
+            assert np.max(np.abs(g[i][c] - ref.data[c]), initial=0) <= 1e-15, (i, c)
