@@ -267,6 +267,11 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         if (aligned4) done = fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, mono ? 2 : 1, P.lp_alpha);
         if (done && frc) { delete ck; return frc; }
     }
+    if (!done && src == SRC_PCM_S16LE_MONO && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // reference order, wave tiles
+        int erc = AUKIT_OK;
+        done = exact_wave_try(ctx, src, interp, d->sample_rate, 48000, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc, 1);
+        if (done && erc) { delete ck; return erc; }
+    }
     if (!done) {
         size_t lds;
         if ((rc = plan_tiles(ctx, segs, cp.ratio, interp, nd, P, &lds))) { delete ck; return rc; }

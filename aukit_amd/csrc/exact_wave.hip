@@ -8,6 +8,7 @@
 // waves per CU.  Sources: 16-bit signed little-endian mono PCM (the fused decode + resample of aukit_decode_resample) and f64 audio
 // rows (aukit_resample, what `audio:resample(48000)` is in the mirrors).  Bit-identical to k_resample (tests compare both with
 // the oracle and with each other); anything it does not take (other formats, sinc, non-integer rates) stays with k_resample.
+// With EPI = 1 the same tiles carry the stream.pcm epilogue (aukit.stream.pcm on s16 mono, F64 storage).
 #include <algorithm>
 #include "fast_wave_dev.h"
 #include "resample_dev.h"
@@ -61,13 +62,29 @@ AUKIT_DEV double sample64(const unsigned char *q) {
 
 template <typename T> AUKIT_DEV void store_exact(T *p, double v) { *p = (T)v; }
 
-template <int SRC, int INTERP, int NV, typename OUT_T>
+// the previous lane's double (lane 0: `carry`) and lane 63's, in the VALU (wave-wide DPP shift: an invalid source lane keeps `old`)
+AUKIT_DEV double prev_lane64(double s, double carry) {
+    const long long sb = __double_as_longlong(s), cb = __double_as_longlong(carry);
+    const int lo = __builtin_amdgcn_update_dpp((int)cb, (int)sb, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(cb >> 32), (int)(sb >> 32), 0x138, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+AUKIT_DEV double last_lane64(double s) {
+    const long long sb = __double_as_longlong(s);
+    const int lo = __builtin_amdgcn_readlane((int)sb, 63), hi = __builtin_amdgcn_readlane((int)(sb >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// EPI 0: Audio:resample (copy unclamped at integer positions, clamp to [-1, 1] otherwise, :666-668)
+// EPI 1: aukit.stream.pcm (:2397-2403): 2-tap low-pass on the RAW previous sample of the same iterator call (0 for its first output),
+//        x 127 / 128, clamp to [-128, 127]; a segment is one iterator call, so a tile with tin == 0 starts with ls = 0
+template <int SRC, int INTERP, int NV, typename OUT_T, int EPI = 0>
 __global__ __launch_bounds__(256) void k_exact_wave(const ResampleParams P, const FastParams F) {
     extern __shared__ double smd[];
     using T = SrcTraits<SRC>;
     // one more tap to the left than the polynomial needs: at a mathematically integer position the reference's x may round to just
-    // below the integer, and its floor(x) is then one table index lower
-    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    // below the integer, and its floor(x) is then one table index lower; the stream epilogue needs the sample before the tile too
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + 1 + (EPI == 1 ? 1 : 0), HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *const sm = smd + wave * (unsigned)F.cap;
@@ -132,13 +149,25 @@ __global__ __launch_bounds__(256) void k_exact_wave(const ResampleParams P, cons
         }
         const double *tab_klo = sm + cur.head;  // slot of table index cur.k_lo
         OUT_T *orow = out + sg.out_off + (size_t)tin * WT;
+        double carry = 0;  // EPI 1: ls, the RAW sample before the tile's first output (Q2)
+        if constexpr (EPI == 1) {
+            bool ii;
+            if (tin > 0) carry = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, tin * (unsigned)WT - 1, &ii);
+        }
         for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
             const unsigned j = rb + lane;
             const bool active = j < cur.cnt;
             const unsigned o = tin * (unsigned)WT + (active ? j : cur.cnt - 1);
             bool isint;
             const double s = eval_at<INTERP>(P, sg, tab_klo, cur.k_lo, o, &isint);
-            if (active) store_exact<OUT_T>(orow + j, isint ? s : lua_clamp(s, -1, 1));  // :667-668
+            if constexpr (EPI == 0) {
+                if (active) store_exact<OUT_T>(orow + j, isint ? s : lua_clamp(s, -1, 1));  // :667-668
+            } else {
+                const double prev = prev_lane64(s, carry);
+                carry = last_lane64(s);
+                const double ns = prev + P.lp_alpha * (s - prev);                                          // :2401
+                if (active) store_exact<OUT_T>(orow + j, lua_clamp(ns * (ns < 0 ? 128 : 127), -128, 127));  // :2402
+            }
         }
         if (!more) break;
         cur = nxt; sg = sg_n; tin = tin_n;
@@ -148,20 +177,21 @@ __global__ __launch_bounds__(256) void k_exact_wave(const ResampleParams P, cons
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
-template <int SRC, int INTERP, typename OUT_T>
+template <int SRC, int INTERP, typename OUT_T, int EPI = 0>
 static void launch_exact_nv(int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid, hipStream_t st) {
     switch (nv) {
-    case 1: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 1, OUT_T>), dim3(grid), dim3(256), lds, st, P, F); break;
-    case 2: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 2, OUT_T>), dim3(grid), dim3(256), lds, st, P, F); break;
-    case 4: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 4, OUT_T>), dim3(grid), dim3(256), lds, st, P, F); break;
-    default: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 8, OUT_T>), dim3(grid), dim3(256), lds, st, P, F); break;
+    case 1: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 1, OUT_T, EPI>), dim3(grid), dim3(256), lds, st, P, F); break;
+    case 2: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 2, OUT_T, EPI>), dim3(grid), dim3(256), lds, st, P, F); break;
+    case 4: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 4, OUT_T, EPI>), dim3(grid), dim3(256), lds, st, P, F); break;
+    default: hipLaunchKernelGGL((k_exact_wave<SRC, INTERP, 8, OUT_T, EPI>), dim3(grid), dim3(256), lds, st, P, F); break;
     }
 }
 
 // returns true when this kernel took the launch (*rc = its status).  src_kind: SRC_PCM_S16LE_MONO or SRC_AUDIO_F64; dtype of the
 // output: AUKIT_F64, or AUKIT_F32 (exact-math option: the exact value rounded once).  Needs linear / cubic and integer rates.
 bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype,
-                    uint64_t algorithmic_bytes, int *rc) {
+                    uint64_t algorithmic_bytes, int *rc, int epi) {
+    if (epi && src_kind != SRC_PCM_S16LE_MONO) return false;
     if (getenv("AUKIT_EXACT_TILED")) return false;  // A/B: the workgroup-tiled kernel
     if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_AUDIO_F64) return false;
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return false;
@@ -170,7 +200,7 @@ bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, d
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
     const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : 2;
-    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + 1, hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + 1 + (epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
     nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 ? 8 : 0)));
@@ -193,12 +223,16 @@ bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, d
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 16);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
 #define AUKIT_EW(S, I) do { if (dtype == AUKIT_F64) launch_exact_nv<S, I, double>(nv, P, F, lds, grid, ctx->stream); else launch_exact_nv<S, I, float>(nv, P, F, lds, grid, ctx->stream); } while (0)
-    if (src_kind == SRC_PCM_S16LE_MONO) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_EW(SRC_PCM_S16LE_MONO, AUKIT_INTERP_LINEAR); else AUKIT_EW(SRC_PCM_S16LE_MONO, AUKIT_INTERP_CUBIC); }
+    if (epi) {
+        if (dtype == AUKIT_F64) { if (interp == AUKIT_INTERP_LINEAR) launch_exact_nv<SRC_PCM_S16LE_MONO, AUKIT_INTERP_LINEAR, double, 1>(nv, P, F, lds, grid, ctx->stream); else launch_exact_nv<SRC_PCM_S16LE_MONO, AUKIT_INTERP_CUBIC, double, 1>(nv, P, F, lds, grid, ctx->stream); }
+        else { if (interp == AUKIT_INTERP_LINEAR) launch_exact_nv<SRC_PCM_S16LE_MONO, AUKIT_INTERP_LINEAR, float, 1>(nv, P, F, lds, grid, ctx->stream); else launch_exact_nv<SRC_PCM_S16LE_MONO, AUKIT_INTERP_CUBIC, float, 1>(nv, P, F, lds, grid, ctx->stream); }
+    } else if (src_kind == SRC_PCM_S16LE_MONO) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_EW(SRC_PCM_S16LE_MONO, AUKIT_INTERP_LINEAR); else AUKIT_EW(SRC_PCM_S16LE_MONO, AUKIT_INTERP_CUBIC); }
     else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_EW(SRC_AUDIO_F64, AUKIT_INTERP_LINEAR); else AUKIT_EW(SRC_AUDIO_F64, AUKIT_INTERP_CUBIC); }
 #undef AUKIT_EW
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_exact_wave launch failed"); return true; }
     static thread_local char nm[96];
-    snprintf(nm, sizeof nm, "k_exact_wave<%s,%s,nv%d>", src_kind == SRC_PCM_S16LE_MONO ? "pcm_s16le_mono" : "audio_f64", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+    snprintf(nm, sizeof nm, "k_exact_wave<%s,%s,nv%d%s>", src_kind == SRC_PCM_S16LE_MONO ? "pcm_s16le_mono" : "audio_f64", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv,
+             epi ? ",stream_pcm" : "");
     *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
     return true;
 }

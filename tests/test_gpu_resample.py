@@ -189,7 +189,7 @@ def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
     ctx.set_option(N.OPT_EXACT_MATH, 1)
     try:
         out2, ck2 = B.stream_decode(ctx, bt, desc, interp, dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith("k_resample<")
+        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<"))  # reference-order fp64 (wave tiles when the rates allow)
         got2 = out2.download()
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
@@ -459,3 +459,29 @@ def test_exact_wave_kernel_is_bit_identical_to_the_tiled_one(ctx, oracle, monkey
             assert len(g[i][c]) == len(ref.data[c])
             assert np.array_equal(g[i][c], g2[i][c]), (i, c)
             assert np.max(np.abs(g[i][c] - ref.data[c]), initial=0) <= 1e-15, (i, c)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate", [44100, 8000, 22050, 32000, 48000 - 1])
+def test_exact_wave_stream_pcm_is_bit_identical_to_the_tiled_kernel(ctx, oracle, monkeypatch, rate, interp):
+    """stream.pcm on s16 mono with AUKIT_F64 storage: the reference-order code + stream epilogue on wave tiles, bit-identical to
+    k_resample's (AUKIT_EXACT_TILED=1) and within 1e-13 of the oracle; ragged streams, chunk and tile boundaries"""
+    B, N = _B(), _N()
+    nsamp = [int(rate * 2.5), rate, rate + 3, 10, int(rate * 1.0001) + 2, 1100, 2, 1025]
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate(nsamp)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed")
+    out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=N.F64)
+    if rate != 47999:
+        assert ctx.last_kernel()[0].startswith("k_exact_wave<pcm_s16le_mono") and ctx.last_kernel()[0].endswith("stream_pcm>"), ctx.last_kernel()
+    got = out.download()
+    monkeypatch.setenv("AUKIT_EXACT_TILED", "1")
+    out2, ck2 = B.stream_decode(ctx, bt, desc, interp, dtype=N.F64)
+    assert ctx.last_kernel()[0].startswith("k_resample<")
+    got2 = out2.download()
+    monkeypatch.delenv("AUKIT_EXACT_TILED")
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, rate, False, False, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        assert np.array_equal(got[i][0], got2[i][0]), i
+        assert np.max(np.abs(got[i][0] - ref.data[0]), initial=0) <= 1e-13, i
