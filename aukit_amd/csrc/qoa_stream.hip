@@ -51,6 +51,76 @@ __global__ __launch_bounds__(64) void k_qoa_stream(const QsJob *jobs, unsigned l
     }
 }
 
+// The same in two passes, for small batches (one file is the usual batch of austream): with one lane per (call, channel) the four
+// dependent table loads of every output are paid in full (17 ms for ten seconds of stereo).  Pass 1: the interpolated, clamped
+// sample of every output, all outputs in parallel (fp64, reference order) into scratch; pass 2: the recursive low-pass
+// (ls = filtered s, :3324-3325) serially per job over contiguous doubles, 32 per round with the next 32 in flight.
+template <int INTERP>
+__global__ __launch_bounds__(256) void k_qoa_stream_interp(const QsJob *jobs, const unsigned long long *scr_off, const short *rows, double *scr, double ratio, double rcp,
+                                                          int exact) {
+    const QsJob job = jobs[blockIdx.y];
+    const short *src = rows + job.src_off;
+    double m1 = 0, z0 = 0;
+    if (job.last_off != ~0ull) { z0 = (double)rows[job.last_off]; m1 = (double)rows[job.last_off - 1]; }
+    const int n = job.n;
+    auto tap = [&](int k) -> double { return k >= 1 ? (double)src[k - 1] : (k == 0 ? z0 : m1); };
+    double *o = scr + scr_off[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < job.nout; i += gridDim.x * 256) {
+        const double nn = (double)i;
+        const double x = (exact ? div_rcp(nn, ratio, rcp) : nn / ratio) + 1.0;
+        const double ffx = floor(x);
+        const int k = (int)ffx;
+        double s;
+        if (x == ffx) s = tap(k);
+        else {
+            const double fx = x - ffx;
+            if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
+            else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else { const double p1 = tap(k), p0 = tap(k - 1), p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2; s = cubic_exact(p0, p1, p2, p3, fx); }
+            s = lua_clamp(s, -128, 127);  // :3323
+        }
+        o[i] = s;
+    }
+}
+template <typename OUT_T>
+__global__ __launch_bounds__(64) void k_qoa_stream_iir(const QsJob *jobs, const unsigned long long *scr_off, unsigned long long njobs, const short *rows, const double *scr,
+                                                      OUT_T *out, double lp_alpha) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+    if (j >= njobs) return;
+    const QsJob job = jobs[j];
+    const double *p = scr + scr_off[j];
+    OUT_T *o = out + job.out_off;
+    double ls = job.last_off != ~0ull ? (double)rows[job.last_off] : 0.0;  // :3316
+    constexpr int R = 32;
+    const int rounds = job.nout / R;
+    double cur[R], nxt[R];
+    if (rounds) {
+#pragma unroll
+        for (int k = 0; k < R; k++) cur[k] = p[k];
+    }
+    for (int r = 0; r < rounds; r++) {
+#pragma unroll
+        for (int k = 0; k < R; k++) nxt[k] = cur[k];
+        if (r + 1 < rounds) {
+#pragma unroll
+            for (int k = 0; k < R; k++) nxt[k] = p[(r + 1) * R + k];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const double s = ls + lp_alpha * (cur[k] - ls);  // :3324
+            ls = s;
+            o[r * R + k] = (OUT_T)s;
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) cur[k] = nxt[k];
+    }
+    for (int i = rounds * R; i < job.nout; i++) {
+        const double s = ls + lp_alpha * (p[i] - ls);
+        ls = s;
+        o[i] = (OUT_T)s;
+    }
+}
+
 struct QFrame { uint64_t off; int samples; };
 
 int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
@@ -183,10 +253,26 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, 
         const QsJob *dj = reinterpret_cast<const QsJob *>(ctx->seg_buf.p);
         const short *rows = reinterpret_cast<const short *>(ctx->tmp_buf.p);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
+        uint64_t scr_elems = 0, max_nout = 0;
+        std::vector<uint64_t> scr_off(jobs.size());
+        for (size_t k = 0; k < jobs.size(); k++) { scr_off[k] = scr_elems; scr_elems += ((uint64_t)jobs[k].nout + 1) & ~1ull; max_nout = std::max<uint64_t>(max_nout, (uint64_t)jobs[k].nout); }
+        if (scr_elems * 8 <= (256ull << 20) && jobs.size() <= 65535 && max_nout) {  // small batch: two passes
+            if ((rc = ctx->tmp_buf3.ensure((size_t)scr_elems * 8 + 64))) { delete ck; return rc; }
+            if ((rc = upload_table(ctx, ctx->misc_buf, scr_off.data(), scr_off.size() * 8))) { delete ck; return rc; }
+            const unsigned long long *dso = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+            double *scr = reinterpret_cast<double *>(ctx->tmp_buf3.p);
+            const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)jobs.size());
+            if (interp == 0) hipLaunchKernelGGL((k_qoa_stream_interp<0>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
+            else if (interp == 1) hipLaunchKernelGGL((k_qoa_stream_interp<1>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
+            else hipLaunchKernelGGL((k_qoa_stream_interp<2>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
+            if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_qoa_stream_iir<double>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<double *>(a->dev), lp_alpha);
+            else hipLaunchKernelGGL((k_qoa_stream_iir<float>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<float *>(a->dev), lp_alpha);
+        } else {
 #define AUKIT_QS(I, T) hipLaunchKernelGGL((k_qoa_stream<I, T>), dim3(grid), dim3(64), 0, ctx->stream, dj, (unsigned long long)jobs.size(), rows, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
         if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_QS(0, double); else if (interp == 1) AUKIT_QS(1, double); else AUKIT_QS(2, double); }
         else { if (interp == 0) AUKIT_QS(0, float); else if (interp == 1) AUKIT_QS(1, float); else AUKIT_QS(2, float); }
 #undef AUKIT_QS
+        }
         AUKIT_HIP_CHECK(hipGetLastError());
         if ((rc = ctx_end_kernel(ctx, "k_qoa_stream", in->total()))) { delete ck; return rc; }
     }
