@@ -604,3 +604,28 @@ def test_fuzz_qoa_corrupted(ctx, oracle, seed):
             assert ck.nchunks[0] == rs.nchunks and ck.status[0] == rs.final_status and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0]), (ch, len(f))
             for c in range(rs.channels):
                 assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (ch, c)
+
+
+def test_degenerate_batches_do_not_crash(ctx, oracle):
+    """zero-length streams, one-byte streams and batches of nothing but those through every loader and stream factory: an
+    error from the library (the reference raises on most of them) or an empty result, never a crash or a hang"""
+    B, N = _B(), _N()
+    descs = [B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), B.make_desc(N.CODEC_PCM, 2, 8000, 8, "unsigned"), B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True),
+             B.make_desc(N.CODEC_DFPWM, 1, 48000), B.make_desc(N.CODEC_DFPWM, 2, 48000), B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512),
+             B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=256), B.make_desc(N.CODEC_QOA), B.make_desc(N.CODEC_FLAC), B.make_desc(N.CODEC_MDFPWM)]
+    batches = [[b""], [b"", b""], [b"\\x00"], [b"", b"\\x01\\x02", b""], [b"\\x00" * 3]]
+    for d in descs:
+        for streams in batches:
+            bt = B.Batch.upload(ctx, streams)
+            for fn in (lambda: B.decode(ctx, bt, d, dtype=N.F64).download(),
+                       lambda: B.decode_resample(ctx, bt, d, 48000, "cubic", dtype=N.F32).download(),
+                       lambda: B.stream_decode(ctx, bt, d, "linear", dtype=(N.I8 if d.codec in (N.CODEC_G711, N.CODEC_ADPCM_WAV, N.CODEC_MSADPCM, N.CODEC_MDFPWM) else N.F64))[0].download(),
+                       lambda: B.dfpwm_transcode_mono(ctx, bt, 2).download() if d.codec == N.CODEC_DFPWM else None):
+                try:
+                    fn()
+                except N.AukitError:
+                    pass
+    # and the library is still healthy afterwards
+    s = np.arange(-500, 500, dtype=np.int16).tobytes()
+    got = B.decode(ctx, B.Batch.upload(ctx, [s]), descs[0], dtype=N.F64).download()[0][0]
+    assert np.array_equal(got, oracle.pcm(s, 16, oracle.SIGNED, 1, 44100).data[0])
