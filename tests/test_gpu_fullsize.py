@@ -147,3 +147,30 @@ def test_config_5_full_batch(ctx, oracle):
     rows = _row_classes(B.mono(ctx, a), n, 480000, k5)
     ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(base[1]), 48000, oracle.CUBIC), 20.0), 0.8))
     assert rms(rows[1].astype(np.float64), ref.data[0]) <= 1e-6
+
+
+def test_one_long_stream(ctx, oracle):
+    """the other extreme of the batch shape: ONE stream of 30 minutes (79 M samples in, 86 M out: tile counters, segment offsets and
+    the 32-bit position arithmetic of the wave kernels far from the 10-second case) through the f32 and the reference-order Audio
+    path and through stream.pcm (1800 iterator calls)"""
+    B, N = _B(), _N()
+    n = int(44100 * 1800 * SCALE) if SCALE >= 0.05 else 44100 * 90
+    rng = np.random.Generator(np.random.PCG64(12))
+    x = (rng.integers(-30000, 30000, n)).astype("<i2")
+    s = x.tobytes()
+    bt = B.Batch.upload(ctx, [s])
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC).data[0]
+    g32 = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32).download()[0][0]
+    assert ctx.last_kernel()[0].startswith("k_fast_wave")
+    assert len(g32) == len(ref) and rms(g32, ref) <= 1e-6
+    g64 = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F64).download()[0][0]
+    assert ctx.last_kernel()[0].startswith("k_exact_wave")
+    assert np.max(np.abs(g64 - ref)) <= 1e-15
+    del g32, g64, ref
+    rs = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, 44100, False, False, oracle.LINEAR)
+    for dt, tol in ((N.F64, 1e-13), (N.F32, 2e-4)):
+        out, ck = B.stream_decode(ctx, bt, desc, "linear", dtype=dt)
+        a = out.download()[0][0]
+        assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0])
+        assert np.max(np.abs(a - rs.data[0])) <= tol
