@@ -174,3 +174,19 @@ def test_one_long_stream(ctx, oracle):
         a = out.download()[0][0]
         assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0])
         assert np.max(np.abs(a - rs.data[0])) <= tol
+
+
+def test_one_long_dfpwm_stream(ctx, oracle):
+    """ONE DFPWM stream of 30 minutes (10.8 MB, stereo): the chunk-parallel decoder plans hundreds of chunks for a single stream
+    (block scan over 10 000 blocks, Q10 slices, the verify pass), loader and fused transcode bit-exact against the oracle"""
+    B, N = _B(), _N()
+    nbytes = int(12000 * 900 * SCALE) if SCALE >= 0.05 else 12000 * 50
+    rng = np.random.Generator(np.random.PCG64(13))
+    s = bytes(rng.integers(0, 256, nbytes, dtype=np.uint8))
+    bt = B.Batch.upload(ctx, [s])
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F64).download()[0]
+    ref = oracle.dfpwm(s, 2, 48000)
+    assert np.array_equal(got[0], ref.data[0]) and np.array_equal(got[1], ref.data[1])
+    fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()[0]
+    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfpwm_encode_i8"
+    assert fused == oracle.audio_dfpwm(oracle.mono(ref), True)
