@@ -190,3 +190,25 @@ def test_one_long_dfpwm_stream(ctx, oracle):
     fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()[0]
     assert ctx.last_kernel()[0] == "k_df_chunks+k_dfpwm_encode_i8"
     assert fused == oracle.audio_dfpwm(oracle.mono(ref), True)
+
+
+def test_one_long_flac_file(ctx, oracle):
+    """ONE FLAC file of five minutes (3200 frames): candidate table, frame chain and job lists for a single long stream; lossless
+    decode and stream.flac (300 iterator calls) against the oracle"""
+    B, N = _B(), _N()
+    n = int(44100 * 300 * SCALE) if SCALE >= 0.05 else 44100 * 20
+    rng = np.random.Generator(np.random.PCG64(14))
+    t = np.arange(n)[:, None] / 44100
+    x = np.clip(np.round(12000 * np.sin(2 * np.pi * np.array([440.0, 557.0]) * t) + rng.integers(-2000, 2000, (n, 2))), -32768, 32767).astype(np.int64)
+    f = oracle.gen_flac(x.ravel(), 2, 16, 44100, 4096)
+    bt = B.Batch.upload(ctx, [f])
+    desc = B.make_desc(N.CODEC_FLAC)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()[0]
+    for c in range(2):
+        assert np.array_equal(np.round(got[c] * 65536).astype(np.int64), x[:, c]), c
+    rs = oracle.stream_flac(f, oracle.LINEAR)
+    out, ck = B.stream_decode(ctx, bt, desc, "linear", dtype=N.F64)
+    a = out.download()[0]
+    assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0])
+    for c in range(2):
+        assert np.max(np.abs(a[c] - rs.data[c])) <= 1e-12, c
