@@ -726,3 +726,137 @@ def test_dfpwm_codec_against_the_published_text(oracle):
         bits.append(bit)
     packed = bytes(sum(int(b) << k for k, b in enumerate(bits[i:i + 8])) for i in range(0, len(bits), 8))
     assert packed == oracle.dfpwm_encode(samples.astype(np.float64))
+
+
+@pytest.mark.parametrize("ch,mono,interp,tail", [(1, False, "linear", 0), (2, False, "cubic", 8), (2, True, "linear", 0), (1, False, "none", 8)])
+def test_q15_stream_qoa_transliterated(oracle, ch, mono, interp, tail):
+    """aukit.stream.qoa on a string (aukit.lua:3239-3336) transliterated, LMS included (weights are NOT wrapped to 16 bits, the sum
+    wraps to int32 through bit32.arshift): frames are read until a call holds at least one second, every slice decodes 20 samples
+    even when the frame's count is not a multiple of 20 (overwritten by the next frame or left as a tail), floor(reconstructed /
+    256), interpolation clamp, recursive low-pass seeded with the previous call's last raw sample, position of the call."""
+    import math
+    import struct as st
+    rng = np.random.Generator(np.random.PCG64(90 + ch))
+    rate = 22050
+    n = 5120 * 9 + 20 * 13 + 7  # the last frame's sample count is not a multiple of 20
+    pcm = rng.integers(-12000, 12000, n * ch).astype(np.int16)
+    data = oracle.gen_qoa(pcm, ch, rate) + b"\\0" * tail
+    ref = oracle.stream_qoa(data, mono, oracle.INTERP[interp])
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def arsh32(a, b):  # signed_rshift: bit32.arshift on the value reduced to uint32, then back to a signed number
+        a &= 0xFFFFFFFF
+        if a & 0x80000000:
+            a -= 0x100000000
+        return a >> b
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "none":
+            return t.get(ffx)
+        if interp == "linear":
+            a, b = t.get(ffx), t.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx
+        p0, p1, p2, p3 = t.get(ffx - 1), t.get(ffx), t.get(ffx + 1), t.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    def length(t):
+        k = 0
+        while (k + 1) in t:
+            k += 1
+        return k
+
+    state = {"pos": 0}
+
+    def read(k):
+        if state["pos"] >= len(data):
+            return None
+        d = data[state["pos"]: state["pos"] + k]
+        state["pos"] += k
+        return d
+
+    head = read(8)
+    assert head[:4] == b"qoaf"
+    fch, = st.unpack(">B", data[8:9])
+    frate = int.from_bytes(data[9:12], "big")
+    lms = [{"h": [0] * 4, "w": [0] * 4} for _ in range(fch)]
+    last = [[0, 0] for _ in range(fch)]
+    file_pos = 0
+    ratio = 48000 / frate
+    alpha = 1 - math.exp(-(frate / 96000) * 2 * math.pi)
+    chunks, positions = [], []
+    while True:
+        chunk = [{-1: last[i][0], 0: last[i][1]} for i in range(fch)]
+        sample_pos = 0
+        while sample_pos < frate:
+            d = read(8)
+            if not d:
+                break
+            if len(d) < 8:
+                raise AssertionError("short frame header")
+            channels = d[0]
+            samplerate = int.from_bytes(d[1:4], "big")
+            samples, frame_size = st.unpack(">HH", d[4:8])
+            data_size = frame_size - 8 - 4 * 4 * channels
+            max_total = (data_size // 8) * 20
+            if channels != fch or samplerate != frate or samples * channels > max_total:
+                break
+            for c in range(channels):
+                lms[c]["h"] = list(st.unpack(">4h", read(8)))
+                lms[c]["w"] = list(st.unpack(">4h", read(8)))
+            for sample_index in range(1, samples + 1, 20):
+                for c in range(channels):
+                    hi, lo = st.unpack(">II", read(8))
+                    sf = (hi >> 28) & 15
+                    for si in range(sample_index, sample_index + 20):
+                        w, h = lms[c]["w"], lms[c]["h"]
+                        predicted = arsh32(w[0] * h[0] + w[1] * h[1] + w[2] * h[2] + w[3] * h[3], 13)
+                        quantized = (hi >> 25) & 7
+                        deq = _QOA_DEQUANT[sf][quantized]
+                        rec = min(max(predicted + deq, -32768), 32767)
+                        chunk[c][sample_pos + si] = math.floor(rec / 256)
+                        hi = ((hi << 3) & 0xFFFFFFFF) + ((lo >> 29) & 7)
+                        lo = (lo << 3) & 0xFFFFFFFF
+                        delta = arsh32(deq, 4)
+                        lms[c]["w"] = [w[i] + (-delta if h[i] < 0 else delta) for i in range(4)]
+                        lms[c]["h"] = [h[1], h[2], h[3], rec]
+            sample_pos += samples
+        n1 = length(chunk[0])
+        if n1 == 0:
+            break
+        newlen = n1 * ratio
+        lines = [[] for _ in range(1 if mono else fch)]
+        ls = [last[j][1] for j in range(fch)]
+        i = 1
+        while i <= newlen:
+            acc = 0
+            for j in range(fch):
+                xx = (i - 1) / ratio + 1
+                s = chunk[j][int(xx)] if xx % 1 == 0 else clamp(interpolate(chunk[j], xx), -128, 127)
+                s = ls[j] + alpha * (s - ls[j])
+                ls[j] = s
+                if mono:
+                    acc = acc + s
+                else:
+                    lines[j].append(s)
+            if mono:
+                lines[0].append(acc / fch)
+            i += 1
+        positions.append(file_pos / frate)
+        file_pos += sample_pos
+        for j in range(fch):
+            l = length(chunk[j])
+            last[j] = [chunk[j].get(l - 1), chunk[j].get(l)]
+        chunks.append(lines)
+    assert len(chunks) == ref.nchunks
+    assert [len(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
+    assert np.array_equal(np.array(positions), ref.chunk_pos)
+    for c in range(ref.channels):
+        got = np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks])
+        assert np.max(np.abs(got - ref.data[c])) <= 1e-12, c
