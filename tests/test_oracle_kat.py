@@ -860,3 +860,99 @@ def test_q15_stream_qoa_transliterated(oracle, ch, mono, interp, tail):
     for c in range(ref.channels):
         got = np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks])
         assert np.max(np.abs(got - ref.data[c])) <= 1e-12, c
+
+
+_MS_ADAPT = {0: 230, 1: 230, 2: 230, 3: 230, 4: 307, 5: 409, 6: 512, 7: 614, -8: 768, -7: 614, -6: 512, -5: 409, -4: 307, -3: 230, -2: 230, -1: 230}
+
+
+@pytest.mark.parametrize("ch,mono,interp", [(1, False, "linear"), (1, False, "cubic"), (2, False, "cubic"), (2, True, "linear")])
+def test_q9_stream_msadpcm_transliterated(oracle, ch, mono, interp):
+    """aukit.stream.msadpcm on a string (aukit.lua:2613-2733) transliterated: the mono branch reads EVERY block header from the start
+    of the data (`str_unpack("<!1Bhhh", data)` has no position), stereo floors each sample and mixes l + r / 2, mono does not floor
+    before interpolating, samplesPerBlock leaves the block's last two samples as look-ahead only."""
+    import math
+    import struct as st
+    rng = np.random.Generator(np.random.PCG64(60 + ch))
+    ba, rate = 256 * ch, 22050
+    spb = (ba - 14) + 2 if ch == 2 else (ba - 7) * 2 + 2
+    pcm = rng.integers(-6000, 6000, spb * 40 * ch).astype(np.int16)
+    data = oracle.gen_msadpcm(pcm, ch, ba)
+    ref = oracle.stream_msadpcm(data, ba, ch, rate, mono, None, oracle.INTERP[interp])
+    c1t, c2t = [256, 512, 0, 192, 240, 460, 392], [0, -256, 0, 64, 0, -208, -232]
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def interpolate(t, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        if interp == "linear":
+            a, b = t.get(ffx), t.get(ffx + 1)
+            return a + ((b if b is not None else a) - a) * fx
+        p0, p1, p2, p3 = t.get(ffx - 1), t.get(ffx), t.get(ffx + 1), t.get(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    def nib(v):
+        return v - 16 if v >= 8 else v
+
+    def scale(p):
+        return p / (128 if p < 0 else 127)
+
+    ratio = 48000 / rate
+    spb_ref = ba - 14 if ch == 2 else (ba - 7) * 2
+    bytes_per_second = ba * math.ceil(rate / spb_ref)
+    newlen = math.floor(spb_ref * ratio)
+    n, chunks = 1, []
+    while True:
+        target = n + bytes_per_second
+        retval = [[] for _ in range(1 if (mono or ch == 1) else 2)]
+        while n < target:
+            if n > len(data):
+                break
+            if ch == 2:
+                piL, piR, dL, dR, s1L, s1R, s2L, s2R = st.unpack_from("<BBhhhhhh", data, n - 1)
+                left = {1: math.floor(scale(s2L)), 2: math.floor(scale(s1L))}
+                right = {1: math.floor(scale(s2R)), 2: math.floor(scale(s1R))}
+                for i in range(14, ba):
+                    b = data[n - 1 + i]
+                    hi, lo = nib(b >> 4), nib(b & 15)
+                    p = clamp(math.floor((s1L * c1t[piL] + s2L * c2t[piL]) / 256) + hi * dL, -32768, 32767)
+                    left[len(left) + 1] = math.floor(scale(p))
+                    s2L, s1L = s1L, p
+                    dL = max(math.floor(_MS_ADAPT[hi] * dL / 256), 16)
+                    p = clamp(math.floor((s1R * c1t[piR] + s2R * c2t[piR]) / 256) + lo * dR, -32768, 32767)
+                    right[len(right) + 1] = math.floor(scale(p))
+                    s2R, s1R = s1R, p
+                    dR = max(math.floor(_MS_ADAPT[lo] * dR / 256), 16)
+                for i in range(1, newlen + 1):
+                    xx = (i - 1) / ratio + 1
+                    l, r = (left[int(xx)], right[int(xx)]) if xx % 1 == 0 else (interpolate(left, xx), interpolate(right, xx))
+                    if mono:
+                        retval[0].append(clamp(math.floor(l + r / 2), -128, 127))
+                    else:
+                        retval[0].append(clamp(math.floor(l), -128, 127))
+                        retval[1].append(clamp(math.floor(r), -128, 127))
+            else:
+                pi, dl, s1, s2 = st.unpack_from("<Bhhh", data, 0)  # always the FIRST block's header (Q9)
+                left = {1: scale(s2), 2: scale(s1)}
+                for i in range(7, ba):
+                    b = data[n - 1 + i]
+                    for v in (nib(b >> 4), nib(b & 15)):
+                        p = clamp(math.floor((s1 * c1t[pi] + s2 * c2t[pi]) / 256) + v * dl, -32768, 32767)
+                        left[len(left) + 1] = scale(p)
+                        s2, s1 = s1, p
+                        dl = max(math.floor(_MS_ADAPT[v] * dl / 256), 16)
+                for i in range(1, newlen + 1):
+                    xx = (i - 1) / ratio + 1
+                    retval[0].append(clamp(math.floor(left[int(xx)] if xx % 1 == 0 else interpolate(left, xx)), -128, 127))
+            n += ba
+        if not retval[0]:
+            break
+        chunks.append(retval)
+    assert len(chunks) == ref.nchunks
+    assert [len(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
+    for c in range(ref.channels):
+        assert np.array_equal(np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks]), ref.data[c]), c
