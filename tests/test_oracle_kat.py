@@ -956,3 +956,89 @@ def test_q9_stream_msadpcm_transliterated(oracle, ch, mono, interp):
     assert [len(c[0]) for c in chunks] == list(ref.chunk_len[:, 0])
     for c in range(ref.channels):
         assert np.array_equal(np.concatenate([np.array(k[c], dtype=np.float64) for k in chunks]), ref.data[c]), c
+
+
+def test_effects_transliterated(oracle):
+    """amplify / fade / normalize / center / delay / echo / reverb (aukit.lua:3356-3580) as plain Python loops over 1-based lists next
+    to the C oracle — the in-place all-pass of reverb reading `sum[i + 20 - samples]` after earlier entries were overwritten, and
+    `o[1..samples]` left dry (Q17), included"""
+    import math
+    rng = np.random.Generator(np.random.PCG64(31))
+    rate, n = 8000, 5000
+    x = rng.uniform(-1, 1, n)
+
+    def clamp(v):
+        return -1 if v < -1 else (1 if v > 1 else v)
+
+    def lua(a):  # 1-based
+        return [None] + list(a)
+
+    def arr(t):
+        return np.array(t[1:], dtype=np.float64)
+
+    A = lambda: oracle.Audio([x.copy()], rate)
+    # amplify
+    assert np.array_equal(oracle.fx_amplify(A(), 1.7).data[0], np.array([clamp(v * 1.7) for v in x]))
+    # fade 0.1 s .. 0.4 s from 1 to 0.2
+    ch = lua(x)
+    start, m = 0.1 * rate, (0.2 - 1.0) / ((0.4 - 0.1) * rate)
+    i = start
+    while i <= 0.4 * rate:
+        ch[int(i)] = clamp(ch[int(i)] * (m * (i - start) + 1.0))
+        i += 1
+    assert np.array_equal(oracle.fx_fade(A(), 0.1, 1.0, 0.4, 0.2).data[0], arr(ch))
+    # normalize (not independent)
+    mx = 0
+    for v in x:
+        mx = max(mx, abs(v))
+    mult = 0.8 / mx
+    assert np.array_equal(oracle.fx_normalize(A(), 0.8).data[0], np.array([clamp(v * mult) for v in x]))
+    # center: per second of samples
+    ch = lua(x)
+    i = 0
+    while i <= n - 1:
+        l = min(n - i, rate)
+        avg = 0
+        for j in range(1, l + 1):
+            avg = avg + ch[i + j]
+        avg = avg / l
+        for j in range(1, l + 1):
+            ch[i + j] = clamp(ch[i + j] - avg)
+        i += rate
+    assert np.array_equal(oracle.fx_center(A()).data[0], arr(ch))
+    # delay / echo
+    samples = math.floor(0.0123 * rate)
+    o = lua(x)
+    orig = list(o)
+    for i in range(samples + 1, n + 1):
+        o[i] = clamp(o[i] + orig[i - samples] * 0.6)
+    assert np.array_equal(oracle.fx_delay(A(), 0.0123, 0.6).data[0], arr(o))
+    o = lua(x)
+    for i in range(samples + 1, n + 1):
+        o[i] = clamp(o[i] + o[i - samples] * 0.6)
+    assert np.array_equal(oracle.fx_echo(A(), 0.0123, 0.6).data[0], arr(o))
+    # reverb
+    delay, decay, wet, dry = 40.0, 0.35, 0.9, 0.2
+    o = lua(x)
+    sm = {}
+    for k, (ds, dc) in enumerate(zip([0, -11.73, 19.31, -7.97], [0, 0.1313, 0.2743, 0.31])):
+        comb = {}
+        samples = math.floor((delay + ds) / 1000 * rate)
+        mul = decay - dc
+        for i in range(1, min(samples, n) + 1):
+            comb[i] = o[i]
+            sm[i] = sm.get(i, 0) + o[i]
+        for i in range(samples + 1, n + 1):
+            s = o[i] + comb[i - samples] * mul
+            comb[i] = s
+            sm[i] = sm.get(i, 0) + s
+    for i in range(1, n + 1):
+        sm[i] = sm[i] * wet + o[i] * dry
+    samples = math.floor(0.08927 * rate)
+    sm[samples + 1] = sm[samples + 1] - 0.131 * sm[1]
+    for i in range(samples + 2, n + 1):
+        sm[i] = sm[i] - 0.131 * sm[i - samples] + 0.131 * sm[i + 20 - samples]
+    o[samples + 1] = clamp(sm[samples + 1] - 0.131 * sm[1])
+    for i in range(samples + 2, n + 1):
+        o[i] = clamp(sm[i] - 0.131 * sm[i - samples] + 0.131 * sm[i + 20 - samples])
+    assert np.max(np.abs(oracle.fx_reverb(A(), delay, decay, wet, dry).data[0] - arr(o))) <= 1e-15
