@@ -1042,3 +1042,72 @@ def test_effects_transliterated(oracle):
     for i in range(samples + 2, n + 1):
         o[i] = clamp(sm[i] - 0.131 * sm[i - samples] + 0.131 * sm[i + 20 - samples])
     assert np.max(np.abs(oracle.fx_reverb(A(), delay, decay, wet, dry).data[0] - arr(o))) <= 1e-15
+
+
+def test_audio_methods_transliterated(oracle):
+    """Audio:resample (fractional `newlen` as the loop bound, copy at integer positions, clamp elsewhere), Audio:mono, Audio:mix
+    (zero padding, missing channels, clamp of sum * amplifier) and Audio:pcm / encodePCM (interleaved and channel after channel)
+    as plain Python next to the C oracle (aukit.lua:653-689, :804-835, :868-910)"""
+    import math
+    rng = np.random.Generator(np.random.PCG64(41))
+
+    def clamp(v):
+        return -1 if v < -1 else (1 if v > 1 else v)
+
+    def cubic(c, xx):
+        ffx = math.floor(xx)
+        fx = xx - ffx
+        g = lambda i: c[i - 1] if 1 <= i <= len(c) else None
+        p0, p1, p2, p3 = g(ffx - 1), g(ffx), g(ffx + 1), g(ffx + 2)
+        p0 = p1 if p0 is None else p0
+        p2 = p1 if p2 is None else p2
+        p3 = p2 if p3 is None else p3
+        return (-0.5 * p0 + 1.5 * p1 - 1.5 * p2 + 0.5 * p3) * fx ** 3 + (p0 - 2.5 * p1 + 2 * p2 - 0.5 * p3) * fx ** 2 + (-0.5 * p0 + 0.5 * p2) * fx + p1
+
+    a = [rng.uniform(-1.2, 1.2, 1234), rng.uniform(-1, 1, 1234)]  # values above 1: copied unclamped at integer positions (Q16)
+    for rate, new in ((44100, 48000), (8000, 48000), (48000, 32000)):
+        ratio = new / rate
+        newlen = len(a[0]) * ratio
+        ref = oracle.resample(oracle.Audio(a, rate), new, oracle.CUBIC)
+        for y in range(2):
+            line = []
+            i = 1
+            while i <= newlen:
+                xx = (i - 1) / ratio + 1
+                line.append(a[y][int(xx) - 1] if xx % 1 == 0 else clamp(cubic(a[y], xx)))
+                i += 1
+            assert len(line) == len(ref.data[y])
+            assert np.max(np.abs(np.array(line) - ref.data[y])) <= 1e-15, (rate, new, y)  # pow(fx, 3) is libm's in Python
+    # mono
+    s3 = [rng.uniform(-1, 1, 500) for _ in range(3)]
+    mono = []
+    for i in range(500):
+        s = 0
+        for c in range(3):
+            s = s + s3[c][i]
+        mono.append(s / 3)
+    assert np.array_equal(oracle.mono(oracle.Audio(s3, 8000)).data[0], np.array(mono))
+    # mix: three audios, different lengths and channel counts
+    auds = [[rng.uniform(-1, 1, 300)], [rng.uniform(-1, 1, 450), rng.uniform(-1, 1, 450)], [rng.uniform(-1, 1, 20) for _ in range(3)]]
+    amp = 0.9
+    ln, cn = max(len(x[0]) for x in auds), max(len(x) for x in auds)
+    ref = oracle.mix([oracle.Audio(x, 8000) for x in auds], amp)
+    for c in range(cn):
+        ch = []
+        for i in range(ln):
+            s = 0
+            for x in auds:
+                if c < len(x):
+                    s = s + (x[c][i] if i < len(x[c]) else 0)
+            ch.append(clamp(s * amp))
+        assert np.array_equal(ref.data[c], np.array(ch)), c
+    # Audio:pcm
+    st = [rng.uniform(-1, 1, 77), rng.uniform(-1, 1, 77)]
+    for bits, dt, odt in ((8, "unsigned", oracle.UNSIGNED), (16, "signed", oracle.SIGNED), (24, "signed", oracle.SIGNED), (32, "unsigned", oracle.UNSIGNED)):
+        mv = 2 ** (bits - 1)
+        add = mv if dt == "unsigned" else 0
+        enc = lambda d: d * (mv if d < 0 else mv - 1) + add
+        inter = [enc(st[c][n]) for n in range(77) for c in range(2)]
+        planar = [enc(st[c][n]) for c in range(2) for n in range(77)]
+        assert np.array_equal(oracle.encode_pcm(oracle.Audio(st, 8000), bits, odt, True), np.array(inter))
+        assert np.array_equal(oracle.encode_pcm(oracle.Audio(st, 8000), bits, odt, False), np.array(planar))
