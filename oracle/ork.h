@@ -13,8 +13,11 @@
  *     image, so the reference cannot be executed to pin this restatement.
  *     What pins it: independent known-answer checks that do not depend on the
  *     restatement (ITU-T G.711 tables, FLAC losslessness, QOA int32 reference
- *     semantics, hand-computed micro-vectors for each reference quirk) — see
- *     tests/test_oracle_*.py.
+ *     semantics, hand-computed micro-vectors for each reference quirk), and a
+ *     second, structurally different reading of the same Lua: line-by-line
+ *     Python transliterations of every stream iterator (pcm, adpcm, msadpcm,
+ *     g711, flac, qoa, dfpwm), of the effects and of Audio:resample / mono /
+ *     mix / pcm, run next to this restatement — see tests/test_oracle_*.py.
  *   - DFPWM arithmetic is NOT in the reference tree (`require "cc.audio.dfpwm"`,
  *     aukit.lua:85, a CC: Tweaked ROM module with no pinned version).  It is
  *     restated here from the published DFPWM1a algorithm: **parity unpinned**.
