@@ -1111,3 +1111,58 @@ def test_audio_methods_transliterated(oracle):
         planar = [enc(st[c][n]) for c in range(2) for n in range(77)]
         assert np.array_equal(oracle.encode_pcm(oracle.Audio(st, 8000), bits, odt, True), np.array(inter))
         assert np.array_equal(oracle.encode_pcm(oracle.Audio(st, 8000), bits, odt, False), np.array(planar))
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_q8_wav_ima_loader_transliterated(oracle, ch):
+    """aukit.wav's IMA path (aukit.lua:1509-1548 → aukit.adpcm :1218-1274) transliterated: per block, mono masks the header step
+    index with 0x0F (Q8) and decodes the bytes low nibble first; stereo re-orders the 4-byte words of both channels into an
+    interleaved nibble table; the header predictor is not emitted; blocks are concatenated"""
+    rng = np.random.Generator(np.random.PCG64(70 + ch))
+    ba = 36 * ch
+    spb = (ba - 4 * ch) * 2 // ch
+    data = oracle.gen_ima(rng.integers(-9000, 9000, spb * 5 * ch).astype(np.int16), ch, ba, 88)
+    ref = oracle.wav_adpcm(data, ba, ch, 22050)
+
+    def clamp(v, lo, hi):
+        return lo if v < lo else (hi if v > hi else v)
+
+    def adpcm_nibbles(nibbles, pred, idx, channels):  # aukit.adpcm on a table, interleaved = true
+        out = [[] for _ in range(channels)]
+        pred, idx = list(pred), list(idx)
+        for i in range(len(nibbles) // channels):
+            for j in range(channels):
+                nib = nibbles[i * channels + j]
+                step = _IMA_STEP[idx[j]]
+                idx[j] = clamp(idx[j] + _IMA_INDEX[nib], 0, 88)
+                diff = (((nib % 8) * step) >> 2) + (step >> 3)
+                pred[j] = clamp(pred[j] - diff, -32768, 32767) if nib >= 8 else clamp(pred[j] + diff, -32768, 32767)
+                out[j].append(pred[j] / (32768 if pred[j] < 0 else 32767))
+        return out
+
+    import struct as st
+    chans = [[] for _ in range(ch)]
+    for n in range(0, len(data), ba):
+        if ch == 2:
+            pL, iL, pR, iR = st.unpack_from("<hBxhB", data, n)
+            nib = {}
+            for i in range(8, ba, 8):
+                for k in range(4):  # left word → odd slots, right word → even slots (1-based)
+                    b = data[n + i + k]
+                    nib[(i - 7 + 2 * k) * 2 - 1] = b & 15
+                    nib[(i - 6 + 2 * k) * 2 - 1] = b >> 4
+                    b = data[n + i + 4 + k]
+                    nib[(i - 7 + 2 * k) * 2] = b & 15
+                    nib[(i - 6 + 2 * k) * 2] = b >> 4
+            flat = [nib[k] for k in range(1, len(nib) + 1)]
+            blk = adpcm_nibbles(flat, [pL, pR], [iL, iR], 2)
+        else:
+            p, ix = st.unpack_from("<hB", data, n)
+            ix &= 0x0F
+            body = data[n + 4: n + ba]
+            flat = [v for b in body for v in (b & 15, b >> 4)]  # topFirst = false: low nibble first
+            blk = adpcm_nibbles(flat, [p], [ix], 1)
+        for c in range(ch):
+            chans[c] += blk[c]
+    for c in range(ch):
+        assert np.array_equal(ref.data[c], np.array(chans[c])), c
