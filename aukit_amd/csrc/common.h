@@ -51,6 +51,9 @@ struct aukit_ctx {
     int num_cus = 256;
     // scratch tables (segment/tile/stream descriptors); plan_key caches the last uploaded plan
     aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2, tmp_buf3;
+    // pinned host staging for downloads / uploads of whole audios (a pageable copy runs at a fraction of the PCIe rate)
+    void *host_stage = nullptr;
+    size_t host_stage_cap = 0;
     std::string plan_key;
     // verified range of the reciprocal-based exact division per ratio (see exact_div_verified)
     std::map<double, uint64_t> div_ok;

@@ -151,6 +151,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release();
+    if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->kev0) (void)hipEventDestroy(c->kev0);
@@ -227,6 +228,8 @@ static int batch_set_offsets(aukit_ctx *ctx, aukit_batch *b, const uint64_t *off
     return AUKIT_OK;
 }
 
+static void *host_stage(aukit_ctx *ctx, size_t bytes);
+
 int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, const uint64_t *offsets, uint32_t n) {
     if (!ctx || !out || !offsets) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -242,7 +245,9 @@ int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, 
     int rc = batch_set_offsets(ctx, b, rel.data(), n);
     if (rc) { aukit_batch_free(b); return rc; }
     if (total) {
-        hipError_t e2 = hipMemcpyAsync(b->data(), bytes + offsets[0], total, hipMemcpyHostToDevice, ctx->stream);
+        const void *srcp = bytes + offsets[0];
+        if (void *st = total <= ((size_t)64 << 20) ? host_stage(ctx, (size_t)total) : nullptr) { memcpy(st, srcp, (size_t)total); srcp = st; }  // small uploads: through pinned memory
+        hipError_t e2 = hipMemcpyAsync(b->data(), srcp, total, hipMemcpyHostToDevice, ctx->stream);
         if (e2 != hipSuccess) { aukit_batch_free(b); return fail(AUKIT_E_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e2)); }
     }
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may free `bytes` right away
@@ -277,8 +282,10 @@ int aukit_batch_offsets(const aukit_batch *b, uint64_t *offsets) {
 const void *aukit_batch_device_ptr(const aukit_batch *b) { return b ? b->data() : nullptr; }
 int aukit_batch_download(aukit_ctx *ctx, const aukit_batch *b, uint8_t *dst) {
     if (!ctx || !b || !dst) return fail(AUKIT_E_ARG, "null argument");
-    if (b->total()) AUKIT_HIP_CHECK(hipMemcpyAsync(dst, b->data(), b->total(), hipMemcpyDeviceToHost, ctx->stream));
+    void *st = b->total() && b->total() <= ((size_t)64 << 20) ? host_stage(ctx, (size_t)b->total()) : nullptr;
+    if (b->total()) AUKIT_HIP_CHECK(hipMemcpyAsync(st ? st : dst, b->data(), b->total(), hipMemcpyDeviceToHost, ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (st) memcpy(dst, st, (size_t)b->total());
     return AUKIT_OK;
 }
 void aukit_batch_free(aukit_batch *b) {
@@ -314,22 +321,36 @@ int aukit_audio_download_raw(aukit_ctx *ctx, const aukit_audio *a, void *dst) {
     return AUKIT_OK;
 }
 
+// pinned staging buffer of the context, grown on demand (up to 1 GiB; beyond that the caller's pageable memory is used directly)
+static void *host_stage(aukit_ctx *ctx, size_t bytes) {
+    if (bytes > ((size_t)1 << 30)) return nullptr;
+    if (ctx->host_stage_cap < bytes) {
+        if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+        ctx->host_stage = nullptr; ctx->host_stage_cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+        if (hipHostMalloc(&ctx->host_stage, cap, hipHostMallocDefault) != hipSuccess) { ctx->host_stage = nullptr; (void)hipGetLastError(); return nullptr; }
+        ctx->host_stage_cap = cap;
+    }
+    return ctx->host_stage;
+}
+
 int aukit_audio_download(aukit_ctx *ctx, const aukit_audio *a, double *dst) {
     if (!ctx || !a || !dst) return fail(AUKIT_E_ARG, "null argument");
-    std::vector<unsigned char> raw((size_t)a->total * dtype_size(a->dtype) + 8);
-    int rc = aukit_audio_download_raw(ctx, a, raw.data());
+    const size_t bytes = (size_t)a->total * dtype_size(a->dtype);
+    std::vector<unsigned char> pageable;
+    const unsigned char *raw = static_cast<const unsigned char *>(host_stage(ctx, bytes + 8));
+    if (!raw) { pageable.resize(bytes + 8); raw = pageable.data(); }
+    int rc = aukit_audio_download_raw(ctx, a, const_cast<unsigned char *>(raw));
     if (rc) return rc;
     size_t w = 0;
     for (uint32_t s = 0; s < a->n; s++)
         for (int c = 0; c < a->channels; c++) {
-            size_t base = (size_t)a->row_off[s] + (size_t)c * a->row_stride[s];
-            for (uint64_t i = 0; i < a->len[s]; i++) {
-                double v;
-                if (a->dtype == AUKIT_F64) v = reinterpret_cast<const double *>(raw.data())[base + i];
-                else if (a->dtype == AUKIT_F32) v = (double)reinterpret_cast<const float *>(raw.data())[base + i];
-                else v = (double)reinterpret_cast<const signed char *>(raw.data())[base + i];
-                dst[w++] = v;
-            }
+            const size_t base = (size_t)a->row_off[s] + (size_t)c * a->row_stride[s];
+            const uint64_t L = a->len[s];
+            if (a->dtype == AUKIT_F64) memcpy(dst + w, reinterpret_cast<const double *>(raw) + base, (size_t)L * 8);
+            else if (a->dtype == AUKIT_F32) { const float *p = reinterpret_cast<const float *>(raw) + base; for (uint64_t i = 0; i < L; i++) dst[w + i] = (double)p[i]; }
+            else { const signed char *p = reinterpret_cast<const signed char *>(raw) + base; for (uint64_t i = 0; i < L; i++) dst[w + i] = (double)p[i]; }
+            w += (size_t)L;
         }
     return AUKIT_OK;
 }
