@@ -184,6 +184,8 @@ __global__ __launch_bounds__(64) void k_dfpwm_transcode_stereo(const unsigned ch
 
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
                            const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0);
+bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff,
+                           int *rc);  // exact parallel encoder for batches of a few streams (dfpwm_par.hip)
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const unsigned long long *d_in_off, const unsigned long long *d_count, uint32_t n, unsigned char *out,
                     const unsigned long long *d_ooff);
 
@@ -831,10 +833,13 @@ int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, a
         hipLaunchKernelGGL((k_dfpwm_quantize<float>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float *>(in->dev), m, m + in->n, m + 2 * (size_t)in->n,
                            in->channels, interleaved, q, t, err);
     AUKIT_HIP_CHECK(hipGetLastError());
-    if ((rc = dfpwm_encode_i8(ctx, q, t, t + in->n, in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off)))) return rc;
+    int erc = AUKIT_OK;
+    const bool small = dfpwm_encode_i8_small(ctx, q, tab.data(), tab.data() + in->n, in->n, b->data(), off.data(), &erc);
+    if (small && erc) return erc;
+    if (!small && (rc = dfpwm_encode_i8(ctx, q, t, t + in->n, in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off)))) return rc;
     uint64_t elems = 0;
     for (uint64_t l : in->len) elems += l * in->channels;
-    if ((rc = ctx_end_kernel(ctx, "k_dfpwm_quantize+k_dfpwm_encode_i8", elems * dtype_size(in->dtype) + off[in->n]))) return rc;
+    if ((rc = ctx_end_kernel(ctx, small ? "k_dfpwm_quantize+k_dfe_*" : "k_dfpwm_quantize+k_dfpwm_encode_i8", elems * dtype_size(in->dtype) + off[in->n]))) return rc;
     int herr = 0;
     AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -896,6 +901,11 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
         int prc = AUKIT_OK;
         if (dfpwm_decode_parallel(ctx, in, 1, 2, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, nullptr, &prc)) {
             if (prc) return prc;
+            int erc = AUKIT_OK;
+            if (dfpwm_encode_i8_small(ctx, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), tab.data(), tab.data() + in->n, in->n, b->data(), off.data(), &erc)) {
+                if (erc) return erc;
+                return ctx_end_kernel(ctx, "k_df_chunks+k_dfe_*", in->total() + off[in->n]);
+            }
             if ((rc = dfpwm_encode_i8(ctx, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), t, t + in->n, in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off)))) return rc;
             return ctx_end_kernel(ctx, "k_df_chunks+k_dfpwm_encode_i8", in->total() + off[in->n]);
         }

@@ -1,4 +1,5 @@
-// dfpwm_par.hip — chunk-parallel DFPWM *decoding*, bit-exact (the encoder stays one lane per stream: its bits depend on its state).
+// dfpwm_par.hip — chunk-parallel DFPWM decoding, bit-exact; the serial int8 encoder; and an exact parallel encoder for small batches
+// (second half of the file).
 //
 // aukit.dfpwm feeds one decoder per stream, serially (aukit.lua:1399-1412).  One lane per stream leaves most of the GPU idle for
 // batches below ~10^5 streams, and speculation on the whole state does not work: the strength counter only forgets its start at
@@ -397,6 +398,203 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
         h_fed[s] = nb ? nb + (nb + adv - 1) / adv - 1 : 0;  // Σ min(adv + 1, nb - adv k)
     }
     return dfpwm_decode_parallel_feed(ctx, in->data(), h_off, h_fed, adv + 1, adv, mode, C, out, d_out_off, d_out_stride, lead, rc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Exact parallel ENCODING for small batches (one file is the usual batch of auconvert: 12 ms of serial encoder for ten seconds).
+// The encoder's bits depend on its state, so nothing is scannable — but its state space collapses: started 2048 samples early from
+// every (strength, previous bit) pair and an arbitrary charge, the 2032 candidate encoders end in a handful of distinct states
+// (4-11 on synthetic audio, CPU experiment), and the true state is one of them.  So, per chunk of ~7500 samples:
+//   1. k_dfe_cand      2032 lanes warm up over the 2048 samples before the chunk                      → candidate start states
+//   2. k_dfe_distinct  the distinct ones (LDS hash set, at most 64)
+//   3. k_dfe_ends      one lane per distinct start state runs the chunk                               → its end state
+//   4. k_dfe_resolve   one lane per stream walks its chunks from the reset state: the true start of a chunk is the end of the one
+//                      before it; looked up among the chunk's candidates — or, if it is not there, the chunk is run on the spot
+//   5. k_dfe_emit      one lane per chunk encodes it from its true start state
+// Exact by construction (step 4 only ever follows true states); the candidates decide the speed, not the bytes.  Work grows by
+// ~500x per stream, so this is for batches of a few streams; larger ones keep one lane per stream.
+struct DfeChunk { u64 in_off, out_off; unsigned count, stream, first, last; };
+constexpr unsigned DFE_W = 2048, DFE_NC = 2032, DFE_INIT = 128u;  // warm-up samples; candidates = 1016 strengths x 2; reset state packed
+AUKIT_DEV unsigned dfe_pack(const DfEnc &e) { return (unsigned)e.cu | (unsigned)e.strength << 8 | (e.pb > 0 ? 1u << 18 : 0u); }
+AUKIT_DEV DfEnc dfe_unpack(unsigned v) { DfEnc e; e.cu = (int)(v & 255u); e.strength = (int)((v >> 8) & 1023u); e.pb = (v >> 18) & 1u ? 1 : -1; return e; }
+
+// runs `count` samples of one chunk; EMIT: writes count / 8 bytes (+ one padded with samples of value 0 when `pad`)
+template <bool EMIT>
+AUKIT_DEV void dfe_run(const signed char *p, unsigned count, DfEnc &e, unsigned char *o, bool pad) {
+    unsigned i = 0;
+    uint4 cur = count ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);  // chunk starts are 16-byte aligned, rows are padded
+    for (; i + 16 <= count; i += 16) {
+        uint4 nxt = cur;
+        if (i + 16 < count) nxt = *reinterpret_cast<const uint4 *>(p + i + 16);
+        const unsigned w[4] = {cur.x ^ 0x80808080u, cur.y ^ 0x80808080u, cur.z ^ 0x80808080u, cur.w ^ 0x80808080u};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned byte = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) byte |= df_encode_u(e, (w[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF) & (1u << b);
+            if (EMIT) o[(i >> 3) + h] = (unsigned char)byte;
+        }
+        cur = nxt;
+    }
+    if (i < count) {  // the stream's last samples
+        const unsigned w[4] = {cur.x ^ 0x80808080u, cur.y ^ 0x80808080u, cur.z ^ 0x80808080u, cur.w ^ 0x80808080u};
+        for (unsigned k0 = i; k0 < count; k0 += 8) {
+            if (!pad && k0 + 8 > count) break;
+            unsigned byte = 0;
+            for (int b = 0; b < 8; b++) {
+                const unsigned k = k0 + b;
+                const unsigned u = k < count ? (w[(k - i) >> 2] >> (8 * ((k - i) & 3))) & 0xFF : 128u;
+                byte |= df_encode_u(e, u) & (1u << b);
+            }
+            if (EMIT) o[k0 >> 3] = (unsigned char)byte;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dfe_cand(const signed char *in, const DfeChunk *chunks, unsigned *cand) {
+    __shared__ unsigned char warm[DFE_W];
+    const DfeChunk ch = chunks[blockIdx.y];
+    const unsigned id = blockIdx.x * 256 + threadIdx.x;
+    unsigned *dst = cand + (size_t)blockIdx.y * 2048 + id;
+    if (ch.first) { *dst = 0xFFFFFFFFu; return; }  // the stream's first chunk starts from the reset state
+    const signed char *p = in + ch.in_off - DFE_W;
+    *reinterpret_cast<uint2 *>(warm + 8 * threadIdx.x) = *reinterpret_cast<const uint2 *>(p + 8 * threadIdx.x);
+    __syncthreads();
+    if (id >= DFE_NC) { *dst = 0xFFFFFFFFu; return; }
+    DfEnc e;
+    e.cu = 128; e.strength = 8 + (int)(id >> 1); e.pb = id & 1 ? 1 : -1;
+    for (unsigned k = 0; k < DFE_W; k += 4) {
+        const unsigned w = *reinterpret_cast<const unsigned *>(warm + k) ^ 0x80808080u;
+#pragma unroll
+        for (int b = 0; b < 4; b++) df_encode_u(e, (w >> (8 * b)) & 0xFF);
+    }
+    *dst = dfe_pack(e);
+}
+
+__global__ __launch_bounds__(256) void k_dfe_distinct(const DfeChunk *chunks, const unsigned *cand, unsigned *dist, unsigned *dcount) {
+    __shared__ unsigned table[128];
+    __shared__ int overflow;
+    const unsigned c = blockIdx.x;
+    if (threadIdx.x < 128) table[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) overflow = 0;
+    __syncthreads();
+    if (chunks[c].first) {
+        if (threadIdx.x == 0) { dist[(size_t)c * 64] = DFE_INIT; dcount[c] = 1; }
+        return;
+    }
+    for (unsigned i = threadIdx.x; i < 2048; i += 256) {
+        const unsigned v = cand[(size_t)c * 2048 + i];
+        if (v == 0xFFFFFFFFu) continue;
+        unsigned h = (v * 2654435761u) >> 25;
+        int probes = 0;
+        for (;; h = (h + 1) & 127) {
+            const unsigned old = atomicCAS(&table[h], 0xFFFFFFFFu, v);
+            if (old == 0xFFFFFFFFu || old == v) break;
+            if (++probes > 127) { overflow = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned k = 0;
+        for (int h = 0; h < 128; h++)
+            if (table[h] != 0xFFFFFFFFu) { if (k < 64) dist[(size_t)c * 64 + k] = table[h]; k++; }
+        dcount[c] = (k > 64 || overflow) ? 0u : k;  // too many survivors: the resolve pass runs this chunk itself
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dfe_ends(const signed char *in, const DfeChunk *chunks, const unsigned *dist, const unsigned *dcount, unsigned *dend) {
+    const unsigned c = blockIdx.x, k = threadIdx.x;
+    if (k >= dcount[c]) return;
+    const DfeChunk ch = chunks[c];
+    DfEnc e = dfe_unpack(dist[(size_t)c * 64 + k]);
+    dfe_run<false>(in + ch.in_off, ch.count, e, nullptr, false);
+    dend[(size_t)c * 64 + k] = dfe_pack(e);
+}
+
+__global__ __launch_bounds__(64) void k_dfe_resolve(const signed char *in, const DfeChunk *chunks, const unsigned *stream_first, unsigned n, const unsigned *dist,
+                                                   const unsigned *dcount, const unsigned *dend, unsigned *start, unsigned *stats) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    unsigned state = DFE_INIT, missed = 0;
+    for (unsigned c = stream_first[s]; c < stream_first[s + 1]; c++) {
+        start[c] = state;
+        unsigned found = 0xFFFFFFFFu;
+        for (unsigned k = 0; k < dcount[c]; k++)
+            if (dist[(size_t)c * 64 + k] == state) found = k;
+        if (found != 0xFFFFFFFFu) state = dend[(size_t)c * 64 + found];
+        else {  // not among the candidates: run the chunk from the true state here
+            const DfeChunk ch = chunks[c];
+            DfEnc e = dfe_unpack(state);
+            dfe_run<false>(in + ch.in_off, ch.count, e, nullptr, false);
+            state = dfe_pack(e);
+            missed++;
+        }
+    }
+    if (missed) atomicAdd(&stats[0], missed);
+}
+
+__global__ __launch_bounds__(64) void k_dfe_emit(const signed char *in, const DfeChunk *chunks, unsigned nchunks, const unsigned *start, unsigned char *out) {
+    const unsigned c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= nchunks) return;
+    const DfeChunk ch = chunks[c];
+    DfEnc e = dfe_unpack(start[c]);
+    dfe_run<true>(in + ch.in_off, ch.count, e, out + ch.out_off, ch.last != 0);
+}
+
+// host: returns true when the small-batch path took the encode (*rc = its status).  h_* are host copies of the device tables.
+bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff,
+                           int *rc) {
+    if (n == 0 || n > 16 || getenv("AUKIT_DFPWM_SERIAL")) return false;
+    uint64_t maxc = 0;
+    for (uint32_t s = 0; s < n; s++) maxc = std::max(maxc, h_count[s]);
+    if (maxc < 65536 || maxc > 0xF0000000ull) return false;
+    std::vector<DfeChunk> chunks;
+    std::vector<unsigned> sfirst(n + 1, 0);
+    unsigned want = 64;  // chunks per stream
+    if (const char *e = getenv("AUKIT_DFPWM_ENC_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
+    for (uint32_t s = 0; s < n; s++) {
+        sfirst[s] = (unsigned)chunks.size();
+        const uint64_t N = h_count[s];
+        uint64_t L = std::max<uint64_t>(4096, ((N + want - 1) / want + 63) & ~63ull);  // a multiple of 64 samples, at least 2 warm-ups long
+        for (uint64_t p = 0; p < N || p == 0; p += L) {
+            DfeChunk c;
+            c.in_off = h_in_off[s] + p; c.out_off = h_ooff[s] + p / 8; c.count = (unsigned)std::min<uint64_t>(L, N - p); c.stream = s;
+            c.first = p == 0 ? 1u : 0u; c.last = p + L >= N ? 1u : 0u;
+            chunks.push_back(c);
+            if (N == 0) break;
+        }
+    }
+    sfirst[n] = (unsigned)chunks.size();
+    const size_t nch = chunks.size();
+    const size_t b_chunks = nch * sizeof(DfeChunk), b_sf = ((size_t)n + 1) * 4, b_cand = nch * 2048 * 4, b_dist = nch * 64 * 4, b_cnt = nch * 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_chunks = take(b_chunks), o_sf = take(b_sf), o_cand = take(b_cand), o_dist = take(b_dist), o_dcount = take(b_cnt), o_dend = take(b_dist), o_start = take(b_cnt), o_stats = take(16);
+    if ((*rc = ctx->tmp_buf3.ensure(o + 64))) return true;
+    char *B = reinterpret_cast<char *>(ctx->tmp_buf3.p);
+    if (hipMemcpyAsync(B + o_chunks, chunks.data(), b_chunks, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(B + o_sf, sfirst.data(), b_sf, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(B + o_stats, 0, 16, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        *rc = fail(AUKIT_E_HIP, "upload of the DFPWM encoder chunk table failed");
+        return true;
+    }
+    const DfeChunk *dch = reinterpret_cast<const DfeChunk *>(B + o_chunks);
+    unsigned *cand = reinterpret_cast<unsigned *>(B + o_cand), *dist = reinterpret_cast<unsigned *>(B + o_dist), *dcount = reinterpret_cast<unsigned *>(B + o_dcount);
+    unsigned *dend = reinterpret_cast<unsigned *>(B + o_dend), *start = reinterpret_cast<unsigned *>(B + o_start), *stats = reinterpret_cast<unsigned *>(B + o_stats);
+    hipLaunchKernelGGL(k_dfe_cand, dim3(8, (unsigned)nch), dim3(256), 0, ctx->stream, in, dch, cand);
+    hipLaunchKernelGGL(k_dfe_distinct, dim3((unsigned)nch), dim3(256), 0, ctx->stream, dch, cand, dist, dcount);
+    hipLaunchKernelGGL(k_dfe_ends, dim3((unsigned)nch), dim3(64), 0, ctx->stream, in, dch, dist, dcount, dend);
+    hipLaunchKernelGGL(k_dfe_resolve, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in, dch, reinterpret_cast<const unsigned *>(B + o_sf), n, dist, dcount, dend, start, stats);
+    hipLaunchKernelGGL(k_dfe_emit, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, ctx->stream, in, dch, (unsigned)nch, start, out);
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM encode launch failed"); return true; }
+    if (getenv("AUKIT_DFPWM_STATS")) {
+        unsigned h[2] = {0, 0};
+        (void)hipMemcpyAsync(h, stats, 8, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[dfpwm] encoder: %u streams in %zu chunks, %u chunk starts not among the candidates (run serially)\n", n, nch, h[0]);
+    }
+    *rc = AUKIT_OK;
+    return true;
 }
 
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const u64 *d_in_off, const u64 *d_count, uint32_t n, unsigned char *out, const u64 *d_ooff) {

@@ -112,7 +112,7 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle, monkeypatch):
         assert u == ref
         assert f == ref
     assert len(fused[0]) == 60010  # Q10: 120 000 B → 960 152 samples → 480 076 mono samples → 60 010 B
-    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfpwm_encode_i8"  # chunk-parallel exact decode + one encoder lane per stream
+    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfe_*"  # chunk-parallel exact decode + (four streams: a small batch) the exact parallel encoder
     # the same bytes through every schedule: one lane per stream; 2-byte blocks (a warm-up of 16 steps: most recorded start states
     # are wrong and the verify pass redoes the chunks); chunk and Q10 slice boundaries in odd positions
     for env in ({"AUKIT_DFPWM_SERIAL": "1"}, {"AUKIT_DFPWM_BLOCK": "2", "AUKIT_DFPWM_CHUNKS": "1000"}, {"AUKIT_DFPWM_BLOCK": "6002", "AUKIT_DFPWM_CHUNKS": "50"},
@@ -346,3 +346,34 @@ def test_stream_qoa(ctx, oracle, ch, mono, interp):
         assert ck.status[i] == ref.final_status
         for c in range(ref.channels):
             assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-12, (i, c)
+
+
+def test_dfpwm_parallel_encoder_small_batches(ctx, oracle, monkeypatch):
+    """Batches of a few long streams encode in parallel chunks (candidate start states from a 2048-sample warm-up of every
+    (strength, previous bit) pair, true states chained through them): the bytes equal the serial encoder's and the oracle's for
+    ordinary audio, rail-to-rail squares, silence, full-scale noise and constant rails, with 64 / 7 / 200 chunks per stream."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 200000
+    t = np.arange(n) / 48000
+    sigs = [0.6 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.1, 0.1, n), np.where((np.arange(n) // 300) % 2 == 0, 1.0, -1.0), np.zeros(n), rng.uniform(-1, 1, n),
+            np.full(n, 1.0), np.full(n, -1.0), 0.02 * np.sin(2 * np.pi * 50 * t), np.concatenate([np.zeros(70000), rng.uniform(-1, 1, 60001), np.full(69999, 0.5)])]
+    sigs.append(sigs[0][:65536])
+    sigs.append(sigs[3][:70003])
+    ab = B.AudioBatch.upload(ctx, [[x] for x in sigs], 48000, dtype=N.F64)
+    got = B.dfpwm_encode(ctx, ab, True).download()
+    assert ctx.last_kernel()[0] == "k_dfpwm_quantize+k_dfe_*", ctx.last_kernel()
+    for x, g in zip(sigs, got):
+        assert g == oracle.audio_dfpwm(oracle.Audio([x], 48000), True)
+    for env in ({"AUKIT_DFPWM_ENC_CHUNKS": "7"}, {"AUKIT_DFPWM_ENC_CHUNKS": "200"}, {"AUKIT_DFPWM_SERIAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        again = B.dfpwm_encode(ctx, ab, True).download()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert again == got, env
+    # stereo, interleaved and channel after channel, through the same encoder
+    st = [[sigs[0][:100000], sigs[3][:100000]]]
+    ab2 = B.AudioBatch.upload(ctx, st, 48000, dtype=N.F64)
+    for inter in (True, False):
+        assert B.dfpwm_encode(ctx, ab2, inter).download()[0] == oracle.audio_dfpwm(oracle.Audio(st[0], 48000), inter)
