@@ -14,6 +14,7 @@ checks arguments the way cc.expect does, and moves handles around.  Lua `data` s
 Batch use (N streams per call) goes through `aukit_amd.batch` directly.
 """
 import math
+import re
 import struct
 
 import numpy as np
@@ -501,6 +502,66 @@ def au(data):  # aukit.lua:1639
     if e == 27:
         return g711(p, False, ch, sr)
     raise LuaError(f"unsupported encoding type {e}")
+
+
+# aukit.lua:2134-2146: (string.unpack format, bit depth, data type) in table order; every format reads 8 values
+_DETECT_FMTS = (("<8b", 8, "signed"), ("<8B", 8, "unsigned"), ("<8h", 16, "signed"), ("<8i", 32, "signed"),
+                ("<8f", 32, "float"), (None, 24, "signed"), ("<8I", 32, "unsigned"), (None, 24, "unsigned"),
+                ("<8H", 16, "unsigned"))
+
+
+def _detect_unpack(fmt, bits, typ, data, init):
+    """pcall(string.unpack, fmt, data, init) → list of 8 numbers or None (Lua 5.3 lstrlib.c str_unpack position rules)."""
+    n = len(data)
+    if init < 0:
+        init = 0 if -init > n else n + init + 1
+    if init < 1 or init - 1 > n:  # "initial position out of string"
+        return None
+    nbytes = bits  # 8 values of bits/8 bytes
+    raw = data[init - 1:init - 1 + nbytes]
+    if len(raw) < nbytes:  # "data string too short"
+        return None
+    if fmt is not None:
+        return list(struct.unpack(fmt, raw))
+    return [int.from_bytes(raw[i:i + 3], "little", signed=(typ == "signed")) for i in range(0, 24, 3)]
+
+
+def detect(data):  # aukit.lua:2156 → (type, bitDepth, dataType); host-side bytes only
+    """Container magic, then the reference's "near silence at either end" PCM heuristic, then the DFPWM idle pattern."""
+    _expect(1, data, "string")
+    data = bytes(data)
+    if re.match(rb"RIFF....WAVE", data, re.S):
+        return "wav", None, None
+    if re.match(rb"FORM....AIF[FC]", data, re.S):
+        return "aiff", None, None
+    if data[:4] == b".snd":
+        return "au", None, None
+    if data[:4] == b"fLaC":
+        return "flac", None, None
+    if data[:7] == b"MDFPWM\x03":
+        return "mdfpwm", None, None
+    if data[:4] == b"qoaf":
+        return "qoa", None, None
+    for fmt, bits, typ in _DETECT_FMTS:
+        mid = 2.0 ** (bits - 1) if typ == "unsigned" else 0
+        gap = 0.001 if typ == "float" else 8 * 2.0 ** (bits - 8)
+        # :2172 reads from the start, :2183 from `#data - bitDepth` (the bit depth, not the byte count, is subtracted)
+        for init in (1, len(data) - bits):
+            nums = _detect_unpack(fmt, bits, typ, data, init)
+            if nums is None:
+                continue
+            allzero, ok = True, True
+            for v in nums:
+                if v != mid:
+                    allzero = False
+                if v < mid - gap or v > mid + gap:
+                    ok = False
+                    break
+            if ok and not allzero:
+                return "pcm", bits, typ
+    if b"\x55" * 12 in data or b"\xaa" * 12 in data:
+        return "dfpwm", None, None
+    return None, None, None
 
 
 # ---------------------------------------------------------------- aukit.stream.*  (aukit.lua:2207-3337)
