@@ -208,7 +208,10 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             // prefill :2376-2386 reads eagerly up to index iend
             if (src_base + iend[interp] > nframes - 1) { ck->status[s] = is_float ? 0 : AUKIT_E_LUA; break; }
             const long long w_avail = nframes - 1 - src_base;
-            const std::vector<int> &need = is_float ? cp.req : cp.acc;
+            // float strings: read() hands out nil past the end (:2291-2311) and interpolate falls back on its neighbours, so only the
+            // floor index must exist; with a mono mix-down of several channels the lazy __index adds that nil (:2368) and raises
+            // like the integer readers do on their first read past the end
+            const std::vector<int> &need = (is_float && !mono) ? cp.req : cp.acc;
             uint32_t n_out = (uint32_t)(std::upper_bound(need.begin(), need.end(), (int)std::min<long long>(w_avail, 0x7FFFFFFF)) - need.begin());
             if (n_out == 0) break;  // :2407
             Seg g;

@@ -267,6 +267,25 @@ def test_stream_pcm_f32_tolerance_and_float_input(ctx, oracle):
     assert np.max(np.abs(out.download()[0][0] - ref.data[0])) <= 1e-13
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("ch,mono", [(2, False), (2, True), (3, False), (3, True)])
+def test_stream_pcm_float_end_of_data(ctx, oracle, interp, ch, mono):
+    """32-bit float strings: read() returns nil past the end (aukit.lua:2291-2311).  Per channel the interpolators fall back on
+    the neighbouring sample and the chunk runs on to the next whole index; with a mono mix-down the lazy __index adds that nil
+    (:2368) and the chunk ends at the first read past the end, like the integer formats (found by the seed soak)."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(77 + ch))
+    streams = [rng.uniform(-1, 1, n * ch).astype("<f4").tobytes() for n in (3, 4, 1716, 12000 + 7)]
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_PCM, ch, 12000, 32, "float"), interp, mono=mono, dtype=N.F64)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, 32, oracle.FLOAT, ch, 12000, False, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        for c in range(ref.channels):
+            assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-13, (i, c)
+
+
 @pytest.mark.parametrize("interp", ["none", "linear", "cubic"])
 @pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
 def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):

@@ -1166,3 +1166,30 @@ def test_q8_wav_ima_loader_transliterated(oracle, ch):
             chans[c] += blk[c]
     for c in range(ch):
         assert np.array_equal(ref.data[c], np.array(chans[c])), c
+
+
+def test_stream_pcm_float_string_end_of_data_by_hand(oracle):
+    """Worked by hand from aukit.lua:2291-2311 / :2367-2371 / :228-266, 3 frames at 12 kHz (ratio 4), linear:
+    float read() returns nil past the end instead of raising.  Per channel: outputs 10-12 (x = 3.25 .. 3.75) take
+    `data[4] or data[3]` and equal d[3]; output 13 is `d[y][4]` = nil and `s - ls[y]` raises → 12 samples.  Mono over 2+ channels:
+    the lazy __index computes `(rawget(self, i) or 0) + read()` → arithmetic on nil at output 10 → 9 samples, as for integers,
+    whose read() raises at the same place on `s < 0`.  One channel forces mono off (:2243)."""
+    for ch in (1, 2, 3):
+        x = np.linspace(-0.5, 0.75, 3 * ch)
+        f = x.astype("<f4").tobytes()
+        per_channel = oracle.stream_pcm(f, 32, oracle.FLOAT, ch, 12000, False, False, oracle.LINEAR)
+        assert per_channel.nchunks == 1 and list(per_channel.chunk_len[:, 0]) == [12] and per_channel.final_status == 0
+        xf = x.astype("<f4").astype(np.float64).reshape(3, ch)
+        alpha = 1 - np.exp(-(12000 / 96000) * 2 * np.pi)
+        for c in range(ch):
+            s = [xf[0, c] + (xf[1, c] - xf[0, c]) * k / 4 for k in range(4)] + [xf[1, c] + (xf[2, c] - xf[1, c]) * k / 4 for k in range(4)] + [xf[2, c]] * 4
+            ls, want = 0.0, []
+            for v in s:
+                ns = ls + alpha * (v - ls)
+                want.append(min(max(ns * (128 if ns < 0 else 127), -128), 127))
+                ls = v
+            assert np.max(np.abs(per_channel.data[c] - np.array(want))) <= 1e-12
+        mixed = oracle.stream_pcm(f, 32, oracle.FLOAT, ch, 12000, False, True, oracle.LINEAR)
+        assert list(mixed.chunk_len[:, 0]) == ([12] if ch == 1 else [9]) and mixed.final_status == 0
+        i16 = (x * 30000).astype("<i2").tobytes()
+        assert list(oracle.stream_pcm(i16, 16, oracle.SIGNED, ch, 12000, False, False, oracle.LINEAR).chunk_len[:, 0]) == [9]
