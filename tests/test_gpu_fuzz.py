@@ -648,3 +648,84 @@ def test_degenerate_batches_do_not_crash(ctx, oracle):
     s = np.arange(-500, 500, dtype=np.int16).tobytes()
     got = B.decode(ctx, B.Batch.upload(ctx, [s]), descs[0], dtype=N.F64).download()[0][0]
     assert np.array_equal(got, oracle.pcm(s, 16, oracle.SIGNED, 1, 44100).data[0])
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
+def test_fuzz_adpcm_loaders(ctx, oracle, seed):
+    """aukit.adpcm on random bytes with random channel count / nibble order / planar layout / start predictor and step index
+    (aukit.lua:1183-1274), and aukit.wav's IMA blocks (aukit.lua:1509-1548) at random block sizes incl. a partial last block"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(12000 + seed))
+    ch = int(rng.integers(1, 4))
+    top_first, interleaved = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    pred = [int(rng.integers(-32768, 32768)) for _ in range(ch)]
+    idx = [int(rng.integers(0, 89)) for _ in range(ch)]
+    streams = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (1, 2, ch, ch * int(rng.integers(2, 700)), 3 * ch * int(rng.integers(100, 900)))]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_ADPCM, ch, 22050, interleaved=interleaved, top_first=top_first, predictor=pred, step_index=idx)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    for s, g in zip(streams, got):
+        ref = oracle.adpcm(s, ch, 22050, top_first, interleaved, pred, idx)
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c]), (ch, top_first, interleaved, len(s), c)
+    wch = int(rng.integers(1, 3))
+    ba = 4 * wch * int(rng.integers(2, 260))
+    spb = (ba - 4 * wch) * 2 // wch
+    files = []
+    for nb in (1, int(rng.integers(2, 9))):
+        x = rng.integers(-20000, 20000, (spb * nb, wch)).astype(np.int16)
+        f = oracle.gen_ima(x.ravel(), wch, ba, int(rng.integers(0, 16)))
+        files.append(f)
+    if wch == 1 and ba > 9:
+        files.append(files[-1][: len(files[-1]) - int(rng.integers(1, ba - 8))])
+    bt = B.Batch.upload(ctx, files)
+    desc = B.make_desc(N.CODEC_ADPCM_WAV, wch, 22050, block_align=ba)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    res = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    for f, g, r in zip(files, got, res):
+        ref = oracle.wav_adpcm(f, ba, wch, 22050)
+        rr = oracle.resample(ref, 48000, oracle.INTERP[interp])
+        for c in range(wch):
+            assert np.array_equal(g[c], ref.data[c]), (wch, ba, len(f), c)
+            assert len(r[c]) == len(rr.data[c]) and np.max(np.abs(r[c] - rr.data[c]), initial=0) <= 1e-15, (wch, ba, interp, c)
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
+def test_fuzz_encode_pcm_sinc_speed(ctx, oracle, seed):
+    """Audio:pcm (aukit.lua:901) at every bit depth / type / layout on samples over the whole [-1, 1] range incl. exact ±1 and 0,
+    sinc resampling (aukit.lua:267-281) between random rates, effects.speed (aukit.lua:3376) with a random multiplier"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(13000 + seed))
+    ch = int(rng.integers(1, 4))
+    rate = int(rng.choice(RATES))
+    a = []
+    for n in (1, 2, int(rng.integers(3, 40)), int(rng.integers(500, 4000))):
+        rows = [rng.uniform(-1, 1, n) for _ in range(ch)]
+        for r in rows:
+            r[rng.integers(0, n)] = [1.0, -1.0, 0.0][int(rng.integers(0, 3))]
+        a.append(rows)
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F64)
+    bits = int(rng.choice([8, 16, 24, 32]))
+    dt = ["signed", "unsigned", "float"][int(rng.integers(0, 3 if bits == 32 else 2))]
+    inter = bool(rng.integers(0, 2))
+    got = B.encode_pcm(ctx, ab, bits, dt, inter).download()
+    for s in range(len(a)):
+        ref = oracle.encode_pcm(oracle.Audio(a[s], rate), bits, oracle.DTYPE[dt], inter)
+        assert np.array_equal(got[s][0], ref), (bits, dt, inter, ch, s)
+    new_rate = int(rng.choice([48000, 16000, 44100, 8000, 96000]))
+    if new_rate != rate:
+        r = B.resample(ctx, ab, new_rate, "sinc").download()
+        for s in range(len(a)):
+            rr = oracle.resample(oracle.Audio(a[s], rate), new_rate, oracle.SINC)
+            for c in range(ch):
+                assert len(r[s][c]) == len(rr.data[c]) and _maxdiff(r[s][c], rr.data[c]) <= 1e-11, (rate, new_rate, s, c)
+    mult = float(rng.choice([0.5, 0.75, 1.25, 2.0, float(rng.uniform(0.3, 3.0))]))
+    if mult != 1.0:
+        di = int(rng.integers(1, 3))  # aukit.defaultInterpolation: linear / cubic
+        B.effect(ctx, ab, "speed", mult, di)
+        sp = ab.download()
+        for s in range(len(a)):
+            ref = oracle.fx_speed(oracle.Audio(a[s], rate), mult, [None, oracle.LINEAR, oracle.CUBIC][di])
+            for c in range(ch):
+                assert len(sp[s][c]) == len(ref.data[c]) and _maxdiff(sp[s][c], ref.data[c]) <= 1e-15, (mult, di, s, c)
