@@ -729,3 +729,46 @@ def test_fuzz_encode_pcm_sinc_speed(ctx, oracle, seed):
             ref = oracle.fx_speed(oracle.Audio(a[s], rate), mult, [None, oracle.LINEAR, oracle.CUBIC][di])
             for c in range(ch):
                 assert len(sp[s][c]) == len(ref.data[c]) and _maxdiff(sp[s][c], ref.data[c]) <= 1e-15, (mult, di, s, c)
+
+
+@pytest.mark.parametrize("seed", _seeds(10))
+def test_fuzz_dfpwm_parallel_encoder(ctx, oracle, seed, monkeypatch):
+    """Audio:dfpwm (aukit.lua:1005) on small batches of long streams — the chunk-parallel exact encoder — over random signal
+    characters (tones with noise, bursts, rails, silence with clicks, slow ramps, full-scale noise), lengths just above the
+    65 536-sample threshold up to a few hundred thousand, 1-3 channels, random chunk counts: bytes equal to the oracle's."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(14000 + seed))
+    monkeypatch.setenv("AUKIT_DFPWM_ENC_CHUNKS", str(int(rng.choice([64, 3, 17, 128, 251]))))
+    ch = int(rng.integers(1, 4))
+    nstreams = int(rng.integers(1, 4))
+    a = []
+    for _ in range(nstreams):
+        n = int(rng.choice([65536, 65537, 70001, int(rng.integers(66000, 300000))]))
+        rows = []
+        for _ in range(ch):
+            t = np.arange(n) / 48000
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                x = rng.uniform(0.05, 0.9) * np.sin(2 * np.pi * rng.uniform(30, 9000) * t) + rng.uniform(-1, 1, n) * rng.uniform(0, 0.1)
+            elif kind == 1:
+                x = np.where(rng.uniform(0, 1, n) < 0.001, rng.uniform(-1, 1, n), 0.0)  # silence with clicks
+            elif kind == 2:
+                x = np.where((np.arange(n) // int(rng.integers(2, 5000))) % 2 == 0, 1.0, -1.0) * rng.choice([1.0, 0.5])
+            elif kind == 3:
+                x = np.linspace(-1, 1, n) * rng.choice([1.0, -1.0])
+            elif kind == 4:
+                env = (np.sin(2 * np.pi * rng.uniform(0.5, 5) * t) > 0.3).astype(np.float64)
+                x = env * rng.uniform(-1, 1, n) * rng.uniform(0.1, 1.0)  # noise bursts between silences
+            else:
+                x = rng.uniform(-1, 1, n) * rng.uniform(0.3, 1.0)
+            rows.append(np.clip(x, -1, 1))
+        a.append(rows)
+    ab = B.AudioBatch.upload(ctx, a, 48000, dtype=N.F64)
+    inter = bool(rng.integers(0, 2))
+    got = B.dfpwm_encode(ctx, ab, inter).download()
+    name = ctx.last_kernel()[0]
+    # noise-like chunks can leave more candidate states than the tables hold: those batches take the one-lane-per-stream encoder
+    assert name in ("k_dfpwm_quantize+k_dfe_*", "k_dfpwm_quantize+k_dfpwm_encode_i8"), name
+    print("encoder:", name)
+    for s in range(nstreams):
+        assert got[s] == oracle.audio_dfpwm(oracle.Audio(a[s], 48000), inter), (ch, nstreams, s, inter)
