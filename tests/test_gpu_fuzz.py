@@ -287,7 +287,7 @@ def test_fuzz_pcm_formats(ctx, oracle, seed):
     dt = ["signed", "unsigned", "float"][int(rng.integers(0, 3 if bits == 32 else 2))]
     be = bool(rng.integers(0, 2))
     ch = int(rng.integers(1, 4))
-    rate = int(rng.choice([8000, 12000, 22050, 44100, 48000]))
+    rate = int(rng.choice([8000, 12000, 22050, 44100, 48000] + RATES))
     interp = ["none", "linear", "cubic"][int(rng.integers(0, 3))]
     odt = {"signed": oracle.SIGNED, "unsigned": oracle.UNSIGNED, "float": oracle.FLOAT}[dt]
     streams = []
