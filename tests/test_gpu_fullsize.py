@@ -22,6 +22,21 @@ SCALE = float(os.environ.get("AUKIT_FULLSIZE_SCALE", "1.0"))
 K = 8  # distinct signals per batch
 
 
+def _huge_ok():
+    """the beyond-4-GiB batches hold tens of GB on the host: AUKIT_HUGE=1 / 0 forces them on / off, otherwise they run where the
+    host has at least 128 GiB available"""
+    v = os.environ.get("AUKIT_HUGE")
+    if v is not None:
+        return v == "1"
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) >= 128 * 1024 * 1024
+    except OSError:
+        pass
+    return False
+
+
 def _B():
     from aukit_amd import batch as B
     return B
@@ -212,3 +227,78 @@ def test_one_long_flac_file(ctx, oracle):
     assert ck.nchunks[0] == rs.nchunks and list(ck.lens[0][:rs.nchunks]) == list(rs.chunk_len[:, 0])
     for c in range(2):
         assert np.max(np.abs(a[c] - rs.data[c])) <= 1e-12, c
+
+
+@pytest.mark.skipif(not _huge_ok(), reason="needs ~25 GB of host memory and ~20 GB of HBM (AUKIT_HUGE=1 forces it)")
+def test_batch_beyond_4GiB_offsets(ctx):
+    """6144 × s16le 44.1 kHz 10 s: 5.4 GB of input (byte offsets past 2^32) → 11.8 GB of f32 output (element indices past 2^31).
+    Every stream is one of 8 signals: the rows must fall into 8 classes of identical rows, and each class must equal, bit for bit,
+    the row the same kernel produces in an 8-stream batch — for :resample and for stream.pcm."""
+    B, N = _B(), _N()
+    n = 6144
+    base = [pcm16(441000, 44100, 1, i).tobytes() for i in range(K)]
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    small = B.Batch.upload(ctx, base)
+    want = B.decode_resample(ctx, small, desc, 48000, "cubic", dtype=N.F32).download()
+    want_s = B.stream_decode(ctx, small, desc, "cubic", dtype=N.F32)[0].download()
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    assert int(bt.offsets()[-1]) > 2 ** 32
+    out = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave")
+    rows = _row_classes(out, n, 480000, K)
+    for c in range(K):
+        assert np.array_equal(rows[c], want[c][0]) and np.array_equal(rows[n - K + c], want[c][0]), c
+    del rows
+    out.free()
+    out, ck = B.stream_decode(ctx, bt, desc, "cubic", dtype=N.F32)
+    rows = _row_classes(out, n, len(want_s[0][0]), K)
+    for c in range(K):
+        assert np.array_equal(rows[c], want_s[c][0]) and np.array_equal(rows[n - K + c], want_s[c][0]), c
+    assert np.all(np.asarray(ck.nchunks) == ck.nchunks[0])
+
+
+@pytest.mark.skipif(not _huge_ok(), reason="needs ~40 GB of host memory and ~35 GB of HBM (AUKIT_HUGE=1 forces it)")
+def test_other_paths_beyond_4GiB(ctx, oracle):
+    """The same construction for the reference-order fp64 kernel (23.6 GB of f64 rows), stream.g711 → int8 (4.4 G output elements)
+    and the DFPWM stereo → mono → DFPWM transcode (4.8 GB of input): classes of identical rows equal to an 8-stream batch's."""
+    B, N = _B(), _N()
+    base = [pcm16(441000, 44100, 1, i).tobytes() for i in range(K)]
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    want = B.decode_resample(ctx, B.Batch.upload(ctx, base), desc, 48000, "cubic", dtype=N.F64).download()
+    n = 6144
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    out = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F64)
+    assert ctx.last_kernel()[0].startswith("k_exact_wave")
+    rows = _row_classes(out, n, 480000, K)
+    for c in range(K):
+        assert np.array_equal(rows[c], want[c][0]) and np.array_equal(rows[n - K + c], want[c][0]), c
+    del rows
+    out.free()
+    bt.free()
+
+    g = [oracle.gen_g711(pcm16(80000, 8000, 2, i), True) for i in range(K)]
+    gdesc = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
+    want = B.stream_decode(ctx, B.Batch.upload(ctx, g), gdesc, "cubic", dtype=N.I8)[0].download()
+    n = 9216
+    bt = B.Batch.upload(ctx, [g[i % K] for i in range(n)])
+    out, _ = B.stream_decode(ctx, bt, gdesc, "cubic", dtype=N.I8)
+    rows = _row_classes(out, n, len(want[0][0]), K)
+    assert rows.size > 2 ** 32
+    for c in range(K):
+        assert np.array_equal(rows[c], want[c][0]) and np.array_equal(rows[n - K + c], want[c][0]), c
+    del rows
+    out.free()
+    bt.free()
+
+    d = []
+    for i in range(K):
+        l, r = np.round(signal(480000, 48000, 4, 2 * i) * 100), np.round(signal(480000, 48000, 4, 2 * i + 1) * 90)
+        d.append(oracle.dfpwm_encode(np.stack([l, r], 1).ravel()))
+    assert len(d[0]) == 120000
+    want = B.dfpwm_transcode_mono(ctx, B.Batch.upload(ctx, d * 4), 2).download()  # 32 streams: the one-lane-per-stream encoder
+    n = 40000
+    bt = B.Batch.upload(ctx, [d[i % K] for i in range(n)])
+    assert int(bt.offsets()[-1]) > 2 ** 32
+    got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    for i in range(n):
+        assert got[i] == want[i % K], i
