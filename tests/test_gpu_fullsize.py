@@ -302,3 +302,43 @@ def test_other_paths_beyond_4GiB(ctx, oracle):
     got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
     for i in range(n):
         assert got[i] == want[i % K], i
+
+
+@pytest.mark.skipif(not _huge_ok(), reason="needs ~30 GB of host memory and ~40 GB of HBM (AUKIT_HUGE=1 forces it)")
+def test_flac_and_ima_beyond_4GiB(ctx, oracle):
+    """2560 × FLAC 44.1 kHz stereo 10 s (4.5 GB of frames: bit positions past 2^35) → lossless decode of every stream checked on a
+    spread of rows, the resampled pipeline rows in classes; 40 960 × 220 IMA blocks (4.6 GB) → stream.adpcm int8 in classes."""
+    import ctypes as C
+    B, N = _B(), _N()
+    k5, n = 4, 2560
+    pcm = [np.stack([pcm16(441000, 44100, 5, 2 * i), pcm16(441000, 44100, 5, 2 * i + 1)], 1).astype(np.int64) for i in range(k5)]
+    base = [oracle.gen_flac(p.ravel(), 2, 16, 44100, 4096) for p in pcm]
+    bt = B.Batch.upload(ctx, [base[i % k5] for i in range(n)])
+    assert int(bt.offsets()[-1]) > 2 ** 32
+    desc = B.make_desc(N.CODEC_FLAC)
+    dec = B.decode(ctx, bt, desc, dtype=N.F32)
+    lens, off, stride = dec.layout()
+    assert np.all(lens == 441000)
+    raw = np.zeros(dec.info()["total_elems"], dtype=np.float32)
+    N.check(N.lib().aukit_audio_download_raw(ctx._h, dec._h, raw.ctypes.data_as(C.c_void_p)))
+    for s_i in list(range(0, n, 37)) + list(range(n - 8, n)):
+        for c in range(2):
+            row = raw[int(off[s_i]) + c * int(stride[s_i]): int(off[s_i]) + c * int(stride[s_i]) + 441000]
+            assert np.array_equal(row, (pcm[s_i % k5][:, c] / 65536.0).astype(np.float32)), (s_i, c)
+    del raw
+    dec.free()
+    a = B.mono(ctx, B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32))
+    _row_classes(a, n, 480000, k5)
+    a.free()
+    bt.free()
+
+    ima = [oracle.gen_ima(pcm16(1016 * 220, 22050, 3, i), 1, 512, 88) for i in range(K)]
+    idesc = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
+    want = B.stream_decode(ctx, B.Batch.upload(ctx, ima), idesc, "cubic", dtype=N.I8)[0].download()
+    n = 40960
+    bt = B.Batch.upload(ctx, [ima[i % K] for i in range(n)])
+    assert int(bt.offsets()[-1]) > 2 ** 32
+    out, _ = B.stream_decode(ctx, bt, idesc, "cubic", dtype=N.I8)
+    rows = _row_classes(out, n, len(want[0][0]), K)
+    for c in range(K):
+        assert np.array_equal(rows[c], want[c][0]) and np.array_equal(rows[n - K + c], want[c][0]), c
