@@ -342,3 +342,36 @@ def test_flac_and_ima_beyond_4GiB(ctx, oracle):
     rows = _row_classes(out, n, len(want[0][0]), K)
     for c in range(K):
         assert np.array_equal(rows[c], want[c][0]) and np.array_equal(rows[n - K + c], want[c][0]), c
+
+
+@pytest.mark.skipif(not _huge_ok(), reason="needs ~20 GB of host memory (AUKIT_HUGE=1 forces it)")
+def test_single_stream_beyond_2G_samples(ctx, oracle):
+    """ONE s16le 44.1 kHz stream of 2.146e9 samples (13.5 hours, 4.3 GB; the library refuses more than 0x7FFFFFF0 frames per stream
+    with "stream too long") → cubic → 48 kHz f32: 2.336e9 outputs, output positions past 2^31.
+    44100/48000 = 147/160, so output 160k+1 sits exactly on input 147k+1: the oracle resamples windows of the input cut at
+    multiples of 147 and must match the GPU row at the corresponding multiples of 160 (head, middle, the last samples)."""
+    B, N = _B(), _N()
+    KK = 14_598_000  # a multiple of the 3000-block period
+    n_in = 147 * KK  # 2.1459e9 <= 0x7FFFFFF0
+    period = pcm16(147 * 3000, 44100, 1, 3)
+    x = np.tile(period, n_in // len(period))
+    x[-50000:] = pcm16(50000, 44100, 1, 4)  # the tail differs from the periodic body
+    assert len(x) == n_in
+    bt = B.Batch.upload(ctx, [x.tobytes()])
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    out = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith("k_fast_wave")
+    got = out.download()[0][0]
+    assert len(got) == 160 * KK
+    for k in (0, 7_000_000, 13_421_800, KK - 400):
+        seg = x[147 * k:147 * k + 147 * 400 + 8]
+        ref = oracle.resample(oracle.pcm(seg.tobytes(), 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC).data[0]
+        m = min(160 * 400 - 8, len(got) - 160 * k)
+        lo = 0 if k == 0 else 8  # a window cut out of the middle lacks the sample before its first one
+        hi = m if 147 * k + len(seg) >= n_in else m - 8
+        assert rms(got[160 * k + lo:160 * k + hi].astype(np.float64), ref[lo:hi]) <= 1e-6, k
+        assert np.max(np.abs(got[160 * k + lo:160 * k + hi] - ref[lo:hi])) <= 1e-5, k
+    del got, out
+    too_long = B.Batch.upload(ctx, [np.zeros(0x7FFFFFF0 + 2, dtype=np.int16).tobytes()])
+    with pytest.raises(N.AukitError, match="stream too long"):
+        B.decode_resample(ctx, too_long, desc, 48000, "cubic", dtype=N.F32)
