@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
 HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "resample_dev.h", "dfpwm_dev.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -30,7 +30,7 @@ PACK_TRUNC, PACK_FLOOR, PACK_STRICT = 0, 1, 2
 # every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aukit_abi_version", "aukit_last_error", "aukit_ctx_create", "aukit_ctx_destroy", "aukit_ctx_set_stream", "aukit_ctx_get_stream",
-    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_option", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end",
+    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_option", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end", "aukit_timer_stats",
     "aukit_ctx_set_kernel_timing", "aukit_ctx_last_kernel",
     "aukit_batch_upload", "aukit_batch_wrap_device", "aukit_batch_info", "aukit_batch_offsets", "aukit_batch_device_ptr",
     "aukit_batch_download", "aukit_batch_free",
@@ -58,20 +58,42 @@ class AukitError(RuntimeError):
         self.msg = msg
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 all of csrc/ into aukit_amd/libaukit_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
-        return LIB_PATH
+def build(force=False, verbose=False, jobs=None):
+    """hipcc --offload-arch=gfx950 every file of csrc/ into an object under aukit_amd/build/ (only the ones whose source or any
+    header changed; up to `jobs` compilers at once), then link aukit_amd/libaukit_hip.so (cross-compiles without a GPU)."""
+    import concurrent.futures
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-           "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+    bdir = os.path.join(_HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    hdr_m = max(os.path.getmtime(h) for h in hdrs)
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in srcs + hdrs):
+        return LIB_PATH  # up to date (the objects under build/ do not travel to the GPU box; the library does)
+    todo, objs = [], []
+    for s in srcs:
+        o = os.path.join(bdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            todo.append((s, o))
+
+    def cc(so):
+        cmd = [hipcc] + flags + ["-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(cc, todo))
+    if todo or not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 

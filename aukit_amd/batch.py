@@ -76,6 +76,12 @@ class Context:
     def set_kernel_timing(self, on=True):
         N.check(N.lib().aukit_ctx_set_kernel_timing(self._h, int(on)))
 
+    def timer_stats(self):
+        """(kernel launches, algorithmic bytes) since timer_begin"""
+        nl, nb = C.c_uint64(), C.c_uint64()
+        N.check(N.lib().aukit_timer_stats(self._h, C.byref(nl), C.byref(nb)))
+        return nl.value, nb.value
+
     def last_kernel(self):
         name = C.c_char_p()
         ms = C.c_float()

@@ -134,6 +134,10 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int frc = AUKIT_OK;
         if (aligned4 && fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
+    if (do_resample && dtype == AUKIT_F32 && C == 1 && ctx->exact_math == 1 && src == SRC_PCM_S16LE_MONO) {  // fp64 arithmetic, f32 store (wave_f64.hip)
+        int wrc = AUKIT_OK;
+        if (wave_f64_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &wrc)) return wrc;
+    }
     if (do_resample && C == 1 && src == SRC_PCM_S16LE_MONO) {  // reference-order fp64 on wave tiles (exact_wave.hip)
         int erc = AUKIT_OK;
         if (exact_wave_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc)) return erc;

@@ -43,14 +43,19 @@ struct aukit_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // user timer
     hipEvent_t kev0 = nullptr, kev1 = nullptr;  // per-kernel timing
     bool ktiming = false;
-    bool exact_math = false;    // AUKIT_OPT_EXACT_MATH: F32 storage also uses the fp64 reference-order kernels
+    int exact_math = 0;         // AUKIT_OPT_EXACT_MATH: 1 = F32 storage is computed in fp64 (wave_f64.hip; reference-order kernels where that
+                                //   one does not apply), 2 = always the reference-order kernels; 0 = f32 taps
     bool fast_store_x4 = true;  // AUKIT_OPT_STORE_X4: LDS-transposed 16-byte stores in the fast kernels
     std::string last_kernel;
     float last_ms = 0.f;
     uint64_t last_bytes = 0;
+    uint64_t timer_launches = 0, timer_bytes = 0;  // since aukit_timer_begin: kernel launches and their algorithmic bytes
     int num_cus = 256;
     // scratch tables (segment/tile/stream descriptors); plan_key caches the last uploaded plan
     aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2, tmp_buf3;
+    aukit::DevBuf wt_buf;       // phase-weight table of wave_f64.hip, cached per (b, interpolation)
+    unsigned wt_b = 0, wt_doubles = 0;
+    int wt_interp = -1;
     // pinned host staging for downloads / uploads of whole audios (a pageable copy runs at a fraction of the PCIe rate)
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;

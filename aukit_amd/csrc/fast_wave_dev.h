@@ -28,6 +28,20 @@ AUKIT_DEV float g711_f32b(unsigned byte, int ulaw, float scale) {
     return (float)(neg ? -m : m) * scale;
 }
 
+// Read-only descriptor tables (segments, tile maps, stream offsets) are read through the CONSTANT address space: with a
+// wave-uniform index that is an s_load (SMEM, lgkmcnt) wherever it stands.  As plain global loads hipcc must assume that the
+// kernel's own output stores may alias them and emits VMEM loads once a store precedes them — and on gfx9 waiting for a VMEM
+// load (vmcnt) also waits for every store issued before it: the per-tile descriptor fetch drained the wave's whole store queue.
+#define AUKIT_CONST_AS __attribute__((address_space(4)))
+template <typename T> AUKIT_DEV const AUKIT_CONST_AS T *as_const(const T *p) { return (const AUKIT_CONST_AS T *)p; }
+AUKIT_DEV Seg load_seg(const Seg *segs, unsigned sidx) {
+    const AUKIT_CONST_AS unsigned long long *q = (const AUKIT_CONST_AS unsigned long long *)(segs + sidx);
+    union { unsigned long long u[5]; Seg s; } x;
+#pragma unroll
+    for (int i = 0; i < 5; i++) x.u[i] = q[i];
+    return x.s;
+}
+
 struct WaveTile {
     const unsigned char *al;   // 16-byte aligned address of the first vector
     float *orow;               // output of the tile's first sample
@@ -42,8 +56,8 @@ AUKIT_DEV WaveTile describe(const ResampleParams &P, const FastParams &F, unsign
     using T = SrcTraits<SRC>;
     unsigned sidx, tin;
     if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
-    else { sidx = P.tile_seg[t]; tin = t - P.seg_tile0[sidx]; }
-    const Seg sg = P.segs[sidx];
+    else { sidx = as_const(P.tile_seg)[t]; tin = t - as_const(P.seg_tile0)[sidx]; }
+    const Seg sg = load_seg(P.segs, sidx);
     WaveTile w;
     const unsigned o0 = tin * (unsigned)WT;
     w.cnt = o0 < sg.n_out ? min((unsigned)WT, sg.n_out - o0) : 0u;
@@ -56,8 +70,8 @@ AUKIT_DEV WaveTile describe(const ResampleParams &P, const FastParams &F, unsign
     w.n_stage = (int)klast + 1 + HL + HR;
     w.w_lo = sg.w_lo;
     w.w_hi = sg.w_hi;
-    if constexpr (SRC == SRC_AUDIO_F32 || SRC == SRC_I32) w.base = P.src + 4 * (size_t)P.src_off[sg.stream] + 4 * sg.src_base;
-    else w.base = P.src + (size_t)P.src_off[sg.stream] + (long long)T::BYTES * sg.src_base;
+    if constexpr (SRC == SRC_AUDIO_F32 || SRC == SRC_I32) w.base = P.src + 4 * (size_t)as_const(P.src_off)[sg.stream] + 4 * sg.src_base;
+    else w.base = P.src + (size_t)as_const(P.src_off)[sg.stream] + (long long)T::BYTES * sg.src_base;
     const unsigned char *a0 = w.base + (long long)T::BYTES * w.k_lo;
     w.al = (const unsigned char *)((uintptr_t)a0 & ~(uintptr_t)15);
     w.head = (int)(a0 - w.al) / T::BYTES;
@@ -66,6 +80,7 @@ AUKIT_DEV WaveTile describe(const ResampleParams &P, const FastParams &F, unsign
     return w;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NV>
 AUKIT_DEV void issue_loads(const ResampleParams &P, const WaveTile &w, int lane, uint4 (&pre)[NV]) {
 #pragma unroll
@@ -73,8 +88,42 @@ AUKIT_DEV void issue_loads(const ResampleParams &P, const WaveTile &w, int lane,
         const int v = lane + 64 * i;
         const unsigned char *p = w.al + 16 * (size_t)v;
         pre[i] = make_uint4(0, 0, 0, 0);
-        if (v < w.nvec && p >= P.safe_lo && p + 16 <= P.safe_hi) pre[i] = *reinterpret_cast<const uint4 *>(p);
+        if (v < w.nvec && p >= P.safe_lo && p + 16 <= P.safe_hi) {
+            const u32x4 r = *(const __attribute__((address_space(1))) u32x4 *)p;  // one global_load_dwordx4 (a uint4 deref goes through a generic reference: flat_load)
+            pre[i] = make_uint4(r.x, r.y, r.z, r.w);
+        }
     }
+}
+
+// Where the wave waits for the next tile's loads.  hipcc waits for `pre` where it is first used — at the top of the tile loop, right
+// after the sixteen row stores of the tile before.  On gfx9 loads and stores share vmcnt and return out of order with respect to
+// each other, so that wait can only be vmcnt(0): every wave sat out the write latency of the stores it had just issued before it
+// touched loads that had landed long ago (a hand-counted vmcnt(16) there returns garbage — tried).  The kernels therefore keep a
+// tile's sixteen results in registers, "use" the NEXT tile's loads here (an empty asm that takes them as operands: hipcc puts its
+// vmcnt(0) in front of it — the loads were issued before the tile's arithmetic, a whole tile of work ago, and the only stores still
+// counted are the tile-before's, a tile older still) and only then issue the stores, which drain while the next tile is staged and
+// evaluated.  The results pass through the same statements as in/out operands, so the stores (which need them) stay below; no
+// "memory" clobber (with one hipcc loses the address space of the kernel-argument pointers and turns every load into flat_load).
+// hipcc's waitcnt pass merges the states of every edge into the tile loop's header: `pre` must be "used" (waited for) on ALL of them —
+// before the loop for the first tile, and on the partial-tile path — or its vmcnt(0) lands at the top of the loop after all.
+template <int NV>
+AUKIT_DEV void pre_landed(uint4 (&pre)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) asm volatile("" : "+v"(pre[i].x), "+v"(pre[i].y), "+v"(pre[i].z), "+v"(pre[i].w));
+}
+template <int NV>
+AUKIT_DEV void loads_landed(uint4 (&pre)[NV], float (&res)[16]) {
+    static_assert(NV == 1 || NV == 2 || NV == 4, "NV");
+    if constexpr (NV == 1) asm volatile("" : "+v"(pre[0].x), "+v"(pre[0].y), "+v"(pre[0].z), "+v"(pre[0].w), "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]));
+    else if constexpr (NV == 2)
+        asm volatile("" : "+v"(pre[0].x), "+v"(pre[0].y), "+v"(pre[0].z), "+v"(pre[0].w), "+v"(pre[1].x), "+v"(pre[1].y), "+v"(pre[1].z), "+v"(pre[1].w), "+v"(res[0]), "+v"(res[1]), "+v"(res[2]),
+                     "+v"(res[3]));
+    else {
+        asm volatile("" : "+v"(pre[0].x), "+v"(pre[0].y), "+v"(pre[0].z), "+v"(pre[0].w), "+v"(pre[1].x), "+v"(pre[1].y), "+v"(pre[1].z), "+v"(pre[1].w));
+        asm volatile("" : "+v"(pre[2].x), "+v"(pre[2].y), "+v"(pre[2].z), "+v"(pre[2].w), "+v"(pre[3].x), "+v"(pre[3].y), "+v"(pre[3].z), "+v"(pre[3].w), "+v"(res[0]), "+v"(res[1]), "+v"(res[2]),
+                     "+v"(res[3]));
+    }
+    asm volatile("" : "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
 }
 
 template <int SRC>

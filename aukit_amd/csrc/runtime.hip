@@ -62,6 +62,8 @@ int ctx_begin_kernel(aukit_ctx *ctx) {
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes) {
     ctx->last_kernel = name ? name : "";
     ctx->last_bytes = algorithmic_bytes;
+    ctx->timer_launches++;
+    ctx->timer_bytes += algorithmic_bytes;
     if (ctx->ktiming) {
         AUKIT_HIP_CHECK(hipEventRecord(ctx->kev1, ctx->stream));
         AUKIT_HIP_CHECK(hipEventSynchronize(ctx->kev1));
@@ -150,7 +152,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release();
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release();
     if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -162,6 +164,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
 
 int aukit_ctx_set_stream(aukit_ctx *c, void *s) {
     if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    AUKIT_HIP_CHECK(hipSetDevice(c->device));
     AUKIT_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)s;
@@ -186,16 +189,28 @@ int aukit_ctx_set_sinc_window(aukit_ctx *c, int w) {
 }
 int aukit_ctx_set_option(aukit_ctx *c, int option, int value) {
     if (!c) return fail(AUKIT_E_ARG, "ctx is null");
-    if (option == AUKIT_OPT_EXACT_MATH) c->exact_math = value != 0;
+    if (option == AUKIT_OPT_EXACT_MATH) c->exact_math = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (option == AUKIT_OPT_STORE_X4) c->fast_store_x4 = value != 0;
     else return fail(AUKIT_E_ARG, "unknown option %d", option);
     return AUKIT_OK;
 }
 int aukit_timer_begin(aukit_ctx *c) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    AUKIT_HIP_CHECK(hipSetDevice(c->device));
+    c->timer_launches = 0;
+    c->timer_bytes = 0;
     AUKIT_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     return AUKIT_OK;
 }
+int aukit_timer_stats(aukit_ctx *c, uint64_t *launches, uint64_t *algorithmic_bytes) {
+    if (!c) return fail(AUKIT_E_ARG, "ctx is null");
+    if (launches) *launches = c->timer_launches;
+    if (algorithmic_bytes) *algorithmic_bytes = c->timer_bytes;
+    return AUKIT_OK;
+}
 int aukit_timer_end(aukit_ctx *c, float *ms) {
+    if (!c || !ms) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_HIP_CHECK(hipSetDevice(c->device));
     AUKIT_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     AUKIT_HIP_CHECK(hipEventSynchronize(c->ev1));
     AUKIT_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -257,6 +272,7 @@ int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, 
 
 int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_bytes, const uint64_t *offsets, uint32_t n) {
     if (!ctx || !out || !offsets) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));  // the offsets table below must land on the context's device
     aukit_batch *b = new aukit_batch();
     b->base = (uint8_t *)const_cast<void *>(dev_bytes);
     b->front_pad = 0;

@@ -1,0 +1,383 @@
+// wave_f64.hip — `aukit.pcm(d, 16, "signed", 1, rate):resample(new_rate, interp)` computed in fp64 and stored as f32: the graded
+// configuration of SURVEY §8d ("config T: f32 store of fp64 math"), AUKIT_OPT_EXACT_MATH = 1 with AUKIT_F32 storage.
+//
+// Arithmetic.  The reference evaluates, per output i (aukit.lua:662-669, :261-266), x = (i-1)/ratio + 1 and the Catmull-Rom cubic
+//   (-0.5 p0 + 1.5 p1 - 1.5 p2 + 0.5 p3) fx^3 + (p0 - 2.5 p1 + 2 p2 - 0.5 p3) fx^2 + (-0.5 p0 + 0.5 p2) fx + p1
+// in doubles.  k_exact_wave (exact_wave.hip) reproduces that expression operation by operation (≈41 fp64 instructions per output:
+// verified reciprocal division, a correctly rounded pow(fx, 3), every product and sum in the reference's order) and is what AUKIT_F64
+// storage uses.  A result that is rounded to f32 on its way out cannot show the last bits of those doubles, so this kernel keeps the
+// *arithmetic type* (every tap, weight, product and sum is an fp64 value) and drops the operation order:
+//   * the position is the exact rational (i-1)·a/b (a/b = old_rate/new_rate in lowest terms) carried as (q, rem) by integer
+//     additions, so fx = rem/b takes one of b values;
+//   * the polynomial is regrouped by tap, out = w0(fx) p0 + w1(fx) p1 + w2(fx) p2 + w3(fx) p3, with the four weights of every one of
+//     the b phases computed on the host in extended precision, rounded to fp64 once and kept in LDS (b ≤ 512: 44.1 → 48 kHz has
+//     b = 160, 5 KiB) — one multiply and three FMAs per output instead of fifteen fp64 operations; for larger b the kernel
+//     evaluates the same polynomial as an fp64 Horner form on fx = rem · RN(1/b);
+//   * samples are staged once per tile as doubles, s · 2^-15 (s < 0) or s · RN(1/32767) (≤ 1 ulp from the reference's s / 32767);
+//   * `x % 1 == 0` (:666) is rem == 0, whose weights are (0, 1, 0, 0): the copy falls out of the same expression, and samples
+//     of a 16-bit source lie in [-1, 1], so clamping them changes nothing; the clamp runs after the rounding to f32 (monotone
+//     rounding and representable bounds: the same value as clamping before it).
+// The polynomial regrouping moves a result by ulps of fp64 (1e-16).  The exact position moves it more: the reference's x is a
+// rounded double (relative error 1e-16 of x, up to 5e-11 in fx ten seconds into a 44.1 kHz stream), so its interpolated double
+// and the one computed here differ by up to ~1e-11 — the kernel is the closer of the two to the real-number value.  In the f32
+// store that shows as neighbouring floats in 1e-4 … 1e-3 of the outputs, never more than one f32 ulp (tests/test_gpu_wave_f64.py
+// asserts both); the bar of SURVEY §8d is 1e-6 RMS.
+//
+// Memory pipeline.  A wave owns tiles of TILE outputs and a private LDS window; per tile it
+//   1. converts the tile's raw 16-bit samples (already in LDS) to doubles in its window;
+//   2. starts the NEXT tile's raw samples on their way, global → LDS directly (`global_load_lds_dwordx4`: no VGPR holds them, so
+//      hipcc has no load result to wait for anywhere);
+//   3. evaluates the tile's TILE/64 rows into registers — LDS reads hand-issued one row ahead with counted lgkmcnt waits;
+//   4. waits vmcnt(0) — the DMA of step 2 has had the whole of step 3 to land, and the only stores still counted are the tile
+//      before's, a tile older still;
+//   5. issues the tile's row stores, which drain while steps 1-3 of the next tile run.
+// The order 3-4-5 is the point.  On gfx9 loads and stores share vmcnt and return out of order with respect to each other, so a wave
+// that must see its next tile's samples can only wait for vmcnt(0).  With the stores issued row by row (the first version of this
+// kernel, and k_fast_wave in round 1) that wait sits right behind sixteen fresh stores and every wave sits out their write latency
+// once per tile; a hand-counted vmcnt(16) there returns garbage (tried: the loads are overtaken).  Same-box A/B in DESIGN.md §3.
+#include <algorithm>
+#include "fast_wave_dev.h"
+
+namespace aukit {
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+#define AUKIT_GLOBAL_AS __attribute__((address_space(1)))
+#define AUKIT_LDS_AS __attribute__((address_space(3)))
+AUKIT_DEV unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const AUKIT_LDS_AS char *)p; }
+
+// ---- one row's operands, read from LDS by hand.  hipcc merges adjacent 8-byte reads into ds_read2_b64 (8 LDS cycles where two
+// ds_read_b64 cost 2 each, MI355X_MICROARCH.md §LDS), waits lgkmcnt(0) for every row before it issues the next row's reads, and —
+// knowing that an LDS-DMA is in flight — would put a vmcnt(0) in front of its own ds_reads.  Here a row's reads are issued as
+// written and waited for only after the NEXT row's are in the queue (LDS returns in order: lgkmcnt(N) = this row has landed, N = reads
+// per row).  The values pass through the s_waitcnt statement as in/out operands so that no use can be scheduled above it.
+template <int INTERP, bool TAB> struct Row;
+template <> struct Row<AUKIT_INTERP_CUBIC, true> {  // 4 taps, 4 weights of the phase
+    static constexpr int N = 6;
+    double p0, p1, p2, p3; dbl2 w01, w23;
+    AUKIT_DEV void issue(unsigned tap, unsigned wa, unsigned wb) {
+        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\tds_read_b64 %3, %6 offset:24\n\t"
+                     "ds_read_b128 %4, %7\n\tds_read_b128 %5, %8"
+                     : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(w01), "=&v"(w23) : "v"(tap), "v"(wa), "v"(wb));
+    }
+    template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(w01), "+v"(w23) : "n"(K)); }
+    AUKIT_DEV float eval(unsigned, double) const { return (float)__builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0))); }
+};
+template <> struct Row<AUKIT_INTERP_LINEAR, true> {  // 2 taps, fx of the phase
+    static constexpr int N = 3;
+    double p1, p2, fx;
+    AUKIT_DEV void issue(unsigned tap, unsigned wa, unsigned) {
+        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %4" : "=&v"(p1), "=&v"(p2), "=&v"(fx) : "v"(tap), "v"(wa));
+    }
+    template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(p1), "+v"(p2), "+v"(fx) : "n"(K)); }
+    AUKIT_DEV float eval(unsigned, double) const { return (float)__builtin_fma(p2 - p1, fx, p1); }
+};
+template <> struct Row<AUKIT_INTERP_CUBIC, false> {  // 4 taps, Horner on fx = rem * RN(1/b)
+    static constexpr int N = 4;
+    double p0, p1, p2, p3;
+    AUKIT_DEV void issue(unsigned tap, unsigned, unsigned) {
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                     : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(tap));
+    }
+    template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "n"(K)); }
+    AUKIT_DEV float eval(unsigned rem, double inv_b) const {
+        const double fx = (double)rem * inv_b;
+        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+        const double c2 = __builtin_fma(-0.5, p3, __builtin_fma(2.0, p2, __builtin_fma(-2.5, p1, p0)));
+        const double c1 = 0.5 * (p2 - p0);
+        return (float)__builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+    }
+};
+template <> struct Row<AUKIT_INTERP_LINEAR, false> {
+    static constexpr int N = 2;
+    double p1, p2;
+    AUKIT_DEV void issue(unsigned tap, unsigned, unsigned) { asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(p1), "=&v"(p2) : "v"(tap)); }
+    template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(p1), "+v"(p2) : "n"(K)); }
+    AUKIT_DEV float eval(unsigned rem, double inv_b) const { return (float)__builtin_fma(p2 - p1, (double)rem * inv_b, p1); }
+};
+
+// the compiler-scheduled evaluation of one output (partial tiles: the last tile of a stream)
+template <int INTERP, bool TAB>
+AUKIT_DEV float eval_plain(const double *tab, const double *wt, unsigned b, double inv_b, unsigned q, unsigned rem) {
+    const double p1 = tab[q], p2 = tab[q + 1];
+    if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+        const double fx = TAB ? wt[rem] : (double)rem * inv_b;
+        return (float)__builtin_fma(p2 - p1, fx, p1);
+    } else {
+        const double p0 = tab[(int)q - 1], p3 = tab[q + 2];
+        if constexpr (TAB) {
+            const double2 w01 = reinterpret_cast<const double2 *>(wt)[rem], w23 = reinterpret_cast<const double2 *>(wt)[b + rem];
+            return (float)__builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0)));
+        } else {
+            const double fx = (double)rem * inv_b;
+            const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+            const double c2 = __builtin_fma(-0.5, p3, __builtin_fma(2.0, p2, __builtin_fma(-2.5, p1, p0)));
+            const double c1 = 0.5 * (p2 - p0);
+            return (float)__builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+        }
+    }
+}
+
+// describe() of fast_wave_dev.h for a tile size that is a template parameter (F.wc / F.wd are computed for the same TILE on the host)
+template <int TILE, int HL, int HR>
+AUKIT_DEV WaveTile describe_t(const ResampleParams &P, const FastParams &F, unsigned t) {
+    unsigned sidx, tin;
+    if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
+    else { sidx = as_const(P.tile_seg)[t]; tin = t - as_const(P.seg_tile0)[sidx]; }
+    const Seg sg = load_seg(P.segs, sidx);
+    WaveTile w;
+    const unsigned o0 = tin * (unsigned)TILE;
+    w.cnt = o0 < sg.n_out ? min((unsigned)TILE, sg.n_out - o0) : 0u;
+    const unsigned td = tin * F.wd;  // (o0 * a) = (tin * wc + td / b) * b + td % b
+    const unsigned tq = td / F.b;
+    const unsigned kb = tin * F.wc + tq;
+    w.r0 = td - tq * F.b;
+    const unsigned klast = w.cnt ? (w.r0 + (w.cnt - 1) * F.a) / F.b : 0u;
+    w.k_lo = 1 + (int)kb - HL;
+    w.n_stage = (int)klast + 1 + HL + HR;
+    w.w_lo = sg.w_lo;
+    w.w_hi = sg.w_hi;
+    w.base = P.src + (size_t)as_const(P.src_off)[sg.stream] + 2ll * sg.src_base;
+    const unsigned char *a0 = w.base + 2ll * w.k_lo;
+    w.al = (const unsigned char *)((uintptr_t)a0 & ~(uintptr_t)15);
+    w.head = (int)(a0 - w.al) / 2;
+    w.nvec = (w.head + w.n_stage + 7) / 8;
+    w.orow = reinterpret_cast<float *>(P.out) + sg.out_off + o0;
+    return w;
+}
+
+constexpr int VMCNT0 = 0x0F70;  // s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15) on gfx9: every VMEM operation of the wave has completed
+
+template <int INTERP, int TILE, int NV, bool TAB>
+__global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const FastParams F, const double *__restrict__ wg, const unsigned wt_doubles,
+                                                  const double inv_b) {
+    extern __shared__ double smd[];  // [phase weights][4 × window of F.cap doubles][4 × raw tile of NV KiB]: ONE array (a second one makes hipcc drain every DMA early)
+    constexpr int HL = INTERP == AUKIT_INTERP_CUBIC ? 1 : 0, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    constexpr int ROWS = TILE / 64;
+    using R = Row<INTERP, TAB>;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (TAB) {  // the weights of the b phases: LDS, once per workgroup
+        for (unsigned i = threadIdx.x; i < wt_doubles / 2; i += 256) reinterpret_cast<double2 *>(smd)[i] = reinterpret_cast<const double2 *>(wg)[i];
+        __syncthreads();
+    }
+    const double *const wt = smd;
+    double *const sm = smd + (TAB ? wt_doubles : 0u) + wave * (unsigned)F.cap;
+    unsigned char *const raw = reinterpret_cast<unsigned char *>(smd + (TAB ? wt_doubles : 0u) + 4u * (unsigned)F.cap) + wave * (unsigned)(NV * 1024);
+    const unsigned nwaves = gridDim.x * 4u;
+    const unsigned lane_a = (unsigned)lane * F.a;
+
+    unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    if (t >= P.n_tiles) return;
+    // raw samples of a tile, global → LDS: lane l of instruction i brings the 16-byte vector l + 64 i (clamped into the allocation: slots
+    // of vectors the tile does not have, or that straddle the allocation, are never converted / are patched below)
+    auto dma = [&](const WaveTile &w) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = lane + 64 * i;
+            const unsigned char *p = w.al + 16 * (size_t)v;
+            const bool ok = v < w.nvec && p >= P.safe_lo && p + 16 <= P.safe_hi;
+            __builtin_amdgcn_global_load_lds((const AUKIT_GLOBAL_AS void *)(ok ? p : P.safe_lo), (AUKIT_LDS_AS void *)(raw + 1024 * i), 16, 0, 0);
+        }
+    };
+    WaveTile cur = describe_t<TILE, HL, HR>(P, F, t);
+    dma(cur);
+    __builtin_amdgcn_s_waitcnt(VMCNT0);
+    const double sc_pos = 1.0 / 32767.0, sc_neg = 1.0 / 32768.0;
+    for (;;) {
+        // ---- 1. raw → window as doubles
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = lane + 64 * i;
+            if (v >= cur.nvec) continue;
+            const uint4 u = *reinterpret_cast<const uint4 *>(raw + 16 * v);
+            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
+            double d[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int s = (e & 1) ? ((int)ww[e >> 1] >> 16) : (int)(short)(ww[e >> 1] & 0xFFFF);
+                d[e] = (double)s * (s < 0 ? sc_neg : sc_pos);  // s / (s < 0 and 32768 or 32767)  :1081
+            }
+            double2 *o = reinterpret_cast<double2 *>(sm + 8 * v);
+            o[0] = make_double2(d[0], d[1]); o[1] = make_double2(d[2], d[3]); o[2] = make_double2(d[4], d[5]); o[3] = make_double2(d[6], d[7]);
+        }
+        {
+            const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
+            auto sample = [&](const unsigned char *q) { const short s = (short)(q[0] | q[1] << 8); return (double)s * (s < 0 ? sc_neg : sc_pos); };
+            if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare: vectors that straddle the allocation
+                for (int idx = lane; idx < cur.nvec * 8; idx += 64) {
+                    const unsigned char *q = cur.al + (size_t)idx * 2;
+                    const unsigned char *vb = cur.al + 16 * (size_t)(idx / 8);
+                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q + 2 <= P.safe_hi) ? sample(q) : 0.0;
+                }
+            }
+            // nil fall-backs of interpolate.{linear,cubic} (aukit.lua:259, :264) = replicated edge samples
+            const int k_hi = cur.k_lo + cur.n_stage - 1;
+            if (cur.k_lo < cur.w_lo) {
+                const double e_lo = sample(cur.base + 2ll * cur.w_lo);
+                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) sm[cur.head + idx] = e_lo;
+            }
+            if (k_hi > cur.w_hi) {
+                const double e_hi = sample(cur.base + 2ll * cur.w_hi);
+                const int first = cur.w_hi + 1 - cur.k_lo;
+                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) sm[cur.head + first + idx] = e_hi;
+            }
+        }
+        // ---- 2. the next tile's raw samples (the conversion above has consumed this tile's: its ds_reads were waited for)
+        const unsigned tn = t + nwaves;
+        const bool more = tn < P.n_tiles;
+        WaveTile nxt = cur;
+        if (more) {  // wave-uniform
+            nxt = describe_t<TILE, HL, HR>(P, F, tn);
+            dma(nxt);
+        }
+        const double *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
+        float *orow = cur.orow;
+        const bool full = cur.cnt == (unsigned)TILE;  // wave-uniform
+        float res[ROWS];
+        if (full) {
+            // ---- 3. the rows, into registers
+            const unsigned n0 = cur.r0 + lane_a;
+            unsigned q = __umulhi(n0, F.magic);
+            unsigned rem = n0 - q * F.b;
+            asm volatile("" ::: "memory");  // the staging stores above stay above
+            const unsigned tap0 = lds_addr(tab) - (INTERP == AUKIT_INTERP_CUBIC ? 8u : 0u), wa0 = lds_addr(wt), wb0 = lds_addr(wt) + 16u * F.b;
+            constexpr unsigned WSH = INTERP == AUKIT_INTERP_CUBIC ? 4 : 3;  // bytes per phase in the first weight array: 16 (w0, w1) / 8 (fx)
+            R nx;
+            nx.issue(tap0 + 8u * q, wa0 + (rem << WSH), wb0 + (rem << WSH));
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                R c = nx;
+                const unsigned rem_c = rem;
+                if (r + 1 < ROWS) {
+                    rem += F.dr64;  // the same lane, one row (64 outputs) further
+                    q += F.dq64;
+                    const bool wrap = rem >= F.b;
+                    rem -= wrap ? F.b : 0u;
+                    q += wrap ? 1u : 0u;
+                    nx.issue(tap0 + 8u * q, wa0 + (rem << WSH), wb0 + (rem << WSH));
+                    c.template wait<R::N>();
+                } else {
+                    c.template wait<0>();
+                }
+                res[r] = __builtin_amdgcn_fmed3f(c.eval(rem_c, inv_b), -1.0f, 1.0f);  // :667-668
+            }
+            asm volatile("" ::: "memory");  // the next tile's staging stores stay below
+        }
+        // ---- 4. the next tile's samples have landed (and the stores of the tile before this one have long completed).  On the straight
+        // path of the loop body on purpose: inside the two branches, the structurizer's flow blocks leave hipcc a static path around
+        // the wait, and its waitcnt pass then drains the DMA (and every store) at the top of the loop after all.
+        __builtin_amdgcn_s_waitcnt(VMCNT0);
+        unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
+        asm volatile("" : "+s"(full2));  // opaque: or jump threading fuses the two `if (full)` and the wait is back inside the branches
+        if (full2) {
+            // ---- 5. this tile's stores: in flight while the next tile is converted and evaluated
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) orow[r * 64 + lane] = res[r];
+        } else {
+            for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+                const unsigned j = rb + lane;
+                const unsigned n = cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a;
+                const unsigned q = __umulhi(n, F.magic);
+                const unsigned rem = n - q * F.b;
+                const float v = eval_plain<INTERP, TAB>(tab, wt, F.b, inv_b, q, rem);
+                if (j < cur.cnt) orow[j] = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);
+            }
+        }
+        if (!more) break;
+        cur = nxt;
+        t = tn;
+    }
+}
+
+bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
+
+template <int INTERP, int TILE, bool TAB>
+static void launch_wf64(int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, size_t lds, unsigned grid, hipStream_t st) {
+    switch (nv) {
+    case 1: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 1, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
+    case 2: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 2, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
+    default: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 4, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
+    }
+}
+template <int TILE>
+static void launch_wf64_tile(int interp, bool tab, int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, size_t lds, unsigned grid,
+                             hipStream_t st) {
+    if (tab) { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, true>(nv, P, F, wg, wtd, inv_b, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, true>(nv, P, F, wg, wtd, inv_b, lds, grid, st); }
+    else { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, false>(nv, P, F, wg, wtd, inv_b, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, false>(nv, P, F, wg, wtd, inv_b, lds, grid, st); }
+}
+
+// weights of the b phases, fx = rem / b, from the reference's polynomial (aukit.lua:265) regrouped by tap; computed in long double
+// (64-bit mantissa on this host) and rounded once.  Layout: cubic [b] × (w0, w1) then [b] × (w2, w3); linear [b] × fx (padded to even).
+static void phase_weights(unsigned b, int interp, std::vector<double> &w) {
+    if (interp == AUKIT_INTERP_LINEAR) {
+        w.assign((b + 1) & ~1u, 0.0);
+        for (unsigned r = 0; r < b; r++) w[r] = (double)((long double)r / (long double)b);
+        return;
+    }
+    w.assign((size_t)4 * b, 0.0);
+    for (unsigned r = 0; r < b; r++) {
+        const long double f = (long double)r / (long double)b, f2 = f * f, f3 = f2 * f;
+        w[2 * r] = (double)(-0.5L * f3 + f2 - 0.5L * f);
+        w[2 * r + 1] = (double)(1.5L * f3 - 2.5L * f2 + 1.0L);
+        w[2 * b + 2 * r] = (double)(-1.5L * f3 + 2.0L * f2 + 0.5L * f);
+        w[2 * b + 2 * r + 1] = (double)(0.5L * f3 - 0.5L * f2);
+    }
+}
+
+// returns true when this kernel took the launch (*rc = its status): 16-bit signed little-endian mono → linear / cubic → f32, integer rates
+bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
+                  uint64_t algorithmic_bytes, int *rc) {
+    if (src_kind != SRC_PCM_S16LE_MONO) return false;
+    FastParams F;
+    if (!fast_eligible(SRC_PCM_S16LE_MONO, interp, old_rate, new_rate, F)) return false;
+    for (const Seg &g : segs)
+        if (g.w_hi < g.w_lo && g.n_out) return false;
+    int tile = 512;  // outputs per wave tile: 512 keeps six workgroups (24 waves) per CU next to their windows; 1024 keeps three
+    if (const char *e = getenv("AUKIT_F64_TILE")) tile = atoi(e) == 1024 ? 1024 : 512;
+    const int spv = 8;
+    const int hl = interp == AUKIT_INTERP_CUBIC ? 1 : 0, hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int win = (int)(((unsigned long long)(tile - 1) * F.a) / F.b) + 2 + hl + hr;
+    int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
+    nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
+    if (!nv) return false;
+    uint64_t max_tiles = 0;
+    for (const Seg &g : segs) max_tiles = std::max<uint64_t>(max_tiles, (g.n_out + tile - 1) / tile);
+    F.wc = (unsigned)(((unsigned long long)tile * F.a) / F.b);
+    F.wd = (unsigned)(((unsigned long long)tile * F.a) % F.b);
+    if ((double)max_tiles * (double)F.wd >= 4294967296.0 || ((double)max_tiles + 1) * (double)F.wc >= 2147483648.0) return false;
+    if (((double)F.b + (double)tile * (double)F.a) * (double)F.b >= 4294967296.0) return false;
+    F.cap = nv * 64 * spv;  // doubles per wave window
+    F.dq64 = (unsigned)((64ull * F.a) / F.b);
+    F.dr64 = (unsigned)((64ull * F.a) % F.b);
+    bool tab = F.b <= 512;
+    if (const char *e = getenv("AUKIT_F64_HORNER")) tab = tab && atoi(e) == 0;  // A/B: the Horner form for every ratio
+    unsigned wtd = 0;
+    if (tab) {
+        if (ctx->wt_b != F.b || ctx->wt_interp != interp) {
+            std::vector<double> w;
+            phase_weights(F.b, interp, w);
+            if ((*rc = upload_table(ctx, ctx->wt_buf, w.data(), w.size() * sizeof(double)))) return true;
+            ctx->wt_b = F.b; ctx->wt_interp = interp; ctx->wt_doubles = (unsigned)w.size();
+        }
+        wtd = ctx->wt_doubles;
+    }
+    const size_t lds = ((size_t)F.cap * 4 + wtd) * 8 + (size_t)4 * nv * 1024;
+    if (lds > 64 * 1024) return false;
+    if ((*rc = plan_tiles_sized(ctx, segs, tile, P))) return true;
+    if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
+    unsigned per_cu = 16;
+    if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
+    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
+    if ((*rc = ctx_begin_kernel(ctx))) return true;
+    const double *wg = reinterpret_cast<const double *>(ctx->wt_buf.p);
+    const double inv_b = 1.0 / (double)F.b;
+    if (tile == 1024) launch_wf64_tile<1024>(interp, tab, nv, P, F, wg, wtd, inv_b, lds, grid, ctx->stream);
+    else launch_wf64_tile<512>(interp, tab, nv, P, F, wg, wtd, inv_b, lds, grid, ctx->stream);
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_wave_f64 launch failed"); return true; }
+    static thread_local char nm[96];
+    snprintf(nm, sizeof nm, "k_wave_f64<pcm_s16le_mono,%s,tile%d,nv%d,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", tile, nv, tab ? "phase_table" : "horner");
+    *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
+    return true;
+}
+
+}  // namespace aukit

@@ -90,25 +90,28 @@ class Pcm16Cubic(Workload):
         import numpy as np
         from oracle import oracle as O
         O.build()
-        rng = np.random.Generator(np.random.PCG64(0xA0C17 + 1000))
+        # DISTINCT streams of the workload's shape (64 of them = 56 MB of input + a fresh 3.8 MB fp64 row per call: not cache-resident), cycled
         t = np.arange(self.n_samples) / SRC_RATE
-        data = np.round((0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, self.n_samples)) * 32767).astype(np.int16).tobytes()
+        sine = 0.5 * np.sin(2 * np.pi * 440 * t)
+        distinct = []
+        for i in range(min(64, max(args.cpu_streams, 1))):
+            rng = np.random.Generator(np.random.PCG64(0xA0C17 + 1000 + i))
+            distinct.append(np.round((sine + rng.uniform(-0.25, 0.25, self.n_samples)) * 32767).astype(np.int16).tobytes())
+        one = lambda i: len(O.resample(O.pcm(distinct[i % len(distinct)], 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
         done, t0 = 0, time.perf_counter()
-        for _ in range(args.cpu_streams):
-            done += len(O.resample(O.pcm(data, 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
+        for i in range(args.cpu_streams):
+            done += one(i)
         dt = time.perf_counter() - t0
         # (ii) every host core, one stream per task; ctypes releases the GIL around the C calls
         import concurrent.futures
-        import os
         cores = os.cpu_count() or 1
-        one = lambda _: len(O.resample(O.pcm(data, 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
         t1 = time.perf_counter()
         with concurrent.futures.ThreadPoolExecutor(cores) as ex:
             n_all = max(args.cpu_streams, min(args.streams, 16 * cores))
             done_all = sum(ex.map(one, range(n_all)))
         dt_all = time.perf_counter() - t1
         return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                "sample": f"{args.cpu_streams} of the {args.streams} streams ({self.n_samples} samples each), scalar fp64 C oracle, {dt:.1f} s",
+                "sample": f"{args.cpu_streams} streams of the workload's shape ({self.n_samples} samples each, {len(distinct)} distinct ones cycled), scalar fp64 C oracle (reference arithmetic), {dt:.1f} s",
                 "all_cores": {"value": done_all / dt_all / 1e6, "unit": "Msamples/s", "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
 
 
@@ -292,10 +295,53 @@ class FlacPipeline(Workload):
         return int(self.m.layout()[0].sum())
 
 
-WORKLOADS = {w.name: w for w in (Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
+class SelftestNull(Workload):
+    """No GPU, no kernel: a fixed sleep per step.  Exists so that the N-rank control flow of this file (self-launch of --gpus N, rendezvous,
+    barriers, max-over-ranks time, summed units) runs on CPU under gloo (tests/test_bench_launch.py).  Never a measurement."""
+    name, unit, arith = "selftest_null", "units/s", "none"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.step = lambda: time.sleep(0.002 * (1 + rank))
+        self.desc = "selftest: sleep(2 ms x (rank + 1)) per step, 1000 units per step and rank"
+        return self
+
+    def out_samples(self):
+        return 1000
 
 
-def main():
+WORKLOADS = {w.name: w for w in (SelftestNull, Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start N ranks of this same file through
+    torch.distributed.run (one process per GPU) and hand their exit code back.  Runs BEFORE this process has made any GPU call
+    (children are fresh processes: nothing that has initialised the GPU is ever re-exec'ed)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def reduce_over_ranks(dist, torch, rdev, dt, units):
+    """(max over ranks of the timed region, sum over ranks of the units processed in it): the whole-job rate is units ÷ time."""
+    tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ts = torch.tensor([float(units)], device=rdev, dtype=torch.float64)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return float(tt.item()), float(ts.item())
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -304,29 +350,50 @@ def main():
     ap.add_argument("--workload", default="pcm16_cubic", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default 4096; 16384 for dfpwm_transcode)")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="STORAGE type of the output rows")
     ap.add_argument("--cpu-streams", type=int, default=1024, help="streams timed on the CPU oracle (0 disables)")
     ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the v1 fast kernel")
-    ap.add_argument("--exact-math", type=int, default=0, help="1: fp64 reference-order kernel even for f32 storage")
+    ap.add_argument("--exact-math", type=int, default=None,
+                    help="arithmetic behind f32 storage: 1 = fp64 (the reference computes in doubles; default for pcm16_cubic, the driver's line), "
+                         "2 = fp64 in the reference's operation order, 0 = f32 taps (default for the other workloads)")
+    ap.add_argument("--extra-windows", type=int, default=4, help="further K-step windows timed after the contractual one (spread of the measurement)")
+    ap.add_argument("--fast-line", type=int, default=1, help="pcm16_cubic: also time the f32-tap kernel and report it as roofline_fast")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.streams is None:
         args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048}.get(args.workload, 4096)
+    if args.exact_math is None:
+        args.exact_math = 1 if args.workload == "pcm16_cubic" else 0
+    selftest = args.workload == "selftest_null"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     import torch
     import torch.distributed as dist
-    from aukit_amd import _native as N
-    from aukit_amd import batch as B
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: aukit_amd has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let `python bench.py --gpus N` start them)")
+    if selftest:
+        N = B = ctx = None
+        dev = torch.device("cpu")
+        args.backend = "gloo" if args.backend == "nccl" else args.backend
+        sync = lambda: None
+    else:
+        from aukit_amd import _native as N
+        from aukit_amd import batch as B
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: aukit_amd has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {local_rank} has no GPU ({torch.cuda.device_count()} visible): --gpus must not exceed the GPUs of the node")
+        dev_index = local_rank
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -335,53 +402,83 @@ def main():
             dist.init_process_group(args.backend)
     rdev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    ctx = B.Context(dev_index)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launch on torch's current stream
-    ctx.set_option(N.OPT_STORE_X4, args.store_x4)
-    ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
+    if not selftest:
+        ctx = B.Context(dev_index)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launch on torch's current stream
+        ctx.set_option(N.OPT_STORE_X4, args.store_x4)
+        ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
     wl = WORKLOADS[args.workload]().setup(torch, dev, ctx, args, rank, N, B)
-    torch.cuda.synchronize()
+    sync()
+
+    def timed_window():
+        """K steps bracketed by barrier + synchronize on both sides; returns (wall seconds, HIP-event ms, launches, algorithmic bytes)"""
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        if ctx:
+            ctx.timer_begin()  # HIP events on the stream the kernels are launched on
+        for _ in range(args.steps):
+            wl.step()
+        ev_ms = ctx.timer_end() if ctx else 0.0
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
+        nl, nb = ctx.timer_stats() if ctx else (0, 0)
+        return dt, ev_ms, nl, nb
 
     # untimed pre-warm (half a second of steps) so that the timed region never starts on a GPU that is still leaving its idle
-    # power state — measured: no difference on the boxes of this pool (846-855 G samples/s either way), kept as insurance; then the
-    # W warm-up steps
+    # power state; then the W warm-up steps
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
+    while not selftest and time.perf_counter() - t_pre < args.prewarm:
         wl.step()
-        torch.cuda.synchronize()
+        sync()
     for _ in range(args.warmup):
         wl.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.timer_begin()  # HIP events on the stream the kernels are launched on
-    for _ in range(args.steps):
-        wl.step()
-    ev_ms = ctx.timer_end()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
+    dt, ev_ms, n_launch, alg_total = timed_window()  # THE measurement: exactly K steps
     out_samples = wl.out_samples()
-    name, _, alg_bytes = ctx.last_kernel()
+    name = ctx.last_kernel()[0] if ctx else "none"
     if world > 1:
-        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ts = torch.tensor([float(out_samples)], device=rdev, dtype=torch.float64)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        total_samples = float(ts.item())
+        dt, total_samples = reduce_over_ranks(dist, torch, rdev, dt, out_samples)
     else:
         total_samples = float(out_samples)
+    # spread of the measurement: further windows of the same K steps, each reduced like the first (max over ranks)
+    windows = [dt / args.steps * 1e3]
+    kernel_windows = [ev_ms / args.steps]
+    for _ in range(max(args.extra_windows, 0)):
+        d2, e2, _, _ = timed_window()
+        if world > 1:
+            d2, _ = reduce_over_ranks(dist, torch, rdev, d2, out_samples)
+        windows.append(d2 / args.steps * 1e3)
+        kernel_windows.append(e2 / args.steps)
+
+    fast = None
+    if not selftest and args.workload == "pcm16_cubic" and args.exact_math != 0 and args.fast_line and args.dtype == "f32":
+        ctx.set_option(N.OPT_EXACT_MATH, 0)  # the f32-tap kernel on the same batch: a secondary figure, never `value`
+        for _ in range(args.warmup):
+            wl.step()
+        _, fe, _, fb = timed_window()
+        fast = (ctx.last_kernel()[0], fe / args.steps, fb // args.steps)
+        ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
 
     if rank == 0:
+        import statistics
         kernel_ms = ev_ms / args.steps
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        alg_bytes = alg_total // max(args.steps, 1)      # algorithmic bytes of every launch of one step
+        launches = n_launch // max(args.steps, 1)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         headline = args.workload == "pcm16_cubic"
+        if getattr(wl, "arith", None):
+            arith = wl.arith
+        elif name.startswith("k_fast"):
+            arith = "f32"
+        elif "dfpwm" in name:
+            arith = "i32"
+        else:
+            arith = "f64"
         line = {
             "metric": "Msamples/s decoded+resampled to 48kHz, 4096-stream batch" if headline else f"Msamples/s ({args.workload})",
             "value": total_samples * args.steps / dt / 1e6,
@@ -393,16 +490,28 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            # arithmetic type of the path: the f32-store fast kernels use exact integer positions + f32 FMA taps,
-            # the reference-order kernels (f64 store or --exact-math 1) compute in fp64; DFPWM / ADPCM decode is int32
-            "dtype": getattr(wl, "arith", None) or ("f32" if name.startswith("k_fast") else ("i32" if "dfpwm" in name else "f64")),
+            # arithmetic type of the path: "f64" = every tap, weight, product and sum is an fp64 value (the reference computes in Lua
+            # doubles), whatever the storage type of the rows; the f32-tap kernels report "f32"; DFPWM / ADPCM decode is int32
+            "dtype": arith,
             "data": "synthetic",
             "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds,
-                       "parallelism": f"shard{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _measured_traffic(name, args), "kernel": name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_out_sample": alg_bytes / max(out_samples, 1)},
+                       "parallelism": f"shard{world}", "storage": args.dtype, "exact_math": args.exact_math},
+            "windows": {"ms_per_step": [round(w, 4) for w in windows], "median": statistics.median(windows), "min": min(windows), "max": max(windows),
+                        "kernel_ms_median": statistics.median(kernel_windows), "note": "window 0 is the contractual K-step region `value` comes from"},
         }
+        if not selftest:
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                "traffic": _measured_traffic(name, args) if launches == 1 else None, "kernel": name, "kernel_ms": kernel_ms,
+                                "launches_per_step": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                                "bytes_per_out_sample": alg_bytes / max(out_samples, 1),
+                                "frac_median_window": alg_bytes / (statistics.median(kernel_windows) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if launches > 1:
+                line["roofline"]["note"] = "several launches per step: algorithmic bytes are summed over the launches, the time is the whole step"
+        if fast:
+            fa = fast[2] / (fast[1] * 1e-3) / 1e9
+            line["roofline_fast"] = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "kernel": fast[0],
+                                     "kernel_ms": fast[1], "dtype": "f32", "traffic": _measured_traffic(fast[0], args),
+                                     "note": "same batch through the f32-tap kernel (AUKIT_OPT_EXACT_MATH = 0): secondary figure"}
         if world == 1 and args.cpu_streams > 0:
             cb = wl.cpu_baseline(args)
             if cb:

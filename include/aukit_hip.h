@@ -107,14 +107,18 @@ int aukit_ctx_set_dtype(aukit_ctx *ctx, int dtype);
 int aukit_ctx_set_sinc_window(aukit_ctx *ctx, int w);
 /* tuning / fidelity switches */
 typedef enum {
-    AUKIT_OPT_EXACT_MATH = 0, /* 1: AUKIT_F32 results are computed by the fp64 reference-order kernels too (default 0:
-                                 f32 FMA arithmetic with exact rational positions, ≤ 1e-6 RMS from the reference) */
+    AUKIT_OPT_EXACT_MATH = 0, /* arithmetic behind AUKIT_F32 storage.  0 (default): f32 FMA taps on exact rational positions, ≤ 1e-6 RMS
+                                 from the reference.  1: fp64 arithmetic, rounded to f32 once when stored (aukit.lua computes in
+                                 doubles, :261-266, :662-669): the fp64 phase-weight kernel where it applies (16-bit mono PCM),
+                                 else the reference-order kernels.  2: always the reference-order fp64 kernels. */
     AUKIT_OPT_STORE_X4 = 1    /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
 } aukit_option;
 int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 /* hipEvent pair on the ctx stream: begin(); ...launches...; end() → elapsed milliseconds */
 int aukit_timer_begin(aukit_ctx *ctx);
 int aukit_timer_end(aukit_ctx *ctx, float *ms);
+/* kernel launches since aukit_timer_begin and the sum of their algorithmic bytes (input read once + output written once) */
+int aukit_timer_stats(aukit_ctx *ctx, uint64_t *launches, uint64_t *algorithmic_bytes);
 /* name and duration (ms, hipEvents around the launch) of the most recent kernel launched through
  * aukit_decode_resample / aukit_stream_decode when profiling is enabled */
 int aukit_ctx_set_kernel_timing(aukit_ctx *ctx, int enabled);

@@ -425,10 +425,10 @@ def test_exact_math_option_uses_fp64_kernel(ctx, oracle):
     B, N = _B(), _N()
     s = pcm16(20000, 44100, 1, 0).tobytes()
     bt = B.Batch.upload(ctx, [s])
-    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    ctx.set_option(N.OPT_EXACT_MATH, 2)
     try:
         out = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), 48000, "cubic", dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith("k_exact_wave<")  # reference-order fp64, wave tiles (exact_wave.hip)
+        assert ctx.last_kernel()[0].startswith("k_exact_wave<")  # reference-order fp64, wave tiles (exact_wave.hip); level 1: tests/test_gpu_wave_f64.py
         ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
         assert np.array_equal(out.download()[0][0], ref.data[0].astype(np.float32).astype(np.float64)) or rms(out.download()[0][0], ref.data[0]) <= 5e-8
     finally:
