@@ -28,7 +28,7 @@ static void fill_source(ResampleParams &P, const aukit_batch *in, const aukit_co
     P.src_off = reinterpret_cast<const unsigned long long *>(in->d_off);
     P.src_frames = nullptr;
     P.safe_lo = in->base;
-    P.safe_hi = in->base + (in->cap & ~(size_t)15);
+    P.safe_hi = in->base + in->cap;  // the true end: a wrapped batch need not end on a 16-byte boundary, and its last samples are read one by one
     P.channels = d->channels;
     P.bit_depth = d->bit_depth;
     P.data_type = d->data_type;
@@ -423,7 +423,7 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     const int ip = do_resample ? interp : AUKIT_INTERP_NONE;
     if (src_kind == SRC_I32 && dtype == AUKIT_F32 && do_resample && rows_dev == ctx->tmp_buf.p) {  // F32 pipelines: tolerance path
         P.safe_lo = reinterpret_cast<const unsigned char *>(rows_dev);
-        P.safe_hi = P.safe_lo + (ctx->tmp_buf.cap & ~(size_t)15);
+        P.safe_hi = P.safe_lo + ctx->tmp_buf.cap;
         int frc = AUKIT_OK;
         if (fast_try(ctx, SRC_I32, ip, rate, new_rate, segs, P, in_elems * 4 + out_elems * 4, &frc)) return frc;
     }
@@ -501,7 +501,7 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     P.channels = 1;
     P.out = a->dev;
     P.safe_lo = reinterpret_cast<const unsigned char *>(in->dev);
-    P.safe_hi = P.safe_lo + (in->cap_bytes & ~(size_t)15);
+    P.safe_hi = P.safe_lo + in->cap_bytes;
     if (in->dtype == AUKIT_F32) {
         int frc = AUKIT_OK;
         if (fast_try(ctx, SRC_AUDIO_F32, interp, in->rate, new_rate, segs, P, (in_elems + out_elems) * 4, &frc)) return frc;

@@ -51,7 +51,7 @@ struct ResampleParams {
     const unsigned char *src;
     const unsigned long long *src_off;     // per stream: byte offset (batch) / element offset (audio rows)
     const unsigned long long *src_frames;  // per stream: frames per channel (planar PCM)
-    const unsigned char *safe_lo, *safe_hi; // 16-byte vector loads allowed in [safe_lo, safe_hi)
+    const unsigned char *safe_lo, *safe_hi; // the allocation: a 16-byte vector load at p needs safe_lo <= p and p + 16 <= safe_hi
     int channels;      // channels in the source data
     int stage_channels;// channels staged per tile (1 when the source is pre-mixed or planar rows)
     int bit_depth, data_type, big_endian, planar, ulaw;

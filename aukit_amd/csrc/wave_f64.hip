@@ -184,21 +184,18 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
     __builtin_amdgcn_s_waitcnt(VMCNT0);
     const double sc_pos = 1.0 / 32767.0, sc_neg = 1.0 / 32768.0;
     for (;;) {
-        // ---- 1. raw → window as doubles
+        // ---- 1. raw → window as doubles.  Instruction j: lane l converts the dword 64 j + l (two samples) and writes window slots
+        // 128 j + 2 l, + 1 — consecutive lanes read consecutive dwords and write consecutive 16-byte pairs: conflict-free both ways.
+        // (The first version had every lane convert its own 16-byte vector into 64 contiguous bytes: ds_write_b128 at a 64-byte lane
+        // stride is a 4-way bank conflict, and the PMC pass showed a third of the kernel's LDS cycles to be conflicts — profiles/.)
+        unsigned rw[NV * 4];
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const int v = lane + 64 * i;
-            if (v >= cur.nvec) continue;
-            const uint4 u = *reinterpret_cast<const uint4 *>(raw + 16 * v);
-            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
-            double d[8];
+        for (int j = 0; j < NV * 4; j++) rw[j] = reinterpret_cast<const unsigned *>(raw)[64 * j + lane];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int s = (e & 1) ? ((int)ww[e >> 1] >> 16) : (int)(short)(ww[e >> 1] & 0xFFFF);
-                d[e] = (double)s * (s < 0 ? sc_neg : sc_pos);  // s / (s < 0 and 32768 or 32767)  :1081
-            }
-            double2 *o = reinterpret_cast<double2 *>(sm + 8 * v);
-            o[0] = make_double2(d[0], d[1]); o[1] = make_double2(d[2], d[3]); o[2] = make_double2(d[4], d[5]); o[3] = make_double2(d[6], d[7]);
+        for (int j = 0; j < NV * 4; j++) {
+            const unsigned w = rw[j];
+            const int s0 = (int)(short)(w & 0xFFFF), s1 = (int)w >> 16;
+            reinterpret_cast<double2 *>(sm)[64 * j + lane] = make_double2((double)s0 * (s0 < 0 ? sc_neg : sc_pos), (double)s1 * (s1 < 0 ? sc_neg : sc_pos));  // s / (s < 0 and 32768 or 32767)  :1081
         }
         {
             const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
@@ -365,7 +362,7 @@ bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, dou
     if (lds > 64 * 1024) return false;
     if ((*rc = plan_tiles_sized(ctx, segs, tile, P))) return true;
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
-    unsigned per_cu = 16;
+    unsigned per_cu = 64;  // workgroups per CU in the grid (6 are resident): 16 → 64 measured +4 % (finer hand-out of the tail across CUs / XCDs)
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;

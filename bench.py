@@ -340,6 +340,59 @@ def reduce_over_ranks(dist, torch, rdev, dt, units):
     return float(tt.item()), float(ts.item())
 
 
+XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (the brief's figure): every peer's share crosses exactly one
+
+
+def time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync):
+    """SURVEY 8e's second curve: the job's input starts on rank 0 (all `world` shards back to back in its HBM), is scattered device to device
+    (aukit_amd.shard.scatter_batch: RCCL point-to-point, each peer's share over its own xGMI link, received straight into the tensor
+    the library then wraps with aukit_batch_wrap_device), every rank runs ONE pass, and the output rows are gathered to rank 0
+    (shard.gather_audio: sent straight from aukit_audio_device_ptr).  Returns the three times (max over ranks) and the inclusive rate."""
+    from aukit_amd import shard
+    own_group = False
+    if not dist.is_initialized():  # N = 1: a one-rank group, so that the same code runs (its scatter / gather are views, nothing moves)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+        own_group = True
+    try:
+        whole = None
+        if rank == 0:
+            x = wl.x.view(torch.uint8)
+            big = x.repeat(world) if world > 1 else x  # every rank's shard (the same synthetic content), resident on rank 0
+            n = args.streams * world
+            whole = B.Batch.wrap(ctx, big.data_ptr(), [i * wl.n_samples * 2 for i in range(n + 1)], keep=big)
+        out = B.AudioBatch(ctx)
+        times = []
+        for it in range(2):  # the first round pays RCCL's connection set-up: report the second
+            sync(); dist.barrier(); sync()
+            t0 = time.perf_counter()
+            mine, (lo, hi) = shard.scatter_batch(ctx, whole, src=0, device=dev)
+            sync(); t1 = time.perf_counter()
+            B.decode_resample(ctx, mine, wl.d, DST_RATE, args.interp, dtype=wl.dtype, out=out)
+            ctx.sync(); sync(); t2 = time.perf_counter()
+            got = shard.gather_audio(out, dst=0, device=dev)
+            sync(); dist.barrier(); sync()
+            t3 = time.perf_counter()
+            times.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+            nbytes_out = sum(int(t.numel()) for t, _ in got) if got is not None else 0
+            nsamp = sum(int(m["lens"].sum()) for _, m in got) if got is not None else 0
+            del got, mine
+        tt = torch.tensor(times[-1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sc, co, ga, tot = [float(v) for v in tt.tolist()]
+        if rank != 0:
+            return None
+        share_in = args.streams * wl.n_samples * 2
+        share_out = nbytes_out / max(world, 1)
+        return {"scatter_s": sc, "compute_s": co, "gather_s": ga, "total_s": tot, "value_inclusive": nsamp / tot / 1e6, "unit": "Msamples/s",
+                "bytes_scattered_per_peer": share_in, "bytes_gathered_per_peer": int(share_out), "peers": world - 1,
+                "xgmi_link_GBs": XGMI_LINK_GBS, "link_bound_s": ((share_in + share_out) / (XGMI_LINK_GBS * 1e9)) if world > 1 else 0.0,
+                "note": "input on rank 0 -> RCCL scatter (HBM to HBM) -> one pass per rank -> gather of the output rows to rank 0; max over ranks; "
+                        "xGMI-bound by construction (SURVEY 8e), reported beside `value`, never as it"}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -358,6 +411,9 @@ def main(argv=None):
                          "2 = fp64 in the reference's operation order, 0 = f32 taps (default for the other workloads)")
     ap.add_argument("--extra-windows", type=int, default=4, help="further K-step windows timed after the contractual one (spread of the measurement)")
     ap.add_argument("--fast-line", type=int, default=1, help="pcm16_cubic: also time the f32-tap kernel and report it as roofline_fast")
+    ap.add_argument("--distribute", type=int, default=0,
+                    help="1: after the measurement, ALSO time the distribution variant (rank 0 holds every rank's input in its HBM: device-to-device "
+                         "scatter over RCCL, one pass, gather of the output rows to rank 0) and report it as `distribute` — a second number, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args(argv)
@@ -464,6 +520,14 @@ def main(argv=None):
         fast = (ctx.last_kernel()[0], fe / args.steps, fb // args.steps)
         ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
 
+    distribute = None
+    if args.distribute and not selftest and args.workload == "pcm16_cubic":
+        try:
+            distribute = time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync)
+        except Exception as e:  # the distribution figure is optional: never lose the line to it
+            distribute = {"error": f"{type(e).__name__}: {e}"}
+
+    line = None
     if rank == 0:
         import statistics
         kernel_ms = ev_ms / args.steps
@@ -512,14 +576,23 @@ def main(argv=None):
             line["roofline_fast"] = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "kernel": fast[0],
                                      "kernel_ms": fast[1], "dtype": "f32", "traffic": _measured_traffic(fast[0], args),
                                      "note": "same batch through the f32-tap kernel (AUKIT_OPT_EXACT_MATH = 0): secondary figure"}
+        if distribute:
+            line["distribute"] = distribute
         if world == 1 and args.cpu_streams > 0:
             cb = wl.cpu_baseline(args)
             if cb:
                 line["cpu_baseline"] = cb
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line, last: RCCL writes its version banner through C stdio, which would otherwise be flushed behind it at exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,89 @@
+"""The product path sharded: a batch is cut with shard.partition, every shard is handed to the library from a device
+tensor through aukit_batch_wrap_device (what a rank does with the bytes RCCL delivered), runs in its OWN context, and the shards' rows
+put back in rank order are, bit for bit, the rows of the unsharded call.  One GPU is all a test box has, so the "ranks" are contexts
+on cuda:0; the transport itself is tested over gloo (tests/test_host_math.py) and the N-rank launch in tests/test_bench_launch.py."""
+import numpy as np
+import pytest
+
+from tests.util import pcm16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_equals_single(ctx, world):
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    from aukit_amd import shard
+    lens = [30000, 100, 4097, 1, 52000, 7, 9000, 1024, 2048, 33333, 5, 777]
+    streams = [pcm16(n, 44100, 1, i).tobytes() for i, n in enumerate(lens)]
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    whole = B.Batch.upload(ctx, streams)  # the job's bytes, resident in HBM
+    starts = whole.offsets().astype(np.int64)
+    for exact in (0, 1):
+        ctx.set_option(N.OPT_EXACT_MATH, exact)
+        try:
+            single = B.decode_resample(ctx, whole, desc, 48000, "cubic", dtype=N.F32).download()
+        finally:
+            ctx.set_option(N.OPT_EXACT_MATH, 0)
+        parts = shard.partition([len(s) for s in streams], world)
+        assert parts[0][0] == 0 and parts[-1][1] == len(streams) and all(parts[g][1] == parts[g + 1][0] for g in range(world - 1))
+        rows = []
+        for lo, hi in parts:
+            c2 = B.Context(0)  # a rank's own context (own stream, own scratch)
+            c2.set_option(N.OPT_EXACT_MATH, exact)
+            try:
+                # what rank g holds after the scatter: `hi - lo` streams back to back in device memory, handed over with aukit_batch_wrap_device
+                bt = B.Batch.wrap(c2, whole.device_ptr() + int(starts[lo]), (starts[lo:hi + 1] - starts[lo]).astype(np.uint64), keep=whole)
+                rows += B.decode_resample(c2, bt, desc, 48000, "cubic", dtype=N.F32).download()
+            finally:
+                c2.close()
+        assert len(rows) == len(single)
+        for a, b in zip(rows, single):
+            assert np.array_equal(a[0], b[0])
+
+
+def test_device_views_and_one_rank_group():
+    """shard.device_view / scatter_batch / gather_audio on the GPU, in a child process that loads torch BEFORE the library (torch bundles its
+    own HIP runtime and must be the first to load it): a one-rank RCCL group, where the source's shard and the gathered rows are zero-copy
+    views of the library's own device memory."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+torch.cuda.set_device(0)
+from aukit_amd import _native as N, batch as B, shard
+from tests.util import pcm16
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29877", rank=0, world_size=1, device_id=dev)
+ctx = B.Context(0)
+streams = [pcm16(n, 44100, 1, i).tobytes() for i, n in enumerate([5000, 300, 41, 0, 70000])]
+bt = B.Batch.upload(ctx, streams)
+v = shard.device_view(bt.device_ptr(), int(bt.offsets()[-1]), dev, keep=bt)
+assert v.data_ptr() == bt.device_ptr() and v.cpu().numpy().tobytes() == b"".join(streams)
+mine, (lo, hi) = shard.scatter_batch(ctx, bt, src=0, device=dev)
+assert (lo, hi) == (0, 5) and mine.device_ptr() == bt.device_ptr()
+desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+out = B.decode_resample(ctx, mine, desc, 48000, "cubic", dtype=N.F32)
+ctx.sync()
+got = shard.gather_audio(out, dst=0, device=dev)
+assert len(got) == 1
+t, m = got[0]
+assert t.data_ptr() == out.device_ptr() and m["channels"] == 1 and m["dtype"] == N.F32 and m["rate"] == 48000.0
+rows = t.view(torch.float32).cpu().numpy()
+for s, g in enumerate(out.download()):
+    assert int(m["lens"][s]) == len(g[0])
+    assert np.array_equal(rows[int(m["row_off"][s]):int(m["row_off"][s]) + len(g[0])].astype(np.float64), g[0])
+enc = B.dfpwm_encode(ctx, B.decode_resample(ctx, mine, desc, 48000, "cubic", dtype=N.F64)) if hasattr(B, "dfpwm_encode") else None
+if enc is not None:
+    gb = shard.gather_batch(enc, dst=0, device=dev)
+    assert len(gb) == 1 and gb[0][0].cpu().numpy().tobytes() == b"".join(enc.download())
+dist.destroy_process_group()
+print("OK")
+""" % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-3000:]

@@ -136,3 +136,53 @@ def test_scatter_process_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and lo == 0 and 0 < hi < 9
+
+
+def _worker_transport(rank, world, port, q):
+    """the device face's transport (aukit_amd.shard._scatter_bytes / _gather_bytes_with_table) on CPU tensors under gloo: the same code
+    moves cuda tensors under nccl; here it must deliver exactly the partition's byte ranges, views for the source rank, and opaque tables"""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aukit_amd import shard
+    dev = torch.device("cpu")
+    rng = np.random.Generator(np.random.PCG64(99))
+    sizes = [0, 700, 1, 1300, 0, 64, 5000, 3, 900][: 9 if world < 3 else 2]  # world 3: two streams only, one rank gets an empty shard
+    blob = rng.integers(0, 256, int(sum(sizes)), dtype=np.uint8)
+    flat = torch.from_numpy(blob.copy()) if rank == 0 else None
+    mine, sz, (lo, hi) = shard._scatter_bytes(flat, sizes if rank == 0 else None, 0, dev, None)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    ok = list(sz) == sizes[lo:hi] and np.array_equal(mine.numpy(), blob[starts[lo]:starts[hi]])
+    if rank == 0 and mine.numel():
+        ok = ok and mine.data_ptr() == flat.data_ptr() + int(starts[lo])  # the source's own shard is a view, not a copy
+    # every rank "processes" its shard (doubles every byte mod 256) and the results travel back with a layout table
+    table = np.array([rank, lo, hi, -7], dtype=np.int64)
+    got = shard._gather_bytes_with_table((mine * 2), table, 0, dev, None)
+    if rank == 0:
+        parts = shard.partition(sizes, world)
+        whole = np.concatenate([g[0].numpy() for g in got])
+        ok = ok and np.array_equal(whole, (blob * 2).astype(np.uint8)) and [list(g[1]) for g in got] == [[r, a, b, -7] for r, (a, b) in enumerate(parts)]
+        q.put(bool(ok))
+    else:
+        assert got is None and ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_face_transport_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_worker_transport, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
