@@ -85,6 +85,7 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         }
         frames[s] = nb / frame_bytes;
         lens[s] = do_resample ? resample_count(frames[s], ratio) : frames[s];
+        if (frames[s] > 0x7FFFFFF0ull || lens[s] > 0xFFFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "stream too long");  // Seg carries 32-bit counts: refuse before anything is allocated
         if (lens[s]) {
             double xl = host_pos(lens[s] - 1, ratio);
             if (std::floor(xl) > (double)frames[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
@@ -386,6 +387,7 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     for (uint32_t s = 0; s < n; s++) {
         const uint64_t L = row_len[(size_t)s * channels];
         lens[s] = do_resample ? resample_count(L, ratio) : L;  // newlen uses #data[1]  :659
+        if (L > 0x7FFFFFF0ull || lens[s] > 0xFFFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "stream too long");
         for (int c = 0; c < channels; c++) {
             if (row_len[(size_t)s * channels + c] < L && lens[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
             in_elems += row_len[(size_t)s * channels + c];
@@ -469,6 +471,7 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     uint64_t in_elems = 0, out_elems = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         lens[s] = resample_count(in->len[s], ratio);
+        if (in->len[s] > 0x7FFFFFF0ull || lens[s] > 0xFFFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "stream too long");
         if (lens[s] && std::floor(host_pos(lens[s] - 1, ratio)) > (double)in->len[s]) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
         in_elems += in->len[s] * (uint64_t)C;
         out_elems += lens[s] * (uint64_t)C;

@@ -298,13 +298,14 @@ __global__ __launch_bounds__(256) void k_wetdry(const T *data, RowMeta m, double
         sum[base + i] = sum[base + i] * wet + (double)data[base + i] * dry;
 }
 // in-place all-pass :3574-3575: sum[i] = sum[i] - 0.131*sum[i-S] + 0.131*sum[i+20-S], i >= S+2 (1-based).
-// Element i depends on i-S and i-S+20, both at least S-20 behind: blocks of S-20 elements are internally independent.
+// Element i depends on i-S and i-S+20, both at least S-20 behind: blocks of S-20 elements are internally independent
+// (S == 20: the second one is the element itself, blocks of S).
 __global__ __launch_bounds__(1024) void k_allpass(double *sum, RowMeta m, long long S) {
     const unsigned r = blockIdx.x;
     unsigned long long base, len;
     row_of(m, r, &base, &len);
     double *s = sum + base;  // s[i-1] = sum[i]
-    const long long n = (long long)len, W = S - 20;
+    const long long n = (long long)len, W = S > 20 ? S - 20 : S;  // S == 20 (rates of 224.1 … 235.2 Hz): sum[i + 20 - S] is sum[i] itself, only i - S lies behind
     if (threadIdx.x == 0) s[S] = s[S] - 0.131 * s[0];  // sum[S+1] -= 0.131 * sum[1]
     __threadfence();
     __syncthreads();

@@ -90,6 +90,23 @@ def test_reverb(ctx, oracle):
     assert np.max(np.abs(ab.download()[0][1] - ref.data[1])) <= 1e-13
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("rate", [224.5, 230, 235, 236, 300])
+def test_reverb_at_low_sample_rates(ctx, oracle, rate):
+    """floor(0.08927 * rate) == 20 for rates of about 224.1 … 235.2 Hz: the second all-pass tap of aukit.lua:3575 is then the element
+    itself (sum[i + 20 - samples] = sum[i]); the block-parallel all-pass must neither hang (its block width was samples - 20 = 0) nor
+    differ from the oracle.  236 / 300 Hz: the first rates with one / six elements per block."""
+    B, N = _B(), _N()
+    a = _audios(rate=22050, lens=(4000, 700), ch=2)
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F64)
+    B.effect(ctx, ab, "reverb", 100.0, 0.3, 0.8, 0.2)
+    got = ab.download()
+    for s in range(2):
+        ref = oracle.fx_reverb(oracle.Audio(a[s], rate), 100.0, 0.3, 0.8, 0.2)
+        for c in range(2):
+            assert np.max(np.abs(got[s][c] - ref.data[c])) <= 1e-13
+
+
 def test_speed_and_trim(ctx, oracle):
     B, N = _B(), _N()
     a = _audios(lens=(20000, 3000))
