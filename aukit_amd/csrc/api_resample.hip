@@ -464,6 +464,7 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     if (in->dtype != AUKIT_F64 && in->dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "resample needs a float audio");
     if (*out == in) return fail(AUKIT_E_ARG, "resample cannot run in place");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    AUKIT_FLUSH(ctx, in);
     const double ratio = new_rate / in->rate;  // :658
     if (!(ratio > 0)) return fail(AUKIT_E_ARG, "bad sample rate");
     const int C = in->channels;

@@ -342,6 +342,46 @@ AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned
     idx = idx_end;
 }
 
+// The same for a whole 1024-nibble chunk whose 16 nibbles per lane arrive as two little-endian words (one-channel WAV blocks: the
+// common case of stream.adpcm): no validity predicates, no exec-masked emits, the step table read from LDS (`steps`, 89 ints) — the
+// __constant__ array indexed per lane is a global load per nibble.
+template <class Emit>
+AUKIT_DEV void ima_wave_chunk_full(unsigned w0, unsigned w1, const int *steps, int lane, int &pred, int &idx, Emit emit) {
+    unsigned nibs[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { nibs[k] = (w0 >> (4 * k)) & 15u; nibs[8 + k] = (w1 >> (4 * k)) & 15u; }
+    Sat f = sat_id();
+#pragma unroll
+    for (int k = 0; k < 16; k++) f = sat_then(f, Sat{ima_index_delta(nibs[k]), 0, 88});
+    const Sat inc = wave_scan_incl(f, lane);
+    Sat exc = sat_shfl_up(inc, 1);
+    if (lane == 0) exc = sat_id();
+    int si = sat_apply(exc, idx);
+    const int idx_end = sat_apply(Sat{__shfl(inc.a, 63), __shfl(inc.lo, 63), __shfl(inc.hi, 63)}, idx);
+    int delta[16];
+    Sat g = sat_id();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int step = steps[si];                                                   // :2807
+        si = clampi(si + ima_index_delta(nibs[k]), 0, 88);                            // :2808
+        const int diff = (int)(((nibs[k] & 7) * (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
+        delta[k] = (nibs[k] & 8) ? -diff : diff;
+        g = sat_then(g, Sat{delta[k], -32768, 32767});                                // :2810-2811
+    }
+    const Sat ginc = wave_scan_incl(g, lane);
+    Sat gexc = sat_shfl_up(ginc, 1);
+    if (lane == 0) gexc = sat_id();
+    int p = sat_apply(gexc, pred);
+    const int pred_end = sat_apply(Sat{__shfl(ginc.a, 63), __shfl(ginc.lo, 63), __shfl(ginc.hi, 63)}, pred);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        p = clampi(p + delta[k], -32768, 32767);
+        emit(k, p);
+    }
+    pred = pred_end;
+    idx = idx_end;
+}
+
 // one row of int16 predictors per (stream, channel): whole-stream raw ADPCM or a sequence of WAV blocks
 struct ImaRowJob {
     unsigned long long src_off;   // byte offset of the stream
@@ -415,6 +455,7 @@ struct ImaStreamParams {
     unsigned fa, fb, fmagic;
     double inv_fb;
     unsigned fdq, fdr;                   // 64 fa = fdq fb + fdr
+    unsigned long long bps;              // k_ima_stream_f32: blocks per stream when that is the same for every stream, else 0
 };
 
 template <int INTERP, typename OUT_T>
@@ -512,6 +553,134 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- stream.adpcm, one channel, linear / cubic, integer rates with at most 512 output phases (22 050 → 48 000 Hz has 320): config 3a.
+// The block is kept in LDS as the int16 predictors themselves (exact floats, 4 bytes a sample) and every output is decided in up to
+// three tiers, each taken only when it is certain of the integer interval the reference's value falls into (the output is floor()ed,
+// :2823) — the argument of floor_wave.hip, with one more difficulty: the samples are p / 128 (p < 0) or p / 127 (:2812), not exact in
+// f32 and with two scales inside one interpolation window.
+//   1. f32, straight-line for the whole wave.  With pp = max(p, 0): sample = (p + pp / 127) / 128, so by linearity the interpolated
+//      value is (A + B / 127) / 128, A and B the same tap-weighted sums over p and pp.  Taps are exact integers below 2^15; the
+//      weights of the output's phase come from an LDS table (computed in fp64 on the host, rounded once: ≤ 2^-25 relative, the
+//      position itself is exact); four FMAs per sum round at magnitudes below 2^16 (half an ulp = 2^-9 each).  In units of the
+//      output: (4 · 2^-25 · 2^15 + 4 · 2^-9 + 2^-9) / 128 + the B branch at 1 / 127 of that < 1.2e-4.  Taken when the value lies more
+//      than 1e-3 away from an integer.
+//   2. (about one output in 500) the polynomial in fp64 on exact doubles and the exact rational position, FMA Horner form, taken
+//      when more than 1e-6 away from an integer (the reference's x carries < 1024 · 2^-53 of rounding, times a slope below 1600).
+//   3. otherwise, and where the nil fall-backs of the block's ends apply: the reference-order code on the same table.
+// Same-box A/B against the fp64-only short-cut of k_ima_stream (AUKIT_IMA_F64=1) in DESIGN.md §3.
+template <int INTERP, typename OUT_T>
+__global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P, const float *__restrict__ wg) {
+    extern __shared__ float smf[];
+    constexpr int WF = INTERP == AUKIT_INTERP_CUBIC ? 4 : 1;  // floats per phase: w0..w3 / fx
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned i = threadIdx.x; i < P.fb * WF; i += 256) smf[i] = wg[i];
+    int *const steps = reinterpret_cast<int *>(smf + ((P.fb * WF + 3) & ~3u));  // ima_step_table (:161-171), 89 entries (96 slots)
+    if (threadIdx.x < 89) steps[threadIdx.x] = c_ima_step[threadIdx.x];
+    __syncthreads();
+    const float *const wt = smf;
+    float *const sm = smf + ((P.fb * WF + 3) & ~3u) + 96 + (size_t)wave * P.cap;  // sm[q] = d[q + 1], unskewed: see the decode below
+    const unsigned long long ba = (unsigned long long)P.block_align;
+    const unsigned long long nwr = (ba - 4ull) / 4ull;     // real word groups per block
+    const double spb = (double)(ba - 4ull) * 2;            // samplesPerBlock :2765
+    ResampleParams RP;  // only the position fields are used by pos_of / eval_at
+    RP.ratio = P.ratio; RP.rcp = P.rcp; RP.exact_rcp = P.exact_rcp; RP.sinc_w = 10;
+    const float c127 = 1.0f / 127.0f;
+    for (unsigned long long gb = (unsigned long long)blockIdx.x * 4 + wave; gb < P.nblocks; gb += (unsigned long long)gridDim.x * 4) {
+        unsigned lo = 0, hi = P.nstreams;  // stream of this block (wave-uniform): a division when every stream has the same number of blocks, else a binary search in blk0
+        if (P.bps) lo = (unsigned)(gb / P.bps);
+        else while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (P.blk0[mid] <= gb) lo = mid; else hi = mid; }
+        const unsigned s = lo;
+        const unsigned long long bi = gb - P.blk0[s];
+        const unsigned long long nbytes = P.off[s + 1] - P.off[s], b0 = bi * ba, rem_bytes = nbytes - b0;
+        const unsigned char *blk = P.src + P.off[s] + b0;
+        long long ng = (long long)((rem_bytes - 1) / 4ull) - 1;  // word groups decoded, junk word included (Q6)  :2800-2802
+        if (ng > (long long)nwr + 1) ng = (long long)nwr + 1;
+        if (ng < 0) ng = 0;
+        const unsigned long long nb = (unsigned long long)ng * 8;  // #d[1]
+        unsigned newlen = P.newlen_full;
+        if ((double)nb < spb) newlen = (unsigned)floor((double)nb * P.ratio);  // :2817
+        int pred = (short)(blk[0] | blk[1] << 8);
+        int idx = blk[2];  // used unmasked :2799
+        if (idx > 88 && nb > 0) { if (lane == 0) atomicCAS(P.err, 0, 3); continue; }
+        // The table is NOT skewed: a lane owns 16 consecutive entries, so its ds_write_b32 stores collide 16-way in the banks — a few
+        // hundred LDS cycles per block on an LDS pipe that is a twentieth busy, against 2 address instructions per tap and 3 per
+        // store on the VALU, which is what the kernel is bound by (PMC: profiles/).
+        NibSeq seq{blk + 4, 0, 1, 0, 0, 1, 0};
+        if (nb == 1024) {  // a whole block (all but possibly the stream's last): two words per lane, straight-line
+            const unsigned char *wp = blk + 4 + 8 * lane;
+            unsigned w0, w1;
+            if ((reinterpret_cast<uintptr_t>(blk) & 3) == 0) { const uint2 ww = *reinterpret_cast<const uint2 *>(wp); w0 = ww.x; w1 = ww.y; }  // wave-uniform
+            else { w0 = (unsigned)wp[0] | (unsigned)wp[1] << 8 | (unsigned)wp[2] << 16 | (unsigned)wp[3] << 24; w1 = (unsigned)wp[4] | (unsigned)wp[5] << 8 | (unsigned)wp[6] << 16 | (unsigned)wp[7] << 24; }
+            float *const mine = sm + 16 * lane;
+            ima_wave_chunk_full(w0, w1, steps, lane, pred, idx, [&](int k, int p) { mine[k] = (float)p; });
+        } else {
+            for (unsigned long long q0 = 0; q0 < nb; q0 += 1024) ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { sm[q] = (float)p; });
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        Seg sg;
+        sg.w_lo = 1; sg.w_hi = (int)nb;
+        OUT_T *obase = reinterpret_cast<OUT_T *>(P.out) + P.out_off[s] + bi * (unsigned long long)P.newlen_full;
+        const int nbi = (int)nb;
+        auto slow = [&](int k, unsigned rem, unsigned j, bool inside) -> float {  // tiers 2 and 3
+            double v = 0;
+            bool ok = false;
+            if (inside) {
+                const int s1 = k - 1;
+                const double p1 = CvIma8::cv((double)sm[s1]), p2 = CvIma8::cv((double)sm[s1 + 1]);
+                const double fx = (double)rem * P.inv_fb;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
+                else {
+                    const double p0 = CvIma8::cv((double)sm[s1 - 1]), p3 = CvIma8::cv((double)sm[s1 + 2]);
+                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                    const double c1 = 0.5 * (p2 - p0);
+                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+                }
+                const double fr = v - floor(v);
+                ok = fr > 1e-6 && fr < 1 - 1e-6;
+            }
+            if (!ok) { bool isint; v = eval_at<INTERP, false, float, CvIma8>(RP, sg, sm, 1, j, &isint); }
+            return (float)lua_clamp(floor(v), -128, 127);
+        };
+        // floor(j fa / fb) and the remainder: by the reciprocal for the lane's first output (exact: (newlen * fa + fb) * fb < 2^32),
+        // then advanced by additions — 64 outputs further is 64 fa = dq fb + dr
+        unsigned q0 = __umulhi((unsigned)lane * P.fa, P.fmagic);
+        unsigned rem = (unsigned)lane * P.fa - q0 * P.fb;
+        for (unsigned rb = 0; rb < newlen; rb += 64, q0 += P.fdq, rem += P.fdr) {
+            const unsigned j = rb + lane;
+            const bool active = j < newlen;
+            if (rem >= P.fb) { rem -= P.fb; q0++; }
+            const int k = (int)q0 + 1;  // floor(x)
+            // straight-line for the whole wave: taps outside the table are read from a safe slot and the lane is sent to tier 3
+            const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi);  // one spare tap on the left (x may round below an integer)
+            const int s1 = inside ? k - 1 : 2;
+            const float *tp = sm + s1;
+            const float p1 = tp[0], p2 = tp[1];
+            auto pos = [](float p) { return __builtin_amdgcn_fmed3f(p, 0.0f, __builtin_inff()); };  // max(p, 0) as one v_med3_f32 (fmaxf costs a canonicalising v_max on top)
+            float A, Bv;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                const float fx = wt[rem];
+                A = __builtin_fmaf(p2 - p1, fx, p1);
+                const float q1 = pos(p1), q2 = pos(p2);
+                Bv = __builtin_fmaf(q2 - q1, fx, q1);
+            } else {
+                const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * rem);
+                const float p0 = tp[-1], p3 = tp[2];
+                A = __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
+                Bv = __builtin_fmaf(w.w, pos(p3), __builtin_fmaf(w.z, pos(p2), __builtin_fmaf(w.y, pos(p1), w.x * pos(p0))));
+            }
+            const float v = __builtin_fmaf(Bv, c127, A) * (1.0f / 128.0f);
+            float fl = floorf(v);
+            const float fr = v - fl;
+            const bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
+            if (active && !accept) fl = slow(k, rem, j, inside);
+            if (active) obase[j] = (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);  // :2824
+        }
+        __builtin_amdgcn_wave_barrier();  // the next block's decode overwrites the table
     }
 }
 
@@ -727,6 +896,48 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 P.fdq = (unsigned)((64ull * fa) / fb); P.fdr = (unsigned)((64ull * fa) % fb);
             }
         }
+        // one channel, at most 512 phases: the three-tier kernel on an f32 table (k_ima_stream_f32)
+        if (P.fast && P.fb <= 512 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !getenv("AUKIT_IMA_F64")) {
+            const int wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
+            std::vector<float> w((size_t)P.fb * wf);
+            for (unsigned r = 0; r < P.fb; r++) {
+                const long double f = (long double)r / (long double)P.fb, f2 = f * f, f3 = f2 * f;
+                if (wf == 1) w[r] = (float)f;
+                else {
+                    w[4 * r] = (float)(-0.5L * f3 + f2 - 0.5L * f); w[4 * r + 1] = (float)(1.5L * f3 - 2.5L * f2 + 1.0L);
+                    w[4 * r + 2] = (float)(-1.5L * f3 + 2.0L * f2 + 0.5L * f); w[4 * r + 3] = (float)(0.5L * f3 - 0.5L * f2);
+                }
+            }
+            if ((rc = upload_table(ctx, ctx->tmp_buf3, w.data(), w.size() * 4))) { delete ck; return rc; }
+            P.bps = 0;
+            if (in->n) {
+                const uint64_t b1 = blk0[1] - blk0[0];
+                bool uni = b1 > 0;
+                for (uint32_t s = 1; s < in->n && uni; s++) uni = blk0[s + 1] - blk0[s] == b1;
+                if (uni) P.bps = b1;
+            }
+            const int capf = (int)((ba - 4ull) * 2 + 8 + 8 + 15) & ~15;  // floats per wave: the block's nibbles + the junk word's + slack, unskewed
+            const size_t lds = ((((size_t)P.fb * wf + 3) & ~(size_t)3) + 96) * 4 + (size_t)capf * 4 * 4;
+            if (lds <= 64 * 1024) {
+                P.cap = capf;
+                const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+                const unsigned grid = (unsigned)std::min<uint64_t>((nblocks + 3) / 4, (uint64_t)ctx->num_cus * per_cu * 4);
+                if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
+                const float *wgp = reinterpret_cast<const float *>(ctx->tmp_buf3.p);
+                if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_LINEAR, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); else hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_CUBIC, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); }
+                else { if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_LINEAR, double>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); else hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_CUBIC, double>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); }
+                if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_ima_stream_f32 launch failed"); }
+                uint64_t out_elems = 0;
+                for (uint64_t l : lens) out_elems += l * nd;
+                if ((rc = ctx_end_kernel(ctx, "k_ima_stream_f32", in->total() + out_elems * dtype_size(dtype)))) { delete ck; return rc; }
+                int herr = 0;
+                AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (herr) { delete ck; return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')"); }  // ima_step_table[idx > 88]
+                if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+                return AUKIT_OK;
+            }
+        }
         unsigned nwv = 4;
         while (nwv > 1 && (size_t)P.cap * C * 8 * nwv > 64 * 1024) nwv >>= 1;
         const size_t lds = (size_t)P.cap * C * 8 * nwv;
@@ -786,6 +997,7 @@ int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, a
     if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
     if (in->dtype != AUKIT_F64 && in->dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "dfpwm encode needs a float audio");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    AUKIT_FLUSH(ctx, in);
     std::vector<uint64_t> off(in->n + 1, 0);
     for (uint32_t s = 0; s < in->n; s++) off[s + 1] = off[s] + (in->len[s] * (uint64_t)in->channels + 7) / 8;
     aukit_batch *b = *out;

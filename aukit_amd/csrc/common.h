@@ -88,6 +88,17 @@ struct aukit_audio {
     uint64_t *d_meta = nullptr;  // device: len[n], row_off[n], row_stride[n]
     size_t meta_cap = 0;
     uint64_t version = 0;
+    // max |x| of every row (bit pattern of a non-negative double), a by-product of the pass that last rewrote the rows (k_onepole):
+    // effects.normalize then needs no pass of its own over the samples to find its peak (aukit.lua:3439-3444)
+    uint64_t *d_rowmax = nullptr;
+    size_t rowmax_cap = 0;
+    bool rowmax_valid = false;
+    // a deferred element-wise map: effects.normalize's `ch[i] = clamp(ch[i] * mult, -1, 1)` (:3455) has been asked for but not yet applied;
+    // the next reader applies it on the fly (Audio:mono does: config 5's tail) or audio_flush() materialises it first
+    bool pend_norm = false;
+    double pend_peak = 1;
+    int pend_independent = 0;
+    aukit_ctx *pend_ctx = nullptr;
 };
 
 struct aukit_chunks {
@@ -104,6 +115,13 @@ static inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m
 
 // (re)shape *out for n streams of the given lengths; reuses its buffers when they are large enough.
 int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, double rate, int dtype, const uint64_t *lens);
+// applies a deferred map (aukit_audio::pend_norm) in place; every entry point that reads an audio's samples calls it first
+int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
+#define AUKIT_FLUSH(ctx, a)                                                   \
+    do {                                                                      \
+        if ((a) && (a)->pend_norm) { int _frc = ::aukit::audio_flush((ctx), (a)); if (_frc) return _frc; } \
+    } while (0)
+int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 int ctx_begin_kernel(aukit_ctx *ctx);
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes);
 // uploads a host table into a ctx scratch buffer on the ctx stream

@@ -37,11 +37,21 @@ AUKIT_DEV void row_of(const RowMeta &m, unsigned r, unsigned long long *base, un
 enum MapOp { MAP_AMPLIFY, MAP_INVERT, MAP_FADE, MAP_SCALE_ROWMAX, MAP_DELAY };
 struct MapArgs {
     double a0, a1, a2, a3;       // op-specific scalars
-    const double *rowmax;        // MAP_SCALE_ROWMAX: max |x| per stream (or per row when `independent`)
+    const double *rowmax;        // MAP_SCALE_ROWMAX: max |x| per ROW; the stream's maximum (not `independent`) is taken over its rows here
     int independent;
     const void *aux;             // MAP_DELAY: copy of the original samples
     unsigned long long lag;
 };
+
+// effects.normalize's multiplier for row r from the per-row maxima: peak / max over the row (independent) or over every row of its stream;
+// math.max(max, abs(x)) skips NaNs, so do the comparisons here (:3440-3451)
+AUKIT_DEV double norm_mult(const double *rowmax, double peak, int independent, unsigned r, int channels) {
+    if (independent) return peak / rowmax[r];
+    const unsigned s0 = r / (unsigned)channels * (unsigned)channels;
+    double mx = 0;
+    for (int c = 0; c < channels; c++) { const double v = rowmax[s0 + c]; mx = mx < v ? v : mx; }
+    return peak / mx;
+}
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void k_map(T *data, RowMeta m, MapArgs A) {
@@ -50,7 +60,7 @@ __global__ __launch_bounds__(256) void k_map(T *data, RowMeta m, MapArgs A) {
     row_of(m, r, &base, &len);
     T *row = data + base;
     double mult = 0;
-    if constexpr (OP == MAP_SCALE_ROWMAX) mult = A.a0 / A.rowmax[A.independent ? r : r / (unsigned)m.channels];  // peak / max  :3444
+    if constexpr (OP == MAP_SCALE_ROWMAX) mult = norm_mult(A.rowmax, A.a0, A.independent, r, m.channels);  // peak / max  :3444
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
         double x = (double)row[i];
         if constexpr (OP == MAP_AMPLIFY) row[i] = (T)lua_clamp(x * A.a0, -1, 1);                       // :3365
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(256) void k_map(T *data, RowMeta m, MapArgs A) {
 
 // max |x| per row → atomicMax on the (non-negative) bit pattern; NaNs are skipped like math.max does
 template <typename T>
-__global__ __launch_bounds__(256) void k_rowmax(const T *data, RowMeta m, unsigned long long *out, int independent) {
+__global__ __launch_bounds__(256) void k_rowmax(const T *data, RowMeta m, unsigned long long *out) {
     const unsigned r = blockIdx.y;
     unsigned long long base, len;
     row_of(m, r, &base, &len);
@@ -83,19 +93,42 @@ __global__ __launch_bounds__(256) void k_rowmax(const T *data, RowMeta m, unsign
     __syncthreads();
     if (threadIdx.x == 0) {  // one atomic per workgroup (per-wave atomics on ~N addresses serialised: 13.6 ms → see profiles/)
         for (int w = 1; w < 4; w++) mx = mx < red[w] ? red[w] : mx;
-        atomicMax(out + (independent ? r : r / (unsigned)m.channels), (unsigned long long)__double_as_longlong(mx));
+        atomicMax(out + r, (unsigned long long)__double_as_longlong(mx));
     }
 }
 
 // Audio:mono  :682-687  (s = 0 + c1 + c2 ...; s / cn)
-template <typename T>
-__global__ __launch_bounds__(256) void k_mono(const T *in, RowMeta mi, T *out, RowMeta mo) {
+// NORM: the input carries a deferred effects.normalize (aukit_audio::pend_norm): every sample is read as the value the map would have
+// stored, (T)clamp(x * mult, -1, 1) — the same bits as k_map<normalize> followed by the plain kernel, one pass over the rows less
+template <typename T, bool NORM>
+__global__ __launch_bounds__(256) void k_mono(const T *in, RowMeta mi, T *out, RowMeta mo, const double *rowmax, double peak, int independent) {
     const unsigned s = blockIdx.y;
     const unsigned long long len = mi.len[s], ib = mi.off[s], st = mi.stride[s], ob = mo.off[s];
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
-        double acc = 0;
-        for (int c = 0; c < mi.channels; c++) acc = acc + (double)in[ib + (unsigned long long)c * st + i];
-        out[ob + i] = (T)(acc / mi.channels);
+    double mult[AUKIT_MAX_CHANNELS];
+    if constexpr (NORM)
+        for (int c = 0; c < mi.channels; c++) mult[c] = norm_mult(rowmax, peak, independent, s * (unsigned)mi.channels + c, mi.channels);
+    // 16 bytes per thread and channel (rows start on 64-byte boundaries and are padded to 16 elements, audio_prepare: whole vectors are
+    // readable and writable); the scalar version of round 1 ran at 4.0 TB/s
+    constexpr int V = 16 / (int)sizeof(T);
+    const unsigned long long nvec = (len + V - 1) / V;
+    for (unsigned long long v = (unsigned long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (unsigned long long)gridDim.x * 256) {
+        double acc[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) acc[k] = 0;
+        for (int c = 0; c < mi.channels; c++) {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(in + ib + (unsigned long long)c * st + v * V);
+            const T *xv = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                double x = (double)xv[k];
+                if constexpr (NORM) x = (double)(T)lua_clamp(x * mult[c], -1, 1);  // :3455
+                acc[k] = acc[k] + x;
+            }
+        }
+        T o[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) o[k] = (T)(acc[k] / mi.channels);
+        *reinterpret_cast<uint4 *>(out + ob + v * V) = *reinterpret_cast<const uint4 *>(o);
     }
 }
 
@@ -164,17 +197,25 @@ AUKIT_DEV Aff aff_then(const Aff &f, const Aff &g) { return Aff{g.A * f.A, __bui
 // loads are issued before the scan, and carries / wave totals are double-buffered so that one barrier per tile is enough
 // (round 1: scalar strided accesses, no prefetch, 4 barriers per tile — 1.9 TB/s; see profiles/).
 template <typename T, bool HIGHPASS>
-__global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a) {
+__global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a, unsigned long long *rowmax) {
     constexpr int PER = 64 / (int)sizeof(T), TILE = 256 * PER, NV = PER * (int)sizeof(T) / 16;
     __shared__ Aff wave_tot[2][4];
     __shared__ double carry_y[2], carry_x[2];
     const unsigned r = blockIdx.x;
     unsigned long long base, len;
     row_of(m, r, &base, &len);
-    if (len < 2) return;
     T *row = data + base;
+    if (len < 2) {  // nothing to filter (:3590, :3608 start at the second sample); the row's maximum is still owed
+        if (threadIdx.x == 0) {
+            double v = len ? fabs((double)row[0]) : 0.0;
+            if (!(v == v)) v = 0;
+            rowmax[r] = (unsigned long long)__double_as_longlong(v);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { carry_y[0] = 0; carry_x[0] = 0; }
+    double mx = 0;  // max |stored value| over this thread's samples: effects.normalize's peak search (:3440-3442), NaNs skipped like math.max
     uint4 raw[NV], nraw[NV];
     T xb = 0, nxb = 0;  // HIGHPASS: the ORIGINAL sample before this thread's first one, for the first lane of waves 1..3
     auto fetch = [&](unsigned long long t0, uint4 (&dst)[NV], T &before) {
@@ -239,6 +280,7 @@ __global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a) {
             else y = y + a * (x[k] - y);                 // d[i] = l + a * (d[i] - l)      :3594
             xp = x[k];
             out[k] = (T)y;
+            if (k < cnt) { const double v = fabs((double)out[k]); mx = mx < v ? v : mx; }
             if (k == cnt - 1 && i0 + k == tile_last) carry_y[ph ^ 1] = y;
         }
         const uint4 *ov = reinterpret_cast<const uint4 *>(out);
@@ -252,6 +294,14 @@ __global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a) {
 #pragma unroll
         for (int v = 0; v < NV; v++) raw[v] = nraw[v];
         xb = nxb;
+    }
+    __shared__ double redmx[4];
+    for (int o = 32; o; o >>= 1) { const double t = __shfl_xor(mx, o); mx = mx < t ? t : mx; }
+    if (lane == 0) redmx[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) mx = mx < redmx[w] ? redmx[w] : mx;
+        rowmax[r] = (unsigned long long)__double_as_longlong(mx);
     }
 }
 
@@ -360,31 +410,57 @@ static int run_map(aukit_ctx *ctx, aukit_audio *a, const MapArgs &A, const char 
     return ctx_end_kernel(ctx, name, 2 * audio_bytes(a));
 }
 
-static int fx_normalize(aukit_ctx *ctx, aukit_audio *a, double peak, int independent) {
-    if (a->n == 0) return AUKIT_OK;
-    size_t cnt = (size_t)a->n * (independent ? a->channels : 1);
-    int rc = ctx->tmp_buf.ensure(cnt * 8);
-    if (rc) return rc;
-    AUKIT_HIP_CHECK(hipMemsetAsync(ctx->tmp_buf.p, 0, cnt * 8, ctx->stream));
-    dim3 grid(xblocks(a, 32), a->n * a->channels);
-    AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_rowmax<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(a->dev), meta_of(a),
-                                           reinterpret_cast<unsigned long long *>(ctx->tmp_buf.p), independent));
-    AUKIT_HIP_CHECK(hipGetLastError());
+int audio_flush(aukit_ctx *ctx, const aukit_audio *ca) {
+    aukit_audio *a = const_cast<aukit_audio *>(ca);
+    if (!a || !a->pend_norm) return AUKIT_OK;
+    if (!ctx) ctx = a->pend_ctx;
+    if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred map and no context to apply it with");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    a->pend_norm = false;
     MapArgs A{};
-    A.a0 = peak;
-    A.rowmax = reinterpret_cast<const double *>(ctx->tmp_buf.p);
-    A.independent = independent;
+    A.a0 = a->pend_peak;
+    A.rowmax = reinterpret_cast<const double *>(a->d_rowmax);
+    A.independent = a->pend_independent;
+    a->rowmax_valid = false;  // the maxima described the samples before the map
     return run_map<MAP_SCALE_ROWMAX>(ctx, a, A, "k_map<normalize>");
+}
+
+// effects.normalize  :3430-3458.  Two things make config 5's tail (highpass → normalize → mono) three passes over the rows instead of five:
+// the peak search reuses the per-row maxima the pass before it left behind (k_onepole; had_rowmax), and the scaling itself is deferred
+// (aukit_audio::pend_norm) to whoever reads the samples next — Audio:mono applies it while it reads, anything else materialises it first.
+static int fx_normalize(aukit_ctx *ctx, aukit_audio *a, double peak, int independent, bool had_rowmax) {
+    if (a->n == 0) return AUKIT_OK;
+    int rc = audio_rowmax_ensure(a);
+    if (rc) return rc;
+    if (!had_rowmax || getenv("AUKIT_NO_TAIL_FUSION")) {
+        const size_t cnt = (size_t)a->n * a->channels;
+        AUKIT_HIP_CHECK(hipMemsetAsync(a->d_rowmax, 0, cnt * 8, ctx->stream));
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        dim3 grid(xblocks(a, 32), a->n * a->channels);
+        AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_rowmax<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(a->dev), meta_of(a),
+                                               reinterpret_cast<unsigned long long *>(a->d_rowmax)));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        if ((rc = ctx_end_kernel(ctx, "k_rowmax", audio_bytes(a)))) return rc;
+    }
+    a->pend_norm = true;
+    a->pend_peak = peak;
+    a->pend_independent = independent;
+    a->pend_ctx = ctx;
+    if (getenv("AUKIT_NO_TAIL_FUSION")) return audio_flush(ctx, a);  // A/B: five passes
+    return AUKIT_OK;
 }
 
 static int fx_onepole(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass) {
     if (a->n == 0) return AUKIT_OK;
-    int rc = ctx_begin_kernel(ctx);
+    int rc = audio_rowmax_ensure(a);
     if (rc) return rc;
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
     dim3 grid(a->n * a->channels);
-    if (highpass) AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef));
-    else AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, false>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef));
+    unsigned long long *rm = reinterpret_cast<unsigned long long *>(a->d_rowmax);
+    if (highpass) AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef, rm));
+    else AUKIT_DISPATCH_T(a, hipLaunchKernelGGL((k_onepole<T, false>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<T *>(a->dev), meta_of(a), coef, rm));
     AUKIT_HIP_CHECK(hipGetLastError());
+    a->rowmax_valid = true;  // max |x| of every row as stored: a following effects.normalize needs no pass of its own to find its peak
     return ctx_end_kernel(ctx, highpass ? "k_onepole<highpass>" : "k_onepole<lowpass>", 2 * audio_bytes(a));
 }
 
@@ -435,10 +511,14 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
     if (in->n == 0) return AUKIT_OK;
     if ((rc = ctx_begin_kernel(ctx))) return rc;
     dim3 grid(xblocks(in), in->n);
-    AUKIT_DISPATCH_T(in, hipLaunchKernelGGL((k_mono<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(in->dev), meta_of(in),
-                                            reinterpret_cast<T *>(o->dev), meta_of(o)));
+    if (in->pend_norm)  // the deferred effects.normalize of the input is applied as the rows are read (the input itself stays deferred)
+        AUKIT_DISPATCH_T(in, hipLaunchKernelGGL((k_mono<T, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(in->dev), meta_of(in), reinterpret_cast<T *>(o->dev),
+                                                meta_of(o), reinterpret_cast<const double *>(in->d_rowmax), in->pend_peak, in->pend_independent));
+    else
+        AUKIT_DISPATCH_T(in, hipLaunchKernelGGL((k_mono<T, false>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const T *>(in->dev), meta_of(in), reinterpret_cast<T *>(o->dev),
+                                                meta_of(o), nullptr, 1.0, 0));
     AUKIT_HIP_CHECK(hipGetLastError());
-    return ctx_end_kernel(ctx, "k_mono", audio_bytes(in) + audio_bytes(o));
+    return ctx_end_kernel(ctx, in->pend_norm ? "k_mono<normalize>" : "k_mono", audio_bytes(in) + audio_bytes(o));
 }
 
 int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, double amplifier, aukit_audio **out) {
@@ -447,6 +527,7 @@ int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, doubl
     const aukit_audio *self = audios[0];
     AUKIT_FLOAT_ONLY(self);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    for (int a = 0; a < count; a++) AUKIT_FLUSH(ctx, audios[a]);
     int cn = self->channels;
     std::vector<uint64_t> lens(self->len);
     for (int a = 1; a < count; a++) {
@@ -477,6 +558,7 @@ int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, doubl
 int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out) {
     if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_FLOAT_ONLY(in);
+    AUKIT_FLUSH(ctx, in);
     if (bit_depth != 8 && bit_depth != 16 && bit_depth != 24 && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
     if (data_type < 0 || data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
     if (data_type == AUKIT_FLOAT && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
@@ -502,6 +584,9 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
     if (!ctx || !a) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_FLOAT_ONLY(a);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    AUKIT_FLUSH(ctx, a);  // every effect reads the samples
+    const bool had_rowmax = a->rowmax_valid;
+    a->rowmax_valid = false;  // ... and rewrites them (k_onepole leaves new maxima behind)
     auto arg = [&](int i, double def) { return (args && i < nargs) ? args[i] : def; };
     auto need = [&](int k) { return nargs >= k && args; };
     MapArgs A{};
@@ -531,7 +616,7 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
         return run_map<MAP_FADE>(ctx, a, A, "k_map<fade>");
     }
     case AUKIT_FX_NORMALIZE:
-        return fx_normalize(ctx, a, arg(0, 1.0), arg(1, 0.0) != 0);
+        return fx_normalize(ctx, a, arg(0, 1.0), arg(1, 0.0) != 0, had_rowmax);
     case AUKIT_FX_CENTER: {
         if (a->rate != std::floor(a->rate) || a->rate < 1) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
         if (a->n == 0) return AUKIT_OK;

@@ -48,7 +48,11 @@ static const char *flac_err_msg(int e) {
 }
 enum { FLAG_OVERFLOW = 1, FLAG_INTERNAL = 2 };
 
-constexpr int WN = 16;    // 64-bit words of bit-stream window per lane in LDS (128 bytes)
+#ifndef AUKIT_FLAC_WN
+#define AUKIT_FLAC_WN 16
+#endif
+constexpr int WN = AUKIT_FLAC_WN;  // 64-bit words of bit-stream window per lane in LDS (16: 128 bytes); 8 or 16
+constexpr int LPW = WN / 2;        // lanes that refill one window with 16 bytes each
 constexpr int WSTR = 2 * WN + 1;  // row stride of the window array in 32-bit words (odd: lanes at the same offset hit distinct banks)
 constexpr unsigned LOW_BITS = (WN - 4) * 64;  // a lane stops for a refill once it is this far into its window
 constexpr int NC = 32;    // values a lane produces (extract) / restores (restore) per round
@@ -246,20 +250,51 @@ AUKIT_DEV unsigned hash_lookup(const CandHash &H, u64 key) {
 // One 16-byte vector (+ the first byte of the next one) per thread and step: 16 byte positions are tested for the sync code
 // (round 1 read two bytes per thread and launched 4 M workgroups: 6 ms for 3.6 GB; this is one pass at HBM speed).
 __global__ __launch_bounds__(256) void k_flac_find(const FlacGlobals G, u64 total, unsigned n, Cand *cands, u64 cap, u64 *count, CandHash H) {
+    // candidates are collected per workgroup in LDS and published with ONE atomic on the global counter: with an atomicAdd per
+    // candidate (220 000 of them on one word, ≈ 88 per µs: MI355X_MICROARCH.md, dequeue) the counter alone cost 2.5 of the kernel's 2.8 ms
+    constexpr unsigned LMAX = 1024;
+    __shared__ Cand s_list[LMAX];
+    __shared__ unsigned s_n;
+    __shared__ u64 s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const u64 base_off = G.base_bit >> 3;  // G.src = (bytes of G.w0) + base_off
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(G.w0);
     const u64 nvec = G.safe_words >> 1;
-    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < nvec; c += (u64)gridDim.x * 256) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(wb + 16 * c);
-        const unsigned nxt = (c + 1 < nvec) ? *reinterpret_cast<const unsigned *>(wb + 16 * c + 16) : 0u;
+    // four vectors per thread and trip, all loads issued before the first is looked at: with one load per trip the kernel had
+    // 16 KiB in flight per CU and ran at 1.3 TB/s (latency-bound, not VALU-bound: the SWAR test below changed nothing by itself)
+    constexpr int UN = 4;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 c0 = (u64)blockIdx.x * 256 + threadIdx.x; c0 < nvec; c0 += stride * UN) {
+      uint4 vv[UN];
+      unsigned nn[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+          const u64 c = c0 + stride * u;
+          vv[u] = make_uint4(0, 0, 0, 0);
+          nn[u] = 0;
+          if (c < nvec) {
+              vv[u] = *reinterpret_cast<const uint4 *>(wb + 16 * c);
+              if (c + 1 < nvec) nn[u] = *reinterpret_cast<const unsigned *>(wb + 16 * c + 16);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const u64 c = c0 + stride * u;
+        if (c >= nvec) break;
+        const uint4 v = vv[u];
+        const unsigned nxt = nn[u];
         const unsigned w[5] = {v.x, v.y, v.z, v.w, nxt};
+        // byte 0 = 0xFF, byte 1 = 0xF8 / 0xF9 (0x3FFE :518, reserved bit clear), four positions per dword at once: z has a zero byte
+        // exactly where both hold, and the carry-free zero-byte test marks those bytes (round 1 tested the 16 positions one by one
+        // with 64-bit shifts: 2.8 ms for 3.6 GB, VALU-bound)
         unsigned hits = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u64 x = (u64)w[q] | (u64)w[q + 1] << 32;
-#pragma unroll
-            for (int i = 0; i < 4; i++)  // byte 0 = 0xFF, byte 1 = 0xF8 / 0xF9 (0x3FFE :518, reserved bit clear)
-                hits |= ((((unsigned)(x >> (8 * i))) & 0xFEFFu) == 0xF8FFu) ? 1u << (4 * q + i) : 0u;
+            const unsigned t = w[q], u = __builtin_amdgcn_alignbit(w[q + 1], w[q], 8);  // u: every byte's successor
+            const unsigned z = ~t | ((u & 0xFEFEFEFEu) ^ 0xF8F8F8F8u);
+            const unsigned zb = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);  // 0x80 in every zero byte of z, nowhere else
+            if (zb) hits |= (((zb >> 7) & 1u) | ((zb >> 14) & 2u) | ((zb >> 21) & 4u) | ((zb >> 28) & 8u)) << (4 * q);
         }
         while (hits) {
             const int i = __builtin_ctz(hits);
@@ -275,9 +310,22 @@ __global__ __launch_bounds__(256) void k_flac_find(const FlacGlobals G, u64 tota
             if (si.status || p < G.off[s] + si.first_byte || p + 1 >= b1) continue;
             // Speed-only filter: a frame that fails it is still decoded — the chain asks for any position that is not in the table.
             if (!flac_header_plausible(G.src, p, b1, si.channels, si.depth)) continue;
-            const u64 k = atomicAdd(count, 1ull);
-            if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
+            const unsigned kl = atomicAdd(&s_n, 1u);
+            if (kl < LMAX) s_list[kl] = Cand{s, 0, p};
+            else {  // the workgroup's list is full: publish this one directly
+                const u64 k = atomicAdd(count, 1ull);
+                if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
+            }
         }
+      }
+    }
+    __syncthreads();
+    const unsigned nl = min(s_n, LMAX);
+    if (threadIdx.x == 0) s_base = nl ? atomicAdd(count, (u64)nl) : 0ull;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nl; i += 256) {
+        const u64 k = s_base + i;
+        if (k < cap) { cands[k] = s_list[i]; hash_insert(H, s_list[i].byte, (unsigned)k); }
     }
 }
 __global__ __launch_bounds__(64) void k_flac_hash_insert(const Cand *cands, unsigned first, unsigned count, CandHash H) {
@@ -352,10 +400,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
             const bool want = st != ST_DONE && (fresh || (b.wi - b.win_lo) >= (u64)(WN / 4));
             const u64 new_lo = b.wi & ~1ull;
             if (want) b.win_lo = new_lo;
-            const int sub8 = lane & 7, grp = lane >> 3;
+            const int sub8 = lane % LPW, grp = lane / LPW;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int s = i * 8 + grp;
+            for (int i = 0; i < LPW; i++) {
+                const int s = i * (64 / LPW) + grp;
                 const int w = __shfl((int)want, s);
                 const u64 ws = __shfl(new_lo, s);
                 if (w) {

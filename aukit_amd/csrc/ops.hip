@@ -71,6 +71,7 @@ int aukit_concat(aukit_ctx *ctx, const aukit_audio *const *in, uint32_t count, a
     int rc = check_group(in, count, *out);
     if (rc) return rc;
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    for (uint32_t g = 0; g < count; g++) AUKIT_FLUSH(ctx, in[g]);
     const uint32_t n = in[0]->n;
     int cn = 0;
     for (uint32_t a = 0; a < count; a++) cn = std::max(cn, in[a]->channels);  // :703
@@ -102,6 +103,7 @@ int aukit_sub(aukit_ctx *ctx, const aukit_audio *in, double start, double last, 
     const aukit_audio *grp[1] = {in};
     int rc = check_group(grp, 1, *out);
     if (rc) return rc;
+    AUKIT_FLUSH(ctx, in);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     const double start_f = std::floor(start), last_f = std::floor(last);
     std::vector<uint64_t> lens(in->n), first(in->n);
@@ -138,6 +140,7 @@ int aukit_combine(aukit_ctx *ctx, const aukit_audio *const *in, uint32_t count, 
     int rc = check_group(in, count, *out);
     if (rc) return rc;
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    for (uint32_t g = 0; g < count; g++) AUKIT_FLUSH(ctx, in[g]);
     const uint32_t n = in[0]->n;
     int cn = 0;
     for (uint32_t a = 0; a < count; a++) cn += in[a]->channels;
@@ -169,6 +172,7 @@ int aukit_split(aukit_ctx *ctx, const aukit_audio *in, const int32_t *channels, 
     const aukit_audio *grp[1] = {in};
     int rc = check_group(grp, 1, *out);
     if (rc) return rc;
+    AUKIT_FLUSH(ctx, in);
     if (count == 0) return fail(AUKIT_E_LUA, "bad argument #1 (cannot use empty table)");
     if (count > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
     for (uint32_t k = 0; k < count; k++)
@@ -190,6 +194,7 @@ int aukit_rep(aukit_ctx *ctx, const aukit_audio *in, double count, aukit_audio *
     const aukit_audio *grp[1] = {in};
     int rc = check_group(grp, 1, *out);
     if (rc) return rc;
+    AUKIT_FLUSH(ctx, in);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     const uint64_t reps = count >= 1 ? (uint64_t)std::floor(count) : 0;
     std::vector<uint64_t> lens(in->n);
@@ -211,6 +216,7 @@ int aukit_reverse(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
     const aukit_audio *grp[1] = {in};
     int rc = check_group(grp, 1, *out);
     if (rc) return rc;
+    AUKIT_FLUSH(ctx, in);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     aukit_audio *o = *out;
     if ((rc = audio_prepare(ctx, &o, in->n, in->channels, in->rate, in->dtype, in->len.data()))) return rc;
@@ -319,6 +325,7 @@ int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, do
 int aukit_pack_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode, aukit_batch **out) {
     if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");
     if (in->dtype != AUKIT_F64 && in->dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "pack needs a float audio");
+    AUKIT_FLUSH(ctx, in);
     if (bit_depth != 8 && bit_depth != 16 && bit_depth != 24 && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
     if (data_type < 0 || data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
     if (data_type == AUKIT_FLOAT && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");

@@ -21,9 +21,13 @@ AUKIT_DEV double pos_of(const ResampleParams &P, unsigned o) {
 // SKEW16: the table is stored with one pad slot per 16 entries (slot(i) = i + i/16) so that lanes which each own 16
 // consecutive entries write to distinct LDS banks (k_ima_stream).
 // TAB_T: double, or float for tables whose samples are exact in f32 (G.711: multiples of 1/64) — converted on read.
-template <int INTERP, bool SKEW16 = false, typename TAB_T = double>
+// CV: what a table entry means — the identity, or (k_ima_stream_f32) the int16 predictor p kept as an exact float, read as the
+// reference's sample p / (p < 0 and 128 or 127) (aukit.lua:2812)
+struct CvIdentity { static AUKIT_DEV double cv(double v) { return v; } };
+struct CvIma8 { static AUKIT_DEV double cv(double p) { return p < 0 ? p * (1.0 / 128) : div_rcp(p, 127.0, 1.0 / 127.0); } };
+template <int INTERP, bool SKEW16 = false, typename TAB_T = double, typename CV = CvIdentity>
 AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const TAB_T *tabp, int k_lo, unsigned o, bool *isint) {
-    struct { const TAB_T *p; AUKIT_DEV double operator[](int i) const { return (double)(SKEW16 ? p[i + (i >> 4)] : p[i]); } } tab{tabp};
+    struct { const TAB_T *p; AUKIT_DEV double operator[](int i) const { return CV::cv((double)(SKEW16 ? p[i + (i >> 4)] : p[i])); } } tab{tabp};
     double x = pos_of(P, o);
     double ffx = floor(x);
     int k = (int)ffx;

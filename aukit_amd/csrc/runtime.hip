@@ -72,12 +72,25 @@ int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes)
     return AUKIT_OK;
 }
 
+int audio_rowmax_ensure(aukit_audio *a) {
+    const size_t need = std::max<size_t>((size_t)a->n * a->channels, 1) * sizeof(uint64_t);
+    if (need <= a->rowmax_cap && a->d_rowmax) return AUKIT_OK;
+    if (a->d_rowmax) (void)hipFree(a->d_rowmax);
+    a->d_rowmax = nullptr; a->rowmax_cap = 0; a->rowmax_valid = false;
+    hipError_t e = hipMalloc((void **)&a->d_rowmax, need);
+    if (e != hipSuccess) return fail(AUKIT_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    a->rowmax_cap = need;
+    return AUKIT_OK;
+}
+
 int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, double rate, int dtype, const uint64_t *lens) {
     if (!out) return fail(AUKIT_E_ARG, "out is null");
     if (channels < 1) return fail(AUKIT_E_ARG, "channels out of range");
     aukit_audio *a = *out;
     if (!a) a = new aukit_audio();
     a->n = n; a->channels = channels; a->rate = rate; a->dtype = dtype;
+    a->rowmax_valid = false;  // new contents are on their way
+    a->pend_norm = false;
     a->len.assign(lens, lens + n);
     a->row_off.resize(n);
     a->row_stride.resize(n);
@@ -328,10 +341,16 @@ int aukit_audio_layout(const aukit_audio *a, uint64_t *lens, uint64_t *row_off, 
     if (row_stride) std::copy(a->row_stride.begin(), a->row_stride.end(), row_stride);
     return AUKIT_OK;
 }
-void *aukit_audio_device_ptr(const aukit_audio *a) { return a ? a->dev : nullptr; }
+void *aukit_audio_device_ptr(const aukit_audio *a) {
+    if (!a) return nullptr;
+    if (a->pend_norm && audio_flush(a->pend_ctx, a)) return nullptr;  // the caller reads the samples: a deferred map is applied first
+    const_cast<aukit_audio *>(a)->rowmax_valid = false;              // ... and may write them
+    return a->dev;
+}
 
 int aukit_audio_download_raw(aukit_ctx *ctx, const aukit_audio *a, void *dst) {
     if (!ctx || !a || !dst) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_FLUSH(ctx, a);
     if (a->total) AUKIT_HIP_CHECK(hipMemcpyAsync(dst, a->dev, (size_t)a->total * dtype_size(a->dtype), hipMemcpyDeviceToHost, ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return AUKIT_OK;
@@ -399,6 +418,7 @@ int aukit_audio_upload(aukit_ctx *ctx, aukit_audio **out, const double *samples,
 
 int aukit_audio_clone(aukit_ctx *ctx, const aukit_audio *a, aukit_audio **out) {
     if (!ctx || !a || !out) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_FLUSH(ctx, a);
     aukit_audio *b = *out;
     int rc = audio_prepare(ctx, &b, a->n, a->channels, a->rate, a->dtype, a->len.data());
     if (rc) return rc;
@@ -411,6 +431,7 @@ void aukit_audio_free(aukit_audio *a) {
     if (!a) return;
     if (a->dev) (void)hipFree(a->dev);
     if (a->d_meta) (void)hipFree(a->d_meta);
+    if (a->d_rowmax) (void)hipFree(a->d_rowmax);
     delete a;
 }
 

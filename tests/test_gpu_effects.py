@@ -169,3 +169,50 @@ def test_auplay_pipeline(ctx, oracle):
     got = mo.download()[0][0]
     ref = oracle.fx_lowpass(oracle.fx_normalize(oracle.mono(oracle.resample(oracle.pcm(st, 16, oracle.SIGNED, 2, 44100), 48000, oracle.LINEAR)), 0.8), 22050.0)
     assert np.max(np.abs(got - ref.data[0])) <= 1e-12
+
+
+@pytest.mark.parametrize("dt", ["F64", "F32"])
+@pytest.mark.parametrize("independent", [False, True])
+@pytest.mark.parametrize("first", ["highpass", "lowpass", "none"])
+def test_deferred_normalize_and_reused_row_maxima(ctx, oracle, monkeypatch, first, independent, dt):
+    """config 5's tail (aukit.lua:3604-3618, :3439-3456, :682-687).  effects.normalize takes its peak from the per-row maxima the
+    filter pass left behind and defers its scaling to the next reader: Audio:mono applies it while reading, anything else (a download,
+    another effect, a second mono) materialises it.  Every observable result is bit-identical to the five-pass sequence
+    (AUKIT_NO_TAIL_FUSION=1) and within tolerance of the oracle."""
+    B, N = _B(), _N()
+    dtype = getattr(N, dt)
+    a = _audios(rate=22050, lens=(30000, 1, 2, 4097, 700), ch=2)
+    src = [[x.astype(np.float32).astype(np.float64) for x in s] for s in a] if dt == "F32" else a
+
+    def run():
+        ab = B.AudioBatch.upload(ctx, src, 22050, dtype=dtype)
+        if first != "none":
+            B.effect(ctx, ab, first, 300.0)
+        B.effect(ctx, ab, "normalize", 0.8, 1.0 if independent else 0.0)
+        m1 = B.mono(ctx, ab).download()          # fused: the map is applied while mono reads
+        st = ab.download()                       # materialises the deferred map
+        m2 = B.mono(ctx, ab).download()          # plain mono of the materialised rows
+        B.effect(ctx, ab, "normalize", 0.5)      # a second normalize: peak search from scratch, deferred again ...
+        B.effect(ctx, ab, "invert")              # ... and flushed by the next effect
+        return m1, st, m2, ab.download()
+
+    got = run()
+    monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
+    plain = run()
+    monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
+    for g, p in zip(got, plain):
+        for s in range(len(a)):
+            for c in range(len(g[s])):
+                assert np.array_equal(g[s][c], p[s][c]), (s, c)
+    tol = 1e-12 if dt == "F64" else 1e-6
+    for s in range(len(a)):
+        ref = oracle.Audio([x.copy() for x in src[s]], 22050)
+        if first == "highpass":
+            ref = oracle.fx_highpass(ref, 300.0)
+        elif first == "lowpass":
+            ref = oracle.fx_lowpass(ref, 300.0)
+        ref = oracle.fx_normalize(ref, 0.8, independent)
+        assert np.array_equal(got[0][s][0], got[2][s][0])  # fused mono == mono of the materialised rows
+        assert rms(got[0][s][0], oracle.mono(ref).data[0]) <= tol
+        for c in range(2):
+            assert rms(got[1][s][c], ref.data[c]) <= tol

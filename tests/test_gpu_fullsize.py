@@ -2,12 +2,13 @@
 
   * config T (4096 × s16le 44.1 kHz 10 s → cubic → 48 kHz f32): every stream is one of 8 distinct signals, so the 4096
     outputs must fall into 8 classes of bit-identical rows (catches any tile / segment / stream-offset mistake at scale);
-    one row per class is compared with the oracle (≤ 1e-6 RMS) and with the fp64 reference-order kernel.
+    EVERY class is compared with the oracle (≤ 1e-6 RMS), and so are the fp64-arithmetic kernel of the graded configuration
+    (k_wave_f64) and the reference-order kernel (within one f32 ulp of the oracle's double).
   * config 2 (4096 × µ-law 8 kHz → cubic): same construction.
-  * config 3 (4096 × 220 IMA blocks → stream.adpcm cubic): same, bit-exact vs oracle.
+  * config 3 (4096 × 220 IMA blocks → stream.adpcm cubic): same, every class bit-exact vs oracle.
   * config 4 (16384 × 120 000 B DFPWM stereo → mono → DFPWM): encode→decode round trip property + class identity + oracle bytes.
   * config 5 (2048 × FLAC 44.1 kHz stereo 10 s → cubic → highpass → normalize → mono): losslessness of the decode (every decoded
-    row equals the PCM that was encoded, exactly), class identity of the pipeline output, one class against the oracle pipeline.
+    row equals the PCM that was encoded, exactly), class identity of the pipeline output, every class against the oracle pipeline.
 Sizes are the BASELINE ones unless AUKIT_FULLSIZE_SCALE (default 1.0) shrinks the stream count.
 """
 import os
@@ -73,19 +74,24 @@ def test_config_T_full_batch(ctx, oracle):
     out = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
     assert ctx.last_kernel()[0].startswith("k_fast_wave")
     rows = _row_classes(out, n, 480000, K)
-    for c in (0, K - 1):
-        ref = oracle.resample(oracle.pcm(base[c], 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
-        assert rms(rows[c].astype(np.float64), ref.data[0]) <= 1e-6
-    # the fp64 reference-order kernel on the same batch: identical classes, ≤ 1e-6 RMS from the fast path, f32-rounded oracle values
-    ctx.set_option(N.OPT_EXACT_MATH, 1)
-    try:
-        out2 = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
-        rows2 = _row_classes(out2, n, 480000, K)
-    finally:
-        ctx.set_option(N.OPT_EXACT_MATH, 0)
-    ref = oracle.resample(oracle.pcm(base[0], 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC)
-    assert np.max(np.abs(rows2[0].astype(np.float64) - ref.data[0])) <= 1.2e-7  # f32 rounding of the exact value (± a pow3 ulp)
-    assert rms(rows[0].astype(np.float64), rows2[0].astype(np.float64)) <= 1e-6
+    refs = [oracle.resample(oracle.pcm(base[c], 16, oracle.SIGNED, 1, 44100), 48000, oracle.CUBIC).data[0] for c in range(K)]
+    for c in range(K):  # every class against the oracle
+        assert rms(rows[c].astype(np.float64), refs[c]) <= 1e-6
+    # the graded configuration (fp64 arithmetic, f32 store: k_wave_f64) and the reference-order kernel on the same batch: identical
+    # classes, every class within one f32 ulp of the oracle's double, ≤ 1e-6 RMS from the f32-tap path
+    for level, prefix in ((1, "k_wave_f64<"), (2, "k_exact_wave<")):
+        ctx.set_option(N.OPT_EXACT_MATH, level)
+        try:
+            out2 = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+            assert ctx.last_kernel()[0].startswith(prefix), ctx.last_kernel()
+            rows2 = _row_classes(out2, n, 480000, K)
+        finally:
+            ctx.set_option(N.OPT_EXACT_MATH, 0)
+        for c in range(K):
+            assert np.max(np.abs(rows2[c].astype(np.float64) - refs[c])) <= 1.2e-7  # f32 rounding of the fp64 value
+            assert rms(rows[c].astype(np.float64), rows2[c].astype(np.float64)) <= 1e-6
+            if level == 1:  # neighbouring floats where the exact position and the reference's rounded x disagree (wave_f64.hip): a small fraction
+                assert np.count_nonzero(rows2[c] != refs[c].astype(np.float32)) <= 480000 // 200
 
 
 def test_config_2_full_batch(ctx, oracle):
@@ -95,12 +101,14 @@ def test_config_2_full_batch(ctx, oracle):
     bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
     desc = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
     rows = _row_classes(B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32), n, 480000, K)
-    ref = oracle.resample(oracle.g711(base[3], True, 1, 8000), 48000, oracle.CUBIC)
-    assert rms(rows[3].astype(np.float64), ref.data[0]) <= 1e-6
+    for c in range(K):
+        ref = oracle.resample(oracle.g711(base[c], True, 1, 8000), 48000, oracle.CUBIC)
+        assert rms(rows[c].astype(np.float64), ref.data[0]) <= 1e-6
     out, ck = B.stream_decode(ctx, bt, desc, "cubic", dtype=N.I8)  # (b) stream.g711 ×10 calls, bit-exact incl. floor
     assert np.all(ck.nchunks == 10) and np.all(ck.lens == 48000)
     rows = _row_classes(out, n, 480000, K)
-    assert np.array_equal(rows[5], oracle.stream_g711(base[5], True, 1, 8000, False, oracle.CUBIC).data[0])
+    for c in range(K):
+        assert np.array_equal(rows[c], oracle.stream_g711(base[c], True, 1, 8000, False, oracle.CUBIC).data[0])
 
 
 def test_config_3_full_batch(ctx, oracle):
@@ -111,7 +119,7 @@ def test_config_3_full_batch(ctx, oracle):
     out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", dtype=N.I8)
     assert np.all(ck.nchunks == 10) and np.all(ck.lens.sum(axis=1) == 486403)  # 219×2211 + 2194
     rows = _row_classes(out, n, 486403, K)
-    for c in (0, 6):
+    for c in range(K):
         assert np.array_equal(rows[c], oracle.stream_adpcm(base[c], 512, 1, 22050, False, oracle.CUBIC).data[0])
 
 
@@ -128,7 +136,7 @@ def test_config_4_full_batch(ctx, oracle):
     assert all(len(g) == 60010 for g in got)
     for c in range(K):
         assert all(g == got[c] for g in got[c::K])
-    for c in (0, K - 1):
+    for c in range(K):
         assert got[c] == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(base[c], 2, 48000)), True)
     # encode → decode round trip (lossy codec): the re-encoded mono stream still tracks the mono mix of the decoded input
     a = oracle.mono(oracle.dfpwm(base[0], 2, 48000)).data[0]
@@ -160,8 +168,9 @@ def test_config_5_full_batch(ctx, oracle):
     B.effect(ctx, a, "highpass", 20.0)
     B.effect(ctx, a, "normalize", 0.8)
     rows = _row_classes(B.mono(ctx, a), n, 480000, k5)
-    ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(base[1]), 48000, oracle.CUBIC), 20.0), 0.8))
-    assert rms(rows[1].astype(np.float64), ref.data[0]) <= 1e-6
+    for c in range(k5):
+        ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(base[c]), 48000, oracle.CUBIC), 20.0), 0.8))
+        assert rms(rows[c].astype(np.float64), ref.data[0]) <= 1e-6
 
 
 def test_one_long_stream(ctx, oracle):
