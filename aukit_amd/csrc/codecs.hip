@@ -183,7 +183,9 @@ __global__ __launch_bounds__(64) void k_dfpwm_transcode_stereo(const unsigned ch
 }
 
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
-                           const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0);
+                           const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0, const DfSliceHook *hook = nullptr);
+int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const unsigned long long *d_moff, const unsigned long long *d_mcount, unsigned char *out,
+                           const unsigned long long *d_ooff, const uint64_t *h_ooff, int slices, bool *taken);
 bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff,
                            int *rc);  // exact parallel encoder for batches of a few streams (dfpwm_par.hip)
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const unsigned long long *d_in_off, const unsigned long long *d_count, uint32_t n, unsigned char *out,
@@ -1110,6 +1112,21 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
         if ((rc = ctx->tmp_buf.ensure((size_t)mtot + 64))) return rc;
         if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;
         const unsigned long long *t = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+        // large batches: decoder and encoder pipelined over time slices on two HIP streams (dfpwm_par.hip)
+        const uint64_t lanes_full = (uint64_t)ctx->num_cus * 512;  // chunk lanes that fill the chip in mix mode
+        // every slice must still give the decoder a chip-filling launch (lanes_full / n chunks per stream) of chunks long enough to
+        // keep the 256-byte warm-up at 1/15 of their work
+        uint64_t max_bytes = 0;
+        for (uint32_t s = 0; s < in->n; s++) max_bytes = std::max<uint64_t>(max_bytes, in->off[s + 1] - in->off[s]);
+        const uint64_t want = std::max<uint64_t>(1, lanes_full / in->n);
+        int slices = in->n >= 2048 ? (int)std::min<uint64_t>(8, max_bytes / 1920 / want) : 1;  // measured on config 4: 1 / 4 / 8 slices = 27.0 / 25.7 / 24.4 ms per step
+        if (const char *e = getenv("AUKIT_DFPWM_SLICES")) slices = atoi(e);
+        if (slices > 1) {
+            bool taken = false;
+            rc = dfpwm_transcode_sliced(ctx, in, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, t + in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), off.data(), slices, &taken);
+            if (rc) return rc;
+            if (taken) return ctx_end_kernel(ctx, "k_df_chunks|k_dfpwm_encode_i8_slice", in->total() + off[in->n]);
+        }
         int prc = AUKIT_OK;
         if (dfpwm_decode_parallel(ctx, in, 1, 2, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, nullptr, &prc)) {
             if (prc) return prc;

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64) void k_mdfpwm_decode(const unsigned char *src, 
 
 bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const std::vector<uint64_t> &h_off, const std::vector<uint64_t> &h_fed, uint64_t run,
                                 uint64_t stride, int mode, int C, signed char *out, const unsigned long long *d_out_off, const unsigned long long *d_out_stride,
-                                uint64_t lead, int *rc);
+                                uint64_t lead, int *rc, const DfSliceHook *hook = nullptr);
 struct MdHeader { uint64_t payload, length; };
 static int mdfpwm_header(const uint8_t *h, uint64_t nb, MdHeader *out, const char *badmsg) {
     if (nb < 7 || memcmp(h, "MDFPWM\3", 7) != 0) return fail(AUKIT_E_ARG, "%s", badmsg);
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64) void k_dfpwm_stream_rows(const unsigned char *s
 }
 
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
-                           const unsigned long long *d_out_stride, int *rc, uint64_t adv, uint64_t lead);
+                           const unsigned long long *d_out_stride, int *rc, uint64_t adv, uint64_t lead, const DfSliceHook *hook = nullptr);
 __global__ __launch_bounds__(256) void k_row_heads_zero(signed char *out, const unsigned long long *row_off, unsigned n) {
     const unsigned s = blockIdx.x * 256 + threadIdx.x;
     if (s < n) out[row_off[s]] = 0;

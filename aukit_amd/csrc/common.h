@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -53,6 +54,10 @@ struct aukit_ctx {
     int num_cus = 256;
     // scratch tables (segment/tile/stream descriptors); plan_key caches the last uploaded plan
     aukit::DevBuf seg_buf, tile_buf, misc_buf, tmp_buf, tmp_buf2, tmp_buf3;
+    aukit::DevBuf enc_state_buf;  // DFPWM encoder states between the time slices of a transcode (dfpwm_par.hip)
+    hipStream_t aux_stream = nullptr, dec_stream = nullptr;  // aux_stream: the sliced transcode's encoder runs here (dec_stream: unused, kept for the CU-mask experiment)
+    hipEvent_t aux_ev[10] = {};
+    int aux_enc_cus = -1;
     aukit::DevBuf wt_buf;       // phase-weight table of wave_f64.hip, cached per (b, interpolation)
     unsigned wt_b = 0, wt_doubles = 0;
     int wt_interp = -1;
@@ -115,6 +120,12 @@ static inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m
 
 // (re)shape *out for n streams of the given lengths; reuses its buffers when they are large enough.
 int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, double rate, int dtype, const uint64_t *lens);
+// time slices of the chunk-parallel DFPWM decoder (dfpwm_par.hip): after_slice(k, slices, fed_lo, fed_hi) is called on the host once the
+// kernels of slice k are enqueued on ctx->stream — fed bytes [fed_lo, fed_hi) of every stream are then final in stream order
+struct DfSliceHook {
+    int slices = 1;
+    std::function<int(unsigned, unsigned, unsigned long long, unsigned long long)> after_slice;
+};
 // applies a deferred map (aukit_audio::pend_norm) in place; every entry point that reads an audio's samples calls it first
 int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
 #define AUKIT_FLUSH(ctx, a)                                                   \

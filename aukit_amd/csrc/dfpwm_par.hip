@@ -91,6 +91,7 @@ struct DfParParams {
     signed char *out;
     const u64 *out_off, *out_stride;  // rows: element offset of channel 0 / channel stride per stream; mix: element offset per stream
     unsigned *stats;
+    unsigned c_lo, c_hi;  // k_df_chunks / k_df_verify: the chunk indices [c_lo, c_hi) of every stream (a time slice of the batch)
 };
 
 // The eight clamp-add steps of one byte, given the bit before it, compose to one clamp-add map: 512 table entries per workgroup.
@@ -235,8 +236,9 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
         __syncthreads();
     }
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
-    if (c >= P.nchunk) return;
+    const unsigned cr = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)cr * P.n);  // a wave = one chunk index of 64 streams
+    const unsigned c = cr + P.c_lo;
+    if (c >= P.c_hi) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
     const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
@@ -262,9 +264,11 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
     const u64 fed = P.fed[s], CH = (u64)P.bpc * P.W;
     const DfOut O = dfp_out(P, s, nullptr);
     int truth[6];
-    for (int i = 0; i < 6; i++) truth[i] = P.st_end[(size_t)s * P.nchunk * 6 + i];
-    unsigned redone = 0, chunks = 1;
-    for (unsigned c = 1; c < P.nchunk; c++) {
+    const unsigned c_first = P.c_lo > 1 ? P.c_lo : 1;  // the chunk before it was verified by the slice before this one (chunk 0 starts from the reset state: always true)
+    for (int i = 0; i < 6; i++) truth[i] = P.st_end[((size_t)s * P.nchunk + c_first - 1) * 6 + i];
+    if (truth[1] < 0) return;  // the stream ended before this slice
+    unsigned redone = 0, chunks = P.c_lo == 0 ? 1 : 0;
+    for (unsigned c = c_first; c < P.c_hi; c++) {
         const int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6;
         int *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
         if (ss[1] < 0) break;
@@ -341,19 +345,106 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
     }
 }
 
+// The same encoder over the samples [lo, hi) of every stream (lo, hi multiples of 64; `last`: to the end of the stream, tail and padding
+// included), its state carried in `state` ([n] × {charge + 128, strength, previous bit}): the slices of a batch are encoded one after
+// the other on their own HIP stream while the decoder works on the next slice (dfpwm_transcode_sliced below).
+// Output: `out` is a STAGING buffer with one row of `ostride` bytes (a multiple of 16) per stream — eight samples make a byte and a round of 64
+// samples one aligned 8-byte store per lane.  (Storing byte by byte straight into the packed result — rows 60 010 bytes apart, 64 lanes,
+// 64 cache lines per instruction — is what made the encoder lose a factor of 2-4 as soon as it shared a CU's memory path with anything:
+// traced in profiles/.)  k_dfpwm_compact moves the rows to their packed places afterwards.
+__global__ __launch_bounds__(64) void k_dfpwm_encode_i8_slice(const signed char *in, const u64 *in_off, const u64 *count, unsigned n, unsigned char *out, u64 ostride, int *state,
+                                                              u64 lo, u64 hi, int first, int last) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const u64 L = count[s];
+    hi = last ? L : (hi < L ? hi : L & ~63ull);  // a stream that ends inside a middle slice: whole rounds only, the rest belongs to the last slice
+    const signed char *p = in + in_off[s];  // 16-byte aligned (host)
+    unsigned char *o = out + (u64)s * ostride;
+    DfEnc e{};
+    u64 i = 0;  // the stream's own progress (a short stream is not where the slice starts)
+    int *st = state + 6 * (size_t)s;
+    if (!first) { e.cu = st[0]; e.strength = st[1]; e.pb = st[2]; i = (u64)(unsigned)st[4] | (u64)(unsigned)st[5] << 32; }
+    (void)lo;
+    u64 w = i >> 3;
+    uint4 cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = i + 16u * k < L ? *reinterpret_cast<const uint4 *>(p + i + 16 * k) : make_uint4(0, 0, 0, 0);
+    for (; i + 64 <= hi; i += 64) {
+        uint4 nxt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = i + 64 + 16 * k < L ? *reinterpret_cast<const uint4 *>(p + i + 64 + 16 * k) : make_uint4(0, 0, 0, 0);
+        unsigned ob[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned words[4] = {cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u, cur[k].z ^ 0x80808080u, cur[k].w ^ 0x80808080u};  // u = v + 128
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) byte |= df_encode_u(e, (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF) & (1u << b);
+                ob[k >> 1] |= (byte & 255u) << (8 * (2 * (k & 1) + h));
+            }
+        }
+        *reinterpret_cast<uint2 *>(o + w) = make_uint2(ob[0], ob[1]);  // w is a multiple of 8 here
+        w += 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+    if (last) {
+        for (int k = 0; k < 4 && i < L; k++, i += 16) {  // the last < 64 samples
+            const unsigned words[4] = {cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u, cur[k].z ^ 0x80808080u, cur[k].w ^ 0x80808080u};
+            for (int h = 0; h < 2 && i + 8 * h < L; h++) {
+                unsigned byte = 0;
+                for (int b = 0; b < 8; b++) {
+                    const u64 idx = i + 8 * h + b;
+                    const unsigned u = idx < L ? (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF : 128u;  // the last byte is padded with samples of value 0
+                    byte |= df_encode_u(e, u) & (1u << b);
+                }
+                o[w++] = (unsigned char)byte;
+            }
+        }
+    }
+    st[0] = e.cu; st[1] = e.strength; st[2] = e.pb; st[4] = (int)(unsigned)i; st[5] = (int)(unsigned)(i >> 32);
+}
+
+// staging rows (stride `sstride`) → the packed batch: stream s's `ooff[s + 1] - ooff[s]` bytes go to out + ooff[s]
+__global__ __launch_bounds__(256) void k_dfpwm_compact(const unsigned char *stage, u64 sstride, unsigned char *out, const u64 *ooff, unsigned n) {
+    const unsigned s = blockIdx.y;
+    const u64 len = ooff[s + 1] - ooff[s];
+    const unsigned char *src = stage + (u64)s * sstride;
+    unsigned char *dst = out + ooff[s];
+    // destination dwords: a head of up to 3 bytes, aligned dwords assembled from the (4-byte aligned) staging row, a tail
+    const u64 head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j * 4 < len + 4; j += (u64)gridDim.x * 256) {
+        if (j == 0) { for (u64 k = 0; k < head && k < len; k++) dst[k] = src[k]; continue; }
+        const u64 d0 = head + 4 * (j - 1);  // byte index in the row
+        if (d0 >= len) continue;
+        if (d0 + 4 <= len) {
+            const u64 a = d0 & ~3ull;
+            const unsigned sh = (unsigned)(d0 & 3) * 8;
+            const unsigned lo = *reinterpret_cast<const unsigned *>(src + a), hi = *reinterpret_cast<const unsigned *>(src + a + 4);
+            *reinterpret_cast<unsigned *>(dst + d0) = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+        } else for (u64 k = d0; k < len; k++) dst[k] = src[k];
+    }
+}
+
 // host: plan + launch for `n` (pseudo-)streams given by their first source byte and fed byte count.  `out`: rows (mode 0, C
 // channels, per-stream row offsets / strides as device arrays) or mono mix (mode 1, per-stream element offsets).  Returns false
 // (nothing launched) when the batch is better served one lane per stream.
 bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const std::vector<uint64_t> &h_off, const std::vector<uint64_t> &h_fed, uint64_t run,
-                                uint64_t stride, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, uint64_t lead, int *rc) {
+                                uint64_t stride, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, uint64_t lead, int *rc,
+                                const DfSliceHook *hook) {
     const uint32_t n = (uint32_t)h_off.size();
     uint64_t fed_max = 0;
     for (uint64_t f : h_fed) fed_max = std::max(fed_max, f);
     uint64_t W = n >= 4096 ? 1024 : 512;  // small batches: more, shorter chunks
+    const bool sliced = hook && hook->slices > 1 && !getenv("AUKIT_DFPWM_CHUNKS") && !getenv("AUKIT_DFPWM_BLOCK");
+    if (sliced) W = 256;  // time slices need `slices` x more chunks per stream: shorter warm-up blocks keep the warm-up at 1/15 of a chunk
     if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(2, strtoull(e, nullptr, 10) & ~1ull);
     const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
     // chunks per stream for one full round of lanes: 1024 per CU, 512 in mix mode (two workgroups per CU next to their 64 KiB tables)
     unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * (mode == 1 ? 512 : 1024) / std::max<uint32_t>(n, 1));
+    if (sliced) want *= (unsigned)hook->slices;
     if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 6u);  // warm-up (1 block) <= 1/6 of a chunk
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
@@ -376,9 +467,15 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     const unsigned cb = 256;  // (1024 lanes sharing one table, 8 waves per SIMD instead of 2: 7 % slower — the kernel is issue-bound)
-    hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * nchunk + cb - 1) / cb)), dim3(cb), mode == 1 ? 65536 : 0, ctx->stream, P);
-    hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
-    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
+    const unsigned nsl = sliced ? std::min<unsigned>((unsigned)hook->slices, nchunk) : 1u;
+    for (unsigned k = 0; k < nsl; k++) {  // time slices: chunk indices [c_lo, c_hi) of every stream, in order
+        P.c_lo = (unsigned)((u64)nchunk * k / nsl);
+        P.c_hi = (unsigned)((u64)nchunk * (k + 1) / nsl);
+        hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * (P.c_hi - P.c_lo) + cb - 1) / cb)), dim3(cb), mode == 1 ? 65536 : 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
+        if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
+        if (sliced && (*rc = hook->after_slice(k, nsl, (u64)P.c_lo * bpc * W, (u64)P.c_hi * bpc * W))) return true;  // fed bytes [lo, hi) of every stream are final
+    }
     if (getenv("AUKIT_DFPWM_STATS")) {
         unsigned h[2] = {0, 0};
         (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -391,13 +488,88 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
 
 // aukit.dfpwm / stream.dfpwm on a batch: overlapping slices advanced by `adv`
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const u64 *d_out_off, const u64 *d_out_stride, int *rc,
-                           uint64_t adv, uint64_t lead) {
+                           uint64_t adv, uint64_t lead, const DfSliceHook *hook) {
     std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + in->n), h_fed(in->n);
     for (uint32_t s = 0; s < in->n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
         h_fed[s] = nb ? nb + (nb + adv - 1) / adv - 1 : 0;  // Σ min(adv + 1, nb - adv k)
     }
-    return dfpwm_decode_parallel_feed(ctx, in->data(), h_off, h_fed, adv + 1, adv, mode, C, out, d_out_off, d_out_stride, lead, rc);
+    return dfpwm_decode_parallel_feed(ctx, in->data(), h_off, h_fed, adv + 1, adv, mode, C, out, d_out_off, d_out_stride, lead, rc, hook);
+}
+
+// aukit.dfpwm(d, 2, rate):mono():dfpwm() on a large batch (config 4).  The encoder is one serial chain per stream (its bits depend on its
+// state): ten seconds take it 11.7 ms whatever the batch, on the 256 SIMDs its 256 waves land on.  Run after the decoder (12.5 ms on the
+// whole chip) that was 27 ms per step.  Here the batch is cut into time slices: the decoder works through chunk indices [c_lo, c_hi) of
+// every stream, and as soon as a slice is verified the encoder follows on a second HIP stream (high priority: it is the critical
+// path), carrying its per-stream state from slice to slice — at the end only the last slice's encoding is left.  Bit-identical bytes.
+int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const u64 *d_moff, const u64 *d_mcount, unsigned char *out, const u64 *d_ooff,
+                           const uint64_t *h_ooff, int slices, bool *taken) {
+    *taken = false;
+    int enc_cus = 0;  // CUs reserved for the encoder; 0 (default): decoder and encoder share every CU — see below, reserving lost
+    if (const char *e = getenv("AUKIT_DFPWM_ENC_CUS")) enc_cus = std::max(0, std::min(atoi(e), ctx->num_cus - 8));
+    if (!ctx->aux_stream || ctx->aux_enc_cus != enc_cus) {
+        // Sharing every CU (the default): an encoder wave beside two decoder waves on one SIMD slows both by ~40 % (traced, profiles/),
+        // and as one encoder wave lands on every CU every decoder workgroup has a slowed wave; with s_setprio 3 in the encoder it keeps
+        // its speed and the decoder runs 1.8x longer (27 ms per step: no gain).  Disjoint CU masks (AUKIT_DFPWM_ENC_CUS = 32 / 48 / 64;
+        // the masks do what they say: tools/micro/cumask_probe.hip) lose outright — 41 / 39 / 34 ms per step: 256 encoder waves packed
+        // on few CUs run several times slower than one per CU, whatever their store width.
+        if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); ctx->aux_stream = nullptr; }
+        if (ctx->dec_stream) { (void)hipStreamSynchronize(ctx->dec_stream); (void)hipStreamDestroy(ctx->dec_stream); ctx->dec_stream = nullptr; }
+        if (enc_cus > 0) {
+            const int words = (ctx->num_cus + 31) / 32;
+            std::vector<uint32_t> m_enc(words, 0), m_dec(words, 0);
+            for (int cu = 0; cu < ctx->num_cus; cu++) (cu < enc_cus ? m_enc : m_dec)[cu >> 5] |= 1u << (cu & 31);
+            AUKIT_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)words, m_enc.data()));
+            AUKIT_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->dec_stream, (uint32_t)words, m_dec.data()));
+        } else {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            AUKIT_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
+        }
+        for (int i = 0; i < 10; i++) if (!ctx->aux_ev[i]) AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
+        ctx->aux_enc_cus = enc_cus;
+    }
+    hipStream_t const user_stream = ctx->stream;
+    struct Restore { aukit_ctx *c; hipStream_t s; ~Restore() { c->stream = s; } } restore{ctx, user_stream};
+    if (ctx->dec_stream) {  // the decoder's launches go to the masked stream: ctx->stream is swapped for the duration of this call
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->aux_ev[9], user_stream));
+        AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->dec_stream, ctx->aux_ev[9], 0));
+        ctx->stream = ctx->dec_stream;
+    }
+    const uint32_t n = in->n;
+    uint64_t max_out = 0;
+    for (uint32_t s = 0; s < n; s++) max_out = std::max<uint64_t>(max_out, h_ooff[s + 1] - h_ooff[s]);
+    const u64 sstride = round_up(max_out + 16, 16);  // the staging row holds whole 8-byte rounds (+ slack for the compaction's dword reads)
+    int rc = ctx->enc_state_buf.ensure((size_t)n * 24 + 64 + (size_t)n * sstride);
+    if (rc) return rc;
+    int *state = reinterpret_cast<int *>(ctx->enc_state_buf.p);
+    unsigned char *stage = reinterpret_cast<unsigned char *>(ctx->enc_state_buf.p) + round_up((size_t)n * 24 + 16, 64);
+    DfSliceHook hook;
+    hook.slices = std::min(slices, 8);
+    // (the table of mono offsets `d_moff` was uploaded on the caller's stream: ordered by the event above)
+    hook.after_slice = [&](unsigned k, unsigned nsl, u64 fed_lo, u64 fed_hi) -> int {
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->aux_ev[k], ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[k], 0));
+        hipLaunchKernelGGL(k_dfpwm_encode_i8_slice, dim3((n + 63) / 64), dim3(64), 0, ctx->aux_stream, mono, d_moff, d_mcount, n, stage, sstride, state, 4 * fed_lo, 4 * fed_hi,
+                           k == 0 ? 1 : 0, k + 1 == nsl ? 1 : 0);  // stereo: four mono samples per fed byte
+        AUKIT_HIP_CHECK(hipGetLastError());
+        if (k + 1 == nsl) {
+            hipLaunchKernelGGL(k_dfpwm_compact, dim3((unsigned)std::min<u64>((max_out / 4 + 256) / 256, 4), n), dim3(256), 0, ctx->aux_stream, stage, sstride, out, d_ooff, n);
+            AUKIT_HIP_CHECK(hipGetLastError());
+            AUKIT_HIP_CHECK(hipEventRecord(ctx->aux_ev[8], ctx->aux_stream));
+            AUKIT_HIP_CHECK(hipStreamWaitEvent(user_stream, ctx->aux_ev[8], 0));  // the encoder's last slice ends the call (it waited for the decoder's)
+        }
+        return AUKIT_OK;
+    };
+    int prc = AUKIT_OK;
+    const bool ran = dfpwm_decode_parallel(ctx, in, 1, 2, mono, d_moff, nullptr, &prc, 6000, 0, &hook);
+    if (ctx->dec_stream) {  // whatever was enqueued on the masked stream is ordered before the caller's next work
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->aux_ev[9], ctx->dec_stream));
+        AUKIT_HIP_CHECK(hipStreamWaitEvent(user_stream, ctx->aux_ev[9], 0));
+    }
+    if (!ran) return AUKIT_OK;  // not taken: the caller runs the plain sequence
+    *taken = true;
+    return prc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -165,7 +165,13 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release();
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release();
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        if (c->dec_stream) { (void)hipStreamSynchronize(c->dec_stream); (void)hipStreamDestroy(c->dec_stream); }
+        for (int i = 0; i < 10; i++) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
+        (void)hipStreamDestroy(c->aux_stream);
+    }
     if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
