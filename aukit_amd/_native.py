@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 if os.environ.get("AUKIT_LIB"):  # A/B of library builds on one box (tools/build_variant.sh): never set in tests or by the driver
     LIB_PATH = os.path.abspath(os.environ["AUKIT_LIB"])
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "container.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
 HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "resample_dev.h", "dfpwm_dev.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -38,7 +38,7 @@ EXPORTS = [
     "aukit_batch_download", "aukit_batch_free",
     "aukit_audio_upload", "aukit_audio_info", "aukit_audio_layout", "aukit_audio_device_ptr", "aukit_audio_download",
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
-    "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
+    "aukit_parse_container", "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
 ]
@@ -49,6 +49,15 @@ class CodecDesc(C.Structure):
                 ("data_type", C.c_int32), ("big_endian", C.c_int32), ("interleaved", C.c_int32), ("ulaw", C.c_int32),
                 ("top_first", C.c_int32), ("block_align", C.c_int32), ("ncoef", C.c_int32), ("coef1", C.c_int16 * 32),
                 ("coef2", C.c_int16 * 32), ("predictor", C.c_int32 * MAX_CH), ("step_index", C.c_int32 * MAX_CH)]
+
+
+class Container(C.Structure):
+    _fields_ = [("desc", CodecDesc), ("payload_off", C.c_uint64), ("payload_len", C.c_uint64), ("wav_data_type", C.c_int32), ("bit_depth", C.c_int32),
+                ("length_seconds", C.c_double)]
+
+
+CONTAINER_WAV, CONTAINER_AIFF, CONTAINER_AU = 0, 1, 2
+WAVDT = ("signed", "unsigned", "float", "alaw", "ulaw", "adpcm", "msadpcm", "dfpwm")
 
 
 class AukitError(RuntimeError):

@@ -342,166 +342,49 @@ def flac(data, head=None):
     return Audio(_load(B.make_desc(N.CODEC_FLAC), data), {}, {"dataType": "signed"})
 
 
-# ---- container parsers: host-side header walking only (aukit.lua:1456-1651, :2927-3113) ----
-_WAV_GUID = {
-    bytes.fromhex("0100000000001000800000aa00389b71"): "pcm", bytes.fromhex("0200000000001000800000aa00389b71"): "msadpcm",
-    bytes.fromhex("0300000000001000800000aa00389b71"): "float", bytes.fromhex("0600000000001000800000aa00389b71"): "alaw",
-    bytes.fromhex("0700000000001000800000aa00389b71"): "ulaw", bytes.fromhex("1100000000001000800000aa00389b71"): "adpcm",
-    bytes.fromhex("3ac1fa38811d4361a40dce53ca607cd1"): "dfpwm",
-}
+# ---- container front-ends: the header walk is the library's (aukit_parse_container, csrc/container.hip: host-side C, bound by the LuaJIT
+# shim as well); this side only hands the payload range to the loaders (aukit.lua:1456-1651, :2927-3113) ----
+def _parse(data, kind, stream=False):
+    """→ (N.Container, payload bytes); raises the reference's errors (truncated chunk headers included)"""
+    import ctypes as C
+    buf = bytes(data)
+    c = N.Container()
+    rc = N.lib().aukit_parse_container(buf, C.c_uint64(len(buf)), kind, int(bool(stream)), C.byref(c))
+    if rc:
+        raise LuaError(N.lib().aukit_last_error().decode(errors="replace"))
+    return c, buf[c.payload_off:c.payload_off + c.payload_len]
 
 
-def _parse_wav(data):
-    """→ dict(dataType, channels, sampleRate, bitDepth, blockAlign, coefficients, payload) per aukit.lua:1459-1507 / :2932-2979."""
-    if bytes(data[:4]) != b"RIFF" or bytes(data[8:12]) != b"WAVE":
-        raise LuaError("bad argument #1 (not a WAV file)")
-    pos, fmt = 12, None
-    while pos + 8 <= len(data):
-        tag, size = bytes(data[pos:pos + 4]), struct.unpack("<I", data[pos + 4:pos + 8])[0]
-        pos += 8
-        if tag == b"fmt ":
-            chunk = bytes(data[pos:pos + size])
-            f, ch, sr, ba, bd = struct.unpack("<HHIxxxxHH", chunk[:16])
-            coeffs = None
-            if f == 1:
-                dt = "unsigned" if bd == 8 else "signed"
-            elif f == 2:
-                dt = "msadpcm"
-                nco = struct.unpack("<H", chunk[20:22])[0]
-                if nco > 0:
-                    coeffs = [[], []]
-                    for i in range(1, nco + 1):
-                        a, b = struct.unpack("<hh", chunk[i * 4 + 18:i * 4 + 22])
-                        coeffs[0].append(a)
-                        coeffs[1].append(b)
-            elif f == 3:
-                dt = "float"
-            elif f == 6:
-                dt = "alaw"
-            elif f == 7:
-                dt = "ulaw"
-            elif f == 0x11:
-                dt = "adpcm"
-            elif f == 0xFFFE:
-                bd = struct.unpack("<H", chunk[18:20])[0]
-                kind = _WAV_GUID.get(chunk[24:40])
-                if kind is None:
-                    raise LuaError("unsupported WAV file")
-                dt = {"pcm": "unsigned" if bd == 8 else "signed"}.get(kind, kind)
-            else:
-                raise LuaError("unsupported WAV file")
-            fmt = dict(dataType=dt, channels=ch, sampleRate=sr, bitDepth=bd, blockAlign=ba, coefficients=coeffs)
-            pos += size
-        elif tag == b"data":
-            if fmt is None:
-                raise LuaError("invalid WAV file")
-            payload = bytes(data[pos:pos + size])
-            if len(payload) < size:
-                raise LuaError("invalid WAV file")
-            fmt["payload"] = payload
-            fmt["size"] = size
-            return fmt
-        else:
-            pos += size
-    raise LuaError("invalid WAV file")
-
-
-def _aiff_rate(e, m):
-    s = -1 if e & 0x8000 else 1
-    e = ((e & 0x7FFF) - 0x3FFE) % 0x800
-    return math.ldexp(m * s / 0x100000000000000, e)  # aukit.lua:1603-1605
-
-
-def _parse_aiff(data):
-    if bytes(data[:4]) != b"FORM":
-        raise LuaError("bad argument #1 (not an AIFF file)")
-    kind = bytes(data[8:12])
-    if kind not in (b"AIFF", b"AIFC"):
-        raise LuaError("bad argument #1 (not an AIFF file)")
-    pos, comm = 12, None
-    while pos + 8 <= len(data):
-        tag, size = bytes(data[pos:pos + 4]), struct.unpack(">I", data[pos + 4:pos + 8])[0]
-        pos += 8
-        if tag == b"COMM":
-            ch, length, bd, e = struct.unpack(">hIhH", data[pos:pos + 10])
-            m = struct.unpack(">Q", data[pos + 10:pos + 18])[0] >> 8  # ">I7" reads 7 bytes
-            p = pos + 18
-            comp = None
-            if kind == b"AIFC":
-                comp = bytes(data[p:p + 4])
-                ln = data[p + 4]
-                p += 5 + ln
-                if ln % 2 == 0:
-                    p += 1
-            comm = dict(channels=ch, length=length * ch * (bd // 8), bitDepth=bd, sampleRate=_aiff_rate(e, m), compression=comp)
-            pos = p
-        elif tag == b"SSND":
-            if comm is None:
-                raise LuaError("invalid AIFF file")
-            offset = struct.unpack(">I", data[pos:pos + 4])[0]
-            pos += 8
-            comm["payload"] = bytes(data[pos + offset:pos + offset + comm["length"]])
-            return comm
-        else:
-            pos += size
-    raise LuaError("invalid AIFF file")
-
-
-def _parse_au(data):
-    magic, offset, size, enc, sr, ch = struct.unpack(">4sIIIII", data[:24])
-    if magic != b".snd":
-        raise LuaError("invalid AU file")
-    payload = bytes(data[offset - 1:]) if size == 0xFFFFFFFF else bytes(data[offset - 1:offset - 1 + size])  # str_sub(data, offset, ...) is 1-based
-    return dict(encoding=enc, sampleRate=sr, channels=ch, payload=payload, size=size)
+def _desc_copy(c):
+    d = N.CodecDesc()
+    import ctypes as C
+    C.memmove(C.byref(d), C.byref(c.desc), C.sizeof(d))
+    return d
 
 
 def wav(data, head=None):  # aukit.lua:1456
     _expect(1, data, "string")
-    f = _parse_wav(data)
-    dt, p = f["dataType"], f["payload"]
-    if dt == "adpcm":
-        a = Audio(_load(B.make_desc(N.CODEC_ADPCM_WAV, f["channels"], f["sampleRate"], block_align=f["blockAlign"]), p))
-    elif dt == "msadpcm":
-        a = msadpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], f["coefficients"])
-    elif dt in ("alaw", "ulaw"):
-        a = g711(p, dt == "ulaw", f["channels"], f["sampleRate"])
-    elif dt == "dfpwm":
-        a = dfpwm(p, f["channels"], f["sampleRate"])
-    else:
-        a = pcm(p, f["bitDepth"], dt, f["channels"], f["sampleRate"], True, False)
+    c, p = _parse(data, N.CONTAINER_WAV)
+    a = Audio(_load(_desc_copy(c), p))
     a.metadata = {}
-    a.info = {"dataType": dt, "bitDepth": f["bitDepth"]}
+    a.info = {"dataType": N.WAVDT[c.wav_data_type], "bitDepth": c.bit_depth}
     return a
 
 
 def aiff(data, head=None):  # aukit.lua:1580
     _expect(1, data, "string")
-    f = _parse_aiff(data)
-    c, p = f["compression"], f["payload"]
-    if c in (None, b"NONE"):
-        return pcm(p, f["bitDepth"], "signed", f["channels"], f["sampleRate"], True, True)
-    if c == b"sowt":
-        return pcm(p, f["bitDepth"], "signed", f["channels"], f["sampleRate"], True, False)
-    if c in (b"fl32", b"FL32"):
-        return pcm(p, 32, "float", f["channels"], f["sampleRate"], True, True)
-    if c in (b"alaw", b"ulaw", b"ALAW", b"ULAW"):
-        return g711(p, c in (b"ulaw", b"ULAW"), f["channels"], f["sampleRate"])
-    raise LuaError("Unsupported compression scheme " + c.decode(errors="replace"))
+    c, p = _parse(data, N.CONTAINER_AIFF)
+    d = _desc_copy(c)
+    info = {"bitDepth": d.bit_depth, "dataType": ("signed", "unsigned", "float")[d.data_type]} if d.codec == N.CODEC_PCM else {"bitDepth": 8, "dataType": "signed"}  # what aukit.pcm / aukit.g711 set
+    return Audio(_load(d, p), {}, info)
 
 
 def au(data):  # aukit.lua:1639
     _expect(1, data, "string")
-    f = _parse_au(data)
-    e, p, ch, sr = f["encoding"], f["payload"], f["channels"], f["sampleRate"]
-    if e == 1:
-        return g711(p, True, ch, sr)
-    if e in (2, 3, 4, 5):
-        return pcm(p, {2: 8, 3: 16, 4: 24, 5: 32}[e], "signed", ch, sr, True, True)
-    if e == 6:
-        return pcm(p, 32, "float", ch, sr, True, True)
-    if e == 27:
-        return g711(p, False, ch, sr)
-    raise LuaError(f"unsupported encoding type {e}")
+    c, p = _parse(data, N.CONTAINER_AU)
+    d = _desc_copy(c)
+    info = {"bitDepth": d.bit_depth, "dataType": ("signed", "unsigned", "float")[d.data_type]} if d.codec == N.CODEC_PCM else {"bitDepth": 8, "dataType": "signed"}
+    return Audio(_load(d, p), {}, info)
 
 
 # aukit.lua:2134-2146: (string.unpack format, bit depth, data type) in table order; every format reads 8 values
@@ -634,46 +517,26 @@ class _StreamNS:
         _expect(1, data, "string")
         return self._run(B.make_desc(N.CODEC_QOA), data, mono, N.F64)
 
-    def wav(self, data, mono=None, ignoreHeader=None):  # :2927: header parse + dispatch (:2992-2996)
+    def _container(self, data, kind, mono):
+        c, p = _parse(data, kind, stream=True)
+        d = _desc_copy(c)
+        dtype = N.F64 if d.codec in (N.CODEC_PCM, N.CODEC_DFPWM) else N.I8  # what stream.pcm / .dfpwm vs .g711 / .adpcm / .msadpcm hand out
+        it, length = self._run(d, p, mono, dtype, endless_empty=d.codec == N.CODEC_G711)
+        return it, (length if math.isnan(c.length_seconds) else c.length_seconds)
+
+    def wav(self, data, mono=None, ignoreHeader=None):  # :2927: header walk (library) + dispatch (:2992-2996)
         _expect(1, data, "string")
-        f = _parse_wav(data)
-        dt, p = f["dataType"], f["payload"]
-        if dt == "adpcm":
-            return self.adpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], mono)
-        if dt == "msadpcm":
-            return self.msadpcm(p, f["blockAlign"], f["channels"], f["sampleRate"], mono, f["coefficients"])
-        if dt == "dfpwm":
-            return self.dfpwm(p, f["sampleRate"], f["channels"], mono)[0], f["size"] / f["channels"] / (f["bitDepth"] / 8) / f["sampleRate"]
-        if dt in ("alaw", "ulaw"):
-            return self.g711(p, dt == "ulaw", f["channels"], f["sampleRate"], mono)
-        return self.pcm(p, f["bitDepth"], dt, f["channels"], f["sampleRate"], False, mono)[0], f["size"] / f["channels"] / (f["bitDepth"] / 8) / f["sampleRate"]
+        return self._container(data, N.CONTAINER_WAV, mono)
 
     def aiff(self, data, mono=None, ignoreHeader=None):  # :3016
         _expect(1, data, "string")
-        f = _parse_aiff(data)
-        c, p, ch, sr, bd, ln = f["compression"], f["payload"], f["channels"], f["sampleRate"], f["bitDepth"], f["length"]
-        if c in (None, b"NONE", b"sowt"):
-            return self.pcm(p, bd, "signed", ch, sr, True, mono)[0], ln / ch / (bd / 8) / sr  # :3064-3065 (both big-endian in the reference)
-        if c in (b"fl32", b"FL32"):
-            return self.pcm(p, 32, "float", ch, sr, True, mono)[0], ln / ch / 4 / sr
-        if c in (b"alaw", b"ulaw", b"ALAW", b"ULAW"):
-            return self.g711(p, c in (b"ulaw", b"ULAW"), ch, sr, mono)[0], ln / ch / sr
-        raise LuaError("Unsupported compression scheme " + c.decode(errors="replace"))
+        _expect(2, mono, "boolean", "nil")
+        return self._container(data, N.CONTAINER_AIFF, mono)
 
     def au(self, data, mono=None, ignoreHeader=None):  # :3086
         _expect(1, data, "string")
-        f = _parse_au(data)
-        e, p, ch, sr, size = f["encoding"], f["payload"], f["channels"], f["sampleRate"], f["size"]
-        if e == 1:
-            return self.g711(p, True, ch, sr, mono)[0], size / ch / sr
-        if e in (2, 3, 4, 5):
-            bd = {2: 8, 3: 16, 4: 24, 5: 32}[e]
-            return self.pcm(p, bd, "signed", ch, sr, True, mono)[0], size / ch / (bd // 8) / sr
-        if e == 6:
-            return self.pcm(p, 32, "float", ch, sr, True, mono)[0], size / ch / 4 / sr
-        if e == 27:
-            return self.g711(p, False, ch, sr, mono)[0], size / ch / sr
-        raise LuaError(f"unsupported encoding type {e}")
+        _expect(2, mono, "boolean", "nil")
+        return self._container(data, N.CONTAINER_AU, mono)
 
 
 stream = _StreamNS()

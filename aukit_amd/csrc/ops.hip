@@ -266,10 +266,10 @@ __global__ __launch_bounds__(256) void k_pack(const T *in, const u64 *len, const
         unsigned long long bits;
         if (data_type == AUKIT_FLOAT) bits = __float_as_uint((float)d);           // encode = identity, "f"
         else {
-            const double v = d * (d < 0 ? max_value : max_value - 1) + add;      // :875
+            const double v = (mode & AUKIT_PACK_PREENCODED) ? d : d * (d < 0 ? max_value : max_value - 1) + add;  // :875 (or already Audio:pcm's output)
             double r;
-            if (mode == AUKIT_PACK_FLOOR) r = floor(v);
-            else if (mode == AUKIT_PACK_TRUNC) r = trunc(v);
+            if ((mode & 7) == AUKIT_PACK_FLOOR) r = floor(v);
+            else if ((mode & 7) == AUKIT_PACK_TRUNC) r = trunc(v);
             else { r = v; if (v != floor(v)) atomicCAS(err, 0, 1); }            // PUC Lua 5.3: "number has no integer representation"
             if (!(r >= -9.2e18 && r <= 9.2e18)) { atomicCAS(err, 0, 1); r = 0; }
             bits = (unsigned long long)(long long)r;                              // two's complement, low `bytes` bytes kept (no range check in pack)
@@ -329,7 +329,7 @@ int aukit_pack_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int dat
     if (bit_depth != 8 && bit_depth != 16 && bit_depth != 24 && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
     if (data_type < 0 || data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
     if (data_type == AUKIT_FLOAT && bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
-    if (int_mode < AUKIT_PACK_TRUNC || int_mode > AUKIT_PACK_STRICT) return fail(AUKIT_E_ARG, "bad integer conversion mode");
+    if ((int_mode & 7) > AUKIT_PACK_STRICT || (int_mode & ~(7 | AUKIT_PACK_PREENCODED)) != 0) return fail(AUKIT_E_ARG, "bad integer conversion mode");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     const int bytes = bit_depth / 8;
     std::vector<uint64_t> off(in->n + 1, 0);

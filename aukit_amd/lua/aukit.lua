@@ -2,18 +2,27 @@
 --- by libaukit_hip.so (include/aukit_hip.h).  Host code stays Lua: `local aukit = require "aukit"` keeps working, the
 --- per-sample loops run on the MI355X.
 ---
---- NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Lua / LuaJIT (see DESIGN.md §1); the Python mirror
---- aukit_amd/aukit.py implements the same mapping and is what the GPU tests drive.  This file is the binding a
---- maintainer would add next to the reference (INTEGRATION.md).  Strings in, tables out — same shapes as the reference:
----   Audio.data[c][i] doubles, stream iterators returning `chunk, pos` with chunk[c][i] in [-128, 127].
+--- NOT EXECUTED IN THIS REPOSITORY: the build image has no Lua / LuaJIT (DESIGN.md §1).  The Python mirror aukit_amd/aukit.py
+--- implements the same mapping over the same C entry points and is what the GPU tests drive; this file is the binding a
+--- maintainer would add next to the reference (INTEGRATION.md has the per-function support matrix).  Strings in, tables out —
+--- the shapes of the reference: Audio.data[c][i] doubles, stream iterators returning `chunk, pos` with chunk[c][i] in [-128, 127].
+---
+--- Covered (reference line numbers in aukit.lua): loaders aukit.pcm :1049, .adpcm :1183, .msadpcm :1283, .g711 :1361, .dfpwm :1392,
+--- .mdfpwm :1420, .wav :1456, .aiff :1580, .au :1639, .flac :1657, .qoa :1706; aukit.new :1783, .tone :1808, .pack :1861;
+--- Audio:len / :channels / :resample :653 / :mono :677 / :concat :695 / :sub :725 / :combine :751 / :split :781 / :mix :804 /
+--- :rep :839 / :reverse :856 / :pcm :901 / :stream :921 / :wav :954 / :dfpwm :1005; aukit.stream.* :2228-3337; aukit.effects.* :3356-3618.
+--- Left to the reference's own Lua (not on the path: SURVEY.md §8): aukit.play / Player, aukit.noise (draws from the VM's math.random),
+--- aukit.detect, metadata (LIST / ID3) reading and writing, reader-FUNCTION inputs of aukit.stream.* (strings only here).
 local ffi = require "ffi"
 
 ffi.cdef [[
 typedef struct aukit_ctx aukit_ctx; typedef struct aukit_batch aukit_batch; typedef struct aukit_audio aukit_audio; typedef struct aukit_chunks aukit_chunks;
 typedef struct { int32_t codec, channels; double sample_rate; int32_t bit_depth, data_type, big_endian, interleaved, ulaw, top_first, block_align, ncoef;
                  int16_t coef1[32], coef2[32]; int32_t predictor[8], step_index[8]; } aukit_codec_desc;
+typedef struct { aukit_codec_desc desc; uint64_t payload_off, payload_len; int32_t wav_data_type, bit_depth; double length_seconds; } aukit_container;
 const char *aukit_last_error(void);
 int aukit_ctx_create(aukit_ctx **out, int device); void aukit_ctx_destroy(aukit_ctx *ctx);
+int aukit_parse_container(const uint8_t *bytes, uint64_t n, int kind, int stream, aukit_container *out);
 int aukit_batch_upload(aukit_ctx *, aukit_batch **, const uint8_t *bytes, const uint64_t *offsets, uint32_t n);
 int aukit_batch_info(const aukit_batch *, uint32_t *n, uint64_t *total); int aukit_batch_download(aukit_ctx *, const aukit_batch *, uint8_t *dst); void aukit_batch_free(aukit_batch *);
 int aukit_audio_upload(aukit_ctx *, aukit_audio **, const double *samples, const uint64_t *lens, uint32_t n, int channels, double rate, int dtype);
@@ -44,24 +53,53 @@ local C = ffi.load(os.getenv("AUKIT_HIP_LIB") or "aukit_hip")
 local F64, I8 = 0, 2
 local INTERP = {none = 0, linear = 1, cubic = 2, sinc = 3}
 local DTYPE = {signed = 0, unsigned = 1, float = 2}
+local DTYPE_NAME = {[0] = "signed", "unsigned", "float"}
 local CODEC = {pcm = 0, g711 = 1, adpcm = 2, adpcm_wav = 3, msadpcm = 4, dfpwm = 5, mdfpwm = 6, qoa = 7, flac = 8}
+local WAVDT = {[0] = "signed", "unsigned", "float", "alaw", "ulaw", "adpcm", "msadpcm", "dfpwm"}
 local FX = {amplify = 0, speed = 1, fade = 2, invert = 3, normalize = 4, center = 5, trim = 6, delay = 7, echo = 8, reverb = 9, lowpass = 10, highpass = 11}
 
 local aukit = {_VERSION = "1.10.0", defaultInterpolation = "linear", effects = {}, stream = {}}
+
+-- cc.expect (aukit.lua:84): "bad argument #n (expected T, got U)" / "(number outside of range)", raised at the caller's level
+local function expect(n, v, ...)
+    local t = type(v)
+    for i = 1, select("#", ...) do if t == select(i, ...) then return v end end
+    local names = {...}
+    local want = #names < 3 and table.concat(names, " or ") or (table.concat(names, ", ", 1, #names - 1) .. ", or " .. names[#names])
+    error(("bad argument #%d (expected %s, got %s)"):format(n, want, t), 3)
+end
+local function range(n, v, lo, hi)
+    if v ~= v or v < (lo or -math.huge) or v > (hi or math.huge) then error(("bad argument #%d (number outside of range)"):format(n), 3) end
+    return v
+end
+
+local unpack = table.unpack or unpack  -- LuaJIT is Lua 5.1: no table.unpack, no string.pack
+-- little-endian integer fields of a RIFF header without string.pack
+local function u16(v) v = math.floor(v) % 65536 return string.char(v % 256, math.floor(v / 256)) end
+local function u32(v) v = math.floor(v) % 4294967296 return string.char(v % 256, math.floor(v / 256) % 256, math.floor(v / 65536) % 256, math.floor(v / 16777216)) end
 
 local ctxp = ffi.new("aukit_ctx*[1]")
 local function ctx()
     if ctxp[0] == nil and C.aukit_ctx_create(ctxp, 0) ~= 0 then error(ffi.string(C.aukit_last_error()), 3) end
     return ctxp[0]
 end
--- every native status becomes the Lua error the reference raises (AUKIT_E_LUA carries the reference's own message)
+-- every native status becomes the Lua error the reference raises (AUKIT_E_ARG / AUKIT_E_LUA carry the reference's own message)
 local function check(rc) if rc ~= 0 then error(ffi.string(C.aukit_last_error()), 3) end end
 
-local function upload(str)
-    local off = ffi.new("uint64_t[2]", 0, #str)
+local function upload(str, first, len)
+    first = first or 0
+    len = len or #str
+    local off = ffi.new("uint64_t[2]", 0, len)
     local b = ffi.new("aukit_batch*[1]")
-    check(C.aukit_batch_upload(ctx(), b, ffi.cast("const uint8_t*", str), off, 1))
+    check(C.aukit_batch_upload(ctx(), b, ffi.cast("const uint8_t*", str) + first, off, 1))
     return ffi.gc(b[0], C.aukit_batch_free)
+end
+local function batch_string(b)
+    local n, tot = ffi.new("uint32_t[1]"), ffi.new("uint64_t[1]")
+    check(C.aukit_batch_info(b, n, tot))
+    local buf = ffi.new("uint8_t[?]", math.max(tonumber(tot[0]), 1))
+    check(C.aukit_batch_download(ctx(), b, buf))
+    return ffi.string(buf, tot[0])
 end
 
 local function desc(t)
@@ -70,10 +108,24 @@ local function desc(t)
     d.bit_depth = t.bitDepth or 8; d.data_type = DTYPE[t.dataType or "signed"]; d.big_endian = t.bigEndian and 1 or 0
     d.interleaved = t.interleaved == false and 0 or 1; d.ulaw = t.ulaw and 1 or 0; d.top_first = t.topFirst == false and 0 or 1
     d.block_align = t.blockAlign or 0
+    if t.coefficients then  -- aukit.msadpcm's `coefficients` = {{c1...}, {c2...}} (aukit.lua:1304)
+        local n = #t.coefficients[1]
+        if n > 32 then error("at most 32 MS-ADPCM coefficient pairs are supported", 3) end
+        d.ncoef = n
+        for i = 1, n do d.coef1[i - 1] = t.coefficients[1][i]; d.coef2[i - 1] = t.coefficients[2][i] end
+    end
+    for c = 1, 8 do  -- aukit.adpcm's predictor / step_index: a number or one per channel (:1190-1215)
+        local p, s = t.predictor, t.step_index
+        if type(p) == "table" then p = p[c] end
+        if type(s) == "table" then s = s[c] end
+        d.predictor[c - 1] = p or 0
+        d.step_index[c - 1] = s or 0
+    end
     return d
 end
 
---- Audio objects wrap a device handle; `data` is materialised on first access like any other Lua table.
+--- Audio objects wrap a device handle.  `data` is downloaded on first access and cached; the in-place effects drop the cache.
+--- Lua code that edits audio.data by hand must call aukit.upload(audio) before handing the object back to this module.
 local Audio = {}
 local Audio_mt = {__name = "Audio"}
 local function wrap(h, metadata, info)
@@ -86,166 +138,363 @@ local function geom(self)
     check(C.aukit_audio_layout(self._h, len, nil, nil))
     return ch[0], rate[0], tonumber(len[0])
 end
+-- the samples of one audio as ONE FFI array [channel][i] (a memcpy from pinned staging, no Lua tables yet)
+local function fetch(self)
+    local ch, _, len = geom(self)
+    local buf = ffi.new("double[?]", math.max(ch * len, 1))
+    check(C.aukit_audio_download(ctx(), self._h, buf))
+    return buf, ch, len
+end
 function Audio_mt.__index(self, k)
     if k == "sampleRate" then local _, r = geom(self) return r end
     if k == "data" then
-        local ch, _, len = geom(self)
-        local buf = ffi.new("double[?]", math.max(ch * len, 1))
-        check(C.aukit_audio_download(ctx(), self._h, buf))
+        local buf, ch, len = fetch(self)
         local data = {}
         for c = 1, ch do local t = {} for i = 1, len do t[i] = buf[(c - 1) * len + i - 1] end data[c] = t end
-        rawset(self, "data", data)  -- NB: Lua code that edits audio.data by hand must call aukit.upload(audio) afterwards
+        rawset(self, "data", data)
         return data
     end
     return Audio[k]
 end
-function Audio:len() local _, r, len = geom(self) return len / r end
-function Audio:channels() return (geom(self)) end
-function Audio:resample(sampleRate, interpolation)
-    interpolation = interpolation or aukit.defaultInterpolation
+local function expectAudio(n, var)
+    if type(var) == "table" and getmetatable(var) == Audio_mt then return var end
+    expect(n, var, "Audio")  -- always fails (aukit.lua:234-237)
+end
+--- pushes a hand-edited audio.data back to the device (no reference counterpart: there the table IS the audio)
+function aukit.upload(audio)
+    expectAudio(1, audio)
+    local data = rawget(audio, "data")
+    if not data then return audio end
+    local ch, len = #data, #data[1]
+    local buf = ffi.new("double[?]", math.max(ch * len, 1))
+    for c = 1, ch do for i = 1, len do buf[(c - 1) * len + i - 1] = data[c][i] end end
+    local lens = ffi.new("uint64_t[1]", len)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_audio_upload(ctx(), o, buf, lens, 1, ch, audio.sampleRate, F64))
+    audio._h = ffi.gc(o[0], C.aukit_audio_free)
+    return audio
+end
+
+function Audio:len() local _, r, len = geom(self) return len / r end   -- :638
+function Audio:channels() return (geom(self)) end                      -- :645
+function Audio:resample(sampleRate, interpolation)                     -- :653
+    expect(1, sampleRate, "number")
+    interpolation = expect(2, interpolation, "string", "nil") or aukit.defaultInterpolation
     if not INTERP[interpolation] then error("bad argument #2 (invalid interpolation type)", 2) end
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_resample(ctx(), self._h, sampleRate, INTERP[interpolation], o))
     return wrap(o[0], self.metadata, self.info)
 end
-function Audio:mono()
+function Audio:mono()                                                  -- :677
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_mono(ctx(), self._h, o))
     return wrap(o[0], self.metadata, self.info)
 end
-function Audio:mix(amplifier, ...)
+-- group calls want equal sample rates: resample first, like :702 / :756 / :812; the returned list keeps the temporaries alive
+local function group(self, first_argn, ...)
     local audios = {self, ...}
-    if type(amplifier) ~= "number" then table.insert(audios, 2, amplifier) amplifier = 1 end
     local arr = ffi.new("const aukit_audio*[?]", #audios)
     for i, a in ipairs(audios) do
+        if i > 1 then expectAudio(first_argn + i - 2, a) end
         if a.sampleRate ~= self.sampleRate then a = a:resample(self.sampleRate) audios[i] = a end
         arr[i - 1] = a._h
     end
+    return arr, #audios, audios
+end
+function Audio:mix(amplifier, ...)                                     -- :804
+    local arr, n, keep
+    if type(amplifier) == "number" then arr, n, keep = group(self, 2, ...)
+    else arr, n, keep = group(self, 1, amplifier, ...) amplifier = 1 end
     local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_mix(ctx(), arr, #audios, amplifier, o))
+    check(C.aukit_mix(ctx(), arr, n, amplifier, o))
+    keep = nil
     return wrap(o[0], self.metadata, self.info)
 end
-function Audio:dfpwm(interleaved)
-    local b = ffi.new("aukit_batch*[1]")
-    check(C.aukit_dfpwm_encode(ctx(), self._h, interleaved == false and 0 or 1, b))
-    local n, tot = ffi.new("uint32_t[1]"), ffi.new("uint64_t[1]")
-    check(C.aukit_batch_info(b[0], n, tot))
-    local buf = ffi.new("uint8_t[?]", math.max(tonumber(tot[0]), 1))
-    check(C.aukit_batch_download(ctx(), b[0], buf))
-    C.aukit_batch_free(b[0])
-    return ffi.string(buf, tot[0])
-end
-
--- structural methods (aukit.lua:690-866): device-side row copies, the source objects are never touched
-local function group(self, ...)
-    local audios = {self, ...}
-    local arr = ffi.new("const aukit_audio*[?]", #audios)
-    for i, a in ipairs(audios) do
-        if a.sampleRate ~= self.sampleRate then a = a:resample(self.sampleRate) audios[i] = a end  -- :702, :756
-        arr[i - 1] = a._h
-    end
-    return arr, #audios, audios  -- `audios` keeps the resampled temporaries alive across the call
-end
-function Audio:concat(...)
-    local arr, n, keep = group(self, ...)
+function Audio:concat(...)                                             -- :695
+    local arr, n, keep = group(self, 1, ...)
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_concat(ctx(), arr, n, o))
-    return wrap(o[0], self.metadata, self.info), keep and nil
-end
-function Audio:combine(...)
-    local arr, n, keep = group(self, ...)
-    local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_combine(ctx(), arr, n, o))
-    return wrap(o[0], self.metadata, self.info), keep and nil
-end
-function Audio:sub(start, last)
-    local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_sub(ctx(), self._h, start or 0, last or 0, o))
+    keep = nil
     return wrap(o[0], self.metadata, self.info)
 end
-function Audio:split(...)
+function Audio:combine(...)                                            -- :751
+    local arr, n, keep = group(self, 1, ...)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_combine(ctx(), arr, n, o))
+    keep = nil
+    return wrap(o[0], self.metadata, self.info)
+end
+function Audio:sub(start, last)                                        -- :725
+    start = expect(1, start, "number", "nil") or 0
+    last = expect(2, last, "number", "nil") or 0
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_sub(ctx(), self._h, start, last, o))
+    return wrap(o[0], self.metadata, self.info)
+end
+function Audio:split(...)                                              -- :781
     local res = {}
     for n, cl in ipairs {...} do
-        if #cl == 0 then error("bad argument #" .. n .. " (cannot use empty table)") end
+        expect(n, cl, "table")
+        if #cl == 0 then error("bad argument #" .. n .. " (cannot use empty table)", 2) end
         local ch = ffi.new("int32_t[?]", #cl, cl)
         local o = ffi.new("aukit_audio*[1]")
         check(C.aukit_split(ctx(), self._h, ch, #cl, o))
         res[#res + 1] = wrap(o[0], self.metadata, self.info)
     end
-    return table.unpack(res)
+    return unpack(res)
 end
-function Audio:rep(count)
+function Audio:rep(count)                                              -- :839
+    expect(1, count, "number")
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_rep(ctx(), self._h, count, o))
     return wrap(o[0], self.metadata, self.info)
 end
-function Audio:reverse()
+function Audio:reverse()                                               -- :856
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_reverse(ctx(), self._h, o))
     return wrap(o[0], self.metadata, self.info)
 end
-local WAVE = {sine = 1, triangle = 2, sawtooth = 3, square = 4}
-function aukit.new(duration, channels, sampleRate)
+
+local function check_pcm_args(bitDepth, dataType)  -- :908-910, :925-927
+    if bitDepth ~= 8 and bitDepth ~= 16 and bitDepth ~= 24 and bitDepth ~= 32 then error("bad argument #2 (invalid bit depth)", 3) end
+    if dataType ~= "signed" and dataType ~= "unsigned" and dataType ~= "float" then error("bad argument #3 (invalid data type)", 3) end
+    if dataType == "float" and bitDepth ~= 32 then error("bad argument #2 (float audio must have 32-bit depth)", 3) end
+end
+-- encodePCM (:868-894) on the device: d * (d < 0 and maxValue or maxValue - 1) + add, as doubles in the reference's order
+local function encoded(self, bitDepth, dataType, interleaved)
     local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_tone(ctx(), 1, 0, duration, 1, 0, 0.5, channels or 1, sampleRate or 48000, F64, o))
+    check(C.aukit_encode_pcm(ctx(), self._h, bitDepth, DTYPE[dataType], interleaved and 1 or 0, o))
+    local tmp = wrap(o[0])
+    local buf, _, len = fetch(tmp)  -- one row of channels × length values
+    return buf, len
+end
+function Audio:pcm(bitDepth, dataType, interleaved)                    -- :901
+    bitDepth = expect(1, bitDepth, "number", "nil") or 8
+    dataType = expect(2, dataType, "string", "nil") or "signed"
+    expect(3, interleaved, "boolean", "nil")
+    if interleaved == nil then interleaved = true end
+    check_pcm_args(bitDepth, dataType)
+    local buf, len = encoded(self, bitDepth, dataType, interleaved)
+    local t = {}
+    for i = 1, len do t[i] = buf[i - 1] end
+    return t
+end
+function Audio:stream(chunkSize, bitDepth, dataType)                   -- :921
+    chunkSize = expect(1, chunkSize, "number", "nil") or 131072
+    bitDepth = expect(2, bitDepth, "number", "nil") or 8
+    dataType = expect(3, dataType, "string", "nil") or "signed"
+    check_pcm_args(bitDepth, dataType)
+    local ch, rate, len = geom(self)
+    local buf = encoded(self, bitDepth, dataType, false)  -- channel after channel: buf[(c - 1) * len + n - 1]
+    local pos = 1
+    return function()
+        if pos == nil or pos > len then pos = nil return nil end  -- :878
+        local p = pos / rate
+        local chunk = {}
+        for c = 1, ch do
+            local t = {}
+            for n = pos, math.min(pos + chunkSize - 1, len) do t[n - pos + 1] = buf[(c - 1) * len + n - 1] end
+            chunk[c] = t
+        end
+        pos = pos + chunkSize
+        return chunk, p
+    end, len / rate
+end
+function Audio:dfpwm(interleaved)                                      -- :1005
+    expect(1, interleaved, "boolean", "nil")
+    local b = ffi.new("aukit_batch*[1]")
+    check(C.aukit_dfpwm_encode(ctx(), self._h, interleaved == false and 0 or 1, b))
+    local s = batch_string(b[0])
+    C.aukit_batch_free(b[0])
+    return s
+end
+-- packed sample bytes (aukit.pack ∘ Audio:pcm).  int_mode 0 = truncate like the CC: Tweaked VM's string.pack (a Java long cast); 1 = floor; 2 = PUC
+-- Lua 5.3's "number has no integer representation" error — what string.pack does with a non-integer is the VM's business (include/aukit_hip.h)
+local function packed(self, bitDepth, dataType, bigEndian, interleaved)
+    local b = ffi.new("aukit_batch*[1]")
+    check(C.aukit_pack_pcm(ctx(), self._h, bitDepth, DTYPE[dataType], bigEndian and 1 or 0, interleaved and 1 or 0, aukit.packIntegerMode or 0, b))
+    local s = batch_string(b[0])
+    C.aukit_batch_free(b[0])
+    return s
+end
+local wavExtensibleChannels = {0x04, 0x03, 0x07, 0x33, 0x37, 0x3F, 0x637, 0x63F, 0x50F7, 0x50FF, 0x56F7, 0x56FF}  -- :141-154 (by channel count)
+local dfpwmGUID = "\x3a\xc1\xfa\x38\x81\x1d\x43\x61\xa4\x0d\xce\x53\xca\x60\x7c\xd1"                          -- :138
+function Audio:wav(bitDepth)                                           -- :954 (metadata / LIST chunk not written: out of scope)
+    bitDepth = expect(1, bitDepth, "number", "nil") or 16
+    local ch, rate, len = geom(self)
+    if bitDepth == 1 then
+        local str = self:dfpwm(true)
+        -- "<c4Ic4c4IHHIIHHHHIc16c4IIc4I" (:983-988)
+        return "RIFF" .. u32(#str + 72) .. "WAVE" .. "fmt " .. u32(40) .. u16(0xFFFE) .. u16(ch) .. u32(rate) .. u32(rate * ch / 8) .. u16(math.ceil(ch / 8)) .. u16(1) ..
+            u16(22) .. u16(1) .. u32(wavExtensibleChannels[ch] or 0) .. dfpwmGUID .. "fact" .. u32(4) .. u32(len) .. "data" .. u32(#str) .. str
+    elseif bitDepth ~= 8 and bitDepth ~= 16 and bitDepth ~= 24 and bitDepth ~= 32 then error("bad argument #2 (invalid bit depth)", 2) end
+    local str = packed(self, bitDepth, bitDepth == 8 and "unsigned" or "signed", false, true)
+    -- "<c4Ic4c4IHHIIHHc4I" (:996)
+    return "RIFF" .. u32(#str + 36) .. "WAVE" .. "fmt " .. u32(16) .. u16(1) .. u16(ch) .. u32(rate) .. u32(rate * ch * bitDepth / 8) .. u16(ch * bitDepth / 8) .. u16(bitDepth) ..
+        "data" .. u32(#str) .. str
+end
+
+-- ---------------------------------------------------------------- generators, packing
+local WAVE = {sine = 1, triangle = 2, sawtooth = 3, square = 4}
+function aukit.new(duration, channels, sampleRate)                     -- :1783
+    expect(1, duration, "number")
+    channels = expect(2, channels, "number", "nil") or 1
+    sampleRate = expect(3, sampleRate, "number", "nil") or 48000
+    range(2, channels, 1) range(3, sampleRate, 1)
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_tone(ctx(), 1, 0, duration, 1, 0, 0.5, channels, sampleRate, F64, o))
     return wrap(o[0], {}, {})
 end
-function aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)
-    local w = WAVE[waveType or "sine"]
+function aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)  -- :1808
+    expect(1, frequency, "number") expect(2, duration, "number")
+    amplitude = expect(3, amplitude, "number", "nil") or 1
+    waveType = expect(4, waveType, "string", "nil") or "sine"
+    duty = expect(5, duty, "number", "nil") or 0.5
+    channels = expect(6, channels, "number", "nil") or 1
+    sampleRate = expect(7, sampleRate, "number", "nil") or 48000
+    local w = WAVE[waveType]
     if not w then error("bad argument #4 (invalid wave type)", 2) end
     local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_tone(ctx(), 1, frequency, duration, amplitude or 1, w, duty or 0.5, channels or 1, sampleRate or 48000, F64, o))
+    check(C.aukit_tone(ctx(), 1, frequency, duration, amplitude, w, duty, channels, sampleRate, F64, o))
     return wrap(o[0], {}, {})
 end
--- the sample bytes of Audio:wav (aukit.lua:966-971); the RIFF header is string.pack'ed around them exactly as :993-996 does.
--- int_mode 0 = truncate like the CC: Tweaked VM's string.pack (a Java long cast); see include/aukit_hip.h
-local function wav_body(self, bitDepth)
+--- aukit.pack(data, bitDepth, dataType, bigEndian) :1861 takes the number table Audio:pcm returns; with an Audio as first argument the
+--- round trip through Lua tables is skipped (the device packs its own encodePCM output)
+function aukit.pack(data, bitDepth, dataType, bigEndian)
+    bitDepth = expect(2, bitDepth, "number", "nil") or 8
+    dataType = expect(3, dataType, "string", "nil") or "signed"
+    check_pcm_args(bitDepth, dataType)
+    if type(data) == "table" and getmetatable(data) == Audio_mt then return packed(data, bitDepth, dataType, bigEndian, true) end
+    expect(1, data, "string", "table")
+    if type(data) == "string" then return data end                    -- :1867
+    -- a table of numbers (what Audio:pcm returned): upload it as one row and let the device pack it with the same rules
+    local n = #data
+    local buf = ffi.new("double[?]", math.max(n, 1))
+    for i = 1, n do buf[i - 1] = data[i] end
+    local lens, o = ffi.new("uint64_t[1]", n), ffi.new("aukit_audio*[1]")
+    check(C.aukit_audio_upload(ctx(), o, buf, lens, 1, 1, 48000, F64))
+    local row = wrap(o[0])
+    -- the numbers are already encodePCM's output (:868-894): pack them as they are — a "float" pass-through of bitDepth-wide integers is what
+    -- aukit_pack_pcm does when its input is flagged pre-encoded (int_mode + 8)
     local b = ffi.new("aukit_batch*[1]")
-    check(C.aukit_pack_pcm(ctx(), self._h, bitDepth, bitDepth == 8 and 1 or 0, 0, 1, 0, b))
-    local n, tot = ffi.new("uint32_t[1]"), ffi.new("uint64_t[1]")
-    check(C.aukit_batch_info(b[0], n, tot))
-    local buf = ffi.new("uint8_t[?]", math.max(tonumber(tot[0]), 1))
-    check(C.aukit_batch_download(ctx(), b[0], buf))
+    check(C.aukit_pack_pcm(ctx(), row._h, bitDepth, DTYPE[dataType], bigEndian and 1 or 0, 1, (aukit.packIntegerMode or 0) + 8, b))
+    local str = batch_string(b[0])
     C.aukit_batch_free(b[0])
-    return ffi.string(buf, tot[0])
+    return str
 end
-aukit._wav_body = wav_body
 
-local function loader(d, data, info)
+-- ---------------------------------------------------------------- loaders
+local function loader(d, data, info, first, len)
     local o = ffi.new("aukit_audio*[1]")
-    check(C.aukit_decode(ctx(), upload(data), d, F64, o))
+    check(C.aukit_decode(ctx(), upload(data, first, len), d, F64, o))
     return wrap(o[0], {}, info)
 end
-function aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved, bigEndian)
+function aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved, bigEndian)  -- :1049
+    expect(1, data, "string", "table")
+    if type(data) == "table" then error("aukit.pcm with a table of numbers: pack it first (aukit.pack) — the device path takes byte strings", 2) end
+    bitDepth = expect(2, bitDepth, "number", "nil") or 8
+    dataType = expect(3, dataType, "string", "nil") or "signed"
+    channels = expect(4, channels, "number", "nil") or 1
+    sampleRate = expect(5, sampleRate, "number", "nil") or 48000
+    expect(6, interleaved, "boolean", "nil") expect(7, bigEndian, "boolean", "nil")
     return loader(desc {codec = "pcm", bitDepth = bitDepth, dataType = dataType, channels = channels, sampleRate = sampleRate, interleaved = interleaved, bigEndian = bigEndian},
-        data, {bitDepth = bitDepth or 8, dataType = dataType or "signed"})
+        data, {bitDepth = bitDepth, dataType = dataType})
 end
-function aukit.g711(data, ulaw, channels, sampleRate) return loader(desc {codec = "g711", ulaw = ulaw, channels = channels, sampleRate = sampleRate or 8000}, data) end
-function aukit.dfpwm(data, channels, sampleRate) return loader(desc {codec = "dfpwm", channels = channels, sampleRate = sampleRate}, data) end
-function aukit.msadpcm(data, blockAlign, channels, sampleRate) return loader(desc {codec = "msadpcm", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate}, data) end
-function aukit.mdfpwm(data) return loader(desc {codec = "mdfpwm"}, data) end
-function aukit.qoa(data) return loader(desc {codec = "qoa"}, data) end
-function aukit.flac(data) return loader(desc {codec = "flac"}, data) end
--- aukit.wav / aiff / au: parse the container header in Lua exactly as the reference does (aukit.lua:1456-1651),
--- then call the loader above on the payload (IMA blocks: codec = "adpcm_wav" with blockAlign).
+function aukit.adpcm(data, channels, sampleRate, topFirst, interleaved, predictor, step_index)  -- :1183 (string input)
+    expect(1, data, "string", "table")
+    if type(data) == "table" then error("aukit.adpcm with a table of nibbles is not offered by the device path (pass the byte string)", 2) end
+    channels = expect(2, channels, "number", "nil") or 1
+    sampleRate = expect(3, sampleRate, "number", "nil") or 48000
+    expect(4, topFirst, "boolean", "nil") expect(5, interleaved, "boolean", "nil")
+    expect(6, predictor, "number", "table", "nil") expect(7, step_index, "number", "table", "nil")
+    return loader(desc {codec = "adpcm", channels = channels, sampleRate = sampleRate, topFirst = topFirst, interleaved = interleaved, predictor = predictor, step_index = step_index},
+        data, {bitDepth = 16, dataType = "signed"})
+end
+function aukit.msadpcm(data, blockAlign, channels, sampleRate, coefficients)  -- :1283
+    expect(1, data, "string") expect(2, blockAlign, "number")
+    channels = expect(3, channels, "number", "nil") or 1
+    sampleRate = expect(4, sampleRate, "number", "nil") or 48000
+    expect(5, coefficients, "table", "nil")
+    return loader(desc {codec = "msadpcm", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate, coefficients = coefficients}, data, {bitDepth = 16, dataType = "signed"})
+end
+function aukit.g711(data, ulaw, channels, sampleRate)                  -- :1361
+    expect(1, data, "string") expect(2, ulaw, "boolean")
+    channels = expect(3, channels, "number", "nil") or 1
+    sampleRate = expect(4, sampleRate, "number", "nil") or 8000
+    return loader(desc {codec = "g711", ulaw = ulaw, channels = channels, sampleRate = sampleRate}, data, {bitDepth = 8, dataType = "signed"})
+end
+function aukit.dfpwm(data, channels, sampleRate)                       -- :1392
+    expect(1, data, "string")
+    channels = expect(2, channels, "number", "nil") or 1
+    sampleRate = expect(3, sampleRate, "number", "nil") or 48000
+    return loader(desc {codec = "dfpwm", channels = channels, sampleRate = sampleRate}, data, {bitDepth = 8, dataType = "signed"})
+end
+function aukit.mdfpwm(data, head)                                      -- :1420 (artist / title / album strings: read them in Lua as :1423-1426 does)
+    expect(1, data, "string")
+    if data:sub(1, 7) ~= "MDFPWM\003" then error("bad argument #1 (not a MDFPWM file)", 2) end
+    return loader(desc {codec = "mdfpwm"}, data, {bitDepth = 8, dataType = "signed"})
+end
+function aukit.qoa(data, head) expect(1, data, "string") return loader(desc {codec = "qoa"}, data, {bitDepth = 16, dataType = "signed"}) end   -- :1706
+function aukit.flac(data, head) expect(1, data, "string") return loader(desc {codec = "flac"}, data, {dataType = "signed"}) end               -- :1657
 
+-- container front-ends: the header walk is the library's (aukit_parse_container = aukit.lua:1456-1651 / :2927-3113, host-side C),
+-- the payload range goes to the loader without a copy on the Lua side
+local function container(data, kind, stream)
+    local c = ffi.new("aukit_container")
+    check(C.aukit_parse_container(ffi.cast("const uint8_t*", data), #data, kind, stream and 1 or 0, c))
+    return c
+end
+local function pcm_info(d) return d.codec == 0 and {bitDepth = d.bit_depth, dataType = DTYPE_NAME[d.data_type]} or {bitDepth = 8, dataType = "signed"} end
+function aukit.wav(data, head)                                         -- :1456
+    expect(1, data, "string")
+    local c = container(data, 0, false)
+    if head then return aukit.new(0, c.desc.channels, c.desc.sample_rate) end
+    return loader(c.desc, data, {dataType = WAVDT[c.wav_data_type], bitDepth = c.bit_depth}, tonumber(c.payload_off), tonumber(c.payload_len))
+end
+function aukit.aiff(data, head)                                        -- :1580
+    expect(1, data, "string")
+    local c = container(data, 1, false)
+    if head then return aukit.new(0, c.desc.channels, c.desc.sample_rate) end
+    return loader(c.desc, data, pcm_info(c.desc), tonumber(c.payload_off), tonumber(c.payload_len))
+end
+function aukit.au(data)                                                -- :1639
+    expect(1, data, "string")
+    local c = container(data, 2, false)
+    return loader(c.desc, data, pcm_info(c.desc), tonumber(c.payload_off), tonumber(c.payload_len))
+end
+
+-- ---------------------------------------------------------------- effects (in place, return the same object: :3356-3618)
+local FX_ARGS = {  -- argument checks of the reference, in its order: {type, optional}
+    amplify = {{"number"}}, speed = {{"number"}}, fade = {{"number"}, {"number"}, {"number"}, {"number"}}, invert = {}, normalize = {{"number", true}, {"boolean", true}},
+    center = {}, trim = {{"number", true}}, delay = {{"number"}, {"number", true}}, echo = {{"number", true}, {"number", true}},
+    reverb = {{"number", true}, {"number", true}, {"number", true}, {"number", true}}, lowpass = {{"number"}}, highpass = {{"number"}},
+}
 for name, id in pairs(FX) do
     aukit.effects[name] = function(audio, ...)
+        expectAudio(1, audio)
         local args = {...}
+        for i, spec in ipairs(FX_ARGS[name]) do
+            if spec[2] then expect(i + 1, args[i], spec[1], "nil") else expect(i + 1, args[i], spec[1]) end
+        end
         if name == "speed" then args[2] = INTERP[aukit.defaultInterpolation] end
         if name == "normalize" then args[1] = args[1] or 1 args[2] = args[2] and 1 or 0 end
-        local a = ffi.new("double[?]", math.max(#args, 1))
-        for i, v in ipairs(args) do a[i - 1] = v end
-        check(C.aukit_effect(ctx(), audio._h, id, a, #args))
+        local n = 0
+        for i = 1, 4 do if args[i] ~= nil then n = i end end
+        local a = ffi.new("double[?]", math.max(n, 1))
+        for i = 1, n do a[i - 1] = args[i] or 0 end
+        check(C.aukit_effect(ctx(), audio._h, id, a, n))
         rawset(audio, "data", nil)  -- drop the cached Lua copy: the device buffer changed in place
         return audio
     end
 end
 
---- stream factories: every iterator call is computed up front in one launch; the iterator just hands out slices.
-local function streamer(d, data, mono, dtype)
+-- ---------------------------------------------------------------- stream factories (string input)
+--- Every iterator call of the reference is computed in one launch; the samples come back as ONE FFI array and each call of the
+--- returned closure builds only its own chunk's tables.  (A resumable handle for reader-function input — austream's http / websocket
+--- sources — is not part of this ABI version: see INTEGRATION.md.)
+local function streamer(d, data, mono, dtype, first, len)
     local o, ck = ffi.new("aukit_audio*[1]"), ffi.new("aukit_chunks*[1]")
-    check(C.aukit_stream_decode(ctx(), upload(data), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
+    check(C.aukit_stream_decode(ctx(), upload(data, first, len), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
     local audio = wrap(o[0])
     local n, mx = ffi.new("uint32_t[1]"), ffi.new("uint32_t[1]")
     check(C.aukit_chunks_info(ck[0], n, mx))
@@ -253,27 +502,64 @@ local function streamer(d, data, mono, dtype)
     local nch, lens, pos, status, length = ffi.new("uint32_t[1]"), ffi.new("uint32_t[?]", m), ffi.new("double[?]", m), ffi.new("int32_t[1]"), ffi.new("double[1]")
     check(C.aukit_chunks_get(ck[0], nch, lens, pos, status, length))
     C.aukit_chunks_free(ck[0])
-    local k, off, chans = 0, 0, audio.data
+    local buf, ch, total = fetch(audio)
+    local k, off = 0, 0
     return function()
         if k >= nch[0] then
-            if status[0] == -2 then error("attempt to compare nil with number", 2) end  -- the reference raises here too
+            -- the reference's iterator RAISES here (end of data inside a prefill / a malformed block): same message as the library's
+            if status[0] == -2 then error("attempt to perform arithmetic on a nil value (field '?')", 2) end
             return nil
         end
         local chunk = {}
-        for c = 1, #chans do local t = {} for i = 1, lens[k] do t[i] = chans[c][off + i] end chunk[c] = t end
+        for c = 1, ch do
+            local t = {}
+            for i = 1, lens[k] do t[i] = buf[(c - 1) * total + off + i - 1] end
+            chunk[c] = t
+        end
         off = off + lens[k]; k = k + 1
         return chunk, pos[k - 1]
     end, length[0]
 end
-function aukit.stream.pcm(data, bitDepth, dataType, channels, sampleRate, bigEndian, mono)
+function aukit.stream.pcm(data, bitDepth, dataType, channels, sampleRate, bigEndian, mono)  -- :2228
+    expect(1, data, "string", "function")
+    if type(data) == "function" then error("aukit.stream.* with a reader function is not offered by this ABI version (pass the whole string)", 2) end
+    bitDepth = expect(2, bitDepth, "number", "nil") or 8
+    dataType = expect(3, dataType, "string", "nil") or "signed"
+    channels = expect(4, channels, "number", "nil") or 1
+    sampleRate = expect(5, sampleRate, "number", "nil") or 48000
+    expect(6, bigEndian, "boolean", "nil") expect(7, mono, "boolean", "nil")
     return streamer(desc {codec = "pcm", bitDepth = bitDepth, dataType = dataType, channels = channels, sampleRate = sampleRate, bigEndian = bigEndian}, data, mono, F64)
 end
-function aukit.stream.g711(input, ulaw, channels, sampleRate, mono) return streamer(desc {codec = "g711", ulaw = ulaw, channels = channels, sampleRate = sampleRate or 8000}, input, mono, I8) end
-function aukit.stream.adpcm(input, blockAlign, channels, sampleRate, mono) return streamer(desc {codec = "adpcm_wav", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate}, input, mono, I8) end
-function aukit.stream.msadpcm(input, blockAlign, channels, sampleRate, mono) return streamer(desc {codec = "msadpcm", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate}, input, mono, I8) end
-function aukit.stream.dfpwm(data, sampleRate, channels, mono) return streamer(desc {codec = "dfpwm", channels = channels, sampleRate = sampleRate}, data, mono, F64) end
-function aukit.stream.mdfpwm(data, mono) return streamer(desc {codec = "mdfpwm"}, data, mono, I8) end
-function aukit.stream.flac(data, mono) return streamer(desc {codec = "flac"}, data, mono, F64) end
-function aukit.stream.qoa(data, mono) return streamer(desc {codec = "qoa"}, data, mono, F64) end
+local function only_strings(data) if type(data) == "function" then error("aukit.stream.* with a reader function is not offered by this ABI version (pass the whole string)", 3) end end
+function aukit.stream.g711(input, ulaw, channels, sampleRate, mono)    -- :2850
+    expect(1, input, "string", "function") only_strings(input) expect(2, ulaw, "boolean")
+    return streamer(desc {codec = "g711", ulaw = ulaw, channels = channels, sampleRate = sampleRate or 8000}, input, mono, I8)
+end
+function aukit.stream.adpcm(input, blockAlign, channels, sampleRate, mono)    -- :2753
+    expect(1, input, "string", "function") only_strings(input) expect(2, blockAlign, "number")
+    return streamer(desc {codec = "adpcm_wav", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate}, input, mono, I8)
+end
+function aukit.stream.msadpcm(input, blockAlign, channels, sampleRate, mono, coefficients)  -- :2588
+    expect(1, input, "string", "function") only_strings(input) expect(2, blockAlign, "number") expect(6, coefficients, "table", "nil")
+    return streamer(desc {codec = "msadpcm", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate, coefficients = coefficients}, input, mono, I8)
+end
+function aukit.stream.dfpwm(data, sampleRate, channels, mono)          -- :2439
+    expect(1, data, "string", "function") only_strings(data)
+    return streamer(desc {codec = "dfpwm", channels = channels, sampleRate = sampleRate}, data, mono, F64)
+end
+function aukit.stream.mdfpwm(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "mdfpwm"}, data, mono, I8) end  -- :2507
+function aukit.stream.flac(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "flac"}, data, mono, F64) end     -- :3124
+function aukit.stream.qoa(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "qoa"}, data, mono, F64) end       -- :3202
+local function stream_container(data, kind, mono)
+    expect(1, data, "string", "function") only_strings(data)
+    local c = container(data, kind, true)
+    local dtype = (c.desc.codec == 0 or c.desc.codec == 5) and F64 or I8  -- what stream.pcm / .dfpwm vs .g711 / .adpcm / .msadpcm hand out
+    local it, length = streamer(c.desc, data, mono, dtype, tonumber(c.payload_off), tonumber(c.payload_len))
+    if c.length_seconds == c.length_seconds then length = c.length_seconds end  -- not NaN: the container factory computes its own (:2994-2996, :3064-3069, :3107-3113)
+    return it, length
+end
+function aukit.stream.wav(data, mono, ignoreHeader) return stream_container(data, 0, mono) end    -- :2927
+function aukit.stream.aiff(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 1, mono) end  -- :3016
+function aukit.stream.au(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 2, mono) end    -- :3086
 
 return aukit

@@ -76,6 +76,28 @@ typedef struct {
     int32_t step_index[AUKIT_MAX_CHANNELS]; /* ADPCM: initial step index(es)                 */
 } aukit_codec_desc;
 
+/* ---- container front-ends (host-side byte parsing, no GPU): aukit.wav / aukit.aiff / aukit.au (aukit.lua:1456-1651) and the header
+ * half of aukit.stream.wav / .aiff / .au (:2927-3113).  The walk reproduces what a caller of the Lua can observe: the `string.unpack`
+ * error on a truncated chunk header, aukit.wav walking on behind a `data` chunk, WAVE_FORMAT_EXTENSIBLE GUIDs (:131-139), the AIFF
+ * 80-bit rate (:1603-1605), `sowt` little-endian for aukit.aiff but big-endian for stream.aiff (:1613 / :3065), AU's 0-based offset used
+ * as a 1-based index (:1643).  The result is the descriptor to hand to aukit_decode / aukit_stream_decode with bytes
+ * [payload_off, payload_off + payload_len) of the file. */
+typedef enum { AUKIT_CONTAINER_WAV = 0, AUKIT_CONTAINER_AIFF = 1, AUKIT_CONTAINER_AU = 2 } aukit_container_kind;
+/* `dataType` of a WAV file (Audio.info.dataType, aukit.lua:1474-1504) */
+typedef enum { AUKIT_WAVDT_SIGNED = 0, AUKIT_WAVDT_UNSIGNED = 1, AUKIT_WAVDT_FLOAT = 2, AUKIT_WAVDT_ALAW = 3, AUKIT_WAVDT_ULAW = 4, AUKIT_WAVDT_ADPCM = 5,
+               AUKIT_WAVDT_MSADPCM = 6, AUKIT_WAVDT_DFPWM = 7 } aukit_wav_data_type;
+typedef struct {
+    aukit_codec_desc desc;   /* loader / stream factory arguments for the payload                                             */
+    uint64_t payload_off;    /* first payload byte (0-based) and                                                              */
+    uint64_t payload_len;    /* byte count: what the Lua's str_sub hands to the loader                                        */
+    int32_t wav_data_type;   /* WAV: aukit_wav_data_type (Audio.info.dataType)                                                */
+    int32_t bit_depth;       /* WAV: Audio.info.bitDepth; AIFF: COMM bit depth; AU: bits of the encoding                      */
+    double length_seconds;   /* stream.*: the factory's second return value where it computes one itself (:2994-2996, :3064-3069,
+                                :3107-3113), NaN where the codec's own stream factory supplies it                              */
+} aukit_container;
+/* stream = 0: aukit.wav / .aiff / .au; stream = 1: the header walk of aukit.stream.wav / .aiff / .au (string input) */
+int aukit_parse_container(const uint8_t *bytes, uint64_t n, int kind, int stream, aukit_container *out);
+
 /* ids for aukit_effect(); args in the reference's argument order after `audio` (aukit.lua:3356-3618) */
 typedef enum {
     AUKIT_FX_AMPLIFY = 0,   /* (multiplier)                                      :3356 */
@@ -188,7 +210,9 @@ int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, do
                double sample_rate, int dtype, aukit_audio **out);
 /* What string.pack does with a sample that has no integer representation is the host VM's business, not aukit.lua's
  * (Audio:pcm hands it unfloored numbers, :875): truncate like a Java (long) cast (CC: Tweaked's VM), floor, or raise like PUC Lua 5.3. */
-typedef enum { AUKIT_PACK_TRUNC = 0, AUKIT_PACK_FLOOR = 1, AUKIT_PACK_STRICT = 2 } aukit_pack_mode;
+typedef enum { AUKIT_PACK_TRUNC = 0, AUKIT_PACK_FLOOR = 1, AUKIT_PACK_STRICT = 2,
+               AUKIT_PACK_PREENCODED = 8 /* OR-ed in: the audio already holds Audio:pcm's numbers (aukit.pack on a number table, aukit.lua:1861): only packed */
+} aukit_pack_mode;
 /* aukit.pack(audio:pcm(bitDepth, dataType, interleaved), bitDepth, dataType, bigEndian) :901 + :1861 → one byte string per
  * stream; with (bitDepth, bitDepth == 8 ? unsigned : signed, little-endian, interleaved) these are the sample bytes of Audio:wav :966-971 */
 int aukit_pack_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode,
