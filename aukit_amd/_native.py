@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 if os.environ.get("AUKIT_LIB"):  # A/B of library builds on one box (tools/build_variant.sh): never set in tests or by the driver
     LIB_PATH = os.path.abspath(os.environ["AUKIT_LIB"])
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "container.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "container.hip", "stream_handle.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "qoa_stream.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
 HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "resample_dev.h", "dfpwm_dev.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -28,6 +28,7 @@ MAX_CH = 8
 OPT_EXACT_MATH, OPT_STORE_X4 = 0, 1
 WAVE_NONE, WAVE_SINE, WAVE_TRIANGLE, WAVE_SAWTOOTH, WAVE_SQUARE = 0, 1, 2, 3, 4
 PACK_TRUNC, PACK_FLOOR, PACK_STRICT = 0, 1, 2
+STREAM_CHUNK, STREAM_NEED_INPUT, STREAM_END = 0, 1, 2
 
 # every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -40,6 +41,7 @@ EXPORTS = [
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
     "aukit_parse_container", "aukit_decode", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
+    "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_close",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
 ]
 
@@ -125,7 +127,7 @@ def lib():
     L.aukit_audio_device_ptr.restype = C.c_void_p
     L.aukit_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.aukit_batch_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
-    for name in ("aukit_ctx_destroy", "aukit_batch_free", "aukit_audio_free", "aukit_chunks_free"):
+    for name in ("aukit_ctx_destroy", "aukit_batch_free", "aukit_audio_free", "aukit_chunks_free", "aukit_stream_close"):
         getattr(L, name).restype = None
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L

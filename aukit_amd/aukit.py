@@ -59,6 +59,13 @@ def _expect(n, v, *types):
     raise LuaError(f"bad argument #{n} (expected {want}, got {got})")
 
 
+def _expect_src(n, v):
+    """aukit.stream.*: `string | function` (a reader returning strings, then nil)"""
+    if callable(v):
+        return v
+    return _expect(n, v, "string", "function")
+
+
 def _interp(name, argn=2):
     if name not in N.INTERP:
         raise LuaError(f"bad argument #{argn} (invalid interpolation type)")
@@ -349,10 +356,15 @@ def _parse(data, kind, stream=False):
     import ctypes as C
     buf = bytes(data)
     c = N.Container()
-    rc = N.lib().aukit_parse_container(buf, C.c_uint64(len(buf)), kind, int(bool(stream)), C.byref(c))
+    rc = N.lib().aukit_parse_container(buf, C.c_uint64(len(buf)), kind, int(stream), C.byref(c))
     if rc:
         raise LuaError(N.lib().aukit_last_error().decode(errors="replace"))
     return c, buf[c.payload_off:c.payload_off + c.payload_len]
+
+
+def _parse_first_piece(data, kind):
+    """header walk on the first piece of a reader function (aukit_parse_container mode 2)"""
+    return _parse(data, kind, stream=2)
 
 
 def _desc_copy(c):
@@ -452,7 +464,37 @@ class _StreamNS:
     """Iterator factories: `it, length = aukit.stream.pcm(...)`; `for chunk, pos in it` (chunk = list of per-channel arrays)."""
 
     @staticmethod
+    def _run_fn(desc, fn, first, mono, dtype, length_override=None):
+        """reader-function input (aukit.lua:2776-2786 ...): `first` is what the first fn() call returned, the rest is pulled as chunks run out.
+        The chunks are those of the string version for the concatenated input (the library's resumable handle)."""
+        ctx = context()
+        h = _wrap(B.StreamHandle, ctx, desc, _interp(defaultInterpolation, 0), bool(mono), dtype)
+        _wrap(h.feed, first)
+
+        def it():
+            done = False
+            while True:
+                kind, chans, pos = _wrap(h.next)
+                if kind == "chunk":
+                    yield chans, pos
+                elif kind == "end":
+                    h.close()
+                    return
+                else:  # need input
+                    piece = None if done else fn()
+                    if piece is None:
+                        done = True
+                        _wrap(h.finish)
+                    else:
+                        _wrap(h.feed, piece)
+        return it(), (_wrap(h.length) if length_override is None else length_override)
+
+    @staticmethod
     def _run(desc, data, mono, dtype, length_override=None, endless_empty=False):
+        if callable(data):
+            first = data()
+            _expect(1, first, "string")
+            return _StreamNS._run_fn(desc, data, first, mono, dtype, length_override)
         ctx = context()
         bt = _wrap(B.Batch.upload, ctx, [data])
         out, ck = _wrap(B.stream_decode, ctx, bt, desc, _interp(defaultInterpolation, 0), bool(mono), dtype)
@@ -472,7 +514,7 @@ class _StreamNS:
         return it(), (float(ck.length_seconds[0]) if length_override is None else length_override)
 
     def pcm(self, data, bitDepth=None, dataType=None, channels=None, sampleRate=None, bigEndian=None, mono=None):
-        _expect(1, data, "string")
+        _expect_src(1, data)
         bitDepth = 8 if bitDepth is None else bitDepth
         dataType = "signed" if dataType is None else dataType
         if dataType not in ("signed", "unsigned", "float"):
@@ -481,60 +523,67 @@ class _StreamNS:
         return self._run(d, data, mono, N.F64)
 
     def dfpwm(self, data, sampleRate=None, channels=None, mono=None):
-        _expect(1, data, "string")
+        _expect_src(1, data)
         d = B.make_desc(N.CODEC_DFPWM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate)
         return self._run(d, data, mono, N.F64)
 
     def mdfpwm(self, data, mono=None):
-        _expect(1, data, "string")
+        _expect_src(1, data)
         if bytes(data[:7]) != b"MDFPWM\x03":
             raise LuaError("bad argument #1 (invalid MDFPWM data)")
         return self._run(B.make_desc(N.CODEC_MDFPWM), data, mono, N.I8)
 
     def msadpcm(self, input, blockAlign, channels=None, sampleRate=None, mono=None, coefficients=None):
-        _expect(1, input, "string")
+        _expect_src(1, input)
         _expect(2, blockAlign, "number")
         d = B.make_desc(N.CODEC_MSADPCM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, block_align=blockAlign, coefficients=coefficients)
         return self._run(d, input, mono, N.I8)
 
     def adpcm(self, input, blockAlign, channels=None, sampleRate=None, mono=None):
-        _expect(1, input, "string")
+        _expect_src(1, input)
         _expect(2, blockAlign, "number")
         d = B.make_desc(N.CODEC_ADPCM_WAV, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, block_align=blockAlign)
         return self._run(d, input, mono, N.I8)
 
     def g711(self, input, ulaw, channels=None, sampleRate=None, mono=None):
-        _expect(1, input, "string")
+        _expect_src(1, input)
         _expect(2, ulaw, "boolean")
         d = B.make_desc(N.CODEC_G711, 1 if channels is None else channels, 8000 if sampleRate is None else sampleRate, ulaw=ulaw)
         return self._run(d, input, mono, N.I8, endless_empty=True)
 
     def flac(self, data, mono=None):
-        _expect(1, data, "string")
+        _expect_src(1, data)
         return self._run(B.make_desc(N.CODEC_FLAC), data, mono, N.F64)
 
     def qoa(self, data, mono=None):
-        _expect(1, data, "string")
+        _expect_src(1, data)
         return self._run(B.make_desc(N.CODEC_QOA), data, mono, N.F64)
 
     def _container(self, data, kind, mono):
-        c, p = _parse(data, kind, stream=True)
+        fn = None
+        if callable(data):  # "the first chunk MUST contain the ENTIRE header" (:2918): the header walk runs on it, the payload that follows it is the first piece
+            fn, data = data, data()
+            _expect(1, data, "string")
+        c, p = _parse(data, kind, stream=True) if fn is None else _parse_first_piece(data, kind)
         d = _desc_copy(c)
         dtype = N.F64 if d.codec in (N.CODEC_PCM, N.CODEC_DFPWM) else N.I8  # what stream.pcm / .dfpwm vs .g711 / .adpcm / .msadpcm hand out
-        it, length = self._run(d, p, mono, dtype, endless_empty=d.codec == N.CODEC_G711)
+        if fn is not None:
+            it, length = self._run_fn(d, fn, p, mono, dtype)
+        else:
+            it, length = self._run(d, p, mono, dtype, endless_empty=d.codec == N.CODEC_G711)
         return it, (length if math.isnan(c.length_seconds) else c.length_seconds)
 
     def wav(self, data, mono=None, ignoreHeader=None):  # :2927: header walk (library) + dispatch (:2992-2996)
-        _expect(1, data, "string")
+        _expect_src(1, data)
         return self._container(data, N.CONTAINER_WAV, mono)
 
     def aiff(self, data, mono=None, ignoreHeader=None):  # :3016
-        _expect(1, data, "string")
+        _expect_src(1, data)
         _expect(2, mono, "boolean", "nil")
         return self._container(data, N.CONTAINER_AIFF, mono)
 
     def au(self, data, mono=None, ignoreHeader=None):  # :3086
-        _expect(1, data, "string")
+        _expect_src(1, data)
         _expect(2, mono, "boolean", "nil")
         return self._container(data, N.CONTAINER_AU, mono)
 

@@ -383,3 +383,49 @@ def stream_decode(ctx, batch, desc, interp, mono=False, dtype=None, out=None):
     N.check(N.lib().aukit_stream_decode(ctx._h, batch._h, C.byref(desc), _interp(interp), int(bool(mono)),
                                         ctx.dtype if dtype is None else dtype, C.byref(out._h), C.byref(ch)))
     return out, Chunks(ch)
+
+
+class StreamHandle:
+    """aukit.stream.<codec> fed piece by piece (aukit_stream_open / feed / finish / next): the chunks are those of the string version for the
+    concatenation of everything fed, whatever the feeding pattern (include/aukit_hip.h)."""
+
+    def __init__(self, ctx, desc, interp, mono=False, dtype=None, cap=1 << 20):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self._cap = int(cap)
+        N.check(N.lib().aukit_stream_open(ctx._h, C.byref(desc), _interp(interp), int(bool(mono)), ctx.dtype if dtype is None else dtype, C.byref(self._h)))
+
+    def feed(self, data):
+        b = bytes(data)
+        N.check(N.lib().aukit_stream_feed(self._h, b, C.c_uint64(len(b))))
+
+    def finish(self):
+        N.check(N.lib().aukit_stream_finish(self._h))
+
+    def next(self):
+        """→ ("chunk", [per-channel float64 arrays], pos) | ("need_input", None, None) | ("end", None, None)"""
+        buf = np.zeros(self._cap * AUKIT_MAX_CH, dtype=np.float64)
+        ln, ch, st, pos = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_double()
+        N.check(N.lib().aukit_stream_next(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint32(self._cap), C.byref(ln), C.byref(ch), C.byref(pos), C.byref(st)))
+        if st.value == N.STREAM_CHUNK:
+            return "chunk", [buf[c * self._cap: c * self._cap + ln.value].copy() for c in range(ch.value)], pos.value
+        return ("need_input" if st.value == N.STREAM_NEED_INPUT else "end"), None, None
+
+    def length(self):
+        s = C.c_double()
+        N.check(N.lib().aukit_stream_length(self._h, C.byref(s)))
+        return s.value
+
+    def close(self):
+        if self._h:
+            N.lib().aukit_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+AUKIT_MAX_CH = N.MAX_CH

@@ -71,7 +71,9 @@ void lua_sub(uint64_t n, double i, double j, uint64_t *off, uint64_t *len) {
     *len = (uint64_t)j - (uint64_t)i + 1;
 }
 
-int parse_wav(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o) {
+// stream: 0 = aukit.wav, 1 = aukit.stream.wav on a string, 2 = on the first piece of a reader function (`fn` set: the size checks of
+// :2977 / :3046 do not apply, the payload is what the piece holds)
+int parse_wav(const uint8_t *bytes, uint64_t n, int stream, aukit_container *o) {
     Rd r{bytes, n};
     if (!r.have(1, 4)) return fail(AUKIT_E_LUA, "%s", kShort);
     if (memcmp(bytes, "RIFF", 4) != 0) return fail(AUKIT_E_ARG, "bad argument #1 (not a WAV file)");
@@ -128,7 +130,7 @@ int parse_wav(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o)
         } else if (memcmp(tg, "data", 4) == 0) {
             uint64_t off, len;
             lua_sub(n, (double)pos, (double)pos + (double)size - 1, &off, &len);
-            if (len < size) return fail(AUKIT_E_LUA, "invalid WAV file");
+            if (len < size && stream != 2) return fail(AUKIT_E_LUA, "invalid WAV file");
             if (!have_fmt) return fail(AUKIT_E_ARG, "bad argument #2 (expected number, got nil)");  // aukit.pcm(data, nil, ...): the first check that fails
             desc_from_wav(o, dt, channels, rate, bits, block_align);
             o->payload_off = off; o->payload_len = len;
@@ -158,7 +160,7 @@ int parse_wav(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o)
     return fail(AUKIT_E_LUA, "invalid WAV file");
 }
 
-int parse_aiff(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o) {
+int parse_aiff(const uint8_t *bytes, uint64_t n, int stream, aukit_container *o) {
     Rd r{bytes, n};
     if (!r.have(1, 4)) return fail(AUKIT_E_LUA, "%s", kShort);
     if (memcmp(bytes, "FORM", 4) != 0) return fail(AUKIT_E_ARG, "bad argument #1 (not an AIFF file)");
@@ -207,7 +209,7 @@ int parse_aiff(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o
             if (!have_comm) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (local 'length')");
             uint64_t off, len;
             lua_sub(n, (double)pos + offset, (double)pos + offset + length - 1, &off, &len);
-            if (stream && (double)len < length) return fail(AUKIT_E_LUA, "invalid AIFF file");
+            if (stream == 1 && (double)len < length) return fail(AUKIT_E_LUA, "invalid AIFF file");
             aukit_codec_desc &d = o->desc;
             d.channels = channels; d.sample_rate = rate; d.interleaved = 1;
             o->bit_depth = bits;
@@ -233,7 +235,7 @@ int parse_aiff(const uint8_t *bytes, uint64_t n, bool stream, aukit_container *o
     return fail(AUKIT_E_LUA, "invalid AIFF file");
 }
 
-int parse_au(const uint8_t *bytes, uint64_t n, bool, aukit_container *o) {
+int parse_au(const uint8_t *bytes, uint64_t n, int, aukit_container *o) {
     Rd r{bytes, n};
     if (!r.have(1, 24)) return fail(AUKIT_E_LUA, "%s", kShort);  // ">c4IIIII"
     if (memcmp(bytes, ".snd", 4) != 0) return fail(AUKIT_E_LUA, "invalid AU file");
@@ -263,9 +265,9 @@ extern "C" int aukit_parse_container(const uint8_t *bytes, uint64_t n, int kind,
     memset(out, 0, sizeof *out);
     out->length_seconds = std::nan("");
     switch (kind) {
-    case AUKIT_CONTAINER_WAV: return parse_wav(bytes, n, stream != 0, out);
-    case AUKIT_CONTAINER_AIFF: return parse_aiff(bytes, n, stream != 0, out);
-    case AUKIT_CONTAINER_AU: return parse_au(bytes, n, stream != 0, out);
+    case AUKIT_CONTAINER_WAV: return parse_wav(bytes, n, stream, out);
+    case AUKIT_CONTAINER_AIFF: return parse_aiff(bytes, n, stream, out);
+    case AUKIT_CONTAINER_AU: return parse_au(bytes, n, stream, out);
     }
     return fail(AUKIT_E_ARG, "unknown container kind %d", kind);
 }

@@ -1,0 +1,178 @@
+// stream_handle.hip — a resumable stream: aukit.stream.* fed piece by piece (the reader-FUNCTION input of the reference, aukit.lua:2776-2786
+// and its siblings; austream.lua:19-64 feeds http / websocket / file readers).
+//
+// The reference's function-input mode hands out whatever the reader's buffering happens to produce: the chunk boundaries of
+// aukit.stream.adpcm(fn, ...) depend on how many bytes each fn() call returned — there is no single answer to reproduce.
+// This handle gives the one well-defined answer: the chunks it delivers are EXACTLY the chunks aukit.stream.*(s, ...) delivers for the string
+// s = everything fed so far and later, whatever the feeding pattern.  It does that by brute force made affordable by the GPU: the bytes
+// accumulate in a device buffer (only the new ones travel), and whenever a chunk is asked for that is not decided yet the whole prefix is
+// run through aukit_stream_decode again (ten minutes of 44.1 kHz stereo: about a millisecond).  A chunk is decided once a later chunk
+// exists — every iterator call of the reference consumes a fixed slice of its input, so a call that was followed by another one had all
+// the input it wanted (tests/test_gpu_stream_handle.py checks this against the string result for every codec at random split points) —
+// or once aukit_stream_finish has declared the input complete.  Only decided chunks are copied to the host, each once.
+#include <algorithm>
+#include "common.h"
+
+struct aukit_stream {
+    aukit_ctx *ctx = nullptr;
+    aukit_codec_desc desc{};
+    int interp = 0, mono = 0, dtype = AUKIT_F64;
+    uint8_t *dbuf = nullptr;   // device: everything fed so far
+    size_t dcap = 0, fed = 0;
+    bool finished = false, dirty = true;
+    aukit_audio *out = nullptr;       // last decode of the prefix
+    aukit_chunks *ck = nullptr;
+    uint32_t delivered = 0;
+    uint64_t delivered_samples = 0;   // per channel
+    uint64_t decoded_at = ~0ull;      // `fed` when the prefix was last decoded
+};
+
+namespace aukit {
+static int grow(aukit_stream *h, size_t need) {
+    if (need <= h->dcap) return AUKIT_OK;
+    size_t cap = std::max<size_t>(need + need / 2 + 4096, 1 << 16);
+    uint8_t *nb = nullptr;
+    hipError_t e = hipMalloc((void **)&nb, cap + 64);
+    if (e != hipSuccess) return fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    if (h->fed) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf, h->fed, hipMemcpyDeviceToDevice, h->ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    if (h->dbuf) (void)hipFree(h->dbuf);
+    h->dbuf = nb;
+    h->dcap = cap;
+    return AUKIT_OK;
+}
+static int redecode(aukit_stream *h) {
+    // an unfinished prefix may end inside a sample frame, which the string version refuses (:1064 and the G.711 / stream.pcm frame checks):
+    // decode the whole frames only — the rest joins them with the next piece
+    uint64_t usable = h->fed;
+    if (!h->finished) {
+        const uint64_t C = (uint64_t)std::max(h->desc.channels, 1);
+        if (h->desc.codec == AUKIT_CODEC_PCM) usable -= usable % (C * (uint64_t)std::max(h->desc.bit_depth / 8, 1));
+        else if (h->desc.codec == AUKIT_CODEC_G711 || h->desc.codec == AUKIT_CODEC_DFPWM) usable -= usable % C;
+        else if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.block_align > 0) usable -= usable % (uint64_t)h->desc.block_align;  // a partial block raises (:2640)
+    }
+    const uint64_t off[2] = {0, usable};
+    aukit_batch *b = nullptr;
+    int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
+    if (rc) return rc;
+    aukit_chunks *ck = nullptr;
+    rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->out, &ck);
+    if (!rc) rc = aukit_ctx_sync(h->ctx);
+    aukit_batch_free(b);
+    if (rc) { if (ck) aukit_chunks_free(ck); return rc; }
+    if (h->ck) aukit_chunks_free(h->ck);
+    h->ck = ck;
+    h->decoded_at = h->fed;
+    h->dirty = false;
+    return AUKIT_OK;
+}
+}  // namespace aukit
+
+using namespace aukit;
+
+extern "C" {
+
+int aukit_stream_open(aukit_ctx *ctx, const aukit_codec_desc *desc, int interp, int mono, int dtype, aukit_stream **out) {
+    if (!ctx || !desc || !out) return fail(AUKIT_E_ARG, "null argument");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
+    aukit_stream *h = new aukit_stream();
+    h->ctx = ctx; h->desc = *desc; h->interp = interp; h->mono = mono ? 1 : 0; h->dtype = dtype;
+    *out = h;
+    return AUKIT_OK;
+}
+
+int aukit_stream_feed(aukit_stream *h, const uint8_t *bytes, uint64_t n) {
+    if (!h || (!bytes && n)) return fail(AUKIT_E_ARG, "null argument");
+    if (h->finished) return fail(AUKIT_E_ARG, "aukit_stream_feed after aukit_stream_finish");
+    if (!n) return AUKIT_OK;
+    AUKIT_HIP_CHECK(hipSetDevice(h->ctx->device));
+    int rc = grow(h, h->fed + n);
+    if (rc) return rc;
+    AUKIT_HIP_CHECK(hipMemcpyAsync(h->dbuf + h->fed, bytes, n, hipMemcpyHostToDevice, h->ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));  // the caller may reuse `bytes`
+    h->fed += n;
+    h->dirty = true;
+    return AUKIT_OK;
+}
+
+int aukit_stream_finish(aukit_stream *h) {
+    if (!h) return fail(AUKIT_E_ARG, "null argument");
+    h->finished = true;
+    h->dirty = true;  // the complete input is decoded once more: its last chunk(s) and its end status are now final
+    return AUKIT_OK;
+}
+
+// One chunk per call, in order.  *state: AUKIT_STREAM_CHUNK — `*len` samples of each of `*channels` channels were written to dst
+// (channel c at dst + c * cap; cap >= 48000 always suffices... see aukit_stream_peek for the size), `*pos` is the iterator's second return value;
+// AUKIT_STREAM_NEED_INPUT — nothing is decided yet: feed more or finish; AUKIT_STREAM_END — the iterator has returned nil.  Where the
+// reference's iterator RAISES instead of returning nil (end of data inside a prefill, a malformed block) the call that would have raised
+// returns AUKIT_E_LUA with the reference's message.
+int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state) {
+    if (!h || !len || !state) return fail(AUKIT_E_ARG, "null argument");
+    AUKIT_HIP_CHECK(hipSetDevice(h->ctx->device));
+    *len = 0;
+    auto decided = [&]() -> uint32_t {  // chunks of the last decode that no further input can change
+        if (!h->ck) return 0;
+        const uint32_t nch = h->ck->nchunks.empty() ? 0 : h->ck->nchunks[0];
+        return h->finished ? nch : (nch ? nch - 1 : 0);
+    };
+    if (h->delivered >= decided() && (h->dirty || h->decoded_at != h->fed || !h->ck)) {
+        int rc = redecode(h);
+        if (rc && h->finished) return rc;  // the string version's own error for these bytes
+        if (rc) {  // a prefix the string version cannot take (it ends inside a header, a frame ...): nothing new is decided — more input, or finish, settles it
+            h->dirty = false;
+            h->decoded_at = h->fed;
+        }
+    }
+    const uint32_t avail = decided();
+    if (h->delivered >= avail) {
+        if (!h->finished) { *state = AUKIT_STREAM_NEED_INPUT; return AUKIT_OK; }
+        if (h->ck && !h->ck->status.empty() && h->ck->status[0] == AUKIT_E_LUA) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        *state = AUKIT_STREAM_END;
+        return AUKIT_OK;
+    }
+    const uint32_t k = h->delivered;
+    const uint32_t n = h->ck->lens[k];
+    const int C = h->out->channels;
+    if (channels) *channels = C;
+    if (pos) *pos = h->ck->pos[k];
+    if (n > cap) { *len = n; return fail(AUKIT_E_ARG, "chunk of %u samples does not fit the %u offered", n, cap); }
+    if (n && !dst) return fail(AUKIT_E_ARG, "null argument");
+    const size_t esz = dtype_size(h->out->dtype);
+    std::vector<unsigned char> tmp((size_t)n * C * esz + 8);
+    for (int c = 0; c < C && n; c++) {
+        const char *src = reinterpret_cast<const char *>(h->out->dev) + (h->out->row_off[0] + (uint64_t)c * h->out->row_stride[0] + h->delivered_samples) * esz;
+        AUKIT_HIP_CHECK(hipMemcpyAsync(tmp.data() + (size_t)c * n * esz, src, (size_t)n * esz, hipMemcpyDeviceToHost, h->ctx->stream));
+    }
+    AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    for (int c = 0; c < C; c++)
+        for (uint32_t i = 0; i < n; i++) {
+            const size_t e = (size_t)c * n + i;
+            dst[(size_t)c * cap + i] = h->out->dtype == AUKIT_F64 ? reinterpret_cast<const double *>(tmp.data())[e]
+                                     : h->out->dtype == AUKIT_F32 ? (double)reinterpret_cast<const float *>(tmp.data())[e] : (double)reinterpret_cast<const signed char *>(tmp.data())[e];
+        }
+    *len = n;
+    *state = AUKIT_STREAM_CHUNK;
+    h->delivered++;
+    h->delivered_samples += n;
+    return AUKIT_OK;
+}
+
+// the total length in seconds the stream factory returns as its second value, for what has been fed so far (meaningful after finish, or
+// for codecs whose header carries it)
+int aukit_stream_length(aukit_stream *h, double *seconds) {
+    if (!h || !seconds) return fail(AUKIT_E_ARG, "null argument");
+    if (!h->ck || h->dirty) { int rc = redecode(h); if (rc) return rc; }
+    *seconds = h->ck->length_seconds.empty() ? 0.0 : h->ck->length_seconds[0];
+    return AUKIT_OK;
+}
+
+void aukit_stream_close(aukit_stream *h) {
+    if (!h) return;
+    if (h->ck) aukit_chunks_free(h->ck);
+    if (h->out) aukit_audio_free(h->out);
+    if (h->dbuf) (void)hipFree(h->dbuf);
+    delete h;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@
 --- Audio:len / :channels / :resample :653 / :mono :677 / :concat :695 / :sub :725 / :combine :751 / :split :781 / :mix :804 /
 --- :rep :839 / :reverse :856 / :pcm :901 / :stream :921 / :wav :954 / :dfpwm :1005; aukit.stream.* :2228-3337; aukit.effects.* :3356-3618.
 --- Left to the reference's own Lua (not on the path: SURVEY.md §8): aukit.play / Player, aukit.noise (draws from the VM's math.random),
---- aukit.detect, metadata (LIST / ID3) reading and writing, reader-FUNCTION inputs of aukit.stream.* (strings only here).
+--- aukit.detect, metadata (LIST / ID3) reading and writing.
 local ffi = require "ffi"
 
 ffi.cdef [[
@@ -47,6 +47,11 @@ int aukit_pack_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_typ
 int aukit_stream_decode(aukit_ctx *, const aukit_batch *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_chunks_info(const aukit_chunks *, uint32_t *n, uint32_t *max_chunks);
 int aukit_chunks_get(const aukit_chunks *, uint32_t *nchunks, uint32_t *lens, double *pos, int32_t *status, double *length_seconds); void aukit_chunks_free(aukit_chunks *);
+typedef struct aukit_stream aukit_stream;
+int aukit_stream_open(aukit_ctx *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_stream **out);
+int aukit_stream_feed(aukit_stream *, const uint8_t *bytes, uint64_t n); int aukit_stream_finish(aukit_stream *);
+int aukit_stream_next(aukit_stream *, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
+int aukit_stream_length(aukit_stream *, double *seconds); void aukit_stream_close(aukit_stream *);
 ]]
 
 local C = ffi.load(os.getenv("AUKIT_HIP_LIB") or "aukit_hip")
@@ -489,10 +494,48 @@ for name, id in pairs(FX) do
 end
 
 -- ---------------------------------------------------------------- stream factories (string input)
---- Every iterator call of the reference is computed in one launch; the samples come back as ONE FFI array and each call of the
---- returned closure builds only its own chunk's tables.  (A resumable handle for reader-function input — austream's http / websocket
---- sources — is not part of this ABI version: see INTEGRATION.md.)
+--- String input: every iterator call of the reference is computed in one launch; the samples come back as ONE FFI array and each call of the
+--- returned closure builds only its own chunk's tables.  Reader-function input (austream's http / websocket / file sources): the library's
+--- resumable handle — pieces are fed as the closure runs dry, and the chunks are those of the string version for the concatenated input.
+local CHUNK_CAP = 1048576
+local function streamer_fn(d, fn, first, mono, dtype)
+    local hp = ffi.new("aukit_stream*[1]")
+    check(C.aukit_stream_open(ctx(), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, hp))
+    local h = ffi.gc(hp[0], C.aukit_stream_close)
+    local function feed(s) check(C.aukit_stream_feed(h, ffi.cast("const uint8_t*", s), #s)) end
+    feed(first)
+    local buf = ffi.new("double[?]", CHUNK_CAP * 8)
+    local len, ch, st, pos = ffi.new("uint32_t[1]"), ffi.new("int32_t[1]"), ffi.new("int32_t[1]"), ffi.new("double[1]")
+    local done, ended = false, false
+    local length = ffi.new("double[1]")
+    check(C.aukit_stream_length(h, length))
+    return function()
+        while not ended do
+            check(C.aukit_stream_next(h, buf, CHUNK_CAP, len, ch, pos, st))
+            if st[0] == 0 then      -- AUKIT_STREAM_CHUNK
+                local chunk = {}
+                for c = 1, ch[0] do
+                    local t = {}
+                    for i = 1, len[0] do t[i] = buf[(c - 1) * CHUNK_CAP + i - 1] end
+                    chunk[c] = t
+                end
+                return chunk, pos[0]
+            elseif st[0] == 2 then  -- AUKIT_STREAM_END
+                ended = true
+            else                    -- AUKIT_STREAM_NEED_INPUT
+                local piece = (not done) and fn() or nil
+                if piece == nil then done = true check(C.aukit_stream_finish(h)) else feed(piece) end
+            end
+        end
+        return nil
+    end, length[0]
+end
 local function streamer(d, data, mono, dtype, first, len)
+    if type(data) == "function" then
+        local piece = data()
+        expect(1, piece, "string")
+        return streamer_fn(d, data, piece, mono, dtype)
+    end
     local o, ck = ffi.new("aukit_audio*[1]"), ffi.new("aukit_chunks*[1]")
     check(C.aukit_stream_decode(ctx(), upload(data, first, len), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
     local audio = wrap(o[0])
@@ -522,7 +565,6 @@ local function streamer(d, data, mono, dtype, first, len)
 end
 function aukit.stream.pcm(data, bitDepth, dataType, channels, sampleRate, bigEndian, mono)  -- :2228
     expect(1, data, "string", "function")
-    if type(data) == "function" then error("aukit.stream.* with a reader function is not offered by this ABI version (pass the whole string)", 2) end
     bitDepth = expect(2, bitDepth, "number", "nil") or 8
     dataType = expect(3, dataType, "string", "nil") or "signed"
     channels = expect(4, channels, "number", "nil") or 1
@@ -530,28 +572,37 @@ function aukit.stream.pcm(data, bitDepth, dataType, channels, sampleRate, bigEnd
     expect(6, bigEndian, "boolean", "nil") expect(7, mono, "boolean", "nil")
     return streamer(desc {codec = "pcm", bitDepth = bitDepth, dataType = dataType, channels = channels, sampleRate = sampleRate, bigEndian = bigEndian}, data, mono, F64)
 end
-local function only_strings(data) if type(data) == "function" then error("aukit.stream.* with a reader function is not offered by this ABI version (pass the whole string)", 3) end end
 function aukit.stream.g711(input, ulaw, channels, sampleRate, mono)    -- :2850
-    expect(1, input, "string", "function") only_strings(input) expect(2, ulaw, "boolean")
+    expect(1, input, "string", "function") expect(2, ulaw, "boolean")
     return streamer(desc {codec = "g711", ulaw = ulaw, channels = channels, sampleRate = sampleRate or 8000}, input, mono, I8)
 end
 function aukit.stream.adpcm(input, blockAlign, channels, sampleRate, mono)    -- :2753
-    expect(1, input, "string", "function") only_strings(input) expect(2, blockAlign, "number")
+    expect(1, input, "string", "function") expect(2, blockAlign, "number")
     return streamer(desc {codec = "adpcm_wav", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate}, input, mono, I8)
 end
 function aukit.stream.msadpcm(input, blockAlign, channels, sampleRate, mono, coefficients)  -- :2588
-    expect(1, input, "string", "function") only_strings(input) expect(2, blockAlign, "number") expect(6, coefficients, "table", "nil")
+    expect(1, input, "string", "function") expect(2, blockAlign, "number") expect(6, coefficients, "table", "nil")
     return streamer(desc {codec = "msadpcm", blockAlign = blockAlign, channels = channels, sampleRate = sampleRate, coefficients = coefficients}, input, mono, I8)
 end
 function aukit.stream.dfpwm(data, sampleRate, channels, mono)          -- :2439
-    expect(1, data, "string", "function") only_strings(data)
+    expect(1, data, "string", "function")
     return streamer(desc {codec = "dfpwm", channels = channels, sampleRate = sampleRate}, data, mono, F64)
 end
-function aukit.stream.mdfpwm(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "mdfpwm"}, data, mono, I8) end  -- :2507
-function aukit.stream.flac(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "flac"}, data, mono, F64) end     -- :3124
-function aukit.stream.qoa(data, mono) expect(1, data, "string", "function") only_strings(data) return streamer(desc {codec = "qoa"}, data, mono, F64) end       -- :3202
+function aukit.stream.mdfpwm(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "mdfpwm"}, data, mono, I8) end  -- :2507
+function aukit.stream.flac(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "flac"}, data, mono, F64) end     -- :3124
+function aukit.stream.qoa(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "qoa"}, data, mono, F64) end       -- :3202
 local function stream_container(data, kind, mono)
-    expect(1, data, "string", "function") only_strings(data)
+    expect(1, data, "string", "function")
+    if type(data) == "function" then  -- "the first chunk MUST contain the ENTIRE header" (:2918): the walk runs on it, what follows the header is the first piece
+        local fn, piece = data, data()
+        expect(1, piece, "string")
+        local c = ffi.new("aukit_container")
+        check(C.aukit_parse_container(ffi.cast("const uint8_t*", piece), #piece, kind, 2, c))
+        local dtype = (c.desc.codec == 0 or c.desc.codec == 5) and F64 or I8
+        local it, length = streamer_fn(c.desc, fn, piece:sub(tonumber(c.payload_off) + 1, tonumber(c.payload_off + c.payload_len)), mono, dtype)
+        if c.length_seconds == c.length_seconds then length = c.length_seconds end
+        return it, length
+    end
     local c = container(data, kind, true)
     local dtype = (c.desc.codec == 0 or c.desc.codec == 5) and F64 or I8  -- what stream.pcm / .dfpwm vs .g711 / .adpcm / .msadpcm hand out
     local it, length = streamer(c.desc, data, mono, dtype, tonumber(c.payload_off), tonumber(c.payload_len))

@@ -95,7 +95,8 @@ typedef struct {
     double length_seconds;   /* stream.*: the factory's second return value where it computes one itself (:2994-2996, :3064-3069,
                                 :3107-3113), NaN where the codec's own stream factory supplies it                              */
 } aukit_container;
-/* stream = 0: aukit.wav / .aiff / .au; stream = 1: the header walk of aukit.stream.wav / .aiff / .au (string input) */
+/* stream = 0: aukit.wav / .aiff / .au; 1: the header walk of aukit.stream.wav / .aiff / .au on a string; 2: on the first piece a reader
+ * function returned ("the first chunk MUST contain the ENTIRE header", :2918): the payload is what that piece holds of it */
 int aukit_parse_container(const uint8_t *bytes, uint64_t n, int kind, int stream, aukit_container *out);
 
 /* ids for aukit_effect(); args in the reference's argument order after `audio` (aukit.lua:3356-3618) */
@@ -230,6 +231,22 @@ int aukit_chunks_info(const aukit_chunks *c, uint32_t *n, uint32_t *max_chunks);
 int aukit_chunks_get(const aukit_chunks *c, uint32_t *nchunks /* n */, uint32_t *lens /* n*max */, double *pos /* n*max */,
                      int32_t *status /* n */, double *length_seconds /* n */);
 void aukit_chunks_free(aukit_chunks *c);
+
+/* ---- aukit.stream.<codec>(fn, ...): the reader-FUNCTION input (aukit.lua:2776-2786 and siblings; austream.lua:19-64), as a resumable handle.
+ * Bytes are fed in any pieces; the chunks handed out are exactly those aukit.stream.<codec>(s, ...) hands out for the string s = every
+ * byte fed (the reference's own function mode cuts chunks wherever the reader's buffers end, SURVEY Q6: nothing to reproduce there).
+ * A chunk is delivered once it is decided — a later chunk exists, or aukit_stream_finish was called.  One stream per handle. */
+typedef struct aukit_stream aukit_stream;
+typedef enum { AUKIT_STREAM_CHUNK = 0, AUKIT_STREAM_NEED_INPUT = 1, AUKIT_STREAM_END = 2 } aukit_stream_state;
+int aukit_stream_open(aukit_ctx *ctx, const aukit_codec_desc *desc, int interp, int mono, int dtype, aukit_stream **out);
+int aukit_stream_feed(aukit_stream *s, const uint8_t *bytes, uint64_t n);   /* fn() returned a string */
+int aukit_stream_finish(aukit_stream *s);                                    /* fn() returned nil */
+/* the iterator call: state = CHUNK (`*len` samples per channel at dst + c * cap, `*pos` = its second return value), NEED_INPUT, or END (nil).
+ * Where the reference's iterator raises instead of ending, the call returns AUKIT_E_LUA.  A chunk never exceeds 48000 samples per channel
+ * except stream.flac / stream.qoa (one coded block resampled: at most 65535 * 48000 / sampleRate). */
+int aukit_stream_next(aukit_stream *s, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
+int aukit_stream_length(aukit_stream *s, double *seconds);                   /* the factory's second return value, for the bytes fed so far */
+void aukit_stream_close(aukit_stream *s);
 
 #ifdef __cplusplus
 }

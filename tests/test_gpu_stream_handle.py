@@ -1,0 +1,175 @@
+"""The resumable stream handle (aukit_stream_open / feed / finish / next: the reader-FUNCTION input of aukit.stream.*, aukit.lua:2776-2786,
+austream.lua:19-64).  Contract: whatever the feeding pattern, the chunks that come out are EXACTLY the chunks of the string version
+(aukit_stream_decode, itself checked against the oracle elsewhere) for the concatenation of the pieces — lengths, positions, samples, and
+the error the reference's iterator raises at the end where it does.  Every codec, seeded random piece sizes incl. 1-byte pieces and
+pieces cut inside headers / blocks / frames."""
+import numpy as np
+import pytest
+
+from tests.util import pcm16
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    return B, N
+
+
+def _whole(ctx, B, data, desc, interp, mono, dtype):
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [data]), desc, interp, mono=mono, dtype=dtype)
+    chans = out.download()[0]
+    n = int(ck.nchunks[0])
+    res, off = [], 0
+    for k in range(n):
+        ln = int(ck.lens[0][k])
+        res.append(([c[off:off + ln] for c in chans], float(ck.pos[0][k])))
+        off += ln
+    return res, int(ck.status[0]), float(ck.length_seconds[0])
+
+
+def _pieces(rng, data, mode):
+    if mode == "bytes":
+        cuts = sorted(set(rng.integers(1, len(data), min(len(data) - 1, 300)).tolist()))
+    elif mode == "few":
+        cuts = sorted(set(rng.integers(1, len(data), 3).tolist()))
+    else:  # "mixed": runs of tiny pieces between big ones
+        cuts, p = [], 0
+        while p < len(data):
+            p += int(rng.choice([1, 2, 7, 100, 4096, 30000, 200000]))
+            if p < len(data):
+                cuts.append(p)
+    cuts = [0] + cuts + [len(data)]
+    return [data[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+def _via_handle(ctx, B, N, pieces, desc, interp, mono, dtype):
+    h = B.StreamHandle(ctx, desc, interp, mono, dtype)
+    res, err, it = [], None, iter(pieces)
+    done = False
+    try:
+        while True:
+            kind, chans, pos = h.next()
+            if kind == "chunk":
+                res.append((chans, pos))
+            elif kind == "end":
+                break
+            else:
+                p = None if done else next(it, None)
+                if p is None:
+                    done = True
+                    h.finish()
+                else:
+                    h.feed(p)
+    except N.AukitError as e:
+        err = e.code
+    length = h.length() if err is None else None
+    h.close()
+    return res, err, length
+
+
+def _inputs(oracle, N, B):
+    O = oracle
+    rng = np.random.Generator(np.random.PCG64(77))
+    st = np.stack([pcm16(70000, 44100, 9, 0), pcm16(70000, 44100, 9, 1)], 1)
+    cases = {
+        "pcm16_mono_44k": (pcm16(150001, 44100, 9, 2).tobytes(), B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), False, N.F64),
+        "pcm16_stereo_mix": (st.tobytes(), B.make_desc(N.CODEC_PCM, 2, 44100, 16, "signed"), True, N.F64),
+        "pcm_f32_22k": (rng.uniform(-1, 1, 50000).astype("<f4").tobytes(), B.make_desc(N.CODEC_PCM, 1, 22050, 32, "float"), False, N.F64),
+        "pcm8_odd_rate": (rng.integers(0, 256, 40001, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_PCM, 1, 11025, 8, "unsigned"), False, N.F32),
+        "g711": (rng.integers(0, 256, 30011, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True), False, N.I8),
+        "ima": (O.gen_ima(pcm16(1016 * 60 + 300, 22050, 9, 3), 1, 512, 88), B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), False, N.I8),
+        "ima_stereo": (O.gen_ima(st[:1017 * 40].ravel(), 2, 1024, 88), B.make_desc(N.CODEC_ADPCM_WAV, 2, 44100, block_align=1024), True, N.I8),
+        "msadpcm": (O.gen_msadpcm(st[:30000].ravel(), 2, 1024), B.make_desc(N.CODEC_MSADPCM, 2, 44100, block_align=1024), False, N.I8),
+        "dfpwm": (rng.integers(0, 256, 40007, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_DFPWM, 1, 48000), False, N.F64),
+        "dfpwm_stereo": (rng.integers(0, 256, 30000, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_DFPWM, 2, 32000), True, N.F64),
+        "mdfpwm": (O.gen_mdfpwm(rng.integers(0, 256, 18000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 18000, dtype=np.uint8).tobytes()), B.make_desc(N.CODEC_MDFPWM), False, N.I8),
+        "qoa": (O.gen_qoa(st[:26000].ravel(), 2, 44100), B.make_desc(N.CODEC_QOA), False, N.F64),
+        "flac": (O.gen_flac(st[:40000].astype(np.int64).ravel(), 2, 16, 44100, 1152), B.make_desc(N.CODEC_FLAC), False, N.F64),
+    }
+    return cases
+
+
+CASES = ["pcm16_mono_44k", "pcm16_stereo_mix", "pcm_f32_22k", "pcm8_odd_rate", "g711", "ima", "ima_stereo", "msadpcm", "dfpwm", "dfpwm_stereo", "mdfpwm", "qoa", "flac"]
+
+
+@pytest.mark.parametrize("mode", ["mixed", "few", "bytes"])
+@pytest.mark.parametrize("case", CASES)
+def test_handle_equals_string_version(ctx, oracle, case, mode):
+    B, N = _mods()
+    data, desc, mono, dtype = _inputs(oracle, N, B)[case]
+    interp = "cubic" if case != "pcm8_odd_rate" else "linear"
+    want, status, length = _whole(ctx, B, data, desc, interp, mono, dtype)
+    rng = np.random.Generator(np.random.PCG64(hash((case, mode)) & 0xFFFF))
+    got, err, glen = _via_handle(ctx, B, N, _pieces(rng, data, mode), desc, interp, mono, dtype)
+    assert len(got) == len(want), (len(got), len(want))
+    for (gc, gp), (wc, wp) in zip(got, want):
+        assert len(gc) == len(wc) and (gp == wp or (np.isnan(gp) and np.isnan(wp)))
+        for a, b in zip(gc, wc):
+            assert np.array_equal(a, b)
+    assert (err == N.E_LUA) == (status == N.E_LUA)  # where the reference's iterator raises at the end, so does the handle's last call
+    if err is None:
+        assert glen == length
+
+
+def test_handle_truncated_inputs_and_protocol(ctx, oracle):
+    """ends that fall inside a block / a frame / a prefill: same chunks, same final status as the string version of the truncated bytes;
+    feeding after finish is refused; an empty stream ends at once"""
+    B, N = _mods()
+    cases = _inputs(oracle, N, B)
+    for case in ("pcm16_mono_44k", "ima", "flac", "qoa", "msadpcm"):
+        data, desc, mono, dtype = cases[case]
+        for cut in (len(data) - 1, len(data) - 37, len(data) // 2 + 3):
+            d = data[:cut]
+            try:
+                want, status, _ = _whole(ctx, B, d, desc, "cubic", mono, dtype)
+            except N.AukitError as e:
+                # bytes the string version refuses outright (half a sample frame at the end): the handle cannot know before finish — it has
+                # handed out the chunks decided until then, and the first call after finish returns the string version's error
+                got, err, _ = _via_handle(ctx, B, N, [d[:cut // 3], d[cut // 3:]], desc, "cubic", mono, dtype)
+                assert err == e.code, (case, cut)
+                continue
+            got, err, _ = _via_handle(ctx, B, N, [d[:cut // 3], d[cut // 3:]], desc, "cubic", mono, dtype)
+            assert len(got) == len(want) and (err == N.E_LUA) == (status == N.E_LUA), (case, cut)
+            for (gc, gp), (wc, wp) in zip(got, want):
+                assert all(np.array_equal(a, b) for a, b in zip(gc, wc))
+    data, desc, mono, dtype = cases["g711"]
+    h = B.StreamHandle(ctx, desc, "linear", False, dtype)
+    assert h.next()[0] == "need_input"
+    h.finish()
+    assert h.next()[0] == "end"
+    with pytest.raises(N.AukitError):
+        h.feed(b"abc")
+    h.close()
+
+
+def test_mirror_stream_with_reader_function(ctx, oracle):
+    """aukit.stream.pcm / .wav with a reader function (the mirror of austream's use): same chunks as with the whole string"""
+    import struct
+    import aukit_amd.aukit as aukit
+    pcm = pcm16(120000, 44100, 9, 5).tobytes()
+    aukit.defaultInterpolation = "cubic"
+    try:
+        it, length = aukit.stream.pcm(pcm, 16, "signed", 1, 44100)
+        want = list(it)
+        pieces = [pcm[i:i + 8191] for i in range(0, len(pcm), 8191)]
+        src = iter(pieces)
+        it2, _ = aukit.stream.pcm(lambda: next(src, None), 16, "signed", 1, 44100)
+        got = list(it2)
+        assert len(got) == len(want)
+        for (gc, gp), (wc, wp) in zip(got, want):
+            assert gp == wp and np.array_equal(gc[0], wc[0])
+        fmt = struct.pack("<HHIIHH", 1, 1, 44100, 88200, 2, 16)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(pcm)) + pcm
+        wav = b"RIFF" + struct.pack("<I", len(body)) + body
+        it3, len3 = aukit.stream.wav(wav)
+        wpieces = [wav[:5000]] + [wav[i:i + 20000] for i in range(5000, len(wav), 20000)]  # the first piece holds the whole header (:2918)
+        wsrc = iter(wpieces)
+        it4, len4 = aukit.stream.wav(lambda: next(wsrc, None))
+        a, b = list(it3), list(it4)
+        assert len(a) == len(b) == len(want) and len3 == len4 == len(pcm) / 2 / 44100
+        for (gc, gp), (wc, wp) in zip(b, a):
+            assert gp == wp and np.array_equal(gc[0], wc[0])
+    finally:
+        aukit.defaultInterpolation = "linear"
