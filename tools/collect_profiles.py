@@ -10,18 +10,19 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
 n = 0
-for f in sorted(glob.glob(os.path.join(src, "r1_*.csv"))):
+for f in sorted(glob.glob(os.path.join(src, "r1_*.csv")) + glob.glob(os.path.join(src, "r1_*_timeline.txt"))):
     shutil.copy(f, os.path.join(dst, "r%s_%s" % (rnd, os.path.basename(f)[3:])))
     n += 1
 shutil.copy(os.path.join(root, "gpurun_out", "bench_lines.jsonl"), os.path.join(dst, "r%s_bench_lines.jsonl" % rnd))
 
 # kernel name as bench.py reports it (ctx.last_kernel) -> (tag, substring of the rocprofv3 kernel name)
-DOMINANT = [("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<"),
+DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table>", "wavef64", "k_wave_f64<"),
+            ("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<"),
             ("k_fast_wave_stream<pcm_s16le_mono,cubic,nv2,stream_pcm>", "pcmstream", "k_fast_wave_stream<"),
             ("k_fast_wave_coef<g711_mono,cubic,nv1>", "g711cubic", "k_fast_wave_coef<"),
             ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<"),
             ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<"),
-            ("k_ima_stream", "ima", "k_ima_stream<")]
+            ("k_ima_stream_f32", "ima", "k_ima_stream_f32<")]
 
 
 def first(tag, which, pat, col):

@@ -28,6 +28,9 @@ with open(sys.argv[2], "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 PY
 
+# kernel timeline of the last step (which kernels overlap on which queue), when the caller names the step's first kernel
+[ -n "$TIMELINE_PAT" ] && python3 tools/trace_overlap.py $RAW/stats "$TIMELINE_PAT" > $OUT/${TAG}_timeline.txt
+
 pass_pmc() {  # $1 = name, rest = counters
   name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $RAW/$name -o $name -- python3 $ARGS > $OUT/${TAG}_$name.log 2>&1
