@@ -8,6 +8,8 @@
 //   (block, channel): 16 nibbles per lane, wave64 shuffle scan for the step index, again for the predictor.
 //   The stream.adpcm path keeps the decoded block in LDS and resamples it in the same kernel (fp64, reference order).
 #include <algorithm>
+#include <chrono>
+#include <map>
 #include "resample.h"
 #include "resample_dev.h"
 #include "dfpwm_dev.h"
@@ -805,33 +807,33 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     const uint32_t newlen_full = (uint32_t)std::floor(spb * ratio);                // :2768
     const uint64_t ips = (uint64_t)iterPerSecond;
     const int nd = mono ? 1 : C;
+    static const bool TT = getenv("AUKIT_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[ima host] %-12s %7.1f us\n", w, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
     aukit_chunks *ck = new aukit_chunks();
     ck->n = in->n;
     ck->nchunks.assign(in->n, 0);
     ck->status.assign(in->n, 0);
     ck->length_seconds.assign(in->n, 0);
     std::vector<uint64_t> lens(in->n, 0), blk0(in->n + 1, 0);
-    std::vector<std::vector<uint32_t>> clen(in->n);
-    std::vector<std::vector<double>> cpos(in->n);
     std::vector<unsigned> first_bad(in->n, 0xFFFFFFFFu);
-    if (in->n) {  // which streams die on a header index above 88, and where
+    if (in->n) {  // which streams die on a header index above 88, and where (the answer is awaited after the plans below were made)
         int rc0 = ctx->misc_buf.ensure((size_t)in->n * 4 + 16);
         if (rc0) { delete ck; return rc0; }
         unsigned *dfb = reinterpret_cast<unsigned *>(ctx->misc_buf.p);
         hipLaunchKernelGGL(k_ima_scan_headers, dim3(in->n), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), in->n, C,
                            (unsigned long long)ba, dfb);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(first_bad.data(), dfb, (size_t)in->n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "stream.adpcm header scan failed"); }
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(first_bad.data(), dfb, (size_t)in->n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            delete ck; return fail(AUKIT_E_HIP, "stream.adpcm header scan failed");
+        }
     }
-    for (uint32_t s = 0; s < in->n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s];
-        ck->length_seconds[s] = (double)nb / (double)ba * spb / d->sample_rate;   // :2834
+    // The iterator calls of one stream depend on its byte count and on where a bad header stops it: one plan per distinct pair.
+    struct Plan { uint64_t blocks = 0, total = 0; std::vector<uint32_t> len; std::vector<double> pos; };
+    auto make_plan = [&](uint64_t nb, uint64_t calls_ok) {
+        Plan pl;
         // blocks processed: while n + 4C <= #data (1-based n)  :2794
         const uint64_t nblk = nb >= 4ull * C + 1 ? (nb - 4ull * C - 1) / ba + 1 : 0;
-        // a bad header kills the iterator call that reaches it: only the calls before that one deliver
-        const uint64_t calls_ok = first_bad[s] == 0xFFFFFFFFu ? ~0ull : (uint64_t)first_bad[s] / std::max<uint64_t>(ips, 1);
-        if (calls_ok != ~0ull) ck->status[s] = AUKIT_E_LUA;  // "attempt to perform arithmetic on a nil value (field '?')"
-        blk0[s + 1] = blk0[s] + (calls_ok == ~0ull ? nblk : std::min<uint64_t>(nblk, calls_ok * ips));
+        pl.blocks = calls_ok == ~0ull ? nblk : std::min<uint64_t>(nblk, calls_ok * ips);
         uint64_t done = 0;
         for (uint64_t call = 0;; call++) {  // one iterator call = up to iterPerSecond blocks
             if (call == calls_ok) break;
@@ -853,24 +855,61 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             // a short block is always the last one (n advances past #data), so block b's outputs start at b * newlen_full
             done += take;
             if (produced == 0) break;  // #retval[1] == 0 → nil
-            clen[s].push_back((uint32_t)produced);
-            cpos[s].push_back(((double)(done * ba + 1)) / bytesPerSecond);  // (n + pos) / bytesPerSecond :2833
-            lens[s] += produced;
-            if (take < ips && done >= nblk) { /* the next call sees n + 4C > #data and returns nil */ }
-            if (done >= nblk) break;
+            pl.len.push_back((uint32_t)produced);
+            pl.pos.push_back(((double)(done * ba + 1)) / bytesPerSecond);  // (n + pos) / bytesPerSecond :2833
+            pl.total += produced;
+            if (done >= nblk) break;   // the next call sees n + 4C > #data and returns nil
         }
-        ck->nchunks[s] = (uint32_t)clen[s].size();
+        return pl;
+    };
+    std::map<std::pair<uint64_t, uint64_t>, Plan> plans;
+    std::vector<const Plan *> plan_of(in->n, nullptr);
+    const Plan *last = nullptr;
+    uint64_t last_nb = ~0ull;
+    for (uint32_t s = 0; s < in->n; s++) {   // the good-header plans while the scan runs
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        if (nb != last_nb) {
+            auto it = plans.find({nb, ~0ull});
+            if (it == plans.end()) it = plans.emplace(std::make_pair(nb, ~0ull), make_plan(nb, ~0ull)).first;
+            last = &it->second; last_nb = nb;
+        }
+        plan_of[s] = last;
+    }
+    if (in->n && hipStreamSynchronize(ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "stream.adpcm header scan failed"); }
+    lap("scan+plans");
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        ck->length_seconds[s] = (double)nb / (double)ba * spb / d->sample_rate;   // :2834
+        if (first_bad[s] != 0xFFFFFFFFu) {
+            // a bad header kills the iterator call that reaches it: only the calls before that one deliver
+            const uint64_t calls_ok = (uint64_t)first_bad[s] / std::max<uint64_t>(ips, 1);
+            ck->status[s] = AUKIT_E_LUA;  // "attempt to perform arithmetic on a nil value (field '?')"
+            auto it = plans.find({nb, calls_ok});
+            if (it == plans.end()) it = plans.emplace(std::make_pair(nb, calls_ok), make_plan(nb, calls_ok)).first;
+            plan_of[s] = &it->second;
+        }
+        const Plan &pl = *plan_of[s];
+        blk0[s + 1] = blk0[s] + pl.blocks;
+        lens[s] = pl.total;
+        ck->nchunks[s] = (uint32_t)pl.len.size();
         ck->max_chunks = std::max<uint32_t>(ck->max_chunks, ck->nchunks[s]);
     }
     const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
     ck->lens.assign((size_t)ck->n * mc, 0);
     ck->pos.assign((size_t)ck->n * mc, 0);
-    for (uint32_t s = 0; s < in->n; s++)
-        for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = clen[s][k]; ck->pos[(size_t)s * mc + k] = cpos[s][k]; }
+    for (uint32_t s = 0; s < in->n; s++) {
+        const Plan &pl = *plan_of[s];
+        if (!pl.len.empty()) {
+            memcpy(&ck->lens[(size_t)s * mc], pl.len.data(), pl.len.size() * sizeof(uint32_t));
+            memcpy(&ck->pos[(size_t)s * mc], pl.pos.data(), pl.pos.size() * sizeof(double));
+        }
+    }
     int rc;
+    lap("plan");
     aukit_audio *a = *out;
     if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
     *out = a;
+    lap("prepare");
     const uint64_t nblocks = blk0[in->n];
     if (nblocks) {
         std::vector<uint64_t> tab(blk0);
@@ -924,6 +963,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 P.cap = capf;
                 const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
                 const unsigned grid = (unsigned)std::min<uint64_t>((nblocks + 3) / 4, (uint64_t)ctx->num_cus * per_cu * 4);
+                lap("tables");
                 if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
                 const float *wgp = reinterpret_cast<const float *>(ctx->tmp_buf3.p);
                 if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_LINEAR, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); else hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_CUBIC, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); }
@@ -935,8 +975,10 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 int herr = 0;
                 AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
                 AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                lap("kernel+sync");
                 if (herr) { delete ck; return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')"); }  // ima_step_table[idx > 88]
                 if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+                lap("chunks out");
                 return AUKIT_OK;
             }
         }

@@ -235,7 +235,7 @@ class ImaStream(Workload):
         self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
         self.out = B.AudioBatch(ctx)
         self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=N.I8, out=self.out)
-        self.arith = "i32 decode + f64 resample"
+        self.arith = "i32 decode + f32 resample with f64 / reference-order fallback under the floor (bit-exact)"
         self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B -> stream.adpcm cubic, int8 out (config 3a)"
         return self
 
