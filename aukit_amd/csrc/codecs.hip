@@ -732,7 +732,7 @@ static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_c
     if (rc) return rc;
     const size_t jbytes = jobs.size() * sizeof(ImaRowJob);
     if ((rc = ctx->tmp_buf2.ensure(jbytes + 16))) return rc;
-    if (jbytes) AUKIT_HIP_CHECK(hipMemcpyAsync(ctx->tmp_buf2.p, jobs.data(), jbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (jbytes) { int hrc = h2d_table(ctx, ctx->tmp_buf2.p, jobs.data(), jbytes); if (hrc) return hrc; }
     int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->tmp_buf2.p) + jbytes);
     AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
     if (!jobs.empty()) {
@@ -1059,7 +1059,7 @@ int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, a
     if (b->d_off) (void)hipFree(b->d_off);
     b->d_off = nullptr;
     AUKIT_HIP_CHECK(hipMalloc((void **)&b->d_off, ((size_t)in->n + 2) * 8));
-    AUKIT_HIP_CHECK(hipMemcpyAsync(b->d_off, off.data(), ((size_t)in->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    { int hrc = h2d_table(ctx, b->d_off, off.data(), ((size_t)in->n + 1) * 8); if (hrc) return hrc; }
     int *err = reinterpret_cast<int *>(b->d_off + in->n + 1);
     AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
     b->version++;
@@ -1132,7 +1132,7 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
         if (b->d_off) (void)hipFree(b->d_off);
         b->d_off = nullptr;
         AUKIT_HIP_CHECK(hipMalloc((void **)&b->d_off, ((size_t)in->n + 2) * 8));
-        AUKIT_HIP_CHECK(hipMemcpyAsync(b->d_off, off.data(), ((size_t)in->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        { int hrc = h2d_table(ctx, b->d_off, off.data(), ((size_t)in->n + 1) * 8); if (hrc) return hrc; }
     }
     b->version++;
     *out = b;

@@ -128,7 +128,7 @@ static int msadpcm_rows(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
     if (rc) return rc;
     const size_t jbytes = jobs.size() * sizeof(MsJob);
     if ((rc = ctx->tmp_buf2.ensure(jbytes + 16))) return rc;
-    if (jbytes) AUKIT_HIP_CHECK(hipMemcpyAsync(ctx->tmp_buf2.p, jobs.data(), jbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (jbytes) { int hrc = h2d_table(ctx, ctx->tmp_buf2.p, jobs.data(), jbytes); if (hrc) return hrc; }
     int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->tmp_buf2.p) + jbytes);
     AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
     if (jobs.empty()) return AUKIT_OK;

@@ -64,6 +64,13 @@ struct aukit_ctx {
     // pinned host staging for downloads / uploads of whole audios (a pageable copy runs at a fraction of the PCIe rate)
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;
+    // descriptor tables travel through a two-half pinned ring (upload_table): a pageable hipMemcpyAsync would block the host until the
+    // previous kernel on the stream has finished, serialising the planner of call k + 1 with the kernel of call k
+    char *tab_ring = nullptr;
+    size_t tab_half = 0, tab_head = 0;
+    int tab_cur = 0;
+    bool tab_used[2] = {false, false};
+    hipEvent_t tab_ev[2] = {};
     std::string plan_key;
     // verified range of the reciprocal-based exact division per ratio (see exact_div_verified)
     std::map<double, uint64_t> div_ok;
@@ -137,6 +144,7 @@ int ctx_begin_kernel(aukit_ctx *ctx);
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes);
 // uploads a host table into a ctx scratch buffer on the ctx stream
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes);
+int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes);  // pinned-ring H2D on ctx->stream (runtime.hip)
 // q = RN(n / d) computed as fma(fma(-d, n*r, n), r, n*r) with r = RN(1/d) is exact for the integers
 // n in [0, count): verified on the host once per (d, count) and cached in ctx->div_ok.
 bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count);

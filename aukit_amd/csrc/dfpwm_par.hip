@@ -453,9 +453,7 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nblk * sizeof(SatMap), b_ss = (size_t)n * (nblk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
     if ((*rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + 2 * b_st + 256))) return true;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
-    if (hipMemcpyAsync(B, h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(B + (size_t)n * 8, h_fed.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "upload of the DFPWM stream table failed"); return true; }
+    if ((*rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (*rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return true;
     DfParParams P{};
     P.src = src; P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{run, stride};
     P.n = n; P.nblk = nblk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
@@ -746,9 +744,8 @@ bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t
     const size_t o_chunks = take(b_chunks), o_sf = take(b_sf), o_cand = take(b_cand), o_dist = take(b_dist), o_dcount = take(b_cnt), o_dend = take(b_dist), o_start = take(b_cnt), o_stats = take(16);
     if ((*rc = ctx->tmp_buf3.ensure(o + 64))) return true;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf3.p);
-    if (hipMemcpyAsync(B + o_chunks, chunks.data(), b_chunks, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(B + o_sf, sfirst.data(), b_sf, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemsetAsync(B + o_stats, 0, 16, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (h2d_table(ctx, B + o_chunks, chunks.data(), b_chunks) || h2d_table(ctx, B + o_sf, sfirst.data(), b_sf) ||
+        hipMemsetAsync(B + o_stats, 0, 16, ctx->stream) != hipSuccess) {
         *rc = fail(AUKIT_E_HIP, "upload of the DFPWM encoder chunk table failed");
         return true;
     }

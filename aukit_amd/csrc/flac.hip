@@ -1070,9 +1070,8 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         ctx->plan_key.clear();  // seg_buf no longer holds a cached resample plan
         SubJob *d_jobs = reinterpret_cast<SubJob *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_jobs);
         FrameRec *d_frames = reinterpret_cast<FrameRec *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_frames);
-        AUKIT_HIP_CHECK(hipMemcpyAsync(d_rowoff, D.row_off.data(), (size_t)n * C * 8, hipMemcpyHostToDevice, ctx->stream));
-        AUKIT_HIP_CHECK(hipMemcpyAsync(d_fbase, fbase.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        AUKIT_HIP_CHECK(hipMemcpyAsync(d_kbase, kbase, sizeof kbase, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8)) ||
+            (rc = h2d_table(ctx, d_kbase, kbase, sizeof kbase))) return rc;
         R *rows = reinterpret_cast<R *>(ctx->tmp_buf.p);
         const R *scratch = reinterpret_cast<const R *>(ctx->tmp_buf3.p);
         if (njobs) {

@@ -29,11 +29,41 @@ void DevBuf::release() {
     cap = 0;
 }
 
+// Host -> device copy of a descriptor table on the context's stream that never blocks the host on the stream's earlier work.
+int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return AUKIT_OK;
+    static const bool no_ring = getenv("AUKIT_NO_TABLE_RING") != nullptr;
+    const size_t HALF = (size_t)16 << 20;
+    if (!no_ring && bytes <= HALF / 4) {
+        if (!ctx->tab_ring) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&ctx->tab_ring), 2 * HALF, hipHostMallocDefault) != hipSuccess) { ctx->tab_ring = nullptr; (void)hipGetLastError(); }
+            else if (hipEventCreateWithFlags(&ctx->tab_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->tab_ev[1], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipHostFree(ctx->tab_ring); ctx->tab_ring = nullptr;
+            } else { ctx->tab_half = HALF; ctx->tab_head = 0; ctx->tab_cur = 0; ctx->tab_used[0] = true; ctx->tab_used[1] = false; }
+        }
+        if (ctx->tab_ring) {
+            if (ctx->tab_head + bytes > ctx->tab_half) {   // this half is full: everything copied out of it so far is ahead of this event
+                AUKIT_HIP_CHECK(hipEventRecord(ctx->tab_ev[ctx->tab_cur], ctx->stream));
+                ctx->tab_cur ^= 1;
+                ctx->tab_head = 0;
+                if (ctx->tab_used[ctx->tab_cur]) AUKIT_HIP_CHECK(hipEventSynchronize(ctx->tab_ev[ctx->tab_cur]));
+                ctx->tab_used[ctx->tab_cur] = true;
+            }
+            char *st = ctx->tab_ring + (size_t)ctx->tab_cur * ctx->tab_half + ctx->tab_head;
+            memcpy(st, src, bytes);
+            ctx->tab_head += (bytes + 63) & ~(size_t)63;
+            AUKIT_HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+            return AUKIT_OK;
+        }
+    }
+    AUKIT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AUKIT_OK;
+}
+
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes) {
     int rc = buf.ensure(std::max<size_t>(bytes, 16));
     if (rc) return rc;
-    if (bytes) AUKIT_HIP_CHECK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return AUKIT_OK;
+    return h2d_table(ctx, buf.p, src, bytes);
 }
 
 bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count) {
@@ -122,7 +152,7 @@ int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, d
         std::copy(a->len.begin(), a->len.end(), m.begin());
         std::copy(a->row_off.begin(), a->row_off.end(), m.begin() + n);
         std::copy(a->row_stride.begin(), a->row_stride.end(), m.begin() + 2 * (size_t)n);
-        AUKIT_HIP_CHECK(hipMemcpyAsync(a->d_meta, m.data(), mbytes, hipMemcpyHostToDevice, ctx->stream));
+        { int hrc = h2d_table(ctx, a->d_meta, m.data(), mbytes); if (hrc) return hrc; }
     }
     a->version++;
     *out = a;
@@ -173,6 +203,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
         (void)hipStreamDestroy(c->aux_stream);
     }
     if (c->host_stage) (void)hipHostFree(c->host_stage);
+    if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->kev0) (void)hipEventDestroy(c->kev0);
