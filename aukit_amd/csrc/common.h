@@ -57,6 +57,8 @@ struct aukit_ctx {
     aukit::DevBuf enc_state_buf;  // DFPWM encoder states between the time slices of a transcode (dfpwm_par.hip)
     hipStream_t aux_stream = nullptr, dec_stream = nullptr;  // aux_stream: the sliced transcode's encoder runs here (dec_stream: unused, kept for the CU-mask experiment)
     hipEvent_t aux_ev[10] = {};
+    hipStream_t side_stream = nullptr;   // independent kernels of one call run next to each other (FLAC's order classes): ctx_side_stream()
+    hipEvent_t side_ev[2] = {};
     int aux_enc_cus = -1;
     aukit::DevBuf wt_buf;       // phase-weight table of wave_f64.hip, cached per (b, interpolation)
     unsigned wt_b = 0, wt_doubles = 0;
@@ -144,7 +146,9 @@ int ctx_begin_kernel(aukit_ctx *ctx);
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes);
 // uploads a host table into a ctx scratch buffer on the ctx stream
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes);
-int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes);  // pinned-ring H2D on ctx->stream (runtime.hip)
+int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes);
+int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side);  // side stream that starts after everything queued on ctx->stream so far (runtime.hip)
+int ctx_side_join(aukit_ctx *ctx);                     // ctx->stream continues after everything queued on the side stream  // pinned-ring H2D on ctx->stream (runtime.hip)
 // q = RN(n / d) computed as fma(fma(-d, n*r, n), r, n*r) with r = RN(1/d) is exact for the integers
 // n in [0, count): verified on the host once per (d, count) and cached in ctx->div_ok.
 bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count);

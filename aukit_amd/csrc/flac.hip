@@ -632,7 +632,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 // candidate crawling through garbage on one lane would otherwise hold its whole wave for tens of milliseconds
                 b.limit = (A.limit_factor > 0 && !c.nolimit) ? b.pos + (u64)A.limit_factor * (u64)bs * (u64)C * (u64)(depth + 2) / 4 + 4096 : ~0ull;
                 const u64 need = (u64)nsub * (u64)bs;
-                cand_scratch = atomicAdd(A.scratch_cursor, (need + 3) & ~3ull);
+                // + 32 values: block sizes are powers of two times the channel count, and without the skew every candidate's values would start at the
+                // same offset within 16 KiB — the 64 lanes of a wave here, and of a wave of k_flac_restore, would then ask the same few memory
+                // channels for their 128 bytes each (measured: the restore kernels moved 2.8 TB/s that way)
+                cand_scratch = atomicAdd(A.scratch_cursor, ((need + 3) & ~3ull) + 32);
                 store_ok = cand_scratch + need <= A.scratch_cap;
                 gcur = cand_scratch;
                 ch = 0;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
     const u64 endb = G.off[s + 1];
     u64 sp = 0;
     unsigned nf = 0;
-    unsigned kc[4] = {0, 0, 0, 0};
+    unsigned kc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // jobs per (order class, channel assignment): class * 4 + (0 = independent, 1..3 = 8..10)
     int stream_status = FE_OK;
     bool go = at < endb;  // readByte() → nil → decodeFrame returns false
     while (go) {          // (single-exit loop: the multi-break form of this walk was miscompiled by hipcc 7.2 — status lost)
@@ -696,7 +699,8 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
                 ci[k].sample_off = sp;
                 ci[k].seq = nf;
                 ci[k].used = 1;
-                for (int c = 0; c < f.nsub; c++) kc[sd[(size_t)k * C + c].kind & 3]++;
+                if (C == 2) kc[4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0)] += 2;  // a stereo frame's two jobs share a wave (k_flac_jobs)
+                else for (int c = 0; c < f.nsub; c++) kc[4 * (sd[(size_t)k * C + c].kind & 3)]++;
                 sp += (u64)f.blocksize;
                 nf++;
                 at = f.end_byte;
@@ -712,25 +716,46 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
     r.nframes = nf;
     r.status = stream_status;
     out[s] = r;
-    for (int q = 0; q < 4; q++) if (kc[q]) atomicAdd(&kind_count[q], (u64)kc[q]);
+    for (int q = 0; q < 16; q++) if (kc[q]) atomicAdd(&kind_count[q], (u64)kc[q]);
 }
 
-struct SubJob { u64 src, dst; unsigned desc; int bs; };
+struct SubJob { u64 src, dst; unsigned desc; int bs; int asgn, pad; };  // asgn: the frame's channel assignment when it decorrelates (8..10), else 0
 struct FrameRec { u64 sample_off; int bs, chan_asgn; unsigned stream, pad; };
 
 __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const CandInfo *ci, const SubDesc *sd, unsigned ncand, int C, const u64 *row_off,
                                                   const u64 *frame_base, const u64 *kind_base, u64 *kind_fill, SubJob *jobs, FrameRec *frames) {
-    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    // thread t takes candidate (t mod 64) * (threads / 64) + t / 64: the 64 candidates of a wave lie far apart (other streams), and since a wave's
+    // jobs get neighbouring slots, the subframes one wave of k_flac_restore works on do not sit at one offset within their rows' 16 KiB blocks
+    const unsigned t = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+    const unsigned k = (t & 63) * (nthr / 64) + t / 64;
     CandInfo f{};
     if (k < ncand) f = ci[k];
     const bool used = k < ncand && f.used;
     const unsigned s = used ? cands[k].stream : 0;
     const int lane = threadIdx.x & 63;
+    if (C == 2) {
+        // Stereo: both subframes of a frame go to adjacent slots (even = channel 0) of the order class of the larger predictor, so that
+        // k_flac_restore can decorrelate them out of LDS — every class count is even, so slots keep their parity.
+        const int kind = used ? 4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0) : -1;
+        for (int q = 0; q < 16; q++) {
+            const u64 m = __ballot(kind == q);
+            if (!m) continue;
+            u64 base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(&kind_fill[q], 2 * (u64)__builtin_popcountll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+            if (kind == q) {
+                const u64 slot = kind_base[q] + base + 2 * (u64)__builtin_popcountll(m & ((1ull << lane) - 1));
+                const int asgn = f.chan_asgn >= 8 ? f.chan_asgn : 0;
+                jobs[slot] = SubJob{f.scratch, row_off[(size_t)s * 2] + f.sample_off, k * 2u, f.blocksize, asgn, 0};
+                jobs[slot + 1] = SubJob{f.scratch + (u64)f.blocksize, row_off[(size_t)s * 2 + 1] + f.sample_off, k * 2u + 1, f.blocksize, asgn, 0};
+            }
+        }
+    } else
     for (int c = 0; c < C; c++) {  // wave-uniform trip count; one atomic per wave and order class instead of one per subframe
         const bool have = used && c < f.nsub;
-        const int kind = have ? (sd[(size_t)k * C + c].kind & 3) : -1;
+        const int kind = have ? 4 * (sd[(size_t)k * C + c].kind & 3) : -1;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 16; q += 4) {
             const u64 m = __ballot(kind == q);
             if (!m) continue;
             u64 base = 0;
@@ -738,24 +763,221 @@ __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const Cand
             base = __shfl(base, __builtin_ctzll(m));
             if (kind == q) {
                 const u64 slot = kind_base[q] + base + (u64)__builtin_popcountll(m & ((1ull << lane) - 1));
-                jobs[slot] = SubJob{f.scratch + (u64)c * f.blocksize, row_off[(size_t)s * C + c] + f.sample_off, k * (unsigned)C + c, f.blocksize};
+                jobs[slot] = SubJob{f.scratch + (u64)c * f.blocksize, row_off[(size_t)s * C + c] + f.sample_off, k * (unsigned)C + c, f.blocksize, 0, 0};
             }
         }
     }
     if (used) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
 }
 
-// restoreLinearPrediction (:411-419) + result[i] * 2^shift (:467-469).  One lane per subframe; 32 values per lane and round
-// travel global → LDS → lane → LDS → global so that both directions move 128 contiguous bytes per subframe.
+// A value on its way out of the prediction (int32 rows): decorrelated against the partner lane's value of the same sample — lanes 2p / 2p+1
+// hold channel 0 / 1 of one stereo frame and walk in step (k_flac_jobs) — and wrapped at 2^(depth-1)  (:482-507, Q14).  `o` and the partner's
+// value are below 2^29 in magnitude (the callers see to it), so 32-bit arithmetic is exact; depth > 30 goes to the double rows.
+struct FlacTail {
+    int asg, asg_u, wrap_half, wrap_full, depth;
+    bool odd, uniform;
+    __device__ __forceinline__ void init(int lane, int asgn, bool idle, int d) {
+        asg = asgn; odd = lane & 1; depth = d;
+        asg_u = __builtin_amdgcn_readfirstlane(asgn);
+        uniform = __all(idle || asgn == asg_u);   // jobs of one class are sorted by assignment: all but a few waves
+        wrap_half = d > 0 && d <= 30 ? 1 << (d - 1) : 0x7FFFFFFF;
+        wrap_full = d > 0 && d <= 30 ? 1 << d : 0;
+    }
+    __device__ __forceinline__ int operator()(int o) const {
+        if (depth <= 0) return o;
+        int v = o;
+        if (uniform) {
+            if (asg_u) {
+                const int par = __builtin_amdgcn_update_dpp(0, o, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]: lane ^ 1
+                if (asg_u == 8) v = odd ? par - o : o;                                   // left/side
+                else if (asg_u == 9) v = odd ? o : o + par;                              // side/right
+                else { const int side = odd ? o : par; v = (odd ? par : o + par) - (side >> 1); }   // mid/side: right = mid - floor(side / 2), left = right + side
+            }
+        } else {
+            const int par = __builtin_amdgcn_update_dpp(0, o, 0xB1, 0xF, 0xF, false);
+            if (asg == 8) v = odd ? par - o : o;
+            else if (asg == 9) v = odd ? o : o + par;
+            else if (asg == 10) { const int side = odd ? o : par; v = (odd ? par : o + par) - (side >> 1); }
+        }
+        return v >= wrap_half ? v - wrap_full : v;
+    }
+};
+
+// restoreLinearPrediction (:411-419) + result[i] * 2^shift (:467-469) + the tail above, int32 rows, the FAST version: one lane per subframe;
+// 32 values per lane and round travel global → LDS → lane → LDS → global so that both directions move 128 contiguous bytes per subframe.
+// The taps are two full-rate 24-bit multiply-adds each — coef = 2^S ch + cl, S = min(L, 8) — instead of one quarter-rate 64-bit
+// multiply-add: floor((2^S Sh + Sl) / 2^L) = (Sh + (Sl >> S)) >> (L - S), exact as long as every restored value stays below a bound hb chosen
+// per subframe so that neither partial sum can leave 32 bits.  A wave that cannot promise that (negative shift, many wasted bits) or meets a
+// value at or beyond the bound (24-bit audio, garbage) marks itself in `redo` and leaves; k_flac_restore does those waves with 64-bit sums.
+// Kept lean on purpose (no cross-round prefetch, no 64-bit state): at ~100 VGPRs five waves share a SIMD and cover each other's loads.
+__device__ __forceinline__ int mad24(int a, int b, int c) {   // named outright: from __mul24 hipcc derives sign extensions (v_bfe_i32) it does not need
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// the tail for a wave whose jobs share one channel assignment (ASG = 0, 8, 9, 10), or per lane (ASG = -1)
+template <int ASG> __device__ __forceinline__ int flac_tail(int o, bool odd, int asg, int wrap_half, int wrap_full) {
+    int v = o;
+    if constexpr (ASG != 0) {
+        const int par = __builtin_amdgcn_update_dpp(0, o, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]: lane ^ 1
+        if constexpr (ASG == 8) v = odd ? par - o : o;                                   // left/side
+        else if constexpr (ASG == 9) v = odd ? o : o + par;                              // side/right
+        else if constexpr (ASG == 10) { const int side = odd ? o : par; v = (odd ? par : o + par) - (side >> 1); }   // mid/side
+        else {
+            const int side = odd ? o : par;
+            const int v8 = odd ? par - o : o, v9 = odd ? o : o + par, v10 = (odd ? par : o + par) - (side >> 1);
+            v = asg == 8 ? v8 : (asg == 9 ? v9 : (asg == 10 ? v10 : o));
+        }
+    }
+    return v >= wrap_half ? v - wrap_full : v;
+}
+
+// One wave's rounds (k_flac_restore_fast).  Returns false when a value reached the bound.
+template <int MAXO, int ASG>
+__device__ __forceinline__ bool flac_fast_rounds(const int *scratch, int *rows, int *s_v, const u64 *s_src, const u64 *s_dst, const int *s_bs, int lane, int bs, int maxbs,
+                                                 int order, int S, int sh8, int wasted, int hb, int asg, int depth, const int (&cl)[MAXO], const int (&chh)[MAXO]) {
+    const bool odd = lane & 1;
+    const int wrap_half = 1 << (depth - 1), wrap_full = 1 << depth;   // 1 <= depth <= 30
+    const int grp = lane >> 3, sub4 = 4 * (lane & 7);
+    int *row = s_v + lane * OSTR;
+    int hist[MAXO];
+#pragma unroll
+    for (int q = 0; q < MAXO; q++) hist[q] = 0;
+    unsigned badacc = 0;   // bits at and above 2 hb of (v + hb): zero while every value is inside [-hb, hb)
+    // four values: taps named statically, the history moves by four registers once; WARM: the first `order` values are copied (:409)
+    auto turn = [&](int k, int i0, auto warm) {
+        constexpr bool WARM = decltype(warm)::value;
+        const int r0 = row[k], r1 = row[k + 1], r2 = row[k + 2], r3 = row[k + 3];
+        const int res[4] = {r0, r1, r2, r3};
+        int nv[4], out[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            int sl = 0, sh = 0;
+#pragma unroll
+            for (int q = 0; q < MAXO; q++) {
+                const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj];
+                sl = mad24(t, cl[q], sl);
+                sh = mad24(t, chh[q], sh);
+            }
+            int pr = (sh + (sl >> S)) >> sh8;
+            if constexpr (WARM) pr = i0 + jj >= order ? pr : 0;
+            const int v = res[jj] + pr;
+            badacc |= (unsigned)(v + hb);
+            nv[jj] = v;
+            out[jj] = flac_tail<ASG>((int)((unsigned)v << wasted), odd, asg, wrap_half, wrap_full);   // |v| < 2^23, wasted < 6
+        }
+        row[k] = out[0]; row[k + 1] = out[1]; row[k + 2] = out[2]; row[k + 3] = out[3];
+#pragma unroll
+        for (int q = MAXO - 1; q >= 4; q--) hist[q] = hist[q - 4];
+#pragma unroll
+        for (int q = 0; q < 4 && q < MAXO; q++) hist[q] = nv[3 - q];
+    };
+    // Memory schedule of a round: the next round's residuals are requested before this round is predicted, and this round's results wait in
+    // registers until the NEXT round's data has been awaited — loads and stores share one counter (vmcnt) and complete out of order with
+    // respect to each other, so a wave that waits for loads with stores behind it in flight waits for those stores as well; issued right after
+    // the wait, the stores have a whole prediction phase to drain before the next one.
+    // The element offsets (below 2^32: the kernel checked) and block sizes of the eight subframes a lane moves data for are fetched once, so a
+    // round's requests and stores need no look-ups.
+    uint4 pre[8], out[8];
+    unsigned src[8], dst[8], bs2[4];   // bs2: two 16-bit block sizes per register
+#pragma unroll
+    for (int i = 0; i < 8; i++) { src[i] = (unsigned)s_src[8 * i + grp] + sub4; dst[i] = (unsigned)s_dst[8 * i + grp] + sub4; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) bs2[i] = (unsigned)s_bs[16 * i + grp] | ((unsigned)s_bs[16 * i + 8 + grp] << 16);
+    auto bs_of = [&](int i) -> int { return (int)((i & 1) ? bs2[i >> 1] >> 16 : bs2[i >> 1] & 0xFFFFu); };
+    auto request = [&](int base) {   // 8 lanes × 4 values per subframe, 8 subframes per instruction
+#pragma unroll
+        for (int i = 0; i < 8; i++) { pre[i] = make_uint4(0, 0, 0, 0); if (base + sub4 < bs_of(i)) pre[i] = *reinterpret_cast<const uint4 *>(scratch + src[i] + base); }
+    };
+    auto store = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (base + sub4 < bs_of(i)) *reinterpret_cast<uint4 *>(rows + dst[i] + base) = out[i];
+    };
+    request(0);
+    for (int base = 0; base < maxbs; base += NC) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {   // (waits for the requested residuals)
+            int *d = s_v + (8 * i + grp) * OSTR + sub4;
+            d[0] = (int)pre[i].x; d[1] = (int)pre[i].y; d[2] = (int)pre[i].z; d[3] = (int)pre[i].w;
+        }
+        if (base > 0) store(base - NC);
+        if (base + NC < maxbs) request(base + NC);
+        __syncthreads();
+        const int nmine = min(NC, bs - base);   // a multiple of 4
+        if (base == 0) { for (int k = 0; k < nmine; k += 4) turn(k, k, std::true_type{}); }
+        else { for (int k = 0; k < nmine; k += 4) turn(k, 0, std::false_type{}); }
+        if (__any((badacc & ~(2u * (unsigned)hb - 1u)) != 0)) return false;   // nothing of this round has left (earlier rounds were exact)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int *d = s_v + (8 * i + grp) * OSTR + sub4;
+            out[i] = make_uint4((unsigned)d[0], (unsigned)d[1], (unsigned)d[2], (unsigned)d[3]);
+        }
+        __syncthreads();
+    }
+    store(((maxbs - 1) / NC) * NC);
+    return true;
+}
+
+template <int MAXO>
+__global__ __launch_bounds__(64) void k_flac_restore_fast(const SubJob *jobs, u64 njobs, const SubDesc *sd, const int *scratch, int *rows, unsigned *redo, int depth) {
+    __shared__ int s_v[64 * OSTR];
+    __shared__ u64 s_src[64], s_dst[64];
+    __shared__ int s_bs[64];
+    const int lane = threadIdx.x;
+    const u64 j = (u64)blockIdx.x * 64 + lane;
+    SubJob job{0, 0, 0, 0, 0, 0};
+    if (j < njobs) job = jobs[j];
+    int order = 0, lshift = 0, wasted = 0;
+    int cl[MAXO], chh[MAXO];
+#pragma unroll
+    for (int q = 0; q < MAXO; q++) { cl[q] = 0; chh[q] = 0; }
+    int scl = 1, sch = 1;
+    if (j < njobs) {
+        const SubDesc &d = sd[job.desc];
+        order = d.order; lshift = d.lshift; wasted = d.wasted;
+        const int S = min(max(lshift, 0), 8);
+#pragma unroll
+        for (int q = 0; q < MAXO; q++)
+            if (q < order) { const int c = (int)d.coef[q]; cl[q] = c & ((1 << S) - 1); chh[q] = c >> S; scl += cl[q]; sch += chh[q] < 0 ? -chh[q] : chh[q]; }
+    }
+    const int hb = min(1 << 23, 1 << (29 - (31 - __clz(max(scl, sch)))));   // a power of two; hb * max(sum cl, sum |ch|) < 2^30
+    // 16-byte accesses (block sizes are multiples of 4 but for a stream's last frame), 32-bit element offsets, 16-bit block sizes — else the general kernel
+    const bool vec = __all((job.src & 3) == 0 && (job.dst & 3) == 0 && (job.bs & 3) == 0 && job.bs < 65536 && (job.src >> 32) == 0 && (job.dst >> 32) == 0);
+    if (!__all(j >= njobs || (lshift >= 0 && wasted < 6)) || !vec || depth > 30 || depth < 1) { if (lane == 0) redo[blockIdx.x] = 1; return; }
+    s_src[lane] = job.src; s_dst[lane] = job.dst; s_bs[lane] = job.bs;
+    int maxbs = job.bs;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) maxbs = max(maxbs, __shfl_xor(maxbs, m));
+    __syncthreads();
+    const int S = min(lshift, 8), sh8 = lshift - S;
+    const int asg_u = __builtin_amdgcn_readfirstlane(job.asgn);
+    const bool uniform = __all(j >= njobs || job.asgn == asg_u);   // jobs of one class are sorted by assignment: all but a few waves
+    bool ok;
+#define AUKIT_ROUNDS(A) ok = flac_fast_rounds<MAXO, A>(scratch, rows, s_v, s_src, s_dst, s_bs, lane, job.bs, maxbs, order, S, sh8, wasted, hb, job.asgn, depth, cl, chh)
+    if (!uniform) AUKIT_ROUNDS(-1);
+    else if (asg_u == 0) AUKIT_ROUNDS(0);
+    else if (asg_u == 8) AUKIT_ROUNDS(8);
+    else if (asg_u == 9) AUKIT_ROUNDS(9);
+    else AUKIT_ROUNDS(10);
+#undef AUKIT_ROUNDS
+    if (!ok && lane == 0) redo[blockIdx.x] = 1;
+}
+
+// The general version: int32 rows with 64-bit sums and overflow detection (the waves k_flac_restore_fast left in `redo`, every wave when
+// redo is null), or double rows with the Lua's own arithmetic (they leave the tail to k_flac_finish).
 template <typename R, int MAXO>
-__global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njobs, const SubDesc *sd, const R *scratch, R *rows, unsigned *flags) {
+__global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njobs, const SubDesc *sd, const R *scratch, R *rows, unsigned *flags, int depth,
+                                                     const unsigned *redo) {
     constexpr bool INT = std::is_same<R, int>::value;  // int32 rows: exact integer prediction with overflow detection; double rows: the Lua's own arithmetic
+    if (redo && !redo[blockIdx.x]) return;
     __shared__ R s_v[64 * OSTR];
     __shared__ u64 s_src[64], s_dst[64];
     __shared__ int s_bs[64];
     const int lane = threadIdx.x;
     const u64 j = (u64)blockIdx.x * 64 + lane;
-    SubJob job{0, 0, 0, 0};
+    SubJob job{0, 0, 0, 0, 0, 0};
     if (j < njobs) job = jobs[j];
     int order = 0, lshift = 0, wasted = 0;
     R coef[MAXO > 0 ? MAXO : 1], hist[MAXO > 0 ? MAXO : 1];
@@ -769,11 +991,13 @@ __global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njo
     }
     const double div = ldexp(1.0, lshift), mul = ldexp(1.0, wasted);
     s_src[lane] = job.src; s_dst[lane] = job.dst; s_bs[lane] = job.bs;
+    bool ovf = INT && depth > 30;
     int maxbs = job.bs;
+    [[maybe_unused]] FlacTail fin;
+    fin.init(lane, job.asgn, j >= njobs, INT ? depth : 0);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) maxbs = max(maxbs, __shfl_xor(maxbs, m));
     __syncthreads();
-    bool ovf = false;
     const int half = lane >> 5, k32 = lane & 31;
     // 16-byte path: 8 lanes × 4 values per subframe and round, 8 subframes per instruction; the next round's loads are in flight
     // while this round is predicted.  Needs 4-element alignment of every subframe of the wave (block sizes are multiples of 4 but for
@@ -825,7 +1049,8 @@ __global__ __launch_bounds__(64) void k_flac_restore(const SubJob *jobs, u64 njo
                 }
                 const long long o = v << wasted;
                 if (o != (long long)(int)o) ovf = true;
-                s_v[lane * OSTR + k] = (int)o;
+                if (job.asgn && (unsigned long long)(o + (1ll << 29)) >= (1ull << 30)) ovf = true;   // the decorrelation is done in 32 bits
+                s_v[lane * OSTR + k] = fin((int)o);
             } else {
                 double v = s_v[lane * OSTR + k];
                 if constexpr (MAXO > 0) {
@@ -928,7 +1153,7 @@ struct Carve {
     size_t at = 0;
     size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
 };
-struct Counters { u64 ncand, scratch_cursor, kind_count[4], kind_fill[4]; unsigned flags, pad; };
+struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, pad; };
 
 static bool g_flac_force_wide() { const char *e = getenv("AUKIT_FLAC_WIDE"); return e && atoi(e) != 0; }
 
@@ -961,7 +1186,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         Carve cv;
         const size_t o_cnt = cv.take(sizeof(Counters)), o_chain = cv.take((size_t)n * sizeof(ChainOut)), o_cand = cv.take(capc * sizeof(Cand)),
                      o_ci = cv.take(capc * sizeof(CandInfo)), o_sd = cv.take(capc * C * sizeof(SubDesc)), o_keys = cv.take(hs * 8), o_vals = cv.take(hs * 4),
-                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8), o_kbase = cv.take(4 * 8);
+                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8), o_kbase = cv.take(16 * 8);
         if ((rc = ctx->tmp_buf2.ensure(cv.at))) return rc;
         char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
         Counters *d_cnt = reinterpret_cast<Counters *>(B + o_cnt);
@@ -1061,8 +1286,9 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             nfr += chain[s].nframes;
             D.status[s] = chain[s].status;
         }
-        uint64_t kbase[4], njobs = 0;
-        for (int q = 0; q < 4; q++) { kbase[q] = njobs; njobs += hc.kind_count[q]; }
+        uint64_t kbase[17], njobs = 0;   // jobs sorted by order class, then by channel assignment (waves of one assignment decorrelate without divergence)
+        for (int q = 0; q < 16; q++) { kbase[q] = njobs; njobs += hc.kind_count[q]; }
+        kbase[16] = njobs;
         if ((rc = ctx->tmp_buf.ensure((size_t)tot * sizeof(R) + 256))) return rc;
         Carve cj;
         const size_t o_jobs = cj.take(njobs * sizeof(SubJob)), o_frames = cj.take(nfr * sizeof(FrameRec));
@@ -1071,7 +1297,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         SubJob *d_jobs = reinterpret_cast<SubJob *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_jobs);
         FrameRec *d_frames = reinterpret_cast<FrameRec *>(reinterpret_cast<char *>(ctx->seg_buf.p) + o_frames);
         if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8)) ||
-            (rc = h2d_table(ctx, d_kbase, kbase, sizeof kbase))) return rc;
+            (rc = h2d_table(ctx, d_kbase, kbase, 16 * 8))) return rc;
         R *rows = reinterpret_cast<R *>(ctx->tmp_buf.p);
         const R *scratch = reinterpret_cast<const R *>(ctx->tmp_buf3.p);
         if (njobs) {
@@ -1079,11 +1305,28 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
                                d_jobs, d_frames);
             AUKIT_HIP_CHECK(hipGetLastError());
             // ---- 6. prediction, grouped by order class so that the lanes of a wave run the same number of taps
+            constexpr bool fused_tail = std::is_same<R, int>::value;  // int32 rows: decorrelate + wrap inside k_flac_restore
             if ((rc = ctx_begin_kernel(ctx))) return rc;
-#define AUKIT_RESTORE(Q, MAXO)                                                                                                                    \
-    if (hc.kind_count[Q])                                                                                                                         \
-        hipLaunchKernelGGL((k_flac_restore<R, MAXO>), dim3((unsigned)((hc.kind_count[Q] + 63) / 64)), dim3(64), 0, ctx->stream, d_jobs + kbase[Q], \
-                           (u64)hc.kind_count[Q], d_sd, scratch, rows, &d_cnt->flags)
+            // int32 rows: the lean 24-bit kernel first, then the general one on the waves it declined (AUKIT_FLAC_SLOW_RESTORE: on all of them)
+            const bool slow_only = getenv("AUKIT_FLAC_SLOW_RESTORE") != nullptr;
+            unsigned *d_redo = nullptr;
+            if (fused_tail && !slow_only) {
+                const size_t nwaves = (size_t)(njobs / 64 + 8);
+                if ((rc = ctx->tile_buf.ensure(nwaves * 4))) return rc;
+                d_redo = reinterpret_cast<unsigned *>(ctx->tile_buf.p);
+                AUKIT_HIP_CHECK(hipMemsetAsync(d_redo, 0, nwaves * 4, ctx->stream));
+            }
+#define AUKIT_RESTORE(Q, MAXO)                                                                                                                     \
+    if (kbase[4 * (Q) + 4] > kbase[4 * (Q)]) {                                                                                                     \
+        const u64 nj = kbase[4 * (Q) + 4] - kbase[4 * (Q)];                                                                                        \
+        const unsigned grid = (unsigned)((nj + 63) / 64);                                                                                          \
+        unsigned *redo = d_redo && MAXO > 0 ? d_redo + kbase[4 * (Q)] / 64 + (Q) : nullptr;                                                        \
+        if constexpr (fused_tail && MAXO > 0)                                                                                                      \
+            if (redo) hipLaunchKernelGGL((k_flac_restore_fast<(MAXO > 0 ? MAXO : 1)>), dim3(grid), dim3(64), 0, ctx->stream, d_jobs + kbase[4 * (Q)], nj, d_sd, \
+                                         reinterpret_cast<const int *>(scratch), reinterpret_cast<int *>(rows), redo, D.depth);                    \
+        hipLaunchKernelGGL((k_flac_restore<R, MAXO>), dim3(grid), dim3(64), 0, ctx->stream, d_jobs + kbase[4 * (Q)], nj, d_sd, scratch, rows,      \
+                           &d_cnt->flags, fused_tail ? D.depth : 0, redo);                                                                         \
+    }
             AUKIT_RESTORE(0, 0);
             AUKIT_RESTORE(1, 4);
             AUKIT_RESTORE(2, 12);
@@ -1091,9 +1334,11 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
 #undef AUKIT_RESTORE
             AUKIT_HIP_CHECK(hipGetLastError());
             if ((rc = ctx_end_kernel(ctx, "k_flac_restore", 2 * tot * sizeof(R)))) return rc;
-            // ---- 7. decorrelate + wrap
-            hipLaunchKernelGGL((k_flac_finish<R>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, d_frames, d_rowoff, C, rows, D.depth, &d_cnt->flags);
-            AUKIT_HIP_CHECK(hipGetLastError());
+            // ---- 7. decorrelate + wrap (double rows; int32 rows did it on the way out of the prediction)
+            if (!fused_tail) {
+                hipLaunchKernelGGL((k_flac_finish<R>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, d_frames, d_rowoff, C, rows, D.depth, &d_cnt->flags);
+                AUKIT_HIP_CHECK(hipGetLastError());
+            }
         }
         std::vector<FrameRec> hfr;
         if (want_frames && nfr) {

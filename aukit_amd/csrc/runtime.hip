@@ -60,6 +60,22 @@ int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return AUKIT_OK;
 }
 
+int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side) {
+    if (!ctx->side_stream) {
+        AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming));
+    }
+    AUKIT_HIP_CHECK(hipEventRecord(ctx->side_ev[0], ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+    *side = ctx->side_stream;
+    return AUKIT_OK;
+}
+int ctx_side_join(aukit_ctx *ctx) {
+    AUKIT_HIP_CHECK(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+    AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
+    return AUKIT_OK;
+}
+
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes) {
     int rc = buf.ensure(std::max<size_t>(bytes, 16));
     if (rc) return rc;
@@ -203,6 +219,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
         (void)hipStreamDestroy(c->aux_stream);
     }
     if (c->host_stage) (void)hipHostFree(c->host_stage);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -44,6 +44,26 @@ def test_flac_decode_bit_exact_and_lossless(ctx, oracle, depth, ch):
             assert np.array_equal(np.round(g[c] * 2 ** depth).astype(np.int64), p[:, c])  # independent: FLAC is lossless
 
 
+@pytest.mark.parametrize("depth", [16, 24])
+def test_flac_both_prediction_kernels_agree(ctx, oracle, monkeypatch, depth):
+    """int32 rows are predicted by the 24-bit multiply-add kernel where it can promise exactness (16-bit audio) and by the 64-bit one
+    elsewhere (24-bit audio trips the bound, ragged last frames are declined up front); AUKIT_FLAC_SLOW_RESTORE sends every wave to the
+    second.  Stereo so that every channel assignment, wasted bits and the decorrelation out of the partner lane take part."""
+    B, N = _B(), _N()
+    pcms = [_pcm(n, 2, depth, 5, 20 + i) for i, n in enumerate((4096 * 40 + 2728, 4096 * 3, 1152 * 9 + 4))]
+    streams = [oracle.gen_flac(p.ravel(), 2, depth, 44100, bs) for p, bs in zip(pcms, (4096, 4096, 1152))] * 12   # several full waves of subframes
+    bt = B.Batch.upload(ctx, streams)
+    fast = B.decode(ctx, bt, B.make_desc(N.CODEC_FLAC), dtype=N.F64).download()
+    monkeypatch.setenv("AUKIT_FLAC_SLOW_RESTORE", "1")
+    slow = B.decode(ctx, bt, B.make_desc(N.CODEC_FLAC), dtype=N.F64).download()
+    monkeypatch.delenv("AUKIT_FLAC_SLOW_RESTORE")
+    for i, (f, s) in enumerate(zip(fast, slow)):
+        p = pcms[i % 3]
+        for c in range(2):
+            assert np.array_equal(f[c], s[c])
+            assert np.array_equal(np.round(f[c] * 2 ** depth).astype(np.int64), p[:, c])
+
+
 def test_flac_blocksizes_and_config5_pipeline(ctx, oracle):
     B, N = _B(), _N()
     st = np.stack([pcm16(30000, 44100, 5, 0), pcm16(30000, 44100, 5, 1)], 1).astype(np.int64)
