@@ -6,7 +6,7 @@
 // its floor, which noisy input rarely touches.  But the decoder's strength is a saturating ±1 counter driven by
 // the INPUT bits alone (bit == previous bit ? min(s + 1, 1023) : max(s - 1, 8)), i.e. a composition of clamp-add maps
 // (a, lo, hi) — associative, so it is known exactly at any position after a scan:
-//   1. k_df_blockmaps   lane per (stream, 1 KiB block): the block's composite clamp-add map;
+//   1. k_df_blockmaps   lane per (stream, map block): the composite clamp-add map of the bytes between two chunk warm-up starts;
 //   2. k_df_blockscan   lane per stream: strength at every block start;
 //   3. k_df_chunks      lane per (stream, chunk): starts one block early with the exact strength and previous bit, charge and
 //                       filter state zero — the charge update is a contraction towards the target ((1 - s/1024) per step, plus
@@ -77,7 +77,8 @@ struct DfParParams {
     const u64 *fed;     // [n] bytes fed to its decoder
     Feed feed;
     unsigned n;
-    unsigned nblk;      // 1 KiB blocks per stream (max over the batch)
+    unsigned nblk;      // map blocks per stream (max over the batch) = chunks per stream: block b covers the fed bytes [B(b), B(b + 1)),
+                        // B(0) = 0, B(b) = b * bpc * W - W — the positions where the chunk lanes start their warm-up
     unsigned bpc;       // blocks per chunk
     unsigned nchunk;    // chunks per stream
     u64 W;              // block size in fed bytes
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     if (blk >= P.nblk) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
-    const u64 f0 = (u64)blk * P.W, f1 = f0 + P.W < fed ? f0 + P.W : fed;
+    const u64 CH = (u64)P.bpc * P.W, e1 = (u64)(blk + 1) * CH - P.W;
+    const u64 f0 = blk ? (u64)blk * CH - P.W : 0, f1 = e1 < fed ? e1 : fed;
     SatMap f{0, -(1 << 28), 1 << 28};
     if (f0 < fed) {
         int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     DfDec d{};
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
-        d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + (size_t)c * P.bpc - 1];
+        d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
         d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
         dfp_run<false>(p, fw, f0, d, O);
     }
@@ -450,19 +452,19 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
     if (n == 0 || nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
     // scratch: stream table, maps, strengths, states, stats
-    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nblk * sizeof(SatMap), b_ss = (size_t)n * (nblk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
+    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nchunk * sizeof(SatMap), b_ss = (size_t)n * (nchunk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
     if ((*rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + 2 * b_st + 256))) return true;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((*rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (*rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return true;
     DfParParams P{};
     P.src = src; P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{run, stride};
-    P.n = n; P.nblk = nblk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+    P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
     P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
     P.st_start = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss + b_st);
     P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + 2 * b_st);
     P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
-    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     const unsigned cb = 256;  // (1024 lanes sharing one table, 8 waves per SIMD instead of 2: 7 % slower — the kernel is issue-bound)
     const unsigned nsl = sliced ? std::min<unsigned>((unsigned)hook->slices, nchunk) : 1u;

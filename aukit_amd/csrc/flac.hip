@@ -737,9 +737,11 @@ __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const Cand
         // Stereo: both subframes of a frame go to adjacent slots (even = channel 0) of the order class of the larger predictor, so that
         // k_flac_restore can decorrelate them out of LDS — every class count is even, so slots keep their parity.
         const int kind = used ? 4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0) : -1;
-        for (int q = 0; q < 16; q++) {
+        u64 todo = __ballot(kind >= 0);
+        while (todo) {   // one turn per class present in the wave (a handful), one atomic each
+            const int q = __shfl(kind, __builtin_ctzll(todo));
             const u64 m = __ballot(kind == q);
-            if (!m) continue;
+            todo &= ~m;
             u64 base = 0;
             if (lane == __builtin_ctzll(m)) base = atomicAdd(&kind_fill[q], 2 * (u64)__builtin_popcountll(m));
             base = __shfl(base, __builtin_ctzll(m));
