@@ -73,7 +73,10 @@ struct aukit_ctx {
     int tab_cur = 0;
     bool tab_used[2] = {false, false};
     hipEvent_t tab_ev[2] = {};
-    std::string plan_key;
+    std::string plan_key;   // non-empty: seg_buf / tile_buf still hold the tables of plan_segs (any other upload into them clears it)
+    std::vector<unsigned char> plan_segs;   // the segment descriptors of that plan, byte for byte
+    int plan_tile_out = 0;
+    unsigned plan_n_tiles = 0, plan_tiles_per_seg = 0;
     // verified range of the reciprocal-based exact division per ratio (see exact_div_verified)
     std::map<double, uint64_t> div_ok;
 };

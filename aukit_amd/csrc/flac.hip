@@ -1315,6 +1315,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             if (fused_tail && !slow_only) {
                 const size_t nwaves = (size_t)(njobs / 64 + 8);
                 if ((rc = ctx->tile_buf.ensure(nwaves * 4))) return rc;
+                ctx->plan_key.clear();
                 d_redo = reinterpret_cast<unsigned *>(ctx->tile_buf.p);
                 AUKIT_HIP_CHECK(hipMemsetAsync(d_redo, 0, nwaves * 4, ctx->stream));
             }

@@ -370,6 +370,18 @@ int plan_tiles(aukit_ctx *ctx, const std::vector<Seg> &segs, double ratio, int i
 // tile tables for a given tile size: uploads segs (+ tile → segment tables for ragged batches)
 int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out, ResampleParams &P) {
     P.tile_out = tile_out;
+    // The same call on the same batch again (a streaming server's steady state, the bench): the tables are still on the device — for
+    // stream.pcm on 4096 ten-second streams they are 1.6 MB of segments and 7.7 MB of tile -> segment entries per call.
+    const size_t seg_bytes = segs.size() * sizeof(Seg);
+    if (!ctx->plan_key.empty() && ctx->plan_tile_out == tile_out && ctx->plan_segs.size() == seg_bytes && seg_bytes &&
+        memcmp(ctx->plan_segs.data(), segs.data(), seg_bytes) == 0 && !getenv("AUKIT_NO_PLAN_CACHE")) {
+        P.n_tiles = ctx->plan_n_tiles;
+        P.segs = reinterpret_cast<const Seg *>(ctx->seg_buf.p);
+        P.tiles_per_seg = ctx->plan_tiles_per_seg;
+        if (P.tiles_per_seg) { P.tile_seg = nullptr; P.seg_tile0 = nullptr; }
+        else { P.tile_seg = reinterpret_cast<const unsigned *>(ctx->tile_buf.p); P.seg_tile0 = P.tile_seg + P.n_tiles; }
+        return AUKIT_OK;
+    }
     uint64_t max_out = 0;
     std::vector<unsigned> tile0(segs.size() + 1, 0);
     bool uniform = true;
@@ -384,7 +396,7 @@ int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out,
     }
     if (nt > 0xFFFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "too many tiles");
     P.n_tiles = (unsigned)nt;
-    int rc = upload_table(ctx, ctx->seg_buf, segs.data(), segs.size() * sizeof(Seg));
+    int rc = upload_table(ctx, ctx->seg_buf, segs.data(), seg_bytes);
     if (rc) return rc;
     P.segs = reinterpret_cast<const Seg *>(ctx->seg_buf.p);
     if (uniform && tps0 > 0) {
@@ -404,6 +416,11 @@ int plan_tiles_sized(aukit_ctx *ctx, const std::vector<Seg> &segs, int tile_out,
         P.tile_seg = reinterpret_cast<const unsigned *>(ctx->tile_buf.p);
         P.seg_tile0 = P.tile_seg + nt;
     }
+    ctx->plan_segs.assign(reinterpret_cast<const unsigned char *>(segs.data()), reinterpret_cast<const unsigned char *>(segs.data()) + seg_bytes);
+    ctx->plan_tile_out = tile_out;
+    ctx->plan_n_tiles = P.n_tiles;
+    ctx->plan_tiles_per_seg = P.tiles_per_seg;
+    ctx->plan_key = "tiles";
     return AUKIT_OK;
 }
 

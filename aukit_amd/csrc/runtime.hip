@@ -77,6 +77,7 @@ int ctx_side_join(aukit_ctx *ctx) {
 }
 
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes) {
+    if (&buf == &ctx->seg_buf || &buf == &ctx->tile_buf) ctx->plan_key.clear();  // (plan_tiles_sized sets it again after its own uploads)
     int rc = buf.ensure(std::max<size_t>(bytes, 16));
     if (rc) return rc;
     return h2d_table(ctx, buf.p, src, bytes);

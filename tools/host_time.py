@@ -23,5 +23,7 @@ for w in names:
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(10): wl.step()
     torch.cuda.synchronize(); tot = (time.perf_counter() - t) / 10
-    print("%-22s host %.3f ms/call   step %.3f ms" % (w, sorted(host)[5] * 1e3, tot * 1e3), flush=True)
+    wl.step(); torch.cuda.synchronize()
+    name, kms, _ = ctx.last_kernel()     # HIP events around the last kernel of the last call
+    print("%-22s host %.3f ms/call   step %.3f ms   last kernel %.3f ms (%s)" % (w, sorted(host)[5] * 1e3, tot * 1e3, kms, name[:40]), flush=True)
     del wl, ctx
