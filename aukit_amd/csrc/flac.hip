@@ -79,7 +79,8 @@ struct FlacGlobals {
 // reaches outside the window (long warm-up / coefficient runs, the 44-bit look-back of readUint(n >= 32)).
 struct Bits {
     const u64 *w0;
-    const unsigned *lw; // this lane's window row: lw[k] = big-endian 32-bit word k of the stream, counted from 64-bit word win_lo
+    const unsigned *lw; // this lane's window row, a ring: lw[k mod 2 WN] = big-endian 32-bit word k of the stream (counted from w0), valid for the
+                        // 64-bit words [win_lo, win_lo + WN); a slide of the window loads only the 16-byte lines that are new
     u64 safe_words;
     u64 first, end;     // bit offsets (relative to w0) of the BitInputStream start and of the end of the string
     u64 pos, limit;
@@ -89,7 +90,7 @@ struct Bits {
 AUKIT_DEV u64 be64(u64 v) { return __builtin_bswap64(v); }
 AUKIT_DEV u64 fetch(const Bits &b, u64 wi) {
     const u64 d = wi - b.win_lo;
-    if (d < (u64)WN) return (u64)b.lw[2 * d] << 32 | b.lw[2 * d + 1];
+    if (d < (u64)WN) { const unsigned k = (unsigned)(2 * wi) & (2 * WN - 1); return (u64)b.lw[k] << 32 | b.lw[k + 1]; }
     return wi < b.safe_words ? be64(b.w0[wi]) : 0ull;
 }
 AUKIT_DEV void bits_seek(Bits &b, u64 pos) {
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         {
             const bool want = st != ST_DONE && (fresh || (b.wi - b.win_lo) >= (u64)(WN / 4));
             const u64 new_lo = b.wi & ~1ull;
+            // lines (16 bytes = two 64-bit words) of the new window that the old one did not hold: all of them for a fresh lane or a jump
+            const u64 keep_from = fresh ? ~0ull : b.win_lo / 2 + WN / 2;   // first line index the ring does not hold yet
             if (want) b.win_lo = new_lo;
             const int sub8 = lane % LPW, grp = lane / LPW;
 #pragma unroll
@@ -406,13 +409,18 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 const int s = i * (64 / LPW) + grp;
                 const int w = __shfl((int)want, s);
                 const u64 ws = __shfl(new_lo, s);
+                const u64 kf = __shfl(keep_from, s);
                 if (w) {
-                    const u64 wj = ws + 2 * (u64)sub8;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (wj < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + wj);
-                    unsigned *wrow = s_win + s * WSTR + 4 * sub8;
-                    wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
-                    wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
+                    // ring slot sub8 holds the line of the new window that is congruent to sub8 mod LPW
+                    const u64 l0 = ws / 2, line = l0 + (((u64)sub8 - l0) & (u64)(LPW - 1));
+                    if (kf == ~0ull || line >= kf || line < kf - WN / 2) {
+                        const u64 wj = 2 * line;
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (wj < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + wj);
+                        unsigned *wrow = s_win + s * WSTR + 4 * sub8;
+                        wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
+                        wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
+                    }
                 }
             }
             __syncthreads();
@@ -433,9 +441,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 const unsigned end_rel = (unsigned)min(b.end - wbase, (u64)1 << 30);
                 const unsigned limit_rel = (unsigned)min(b.limit > wbase ? b.limit - wbase : 0ull, (u64)1 << 30);
                 unsigned wd = (rp >> 5) + 2;  // next 32-bit word of the window to shift in
-                u64 buf = ((u64)b.lw[wd - 2] << 32 | b.lw[wd - 1]) << (rp & 31);
+                const unsigned ring0 = (unsigned)(2 * b.win_lo);  // absolute index of the window's first 32-bit word (the ring index is that mod 2 WN)
+                u64 buf = ((u64)b.lw[(ring0 + wd - 2) & (2 * WN - 1)] << 32 | b.lw[(ring0 + wd - 1) & (2 * WN - 1)]) << (rp & 31);
                 int avail = 64 - (int)(rp & 31);  // valid bits at the top of buf; >= 32 at the top of every iteration
-                unsigned wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];  // loaded one iteration ahead: LDS latency stays off the dependency chain
+                unsigned wnext = b.lw[(ring0 + wd) & (2 * WN - 1)];  // loaded one iteration ahead: LDS latency stays off the dependency chain (past the window's end: stale words nobody uses)
                 const bool warm = st == ST_WARM;
                 int why = 0;  // 1: hand over to the generic reader, 2: ran off the end of the data, 3: over the bit budget
                 bool go = true;
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     buf |= need ? (u64)wnext << (32 - avail) : 0ull;
                     avail += need ? 32 : 0;
                     wd += need ? 1u : 0u;
-                    wnext = b.lw[min(wd, (unsigned)(2 * WN - 1))];
+                    wnext = b.lw[(ring0 + wd) & (2 * WN - 1)];
                     // a header sets the coding of partition pi and its number of residuals (:394-395, :403); a value is stored
                     const int count = psize - (pi == 0 ? min(order, psize) : 0);
                     const bool gh = good & hdr;
