@@ -394,6 +394,18 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     u64 cand_scratch = 0, gcur = 0, end_byte = 0;
     SubDesc *sd = A.sd + (size_t)idx * C;
     R *const orow = s_out + lane * OSTRX;
+    // the values of stream s go to 128 contiguous bytes; two streams per store instruction.  A round's values are stored at the top of the NEXT
+    // round, behind the wait for that round's window lines: loads and stores share one counter (vmcnt), so stores issued in front of that wait
+    // would be waited for as well; issued behind it they drain while the next round is decoded.
+    auto flush = [&]() {
+        constexpr int PER = 64 / NCX;  // streams per store instruction
+        const int part = lane / NCX, k = lane % NCX;
+        for (int i = 0; i < NCX; i++) {
+            const int s = PER * i + part;
+            if (k < s_cnt[s]) A.scratch[s_ptr[s] + k] = s_out[s * OSTRX + k];
+        }
+    };
+    bool have_flush = false;
 
     for (;;) {
         // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     }
                 }
             }
+            if (have_flush) flush();
             __syncthreads();
             if (fresh && st != ST_DONE) { bits_seek(b, b.pos); fresh = false; }
         }
@@ -657,21 +670,13 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 st = ST_DONE;
             } else break;  // ST_DIRECT_WAIT: resume after this round's flush
         }
-        // ---- flush: the values of stream s go to 128 contiguous bytes; two streams per store instruction
+        // ---- this round's values: where they go (stored by the next round's flush, or right here after the last round)
         s_cnt[lane] = store_ok ? cnt : 0;
         s_ptr[lane] = gcur;
         gcur += (u64)cnt;
         __syncthreads();
-        {
-            constexpr int PER = 64 / NCX;  // streams per store instruction
-            const int part = lane / NCX, k = lane % NCX;
-            for (int i = 0; i < NCX; i++) {
-                const int s = PER * i + part;
-                if (k < s_cnt[s]) A.scratch[s_ptr[s] + k] = s_out[s * OSTRX + k];
-            }
-        }
-        __syncthreads();
-        if (__ballot(st != ST_DONE) == 0) break;
+        have_flush = true;
+        if (__ballot(st != ST_DONE) == 0) { flush(); break; }
     }
     if (valid) {
         CandInfo f;
