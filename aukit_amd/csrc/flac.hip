@@ -1216,7 +1216,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, ctx->stream));
         // ---- 2. sync candidates
         const uint64_t cand_room = capc - n - 64;  // the tail is kept for positions the chain asks for
-        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 16)), dim3(256), 0, ctx->stream, G,
+        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 64)), dim3(256), 0, ctx->stream, G,
                            (u64)in->total(), n, d_cand, cand_room, &d_cnt->ncand, H);
         AUKIT_HIP_CHECK(hipGetLastError());
         Counters hc;
