@@ -57,6 +57,9 @@ constexpr int WSTR = 2 * WN + 1;  // row stride of the window array in 32-bit wo
 constexpr unsigned LOW_BITS = (WN - 4) * 64;  // a lane stops for a refill once it is this far into its window
 constexpr int NC = 32;    // values a lane produces (extract) / restores (restore) per round
 constexpr int OSTR = 33;  // row stride of the value array
+#ifndef AUKIT_FLAC_CAREFUL_LOOP
+#define AUKIT_FLAC_CAREFUL_LOOP 0   // 1: k_flac_extract uses its end-of-data-aware field loop in every round (A/B)
+#endif
 #ifndef AUKIT_FLAC_NCX
 #define AUKIT_FLAC_NCX 32
 #endif
@@ -461,6 +464,55 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 const bool warm = st == ST_WARM;
                 int why = 0;  // 1: hand over to the generic reader, 2: ran off the end of the data, 3: over the bit budget
                 bool go = true;
+                // The window does not reach the end of the data for any lane of the wave (all rounds but a stream's last few): a leaner copy
+                // of the loop below — no end-of-data test, two window words in registers and a third one on its way instead of a 64-bit shift
+                // register, mode bits as integers, one rare exit in front of the store.  Same fields, same state afterwards.
+                const bool near_end = end_rel < (unsigned)(2 * WN * 32 + 64);
+                if (!__any(near_end) && !AUKIT_FLAC_CAREFUL_LOOP) {
+                    unsigned k = rp >> 5, sb = rp & 31u;          // word of the window and bit within it
+                    unsigned w0 = b.lw[(ring0 + k) & (2 * WN - 1)], w1 = b.lw[(ring0 + k + 1) & (2 * WN - 1)];
+                    unsigned wn = wnext;                          // word k + 2
+                    wd = k + 2;
+                    int fixed = (warm || esc) ? 1 : 0, nfix = warm ? sdepth : nbits;
+                    const int count_first = psize - min(order, psize), count_rest = psize, pbs = 32 - param_bits;
+                    const int warm_i = warm ? 1 : 0;
+                    for (;;) {
+                        const unsigned hi = (unsigned)((((u64)w0 << 32) | w1) << sb >> 32);
+                        const int hdr = (remaining == 0) & (warm_i ^ 1);
+                        const int z = __builtin_clz(hi | 1u);
+                        const int tot_r = z + 1 + param;
+                        const unsigned ur = ((unsigned)z << param) | ((((hi << z) << 1) >> 1) >> (31 - param));
+                        const int v_rice = (int)(ur >> 1) ^ -(int)(ur & 1u);
+                        const int v_fix = nfix ? ((int)hi >> ((32 - nfix) & 31)) : 0;
+                        const int pv = (int)(hi >> pbs);
+                        const int is_esc = pv >= escape ? 1 : 0;
+                        const int total = hdr ? param_bits + 5 * is_esc : (fixed ? nfix : tot_r);
+                        const unsigned nrp = rp + (unsigned)total;
+                        const int bad_h = ((is_esc ^ 1) & (pv > 26)) | ((nrp > limit_rel) ? 2 : 0);   // 1: generic reader, 2/3: over the bit budget
+                        const int bad_v = (fixed ^ 1) & ((hi == 0u) | (tot_r > 32));
+                        const int bad = hdr ? bad_h : bad_v;
+                        if (bad) { why = hdr ? ((bad_h & 1) ? 1 : 3) : 1; break; }
+                        orow[hdr ? NCX : cnt] = (R)(fixed ? v_fix : v_rice);   // (slot NCX: nobody's)
+                        const unsigned s2 = sb + (unsigned)total;
+                        const bool cross = s2 >= 32u;
+                        sb = s2 & 31u;
+                        w0 = cross ? w1 : w0;
+                        w1 = cross ? wn : w1;
+                        wd += cross ? 1u : 0u;
+                        wn = b.lw[(ring0 + wd) & (2 * WN - 1)];
+                        rp = nrp;
+                        const int nb5 = (int)((hi << param_bits) >> 27);
+                        param = hdr ? pv : param;
+                        fixed = hdr ? is_esc : fixed;
+                        nfix = hdr ? (is_esc ? nb5 : 0) : nfix;
+                        remaining = hdr ? (pi == 0 ? count_first : count_rest) : remaining - 1;
+                        cnt += hdr ^ 1;
+                        pi += (remaining == 0) & (warm_i ^ 1);   // a finished (or empty) partition
+                        if (!((cnt < NCX) & (rp < LOW_BITS) & ((remaining > 0) | ((warm_i ^ 1) & (pi < nparts))))) break;
+                    }
+                    if (!warm) { esc = fixed != 0; nbits = nfix; }
+                }
+                else
                 while (go) {
                     const bool hdr = !warm & (remaining == 0);
                     const bool fixed = warm | esc;
