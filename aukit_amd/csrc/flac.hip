@@ -360,6 +360,7 @@ template <typename R> struct ExtractArgs {
     u64 *scratch_cursor;
     unsigned *flags;
     int limit_factor;
+    unsigned *ticket;       // next candidate (relative to first) nobody has taken yet
 };
 
 // decodeFrame (:510-557) without prediction: header, per-subframe warm-up / residual values → scratch, predictor → SubDesc.
@@ -370,24 +371,25 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     __shared__ u64 s_ptr[64];
     __shared__ int s_cnt[64];
     const int lane = threadIdx.x;
-    const unsigned rel = blockIdx.x * 64 + lane;
-    const bool valid = rel < A.count;
-    const unsigned idx = A.first + (valid ? rel : 0);
-    const Cand c = A.cands[idx];
-    const FlacStreamInfo si = A.G.info[c.stream];
-    const int C = A.C, depth = si.depth;
+    const int C = A.C;
+    // A lane owns one candidate at a time and takes the next one off a ticket counter when its frame is done (`take` below, at round
+    // boundaries): frames differ a lot in length — a VERBATIM subframe has four times the bits of a Rice-coded one — and with a fixed
+    // candidate per lane a wave lived as long as its longest frame, most of its lanes idle for the second half; the grid is sized to what
+    // the chip holds at once, so there is no thinly populated second generation of workgroups either.
+    bool have = false;
+    unsigned idx = 0;
+    Cand c{};
+    FlacStreamInfo si{};
+    int depth = 0;
     Bits b;
     b.w0 = A.G.w0;
     b.lw = s_win + lane * WSTR;
     b.safe_words = A.G.safe_words;
-    b.first = A.G.base_bit + 8 * (A.G.off[c.stream] + si.first_byte);
-    b.end = A.G.base_bit + 8 * A.G.off[c.stream + 1];
+    b.first = b.end = b.pos = b.wi = 0;
     b.eof = 0;
     b.limit = ~0ull;
-    b.pos = A.G.base_bit + 8 * c.byte;
-    b.wi = b.pos >> 6;
     b.win_lo = 0; b.cur = b.nxt = b.nxt2 = 0;
-    int st = valid ? ST_FRAME : ST_DONE;
+    int st = ST_DONE;
     bool fresh = true;
     int status = FE_OK, bs = 0, chan_asgn = 0, nsub = 0, ch = 0;
     int order = 0, type = 0, wasted = 0, sdepth = 0, lshift = 0, after = ST_SUBEND, resume = ST_SUB;
@@ -395,8 +397,52 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     bool esc = false, direct = false, store_ok = false, ovf = false, gen_once = false, gen_part = false;
     long long cval = 0;
     u64 cand_scratch = 0, gcur = 0, end_byte = 0;
-    SubDesc *sd = A.sd + (size_t)idx * C;
+    SubDesc *sd = A.sd;
     R *const orow = s_out + lane * OSTRX;
+    auto start = [&](unsigned rel) {   // this lane's next candidate: everything a frame's decoding keeps between rounds, as at kernel entry
+        have = true;
+        idx = A.first + rel;
+        c = A.cands[idx];
+        si = A.G.info[c.stream];
+        depth = si.depth;
+        b.first = A.G.base_bit + 8 * (A.G.off[c.stream] + si.first_byte);
+        b.end = A.G.base_bit + 8 * A.G.off[c.stream + 1];
+        b.eof = 0;
+        b.limit = ~0ull;
+        b.pos = A.G.base_bit + 8 * c.byte;
+        b.wi = b.pos >> 6;
+        b.win_lo = 0; b.cur = b.nxt = b.nxt2 = 0;
+        st = ST_FRAME;
+        fresh = true;
+        status = FE_OK; bs = 0; chan_asgn = 0; nsub = 0; ch = 0;
+        order = 0; type = 0; wasted = 0; sdepth = 0; lshift = 0; after = ST_SUBEND; resume = ST_SUB;
+        nparts = 0; psize = 0; pi = 0; param = 0; nbits = 0; param_bits = 4; escape = 15; remaining = 0; jpos = 0;
+        esc = false; direct = false; store_ok = false; ovf = false; gen_once = false; gen_part = false;
+        cval = 0;
+        cand_scratch = 0; gcur = 0; end_byte = 0;
+        sd = A.sd + (size_t)idx * C;
+    };
+    auto finish = [&]() {              // the frame is done (or failed): what the chain walk needs to know about it
+        CandInfo f;
+        f.end_byte = end_byte;
+        f.scratch = cand_scratch;
+        f.sample_off = 0;
+        f.blocksize = bs; f.chan_asgn = chan_asgn; f.status = status; f.nsub = nsub;
+        f.seq = 0; f.used = 0;
+        A.ci[idx] = f;
+        if (ovf && status == FE_OK) atomicOr(A.flags, (unsigned)FLAG_OVERFLOW);
+        have = false;
+    };
+    auto take = [&]() {                // every lane without a frame takes a ticket: one atomic per wave
+        const u64 m = __ballot(!have);
+        if (!m) return;
+        unsigned base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(A.ticket, (unsigned)__builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        const unsigned rel = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1));
+        if (!have && rel < A.count) start(rel);
+    };
+    take();
     // the values of stream s go to 128 contiguous bytes; two streams per store instruction.  A round's values are stored at the top of the NEXT
     // round, behind the wait for that round's window lines: loads and stores share one counter (vmcnt), so stores issued in front of that wait
     // would be waited for as well; issued behind it they drain while the next round is decoded.
@@ -728,17 +774,9 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         gcur += (u64)cnt;
         __syncthreads();
         have_flush = true;
+        if (have && st == ST_DONE) finish();
+        take();
         if (__ballot(st != ST_DONE) == 0) { flush(); break; }
-    }
-    if (valid) {
-        CandInfo f;
-        f.end_byte = end_byte;
-        f.scratch = cand_scratch;
-        f.sample_off = 0;
-        f.blocksize = bs; f.chan_asgn = chan_asgn; f.status = status; f.nsub = nsub;
-        f.seq = 0; f.used = 0;
-        A.ci[idx] = f;
-        if (ovf && status == FE_OK) atomicOr(A.flags, (unsigned)FLAG_OVERFLOW);
     }
 }
 
@@ -1221,7 +1259,7 @@ struct Carve {
     size_t at = 0;
     size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
 };
-struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, pad; };
+struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, ticket; };
 
 static bool g_flac_force_wide() { const char *e = getenv("AUKIT_FLAC_WIDE"); return e && atoi(e) != 0; }
 
@@ -1284,7 +1322,11 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.sd = d_sd; A.C = C;
             A.scratch = reinterpret_cast<R *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
             A.limit_factor = limit_factor;
-            hipLaunchKernelGGL((k_flac_extract<R>), dim3((count + 63) / 64), dim3(64), 0, ctx->stream, A);
+            A.ticket = &d_cnt->ticket;
+            AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->ticket, 0, 4, ctx->stream));
+            // lanes pull candidates off the ticket counter: as many workgroups as the chip holds at once (17.6 KB of LDS each: 9 per CU)
+            const unsigned grid = std::min<unsigned>((count + 63) / 64, (unsigned)ctx->num_cus * 9u);
+            hipLaunchKernelGGL((k_flac_extract<R>), dim3(grid), dim3(64), 0, ctx->stream, A);
             AUKIT_HIP_CHECK(hipGetLastError());
             return AUKIT_OK;
         };
