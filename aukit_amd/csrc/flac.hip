@@ -458,6 +458,10 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         }
     };
     bool have_flush = false;
+    uint4 pf[LPW];      // per stream this lane loads for: the line that will replace its slot's line, already requested
+    u64 pf_line[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; i++) { pf[i] = make_uint4(0, 0, 0, 0); pf_line[i] = ~0ull; }
 
     for (;;) {
         // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per stream, 8 streams per load
@@ -478,12 +482,20 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     // ring slot sub8 holds the line of the new window that is congruent to sub8 mod LPW
                     const u64 l0 = ws / 2, line = l0 + (((u64)sub8 - l0) & (u64)(LPW - 1));
                     if (kf == ~0ull || line >= kf || line < kf - WN / 2) {
-                        const u64 wj = 2 * line;
-                        uint4 v = make_uint4(0, 0, 0, 0);
-                        if (wj < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + wj);
+                        // the line that follows a slot's line into the slot (eight lines on) was requested when that one arrived: a round ago or
+                        // more, so it is here — unless the lane is new or jumped, then it is fetched now
+                        uint4 v = pf[i];
+                        if (pf_line[i] != line) {
+                            v = make_uint4(0, 0, 0, 0);
+                            if (2 * line < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
+                        }
                         unsigned *wrow = s_win + s * WSTR + 4 * sub8;
                         wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
                         wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
+                        const u64 nl = line + LPW;
+                        pf_line[i] = nl;
+                        pf[i] = make_uint4(0, 0, 0, 0);
+                        if (2 * nl < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * nl);
                     }
                 }
             }
@@ -1331,7 +1343,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             A.ticket = &d_cnt->ticket;
             AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->ticket, 0, 4, ctx->stream));
             // lanes pull candidates off the ticket counter: as many workgroups as the chip holds at once (17.6 KB of LDS each: 9 per CU)
-            const unsigned grid = std::min<unsigned>((count + 63) / 64, (unsigned)ctx->num_cus * 9u);
+            const unsigned grid = std::min<unsigned>((count + 63) / 64, (unsigned)ctx->num_cus * 8u);
             hipLaunchKernelGGL((k_flac_extract<R>), dim3(grid), dim3(64), 0, ctx->stream, A);
             AUKIT_HIP_CHECK(hipGetLastError());
             return AUKIT_OK;
