@@ -450,6 +450,21 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
     // round, behind the wait for that round's window lines: loads and stores share one counter (vmcnt), so stores issued in front of that wait
     // would be waited for as well; issued behind it they drain while the next round is decoded.
     auto flush = [&]() {
+        // the usual round — every lane of the wave produced NCX values (or none) and writes them to a 16-byte aligned place — goes out as
+        // 16 bytes per lane, 64 / (NCX / 4) streams per store instruction
+        if (sizeof(R) == 4 && __all((s_cnt[lane] == NCX && (s_ptr[lane] & 3) == 0) || s_cnt[lane] == 0)) {
+            constexpr int LPS = NCX / 4, SPI = 64 / LPS;   // lanes per stream, streams per instruction
+            const int grp = lane / LPS, q4 = 4 * (lane % LPS);
+#pragma unroll
+            for (int i = 0; i < LPS; i++) {
+                const int s = SPI * i + grp;
+                if (s_cnt[s]) {
+                    const R *v = s_out + s * OSTRX + q4;
+                    *reinterpret_cast<uint4 *>(A.scratch + s_ptr[s] + q4) = make_uint4((unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]);
+                }
+            }
+            return;
+        }
         constexpr int PER = 64 / NCX;  // streams per store instruction
         const int part = lane / NCX, k = lane % NCX;
         for (int i = 0; i < NCX; i++) {
@@ -505,8 +520,11 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
         }
         // ---- every lane advances its own frame until it has produced NCX values or its window runs low
         int cnt = 0;
+        // a round that starts at an odd place produces as many values less as bring the next one back to a multiple of four: the 16-byte
+        // flush wants aligned rows, and one short round (first of a frame, after a run of long codes) would otherwise spoil every later one
+        const int lim = NCX - (int)(gcur & 3);
         if (st == ST_DIRECT_WAIT) { __threadfence(); direct = true; st = resume; }
-        while (st != ST_DONE && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+        while (st != ST_DONE && cnt < lim && (b.wi - b.win_lo) < (u64)(WN - 4)) {
             if (!direct && !gen_once && !gen_part && (st == ST_CODES || st == ST_PART || (st == ST_WARM && sdepth < 32))) {
                 // ---- fast path for everything that is a run of bit fields: Rice partitions incl. their headers and escape-coded
                 // partitions (:393-407), warm-up samples and VERBATIM subframes (:422-424, :456-458).  A 64-bit shift register is fed
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                         remaining = hdr ? (pi == 0 ? count_first : count_rest) : remaining - 1;
                         cnt += hdr ^ 1;
                         pi += (remaining == 0) & (warm_i ^ 1);   // a finished (or empty) partition
-                        if (!((cnt < NCX) & (rp < LOW_BITS) & ((remaining > 0) | ((warm_i ^ 1) & (pi < nparts))))) break;
+                        if (!((cnt < lim) & (rp < LOW_BITS) & ((remaining > 0) | ((warm_i ^ 1) & (pi < nparts))))) break;
                     }
                     if (!warm) { esc = fixed != 0; nbits = nfix; }
                 }
@@ -615,7 +633,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     nbits = gh ? (is_esc ? nb5 : 0) : nbits;
                     remaining = good ? (hdr ? count : remaining - 1) : remaining;
                     pi += (good & !warm & (remaining == 0)) ? 1 : 0;  // a finished (or empty) partition
-                    go = good & (cnt < NCX) & (rp < LOW_BITS) & ((remaining > 0) | (!warm & (pi < nparts)));
+                    go = good & (cnt < lim) & (rp < LOW_BITS) & ((remaining > 0) | (!warm & (pi < nparts)));
                 }
                 bits_seek(b, wbase + rp);
                 if (why == 1) gen_once = true;
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                     else st = remaining > 0 ? ST_CODES : (pi < nparts ? ST_PART : ST_SUBEND);
                 }
             } else if (st == ST_CODES) {
-                while (remaining > 0 && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                while (remaining > 0 && cnt < lim && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = esc ? read_sint(b, nbits) : read_rice(b, param);
                     if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
                     if (direct) { if (store_ok) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
@@ -638,7 +656,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 if (b.eof) { status = FE_NIL; st = ST_DONE; }
                 else if (remaining == 0) { pi++; gen_part = false; st = pi < nparts ? ST_PART : ST_SUBEND; }
             } else if (st == ST_WARM) {  // warm-up samples (:422-424, :430-432) or a VERBATIM subframe (:456-458)
-                while (remaining > 0 && cnt < NCX && (b.wi - b.win_lo) < (u64)(WN - 4)) {
+                while (remaining > 0 && cnt < lim && (b.wi - b.win_lo) < (u64)(WN - 4)) {
                     const long long v = read_sint(b, sdepth);
                     if constexpr (sizeof(R) == 4) { if (v != (long long)(R)v) ovf = true; }
                     if (direct) { if (store_ok && jpos < bs) A.scratch[cand_scratch + (u64)ch * bs + jpos] = (R)v; }
@@ -653,7 +671,7 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                 }
             } else if (st == ST_CONST) {  // :453-454
                 if constexpr (sizeof(R) == 4) { if (cval != (long long)(R)cval) ovf = true; }
-                while (remaining > 0 && cnt < NCX) { orow[cnt++] = (R)cval; remaining--; }
+                while (remaining > 0 && cnt < lim) { orow[cnt++] = (R)cval; remaining--; }
                 if (remaining == 0) st = ST_SUBEND;
             } else if (st == ST_PART) {  // :394-406
                 gen_once = false;
