@@ -23,6 +23,9 @@
 namespace aukit {
 
 typedef unsigned long long u64;
+#ifndef AUKIT_DF_MAPS_NQ
+#define AUKIT_DF_MAPS_NQ 4
+#endif
 
 struct SatMap { int a, lo, hi; };
 AUKIT_DEV int sm_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -96,8 +99,10 @@ struct DfParParams {
 };
 
 // The eight clamp-add steps of one byte, given the bit before it, compose to one clamp-add map: 512 table entries per workgroup.
+// (one dword per entry: eight unit steps inside [8, 1023] give a in [-8, 8], lo in [8, 16], hi in [1015, 1023]; as three ints the random
+// look-ups of a wave spent 70 % of their LDS cycles in bank conflicts — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02_dfpwm_pmc_lds.csv)
 __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
-    __shared__ SatMap bm[512];
+    __shared__ unsigned bm[512];
     for (int e = threadIdx.x; e < 512; e += 256) {
         unsigned byte = e & 255;
         int prev = e >> 8;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             f = sm_then(f, SatMap{bit == prev ? 1 : -1, 8, 1023});
             prev = bit;
         }
-        bm[e] = f;
+        bm[e] = (unsigned)(f.a + 8) | ((unsigned)(f.lo - 8) << 8) | ((unsigned)(1023 - f.hi) << 16);
     }
     __syncthreads();
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -132,10 +137,48 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             }
             b = 1;
         }
-        fed_for_each(p, b, f1, P.feed, [&](unsigned byte) {
-            f = sm_then(f, bm[(prev << 8) | byte]);
+        auto step = [&](unsigned byte) {
+            const unsigned e = bm[(prev << 8) | byte];
+            f = sm_then(f, SatMap{(int)(e & 31u) - 8, 8 + (int)((e >> 8) & 15u), 1023 - (int)((e >> 16) & 15u)});
             prev = byte >> 7;
-        });
+        };
+        // The usual block lies inside one run of the feed: 64 bytes per turn with the next 64 requested before these are looked at.  With one
+        // 16-byte vector ahead (fed_for_each) a lane had 16 bytes in flight and the kernel moved 0.8 TB/s, waiting 66 % of its time.
+        const u64 k0 = b / P.feed.run;
+        if (f1 > b && (f1 - 1) / P.feed.run == k0) {
+            const unsigned char *a = p + k0 * P.feed.stride + (b - k0 * P.feed.run);
+            u64 rem = f1 - b;
+            while (rem && ((uintptr_t)a & 15)) { step((unsigned)*a); a++; rem--; }
+            constexpr int NQ = AUKIT_DF_MAPS_NQ;   // 16-byte vectors per turn
+            uint4 cur[NQ], nxt[NQ];
+            if (rem >= 16 * NQ) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) cur[q] = reinterpret_cast<const uint4 *>(a)[q];
+            }
+            while (rem >= 16 * NQ) {
+                const bool more = rem >= 32 * NQ;
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) nxt[q] = reinterpret_cast<const uint4 *>(a + 16 * NQ)[q];
+                }
+#pragma unroll 1
+                for (int q = 0; q < NQ; q++) {
+                    const unsigned w4[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll 1
+                    for (int w = 0; w < 4; w++) {
+                        const unsigned word = w4[w];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) step((word >> (8 * j)) & 0xFF);
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
+                }
+                a += 16 * NQ; rem -= 16 * NQ;
+            }
+            while (rem) { step((unsigned)*a); a++; rem--; }
+        } else fed_for_each(p, b, f1, P.feed, step);
     }
     P.maps[(size_t)s * P.nblk + blk] = f;
 }
