@@ -63,12 +63,14 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
         float *orow = cur.orow;
         float carry = 0.f;  // the raw sample before the tile's first output: position n = r0 - a, one table step back when that is negative
         if (!first) carry = cur.r0 >= F.a ? interp_row<INTERP, false>(F, tab, cur.r0 - F.a) : interp_row<INTERP, false>(F, tab - 1, cur.r0 + F.b - F.a);
-        if (cur.cnt == (unsigned)WT) {  // whole tile: (q, rem) advanced by additions, as in k_fast_wave
+        if ((cur.cnt & 63u) == 0) {  // whole rows (every tile of an iterator call of 48000 outputs: 46 of 1024 and one of 896): (q, rem) advanced by additions, as in k_fast_wave
             const unsigned n0 = cur.r0 + (unsigned)lane * F.a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
+            const int rows = (int)(cur.cnt >> 6);   // wave-uniform
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
+                if (r >= rows) break;
                 const float s = interp_qr_raw<INTERP>(F, tab, q, rem);
                 const float prev = prev_lane(s, carry);
                 carry = last_lane(s);

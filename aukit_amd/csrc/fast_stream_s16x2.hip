@@ -145,12 +145,14 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream_s16x2(const ResamplePa
                 if (active) orowR[j] = orr;
             }
         };
-        if (cur.cnt == (unsigned)WT) {
+        if ((cur.cnt & 63u) == 0) {  // whole rows (an iterator call of 48000 outputs ends in a tile of 896)
             const unsigned n0 = cur.r0 + (unsigned)lane * F.a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
+            const int rows = (int)(cur.cnt >> 6);   // wave-uniform
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
+                if (r >= rows) break;
                 row(q, rem, (unsigned)(r * 64 + lane), true);
                 rem += F.dr64;
                 q += F.dq64;
