@@ -188,6 +188,8 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
                            const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0, const DfSliceHook *hook = nullptr);
 int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const unsigned long long *d_moff, const unsigned long long *d_mcount, unsigned char *out,
                            const unsigned long long *d_ooff, const uint64_t *h_ooff, int slices, bool *taken);
+int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const unsigned long long *d_moff, const unsigned long long *d_mcount, unsigned char *out,
+                          const unsigned long long *d_ooff, const uint64_t *h_ooff, bool *taken);
 bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff,
                            int *rc);  // exact parallel encoder for batches of a few streams (dfpwm_par.hip)
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const unsigned long long *d_in_off, const unsigned long long *d_count, uint32_t n, unsigned char *out,
@@ -1163,6 +1165,14 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
         const uint64_t want = std::max<uint64_t>(1, lanes_full / in->n);
         int slices = in->n >= 2048 ? (int)std::min<uint64_t>(8, max_bytes / 1920 / want) : 1;  // measured on config 4: 1 / 4 / 8 slices = 27.0 / 25.7 / 24.4 ms per step
         if (const char *e = getenv("AUKIT_DFPWM_SLICES")) slices = atoi(e);
+        // batches of up to one 64-stream group per CU: decoder and encoder in one persistent launch (AUKIT_DFPWM_FUSED=1: whatever the size, 0: never)
+        const char *fe = getenv("AUKIT_DFPWM_FUSED");
+        if (fe ? atoi(fe) != 0 : (in->n >= 2048 && !getenv("AUKIT_DFPWM_SLICES"))) {
+            bool taken = false;
+            rc = dfpwm_transcode_fused(ctx, in, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, t + in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), off.data(), &taken);
+            if (rc) return rc;
+            if (taken) return ctx_end_kernel(ctx, "k_df_fused", in->total() + off[in->n]);
+        }
         if (slices > 1) {
             bool taken = false;
             rc = dfpwm_transcode_sliced(ctx, in, reinterpret_cast<signed char *>(ctx->tmp_buf.p), t, t + in->n, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), off.data(), slices, &taken);

@@ -42,8 +42,9 @@ AUKIT_DEV u64 dfp_src_index(u64 f, const Feed &fd) { const u64 k = f / fd.run; r
 
 // Calls fn(byte) for the fed bytes [f0, f1) in order.  Inside a run the source is contiguous: aligned 16-byte loads (the next one
 // in flight while the current one is consumed), single bytes up to the first aligned address and around the end of a run.
-template <typename F>
-AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn) {
+// fn4(word) takes four fed bytes at once (the dwords of the aligned vectors: little-endian, first byte lowest).
+template <typename F, typename F4>
+AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn, F4 &&fn4) {
     if (f0 >= f1) return;
     const u64 k0 = f0 / fd.run, o0 = f0 - k0 * fd.run;
     const unsigned char *a = p + k0 * fd.stride + o0;  // next source byte
@@ -60,11 +61,7 @@ AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &
             if (have) pre = *reinterpret_cast<const uint4 *>(a + 16);
             const unsigned w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll 1
-            for (int w = 0; w < 4; w++) {
-                const unsigned word = w4[w];
-#pragma unroll
-                for (int j = 0; j < 4; j++) fn((word >> (8 * j)) & 0xFF);
-            }
+            for (int w = 0; w < 4; w++) fn4(w4[w]);
             a += 16; left -= 16; rem -= 16;
         } else {
             fn((unsigned)*a);
@@ -72,6 +69,13 @@ AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &
         }
         if (left == 0) { a += skip; left = run; have = false; }
     }
+}
+template <typename F>
+AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn) {
+    fed_for_each(p, f0, f1, fd, fn, [&](unsigned word) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) fn((word >> (8 * j)) & 0xFF);
+    });
 }
 
 struct DfParParams {
@@ -204,21 +208,36 @@ struct DfOut {  // where decoded samples go
 template <bool EMIT>
 AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
     u64 i = 8 * f0;  // index of the next decoded sample in the fed order
-    fed_for_each(p, f0, f1, O.feed, [&](unsigned byte) {
-        const unsigned nb = ~byte;
-        if (!EMIT) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) df_decode_b(d, df_pm1(nb, k));
-        } else if (O.mode == 1) {  // stereo frames → one mono int8 each (4 per fed byte: one dword store)
-            const signed char *lutc = O.lut + 128 * 257;  // indexed by signed (l, r)
+    if (EMIT && O.mode == 1) {
+        // stereo frames → one mono int8 each: 4 per fed byte (one dword store), 16 per aligned source dword (one 16-byte store — a
+        // quarter of the store instructions, each of which visits 64 cache lines for the 64 streams of a wave)
+        const signed char *lutc = O.lut + 128 * 257;  // indexed by signed (l, r)
+        auto four = [&](unsigned byte) -> unsigned {
+            const unsigned nb = ~byte;
             unsigned packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
                 packed |= ((unsigned)(unsigned char)lutc[l * 256 + r]) << (8 * k);
             }
-            *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = packed;
-            i += 8;
+            return packed;
+        };
+        typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+        fed_for_each(p, f0, f1, O.feed,
+                     [&](unsigned byte) { *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = four(byte); i += 8; },
+                     [&](unsigned word) {
+                         u32x4a v;
+                         v.x = four(word & 0xFF); v.y = four((word >> 8) & 0xFF); v.z = four((word >> 16) & 0xFF); v.w = four(word >> 24);
+                         *reinterpret_cast<u32x4a *>(O.base + (i >> 1)) = v;
+                         i += 32;
+                     });
+        return;
+    }
+    fed_for_each(p, f0, f1, O.feed, [&](unsigned byte) {
+        const unsigned nb = ~byte;
+        if (!EMIT) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) df_decode_b(d, df_pm1(nb, k));
         } else if (O.C == 1 && O.lead) {  // row shifted by `lead` elements: byte stores
 #pragma unroll
             for (int k = 0; k < 8; k++) O.base[O.lead + i + k] = (signed char)df_decode_b(d, df_pm1(nb, k));
@@ -613,6 +632,334 @@ int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *m
     if (!ran) return AUKIT_OK;  // not taken: the caller runs the plain sequence
     *taken = true;
     return prc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The transcode as ONE persistent launch (config 4 when the batch has at most one group of 64 streams per CU).
+// The time slices above cost max(decoder, encoder) per slice: every CU hosts one encoder wave, that wave's SIMD carries the encoder's
+// work on top of its share of the decoder's, and a slice ends when its slowest SIMD does.  Here one workgroup per CU (448 threads =
+// 7 waves: the dispatcher deals them round-robin over the four SIMDs, so one wave sits alone on its SIMD — found at run time from
+// HW_ID) runs until the batch is done:
+//   * the six waves that share three SIMDs are decoders: they take units (chunk index c, group of 64 streams j) off a ticket counter
+//     in time order, decode them exactly as k_df_chunks does, and publish flag[c][j] behind a release fence;
+//   * the lone wave is the ENCODER of the workgroup's own group of 64 streams: it waits for flag[c][j] (acquire), checks every lane's
+//     recorded start state against the true end state before it (k_df_verify's job, one chunk at a time: a mismatching lane decodes
+//     its chunk again serially from the true state before it encodes it), and encodes the chunk's mono samples, state in registers.
+//     While its next chunk is not there yet it takes decoder tickets itself, so its SIMD never idles.
+// Nothing waits for a wave that is not running: decoders wait for nobody, an encoder only for units that running waves have taken
+// or will take.  Bit-identical bytes; the staging rows and k_dfpwm_compact are those of the sliced version.
+struct DfFusedParams {
+    DfParParams P;        // src, off, fed, feed, n, bpc, nchunk, W, s_start, out = mono samples, out_off, stats
+    int *fst;             // [nchunk][10][npad]: start state (5 ints) and end state (5 ints) of every chunk lane, stream index fastest
+    unsigned *flags;      // [nchunk][G] unit done;  flags[nchunk * G] = the ticket counter, [nchunk * G + 1] = workgroups whose encoder sat alone
+    unsigned G, npad, total;
+    unsigned dbg;         // timing experiments only (AUKIT_DFPWM_FUSED_DBG; results are wrong with bits 1, 2): 1 encoder takes no tickets, 2 no encoder, 4 no release fence, 8 no acquire fence, 16 no decoders (the encoder alone on the chip)
+    const u64 *mcount;    // mono samples per stream
+    unsigned char *stage; // encoder output rows
+    u64 sstride;
+};
+
+AUKIT_DEV void dff_decode_unit(const DfFusedParams &F, unsigned c, unsigned j, const signed char *lut, unsigned lane) {
+    const DfParParams &P = F.P;
+    const unsigned s = j * 64 + lane;
+    if (s < P.n) {
+        const unsigned char *p = P.src + P.off[s];
+        const u64 fed = P.fed[s];
+        const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+        int *st = F.fst + (size_t)c * 10 * F.npad + s;
+        if (f0 >= fed && c > 0) st[(size_t)F.npad] = -1;  // strength -1: no such chunk
+        else {
+            DfOut O = dfp_out(P, s, lut);
+            O.mode = 1; O.C = 2;  // (constants here: the other output modes of dfp_run drop out of this kernel)
+            DfDec d{};
+            if (c > 0) {
+                const u64 fw = f0 - P.W;
+                d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
+                d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
+                dfp_run<false>(p, fw, f0, d, O);
+            }
+            int v[6];
+            dfp_pack(d, v);
+#pragma unroll
+            for (int i = 0; i < 5; i++) st[(size_t)i * F.npad] = v[i];
+            dfp_run<true>(p, f0, f1, d, O);
+            dfp_pack(d, v);
+#pragma unroll
+            for (int i = 0; i < 5; i++) st[(size_t)(5 + i) * F.npad] = v[i];
+        }
+    }
+    if (!(F.dbg & 4)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's stores are visible chip-wide (other XCDs' L2 included) before the flag is
+    if (lane == 0) __hip_atomic_store(&F.flags[(size_t)c * F.G + j], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one ticket, wave-uniform
+AUKIT_DEV unsigned dff_take(const DfFusedParams &F, unsigned lane) {
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(&F.flags[(size_t)F.P.nchunk * F.G], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+}
+
+AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char *lut, unsigned lane) {
+    const DfParParams &P = F.P;
+    const unsigned s = j * 64 + lane;
+    const bool act = s < P.n;
+    const u64 L = act ? F.mcount[s] : 0, fed = act ? P.fed[s] : 0;
+    const unsigned char *src = act ? P.src + P.off[s] : P.src;
+    const signed char *p = P.out + (act ? P.out_off[s] : 0);  // this stream's mono samples (16-byte aligned: host)
+    unsigned char *o = F.stage + (u64)s * F.sstride;
+    const u64 CH = (u64)P.bpc * P.W;
+    DfEnc e{};
+    u64 i = 0, w = 0;
+    int truth[6] = {0, 0, 0, 0, 0, 0};
+    unsigned redone = 0, chunks = 0;
+    bool tickets = !(F.dbg & 1);
+    // one round: 64 samples → 8 bytes
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto round_bits = [&](const u32x4 &q0, const u32x4 &q1, const u32x4 &q2, const u32x4 &q3) -> uint2 {
+        unsigned ob[2] = {0, 0};
+        const u32x4 q[4] = {q0, q1, q2, q3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned words[4] = {q[k].x ^ 0x80808080u, q[k].y ^ 0x80808080u, q[k].z ^ 0x80808080u, q[k].w ^ 0x80808080u};  // u = v + 128
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                unsigned byte = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) byte |= df_encode_u(e, (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF) & (1u << b);
+                ob[k >> 1] |= (byte & 255u) << (8 * (2 * (k & 1) + h));
+            }
+        }
+        i += 64;
+        return make_uint2(ob[0], ob[1]);
+    };
+    unsigned long long t_wait = 0, t_enc = 0, tt = wall_clock64();
+    unsigned c = 0;
+    while (c < P.nchunk) {
+        // wait for the next unit (decoding others meanwhile), then take every further unit that is already there: one span
+        const unsigned *fl = &F.flags[(size_t)c * F.G + j];
+        unsigned ready = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (F.dbg & 16);
+        while (!ready) {
+            if (tickets) {
+                const unsigned t = dff_take(F, lane);
+                if (t < F.total) dff_decode_unit(F, t / F.G, t % F.G, lut, lane);
+                else tickets = false;
+            } else __builtin_amdgcn_s_sleep(32);
+            ready = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned c1 = c + 1;
+        for (unsigned k = 1; k < 8; k++) {  // (bounded, single exit)
+            const bool more = c1 == c + k && c1 < P.nchunk && (__hip_atomic_load(fl + (size_t)k * F.G * (c + k < P.nchunk ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (F.dbg & 16)) != 0;
+            if (more) c1++;
+        }
+        if (!(F.dbg & 8)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        { const unsigned long long now = wall_clock64(); t_wait += now - tt; tt = now; }
+        for (unsigned cc = c; cc < c1; cc++) {
+            const u64 f0 = (u64)cc * CH;
+            if (act && (f0 < fed || cc == 0) && !(F.dbg & 16)) {
+                const int *st = F.fst + (size_t)cc * 10 * F.npad + s;
+                chunks++;
+                bool same = true;
+                if (cc > 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) same = same && st[(size_t)k * F.npad] == truth[k];
+                }
+                if (same) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) truth[k] = st[(size_t)(5 + k) * F.npad];
+                } else {  // (never on real data: the warm-up converges) decode the chunk again from the true state
+                    DfDec d;
+                    dfp_unpack(truth, d);
+                    const u64 f1 = f0 + CH < fed ? f0 + CH : fed;
+                    DfOut O = dfp_out(P, s, lut);
+                    O.mode = 1; O.C = 2;
+                    dfp_run<true>(src, f0, f1, d, O);
+                    dfp_pack(d, truth);
+                    redone++;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the samples just stored are read back below
+                }
+            }
+        }
+        // encode the samples these chunks made final (whole rounds of 64; the last chunk takes every stream to its end).  Under the
+        // decoders' traffic a load takes longer than a round (~1.4 us of dependent instructions): four rounds are kept in flight.
+        const bool last = c1 == P.nchunk;
+        const u64 lim = 4 * (u64)c1 * CH;
+        const u64 hi = last ? L : (lim < L ? lim : L & ~63ull);
+        // Four rounds (256 samples, ~6 us of dependent instructions) per turn.  Beside six decoder waves a load or a store of this wave
+        // takes several microseconds to come back, and the only wait hipcc's own scheduling leaves in a loop like this is a wait for
+        // everything; so the schedule is made by hand: the loads of the NEXT turn first (inline asm: they stay where they are;
+        // their registers pass through the wait as operands, so nothing reads or reuses them earlier), then this turn's arithmetic,
+        // then ONE wait — for those loads and for the stores of the turn before, both a whole turn old — and this turn's four stores.
+        if (i + 256 <= hi) {
+            u32x4 B[16];
+#define AUKIT_DFF_ISSUE(ptr)                                                                                                            \
+            asm volatile("global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:16\n\t"                        \
+                         "global_load_dwordx4 %2, %16, off offset:32\n\tglobal_load_dwordx4 %3, %16, off offset:48\n\t"              \
+                         "global_load_dwordx4 %4, %16, off offset:64\n\tglobal_load_dwordx4 %5, %16, off offset:80\n\t"              \
+                         "global_load_dwordx4 %6, %16, off offset:96\n\tglobal_load_dwordx4 %7, %16, off offset:112\n\t"             \
+                         "global_load_dwordx4 %8, %16, off offset:128\n\tglobal_load_dwordx4 %9, %16, off offset:144\n\t"            \
+                         "global_load_dwordx4 %10, %16, off offset:160\n\tglobal_load_dwordx4 %11, %16, off offset:176\n\t"          \
+                         "global_load_dwordx4 %12, %16, off offset:192\n\tglobal_load_dwordx4 %13, %16, off offset:208\n\t"          \
+                         "global_load_dwordx4 %14, %16, off offset:224\n\tglobal_load_dwordx4 %15, %16, off offset:240"               \
+                         : "=&v"(B[0]), "=&v"(B[1]), "=&v"(B[2]), "=&v"(B[3]), "=&v"(B[4]), "=&v"(B[5]), "=&v"(B[6]), "=&v"(B[7]), "=&v"(B[8]),    \
+                           "=&v"(B[9]), "=&v"(B[10]), "=&v"(B[11]), "=&v"(B[12]), "=&v"(B[13]), "=&v"(B[14]), "=&v"(B[15])                        \
+                         : "v"(ptr) : "memory")
+#define AUKIT_DFF_WAIT()                                                                                                                \
+            asm volatile("s_waitcnt vmcnt(0)"                                                                                           \
+                         : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]), "+v"(B[8]),            \
+                           "+v"(B[9]), "+v"(B[10]), "+v"(B[11]), "+v"(B[12]), "+v"(B[13]), "+v"(B[14]), "+v"(B[15]) : : "memory")
+            u32x4 A[16];
+            {
+                const signed char *pn = p + i;
+                AUKIT_DFF_ISSUE(pn);
+                AUKIT_DFF_WAIT();
+#pragma unroll
+                for (int k = 0; k < 16; k++) A[k] = B[k];
+            }
+            while (i + 256 <= hi) {
+                // never past what is final: a lane with nothing further reads its current samples again
+                const signed char *pn = p + (i + 512 <= hi ? i + 256 : i);
+                AUKIT_DFF_ISSUE(pn);
+                __builtin_amdgcn_sched_barrier(0);
+                uint2 ob[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) ob[r] = round_bits(A[4 * r], A[4 * r + 1], A[4 * r + 2], A[4 * r + 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                AUKIT_DFF_WAIT();  // nothing asynchronous is alive across the loop's back edge (hipcc copies loop-carried values around there)
+#pragma unroll
+                for (int r = 0; r < 4; r++) *reinterpret_cast<uint2 *>(o + w + 8 * r) = ob[r];  // (w is a multiple of 8); waited for a turn later
+                w += 32;
+#pragma unroll
+                for (int k = 0; k < 16; k++) A[k] = B[k];
+            }
+#undef AUKIT_DFF_ISSUE
+#undef AUKIT_DFF_WAIT
+        }
+        while (i + 64 <= hi) {  // what is left of a span that is not a multiple of 256 samples (stream ends, odd chunk sizes)
+            const u32x4 *q = reinterpret_cast<const u32x4 *>(p + i);
+            const u32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            *reinterpret_cast<uint2 *>(o + w) = round_bits(q0, q1, q2, q3);
+            w += 8;
+        }
+        if (last && i < L) {  // the last < 64 samples, the last byte padded with samples of value 0
+            for (; i < L; i += 8) {
+                unsigned byte = 0;
+                for (int b = 0; b < 8; b++) {
+                    const unsigned u = i + b < L ? (unsigned)((int)p[i + b] + 128) : 128u;
+                    byte |= df_encode_u(e, u) & (1u << b);
+                }
+                o[w++] = (unsigned char)byte;
+            }
+        }
+        c = c1;
+        { const unsigned long long now = wall_clock64(); t_enc += now - tt; tt = now; }
+    }
+    if (lane == 0) { atomicAdd(&F.flags[(size_t)P.nchunk * F.G + 3], (unsigned)(t_wait >> 4)); atomicAdd(&F.flags[(size_t)P.nchunk * F.G + 4], (unsigned)(t_enc >> 4)); }
+    if (redone) atomicAdd(&P.stats[0], redone);
+    if (chunks) atomicAdd(&P.stats[1], chunks);
+}
+
+__global__ __launch_bounds__(448) void k_df_fused(const DfFusedParams F) {
+    extern __shared__ signed char lut[];  // 64 KiB mix table (+ padding so that a CU holds one workgroup)
+    __shared__ unsigned simd_of[8];
+    for (int i = threadIdx.x; i < 65536; i += blockDim.x) lut[i] = (signed char)dfp_mix((i >> 8) - 128, (i & 255) - 128);
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (lane == 0) simd_of[wave] = (hw >> 4) & 3u;
+    __syncthreads();
+    // the encoder: the wave that has its SIMD to itself (wave 3 when the seven waves were dealt round-robin)
+    unsigned enc = 3, alone = 0;
+    for (unsigned a = 0; a < 7; a++) {
+        unsigned others = 0;
+        for (unsigned b = 0; b < 7; b++) others += (b != a && simd_of[b] == simd_of[a]) ? 1u : 0u;
+        if (others == 0 && !alone) { enc = a; alone = 1; }
+    }
+    if (threadIdx.x == 0 && alone) atomicAdd(&F.flags[(size_t)F.P.nchunk * F.G + 1], 1u);
+    if (wave == enc && (F.dbg & 2)) return;
+    if (wave == enc && blockIdx.x < F.G) {
+        const unsigned long long t0 = wall_clock64();
+        dff_encoder(F, blockIdx.x, lut, lane);
+        if (lane == 0) atomicMax(&F.flags[(size_t)F.P.nchunk * F.G + 2], (unsigned)(wall_clock64() - t0));  // (AUKIT_DFPWM_STATS: the slowest encoder, 100 MHz ticks)
+        return;
+    }
+    if (F.dbg & 32) {  // timing experiment: the decoder waves as a pure VALU load
+        float v0 = (float)lane, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f;
+        for (int it = 0; it < 2500000; it++) { v0 = v0 * 1.0001f + 0.5f; v1 = v1 * 1.0001f + 0.5f; v2 = v2 * 1.0001f + 0.5f; v3 = v3 * 1.0001f + 0.5f; }
+        if (v0 + v1 + v2 + v3 == 12345.f) F.flags[0] = 7;
+        return;
+    }
+    unsigned t = (F.dbg & 16) ? F.total : dff_take(F, lane);
+    while (t < F.total) {
+        dff_decode_unit(F, t / F.G, t % F.G, lut, lane);
+        t = dff_take(F, lane);
+    }
+}
+
+// host side of the fused transcode; *taken = false (nothing launched) when the batch does not fit its shape
+int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const u64 *d_moff, const u64 *d_mcount, unsigned char *out, const u64 *d_ooff,
+                          const uint64_t *h_ooff, bool *taken) {
+    *taken = false;
+    const uint32_t n = in->n;
+    const unsigned G = (n + 63) / 64;
+    if (n == 0 || G > (unsigned)ctx->num_cus || getenv("AUKIT_DFPWM_SERIAL")) return AUKIT_OK;
+    std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + n), h_fed(n);
+    uint64_t fed_max = 0, max_out = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        h_fed[s] = nb ? nb + (nb + 6000 - 1) / 6000 - 1 : 0;  // 6001-byte slices advanced by 6000 (Q10)
+        fed_max = std::max(fed_max, h_fed[s]);
+        max_out = std::max<uint64_t>(max_out, h_ooff[s + 1] - h_ooff[s]);
+    }
+    uint64_t W = 256;
+    if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(16, strtoull(e, nullptr, 10) & ~15ull);  // 4 W mono samples = whole encoder rounds
+    const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
+    // units per decoder wave: enough of them that the last ones end close together, long enough that the warm-up stays 1/8 of a chunk
+    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 384 * 10 / n);
+    if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
+    const unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 8u);
+    const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
+    if (nchunk < 2) return AUKIT_OK;
+    const unsigned npad = (unsigned)round_up(n, 64);
+    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nchunk * sizeof(SatMap), b_ss = (size_t)n * (nchunk + 1) * 4, b_st = (size_t)nchunk * 10 * npad * 4,
+                 b_fl = round_up(((size_t)nchunk * G + 5) * 4, 64);
+    int rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + b_st + b_fl + 256);
+    if (rc) return rc;
+    char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+    if ((rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
+    const u64 sstride = round_up(max_out + 16, 16);
+    if ((rc = ctx->enc_state_buf.ensure((size_t)n * sstride + 64))) return rc;
+    DfFusedParams F{};
+    DfParParams &P = F.P;
+    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{6001, 6000};
+    P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+    P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
+    F.fst = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss);
+    F.flags = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st);
+    P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st + b_fl);
+    P.mode = 1; P.C = 2; P.out = mono; P.out_off = d_moff; P.out_stride = nullptr; P.lead = 0;
+    if (const char *e = getenv("AUKIT_DFPWM_FUSED_DBG")) F.dbg = (unsigned)atoi(e);
+    F.G = G; F.npad = npad; F.total = nchunk * G; F.mcount = d_mcount;
+    F.stage = reinterpret_cast<unsigned char *>(ctx->enc_state_buf.p); F.sstride = sstride;
+    if (hipMemsetAsync(F.flags, 0, b_fl + 8, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
+    static bool attr_set = false;
+    const unsigned lds = 65536 + 20480;  // more than half of a CU's 160 KiB: one workgroup per CU
+    if (!attr_set) { AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_df_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_dfpwm_compact, dim3((unsigned)std::min<u64>((max_out / 4 + 256) / 256, 4), n), dim3(256), 0, ctx->stream, F.stage, sstride, out, d_ooff, n);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    if (getenv("AUKIT_DFPWM_STATS")) {
+        unsigned h[2] = {0, 0}, al[4] = {0, 0, 0, 0};
+        (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 16, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms)\n",
+                n, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G);
+    }
+    *taken = true;
+    return AUKIT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -126,6 +126,20 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle, monkeypatch):
         assert again == fused, env
         for x, y in zip(dec, au.download()):
             assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), env
+    # the one-launch transcode of large batches (k_df_fused: decoder waves on a ticket counter, one encoder wave per 64 streams following
+    # them chunk by chunk), forced onto this small batch: default shape; 16-byte warm-up blocks (most recorded start states are wrong and
+    # the encoder lanes decode their chunks again); odd chunk sizes; one chunk per block
+    for env in ({}, {"AUKIT_DFPWM_BLOCK": "16", "AUKIT_DFPWM_CHUNKS": "1000"}, {"AUKIT_DFPWM_BLOCK": "6000", "AUKIT_DFPWM_CHUNKS": "50"},
+                {"AUKIT_DFPWM_BLOCK": "250", "AUKIT_DFPWM_CHUNKS": "7"}, {"AUKIT_DFPWM_BLOCK": "48", "AUKIT_DFPWM_CHUNKS": "100000"}):
+        monkeypatch.setenv("AUKIT_DFPWM_FUSED", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        again = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        assert ctx.last_kernel()[0] == "k_df_fused"
+        monkeypatch.delenv("AUKIT_DFPWM_FUSED")
+        for k in env:
+            monkeypatch.delenv(k)
+        assert again == fused, env
     monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
     B.dfpwm_transcode_mono(ctx, bt, 2)
     assert ctx.last_kernel()[0] == "k_dfpwm_transcode_stereo"
@@ -145,6 +159,33 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle, monkeypatch):
     monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
     assert B.dfpwm_transcode_mono(ctx, bt2, 2).download() == fused2
     assert fused2[1:] == fused
+
+
+def test_fused_transcode_ragged_groups(ctx, oracle, monkeypatch):
+    """k_df_fused on 150 streams (three groups of 64, the last one partial) of six different lengths, empty and one-slice streams among
+    them: the bytes of the one-lane-per-stream kernel and of the oracle."""
+    B = _B()
+    base = []
+    for i, n in enumerate((30000, 0, 6000, 18016, 6001, 12345 * 2)):
+        l, r = np.round(signal(n * 4, 48000, 4, 60 + 2 * i) * 100), np.round(signal(n * 4, 48000, 4, 61 + 2 * i) * 90)
+        base.append(oracle.dfpwm_encode(np.stack([l, r], 1).ravel()) if n else b"")
+    bt = B.Batch.upload(ctx, [base[(i * 5 + i // 7) % 6] for i in range(150)])
+    monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
+    want = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
+    for env in ({}, {"AUKIT_DFPWM_BLOCK": "32", "AUKIT_DFPWM_CHUNKS": "40"}):
+        monkeypatch.setenv("AUKIT_DFPWM_FUSED", "1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        assert ctx.last_kernel()[0] == "k_df_fused"
+        monkeypatch.delenv("AUKIT_DFPWM_FUSED")
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got == want, env
+    for c in range(6):
+        i = [(i * 5 + i // 7) % 6 for i in range(150)].index(c)
+        assert want[i] == (oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(base[c], 2, 48000)), True) if base[c] else b""), c
 
 
 @pytest.mark.parametrize("ch,mono,rate", [(1, False, 48000), (2, False, 48000), (2, True, 48000), (1, False, 24000), (2, True, 32000)])
