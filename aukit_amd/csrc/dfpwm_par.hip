@@ -19,6 +19,9 @@
 #include <algorithm>
 #include "common.h"
 #include "dfpwm_dev.h"
+#ifndef AUKIT_DFF_R
+#define AUKIT_DFF_R 4  // rounds of 64 samples per turn of the fused transcode's encoder (2 or 4)
+#endif
 
 namespace aukit {
 
@@ -102,6 +105,9 @@ struct DfParParams {
     unsigned c_lo, c_hi;  // k_df_chunks / k_df_verify: the chunk indices [c_lo, c_hi) of every stream (a time slice of the batch)
 };
 
+// first fed byte of chunk c
+AUKIT_DEV u64 dfp_chunk_start(const DfParParams &P, unsigned c) { return (u64)c * P.bpc * P.W; }
+
 // The eight clamp-add steps of one byte, given the bit before it, compose to one clamp-add map: 512 table entries per workgroup.
 // (one dword per entry: eight unit steps inside [8, 1023] give a in [-8, 8], lo in [8, 16], hi in [1015, 1023]; as three ints the random
 // look-ups of a wave spent 70 % of their LDS cycles in bank conflicts — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02_dfpwm_pmc_lds.csv)
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     if (blk >= P.nblk) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
-    const u64 CH = (u64)P.bpc * P.W, e1 = (u64)(blk + 1) * CH - P.W;
-    const u64 f0 = blk ? (u64)blk * CH - P.W : 0, f1 = e1 < fed ? e1 : fed;
+    const u64 e1 = dfp_chunk_start(P, blk + 1) - P.W;
+    const u64 f0 = blk ? dfp_chunk_start(P, blk) - P.W : 0, f1 = e1 < fed ? e1 : fed;
     SatMap f{0, -(1 << 28), 1 << 28};
-    if (f0 < fed) {
+    if (f0 < f1) {
         int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
         u64 b = f0;
         if (b == 0) {  // from the reset state (strength 0) the first step lands on 8 either way: do the stream's first byte bit by bit
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (c >= P.c_hi) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
-    const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+    const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
     int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6, *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
     if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
     const DfOut O = dfp_out(P, s, lut);
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
-    const u64 fed = P.fed[s], CH = (u64)P.bpc * P.W;
+    const u64 fed = P.fed[s];
     const DfOut O = dfp_out(P, s, nullptr);
     int truth[6];
     const unsigned c_first = P.c_lo > 1 ? P.c_lo : 1;  // the chunk before it was verified by the slice before this one (chunk 0 starts from the reset state: always true)
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
         if (same) { for (int i = 0; i < 6; i++) truth[i] = se[i]; continue; }
         DfDec d;
         dfp_unpack(truth, d);
-        const u64 f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+        const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
         if (P.mode == 1) {  // no table in this kernel: mix computed on the spot
             u64 i = 4 * f0;
             for (u64 b = f0; b < f1; b++) {
@@ -653,7 +659,7 @@ struct DfFusedParams {
     int *fst;             // [nchunk][10][npad]: start state (5 ints) and end state (5 ints) of every chunk lane, stream index fastest
     unsigned *flags;      // [nchunk][G] unit done;  flags[nchunk * G] = the ticket counter, [nchunk * G + 1] = workgroups whose encoder sat alone
     unsigned G, npad, total;
-    unsigned dbg;         // timing experiments only (AUKIT_DFPWM_FUSED_DBG; results are wrong with bits 1, 2): 1 encoder takes no tickets, 2 no encoder, 4 no release fence, 8 no acquire fence, 16 no decoders (the encoder alone on the chip)
+    unsigned dbg;         // AUKIT_DFPWM_FUSED_DBG, A/B only: 1 = the encoder waves never take decoder tickets (same bytes)
     const u64 *mcount;    // mono samples per stream
     unsigned char *stage; // encoder output rows
     u64 sstride;
@@ -665,7 +671,7 @@ AUKIT_DEV void dff_decode_unit(const DfFusedParams &F, unsigned c, unsigned j, c
     if (s < P.n) {
         const unsigned char *p = P.src + P.off[s];
         const u64 fed = P.fed[s];
-        const u64 CH = (u64)P.bpc * P.W, f0 = (u64)c * CH, f1 = f0 + CH < fed ? f0 + CH : fed;
+        const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
         int *st = F.fst + (size_t)c * 10 * F.npad + s;
         if (f0 >= fed && c > 0) st[(size_t)F.npad] = -1;  // strength -1: no such chunk
         else {
@@ -688,7 +694,7 @@ AUKIT_DEV void dff_decode_unit(const DfFusedParams &F, unsigned c, unsigned j, c
             for (int i = 0; i < 5; i++) st[(size_t)(5 + i) * F.npad] = v[i];
         }
     }
-    if (!(F.dbg & 4)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's stores are visible chip-wide (other XCDs' L2 included) before the flag is
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's stores are visible chip-wide (other XCDs' L2 included) before the flag is
     if (lane == 0) __hip_atomic_store(&F.flags[(size_t)c * F.G + j], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -707,7 +713,6 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
     const unsigned char *src = act ? P.src + P.off[s] : P.src;
     const signed char *p = P.out + (act ? P.out_off[s] : 0);  // this stream's mono samples (16-byte aligned: host)
     unsigned char *o = F.stage + (u64)s * F.sstride;
-    const u64 CH = (u64)P.bpc * P.W;
     DfEnc e{};
     u64 i = 0, w = 0;
     int truth[6] = {0, 0, 0, 0, 0, 0};
@@ -737,25 +742,25 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
     while (c < P.nchunk) {
         // wait for the next unit (decoding others meanwhile), then take every further unit that is already there: one span
         const unsigned *fl = &F.flags[(size_t)c * F.G + j];
-        unsigned ready = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (F.dbg & 16);
+        unsigned ready = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (!ready) {
             if (tickets) {
                 const unsigned t = dff_take(F, lane);
                 if (t < F.total) dff_decode_unit(F, t / F.G, t % F.G, lut, lane);
                 else tickets = false;
-            } else __builtin_amdgcn_s_sleep(32);
+            } else __builtin_amdgcn_s_sleep(8);
             ready = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         unsigned c1 = c + 1;
         for (unsigned k = 1; k < 8; k++) {  // (bounded, single exit)
-            const bool more = c1 == c + k && c1 < P.nchunk && (__hip_atomic_load(fl + (size_t)k * F.G * (c + k < P.nchunk ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (F.dbg & 16)) != 0;
+            const bool more = c1 == c + k && c1 < P.nchunk && __hip_atomic_load(fl + (size_t)k * F.G * (c + k < P.nchunk ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (more) c1++;
         }
-        if (!(F.dbg & 8)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         { const unsigned long long now = wall_clock64(); t_wait += now - tt; tt = now; }
         for (unsigned cc = c; cc < c1; cc++) {
-            const u64 f0 = (u64)cc * CH;
-            if (act && (f0 < fed || cc == 0) && !(F.dbg & 16)) {
+            const u64 f0 = dfp_chunk_start(P, cc);
+            if (act && (f0 < fed || cc == 0)) {
                 const int *st = F.fst + (size_t)cc * 10 * F.npad + s;
                 chunks++;
                 bool same = true;
@@ -769,7 +774,7 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
                 } else {  // (never on real data: the warm-up converges) decode the chunk again from the true state
                     DfDec d;
                     dfp_unpack(truth, d);
-                    const u64 f1 = f0 + CH < fed ? f0 + CH : fed;
+                    const u64 e1 = dfp_chunk_start(P, cc + 1), f1 = e1 < fed ? e1 : fed;
                     DfOut O = dfp_out(P, s, lut);
                     O.mode = 1; O.C = 2;
                     dfp_run<true>(src, f0, f1, d, O);
@@ -782,56 +787,59 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
         // encode the samples these chunks made final (whole rounds of 64; the last chunk takes every stream to its end).  Under the
         // decoders' traffic a load takes longer than a round (~1.4 us of dependent instructions): four rounds are kept in flight.
         const bool last = c1 == P.nchunk;
-        const u64 lim = 4 * (u64)c1 * CH;
+        const u64 lim = 4 * dfp_chunk_start(P, c1);
         const u64 hi = last ? L : (lim < L ? lim : L & ~63ull);
         // Four rounds (256 samples, ~6 us of dependent instructions) per turn.  Beside six decoder waves a load or a store of this wave
         // takes several microseconds to come back, and the only wait hipcc's own scheduling leaves in a loop like this is a wait for
         // everything; so the schedule is made by hand: the loads of the NEXT turn first (inline asm: they stay where they are;
         // their registers pass through the wait as operands, so nothing reads or reuses them earlier), then this turn's arithmetic,
         // then ONE wait — for those loads and for the stores of the turn before, both a whole turn old — and this turn's four stores.
-        if (i + 256 <= hi) {
-            u32x4 B[16];
-#define AUKIT_DFF_ISSUE(ptr)                                                                                                            \
-            asm volatile("global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:16\n\t"                        \
-                         "global_load_dwordx4 %2, %16, off offset:32\n\tglobal_load_dwordx4 %3, %16, off offset:48\n\t"              \
-                         "global_load_dwordx4 %4, %16, off offset:64\n\tglobal_load_dwordx4 %5, %16, off offset:80\n\t"              \
-                         "global_load_dwordx4 %6, %16, off offset:96\n\tglobal_load_dwordx4 %7, %16, off offset:112\n\t"             \
-                         "global_load_dwordx4 %8, %16, off offset:128\n\tglobal_load_dwordx4 %9, %16, off offset:144\n\t"            \
-                         "global_load_dwordx4 %10, %16, off offset:160\n\tglobal_load_dwordx4 %11, %16, off offset:176\n\t"          \
-                         "global_load_dwordx4 %12, %16, off offset:192\n\tglobal_load_dwordx4 %13, %16, off offset:208\n\t"          \
-                         "global_load_dwordx4 %14, %16, off offset:224\n\tglobal_load_dwordx4 %15, %16, off offset:240"               \
-                         : "=&v"(B[0]), "=&v"(B[1]), "=&v"(B[2]), "=&v"(B[3]), "=&v"(B[4]), "=&v"(B[5]), "=&v"(B[6]), "=&v"(B[7]), "=&v"(B[8]),    \
-                           "=&v"(B[9]), "=&v"(B[10]), "=&v"(B[11]), "=&v"(B[12]), "=&v"(B[13]), "=&v"(B[14]), "=&v"(B[15])                        \
+        constexpr int R = AUKIT_DFF_R;  // rounds per turn
+        if (i + 64 * R <= hi) {
+            u32x4 B[4 * R];
+#define AUKIT_DFF_ISSUE8(b, ptr, o0, o1, o2, o3, o4, o5, o6, o7)                                                                           \
+            asm volatile("global_load_dwordx4 %0, %8, off offset:" #o0 "\n\tglobal_load_dwordx4 %1, %8, off offset:" #o1 "\n\t"                \
+                         "global_load_dwordx4 %2, %8, off offset:" #o2 "\n\tglobal_load_dwordx4 %3, %8, off offset:" #o3 "\n\t"                \
+                         "global_load_dwordx4 %4, %8, off offset:" #o4 "\n\tglobal_load_dwordx4 %5, %8, off offset:" #o5 "\n\t"                \
+                         "global_load_dwordx4 %6, %8, off offset:" #o6 "\n\tglobal_load_dwordx4 %7, %8, off offset:" #o7                       \
+                         : "=&v"(B[b]), "=&v"(B[b + 1]), "=&v"(B[b + 2]), "=&v"(B[b + 3]), "=&v"(B[b + 4]), "=&v"(B[b + 5]), "=&v"(B[b + 6]), "=&v"(B[b + 7]) \
                          : "v"(ptr) : "memory")
-#define AUKIT_DFF_WAIT()                                                                                                                \
-            asm volatile("s_waitcnt vmcnt(0)"                                                                                           \
-                         : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]), "+v"(B[8]),            \
-                           "+v"(B[9]), "+v"(B[10]), "+v"(B[11]), "+v"(B[12]), "+v"(B[13]), "+v"(B[14]), "+v"(B[15]) : : "memory")
-            u32x4 A[16];
+#define AUKIT_DFF_TIE8(b, text)                                                                                                         \
+            asm volatile(text : "+v"(B[b]), "+v"(B[b + 1]), "+v"(B[b + 2]), "+v"(B[b + 3]), "+v"(B[b + 4]), "+v"(B[b + 5]), "+v"(B[b + 6]), "+v"(B[b + 7]) : : "memory")
+#if AUKIT_DFF_R == 4
+#define AUKIT_DFF_ISSUE(ptr) do { AUKIT_DFF_ISSUE8(0, ptr, 0, 16, 32, 48, 64, 80, 96, 112); AUKIT_DFF_ISSUE8(8, ptr, 128, 144, 160, 176, 192, 208, 224, 240); } while (0)
+#define AUKIT_DFF_WAIT() do { AUKIT_DFF_TIE8(0, "s_waitcnt vmcnt(0)"); AUKIT_DFF_TIE8(8, ""); } while (0)
+#else
+#define AUKIT_DFF_ISSUE(ptr) AUKIT_DFF_ISSUE8(0, ptr, 0, 16, 32, 48, 64, 80, 96, 112)
+#define AUKIT_DFF_WAIT() AUKIT_DFF_TIE8(0, "s_waitcnt vmcnt(0)")
+#endif
+            u32x4 A[4 * R];
             {
                 const signed char *pn = p + i;
                 AUKIT_DFF_ISSUE(pn);
                 AUKIT_DFF_WAIT();
 #pragma unroll
-                for (int k = 0; k < 16; k++) A[k] = B[k];
+                for (int k = 0; k < 4 * R; k++) A[k] = B[k];
             }
-            while (i + 256 <= hi) {
+            while (i + 64 * R <= hi) {
                 // never past what is final: a lane with nothing further reads its current samples again
-                const signed char *pn = p + (i + 512 <= hi ? i + 256 : i);
+                const signed char *pn = p + (i + 128 * R <= hi ? i + 64 * R : i);
                 AUKIT_DFF_ISSUE(pn);
                 __builtin_amdgcn_sched_barrier(0);
-                uint2 ob[4];
+                uint2 ob[R];
 #pragma unroll
-                for (int r = 0; r < 4; r++) ob[r] = round_bits(A[4 * r], A[4 * r + 1], A[4 * r + 2], A[4 * r + 3]);
+                for (int r = 0; r < R; r++) ob[r] = round_bits(A[4 * r], A[4 * r + 1], A[4 * r + 2], A[4 * r + 3]);
                 __builtin_amdgcn_sched_barrier(0);
                 AUKIT_DFF_WAIT();  // nothing asynchronous is alive across the loop's back edge (hipcc copies loop-carried values around there)
 #pragma unroll
-                for (int r = 0; r < 4; r++) *reinterpret_cast<uint2 *>(o + w + 8 * r) = ob[r];  // (w is a multiple of 8); waited for a turn later
-                w += 32;
+                for (int r = 0; r < R; r++) *reinterpret_cast<uint2 *>(o + w + 8 * r) = ob[r];  // (w is a multiple of 8); waited for a turn later
+                w += 8 * R;
 #pragma unroll
-                for (int k = 0; k < 16; k++) A[k] = B[k];
+                for (int k = 0; k < 4 * R; k++) A[k] = B[k];
             }
 #undef AUKIT_DFF_ISSUE
+#undef AUKIT_DFF_ISSUE8
+#undef AUKIT_DFF_TIE8
 #undef AUKIT_DFF_WAIT
         }
         while (i + 64 <= hi) {  // what is left of a span that is not a multiple of 256 samples (stream ends, odd chunk sizes)
@@ -875,23 +883,21 @@ __global__ __launch_bounds__(448) void k_df_fused(const DfFusedParams F) {
         if (others == 0 && !alone) { enc = a; alone = 1; }
     }
     if (threadIdx.x == 0 && alone) atomicAdd(&F.flags[(size_t)F.P.nchunk * F.G + 1], 1u);
-    if (wave == enc && (F.dbg & 2)) return;
     if (wave == enc && blockIdx.x < F.G) {
         const unsigned long long t0 = wall_clock64();
         dff_encoder(F, blockIdx.x, lut, lane);
         if (lane == 0) atomicMax(&F.flags[(size_t)F.P.nchunk * F.G + 2], (unsigned)(wall_clock64() - t0));  // (AUKIT_DFPWM_STATS: the slowest encoder, 100 MHz ticks)
         return;
     }
-    if (F.dbg & 32) {  // timing experiment: the decoder waves as a pure VALU load
-        float v0 = (float)lane, v1 = v0 + 1.f, v2 = v0 + 2.f, v3 = v0 + 3.f;
-        for (int it = 0; it < 2500000; it++) { v0 = v0 * 1.0001f + 0.5f; v1 = v1 * 1.0001f + 0.5f; v2 = v2 * 1.0001f + 0.5f; v3 = v3 * 1.0001f + 0.5f; }
-        if (v0 + v1 + v2 + v3 == 12345.f) F.flags[0] = 7;
-        return;
-    }
-    unsigned t = (F.dbg & 16) ? F.total : dff_take(F, lane);
+    const unsigned long long td0 = wall_clock64();
+    unsigned t = dff_take(F, lane);
     while (t < F.total) {
         dff_decode_unit(F, t / F.G, t % F.G, lut, lane);
         t = dff_take(F, lane);
+    }
+    if (lane == 0) {  // (AUKIT_DFPWM_STATS) the slowest and the mean decoder wave
+        atomicMax(&F.flags[(size_t)F.P.nchunk * F.G + 5], (unsigned)(wall_clock64() - td0));
+        atomicAdd(&F.flags[(size_t)F.P.nchunk * F.G + 6], (unsigned)((wall_clock64() - td0) >> 8));
     }
 }
 
@@ -921,7 +927,7 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     if (nchunk < 2) return AUKIT_OK;
     const unsigned npad = (unsigned)round_up(n, 64);
     const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nchunk * sizeof(SatMap), b_ss = (size_t)n * (nchunk + 1) * 4, b_st = (size_t)nchunk * 10 * npad * 4,
-                 b_fl = round_up(((size_t)nchunk * G + 5) * 4, 64);
+                 b_fl = round_up(((size_t)nchunk * G + 8) * 4, 64);
     int rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + b_st + b_fl + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
@@ -951,12 +957,12 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     hipLaunchKernelGGL(k_dfpwm_compact, dim3((unsigned)std::min<u64>((max_out / 4 + 256) / 256, 4), n), dim3(256), 0, ctx->stream, F.stage, sstride, out, d_ooff, n);
     AUKIT_HIP_CHECK(hipGetLastError());
     if (getenv("AUKIT_DFPWM_STATS")) {
-        unsigned h[2] = {0, 0}, al[4] = {0, 0, 0, 0};
+        unsigned h[2] = {0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
         (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 16, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 24, hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms)\n",
-                n, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G);
+        fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms); decoder waves: slowest %.2f ms, mean %.2f ms\n",
+                n, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G, al[4] * 1e-5, al[5] * 256e-5 / (6.0 * std::max<int>(ctx->num_cus, (int)G)));
     }
     *taken = true;
     return AUKIT_OK;
