@@ -653,7 +653,7 @@ int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *m
 //     its chunk again serially from the true state before it encodes it), and encodes the chunk's mono samples, state in registers.
 //     While its next chunk is not there yet it takes decoder tickets itself, so its SIMD never idles.
 // Nothing waits for a wave that is not running: decoders wait for nobody, an encoder only for units that running waves have taken
-// or will take.  Bit-identical bytes; the staging rows and k_dfpwm_compact are those of the sliced version.
+// or will take.  Bit-identical bytes, written straight into the packed result (8 bytes per round: no staging rows, no compaction pass).
 struct DfFusedParams {
     DfParParams P;        // src, off, fed, feed, n, bpc, nchunk, W, s_start, out = mono samples, out_off, stats
     int *fst;             // [nchunk][10][npad]: start state (5 ints) and end state (5 ints) of every chunk lane, stream index fastest
@@ -661,8 +661,8 @@ struct DfFusedParams {
     unsigned G, npad, total;
     unsigned dbg;         // AUKIT_DFPWM_FUSED_DBG, A/B only: 1 = the encoder waves never take decoder tickets (same bytes)
     const u64 *mcount;    // mono samples per stream
-    unsigned char *stage; // encoder output rows
-    u64 sstride;
+    unsigned char *enc_out;  // the packed result
+    const u64 *ooff;         // [n + 1] byte offset of every stream's bytes in it
 };
 
 AUKIT_DEV void dff_decode_unit(const DfFusedParams &F, unsigned c, unsigned j, const signed char *lut, unsigned lane) {
@@ -712,7 +712,7 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
     const u64 L = act ? F.mcount[s] : 0, fed = act ? P.fed[s] : 0;
     const unsigned char *src = act ? P.src + P.off[s] : P.src;
     const signed char *p = P.out + (act ? P.out_off[s] : 0);  // this stream's mono samples (16-byte aligned: host)
-    unsigned char *o = F.stage + (u64)s * F.sstride;
+    unsigned char *o = F.enc_out + (act ? F.ooff[s] : 0);  // rows are 60 010 bytes apart: 2-byte aligned, the stores below say so
     DfEnc e{};
     u64 i = 0, w = 0;
     int truth[6] = {0, 0, 0, 0, 0, 0};
@@ -720,6 +720,7 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
     bool tickets = !(F.dbg & 1);
     // one round: 64 samples → 8 bytes
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(1)));  // (unaligned global stores are single instructions on gfx950)
     auto round_bits = [&](const u32x4 &q0, const u32x4 &q1, const u32x4 &q2, const u32x4 &q3) -> uint2 {
         unsigned ob[2] = {0, 0};
         const u32x4 q[4] = {q0, q1, q2, q3};
@@ -832,7 +833,7 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
                 __builtin_amdgcn_sched_barrier(0);
                 AUKIT_DFF_WAIT();  // nothing asynchronous is alive across the loop's back edge (hipcc copies loop-carried values around there)
 #pragma unroll
-                for (int r = 0; r < R; r++) *reinterpret_cast<uint2 *>(o + w + 8 * r) = ob[r];  // (w is a multiple of 8); waited for a turn later
+                for (int r = 0; r < R; r++) { u32x2u v; v.x = ob[r].x; v.y = ob[r].y; *reinterpret_cast<u32x2u *>(o + w + 8 * r) = v; }  // waited for a turn later
                 w += 8 * R;
 #pragma unroll
                 for (int k = 0; k < 4 * R; k++) A[k] = B[k];
@@ -845,7 +846,9 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
         while (i + 64 <= hi) {  // what is left of a span that is not a multiple of 256 samples (stream ends, odd chunk sizes)
             const u32x4 *q = reinterpret_cast<const u32x4 *>(p + i);
             const u32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            *reinterpret_cast<uint2 *>(o + w) = round_bits(q0, q1, q2, q3);
+            const uint2 ob = round_bits(q0, q1, q2, q3);
+            u32x2u v; v.x = ob.x; v.y = ob.y;
+            *reinterpret_cast<u32x2u *>(o + w) = v;
             w += 8;
         }
         if (last && i < L) {  // the last < 64 samples, the last byte padded with samples of value 0
@@ -932,8 +935,6 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
-    const u64 sstride = round_up(max_out + 16, 16);
-    if ((rc = ctx->enc_state_buf.ensure((size_t)n * sstride + 64))) return rc;
     DfFusedParams F{};
     DfParParams &P = F.P;
     P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{6001, 6000};
@@ -945,7 +946,7 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     P.mode = 1; P.C = 2; P.out = mono; P.out_off = d_moff; P.out_stride = nullptr; P.lead = 0;
     if (const char *e = getenv("AUKIT_DFPWM_FUSED_DBG")) F.dbg = (unsigned)atoi(e);
     F.G = G; F.npad = npad; F.total = nchunk * G; F.mcount = d_mcount;
-    F.stage = reinterpret_cast<unsigned char *>(ctx->enc_state_buf.p); F.sstride = sstride;
+    F.enc_out = out; F.ooff = d_ooff;
     if (hipMemsetAsync(F.flags, 0, b_fl + 8, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
@@ -953,8 +954,6 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     const unsigned lds = 65536 + 20480;  // more than half of a CU's 160 KiB: one workgroup per CU
     if (!attr_set) { AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_df_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
-    AUKIT_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_dfpwm_compact, dim3((unsigned)std::min<u64>((max_out / 4 + 256) / 256, 4), n), dim3(256), 0, ctx->stream, F.stage, sstride, out, d_ooff, n);
     AUKIT_HIP_CHECK(hipGetLastError());
     if (getenv("AUKIT_DFPWM_STATS")) {
         unsigned h[2] = {0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
