@@ -909,59 +909,70 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
                           const uint64_t *h_ooff, bool *taken) {
     *taken = false;
     const uint32_t n = in->n;
-    const unsigned G = (n + 63) / 64;
-    if (n == 0 || G > (unsigned)ctx->num_cus || getenv("AUKIT_DFPWM_SERIAL")) return AUKIT_OK;
+    if (n == 0 || getenv("AUKIT_DFPWM_SERIAL")) return AUKIT_OK;
+    // more than one 64-stream group per CU: sub-batches of whole groups, one launch after the other (every CU hosts one encoder wave)
+    unsigned cap = (unsigned)ctx->num_cus;
+    if (const char *e = getenv("AUKIT_DFPWM_FUSED_GROUPS")) cap = (unsigned)std::max(1, std::min(atoi(e), ctx->num_cus));  // (tests: sub-batches of a small batch)
+    const unsigned G_all = (n + 63) / 64, nsub = (G_all + cap - 1) / cap, G_sub = (G_all + nsub - 1) / nsub;
+    const uint32_t n_sub = std::min<uint32_t>(n, G_sub * 64u);
+    // a launch takes the encoder's serial 13 ms however few streams it has: batches that leave the last launches thinly populated
+    // (20 000 streams = 313 groups: two launches at 61 %) are left to the time-sliced version, which scales with the stream count
+    if (nsub > 1 && (double)G_all < 0.75 * (double)nsub * cap && !getenv("AUKIT_DFPWM_FUSED")) return AUKIT_OK;
     std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + n), h_fed(n);
-    uint64_t fed_max = 0, max_out = 0;
+    uint64_t fed_max = 0;
     for (uint32_t s = 0; s < n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
         h_fed[s] = nb ? nb + (nb + 6000 - 1) / 6000 - 1 : 0;  // 6001-byte slices advanced by 6000 (Q10)
         fed_max = std::max(fed_max, h_fed[s]);
-        max_out = std::max<uint64_t>(max_out, h_ooff[s + 1] - h_ooff[s]);
     }
+    (void)h_ooff;
     uint64_t W = 256;
     if (const char *e = getenv("AUKIT_DFPWM_BLOCK")) W = std::max<uint64_t>(16, strtoull(e, nullptr, 10) & ~15ull);  // 4 W mono samples = whole encoder rounds
     const unsigned nblk = (unsigned)((fed_max + W - 1) / W);
     // units per decoder wave: enough of them that the last ones end close together, long enough that the warm-up stays 1/8 of a chunk
-    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 384 * 10 / n);
+    unsigned want = (unsigned)std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 384 * 10 / n_sub);
     if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     const unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 8u);
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
-    const unsigned npad = (unsigned)round_up(n, 64);
-    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nchunk * sizeof(SatMap), b_ss = (size_t)n * (nchunk + 1) * 4, b_st = (size_t)nchunk * 10 * npad * 4,
-                 b_fl = round_up(((size_t)nchunk * G + 8) * 4, 64);
+    const unsigned npad = (unsigned)round_up(n_sub, 64);
+    const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n_sub * nchunk * sizeof(SatMap), b_ss = (size_t)n_sub * (nchunk + 1) * 4, b_st = (size_t)nchunk * 10 * npad * 4,
+                 b_fl = round_up(((size_t)nchunk * G_sub + 8) * 4, 64);
     int rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + b_st + b_fl + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
-    DfFusedParams F{};
-    DfParParams &P = F.P;
-    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B); P.fed = P.off + n; P.feed = Feed{6001, 6000};
-    P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
-    P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
-    F.fst = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss);
-    F.flags = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st);
-    P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st + b_fl);
-    P.mode = 1; P.C = 2; P.out = mono; P.out_off = d_moff; P.out_stride = nullptr; P.lead = 0;
-    if (const char *e = getenv("AUKIT_DFPWM_FUSED_DBG")) F.dbg = (unsigned)atoi(e);
-    F.G = G; F.npad = npad; F.total = nchunk * G; F.mcount = d_mcount;
-    F.enc_out = out; F.ooff = d_ooff;
-    if (hipMemsetAsync(F.flags, 0, b_fl + 8, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
-    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
-    hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     static bool attr_set = false;
     const unsigned lds = 65536 + 20480;  // more than half of a CU's 160 KiB: one workgroup per CU
     if (!attr_set) { AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_df_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-    hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
-    AUKIT_HIP_CHECK(hipGetLastError());
-    if (getenv("AUKIT_DFPWM_STATS")) {
-        unsigned h[2] = {0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
-        (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 24, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms); decoder waves: slowest %.2f ms, mean %.2f ms\n",
-                n, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G, al[4] * 1e-5, al[5] * 256e-5 / (6.0 * std::max<int>(ctx->num_cus, (int)G)));
+    for (uint32_t s0 = 0; s0 < n; s0 += n_sub) {
+        const uint32_t ns = std::min<uint32_t>(n_sub, n - s0);
+        const unsigned G = (ns + 63) / 64;
+        DfFusedParams F{};
+        DfParParams &P = F.P;
+        P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B) + s0; P.fed = reinterpret_cast<const u64 *>(B) + n + s0; P.feed = Feed{6001, 6000};
+        P.n = ns; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+        P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
+        F.fst = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss);
+        F.flags = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st);
+        P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + b_st + b_fl);
+        P.mode = 1; P.C = 2; P.out = mono; P.out_off = d_moff + s0; P.out_stride = nullptr; P.lead = 0;
+        if (const char *e = getenv("AUKIT_DFPWM_FUSED_DBG")) F.dbg = (unsigned)atoi(e);
+        F.G = G; F.npad = npad; F.total = nchunk * G; F.mcount = d_mcount + s0;
+        F.enc_out = out; F.ooff = d_ooff + s0;
+        if (hipMemsetAsync(F.flags, 0, b_fl + 8, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+        hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)ns * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_df_blockscan, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        if (getenv("AUKIT_DFPWM_STATS")) {
+            unsigned h[2] = {0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 24, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms); decoder waves: slowest %.2f ms, mean %.2f ms\n",
+                    ns, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G, al[4] * 1e-5, al[5] * 256e-5 / (6.0 * std::max<int>(ctx->num_cus, (int)G)));
+        }
     }
     *taken = true;
     return AUKIT_OK;

@@ -173,7 +173,8 @@ def test_fused_transcode_ragged_groups(ctx, oracle, monkeypatch):
     monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
     want = B.dfpwm_transcode_mono(ctx, bt, 2).download()
     monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
-    for env in ({}, {"AUKIT_DFPWM_BLOCK": "32", "AUKIT_DFPWM_CHUNKS": "40"}):
+    # (the last one: sub-batches of one 64-stream group, the way batches beyond one group per CU are cut)
+    for env in ({}, {"AUKIT_DFPWM_BLOCK": "32", "AUKIT_DFPWM_CHUNKS": "40"}, {"AUKIT_DFPWM_FUSED_GROUPS": "1"}, {"AUKIT_DFPWM_FUSED_GROUPS": "2", "AUKIT_DFPWM_BLOCK": "64"}):
         monkeypatch.setenv("AUKIT_DFPWM_FUSED", "1")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
