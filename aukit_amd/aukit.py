@@ -277,7 +277,7 @@ def pack(data, bitDepth=None, dataType=None, bigEndian=None, int_mode=N.PACK_TRU
 
 # ---------------------------------------------------------------- loaders  (aukit.lua:1049-1777)
 def pcm(data, bitDepth=None, dataType=None, channels=None, sampleRate=None, interleaved=None, bigEndian=None):
-    _expect(1, data, "string")
+    _expect(1, data, "string", "table")  # :1050 — a table of numbers is normalised as it is (:1077-1096)
     bitDepth = 8 if bitDepth is None else bitDepth
     dataType = "signed" if dataType is None else dataType
     channels = 1 if channels is None else channels
@@ -286,6 +286,8 @@ def pcm(data, bitDepth=None, dataType=None, channels=None, sampleRate=None, inte
     if dataType not in ("signed", "unsigned", "float"):
         raise LuaError("bad argument #3 (invalid data type)")
     d = B.make_desc(N.CODEC_PCM, channels, sampleRate, bitDepth, dataType, bool(bigEndian), interleaved)
+    if isinstance(data, (list, tuple)):
+        return Audio(_wrap(B.decode_table, context(), [data], d), {}, {"bitDepth": bitDepth, "dataType": dataType})
     return Audio(_load(d, data), {}, {"bitDepth": bitDepth, "dataType": dataType})
 
 

@@ -265,6 +265,20 @@ def decode(ctx, batch, desc, dtype=None, out=None):
     return out
 
 
+def decode_table(ctx, tables, desc, out=None):
+    """aukit.pcm on TABLES of numbers (aukit.lua:1077-1096): `tables` = one sequence of numbers per stream.  Storage = ctx.dtype."""
+    import numpy as np
+    out = out if out is not None else AudioBatch(ctx)
+    arrs = [np.ascontiguousarray(t, dtype=np.float64).ravel() for t in tables]
+    offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        offs[1:] = np.cumsum([a.size for a in arrs])
+    vals = np.concatenate(arrs) if arrs and offs[-1] else np.zeros(1, dtype=np.float64)
+    N.check(N.lib().aukit_decode_table(ctx._h, vals.ctypes.data_as(C.POINTER(C.c_double)), offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(arrs)),
+                                       C.byref(desc), C.byref(out._h)))
+    return out
+
+
 def decode_resample(ctx, batch, desc, new_rate, interp, dtype=None, out=None):
     out = out if out is not None else AudioBatch(ctx)
     N.check(N.lib().aukit_decode_resample(ctx._h, batch._h, C.byref(desc), C.c_double(new_rate), _interp(interp),

@@ -67,8 +67,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
             const unsigned n0 = cur.r0 + (unsigned)lane * F.a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
-            const int rows = (int)(cur.cnt >> 6);   // wave-uniform
-#pragma unroll
+            const int rows = (int)(cur.cnt >> 6);   // wave-uniform (the early exit keeps this a loop: hipcc does not unroll it, and it measured no slower)
             for (int r = 0; r < WT / 64; r++) {
                 if (r >= rows) break;
                 const float s = interp_qr_raw<INTERP>(F, tab, q, rem);

@@ -232,6 +232,28 @@ int aukit_reverse(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
 
 namespace aukit {
 
+// aukit.pcm on a TABLE of numbers  aukit.lua:1077-1096 (the three read() closures), :1161-1171 (interleaved frames, or the channels one after
+// the other): element e of a stream's table goes to (channel, index) and is normalised like an unpacked sample — in doubles, by division
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcm_table(const double *vals, const u64 *voff, T *out, const u64 *row_off, const u64 *row_stride, int channels, int interleaved,
+                                                   int data_type, double max_value) {
+    const unsigned s = blockIdx.y;
+    const u64 v0 = voff[s], total = voff[s + 1] - v0, len = total / (u64)channels;
+    T *row = out + row_off[s];
+    const u64 stride = row_stride[s];
+    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < total; e += (u64)gridDim.x * 256) {
+        const double v = vals[v0 + e];
+        double r;
+        if (data_type == AUKIT_SIGNED) r = v / (v < 0 ? max_value : max_value - 1);                 // :1082
+        else if (data_type == AUKIT_UNSIGNED) r = (v - 128) / (v < 128 ? max_value : max_value - 1);  // :1088 (Q4)
+        else r = v;                                                                                   // :1094
+        u64 j, i;
+        if (interleaved && channels > 1) { i = e / (u64)channels; j = e - i * (u64)channels; }
+        else { j = e / len; i = e - j * len; }
+        row[j * stride + i] = (T)r;
+    }
+}
+
 // wavegen  aukit.lua:286-299, evaluated at x = i / sampleRate, i = 1 .. duration * sampleRate  (:1826)
 template <typename T>
 __global__ __launch_bounds__(256) void k_tone(T *out, const u64 *row_off, u64 len, double rate, double freq, double amp, int wave, double duty) {
@@ -318,6 +340,53 @@ int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, do
     }
     AUKIT_HIP_CHECK(hipGetLastError());
     return ctx_end_kernel(ctx, "k_tone", (uint64_t)n * channels * len * dtype_size(dtype));
+}
+
+// aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved) with `data` a TABLE of numbers (aukit.lua:1077-1096): `n` tables
+// as one host array of doubles + element offsets.  Values are used as they are (no range check, fractions allowed), as in the reference.
+int aukit_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out) {
+    if (!ctx || !d || !out || (n && (!offsets || (offsets[n] && !values)))) return fail(AUKIT_E_ARG, "null argument");
+    if (d->codec != AUKIT_CODEC_PCM) return fail(AUKIT_E_UNSUPPORTED, "table input: aukit.pcm only");
+    if (d->bit_depth != 8 && d->bit_depth != 16 && d->bit_depth != 24 && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (invalid bit depth)");
+    if (d->data_type < 0 || d->data_type > 2) return fail(AUKIT_E_ARG, "bad argument #3 (invalid data type)");
+    if (d->data_type == AUKIT_FLOAT && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
+    if (d->channels < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
+    if (!(d->sample_rate >= 1)) return fail(AUKIT_E_ARG, "bad argument #5 (number outside of range)");
+    if (d->channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
+    const int dtype = ctx->dtype == AUKIT_F32 ? AUKIT_F32 : AUKIT_F64;
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> lens(n);
+    for (uint32_t s = 0; s < n; s++) {
+        if (offsets[s + 1] < offsets[s]) return fail(AUKIT_E_ARG, "offsets must not decrease");
+        const uint64_t cnt = offsets[s + 1] - offsets[s];
+        if (cnt % (uint64_t)d->channels != 0) return fail(AUKIT_E_ARG, "bad argument #1 (uneven amount of data per channel)");  // :1064
+        lens[s] = cnt / (uint64_t)d->channels;
+    }
+    aukit_audio *o = *out;
+    int rc = audio_prepare(ctx, &o, n, d->channels, d->sample_rate, dtype, lens.data());
+    if (rc) return rc;
+    *out = o;
+    const uint64_t total = n ? offsets[n] - offsets[0] : 0;
+    if (!total) return AUKIT_OK;
+    if ((rc = ctx->tmp_buf.ensure((size_t)total * 8 + 64))) return rc;
+    AUKIT_HIP_CHECK(hipMemcpyAsync(ctx->tmp_buf.p, values + offsets[0], (size_t)total * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint64_t> tab(3 * (size_t)n + 1);
+    for (uint32_t s = 0; s <= n; s++) tab[s] = offsets[s] - offsets[0];
+    for (uint32_t s = 0; s < n; s++) { tab[n + 1 + s] = o->row_off[s]; tab[2 * (size_t)n + 1 + s] = o->row_stride[s]; }
+    if ((rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return rc;
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
+    uint64_t longest = 0;
+    for (uint32_t s = 0; s < n; s++) longest = std::max<uint64_t>(longest, offsets[s + 1] - offsets[s]);
+    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest + 1023) / 1024, 1024));
+    const u64 *t = reinterpret_cast<const u64 *>(ctx->misc_buf.p);
+    const double max_value = std::ldexp(1.0, d->bit_depth - 1);
+    for (uint32_t first = 0; first < n; first += 65535) {
+        const unsigned gy = std::min<uint32_t>(65535, n - first);
+        if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_pcm_table<double>), dim3(gx, gy), dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(ctx->tmp_buf.p), t + first, reinterpret_cast<double *>(o->dev), t + n + 1 + first, t + 2 * (size_t)n + 1 + first, d->channels, d->interleaved, d->data_type, max_value);
+        else hipLaunchKernelGGL((k_pcm_table<float>), dim3(gx, gy), dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(ctx->tmp_buf.p), t + first, reinterpret_cast<float *>(o->dev), t + n + 1 + first, t + 2 * (size_t)n + 1 + first, d->channels, d->interleaved, d->data_type, max_value);
+    }
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, "k_pcm_table", total * 8 + total * dtype_size(dtype));
 }
 
 // aukit.pack(audio:pcm(bitDepth, dataType, interleaved), bitDepth, dataType, bigEndian)  aukit.lua:901-910, :1861-1878 — the

@@ -42,6 +42,7 @@ int aukit_combine(aukit_ctx *, const aukit_audio *const *audios, uint32_t count,
 int aukit_split(aukit_ctx *, const aukit_audio *, const int32_t *channels, uint32_t count, aukit_audio **out);
 int aukit_rep(aukit_ctx *, const aukit_audio *, double count, aukit_audio **out);
 int aukit_reverse(aukit_ctx *, const aukit_audio *, aukit_audio **out);
+int aukit_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out);
 int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
 int aukit_pack_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode, aukit_batch **out);
 int aukit_stream_decode(aukit_ctx *, const aukit_batch *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
@@ -396,12 +397,21 @@ local function loader(d, data, info, first, len)
 end
 function aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved, bigEndian)  -- :1049
     expect(1, data, "string", "table")
-    if type(data) == "table" then error("aukit.pcm with a table of numbers: pack it first (aukit.pack) — the device path takes byte strings", 2) end
     bitDepth = expect(2, bitDepth, "number", "nil") or 8
     dataType = expect(3, dataType, "string", "nil") or "signed"
     channels = expect(4, channels, "number", "nil") or 1
     sampleRate = expect(5, sampleRate, "number", "nil") or 48000
     expect(6, interleaved, "boolean", "nil") expect(7, bigEndian, "boolean", "nil")
+    if type(data) == "table" then  -- :1077-1096: the numbers as they are, one double each
+        local n = #data
+        local vals = ffi.new("double[?]", math.max(n, 1))
+        for i = 1, n do vals[i - 1] = data[i] end
+        local offs = ffi.new("uint64_t[2]", {0, n})
+        local o = ffi.new("aukit_audio*[1]")
+        check(C.aukit_decode_table(ctx(), vals, offs, 1, desc {codec = "pcm", bitDepth = bitDepth, dataType = dataType, channels = channels, sampleRate = sampleRate,
+            interleaved = interleaved, bigEndian = bigEndian}, o))
+        return wrap(o[0], {}, {bitDepth = bitDepth, dataType = dataType})
+    end
     return loader(desc {codec = "pcm", bitDepth = bitDepth, dataType = dataType, channels = channels, sampleRate = sampleRate, interleaved = interleaved, bigEndian = bigEndian},
         data, {bitDepth = bitDepth, dataType = dataType})
 end

@@ -204,6 +204,10 @@ int aukit_combine(aukit_ctx *ctx, const aukit_audio *const *audios, uint32_t cou
 int aukit_split(aukit_ctx *ctx, const aukit_audio *in, const int32_t *channels, uint32_t count, aukit_audio **out);
 int aukit_rep(aukit_ctx *ctx, const aukit_audio *in, double count, aukit_audio **out);                   /* Audio:rep :839 */
 int aukit_reverse(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out);                             /* Audio:reverse :856 */
+/* aukit.pcm(data, ...) with `data` a TABLE of numbers, aukit.lua:1077-1096 + :1161-1171 — `n` tables as one host array of doubles with
+ * element offsets [n + 1]; d->codec = AUKIT_CODEC_PCM, bit_depth / data_type / channels / sample_rate / interleaved as for the string.
+ * Values are taken as they are (no range check, fractions allowed: s / (s < 0 and 2^(b-1) or 2^(b-1)-1), :1082).  Storage = the context's dtype. */
+int aukit_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out);
 typedef enum { AUKIT_WAVE_NONE = 0 /* aukit.new: silence */, AUKIT_WAVE_SINE = 1, AUKIT_WAVE_TRIANGLE = 2, AUKIT_WAVE_SAWTOOTH = 3, AUKIT_WAVE_SQUARE = 4 } aukit_wave;
 /* aukit.new(duration, channels, sampleRate) :1783 / aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)
  * :1808 — `n` identical audios (aukit.noise draws from the host VM's math.random and cannot be reproduced) */

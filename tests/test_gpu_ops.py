@@ -164,3 +164,40 @@ def test_mirror_structural_methods_and_wav(oracle, OPS):
     assert wd[8:16] == b"WAVEfmt " and int.from_bytes(wd[20:22], "little") == 0xFFFE and wd[-len(a.dfpwm(True)):] == a.dfpwm(True)
     bd = aukit.wav(wd)
     assert bd.channels() == 2 and abs(len(bd.data[0]) - 4800) <= 16
+
+
+def test_pcm_table_input(ctx, oracle):
+    """aukit.pcm on a TABLE of numbers (aukit.lua:1077-1096, :1161-1171): values as they are — fractions, out-of-range numbers, every data
+    type and layout — bit for bit the oracle's doubles; the uneven-table error; several tables per call."""
+    import aukit_amd.batch as B
+    import aukit_amd._native as N
+    rng = np.random.default_rng(7)
+    cases = [(8, "signed", 1, True), (16, "signed", 2, True), (16, "signed", 2, False), (24, "unsigned", 3, True), (8, "unsigned", 1, True), (32, "float", 2, False),
+             (32, "signed", 4, True)]
+    for depth, dt, ch, inter in cases:
+        tabs = []
+        for n in (0, ch * 1, ch * 777, ch * 4097):
+            v = rng.integers(-40000, 40000, n).astype(np.float64)
+            v[::5] += 0.25  # Lua numbers need not be integers
+            tabs.append(v)
+        d = B.make_desc(N.CODEC_PCM, ch, 44100, depth, dt, False, inter)
+        for dtype, tol in ((N.F64, 0.0), (N.F32, 1e-6)):
+            c2 = B.Context(0, dtype=dtype)
+            got = B.decode_table(c2, tabs, d).download()
+            for v, g in zip(tabs, got):
+                ref = oracle.pcm_table(v, depth, {"signed": oracle.SIGNED, "unsigned": oracle.UNSIGNED, "float": oracle.FLOAT}[dt], ch, 44100, inter)
+                assert len(g) == ch
+                for c in range(ch):
+                    assert len(g[c]) == len(ref.data[c])
+                    if tol == 0.0:
+                        assert np.array_equal(g[c], ref.data[c]), (depth, dt, ch, inter, c)
+                    elif len(g[c]):
+                        assert np.max(np.abs(g[c] - ref.data[c]) / np.maximum(1.0, np.abs(ref.data[c]))) <= tol
+            c2.close()
+    with pytest.raises(N.AukitError, match="uneven amount of data per channel"):
+        B.decode_table(ctx, [np.arange(5.0)], B.make_desc(N.CODEC_PCM, 2, 48000, 8, "signed"))
+    # the mirror: a Python list is a Lua table
+    from aukit_amd import aukit as A
+    a = A.pcm([0, 127, -128, 64.5], 8, "signed", 2, 48000)
+    assert a.channels() == 2 and a.len() == 2 / 48000
+    assert np.array_equal(a.data[0], [0.0, -1.0]) and np.array_equal(a.data[1], [1.0, 64.5 / 127])
