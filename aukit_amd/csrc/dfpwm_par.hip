@@ -239,6 +239,64 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
                      });
         return;
     }
+    if (EMIT && O.mode == 0 && (O.C == 2 || (O.C == 1 && !O.lead))) {
+        // de-interleaved rows of one or two channels, the loaders' usual cases: 16-byte stores for the dwords of the aligned source vectors
+        typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+        if (O.C == 2) {
+            auto pair = [&](unsigned byte, unsigned &c0, unsigned &c1) {  // four stereo frames of one fed byte
+                const unsigned nb = ~byte;
+                c0 = 0; c1 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    c0 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k))) << (8 * k);
+                    c1 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k + 1))) << (8 * k);
+                }
+            };
+            fed_for_each(p, f0, f1, O.feed,
+                         [&](unsigned byte) {
+                             unsigned c0, c1;
+                             pair(byte, c0, c1);
+                             *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = c0;
+                             *reinterpret_cast<unsigned *>(O.base + O.stride + (i >> 1)) = c1;
+                             i += 8;
+                         },
+                         [&](unsigned word) {
+                             unsigned a[4], b[4];
+                             pair(word & 0xFF, a[0], b[0]); pair((word >> 8) & 0xFF, a[1], b[1]); pair((word >> 16) & 0xFF, a[2], b[2]); pair(word >> 24, a[3], b[3]);
+                             u32x4a va, vb;
+                             va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = b[0]; vb.y = b[1]; vb.z = b[2]; vb.w = b[3];
+                             *reinterpret_cast<u32x4a *>(O.base + (i >> 1)) = va;
+                             *reinterpret_cast<u32x4a *>(O.base + O.stride + (i >> 1)) = vb;
+                             i += 32;
+                         });
+        } else {
+            auto eight = [&](unsigned byte, unsigned &lo, unsigned &hi) {  // the eight samples of one fed byte
+                const unsigned nb = ~byte;
+                lo = 0; hi = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) lo |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, k))) << (8 * k);
+#pragma unroll
+                for (int k = 0; k < 4; k++) hi |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 4 + k))) << (8 * k);
+            };
+            fed_for_each(p, f0, f1, O.feed,
+                         [&](unsigned byte) {
+                             unsigned lo, hi;
+                             eight(byte, lo, hi);
+                             *reinterpret_cast<uint2 *>(O.base + i) = make_uint2(lo, hi);
+                             i += 8;
+                         },
+                         [&](unsigned word) {
+                             unsigned a[8];
+                             eight(word & 0xFF, a[0], a[1]); eight((word >> 8) & 0xFF, a[2], a[3]); eight((word >> 16) & 0xFF, a[4], a[5]); eight(word >> 24, a[6], a[7]);
+                             u32x4a va, vb;
+                             va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = a[4]; vb.y = a[5]; vb.z = a[6]; vb.w = a[7];
+                             *reinterpret_cast<u32x4a *>(O.base + i) = va;
+                             *reinterpret_cast<u32x4a *>(O.base + i + 16) = vb;
+                             i += 32;
+                         });
+        }
+        return;
+    }
     fed_for_each(p, f0, f1, O.feed, [&](unsigned byte) {
         const unsigned nb = ~byte;
         if (!EMIT) {
@@ -247,24 +305,6 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
         } else if (O.C == 1 && O.lead) {  // row shifted by `lead` elements: byte stores
 #pragma unroll
             for (int k = 0; k < 8; k++) O.base[O.lead + i + k] = (signed char)df_decode_b(d, df_pm1(nb, k));
-            i += 8;
-        } else if (O.C == 1) {
-            unsigned lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) lo |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, k))) << (8 * k);
-#pragma unroll
-            for (int k = 0; k < 4; k++) hi |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 4 + k))) << (8 * k);
-            *reinterpret_cast<uint2 *>(O.base + i) = make_uint2(lo, hi);
-            i += 8;
-        } else if (O.C == 2) {
-            unsigned c0 = 0, c1 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                c0 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k))) << (8 * k);
-                c1 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k + 1))) << (8 * k);
-            }
-            *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = c0;
-            *reinterpret_cast<unsigned *>(O.base + O.stride + (i >> 1)) = c1;
             i += 8;
         } else {
 #pragma unroll
@@ -942,9 +982,8 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
-    static bool attr_set = false;
     const unsigned lds = 65536 + 20480;  // more than half of a CU's 160 KiB: one workgroup per CU
-    if (!attr_set) { AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_df_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    if (!ctx->fused_attr_set) { AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_df_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->fused_attr_set = true; }
     for (uint32_t s0 = 0; s0 < n; s0 += n_sub) {
         const uint32_t ns = std::min<uint32_t>(n_sub, n - s0);
         const unsigned G = (ns + 63) / 64;
