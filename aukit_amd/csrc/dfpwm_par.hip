@@ -423,10 +423,12 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = 16u * k < L ? *reinterpret_cast<const uint4 *>(p + 16 * k) : make_uint4(0, 0, 0, 0);
     u64 i = 0;
-    for (; i + 64 <= L; i += 64) {
+    typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(1)));  // the packed rows start anywhere: one unaligned 8-byte store per round
+    for (; i + 64 <= L; i += 64) {                                            // (a byte per store instruction was 64 cache lines for 64 bytes)
         uint4 nxt[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) nxt[k] = i + 64 + 16 * k < L ? *reinterpret_cast<const uint4 *>(p + i + 64 + 16 * k) : make_uint4(0, 0, 0, 0);
+        unsigned ob[2] = {0, 0};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned words[4] = {cur[k].x ^ 0x80808080u, cur[k].y ^ 0x80808080u, cur[k].z ^ 0x80808080u, cur[k].w ^ 0x80808080u};  // u = v + 128
@@ -435,9 +437,12 @@ __global__ __launch_bounds__(64) void k_dfpwm_encode_i8(const signed char *in, c
                 unsigned byte = 0;
 #pragma unroll
                 for (int b = 0; b < 8; b++) byte |= df_encode_u(e, (words[2 * h + (b >> 2)] >> (8 * (b & 3))) & 0xFF) & (1u << b);
-                o[w++] = (unsigned char)byte;
+                ob[k >> 1] |= (byte & 255u) << (8 * (2 * (k & 1) + h));
             }
         }
+        u32x2u v; v.x = ob[0]; v.y = ob[1];
+        *reinterpret_cast<u32x2u *>(o + w) = v;
+        w += 8;
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
