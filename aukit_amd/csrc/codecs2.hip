@@ -268,22 +268,41 @@ __global__ __launch_bounds__(64) void k_qoa(const unsigned char *src, const QoaJ
     for (int k = 0; k < 4; k++) { h[k] = rdbe16s(l + 2 * k); w[k] = rdbe16s(l + 8 + 2 * k); }
     const unsigned char *sl = f + 8 + 16 * job.channels;
     short *o = out + job.out_off;
+    // One lane per (frame, channel): a slice is read as one unaligned 8-byte load and its 20 samples leave as 16 + 16 + 8 bytes (the rows
+    // start anywhere: 2-byte aligned).  Sample by sample — 2-byte stores, 64 cache lines per store instruction for the 64 frames of a wave,
+    // and eight byte loads per slice — the memory pipe of the CU was what the kernel waited for.
+    typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(1)));
+    typedef unsigned u32x4h __attribute__((ext_vector_type(4), aligned(2)));
+    typedef unsigned u32x2h __attribute__((ext_vector_type(2), aligned(2)));
     for (int si0 = 0; si0 < job.samples; si0 += 20) {
         const unsigned char *p = sl + 8 * ((size_t)(si0 / 20) * job.channels + job.c);
-        unsigned hi = rdbe32(p), lo = rdbe32(p + 4);
+        const u32x2u raw = *reinterpret_cast<const u32x2u *>(p);
+        unsigned hi = __builtin_bswap32(raw.x), lo = __builtin_bswap32(raw.y);
         const int sf = hi >> 28;
+        unsigned pk[10];
+#pragma unroll
         for (int k = 0; k < 20; k++) {
             const long long sum = w[0] * h[0] + w[1] * h[1] + w[2] * h[2] + w[3] * h[3];
             const int predicted = ((int)(unsigned)(unsigned long long)sum) >> 13;         // signed_rshift: wrap to int32, arithmetic shift :1681-1689
             const int deq = c_qoa_dequant[sf][(hi >> 25) & 7];
             int rec = predicted + deq;
             rec = rec < -32768 ? -32768 : (rec > 32767 ? 32767 : rec);
-            if (si0 + k < job.emit) o[si0 + k] = (short)(shift8 ? (rec >> 8) : rec);       // stream.qoa: math.floor(reconstructed / 256) :3299
+            const unsigned v16 = (unsigned)(shift8 ? (rec >> 8) : rec) & 0xFFFFu;         // stream.qoa: math.floor(reconstructed / 256) :3299
+            if (k & 1) pk[k >> 1] |= v16 << 16; else pk[k >> 1] = v16;
             hi = (hi << 3) | (lo >> 29);
             lo <<= 3;
             const int delta = deq >> 4;                                                    // signed_rshift(residual, 4)
             for (int q = 0; q < 4; q++) w[q] += h[q] < 0 ? -delta : delta;                 // :1694-1699
             h[0] = h[1]; h[1] = h[2]; h[2] = h[3]; h[3] = rec;
+        }
+        if (si0 + 20 <= job.emit) {
+            u32x4h a, b; u32x2h c;
+            a.x = pk[0]; a.y = pk[1]; a.z = pk[2]; a.w = pk[3]; b.x = pk[4]; b.y = pk[5]; b.z = pk[6]; b.w = pk[7]; c.x = pk[8]; c.y = pk[9];
+            *reinterpret_cast<u32x4h *>(o + si0) = a;
+            *reinterpret_cast<u32x4h *>(o + si0 + 8) = b;
+            *reinterpret_cast<u32x2h *>(o + si0 + 16) = c;
+        } else {
+            for (int k = 0; k < 20; k++) if (si0 + k < job.emit) o[si0 + k] = (short)((pk[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
         }
     }
 }
