@@ -50,10 +50,16 @@ __global__ __launch_bounds__(64) void k_msadpcm(const MsParams P) {
     if (j >= P.njobs) return;
     const MsJob job = P.jobs[j];
     const unsigned char *blk = P.src + job.blk_off, *h = P.src + job.hdr_off;
-    auto emit = [&](double *o, unsigned long long i, double p) {
-        double v = p / (p < 0 ? P.div_neg : P.div_pos);
-        o[i] = P.floor_all ? floor(v) : v;
+    auto norm = [&](double p) {
+        const double v = p / (p < 0 ? P.div_neg : P.div_pos);
+        return P.floor_all ? floor(v) : v;
     };
+    auto emit = [&](double *o, unsigned long long i, double p) { o[i] = norm(p); };
+    // One lane per block: four data bytes per (unaligned) dword load and 16-byte stores — byte loads and one 8-byte store per sample made
+    // every memory instruction of the wave a visit to 64 cache lines.
+    typedef unsigned u32u __attribute__((aligned(1)));
+    typedef double dbl2a __attribute__((ext_vector_type(2), aligned(8)));
+    auto nibs = [](int b, int &hi, int &lo) { hi = b >> 4; lo = b & 15; if (hi >= 8) hi -= 16; if (lo >= 8) lo -= 16; };
     if (P.C == 2) {
         const int piL = h[0], piR = h[1];
         if (piL >= P.ncoef || piR >= P.ncoef) { atomicCAS(P.err, 0, 1); return; }
@@ -62,11 +68,27 @@ __global__ __launch_bounds__(64) void k_msadpcm(const MsParams P) {
         double *oL = P.out + job.out_off, *oR = P.out + job.out_off_r;
         emit(oL, 0, s2L); emit(oL, 1, s1L); emit(oR, 0, s2R); emit(oR, 1, s1R);
         unsigned long long w = 2;
-        for (int i = 14; i < P.block_align; i++) {
-            const int b = blk[i];
-            int hi = b >> 4, lo = b & 15;
-            if (hi >= 8) hi -= 16;
-            if (lo >= 8) lo -= 16;
+        int i = 14;
+        for (; i + 4 <= P.block_align; i += 4) {
+            const unsigned word = *reinterpret_cast<const u32u *>(blk + i);
+            double l[4], r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int hi, lo;
+                nibs((int)((word >> (8 * k)) & 0xFF), hi, lo);
+                l[k] = norm(ms_step(s1L, s2L, dL, c1L, c2L, hi));
+                r[k] = norm(ms_step(s1R, s2R, dR, c1R, c2R, lo));
+            }
+            dbl2a v;
+            v.x = l[0]; v.y = l[1]; *reinterpret_cast<dbl2a *>(oL + w) = v;
+            v.x = l[2]; v.y = l[3]; *reinterpret_cast<dbl2a *>(oL + w + 2) = v;
+            v.x = r[0]; v.y = r[1]; *reinterpret_cast<dbl2a *>(oR + w) = v;
+            v.x = r[2]; v.y = r[3]; *reinterpret_cast<dbl2a *>(oR + w + 2) = v;
+            w += 4;
+        }
+        for (; i < P.block_align; i++) {
+            int hi, lo;
+            nibs(blk[i], hi, lo);
             emit(oL, w, ms_step(s1L, s2L, dL, c1L, c2L, hi));
             emit(oR, w, ms_step(s1R, s2R, dR, c1R, c2R, lo));
             w++;
@@ -80,11 +102,23 @@ __global__ __launch_bounds__(64) void k_msadpcm(const MsParams P) {
         // stream mono leaves the two header samples unfloored too (:2708-2709)
         emit(o, 0, s2); emit(o, 1, s1);
         unsigned long long w = 2;
-        for (int i = 7; i < P.block_align; i++) {
-            const int b = blk[i];
-            int hi = b >> 4, lo = b & 15;
-            if (hi >= 8) hi -= 16;
-            if (lo >= 8) lo -= 16;
+        int i = 7;
+        for (; i + 4 <= P.block_align; i += 4) {
+            const unsigned word = *reinterpret_cast<const u32u *>(blk + i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int hi, lo;
+                nibs((int)((word >> (8 * k)) & 0xFF), hi, lo);
+                dbl2a v;
+                v.x = norm(ms_step(s1, s2, d, c1, c2, hi));
+                v.y = norm(ms_step(s1, s2, d, c1, c2, lo));
+                *reinterpret_cast<dbl2a *>(o + w) = v;
+                w += 2;
+            }
+        }
+        for (; i < P.block_align; i++) {
+            int hi, lo;
+            nibs(blk[i], hi, lo);
             emit(o, w++, ms_step(s1, s2, d, c1, c2, hi));
             emit(o, w++, ms_step(s1, s2, d, c1, c2, lo));
         }
