@@ -377,6 +377,40 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
 // Block codecs decode to compact integer rows (int16 predictors / int8 DFPWM samples) in a scratch buffer; this turns
 // those rows into an Audio: v / (v < 0 and norm_neg or norm_pos), optionally resampled in the same pass
 // (`loader(...):resample(new_rate, interp)`).  Row r = stream r / channels, channel r % channels.
+// ---- integer rows → Audio without resampling (the loaders aukit.dfpwm / adpcm / qoa / flac: `s / (s < 0 and 2^(b-1) or 2^(b-1)-1)`, :1082 and
+// siblings).  The general kernel (k_resample, interpolation "none") evaluates a position per sample and moved 2 TB/s; this is the same division
+// with 16-byte stores, consecutive lanes on consecutive vectors.  int8 samples go through a 256-entry table of their (true) quotients.
+struct ConvRow { unsigned long long src, dst, len; };
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void k_convert_rows(const S *src, const ConvRow *rows, T *out, double norm_pos, double norm_neg) {
+    __shared__ double lut[256];
+    if (sizeof(S) == 1) {
+        const int v = (int)threadIdx.x - 128;
+        lut[threadIdx.x] = (double)v / (v < 0 ? norm_neg : norm_pos);
+        __syncthreads();
+    }
+    const ConvRow r = rows[blockIdx.y];
+    const S *p = src + r.src;
+    T *o = out + r.dst;
+    constexpr int PV = 16 / (int)sizeof(T);  // samples per 16-byte store: consecutive lanes write consecutive vectors (1 KiB per store instruction)
+    typedef S svp __attribute__((ext_vector_type(PV), aligned(1)));
+    typedef T tvp __attribute__((ext_vector_type(PV), aligned(16)));  // rows of an Audio start on 64-byte boundaries (audio_prepare)
+    auto conv = [&](S v) -> T {
+        if (sizeof(S) == 1) return (T)lut[(int)v + 128];
+        return (T)((double)v / (v < 0 ? norm_neg : norm_pos));
+    };
+    const unsigned long long groups = r.len / PV;
+#pragma unroll 4
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (unsigned long long)gridDim.x * 256) {
+        const svp v = *reinterpret_cast<const svp *>(p + PV * g);
+        tvp w;
+#pragma unroll
+        for (int e = 0; e < PV; e++) w[e] = conv(v[e]);
+        *reinterpret_cast<tvp *>(o + PV * g) = w;
+    }
+    if (blockIdx.x == 0) for (unsigned long long i = groups * PV + threadIdx.x; i < r.len; i += 256) o[i] = conv(p[i]);
+}
+
 int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len,
                         uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
                         double norm_neg, aukit_audio **out) {
@@ -399,6 +433,35 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     int rc;
     if ((rc = audio_prepare(ctx, &a, n, channels, do_resample ? new_rate : rate, dtype, lens.data()))) return rc;
     *out = a;
+    if (!do_resample && (src_kind == SRC_I8 || src_kind == SRC_I16 || src_kind == SRC_I32) && !getenv("AUKIT_NO_FAST_CONVERT")) {
+        std::vector<ConvRow> cr((size_t)n * channels);
+        uint64_t longest = 0;
+        for (uint32_t s = 0; s < n; s++)
+            for (int c = 0; c < channels; c++) {
+                const size_t r = (size_t)s * channels + c;
+                cr[r] = ConvRow{row_off[r], a->row_off[s] + (uint64_t)c * a->row_stride[s], lens[s]};
+                longest = std::max(longest, lens[s]);
+            }
+        if (cr.empty() || longest == 0) return AUKIT_OK;
+        if ((rc = upload_table(ctx, ctx->misc_buf, cr.data(), cr.size() * sizeof(ConvRow)))) return rc;
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        const ConvRow *d_cr = reinterpret_cast<const ConvRow *>(ctx->misc_buf.p);
+        const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest / 4 + 255) / 256 / 8, 64));
+        for (size_t first = 0; first < cr.size(); first += 65535) {
+            const dim3 grid(gx, (unsigned)std::min<size_t>(65535, cr.size() - first));
+#define AUKIT_CONV(S)                                                                                                                                   \
+            do {                                                                                                                                        \
+                if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_convert_rows<S, double>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const S *>(rows_dev), d_cr + first, reinterpret_cast<double *>(a->dev), norm_pos, norm_neg); \
+                else hipLaunchKernelGGL((k_convert_rows<S, float>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const S *>(rows_dev), d_cr + first, reinterpret_cast<float *>(a->dev), norm_pos, norm_neg);              \
+            } while (0)
+            if (src_kind == SRC_I8) AUKIT_CONV(signed char);
+            else if (src_kind == SRC_I16) AUKIT_CONV(short);
+            else AUKIT_CONV(int);
+#undef AUKIT_CONV
+        }
+        AUKIT_HIP_CHECK(hipGetLastError());
+        return ctx_end_kernel(ctx, "k_convert_rows", in_elems * (src_kind == SRC_I16 ? 2 : src_kind == SRC_I32 ? 4 : 1) + out_elems * dtype_size(dtype));
+    }
     std::vector<Seg> segs((size_t)n * channels);
     for (uint32_t s = 0; s < n; s++)
         for (int c = 0; c < channels; c++) {
