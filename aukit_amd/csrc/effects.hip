@@ -83,10 +83,17 @@ __global__ __launch_bounds__(256) void k_rowmax(const T *data, RowMeta m, unsign
     row_of(m, r, &base, &len);
     const T *row = data + base;
     double mx = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
-        double v = fabs((double)row[i]);
-        mx = mx < v ? v : mx;
+    // 16 bytes per lane and load (rows start on 64-byte boundaries); one element per load moved 1.3 TB/s of this read-only pass
+    constexpr int PV = 16 / (int)sizeof(T);
+    typedef T tvp __attribute__((ext_vector_type(PV), aligned(16)));
+    const unsigned long long groups = len / PV;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (unsigned long long)gridDim.x * 256) {
+        const tvp w = *reinterpret_cast<const tvp *>(row + PV * g);
+#pragma unroll
+        for (int e = 0; e < PV; e++) { const double v = fabs((double)w[e]); mx = mx < v ? v : mx; }
     }
+    if (blockIdx.x == 0)
+        for (unsigned long long i = groups * PV + threadIdx.x; i < len; i += 256) { const double v = fabs((double)row[i]); mx = mx < v ? v : mx; }
     __shared__ double red[4];
     for (int o = 32; o; o >>= 1) { double t = __shfl_xor(mx, o); mx = mx < t ? t : mx; }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
