@@ -61,18 +61,30 @@ __global__ __launch_bounds__(256) void k_map(T *data, RowMeta m, MapArgs A) {
     T *row = data + base;
     double mult = 0;
     if constexpr (OP == MAP_SCALE_ROWMAX) mult = norm_mult(A.rowmax, A.a0, A.independent, r, m.channels);  // peak / max  :3444
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
-        double x = (double)row[i];
-        if constexpr (OP == MAP_AMPLIFY) row[i] = (T)lua_clamp(x * A.a0, -1, 1);                       // :3365
-        else if constexpr (OP == MAP_INVERT) row[i] = (T)(-x);                                           // :3421
-        else if constexpr (OP == MAP_SCALE_ROWMAX) row[i] = (T)lua_clamp(x * mult, -1, 1);              // :3455
+    auto op = [&](unsigned long long i, T cur) -> T {
+        const double x = (double)cur;
+        if constexpr (OP == MAP_AMPLIFY) return (T)lua_clamp(x * A.a0, -1, 1);                       // :3365
+        else if constexpr (OP == MAP_INVERT) return (T)(-x);                                           // :3421
+        else if constexpr (OP == MAP_SCALE_ROWMAX) return (T)lua_clamp(x * mult, -1, 1);              // :3455
         else if constexpr (OP == MAP_FADE) {  // Lua index li = i + 1 in [start, limit]  :3406-3408
-            double li = (double)(i + 1);
-            if (li >= A.a0 && li <= A.a1) row[i] = (T)lua_clamp(x * (A.a2 * (li - A.a0) + A.a3), -1, 1);
-        } else if constexpr (OP == MAP_DELAY) {  // o[i] = clamp(o[i] + original[i - samples] * multiplier)  :3514
-            if (i >= A.lag) row[i] = (T)lua_clamp(x + (double)reinterpret_cast<const T *>(A.aux)[base + i - A.lag] * A.a0, -1, 1);
+            const double li = (double)(i + 1);
+            return (li >= A.a0 && li <= A.a1) ? (T)lua_clamp(x * (A.a2 * (li - A.a0) + A.a3), -1, 1) : cur;
+        } else {                              // MAP_DELAY: o[i] = clamp(o[i] + original[i - samples] * multiplier)  :3514
+            return i >= A.lag ? (T)lua_clamp(x + (double)reinterpret_cast<const T *>(A.aux)[base + i - A.lag] * A.a0, -1, 1) : cur;
         }
+    };
+    // 16 bytes per lane and access (rows start on 64-byte boundaries)
+    constexpr int PV = 16 / (int)sizeof(T);
+    typedef T tvp __attribute__((ext_vector_type(PV), aligned(16)));
+    const unsigned long long groups = len / PV;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (unsigned long long)gridDim.x * 256) {
+        tvp w = *reinterpret_cast<const tvp *>(row + PV * g);
+#pragma unroll
+        for (int e = 0; e < PV; e++) w[e] = op(PV * g + e, w[e]);
+        *reinterpret_cast<tvp *>(row + PV * g) = w;
     }
+    if (blockIdx.x == 0)
+        for (unsigned long long i = groups * PV + threadIdx.x; i < len; i += 256) row[i] = op(i, row[i]);
 }
 
 // max |x| per row → atomicMax on the (non-negative) bit pattern; NaNs are skipped like math.max does

@@ -31,7 +31,7 @@ def reuse(key, f):
     def g():
         keep[key] = f(keep.get(key))
     return g
-for fx, args in (("amplify", (0.5,)), ("invert", ()), ("normalize", (0.8,)), ("center", (48000,)), ("fade", (1.0, 2.0, 0.2)), ("lowpass", (4000.0,)), ("highpass", (20.0,)),
+for fx, args in (("amplify", (0.5,)), ("invert", ()), ("normalize", (0.8,)), ("center", (48000,)), ("fade", (1.0, 2.0, 0.2, 1.0)), ("lowpass", (4000.0,)), ("highpass", (20.0,)),
                  ("delay", (0.05, 0.5)), ("echo", (0.05, 0.5)), ("reverb", ())):
     rate("effects." + fx, lambda fx=fx, args=args: B.effect(ctx, au, fx, *args), rw)
 rate("Audio:mono", reuse("m", lambda o: B.mono(ctx, au, out=o)), 1.5 * elems * esz / 1e9)
