@@ -146,6 +146,8 @@ int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
         if ((a) && (a)->pend_norm) { int _frc = ::aukit::audio_flush((ctx), (a)); if (_frc) return _frc; } \
     } while (0)
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
+// the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time
+void *ctx_host_stage(aukit_ctx *ctx, size_t bytes);
 int ctx_begin_kernel(aukit_ctx *ctx);
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes);
 // uploads a host table into a ctx scratch buffer on the ctx stream

@@ -105,11 +105,23 @@ __global__ __launch_bounds__(64) void k_qoa_stream_iir(const QsJob *jobs, const 
 #pragma unroll
             for (int k = 0; k < R; k++) nxt[k] = p[(r + 1) * R + k];
         }
+        OUT_T res[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const double s = ls + lp_alpha * (cur[k] - ls);  // :3324
             ls = s;
-            o[r * R + k] = (OUT_T)s;
+            res[k] = (OUT_T)s;
+        }
+        {   // 16 bytes per store (a job's outputs start anywhere in the row: element-aligned vectors)
+            constexpr int PV = 16 / (int)sizeof(OUT_T);
+            typedef OUT_T ovp __attribute__((ext_vector_type(PV), aligned(sizeof(OUT_T))));
+#pragma unroll
+            for (int v = 0; v < R / PV; v++) {
+                ovp w;
+#pragma unroll
+                for (int e = 0; e < PV; e++) w[e] = res[v * PV + e];
+                *reinterpret_cast<ovp *>(o + r * R + v * PV) = w;
+            }
         }
 #pragma unroll
         for (int k = 0; k < R; k++) cur[k] = nxt[k];
@@ -127,7 +139,12 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, 
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.qoa: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.qoa output must be AUKIT_F64 or AUKIT_F32");
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
-    std::vector<uint8_t> host(in->total() + 16);
+    // (through the context's pinned staging buffer: a fresh 360 MB std::vector — zero-filled, then page-faulted in by a pageable copy — was
+    // 80 of the 100 ms a 1024-stream call took)
+    std::vector<uint8_t> host_pageable;
+    uint8_t *host_p = static_cast<uint8_t *>(ctx_host_stage(ctx, (size_t)in->total() + 16));
+    if (!host_p) { host_pageable.resize(in->total() + 16); host_p = host_pageable.data(); }
+    struct HostView { uint8_t *p; uint8_t *data() const { return p; } } host{host_p};
     if (in->total()) AUKIT_HIP_CHECK(hipMemcpyAsync(host.data(), in->data(), in->total(), hipMemcpyDeviceToHost, ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     int C = 0;
@@ -256,15 +273,19 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, 
         uint64_t scr_elems = 0, max_nout = 0;
         std::vector<uint64_t> scr_off(jobs.size());
         for (size_t k = 0; k < jobs.size(); k++) { scr_off[k] = scr_elems; scr_elems += ((uint64_t)jobs[k].nout + 1) & ~1ull; max_nout = std::max<uint64_t>(max_nout, (uint64_t)jobs[k].nout); }
-        if (scr_elems * 8 <= (256ull << 20) && jobs.size() <= 65535 && max_nout) {  // small batch: two passes
+        // two passes whenever the scratch (one double per output) is affordable: the one-lane-per-job kernel pays four dependent table loads
+        // and ~60 fp64 operations per output on a few hundred waves (1024 stereo streams of ten seconds: 94 ms against 7 ms in two passes)
+        if (scr_elems * 8 <= (48ull << 30) && max_nout && !getenv("AUKIT_QOA_ONE_PASS")) {
             if ((rc = ctx->tmp_buf3.ensure((size_t)scr_elems * 8 + 64))) { delete ck; return rc; }
             if ((rc = upload_table(ctx, ctx->misc_buf, scr_off.data(), scr_off.size() * 8))) { delete ck; return rc; }
             const unsigned long long *dso = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
             double *scr = reinterpret_cast<double *>(ctx->tmp_buf3.p);
-            const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)jobs.size());
-            if (interp == 0) hipLaunchKernelGGL((k_qoa_stream_interp<0>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
-            else if (interp == 1) hipLaunchKernelGGL((k_qoa_stream_interp<1>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
-            else hipLaunchKernelGGL((k_qoa_stream_interp<2>), g1, dim3(256), 0, ctx->stream, dj, dso, rows, scr, ratio, 1.0 / ratio, exact);
+            for (size_t first = 0; first < jobs.size(); first += 65535) {  // (grid.y holds 65535 jobs)
+                const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)std::min<size_t>(65535, jobs.size() - first));
+                if (interp == 0) hipLaunchKernelGGL((k_qoa_stream_interp<0>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
+                else if (interp == 1) hipLaunchKernelGGL((k_qoa_stream_interp<1>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
+                else hipLaunchKernelGGL((k_qoa_stream_interp<2>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
+            }
             if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_qoa_stream_iir<double>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<double *>(a->dev), lp_alpha);
             else hipLaunchKernelGGL((k_qoa_stream_iir<float>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<float *>(a->dev), lp_alpha);
         } else {

@@ -508,3 +508,5 @@ int aukit_chunks_get(const aukit_chunks *c, uint32_t *nchunks, uint32_t *lens, d
 void aukit_chunks_free(aukit_chunks *c) { delete c; }
 
 }  // extern "C"
+
+namespace aukit { void *ctx_host_stage(aukit_ctx *ctx, size_t bytes) { return host_stage(ctx, bytes); } }
