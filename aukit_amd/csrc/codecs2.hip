@@ -472,20 +472,41 @@ static int mdfpwm_header(const uint8_t *h, uint64_t nb, MdHeader *out, const cha
     return AUKIT_OK;
 }
 
+// the first `take` bytes of every stream, side by side (one launch and one copy to the host instead of a copy per stream: 1024 streams
+// spent 30 of their 33 ms in 1024 synchronous 300-byte copies)
+__global__ __launch_bounds__(64) void k_gather_heads(const unsigned char *src, const unsigned long long *off, unsigned n, unsigned take, unsigned char *dst) {
+    const unsigned s = blockIdx.x;
+    if (s >= n) return;
+    const unsigned long long nb = off[s + 1] - off[s];
+    for (unsigned i = threadIdx.x; i < take; i += 64) dst[(size_t)s * take + i] = i < nb ? src[off[s] + i] : 0;
+}
+
 // decodes both channels of every stream into int8 rows in ctx->tmp_buf; returns per-row offsets / decoded lengths
 static int mdfpwm_rows(aukit_ctx *ctx, const aukit_batch *in, const char *badmsg, std::vector<MdHeader> &hdrs, std::vector<uint64_t> &row_off,
                        std::vector<uint64_t> &row_len) {
-    std::vector<uint8_t> head(300);
+    constexpr unsigned HEAD = 300;
+    std::vector<uint8_t> heads_pageable;
+    uint8_t *heads = nullptr;
+    if (in->n) {
+        int grc = ctx->tmp_buf3.ensure((size_t)in->n * HEAD + 64);
+        if (grc) return grc;
+        hipLaunchKernelGGL(k_gather_heads, dim3(in->n), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), in->n, HEAD,
+                           reinterpret_cast<unsigned char *>(ctx->tmp_buf3.p));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        heads = static_cast<uint8_t *>(ctx_host_stage(ctx, (size_t)in->n * HEAD));
+        if (!heads) { heads_pageable.resize((size_t)in->n * HEAD); heads = heads_pageable.data(); }
+        AUKIT_HIP_CHECK(hipMemcpyAsync(heads, ctx->tmp_buf3.p, (size_t)in->n * HEAD, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     hdrs.resize(in->n);
     row_off.assign((size_t)in->n * 2, 0);
     row_len.assign((size_t)in->n * 2, 0);
     std::vector<uint64_t> tab((size_t)in->n * 4, 0);
     uint64_t tot = 0;
     for (uint32_t s = 0; s < in->n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s], take = std::min<uint64_t>(nb, 300);
-        if (take) AUKIT_HIP_CHECK(hipMemcpyAsync(head.data(), in->data() + in->off[s], take, hipMemcpyDeviceToHost, ctx->stream));
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        int rc = mdfpwm_header(head.data(), take == nb ? nb : std::max<uint64_t>(take, 300), &hdrs[s], badmsg);
+        const uint64_t nb = in->off[s + 1] - in->off[s], take = std::min<uint64_t>(nb, HEAD);
+        const uint8_t *head = heads + (size_t)s * HEAD;
+        int rc = mdfpwm_header(head, take == nb ? nb : std::max<uint64_t>(take, 300), &hdrs[s], badmsg);
         if (rc) return rc;
         if (hdrs[s].payload > nb) return fail(AUKIT_E_LUA, "data string too short");
         const uint64_t pl = nb - hdrs[s].payload;
