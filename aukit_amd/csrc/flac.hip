@@ -1599,6 +1599,84 @@ __global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs
     }
 }
 
+// The same in two passes (what stream.qoa does, qoa_stream.hip): with one lane per (frame, channel) job every output pays four dependent,
+// scattered table loads and a scattered 4-byte store (1024 stereo streams of ten seconds: 36 ms).  Pass 1: the interpolated sample of
+// every output, all outputs in parallel, into a scratch of doubles; pass 2: the recursive low-pass (:3179) and the scaling, serially per job
+// over contiguous doubles, 32 per round with the next 32 in flight, 16-byte stores.  Same operations in the same order: same values.
+template <int INTERP, typename R>
+__global__ __launch_bounds__(256) void k_flac_stream_interp(const FsJob *jobs, const u64 *scr_off, const R *rows, double full, double *scr, double ratio, double rcp, int exact) {
+    const FsJob job = jobs[blockIdx.y];
+    double m1 = 0, z0 = 0;
+    if (job.last_off != ~0ull) z0 = flac_row_value(rows, job.last_off, full);
+    if (job.m1_off != ~0ull) m1 = flac_row_value(rows, job.m1_off, full);
+    const int n = job.blocksize;
+    auto tap = [&](int k) -> double { return k >= 1 ? flac_row_value(rows, job.src_off + (u64)(k - 1), full) : (k == 0 ? z0 : m1); };
+    double *o = scr + scr_off[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < job.nout; i += gridDim.x * 256) {
+        const double nn = (double)i;
+        const double x = (exact ? div_rcp(nn, ratio, rcp) : nn / ratio) + 1.0;
+        const double ffx = floor(x);
+        const int k = (int)ffx;
+        double s;
+        if (x == ffx) s = tap(k);
+        else {
+            const double fx = x - ffx;
+            if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
+            else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else {
+                const double p1 = tap(k), p0 = (k - 1 >= -1) ? tap(k - 1) : p1, p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2;
+                s = cubic_exact(p0, p1, p2, p3, fx);
+            }
+        }
+        o[i] = s;
+    }
+}
+template <typename OUT_T, typename R>
+__global__ __launch_bounds__(64) void k_flac_stream_iir(const FsJob *jobs, const u64 *scr_off, u64 njobs, const R *rows, double full, const double *scr, OUT_T *out, double lp_alpha) {
+    const u64 j = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (j >= njobs) return;
+    const FsJob job = jobs[j];
+    double z0 = 0;
+    if (job.last_off != ~0ull) z0 = flac_row_value(rows, job.last_off, full);
+    double ls = z0 / (z0 < 0 ? 128 : 127);   // :3172
+    const double *p = scr + scr_off[j];
+    OUT_T *o = out + job.out_off;
+    constexpr int RN = 32, PV = 16 / (int)sizeof(OUT_T);
+    typedef OUT_T ovp __attribute__((ext_vector_type(PV), aligned(sizeof(OUT_T))));
+    const int rounds = job.nout / RN;
+    double cur[RN], nxt[RN];
+    if (rounds) {
+#pragma unroll
+        for (int k = 0; k < RN; k++) cur[k] = p[k];
+    }
+    auto step = [&](double v) -> OUT_T {
+        const double s = ls + lp_alpha * (v - ls);  // :3179 (recursive: ls = filtered s, Q14)
+        ls = s;
+        return (OUT_T)lua_clamp(s * (s < 0 ? 128 : 127), -128, 127);
+    };
+    for (int r = 0; r < rounds; r++) {
+#pragma unroll
+        for (int k = 0; k < RN; k++) nxt[k] = cur[k];
+        if (r + 1 < rounds) {
+#pragma unroll
+            for (int k = 0; k < RN; k++) nxt[k] = p[(r + 1) * RN + k];
+        }
+        OUT_T res[RN];
+#pragma unroll
+        for (int k = 0; k < RN; k++) res[k] = step(cur[k]);
+#pragma unroll
+        for (int v = 0; v < RN / PV; v++) {
+            ovp w;
+#pragma unroll
+            for (int e = 0; e < PV; e++) w[e] = res[v * PV + e];
+            *reinterpret_cast<ovp *>(o + r * RN + v * PV) = w;
+        }
+#pragma unroll
+        for (int k = 0; k < RN; k++) cur[k] = nxt[k];
+    }
+    for (int i = rounds * RN; i < job.nout; i++) o[i] = step(p[i]);
+}
+
 int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.flac: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.flac output must be AUKIT_F64 or AUKIT_F32");
@@ -1675,12 +1753,34 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
         const FsJob *dj = reinterpret_cast<const FsJob *>(ctx->seg_buf.p);
         const double full = std::ldexp(1.0, D.depth);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
+        uint64_t scr_elems = 0, max_nout = 0;
+        std::vector<uint64_t> scr_off(jobs.size());
+        for (size_t k = 0; k < jobs.size(); k++) { scr_off[k] = scr_elems; scr_elems += ((uint64_t)jobs[k].nout + 1) & ~1ull; max_nout = std::max<uint64_t>(max_nout, (uint64_t)jobs[k].nout); }
+        if (scr_elems * 8 <= (48ull << 30) && max_nout && !getenv("AUKIT_FLAC_STREAM_ONE_PASS")) {  // two passes
+            if ((rc = ctx->tmp_buf3.ensure((size_t)scr_elems * 8 + 64))) { delete ck; return rc; }
+            if ((rc = upload_table(ctx, ctx->misc_buf, scr_off.data(), scr_off.size() * 8))) { delete ck; return rc; }
+            const u64 *dso = reinterpret_cast<const u64 *>(ctx->misc_buf.p);
+            double *scr = reinterpret_cast<double *>(ctx->tmp_buf3.p);
+            for (size_t first = 0; first < jobs.size(); first += 65535) {
+                const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)std::min<size_t>(65535, jobs.size() - first));
+#define AUKIT_FI2(I, R) hipLaunchKernelGGL((k_flac_stream_interp<I, R>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, reinterpret_cast<const R *>(ctx->tmp_buf.p), full, scr, ratio, 1.0 / ratio, exact)
+#define AUKIT_FI(I) do { if (D.wide) AUKIT_FI2(I, double); else AUKIT_FI2(I, int); } while (0)
+                if (interp == 0) AUKIT_FI(0); else if (interp == 1) AUKIT_FI(1); else AUKIT_FI(2);
+#undef AUKIT_FI
+#undef AUKIT_FI2
+            }
+#define AUKIT_FR(T, R) hipLaunchKernelGGL((k_flac_stream_iir<T, R>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (u64)jobs.size(), reinterpret_cast<const R *>(ctx->tmp_buf.p), full, scr, reinterpret_cast<T *>(a->dev), lp_alpha)
+            if (dtype == AUKIT_F64) { if (D.wide) AUKIT_FR(double, double); else AUKIT_FR(double, int); }
+            else { if (D.wide) AUKIT_FR(float, double); else AUKIT_FR(float, int); }
+#undef AUKIT_FR
+        } else {
 #define AUKIT_FS2(I, T, R) hipLaunchKernelGGL((k_flac_stream<I, T, R>), dim3(grid), dim3(64), 0, ctx->stream, dj, (u64)jobs.size(), reinterpret_cast<const R *>(ctx->tmp_buf.p), full, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
 #define AUKIT_FS(I, T) do { if (D.wide) AUKIT_FS2(I, T, double); else AUKIT_FS2(I, T, int); } while (0)
         if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_FS(0, double); else if (interp == 1) AUKIT_FS(1, double); else AUKIT_FS(2, double); }
         else { if (interp == 0) AUKIT_FS(0, float); else if (interp == 1) AUKIT_FS(1, float); else AUKIT_FS(2, float); }
 #undef AUKIT_FS
 #undef AUKIT_FS2
+        }
         AUKIT_HIP_CHECK(hipGetLastError());
         if ((rc = ctx_end_kernel(ctx, "k_flac_stream", in->total() + nouts * dtype_size(dtype)))) { delete ck; return rc; }
     }
