@@ -235,7 +235,7 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, 
     for (uint32_t s = 0; s < in->n; s++)
         for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = clen[s][k]; ck->pos[(size_t)s * mc + k] = cpos[s][k]; }
     int rc;
-    aukit_audio *full = nullptr;
+    aukit_audio *&full = ctx->stream_full;  // reused from call to call (audio_prepare keeps buffers that are large enough)
     aukit_audio **dst = mono && C > 1 ? &full : out;
     aukit_audio *a = *dst;
     if ((rc = audio_prepare(ctx, &a, in->n, C, 48000, dtype, lens.data()))) { delete ck; return rc; }
@@ -299,8 +299,6 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, 
     }
     if (mono && C > 1) {  // lines[1][i] = (0 + s_1 + ... + s_C) / C  :3326-3329 — the same sum order as Audio:mono
         rc = aukit_mono(ctx, full, out);
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        aukit_audio_free(full);
         if (rc) { delete ck; return rc; }
     }
     if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;

@@ -219,6 +219,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
         for (int i = 0; i < 10; i++) if (c->aux_ev[i]) (void)hipEventDestroy(c->aux_ev[i]);
         (void)hipStreamDestroy(c->aux_stream);
     }
+    if (c->stream_full) { aukit_audio_free(c->stream_full); c->stream_full = nullptr; }
     if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }

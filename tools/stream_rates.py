@@ -36,9 +36,9 @@ bt = B.Batch.upload(ctx, [rng.integers(0, 256, 44100 * sec * 3, dtype=np.uint8).
 rate("stream.pcm 24-bit mono 44.1k linear f32", bt, B.make_desc(N.CODEC_PCM, 1, 44100, 24, "signed"), "linear", False, N.F32)
 del bt
 bt = B.Batch.upload(ctx, [rng.integers(0, 256, 60000 * 2, dtype=np.uint8).tobytes()] * n)
-rate("stream.dfpwm stereo 48k (i8)", bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), "linear", False, N.I8)
-rate("stream.dfpwm stereo 48k mono (i8)", bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), "linear", True, N.I8)
-rate("stream.dfpwm mono 32k cubic (i8)", bt, B.make_desc(N.CODEC_DFPWM, 1, 32000), "cubic", False, N.I8)
+rate("stream.dfpwm stereo 48k (f32)", bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), "linear", False, N.F32)
+rate("stream.dfpwm stereo 48k mono (f32)", bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), "linear", True, N.F32)
+rate("stream.dfpwm mono 32k cubic (f32)", bt, B.make_desc(N.CODEC_DFPWM, 1, 32000), "cubic", False, N.F32)
 del bt
 md = O.gen_mdfpwm(rng.integers(0, 256, 60000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 60000, dtype=np.uint8).tobytes())
 bt = B.Batch.upload(ctx, [md] * n)
@@ -62,6 +62,6 @@ rate("stream.flac stereo 44.1k cubic (f32)", bt, B.make_desc(N.CODEC_FLAC, 2, 44
 del bt
 im = O.gen_ima(base_pcm[0][::2].copy(), 1, 512)
 bt = B.Batch.upload(ctx, [im] * n)
-rate("stream.adpcm mono 22.05k cubic (i8)", bt, B.make_desc(N.CODEC_ADPCM, 1, 22050, block_align=512), "cubic", False, N.I8)
+rate("stream.adpcm mono 22.05k cubic (i8)", bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", False, N.I8)
 bt2 = B.Batch.upload(ctx, [rng.integers(0, 256, 80000, dtype=np.uint8).tobytes()] * n)
 rate("stream.g711 stereo 8k cubic (i8)", bt2, B.make_desc(N.CODEC_G711, 2, 8000, ulaw=True), "cubic", False, N.I8)
