@@ -210,7 +210,10 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
     unsigned long long a = (unsigned long long)old_rate, b = (unsigned long long)new_rate, x = a, y = b;
     while (y) { unsigned long long t = x % y; x = y; y = t; }
     a /= x; b /= x;
-    if (b < 2) return false;  // ratio 1/b with b == 1: every x is an integer, nothing to interpolate — exact path
+    // b == 1 (equal rates — a 48 kHz source through stream.pcm, the usual case of austream — or an integer decimation): every position is an
+    // integer; written as 2a / 2 the same machinery applies (rem is always 0: the interpolators return the tap itself, :666 / :2395) and the
+    // division magic fits 32 bits
+    if (b < 2) { a *= 2; b *= 2; }
     F.tile_out = 4096;
     if (const char *e = getenv("AUKIT_FAST_TILE")) { int v = atoi(e); if (v >= 1024 && v % 1024 == 0) F.tile_out = v; }  // tuning knob
     while (F.tile_out > 1024 && ((double)F.tile_out * (double)a / (double)b + 64) * 4 > 40 * 1024) F.tile_out -= 1024;
