@@ -103,7 +103,7 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;  // staged samples per wave tile (upper bound)
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
-    nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
+    nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 && src_kind == SRC_PCM_S16LE_STEREO ? 8 : 0)));  // (8: interleaved stereo at equal rates)
     if (!nv) return AUKIT_OK;  // strong down-sampling: v1 handles it
     uint64_t max_tiles = 0;
     for (const Seg &g : segs) max_tiles = std::max<uint64_t>(max_tiles, (g.n_out + WT - 1) / WT);

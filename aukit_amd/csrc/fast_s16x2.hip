@@ -119,6 +119,7 @@ static int launch_s16x2_nv(aukit_ctx *ctx, int nv, const ResampleParams &P, cons
     case 1: hipLaunchKernelGGL((k_fast_wave_s16x2<INTERP, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
     case 2: hipLaunchKernelGGL((k_fast_wave_s16x2<INTERP, 2>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
     case 4: hipLaunchKernelGGL((k_fast_wave_s16x2<INTERP, 4>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
+    case 8: hipLaunchKernelGGL((k_fast_wave_s16x2<INTERP, 8>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
     default: return fail(AUKIT_E_ARG, "bad NV");
     }
     AUKIT_HIP_CHECK(hipGetLastError());

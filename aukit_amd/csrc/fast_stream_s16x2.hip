@@ -179,6 +179,7 @@ static int launch_ss_nv(aukit_ctx *ctx, int nv, const ResampleParams &P, const F
     case 1: hipLaunchKernelGGL((k_fast_wave_stream_s16x2<INTERP, 1, MONO>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
     case 2: hipLaunchKernelGGL((k_fast_wave_stream_s16x2<INTERP, 2, MONO>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
     case 4: hipLaunchKernelGGL((k_fast_wave_stream_s16x2<INTERP, 4, MONO>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;
+    case 8: hipLaunchKernelGGL((k_fast_wave_stream_s16x2<INTERP, 8, MONO>), dim3(grid), dim3(256), lds, ctx->stream, P, F); break;  // equal rates: a tile's window is 1027 frames
     default: return fail(AUKIT_E_ARG, "bad NV");
     }
     AUKIT_HIP_CHECK(hipGetLastError());
