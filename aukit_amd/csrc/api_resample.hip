@@ -66,7 +66,8 @@ static inline uint64_t resample_count(uint64_t n_in, double ratio) {
 // the interleaved or planar string.  The general kernel (k_resample, interpolation "none": a position per sample, the window staged
 // through LDS) moved 1 TB/s on 16-bit stereo.  Same arithmetic: the integer, then s / (s < 0 and 2^(b-1) or 2^(b-1)-1) in doubles (:1133), (s - 128) / ... for
 // unsigned (:1152, Q4), floats as they are (:1114).
-struct UnpackRow { unsigned long long src, dst, frames, first, step; };  // sample k of the row is `first + k * step` samples into the stream's bytes
+struct UnpackRow { unsigned long long src, dst, frames, first, step, mix; };  // sample k of the row is `first + k * step` samples into the stream's bytes;
+                                                                                 // mix > 1: the mean of `mix` consecutive samples from there (stream.pcm's mono, :2368)
 template <int BYTES, typename T>
 __global__ __launch_bounds__(256) void k_pcm_unpack(const unsigned char *src, const UnpackRow *rows, T *out, int data_type, int big_endian) {
     const UnpackRow r = rows[blockIdx.y];
@@ -75,20 +76,27 @@ __global__ __launch_bounds__(256) void k_pcm_unpack(const unsigned char *src, co
     constexpr int PV = 16 / (int)sizeof(T);
     typedef T tvp __attribute__((ext_vector_type(PV), aligned(16)));  // rows of an Audio start on 64-byte boundaries (audio_prepare)
     const double maxv = (double)(1ull << (8 * BYTES - 1));
-    auto conv = [&](unsigned long long k) -> T {
-        const unsigned char *q = p + (r.first + k * r.step) * BYTES;
+    auto one = [&](unsigned long long idx) -> double {
+        const unsigned char *q = p + idx * BYTES;
         unsigned u = 0;
 #pragma unroll
         for (int b = 0; b < BYTES; b++) u |= (unsigned)q[b] << (8 * (big_endian ? BYTES - 1 - b : b));
-        if (data_type == AUKIT_FLOAT) return (T)(double)__uint_as_float(u);
+        if (data_type == AUKIT_FLOAT) return (double)__uint_as_float(u);
         double v;
         if (data_type == AUKIT_SIGNED) {
             const int sv = BYTES == 4 ? (int)u : ((int)(u << (32 - 8 * BYTES)) >> (32 - 8 * BYTES));
             v = (double)sv;
-            return (T)(v / (v < 0 ? maxv : maxv - 1));
+            return v / (v < 0 ? maxv : maxv - 1);
         }
         v = (double)u;
-        return (T)((v - 128) / (v < 128 ? maxv : maxv - 1));
+        return (v - 128) / (v < 128 ? maxv : maxv - 1);
+    };
+    auto conv = [&](unsigned long long k) -> T {
+        const unsigned long long idx = r.first + k * r.step;
+        if (r.mix <= 1) return (T)one(idx);
+        double acc = 0;  // self[i] = ((0 + read()) + read() ...) / channels  :2368
+        for (unsigned long long c = 0; c < r.mix; c++) acc = acc + one(idx + c);
+        return (T)(acc / (double)r.mix);
     };
     const unsigned long long groups = r.frames / PV;
 #pragma unroll 2
@@ -147,6 +155,7 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
                 u.frames = frames[s];
                 u.first = planar ? (uint64_t)c * frames[s] : (uint64_t)c;   // :1161-1169
                 u.step = planar ? 1 : (uint64_t)C;
+                u.mix = 0;
                 longest = std::max(longest, frames[s]);
             }
         if (ur.empty() || longest == 0) return AUKIT_OK;
@@ -349,6 +358,63 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         int frc = AUKIT_OK;
         if (aligned4) done = fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, mono ? 2 : 1, P.lp_alpha);
         if (done && frc) { delete ck; return frc; }
+    }
+    if (!done && dtype == AUKIT_F32 && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !getenv("AUKIT_NO_FAST_CONVERT")) {
+        // every other PCM format (8-bit unsigned at 48 kHz is what most ComputerCraft audio is kept in), f32 tolerance path: the string is
+        // unpacked to one f32 row per output channel (k_pcm_unpack; the `mono` mix is made there, in the reference's order) and the stream.pcm
+        // wave kernel runs on the rows (fast_stream_f32.hip).  The reference-order kernel below moved 190 G samples/s on these.
+        std::vector<UnpackRow> ur((size_t)in->n * nd);
+        std::vector<uint64_t> roff((size_t)in->n * nd);
+        uint64_t tot = 0, longest = 0;
+        for (uint32_t s = 0; s < in->n; s++) {
+            const uint64_t fr = (in->off[s + 1] - in->off[s]) / ((size_t)bd * C);
+            for (int c = 0; c < nd; c++) {
+                UnpackRow &u = ur[(size_t)s * nd + c];
+                u.src = in->off[s]; u.dst = tot; u.frames = fr;
+                u.first = mono ? 0 : (uint64_t)c; u.step = (uint64_t)C; u.mix = mono ? (uint64_t)C : 0;
+                roff[(size_t)s * nd + c] = tot;
+                tot += round_up(std::max<uint64_t>(fr, 1), 16) + 16;
+            }
+            longest = std::max(longest, fr);
+        }
+        std::vector<Seg> rsegs;
+        rsegs.reserve(segs.size() * (size_t)nd);
+        for (const Seg &g : segs)
+            for (int c = 0; c < nd; c++) {
+                Seg r = g;
+                r.stream = g.stream * (unsigned)nd + (unsigned)c;
+                r.out_off = g.out_off + (uint64_t)c * g.out_stride;
+                r.out_stride = 0;
+                rsegs.push_back(r);
+            }
+        if (longest && (rc = ctx->tmp_buf.ensure((size_t)tot * 4 + 256)) == AUKIT_OK && (rc = upload_table(ctx, ctx->tmp_buf2, ur.data(), ur.size() * sizeof(UnpackRow))) == AUKIT_OK &&
+            (rc = upload_table(ctx, ctx->misc_buf, roff.data(), roff.size() * sizeof(uint64_t))) == AUKIT_OK) {
+            const UnpackRow *d_ur = reinterpret_cast<const UnpackRow *>(ctx->tmp_buf2.p);
+            const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest / 4 + 255) / 256 / 4, 64));
+            if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
+            for (size_t first = 0; first < ur.size(); first += 65535) {
+                const dim3 grid(gx, (unsigned)std::min<size_t>(65535, ur.size() - first));
+                float *rows = reinterpret_cast<float *>(ctx->tmp_buf.p);
+                if (bd == 1) hipLaunchKernelGGL((k_pcm_unpack<1, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else if (bd == 2) hipLaunchKernelGGL((k_pcm_unpack<2, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else if (bd == 3) hipLaunchKernelGGL((k_pcm_unpack<3, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else hipLaunchKernelGGL((k_pcm_unpack<4, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+            }
+            if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_pcm_unpack launch failed"); }
+            if ((rc = ctx_end_kernel(ctx, "k_pcm_unpack", in_bytes + tot * 4))) { delete ck; return rc; }
+            ResampleParams R;
+            memset(&R, 0, sizeof R);
+            R.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
+            R.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+            R.channels = 1;
+            R.out = a->dev;
+            R.lp_alpha = P.lp_alpha;
+            R.safe_lo = R.src;
+            R.safe_hi = R.src + ctx->tmp_buf.cap;
+            int frc = AUKIT_OK;
+            done = fast_try(ctx, SRC_AUDIO_F32, interp, d->sample_rate, 48000, rsegs, R, in_bytes + out_elems * 4, &frc, 1, P.lp_alpha);
+            if (done && frc) { delete ck; return frc; }
+        } else if (rc) { delete ck; return rc; }
     }
     if (!done && src == SRC_PCM_S16LE_MONO && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // reference order, wave tiles
         int erc = AUKIT_OK;

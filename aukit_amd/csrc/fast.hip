@@ -285,7 +285,7 @@ bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double 
         return taken;
     }
     if (epi) {  // epilogues other than Audio:resample exist as wave kernels only (fast_stream.hip)
-        if (src_kind != SRC_PCM_S16LE_MONO) return false;
+        if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_AUDIO_F32) return false;
         bool taken = false;
         int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
         if (taken) *rc = r2;

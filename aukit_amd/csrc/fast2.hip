@@ -103,7 +103,7 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;  // staged samples per wave tile (upper bound)
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
-    nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 && src_kind == SRC_PCM_S16LE_STEREO ? 8 : 0)));  // (8: interleaved stereo at equal rates)
+    nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 && (src_kind == SRC_PCM_S16LE_STEREO || (src_kind == SRC_AUDIO_F32 && F.epi == 1)) ? 8 : 0)));  // (8: interleaved stereo at equal rates)
     if (!nv) return AUKIT_OK;  // strong down-sampling: v1 handles it
     uint64_t max_tiles = 0;
     for (const Seg &g : segs) max_tiles = std::max<uint64_t>(max_tiles, (g.n_out + WT - 1) / WT);
@@ -131,6 +131,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
         static thread_local char nmx[96];
         snprintf(nmx, sizeof nmx, "k_fast_wave_stream_s16x2<%s,nv%d,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, F.epi == 2 ? "mono" : "stereo");
         return ctx_end_kernel(ctx, nmx, algorithmic_bytes);
+    }
+    if (F.epi == 1 && src_kind == SRC_AUDIO_F32) {  // stream.pcm on unpacked f32 rows (fast_stream_f32.hip)
+        if ((rc = launch_fast_wave_stream_f32(ctx, interp, nv, P, F, lds, grid))) return rc;
+        static thread_local char nmf[96];
+        snprintf(nmf, sizeof nmf, "k_fast_wave_stream<audio_f32,%s,nv%d,stream_pcm>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+        return ctx_end_kernel(ctx, nmf, algorithmic_bytes);
     }
     if (F.epi == 1) {
         if ((rc = launch_fast_wave_stream(ctx, interp, nv, P, F, lds, grid))) return rc;

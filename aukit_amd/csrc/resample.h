@@ -91,6 +91,7 @@ struct FastParams {
     unsigned dq64, dr64; // 64 * a = dq64 * b + dr64: one row of a wave tile further down, (q, rem) advance by (dq64, dr64) with one carry
 };
 int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);
+int launch_fast_wave_stream_f32(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);  // the same on f32 rows
 int launch_fast_wave_s16x2(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, unsigned grid);
 bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype,
                     uint64_t algorithmic_bytes, int *rc, int epi = 0);  // exact_wave.hip: reference-order fp64 on the wave tile engine (epi 1: stream.pcm)
