@@ -359,6 +359,11 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         if (aligned4) done = fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, mono ? 2 : 1, P.lp_alpha);
         if (done && frc) { delete ck; return frc; }
     }
+    if (!done && dtype == AUKIT_F32 && C == 1 && bd == 1 && d->data_type != AUKIT_FLOAT && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !getenv("AUKIT_NO_FAST_CONVERT")) {
+        int frc = AUKIT_OK;  // 8-bit mono: the wave kernel reads the bytes themselves (fast_stream_u8.hip)
+        done = fast_try(ctx, SRC_PCM8_MONO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, 1, P.lp_alpha);
+        if (done && frc) { delete ck; return frc; }
+    }
     if (!done && dtype == AUKIT_F32 && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !getenv("AUKIT_NO_FAST_CONVERT")) {
         // every other PCM format (8-bit unsigned at 48 kHz is what most ComputerCraft audio is kept in), f32 tolerance path: the string is
         // unpacked to one f32 row per output channel (k_pcm_unpack; the `mono` mix is made there, in the reference's order) and the stream.pcm

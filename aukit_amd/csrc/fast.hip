@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_fast_resample(const ResampleParams P, c
 }
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F) {
-    if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_G711_MONO && src_kind != SRC_AUDIO_F32 && src_kind != SRC_I32 && src_kind != SRC_PCM_S16LE_STEREO) return false;
+    if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_G711_MONO && src_kind != SRC_AUDIO_F32 && src_kind != SRC_I32 && src_kind != SRC_PCM_S16LE_STEREO && src_kind != SRC_PCM8_MONO) return false;
     if (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) return false;
     if (old_rate != std::floor(old_rate) || new_rate != std::floor(new_rate) || old_rate < 1 || new_rate < 1 || old_rate > 4e9 || new_rate > 4e9) return false;
     unsigned long long a = (unsigned long long)old_rate, b = (unsigned long long)new_rate, x = a, y = b;
@@ -284,8 +284,9 @@ bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double 
         if (taken) *rc = r2;
         return taken;
     }
+    if (src_kind == SRC_PCM8_MONO && !epi) return false;  // (stream.pcm only)
     if (epi) {  // epilogues other than Audio:resample exist as wave kernels only (fast_stream.hip)
-        if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_AUDIO_F32) return false;
+        if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_AUDIO_F32 && src_kind != SRC_PCM8_MONO) return false;
         bool taken = false;
         int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
         if (taken) *rc = r2;

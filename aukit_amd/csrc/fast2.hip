@@ -99,7 +99,7 @@ static int launch_src2(aukit_ctx *ctx, int interp, int nv, const ResampleParams 
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken) {
     *taken = false;
-    const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : (src_kind == SRC_G711_MONO ? 16 : 4);  // source elements (frames for stereo) per 16-byte vector
+    const int spv = src_kind == SRC_PCM_S16LE_MONO ? 8 : (src_kind == SRC_G711_MONO || src_kind == SRC_PCM8_MONO ? 16 : 4);  // source elements (frames for stereo) per 16-byte vector
     const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (F.epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;  // stream.pcm: one more tap to the left
     const int win = (int)(((unsigned long long)(WT - 1) * F.a) / F.b) + 2 + hl + hr;  // staged samples per wave tile (upper bound)
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
@@ -131,6 +131,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
         static thread_local char nmx[96];
         snprintf(nmx, sizeof nmx, "k_fast_wave_stream_s16x2<%s,nv%d,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, F.epi == 2 ? "mono" : "stereo");
         return ctx_end_kernel(ctx, nmx, algorithmic_bytes);
+    }
+    if (F.epi == 1 && src_kind == SRC_PCM8_MONO) {  // stream.pcm on 8-bit mono strings (fast_stream_u8.hip)
+        if ((rc = launch_fast_wave_stream_u8(ctx, interp, nv, P, F, lds, grid))) return rc;
+        static thread_local char nmu[96];
+        snprintf(nmu, sizeof nmu, "k_fast_wave_stream<pcm8_mono,%s,nv%d,stream_pcm>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+        return ctx_end_kernel(ctx, nmu, algorithmic_bytes);
     }
     if (F.epi == 1 && src_kind == SRC_AUDIO_F32) {  // stream.pcm on unpacked f32 rows (fast_stream_f32.hip)
         if ((rc = launch_fast_wave_stream_f32(ctx, interp, nv, P, F, lds, grid))) return rc;

@@ -15,9 +15,15 @@ constexpr int WT = AUKIT_WT;  // outputs per wave tile = 16 rows of 64
 template <int SRC> struct SrcTraits;
 template <> struct SrcTraits<SRC_PCM_S16LE_MONO> { static constexpr int BYTES = 2, SPV = 8; };
 template <> struct SrcTraits<SRC_G711_MONO> { static constexpr int BYTES = 1, SPV = 16; };
+template <> struct SrcTraits<SRC_PCM8_MONO> { static constexpr int BYTES = 1, SPV = 16; };  // 8-bit PCM: s / (s < 0 and 128 or 127), or (s - 128) / (s < 128 and 128 or 127) for unsigned (Q4)
 template <> struct SrcTraits<SRC_AUDIO_F32> { static constexpr int BYTES = 4, SPV = 4; };
 template <> struct SrcTraits<SRC_I32> { static constexpr int BYTES = 4, SPV = 4; };  // integer rows (FLAC): v * 2^-depth, exact in f32 for |v| < 2^24
 
+// 8-bit PCM sample → f32 (tolerance path: the quotient by 127 as a multiplication, one ulp of f32 from the reference's double division)
+AUKIT_DEV float pcm8_f32(unsigned byte, int is_unsigned) {
+    const int v = is_unsigned ? (int)byte - 128 : (int)(signed char)byte;  // unsigned: s - 128, with s < 128 deciding the divisor — the same test as v < 0
+    return (float)v * (v < 0 ? 1.0f / 128.0f : 1.0f / 127.0f);
+}
 AUKIT_DEV float g711_f32b(unsigned byte, int ulaw, float scale) {
     unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
     int m = b & 15, e = (b >> 4) & 7;
@@ -133,6 +139,8 @@ AUKIT_DEV float sample_at(const ResampleParams &P, const FastParams &F, const un
         return (float)s * (s < 0 ? F.scale_neg : F.scale_pos);
     } else if constexpr (SRC == SRC_G711_MONO) {
         return g711_f32b(*q, P.ulaw, (float)P.g711_scale);
+    } else if constexpr (SRC == SRC_PCM8_MONO) {
+        return pcm8_f32(*q, P.data_type == AUKIT_UNSIGNED);
     } else if constexpr (SRC == SRC_I32) {
         return (float)*reinterpret_cast<const int *>(q) * F.scale_pos;
     } else {
@@ -168,6 +176,13 @@ AUKIT_DEV void write_lds(const ResampleParams &P, const FastParams &F, const Wav
             for (int e = 0; e < 4; e++)
                 o[e] = make_float4(g711_f32b(ww[e] & 0xFF, P.ulaw, sc), g711_f32b((ww[e] >> 8) & 0xFF, P.ulaw, sc),
                                    g711_f32b((ww[e] >> 16) & 0xFF, P.ulaw, sc), g711_f32b(ww[e] >> 24, P.ulaw, sc));
+        } else if constexpr (SRC == SRC_PCM8_MONO) {
+            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
+            const int us = P.data_type == AUKIT_UNSIGNED;
+            float4 *o = reinterpret_cast<float4 *>(sm + 16 * v);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = make_float4(pcm8_f32(ww[e] & 0xFF, us), pcm8_f32((ww[e] >> 8) & 0xFF, us), pcm8_f32((ww[e] >> 16) & 0xFF, us), pcm8_f32(ww[e] >> 24, us));
         } else if constexpr (SRC == SRC_I32) {
             *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4((float)(int)u.x * F.scale_pos, (float)(int)u.y * F.scale_pos, (float)(int)u.z * F.scale_pos, (float)(int)u.w * F.scale_pos);
         } else {

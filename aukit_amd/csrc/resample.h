@@ -25,7 +25,8 @@ struct Seg {
 static_assert(sizeof(Seg) == 40, "Seg layout");
 
 enum SrcKind { SRC_PCM_GENERIC = 0, SRC_PCM_S16LE_MONO = 1, SRC_G711 = 2, SRC_G711_MONO = 3, SRC_AUDIO_F64 = 4, SRC_AUDIO_F32 = 5, SRC_I16 = 6, SRC_I8 = 7, SRC_I32 = 8,
-               SRC_PCM_S16LE_STEREO = 9 /* fast path only (fast_s16x2.hip): interleaved 16-bit stereo frames */ };
+               SRC_PCM_S16LE_STEREO = 9 /* fast path only (fast_s16x2.hip): interleaved 16-bit stereo frames */,
+               SRC_PCM8_MONO = 10 /* fast path only (fast_stream_u8.hip): 8-bit mono, signed or unsigned (P.data_type) */ };
 enum EpiKind {
     EPI_AUDIO = 0,       // Audio:resample  :666-668  (integer x copies unclamped, else clamp ±1)
     EPI_STREAM_PCM = 1,  // stream.pcm      :2397-2403 (no clamp of interp, 2-tap FIR, ×127/128, clamp ±128/127)
@@ -91,6 +92,7 @@ struct FastParams {
     unsigned dq64, dr64; // 64 * a = dq64 * b + dr64: one row of a wave tile further down, (q, rem) advance by (dq64, dr64) with one carry
 };
 int launch_fast_wave_stream(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);
+int launch_fast_wave_stream_u8(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);   // the same on 8-bit mono strings
 int launch_fast_wave_stream_f32(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, size_t lds, unsigned grid);  // the same on f32 rows
 int launch_fast_wave_s16x2(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, unsigned grid);
 bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype,

@@ -203,6 +203,57 @@ def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
             assert rms(got[i][0] / 128, got2[i][0] / 128) <= 1e-6, i
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("bits,dt,be,ch,mono,rate,kernel", [
+    (8, "unsigned", False, 1, False, 48000, "k_fast_wave_stream<pcm8_mono"),   # the classic pre-converted speaker file: bytes read directly
+    (8, "signed", False, 1, False, 44100, "k_fast_wave_stream<pcm8_mono"),
+    (8, "unsigned", False, 2, False, 48000, "k_fast_wave_stream<audio_f32"),   # everything else: unpacked to f32 rows first
+    (8, "unsigned", False, 2, True, 22050, "k_fast_wave_stream<audio_f32"),
+    (24, "signed", False, 2, False, 44100, "k_fast_wave_stream<audio_f32"),
+    (24, "signed", True, 3, True, 32000, "k_fast_wave_stream<audio_f32"),
+    (16, "unsigned", True, 1, False, 48000, "k_fast_wave_stream<audio_f32"),
+    (32, "signed", False, 1, False, 8000, "k_fast_wave_stream<audio_f32"),
+    (32, "float", False, 2, False, 48000, "k_fast_wave_stream<audio_f32"),
+    (16, "signed", False, 1, False, 48000, "k_fast_wave_stream<pcm_s16le_mono"),  # equal rates take the 16-bit kernels too
+    (16, "signed", False, 2, False, 48000, "k_fast_wave_stream_s16x2<"),
+])
+def test_stream_pcm_other_formats_f32_wave_kernels(ctx, oracle, bits, dt, be, ch, mono, rate, kernel, interp):
+    """stream.pcm with F32 storage on PCM formats other than 16-bit 44.1 kHz: 8-bit mono read directly, every other depth / type / byte
+    order / channel count through f32 rows (the mono mix made while unpacking), equal rates (48 kHz sources) included — the oracle's
+    chunking, ≤ 1e-6 RMS on the [-1,1] scale, ≤ 1e-6 RMS from the reference-order kernel; ragged streams."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(1000 + bits * 7 + ch))
+    nfr = [int(rate * 2.5), rate, rate + 3, 10, int(rate * 1.0001) + 2, 1100, 2]
+    streams = []
+    for n in nfr:
+        if dt == "float":
+            streams.append(rng.uniform(-1, 1, n * ch).astype(">f4" if be else "<f4").tobytes())
+        else:
+            streams.append(rng.integers(0, 256, n * ch * (bits // 8), dtype=np.uint8).tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dt, big_endian=be)
+    out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
+    assert ctx.last_kernel()[0].startswith(kernel), ctx.last_kernel()
+    got = out.download()
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        out2, _ = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
+        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<")), ctx.last_kernel()
+        got2 = out2.download()
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, bits, oracle.DTYPE[dt], ch, rate, be, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        assert ck.status[i] == ref.final_status
+        assert len(got[i]) == ref.channels == (1 if (mono and ch > 1) else ch)
+        for c in range(ref.channels):
+            assert len(got[i][c]) == len(ref.data[c])
+            if len(ref.data[c]):
+                assert rms(got[i][c] / 128, ref.data[c] / 128) <= 1e-6, (i, c)
+                assert rms(got[i][c] / 128, got2[i][c] / 128) <= 1e-6, (i, c)
+
+
 @pytest.mark.parametrize("mono", [False, True])
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
 @pytest.mark.parametrize("rate", [44100, 32000, 22050, 8000])
