@@ -933,7 +933,8 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         if (C == 1 && !ctx->exact_math && d->sample_rate == std::floor(d->sample_rate) && d->sample_rate <= 4e9) {
             unsigned long long x = 48000, y = (unsigned long long)d->sample_rate;
             while (y) { const unsigned long long tq = x % y; x = y; y = tq; }
-            const unsigned long long fa = (unsigned long long)d->sample_rate / x, fb = 48000 / x;  // x - 1 = (i - 1) / ratio = (i - 1) * fa / fb
+            unsigned long long fa = (unsigned long long)d->sample_rate / x, fb = 48000 / x;  // x - 1 = (i - 1) / ratio = (i - 1) * fa / fb
+            if (fb == 1) { fa *= 2; fb = 2; }  // a 48 kHz file: every position is an integer (rem is always 0, the weights of phase 0 are 0, 1, 0, 0)
             if (fb >= 2 && ((double)newlen_full * (double)fa + (double)fb) * (double)fb < 4294967296.0) {
                 P.fast = 1; P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb); P.inv_fb = 1.0 / (double)fb;
                 P.fdq = (unsigned)((64ull * fa) / fb); P.fdr = (unsigned)((64ull * fa) % fb);

@@ -302,6 +302,28 @@ def test_stream_adpcm_bit_exact(ctx, oracle, interp, ch, mono, ba):
             assert np.array_equal(got[i][c], ref.data[c]), (i, c)
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate", [48000, 24000, 16000, 44100])
+def test_stream_adpcm_other_rates_bit_exact(ctx, oracle, rate, interp):
+    """stream.adpcm on mono files at 48 kHz (equal rates: every position an integer — the three-tier kernel runs them as 2a / 2), at
+    integer ratios and at 44.1 kHz: floored outputs bit for bit the oracle's, random-byte blocks (saturated predictors) included."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(rate))
+    streams = [oracle.gen_ima(pcm16(1016 * nb, rate, 3, i), 1, 512, 88) for i, nb in enumerate((30, 1, 9))]
+    noise = bytearray(rng.integers(0, 256, 512 * 6, dtype=np.uint8).tobytes())
+    for b in range(6):
+        noise[512 * b + 2] = int(rng.integers(0, 89)); noise[512 * b + 3] = 0  # a valid header step index
+    streams.append(bytes(noise))
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, rate, block_align=512), interp, dtype=N.I8)
+    assert ctx.last_kernel()[0] == "k_ima_stream_f32", ctx.last_kernel()
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_adpcm(s, 512, 1, rate, False, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        assert np.array_equal(got[i][0], ref.data[0]), i
+
+
 def test_stream_adpcm_config3_shape(ctx, oracle):
     """220 × 512-byte mono blocks @22 050 Hz → 219×2211 + 2194 = 486 403 outputs."""
     B, N = _B(), _N()
