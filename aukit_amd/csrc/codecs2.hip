@@ -592,6 +592,30 @@ __global__ __launch_bounds__(256) void k_row_heads_zero(signed char *out, const 
     if (s < n) out[row_off[s]] = 0;
 }
 
+// stream.dfpwm on a 48 kHz file — what nearly every ComputerCraft DFPWM file is: ratio 1, every position x is an integer, `s = audio[x]`
+// (:2481), the same sample goes to every output channel (Q11: x does not depend on j) and the mono mean of C equal integers is that integer.
+// So a chunk's outputs are its decoded samples at stride C: a strided copy with a conversion, 16 bytes per store — instead of the general
+// resampler with its stream.dfpwm epilogue (a position, a window in LDS and a clamp per output).
+template <typename T>
+__global__ __launch_bounds__(256) void k_dfpwm_stream_copy(const signed char *rows, const unsigned long long *row_off, const Seg *segs, T *out, int C, int nd) {
+    const Seg g = segs[blockIdx.y];
+    const signed char *src = rows + row_off[g.stream] + g.src_base + 1;  // audio[1]
+    constexpr int PV = 16 / (int)sizeof(T);
+    typedef T ovp __attribute__((ext_vector_type(PV), aligned(sizeof(T))));
+    const unsigned groups = g.n_out / PV;
+    for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < groups; q += gridDim.x * 256) {
+        ovp w;
+#pragma unroll
+        for (int e = 0; e < PV; e++) w[e] = (T)src[(unsigned long long)(q * PV + e) * (unsigned)C];
+        for (int c = 0; c < nd; c++) *reinterpret_cast<ovp *>(out + g.out_off + (unsigned long long)c * g.out_stride + (unsigned long long)q * PV) = w;
+    }
+    if (blockIdx.x == 0)
+        for (unsigned k = groups * PV + threadIdx.x; k < g.n_out; k += 256) {
+            const T v = (T)src[(unsigned long long)k * (unsigned)C];
+            for (int c = 0; c < nd; c++) out[g.out_off + (unsigned long long)c * g.out_stride + k] = v;
+        }
+}
+
 static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                         aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -657,6 +681,26 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
         hipLaunchKernelGGL(k_dfpwm_stream_rows, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
                            in->n, (unsigned long long)adv, reinterpret_cast<signed char *>(ctx->tmp_buf.p), reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p));
         AUKIT_HIP_CHECK(hipGetLastError());
+        if (d->sample_rate == 48000 && !getenv("AUKIT_NO_FAST_CONVERT")) {  // ratio 1: a strided copy (k_dfpwm_stream_copy)
+            if ((rc = upload_table(ctx, ctx->seg_buf, segs.data(), segs.size() * sizeof(Seg)))) { delete ck; return rc; }
+            ctx->plan_key.clear();  // (seg_buf no longer holds a resample plan)
+            if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
+            uint32_t mmax = 0;
+            for (const Seg &g : segs) mmax = std::max(mmax, g.n_out);
+            const unsigned gx = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((mmax / 4 + 255) / 256, 64));
+            const Seg *dsegs = reinterpret_cast<const Seg *>(ctx->seg_buf.p);
+            for (size_t first = 0; first < segs.size(); first += 65535) {
+                const dim3 grid(gx, (unsigned)std::min<size_t>(65535, segs.size() - first));
+                if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_dfpwm_stream_copy<double>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), d_rowo, dsegs + first, reinterpret_cast<double *>(a->dev), C, nd);
+                else hipLaunchKernelGGL((k_dfpwm_stream_copy<float>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const signed char *>(ctx->tmp_buf.p), d_rowo, dsegs + first, reinterpret_cast<float *>(a->dev), C, nd);
+            }
+            AUKIT_HIP_CHECK(hipGetLastError());
+            uint64_t oe1 = 0;
+            for (uint64_t l : lens) oe1 += l * nd;
+            if ((rc = ctx_end_kernel(ctx, "k_dfpwm_stream_copy", in->total() + oe1 * dtype_size(dtype)))) { delete ck; return rc; }
+            if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+            return AUKIT_OK;
+        }
         ResampleParams P;
         memset(&P, 0, sizeof P);
         P.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
