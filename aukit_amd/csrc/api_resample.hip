@@ -211,7 +211,9 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
     P.out = a->dev;
     if (do_resample && dtype == AUKIT_F32 && C == 1) {  // HBM-bound tolerance path (fast.hip)
         int frc = AUKIT_OK;
-        if (fast_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
+        int fsrc = src;
+        if (d->codec == AUKIT_CODEC_PCM && d->bit_depth == 8 && d->data_type != AUKIT_FLOAT) fsrc = SRC_PCM8_MONO;  // 8-bit mono: the wave kernel reads the bytes themselves
+        if (fast_try(ctx, fsrc, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
     if (do_resample && dtype == AUKIT_F32 && C == 2 && d->codec == AUKIT_CODEC_PCM && !planar && d->bit_depth == 16 && d->data_type == AUKIT_SIGNED && !d->big_endian) {
         bool aligned4 = (((uintptr_t)in->data()) & 3) == 0;  // frames must not straddle dwords

@@ -284,9 +284,14 @@ bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double 
         if (taken) *rc = r2;
         return taken;
     }
-    if (src_kind == SRC_PCM8_MONO && !epi) return false;  // (stream.pcm only)
     if (epi) {  // epilogues other than Audio:resample exist as wave kernels only (fast_stream.hip)
         if (src_kind != SRC_PCM_S16LE_MONO && src_kind != SRC_AUDIO_F32 && src_kind != SRC_PCM8_MONO) return false;
+        bool taken = false;
+        int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
+        if (taken) *rc = r2;
+        return taken;
+    }
+    if (src_kind == SRC_PCM8_MONO) {  // 8-bit mono strings: the wave kernel only
         bool taken = false;
         int r2 = launch_fast_wave(ctx, src_kind, interp, segs, P, F, algorithmic_bytes, &taken);
         if (taken) *rc = r2;

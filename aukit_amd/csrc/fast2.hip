@@ -168,11 +168,12 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     case SRC_G711_MONO: rc = launch_src2<SRC_G711_MONO>(ctx, interp, nv, P, F, lds, grid); break;
     case SRC_AUDIO_F32: rc = launch_src2<SRC_AUDIO_F32>(ctx, interp, nv, P, F, lds, grid); break;
     case SRC_I32: rc = launch_src2<SRC_I32>(ctx, interp, nv, P, F, lds, grid); break;
+    case SRC_PCM8_MONO: rc = launch_src2<SRC_PCM8_MONO>(ctx, interp, nv, P, F, lds, grid); break;
     default: rc = fail(AUKIT_E_ARG, "bad fast source");
     }
     if (rc) return rc;
     static thread_local char nm[96];
-    static const char *srcn[] = {"", "pcm_s16le_mono", "", "g711_mono", "", "audio_f32", "", "", "i32"};
+    static const char *srcn[] = {"", "pcm_s16le_mono", "", "g711_mono", "", "audio_f32", "", "", "i32", "", "pcm8_mono"};
     snprintf(nm, sizeof nm, "k_fast_wave<%s,%s,nv%d>", srcn[src_kind], interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
     return ctx_end_kernel(ctx, nm, algorithmic_bytes);
 }

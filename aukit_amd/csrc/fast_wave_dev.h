@@ -233,7 +233,7 @@ AUKIT_DEV float interp_qr(const FastParams &F, const float *tab, unsigned q, uns
         v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
     }
     const float c = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);  // aukit.lua:667-668
-    if constexpr (SRC == SRC_PCM_S16LE_MONO || SRC == SRC_G711_MONO) return c;
+    if constexpr (SRC == SRC_PCM_S16LE_MONO || SRC == SRC_G711_MONO || SRC == SRC_PCM8_MONO) return c;
     else return rem == 0 ? p1 : c;
 }
 

@@ -204,6 +204,27 @@ def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
 
 
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("dt", ["unsigned", "signed"])
+@pytest.mark.parametrize("rate,new_rate", [(44100, 48000), (22050, 48000), (8000, 48000), (48000, 44100), (48000, 48000)])
+def test_fast_f32_pcm8_mono(ctx, oracle, rate, new_rate, dt, interp):
+    """aukit.pcm(d, 8, dt, 1, rate):resample(new_rate) with F32 storage: the wave kernel reads the bytes themselves — ≤ 1e-6 RMS from the
+    oracle, every byte value present, ragged lengths incl. one sample and an empty string."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(rate + new_rate))
+    streams = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (int(rate * 1.3), 5000, 1024 * 3 + 5, 1, 0, 77)]
+    streams[1] = bytes(range(256)) * 20
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, 1, rate, 8, dt)
+    got = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F32).download()
+    assert ctx.last_kernel()[0].startswith("k_fast_wave<pcm8_mono"), ctx.last_kernel()
+    for s, g in zip(streams, got):
+        ref = oracle.resample(oracle.pcm(s, 8, oracle.DTYPE[dt], 1, rate), new_rate, oracle.INTERP[interp])
+        assert len(g[0]) == len(ref.data[0])
+        if len(g[0]):
+            assert rms(g[0], ref.data[0]) <= 1e-6
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
 @pytest.mark.parametrize("bits,dt,be,ch,mono,rate,kernel", [
     (8, "unsigned", False, 1, False, 48000, "k_fast_wave_stream<pcm8_mono"),   # the classic pre-converted speaker file: bytes read directly
     (8, "signed", False, 1, False, 44100, "k_fast_wave_stream<pcm8_mono"),
