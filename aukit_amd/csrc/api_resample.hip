@@ -634,6 +634,22 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
     P.norm_neg = norm_neg;
     P.out = a->dev;
     const int ip = do_resample ? interp : AUKIT_INTERP_NONE;
+    if ((src_kind == SRC_I16 || src_kind == SRC_I8) && dtype == AUKIT_F32 && do_resample && rows_dev == ctx->tmp_buf.p && !ctx->exact_math &&
+        ((src_kind == SRC_I16 && norm_pos == 32767 && norm_neg == 32768) || (src_kind == SRC_I8 && norm_pos == 127 && norm_neg == 128))) {
+        // int16 / int8 rows (the IMA, MS... , QOA, DFPWM loaders) with a resample behind them, F32 tolerance path: an int16 row IS a 16-bit
+        // little-endian mono string with the same normalisation (s / 32768 | 32767), an int8 row an 8-bit signed one — the wave kernels of the
+        // PCM path take them as they are (byte offsets instead of element offsets).  k_resample moved 120-200 G samples/s on these.
+        const int bytes_per = src_kind == SRC_I16 ? 2 : 1;
+        std::vector<uint64_t> boff(row_off.size());
+        for (size_t r = 0; r < row_off.size(); r++) boff[r] = row_off[r] * (uint64_t)bytes_per;
+        if ((rc = upload_table(ctx, ctx->misc_buf, boff.data(), boff.size() * sizeof(uint64_t)))) return rc;
+        P.data_type = AUKIT_SIGNED;
+        P.safe_lo = reinterpret_cast<const unsigned char *>(rows_dev);
+        P.safe_hi = P.safe_lo + ctx->tmp_buf.cap;
+        int frc = AUKIT_OK;
+        if (fast_try(ctx, src_kind == SRC_I16 ? SRC_PCM_S16LE_MONO : SRC_PCM8_MONO, ip, rate, new_rate, segs, P, in_elems * bytes_per + out_elems * 4, &frc)) return frc;
+        if ((rc = upload_table(ctx, ctx->misc_buf, row_off.data(), row_off.size() * sizeof(uint64_t)))) return rc;  // not taken: element offsets again
+    }
     if (src_kind == SRC_I32 && dtype == AUKIT_F32 && do_resample && rows_dev == ctx->tmp_buf.p) {  // F32 pipelines: tolerance path
         P.safe_lo = reinterpret_cast<const unsigned char *>(rows_dev);
         P.safe_hi = P.safe_lo + ctx->tmp_buf.cap;

@@ -324,6 +324,28 @@ def test_stream_adpcm_other_rates_bit_exact(ctx, oracle, rate, interp):
         assert np.array_equal(got[i][0], ref.data[0]), i
 
 
+def test_int_row_loaders_with_resample_f32_take_the_pcm_wave_kernels(ctx, oracle):
+    """IMA / QOA (int16 rows) and DFPWM (int8 rows) loaders with a resample behind them and F32 storage: the rows are 16-bit / 8-bit mono
+    strings to the wave kernels of the PCM path — ≤ 1e-6 RMS from the oracle, per channel."""
+    B, N = _B(), _N()
+    ima = [oracle.gen_ima(np.stack([pcm16(1017 * nb, 22050, 3, 4 * i + c) for c in range(2)], 1).ravel(), 2, 1024, 88) for i, nb in enumerate((20, 3))]
+    qoa = [oracle.gen_qoa(np.stack([pcm16(n, 44100, 8, 4 * i + c) for c in range(2)], 1).ravel(), 2, 44100) + b"\0" * 8 for i, n in enumerate((5120 * 3 + 777, 9000))]
+    dfp = [oracle.dfpwm_encode(np.round(signal(48000 * 2, 24000, 4, 70 + i) * 100)) for i in range(2)]
+    cases = [("ima", ima, B.make_desc(N.CODEC_ADPCM_WAV, 2, 22050, block_align=1024), lambda s: oracle.wav_adpcm(s, 1024, 2, 22050), 22050, "k_fast_wave"),
+             ("qoa", qoa, B.make_desc(N.CODEC_QOA, 2, 44100), lambda s: oracle.qoa(s), 44100, "k_fast_wave"),
+             ("dfpwm", dfp, B.make_desc(N.CODEC_DFPWM, 1, 24000), lambda s: oracle.dfpwm(s, 1, 24000), 24000, "k_fast_wave")]
+    for name, streams, desc, ref_fn, rate, kernel in cases:
+        for interp in ("linear", "cubic"):
+            got = B.decode_resample(ctx, B.Batch.upload(ctx, streams), desc, 48000, interp, dtype=N.F32).download()
+            assert ctx.last_kernel()[0].startswith(kernel), (name, ctx.last_kernel())
+            for s, g in zip(streams, got):
+                ref = oracle.resample(ref_fn(s), 48000, oracle.INTERP[interp])
+                assert len(g) == ref.channels
+                for c in range(ref.channels):
+                    assert len(g[c]) == len(ref.data[c]), (name, c)
+                    assert rms(g[c], ref.data[c]) <= 1e-6, (name, interp, c)
+
+
 def test_stream_adpcm_config3_shape(ctx, oracle):
     """220 × 512-byte mono blocks @22 050 Hz → 219×2211 + 2194 = 486 403 outputs."""
     B, N = _B(), _N()
