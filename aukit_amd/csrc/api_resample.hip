@@ -221,6 +221,69 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int frc = AUKIT_OK;
         if (aligned4 && fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
+    // (only for formats whose samples lie in [-1, 1] — signed of any depth, 8-bit unsigned: where the reference's rounded position x misses an
+    // integer it interpolates and CLAMPS (:667-668) what the exact rational position copies unclamped, and that shows on samples beyond ±1:
+    // unsigned 16 / 24 / 32-bit (Q4 reaches 2) and float strings keep the reference-order kernel)
+    if (do_resample && dtype == AUKIT_F32 && d->codec == AUKIT_CODEC_PCM && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) &&
+        (d->data_type == AUKIT_SIGNED || (d->data_type == AUKIT_UNSIGNED && d->bit_depth == 8)) && !getenv("AUKIT_NO_FAST_CONVERT")) {
+        // every other PCM format with a resample behind it, F32 tolerance path: unpacked to one f32 row per channel (k_pcm_unpack), then the f32
+        // wave kernel on the rows — what stream.pcm does for these formats.  (k_resample moved 145-210 G samples/s on 24-bit stereo / float.)
+        std::vector<UnpackRow> ur((size_t)in->n * C);
+        std::vector<uint64_t> roff((size_t)in->n * C);
+        uint64_t tot = 0, longest = 0;
+        for (uint32_t s = 0; s < in->n; s++) {
+            for (int c = 0; c < C; c++) {
+                UnpackRow &u = ur[(size_t)s * C + c];
+                u.src = in->off[s]; u.dst = tot; u.frames = frames[s];
+                u.first = planar ? (uint64_t)c * frames[s] : (uint64_t)c; u.step = planar ? 1 : (uint64_t)C; u.mix = 0;
+                roff[(size_t)s * C + c] = tot;
+                tot += round_up(std::max<uint64_t>(frames[s], 1), 16) + 16;
+            }
+            longest = std::max(longest, frames[s]);
+        }
+        std::vector<Seg> rsegs;
+        rsegs.reserve(segs.size() * (size_t)C);
+        for (const Seg &g : segs)
+            for (int c = 0; c < C; c++) {
+                Seg r = g;
+                r.stream = g.stream * (unsigned)C + (unsigned)c;
+                r.out_off = g.out_off + (uint64_t)c * g.out_stride;
+                r.out_stride = 0;
+                rsegs.push_back(r);
+            }
+        if (longest) {
+            if ((rc = ctx->tmp_buf.ensure((size_t)tot * 4 + 256))) return rc;
+            if ((rc = upload_table(ctx, ctx->tmp_buf2, ur.data(), ur.size() * sizeof(UnpackRow)))) return rc;
+            if ((rc = upload_table(ctx, ctx->misc_buf, roff.data(), roff.size() * sizeof(uint64_t)))) return rc;
+            const UnpackRow *d_ur = reinterpret_cast<const UnpackRow *>(ctx->tmp_buf2.p);
+            const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest / 4 + 255) / 256 / 4, 64));
+            const int bytes = d->bit_depth / 8;
+            if ((rc = ctx_begin_kernel(ctx))) return rc;
+            for (size_t first = 0; first < ur.size(); first += 65535) {
+                const dim3 grid(gx, (unsigned)std::min<size_t>(65535, ur.size() - first));
+                float *rows = reinterpret_cast<float *>(ctx->tmp_buf.p);
+                if (bytes == 1) hipLaunchKernelGGL((k_pcm_unpack<1, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else if (bytes == 2) hipLaunchKernelGGL((k_pcm_unpack<2, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else if (bytes == 3) hipLaunchKernelGGL((k_pcm_unpack<3, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+                else hipLaunchKernelGGL((k_pcm_unpack<4, float>), grid, dim3(256), 0, ctx->stream, in->data(), d_ur + first, rows, d->data_type, d->big_endian ? 1 : 0);
+            }
+            AUKIT_HIP_CHECK(hipGetLastError());
+            if ((rc = ctx_end_kernel(ctx, "k_pcm_unpack", in_bytes + tot * 4))) return rc;
+            ResampleParams R;
+            memset(&R, 0, sizeof R);
+            R.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
+            R.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+            R.channels = 1;
+            R.out = a->dev;
+            R.safe_lo = R.src;
+            R.safe_hi = R.src + ctx->tmp_buf.cap;
+            int frc = AUKIT_OK;
+            if (fast_try(ctx, SRC_AUDIO_F32, interp, d->sample_rate, new_rate, rsegs, R, in_bytes + out_elems * 4, &frc)) return frc;
+            if (planar) {  // not taken: the reference-order kernel below wants its frame table back
+                if ((rc = upload_table(ctx, ctx->misc_buf, frames.data(), frames.size() * sizeof(uint64_t)))) return rc;
+            }
+        }
+    }
     if (do_resample && dtype == AUKIT_F32 && C == 1 && ctx->exact_math == 1 && src == SRC_PCM_S16LE_MONO) {  // fp64 arithmetic, f32 store (wave_f64.hip)
         int wrc = AUKIT_OK;
         if (wave_f64_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &wrc)) return wrc;

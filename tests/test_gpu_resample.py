@@ -82,6 +82,34 @@ def test_pcm_formats(ctx, oracle, bits, dtype, be, ch, interleaved):
         assert np.max(np.abs(got[c] - ref.data[c])) <= 1e-15
 
 
+@pytest.mark.parametrize("bits,dtype,be,ch,interleaved", [
+    (8, "unsigned", False, 2, True), (16, "unsigned", True, 1, True), (16, "signed", True, 2, True), (24, "signed", False, 2, True), (24, "unsigned", True, 1, True),
+    (32, "signed", False, 1, True), (32, "float", False, 2, True), (32, "float", True, 1, True), (16, "signed", False, 2, False), (16, "signed", False, 3, True),
+])
+@pytest.mark.parametrize("rate,new_rate", [(22050, 48000), (48000, 44100)])
+def test_pcm_formats_resample_f32_through_rows(ctx, oracle, bits, dtype, be, ch, interleaved, rate, new_rate):
+    """aukit.pcm(any format):resample(...) with F32 storage: unpacked to f32 rows, then the f32 wave kernel — ≤ 1e-6 RMS from the oracle."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(177 + bits + ch))
+    streams = []
+    for frames in (3001, 1, 40000):
+        if dtype == "float":
+            streams.append(rng.uniform(-1, 1, frames * ch).astype(">f4" if be else "<f4").tobytes())
+        else:
+            streams.append(rng.integers(0, 256, frames * ch * (bits // 8), dtype=np.uint8).tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dtype, big_endian=be, interleaved=interleaved)
+    got = B.decode_resample(ctx, bt, desc, new_rate, "cubic", dtype=N.F32).download()
+    in_range = dtype == "signed" or (dtype == "unsigned" and bits == 8)  # samples within [-1, 1]: the only formats the rows path takes (see api_resample.hip)
+    assert ctx.last_kernel()[0].startswith(("k_fast_wave<audio_f32", "k_fast_resample<audio_f32") if in_range else "k_resample<"), ctx.last_kernel()
+    for s, g in zip(streams, got):
+        ref = oracle.resample(oracle.pcm(s, bits, oracle.DTYPE[dtype], ch, rate, interleaved, be), new_rate, oracle.CUBIC)
+        for c in range(ch):
+            assert len(g[c]) == len(ref.data[c])
+            if len(g[c]):
+                assert rms(g[c], ref.data[c]) <= 1e-6, c
+
+
 def test_pcm_uneven_data_is_an_error(ctx):
     B, N = _B(), _N()
     bt = B.Batch.upload(ctx, [b"\0" * 7])
