@@ -110,6 +110,26 @@ def test_pcm_formats_resample_f32_through_rows(ctx, oracle, bits, dtype, be, ch,
                 assert rms(g[c], ref.data[c]) <= 1e-6, c
 
 
+@pytest.mark.parametrize("rate,new_rate", [(48000, 48000), (44100, 44100), (96000, 48000), (48000, 24000)])
+def test_equal_rates_and_integer_decimation_every_kernel_family(oracle, rate, new_rate):
+    """Every position is an integer (the fast kernels run b == 1 as 2a / 2): F64 storage bit for bit the oracle, F32 storage ≤ 1e-6 in the f32
+    kernels, in fp64 arithmetic (exact_math 1) and in the reference order (exact_math 2); ragged streams incl. one sample and none."""
+    B, N = _B(), _N()
+    streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate((50000, 1, 1025, 0))]
+    for dtype, em in ((N.F64, 0), (N.F32, 0), (N.F32, 1), (N.F32, 2)):
+        c2 = B.Context(0, dtype=dtype)
+        c2.set_option(N.OPT_EXACT_MATH, em)
+        bt = B.Batch.upload(c2, streams)
+        for interp in ("linear", "cubic"):
+            got = B.decode_resample(c2, bt, B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed"), new_rate, interp).download()
+            for s, g in zip(streams, got):
+                ref = oracle.resample(oracle.pcm(s, 16, oracle.SIGNED, 1, rate), new_rate, oracle.INTERP[interp]).data[0]
+                assert len(g[0]) == len(ref)
+                if len(ref):
+                    assert np.max(np.abs(g[0] - ref)) <= (0.0 if dtype == N.F64 else 1e-6), (dtype, em, interp, c2.last_kernel()[0])
+        c2.close()
+
+
 def test_pcm_uneven_data_is_an_error(ctx):
     B, N = _B(), _N()
     bt = B.Batch.upload(ctx, [b"\0" * 7])
