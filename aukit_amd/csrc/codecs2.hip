@@ -1,9 +1,7 @@
 // codecs2.hip — MS-ADPCM, QOA, MDFPWM loaders and the remaining stream.* factories (dfpwm, mdfpwm, msadpcm, qoa).
 //
-// MS-ADPCM (aukit.lua:1321-1328) and the QOA LMS (aukit.lua:1686-1701) have a floor / wrap inside the recurrence, so they
-// are sequential per block / frame: one lane per (block, channel) resp. (frame, channel); parallelism comes from
-// blocks × streams.  MS-ADPCM is evaluated in fp64 exactly like the Lua (its `delta` can leave the integer range on
-// adversarial data); QOA in int64 with the int32 wrap of bit32.arshift.  None of these is on a BASELINE config.
+// The QOA LMS (aukit.lua:1686-1701) has a wrap inside the recurrence, so frames are sequential: one lane per (frame, channel);
+// parallelism comes from frames × streams.  (MS-ADPCM lives in msadpcm.hip.)
 #include <algorithm>
 #include "resample.h"
 #include "dfpwm_dev.h"
@@ -14,265 +12,7 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
                         double norm_neg, aukit_audio **out);
 
-AUKIT_DEV double lclamp(double n, double mn, double mx) { return n < mn ? mn : (n > mx ? mx : n); }
-
-// ================================================================= MS-ADPCM
-__constant__ int c_ms_adapt[16] = {230, 230, 230, 230, 307, 409, 512, 614, 768, 614, 512, 409, 307, 230, 230, 230};  // [0..7], [-8..-1]  :173-176
-
-struct MsJob {
-    unsigned long long blk_off;   // byte offset of the block
-    unsigned long long hdr_off;   // byte offset of the header to use (mono: always the stream's first block, Q9)
-    unsigned long long out_off;   // element offset (doubles) of this block's first sample, channel 0
-    unsigned long long out_off_r; // channel 1
-};
-struct MsParams {
-    const unsigned char *src;
-    const MsJob *jobs;
-    unsigned long long njobs;
-    int C, block_align, ncoef;
-    int coef1[32], coef2[32];
-    double div_neg, div_pos;      // 32768/32767 (aukit.msadpcm) or 128/127 (stream.msadpcm)
-    int floor_all;                // stream stereo: every sample floored (:2648-2662); stream mono / Audio path: not
-    double *out;
-    int *err;
-};
-AUKIT_DEV double ms_step(double &s1, double &s2, double &delta, double c1, double c2, int nib) {
-    const double predictor = lclamp(floor((s1 * c1 + s2 * c2) / 256) + nib * delta, -32768, 32767);  // :1321
-    s2 = s1; s1 = predictor;
-    const double nd = floor(c_ms_adapt[nib & 15] * delta / 256);                                      // :1324
-    delta = nd < 16 ? 16 : nd;  // math.max(nd, 16): PUC math.max keeps the first argument unless the next is greater
-    return predictor;
-}
-AUKIT_DEV int rd16(const unsigned char *p) { return (short)(p[0] | p[1] << 8); }
-
-__global__ __launch_bounds__(64) void k_msadpcm(const MsParams P) {
-    const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
-    if (j >= P.njobs) return;
-    const MsJob job = P.jobs[j];
-    const unsigned char *blk = P.src + job.blk_off, *h = P.src + job.hdr_off;
-    auto norm = [&](double p) {
-        const double v = p / (p < 0 ? P.div_neg : P.div_pos);
-        return P.floor_all ? floor(v) : v;
-    };
-    auto emit = [&](double *o, unsigned long long i, double p) { o[i] = norm(p); };
-    // One lane per block: four data bytes per (unaligned) dword load and 16-byte stores — byte loads and one 8-byte store per sample made
-    // every memory instruction of the wave a visit to 64 cache lines.
-    typedef unsigned u32u __attribute__((aligned(1)));
-    typedef double dbl2a __attribute__((ext_vector_type(2), aligned(8)));
-    auto nibs = [](int b, int &hi, int &lo) { hi = b >> 4; lo = b & 15; if (hi >= 8) hi -= 16; if (lo >= 8) lo -= 16; };
-    if (P.C == 2) {
-        const int piL = h[0], piR = h[1];
-        if (piL >= P.ncoef || piR >= P.ncoef) { atomicCAS(P.err, 0, 1); return; }
-        double dL = rd16(h + 2), dR = rd16(h + 4), s1L = rd16(h + 6), s1R = rd16(h + 8), s2L = rd16(h + 10), s2R = rd16(h + 12);
-        const double c1L = P.coef1[piL], c2L = P.coef2[piL], c1R = P.coef1[piR], c2R = P.coef2[piR];
-        double *oL = P.out + job.out_off, *oR = P.out + job.out_off_r;
-        emit(oL, 0, s2L); emit(oL, 1, s1L); emit(oR, 0, s2R); emit(oR, 1, s1R);
-        unsigned long long w = 2;
-        int i = 14;
-        for (; i + 4 <= P.block_align; i += 4) {
-            const unsigned word = *reinterpret_cast<const u32u *>(blk + i);
-            double l[4], r[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int hi, lo;
-                nibs((int)((word >> (8 * k)) & 0xFF), hi, lo);
-                l[k] = norm(ms_step(s1L, s2L, dL, c1L, c2L, hi));
-                r[k] = norm(ms_step(s1R, s2R, dR, c1R, c2R, lo));
-            }
-            dbl2a v;
-            v.x = l[0]; v.y = l[1]; *reinterpret_cast<dbl2a *>(oL + w) = v;
-            v.x = l[2]; v.y = l[3]; *reinterpret_cast<dbl2a *>(oL + w + 2) = v;
-            v.x = r[0]; v.y = r[1]; *reinterpret_cast<dbl2a *>(oR + w) = v;
-            v.x = r[2]; v.y = r[3]; *reinterpret_cast<dbl2a *>(oR + w + 2) = v;
-            w += 4;
-        }
-        for (; i < P.block_align; i++) {
-            int hi, lo;
-            nibs(blk[i], hi, lo);
-            emit(oL, w, ms_step(s1L, s2L, dL, c1L, c2L, hi));
-            emit(oR, w, ms_step(s1R, s2R, dR, c1R, c2R, lo));
-            w++;
-        }
-    } else {
-        const int pi = h[0];
-        if (pi >= P.ncoef) { atomicCAS(P.err, 0, 1); return; }
-        double d = rd16(h + 1), s1 = rd16(h + 3), s2 = rd16(h + 5);
-        const double c1 = P.coef1[pi], c2 = P.coef2[pi];
-        double *o = P.out + job.out_off;
-        // stream mono leaves the two header samples unfloored too (:2708-2709)
-        emit(o, 0, s2); emit(o, 1, s1);
-        unsigned long long w = 2;
-        int i = 7;
-        for (; i + 4 <= P.block_align; i += 4) {
-            const unsigned word = *reinterpret_cast<const u32u *>(blk + i);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int hi, lo;
-                nibs((int)((word >> (8 * k)) & 0xFF), hi, lo);
-                dbl2a v;
-                v.x = norm(ms_step(s1, s2, d, c1, c2, hi));
-                v.y = norm(ms_step(s1, s2, d, c1, c2, lo));
-                *reinterpret_cast<dbl2a *>(o + w) = v;
-                w += 2;
-            }
-        }
-        for (; i < P.block_align; i++) {
-            int hi, lo;
-            nibs(blk[i], hi, lo);
-            emit(o, w++, ms_step(s1, s2, d, c1, c2, hi));
-            emit(o, w++, ms_step(s1, s2, d, c1, c2, lo));
-        }
-    }
-}
-
-static const int ms_c1_default[7] = {256, 512, 0, 192, 240, 460, 392}, ms_c2_default[7] = {0, -256, 0, 64, 0, -208, -232};  // :1304
-
-// decodes every block of every stream into fp64 rows in ctx->tmp_buf; rows are per (stream, channel), blocks back to back
-static int msadpcm_rows(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, bool stream_mode, std::vector<uint64_t> &row_off,
-                        std::vector<uint64_t> &row_len, std::vector<uint64_t> &nblocks, uint64_t *spb_out) {
-    const int C = d->channels;
-    if (C != 1 && C != 2) return fail(AUKIT_E_LUA, "Unsupported number of channels: %d", C);
-    const uint64_t ba = (uint64_t)d->block_align;
-    if (d->block_align < (C == 2 ? 15 : 8)) return fail(AUKIT_E_ARG, "bad blockAlign");
-    const uint64_t spb = C == 2 ? (ba - 14) + 2 : (ba - 7) * 2 + 2;  // samples decoded per block per channel
-    *spb_out = spb;
-    std::vector<MsJob> jobs;
-    row_off.assign((size_t)in->n * C, 0);
-    row_len.assign((size_t)in->n * C, 0);
-    nblocks.assign(in->n, 0);
-    uint64_t tot = 0;
-    for (uint32_t s = 0; s < in->n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s];
-        const uint64_t nblk = (nb + ba - 1) / ba;  // for n = 1, #data, blockAlign
-        if (nblk && nb % ba != 0) return fail(AUKIT_E_LUA, stream_mode ? "bad argument #1 to 'rshift' (number expected, got nil)" : "bad argument #1 to 'rshift' (number expected, got nil)");
-        nblocks[s] = nblk;
-        const uint64_t L = nblk * spb, stride = round_up(std::max<uint64_t>(L, 1), 2);
-        for (int c = 0; c < C; c++) { row_off[(size_t)s * C + c] = tot + (uint64_t)c * stride; row_len[(size_t)s * C + c] = L; }
-        for (uint64_t b = 0; b < nblk; b++) {
-            MsJob j;
-            j.blk_off = in->off[s] + b * ba;
-            j.hdr_off = C == 1 ? in->off[s] : j.blk_off;
-            j.out_off = tot + b * spb;
-            j.out_off_r = tot + stride + b * spb;
-            jobs.push_back(j);
-        }
-        tot += stride * C;
-    }
-    int rc = ctx->tmp_buf.ensure((size_t)tot * 8 + 64);
-    if (rc) return rc;
-    const size_t jbytes = jobs.size() * sizeof(MsJob);
-    if ((rc = ctx->tmp_buf2.ensure(jbytes + 16))) return rc;
-    if (jbytes) { int hrc = h2d_table(ctx, ctx->tmp_buf2.p, jobs.data(), jbytes); if (hrc) return hrc; }
-    int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(ctx->tmp_buf2.p) + jbytes);
-    AUKIT_HIP_CHECK(hipMemsetAsync(err, 0, 8, ctx->stream));
-    if (jobs.empty()) return AUKIT_OK;
-    MsParams P{};
-    P.src = in->data(); P.jobs = reinterpret_cast<const MsJob *>(ctx->tmp_buf2.p); P.njobs = jobs.size();
-    P.C = C; P.block_align = d->block_align;
-    if (d->ncoef > 0) { P.ncoef = std::min(d->ncoef, 32); for (int i = 0; i < P.ncoef; i++) { P.coef1[i] = d->coef1[i]; P.coef2[i] = d->coef2[i]; } }
-    else { P.ncoef = 7; for (int i = 0; i < 7; i++) { P.coef1[i] = ms_c1_default[i]; P.coef2[i] = ms_c2_default[i]; } }
-    P.div_neg = stream_mode ? 128 : 32768; P.div_pos = stream_mode ? 127 : 32767;
-    P.floor_all = (stream_mode && C == 2) ? 1 : 0;
-    P.out = reinterpret_cast<double *>(ctx->tmp_buf.p);
-    P.err = err;
-    if ((rc = ctx_begin_kernel(ctx))) return rc;
-    hipLaunchKernelGGL(k_msadpcm, dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, ctx->stream, P);
-    AUKIT_HIP_CHECK(hipGetLastError());
-    if ((rc = ctx_end_kernel(ctx, "k_msadpcm", in->total() + tot * 8))) return rc;
-    int herr = 0;
-    AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (herr) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (local 'c1')");  // predictor index beyond the coefficient table
-    return AUKIT_OK;
-}
-
-int decode_msadpcm_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample, int dtype,
-                         aukit_audio **out) {
-    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
-    std::vector<uint64_t> row_off, row_len, nblocks;
-    uint64_t spb;
-    int rc = msadpcm_rows(ctx, in, d, false, row_off, row_len, nblocks, &spb);
-    if (rc) return rc;
-    return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, row_off, row_len, in->n, d->channels, d->sample_rate, new_rate, interp, do_resample, dtype, 1, 1, out);
-}
-
-// aukit.stream.msadpcm  aukit.lua:2588-2736
-static int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
-                          aukit_chunks **chunks_out) {
-    const int C = d->channels;
-    if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
-    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
-    if (interp == AUKIT_INTERP_SINC && C == 2) return fail(AUKIT_E_UNSUPPORTED, "stream.msadpcm stereo + sinc reads the previous block through a shifted history (not reproduced)");
-    if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.msadpcm output must be AUKIT_I8 or AUKIT_F64");
-    std::vector<uint64_t> row_off, row_len, nblocks;
-    uint64_t spb_dec;
-    int rc = msadpcm_rows(ctx, in, d, true, row_off, row_len, nblocks, &spb_dec);
-    if (rc) return rc;
-    const uint64_t ba = (uint64_t)d->block_align;
-    const double ratio = 48000 / d->sample_rate;
-    const double samplesPerBlock = C == 2 ? (double)(ba - 14) : (double)(ba - 7) * 2;  // :2617 / :2682 (2 short, Q9)
-    const double ips_d = std::ceil(d->sample_rate / samplesPerBlock);
-    const double bytesPerSecond = (double)ba * ips_d;
-    const uint32_t newlen = (uint32_t)std::max(0.0, std::floor(samplesPerBlock * ratio));
-    const uint64_t ips = (uint64_t)ips_d;
-    const int nd = (C == 2 && !mono) ? 2 : 1;
-    aukit_chunks *ck = new aukit_chunks();
-    ck->n = in->n;
-    ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
-    std::vector<uint64_t> lens(in->n, 0);
-    for (uint32_t s = 0; s < in->n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s];
-        ck->length_seconds[s] = (double)nb / (double)ba * samplesPerBlock / d->sample_rate;
-        ck->nchunks[s] = newlen ? (uint32_t)((nblocks[s] + ips - 1) / ips) : 0;
-        ck->max_chunks = std::max(ck->max_chunks, ck->nchunks[s]);
-        lens[s] = nblocks[s] * newlen;
-    }
-    const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
-    ck->lens.assign((size_t)ck->n * mc, 0);
-    ck->pos.assign((size_t)ck->n * mc, 0);
-    for (uint32_t s = 0; s < in->n; s++)
-        for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
-            const uint64_t done = std::min<uint64_t>((uint64_t)(k + 1) * ips, nblocks[s]), first = (uint64_t)k * ips;
-            ck->lens[(size_t)s * mc + k] = (uint32_t)((done - first) * newlen);
-            ck->pos[(size_t)s * mc + k] = ((double)(done * ba + 1)) / bytesPerSecond;  // (n + pos) / bytesPerSecond
-        }
-    aukit_audio *a = *out;
-    if ((rc = audio_prepare(ctx, &a, in->n, nd, 48000, dtype, lens.data()))) { delete ck; return rc; }
-    *out = a;
-    // one segment per block; its C source rows are consecutive entries of the row table
-    std::vector<Seg> segs;
-    std::vector<uint64_t> blkrows;
-    uint64_t out_elems = 0;
-    for (uint32_t s = 0; s < in->n; s++) {
-        for (uint64_t b = 0; b < nblocks[s]; b++) {
-            Seg g;
-            g.src_base = -1; g.w_lo = 1; g.w_hi = (int)spb_dec; g.n_out = newlen;
-            g.stream = (unsigned)(blkrows.size() / C);
-            g.out_off = a->row_off[s] + b * newlen;
-            g.out_stride = (unsigned)a->row_stride[s];
-            g.pad = 0;
-            for (int c = 0; c < C; c++) blkrows.push_back(row_off[(size_t)s * C + c] + b * spb_dec);
-            segs.push_back(g);
-        }
-        out_elems += lens[s] * nd;
-    }
-    if (!segs.empty() && newlen) {
-        if ((rc = upload_table(ctx, ctx->misc_buf, blkrows.data(), blkrows.size() * 8))) { delete ck; return rc; }
-        ResampleParams P;
-        memset(&P, 0, sizeof P);
-        P.src = reinterpret_cast<const unsigned char *>(ctx->tmp_buf.p);
-        P.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
-        P.channels = C;
-        P.mix_mono = (C == 2 && mono) ? 2 : 0;
-        P.out = a->dev;
-        size_t lds;
-        if ((rc = plan_tiles(ctx, segs, ratio, interp, C, P, &lds))) { delete ck; return rc; }
-        rc = launch_resample(ctx, SRC_AUDIO_F64, interp, EPI_STREAM_FLOOR, dtype, P, lds, in->total() + out_elems * dtype_size(dtype), nullptr);
-        if (rc) { delete ck; return rc; }
-    }
-    if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
-    return AUKIT_OK;
-}
+int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);  // msadpcm.hip
 
 // ================================================================= QOA
 __constant__ int c_qoa_dequant[16][8] = {
@@ -376,8 +116,9 @@ static int qoa_scan(const uint8_t *hdr, uint64_t nb, bool audio_mode, int *file_
     return AUKIT_OK;
 }
 
-int decode_qoa_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
-                     aukit_audio **out) {
+// round 2's aukit.qoa (host-side header walk on a copy of the batch, lane-per-job kernel): the fallback of qoa.hip
+int decode_qoa_audio_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
+                          aukit_audio **out) {
     // headers are parsed on the host (8 bytes per 5120-sample frame); the batch is read back once for that
     // (through the context's pinned staging buffer: a fresh 360 MB std::vector — zero-filled, then page-faulted in by a pageable copy — was
     // 80 of the 100 ms a 1024-stream call took)

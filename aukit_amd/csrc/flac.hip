@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "resample.h"
+#include "stream_tail.h"
 
 namespace aukit {
 
@@ -1746,6 +1747,22 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
         }
     }
     if (!jobs.empty()) {
+        {   // round 3: one launch from the decoded rows (k_iir_tail, stream_tail.hip) instead of the two passes through a scratch of doubles
+            std::vector<TailJob> tj(jobs.size());
+            for (size_t k = 0; k < jobs.size(); k++) {
+                TailJob &t = tj[k];
+                memset(&t, 0, sizeof t);
+                t.src_off = jobs[k].src_off; t.last_off = jobs[k].last_off; t.m1_off = jobs[k].m1_off; t.out_off = jobs[k].out_off;
+                t.n = jobs[k].blocksize; t.nout = jobs[k].nout;
+            }
+            int trc = AUKIT_OK;
+            if (iir_tail_try(ctx, TAIL_FLAC, D.wide ? TAIL_ROWS_F64 : TAIL_ROWS_I32, ctx->tmp_buf.p, std::ldexp(1.0, D.depth), tj, 1, D.rate, interp, dtype, a->dev,
+                             in->total() + nouts * dtype_size(dtype), "k_iir_tail<flac>", &trc)) {
+                if (trc) { delete ck; return trc; }
+                if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+                return AUKIT_OK;
+            }
+        }
         if ((rc = upload_table(ctx, ctx->seg_buf, jobs.data(), jobs.size() * sizeof(FsJob)))) { delete ck; return rc; }
         const uint64_t maxn = 1ull << 17;
         const int exact = exact_div_verified(ctx, ratio, maxn) ? 1 : 0;

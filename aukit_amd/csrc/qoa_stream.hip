@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64) void k_qoa_stream_iir(const QsJob *jobs, const 
 
 struct QFrame { uint64_t off; int samples; };
 
-int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
+// round 2's aukit.stream.qoa: the fallback of qoa.hip (frames of more than 8192 samples, sample rates below ≈ 300 Hz)
+int stream_qoa_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.qoa: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.qoa output must be AUKIT_F64 or AUKIT_F32");
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");

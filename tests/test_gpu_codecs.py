@@ -434,6 +434,27 @@ def test_stream_qoa(ctx, oracle, ch, mono, interp):
             assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-12, (i, c)
 
 
+@pytest.mark.parametrize("rate", [44100, 22050, 8000, 48000, 32000])
+@pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
+def test_stream_qoa_f32_tail(ctx, oracle, ch, mono, rate):
+    """F32 storage: stream.qoa's tail (interpolation, clamp, recursive low-pass, channel mean) runs in ONE launch from the int8 rows with the
+    interpolation in f32 (k_iir_tail_fast, stream_tail.hip).  Tolerance path: 1e-6 RMS of the [-128, 127] scale, and no single
+    sample off by more than 1e-4 of it; the chunk plan is the exact path's."""
+    B, N = _B(), _N()
+    streams = [oracle.gen_qoa(np.stack([pcm16(n, rate, 8, 4 * i + c) for c in range(ch)], 1).ravel(), ch, rate) for i, n in enumerate((rate * 2 + 1234, 5120 * 9, 777, 20))]
+    bt = B.Batch.upload(ctx, streams)
+    for interp in ("none", "linear", "cubic"):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F32)
+        assert ctx.last_kernel()[0].startswith("k_iir_tail"), ctx.last_kernel()
+        got = out.download()
+        for i, s in enumerate(streams):
+            ref = oracle.stream_qoa(s, mono, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            for c in range(ref.channels):
+                assert rms(got[i][c] / 128, ref.data[c] / 128) <= 1e-6, (interp, i, c)
+                assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 128e-4, (interp, i, c)
+
+
 def test_dfpwm_parallel_encoder_small_batches(ctx, oracle, monkeypatch):
     """Batches of a few long streams encode in parallel chunks (candidate start states from a 2048-sample warm-up of every
     (strength, previous bit) pair, true states chained through them): the bytes equal the serial encoder's and the oracle's for

@@ -131,3 +131,25 @@ def test_stream_flac(ctx, oracle, interp):
         assert np.allclose(ck.pos[i][:ref.nchunks], ref.chunk_pos, rtol=0, atol=1e-12)
         for c in range(ref.channels):
             assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-12, (i, c)
+
+
+@pytest.mark.parametrize("rate,bs", [(44100, 4096), (22050, 1152), (8000, 576), (48000, 4096)])
+def test_stream_flac_f32_tail(ctx, oracle, rate, bs):
+    """F32 storage: stream.flac's per-block resample + recursive low-pass + scaling in one launch from the int32 rows, f32 interpolation
+    (k_iir_tail_fast).  Tolerance path: 1e-6 RMS of the [-128, 127] scale."""
+    B, N = _B(), _N()
+    streams = []
+    for i, (n, ch) in enumerate(((rate * 2 + 500, 2), (bs * 3, 1), (700, 2), (1, 1))):
+        p = np.stack([pcm16(n, rate, 5, 2 * i + c) for c in range(ch)], 1).astype(np.int64)
+        streams.append(oracle.gen_flac(p.ravel(), ch, 16, rate, bs))
+    for s in streams:
+        bt = B.Batch.upload(ctx, [s])
+        for interp in ("none", "linear", "cubic"):
+            out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_FLAC), interp, dtype=N.F32)
+            assert ctx.last_kernel()[0].startswith("k_iir_tail"), ctx.last_kernel()
+            got = out.download()[0]
+            ref = oracle.stream_flac(s, oracle.INTERP[interp])
+            assert ck.nchunks[0] == ref.nchunks and list(ck.lens[0][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            for c in range(ref.channels):
+                assert rms(got[c] / 128, ref.data[c] / 128) <= 1e-6, (interp, c)
+                assert np.max(np.abs(got[c] - ref.data[c]), initial=0) <= 128e-4, (interp, c)
