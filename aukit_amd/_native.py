@@ -25,7 +25,8 @@ CODEC_PCM, CODEC_G711, CODEC_ADPCM, CODEC_ADPCM_WAV, CODEC_MSADPCM, CODEC_DFPWM,
 FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center": 5, "trim": 6, "delay": 7, "echo": 8, "reverb": 9,
       "lowpass": 10, "highpass": 11}
 MAX_CH = 8
-OPT_EXACT_MATH, OPT_STORE_X4 = 0, 1
+OPT_EXACT_MATH, OPT_STORE_X4, OPT_COLLECT_STATS = 0, 1, 2
+COUNTER_DFPWM_CHUNKS, COUNTER_DFPWM_CHUNKS_REDONE = 0, 1
 WAVE_NONE, WAVE_SINE, WAVE_TRIANGLE, WAVE_SAWTOOTH, WAVE_SQUARE = 0, 1, 2, 3, 4
 PACK_TRUNC, PACK_FLOOR, PACK_STRICT = 0, 1, 2
 STREAM_CHUNK, STREAM_NEED_INPUT, STREAM_END = 0, 1, 2
@@ -33,7 +34,7 @@ STREAM_CHUNK, STREAM_NEED_INPUT, STREAM_END = 0, 1, 2
 # every symbol include/aukit_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aukit_abi_version", "aukit_last_error", "aukit_ctx_create", "aukit_ctx_destroy", "aukit_ctx_set_stream", "aukit_ctx_get_stream",
-    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_option", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end", "aukit_timer_stats",
+    "aukit_ctx_sync", "aukit_ctx_set_dtype", "aukit_ctx_set_option", "aukit_ctx_get_counter", "aukit_ctx_set_sinc_window", "aukit_timer_begin", "aukit_timer_end", "aukit_timer_stats",
     "aukit_ctx_set_kernel_timing", "aukit_ctx_last_kernel",
     "aukit_batch_upload", "aukit_batch_wrap_device", "aukit_batch_info", "aukit_batch_offsets", "aukit_batch_device_ptr",
     "aukit_batch_download", "aukit_batch_free",

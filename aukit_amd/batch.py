@@ -92,6 +92,12 @@ class Context:
     def set_option(self, option, value):
         N.check(N.lib().aukit_ctx_set_option(self._h, int(option), int(value)))
 
+    def counter(self, which):
+        """a counter of the most recent call that produced it (set_option(OPT_COLLECT_STATS, 1) first): N.COUNTER_*"""
+        v = C.c_uint64()
+        N.check(N.lib().aukit_ctx_get_counter(self._h, int(which), C.byref(v)))
+        return v.value
+
     def set_sinc_window(self, w):
         N.check(N.lib().aukit_ctx_set_sinc_window(self._h, int(w)))
 

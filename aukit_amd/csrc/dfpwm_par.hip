@@ -589,11 +589,12 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
         if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
         if (sliced && (*rc = hook->after_slice(k, nsl, (u64)P.c_lo * bpc * W, (u64)P.c_hi * bpc * W))) return true;  // fed bytes [lo, hi) of every stream are final
     }
-    if (getenv("AUKIT_DFPWM_STATS")) {
+    if (getenv("AUKIT_DFPWM_STATS") || ctx->collect_stats) {
         unsigned h[2] = {0, 0};
         (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "[dfpwm] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone serially\n", n, nchunk, bpc, (unsigned long long)W, h[0], h[1]);
+        ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[1]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[0];
+        if (getenv("AUKIT_DFPWM_STATS")) fprintf(stderr, "[dfpwm] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone serially\n", n, nchunk, bpc, (unsigned long long)W, h[0], h[1]);
     }
     *rc = AUKIT_OK;
     return true;
@@ -1009,12 +1010,14 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
         hipLaunchKernelGGL(k_df_blockscan, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, P);
         hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
         AUKIT_HIP_CHECK(hipGetLastError());
-        if (getenv("AUKIT_DFPWM_STATS")) {
+        if (getenv("AUKIT_DFPWM_STATS") || ctx->collect_stats) {
             unsigned h[2] = {0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
             (void)hipMemcpyAsync(h, P.stats, 8, hipMemcpyDeviceToHost, ctx->stream);
             (void)hipMemcpyAsync(al, F.flags + (size_t)nchunk * G + 1, 24, hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
-            fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms); decoder waves: slowest %.2f ms, mean %.2f ms\n",
+            if (s0 == 0) { ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = 0; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = 0; }
+            ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] += h[1]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] += h[0];
+            if (getenv("AUKIT_DFPWM_STATS")) fprintf(stderr, "[dfpwm fused] %u streams x %u chunks of %u blocks of %llu fed bytes: %u of %u chunks redone by their encoder lane; encoder alone on its SIMD in %u of %d workgroups, slowest encoder %.2f ms (mean over encoders: waiting %.2f ms, verify + encode %.2f ms); decoder waves: slowest %.2f ms, mean %.2f ms\n",
                     ns, nchunk, bpc, (unsigned long long)W, h[0], h[1], al[0], std::max<int>(ctx->num_cus, (int)G), al[1] * 1e-5, al[2] * 16e-5 / G, al[3] * 16e-5 / G, al[4] * 1e-5, al[5] * 256e-5 / (6.0 * std::max<int>(ctx->num_cus, (int)G)));
         }
     }

@@ -38,80 +38,116 @@ __constant__ int c_qoa_deq[16][8] = {
     {1286, -1286, 4288, -4288, 7718, -7718, 12005, -12005}, {1536, -1536, 5120, -5120, 9216, -9216, 14336, -14336}};  // :1662-1679
 
 // ================================================================= the frame walk
-struct QoaFrameRec { unsigned long long pos; unsigned samples; unsigned call; };   // pos: byte offset of the frame header within the stream
-struct QoaWalkOut { unsigned char head[12]; unsigned nframes; unsigned raised; unsigned raised_call; unsigned ncalls; unsigned pad; };
-static_assert(sizeof(QoaWalkOut) == 32 && sizeof(QoaFrameRec) == 16, "walk records");
+// One lane per stream follows the reference's loops — mode 0: aukit.qoa's (:1727-1775); mode 1: stream.qoa's iterator calls (:3256-3308)
+// one after the other — statement for statement (cf. qoa_scan in codecs2.hip, the host version of round 2).  Two passes:
+//   count (FILL false): per stream the file header's 12 bytes, how many calls deliver a chunk, how many (frame, channel) decode jobs they
+//     hold, how many row elements they need, whether the walk raised;
+//   fill (FILL true): with the host's prefix sums of those, the decode jobs themselves (they stay on the device) and one record per call
+//     (row, stride, #table, samples) for the host's chunk plan.
+// A call is walked dry first (its row stride depends on its last frame), then again to emit.
+struct QoaWalkOut { unsigned char head[12]; unsigned ncalls, raised, big, pad; unsigned long long njobs, rows_total, L; };
+struct QoaFillIn { unsigned long long job_first, call_first, row_base, stride; };
+struct QoaCallRec { unsigned long long row0; unsigned stride, n, sample_pos, pad; };
+static_assert(sizeof(QoaWalkOut) == 56 && sizeof(QoaFillIn) == 32 && sizeof(QoaCallRec) == 24, "walk records");
 
-// One lane per stream.  mode 0: aukit.qoa's loop (:1727-1775); mode 1: stream.qoa's iterator calls (:3256-3308) one after the other.
-// FILL false: counts; true: writes the records at recs + first[s].  The two loops below are the reference's, statement for statement
-// (cf. qoa_scan in codecs2.hip, the host version of round 2).
+struct QoaCallWalk { unsigned long long end_pos, n, sample_pos; unsigned nframes; bool raised, big; };
+// one iterator call (mode 1) or the whole file (mode 0) from `pos`; emit(frame_pos, samples, sp) per accepted frame
+template <class Emit>
+static AUKIT_DEV QoaCallWalk qoa_walk_call(const unsigned char *h, unsigned long long nb, unsigned long long pos, int mode, int fc, unsigned fr, double file_samples, Emit emit) {
+    QoaCallWalk w{pos, 0, 0, 0, false, false};
+    auto header_ok = [&](const unsigned char *f, int &channels, int &samples, int &frame_size) {
+        channels = f[0];
+        const unsigned rate = (unsigned)f[1] << 16 | (unsigned)f[2] << 8 | f[3];
+        samples = f[4] << 8 | f[5]; frame_size = f[6] << 8 | f[7];
+        const int data_size = frame_size - 8 - 16 * channels;
+        const int num_slices = data_size >= 0 ? data_size / 8 : -((-data_size + 7) / 8);   // math_floor(data_size / 8)
+        return !(channels != fc || rate != fr || samples * channels > num_slices * 20);
+    };
+    double sample_pos = 0;
+    unsigned long long sp = 0;
+    for (;;) {
+        int channels, samples, frame_size;
+        unsigned long long fpos, need;
+        if (mode == 0) {
+            if (!(pos + 1 + 16ull * fc + 8 <= nb && sample_pos < file_samples)) break;
+            if (!header_ok(h + pos, channels, samples, frame_size)) break;
+            if ((double)frame_size > (double)nb - (double)(pos + 8)) break;   // frame_size > #data - pos + 1, pos after the header (Q18)
+            need = 8 + 16ull * channels + 8ull * (unsigned long long)((samples + 19) / 20) * channels;
+            if (pos + need > nb) { w.raised = true; break; }                  // "data string too short"
+            fpos = pos;
+            pos += need;
+        } else {
+            if (!(sample_pos < (double)fr)) break;
+            if (pos >= nb) break;                                              // read(8) → nil
+            if (pos + 8 > nb) { w.raised = true; break; }
+            fpos = pos;
+            const bool ok = header_ok(h + pos, channels, samples, frame_size);
+            pos += 8;
+            if (!ok) break;                                                    // :3270-3277 (the header is consumed)
+            need = 16ull * channels + 8ull * (unsigned long long)((samples + 19) / 20) * channels;
+            if (pos + need > nb) { w.raised = true; break; }                   // assert(read(8), "Invalid QOA data") / short unpack
+            pos += need;
+        }
+        emit(fpos, samples, sp);
+        w.nframes++;
+        if (samples > 8192) w.big = true;
+        const unsigned long long top = sp + (unsigned long long)((samples + 19) / 20) * 20;
+        w.n = top > w.n ? top : w.n;
+        sp += (unsigned long long)samples;
+        sample_pos += samples;
+    }
+    w.end_pos = pos;
+    w.sample_pos = sp;
+    return w;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_qoa_walk(const unsigned char *src, const unsigned long long *off, unsigned n, int mode, QoaWalkOut *wo,
-                                                const unsigned long long *first, QoaFrameRec *recs) {
+                                                const QoaFillIn *fin, QoaJob *jobs, QoaCallRec *calls) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     const unsigned char *h = src + off[s];
     const unsigned long long nb = off[s + 1] - off[s];
     QoaWalkOut o;
     for (int i = 0; i < 12; i++) o.head[i] = (unsigned long long)i < nb ? h[i] : 0;
-    o.nframes = 0; o.raised = 0; o.raised_call = 0; o.ncalls = 0; o.pad = 0;
-    QoaFrameRec *dst = FILL ? recs + first[s] : nullptr;
+    o.ncalls = 0; o.raised = 0; o.big = 0; o.pad = 0; o.njobs = 0; o.rows_total = 0; o.L = 0;
     if (nb >= 12 && h[0] == 'q' && h[1] == 'o' && h[2] == 'a' && h[3] == 'f') {
         const double file_samples = (double)((unsigned)h[4] << 24 | (unsigned)h[5] << 16 | (unsigned)h[6] << 8 | h[7]);
         const int fc = h[8];
         const unsigned fr = (unsigned)h[9] << 16 | (unsigned)h[10] << 8 | h[11];
-        unsigned long long pos = 8;
-        auto header_ok = [&](const unsigned char *f, int &channels, int &samples, int &frame_size) {
-            channels = f[0];
-            const unsigned rate = (unsigned)f[1] << 16 | (unsigned)f[2] << 8 | f[3];
-            samples = f[4] << 8 | f[5]; frame_size = f[6] << 8 | f[7];
-            const int data_size = frame_size - 8 - 16 * channels;
-            const int num_slices = data_size >= 0 ? data_size / 8 : -((-data_size + 7) / 8);   // math_floor(data_size / 8)
-            return !(channels != fc || rate != fr || samples * channels > num_slices * 20);
-        };
         if (fc >= 1 && fc <= AUKIT_MAX_CHANNELS) {
-            if (mode == 0) {
-                double sample_pos = 0;
-                for (;;) {
-                    if (!(pos + 1 + 16ull * fc + 8 <= nb && sample_pos < file_samples)) break;
-                    int channels, samples, frame_size;
-                    if (!header_ok(h + pos, channels, samples, frame_size)) break;
-                    if ((double)frame_size > (double)nb - (double)(pos + 8)) break;   // frame_size > #data - pos + 1, pos after the header (Q18)
-                    const unsigned long long need = 8 + 16ull * channels + 8ull * (unsigned long long)((samples + 19) / 20) * channels;
-                    if (pos + need > nb) { o.raised = 1; break; }                      // "data string too short"
-                    if (FILL) { dst[o.nframes].pos = pos; dst[o.nframes].samples = (unsigned)samples; dst[o.nframes].call = 0; }
-                    o.nframes++;
-                    pos += need;
-                    sample_pos += samples;
+            unsigned long long pos = 8, jat = 0, rat = 0;
+            if (FILL) { jat = fin[s].job_first; rat = fin[s].row_base; }
+            for (;;) {   // mode 1: one iterator call per turn
+                const QoaCallWalk w = qoa_walk_call(h, nb, pos, mode, fc, fr, file_samples, [](unsigned long long, int, unsigned long long) {});
+                if (w.big) o.big = 1;
+                if (w.raised) { o.raised = 1; break; }
+                if (mode == 1 && w.n == 0) break;                              // #chunk[1] == 0 → nil
+                const unsigned long long stride = mode == 0 ? (FILL ? fin[s].stride : 0) : ((w.n + 2 + 15) / 16) * 16;
+                if (FILL) {
+                    const unsigned nfr = w.nframes;
+                    unsigned k = 0;
+                    qoa_walk_call(h, nb, pos, mode, fc, fr, file_samples, [&](unsigned long long fpos, int samples, unsigned long long sp) {
+                        const bool lastf = ++k == nfr;
+                        for (int c = 0; c < fc; c++) {
+                            QoaJob j;
+                            j.frame_off = off[s] + fpos; j.out_off = rat + (unsigned long long)c * stride + sp;
+                            j.c = c; j.channels = fc; j.samples = samples;
+                            j.emit = lastf ? ((samples + 19) / 20) * 20 : samples;   // Q15: the ≤19-sample tail survives only after the last frame of a table
+                            jobs[jat++] = j;
+                        }
+                    });
+                    QoaCallRec cr;
+                    cr.row0 = rat; cr.stride = (unsigned)stride; cr.n = (unsigned)w.n; cr.sample_pos = (unsigned)w.sample_pos; cr.pad = 0;
+                    calls[fin[s].call_first + o.ncalls] = cr;
+                    rat += stride * (unsigned long long)fc;
                 }
-                o.ncalls = 1;
-            } else {
-                for (unsigned call = 0;; call++) {   // one iterator call
-                    double sample_pos = 0;
-                    unsigned long long nmax = 0, sp = 0;
-                    bool raised = false;
-                    while (sample_pos < (double)fr) {
-                        if (pos >= nb) break;                                          // read(8) → nil
-                        if (pos + 8 > nb) { raised = true; break; }
-                        int channels, samples, frame_size;
-                        const unsigned long long fpos = pos;
-                        const bool ok = header_ok(h + pos, channels, samples, frame_size);
-                        pos += 8;
-                        if (!ok) break;                                                // :3270-3277 (the header is consumed)
-                        const unsigned long long need = 16ull * channels + 8ull * (unsigned long long)((samples + 19) / 20) * channels;
-                        if (pos + need > nb) { raised = true; break; }                 // assert(read(8), "Invalid QOA data") / short unpack
-                        if (FILL) { dst[o.nframes].pos = fpos; dst[o.nframes].samples = (unsigned)samples; dst[o.nframes].call = call; }
-                        o.nframes++;
-                        pos += need;
-                        const unsigned long long top = sp + (unsigned long long)((samples + 19) / 20) * 20;
-                        nmax = top > nmax ? top : nmax;
-                        sp += (unsigned long long)samples;
-                        sample_pos += samples;
-                    }
-                    if (raised) { o.raised = 1; o.raised_call = call; break; }
-                    if (nmax == 0) break;                                              // #chunk[1] == 0 → nil
-                    o.ncalls = call + 1;
-                }
+                o.njobs += (unsigned long long)w.nframes * fc;
+                o.rows_total += stride * (unsigned long long)fc;
+                o.L = w.n;
+                o.ncalls++;
+                pos = w.end_pos;
+                if (mode == 0) break;
             }
         }
     }
@@ -243,23 +279,22 @@ struct QoaLaps {   // AUKIT_HOST_TIMING=1: host laps on stderr
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char *w) { if (on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[qoa host] %-14s %8.1f us\n", w, std::chrono::duration<double, std::micro>(t - t0).count()); t0 = t; } }
 };
-struct QoaStreamFrames { int channels; double rate, file_samples; bool raised; unsigned raised_call, ncalls; size_t first, count; };
+struct QoaStreamInfo { int channels; double rate, file_samples; bool raised, big; unsigned ncalls; uint64_t njobs, rows_total, L, job_first, call_first, row_base, stride; };
 
-// the device walk of every stream; validates the file headers like the reference (errors with its strings)
-static int qoa_walk(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector<QoaStreamFrames> &S, std::vector<QoaFrameRec> &recs) {
+// pass 1 of the device walk; validates the file headers like the reference (errors with its strings)
+static int qoa_walk_count(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector<QoaStreamInfo> &S) {
     const uint32_t n = in->n;
-    S.assign(n, QoaStreamFrames{});
-    recs.clear();
+    S.assign(n, QoaStreamInfo{});
     if (!n) return AUKIT_OK;
-    int rc = ctx->tmp_buf3.ensure((size_t)n * (sizeof(QoaWalkOut) + 8) + 64);
+    int rc = ctx->tmp_buf3.ensure((size_t)n * (sizeof(QoaWalkOut) + sizeof(QoaFillIn)) + 64);
     if (rc) return rc;
     QoaWalkOut *dwo = reinterpret_cast<QoaWalkOut *>(ctx->tmp_buf3.p);
-    unsigned long long *dfirst = reinterpret_cast<unsigned long long *>(dwo + n);
     const unsigned long long *doff = reinterpret_cast<const unsigned long long *>(in->d_off);
-    hipLaunchKernelGGL((k_qoa_walk<false>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), doff, n, mode, dwo, dfirst, static_cast<QoaFrameRec *>(nullptr));
+    hipLaunchKernelGGL((k_qoa_walk<false>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), doff, n, mode, dwo, static_cast<const QoaFillIn *>(nullptr),
+                       static_cast<QoaJob *>(nullptr), static_cast<QoaCallRec *>(nullptr));
     AUKIT_HIP_CHECK(hipGetLastError());
-    // (both read-backs go through the context's pinned staging buffer: a pageable destination of a megabyte makes the runtime pin it on the
-    // fly — 26 ms per call, measured, against 0.4 ms)
+    // (read-backs go through the context's pinned staging buffer: a pageable destination makes the runtime pin it on the fly — 26 ms per
+    // call for a megabyte, measured, against 0.4 ms)
     std::vector<QoaWalkOut> wo(n);
     {
         void *st = ctx_host_stage(ctx, (size_t)n * sizeof(QoaWalkOut));
@@ -267,8 +302,7 @@ static int qoa_walk(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector
         AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (st) memcpy(wo.data(), st, (size_t)n * sizeof(QoaWalkOut));
     }
-    std::vector<unsigned long long> first(n);
-    size_t tot = 0;
+    uint64_t jat = 0, cat = 0, rat = 0;
     for (uint32_t s = 0; s < n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
         const unsigned char *h = wo[s].head;
@@ -276,39 +310,52 @@ static int qoa_walk(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector
         if (nb < 8) return fail(AUKIT_E_LUA, mode == 0 ? "data string too short" : "Not a QOA file");
         if (memcmp(h, "qoaf", 4) != 0) return fail(AUKIT_E_ARG, "Not a QOA file");
         if (nb < 12) return fail(AUKIT_E_LUA, nb == 8 && mode == 1 ? "Not a QOA file" : "data string too short");
-        S[s].file_samples = (double)((uint32_t)h[4] << 24 | (uint32_t)h[5] << 16 | (uint32_t)h[6] << 8 | h[7]);
-        S[s].channels = h[8];
-        S[s].rate = (double)((uint32_t)h[9] << 16 | (uint32_t)h[10] << 8 | h[11]);
-        if (S[s].channels < 1 || S[s].channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", S[s].channels);
-        S[s].raised = wo[s].raised != 0; S[s].raised_call = wo[s].raised_call; S[s].ncalls = wo[s].ncalls;
-        S[s].first = tot; S[s].count = wo[s].nframes;
-        first[s] = tot;
-        tot += wo[s].nframes;
+        QoaStreamInfo &q = S[s];
+        q.file_samples = (double)((uint32_t)h[4] << 24 | (uint32_t)h[5] << 16 | (uint32_t)h[6] << 8 | h[7]);
+        q.channels = h[8];
+        q.rate = (double)((uint32_t)h[9] << 16 | (uint32_t)h[10] << 8 | h[11]);
+        if (q.channels < 1 || q.channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", q.channels);
+        q.raised = wo[s].raised != 0; q.big = wo[s].big != 0; q.ncalls = wo[s].ncalls;
+        q.njobs = wo[s].njobs; q.L = wo[s].L;
+        q.stride = mode == 0 ? round_up(std::max<uint64_t>(q.L, 1), 8) : 0;
+        q.rows_total = mode == 0 ? q.stride * (uint64_t)q.channels : wo[s].rows_total;
+        q.job_first = jat; q.call_first = cat; q.row_base = rat;
+        jat += q.njobs; cat += q.ncalls; rat += q.rows_total;
     }
-    recs.resize(tot);
-    if (!tot) return AUKIT_OK;
-    if ((rc = ctx->misc_buf.ensure(tot * sizeof(QoaFrameRec) + 64))) return rc;
-    { int hrc = h2d_table(ctx, dfirst, first.data(), (size_t)n * 8); if (hrc) return hrc; }
-    QoaFrameRec *drecs = reinterpret_cast<QoaFrameRec *>(ctx->misc_buf.p);
-    hipLaunchKernelGGL((k_qoa_walk<true>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), doff, n, mode, dwo, dfirst, drecs);
+    return AUKIT_OK;
+}
+
+// pass 2: the decode jobs into `djobs` (device), the call records to the host (stream mode: want_calls)
+static int qoa_walk_fill(aukit_ctx *ctx, const aukit_batch *in, int mode, const std::vector<QoaStreamInfo> &S, QoaJob *djobs, uint64_t ncalls, std::vector<QoaCallRec> *calls) {
+    const uint32_t n = in->n;
+    std::vector<QoaFillIn> fin(n);
+    for (uint32_t s = 0; s < n; s++) fin[s] = QoaFillIn{S[s].job_first, S[s].call_first, S[s].row_base, S[s].stride};
+    QoaFillIn *dfin = reinterpret_cast<QoaFillIn *>(reinterpret_cast<QoaWalkOut *>(ctx->tmp_buf3.p) + n);
+    { int hrc = h2d_table(ctx, dfin, fin.data(), (size_t)n * sizeof(QoaFillIn)); if (hrc) return hrc; }
+    int rc = ctx->misc_buf.ensure((size_t)std::max<uint64_t>(ncalls, 1) * sizeof(QoaCallRec) + 64);
+    if (rc) return rc;
+    QoaCallRec *dcalls = reinterpret_cast<QoaCallRec *>(ctx->misc_buf.p);
+    hipLaunchKernelGGL((k_qoa_walk<true>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), n, mode,
+                       static_cast<QoaWalkOut *>(nullptr), dfin, djobs, dcalls);
     AUKIT_HIP_CHECK(hipGetLastError());
-    {
-        void *st = ctx_host_stage(ctx, tot * sizeof(QoaFrameRec));
-        AUKIT_HIP_CHECK(hipMemcpyAsync(st ? st : recs.data(), drecs, tot * sizeof(QoaFrameRec), hipMemcpyDeviceToHost, ctx->stream));
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (st) memcpy(recs.data(), st, tot * sizeof(QoaFrameRec));
+    if (calls) {
+        calls->resize(ncalls);
+        if (ncalls) {
+            void *st = ctx_host_stage(ctx, ncalls * sizeof(QoaCallRec));
+            AUKIT_HIP_CHECK(hipMemcpyAsync(st ? st : calls->data(), dcalls, ncalls * sizeof(QoaCallRec), hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (st) memcpy(calls->data(), st, ncalls * sizeof(QoaCallRec));
+        }
     }
     return AUKIT_OK;
 }
 
 template <bool S8>
-static int qoa_decode_launch(aukit_ctx *ctx, const aukit_batch *in, const std::vector<QoaJob> &jobs, void *rows, uint64_t row_bytes) {
-    if (jobs.empty()) return AUKIT_OK;
-    int rc = upload_table(ctx, ctx->tmp_buf2, jobs.data(), jobs.size() * sizeof(QoaJob));
+static int qoa_decode_launch(aukit_ctx *ctx, const aukit_batch *in, const QoaJob *djobs, uint64_t njobs, void *rows, uint64_t row_bytes) {
+    if (!njobs) return AUKIT_OK;
+    int rc = ctx_begin_kernel(ctx);
     if (rc) return rc;
-    if ((rc = ctx_begin_kernel(ctx))) return rc;
-    hipLaunchKernelGGL((k_qoa_wave<S8>), dim3((unsigned)((jobs.size() + 63) / 64)), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const QoaJob *>(ctx->tmp_buf2.p),
-                       (unsigned long long)jobs.size(), rows);
+    hipLaunchKernelGGL((k_qoa_wave<S8>), dim3((unsigned)((njobs + 63) / 64)), dim3(64), 0, ctx->stream, in->data(), djobs, (unsigned long long)njobs, rows);
     AUKIT_HIP_CHECK(hipGetLastError());
     return ctx_end_kernel(ctx, "k_qoa_wave", in->total() + row_bytes);
 }
@@ -317,47 +364,28 @@ static int qoa_decode_launch(aukit_ctx *ctx, const aukit_batch *in, const std::v
 int decode_qoa_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample, int dtype, aukit_audio **out) {
     if (getenv("AUKIT_QOA_HOST")) return decode_qoa_audio_host(ctx, in, d, new_rate, interp, do_resample, dtype, out);
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
-    std::vector<QoaStreamFrames> S;
-    std::vector<QoaFrameRec> recs;
     QoaLaps laps;
-    int rc = qoa_walk(ctx, in, 0, S, recs);
+    std::vector<QoaStreamInfo> S;
+    int rc = qoa_walk_count(ctx, in, 0, S);
     if (rc) return rc;
-    laps.lap("walk");
+    laps.lap("walk 1");
     const int C = S[0].channels;
     const double rate = S[0].rate;
-    std::vector<QoaJob> jobs;
     std::vector<uint64_t> row_off, row_len;
-    uint64_t tot = 0;
+    uint64_t tot = 0, njobs = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         if (S[s].raised) return fail(AUKIT_E_LUA, "data string too short");
         if (S[s].channels != C || S[s].rate != rate) return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate");
-        const QoaFrameRec *fr = recs.data() + S[s].first;
-        uint64_t L = 0, sp = 0;
-        for (size_t k = 0; k < S[s].count; k++) {
-            if (fr[k].samples > 8192) return decode_qoa_audio_host(ctx, in, d, new_rate, interp, do_resample, dtype, out);   // weights could leave 24 bits
-            L = std::max<uint64_t>(L, sp + (uint64_t)((fr[k].samples + 19) / 20) * 20);
-            sp += fr[k].samples;
-        }
-        const uint64_t stride = round_up(std::max<uint64_t>(L, 1), 8);
-        sp = 0;
-        for (size_t k = 0; k < S[s].count; k++) {
-            const bool lastf = k + 1 == S[s].count;
-            for (int c = 0; c < C; c++) {
-                QoaJob j;
-                j.frame_off = in->off[s] + fr[k].pos; j.out_off = tot + (uint64_t)c * stride + sp;
-                j.c = c; j.channels = C; j.samples = (int)fr[k].samples;
-                j.emit = lastf ? (int)((fr[k].samples + 19) / 20) * 20 : (int)fr[k].samples;  // Q15: the ≤19-sample tail survives only after the last frame
-                jobs.push_back(j);
-            }
-            sp += fr[k].samples;
-        }
-        for (int c = 0; c < C; c++) { row_off.push_back(tot + (uint64_t)c * stride); row_len.push_back(L); }
-        tot += stride * C;
+        if (S[s].big) return decode_qoa_audio_host(ctx, in, d, new_rate, interp, do_resample, dtype, out);   // frames of more than 8192 samples: weights could leave 24 bits
+        for (int c = 0; c < C; c++) { row_off.push_back(S[s].row_base + (uint64_t)c * S[s].stride); row_len.push_back(S[s].L); }
+        tot += S[s].rows_total; njobs += S[s].njobs;
     }
-    laps.lap("jobs");
     if ((rc = ctx->tmp_buf.ensure((size_t)tot * 2 + 64))) return rc;
-    if ((rc = qoa_decode_launch<false>(ctx, in, jobs, ctx->tmp_buf.p, tot * 2))) return rc;
-    laps.lap("decode launch");
+    if ((rc = ctx->tmp_buf2.ensure((size_t)std::max<uint64_t>(njobs, 1) * sizeof(QoaJob) + 64))) return rc;
+    QoaJob *djobs = reinterpret_cast<QoaJob *>(ctx->tmp_buf2.p);
+    if ((rc = qoa_walk_fill(ctx, in, 0, S, djobs, in->n, nullptr))) return rc;
+    if ((rc = qoa_decode_launch<false>(ctx, in, djobs, njobs, ctx->tmp_buf.p, tot * 2))) return rc;
+    laps.lap("walk 2 + decode");
     struct AtExit { QoaLaps &l; ~AtExit() { l.lap("rows -> audio"); } } at_exit{laps};
     return audio_from_int_rows(ctx, SRC_I16, ctx->tmp_buf.p, row_off, row_len, in->n, C, rate, new_rate, interp, do_resample, dtype, 32767, 32768, out);
 }
@@ -368,121 +396,99 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d,
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.qoa: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.qoa output must be AUKIT_F64 or AUKIT_F32");
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
-    std::vector<QoaStreamFrames> S;
-    std::vector<QoaFrameRec> recs;
-    int rc = qoa_walk(ctx, in, 1, S, recs);
+    QoaLaps laps;
+    std::vector<QoaStreamInfo> S;
+    int rc = qoa_walk_count(ctx, in, 1, S);
     if (rc) return rc;
+    laps.lap("walk 1");
     const int C = S[0].channels;
     const double rate = S[0].rate;
     if (!(rate > 0)) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
     const double ratio = 48000 / rate;
+    uint64_t tot = 0, njobs = 0, ncalls = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         if (S[s].channels != C || S[s].rate != rate) return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate");
-        for (size_t k = 0; k < S[s].count; k++) if (recs[S[s].first + k].samples > 8192) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
+        if (S[s].big) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
+        tot += S[s].rows_total; njobs += S[s].njobs; ncalls += S[s].ncalls;
     }
+    std::vector<QoaCallRec> calls;
+    if ((rc = ctx->tmp_buf.ensure((size_t)tot + 64))) return rc;
+    if ((rc = ctx->tmp_buf2.ensure((size_t)std::max<uint64_t>(njobs, 1) * sizeof(QoaJob) + 64))) return rc;
+    QoaJob *djobs = reinterpret_cast<QoaJob *>(ctx->tmp_buf2.p);
+    if ((rc = qoa_walk_fill(ctx, in, 1, S, djobs, ncalls, &calls))) return rc;
+    laps.lap("walk 2");
     aukit_chunks *ck = new aukit_chunks();
     ck->n = in->n;
     ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
     std::vector<uint64_t> lens(in->n, 0);
-    std::vector<QoaJob> djobs;
-    struct Call { uint32_t stream; uint64_t row0, stride, n, nout; };  // row0: element offset of channel 0's table index 1; channel c at row0 + c * stride
-    std::vector<Call> calls;
-    std::vector<double> cpos;
-    uint64_t tot = 0;
+    std::vector<uint64_t> nouts(ncalls, 0);
     for (uint32_t s = 0; s < in->n; s++) {
         ck->length_seconds[s] = S[s].file_samples / rate;
-        const QoaFrameRec *fr = recs.data() + S[s].first;
-        double file_pos = 0;
-        size_t k = 0;
-        uint32_t nch = 0;
-        while (k < S[s].count) {
-            const unsigned call = fr[k].call;
-            size_t e = k;
-            while (e < S[s].count && fr[e].call == call) e++;
-            if (S[s].raised && call == S[s].raised_call) break;   // the call that raised delivers nothing
-            if (call >= S[s].ncalls) break;                          // (a call whose table stayed empty ends the stream)
-            uint64_t n = 0, sp = 0;
-            double sample_pos = 0;
-            for (size_t q = k; q < e; q++) { n = std::max<uint64_t>(n, sp + (uint64_t)((fr[q].samples + 19) / 20) * 20); sp += fr[q].samples; sample_pos += fr[q].samples; }
-            const uint64_t stride = round_up(n + 2, 16);
-            sp = 0;
-            for (size_t q = k; q < e; q++) {
-                const bool lastf = q + 1 == e;
-                for (int c = 0; c < C; c++) {
-                    QoaJob j;
-                    j.frame_off = in->off[s] + fr[q].pos; j.out_off = tot + (uint64_t)c * stride + sp;
-                    j.c = c; j.channels = C; j.samples = (int)fr[q].samples;
-                    j.emit = lastf ? (int)((fr[q].samples + 19) / 20) * 20 : (int)fr[q].samples;
-                    djobs.push_back(j);
-                }
-                sp += fr[q].samples;
-            }
-            const double newlen = (double)n * ratio;                                               // :3312
+        for (unsigned k = 0; k < S[s].ncalls; k++) {
+            const QoaCallRec &cr = calls[S[s].call_first + k];
+            const double newlen = (double)cr.n * ratio;                                            // :3312
             const uint64_t nout = newlen >= 1 ? (uint64_t)std::floor(newlen) : 0;
             if (nout > 0x7FFFFFF0ull) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream too long"); }
-            calls.push_back(Call{s, tot, stride, n, nout});
-            cpos.push_back(file_pos / rate);                                                       // :3332
-            file_pos += sample_pos;
+            nouts[S[s].call_first + k] = nout;
             lens[s] += nout;
-            tot += stride * C;
-            nch++;
-            k = e;
         }
         if (S[s].raised) ck->status[s] = AUKIT_E_LUA;
-        ck->nchunks[s] = nch;
-        ck->max_chunks = std::max(ck->max_chunks, nch);
+        ck->nchunks[s] = S[s].ncalls;
+        ck->max_chunks = std::max(ck->max_chunks, S[s].ncalls);
     }
     const uint32_t mc = std::max<uint32_t>(ck->max_chunks, 1);
     ck->lens.assign((size_t)ck->n * mc, 0);
     ck->pos.assign((size_t)ck->n * mc, 0);
-    {
-        std::vector<uint32_t> at(in->n, 0);
-        for (size_t k = 0; k < calls.size(); k++) {
-            const uint32_t s = calls[k].stream;
-            ck->lens[(size_t)s * mc + at[s]] = (uint32_t)calls[k].nout;
-            ck->pos[(size_t)s * mc + at[s]] = cpos[k];
-            at[s]++;
+    for (uint32_t s = 0; s < in->n; s++) {
+        double file_pos = 0;
+        for (unsigned k = 0; k < S[s].ncalls; k++) {
+            ck->lens[(size_t)s * mc + k] = (uint32_t)nouts[S[s].call_first + k];
+            ck->pos[(size_t)s * mc + k] = file_pos / rate;                                         // :3332
+            file_pos += (double)calls[S[s].call_first + k].sample_pos;
         }
     }
     const bool mix = mono && C > 1;
     aukit_audio *a = *out;
     if ((rc = audio_prepare(ctx, &a, in->n, mix ? 1 : C, 48000, dtype, lens.data()))) { delete ck; return rc; }
     *out = a;
-    if (!calls.empty()) {
-        if ((rc = ctx->tmp_buf.ensure((size_t)tot + 64))) { delete ck; return rc; }
-        if ((rc = qoa_decode_launch<true>(ctx, in, djobs, ctx->tmp_buf.p, tot))) { delete ck; return rc; }
+    laps.lap("plan");
+    if (ncalls) {
+        if ((rc = qoa_decode_launch<true>(ctx, in, djobs, njobs, ctx->tmp_buf.p, tot))) { delete ck; return rc; }
         std::vector<TailJob> jobs;
-        std::vector<uint64_t> outpos(in->n, 0);
-        std::vector<long long> prev(in->n, -1);
-        uint64_t nouts = 0;
-        for (size_t k = 0; k < calls.size(); k++) {
-            const Call &cl = calls[k];
-            for (int c = 0; c < (mix ? 1 : C); c++) {
-                TailJob j;
-                memset(&j, 0, sizeof j);
-                j.src_off = cl.row0 + (uint64_t)c * cl.stride;
-                j.last_off = ~0ull; j.m1_off = ~0ull;
-                if (prev[cl.stream] >= 0) {   // chunk[i] = {[-1] = last[i][1], [0] = last[i][2]}  :3255
-                    const Call &pc = calls[(size_t)prev[cl.stream]];
-                    j.last_off = pc.row0 + (uint64_t)c * pc.stride + pc.n - 1;
-                    j.m1_off = j.last_off - 1;
-                    j.last_cstride = (unsigned)pc.stride;
+        jobs.reserve((size_t)ncalls * (mix ? 1 : C));
+        uint64_t total_out = 0;
+        for (uint32_t s = 0; s < in->n; s++) {
+            uint64_t outpos = 0;
+            for (unsigned k = 0; k < S[s].ncalls; k++) {
+                const QoaCallRec &cl = calls[S[s].call_first + k];
+                const uint64_t nout = nouts[S[s].call_first + k];
+                for (int c = 0; c < (mix ? 1 : C); c++) {
+                    TailJob j;
+                    memset(&j, 0, sizeof j);
+                    j.src_off = cl.row0 + (uint64_t)c * cl.stride;
+                    j.last_off = ~0ull; j.m1_off = ~0ull;
+                    if (k > 0) {   // chunk[i] = {[-1] = last[i][1], [0] = last[i][2]}  :3255
+                        const QoaCallRec &pc = calls[S[s].call_first + k - 1];
+                        j.last_off = pc.row0 + (uint64_t)c * pc.stride + pc.n - 1;
+                        j.m1_off = j.last_off - 1;
+                        j.last_cstride = pc.stride;
+                    }
+                    j.src_cstride = cl.stride;
+                    j.out_off = a->row_off[s] + (mix ? 0 : (uint64_t)c * a->row_stride[s]) + outpos;
+                    j.n = (int)cl.n; j.nout = (int)nout;
+                    jobs.push_back(j);
+                    total_out += nout;
                 }
-                j.src_cstride = (unsigned)cl.stride;
-                j.out_off = a->row_off[cl.stream] + (mix ? 0 : (uint64_t)c * a->row_stride[cl.stream]) + outpos[cl.stream];
-                j.n = (int)cl.n; j.nout = (int)cl.nout;
-                jobs.push_back(j);
-                nouts += cl.nout;
+                outpos += nout;
             }
-            outpos[cl.stream] += cl.nout;
-            prev[cl.stream] = (long long)k;
         }
         int trc = AUKIT_OK;
-        if (!iir_tail_try(ctx, TAIL_QOA, TAIL_ROWS_I8, ctx->tmp_buf.p, 1.0, jobs, mix ? C : 1, rate, interp, dtype, a->dev, tot + nouts * dtype_size(dtype), "k_iir_tail<qoa>", &trc)) {
+        if (!iir_tail_try(ctx, TAIL_QOA, TAIL_ROWS_I8, ctx->tmp_buf.p, 1.0, jobs, mix ? C : 1, rate, interp, dtype, a->dev, tot + total_out * dtype_size(dtype), "k_iir_tail<qoa>", &trc)) {
             delete ck;
             return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);   // very low sample rates: the filter's memory outlasts a tile's warm-up
         }
         if (trc) { delete ck; return trc; }
+        laps.lap("decode + tail");
     }
     if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
     return AUKIT_OK;

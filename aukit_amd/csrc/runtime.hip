@@ -220,6 +220,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
         (void)hipStreamDestroy(c->aux_stream);
     }
     if (c->stream_full) { aukit_audio_free(c->stream_full); c->stream_full = nullptr; }
+    delete c->spcm_ck;
     if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }
@@ -260,7 +261,15 @@ int aukit_ctx_set_option(aukit_ctx *c, int option, int value) {
     if (!c) return fail(AUKIT_E_ARG, "ctx is null");
     if (option == AUKIT_OPT_EXACT_MATH) c->exact_math = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (option == AUKIT_OPT_STORE_X4) c->fast_store_x4 = value != 0;
+    else if (option == AUKIT_OPT_COLLECT_STATS) c->collect_stats = value != 0;
     else return fail(AUKIT_E_ARG, "unknown option %d", option);
+    return AUKIT_OK;
+}
+
+int aukit_ctx_get_counter(aukit_ctx *c, int counter, uint64_t *value) {
+    if (!c || !value) return fail(AUKIT_E_ARG, "null argument");
+    if (counter < 0 || counter >= 8) return fail(AUKIT_E_ARG, "unknown counter %d", counter);
+    *value = c->counters[counter];
     return AUKIT_OK;
 }
 int aukit_timer_begin(aukit_ctx *c) {

@@ -215,10 +215,12 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
             }
         }
         __syncthreads();
+        // thread ↔ E consecutive outputs: warm-up, recurrence, epilogue, and E consecutive elements stored straight from registers — a wave's
+        // 64 × E outputs are one contiguous run, so its two 16-byte stores per lane fill whole lines between them (no trip back through LDS)
         const int e0 = tid * E;
-        for (int c = 0; c < P.C; c++) {
-            float y[E];
-            if (e0 < cnt) {
+        if (e0 < cnt) {
+            float acc[E];
+            for (int c = 0; c < P.C; c++) {
                 const float *xs = xb + c * P.xbn;
                 const int start = wl + e0;
                 const int ws = min(P.W, start), begin = start - ws;
@@ -234,28 +236,23 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
                     const double xv = e0 + i < cnt ? (double)xs[skew(start + i)] : 0.0;
                     const double s = ls + P.lp_alpha * (xv - ls);   // :3324 / :3179
                     ls = s;
-                    y[i] = (float)s;
+                    if constexpr (KIND == TAIL_QOA) acc[i] = c == 0 ? (float)s : acc[i] + (float)s;   // n = n + s  :3327
+                    else { const float f = (float)s; acc[i] = __builtin_amdgcn_fmed3f(f * (f < 0 ? 128.0f : 127.0f), -128.0f, 127.0f); }   // :3181
                 }
             }
-            __syncthreads();
-            if (e0 < cnt) {
-#pragma unroll
-                for (int i = 0; i < E; i++) if (e0 + i < cnt) xb[c * P.xbn + skew(wl + e0 + i)] = y[i];
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < cnt; idx += 256) {
-            const unsigned long long o = (unsigned long long)o0 + (unsigned)idx;
             if constexpr (KIND == TAIL_QOA) {
-                if (P.C == 1) out[job.out_off + o] = (OUT_T)xb[skew(wl + idx)];
-                else {
-                    float acc = 0;
-                    for (int c = 0; c < P.C; c++) acc = acc + xb[c * P.xbn + skew(wl + idx)];
-                    out[job.out_off + o] = (OUT_T)(acc / (float)P.C);   // lines[1][i] = n / file_channels  :3329
+                if (P.C > 1) {
+#pragma unroll
+                    for (int i = 0; i < E; i++) acc[i] = acc[i] / (float)P.C;   // lines[1][i] = n / file_channels  :3329
                 }
+            }
+            OUT_T *const op = out + job.out_off + (unsigned long long)o0 + (unsigned)e0;
+            if (e0 + E <= cnt) {
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                for (int v = 0; v < E / 4; v++) { f4u w; w.x = acc[4 * v]; w.y = acc[4 * v + 1]; w.z = acc[4 * v + 2]; w.w = acc[4 * v + 3]; *reinterpret_cast<f4u *>(op + 4 * v) = w; }
             } else {
-                const float s = xb[skew(wl + idx)];
-                out[job.out_off + o] = (OUT_T)__builtin_amdgcn_fmed3f(s * (s < 0 ? 128.0f : 127.0f), -128.0f, 127.0f);   // :3181
+                for (int i = 0; i < E && e0 + i < cnt; i++) op[i] = acc[i];
             }
         }
     }

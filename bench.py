@@ -59,11 +59,38 @@ def _measured_traffic(kernel, args):
     return None
 
 
+def _fixture(name):
+    """an encoder-made input cached under bench_data/ (tools/make_bench_inputs.py wrote it with the oracle's generators — once, not at bench
+    time: the bench itself needs the checker only for the cpu_baseline leg)"""
+    path = os.path.join(ROOT, "bench_data", name)
+    if not os.path.exists(path):
+        raise SystemExit(f"bench.py: {path} is missing: run `python tools/make_bench_inputs.py` (encoder-made inputs are cached fixtures)")
+    with open(path, "rb") as fh:
+        return fh.read()
+
+
+def _tile_streams(torch, dev, blobs, streams):
+    """`streams` byte strings on the device: the distinct fixture streams, cycled.  Returns (flat uint8 tensor, offsets)."""
+    t = [torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) for b in blobs]
+    order = [i % len(t) for i in range(streams)]
+    x = torch.cat([t[i] for i in order]).contiguous()
+    offs = [0]
+    for i in order:
+        offs.append(offs[-1] + len(blobs[i]))
+    return x, offs
+
+
 class Workload:
-    """setup(torch, dev, ctx, args, rank) → self; step() runs one pass; out_samples = units per pass on this rank."""
+    """setup(torch, dev, ctx, args, rank) → self; step() runs one pass; out_samples = units per pass on this rank.
+    task_bytes(): END-TO-END algorithmic bytes of one step — the input read once + the final output written once (what the roofline
+    fraction of a multi-launch step is measured against; intermediates are the implementation's business)."""
     name = unit = desc = ""
+    distinct = None   # how many distinct streams the synthetic batch cycles through (None: every stream is its own)
 
     def cpu_baseline(self, args):
+        return None
+
+    def task_bytes(self):
         return None
 
 
@@ -85,6 +112,9 @@ class Pcm16Cubic(Workload):
 
     def out_samples(self):
         return int(self.out.layout()[0].sum())
+
+    def task_bytes(self):
+        return int(self.x.numel()) * 2 + self.out_samples() * (4 if self.dtype == 1 else 8)
 
     def cpu_baseline(self, args):
         import numpy as np
@@ -217,63 +247,138 @@ class ImaStream(Workload):
     name, unit = "ima_stream", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
-        import numpy as np
-        from oracle import oracle as O  # the oracle's IMA *encoder* only generates the synthetic input (the reference has none)
-        blocks = int(round(args.seconds * 22))  # 220 blocks of 512 B ≈ 10.1 s @22 050 Hz
-        n = blocks * 512
-        # the config-1 style signal through the AUKit-variant encoder; 8 distinct streams, repeated
-        kinds = []
-        for i in range(8):
-            rng = np.random.Generator(np.random.PCG64(0xA0C17 + 3000 + 8 * rank + i))
-            t = np.arange(1016 * blocks) / 22050.0
-            pcm = np.round((0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, len(t))) * 32767).astype(np.int16)
-            enc = O.gen_ima(pcm, 1, 512, 88)
-            assert len(enc) == n, (len(enc), n)
-            kinds.append(torch.frombuffer(bytearray(enc), dtype=torch.uint8))
-        self.x = torch.cat(kinds).to(dev).repeat((args.streams + 7) // 8)[: args.streams * n].contiguous()
-        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        blocks = 220  # 220 blocks of 512 B ≈ 10.1 s @22 050 Hz: the config-1 style signal through the AUKit-variant encoder
+        if abs(args.seconds - 10.0) > 1e-9:
+            raise SystemExit("ima_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
+        blobs = [_fixture(f"ima_22050_220x512_{i}.bin") for i in range(4)]
+        self.distinct = len(blobs)
+        self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
         self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
         self.out = B.AudioBatch(ctx)
         self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=N.I8, out=self.out)
         self.arith = "i32 decode + f32 resample with f64 / reference-order fallback under the floor (bit-exact)"
-        self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B -> stream.adpcm cubic, int8 out (config 3a)"
+        self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B ({self.distinct} distinct encoder-made streams, cycled) -> stream.adpcm cubic, int8 out (config 3a)"
         return self
 
     def out_samples(self):
         return int(self.out.layout()[0].sum())
+
+    def task_bytes(self):
+        return int(self.x.numel()) + self.out_samples()
+
+
+class MsadpcmStream(Workload):
+    """aukit.stream.msadpcm on encoder-made mono blocks of 1024 B @44.1 kHz (k_ms_wave): not a BASELINE config, a north-star codec."""
+    name, unit = "msadpcm_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        if abs(args.seconds - 10.0) > 1e-9:
+            raise SystemExit("msadpcm_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
+        blobs = [_fixture(f"msadpcm_44100_mono_216x1024_{i}.bin") for i in range(2)]
+        self.distinct = len(blobs)
+        self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=1024)
+        self.out = B.AudioBatch(ctx)
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=N.I8, out=self.out)
+        self.arith = "i32 recurrence (fp64 per lane beyond the int32-safe range) + f32 resample with f64 / reference-order fallback under the floor (bit-exact)"
+        self.desc = f"{args.streams}x MS-ADPCM 44.1kHz mono 216x1024B ({self.distinct} distinct encoder-made streams, cycled) -> stream.msadpcm {args.interp}, int8 out"
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+    def task_bytes(self):
+        return int(self.x.numel()) + self.out_samples()
+
+
+class QoaStream(Workload):
+    """aukit.stream.qoa on encoder-made stereo files @44.1 kHz: frame walk + k_qoa_wave (int8 rows) + k_iir_tail, f32 out."""
+    name, unit = "qoa_stream", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        if abs(args.seconds - 10.0) > 1e-9:
+            raise SystemExit("qoa_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
+        blobs = [_fixture(f"qoa_44100_stereo_10s_{i}.bin") for i in range(2)]
+        self.distinct = len(blobs)
+        self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_QOA, 2, 44100)
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=self.dtype, out=self.out)
+        self.arith = "i32 LMS decode + " + ("f32 interpolation, f64 recurrence" if args.dtype == "f32" else "f64 reference-order tail")
+        self.desc = (f"{args.streams}x QOA 44.1kHz stereo 10s ({self.distinct} distinct encoder-made files, cycled) -> stream.qoa {args.interp}, all iterator calls, "
+                     f"{args.dtype} store; unit = out-samples of both channels")
+        return self
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum()) * 2
+
+    def task_bytes(self):
+        return int(self.x.numel()) + self.out_samples() * (4 if self.dtype == 1 else 8)
 
 
 class DfpwmTranscode(Workload):
     name, unit = "dfpwm_transcode", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
-        n = int(round(args.seconds * 12000))  # 120 000 B = 10 s of 2-channel interleaved DFPWM @48 kHz
-        self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 4000 + rank)
-        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
+        # SURVEY 8d config 4: "produced by the build's DFPWM encoder" — the config-1 style signal, two channels, 48 kHz, through the product's own
+        # aukit.pcm → Audio:dfpwm on the device (sub-batches of 512 streams; every stream has its own noise).  The chunk-parallel decoder's
+        # warm-up / verify / redo step depends on what the bytes are, so the timed input is what the config names, not random bytes.
+        frames = int(round(args.seconds * 48000))
+        nb = frames * 2 // 8
+        self.x = torch.empty(args.streams * nb, dtype=torch.uint8, device=dev)
+        pcm_desc = B.make_desc(N.CODEC_PCM, 2, 48000, 16, "signed")
+        sub = 512
+        a, enc = B.AudioBatch(ctx), B.Batch(ctx, __import__("ctypes").c_void_p())
+        from aukit_amd import shard
+        for s0 in range(0, args.streams, sub):
+            k = min(sub, args.streams - s0)
+            pcm = _sine_noise_s16(torch, dev, k, frames * 2, 48000, 0xA0C17 + 4000 + 97 * rank + s0)   # interleaved frames: the sine is common, the noise per sample
+            bt = B.Batch.wrap(ctx, pcm.data_ptr(), [i * frames * 4 for i in range(k + 1)], keep=pcm)
+            B.decode(ctx, bt, pcm_desc, dtype=N.F32, out=a)
+            B.dfpwm_encode(ctx, a, True, out=enc)
+            ctx.sync()
+            n_e, tot_e = enc.info()
+            assert n_e == k and tot_e == k * nb, (n_e, tot_e, k, nb)
+            self.x[s0 * nb:(s0 + k) * nb].copy_(shard.device_view(enc.device_ptr(), tot_e, dev, keep=enc))
+            torch.cuda.synchronize()
+            del bt, pcm
+        a.free(); enc.free()
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * nb for i in range(args.streams + 1)], keep=self.x)
         self.outb = B.Batch(ctx, __import__("ctypes").c_void_p())
         self.step = lambda: B.dfpwm_transcode_mono(ctx, self.bt, 2, out=self.outb)
-        self.desc = f"{args.streams}x DFPWM 48kHz stereo {args.seconds:g}s -> aukit.dfpwm:mono():dfpwm() fused (config 4); unit = mono samples"
+        self.desc = (f"{args.streams}x DFPWM 48kHz stereo {args.seconds:g}s, made by the build's own encoder (aukit.pcm -> Audio:dfpwm on the device) from the config-1 "
+                     f"style signal -> aukit.dfpwm:mono():dfpwm() fused (config 4); unit = mono samples")
         return self
 
     def out_samples(self):
         return int(self.outb.info()[1]) * 8
+
+    def task_bytes(self):
+        return int(self.x.numel()) + int(self.outb.info()[1])
+
+    def extra(self, ctx, N):
+        """the chunk-parallel decoder's redo count on this input (one more, untimed, step with the counters on)"""
+        ctx.set_option(N.OPT_COLLECT_STATS, 1)
+        self.step()
+        ctx.sync()
+        ctx.set_option(N.OPT_COLLECT_STATS, 0)
+        return {"dfpwm_chunks": ctx.counter(N.COUNTER_DFPWM_CHUNKS), "dfpwm_chunks_redone": ctx.counter(N.COUNTER_DFPWM_CHUNKS_REDONE)}
 
 
 class FlacPipeline(Workload):
     name, unit = "flac_pipeline", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
-        import numpy as np
-        from oracle import oracle as O  # the oracle's FLAC *encoder* only generates the synthetic input (the reference has none)
-        n = int(round(args.seconds * SRC_RATE))
-        rng = np.random.Generator(np.random.PCG64(0xA0C17 + 5000 + rank))
-        t = np.arange(n) / SRC_RATE
-        chans = [np.round((0.5 * np.sin(2 * np.pi * f * t) + rng.uniform(-0.25, 0.25, n)) * 32767 * 0.9) for f in (440.0, 330.0)]
-        one = O.gen_flac(np.stack(chans, 1).astype(np.int32).ravel(), 2, 16, SRC_RATE, 4096)
+        if abs(args.seconds - 10.0) > 1e-9:
+            raise SystemExit("flac_pipeline: the cached fixture is 10 s long (tools/make_bench_inputs.py)")
+        one = _fixture("flac_44100_stereo_10s.bin")
+        self.distinct = 1  # copies of ONE stream back to back: a lane takes consecutive frames of a stream, so the divergence inside a wave is a real file's
         self.flac_bytes = len(one)
-        blob = torch.frombuffer(bytearray(one), dtype=torch.uint8).to(dev)
-        self.x = blob.repeat(args.streams)  # identical streams back to back (throughput does not depend on the content)
-        offs = [i * len(one) for i in range(args.streams + 1)]
+        self.x, offs = _tile_streams(torch, dev, [one], args.streams)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
         self.d = B.make_desc(N.CODEC_FLAC)
         self.a = B.AudioBatch(ctx)
@@ -287,12 +392,15 @@ class FlacPipeline(Workload):
             B.effect(ctx, self.a, "normalize", 0.8)
             B.mono(ctx, self.a, out=self.m)
         self.step = step
-        self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each) -> aukit.flac:resample(48000,'cubic') "
+        self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each, copies of one encoder-made stream) -> aukit.flac:resample(48000,'cubic') "
                      f"-> highpass(20) -> normalize(0.8) -> mono, {args.dtype} store (config 5); unit = mono out-samples")
         return self
 
     def out_samples(self):
         return int(self.m.layout()[0].sum())
+
+    def task_bytes(self):
+        return int(self.x.numel()) + self.out_samples() * (4 if self.dtype == 1 else 8)
 
 
 class SelftestNull(Workload):
@@ -309,7 +417,7 @@ class SelftestNull(Workload):
         return 1000
 
 
-WORKLOADS = {w.name: w for w in (SelftestNull, Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (SelftestNull, Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, MsadpcmStream, QoaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def _free_port():
@@ -418,7 +526,7 @@ def main(argv=None):
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args(argv)
     if args.streams is None:
-        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048}.get(args.workload, 4096)
+        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048, "qoa_stream": 1024, "msadpcm_stream": 1024}.get(args.workload, 4096)
     if args.exact_math is None:
         args.exact_math = 1 if args.workload == "pcm16_cubic" else 0
     selftest = args.workload == "selftest_null"
@@ -559,18 +667,36 @@ def main(argv=None):
             "dtype": arith,
             "data": "synthetic",
             "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds,
-                       "parallelism": f"shard{world}", "storage": args.dtype, "exact_math": args.exact_math},
+                       "parallelism": f"shard{world}", "storage": args.dtype, "exact_math": args.exact_math,
+                       "arithmetic": ("fp64 phase-weight table on exact rational positions (k_wave_f64): the reference's arithmetic TYPE, not its operation order — "
+                                      "within one f32 ulp of the reference-order kernel" if (headline and args.exact_math == 1) else arith)},
             "windows": {"ms_per_step": [round(w, 4) for w in windows], "median": statistics.median(windows), "min": min(windows), "max": max(windows),
                         "kernel_ms_median": statistics.median(kernel_windows), "note": "window 0 is the contractual K-step region `value` comes from"},
         }
         if not selftest:
+            # One launch per step: its algorithmic bytes.  Several launches per step: the TASK's bytes — the input read once + the final output
+            # written once (Workload.task_bytes) — over the whole step's kernel time; the per-launch sum (every intermediate counted on both
+            # sides) is reported next to it, never as the fraction.
+            task = wl.task_bytes() if launches > 1 else None
+            roof_bytes = task if task else alg_bytes
+            achieved = roof_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            tr = _measured_traffic(name, args) if launches == 1 else None
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                "traffic": _measured_traffic(name, args) if launches == 1 else None, "kernel": name, "kernel_ms": kernel_ms,
-                                "launches_per_step": launches, "algorithmic_bytes_per_launch": alg_bytes,
-                                "bytes_per_out_sample": alg_bytes / max(out_samples, 1),
-                                "frac_median_window": alg_bytes / (statistics.median(kernel_windows) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                "traffic": tr, "kernel": name, "kernel_ms": kernel_ms,
+                                "launches_per_step": launches, "algorithmic_bytes_per_launch": roof_bytes if launches == 1 else None,
+                                "algorithmic_bytes_per_step": roof_bytes,
+                                "bytes_per_out_sample": roof_bytes / max(out_samples, 1),
+                                "frac_median_window": roof_bytes / (statistics.median(kernel_windows) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if tr is not None:
+                line["roofline"]["traffic_source"] = "committed PMC pass of this command (profiles/traffic.json; FETCH_SIZE / WRITE_SIZE corrected as the guide prescribes), not collected in this run"
             if launches > 1:
-                line["roofline"]["note"] = "several launches per step: algorithmic bytes are summed over the launches, the time is the whole step"
+                line["roofline"]["launch_bytes_sum"] = alg_bytes
+                line["roofline"]["note"] = ("several launches per step: frac = (input bytes + final output bytes) / the step's kernel time; launch_bytes_sum adds every "
+                                            "launch's own input + output, intermediates included, and is not a roofline fraction of the task")
+            if wl.distinct:
+                line["config"]["distinct_streams"] = wl.distinct
+            if hasattr(wl, "extra"):
+                line["config"].update(wl.extra(ctx, N))
         if fast:
             fa = fast[2] / (fast[1] * 1e-3) / 1e9
             line["roofline_fast"] = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "kernel": fast[0],

@@ -134,9 +134,17 @@ typedef enum {
                                  from the reference.  1: fp64 arithmetic, rounded to f32 once when stored (aukit.lua computes in
                                  doubles, :261-266, :662-669): the fp64 phase-weight kernel where it applies (16-bit mono PCM),
                                  else the reference-order kernels.  2: always the reference-order fp64 kernels. */
-    AUKIT_OPT_STORE_X4 = 1    /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
+    AUKIT_OPT_STORE_X4 = 1,   /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
+    AUKIT_OPT_COLLECT_STATS = 2 /* 1: calls that have counters (aukit_ctx_get_counter) read them back — one more device→host sync per call.
+                                   0 (default): they do not. */
 } aukit_option;
 int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
+/* counters of the most recent call that produced them (AUKIT_OPT_COLLECT_STATS = 1) */
+typedef enum {
+    AUKIT_COUNTER_DFPWM_CHUNKS = 0,        /* chunks the parallel DFPWM decoder cut the batch into (aukit.dfpwm, stream.dfpwm, the transcode) */
+    AUKIT_COUNTER_DFPWM_CHUNKS_REDONE = 1  /* of those, the ones whose warmed-up start state differed from the true one and were decoded again */
+} aukit_counter;
+int aukit_ctx_get_counter(aukit_ctx *ctx, int counter, uint64_t *value);
 /* hipEvent pair on the ctx stream: begin(); ...launches...; end() → elapsed milliseconds */
 int aukit_timer_begin(aukit_ctx *ctx);
 int aukit_timer_end(aukit_ctx *ctx, float *ms);
