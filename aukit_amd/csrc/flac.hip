@@ -20,6 +20,7 @@
 // Rows are int32 when the bit depth is ≤ 24 and no value overflows (checked everywhere; a flagged batch is redone with
 // double rows and the Lua's own floating-point prediction, so even absurd values round the way the reference rounds them).  The division by 2^depth (:505) happens in the consumer.
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 #include "resample.h"
 #include "stream_tail.h"
@@ -1290,6 +1291,13 @@ struct FlacDecoded {
     int channels = 0, depth = 0;
     double rate = 0;
     bool wide = false;  // rows are doubles (already / 2^depth) instead of int32
+    // what the decoder left on the device (valid until the next call that uses the context's scratch tables): the frame records in stream
+    // order, each stream's first record, each (stream, channel) row's offset; and per stream its frame count
+    const struct FrameRec *d_frames = nullptr;
+    const u64 *d_fbase = nullptr, *d_rowoff = nullptr;
+    std::vector<uint64_t> fbase;
+    std::vector<unsigned> nframes;
+    uint64_t nfr = 0;
 };
 
 struct Carve {
@@ -1498,6 +1506,9 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
         AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (flags & FLAG_OVERFLOW) return 1;  // only the int32 instantiation raises it
         D.frames.assign(n, {});
+        D.d_frames = d_frames; D.d_fbase = d_fbase; D.d_rowoff = d_rowoff; D.fbase = fbase; D.nfr = nfr;
+        D.nframes.assign(n, 0);
+        for (uint32_t s = 0; s < n; s++) D.nframes[s] = chain[s].nframes;
         if (want_frames)
             for (uint32_t s = 0; s < n; s++) {
                 D.frames[s].reserve(chain[s].nframes);
@@ -1678,12 +1689,44 @@ __global__ __launch_bounds__(64) void k_flac_stream_iir(const FsJob *jobs, const
     for (int i = rounds * RN; i < job.nout; i++) o[i] = step(p[i]);
 }
 
+// the tail jobs of stream.flac (one per (frame, channel), in the order the reference walks them) from the frame records the decoder left on the
+// device: one lane per stream — `last = {src[#src-1], src[#src]}` is shared across channels and frames (Q14), so a stream's jobs chain
+__global__ __launch_bounds__(64) void k_flac_tail_jobs(const FrameRec *frames, const u64 *fbase, const unsigned *nframes, const u64 *rowoff, const u64 *a_meta, unsigned n, int C,
+                                                      double ratio, TailJob *jobs) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    const u64 *a_row_off = a_meta + n, *a_row_stride = a_meta + 2 * (size_t)n;
+    u64 op = 0, l1 = ~0ull, l2 = ~0ull;  // where last[1], last[2] live in the decoded rows (~0: the initial 0)
+    TailJob *dst = jobs + fbase[s] * (u64)C;
+    for (unsigned f = 0; f < nframes[s]; f++) {
+        const FrameRec fr = frames[fbase[s] + f];
+        const int nout = (int)floor((double)fr.bs * ratio);
+        for (int c = 0; c < C; c++) {
+            TailJob j;
+            j.src_off = rowoff[(size_t)s * C + c] + fr.sample_off;
+            j.last_off = l2; j.m1_off = l1;
+            j.out_off = a_row_off[s] + (u64)c * a_row_stride[s] + op;
+            j.src_cstride = j.last_cstride = j.out_cstride = 0;
+            j.n = fr.bs; j.nout = nout; j.pad = 0;
+            *dst++ = j;
+            // for a one-sample block src[#src-1] is src[0] = the old last[2]  (:3183)
+            if (fr.bs >= 2) { l1 = j.src_off + (u64)fr.bs - 2; l2 = l1 + 1; }
+            else if (fr.bs == 1) { l1 = l2; l2 = j.src_off; }
+        }
+        op += (u64)nout;
+    }
+}
+
 int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
     if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.flac: interpolation must be none, linear or cubic");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.flac output must be AUKIT_F64 or AUKIT_F32");
     FlacDecoded D;
+    static const bool TT = getenv("AUKIT_HOST_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) { if (TT) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[stream.flac host] %-12s %8.1f us\n", w, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
     int rc = flac_decode_rows(ctx, in, D, true);
     if (rc) return rc;
+    lap("decode rows");
     const int C = D.channels;
     const double ratio = 48000 / D.rate;                                      // :3154
     const double lp_alpha = 1 - std::exp(-(D.rate / 96000) * 2 * M_PI);       // :3155
@@ -1722,6 +1765,34 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     aukit_audio *a = *out;
     if ((rc = audio_prepare(ctx, &a, in->n, C, 48000, dtype, lens.data()))) { delete ck; return rc; }
     *out = a;
+    {   // round 3: jobs written on the device from the decoder's frame records, one launch from the decoded rows (k_iir_tail, stream_tail.hip)
+        uint64_t max_nout = 0, sum_nout = 0, njobs = 0;
+        for (uint32_t s = 0; s < in->n; s++)
+            for (auto &fr : D.frames[s]) {
+                const uint64_t no = (uint64_t)std::floor((double)fr.second * ratio);
+                max_nout = std::max(max_nout, no); sum_nout += no * C; njobs += C;
+            }
+        const int rk = D.wide ? TAIL_ROWS_F64 : TAIL_ROWS_I32;
+        const double fullv = std::ldexp(1.0, D.depth);
+        if (njobs && D.d_frames && iir_tail_served(ctx, TAIL_FLAC, rk, 1, D.rate, fullv, interp, dtype, max_nout)) {
+            if ((rc = ctx->misc_buf.ensure(njobs * sizeof(TailJob) + (size_t)in->n * 4 + 64))) { delete ck; return rc; }
+            TailJob *dj = reinterpret_cast<TailJob *>(ctx->misc_buf.p);
+            unsigned *dnf = reinterpret_cast<unsigned *>(dj + njobs);
+            if ((rc = h2d_table(ctx, dnf, D.nframes.data(), (size_t)in->n * 4))) { delete ck; return rc; }
+            hipLaunchKernelGGL(k_flac_tail_jobs, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, D.d_frames, D.d_fbase, dnf, D.d_rowoff, reinterpret_cast<const u64 *>(a->d_meta), in->n, C,
+                               ratio, dj);
+            if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_flac_tail_jobs launch failed"); }
+            lap("plan + jobs");
+            int trc = AUKIT_OK;
+            if (iir_tail_try_dev(ctx, TAIL_FLAC, rk, ctx->tmp_buf.p, fullv, dj, njobs, max_nout, sum_nout, 1, D.rate, interp, dtype, a->dev, in->total() + sum_nout * dtype_size(dtype),
+                                 "k_iir_tail<flac>", &trc)) {
+                if (trc) { delete ck; return trc; }
+                lap("tail launch");
+                if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+                return AUKIT_OK;
+            }
+        }
+    }
     std::vector<FsJob> jobs;
     uint64_t nouts = 0;
     for (uint32_t s = 0; s < in->n; s++) {
@@ -1747,22 +1818,6 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
         }
     }
     if (!jobs.empty()) {
-        {   // round 3: one launch from the decoded rows (k_iir_tail, stream_tail.hip) instead of the two passes through a scratch of doubles
-            std::vector<TailJob> tj(jobs.size());
-            for (size_t k = 0; k < jobs.size(); k++) {
-                TailJob &t = tj[k];
-                memset(&t, 0, sizeof t);
-                t.src_off = jobs[k].src_off; t.last_off = jobs[k].last_off; t.m1_off = jobs[k].m1_off; t.out_off = jobs[k].out_off;
-                t.n = jobs[k].blocksize; t.nout = jobs[k].nout;
-            }
-            int trc = AUKIT_OK;
-            if (iir_tail_try(ctx, TAIL_FLAC, D.wide ? TAIL_ROWS_F64 : TAIL_ROWS_I32, ctx->tmp_buf.p, std::ldexp(1.0, D.depth), tj, 1, D.rate, interp, dtype, a->dev,
-                             in->total() + nouts * dtype_size(dtype), "k_iir_tail<flac>", &trc)) {
-                if (trc) { delete ck; return trc; }
-                if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
-                return AUKIT_OK;
-            }
-        }
         if ((rc = upload_table(ctx, ctx->seg_buf, jobs.data(), jobs.size() * sizeof(FsJob)))) { delete ck; return rc; }
         const uint64_t maxn = 1ull << 17;
         const int exact = exact_div_verified(ctx, ratio, maxn) ? 1 : 0;

@@ -34,7 +34,7 @@ int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return AUKIT_OK;
     static const bool no_ring = getenv("AUKIT_NO_TABLE_RING") != nullptr;
     const size_t HALF = (size_t)16 << 20;
-    if (!no_ring && bytes <= HALF / 4) {
+    if (!no_ring && bytes <= HALF) {   // (a table that fills most of a half just turns the ring over sooner)
         if (!ctx->tab_ring) {
             if (hipHostMalloc(reinterpret_cast<void **>(&ctx->tab_ring), 2 * HALF, hipHostMallocDefault) != hipSuccess) { ctx->tab_ring = nullptr; (void)hipGetLastError(); }
             else if (hipEventCreateWithFlags(&ctx->tab_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->tab_ev[1], hipEventDisableTiming) != hipSuccess) {

@@ -27,5 +27,10 @@ enum { TAIL_ROWS_I8 = 0, TAIL_ROWS_I32 = 1, TAIL_ROWS_F64 = 2 };
 // rates whose filter memory is longer than a tile's warm-up): the caller keeps its two-pass path.
 bool iir_tail_try(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const std::vector<TailJob> &jobs, int mix_channels, double rate,
                   int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc);
+// the same with the jobs already on the device (written by a kernel: stream.flac's come from the frame records the decoder left there);
+// max_nout / sum_nout: the largest and the total output count of the jobs.  iir_tail_served() tells beforehand whether a shape is taken.
+bool iir_tail_served(aukit_ctx *ctx, int kind, int rows_kind, int mix_channels, double rate, double full, int interp, int dtype, uint64_t max_nout);
+bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const TailJob *d_jobs, size_t njobs, uint64_t max_nout, uint64_t sum_nout,
+                      int mix_channels, double rate, int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc);
 
 }  // namespace aukit

@@ -20,9 +20,8 @@ namespace aukit {
 
 struct TailParams {
     const TailJob *jobs;
-    const unsigned *tile_job;    // tile → job
-    const unsigned *job_tile0;   // job → its first tile
-    unsigned n_tiles;
+    unsigned tiles_per_job;      // tile t = (job t / tiles_per_job, tile t % tiles_per_job of it); tiles beyond a job's outputs are skipped
+    unsigned long long n_tiles;
     int W, cap, xbn, C;          // warm-up outputs; LDS doubles per channel for the table window / for the tile's samples; channels per job
     double ratio, rcp;
     int exact;
@@ -50,10 +49,11 @@ __global__ __launch_bounds__(256) void k_iir_tail(const TailParams P) {
     OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
     auto skew = [](int i) { return i + i / E; };
     auto pos = [&](unsigned o) { const double nn = (double)o; return (P.exact ? div_rcp(nn, P.ratio, P.rcp) : nn / P.ratio) + 1.0; };  // x = (i - 1) / ratio + 1
-    for (unsigned t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
-        const unsigned ji = P.tile_job[t];
+    for (unsigned long long t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
+        const unsigned long long ji = t / P.tiles_per_job;
         const TailJob job = P.jobs[ji];
-        const unsigned o0 = (t - P.job_tile0[ji]) * (unsigned)T;
+        const unsigned o0 = (unsigned)(t - ji * P.tiles_per_job) * (unsigned)T;
+        if (o0 >= (unsigned)job.nout) continue;   // (uniform: a short job's spare tiles)
         const int cnt = (int)min((unsigned)T, (unsigned)job.nout - o0);
         const int wl = (int)min((unsigned)P.W, o0);
         const unsigned of = o0 - (unsigned)wl;
@@ -163,10 +163,11 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
     auto rowf = [&](unsigned long long at) -> float { if constexpr (sizeof(R) == 4) return (float)((double)rows[at] * full_rcp); else return (float)rows[at]; };
     auto skew = [](int i) { return i + i / E; };
     auto qr = [&](unsigned o, unsigned &q, unsigned &rem) { q = __umulhi(o * P.fa, P.fmagic); rem = o * P.fa - q * P.fb; };
-    for (unsigned t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
-        const unsigned ji = P.tile_job[t];
+    for (unsigned long long t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
+        const unsigned long long ji = t / P.tiles_per_job;
         const TailJob job = P.jobs[ji];
-        const unsigned o0 = (t - P.job_tile0[ji]) * (unsigned)T;
+        const unsigned o0 = (unsigned)(t - ji * P.tiles_per_job) * (unsigned)T;
+        if (o0 >= (unsigned)job.nout) continue;   // (uniform: a short job's spare tiles)
         const int cnt = (int)min((unsigned)T, (unsigned)job.nout - o0);
         const int wl = (int)min((unsigned)P.W, o0);
         const unsigned of = o0 - (unsigned)wl;
@@ -277,102 +278,105 @@ static void tail_launch_out(int interp, int dtype, const TailParams &P, unsigned
     else tail_launch_interp<KIND, E, R, float>(interp, P, grid, lds, st);
 }
 
-bool iir_tail_try(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const std::vector<TailJob> &jobs, int mix_channels, double rate,
-                  int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc) {
-    *rc = AUKIT_OK;
-    if (jobs.empty()) return true;
-    if (interp < 0 || interp > 2 || (dtype != AUKIT_F64 && dtype != AUKIT_F32) || getenv("AUKIT_NO_IIR_TAIL")) return false;
-    if (kind == TAIL_QOA && rows_kind != TAIL_ROWS_I8) return false;
-    if (kind == TAIL_FLAC && (rows_kind == TAIL_ROWS_I8 || mix_channels > 1)) return false;
-    const int C = std::max(1, mix_channels);
-    const double ratio = 48000 / rate;
-    const double lp_alpha = 1 - std::exp(-(rate / 96000) * 2 * M_PI);   // :3251 / :3155
-    const double decay = (rate / 96000) * 2 * M_PI;                     // a = exp(-decay)
-    if (!(decay > 0) || !(ratio > 0)) return false;
+struct TailShape { bool ok = false, fast = false; int C = 1, E = 4, T = 1024, W = 0, cap = 0, xbn = 0, wf = 1; unsigned long long fa = 0, fb = 0; size_t lds = 0; double ratio = 1, lp_alpha = 0; };
+static TailShape tail_shape(aukit_ctx *ctx, int kind, int rows_kind, int mix_channels, double rate, double full, int interp, int dtype, uint64_t max_nout, uint64_t avg_nout) {
+    TailShape S;
+    if (interp < 0 || interp > 2 || (dtype != AUKIT_F64 && dtype != AUKIT_F32) || getenv("AUKIT_NO_IIR_TAIL")) return S;
+    if (kind == TAIL_QOA && rows_kind != TAIL_ROWS_I8) return S;
+    if (kind == TAIL_FLAC && (rows_kind == TAIL_ROWS_I8 || mix_channels > 1)) return S;
+    S.C = std::max(1, mix_channels);
+    S.ratio = 48000 / rate;
+    S.lp_alpha = 1 - std::exp(-(rate / 96000) * 2 * M_PI);   // :3251 / :3155
+    const double decay = (rate / 96000) * 2 * M_PI;          // a = exp(-decay)
+    if (!(decay > 0) || !(S.ratio > 0)) return S;
     // what the samples can reach: a state of magnitude M still shows as M a^W after W outputs, so the warm-up grows with log M — int8 rows 128,
     // int32 rows 2^31 / full (garbage frames decode to anything an int32 holds); rows of doubles (values beyond int32) have no bound: not served
-    if (rows_kind == TAIL_ROWS_F64) return false;
+    if (rows_kind == TAIL_ROWS_F64) return S;
     const double mag = rows_kind == TAIL_ROWS_I8 ? 128.0 : std::max(1.0, std::ldexp(1.0, 31) / full);
     const double wd = std::ceil((37.0 + std::log(mag)) / decay);
-    uint64_t max_nout = 0, sum_nout = 0;
-    for (const TailJob &j : jobs) { max_nout = std::max<uint64_t>(max_nout, (uint64_t)std::max(j.nout, 0)); sum_nout += (uint64_t)std::max(j.nout, 0); }
-    if (max_nout == 0) return true;
-    const int E = (sum_nout / jobs.size() >= 6144 && kind == TAIL_QOA) ? 8 : 4;   // long jobs (QOA calls): 2048-output tiles; FLAC blocks: 1024
-    const int T = 256 * E;
-    if (wd > (double)T) return false;
-    const int W = (int)wd;
-    const double capd = std::ceil((double)(T + W) / ratio) + 8;
-    if (capd > 32768) return false;
-    const int cap = ((int)capd + 3) & ~3;
-    const int xbn = ((T + W) + (T + W) / E + 2 + 3) & ~3;
+    S.E = (avg_nout >= 6144 && kind == TAIL_QOA) ? 8 : 4;   // long jobs (QOA calls): 2048-output tiles; FLAC blocks: 1024
+    S.T = 256 * S.E;
+    if (wd > (double)S.T) return S;
+    S.W = (int)wd;
+    const double capd = std::ceil((double)(S.T + S.W) / S.ratio) + 8;
+    if (capd > 32768) return S;
+    S.cap = ((int)capd + 3) & ~3;
+    S.xbn = ((S.T + S.W) + (S.T + S.W) / S.E + 2 + 3) & ~3;
     // F32 storage: the f32 interpolation (k_iir_tail_fast) — integer sample rates with at most 512 output phases
-    bool fast = dtype == AUKIT_F32 && !ctx->exact_math && !getenv("AUKIT_NO_TAIL_FAST") && rate == std::floor(rate) && rate <= 4e9 && rows_kind != TAIL_ROWS_F64;
-    unsigned long long fa = 0, fb = 0;
-    if (fast) {
+    S.fast = dtype == AUKIT_F32 && !ctx->exact_math && !getenv("AUKIT_NO_TAIL_FAST") && rate == std::floor(rate) && rate <= 4e9;
+    if (S.fast) {
         unsigned long long x = 48000, y = (unsigned long long)rate;
         while (y) { const unsigned long long tq = x % y; x = y; y = tq; }
-        fa = (unsigned long long)rate / x; fb = 48000 / x;   // x - 1 = (i - 1) / ratio = (i - 1) fa / fb
-        if (fb == 1) { fa *= 2; fb = 2; }
-        fast = fb <= 512 && ((double)max_nout * (double)fa + (double)fb) * (double)fb < 4294967296.0;
+        S.fa = (unsigned long long)rate / x; S.fb = 48000 / x;   // x - 1 = (i - 1) / ratio = (i - 1) fa / fb
+        if (S.fb == 1) { S.fa *= 2; S.fb = 2; }
+        S.fast = S.fb <= 512 && ((double)max_nout * (double)S.fa + (double)S.fb) * (double)S.fb < 4294967296.0;
     }
-    const int wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
-    const size_t lds = fast ? ((((size_t)fb * wf + 3) & ~(size_t)3) + (size_t)C * ((size_t)cap + (size_t)xbn)) * 4 : (size_t)C * ((size_t)cap + (size_t)xbn) * 8;
-    if (lds > 150 * 1024) return false;
-    std::vector<unsigned> tile_job, job_tile0(jobs.size());
-    for (size_t k = 0; k < jobs.size(); k++) {
-        job_tile0[k] = (unsigned)tile_job.size();
-        const unsigned nt = (unsigned)(((uint64_t)std::max(jobs[k].nout, 0) + T - 1) / T);
-        for (unsigned q = 0; q < nt; q++) tile_job.push_back((unsigned)k);
-    }
-    if (tile_job.empty()) return true;
-    if (tile_job.size() > 0x7FFFFFFFull) return false;
-    // one table: jobs | tile_job | job_tile0
-    std::vector<float> w;
-    if (fast) {
-        w.resize((size_t)fb * wf);
-        for (unsigned r = 0; r < fb; r++) {
-            const long double f = (long double)r / (long double)fb, f2 = f * f, f3 = f2 * f;
-            if (wf == 1) w[r] = (float)f;
+    S.wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
+    S.lds = S.fast ? ((((size_t)S.fb * S.wf + 3) & ~(size_t)3) + (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn)) * 4 : (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn) * 8;
+    if (S.lds > 150 * 1024) return S;
+    S.ok = true;
+    return S;
+}
+
+bool iir_tail_served(aukit_ctx *ctx, int kind, int rows_kind, int mix_channels, double rate, double full, int interp, int dtype, uint64_t max_nout) {
+    return tail_shape(ctx, kind, rows_kind, mix_channels, rate, full, interp, dtype, max_nout, max_nout).ok;
+}
+
+bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const TailJob *d_jobs, size_t njobs, uint64_t max_nout, uint64_t sum_nout,
+                      int mix_channels, double rate, int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc) {
+    *rc = AUKIT_OK;
+    if (!njobs || !max_nout) return true;
+    const TailShape S = tail_shape(ctx, kind, rows_kind, mix_channels, rate, full, interp, dtype, max_nout, sum_nout / njobs);
+    if (!S.ok) return false;
+    TailParams P{};
+    P.jobs = d_jobs;
+    P.tiles_per_job = (unsigned)((max_nout + S.T - 1) / S.T);
+    P.n_tiles = (unsigned long long)P.tiles_per_job * njobs;
+    P.W = S.W; P.cap = S.cap; P.xbn = S.xbn; P.C = S.C;
+    P.ratio = S.ratio; P.rcp = 1.0 / S.ratio;
+    P.exact = exact_div_verified(ctx, S.ratio, std::max<uint64_t>(max_nout + 2, 1ull << 17)) ? 1 : 0;
+    P.lp_alpha = S.lp_alpha; P.full = full;
+    P.rows = rows; P.out = out;
+    if (S.fast) {
+        std::vector<float> w((size_t)S.fb * S.wf);
+        for (unsigned r = 0; r < S.fb; r++) {
+            const long double f = (long double)r / (long double)S.fb, f2 = f * f, f3 = f2 * f;
+            if (S.wf == 1) w[r] = (float)f;
             else {
                 w[4 * r] = (float)(-0.5L * f3 + f2 - 0.5L * f); w[4 * r + 1] = (float)(1.5L * f3 - 2.5L * f2 + 1.0L);
                 w[4 * r + 2] = (float)(-1.5L * f3 + 2.0L * f2 + 0.5L * f); w[4 * r + 3] = (float)(0.5L * f3 - 0.5L * f2);
             }
         }
+        if ((*rc = upload_table(ctx, ctx->tile_buf, w.data(), w.size() * 4))) return true;
+        P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
+        P.fa = (unsigned)S.fa; P.fb = (unsigned)S.fb; P.fmagic = (unsigned)((4294967296ull + S.fb - 1) / S.fb);
+        P.dq256 = (unsigned)((256ull * S.fa) / S.fb); P.dr256 = (unsigned)((256ull * S.fa) % S.fb);
     }
-    const size_t jb = jobs.size() * sizeof(TailJob), tb = (tile_job.size() * 4 + 7) & ~(size_t)7, j0b = (job_tile0.size() * 4 + 15) & ~(size_t)15, wb = w.size() * 4;
-    std::vector<unsigned char> tab(jb + tb + j0b + wb);
-    memcpy(tab.data(), jobs.data(), jb);
-    memcpy(tab.data() + jb, tile_job.data(), tile_job.size() * 4);
-    memcpy(tab.data() + jb + tb, job_tile0.data(), job_tile0.size() * 4);
-    if (wb) memcpy(tab.data() + jb + tb + j0b, w.data(), wb);
-    if ((*rc = upload_table(ctx, ctx->seg_buf, tab.data(), tab.size()))) return true;
-    TailParams P{};
-    const unsigned char *d = reinterpret_cast<const unsigned char *>(ctx->seg_buf.p);
-    P.jobs = reinterpret_cast<const TailJob *>(d);
-    P.tile_job = reinterpret_cast<const unsigned *>(d + jb);
-    P.job_tile0 = reinterpret_cast<const unsigned *>(d + jb + tb);
-    P.n_tiles = (unsigned)tile_job.size();
-    P.W = W; P.cap = cap; P.xbn = xbn; P.C = C;
-    P.ratio = ratio; P.rcp = 1.0 / ratio;
-    P.exact = exact_div_verified(ctx, ratio, std::max<uint64_t>(max_nout + 2, 1ull << 17)) ? 1 : 0;
-    P.lp_alpha = lp_alpha; P.full = full;
-    P.rows = rows; P.out = out;
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / S.lds));
     const unsigned grid = (unsigned)std::min<uint64_t>(P.n_tiles, (uint64_t)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-    if (fast) {
-        P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb);
-        P.dq256 = (unsigned)((256ull * fa) / fb); P.dr256 = (unsigned)((256ull * fa) % fb);
-        P.wg = reinterpret_cast<const float *>(d + jb + tb + j0b);
-        if (kind == TAIL_QOA) { if (E == 8) tail_launch_fast<TAIL_QOA, 8, signed char>(interp, P, grid, lds, ctx->stream); else tail_launch_fast<TAIL_QOA, 4, signed char>(interp, P, grid, lds, ctx->stream); }
+    const size_t lds = S.lds;
+    if (S.fast) {
+        if (kind == TAIL_QOA) { if (S.E == 8) tail_launch_fast<TAIL_QOA, 8, signed char>(interp, P, grid, lds, ctx->stream); else tail_launch_fast<TAIL_QOA, 4, signed char>(interp, P, grid, lds, ctx->stream); }
         else tail_launch_fast<TAIL_FLAC, 4, int>(interp, P, grid, lds, ctx->stream);
-    } else
-    if (kind == TAIL_QOA) { if (E == 8) tail_launch_out<TAIL_QOA, 8, signed char>(interp, dtype, P, grid, lds, ctx->stream); else tail_launch_out<TAIL_QOA, 4, signed char>(interp, dtype, P, grid, lds, ctx->stream); }
-    else if (rows_kind == TAIL_ROWS_I32) tail_launch_out<TAIL_FLAC, 4, int>(interp, dtype, P, grid, lds, ctx->stream);
-    else tail_launch_out<TAIL_FLAC, 4, double>(interp, dtype, P, grid, lds, ctx->stream);
+    } else if (kind == TAIL_QOA) { if (S.E == 8) tail_launch_out<TAIL_QOA, 8, signed char>(interp, dtype, P, grid, lds, ctx->stream); else tail_launch_out<TAIL_QOA, 4, signed char>(interp, dtype, P, grid, lds, ctx->stream); }
+    else tail_launch_out<TAIL_FLAC, 4, int>(interp, dtype, P, grid, lds, ctx->stream);
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_iir_tail launch failed"); return true; }
     *rc = ctx_end_kernel(ctx, name, algorithmic_bytes);
     return true;
+}
+
+bool iir_tail_try(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const std::vector<TailJob> &jobs, int mix_channels, double rate,
+                  int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc) {
+    *rc = AUKIT_OK;
+    if (jobs.empty()) return true;
+    uint64_t max_nout = 0, sum_nout = 0;
+    for (const TailJob &j : jobs) { max_nout = std::max<uint64_t>(max_nout, (uint64_t)std::max(j.nout, 0)); sum_nout += (uint64_t)std::max(j.nout, 0); }
+    if (max_nout == 0) return true;
+    if (!tail_shape(ctx, kind, rows_kind, mix_channels, rate, full, interp, dtype, max_nout, sum_nout / jobs.size()).ok) return false;
+    if ((*rc = upload_table(ctx, ctx->seg_buf, jobs.data(), jobs.size() * sizeof(TailJob)))) return true;
+    return iir_tail_try_dev(ctx, kind, rows_kind, rows, full, reinterpret_cast<const TailJob *>(ctx->seg_buf.p), jobs.size(), max_nout, sum_nout, mix_channels, rate, interp, dtype, out,
+                            algorithmic_bytes, name, rc);
 }
 
 }  // namespace aukit
