@@ -561,11 +561,46 @@ class _StreamNS:
         _expect_src(1, data)
         return self._run(B.make_desc(N.CODEC_QOA), data, mono, N.F64)
 
-    def _container(self, data, kind, mono):
+    @staticmethod
+    def _strip_headers(fn, kind):
+        """`ignoreHeader` in reader-function mode (:2983-2989, :3053-3060, :3097-3101): every LATER piece that starts with the container's magic
+        has its header cut off with the reference's own patterns — including what they do to a header they do not fit (a WAV piece whose
+        `data` chunk does not follow `WAVE` within one byte makes string.sub raise; AIFF takes the SSND chunk's SIZE for its offset)."""
+        import re
+
+        def wrapped():
+            d = fn()
+            if d is None:
+                return None
+            d = bytes(d)
+            if kind == N.CONTAINER_WAV:
+                if re.match(rb"RIFF.{4}WAVE", d, re.S):
+                    m = re.match(rb"RIFF.{4}WAVE.?data.{4}", d, re.S)
+                    if not m:
+                        raise LuaError("bad argument #2 to 'sub' (number expected, got nil)")
+                    return d[m.end():]
+            elif kind == N.CONTAINER_AIFF:
+                if re.match(rb"FORM.{4}AIF[FC]", d, re.S):
+                    m = re.match(rb"FORM.{4}AIF[FC].*?SSND(.{4}).{4}", d, re.S)
+                    if not m:
+                        raise LuaError("bad argument #2 to 'unpack' (string expected, got nil)")
+                    return d[m.end() + int.from_bytes(m.group(1), "big"):]
+            else:
+                if re.match(rb".snd", d, re.S):
+                    if len(d) < 8:
+                        raise LuaError("data string too short")
+                    off = int.from_bytes(d[4:8], "big")
+                    return d[max(off - 1, 0):]
+            return d
+        return wrapped
+
+    def _container(self, data, kind, mono, ignoreHeader=None):
         fn = None
         if callable(data):  # "the first chunk MUST contain the ENTIRE header" (:2918): the header walk runs on it, the payload that follows it is the first piece
             fn, data = data, data()
             _expect(1, data, "string")
+            if ignoreHeader:
+                fn = self._strip_headers(fn, kind)
         c, p = _parse(data, kind, stream=True) if fn is None else _parse_first_piece(data, kind)
         d = _desc_copy(c)
         dtype = N.F64 if d.codec in (N.CODEC_PCM, N.CODEC_DFPWM) else N.I8  # what stream.pcm / .dfpwm vs .g711 / .adpcm / .msadpcm hand out
@@ -577,17 +612,17 @@ class _StreamNS:
 
     def wav(self, data, mono=None, ignoreHeader=None):  # :2927: header walk (library) + dispatch (:2992-2996)
         _expect_src(1, data)
-        return self._container(data, N.CONTAINER_WAV, mono)
+        return self._container(data, N.CONTAINER_WAV, mono, ignoreHeader)
 
     def aiff(self, data, mono=None, ignoreHeader=None):  # :3016
         _expect_src(1, data)
         _expect(2, mono, "boolean", "nil")
-        return self._container(data, N.CONTAINER_AIFF, mono)
+        return self._container(data, N.CONTAINER_AIFF, mono, ignoreHeader)
 
     def au(self, data, mono=None, ignoreHeader=None):  # :3086
         _expect_src(1, data)
         _expect(2, mono, "boolean", "nil")
-        return self._container(data, N.CONTAINER_AU, mono)
+        return self._container(data, N.CONTAINER_AU, mono, ignoreHeader)
 
 
 stream = _StreamNS()

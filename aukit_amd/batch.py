@@ -424,7 +424,9 @@ class StreamHandle:
 
     def next(self):
         """→ ("chunk", [per-channel float64 arrays], pos) | ("need_input", None, None) | ("end", None, None)"""
-        buf = np.zeros(self._cap * AUKIT_MAX_CH, dtype=np.float64)
+        if getattr(self, "_buf", None) is None:  # one buffer per handle (a fresh zero-filled 64 MB array per chunk was most of a chunk's cost)
+            self._buf = np.empty(self._cap * AUKIT_MAX_CH, dtype=np.float64)
+        buf = self._buf
         ln, ch, st, pos = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_double()
         N.check(N.lib().aukit_stream_next(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint32(self._cap), C.byref(ln), C.byref(ch), C.byref(pos), C.byref(st)))
         if st.value == N.STREAM_CHUNK:

@@ -20,8 +20,10 @@ struct aukit_stream {
     uint8_t *dbuf = nullptr;   // device: everything fed so far
     size_t dcap = 0, fed = 0;
     bool finished = false, dirty = true;
-    aukit_audio *out = nullptr;       // last decode of the prefix
+    aukit_audio *out = nullptr;       // last SUCCESSFUL decode of the prefix (its chunk table: ck)
+    aukit_audio *spare = nullptr;     // where the next decode goes: swapped in only when it succeeds, so a failed one cannot reshape `out` under `ck`
     aukit_chunks *ck = nullptr;
+    double last_seconds = 0;          // aukit_stream_length's last good answer
     uint32_t delivered = 0;
     uint64_t delivered_samples = 0;   // per channel
     uint64_t decoded_at = ~0ull;      // `fed` when the prefix was last decoded
@@ -56,10 +58,11 @@ static int redecode(aukit_stream *h) {
     int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
-    rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->out, &ck);
+    rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
     if (rc) { if (ck) aukit_chunks_free(ck); return rc; }
+    std::swap(h->out, h->spare);
     if (h->ck) aukit_chunks_free(h->ck);
     h->ck = ck;
     h->decoded_at = h->fed;
@@ -119,6 +122,7 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     if (h->delivered >= decided() && (h->dirty || h->decoded_at != h->fed || !h->ck)) {
         int rc = redecode(h);
         if (rc && h->finished) return rc;  // the string version's own error for these bytes
+        if (rc == AUKIT_E_NOMEM || rc == AUKIT_E_HIP) return rc;  // not a verdict on the bytes: the caller must hear about it
         if (rc) {  // a prefix the string version cannot take (it ends inside a header, a frame ...): nothing new is decided — more input, or finish, settles it
             h->dirty = false;
             h->decoded_at = h->fed;
@@ -162,8 +166,16 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
 // for codecs whose header carries it)
 int aukit_stream_length(aukit_stream *h, double *seconds) {
     if (!h || !seconds) return fail(AUKIT_E_ARG, "null argument");
-    if (!h->ck || h->dirty) { int rc = redecode(h); if (rc) return rc; }
-    *seconds = h->ck->length_seconds.empty() ? 0.0 : h->ck->length_seconds[0];
+    if (!h->ck || h->dirty) {
+        int rc = redecode(h);
+        // The mirrors ask right after the FIRST piece (aukit.lua's streamer functions return the length next to the iterator): a piece that ends
+        // inside a header, or an empty one, is not an error of the stream — answer with what is known (0 before anything decoded) and let
+        // aukit_stream_next / finish bring the real verdict.  Failures of the device are still failures.
+        if (rc == AUKIT_E_NOMEM || rc == AUKIT_E_HIP || (rc && h->finished)) return rc;
+        if (rc) { *seconds = h->last_seconds; return AUKIT_OK; }
+    }
+    h->last_seconds = h->ck->length_seconds.empty() ? 0.0 : h->ck->length_seconds[0];
+    *seconds = h->last_seconds;
     return AUKIT_OK;
 }
 
@@ -171,6 +183,7 @@ void aukit_stream_close(aukit_stream *h) {
     if (!h) return;
     if (h->ck) aukit_chunks_free(h->ck);
     if (h->out) aukit_audio_free(h->out);
+    if (h->spare) aukit_audio_free(h->spare);
     if (h->dbuf) (void)hipFree(h->dbuf);
     delete h;
 }

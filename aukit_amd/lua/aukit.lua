@@ -601,11 +601,29 @@ end
 function aukit.stream.mdfpwm(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "mdfpwm"}, data, mono, I8) end  -- :2507
 function aukit.stream.flac(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "flac"}, data, mono, F64) end     -- :3124
 function aukit.stream.qoa(data, mono) expect(1, data, "string", "function") return streamer(desc {codec = "qoa"}, data, mono, F64) end       -- :3202
-local function stream_container(data, kind, mono)
+-- `ignoreHeader` in reader-function mode (:2983-2989, :3053-3060, :3097-3101): a LATER piece that starts with the container's magic loses its
+-- header — cut with the reference's own patterns, so a header they do not fit fails the way it does there
+local function strip_headers(fn, kind)
+    return function()
+        local d = fn()
+        if not d then return nil end
+        if kind == 0 then
+            if d:match "^RIFF....WAVE" then return d:sub(d:match("^RIFF....WAVE.?data....()")) end
+        elseif kind == 1 then
+            if d:match "^FORM....AIF[FC]" then
+                local n, p = d:match("^FORM....AIF[FC].-SSND(....)....()")
+                return d:sub(p + ((">I"):unpack(n)))
+            end
+        elseif d:match "^.snd" then return d:sub(((">I"):unpack(d:sub(5, 8)))) end
+        return d
+    end
+end
+local function stream_container(data, kind, mono, ignoreHeader)
     expect(1, data, "string", "function")
     if type(data) == "function" then  -- "the first chunk MUST contain the ENTIRE header" (:2918): the walk runs on it, what follows the header is the first piece
         local fn, piece = data, data()
         expect(1, piece, "string")
+        if ignoreHeader then fn = strip_headers(fn, kind) end
         local c = ffi.new("aukit_container")
         check(C.aukit_parse_container(ffi.cast("const uint8_t*", piece), #piece, kind, 2, c))
         local dtype = (c.desc.codec == 0 or c.desc.codec == 5) and F64 or I8
@@ -619,8 +637,8 @@ local function stream_container(data, kind, mono)
     if c.length_seconds == c.length_seconds then length = c.length_seconds end  -- not NaN: the container factory computes its own (:2994-2996, :3064-3069, :3107-3113)
     return it, length
 end
-function aukit.stream.wav(data, mono, ignoreHeader) return stream_container(data, 0, mono) end    -- :2927
-function aukit.stream.aiff(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 1, mono) end  -- :3016
-function aukit.stream.au(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 2, mono) end    -- :3086
+function aukit.stream.wav(data, mono, ignoreHeader) return stream_container(data, 0, mono, ignoreHeader) end    -- :2927
+function aukit.stream.aiff(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 1, mono, ignoreHeader) end  -- :3016
+function aukit.stream.au(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 2, mono, ignoreHeader) end    -- :3086
 
 return aukit

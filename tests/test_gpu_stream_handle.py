@@ -173,3 +173,60 @@ def test_mirror_stream_with_reader_function(ctx, oracle):
             assert gp == wp and np.array_equal(gc[0], wc[0])
     finally:
         aukit.defaultInterpolation = "linear"
+
+
+def test_ignore_header_strips_later_headers_and_first_piece_quirks(ctx, oracle):
+    """(1) stream.wav / .au with a reader function and `ignoreHeader`: a later piece that starts with the container's magic loses its
+    header the way the reference's patterns cut it (aukit.lua:2983-2989, :3097-3101) instead of being decoded as samples; without the flag the
+    header bytes ARE samples.  (2) a first piece the string version cannot take yet (it ends inside a QOA header / is empty) does not make
+    the stream factory raise at open: aukit_stream_length answers with what is known."""
+    import struct
+    import aukit_amd.aukit as aukit
+    B, N = _mods()
+    pcm1, pcm2 = pcm16(30000, 44100, 9, 6).tobytes(), pcm16(20000, 44100, 9, 7).tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 1, 44100, 88200, 2, 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(pcm1)) + pcm1
+    wav1 = b"RIFF" + struct.pack("<I", len(body)) + body
+    # the reference's pattern only fits a header whose `data` chunk follows `WAVE` directly (`^RIFF....WAVE.?data....()`)
+    hdr2 = b"RIFF" + struct.pack("<I", len(pcm2) + 12) + b"WAVE" + b"data" + struct.pack("<I", len(pcm2))
+    want_it, _ = aukit.stream.pcm(pcm1 + pcm2, 16, "signed", 1, 44100)
+    want = np.concatenate([c[0] for c, _ in want_it])
+    src = iter([wav1, hdr2 + pcm2])
+    it, _ = aukit.stream.wav(lambda: next(src, None), None, True)
+    got = np.concatenate([c[0] for c, _ in it])
+    assert np.array_equal(got, want)
+    src = iter([wav1, hdr2 + pcm2])
+    it, _ = aukit.stream.wav(lambda: next(src, None), None, False)  # without the flag the 20 header bytes are ten samples
+    raw = np.concatenate([c[0] for c, _ in it])
+    assert len(raw) > len(want)
+    # a later header the pattern does not fit (fmt chunk in front of data): string.sub(d, nil) raises in the reference
+    src = iter([wav1, wav1])
+    it, _ = aukit.stream.wav(lambda: next(src, None), None, True)
+    with pytest.raises(aukit.LuaError):
+        list(it)
+    # .au: `str_sub(d, offset)` with the header's offset field
+    au_hdr = b".snd" + struct.pack(">IIIII", 24, len(pcm1), 3, 44100, 1)
+    be1, be2 = np.frombuffer(pcm1, "<i2").astype(">i2").tobytes(), np.frombuffer(pcm2, "<i2").astype(">i2").tobytes()
+    src = iter([au_hdr + be1, b".snd" + struct.pack(">IIIII", 25, len(pcm2), 3, 44100, 1) + be2])
+    it, _ = aukit.stream.au(lambda: next(src, None), None, True)
+    got = np.concatenate([c[0] for c, _ in it])
+    ref_it, _ = aukit.stream.au(au_hdr + be1)   # (the string version: one file)
+    ref1 = np.concatenate([c[0] for c, _ in ref_it])
+    assert len(got) > len(ref1) and np.array_equal(got[:30000], ref1[:30000])
+    # (2) first piece ends inside the QOA file header / is the bare magic: open must not raise
+    q = oracle.gen_qoa(pcm16(30000, 44100, 8, 3), 1, 44100)
+    for cut in (6, 10, 20):
+        src = iter([q[:cut], q[cut:]])
+        it, length = aukit.stream.qoa(lambda: next(src, None))
+        full_it, full_len = aukit.stream.qoa(q)
+        a, b = list(it), list(full_it)
+        assert len(a) == len(b)
+        for (gc, gp), (wc, wp) in zip(a, b):
+            assert gp == wp and np.array_equal(gc[0], wc[0])
+    h = B.StreamHandle(ctx, B.make_desc(N.CODEC_QOA), "linear", False, N.F64)
+    h.feed(q[:6])
+    assert h.length() == 0.0   # nothing decodable yet: no error, no length
+    h.feed(q[6:])
+    h.finish()
+    assert h.length() == 30000 / 44100
+    h.close()
