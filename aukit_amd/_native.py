@@ -40,7 +40,7 @@ EXPORTS = [
     "aukit_batch_download", "aukit_batch_free",
     "aukit_audio_upload", "aukit_audio_info", "aukit_audio_layout", "aukit_audio_device_ptr", "aukit_audio_download",
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
-    "aukit_parse_container", "aukit_decode", "aukit_decode_table", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
+    "aukit_parse_container", "aukit_decode", "aukit_decode_table", "aukit_decode_nibbles", "aukit_stream_decode_table", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
     "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_close",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",

@@ -292,7 +292,7 @@ def pcm(data, bitDepth=None, dataType=None, channels=None, sampleRate=None, inte
 
 
 def adpcm(data, channels=None, sampleRate=None, topFirst=None, interleaved=None, predictor=None, step_index=None):
-    _expect(1, data, "string")
+    _expect(1, data, "string", "table")  # :1184 — a table holds one nibble per entry (:1232-1238)
     channels = 1 if channels is None else channels
     sampleRate = 48000 if sampleRate is None else sampleRate
     pred = [predictor] if isinstance(predictor, (int, float)) else predictor
@@ -303,6 +303,11 @@ def adpcm(data, channels=None, sampleRate=None, topFirst=None, interleaved=None,
         raise LuaError("bad argument #7 (table too short)")
     d = B.make_desc(N.CODEC_ADPCM, channels, sampleRate, top_first=True if topFirst is None else topFirst,
                     interleaved=True if interleaved is None else interleaved, predictor=pred, step_index=idx)
+    if isinstance(data, (list, tuple)):
+        for v in data:
+            if not isinstance(v, (int, float)) or v != int(v) or not 0 <= v <= 15:
+                raise LuaError("attempt to perform arithmetic on a nil value (field '?')")  # ima_index_table[nibble]
+        return Audio(_wrap(B.decode_nibbles, context(), [[int(v) for v in data]], d), {}, {"bitDepth": 16, "dataType": "signed"})
     return Audio(_load(d, data), {}, {"bitDepth": 16, "dataType": "signed"})
 
 
@@ -500,6 +505,10 @@ class _StreamNS:
         ctx = context()
         bt = _wrap(B.Batch.upload, ctx, [data])
         out, ck = _wrap(B.stream_decode, ctx, bt, desc, _interp(defaultInterpolation, 0), bool(mono), dtype)
+        return _StreamNS._chunk_iter(out, ck, length_override, endless_empty)
+
+    @staticmethod
+    def _chunk_iter(out, ck, length_override=None, endless_empty=False):
         chans = out.download()[0]
         n = int(ck.nchunks[0])
         lens, poss, status = ck.lens[0][:n], ck.pos[0][:n], int(ck.status[0])
@@ -516,12 +525,17 @@ class _StreamNS:
         return it(), (float(ck.length_seconds[0]) if length_override is None else length_override)
 
     def pcm(self, data, bitDepth=None, dataType=None, channels=None, sampleRate=None, bigEndian=None, mono=None):
-        _expect_src(1, data)
+        if not isinstance(data, (list, tuple)):
+            _expect_src(1, data)
         bitDepth = 8 if bitDepth is None else bitDepth
         dataType = "signed" if dataType is None else dataType
         if dataType not in ("signed", "unsigned", "float"):
             raise LuaError("bad argument #3 (invalid data type)")
         d = B.make_desc(N.CODEC_PCM, 1 if channels is None else channels, 48000 if sampleRate is None else sampleRate, bitDepth, dataType, bool(bigEndian))
+        if isinstance(data, (list, tuple)):  # a table of numbers (:2255-2290): `read()` hands out data[pos], normalised like the string's samples
+            ctx = context()
+            out, ck = _wrap(B.stream_decode_table, ctx, [data], d, _interp(defaultInterpolation, 0), bool(mono), N.F64)
+            return self._chunk_iter(out, ck)
         return self._run(d, data, mono, N.F64)
 
     def dfpwm(self, data, sampleRate=None, channels=None, mono=None):

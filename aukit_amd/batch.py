@@ -285,6 +285,35 @@ def decode_table(ctx, tables, desc, out=None):
     return out
 
 
+def decode_nibbles(ctx, tables, desc, dtype=None, out=None):
+    """aukit.adpcm on TABLES of nibbles (aukit.lua:1183-1184, :1232-1238): `tables` = one sequence of integers 0..15 per stream"""
+    import numpy as np
+    out = out if out is not None else AudioBatch(ctx)
+    arrs = [np.ascontiguousarray(t, dtype=np.uint8).ravel() for t in tables]
+    offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        offs[1:] = np.cumsum([len(a) for a in arrs])
+    flat = np.concatenate(arrs) if arrs and int(offs[-1]) else np.zeros(1, dtype=np.uint8)
+    N.check(N.lib().aukit_decode_nibbles(ctx._h, flat.ctypes.data_as(C.POINTER(C.c_uint8)), offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(arrs)), C.byref(desc),
+                                         ctx.dtype if dtype is None else dtype, C.byref(out._h)))
+    return out
+
+
+def stream_decode_table(ctx, tables, desc, interp, mono=False, dtype=None, out=None):
+    """aukit.stream.pcm on TABLES of numbers (aukit.lua:2255-2290): every iterator call at once, like stream_decode"""
+    import numpy as np
+    out = out if out is not None else AudioBatch(ctx)
+    arrs = [np.ascontiguousarray(t, dtype=np.float64).ravel() for t in tables]
+    offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        offs[1:] = np.cumsum([len(a) for a in arrs])
+    flat = np.concatenate(arrs) if arrs and int(offs[-1]) else np.zeros(1)
+    ch = C.c_void_p()
+    N.check(N.lib().aukit_stream_decode_table(ctx._h, flat.ctypes.data_as(C.POINTER(C.c_double)), offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(arrs)), C.byref(desc),
+                                              _interp(interp), int(bool(mono)), ctx.dtype if dtype is None else dtype, C.byref(out._h), C.byref(ch)))
+    return out, Chunks(ch)
+
+
 def decode_resample(ctx, batch, desc, new_rate, interp, dtype=None, out=None):
     out = out if out is not None else AudioBatch(ctx)
     N.check(N.lib().aukit_decode_resample(ctx._h, batch._h, C.byref(desc), C.c_double(new_rate), _interp(interp),

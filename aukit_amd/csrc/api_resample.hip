@@ -326,7 +326,7 @@ static int build_chunk_plan(double sample_rate, int interp, ChunkPlan &cp) {
 }
 
 static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
-                      aukit_chunks **chunks_out) {
+                      aukit_chunks **chunks_out, bool table = false) {
     int rc;
     if ((rc = check_pcm_desc(d))) return rc;
     if (interp == AUKIT_INTERP_SINC) return fail(AUKIT_E_UNSUPPORTED, "stream.pcm with sinc interpolation reads its lazy table out of order (not reproduced on the GPU)");
@@ -336,7 +336,7 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     const int C = d->channels;
     if (C == 1) mono = 0;  // :2243
     const int nd = mono ? 1 : C;
-    const int bd = d->bit_depth / 8;
+    const int bd = table ? 8 : d->bit_depth / 8;   // a table entry is one number (`len = #data / channels`, :2245)
     static const int istart[4] = {1, 1, 0, 0}, iend[4] = {1, 2, 3, 0};  // :283-284
     const bool is_float = d->data_type == AUKIT_FLOAT;
     // the plan depends on the batch's layout and the descriptor alone: the same batch coming back (austream's loop, bench.py's steps) reuses it
@@ -344,7 +344,7 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     unsigned long long oh = 1469598103934665603ull;   // FNV-1a over the stream offsets (a freed batch's address can come back with another layout)
     for (uint64_t o : in->off) { oh ^= o; oh *= 1099511628211ull; }
     snprintf(keyb, sizeof keyb, "%p/%llu/%u/%llx/%d/%d/%d/%d/%.17g/%d/%d/%d", (const void *)in, (unsigned long long)in->version, in->n, oh,
-             d->bit_depth, d->data_type, d->big_endian, C, d->sample_rate, interp, mono, nd);
+             d->bit_depth + (table ? 1000 : 0), d->data_type, d->big_endian, C, d->sample_rate, interp, mono, nd);
     std::vector<Seg> segs;
     std::vector<uint64_t> lens(in->n, 0);
     uint64_t in_bytes = 0, out_elems = 0;
@@ -430,10 +430,19 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     memset(&P, 0, sizeof P);
     fill_source(P, in, d);
     P.premix_mono = mono ? 1 : 0;
+    P.table = table ? 1 : 0;
     P.lp_alpha = 1 - std::exp(-(d->sample_rate / 96000) * 2 * M_PI);  // :2365
     P.out = a->dev;
-    int src = pick_pcm_source(in, d, false, mono != 0);
+    int src = table ? SRC_PCM_GENERIC : pick_pcm_source(in, d, false, mono != 0);
     bool done = false;
+    if (table) {   // the numbers of a table are not bytes: only the generic staging reads them (reference order, fp64)
+        size_t lds;
+        if ((rc = plan_tiles(ctx, segs, cp_ratio, interp, nd, P, &lds))) { delete ck; return rc; }
+        rc = launch_resample(ctx, src, interp, EPI_STREAM_PCM, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
+        if (rc) { delete ck; return rc; }
+        done = true;
+    }
+    if (!done)
     if (dtype == AUKIT_F32 && src == SRC_PCM_S16LE_MONO && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // f32 tolerance path
         int frc = AUKIT_OK;
         done = fast_try(ctx, src, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, 1, P.lp_alpha);
@@ -831,6 +840,27 @@ int aukit_resample(aukit_ctx *ctx, const aukit_audio *in, double new_rate, int i
     if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) return rc;
     return launch_resample(ctx, in->dtype == AUKIT_F64 ? SRC_AUDIO_F64 : SRC_AUDIO_F32, interp, EPI_AUDIO, in->dtype, P, lds,
                            (in_elems + out_elems) * dtype_size(in->dtype), nullptr);
+}
+
+// aukit.stream.pcm(data, ...) with `data` a TABLE of numbers (aukit.lua:2255-2290): `n` tables as one host array of doubles + element offsets
+int aukit_stream_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *desc, int interp, int mono, int dtype,
+                              aukit_audio **out, aukit_chunks **chunks) {
+    if (!ctx || !desc || !out || (n && (!offsets || (offsets[n] && !values)))) return fail(AUKIT_E_ARG, "null argument");
+    if (desc->codec != AUKIT_CODEC_PCM) return fail(AUKIT_E_UNSUPPORTED, "table input: aukit.stream.pcm only");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> boff((size_t)n + 1);
+    for (uint32_t s = 0; s <= n; s++) {
+        if (s && offsets[s] < offsets[s - 1]) return fail(AUKIT_E_ARG, "offsets must not decrease");
+        boff[s] = (offsets[s] - offsets[0]) * 8;
+    }
+    aukit_batch *b = nullptr;
+    static const double none = 0;
+    int rc = aukit_batch_upload(ctx, &b, reinterpret_cast<const uint8_t *>(n && offsets[n] ? values + offsets[0] : &none), boff.data(), n);
+    if (rc) return rc;
+    rc = stream_pcm(ctx, b, desc, interp, mono, dtype, out, chunks, true);
+    if (!rc) rc = aukit_ctx_sync(ctx);   // the uploaded copy goes away with this call
+    aukit_batch_free(b);
+    return rc;
 }
 
 int aukit_stream_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int interp, int mono, int dtype,

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
 }
 
 static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, double new_rate, int interp, bool do_resample,
-                            int dtype, aukit_audio **out) {
+                            int dtype, aukit_audio **out, const uint64_t *nibble_counts = nullptr) {
     const int C = d->channels;
     const bool wav = d->codec == AUKIT_CODEC_ADPCM_WAV;
     if (C < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
@@ -721,7 +721,7 @@ static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_c
                 if (rem < 3) return fail(AUKIT_E_LUA, "data string too short");
                 L += rem > 4 ? (rem - 4) * 2 : 0;
             }
-        } else L = nb * 2 / (uint64_t)C;  // :1231
+        } else L = nibble_counts ? nibble_counts[s] / (uint64_t)C : nb * 2 / (uint64_t)C;  // :1231 (a table of nibbles: `len = #data / channels`, :1237)
         const uint64_t stride = round_up(std::max<uint64_t>(L, 1), 8);
         for (int c = 0; c < C; c++) {
             ImaRowJob &j = jobs[(size_t)s * C + c];
@@ -1039,6 +1039,37 @@ int stream_block_codec(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
 using namespace aukit;
 
 extern "C" {
+
+// aukit.adpcm(data, ...) with `data` a TABLE of nibbles (aukit.lua:1183-1184, :1232-1238: `read()` hands out data[pos], len = #data / channels)
+int aukit_decode_nibbles(aukit_ctx *ctx, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out) {
+    if (!ctx || !d || !out || (n && (!offsets || (offsets[n] && !nibbles)))) return fail(AUKIT_E_ARG, "null argument");
+    if (d->codec != AUKIT_CODEC_ADPCM) return fail(AUKIT_E_UNSUPPORTED, "table of nibbles: aukit.adpcm only");
+    if (d->channels < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> boff((size_t)n + 1, 0), counts(n, 0);
+    std::vector<uint8_t> packed;
+    for (uint32_t s = 0; s < n; s++) {
+        if (offsets[s + 1] < offsets[s]) return fail(AUKIT_E_ARG, "offsets must not decrease");
+        const uint64_t cnt = offsets[s + 1] - offsets[s];
+        counts[s] = cnt;   // `for i = 1, #data / channels`: whole rounds of `channels` nibbles (ima_decode_audio divides)
+        for (uint64_t i = 0; i < cnt; i += 2) {
+            const unsigned hi = nibbles[offsets[s] + i], lo = i + 1 < cnt ? nibbles[offsets[s] + i + 1] : 0;
+            if (hi > 15 || lo > 15) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");  // ima_index_table[nibble]
+            packed.push_back((uint8_t)(hi << 4 | lo));
+        }
+        boff[s + 1] = packed.size();
+    }
+    aukit_codec_desc dd = *d;
+    dd.top_first = 1;   // the packing above
+    aukit_batch *b = nullptr;
+    static const uint8_t none = 0;
+    int rc = aukit_batch_upload(ctx, &b, packed.empty() ? &none : packed.data(), boff.data(), n);
+    if (rc) return rc;
+    rc = ima_decode_audio(ctx, b, &dd, 0, 0, false, dtype, out, counts.data());
+    if (!rc) rc = aukit_ctx_sync(ctx);
+    aukit_batch_free(b);
+    return rc;
+}
 
 int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, aukit_batch **out) {
     if (!ctx || !in || !out) return fail(AUKIT_E_ARG, "null argument");

@@ -66,6 +66,8 @@ struct ResampleParams {
     int pos_mul;       // x = ((i-1) * pos_mul) / ratio + 1 (stream.dfpwm steps i by `channels`); 0 means 1
     int out_channels;  // EPI_STREAM_DFPWM: rows written per output
     int nt_store;      // fast kernels: non-temporal output stores (tuning knob AUKIT_NT_STORE)
+    int table;         // SRC_PCM_GENERIC: the "string" is a Lua TABLE of numbers (doubles, 8 bytes each: aukit.lua:2255-2290), read as they are
+                       // (last member: the offsets of everything the wave kernels read stay what they were)
 };
 
 // launches the right instantiation; `name` receives a static string naming the kernel

@@ -108,8 +108,10 @@ AUKIT_DEV int stage(const ResampleParams &P, const Seg &sg, int k_lo, int n_stag
         }
         return head;
     } else if constexpr (SRC == SRC_PCM_GENERIC) {
-        const int C = P.channels, SC = P.stage_channels, bd = P.bit_depth >> 3;
+        const int C = P.channels, SC = P.stage_channels, bd = P.table ? 8 : P.bit_depth >> 3;
         const unsigned char *base = P.src + P.src_off[sg.stream];
+        // a table entry is the number itself (`local s = data[pos]`, :2263): no byte order, no width — only the normalisation applies
+        auto raw_at = [&](size_t e) -> double { return P.table ? reinterpret_cast<const double *>(base)[e] : pcm_raw(base + e * bd, bd, P.data_type, P.big_endian); };
         const double maxv = (double)(1ull << (P.bit_depth - 1));
         const unsigned long long frames = P.planar ? P.src_frames[sg.stream] : 0;
         const int total = n_stage * SC;
@@ -119,11 +121,11 @@ AUKIT_DEV int stage(const ResampleParams &P, const Seg &sg, int k_lo, int n_stag
             double v;
             if (P.premix_mono) {  // self[i] = ((0 + read()) + read() ...) / channels   :2368
                 double acc = 0;
-                for (int cc = 0; cc < C; cc++) acc = acc + pcm_norm(pcm_raw(base + ((size_t)g * C + cc) * bd, bd, P.data_type, P.big_endian), P.data_type, maxv);
+                for (int cc = 0; cc < C; cc++) acc = acc + pcm_norm(raw_at((size_t)g * C + cc), P.data_type, maxv);
                 v = acc / C;
             } else {
                 size_t e = P.planar ? ((size_t)c * frames + (size_t)g) : ((size_t)g * C + c);
-                v = pcm_norm(pcm_raw(base + e * bd, bd, P.data_type, P.big_endian), P.data_type, maxv);
+                v = pcm_norm(raw_at(e), P.data_type, maxv);
             }
             sm[c * P.cap + rel] = v;
         }

@@ -43,6 +43,8 @@ int aukit_split(aukit_ctx *, const aukit_audio *, const int32_t *channels, uint3
 int aukit_rep(aukit_ctx *, const aukit_audio *, double count, aukit_audio **out);
 int aukit_reverse(aukit_ctx *, const aukit_audio *, aukit_audio **out);
 int aukit_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out);
+int aukit_decode_nibbles(aukit_ctx *, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out);
+int aukit_stream_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
 int aukit_pack_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode, aukit_batch **out);
 int aukit_stream_decode(aukit_ctx *, const aukit_batch *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
@@ -417,11 +419,24 @@ function aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved, 
 end
 function aukit.adpcm(data, channels, sampleRate, topFirst, interleaved, predictor, step_index)  -- :1183 (string input)
     expect(1, data, "string", "table")
-    if type(data) == "table" then error("aukit.adpcm with a table of nibbles is not offered by the device path (pass the byte string)", 2) end
     channels = expect(2, channels, "number", "nil") or 1
     sampleRate = expect(3, sampleRate, "number", "nil") or 48000
     expect(4, topFirst, "boolean", "nil") expect(5, interleaved, "boolean", "nil")
     expect(6, predictor, "number", "table", "nil") expect(7, step_index, "number", "table", "nil")
+    if type(data) == "table" then  -- :1232-1238: one nibble per entry, `len = #data / channels`
+        local n = #data
+        local nib = ffi.new("uint8_t[?]", math.max(n, 1))
+        for i = 1, n do
+            local v = data[i]
+            if type(v) ~= "number" or v % 1 ~= 0 or v < 0 or v > 15 then error("attempt to perform arithmetic on a nil value (field '?')", 2) end  -- ima_index_table[nibble]
+            nib[i - 1] = v
+        end
+        local offs = ffi.new("uint64_t[2]", {0, n})
+        local o = ffi.new("aukit_audio*[1]")
+        check(C.aukit_decode_nibbles(ctx(), nib, offs, 1, desc {codec = "adpcm", channels = channels, sampleRate = sampleRate, interleaved = interleaved,
+            predictor = predictor, step_index = step_index}, F64, o))
+        return wrap(o[0], {}, {bitDepth = 16, dataType = "signed"})
+    end
     return loader(desc {codec = "adpcm", channels = channels, sampleRate = sampleRate, topFirst = topFirst, interleaved = interleaved, predictor = predictor, step_index = step_index},
         data, {bitDepth = 16, dataType = "signed"})
 end
@@ -547,7 +562,14 @@ local function streamer(d, data, mono, dtype, first, len)
         return streamer_fn(d, data, piece, mono, dtype)
     end
     local o, ck = ffi.new("aukit_audio*[1]"), ffi.new("aukit_chunks*[1]")
-    check(C.aukit_stream_decode(ctx(), upload(data, first, len), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
+    if type(data) == "table" then  -- aukit.stream.pcm on a table of numbers (:2255-2290)
+        local n = #data
+        local vals = ffi.new("double[?]", math.max(n, 1))
+        for i = 1, n do vals[i - 1] = data[i] end
+        check(C.aukit_stream_decode_table(ctx(), vals, ffi.new("uint64_t[2]", {0, n}), 1, d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
+    else
+        check(C.aukit_stream_decode(ctx(), upload(data, first, len), d, INTERP[aukit.defaultInterpolation], mono and 1 or 0, dtype, o, ck))
+    end
     local audio = wrap(o[0])
     local n, mx = ffi.new("uint32_t[1]"), ffi.new("uint32_t[1]")
     check(C.aukit_chunks_info(ck[0], n, mx))
@@ -574,7 +596,7 @@ local function streamer(d, data, mono, dtype, first, len)
     end, length[0]
 end
 function aukit.stream.pcm(data, bitDepth, dataType, channels, sampleRate, bigEndian, mono)  -- :2228
-    expect(1, data, "string", "function")
+    expect(1, data, "string", "table", "function")
     bitDepth = expect(2, bitDepth, "number", "nil") or 8
     dataType = expect(3, dataType, "string", "nil") or "signed"
     channels = expect(4, channels, "number", "nil") or 1

@@ -216,6 +216,11 @@ int aukit_reverse(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out);    
  * element offsets [n + 1]; d->codec = AUKIT_CODEC_PCM, bit_depth / data_type / channels / sample_rate / interleaved as for the string.
  * Values are taken as they are (no range check, fractions allowed: s / (s < 0 and 2^(b-1) or 2^(b-1)-1), :1082).  Storage = the context's dtype. */
 int aukit_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out);
+/* aukit.adpcm(data, ...) with `data` a TABLE of nibbles, aukit.lua:1183-1184 + :1232-1238 (`read()` hands out data[pos]; `len = #data / channels`):
+ * `n` tables as one host array of nibbles (one per byte, 0..15; anything else indexes ima_index_table with nil: AUKIT_E_LUA) with element
+ * offsets [n + 1]; d->codec = AUKIT_CODEC_ADPCM, channels / sample_rate / interleaved / predictor / step_index as for the string (top_first
+ * has no meaning for a table). */
+int aukit_decode_nibbles(aukit_ctx *ctx, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out);
 typedef enum { AUKIT_WAVE_NONE = 0 /* aukit.new: silence */, AUKIT_WAVE_SINE = 1, AUKIT_WAVE_TRIANGLE = 2, AUKIT_WAVE_SAWTOOTH = 3, AUKIT_WAVE_SQUARE = 4 } aukit_wave;
 /* aukit.new(duration, channels, sampleRate) :1783 / aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sampleRate)
  * :1808 — `n` identical audios (aukit.noise draws from the host VM's math.random and cannot be reproduced) */
@@ -237,6 +242,11 @@ int aukit_pack_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int dat
 typedef struct aukit_chunks aukit_chunks;
 int aukit_stream_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *desc, int interp, int mono,
                         int dtype, aukit_audio **out, aukit_chunks **chunks);
+/* aukit.stream.pcm(data, ...) with `data` a TABLE of numbers, aukit.lua:2255-2290 (`read()` hands out `data[pos]` normalised like the string's
+ * samples; `len = #data / channels`): every iterator call at once, as aukit_stream_decode.  Values are taken as they are; reference-order
+ * fp64 arithmetic whatever the storage type (AUKIT_F64 / AUKIT_F32); sinc and rates above 48 kHz refused like the string's (Q3). */
+int aukit_stream_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *offsets /* n + 1, elements */, uint32_t n, const aukit_codec_desc *d, int interp,
+                              int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 /* per stream s: nchunks[s]; chunk k of stream s: length and the iterator's second return value.
  * status[s]: 0 = iterator ended with nil, AUKIT_E_LUA = the reference iterator raises after the last chunk. */
 int aukit_chunks_info(const aukit_chunks *c, uint32_t *n, uint32_t *max_chunks);

