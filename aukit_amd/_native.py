@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 if os.environ.get("AUKIT_LIB"):  # A/B of library builds on one box (tools/build_variant.sh): never set in tests or by the driver
     LIB_PATH = os.path.abspath(os.environ["AUKIT_LIB"])
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_f32.hip", "fast_stream_u8.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "container.hip", "stream_handle.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "msadpcm.hip", "qoa_stream.hip", "qoa.hip", "stream_tail.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip"]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_f32.hip", "fast_stream_u8.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "container.hip", "stream_handle.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "msadpcm.hip", "qoa_stream.hip", "qoa.hip", "stream_tail.hip", "effects.hip", "flac.hip", "ops.hip", "dfpwm_par.hip", "group.hip"]
 HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "fast_stream_body.h", "resample_dev.h", "dfpwm_dev.h", "stream_tail.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
@@ -43,6 +43,8 @@ EXPORTS = [
     "aukit_parse_container", "aukit_decode", "aukit_decode_table", "aukit_decode_nibbles", "aukit_stream_decode_table", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
     "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_close",
+    "aukit_partition", "aukit_group_create", "aukit_group_destroy", "aukit_group_info", "aukit_group_ctx", "aukit_group_sync", "aukit_group_scatter",
+    "aukit_group_gather_audio", "aukit_group_gather_batch",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
 ]
 
@@ -126,9 +128,11 @@ def lib():
     L.aukit_ctx_get_stream.restype = C.c_void_p
     L.aukit_batch_device_ptr.restype = C.c_void_p
     L.aukit_audio_device_ptr.restype = C.c_void_p
+    L.aukit_group_ctx.restype = C.c_void_p
+    L.aukit_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
     L.aukit_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.aukit_batch_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
-    for name in ("aukit_ctx_destroy", "aukit_batch_free", "aukit_audio_free", "aukit_chunks_free", "aukit_stream_close"):
+    for name in ("aukit_ctx_destroy", "aukit_batch_free", "aukit_audio_free", "aukit_chunks_free", "aukit_stream_close", "aukit_group_destroy"):
         getattr(L, name).restype = None
         getattr(L, name).argtypes = [C.c_void_p]
     _lib = L

@@ -102,6 +102,87 @@ class Context:
         N.check(N.lib().aukit_ctx_set_sinc_window(self._h, int(w)))
 
 
+class _GroupContext(Context):
+    """a member context of a Group: owned by the group (never destroyed on its own)"""
+
+    def __init__(self, handle, device, dtype):
+        self._h = C.c_void_p(handle)
+        self.device = device
+        self.dtype = dtype
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+def partition(sizes, world):
+    """aukit_partition: contiguous, byte-balanced stream ranges [(start, end)) per rank"""
+    sz = np.ascontiguousarray(sizes, dtype=np.uint64)
+    cuts = np.zeros(int(world) + 1, dtype=np.uint32)
+    N.check(N.lib().aukit_partition(sz.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(sz)), C.c_uint32(int(world)), cuts.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return [(int(cuts[g]), int(cuts[g + 1])) for g in range(int(world))]
+
+
+class Group:
+    """several GPUs of one node in ONE process (aukit_group): a context per device, scatter of a batch's streams, gather of the results"""
+
+    def __init__(self, devices, dtype=N.F64):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        N.check(N.lib().aukit_group_create(C.byref(self._h), devs, C.c_uint32(len(devices))))
+        self.devices = list(devices)
+        self.contexts = []
+        for r, d in enumerate(devices):
+            c = _GroupContext(N.lib().aukit_group_ctx(self._h, C.c_uint32(r)), d, dtype)
+            N.check(N.lib().aukit_ctx_set_dtype(c._h, dtype))
+            self.contexts.append(c)
+
+    def transport(self):
+        n, t = C.c_uint32(), C.c_int()
+        N.check(N.lib().aukit_group_info(self._h, C.byref(n), C.byref(t)))
+        return "rccl" if t.value else "peer"
+
+    def scatter(self, whole, root=0):
+        """→ ([Batch per member], [(start, end) per member]); the root's shard is a view of `whole`"""
+        W = len(self.devices)
+        hs = (C.c_void_p * W)()
+        cuts = np.zeros(W + 1, dtype=np.uint32)
+        N.check(N.lib().aukit_group_scatter(self._h, C.c_uint32(root), whole._h, hs, cuts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        shards = []
+        for r in range(W):
+            b = Batch(self.contexts[r], C.c_void_p(hs[r]))
+            b._keep = whole
+            shards.append(b)
+        return shards, [(int(cuts[g]), int(cuts[g + 1])) for g in range(W)]
+
+    def gather_audio(self, parts, root=0, out=None):
+        out = out if out is not None else AudioBatch(self.contexts[root])
+        hs = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        N.check(N.lib().aukit_group_gather_audio(self._h, C.c_uint32(root), hs, C.byref(out._h)))
+        return out
+
+    def gather_batch(self, parts, root=0, out=None):
+        out = out if out is not None else Batch(self.contexts[root], C.c_void_p())
+        hs = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        N.check(N.lib().aukit_group_gather_batch(self._h, C.c_uint32(root), hs, C.byref(out._h)))
+        return out
+
+    def sync(self):
+        N.check(N.lib().aukit_group_sync(self._h))
+
+    def close(self):
+        if self._h:
+            for c in self.contexts:
+                c.close()
+            N.lib().aukit_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Batch:
     """N byte strings resident on the device (aukit_batch)."""
 

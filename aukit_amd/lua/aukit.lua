@@ -43,6 +43,13 @@ int aukit_split(aukit_ctx *, const aukit_audio *, const int32_t *channels, uint3
 int aukit_rep(aukit_ctx *, const aukit_audio *, double count, aukit_audio **out);
 int aukit_reverse(aukit_ctx *, const aukit_audio *, aukit_audio **out);
 int aukit_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, aukit_audio **out);
+typedef struct aukit_group aukit_group;
+int aukit_partition(const uint64_t *sizes, uint32_t n, uint32_t world, uint32_t *cuts);
+int aukit_group_create(aukit_group **out, const int *devices, uint32_t n_devices); void aukit_group_destroy(aukit_group *g);
+aukit_ctx *aukit_group_ctx(aukit_group *g, uint32_t rank); int aukit_group_sync(aukit_group *g);
+int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole, aukit_batch **shards, uint32_t *cuts);
+int aukit_group_gather_audio(aukit_group *g, uint32_t root, aukit_audio *const *parts, aukit_audio **whole);
+int aukit_group_gather_batch(aukit_group *g, uint32_t root, aukit_batch *const *parts, aukit_batch **whole);
 int aukit_decode_nibbles(aukit_ctx *, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out);
 int aukit_stream_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
@@ -662,5 +669,53 @@ end
 function aukit.stream.wav(data, mono, ignoreHeader) return stream_container(data, 0, mono, ignoreHeader) end    -- :2927
 function aukit.stream.aiff(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 1, mono, ignoreHeader) end  -- :3016
 function aukit.stream.au(data, mono, ignoreHeader) expect(2, mono, "boolean", "nil") return stream_container(data, 2, mono, ignoreHeader) end    -- :3086
+
+-- ---------------------------------------------------------------- several GPUs (no counterpart in the reference: include/aukit_hip.h, "several GPUs")
+-- aukit.gpus{0, 1, ...} -> group.  group:map(strings, fn) runs fn(ctx_index, shard_batch, ctx) on every member's byte-balanced range of the
+-- strings and returns the gathered result: fn returns an aukit_audio* (a loader / resample chain) or an aukit_batch* (Audio:dfpwm, the
+-- transcode).  Streams are independent, so this is a scatter, N independent single-GPU runs, and a gather — nothing else crosses xGMI.
+function aukit.gpus(devices)
+    local n = #devices
+    local devs = ffi.new("int[?]", n)
+    for i = 1, n do devs[i - 1] = devices[i] end
+    local g = ffi.new("aukit_group*[1]")
+    check(C.aukit_group_create(g, devs, n))
+    local group = {handle = ffi.gc(g[0], C.aukit_group_destroy), size = n}
+    function group:ctx(rank) return C.aukit_group_ctx(self.handle, rank) end
+    function group:map(strings, fn, root)
+        root = root or 0
+        local total, offs = 0, ffi.new("uint64_t[?]", #strings + 1)
+        for i, s in ipairs(strings) do offs[i - 1] = total; total = total + #s end
+        offs[#strings] = total
+        local whole = ffi.new("aukit_batch*[1]")
+        check(C.aukit_batch_upload(self:ctx(root), whole, ffi.cast("const uint8_t*", table.concat(strings)), offs, #strings))
+        local shards, cuts = ffi.new("aukit_batch*[?]", n), ffi.new("uint32_t[?]", n + 1)
+        check(C.aukit_group_scatter(self.handle, root, whole[0], shards, cuts))
+        local audios, batches, is_audio = ffi.new("aukit_audio*[?]", n), ffi.new("aukit_batch*[?]", n), nil
+        for r = 0, n - 1 do
+            local res, kind = fn(r, shards[r], self:ctx(r))   -- kind: "audio" | "batch"
+            is_audio = kind ~= "batch"
+            if is_audio then audios[r] = res else batches[r] = res end
+        end
+        local out
+        if is_audio then
+            local o = ffi.new("aukit_audio*[1]")
+            check(C.aukit_group_gather_audio(self.handle, root, audios, o))
+            out = o[0]
+        else
+            local o = ffi.new("aukit_batch*[1]")
+            check(C.aukit_group_gather_batch(self.handle, root, batches, o))
+            out = o[0]
+        end
+        check(C.aukit_group_sync(self.handle))
+        for r = 0, n - 1 do
+            C.aukit_batch_free(shards[r])
+            if is_audio then C.aukit_audio_free(audios[r]) else C.aukit_batch_free(batches[r]) end
+        end
+        C.aukit_batch_free(whole[0])
+        return out
+    end
+    return group
+end
 
 return aukit

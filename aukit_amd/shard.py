@@ -23,21 +23,12 @@ def partition(sizes, world):
 
     Rank g gets the streams whose cumulative byte midpoint falls in [g/world, (g+1)/world) of the total, which keeps
     the ranges contiguous (outputs concatenate in rank order) and within one stream of the ideal byte split.
+    The arithmetic lives in the library (aukit_partition, csrc/group.hip: a Lua host shards with the same cuts); it needs no GPU.
     """
-    sizes = np.asarray(sizes, dtype=np.float64)
-    n = len(sizes)
     if world < 1:
         raise ValueError("world must be >= 1")
-    if n == 0:
-        return [(0, 0)] * world
-    total = float(sizes.sum())
-    if total <= 0:  # all empty: split by count
-        cuts = [(n * g) // world for g in range(world + 1)]
-    else:
-        mid = np.cumsum(sizes) - sizes / 2
-        owner = np.minimum((mid / total * world).astype(np.int64), world - 1)
-        cuts = [int(np.searchsorted(owner, g, side="left")) for g in range(world)] + [n]
-    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+    from . import batch as B
+    return B.partition(sizes, world)
 
 
 def _dist():

@@ -254,6 +254,27 @@ int aukit_chunks_get(const aukit_chunks *c, uint32_t *nchunks /* n */, uint32_t 
                      int32_t *status /* n */, double *length_seconds /* n */);
 void aukit_chunks_free(aukit_chunks *c);
 
+/* ---- several GPUs of one node.  No function of the path reads another stream, so a batch shards by stream index with no
+ * data-path collective: aukit_partition cuts it into contiguous, byte-balanced ranges; a GROUP is one context per device in this process
+ * (the Lua host is one process that owns the node's GPUs); aukit_group_scatter hands every member its range of a batch that lives on the
+ * root's device — device to device over xGMI, every peer's share in flight at once (hipMemcpyPeerAsync per peer, or, with
+ * AUKIT_GROUP_TRANSPORT=rccl, grouped ncclSend / ncclRecv on an ncclCommInitAll communicator) — each member then runs the ordinary calls
+ * on aukit_group_ctx(g, r) with its shard, and aukit_group_gather_* concatenates the results on the root in rank order.  The reference has
+ * no counterpart (a CC computer has one speaker bus): this is the boundary a host such as austream.lua's source loop (:85-92) would use to
+ * feed a whole node.  One process per GPU instead: aukit_amd/shard.py over torch.distributed (RCCL), same partition. ---- */
+typedef struct aukit_group aukit_group;
+/* cuts[g] .. cuts[g + 1] (g = 0 .. world-1; cuts has world + 1 entries) are rank g's streams */
+int aukit_partition(const uint64_t *sizes /* n: bytes per stream */, uint32_t n, uint32_t world, uint32_t *cuts);
+int aukit_group_create(aukit_group **out, const int *devices, uint32_t n_devices);   /* a device may appear more than once (tests on one GPU) */
+void aukit_group_destroy(aukit_group *g);
+int aukit_group_info(const aukit_group *g, uint32_t *n_devices, int *transport /* 0 = peer copies, 1 = RCCL */);
+aukit_ctx *aukit_group_ctx(aukit_group *g, uint32_t rank);                            /* owned by the group */
+int aukit_group_sync(aukit_group *g);
+/* shards: n_devices entries (NULL or batches to replace); the root's shard is a view of `whole` — keep `whole` alive while shards are used */
+int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole, aukit_batch **shards, uint32_t *cuts /* n_devices + 1 */);
+int aukit_group_gather_audio(aukit_group *g, uint32_t root, aukit_audio *const *parts /* n_devices */, aukit_audio **whole);
+int aukit_group_gather_batch(aukit_group *g, uint32_t root, aukit_batch *const *parts /* n_devices */, aukit_batch **whole);
+
 /* ---- aukit.stream.<codec>(fn, ...): the reader-FUNCTION input (aukit.lua:2776-2786 and siblings; austream.lua:19-64), as a resumable handle.
  * Bytes are fed in any pieces; the chunks handed out are exactly those aukit.stream.<codec>(s, ...) hands out for the string s = every
  * byte fed (the reference's own function mode cuts chunks wherever the reader's buffers end, SURVEY Q6: nothing to reproduce there).

@@ -87,8 +87,8 @@ def test_lua_shim_declarations_match_the_header():
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aukit_hip.h")).read(), flags=re.S)
     lua = open(os.path.join(ROOT, "aukit_amd", "lua", "aukit.lua")).read()
     cdef = lua[lua.index("ffi.cdef [["):lua.index("]]", lua.index("ffi.cdef [["))]
-    hprotos = {m.group(2): m.group(0) for m in re.finditer(r"(?:int|void|const char \*|void \*)\s*\*?(aukit_[a-z0-9_]+)\s*\([^;{]*\)\s*;", hdr) for m in [re.match(r"(.*?)(aukit_[a-z0-9_]+)\s*\(.*", m.group(0), re.S)]}
-    lprotos = {m.group(2): m.group(0) for m in re.finditer(r"(?:int|void|const char \*)\s*\*?(aukit_[a-z0-9_]+)\s*\([^;]*\)\s*;", cdef) for m in [re.match(r"(.*?)(aukit_[a-z0-9_]+)\s*\(.*", m.group(0), re.S)]}
+    hprotos = {m.group(2): m.group(0) for m in re.finditer(r"(?:int|void|const char \*|void \*|aukit_ctx \*)\s*\*?(aukit_[a-z0-9_]+)\s*\([^;{]*\)\s*;", hdr) for m in [re.match(r"(.*?)(aukit_[a-z0-9_]+)\s*\(.*", m.group(0), re.S)]}
+    lprotos = {m.group(2): m.group(0) for m in re.finditer(r"(?:int|void|const char \*|aukit_ctx \*)\s*\*?(aukit_[a-z0-9_]+)\s*\([^;]*\)\s*;", cdef) for m in [re.match(r"(.*?)(aukit_[a-z0-9_]+)\s*\(.*", m.group(0), re.S)]}
     assert len(lprotos) >= 30
     for name, proto in lprotos.items():
         assert name in hprotos, name

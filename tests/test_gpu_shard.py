@@ -87,3 +87,72 @@ print("OK")
 """ % root
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world,root", [(1, 0), (2, 0), (3, 2), (8, 5)])
+def test_group_scatter_compute_gather_through_the_c_abi(ctx, world, root):
+    """sharding without Python's torch.distributed — aukit_partition + aukit_group_create / _scatter / _gather_* (csrc/group.hip).
+    The members are `world` contexts on cuda:0 (a device may repeat in a group), so every line of the peer-copy transport runs on a one-GPU box:
+    the batch lives on member `root`, every member gets its byte-balanced range device to device, runs the ordinary single-GPU calls in its own
+    context, and the gathered rows / bytes are, bit for bit, those of the unsharded call."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    lens = [30000, 100, 4097, 1, 52000, 7, 9000, 1024, 2048, 33333, 5, 777, 0, 12]
+    streams = [pcm16(n, 44100, 1, i).tobytes() for i, n in enumerate(lens)]
+    desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+    single_ctx = ctx
+    whole0 = B.Batch.upload(single_ctx, streams)
+    single = B.decode_resample(single_ctx, whole0, desc, 48000, "cubic", dtype=N.F32).download()
+    single_bytes = B.dfpwm_encode(single_ctx, B.decode_resample(single_ctx, whole0, desc, 48000, "cubic", dtype=N.F64), True).download()
+    g = B.Group([0] * world, dtype=N.F32)
+    try:
+        assert g.transport() == "peer"
+        whole = B.Batch.upload(g.contexts[root], streams)   # the job's bytes, resident on the root member
+        shards, cuts = g.scatter(whole, root)
+        assert cuts == B.partition([len(s) for s in streams], world)
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(streams) and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+        for r, (lo, hi) in enumerate(cuts):
+            assert shards[r].download() == streams[lo:hi]
+        assert shards[root].device_ptr() == whole.device_ptr() + int(whole.offsets()[cuts[root][0]])   # the root's shard is a view
+        parts = [B.decode_resample(g.contexts[r], shards[r], desc, 48000, "cubic", dtype=N.F32) for r in range(world)]
+        got = g.gather_audio(parts, root)
+        g.sync()
+        rows = got.download()
+        assert len(rows) == len(single)
+        for a, b in zip(rows, single):
+            assert np.array_equal(a[0], b[0])
+        enc = [B.dfpwm_encode(g.contexts[r], B.decode_resample(g.contexts[r], shards[r], desc, 48000, "cubic", dtype=N.F64), True) for r in range(world)]
+        allb = g.gather_batch(enc, root)
+        g.sync()
+        assert allb.download() == single_bytes
+    finally:
+        g.close()
+
+
+def test_group_rccl_transport_initialises(ctx, monkeypatch):
+    """AUKIT_GROUP_TRANSPORT=rccl: librccl is dlopen'ed and ncclCommInitAll builds the group's communicators (distinct devices only — a one-GPU box
+    has a group of one, whose scatter / gather move nothing: the messages between members cannot be exercised here, only the set-up and tear-down);
+    a group with a repeated device keeps the peer-copy transport."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    monkeypatch.setenv("AUKIT_GROUP_TRANSPORT", "rccl")
+    g = B.Group([0], dtype=N.F32)
+    try:
+        assert g.transport() == "rccl"
+        streams = [pcm16(n, 44100, 1, i).tobytes() for i, n in enumerate([5000, 300, 41])]
+        whole = B.Batch.upload(g.contexts[0], streams)
+        shards, cuts = g.scatter(whole, 0)
+        assert cuts == [(0, 3)] and shards[0].download() == streams
+        desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
+        out = g.gather_audio([B.decode_resample(g.contexts[0], shards[0], desc, 48000, "cubic", dtype=N.F32)], 0)
+        g.sync()
+        want = B.decode_resample(ctx, B.Batch.upload(ctx, streams), desc, 48000, "cubic", dtype=N.F32).download()
+        for a, b in zip(out.download(), want):
+            assert np.array_equal(a[0], b[0])
+    finally:
+        g.close()
+    g2 = B.Group([0, 0], dtype=N.F32)
+    try:
+        assert g2.transport() == "peer"
+    finally:
+        g2.close()

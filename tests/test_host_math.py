@@ -186,3 +186,24 @@ def test_device_face_transport_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_partition_matches_the_numpy_statement():
+    """aukit_partition against the midpoint rule written out in numpy (what shard.py computed before it called the library)"""
+    from aukit_amd import batch as B
+    rng = np.random.Generator(np.random.PCG64(5))
+    for trial in range(200):
+        n = int(rng.integers(0, 40))
+        world = int(rng.integers(1, 10))
+        sizes = rng.integers(0, 5000, n).astype(np.float64) * (rng.integers(0, 2, n) if trial % 3 == 0 else 1)
+        if n == 0:
+            want = [(0, 0)] * world
+        elif sizes.sum() <= 0:
+            cuts = [(n * g) // world for g in range(world + 1)]
+            want = [(cuts[g], cuts[g + 1]) for g in range(world)]
+        else:
+            mid = np.cumsum(sizes) - sizes / 2
+            owner = np.minimum((mid / sizes.sum() * world).astype(np.int64), world - 1)
+            cuts = [int(np.searchsorted(owner, g, side="left")) for g in range(world)] + [n]
+            want = [(cuts[g], cuts[g + 1]) for g in range(world)]
+        assert B.partition(sizes.astype(np.uint64), world) == want, (trial, n, world)
