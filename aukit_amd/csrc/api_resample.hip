@@ -518,6 +518,12 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             if (done && frc) { delete ck; return frc; }
         } else if (rc) { delete ck; return rc; }
     }
+    if (!done && ctx->exact_math == 1 && dtype == AUKIT_F32 && src == SRC_PCM_S16LE_MONO && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+        // AUKIT_OPT_EXACT_MATH = 1: fp64 arithmetic behind the f32 store, phase-weight table (wave_f64.hip with the stream.pcm epilogue)
+        int wrc = AUKIT_OK;
+        done = wave_f64_try(ctx, src, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &wrc, 1, P.lp_alpha);
+        if (done && wrc) { delete ck; return wrc; }
+    }
     if (!done && src == SRC_PCM_S16LE_MONO && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // reference order, wave tiles
         int erc = AUKIT_OK;
         done = exact_wave_try(ctx, src, interp, d->sample_rate, 48000, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc, 1);

@@ -60,7 +60,7 @@ template <> struct Row<AUKIT_INTERP_CUBIC, true> {  // 4 taps, 4 weights of the 
                      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(w01), "=&v"(w23) : "v"(tap), "v"(wa), "v"(wb));
     }
     template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(w01), "+v"(w23) : "n"(K)); }
-    AUKIT_DEV float eval(unsigned, double) const { return (float)__builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0))); }
+    AUKIT_DEV double eval(unsigned, double) const { return __builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0))); }
 };
 template <> struct Row<AUKIT_INTERP_LINEAR, true> {  // 2 taps, fx of the phase
     static constexpr int N = 3;
@@ -69,7 +69,7 @@ template <> struct Row<AUKIT_INTERP_LINEAR, true> {  // 2 taps, fx of the phase
         asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %4" : "=&v"(p1), "=&v"(p2), "=&v"(fx) : "v"(tap), "v"(wa));
     }
     template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(p1), "+v"(p2), "+v"(fx) : "n"(K)); }
-    AUKIT_DEV float eval(unsigned, double) const { return (float)__builtin_fma(p2 - p1, fx, p1); }
+    AUKIT_DEV double eval(unsigned, double) const { return __builtin_fma(p2 - p1, fx, p1); }
 };
 template <> struct Row<AUKIT_INTERP_CUBIC, false> {  // 4 taps, Horner on fx = rem * RN(1/b)
     static constexpr int N = 4;
@@ -79,12 +79,12 @@ template <> struct Row<AUKIT_INTERP_CUBIC, false> {  // 4 taps, Horner on fx = r
                      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(tap));
     }
     template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "n"(K)); }
-    AUKIT_DEV float eval(unsigned rem, double inv_b) const {
+    AUKIT_DEV double eval(unsigned rem, double inv_b) const {
         const double fx = (double)rem * inv_b;
         const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
         const double c2 = __builtin_fma(-0.5, p3, __builtin_fma(2.0, p2, __builtin_fma(-2.5, p1, p0)));
         const double c1 = 0.5 * (p2 - p0);
-        return (float)__builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+        return __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
     }
 };
 template <> struct Row<AUKIT_INTERP_LINEAR, false> {
@@ -92,27 +92,27 @@ template <> struct Row<AUKIT_INTERP_LINEAR, false> {
     double p1, p2;
     AUKIT_DEV void issue(unsigned tap, unsigned, unsigned) { asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(p1), "=&v"(p2) : "v"(tap)); }
     template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(p1), "+v"(p2) : "n"(K)); }
-    AUKIT_DEV float eval(unsigned rem, double inv_b) const { return (float)__builtin_fma(p2 - p1, (double)rem * inv_b, p1); }
+    AUKIT_DEV double eval(unsigned rem, double inv_b) const { return __builtin_fma(p2 - p1, (double)rem * inv_b, p1); }
 };
 
 // the compiler-scheduled evaluation of one output (partial tiles: the last tile of a stream)
 template <int INTERP, bool TAB>
-AUKIT_DEV float eval_plain(const double *tab, const double *wt, unsigned b, double inv_b, unsigned q, unsigned rem) {
+AUKIT_DEV double eval_plain(const double *tab, const double *wt, unsigned b, double inv_b, unsigned q, unsigned rem) {
     const double p1 = tab[q], p2 = tab[q + 1];
     if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
         const double fx = TAB ? wt[rem] : (double)rem * inv_b;
-        return (float)__builtin_fma(p2 - p1, fx, p1);
+        return __builtin_fma(p2 - p1, fx, p1);
     } else {
         const double p0 = tab[(int)q - 1], p3 = tab[q + 2];
         if constexpr (TAB) {
             const double2 w01 = reinterpret_cast<const double2 *>(wt)[rem], w23 = reinterpret_cast<const double2 *>(wt)[b + rem];
-            return (float)__builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0)));
+            return __builtin_fma(w23.y, p3, __builtin_fma(w23.x, p2, __builtin_fma(w01.y, p1, w01.x * p0)));
         } else {
             const double fx = (double)rem * inv_b;
             const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
             const double c2 = __builtin_fma(-0.5, p3, __builtin_fma(2.0, p2, __builtin_fma(-2.5, p1, p0)));
             const double c1 = 0.5 * (p2 - p0);
-            return (float)__builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+            return __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
         }
     }
 }
@@ -147,11 +147,38 @@ AUKIT_DEV WaveTile describe_t(const ResampleParams &P, const FastParams &F, unsi
 
 constexpr int VMCNT0 = 0x0F70;  // s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15) on gfx9: every VMEM operation of the wave has completed
 
-template <int INTERP, int TILE, int NV, bool TAB>
+// previous lane's value (lane 0: `carry`) / lane 63's value of a double, in the VALU (two 32-bit DPP moves / two v_readlane)
+AUKIT_DEV double prev_lane_d(double s, double carry) {
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(s), cb = (unsigned long long)__double_as_longlong(carry);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)cb, (int)(unsigned)sb, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(cb >> 32), (int)(unsigned)(sb >> 32), 0x138, 0xF, 0xF, false);
+    return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+AUKIT_DEV double last_lane_d(double s) {
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)sb, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(sb >> 32), 63);
+    return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+
+// EPI 0: Audio:resample (clamp to [-1, 1], :667-668).  EPI 1: aukit.stream.pcm's chunk sample (:2397-2403, Q2): the interpolated sample is NOT
+// clamped, `ns = ls + lp_alpha * (s - ls)` with ls the RAW sample before it (0 at the start of an iterator call's chunk = of a segment),
+// `clamp(ns * (ns < 0 and 128 or 127), -128, 127)` — every operation in fp64, the store in f32.  The window reaches one tap further left so
+// that a tile can re-evaluate the raw sample before its first output.
+template <int INTERP, int TILE, int NV, bool TAB, int EPI>
 __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const FastParams F, const double *__restrict__ wg, const unsigned wt_doubles,
-                                                  const double inv_b) {
+                                                  const double inv_b, const double alpha) {
     extern __shared__ double smd[];  // [phase weights][4 × window of F.cap doubles][4 × raw tile of NV KiB]: ONE array (a second one makes hipcc drain every DMA early)
-    constexpr int HL = INTERP == AUKIT_INTERP_CUBIC ? 1 : 0, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + (EPI ? 1 : 0), HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    auto finish = [&](double s, double prev) -> float {   // one output from its raw interpolated sample (EPI 1: and the raw sample before it)
+        if constexpr (EPI == 0) return __builtin_amdgcn_fmed3f((float)s, -1.0f, 1.0f);   // :667-668
+        else {
+            const double ns = prev + alpha * (s - prev);                                  // :2401
+            // ns * (ns < 0 and 128 or 127): the factor is 127.5 - copysign(0.5, ns) (a bit operation and one add instead of a compare and two
+            // selects; -0 gets 128 instead of 127 and is -0 either way); clamp(…, -128, 127) as v_max_f64 / v_min_f64  :2402
+            const double v = ns * (127.5 - __builtin_copysign(0.5, ns));
+            return (float)__builtin_fmin(__builtin_fmax(v, -128.0), 127.0);
+        }
+    };
     constexpr int ROWS = TILE / 64;
     using R = Row<INTERP, TAB>;
     const int lane = threadIdx.x & 63;
@@ -231,6 +258,16 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
         float *orow = cur.orow;
         const bool full = cur.cnt == (unsigned)TILE;  // wave-uniform
         float res[ROWS];
+        [[maybe_unused]] double carry = 0.0;   // EPI 1: the raw sample before the tile's first output (0 at the start of a chunk)
+        if constexpr (EPI == 1) {
+            const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - as_const(P.seg_tile0)[as_const(P.tile_seg)[t]]) == 0;
+            if (!first) {   // position n = r0 - a, one table step back when that is negative
+                const bool back = cur.r0 < F.a;
+                const unsigned n = back ? cur.r0 + F.b - F.a : cur.r0 - F.a;
+                const unsigned q = __umulhi(n, F.magic), rem = n - q * F.b;
+                carry = eval_plain<INTERP, TAB>(back ? tab - 1 : tab, wt, F.b, inv_b, q, rem);
+            }
+        }
         if (full) {
             // ---- 3. the rows, into registers
             const unsigned n0 = cur.r0 + lane_a;
@@ -256,7 +293,9 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
                 } else {
                     c.template wait<0>();
                 }
-                res[r] = __builtin_amdgcn_fmed3f(c.eval(rem_c, inv_b), -1.0f, 1.0f);  // :667-668
+                const double sv = c.eval(rem_c, inv_b);
+                if constexpr (EPI == 0) res[r] = finish(sv, 0.0);
+                else { const double pv = prev_lane_d(sv, carry); carry = last_lane_d(sv); res[r] = finish(sv, pv); }
             }
             asm volatile("" ::: "memory");  // the next tile's staging stores stay below
         }
@@ -276,8 +315,10 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
                 const unsigned n = cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a;
                 const unsigned q = __umulhi(n, F.magic);
                 const unsigned rem = n - q * F.b;
-                const float v = eval_plain<INTERP, TAB>(tab, wt, F.b, inv_b, q, rem);
-                if (j < cur.cnt) orow[j] = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);
+                const double v = eval_plain<INTERP, TAB>(tab, wt, F.b, inv_b, q, rem);
+                double pv = 0.0;
+                if constexpr (EPI == 1) { pv = prev_lane_d(v, carry); carry = last_lane_d(v); }
+                if (j < cur.cnt) orow[j] = finish(v, pv);
             }
         }
         if (!more) break;
@@ -288,19 +329,19 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
-template <int INTERP, int TILE, bool TAB>
-static void launch_wf64(int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, size_t lds, unsigned grid, hipStream_t st) {
+template <int INTERP, int TILE, bool TAB, int EPI>
+static void launch_wf64(int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, double alpha, size_t lds, unsigned grid, hipStream_t st) {
     switch (nv) {
-    case 1: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 1, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
-    case 2: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 2, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
-    default: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 4, TAB>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b); break;
+    case 1: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 1, TAB, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b, alpha); break;
+    case 2: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 2, TAB, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b, alpha); break;
+    default: hipLaunchKernelGGL((k_wave_f64<INTERP, TILE, 4, TAB, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, wtd, inv_b, alpha); break;
     }
 }
-template <int TILE>
-static void launch_wf64_tile(int interp, bool tab, int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, size_t lds, unsigned grid,
-                             hipStream_t st) {
-    if (tab) { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, true>(nv, P, F, wg, wtd, inv_b, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, true>(nv, P, F, wg, wtd, inv_b, lds, grid, st); }
-    else { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, false>(nv, P, F, wg, wtd, inv_b, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, false>(nv, P, F, wg, wtd, inv_b, lds, grid, st); }
+template <int TILE, int EPI>
+static void launch_wf64_tile(int interp, bool tab, int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, double alpha, size_t lds,
+                             unsigned grid, hipStream_t st) {
+    if (tab) { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, true, EPI>(nv, P, F, wg, wtd, inv_b, alpha, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, true, EPI>(nv, P, F, wg, wtd, inv_b, alpha, lds, grid, st); }
+    else { if (interp == AUKIT_INTERP_LINEAR) launch_wf64<AUKIT_INTERP_LINEAR, TILE, false, EPI>(nv, P, F, wg, wtd, inv_b, alpha, lds, grid, st); else launch_wf64<AUKIT_INTERP_CUBIC, TILE, false, EPI>(nv, P, F, wg, wtd, inv_b, alpha, lds, grid, st); }
 }
 
 // weights of the b phases, fx = rem / b, from the reference's polynomial (aukit.lua:265) regrouped by tap; computed in long double
@@ -322,17 +363,18 @@ static void phase_weights(unsigned b, int interp, std::vector<double> &w) {
 }
 
 // returns true when this kernel took the launch (*rc = its status): 16-bit signed little-endian mono → linear / cubic → f32, integer rates
+// epi 1: aukit.stream.pcm's epilogue (alpha = lp_alpha, :2365) — tiles of 512 only
 bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
-                  uint64_t algorithmic_bytes, int *rc) {
+                  uint64_t algorithmic_bytes, int *rc, int epi, double alpha) {
     if (src_kind != SRC_PCM_S16LE_MONO) return false;
     FastParams F;
     if (!fast_eligible(SRC_PCM_S16LE_MONO, interp, old_rate, new_rate, F)) return false;
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
     int tile = 512;  // outputs per wave tile: 512 keeps six workgroups (24 waves) per CU next to their windows; 1024 keeps three
-    if (const char *e = getenv("AUKIT_F64_TILE")) tile = atoi(e) == 1024 ? 1024 : 512;
+    if (const char *e = getenv("AUKIT_F64_TILE")) tile = (atoi(e) == 1024 && !epi) ? 1024 : 512;
     const int spv = 8;
-    const int hl = interp == AUKIT_INTERP_CUBIC ? 1 : 0, hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
     const int win = (int)(((unsigned long long)(tile - 1) * F.a) / F.b) + 2 + hl + hr;
     int nv = (win + 2 * spv + 64 * spv - 1) / (64 * spv);
     nv = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 0));
@@ -368,11 +410,12 @@ bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, dou
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const double *wg = reinterpret_cast<const double *>(ctx->wt_buf.p);
     const double inv_b = 1.0 / (double)F.b;
-    if (tile == 1024) launch_wf64_tile<1024>(interp, tab, nv, P, F, wg, wtd, inv_b, lds, grid, ctx->stream);
-    else launch_wf64_tile<512>(interp, tab, nv, P, F, wg, wtd, inv_b, lds, grid, ctx->stream);
+    if (epi) launch_wf64_tile<512, 1>(interp, tab, nv, P, F, wg, wtd, inv_b, alpha, lds, grid, ctx->stream);
+    else if (tile == 1024) launch_wf64_tile<1024, 0>(interp, tab, nv, P, F, wg, wtd, inv_b, 0.0, lds, grid, ctx->stream);
+    else launch_wf64_tile<512, 0>(interp, tab, nv, P, F, wg, wtd, inv_b, 0.0, lds, grid, ctx->stream);
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_wave_f64 launch failed"); return true; }
     static thread_local char nm[96];
-    snprintf(nm, sizeof nm, "k_wave_f64<pcm_s16le_mono,%s,tile%d,nv%d,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", tile, nv, tab ? "phase_table" : "horner");
+    snprintf(nm, sizeof nm, "k_wave_f64<pcm_s16le_mono,%s,tile%d,nv%d,%s%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", tile, nv, tab ? "phase_table" : "horner", epi ? ",stream_pcm" : "");
     *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
     return true;
 }

@@ -109,3 +109,38 @@ def test_exact_math_levels_pick_their_kernels(ctx, oracle):
         assert np.max(np.abs(out - ref)) <= 1e-15
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate", [44100, 8000, 22050, 32000, 48000, 11025])
+def test_wave_f64_stream_pcm_epilogue(ctx, oracle, rate, interp):
+    """aukit.stream.pcm on 16-bit mono strings with AUKIT_OPT_EXACT_MATH = 1 and f32 storage: k_wave_f64 with the stream.pcm epilogue — the raw
+    interpolated sample and the one before it in fp64, `ns = ls + lp_alpha (s - ls)`, the scale by 128 / 127 and the clamp in fp64, one rounding to
+    f32 (aukit.lua:2397-2403).  Every stored f32 is the oracle's double rounded to f32 or its neighbour (chunk samples reach 128: one f32 ulp is
+    7.6e-6 there, 6e-8 of the [-128, 127] scale), and the chunk plan is the exact path's."""
+    B, N = _mods()
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        lens = [rate * 3 + 11, rate + 1, 4097, 5, 700, 48001]
+        streams = [pcm16(n, rate, 1, i).tobytes() for i, n in enumerate(lens)]
+        streams.append(np.random.Generator(np.random.PCG64(6)).integers(-32768, 32768, 60000).astype(np.int16).tobytes())
+        bt = B.Batch.upload(ctx, streams)
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_PCM, 1, rate, 16, "signed"), interp, dtype=N.F32)
+        name = ctx.last_kernel()[0]
+        assert name.startswith("k_wave_f64<pcm_s16le_mono," + interp) and name.endswith("stream_pcm>"), name
+        got = out.download()
+        diff = total = 0
+        for i, s in enumerate(streams):
+            ref = oracle.stream_pcm(s, 16, oracle.SIGNED, 1, rate, False, False, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            g, r = got[i][0], ref.data[0]
+            assert len(g) == len(r)
+            if len(r):
+                assert rms(g / 128, r / 128) <= 1e-6
+                r32 = r.astype(np.float32)
+                assert np.max(np.abs(g - r32.astype(np.float64))) <= 7.7e-6   # one f32 ulp below 128
+                diff += int(np.count_nonzero(g.astype(np.float32) != r32))
+                total += len(r)
+        assert diff <= max(4, total // 300), (diff, total)
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
