@@ -288,6 +288,10 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int wrc = AUKIT_OK;
         if (wave_f64_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &wrc)) return wrc;
     }
+    if (do_resample && dtype == AUKIT_F32 && C == 1 && ctx->exact_math == 1 && src == SRC_G711_MONO) {  // the same for G.711 up-sampled by > 4.6 (wave_coef_f64.hip)
+        int wrc = AUKIT_OK;
+        if (wave_coef_f64_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &wrc)) return wrc;
+    }
     if (do_resample && C == 1 && src == SRC_PCM_S16LE_MONO) {  // reference-order fp64 on wave tiles (exact_wave.hip)
         int erc = AUKIT_OK;
         if (exact_wave_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc)) return erc;

@@ -101,6 +101,8 @@ bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, d
                     uint64_t algorithmic_bytes, int *rc, int epi = 0);  // exact_wave.hip: reference-order fp64 on the wave tile engine (epi 1: stream.pcm)
 bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
                   uint64_t algorithmic_bytes, int *rc, int epi = 0, double alpha = 0);  // wave_f64.hip: fp64 arithmetic, f32 store (AUKIT_OPT_EXACT_MATH = 1)
+bool wave_coef_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
+                       uint64_t algorithmic_bytes, int *rc);  // wave_coef_f64.hip: G.711 mono, up-sampling by > 4.6, fp64 arithmetic, f32 store
 int launch_fast_wave_stream_s16x2(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, unsigned grid);  // F.epi 1: stereo, 2: mono
 int launch_fast_wave_coef(aukit_ctx *ctx, int src_kind, int interp, int nv, int win, const ResampleParams &P, const FastParams &F, unsigned grid);
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,

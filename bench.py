@@ -528,7 +528,7 @@ def main(argv=None):
     if args.streams is None:
         args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048, "qoa_stream": 1024, "msadpcm_stream": 1024}.get(args.workload, 4096)
     if args.exact_math is None:
-        args.exact_math = 1 if args.workload == "pcm16_cubic" else 0
+        args.exact_math = 1 if args.workload in ("pcm16_cubic", "g711_cubic", "pcm16_stream") else 0   # the workloads that have an fp64-arithmetic wave kernel
     selftest = args.workload == "selftest_null"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -144,3 +144,34 @@ def test_wave_f64_stream_pcm_epilogue(ctx, oracle, rate, interp):
         assert diff <= max(4, total // 300), (diff, total)
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("ulaw", [True, False])
+@pytest.mark.parametrize("rate,new_rate", [(8000, 48000), (8000, 44100), (6000, 48000), (11025, 48000)])
+def test_wave_coef_f64_g711_rounds_the_oracles_double(ctx, oracle, rate, new_rate, ulaw, interp):
+    """BASELINE config 2a in the reference's arithmetic type: aukit.g711(d, ulaw, 1, rate):resample(new_rate, interp) with AUKIT_OPT_EXACT_MATH = 1 and
+    f32 storage runs k_wave_coef_f64 (per-source-sample fp64 coefficients, fp64 Horner form, one rounding to f32) where the up-sampling factor
+    exceeds ≈ 4.6; every stored f32 is the oracle's double rounded to f32 or its neighbour.  Other ratios keep the reference-order kernels."""
+    B, N = _mods()
+    ctx.set_option(N.OPT_EXACT_MATH, 1)
+    try:
+        rng = np.random.Generator(np.random.PCG64(11))
+        streams = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (rate * 2 + 11, 9000, 4097, 1, 2, 3, 5, 700, 171, 172, 1024)]
+        bt = B.Batch.upload(ctx, streams)
+        out = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_G711, 1, rate, ulaw=ulaw), new_rate, interp, dtype=N.F32)
+        name = ctx.last_kernel()[0]
+        if new_rate / rate > 4.7:
+            assert name == "k_wave_coef_f64<g711_mono," + interp + ">", name
+        else:
+            assert name.startswith("k_resample<"), name
+        got = out.download()
+        diff = total = 0
+        for s, g in zip(streams, got):
+            ref = oracle.resample(oracle.g711(s, ulaw, 1, rate), new_rate, oracle.INTERP[interp])
+            d, t = _check(g[0], ref.data[0])
+            diff += d
+            total += t
+        assert diff <= max(2, total // 500), (diff, total)
+    finally:
+        ctx.set_option(N.OPT_EXACT_MATH, 0)
