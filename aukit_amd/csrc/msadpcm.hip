@@ -340,12 +340,16 @@ static AUKIT_DEV void ms_vec_int(const unsigned (&w)[4], int nbytes, MsLane (&L)
 enum { MS_ROWS_I16 = 0, MS_ROWS_F32 = 1, MS_ROWS_F64 = 2, MS_STREAM = 3 };
 
 // C channels; RB bytes of a block per round; MODE one of the enums above; stream mode: INTERP, MIX (stereo: l + r / 2, :2672), OUT_T
-template <int C, int RB, int MODE, int INTERP, bool MIX, typename OUT_T>
+// FB bytes of a block per FETCH (the staging area holds them; FB / RB rounds consume it): the stream kernels fetch 64 bytes at a time and decode
+// them in four rounds of 16 — with 16-byte fetches every 128-byte line of the input came from HBM eight times (PMC FETCH_SIZE, profiles/)
+template <int C, int RB, int MODE, int INTERP, bool MIX, typename OUT_T, int FB = RB>
 __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     constexpr int R = RB * 2 / C;         // samples per channel and round
     constexpr int ROW = 4 + R;            // floats per (block, channel) row: slots 0..3 = table indices R r - 1 .. R r + 2, slot(t) = t - R r + 1
-    constexpr int SEGS = RB / 16;         // 16-byte vectors of a block per round
-    constexpr int INS = RB == 16 ? 4 : RB / 4 + 4;  // dwords between two blocks in the staging area (conflict-free ds_read_b128 per lane)
+    constexpr int SEGS = FB / 16;         // 16-byte vectors of a block per fetch
+    constexpr int RSEG = RB / 16;         // ... per round
+    constexpr int RPF = FB / RB;          // rounds per fetch
+    constexpr int INS = FB == 16 ? 4 : FB / 4 + 4;  // dwords between two blocks in the staging area (conflict-free ds_read_b128 per lane)
     constexpr int HB = 7 * C;
     constexpr bool STREAM = MODE == MS_STREAM;
     constexpr bool FLOORED = STREAM && C == 2;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
 #pragma unroll
         for (int i = 0; i < SEGS; i++) {
             const int b = i * (64 / SEGS) + sblk0;
-            const unsigned char *p = P.src + bp[b] + HB + (unsigned long long)r * RB + sseg * 16;
+            const unsigned char *p = P.src + bp[b] + HB + (unsigned long long)r * FB + sseg * 16;
             u32x4u v = {0, 0, 0, 0};
             if ((unsigned)b < nvalid && p + 16 <= P.safe_hi) v = *reinterpret_cast<const u32x4u *>(p);
             else if ((unsigned)b < nvalid) {   // the last bytes of the allocation
@@ -432,19 +436,23 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     fetch(0, pf);
     [[maybe_unused]] ResampleParams RP;
     if constexpr (STREAM) { RP.ratio = P.ratio; RP.rcp = P.rcp; RP.exact_rcp = P.exact_rcp; RP.sinc_w = 10; RP.pos_mul = 0; }
+    const int nf = (ndata + FB - 1) / FB;                  // fetches
     for (int r = 0; r < nr; r++) {
-        // this round's bytes into the staging area, the next round's on their way
+        const int sub = r % RPF;   // wave-uniform
+        if (sub == 0) {
+            // this fetch's bytes into the staging area, the next fetch's on their way
 #pragma unroll
-        for (int i = 0; i < SEGS; i++) *reinterpret_cast<uint4 *>(inl + (i * (64 / SEGS) + sblk0) * INS + sseg * 4) = make_uint4(pf[i].x, pf[i].y, pf[i].z, pf[i].w);
-        if (r + 1 < nr) fetch(r + 1, pf);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < SEGS; i++) *reinterpret_cast<uint4 *>(inl + (i * (64 / SEGS) + sblk0) * INS + sseg * 4) = make_uint4(pf[i].x, pf[i].y, pf[i].z, pf[i].w);
+            if (r / RPF + 1 < nf) fetch(r / RPF + 1, pf);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         const int nby = ndata - r * RB < RB ? ndata - r * RB : RB;   // bytes of this round
 #pragma unroll
-        for (int v = 0; v < SEGS; v++) {
+        for (int v = 0; v < RSEG; v++) {
             const int nb = nby - 16 * v;   // wave-uniform
             if (nb <= 0) break;
-            const uint4 q = *reinterpret_cast<const uint4 *>(inl + lane * INS + 4 * v);
+            const uint4 q = *reinterpret_cast<const uint4 *>(inl + lane * INS + 4 * (sub * RSEG + v));
             const unsigned w[4] = {q.x, q.y, q.z, q.w};
             const int slot = 4 + v * (32 / C);
             const int s1s[2] = {L[0].s1, L[C - 1].s1}, s2s[2] = {L[0].s2, L[C - 1].s2}, ds[2] = {L[0].d, L[C - 1].d};
@@ -637,14 +645,20 @@ template <int C, int RB, int MODE>
 static void ms_launch_rows(const MsWaveParams &P, unsigned grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((k_ms_wave<C, RB, MODE, AUKIT_INTERP_NONE, false, float>), dim3(grid), dim3(64), lds, st, P);
 }
+// bytes of a block per fetch in the stream kernels.  Measured (1024 x 10 s mono, same box): fetching 64 bytes at a time and decoding them in four
+// rounds of 16 halves the input re-fetch (PMC FETCH x 2: 1.29 -> 0.60 GB for 0.23 GB of blocks — with 16-byte fetches every 128-byte line comes from
+// HBM several times) but costs 4 KB of LDS per wave, i.e. resident waves, and the kernel is bound by those: 2.52 -> 3.04 ms.  Time won: 16.
+constexpr int MS_FB_STREAM = 16;
 template <int C, int RB, bool MIX, typename OUT_T>
 static void ms_launch_stream(int interp, const MsWaveParams &P, unsigned grid, size_t lds, hipStream_t st) {
-    if (interp == AUKIT_INTERP_NONE) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_NONE, MIX, OUT_T>), dim3(grid), dim3(64), lds, st, P);
-    else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T>), dim3(grid), dim3(64), lds, st, P);
-    else hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_CUBIC, MIX, OUT_T>), dim3(grid), dim3(64), lds, st, P);
+    constexpr int FB = RB < MS_FB_STREAM ? MS_FB_STREAM : RB;
+    if (interp == AUKIT_INTERP_NONE) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_NONE, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
+    else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
+    else hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_CUBIC, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
 }
-static size_t ms_lds_bytes(int C, int rb, unsigned wt_floats) {
-    const int R = rb * 2 / C, ROW = 4 + R, INS = rb == 16 ? 4 : rb / 4 + 4;
+static size_t ms_lds_bytes(int C, int rb, unsigned wt_floats, int fb = 0) {
+    if (fb < rb) fb = rb;
+    const int R = rb * 2 / C, ROW = 4 + R, INS = fb == 16 ? 4 : fb / 4 + 4;
     return (size_t)64 * INS * 4 + (size_t)C * 64 * ROW * 4 + 3 * 64 * 8 + 16 * 4 + (size_t)wt_floats * 4;
 }
 
@@ -817,7 +831,7 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
     }
     const int wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
     const int MS_RB = MS_RB_STREAM;
-    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf) : 0;
+    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM) : 0;
     if (wave && lds <= 64 * 1024) {
         const int R = MS_RB * 2 / C, ndata = d->block_align - 7 * C, nr = (ndata + MS_RB - 1) / MS_RB;
         // tables: blk0 (n + 1) | out_off (n) | out_stride (n) | err | rounds (nr) | weights (fb * wf, f32)

@@ -16,13 +16,14 @@ for f in sorted(glob.glob(os.path.join(src, "r1_*.csv")) + glob.glob(os.path.joi
 shutil.copy(os.path.join(root, "gpurun_out", "bench_lines.jsonl"), os.path.join(dst, "r%s_bench_lines.jsonl" % rnd))
 
 # kernel name as bench.py reports it (ctx.last_kernel) -> (tag, substring of the rocprofv3 kernel name)
-DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table>", "wavef64", "k_wave_f64<"),
-            ("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<"),
-            ("k_fast_wave_stream<pcm_s16le_mono,cubic,nv2,stream_pcm>", "pcmstream", "k_fast_wave_stream<"),
-            ("k_fast_wave_coef<g711_mono,cubic,nv1>", "g711cubic", "k_fast_wave_coef<"),
-            ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<"),
-            ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<"),
-            ("k_ima_stream_f32", "ima", "k_ima_stream_f32<")]
+DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table>", "wavef64", "k_wave_f64<", 4096),
+            ("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<", 4096),
+            ("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table,stream_pcm>", "pcmstream", "k_wave_f64<", 4096),
+            ("k_wave_coef_f64<g711_mono,cubic>", "g711cubic", "k_wave_coef_f64<", 4096),
+            ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<", 2048),
+            ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<", 4096),
+            ("k_ima_stream_f32", "ima", "k_ima_stream_f32<", 4096),
+            ("k_ms_wave", "msadpcm", "k_ms_wave<", 1024)]
 
 
 def first(tag, which, pat, col):
@@ -34,14 +35,14 @@ def first(tag, which, pat, col):
 
 
 entries = []
-for kernel, tag, pat in DOMINANT:
+for kernel, tag, pat, nstreams in DOMINANT:
     try:
         fk, wk = first(tag, "fetch", pat, "FETCH_SIZE"), first(tag, "write", pat, "WRITE_SIZE")
     except OSError:
         continue
     if fk is None or wk is None:
         continue
-    entries.append({"kernel": kernel, "streams": 2048 if tag == "stereo" else 4096, "seconds": 10.0, "tag": tag, "fetch_kb": fk, "write_kb": wk,
+    entries.append({"kernel": kernel, "streams": nstreams, "seconds": 10.0, "tag": tag, "fetch_kb": fk, "write_kb": wk,
                     "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)})
 note = ("HBM bytes per launch from rocprofv3 PMC passes of `python3 bench.py --steps 5 --warmup 1 --cpu-streams 0 [--workload W]` "
         "(tools/profile_bench.sh, separate passes for FETCH_SIZE and WRITE_SIZE): FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports wide "
