@@ -128,6 +128,14 @@ struct aukit_audio {
     double pend_peak = 1;
     int pend_independent = 0;
     aukit_ctx *pend_ctx = nullptr;
+    // a deferred resample (flac_tail.hip): aukit_decode_resample on FLAC with F32 storage leaves the decoder's int32 rows here and the resample
+    // owed; effects.highpass / lowpass pay it inside their own pass, anything else that reads the samples materialises it first (audio_flush)
+    bool lazy_rs = false;
+    aukit::DevBuf lazy_rows;                             // taken out of the context's scratch; handed back when the resample is paid
+    std::vector<uint64_t> lazy_row_off, lazy_row_len;    // per (stream, channel): element offset / samples in lazy_rows
+    double lazy_rate = 0, lazy_full = 1;
+    int lazy_interp = 0;
+    aukit_ctx *lazy_ctx = nullptr;
 };
 
 struct aukit_chunks {
@@ -154,8 +162,14 @@ struct DfSliceHook {
 int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
 #define AUKIT_FLUSH(ctx, a)                                                   \
     do {                                                                      \
-        if ((a) && (a)->pend_norm) { int _frc = ::aukit::audio_flush((ctx), (a)); if (_frc) return _frc; } \
+        if ((a) && ((a)->pend_norm || (a)->lazy_rs)) { int _frc = ::aukit::audio_flush((ctx), (a)); if (_frc) return _frc; } \
     } while (0)
+// the deferred resample of flac_tail.hip
+void lazy_drop(aukit_ctx *ctx, aukit_audio *a);
+int lazy_materialize(aukit_ctx *ctx, aukit_audio *a);
+bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
+                       double full, aukit_audio **out, int *rc);
+bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc);
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 // the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time
 void *ctx_host_stage(aukit_ctx *ctx, size_t bytes);

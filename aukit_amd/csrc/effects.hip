@@ -431,6 +431,7 @@ static int run_map(aukit_ctx *ctx, aukit_audio *a, const MapArgs &A, const char 
 
 int audio_flush(aukit_ctx *ctx, const aukit_audio *ca) {
     aukit_audio *a = const_cast<aukit_audio *>(ca);
+    if (a && a->lazy_rs) { int lrc = lazy_materialize(ctx, a); if (lrc) return lrc; }   // an owed resample first (flac_tail.hip)
     if (!a || !a->pend_norm) return AUKIT_OK;
     if (!ctx) ctx = a->pend_ctx;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred map and no context to apply it with");
@@ -523,6 +524,7 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
     AUKIT_FLOAT_ONLY(in);
     if (*out == in) return fail(AUKIT_E_ARG, "mono cannot run in place");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (in->lazy_rs) { int lrc = lazy_materialize(ctx, const_cast<aukit_audio *>(in)); if (lrc) return lrc; }
     aukit_audio *o = *out;
     int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, in->dtype, in->len.data());
     if (rc) return rc;
@@ -603,6 +605,11 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
     if (!ctx || !a) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_FLOAT_ONLY(a);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (a->lazy_rs && !a->pend_norm && nargs >= 1 && args && (id == AUKIT_FX_HIGHPASS || id == AUKIT_FX_LOWPASS)) {   // resample + filter in one pass (flac_tail.hip)
+        int lrc = AUKIT_OK;
+        const double coef = id == AUKIT_FX_HIGHPASS ? 1 / (2 * M_PI * (args[0] / a->rate) + 1) : 1 - std::exp(-(args[0] / a->rate) * 2 * M_PI);   // :3607 / :3589
+        if (lazy_onepole_try(ctx, a, coef, id == AUKIT_FX_HIGHPASS, &lrc)) return lrc;
+    }
     AUKIT_FLUSH(ctx, a);  // every effect reads the samples
     const bool had_rowmax = a->rowmax_valid;
     a->rowmax_valid = false;  // ... and rewrites them (k_onepole leaves new maxima behind)

@@ -1555,11 +1555,16 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
 int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
                       aukit_audio **out) {
     FlacDecoded D;
+    if (*out && ((*out)->lazy_rs || (*out)->lazy_rows.p)) lazy_drop(ctx, *out);   // the output's old rows (a deferred resample nobody asked for) return to the scratch the decoder is about to use
     int rc = flac_decode_rows(ctx, in, D, false);
     if (rc) return rc;
     for (uint32_t s = 0; s < in->n; s++)
         if (D.status[s]) return fail(AUKIT_E_LUA, "%s", flac_err_msg(D.status[s]));  // decodeFLAC raises: the whole load fails
     const double full = std::ldexp(1.0, D.depth);  // :505
+    if (!D.wide && do_resample && dtype == AUKIT_F32) {   // F32 pipelines: the resample is owed — a following effects.highpass / lowpass pays it in its own pass (flac_tail.hip)
+        int lrc = AUKIT_OK;
+        if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc)) return lrc;
+    }
     if (D.wide) return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, 1, 1, out);
     return audio_from_int_rows(ctx, SRC_I32, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, full, full, out);
 }

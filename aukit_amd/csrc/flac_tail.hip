@@ -1,0 +1,298 @@
+// flac_tail.hip — `aukit.flac(d):resample(48000, interp)` followed by `aukit.effects.highpass / lowpass` as ONE pass over the decoded rows
+// (BASELINE config 5's tail).
+//
+// With F32 storage the resampled rows used to be written by k_fast_wave<i32> (7.9 GB for config 5) only to be read back and rewritten by
+// k_onepole (7.9 + 8.1 GB).  Now `aukit_decode_resample` on FLAC leaves the audio LAZY: its int32 rows stay where the decoder put them (the
+// buffer moves from the context's scratch into the audio, so no later call can overwrite it) and the resample is owed.  If the next call is
+// effects.highpass / lowpass, k_rs_onepole below pays it inside the filter pass: one workgroup walks one output row tile by tile —
+//   stage the tile's window of int32 samples as f32 (the `/ 2^depth` of :505 is an exact scaling) → interpolate exactly as
+//   k_fast_wave<i32> does (exact rational positions, f32 Horner form: the same f32 values) → run the one-pole recurrence over the tile in fp64,
+//   thread ↔ 8 consecutive outputs with an affine carry scan across the workgroup and the carry of the tile before (the high-pass at 20 Hz
+//   remembers thousands of samples: no truncation here, cf. stream_tail.hip) → store f32, record the row's |max| for effects.normalize.
+// Anything else that reads the samples first (download, another effect, Audio:mono ...) materialises the resample with the ordinary kernel
+// (audio_flush → lazy_materialize).  AUKIT_NO_TAIL_FUSION=1 switches the laziness off (A/B, tests).
+#include <algorithm>
+#include <type_traits>
+#include "resample.h"
+
+namespace aukit {
+
+int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len,
+                        uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
+                        double norm_neg, aukit_audio **out);
+bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
+
+struct RsOnepoleParams {
+    const int *rows;
+    const unsigned long long *row_off, *row_len;   // per (stream, channel): element offset / samples of the decoded row
+    const unsigned long long *a_meta;              // the audio's len[n], row_off[n], row_stride[n]
+    float *out;
+    unsigned long long *rowmax;
+    unsigned n;
+    int C, cap;
+    unsigned fa, fb, fmagic, dq256, dr256;
+    float inv_b, scale;
+    double coef;
+};
+
+// One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
+// outputs, the tile's carry in registers.  (The first version — a 256-thread workgroup per row, tiles of 2048, five block barriers per tile —
+// ran at 7.3 ms on config 5 against 6.7 ms for the two kernels it replaces: a row is a serial chain of tiles, and what a tile costs is its
+// latency, not its work.)
+template <int INTERP, bool HP>
+__global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
+    extern __shared__ float rsm[];
+    constexpr int E = 8, T = 64 * E;
+    float *const win = rsm;                                  // P.cap floats
+    float *const xb = rsm + P.cap;                           // T + T / E + 8
+    const int lane = threadIdx.x;
+    const unsigned r = blockIdx.x, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
+    const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s];
+    const int L = (int)P.row_len[r];
+    const int *row = P.rows + P.row_off[r];
+    float *orow = P.out + obase;
+    // the slope of the recurrence's affine map y -> m y + ...: a (high-pass, :3614), 1 - alpha (low-pass, :3594)
+    const double m = HP ? P.coef : 1.0 - P.coef;
+    double mp[E + 1];   // m^1 .. m^E (mp[0] = 1)
+    mp[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= E; i++) mp[i] = mp[i - 1] * m;
+    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan
+    Md[0] = mp[E];
+#pragma unroll
+    for (int k = 1; k < 6; k++) Md[k] = Md[k - 1] * Md[k - 1];
+    const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
+    auto skew = [](int i) { return i + i / E; };
+    float mxf = 0.f;
+    double carry_y = 0.0, carry_x = 0.0;   // state and raw sample of the output before the tile (wave-uniform)
+    // x - 1 = o fa / fb exactly.  The tile's first output: (kb, r0) advanced by additions from tile to tile (T fa = wc fb + wd); the outputs inside it
+    // from there (n < fb + T fa: the magic division is exact, as in the wave kernels)
+    const unsigned wc = (unsigned)(((unsigned long long)T * P.fa) / P.fb), wd = (unsigned)(((unsigned long long)T * P.fa) % P.fb);
+    unsigned kb = 0, r0 = 0;   // (row lengths stay below 2^31: checked by the host)
+    // the window of a tile: table indices kb .. kb + nst - 1, clamped into 1 .. #data — the nil fall-backs of interpolate.{linear,cubic} (:259, :264)
+    // are the edge samples repeated.  Its first 512 entries travel through registers, loaded one tile AHEAD (a row is a serial chain of tiles:
+    // a load waited for where it is issued costs its whole latency, eight times per tile in the first cut of this loop)
+    auto tile_nst = [&](unsigned rr, int cn) { const unsigned nn = rr + ((unsigned)cn - 1) * P.fa; return (int)__umulhi(nn, P.fmagic) + 4; };
+    auto fetch = [&](unsigned kk, int nst, int (&pre)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = lane + 64 * u;
+            const unsigned k = kk + (unsigned)j;
+            const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
+            pre[u] = (j < nst && L > 0) ? row[kc - 1] : 0;
+        }
+    };
+    int pre[8];
+    {
+        const int cnt0 = (int)(nout < (unsigned long long)T ? nout : (unsigned long long)T);
+        if (nout) fetch(0u, tile_nst(0u, cnt0), pre);
+    }
+    for (unsigned long long o0 = 0; o0 < nout; o0 += T) {
+        const int cnt = (int)((nout - o0) < (unsigned long long)T ? (nout - o0) : (unsigned long long)T);
+        auto qr = [&](unsigned j, unsigned &q, unsigned &rem) { const unsigned nn = r0 + j * P.fa; q = __umulhi(nn, P.fmagic); rem = nn - q * P.fb; };   // q relative to kb
+        const int nst = tile_nst(r0, cnt);   // table indices kb .. kb + ql + 3 (floor(x) = q + 1; taps q .. q + 3)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++) win[lane + 64 * u] = (float)pre[u] * P.scale;   // (cap >= 512)
+        for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output
+            const unsigned k = kb + (unsigned)j;
+            const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
+            win[j] = L > 0 ? (float)row[kc - 1] * P.scale : 0.f;
+        }
+        unsigned kb_n = kb + wc, r0_n = r0 + wd;
+        if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
+        if (o0 + T < nout) {
+            const unsigned long long left = nout - o0 - T;
+            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto compute = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;   // all 512 outputs exist: no predicates
+        {
+            unsigned q, rem;
+            qr((unsigned)lane, q, rem);
+#pragma unroll
+            for (int u = 0; u < E; u++, q += P.dq256, rem += P.dr256) {   // (dq256 / dr256 hold the step of 64 outputs here)
+                const int idx = lane + 64 * u;
+                if (rem >= P.fb) { rem -= P.fb; q++; }
+                if (FULL || idx < cnt) {
+                    const float *tp = win + q;   // tp[0] = p0 (index kb + q), tp[1] = p1 = data[floor(x)]
+                    const float fx = (float)rem * P.inv_b;
+                    float v;
+                    if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = fmaf(tp[2] - tp[1], fx, tp[1]);
+                    else {
+                        const float p0 = tp[0], p1 = tp[1], p2 = tp[2], p3 = tp[3];
+                        const float c3 = fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
+                        const float c2 = fmaf(-0.5f, p3, fmaf(2.0f, p2, fmaf(-2.5f, p1, p0)));
+                        const float c1 = 0.5f * (p2 - p0);
+                        v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
+                    }
+                    xb[skew(idx)] = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);   // :667-668 (rem == 0: v is p1 itself)
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // lane ↔ E consecutive outputs: the recurrence from a zero state, then the state it really started from
+        const int e0 = lane * E;
+        double z[E];
+        {
+            double xp = (e0 == 0) ? carry_x : ((FULL || e0 <= cnt) ? (double)xb[skew(e0 - 1)] : 0.0);
+            const bool first = o0 == 0 && lane == 0;
+            double y = 0.0;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const double xv = (FULL || e0 + i < cnt) ? (double)xb[skew(e0 + i)] : xp;
+                if (i == 0 && first) y = xv;                               // y[1] = x[1]: the first sample passes  (:3592, :3612)
+                else if constexpr (HP) y = P.coef * (y + xv - xp);              // :3614
+                else y = y + P.coef * (xv - y);                                 // :3594
+                xp = xv;
+                z[i] = y;
+            }
+        }
+        // Y_t = z_t[E - 1] + M Y_(t-1): inclusive scan over the wave, Y_(-1) = the tile's carry
+        double Y = z[E - 1];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double up = __shfl_up(Y, 1 << k);
+            if (lane >= (1 << k)) Y = Y + Md[k] * up;
+        }
+        Y = Y + mlane * carry_y;                       // true state after this lane's last output
+        double yin = __shfl_up(Y, 1);
+        if (lane == 0) yin = carry_y;
+        float res[E];
+        double ylast = 0.0;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const double yv = z[i] + mp[i + 1] * yin;
+            res[i] = (float)yv;
+            if (FULL || e0 + i < cnt) mxf = fmaxf(mxf, fabsf(res[i]));
+            if (!FULL && e0 + i == cnt - 1) ylast = yv;
+        }
+        // the lane that holds the tile's last output hands its state to the next tile
+        if constexpr (FULL) carry_y = __shfl(Y, 63);
+        else carry_y = __shfl(ylast, (cnt - 1) / E);
+        carry_x = (double)xb[skew(cnt - 1)];
+        if (FULL || e0 < cnt) {
+            float *op = orow + o0 + (unsigned)e0;
+            if (FULL || e0 + E <= cnt) {
+                reinterpret_cast<float4 *>(op)[0] = make_float4(res[0], res[1], res[2], res[3]);
+                reinterpret_cast<float4 *>(op)[1] = make_float4(res[4], res[5], res[6], res[7]);
+            } else {
+                for (int i = 0; i < E && e0 + i < cnt; i++) op[i] = res[i];
+            }
+        }
+        };
+        if (cnt == T) compute(std::true_type{}); else compute(std::false_type{});
+        kb = kb_n; r0 = r0_n;
+    }
+    for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
+    if (lane == 0) P.rowmax[r] = (unsigned long long)__double_as_longlong((double)mxf);   // the largest |stored value|, as k_onepole reports it
+}
+
+// ---------------------------------------------------------------- the lazy state
+// gives the rows' buffer back to the context (when its own scratch is empty or smaller) or frees it; clears the state
+void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
+    a->lazy_rs = false;
+    if (a->lazy_rows.p) {
+        if (ctx && ctx->tmp_buf.cap < a->lazy_rows.cap) { ctx->tmp_buf.release(); ctx->tmp_buf = a->lazy_rows; a->lazy_rows = DevBuf{}; }
+        else a->lazy_rows.release();
+    }
+    a->lazy_row_off.clear(); a->lazy_row_len.clear();
+}
+
+// the owed resample with the ordinary kernel, into the audio's own rows
+int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
+    if (!a->lazy_rs) return AUKIT_OK;
+    if (!ctx) ctx = a->lazy_ctx;
+    if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred resample and no context to run it with");
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    // the rows move back into the context's scratch: the wave kernels of audio_from_int_rows take them from there
+    ctx->tmp_buf.release();
+    ctx->tmp_buf = a->lazy_rows;
+    a->lazy_rows = DevBuf{};
+    a->lazy_rs = false;
+    const std::vector<uint64_t> ro = a->lazy_row_off, rl = a->lazy_row_len;
+    aukit_audio *self = a;
+    return audio_from_int_rows(ctx, SRC_I32, ctx->tmp_buf.p, ro, rl, a->n, a->channels, a->lazy_rate, a->rate, a->lazy_interp, true, AUKIT_F32, a->lazy_full, a->lazy_full, &self);
+}
+
+// after the decoder has left int32 rows in ctx->tmp_buf: shape *out as the resampled audio and leave the resample owed.  false: not this shape
+bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
+                       double full, aukit_audio **out, int *rc) {
+    *rc = AUKIT_OK;
+    if (getenv("AUKIT_NO_TAIL_FUSION") || ctx->exact_math || (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) || n == 0) return false;
+    FastParams F;
+    if (!fast_eligible(SRC_I32, interp, rate, new_rate, F)) return false;
+    int e = 0;
+    if (std::frexp(full, &e) != 0.5 || full > 16777216.0) return false;   // v / full must be an exact f32 operation (as fast_try asks)
+    const double ratio = new_rate / rate;
+    std::vector<uint64_t> lens(n);
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t Ls = row_len[(size_t)s * C];
+        for (int c = 1; c < C; c++) if (row_len[(size_t)s * C + c] != Ls) return false;
+        const double nl = (double)Ls * ratio;
+        lens[s] = nl >= 1 ? (uint64_t)std::floor(nl) : 0;                   // newlen uses #data[1]  :659
+        if (Ls == 0 || lens[s] == 0) return false;                          // (the ordinary path has the reference's answers for empty rows)
+        if (std::floor(((double)(lens[s] - 1)) / ratio + 1) > (double)Ls) return false;
+    }
+    aukit_audio *a = *out;
+    if ((*rc = audio_prepare(ctx, &a, n, C, new_rate, AUKIT_F32, lens.data()))) return true;
+    *out = a;
+    a->lazy_rows.release();
+    a->lazy_rows = ctx->tmp_buf;     // the rows leave the context's scratch with the audio: nothing can overwrite them
+    ctx->tmp_buf = DevBuf{};
+    a->lazy_row_off = row_off; a->lazy_row_len = row_len;
+    a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx;
+    a->lazy_rs = true;
+    ctx->last_kernel = "(resample deferred)";
+    return true;
+}
+
+// effects.highpass / lowpass on an audio whose resample is owed: both in one pass.  false: not taken (the caller materialises and filters)
+bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc) {
+    *rc = AUKIT_OK;
+    if (!a->lazy_rs || a->dtype != AUKIT_F32) return false;
+    FastParams F;
+    if (!fast_eligible(SRC_I32, a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
+    constexpr int T = 512;
+    if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;   // exact (q, rem) inside a tile
+    const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3);
+    const size_t lds = ((size_t)cap + T + T / 8 + 8) * 4;
+    if (lds > 60 * 1024) return false;
+    for (uint64_t l : a->lazy_row_len) if (l > 0x7FFFFFF0ull) return false;
+    if ((*rc = audio_rowmax_ensure(a))) return true;
+    if (hipSetDevice(ctx->device) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipSetDevice failed"); return true; }
+    const size_t rows = (size_t)a->n * a->channels;
+    std::vector<uint64_t> tab(a->lazy_row_off);
+    tab.insert(tab.end(), a->lazy_row_len.begin(), a->lazy_row_len.end());
+    if ((*rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return true;
+    RsOnepoleParams P{};
+    P.rows = reinterpret_cast<const int *>(a->lazy_rows.p);
+    P.row_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
+    P.row_len = P.row_off + rows;
+    P.a_meta = reinterpret_cast<const unsigned long long *>(a->d_meta);
+    P.out = reinterpret_cast<float *>(a->dev);
+    P.rowmax = reinterpret_cast<unsigned long long *>(a->d_rowmax);
+    P.n = a->n; P.C = a->channels; P.cap = cap;
+    P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
+    P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
+    P.scale = (float)(1.0 / a->lazy_full);
+    P.coef = coef;
+    if ((*rc = ctx_begin_kernel(ctx))) return true;
+    const size_t ldsb = lds;
+    const dim3 grid((unsigned)rows);
+    if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false>), grid, dim3(64), ldsb, ctx->stream, P); }
+    else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false>), grid, dim3(64), ldsb, ctx->stream, P); }
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
+    uint64_t in_elems = 0, out_elems = 0;
+    for (uint64_t l : a->lazy_row_len) in_elems += l;
+    for (uint64_t l : a->len) out_elems += l * (uint64_t)a->channels;
+    a->rowmax_valid = true;
+    lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
+    *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_elems * 4 + out_elems * 4);
+    return true;
+}
+
+}  // namespace aukit

@@ -135,6 +135,7 @@ int audio_prepare(aukit_ctx *ctx, aukit_audio **out, uint32_t n, int channels, d
     if (channels < 1) return fail(AUKIT_E_ARG, "channels out of range");
     aukit_audio *a = *out;
     if (!a) a = new aukit_audio();
+    if (a->lazy_rs || a->lazy_rows.p) lazy_drop(ctx, a);   // an owed resample of the old contents is moot; its rows' buffer goes back to the context
     a->n = n; a->channels = channels; a->rate = rate; a->dtype = dtype;
     a->rowmax_valid = false;  // new contents are on their way
     a->pend_norm = false;
@@ -408,7 +409,7 @@ int aukit_audio_layout(const aukit_audio *a, uint64_t *lens, uint64_t *row_off, 
 }
 void *aukit_audio_device_ptr(const aukit_audio *a) {
     if (!a) return nullptr;
-    if (a->pend_norm && audio_flush(a->pend_ctx, a)) return nullptr;  // the caller reads the samples: a deferred map is applied first
+    if ((a->pend_norm || a->lazy_rs) && audio_flush(a->pend_norm ? a->pend_ctx : a->lazy_ctx, a)) return nullptr;  // the caller reads the samples: deferred work is done first
     const_cast<aukit_audio *>(a)->rowmax_valid = false;              // ... and may write them
     return a->dev;
 }
@@ -497,6 +498,7 @@ void aukit_audio_free(aukit_audio *a) {
     if (a->dev) (void)hipFree(a->dev);
     if (a->d_meta) (void)hipFree(a->d_meta);
     if (a->d_rowmax) (void)hipFree(a->d_rowmax);
+    a->lazy_rows.release();
     delete a;
 }
 

@@ -81,8 +81,10 @@ def test_flac_blocksizes_and_config5_pipeline(ctx, oracle):
     ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(s), 48000, oracle.CUBIC), 20.0), 0.8))
     assert np.max(np.abs(m[0][0] - ref.data[0])) <= 1e-11 and np.array_equal(m[0][0], m[1][0])
     a32 = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_FLAC), 48000, "cubic", dtype=N.F32)
-    assert ctx.last_kernel()[0].startswith("k_fast_wave<i32")  # F32 pipelines resample the int32 rows with the f32 tolerance kernel
-    assert rms(a32.download()[0][1], oracle.resample(oracle.flac(s), 48000, oracle.CUBIC).data[1]) <= 1e-6
+    assert ctx.last_kernel()[0] == "(resample deferred)"       # F32 pipelines: the resample is owed (flac_tail.hip) ...
+    a32_rows = a32.download()
+    assert ctx.last_kernel()[0].startswith("k_fast_wave<i32")  # ... and a reader materialises it from the int32 rows with the f32 tolerance kernel
+    assert rms(a32_rows[0][1], oracle.resample(oracle.flac(s), 48000, oracle.CUBIC).data[1]) <= 1e-6
     for depth, interp in ((24, "linear"), (8, "cubic")):
         p = _pcm(30000, 2, depth, 5, 3)
         sd = oracle.gen_flac(p.ravel(), 2, depth, 44100, 4096)
@@ -153,3 +155,73 @@ def test_stream_flac_f32_tail(ctx, oracle, rate, bs):
             for c in range(ref.channels):
                 assert rms(got[c] / 128, ref.data[c] / 128) <= 1e-6, (interp, c)
                 assert np.max(np.abs(got[c] - ref.data[c]), initial=0) <= 128e-4, (interp, c)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("rate,ch,bs", [(44100, 2, 4096), (22050, 1, 1152), (8000, 2, 576), (48000, 2, 4096)])
+def test_deferred_resample_fused_into_the_filter_pass(ctx, oracle, monkeypatch, rate, ch, bs, interp):
+    """config 5's tail, round 3 (flac_tail.hip): aukit_decode_resample on FLAC with F32 storage leaves the resample OWED (the decoder's int32 rows
+    move into the audio); effects.highpass / lowpass pay it inside their own pass (k_rs_onepole: same f32 interpolation as k_fast_wave<i32>, the
+    recurrence in fp64 with an affine carry scan), every other reader materialises it with the ordinary kernel.  Observable results: the
+    materialised rows are bit-identical to the eager path (AUKIT_NO_TAIL_FUSION=1); the fused filter agrees with resample-then-filter to a few f32
+    ulps (another scan decomposition) and with the oracle to 1e-6 RMS; per-row maxima feed effects.normalize as before."""
+    B, N = _B(), _N()
+    lens = (rate * 2 + 777, bs * 3, 4097, 700, 2100)
+    streams = []
+    for i, n in enumerate(lens):
+        p = np.stack([pcm16(n, rate, 5, 2 * i + c) for c in range(ch)], 1).astype(np.int64)
+        streams.append(oracle.gen_flac(p.ravel(), ch, 16, rate, bs))
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_FLAC)
+
+    def chain(which):
+        a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
+        name0 = ctx.last_kernel()[0]
+        if which == "download":
+            return a.download(), name0
+        if which == "mono":
+            return B.mono(ctx, a).download(), name0
+        if which == "amplify":
+            B.effect(ctx, a, "amplify", 0.5)
+            return a.download(), name0
+        B.effect(ctx, a, which, 300.0 if which == "lowpass" else 20.0)
+        name1 = ctx.last_kernel()[0]
+        B.effect(ctx, a, "normalize", 0.8)
+        return (a.download(), B.mono(ctx, a).download()), (name0, name1)
+
+    for which in ("download", "mono", "amplify"):
+        got, name = chain(which)
+        assert name == "(resample deferred)", name
+        monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
+        plain, name_p = chain(which)
+        monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
+        assert name_p.startswith(("k_fast_wave<", "k_resample<")), name_p
+        for s in range(len(streams)):
+            for c in range(len(got[s])):
+                assert np.array_equal(got[s][c], plain[s][c]), (which, s, c)
+    for which in ("highpass", "lowpass"):
+        (rows, mono), (n0, n1) = chain(which)
+        assert n0 == "(resample deferred)" and n1 == "k_rs_onepole<" + which + ">", (n0, n1)
+        monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
+        (rows_p, mono_p), (p0, p1) = chain(which)
+        monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
+        assert p1.startswith("k_onepole<"), p1
+        for s_i, s in enumerate(streams):
+            ref = oracle.resample(oracle.flac(s), 48000, oracle.INTERP[interp])
+            ref = oracle.fx_highpass(ref, 20.0) if which == "highpass" else oracle.fx_lowpass(ref, 300.0)
+            ref = oracle.fx_normalize(ref, 0.8)
+            for c in range(ch):
+                assert len(rows[s_i][c]) == len(ref.data[c])
+                assert np.max(np.abs(rows[s_i][c] - rows_p[s_i][c]), initial=0) <= 4e-7, (which, s_i, c)
+                assert rms(rows[s_i][c], ref.data[c]) <= 1e-6, (which, s_i, c)
+            assert np.max(np.abs(mono[s_i][0] - mono_p[s_i][0]), initial=0) <= 4e-7
+            assert rms(mono[s_i][0], oracle.mono(ref).data[0]) <= 1e-6
+    # the output audio reused for the next decode gives the rows' buffer back (no growth), and a deferred audio can be cloned / freed
+    a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
+    a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32, out=a)
+    b = a.clone()
+    want = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+    for s in range(len(streams)):
+        for c in range(ch):
+            assert rms(b.download()[s][c], want[s][c]) <= 1e-6
+    a.free()
