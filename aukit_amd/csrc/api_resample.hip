@@ -221,11 +221,20 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int frc = AUKIT_OK;
         if (aligned4 && fast_try(ctx, SRC_PCM_S16LE_STEREO, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &frc)) return frc;
     }
+    // every other interleaved format of one or two channels: decode + resample in one launch (fast_fmt.hip).  A float string gets the
+    // reference-order kernel queued behind it, to run only if a sample beyond ±1 was met (see fast_fmt.hip)
+    const int *only_if = nullptr;
+    if (do_resample && dtype == AUKIT_F32 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+        int frc = AUKIT_OK;
+        if (fast_fmt_try(ctx, d, interp, new_rate, segs, P, in_bytes + out_elems * 4, &frc, &only_if)) {
+            if (frc || !only_if) return frc;
+        }
+    }
     // (only for formats whose samples lie in [-1, 1] — signed of any depth, 8-bit unsigned: where the reference's rounded position x misses an
     // integer it interpolates and CLAMPS (:667-668) what the exact rational position copies unclamped, and that shows on samples beyond ±1:
     // unsigned 16 / 24 / 32-bit (Q4 reaches 2) and float strings keep the reference-order kernel)
     if (do_resample && dtype == AUKIT_F32 && d->codec == AUKIT_CODEC_PCM && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) &&
-        (d->data_type == AUKIT_SIGNED || (d->data_type == AUKIT_UNSIGNED && d->bit_depth == 8)) && !getenv("AUKIT_NO_FAST_CONVERT")) {
+        (d->data_type == AUKIT_SIGNED || (d->data_type == AUKIT_UNSIGNED && d->bit_depth == 8)) && !only_if && !getenv("AUKIT_NO_FAST_CONVERT")) {
         // every other PCM format with a resample behind it, F32 tolerance path: unpacked to one f32 row per channel (k_pcm_unpack), then the f32
         // wave kernel on the rows — what stream.pcm does for these formats.  (k_resample moved 145-210 G samples/s on 24-bit stereo / float.)
         std::vector<UnpackRow> ur((size_t)in->n * C);
@@ -298,6 +307,16 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
     }
     size_t lds;
     if ((rc = plan_tiles(ctx, segs, ratio, do_resample ? interp : AUKIT_INTERP_NONE, C, P, &lds))) return rc;
+    if (only_if) {  // the conditional redo behind k_fast_wave_fmt: the call is still named after the kernel that (normally) did the work
+        const std::string nm = ctx->last_kernel;
+        const float ms = ctx->last_ms;
+        P.only_if = only_if;
+        rc = launch_resample(ctx, src, interp, EPI_AUDIO, dtype, P, lds, 0, nullptr);
+        ctx->last_kernel = nm;
+        ctx->last_ms += ms;
+        ctx->last_bytes = in_bytes + out_elems * dtype_size(dtype);
+        return rc;
+    }
     return launch_resample(ctx, src, do_resample ? interp : AUKIT_INTERP_NONE, EPI_AUDIO, dtype, P, lds, in_bytes + out_elems * dtype_size(dtype), nullptr);
 }
 

@@ -67,7 +67,8 @@ struct ResampleParams {
     int out_channels;  // EPI_STREAM_DFPWM: rows written per output
     int nt_store;      // fast kernels: non-temporal output stores (tuning knob AUKIT_NT_STORE)
     int table;         // SRC_PCM_GENERIC: the "string" is a Lua TABLE of numbers (doubles, 8 bytes each: aukit.lua:2255-2290), read as they are
-                       // (last member: the offsets of everything the wave kernels read stay what they were)
+                       // (last members: the offsets of everything the wave kernels read stay what they were)
+    const int *only_if;// k_resample: non-null → the launch does nothing unless *only_if != 0 (fast_fmt.hip's flag: a float string with samples beyond ±1)
 };
 
 // launches the right instantiation; `name` receives a static string naming the kernel
@@ -107,6 +108,8 @@ int launch_fast_wave_stream_s16x2(aukit_ctx *ctx, int interp, int nv, const Resa
 int launch_fast_wave_coef(aukit_ctx *ctx, int src_kind, int interp, int nv, int win, const ResampleParams &P, const FastParams &F, unsigned grid);
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken);
+bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
+                  uint64_t algorithmic_bytes, int *rc, const int **only_if);  // fast_fmt.hip: every other interleaved PCM format / G.711 stereo, one launch
 bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
               uint64_t algorithmic_bytes, int *rc, int epi = 0, double alpha = 0);
 

@@ -9,6 +9,7 @@
 #include "resample.h"
 #include "resample_dev.h"
 
+#define AUKIT_CONST_AS_I __attribute__((address_space(4)))
 namespace aukit {
 
 // ------------------------------------------------------------------ sample decoding
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void k_resample(const ResampleParams P) {
     const int rows_per_wave = P.tile_out >> 8;  // tile_out / 64 rows, 4 waves
     const int halo_l = P.halo_l, halo_r = P.halo_r;
     OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
+    if (P.only_if && *(const AUKIT_CONST_AS_I int *)P.only_if == 0) return;  // a conditional redo (fast_fmt.hip) that is not needed
 
     for (unsigned t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
         unsigned sidx, tin;

@@ -101,13 +101,84 @@ def test_pcm_formats_resample_f32_through_rows(ctx, oracle, bits, dtype, be, ch,
     desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dtype, big_endian=be, interleaved=interleaved)
     got = B.decode_resample(ctx, bt, desc, new_rate, "cubic", dtype=N.F32).download()
     in_range = dtype == "signed" or (dtype == "unsigned" and bits == 8)  # samples within [-1, 1]: the only formats the rows path takes (see api_resample.hip)
-    assert ctx.last_kernel()[0].startswith(("k_fast_wave<audio_f32", "k_fast_resample<audio_f32") if in_range else "k_resample<"), ctx.last_kernel()
+    one_launch = interleaved and ch <= 2 and (in_range or dtype == "float")   # fast_fmt.hip
+    assert ctx.last_kernel()[0].startswith("k_fast_wave_fmt<" if one_launch else ("k_fast_wave<audio_f32", "k_fast_resample<audio_f32") if in_range else "k_resample<"), ctx.last_kernel()
     for s, g in zip(streams, got):
         ref = oracle.resample(oracle.pcm(s, bits, oracle.DTYPE[dtype], ch, rate, interleaved, be), new_rate, oracle.CUBIC)
         for c in range(ch):
             assert len(g[c]) == len(ref.data[c])
             if len(g[c]):
                 assert rms(g[c], ref.data[c]) <= 1e-6, c
+
+
+@pytest.mark.parametrize("bits,dtype,be", [(8, "signed", False), (8, "unsigned", False), (16, "signed", True), (24, "signed", False), (24, "signed", True),
+                                           (32, "signed", False), (32, "signed", True), (32, "float", False), (32, "float", True)])
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("rate,new_rate,interp", [(44100, 48000, "cubic"), (8000, 48000, "linear"), (48000, 44100, "linear"), (96000, 48000, "cubic"), (48000, 48000, "cubic")])
+def test_pcm_formats_decode_and_resample_in_one_launch(ctx, oracle, bits, dtype, be, ch, rate, new_rate, interp):
+    """k_fast_wave_fmt (fast_fmt.hip): every interleaved format of one or two channels, decode + resample fused, F32 storage: ≤ 1e-6 RMS from
+    the oracle.  Ragged streams (odd byte offsets for the odd frame sizes), one frame, none."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(977 + bits + ch))
+    streams = []
+    for frames in (3001, 1, 20001, 0, 777):
+        if dtype == "float":
+            streams.append(rng.uniform(-1, 1, frames * ch).astype(">f4" if be else "<f4").tobytes())
+        else:
+            streams.append(rng.integers(0, 256, frames * ch * (bits // 8), dtype=np.uint8).tobytes())
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dtype, big_endian=be)
+    got = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F32).download()
+    name = ctx.last_kernel()[0]
+    special = (bits == 16 and not be and dtype == "signed") or (bits == 8 and ch == 1)   # the specialised kernels keep their formats
+    served = not (rate >= 2 * new_rate and (bits // 8) * ch >= 4)   # the tile's raw window + tables fit 64 KiB of LDS per workgroup (stronger down-sampling of wide frames: the older paths)
+    if served: assert name.startswith("k_fast_wave") and (special or name.startswith("k_fast_wave_fmt<")), name
+    for s, g in zip(streams, got):
+        ref = oracle.resample(oracle.pcm(s, bits, oracle.DTYPE[dtype], ch, rate, True, be), new_rate, oracle.INTERP[interp])
+        for c in range(ch):
+            assert len(g[c]) == len(ref.data[c])
+            if len(g[c]):
+                assert rms(g[c], ref.data[c]) <= 1e-6, (c, name)
+                assert np.max(np.abs(g[c] - ref.data[c])) <= 2e-6, (c, name)
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("rate,new_rate", [(44100, 48000), (22050, 48000), (48000, 48000)])
+def test_float_strings_beyond_one_fall_back_to_the_reference_order(ctx, oracle, ch, rate, new_rate):
+    """A float string may hold samples beyond ±1: where the reference's rounded position misses an integer it clamps what an exact position
+    copies.  The fused kernel flags such input and the reference-order kernel queued behind it redoes the call: the result is the oracle's."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(31 + ch))
+    wild = (rng.uniform(-1, 1, 30000 * ch) * 3).astype("<f4")
+    tame = rng.uniform(-1, 1, 30000 * ch).astype("<f4")
+    one = tame.copy(); one[12345] = 1.5
+    for raw, flagged in ((wild, True), (tame, False), (one, True)):
+        bt = B.Batch.upload(ctx, [tame.tobytes(), raw.tobytes()])
+        desc = B.make_desc(N.CODEC_PCM, ch, rate, 32, "float")
+        got = B.decode_resample(ctx, bt, desc, new_rate, "cubic", dtype=N.F32).download()
+        assert ctx.last_kernel()[0].startswith("k_fast_wave_fmt<float32"), ctx.last_kernel()
+        for s, g in zip((tame, raw), got):
+            ref = oracle.resample(oracle.pcm(s.tobytes(), 32, oracle.DTYPE["float"], ch, rate, True, False), new_rate, oracle.CUBIC)
+            for c in range(ch):
+                assert np.max(np.abs(g[c] - ref.data[c])) <= (1e-6 if flagged else 2e-6), (c, flagged)
+
+
+@pytest.mark.parametrize("ulaw", [True, False])
+@pytest.mark.parametrize("rate,new_rate,interp", [(8000, 48000, "cubic"), (8000, 44100, "linear"), (16000, 8000, "cubic")])
+def test_g711_stereo_decode_and_resample_in_one_launch(ctx, oracle, ulaw, rate, new_rate, interp):
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(6))
+    streams = [rng.integers(0, 256, n * 2, dtype=np.uint8).tobytes() for n in (8000, 8000 * 2 + 1235, 17, 1, 0)]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_G711, 2, rate, ulaw=ulaw)
+    res = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F32).download()
+    assert ctx.last_kernel()[0].startswith("k_fast_wave_fmt<" + ("ulaw" if ulaw else "alaw")), ctx.last_kernel()
+    for s, r in zip(streams, res):
+        refr = oracle.resample(oracle.g711(s, ulaw, 2, rate), new_rate, oracle.INTERP[interp])
+        for c in range(2):
+            assert len(r[c]) == len(refr.data[c])
+            if len(r[c]):
+                assert np.max(np.abs(r[c] - refr.data[c])) <= 1e-6
 
 
 @pytest.mark.parametrize("rate,new_rate", [(48000, 48000), (44100, 44100), (96000, 48000), (48000, 24000)])
@@ -237,7 +308,7 @@ def test_stream_pcm_mono16_f32_wave_kernel(ctx, oracle, rate, interp):
     ctx.set_option(N.OPT_EXACT_MATH, 1)
     try:
         out2, ck2 = B.stream_decode(ctx, bt, desc, interp, dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<"))  # reference-order fp64 (wave tiles when the rates allow)
+        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<", "k_wave_f64<"))  # fp64 arithmetic (round 3: wave_f64.hip's stream.pcm epilogue; reference-order kernels where it does not apply)
         got2 = out2.download()
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
@@ -307,7 +378,7 @@ def test_stream_pcm_other_formats_f32_wave_kernels(ctx, oracle, bits, dt, be, ch
     ctx.set_option(N.OPT_EXACT_MATH, 1)
     try:
         out2, _ = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<")), ctx.last_kernel()
+        assert ctx.last_kernel()[0].startswith(("k_resample<", "k_exact_wave<", "k_wave_f64<")), ctx.last_kernel()
         got2 = out2.download()
     finally:
         ctx.set_option(N.OPT_EXACT_MATH, 0)
