@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
         __builtin_amdgcn_wave_barrier();
         // ---- samples → one f32 table per channel
         const int ne = cur.n_stage * C;
+#pragma unroll 4
         for (int e = lane; e < ne; e += 64) {
             const unsigned off = (unsigned)cur.head + (unsigned)e * B;
             const unsigned w0 = raw[off >> 2], w1 = raw[(off >> 2) + 1];

@@ -90,6 +90,27 @@ def test_reverb(ctx, oracle):
     assert np.max(np.abs(ab.download()[0][1] - ref.data[1])) <= 1e-13
 
 
+@pytest.mark.parametrize("rate,args,fused", [(48000, (100.0, 0.3, 1.0, 0.0), True), (44100, (100.0, 0.3, 0.8, 0.2), True), (22050, (100.0, 0.3, 1.0, 0.0), True),
+                                             (48000, (60.0, 0.45, 0.7, 0.3), True), (48000, (130.0, 0.3, 1.0, 0.0), True), (48000, (250.0, 0.3, 1.0, 0.0), False), (96000, (100.0, 0.3, 1.0, 0.0), False),
+                                             (8000, (100.0, 0.3, 1.0, 0.0), False), (48000, (700.0, 0.3, 1.0, 0.0), False)])
+def test_reverb_f32_in_one_pass(ctx, oracle, rate, args, fused):
+    """effects.reverb on an F32 audio: k_reverb_f32 (four comb rings + the all-pass ring in LDS, one pass over the row) within 1e-6 RMS of
+    the oracle; rates / delays whose state does not fit (or whose lags are shorter than a block) keep the multi-launch path."""
+    B, N = _B(), _N()
+    S = int(np.floor(0.08927 * rate))
+    lens = (rate * 2 + 17, S + 1, S + 2, S + 5000, 3 * S)
+    a = [[signal(n, rate, 2, 2 * i + c).astype(np.float32).astype(np.float64) for c in range(2)] for i, n in enumerate(lens)]
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F32)
+    B.effect(ctx, ab, "reverb", *args)
+    assert (ctx.last_kernel()[0] == "k_reverb_f32") == fused, ctx.last_kernel()
+    got = ab.download()
+    for s in range(len(a)):
+        ref = oracle.fx_reverb(oracle.Audio(a[s], rate), *args)
+        for c in range(2):
+            assert rms(got[s][c], ref.data[c]) <= 1e-6, (s, c)
+            assert np.max(np.abs(got[s][c] - ref.data[c])) <= 4e-6, (s, c)
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("rate", [224.5, 230, 235, 236, 300])
 def test_reverb_at_low_sample_rates(ctx, oracle, rate):

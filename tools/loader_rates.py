@@ -28,7 +28,7 @@ sec = 10
 base = [np.stack([pcm16(44100 * sec, 44100, 8, 4 * i + c) for c in range(2)], 1).ravel() for i in range(4)]
 for bits, dt, ch in ((16, "signed", 2), (8, "unsigned", 1), (24, "signed", 2), (32, "float", 1), (16, "signed", 1)):
     nbytes = 44100 * sec * ch * bits // 8
-    bt = B.Batch.upload(ctx, [rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes() if dt != "float" else rng.standard_normal(44100 * sec * ch).astype("<f4").tobytes()] * n)
+    bt = B.Batch.upload(ctx, [rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes() if dt != "float" else rng.uniform(-1, 1, 44100 * sec * ch).astype("<f4").tobytes()] * n)
     rate(f"pcm {bits}-bit {dt} {ch}ch", bt, B.make_desc(N.CODEC_PCM, ch, 44100, bits, dt), 44100 * sec * ch, 44100)
     del bt
 bt = B.Batch.upload(ctx, [rng.integers(0, 256, 80000 * 2, dtype=np.uint8).tobytes()] * n)
