@@ -224,7 +224,7 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
     // every other interleaved format of one or two channels: decode + resample in one launch (fast_fmt.hip).  A float string gets the
     // reference-order kernel queued behind it, to run only if a sample beyond ±1 was met (see fast_fmt.hip)
     const int *only_if = nullptr;
-    if (do_resample && dtype == AUKIT_F32 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+    if (do_resample && dtype == AUKIT_F32 && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
         int frc = AUKIT_OK;
         if (fast_fmt_try(ctx, d, interp, new_rate, segs, P, in_bytes + out_elems * 4, &frc, &only_if)) {
             if (frc || !only_if) return frc;
@@ -301,7 +301,14 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         int wrc = AUKIT_OK;
         if (wave_coef_f64_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, in_bytes + out_elems * 4, &wrc)) return wrc;
     }
-    if (do_resample && C == 1 && src == SRC_PCM_S16LE_MONO) {  // reference-order fp64 on wave tiles (exact_wave.hip)
+    if (do_resample && dtype == AUKIT_F32 && ctx->exact_math == 1 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+        // every other interleaved format in fp64 arithmetic with an f32 store (fast_fmt.hip with doubles in its tables)
+        int frc = AUKIT_OK;
+        if (fast_fmt_try(ctx, d, interp, new_rate, segs, P, in_bytes + out_elems * 4, &frc, &only_if)) {
+            if (frc || !only_if) return frc;
+        }
+    }
+    if (do_resample && C == 1 && src == SRC_PCM_S16LE_MONO && !only_if) {  // reference-order fp64 on wave tiles (exact_wave.hip)
         int erc = AUKIT_OK;
         if (exact_wave_try(ctx, src, interp, d->sample_rate, new_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &erc)) return erc;
     }

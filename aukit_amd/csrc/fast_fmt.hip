@@ -27,14 +27,31 @@ struct FmtParams {
     float scale_pos, scale_neg;   // signed: 1 / (2^(bits-1) - 1), 1 / 2^(bits-1)   (:1133)
     float g711_scale;
     int *flag;                    // FMT_FLOAT: set when a staged sample is not inside [-1, 1]
+    // fp64 arithmetic (AUKIT_OPT_EXACT_MATH = 1): s / (2^(bits-1) - 1) as a correctly rounded double quotient (div_rcp), s * 2^-(bits-1) exact
+    double dpos, drcp, dneg, dg711, dinv_b;
 };
 
-template <int B>
-AUKIT_DEV float fmt_sample(unsigned raw, const FmtParams &M, bool &wild) {
+AUKIT_DEV int g711_int(unsigned byte, int ulaw) {   // aukit.lua:1371-1379 up to the division by 0x2000
+    unsigned b = byte ^ (ulaw ? 0xFFu : 0x55u);
+    int m = b & 15, e = (b >> 4) & 7;
+    if (!ulaw && e == 0) m = m * 4 + 2;
+    else m = (m * 2 + 33) << e;
+    if (ulaw) m -= 33;
+    const bool neg = ((b & 0x80) != 0) == (ulaw != 0);
+    return neg ? -m : m;
+}
+
+template <int B, typename AT>
+AUKIT_DEV AT fmt_sample(unsigned raw, const FmtParams &M, bool &wild) {
     // `raw`: the sample's B bytes in memory order, lowest address in the low byte
+    constexpr bool F64 = sizeof(AT) == 8;
+    int v;
     if constexpr (B == 1) {
-        if (M.kind == FMT_ULAW || M.kind == FMT_ALAW) return g711_f32b(raw & 0xFF, M.kind == FMT_ULAW, M.g711_scale);
-        return pcm8_f32(raw & 0xFF, M.kind == FMT_UNSIGNED8);
+        if (M.kind == FMT_ULAW || M.kind == FMT_ALAW) {
+            if constexpr (F64) return (AT)((double)g711_int(raw & 0xFF, M.kind == FMT_ULAW) * M.dg711);
+            else return (AT)g711_f32b(raw & 0xFF, M.kind == FMT_ULAW, M.g711_scale);
+        }
+        v = M.kind == FMT_UNSIGNED8 ? (int)(raw & 0xFF) - 128 : (int)(signed char)(raw & 0xFF);   // unsigned: s - 128, with s < 128 deciding the divisor — the same test as v < 0 (Q4)
     } else {
         unsigned u = raw;
         if (M.big_endian) {
@@ -46,12 +63,37 @@ AUKIT_DEV float fmt_sample(unsigned raw, const FmtParams &M, bool &wild) {
             if (M.kind == FMT_FLOAT) {
                 const float f = __uint_as_float(u);
                 wild = wild || !(fabsf(f) <= 1.0f);
-                return f;
+                return (AT)f;
             }
         }
-        const int v = (int)(u << (32 - 8 * B)) >> (32 - 8 * B);
-        return (float)v * (v < 0 ? M.scale_neg : M.scale_pos);
+        v = (int)(u << (32 - 8 * B)) >> (32 - 8 * B);
     }
+    if constexpr (F64) return (AT)(v < 0 ? (double)v * M.dneg : div_rcp((double)v, M.dpos, M.drcp));   // :1133
+    else return (AT)((float)v * (v < 0 ? M.scale_neg : M.scale_pos));
+}
+
+// one output in fp64: the Catmull-Rom polynomial (:261-266) as a Horner form on fx = rem * RN(1/b), every tap, product and sum a double
+// (the arithmetic of wave_f64.hip's table-less variant); rounded to f32, then :667-668
+template <int INTERP>
+AUKIT_DEV float interp_qr_f64(const double *tab, unsigned q, unsigned rem, double inv_b) {
+    const double fx = (double)rem * inv_b;
+    const double p1 = tab[q], p2 = tab[q + 1];
+    double v;
+    if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
+    else {
+        const double p0 = tab[(int)q - 1], p3 = tab[q + 2];
+        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+        const double c2 = __builtin_fma(-0.5, p3, __builtin_fma(2.0, p2, __builtin_fma(-2.5, p1, p0)));
+        const double c1 = 0.5 * (p2 - p0);
+        v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+    }
+    const float c = __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);
+    return rem == 0 ? (float)p1 : c;
+}
+template <int INTERP, typename AT>
+AUKIT_DEV float interp_any(const FastParams &F, const FmtParams &M, const AT *tab, unsigned q, unsigned rem) {
+    if constexpr (sizeof(AT) == 8) return interp_qr_f64<INTERP>(tab, q, rem, M.dinv_b);
+    else return interp_qr<SRC_AUDIO_F32, INTERP>(F, tab, q, rem);
 }
 
 template <int FB, int HL, int HR>
@@ -81,7 +123,7 @@ AUKIT_DEV WaveTile describe_fmt(const ResampleParams &P, const FastParams &F, un
     return w;
 }
 
-template <int B, int C, int INTERP, int NV>
+template <int B, int C, int INTERP, int NV, typename AT>
 __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, const FastParams F, const FmtParams M) {
     extern __shared__ float smf[];
     constexpr int FB = B * C;
@@ -89,8 +131,9 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
     constexpr int RAWW = NV * 64 * 4 + 4;               // dwords of raw window per wave (+ one vector: the second dword of the last sample)
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned *const raw = reinterpret_cast<unsigned *>(smf) + wave * (unsigned)(RAWW + C * F.cap);
-    float *const tab0 = reinterpret_cast<float *>(raw + RAWW);
+    constexpr unsigned AW = sizeof(AT) / 4;                 // dwords per table entry
+    unsigned *const raw = reinterpret_cast<unsigned *>(smf) + wave * (unsigned)(RAWW + C * F.cap * AW);
+    AT *const tab0 = reinterpret_cast<AT *>(raw + RAWW);
     const unsigned nwaves = gridDim.x * 4u;
     const unsigned lane_a = (unsigned)lane * F.a;
     bool wild = false;
@@ -104,7 +147,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
         unsigned u = 0;
 #pragma unroll
         for (int b = 0; b < B; b++) u |= (unsigned)q[b] << (8 * b);
-        return fmt_sample<B>(u, M, wild);
+        return fmt_sample<B, AT>(u, M, wild);
     };
     for (;;) {
         __builtin_amdgcn_wave_barrier();
@@ -124,7 +167,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
             const unsigned w0 = raw[off >> 2], w1 = raw[(off >> 2) + 1];
             const unsigned u = B == 4 ? __builtin_amdgcn_alignbyte(w1, w0, off & 3) : (__builtin_amdgcn_alignbyte(w1, w0, off & 3) & ((1u << (8 * (B & 3))) - 1u));
             const int f = C == 1 ? e : e >> 1, c = C == 1 ? 0 : e & 1;
-            tab0[c * F.cap + f] = fmt_sample<B>(u, M, wild);
+            tab0[c * F.cap + f] = fmt_sample<B, AT>(u, M, wild);
         }
         {
             const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
@@ -135,7 +178,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                     const bool ok0 = v0 >= P.safe_lo && v0 + 16 <= P.safe_hi, ok1 = v1 >= P.safe_lo && v1 + 16 <= P.safe_hi;
                     if (!(ok0 && ok1)) {
                         const int f = C == 1 ? e : e >> 1, c = C == 1 ? 0 : e & 1;
-                        tab0[c * F.cap + f] = (q >= P.safe_lo && q + B <= P.safe_hi) ? global_sample(q) : 0.f;
+                        tab0[c * F.cap + f] = (q >= P.safe_lo && q + B <= P.safe_hi) ? global_sample(q) : (AT)0;
                     }
                 }
             }
@@ -145,7 +188,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                 const unsigned char *q = cur.base + (long long)FB * cur.w_lo;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const float ev = global_sample(q + c * B);
+                    const AT ev = global_sample(q + c * B);
                     for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) tab0[c * F.cap + idx] = ev;
                 }
             }
@@ -154,7 +197,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                 const int first = cur.w_hi + 1 - cur.k_lo;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const float ev = global_sample(q + c * B);
+                    const AT ev = global_sample(q + c * B);
                     for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) tab0[c * F.cap + first + idx] = ev;
                 }
             }
@@ -172,7 +215,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
             nxt = describe_fmt<FB, HL, HR>(P, F, tn);
             issue_loads<NV>(P, nxt, lane, pre);  // in flight while this tile is interpolated
         }
-        const float *tabL = tab0 + HL, *tabR = tab0 + F.cap + HL;  // tab[q] = d[1 + kb + q]
+        const AT *tabL = tab0 + HL, *tabR = tab0 + F.cap + HL;  // tab[q] = d[1 + kb + q]
         float *orowL = cur.orow, *orowR = cur.orow + ostride;
         if (cur.cnt == (unsigned)WTF) {
             const unsigned n0 = cur.r0 + lane_a;
@@ -180,8 +223,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
             unsigned rem = n0 - q * F.b;
 #pragma unroll
             for (int r = 0; r < WTF / 64; r++) {
-                orowL[r * 64 + lane] = interp_qr<SRC_AUDIO_F32, INTERP>(F, tabL, q, rem);
-                if constexpr (C == 2) orowR[r * 64 + lane] = interp_qr<SRC_AUDIO_F32, INTERP>(F, tabR, q, rem);
+                orowL[r * 64 + lane] = interp_any<INTERP, AT>(F, M, tabL, q, rem);
+                if constexpr (C == 2) orowR[r * 64 + lane] = interp_any<INTERP, AT>(F, M, tabR, q, rem);
                 rem += F.dr64;
                 q += F.dq64;
                 const bool wrap = rem >= F.b;
@@ -194,10 +237,10 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                 const unsigned n = cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a;
                 const unsigned q = __umulhi(n, F.magic);
                 const unsigned rem = n - q * F.b;
-                const float vl = interp_qr<SRC_AUDIO_F32, INTERP>(F, tabL, q, rem);
+                const float vl = interp_any<INTERP, AT>(F, M, tabL, q, rem);
                 if (j < cur.cnt) orowL[j] = vl;
                 if constexpr (C == 2) {
-                    const float vr = interp_qr<SRC_AUDIO_F32, INTERP>(F, tabR, q, rem);
+                    const float vr = interp_any<INTERP, AT>(F, M, tabR, q, rem);
                     if (j < cur.cnt) orowR[j] = vr;
                 }
             }
@@ -211,16 +254,21 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
     }
 }
 
-template <int B, int C, int INTERP>
+template <int B, int C, int INTERP, typename AT>
 static void launch_fmt_nv(aukit_ctx *ctx, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
-    if (nv == 1) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
-    else if (nv == 8) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 8>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
-    else hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 4>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    if (nv == 1) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 1, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    else if (nv == 8) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 8, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    else hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 4, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
 }
 template <int B, int C>
-static void launch_fmt_i(aukit_ctx *ctx, int interp, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
-    if (interp == AUKIT_INTERP_LINEAR) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR>(ctx, nv, P, F, M, lds, grid);
-    else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC>(ctx, nv, P, F, M, lds, grid);
+static void launch_fmt_i(aukit_ctx *ctx, int interp, bool f64, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
+    if (f64) {
+        if (interp == AUKIT_INTERP_LINEAR) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, double>(ctx, nv, P, F, M, lds, grid);
+        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, double>(ctx, nv, P, F, M, lds, grid);
+    } else {
+        if (interp == AUKIT_INTERP_LINEAR) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, float>(ctx, nv, P, F, M, lds, grid);
+        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, float>(ctx, nv, P, F, M, lds, grid);
+    }
 }
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
@@ -231,7 +279,8 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
 bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
                   uint64_t algorithmic_bytes, int *rc, const int **only_if) {
     *only_if = nullptr;
-    if (ctx->exact_math || getenv("AUKIT_NO_FAST_FMT")) return false;
+    if (ctx->exact_math > 1 || getenv("AUKIT_NO_FAST_FMT")) return false;
+    const bool f64 = ctx->exact_math == 1;   // fp64 arithmetic, f32 store
     const int C = d->channels;
     if (C != 1 && C != 2) return false;
     FmtParams M;
@@ -241,6 +290,7 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
         B = 1;
         M.kind = P.ulaw ? FMT_ULAW : FMT_ALAW;
         M.g711_scale = (float)P.g711_scale;
+        M.dg711 = P.g711_scale;
     } else if (d->codec == AUKIT_CODEC_PCM) {
         B = d->bit_depth / 8;
         if (B < 1 || B > 4 || P.planar) return false;
@@ -252,6 +302,7 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
         const double full = (double)(1ull << (8 * B - 1));
         M.scale_pos = (float)(1.0 / (full - 1));
         M.scale_neg = (float)(1.0 / full);
+        M.dpos = full - 1; M.drcp = 1.0 / (full - 1); M.dneg = 1.0 / full;
     } else return false;
     FastParams F;
     if (!fast_eligible(SRC_AUDIO_F32, interp, d->sample_rate, new_rate, F)) return false;
@@ -272,7 +323,8 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
     F.cap = (win + 8 + 15) & ~15;
     F.dq64 = (unsigned)((64ull * F.a) / F.b);
     F.dr64 = (unsigned)((64ull * F.a) % F.b);
-    const size_t lds = 4 * ((size_t)(nv * 64 * 4 + 4) + (size_t)C * F.cap) * 4;
+    M.dinv_b = 1.0 / (double)F.b;
+    const size_t lds = 4 * ((size_t)(nv * 64 * 4 + 4) + (size_t)C * F.cap * (f64 ? 2 : 1)) * 4;
     if (lds > 64 * 1024) return false;
     if (M.kind == FMT_FLOAT) {
         if ((*rc = ctx->fmt_flag.ensure(64))) return true;
@@ -284,14 +336,14 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 16u);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     if (M.flag && hipMemsetAsync(M.flag, 0, 4, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
-#define AUKIT_FMT(BB, CC) launch_fmt_i<BB, CC>(ctx, interp, nv, P, F, M, lds, grid)
+#define AUKIT_FMT(BB, CC) launch_fmt_i<BB, CC>(ctx, interp, f64, nv, P, F, M, lds, grid)
     if (C == 1) { if (B == 1) AUKIT_FMT(1, 1); else if (B == 2) AUKIT_FMT(2, 1); else if (B == 3) AUKIT_FMT(3, 1); else AUKIT_FMT(4, 1); }
     else { if (B == 1) AUKIT_FMT(1, 2); else if (B == 2) AUKIT_FMT(2, 2); else if (B == 3) AUKIT_FMT(3, 2); else AUKIT_FMT(4, 2); }
 #undef AUKIT_FMT
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_fast_wave_fmt launch failed"); return true; }
     static thread_local char nm[96];
     static const char *kn[] = {"signed", "unsigned", "float", "ulaw", "alaw"};
-    snprintf(nm, sizeof nm, "k_fast_wave_fmt<%s%d%s,%dch,%s,nv%d>", kn[M.kind], 8 * B, M.big_endian ? "be" : "", C, interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
+    snprintf(nm, sizeof nm, "k_fast_wave_fmt<%s%d%s,%dch,%s,nv%d%s>", kn[M.kind], 8 * B, M.big_endian ? "be" : "", C, interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, f64 ? ",f64" : "");
     *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
     if (M.flag) *only_if = M.flag;
     return true;
