@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the loaders, alone and with a fused resample to 48 kHz (aukit_decode / aukit_decode_resample), per format, on one large
-batch (GPU box).  usage: python tools/loader_rates.py [streams=1024] [f32|f64]"""
+batch (GPU box).  usage: python tools/loader_rates.py [streams=1024] [f32|f64] [exact_math=0|1|2]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,7 @@ from tests.util import pcm16
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dtype = N.F64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else N.F32
 ctx = B.Context(0, dtype=dtype)
+if len(sys.argv) > 3: ctx.set_option(N.OPT_EXACT_MATH, int(sys.argv[3]))
 rng = np.random.default_rng(9)
 def rate(name, bt, d, outs_per_stream_dec, rate_in):
     for label, fn, outs in (("decode", lambda o: B.decode(ctx, bt, d, out=o), outs_per_stream_dec),
