@@ -470,13 +470,26 @@ def time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync):
             whole = B.Batch.wrap(ctx, big.data_ptr(), [i * wl.n_samples * 2 for i in range(n + 1)], keep=big)
         out = B.AudioBatch(ctx)
         times = []
+        def agreed(err):
+            # every rank learns whether ANY rank failed its local stage before the next collective is entered: a rank that raised on its own
+            # (out of memory in the pass, say) would otherwise leave the others waiting inside the gather until the launcher's timeout
+            flag = torch.tensor([0 if err is None else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                raise RuntimeError(f"distribution pass failed on rank {rank}: {err}" if err is not None else "distribution pass failed on another rank")
         for it in range(2):  # the first round pays RCCL's connection set-up: report the second
             sync(); dist.barrier(); sync()
             t0 = time.perf_counter()
             mine, (lo, hi) = shard.scatter_batch(ctx, whole, src=0, device=dev)
             sync(); t1 = time.perf_counter()
-            B.decode_resample(ctx, mine, wl.d, DST_RATE, args.interp, dtype=wl.dtype, out=out)
-            ctx.sync(); sync(); t2 = time.perf_counter()
+            err = None
+            try:
+                B.decode_resample(ctx, mine, wl.d, DST_RATE, args.interp, dtype=wl.dtype, out=out)
+                ctx.sync()
+            except Exception as e:  # noqa: BLE001 — reported through agreed()
+                err = f"{type(e).__name__}: {e}"
+            sync(); t2 = time.perf_counter()
+            agreed(err)   # (outside the timed stages' meaning: a 4-byte all-reduce, counted in the gather time)
             got = shard.gather_audio(out, dst=0, device=dev)
             sync(); dist.barrier(); sync()
             t3 = time.perf_counter()
@@ -561,7 +574,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # a rank lost inside a collective ends the job in minutes, not at the launcher's limit
         else:
             dist.init_process_group(args.backend)
     rdev = dev if args.backend == "nccl" else torch.device("cpu")
