@@ -491,6 +491,13 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         done = fast_try(ctx, SRC_PCM8_MONO, interp, d->sample_rate, 48000, segs, P, in_bytes + out_elems * 4, &frc, 1, P.lp_alpha);
         if (done && frc) { delete ck; return frc; }
     }
+    if (!done && dtype == AUKIT_F32 && !ctx->exact_math && C <= 2 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+        // every other interleaved format of one or two channels: unpack + resample + the stream.pcm epilogue in one launch (fast_fmt.hip, round 3)
+        int frc = AUKIT_OK;
+        const int *unused = nullptr;
+        done = fast_fmt_try(ctx, d, interp, 48000, segs, P, in_bytes + out_elems * 4, &frc, &unused, (mono && C > 1) ? 2 : 1, P.lp_alpha);
+        if (done && frc) { delete ck; return frc; }
+    }
     if (!done && dtype == AUKIT_F32 && !ctx->exact_math && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !getenv("AUKIT_NO_FAST_CONVERT")) {
         // every other PCM format (8-bit unsigned at 48 kHz is what most ComputerCraft audio is kept in), f32 tolerance path: the string is
         // unpacked to one f32 row per output channel (k_pcm_unpack; the `mono` mix is made there, in the reference's order) and the stream.pcm

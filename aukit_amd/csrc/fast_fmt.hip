@@ -15,13 +15,13 @@
 // The kernel therefore raises a flag when it stages such a sample, and the reference-order kernel, queued right behind with the flag as
 // its launch condition (ResampleParams::only_if), redoes the call; without the flag it returns at once.
 #include <algorithm>
-#include "fast_wave_dev.h"
+#include "fast_stream_body.h"   // interp_qr_raw, prev_lane / last_lane: the stream.pcm epilogue
 
 namespace aukit {
 
 constexpr int WTF = 512;  // outputs per wave tile and channel = 8 rows of 64
 
-enum { FMT_SIGNED = 0, FMT_UNSIGNED8 = 1, FMT_FLOAT = 2, FMT_ULAW = 3, FMT_ALAW = 4 };
+enum { FMT_SIGNED = 0, FMT_UNSIGNED8 = 1, FMT_FLOAT = 2, FMT_ULAW = 3, FMT_ALAW = 4, FMT_UNSIGNED = 5 /* 16 / 24 / 32-bit unsigned: (s - 128) / (s < 128 and 2^(b-1) or 2^(b-1) - 1), Q4 — the stream path only */ };
 struct FmtParams {
     int kind, big_endian;
     float scale_pos, scale_neg;   // signed: 1 / (2^(bits-1) - 1), 1 / 2^(bits-1)   (:1133)
@@ -65,6 +65,10 @@ AUKIT_DEV AT fmt_sample(unsigned raw, const FmtParams &M, bool &wild) {
                 wild = wild || !(fabsf(f) <= 1.0f);
                 return (AT)f;
             }
+        }
+        if (M.kind == FMT_UNSIGNED) {   // :1152 (Q4: 128 is subtracted whatever the depth)
+            const float uf = (float)u;
+            return (AT)((uf - 128.0f) * (u < 128u ? M.scale_neg : M.scale_pos));
         }
         v = (int)(u << (32 - 8 * B)) >> (32 - 8 * B);
     }
@@ -123,16 +127,19 @@ AUKIT_DEV WaveTile describe_fmt(const ResampleParams &P, const FastParams &F, un
     return w;
 }
 
-template <int B, int C, int INTERP, int NV, typename AT>
+// EPI 0: Audio:resample (:666-668), one row per channel.  EPI 1: aukit.stream.pcm's chunk samples (:2395-2403: the interpolated sample is not
+// clamped, 2-tap low-pass on the raw sample before it, x 127 | 128, clamp) per channel; EPI 2: the same on the channels' mean (`mono`, :2368).
+template <int B, int C, int INTERP, int NV, typename AT, int EPI = 0>
 __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, const FastParams F, const FmtParams M) {
     extern __shared__ float smf[];
     constexpr int FB = B * C;
-    constexpr int HL = INTERP == AUKIT_INTERP_CUBIC ? 1 : 0, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + (EPI ? 1 : 0), HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;   // the stream epilogue reaches one tap further left
+    constexpr int TC = EPI == 2 ? 1 : C;                  // tables (= output rows)
     constexpr int RAWW = NV * 64 * 4 + 4;               // dwords of raw window per wave (+ one vector: the second dword of the last sample)
     const int lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr unsigned AW = sizeof(AT) / 4;                 // dwords per table entry
-    unsigned *const raw = reinterpret_cast<unsigned *>(smf) + wave * (unsigned)(RAWW + C * F.cap * AW);
+    unsigned *const raw = reinterpret_cast<unsigned *>(smf) + wave * (unsigned)(RAWW + TC * F.cap * AW);
     AT *const tab0 = reinterpret_cast<AT *>(raw + RAWW);
     const unsigned nwaves = gridDim.x * 4u;
     const unsigned lane_a = (unsigned)lane * F.a;
@@ -161,13 +168,23 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
         __builtin_amdgcn_wave_barrier();
         // ---- samples → one f32 table per channel
         const int ne = cur.n_stage * C;
-#pragma unroll 4
-        for (int e = lane; e < ne; e += 64) {
-            const unsigned off = (unsigned)cur.head + (unsigned)e * B;
+        auto lds_sample = [&](unsigned off) {
             const unsigned w0 = raw[off >> 2], w1 = raw[(off >> 2) + 1];
             const unsigned u = B == 4 ? __builtin_amdgcn_alignbyte(w1, w0, off & 3) : (__builtin_amdgcn_alignbyte(w1, w0, off & 3) & ((1u << (8 * (B & 3))) - 1u));
-            const int f = C == 1 ? e : e >> 1, c = C == 1 ? 0 : e & 1;
-            tab0[c * F.cap + f] = fmt_sample<B, AT>(u, M, wild);
+            return fmt_sample<B, AT>(u, M, wild);
+        };
+        if constexpr (EPI == 2) {   // self[i] = ((0 + read()) + read()) / channels  (:2368), in the table's arithmetic
+#pragma unroll 4
+            for (int f = lane; f < cur.n_stage; f += 64) {
+                const unsigned off = (unsigned)cur.head + (unsigned)f * FB;
+                tab0[f] = (lds_sample(off) + lds_sample(off + B)) * (AT)0.5;
+            }
+        } else {
+#pragma unroll 4
+            for (int e = lane; e < ne; e += 64) {
+                const int f = C == 1 ? e : e >> 1, c = C == 1 ? 0 : e & 1;
+                tab0[c * F.cap + f] = lds_sample((unsigned)cur.head + (unsigned)e * B);
+            }
         }
         {
             const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
@@ -178,17 +195,28 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                     const bool ok0 = v0 >= P.safe_lo && v0 + 16 <= P.safe_hi, ok1 = v1 >= P.safe_lo && v1 + 16 <= P.safe_hi;
                     if (!(ok0 && ok1)) {
                         const int f = C == 1 ? e : e >> 1, c = C == 1 ? 0 : e & 1;
-                        tab0[c * F.cap + f] = (q >= P.safe_lo && q + B <= P.safe_hi) ? global_sample(q) : (AT)0;
+                        const AT v = (q >= P.safe_lo && q + B <= P.safe_hi) ? global_sample(q) : (AT)0;
+                        if constexpr (EPI == 2) {   // (rare: redo the frame's mean from memory)
+                            if (c == 0) {
+                                const unsigned char *q1 = q + B;
+                                const AT v1 = (q1 >= P.safe_lo && q1 + B <= P.safe_hi) ? global_sample(q1) : (AT)0;
+                                tab0[f] = (v + v1) * (AT)0.5;
+                            }
+                        } else tab0[c * F.cap + f] = v;
                     }
                 }
             }
             // nil fall-backs of interpolate.{linear,cubic} (aukit.lua:259, :264) = replicated edge samples
             const int k_hi = cur.k_lo + cur.n_stage - 1;
+            auto edge = [&](const unsigned char *q, int c) -> AT {
+                if constexpr (EPI == 2) return (global_sample(q) + global_sample(q + B)) * (AT)0.5;
+                else return global_sample(q + c * B);
+            };
             if (cur.k_lo < cur.w_lo) {
                 const unsigned char *q = cur.base + (long long)FB * cur.w_lo;
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const AT ev = global_sample(q + c * B);
+                for (int c = 0; c < TC; c++) {
+                    const AT ev = edge(q, c);
                     for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) tab0[c * F.cap + idx] = ev;
                 }
             }
@@ -196,8 +224,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
                 const unsigned char *q = cur.base + (long long)FB * cur.w_hi;
                 const int first = cur.w_hi + 1 - cur.k_lo;
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const AT ev = global_sample(q + c * B);
+                for (int c = 0; c < TC; c++) {
+                    const AT ev = edge(q, c);
                     for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) tab0[c * F.cap + first + idx] = ev;
                 }
             }
@@ -217,6 +245,52 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
         }
         const AT *tabL = tab0 + HL, *tabR = tab0 + F.cap + HL;  // tab[q] = d[1 + kb + q]
         float *orowL = cur.orow, *orowR = cur.orow + ostride;
+        if constexpr (EPI != 0) {
+            // aukit.stream.pcm (the body of k_fast_wave_stream, fast_stream_body.h, per table): the raw sample before the tile's first output is
+            // re-evaluated from the window (position n = r0 - a, one table step back when that is negative); the first output of an iterator
+            // call has ls = 0 behind it (:2397)
+            const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - as_const(P.seg_tile0)[as_const(P.tile_seg)[t]]) == 0;
+            const float alpha = F.alpha;
+            float carry[TC];
+#pragma unroll
+            for (int c = 0; c < TC; c++) {
+                const float *tb = reinterpret_cast<const float *>(c ? tabR : tabL);
+                carry[c] = first ? 0.f : (cur.r0 >= F.a ? interp_row<INTERP, false>(F, tb, cur.r0 - F.a) : interp_row<INTERP, false>(F, tb - 1, cur.r0 + F.b - F.a));
+            }
+            auto finish = [&](float sv, float &cy) {
+                const float prev = prev_lane(sv, cy);
+                cy = last_lane(sv);
+                const float ns = fmaf(alpha, sv - prev, prev);                                                 // :2401
+                return __builtin_amdgcn_fmed3f(ns * (ns < 0.f ? 128.f : 127.f), -128.f, 127.f);              // :2402
+            };
+            if ((cur.cnt & 63u) == 0) {   // whole rows: (q, rem) advanced by additions
+                const unsigned n0 = cur.r0 + lane_a;
+                unsigned q = __umulhi(n0, F.magic);
+                unsigned rem = n0 - q * F.b;
+                const int rows = (int)(cur.cnt >> 6);
+                for (int r = 0; r < WTF / 64; r++) {
+                    if (r >= rows) break;
+                    orowL[r * 64 + lane] = finish(interp_qr_raw<INTERP>(F, reinterpret_cast<const float *>(tabL), q, rem), carry[0]);
+                    if constexpr (TC == 2) orowR[r * 64 + lane] = finish(interp_qr_raw<INTERP>(F, reinterpret_cast<const float *>(tabR), q, rem), carry[TC - 1]);
+                    rem += F.dr64;
+                    q += F.dq64;
+                    const bool wrap = rem >= F.b;
+                    rem -= wrap ? F.b : 0u;
+                    q += wrap ? 1u : 0u;
+                }
+            } else {
+                for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+                    const unsigned j = rb + lane;
+                    const unsigned n = cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a;
+                    const float vl = finish(interp_row<INTERP, false>(F, reinterpret_cast<const float *>(tabL), n), carry[0]);
+                    if (j < cur.cnt) orowL[j] = vl;
+                    if constexpr (TC == 2) {
+                        const float vr = finish(interp_row<INTERP, false>(F, reinterpret_cast<const float *>(tabR), n), carry[TC - 1]);
+                        if (j < cur.cnt) orowR[j] = vr;
+                    }
+                }
+            }
+        } else
         if (cur.cnt == (unsigned)WTF) {
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
@@ -254,20 +328,29 @@ __global__ __launch_bounds__(256) void k_fast_wave_fmt(const ResampleParams P, c
     }
 }
 
-template <int B, int C, int INTERP, typename AT>
+template <int B, int C, int INTERP, typename AT, int EPI>
 static void launch_fmt_nv(aukit_ctx *ctx, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
-    if (nv == 1) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 1, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
-    else if (nv == 8) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 8, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
-    else hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 4, AT>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    if (nv == 1) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 1, AT, EPI>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    else if (nv == 8) hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 8, AT, EPI>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
+    else hipLaunchKernelGGL((k_fast_wave_fmt<B, C, INTERP, 4, AT, EPI>), dim3(grid), dim3(256), lds, ctx->stream, P, F, M);
 }
 template <int B, int C>
-static void launch_fmt_i(aukit_ctx *ctx, int interp, bool f64, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
-    if (f64) {
-        if (interp == AUKIT_INTERP_LINEAR) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, double>(ctx, nv, P, F, M, lds, grid);
-        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, double>(ctx, nv, P, F, M, lds, grid);
+static void launch_fmt_i(aukit_ctx *ctx, int interp, bool f64, int epi, int nv, const ResampleParams &P, const FastParams &F, const FmtParams &M, size_t lds, unsigned grid) {
+    const bool lin = interp == AUKIT_INTERP_LINEAR;
+    if (epi == 1) {   // stream.pcm, f32 arithmetic only
+        if (lin) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, float, 1>(ctx, nv, P, F, M, lds, grid);
+        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, float, 1>(ctx, nv, P, F, M, lds, grid);
+    } else if (epi == 2) {
+        if constexpr (C == 2) {
+            if (lin) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, float, 2>(ctx, nv, P, F, M, lds, grid);
+            else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, float, 2>(ctx, nv, P, F, M, lds, grid);
+        }
+    } else if (f64) {
+        if (lin) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, double, 0>(ctx, nv, P, F, M, lds, grid);
+        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, double, 0>(ctx, nv, P, F, M, lds, grid);
     } else {
-        if (interp == AUKIT_INTERP_LINEAR) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, float>(ctx, nv, P, F, M, lds, grid);
-        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, float>(ctx, nv, P, F, M, lds, grid);
+        if (lin) launch_fmt_nv<B, C, AUKIT_INTERP_LINEAR, float, 0>(ctx, nv, P, F, M, lds, grid);
+        else launch_fmt_nv<B, C, AUKIT_INTERP_CUBIC, float, 0>(ctx, nv, P, F, M, lds, grid);
     }
 }
 
@@ -277,10 +360,12 @@ bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, F
 // (nothing launched) when the shape is not served.  *needs_exact: a float string — the caller queues the reference-order kernel behind
 // this one with P.only_if = the flag this launch may raise.
 bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
-                  uint64_t algorithmic_bytes, int *rc, const int **only_if) {
+                  uint64_t algorithmic_bytes, int *rc, const int **only_if, int epi, double alpha) {
     *only_if = nullptr;
     if (ctx->exact_math > 1 || getenv("AUKIT_NO_FAST_FMT")) return false;
     const bool f64 = ctx->exact_math == 1;   // fp64 arithmetic, f32 store
+    if (epi && f64) return false;            // the stream epilogue exists in f32 arithmetic only
+    if (epi == 2 && d->channels != 2) return false;
     const int C = d->channels;
     if (C != 1 && C != 2) return false;
     FmtParams M;
@@ -297,7 +382,8 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
         if (d->data_type == AUKIT_FLOAT) { if (B != 4) return false; M.kind = FMT_FLOAT; }
         else if (d->data_type == AUKIT_SIGNED) M.kind = FMT_SIGNED;
         else if (d->data_type == AUKIT_UNSIGNED && B == 1) M.kind = FMT_UNSIGNED8;
-        else return false;  // unsigned 16 / 24 / 32-bit: Q4 maps them to [-1, 3): the reference-order kernel keeps them
+        else if (d->data_type == AUKIT_UNSIGNED && epi) M.kind = FMT_UNSIGNED;   // stream.pcm does not clamp its interpolated sample (Q2): samples beyond ±1 are no obstacle there
+        else return false;  // unsigned 16 / 24 / 32-bit: Q4 maps them to [-1, 3): the reference-order kernel keeps them for Audio:resample
         M.big_endian = d->big_endian ? 1 : 0;
         const double full = (double)(1ull << (8 * B - 1));
         M.scale_pos = (float)(1.0 / (full - 1));
@@ -309,7 +395,9 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
     const int FB = B * C;
-    const int hl = interp == AUKIT_INTERP_CUBIC ? 1 : 0, hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+    F.epi = epi;
+    F.alpha = (float)alpha;
+    const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
     const int win = (int)(((unsigned long long)(WTF - 1) * F.a) / F.b) + 2 + hl + hr;  // staged frames per wave tile (upper bound)
     const int nvec = (win * FB + 15 + 15) / 16;
     const int nv = nvec <= 64 ? 1 : (nvec <= 256 ? 4 : (nvec <= 512 ? 8 : 0));
@@ -324,9 +412,9 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
     F.dq64 = (unsigned)((64ull * F.a) / F.b);
     F.dr64 = (unsigned)((64ull * F.a) % F.b);
     M.dinv_b = 1.0 / (double)F.b;
-    const size_t lds = 4 * ((size_t)(nv * 64 * 4 + 4) + (size_t)C * F.cap * (f64 ? 2 : 1)) * 4;
+    const size_t lds = 4 * ((size_t)(nv * 64 * 4 + 4) + (size_t)(epi == 2 ? 1 : C) * F.cap * (f64 ? 2 : 1)) * 4;
     if (lds > 64 * 1024) return false;
-    if (M.kind == FMT_FLOAT) {
+    if (M.kind == FMT_FLOAT && !epi) {
         if ((*rc = ctx->fmt_flag.ensure(64))) return true;
         M.flag = reinterpret_cast<int *>(ctx->fmt_flag.p);
     }
@@ -338,14 +426,15 @@ bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double 
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     if (M.flag && hipMemsetAsync(M.flag, 0, 4, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
-#define AUKIT_FMT(BB, CC) launch_fmt_i<BB, CC>(ctx, interp, f64, nv, P, F, M, lds, grid)
+#define AUKIT_FMT(BB, CC) launch_fmt_i<BB, CC>(ctx, interp, f64, epi, nv, P, F, M, lds, grid)
     if (C == 1) { if (B == 1) AUKIT_FMT(1, 1); else if (B == 2) AUKIT_FMT(2, 1); else if (B == 3) AUKIT_FMT(3, 1); else AUKIT_FMT(4, 1); }
     else { if (B == 1) AUKIT_FMT(1, 2); else if (B == 2) AUKIT_FMT(2, 2); else if (B == 3) AUKIT_FMT(3, 2); else AUKIT_FMT(4, 2); }
 #undef AUKIT_FMT
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_fast_wave_fmt launch failed"); return true; }
     static thread_local char nm[96];
-    static const char *kn[] = {"signed", "unsigned", "float", "ulaw", "alaw"};
-    snprintf(nm, sizeof nm, "k_fast_wave_fmt<%s%d%s,%dch,%s,nv%d%s>", kn[M.kind], 8 * B, M.big_endian ? "be" : "", C, interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, f64 ? ",f64" : "");
+    static const char *kn[] = {"signed", "unsigned", "float", "ulaw", "alaw", "unsigned"};
+    snprintf(nm, sizeof nm, "k_fast_wave_fmt<%s%d%s,%dch,%s,nv%d%s%s>", kn[M.kind], 8 * B, M.big_endian ? "be" : "", C, interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv, f64 ? ",f64" : "",
+             epi == 1 ? ",stream_pcm" : (epi == 2 ? ",stream_pcm_mono" : ""));
     *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);
     if (M.flag) *only_if = M.flag;
     return true;

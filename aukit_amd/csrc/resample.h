@@ -109,7 +109,7 @@ int launch_fast_wave_coef(aukit_ctx *ctx, int src_kind, int interp, int nv, int 
 int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector<Seg> &segs, ResampleParams &P, FastParams &F,
                      uint64_t algorithmic_bytes, bool *taken);
 bool fast_fmt_try(aukit_ctx *ctx, const aukit_codec_desc *d, int interp, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
-                  uint64_t algorithmic_bytes, int *rc, const int **only_if);  // fast_fmt.hip: every other interleaved PCM format / G.711 stereo, one launch
+                  uint64_t algorithmic_bytes, int *rc, const int **only_if, int epi = 0, double alpha = 0);  // fast_fmt.hip: every other interleaved PCM format / G.711 stereo, one launch (epi 1 / 2: stream.pcm per channel / on the channels' mean)
 bool fast_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, double new_rate, const std::vector<Seg> &segs, ResampleParams &P,
               uint64_t algorithmic_bytes, int *rc, int epi = 0, double alpha = 0);
 

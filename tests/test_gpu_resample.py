@@ -347,13 +347,18 @@ def test_fast_f32_pcm8_mono(ctx, oracle, rate, new_rate, dt, interp):
 @pytest.mark.parametrize("bits,dt,be,ch,mono,rate,kernel", [
     (8, "unsigned", False, 1, False, 48000, "k_fast_wave_stream<pcm8_mono"),   # the classic pre-converted speaker file: bytes read directly
     (8, "signed", False, 1, False, 44100, "k_fast_wave_stream<pcm8_mono"),
-    (8, "unsigned", False, 2, False, 48000, "k_fast_wave_stream<audio_f32"),   # everything else: unpacked to f32 rows first
-    (8, "unsigned", False, 2, True, 22050, "k_fast_wave_stream<audio_f32"),
-    (24, "signed", False, 2, False, 44100, "k_fast_wave_stream<audio_f32"),
-    (24, "signed", True, 3, True, 32000, "k_fast_wave_stream<audio_f32"),
-    (16, "unsigned", True, 1, False, 48000, "k_fast_wave_stream<audio_f32"),
-    (32, "signed", False, 1, False, 8000, "k_fast_wave_stream<audio_f32"),
-    (32, "float", False, 2, False, 48000, "k_fast_wave_stream<audio_f32"),
+    (8, "unsigned", False, 2, False, 48000, "k_fast_wave_fmt<unsigned8,2ch"),   # every other interleaved format of one or two channels: one launch (fast_fmt.hip)
+    (8, "unsigned", False, 2, True, 22050, "k_fast_wave_fmt<unsigned8,2ch"),
+    (24, "signed", False, 2, False, 44100, "k_fast_wave_fmt<signed24,2ch"),
+    (24, "signed", True, 2, True, 32000, "k_fast_wave_fmt<signed24be,2ch"),
+    (24, "signed", True, 3, True, 32000, "k_fast_wave_stream<audio_f32"),     # more channels: unpacked to f32 rows first
+    (16, "unsigned", True, 1, False, 48000, "k_fast_wave_fmt<unsigned16be,1ch"),
+    (24, "unsigned", False, 2, True, 44100, "k_fast_wave_fmt<unsigned24,2ch"),
+    (32, "unsigned", False, 1, False, 22050, "k_fast_wave_fmt<unsigned32,1ch"),
+    (32, "signed", False, 1, False, 8000, "k_fast_wave_fmt<signed32,1ch"),
+    (32, "float", False, 2, False, 48000, "k_fast_wave_fmt<float32,2ch"),
+    (32, "float", True, 2, True, 44100, "k_fast_wave_fmt<float32be,2ch"),
+    (16, "signed", True, 2, False, 44100, "k_fast_wave_fmt<signed16be,2ch"),
     (16, "signed", False, 1, False, 48000, "k_fast_wave_stream<pcm_s16le_mono"),  # equal rates take the 16-bit kernels too
     (16, "signed", False, 2, False, 48000, "k_fast_wave_stream_s16x2<"),
 ])
