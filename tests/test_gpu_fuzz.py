@@ -319,6 +319,88 @@ def test_fuzz_pcm_formats(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds(16))
+def test_fuzz_pcm_formats_f32_one_launch(ctx, oracle, seed):
+    """F32 storage on a random format (8 / 16 / 24 / 32-bit, signed / unsigned / float, either byte order, 1-3 channels), rate and interpolation:
+    `aukit.pcm(...):resample(48000)` in f32 arithmetic and in fp64 arithmetic (AUKIT_OPT_EXACT_MATH 1) and `aukit.stream.pcm` (with and without
+    `mono`) — k_fast_wave_fmt and the paths around it — within 1e-6 RMS of the oracle; float strings now and then hold samples beyond ±1 (the
+    flagged reference-order redo)."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(91000 + seed))
+    bits = int(rng.choice([8, 16, 24, 32]))
+    dt = ["signed", "unsigned", "float"][int(rng.integers(0, 3 if bits == 32 else 2))]
+    be = bool(rng.integers(0, 2))
+    ch = int(rng.integers(1, 4))
+    rate = int(rng.choice([8000, 11025, 22050, 32000, 44100, 48000]))
+    new_rate = int(rng.choice([48000, 48000, 44100, 22050]))
+    interp = ["linear", "cubic"][int(rng.integers(0, 2))]
+    odt = {"signed": oracle.SIGNED, "unsigned": oracle.UNSIGNED, "float": oracle.FLOAT}[dt]
+    wild = dt == "float" and bool(rng.integers(0, 3) == 0)
+    streams = []
+    for n in (1, 2, int(rng.integers(100, 3000)), rate + int(rng.integers(1, 99)), int(rng.integers(20000, 60000))):
+        if dt == "float":
+            x = rng.uniform(-1, 1, n * ch)
+            if wild and n > 50:
+                x[rng.integers(0, n * ch, 5)] *= 2.5
+            raw = x.astype(">f4" if be else "<f4").tobytes()
+        else:
+            raw = bytes(rng.integers(0, 256, n * ch * (bits // 8), dtype=np.uint8))
+        streams.append(raw)
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_PCM, ch, rate, bits, dt, big_endian=be)
+    refs = [oracle.pcm(s, bits, odt, ch, rate, True, be) for s in streams]
+    rrs = [oracle.resample(r, new_rate, oracle.INTERP[interp]) for r in refs]
+    for em in (0, 1):
+        ctx.set_option(N.OPT_EXACT_MATH, em)
+        try:
+            res = B.decode_resample(ctx, bt, desc, new_rate, interp, dtype=N.F32).download()
+            name = ctx.last_kernel()[0]
+        finally:
+            ctx.set_option(N.OPT_EXACT_MATH, 0)
+        for r, rr in zip(res, rrs):
+            for c in range(ch):
+                assert len(r[c]) == len(rr.data[c]), (bits, dt, be, ch, rate, new_rate, interp, em, name)
+                if len(r[c]):
+                    scale = max(1.0, float(np.max(np.abs(rr.data[c]))))
+                    assert np.max(np.abs(r[c] - rr.data[c])) <= 4e-6 * scale, (bits, dt, be, ch, rate, new_rate, interp, em, name, wild)
+    mono = bool(ch > 1 and rng.integers(0, 2))
+    out, ck = B.stream_decode(ctx, bt, desc, interp, mono=mono, dtype=N.F32)
+    name = ctx.last_kernel()[0]
+    a = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_pcm(s, bits, odt, ch, rate, be, mono, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), (bits, dt, be, ch, rate, interp, mono, i, name)
+        for c in range(ref.channels):
+            assert len(a[i][c]) == len(ref.data[c])
+            if len(ref.data[c]):
+                assert np.max(np.abs(a[i][c] - ref.data[c])) <= 1e-3, (bits, dt, be, ch, rate, interp, mono, i, c, name)   # the [-128, 127] scale: 8e-6 of it
+
+
+@pytest.mark.parametrize("seed", _seeds(8))
+def test_fuzz_reverb_f32(ctx, oracle, seed):
+    """effects.reverb on F32 audios with random rate / delay / decay / wet / dry and ragged lengths: the one-pass kernel where its state fits a CU,
+    the launches of round 2 elsewhere — 1e-6 RMS from the oracle either way."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(92000 + seed))
+    rate = int(rng.choice([16000, 22050, 32000, 44100, 48000, 48000, 64000]))
+    S = int(np.floor(0.08927 * rate))
+    delay = float(rng.choice([40.0, 60.0, 100.0, 100.0, 133.7, 180.0]))
+    decay = float(rng.uniform(0.32, 0.6))
+    wet, dry = float(rng.uniform(0.3, 1.0)), float(rng.uniform(0.0, 0.5))
+    lens = [S + 1 + int(rng.integers(0, 3)), S + int(rng.integers(100, 9000)), rate + int(rng.integers(0, 5000))]
+    ch = int(rng.integers(1, 3))
+    a = [[rng.uniform(-1, 1, n).astype(np.float32).astype(np.float64) * float(rng.uniform(0.1, 0.6)) for _ in range(ch)] for n in lens]
+    ab = B.AudioBatch.upload(ctx, a, rate, dtype=N.F32)
+    B.effect(ctx, ab, "reverb", delay, decay, wet, dry)
+    name = ctx.last_kernel()[0]
+    got = ab.download()
+    for s in range(len(a)):
+        ref = oracle.fx_reverb(oracle.Audio(a[s], rate), delay, decay, wet, dry)
+        for c in range(ch):
+            assert rms(got[s][c], ref.data[c]) <= 1e-6, (rate, delay, decay, wet, dry, s, c, name)
+            assert np.max(np.abs(got[s][c] - ref.data[c])) <= 4e-6, (rate, delay, decay, wet, dry, s, c, name)
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
 def test_fuzz_effects_and_audio_methods(ctx, oracle, seed):
     """random audio (1-3 channels, ragged lengths, values over the full [-1, 1] range incl. exact ±1 and 0) through a random effect
     with random parameters, then :mono / :mix / :resample — F64 storage against the oracle (maps exact, scans 1e-11)"""
