@@ -147,23 +147,28 @@ __global__ __launch_bounds__(256) void k_iir_tail(const TailParams P) {
 // additions), the phase's weights from an LDS table, four FMAs per output on an f32 window — and the recurrence still in fp64.  Against the
 // reference-order kernel above: ≈ 1e-7 of the [-128, 127] scale (the bar of the un-floored stream outputs is 1e-6 RMS of it);
 // 117 → ≈ 35 instructions per output.
-template <int KIND, int INTERP, int E, typename R, typename OUT_T>
+// NT = threads per tile: 256 (a workgroup tile, three block barriers per tile: the first cut) or 64 — a wave-private tile, four independent
+// tiles per workgroup, wave barriers only (round 3: tiles need nothing from each other, so nothing is gained by making four waves march in step)
+template <int KIND, int INTERP, int E, typename R, typename OUT_T, int NT>
 __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
     extern __shared__ float fsm[];
-    constexpr int T = 256 * E;
+    constexpr int T = NT * E;
     constexpr int WF = INTERP == AUKIT_INTERP_CUBIC ? 4 : 1;
-    const int tid = threadIdx.x;
+    const int tid = NT == 256 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const unsigned sub = NT == 256 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nsub = 256 / NT;
+    auto tile_sync = [&]() { if constexpr (NT == 256) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } };
     float *const wt = fsm;
-    float *const win = fsm + ((P.fb * WF + 3) & ~3u);
+    float *const win = fsm + ((P.fb * WF + 3) & ~3u) + sub * (unsigned)(P.C * (P.cap + P.xbn));
     float *const xb = win + (size_t)P.C * P.cap;
     const R *const rows = reinterpret_cast<const R *>(P.rows);
     OUT_T *const out = reinterpret_cast<OUT_T *>(P.out);
-    for (unsigned i = tid; i < P.fb * WF; i += 256) wt[i] = P.wg[i];
+    for (unsigned i = threadIdx.x; i < P.fb * WF; i += 256) wt[i] = P.wg[i];
+    __syncthreads();
     const double full_rcp = 1.0 / P.full;   // a power of two
     auto rowf = [&](unsigned long long at) -> float { if constexpr (sizeof(R) == 4) return (float)((double)rows[at] * full_rcp); else return (float)rows[at]; };
     auto skew = [](int i) { return i + i / E; };
     auto qr = [&](unsigned o, unsigned &q, unsigned &rem) { q = __umulhi(o * P.fa, P.fmagic); rem = o * P.fa - q * P.fb; };
-    for (unsigned long long t = blockIdx.x; t < P.n_tiles; t += gridDim.x) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * nsub + sub; t < P.n_tiles; t += (unsigned long long)gridDim.x * nsub) {
         const unsigned long long ji = t / P.tiles_per_job;
         const TailJob job = P.jobs[ji];
         const unsigned o0 = (unsigned)(t - ji * P.tiles_per_job) * (unsigned)T;
@@ -178,23 +183,53 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
         qr(o0 + (unsigned)cnt - 1, ql, rl);
         const int k_lo = (int)qf;                      // floor(x) - 1 of the tile's first output: the lowest tap
         const int k_hi = min((int)ql + 3, n);
-        const int nst = k_hi - k_lo + 1;
-        __syncthreads();
+        tile_sync();
         for (int c = 0; c < P.C; c++) {
             float z0 = 0;   // table index 0: the history sample
             if (job.last_off != ~0ull) z0 = rowf(job.last_off + (unsigned long long)c * job.last_cstride);
             const unsigned long long base = job.src_off + (unsigned long long)c * job.src_cstride;
-            for (int rel = tid; rel < nst; rel += 256) {
-                const int k = k_lo + rel;
-                win[c * P.cap + rel] = k >= 1 ? rowf(base + (unsigned long long)(k - 1)) : z0;
+            // The window as 16-byte vectors (round 3).  The first cut walked it one element per thread and turn — for int8 rows eight dependent
+            // byte loads per thread and tile, each waited for where it was issued.  Now: the aligned vectors that lie wholly inside the window
+            // (all issued before any is used), the few elements in front of and behind them one per thread; nothing outside the window is read.
+            constexpr int EPV = 16 / (int)sizeof(R);
+            const int kf = k_lo < 1 ? 1 : k_lo, nreal = k_hi - kf + 1;
+            float *const wrow = win + c * P.cap + (kf - k_lo);      // slot of table index kf
+            if (k_lo < 1 && tid == 0) win[c * P.cap] = z0;
+            if (nreal > 0) {
+                const R *const p0 = rows + base + (unsigned long long)(kf - 1);
+                int head = (int)(((16u - (unsigned)((uintptr_t)p0 & 15u)) & 15u) / (unsigned)sizeof(R));
+                head = head < nreal ? head : nreal;
+                const int nvec = (nreal - head) / EPV, tail0 = head + nvec * EPV;
+                constexpr int VU = NT == 256 ? (sizeof(R) == 1 ? 1 : 2) : (sizeof(R) == 1 ? 1 : 2);          // vectors per thread issued together (a tile's window: ~120 of int8, ~480 of int32)
+                for (int v0 = 0; v0 < nvec; v0 += NT * VU) {
+                    uint4 vv[VU];
+#pragma unroll
+                    for (int u = 0; u < VU; u++) { const int v = v0 + tid + NT * u; vv[u] = make_uint4(0, 0, 0, 0); if (v < nvec) vv[u] = *reinterpret_cast<const uint4 *>(p0 + head + (size_t)v * EPV); }
+#pragma unroll
+                    for (int u = 0; u < VU; u++) {
+                        const int v = v0 + tid + NT * u;
+                        if (v >= nvec) continue;
+                        float *d = wrow + head + v * EPV;
+                        const unsigned ww[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                        if constexpr (sizeof(R) == 4) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) d[j] = (float)((double)(int)ww[j] * full_rcp);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 16; j++) d[j] = (float)(signed char)(ww[j >> 2] >> (8 * (j & 3)));
+                        }
+                    }
+                }
+                if (tid < head) wrow[tid] = rowf(base + (unsigned long long)(kf - 1 + tid));
+                if (tid >= 32 && tid - 32 < nreal - tail0) wrow[tail0 + tid - 32] = rowf(base + (unsigned long long)(kf - 1 + tail0 + tid - 32));
             }
         }
-        __syncthreads();
+        tile_sync();
         for (int c = 0; c < P.C; c++) {
             const float *tab = win + c * P.cap - k_lo;   // tab[k] = table index k
             unsigned q, rem;
             qr(of + (unsigned)tid, q, rem);
-            for (int idx = tid; idx < total; idx += 256, q += P.dq256, rem += P.dr256) {
+            for (int idx = tid; idx < total; idx += NT, q += P.dq256, rem += P.dr256) {   // (dq256 / dr256: the step of NT outputs)
                 if (rem >= P.fb) { rem -= P.fb; q++; }
                 const int k = (int)q + 1;   // floor(x)
                 float s;
@@ -215,7 +250,7 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
                 xb[c * P.xbn + skew(idx)] = s;
             }
         }
-        __syncthreads();
+        tile_sync();
         // thread ↔ E consecutive outputs: warm-up, recurrence, epilogue, and E consecutive elements stored straight from registers — a wave's
         // 64 × E outputs are one contiguous run, so its two 16-byte stores per lane fill whole lines between them (no trip back through LDS)
         const int e0 = tid * E;
@@ -261,9 +296,9 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
 
 template <int KIND, int E, typename R>
 static void tail_launch_fast(int interp, const TailParams &P, unsigned grid, size_t lds, hipStream_t st) {
-    if (interp == AUKIT_INTERP_NONE) hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_NONE, E, R, float>), dim3(grid), dim3(256), lds, st, P);
-    else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_LINEAR, E, R, float>), dim3(grid), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_CUBIC, E, R, float>), dim3(grid), dim3(256), lds, st, P);
+    if (interp == AUKIT_INTERP_NONE) hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_NONE, E, R, float, 64>), dim3(grid), dim3(256), lds, st, P);
+    else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_LINEAR, E, R, float, 64>), dim3(grid), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_iir_tail_fast<KIND, AUKIT_INTERP_CUBIC, E, R, float, 64>), dim3(grid), dim3(256), lds, st, P);
 }
 
 template <int KIND, int E, typename R, typename OUT_T>
@@ -294,25 +329,25 @@ static TailShape tail_shape(aukit_ctx *ctx, int kind, int rows_kind, int mix_cha
     if (rows_kind == TAIL_ROWS_F64) return S;
     const double mag = rows_kind == TAIL_ROWS_I8 ? 128.0 : std::max(1.0, std::ldexp(1.0, 31) / full);
     const double wd = std::ceil((37.0 + std::log(mag)) / decay);
-    S.E = (avg_nout >= 6144 && kind == TAIL_QOA) ? 8 : 4;   // long jobs (QOA calls): 2048-output tiles; FLAC blocks: 1024
-    S.T = 256 * S.E;
-    if (wd > (double)S.T) return S;
-    S.W = (int)wd;
-    const double capd = std::ceil((double)(S.T + S.W) / S.ratio) + 8;
-    if (capd > 32768) return S;
-    S.cap = ((int)capd + 3) & ~3;
-    S.xbn = ((S.T + S.W) + (S.T + S.W) / S.E + 2 + 3) & ~3;
-    // F32 storage: the f32 interpolation (k_iir_tail_fast) — integer sample rates with at most 512 output phases
+    // F32 storage: the f32 interpolation (k_iir_tail_fast, wave-private tiles) — integer sample rates with at most 512 output phases
     S.fast = dtype == AUKIT_F32 && !ctx->exact_math && !getenv("AUKIT_NO_TAIL_FAST") && rate == std::floor(rate) && rate <= 4e9;
     if (S.fast) {
         unsigned long long x = 48000, y = (unsigned long long)rate;
         while (y) { const unsigned long long tq = x % y; x = y; y = tq; }
         S.fa = (unsigned long long)rate / x; S.fb = 48000 / x;   // x - 1 = (i - 1) / ratio = (i - 1) fa / fb
         if (S.fb == 1) { S.fa *= 2; S.fb = 2; }
-        S.fast = S.fb <= 512 && ((double)max_nout * (double)S.fa + (double)S.fb) * (double)S.fb < 4294967296.0;
+        S.fast = S.fb <= 512 && ((double)max_nout * (double)S.fa + (double)S.fb) * (double)S.fb < 4294967296.0 && wd <= 192;
     }
+    S.E = (avg_nout >= 6144 && kind == TAIL_QOA) ? 8 : 4;   // long jobs (QOA calls): 2048-output tiles (512 per wave in the fast kernel); FLAC blocks: 1024 (256)
+    S.T = (S.fast ? 64 : 256) * S.E;
+    if (wd > (double)S.T) return S;
+    S.W = (int)wd;
+    const double capd = std::ceil((double)(S.T + S.W) / S.ratio) + 8;
+    if (capd > 32768) return S;
+    S.cap = ((int)capd + 3) & ~3;
+    S.xbn = ((S.T + S.W) + (S.T + S.W) / S.E + 2 + 3) & ~3;
     S.wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
-    S.lds = S.fast ? ((((size_t)S.fb * S.wf + 3) & ~(size_t)3) + (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn)) * 4 : (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn) * 8;
+    S.lds = S.fast ? ((((size_t)S.fb * S.wf + 3) & ~(size_t)3) + 4 * (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn)) * 4 : (size_t)S.C * ((size_t)S.cap + (size_t)S.xbn) * 8;   // (fast: four wave tiles per workgroup)
     if (S.lds > 150 * 1024) return S;
     S.ok = true;
     return S;
@@ -350,10 +385,10 @@ bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows,
         if ((*rc = upload_table(ctx, ctx->tile_buf, w.data(), w.size() * 4))) return true;
         P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
         P.fa = (unsigned)S.fa; P.fb = (unsigned)S.fb; P.fmagic = (unsigned)((4294967296ull + S.fb - 1) / S.fb);
-        P.dq256 = (unsigned)((256ull * S.fa) / S.fb); P.dr256 = (unsigned)((256ull * S.fa) % S.fb);
+        P.dq256 = (unsigned)((64ull * S.fa) / S.fb); P.dr256 = (unsigned)((64ull * S.fa) % S.fb);   // the step of one row of a wave tile (64 outputs)
     }
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / S.lds));
-    const unsigned grid = (unsigned)std::min<uint64_t>(P.n_tiles, (uint64_t)ctx->num_cus * per_cu);
+    const unsigned grid = (unsigned)std::min<uint64_t>(S.fast ? (P.n_tiles + 3) / 4 : P.n_tiles, (uint64_t)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t lds = S.lds;
     if (S.fast) {
