@@ -261,13 +261,32 @@ AUKIT_DEV unsigned hash_lookup(const CandHash &H, u64 key) {
 __global__ __launch_bounds__(256) void k_flac_find(const FlacGlobals G, u64 total, unsigned n, Cand *cands, u64 cap, u64 *count, CandHash H) {
     // candidates are collected per workgroup in LDS and published with ONE atomic on the global counter: with an atomicAdd per
     // candidate (220 000 of them on one word, ≈ 88 per µs: MI355X_MICROARCH.md, dequeue) the counter alone cost 2.5 of the kernel's 2.8 ms
-    constexpr unsigned LMAX = 1024;
+    constexpr unsigned LMAX = 1024, RMAX = 1024;
     __shared__ Cand s_list[LMAX];
-    __shared__ unsigned s_n;
+    __shared__ u64 s_raw[RMAX];
+    __shared__ unsigned s_n, s_nraw;
     __shared__ u64 s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { s_n = 0; s_nraw = 0; }
     __syncthreads();
     const u64 base_off = G.base_bit >> 3;  // G.src = (bytes of G.w0) + base_off
+    auto examine = [&](u64 pa) {   // a position that holds the sync code: is it a plausible frame start of a stream?
+        if (pa < base_off || pa - base_off + 1 >= total) return;
+        const u64 p = pa - base_off;  // byte position in the batch
+        unsigned lo = 0, hi = n;      // stream: off[s] <= p < off[s + 1]
+        while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (G.off[m] <= p) lo = m; else hi = m; }
+        const unsigned s = lo;
+        const FlacStreamInfo si = G.info[s];
+        const u64 b1 = G.off[s + 1];
+        if (si.status || p < G.off[s] + si.first_byte || p + 1 >= b1) return;
+        // Speed-only filter: a frame that fails it is still decoded — the chain asks for any position that is not in the table.
+        if (!flac_header_plausible(G.src, p, b1, si.channels, si.depth)) return;
+        const unsigned kl = atomicAdd(&s_n, 1u);
+        if (kl < LMAX) s_list[kl] = Cand{s, 0, p};
+        else {  // the workgroup's list is full: publish this one directly
+            const u64 k = atomicAdd(count, 1ull);
+            if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
+        }
+    };
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(G.w0);
     const u64 nvec = G.safe_words >> 1;
     // four vectors per thread and trip, all loads issued before the first is looked at: with one load per trip the kernel had
@@ -305,29 +324,22 @@ __global__ __launch_bounds__(256) void k_flac_find(const FlacGlobals G, u64 tota
             const unsigned zb = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);  // 0x80 in every zero byte of z, nowhere else
             if (zb) hits |= (((zb >> 7) & 1u) | ((zb >> 14) & 2u) | ((zb >> 21) & 4u) | ((zb >> 28) & 8u)) << (4 * q);
         }
+        // A hit is only noted here (round 3): what follows it — a binary search over the stream offsets, the header's plausibility test with
+        // its CRC-8 loop: a dozen dependent loads — ran inside the streaming loop, on one or two lanes of a wave whose other lanes waited; a third
+        // of the wave-trips met one (0xFF 0xF8 turns up every 32 KiB of noise, a real frame every 14 KiB).  The workgroup examines its hits
+        // afterwards, one per thread, all at once.
         while (hits) {
             const int i = __builtin_ctz(hits);
             hits &= hits - 1;
             const u64 pa = 16 * c + (u64)i;
-            if (pa < base_off || pa - base_off + 1 >= total) continue;
-            const u64 p = pa - base_off;  // byte position in the batch
-            unsigned lo = 0, hi = n;      // stream: off[s] <= p < off[s + 1]
-            while (hi - lo > 1) { const unsigned m = (lo + hi) >> 1; if (G.off[m] <= p) lo = m; else hi = m; }
-            const unsigned s = lo;
-            const FlacStreamInfo si = G.info[s];
-            const u64 b1 = G.off[s + 1];
-            if (si.status || p < G.off[s] + si.first_byte || p + 1 >= b1) continue;
-            // Speed-only filter: a frame that fails it is still decoded — the chain asks for any position that is not in the table.
-            if (!flac_header_plausible(G.src, p, b1, si.channels, si.depth)) continue;
-            const unsigned kl = atomicAdd(&s_n, 1u);
-            if (kl < LMAX) s_list[kl] = Cand{s, 0, p};
-            else {  // the workgroup's list is full: publish this one directly
-                const u64 k = atomicAdd(count, 1ull);
-                if (k < cap) { cands[k] = Cand{s, 0, p}; hash_insert(H, p, (unsigned)k); }
-            }
+            const unsigned kr = atomicAdd(&s_nraw, 1u);
+            if (kr < RMAX) s_raw[kr] = pa;
+            else examine(pa);   // (the list is full: on the spot, as before)
         }
       }
     }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < min(s_nraw, RMAX); i += 256) examine(s_raw[i]);
     __syncthreads();
     const unsigned nl = min(s_n, LMAX);
     if (threadIdx.x == 0) s_base = nl ? atomicAdd(count, (u64)nl) : 0ull;
