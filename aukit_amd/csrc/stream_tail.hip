@@ -338,7 +338,8 @@ static TailShape tail_shape(aukit_ctx *ctx, int kind, int rows_kind, int mix_cha
         if (S.fb == 1) { S.fa *= 2; S.fb = 2; }
         S.fast = S.fb <= 512 && ((double)max_nout * (double)S.fa + (double)S.fb) * (double)S.fb < 4294967296.0 && wd <= 192;
     }
-    S.E = (avg_nout >= 6144 && kind == TAIL_QOA) ? 8 : 4;   // long jobs (QOA calls): 2048-output tiles (512 per wave in the fast kernel); FLAC blocks: 1024 (256)
+    S.E = ((avg_nout >= 6144 && kind == TAIL_QOA) || (S.fast && avg_nout >= 2048)) ? 8 : 4;
+    if (S.fast && S.C == 1 && avg_nout >= 4096 && !getenv("AUKIT_TAIL_E8")) S.E = 16;   // a thread's warm-up (W steps) is paid once per E outputs: stream.flac's tail 4.6 / 3.3 / 3.1 ms for E = 4 / 8 / 16, stream.qoa's 2.8 -> 2.5   // long jobs (QOA calls): 2048-output tiles; FLAC blocks: 1024; the fast kernel's wave tiles: 512 outputs from 2048 per job on
     S.T = (S.fast ? 64 : 256) * S.E;
     if (wd > (double)S.T) return S;
     S.W = (int)wd;
@@ -392,7 +393,9 @@ bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows,
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t lds = S.lds;
     if (S.fast) {
-        if (kind == TAIL_QOA) { if (S.E == 8) tail_launch_fast<TAIL_QOA, 8, signed char>(interp, P, grid, lds, ctx->stream); else tail_launch_fast<TAIL_QOA, 4, signed char>(interp, P, grid, lds, ctx->stream); }
+        if (kind == TAIL_QOA) { if (S.E == 16) tail_launch_fast<TAIL_QOA, 16, signed char>(interp, P, grid, lds, ctx->stream); else if (S.E == 8) tail_launch_fast<TAIL_QOA, 8, signed char>(interp, P, grid, lds, ctx->stream); else tail_launch_fast<TAIL_QOA, 4, signed char>(interp, P, grid, lds, ctx->stream); }
+        else if (S.E == 16) tail_launch_fast<TAIL_FLAC, 16, int>(interp, P, grid, lds, ctx->stream);
+        else if (S.E == 8) tail_launch_fast<TAIL_FLAC, 8, int>(interp, P, grid, lds, ctx->stream);
         else tail_launch_fast<TAIL_FLAC, 4, int>(interp, P, grid, lds, ctx->stream);
     } else if (kind == TAIL_QOA) { if (S.E == 8) tail_launch_out<TAIL_QOA, 8, signed char>(interp, dtype, P, grid, lds, ctx->stream); else tail_launch_out<TAIL_QOA, 4, signed char>(interp, dtype, P, grid, lds, ctx->stream); }
     else tail_launch_out<TAIL_FLAC, 4, int>(interp, dtype, P, grid, lds, ctx->stream);
