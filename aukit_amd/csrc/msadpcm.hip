@@ -227,6 +227,7 @@ struct MsWaveParams {
     double inv_fb, ratio, rcp;
     int exact_rcp;
     int unit;                                // sample rate 48000: every position is an integer, exactly (x = (i - 1) / 1 + 1)
+    unsigned sst;                            // int8 stream output: bytes per block and output row in the LDS staging area (an odd number of dwords), 0: outputs go out pair by pair
 };
 
 struct MsLane { int s1, s2, d, c1, c2; double ws1, ws2, wd; };
@@ -345,7 +346,8 @@ enum { MS_ROWS_I16 = 0, MS_ROWS_F32 = 1, MS_ROWS_F64 = 2, MS_STREAM = 3 };
 template <int C, int RB, int MODE, int INTERP, bool MIX, typename OUT_T, int FB = RB>
 __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     constexpr int R = RB * 2 / C;         // samples per channel and round
-    constexpr int ROW = 4 + R;            // floats per (block, channel) row: slots 0..3 = table indices R r - 1 .. R r + 2, slot(t) = t - R r + 1
+    constexpr int ROW = 4 + R + 1;        // floats per (block, channel) row: slots 0..3 = table indices R r - 1 .. R r + 2, slot(t) = t - R r + 1
+                                          // (+ 1: an odd stride — a lane's row starts in its own bank; with 36 or 20 every 8th lane shared one)
     constexpr int SEGS = FB / 16;         // 16-byte vectors of a block per fetch
     constexpr int RSEG = RB / 16;         // ... per round
     constexpr int RPF = FB / RB;          // rounds per fetch
@@ -364,6 +366,8 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     unsigned long long *const os = ob + 64;                                        // 64 channel strides
     int *const adl = reinterpret_cast<int *>(os + 64);                             // 16
     float *const wt = reinterpret_cast<float *>(adl + 16);                         // fb × WF (stream mode)
+    constexpr bool LANEOUT = MODE == MS_STREAM && sizeof(OUT_T) == 1;               // int8 chunks: every lane makes its own block's outputs (below)
+    [[maybe_unused]] signed char *const stage = reinterpret_cast<signed char *>(wt + ((MODE == MS_STREAM ? P.fb * WF : 0u) + 3u & ~3u));   // (C == 2 && !MIX ? 2 : 1) × 64 × P.sst bytes
     if (lane < 16) adl[lane] = c_ms_adapt[lane];
     if constexpr (STREAM) for (unsigned i = lane; i < P.fb * WF; i += 64) wt[i] = P.wg[i];
     const unsigned long long ba = (unsigned long long)P.block_align;
@@ -513,113 +517,154 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
             }
         } else {
             // outputs whose floor(x) = k lies in R r + 1 .. R r + R: every tap k - 2 .. k + 2 is in the table now
-            const MsRound rd = P.rounds[r];
+            // (through the constant address space: with a uniform index that is an s_load, counted by lgkmcnt — as a plain global load it sits behind
+            // vmcnt(0), i.e. behind the previous round's output stores and this round's prefetch)
+            MsRound rd;
+            {
+                const __attribute__((address_space(4))) unsigned *rq = (const __attribute__((address_space(4))) unsigned *)(P.rounds + r);
+                rd.jl = rq[0]; rd.nj = rq[1]; rd.dq = rq[2]; rd.dr = rq[3]; rd.aq = rq[4]; rd.ar = rq[5]; rd.nq = rq[6]; rd.nrm = rq[7]; rd.b0q = rq[8];
+            }
             const unsigned nj = rd.nj;
             const int kbase = R * r;            // table index of slot 1
             const int w_hi = (int)P.spb_dec;    // #left
             Seg sg; sg.w_lo = 1; sg.w_hi = w_hi;
             const unsigned total = nvalid * nj;
+            // one output: block-relative index j at position (q0, remc) [x - 1 = q0 + remc / fb], from the block's table rows t0 (t1: the second channel)
+            auto one_output = [&](unsigned j, unsigned q0, unsigned remc, const float *t0, const float *t1, bool active, OUT_T &v0, OUT_T &v1) {
+                const int k = (int)q0 + 1;  // floor(x), exact
+                const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && remc != 0));
+                const int s1 = inside ? k - kbase + 1 : 3;   // slot of table index k
+                auto tier1 = [&](const float *tp) -> float {   // the interpolated value in f32: taps of magnitude < 259 with <= 2^-23 of relative rounding,
+                    const float p1 = tp[s1], p2 = tp[s1 + 1];   // weights rounded once, four roundings below 512: < 3e-4 in all (cf. k_ima_stream_f32)
+                    if constexpr (INTERP == AUKIT_INTERP_NONE) return p1;
+                    else if constexpr (INTERP == AUKIT_INTERP_LINEAR) return __builtin_fmaf(p2 - p1, wt[remc], p1);
+                    else {
+                        const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * remc);
+                        const float p0 = tp[s1 - 1], p3 = tp[s1 + 2];
+                        return __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
+                    }
+                };
+                auto tier2 = [&](const float *tp) -> double {   // fp64, exact rational position, FMA Horner
+                    auto cv = [](float p) -> double { if constexpr (FLOORED) return (double)p; else return CvMsSample::cv((double)p); };
+                    const double p1 = cv(tp[s1]), p2 = cv(tp[s1 + 1]);
+                    const double fx = (double)remc * P.inv_fb;
+                    double v;
+                    if constexpr (INTERP == AUKIT_INTERP_NONE) v = p1;
+                    else if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
+                    else {
+                        const double p0 = cv(tp[s1 - 1]), p3 = cv(tp[s1 + 2]);
+                        const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                        const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                        const double c1 = 0.5 * (p2 - p0);
+                        v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+                    }
+                    return v;
+                };
+                auto tier3 = [&](const float *tp) -> double {   // the reference's own operation order on the same table
+                    bool isint;
+                    if constexpr (FLOORED) return eval_at<INTERP, false, float, CvIdentity>(RP, sg, tp + 1, kbase, j, &isint);
+                    else return eval_at<INTERP, false, float, CvMsSample>(RP, sg, tp + 1, kbase, j, &isint);
+                };
+                // tiers 2 and 3 for one output line: ta alone, or ta + tb / 2 (:2672).  Taps that are all equal need no margin: the FMA form
+                // returns cv(p1) itself (every coefficient is an exact zero) and the reference's sum is cv(p1) + a few ulps, on the same side
+                // of every integer (cv(p1) is an integer only when p1's arithmetic is exact) — digital silence stays off tier 3
+                auto flat = [&](const float *tp) {
+                    if constexpr (INTERP == AUKIT_INTERP_LINEAR) return tp[s1] == tp[s1 + 1];
+                    else if constexpr (INTERP == AUKIT_INTERP_CUBIC) return tp[s1 - 1] == tp[s1] && tp[s1] == tp[s1 + 1] && tp[s1 + 1] == tp[s1 + 2];
+                    else return true;
+                };
+                auto slow = [&](const float *ta, const float *tb) -> double {
+                    double d = 0;
+                    bool ok = inside;
+                    if (inside) {
+                        d = tier2(ta);
+                        bool fl = P.unit || (remc != 0 && flat(ta));   // unit: the value is d[x] itself
+                        if (tb) { d = d + tier2(tb) / 2; fl = P.unit || (fl && flat(tb)); }
+                        if (!fl) { const double fr = d - floor(d); ok = fr > 1e-6 && fr < 1 - 1e-6; }
+                    }
+                    if (!ok) { d = tier3(ta); if (tb) d = d + tier3(tb) / 2; }
+                    return lua_clamp(floor(d), -128, 127);   // :2673 / :2674 / :2727
+                };
+                auto put = [&](float v, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
+                    float fl = floorf(v);
+                    const float fr = v - fl;
+                    bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
+                    if constexpr (FLOORED) { if (INTERP == AUKIT_INTERP_NONE || P.unit) accept = inside; }   // the entry itself (or l + r / 2 of two entries): exact
+                    if (active && !accept) {
+                        const double d = slow(ta, tb);
+                        if constexpr (sizeof(OUT_T) == 8) return (OUT_T)d;
+                        fl = (float)d;
+                    }
+                    if constexpr (sizeof(OUT_T) == 8) return (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);
+                    else return (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);
+                };
+                if constexpr (C == 1) v0 = put(tier1(t0), t0, nullptr);
+                else if constexpr (MIX) v0 = put(__builtin_fmaf(tier1(t1), 0.5f, tier1(t0)), t0, t1);   // l + r / 2
+                else { v0 = put(tier1(t0), t0, nullptr); v1 = put(tier1(t1), t1, nullptr); }
+            };
+            if (nj && LANEOUT && P.sst) {
+                // int8 chunks (round 3).  Every block of the wave has the same geometry, so output j of the round sits at the same (q, rem) in all
+                // of them: lane = block, the position walks in scalar registers, the four taps come from the lane's own row (odd stride: its own
+                // bank) and the weights from one broadcast read.  The results wait in an LDS row per block and leave as before — pairs (block,
+                // output) 64 at a time, consecutive lanes on consecutive bytes — in a loop that only copies.  (The pair-mapped loop below spent
+                // ~90 VALU instructions per 64 outputs on finding out which block, row, position and address a lane's pair has: 3150 of a
+                // round's 3700.)
+                const float *const t0 = tab + lane * ROW, *const t1 = t0 + 64 * ROW;
+                signed char *const st0 = stage + (unsigned)lane * P.sst, *const st1 = st0 + 64u * P.sst;
+                // (the round's constants come from memory, i.e. in vector registers: say that they are the same in every lane, so that the position,
+                // the slot of its taps and the address of its weights are computed once per output by the scalar unit)
+                const unsigned jl_s = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.jl), nj_s = (unsigned)__builtin_amdgcn_readfirstlane((int)nj);
+                unsigned q0 = (unsigned)(((unsigned long long)jl_s * P.fa) / P.fb), rem = jl_s * P.fa - q0 * P.fb;   // scalar arithmetic (jl fa < 2^32: checked by the host)
+                const unsigned dq1 = P.fa / P.fb, dr1 = P.fa - dq1 * P.fb;
+                for (unsigned jj = 0; jj < nj_s; jj++) {
+                    OUT_T v0 = 0, v1 = 0;
+                    one_output(jl_s + jj, q0, rem, t0, t1, valid, v0, v1);
+                    st0[jj] = (signed char)v0;
+                    if constexpr (C == 2 && !MIX) st1[jj] = (signed char)v1;
+                    q0 += dq1; rem += dr1;
+                    if (rem >= P.fb) { rem -= P.fb; q0++; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                unsigned b = rd.b0q ? (unsigned)lane / nj : 0, jj = rd.b0q ? (unsigned)lane % nj : (unsigned)lane;
+                for (unsigned base = 0; base < total; base += 64) {
+                    if (base + lane < total) {
+                        OUT_T *const o0 = reinterpret_cast<OUT_T *>(P.out) + ob[b] + rd.jl + jj;
+                        *o0 = (OUT_T)stage[b * P.sst + jj];
+                        if constexpr (C == 2 && !MIX) o0[os[b]] = (OUT_T)stage[(64u + b) * P.sst + jj];
+                    }
+                    b += rd.dq; jj += rd.dr;
+                    if (jj >= nj) { jj -= nj; b++; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else
             if (nj) {
                 // lanes walk the round's (block, output) pairs 64 at a time; a lane's pair, its floor(x) - 1 = q and the phase rem advance by
                 // additions with one carry each (host-made constants of the round: no multiply or divide per output)
                 unsigned b = rd.b0q ? (unsigned)lane / nj : 0, jj = rd.b0q ? (unsigned)lane % nj : (unsigned)lane;
                 unsigned q0, rem;
                 { const unsigned j = rd.jl + jj; q0 = __umulhi(j * P.fa, P.fmagic); rem = j * P.fa - q0 * P.fb; }
-#ifdef AUKIT_MS_UNROLL
-#pragma unroll AUKIT_MS_UNROLL
-#endif
                 for (unsigned base = 0; base < total; base += 64) {
                     const bool active = base + lane < total;
                     const unsigned bb = active ? b : 0;
-                    const unsigned j = rd.jl + jj;
-                    const int k = (int)q0 + 1;  // floor(x), exact
-                    const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && rem != 0));
-                    const int s1 = inside ? k - kbase + 1 : 3;   // slot of table index k
+                    const unsigned j = rd.jl + jj, q0c = q0, remc = rem;
                     const float *t0 = tab + __umul24(bb, ROW), *t1 = t0 + 64 * ROW;
-                    const unsigned remc = rem;
                     // the next pair of this lane
                     b += rd.dq; jj += rd.dr; q0 += rd.aq; rem += rd.ar;
                     if (rem >= P.fb) { rem -= P.fb; q0++; }
                     if (jj >= nj) { jj -= nj; b++; q0 -= rd.nq; if (rem < rd.nrm) { rem += P.fb; q0--; } rem -= rd.nrm; }
-                    auto tier1 = [&](const float *tp) -> float {   // the interpolated value in f32: taps of magnitude < 259 with <= 2^-23 of relative rounding,
-                        const float p1 = tp[s1], p2 = tp[s1 + 1];   // weights rounded once, four roundings below 512: < 3e-4 in all (cf. k_ima_stream_f32)
-                        if constexpr (INTERP == AUKIT_INTERP_NONE) return p1;
-                        else if constexpr (INTERP == AUKIT_INTERP_LINEAR) return __builtin_fmaf(p2 - p1, wt[remc], p1);
-                        else {
-                            const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * remc);
-                            const float p0 = tp[s1 - 1], p3 = tp[s1 + 2];
-                            return __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
-                        }
-                    };
-                    auto tier2 = [&](const float *tp) -> double {   // fp64, exact rational position, FMA Horner
-                        auto cv = [](float p) -> double { if constexpr (FLOORED) return (double)p; else return CvMsSample::cv((double)p); };
-                        const double p1 = cv(tp[s1]), p2 = cv(tp[s1 + 1]);
-                        const double fx = (double)remc * P.inv_fb;
-                        double v;
-                        if constexpr (INTERP == AUKIT_INTERP_NONE) v = p1;
-                        else if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
-                        else {
-                            const double p0 = cv(tp[s1 - 1]), p3 = cv(tp[s1 + 2]);
-                            const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                            const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                            const double c1 = 0.5 * (p2 - p0);
-                            v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
-                        }
-                        return v;
-                    };
-                    auto tier3 = [&](const float *tp) -> double {   // the reference's own operation order on the same table
-                        bool isint;
-                        if constexpr (FLOORED) return eval_at<INTERP, false, float, CvIdentity>(RP, sg, tp + 1, kbase, j, &isint);
-                        else return eval_at<INTERP, false, float, CvMsSample>(RP, sg, tp + 1, kbase, j, &isint);
-                    };
-                    // tiers 2 and 3 for one output line: ta alone, or ta + tb / 2 (:2672).  Taps that are all equal need no margin: the FMA form
-                    // returns cv(p1) itself (every coefficient is an exact zero) and the reference's sum is cv(p1) + a few ulps, on the same side
-                    // of every integer (cv(p1) is an integer only when p1's arithmetic is exact) — digital silence stays off tier 3
-                    auto flat = [&](const float *tp) {
-                        if constexpr (INTERP == AUKIT_INTERP_LINEAR) return tp[s1] == tp[s1 + 1];
-                        else if constexpr (INTERP == AUKIT_INTERP_CUBIC) return tp[s1 - 1] == tp[s1] && tp[s1] == tp[s1 + 1] && tp[s1 + 1] == tp[s1 + 2];
-                        else return true;
-                    };
-                    auto slow = [&](const float *ta, const float *tb) -> double {
-                        double d = 0;
-                        bool ok = inside;
-                        if (inside) {
-                            d = tier2(ta);
-                            bool fl = P.unit || (remc != 0 && flat(ta));   // unit: the value is d[x] itself
-                            if (tb) { d = d + tier2(tb) / 2; fl = P.unit || (fl && flat(tb)); }
-                            if (!fl) { const double fr = d - floor(d); ok = fr > 1e-6 && fr < 1 - 1e-6; }
-                        }
-                        if (!ok) { d = tier3(ta); if (tb) d = d + tier3(tb) / 2; }
-                        return lua_clamp(floor(d), -128, 127);   // :2673 / :2674 / :2727
-                    };
-                    auto put = [&](OUT_T *o, float v, const float *ta, const float *tb) {
-                        float fl = floorf(v);
-                        const float fr = v - fl;
-                        bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
-                        if constexpr (FLOORED) { if (INTERP == AUKIT_INTERP_NONE || P.unit) accept = inside; }   // the entry itself (or l + r / 2 of two entries): exact
-                        if (active && !accept) {
-                            const double d = slow(ta, tb);
-                            if constexpr (sizeof(OUT_T) == 8) { *o = (OUT_T)d; return; }
-                            fl = (float)d;
-                        }
-                        if (active) {
-                            if constexpr (sizeof(OUT_T) == 8) *o = (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);
-                            else *o = (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);
-                        }
-                    };
                     OUT_T *const o0 = reinterpret_cast<OUT_T *>(P.out) + ob[bb] + j;
-                    if constexpr (C == 1) put(o0, tier1(t0), t0, nullptr);
-                    else if constexpr (MIX) put(o0, __builtin_fmaf(tier1(t1), 0.5f, tier1(t0)), t0, t1);   // l + r / 2
-                    else { put(o0, tier1(t0), t0, nullptr); put(o0 + os[bb], tier1(t1), t1, nullptr); }
+                    OUT_T v0 = 0, v1 = 0;
+                    one_output(j, q0c, remc, t0, t1, active, v0, v1);
+                    if (active) { *o0 = v0; if constexpr (C == 2 && !MIX) o0[os[bb]] = v1; }
                 }
             }
         }
         // the round's last four samples are the next round's slots 0..3
         if (r + 1 < nr) {
             __builtin_amdgcn_wave_barrier();
-            const float4 t = *reinterpret_cast<const float4 *>(r0 + R);
-            *reinterpret_cast<float4 *>(r0) = t;
-            if constexpr (C == 2) { const float4 u = *reinterpret_cast<const float4 *>(r1 + R); *reinterpret_cast<float4 *>(r1) = u; }
+            { const float a0 = r0[R], a1 = r0[R + 1], a2 = r0[R + 2], a3 = r0[R + 3]; r0[0] = a0; r0[1] = a1; r0[2] = a2; r0[3] = a3; }
+            if constexpr (C == 2) { const float a0 = r1[R], a1 = r1[R + 1], a2 = r1[R + 2], a3 = r1[R + 3]; r1[0] = a0; r1[1] = a1; r1[2] = a2; r1[3] = a3; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -656,10 +701,10 @@ static void ms_launch_stream(int interp, const MsWaveParams &P, unsigned grid, s
     else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
     else hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_CUBIC, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
 }
-static size_t ms_lds_bytes(int C, int rb, unsigned wt_floats, int fb = 0) {
+static size_t ms_lds_bytes(int C, int rb, unsigned wt_floats, int fb = 0, size_t stage_bytes = 0) {
     if (fb < rb) fb = rb;
-    const int R = rb * 2 / C, ROW = 4 + R, INS = fb == 16 ? 4 : fb / 4 + 4;
-    return (size_t)64 * INS * 4 + (size_t)C * 64 * ROW * 4 + 3 * 64 * 8 + 16 * 4 + (size_t)wt_floats * 4;
+    const int R = rb * 2 / C, ROW = 4 + R + 1, INS = fb == 16 ? 4 : fb / 4 + 4;
+    return (size_t)64 * INS * 4 + (size_t)C * 64 * ROW * 4 + 3 * 64 * 8 + 16 * 4 + (((size_t)wt_floats + 3) & ~(size_t)3) * 4 + stage_bytes;
 }
 
 struct MsBlocks { std::vector<uint64_t> blk0; uint64_t bps = 0; };
@@ -831,7 +876,18 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
     }
     const int wf = interp == AUKIT_INTERP_CUBIC ? 4 : 1;
     const int MS_RB = MS_RB_STREAM;
-    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM) : 0;
+    // int8 chunks: the round's outputs of every block wait in an LDS row (sst bytes, an odd number of dwords) before they leave
+    unsigned sst = 0;
+    // (stereo only.  Same-box A/B, 1024 ten-second streams, pairs / lanes: stereo 2.98 / 2.81 ms, stereo mixed to mono 2.40 / 2.11, mono 2.55 / 3.26 —
+    // PMC for mono: 828 M / 963 M VALU instructions, LDS bank conflicts 78 M / 0: the copy loop that brings the staged bytes out costs a
+    // mono round more than the bookkeeping it saves, AUKIT_MS_LANES=1 forces it)
+    if (wave && dtype == AUKIT_I8 && !getenv("AUKIT_MS_PAIRS") && (C == 2 || getenv("AUKIT_MS_LANES"))) {
+        const unsigned long long Rr = (unsigned long long)(MS_RB * 2 / C);
+        const unsigned long long njmax = (Rr * fb + fa - 1) / fa + 2;   // outputs whose floor(x) falls into one round's samples
+        sst = (unsigned)((((njmax + 3) / 4) | 1) * 4);
+        if ((size_t)nd * 64 * sst > 24 * 1024) sst = 0;                // strong up-sampling: the pair-mapped loop
+    }
+    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM, (size_t)nd * 64 * sst) : 0;
     if (wave && lds <= 64 * 1024) {
         const int R = MS_RB * 2 / C, ndata = d->block_align - 7 * C, nr = (ndata + MS_RB - 1) / MS_RB;
         // tables: blk0 (n + 1) | out_off (n) | out_stride (n) | err | rounds (nr) | weights (fb * wf, f32)
@@ -882,6 +938,7 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         P.ratio = ratio; P.rcp = 1.0 / ratio;
         P.exact_rcp = exact_div_verified(ctx, ratio, (uint64_t)newlen + 2) ? 1 : 0;
         P.unit = d->sample_rate == 48000 ? 1 : 0;
+        P.sst = sst;
         const unsigned grid = (unsigned)((nblocks + 63) / 64);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
 #define AUKIT_MS_STREAM(CC, RBB, MIXX)                                                                                                 \
