@@ -534,13 +534,22 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                 const int k = (int)q0 + 1;  // floor(x), exact
                 const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && remc != 0));
                 const int s1 = inside ? k - kbase + 1 : 3;   // slot of table index k
-                auto tier1 = [&](const float *tp) -> float {   // the interpolated value in f32: taps of magnitude < 259 with <= 2^-23 of relative rounding,
-                    const float p1 = tp[s1], p2 = tp[s1 + 1];   // weights rounded once, four roundings below 512: < 3e-4 in all (cf. k_ima_stream_f32)
-                    if constexpr (INTERP == AUKIT_INTERP_NONE) return p1;
-                    else if constexpr (INTERP == AUKIT_INTERP_LINEAR) return __builtin_fmaf(p2 - p1, wt[remc], p1);
-                    else {
+                // tier 1: the interpolated value in f32 — taps of magnitude < 259 with <= 2^-23 of relative rounding, weights rounded once, four
+                // roundings below 1024: < 3e-4 in all (cf. k_ima_stream_f32).  Written around p1 (the weights sum to 1): equal taps — silence, a
+                // clipped stretch — give p1 itself, exactly, and `spread` (the largest |tap - p1|, one v_max3) says so; see `put`
+                auto tier1 = [&](const float *tp, float &spread) -> float {
+                    const float p1 = tp[s1], p2 = tp[s1 + 1];
+                    if constexpr (INTERP == AUKIT_INTERP_NONE) { spread = 1.0f; return p1; }
+                    else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { spread = C == 1 ? fabsf(p2 - p1) : 1.0f; return __builtin_fmaf(p2 - p1, wt[remc], p1); }
+                    else if constexpr (C == 1) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * remc);
+                        const float d0 = tp[s1 - 1] - p1, d2 = p2 - p1, d3 = tp[s1 + 2] - p1;
+                        spread = fmaxf(fmaxf(fabsf(d0), fabsf(d2)), fabsf(d3));
+                        return __builtin_fmaf(w.w, d3, __builtin_fmaf(w.z, d2, __builtin_fmaf(w.x, d0, p1)));
+                    } else {   // (stereo: entries are floored integers and tier 2 is cheap there — the plain form measured faster: 2.81 against 3.00 ms)
                         const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * remc);
                         const float p0 = tp[s1 - 1], p3 = tp[s1 + 2];
+                        spread = 1.0f;
                         return __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
                     }
                 };
@@ -585,11 +594,17 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     if (!ok) { d = tier3(ta); if (tb) d = d + tier3(tb) / 2; }
                     return lua_clamp(floor(d), -128, 127);   // :2673 / :2674 / :2727
                 };
-                auto put = [&](float v, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
+                auto put = [&](float v, float spread, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
                     float fl = floorf(v);
                     const float fr = v - fl;
                     bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
                     if constexpr (FLOORED) { if (INTERP == AUKIT_INTERP_NONE || P.unit) accept = inside; }   // the entry itself (or l + r / 2 of two entries): exact
+                    // Equal taps: the difference forms of tier 1 return the entry itself (or l + r / 2), and an f32 entry that is an integer IS the
+                    // reference's value (an entry is the predictor times 1/128 — exact — or times RN(1/127): integral only for multiples of 127,
+                    // which it then represents exactly; anything else is 1/127 away from every integer).  Measured on the bench's encoder-made
+                    // streams: 5 % of the outputs sit in such stretches (the encoder clips) and went through tier 2 one or two lanes at a time —
+                    // half of the wave's turns, 1.2 of the kernel's 2.6 ms.
+                    if constexpr (INTERP != AUKIT_INTERP_NONE && C == 1) accept = accept || (inside && fr == 0.0f && spread == 0.0f && remc != 0);
                     if (active && !accept) {
                         const double d = slow(ta, tb);
                         if constexpr (sizeof(OUT_T) == 8) return (OUT_T)d;
@@ -598,9 +613,10 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     if constexpr (sizeof(OUT_T) == 8) return (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);
                     else return (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);
                 };
-                if constexpr (C == 1) v0 = put(tier1(t0), t0, nullptr);
-                else if constexpr (MIX) v0 = put(__builtin_fmaf(tier1(t1), 0.5f, tier1(t0)), t0, t1);   // l + r / 2
-                else { v0 = put(tier1(t0), t0, nullptr); v1 = put(tier1(t1), t1, nullptr); }
+                float sa = 1.0f, sb = 1.0f;
+                if constexpr (C == 1) { const float a = tier1(t0, sa); v0 = put(a, sa, t0, nullptr); }
+                else if constexpr (MIX) { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(__builtin_fmaf(b2, 0.5f, a), fmaxf(sa, sb), t0, t1); }   // l + r / 2
+                else { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(a, sa, t0, nullptr); v1 = put(b2, sb, t1, nullptr); }
             };
             if (nj && LANEOUT && P.sst) {
                 // int8 chunks (round 3).  Every block of the wave has the same geometry, so output j of the round sits at the same (q, rem) in all
