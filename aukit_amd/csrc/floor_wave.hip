@@ -186,7 +186,11 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             }
             float fl = floorf(w);
             const float fr = w - fl;
-            const bool accept = rem == 0 ? int_ratio : (fr > 1e-3f && fr < 1 - 1e-3f);
+            // (as plain boolean algebra — the masks stay in scalar registers; written `rem == 0 ? int_ratio : guard` hipcc built the choice out
+            // of six VALU instructions per row, in a kernel that is bound by exactly those.  At rem == 0 without an integer ratio the guard
+            // may answer as well: the reference returns p1 itself or, where its x rounds just below the integer, a value within 1e-9 of it.)
+            const bool guard = fr > 1e-3f && fr < 1 - 1e-3f;
+            const bool accept = guard || (int_ratio && rem == 0);
             if (active && !accept) fl = slow(q, rem, j);  // about one wave row in eight has such a lane
             if (active) store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f));  // :2909
         }
