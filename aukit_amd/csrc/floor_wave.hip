@@ -22,6 +22,7 @@
 // no fp64 copy of the window (tiers 2-3 convert the exact f32 samples on read) 778.  Four outputs per lane with packed stores on
 // top of that changed nothing (771): what is left is per-tile work (describe, staging, the coefficient pass, LDS round trips).
 #include <algorithm>
+#include <type_traits>
 #include "fast_wave_dev.h"
 #include "resample_dev.h"
 
@@ -151,9 +152,13 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             }
             return (float)lua_clamp(floor(v), -128, 127);
         };
-        for (unsigned rb = 0; rb < cur.cnt; rb += 64, q += F.dq64, rem += F.dr64) {
+        // (a full tile — all of a one-second chunk's but its last — runs a copy of the loop without the `active` predicate: three VALU instructions
+        // per row in a kernel that is bound by them)
+        auto rows = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        for (unsigned rb = 0; rb < (FULL ? (unsigned)WT : cur.cnt); rb += 64, q += F.dq64, rem += F.dr64) {
             const unsigned j = rb + lane;
-            const bool active = j < cur.cnt;  // lanes past the end of a short tile compute on (their taps are still inside the tables)
+            const bool active = FULL || j < cur.cnt;  // lanes past the end of a short tile compute on (their taps are still inside the tables)
             const bool wrap = rem >= F.b;
             rem -= wrap ? F.b : 0u;
             q += wrap ? 1u : 0u;
@@ -192,8 +197,10 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             const bool guard = fr > 1e-3f && fr < 1 - 1e-3f;
             const bool accept = guard || (int_ratio && rem == 0);
             if (active && !accept) fl = slow(q, rem, j);  // about one wave row in eight has such a lane
-            if (active) store_floor(orow + j, fminf(fmaxf(fl, -128.0f), 127.0f));  // :2909
+            if (active) store_floor(orow + j, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));  // :2909 (one v_med3; fl is never a nan: the window holds finite samples)
         }
+        };
+        if (cur.cnt == (unsigned)WT) rows(std::true_type{}); else rows(std::false_type{});
         if (DW) __builtin_amdgcn_wave_barrier();  // the next tile's staging overwrites both tables
         if (!more) break;
         cur = nxt;
