@@ -8,6 +8,7 @@
 //   (block, channel): 16 nibbles per lane, wave64 shuffle scan for the step index, again for the predictor.
 //   The stream.adpcm path keeps the decoded block in LDS and resamples it in the same kernel (fp64, reference order).
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <map>
 #include "resample.h"
@@ -656,13 +657,24 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
         // then advanced by additions — 64 outputs further is 64 fa = dq fb + dr
         unsigned q0 = __umulhi((unsigned)lane * P.fa, P.fmagic);
         unsigned rem = (unsigned)lane * P.fa - q0 * P.fb;
-        for (unsigned rb = 0; rb < newlen; rb += 64, q0 += P.fdq, rem += P.fdr) {
+        // Rows of 64 outputs whose taps all lie inside the table and which are all wanted — every row of a block but its first and its last one
+        // or two — run a copy of the loop body without the `inside` / `active` bookkeeping (round 3: the kernel is bound by its VALU instructions,
+        // and those were six of a row's ~50): rows rb with rb fa >= 2 fb (floor(x) >= 3) and floor((rb + 63) fa / fb) + 3 <= nb, rb + 63 < newlen
+        const unsigned mid_lo = (unsigned)(((((3ull * P.fb + P.fa - 1) / P.fa) + 63) / 64) * 64);   // (3 fb: a margin of one sample)
+        unsigned mid_end = 0;   // rows rb with rb + 64 <= mid_end are clean
+        if (newlen >= 64 && nbi >= 4) {
+            const unsigned long long jm = (((unsigned long long)(nbi - 3) * P.fb) / P.fa);       // outputs j <= jm - 1 have floor(j fa / fb) + 3 <= nb
+            const unsigned long long lim = jm < newlen ? jm : newlen;
+            mid_end = (unsigned)(lim & ~63ull);
+        }
+        auto row = [&](unsigned rb, auto cleanc) {
+            constexpr bool CLEAN = decltype(cleanc)::value;
             const unsigned j = rb + lane;
-            const bool active = j < newlen;
+            const bool active = CLEAN || j < newlen;
             if (rem >= P.fb) { rem -= P.fb; q0++; }
             const int k = (int)q0 + 1;  // floor(x)
             // straight-line for the whole wave: taps outside the table are read from a safe slot and the lane is sent to tier 3
-            const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi);  // one spare tap on the left (x may round below an integer)
+            const bool inside = CLEAN || (INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= nbi) : (k >= 2 && k + 1 <= nbi));  // one spare tap on the left (x may round below an integer)
             const int s1 = inside ? k - 1 : 2;
             const float *tp = sm + s1;
             const float p1 = tp[0], p2 = tp[1];
@@ -684,7 +696,10 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             const float fr = v - fl;
             const bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
             if (active && !accept) fl = slow(k, rem, j, inside);
-            if (active) obase[j] = (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);  // :2824
+            if (active) obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);  // :2824 (one v_med3; fl is finite)
+        };
+        for (unsigned rb = 0; rb < newlen; rb += 64, q0 += P.fdq, rem += P.fdr) {
+            if (rb >= mid_lo && rb + 64 <= mid_end) row(rb, std::true_type{}); else row(rb, std::false_type{});
         }
         __builtin_amdgcn_wave_barrier();  // the next block's decode overwrites the table
     }
