@@ -610,8 +610,8 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                         if constexpr (sizeof(OUT_T) == 8) return (OUT_T)d;
                         fl = (float)d;
                     }
-                    if constexpr (sizeof(OUT_T) == 8) return (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);
-                    else return (OUT_T)(int)fminf(fmaxf(fl, -128.0f), 127.0f);
+                    if constexpr (sizeof(OUT_T) == 8) return (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);   // (a nan — garbage input on the fp64 path — stays what fmin / fmax make of it)
+                    else return (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
                 };
                 float sa = 1.0f, sb = 1.0f;
                 if constexpr (C == 1) { const float a = tier1(t0, sa); v0 = put(a, sa, t0, nullptr); }
