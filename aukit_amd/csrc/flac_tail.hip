@@ -57,10 +57,13 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     mp[0] = 1.0;
 #pragma unroll
     for (int i = 1; i <= E; i++) mp[i] = mp[i - 1] * m;
-    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan
+    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan — zero in the lanes a step does not reach (no select, no
+                        // branch inside the tile loop: the kernel is bound by its instruction count)
     Md[0] = mp[E];
 #pragma unroll
     for (int k = 1; k < 6; k++) Md[k] = Md[k - 1] * Md[k - 1];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Md[k] = lane >= (1 << k) ? Md[k] : 0.0;
     const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
     auto skew = [](int i) { return i + i / E; };
     float mxf = 0.f;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
                 const double xv = (FULL || e0 + i < cnt) ? (double)xb[skew(e0 + i)] : xp;
                 if (i == 0 && first) y = xv;                               // y[1] = x[1]: the first sample passes  (:3592, :3612)
                 else if constexpr (HP) y = P.coef * (y + xv - xp);              // :3614
-                else y = y + P.coef * (xv - y);                                 // :3594
+                else y = __builtin_fma(P.coef, xv - y, y);                      // :3594 (fused: the tolerance path)
                 xp = xv;
                 z[i] = y;
             }
@@ -156,16 +159,16 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const double up = __shfl_up(Y, 1 << k);
-            if (lane >= (1 << k)) Y = Y + Md[k] * up;
+            Y = __builtin_fma(Md[k], up, Y);   // (Md[k] is 0 where lane < 2^k; Y and up are finite)
         }
-        Y = Y + mlane * carry_y;                       // true state after this lane's last output
+        Y = __builtin_fma(mlane, carry_y, Y);          // true state after this lane's last output
         double yin = __shfl_up(Y, 1);
         if (lane == 0) yin = carry_y;
         float res[E];
         double ylast = 0.0;
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            const double yv = z[i] + mp[i + 1] * yin;
+            const double yv = __builtin_fma(mp[i + 1], yin, z[i]);
             res[i] = (float)yv;
             if (FULL || e0 + i < cnt) mxf = fmaxf(mxf, fabsf(res[i]));
             if (!FULL && e0 + i == cnt - 1) ylast = yv;
