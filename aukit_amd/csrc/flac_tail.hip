@@ -33,18 +33,33 @@ struct RsOnepoleParams {
     unsigned fa, fb, fmagic, dq256, dr256;
     float inv_b, scale;
     double coef;
+    const float *wg;   // cubic: the four tap weights of each of the fb output phases (null: the Horner form on fx = rem / fb)
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
 // outputs, the tile's carry in registers.  (The first version — a 256-thread workgroup per row, tiles of 2048, five block barriers per tile —
 // ran at 7.3 ms on config 5 against 6.7 ms for the two kernels it replaces: a row is a serial chain of tiles, and what a tile costs is its
 // latency, not its work.)
-template <int INTERP, bool HP>
+// A double moved between lanes by DPP (two v_mov_b32 with a DPP modifier: VALU latency) instead of ds_bpermute (two LDS round trips): lanes without a
+// source lane — and rows outside ROW_MASK — get 0.  CTRL: row_shr:n = 0x110 + n, row_bcast15 = 0x142, row_bcast31 = 0x143, wave_shr:1 = 0x138.
+template <int CTRL, int ROW_MASK = 0xF>
+AUKIT_DEV double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
+// three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
+template <int INTERP, bool HP, bool TAB>
 __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     extern __shared__ float rsm[];
     constexpr int E = 8, T = 64 * E;
     float *const win = rsm;                                  // P.cap floats
     float *const xb = rsm + P.cap;                           // T + T / E + 8
+    [[maybe_unused]] float *const wt = xb + (T + T / E + 8);                 // TAB: 4 fb floats
+    if constexpr (TAB) { for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64) wt[i] = P.wg[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     const int lane = threadIdx.x;
     const unsigned r = blockIdx.x, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
     const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s];
@@ -57,13 +72,14 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     mp[0] = 1.0;
 #pragma unroll
     for (int i = 1; i <= E; i++) mp[i] = mp[i - 1] * m;
-    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan — zero in the lanes a step does not reach (no select, no
-                        // branch inside the tile loop: the kernel is bound by its instruction count)
+    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan
     Md[0] = mp[E];
 #pragma unroll
     for (int k = 1; k < 6; k++) Md[k] = Md[k - 1] * Md[k - 1];
-#pragma unroll
-    for (int k = 0; k < 6; k++) Md[k] = lane >= (1 << k) ? Md[k] : 0.0;
+    // the scan runs on DPP moves: four steps inside rows of 16 lanes (a lane without a source receives 0), then lane 15 / lane 31 of the row(s)
+    // before — with what the receiving lane's distance makes of them
+    const double mA = (lane & 16) ? pow(mp[E], (double)((lane & 15) + 1)) : 0.0;
+    const double mB = lane >= 32 ? pow(mp[E], (double)(lane - 31)) : 0.0;
     const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
     auto skew = [](int i) { return i + i / E; };
     float mxf = 0.f;
@@ -124,7 +140,10 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
                     const float fx = (float)rem * P.inv_b;
                     float v;
                     if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = fmaf(tp[2] - tp[1], fx, tp[1]);
-                    else {
+                    else if constexpr (TAB) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * rem);
+                        v = fmaf(w.w, tp[3], fmaf(w.z, tp[2], fmaf(w.y, tp[1], w.x * tp[0])));
+                    } else {
                         const float p0 = tp[0], p1 = tp[1], p2 = tp[2], p3 = tp[3];
                         const float c3 = fmaf(1.5f, p1 - p2, 0.5f * (p3 - p0));
                         const float c2 = fmaf(-0.5f, p3, fmaf(2.0f, p2, fmaf(-2.5f, p1, p0)));
@@ -156,13 +175,14 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         }
         // Y_t = z_t[E - 1] + M Y_(t-1): inclusive scan over the wave, Y_(-1) = the tile's carry
         double Y = z[E - 1];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const double up = __shfl_up(Y, 1 << k);
-            Y = __builtin_fma(Md[k], up, Y);   // (Md[k] is 0 where lane < 2^k; Y and up are finite)
-        }
+        Y = __builtin_fma(Md[0], dpp_f64<0x111>(Y), Y);
+        Y = __builtin_fma(Md[1], dpp_f64<0x112>(Y), Y);
+        Y = __builtin_fma(Md[2], dpp_f64<0x114>(Y), Y);
+        Y = __builtin_fma(Md[3], dpp_f64<0x118>(Y), Y);
+        Y = __builtin_fma(mA, dpp_f64<0x142, 0xA>(Y), Y);
+        Y = __builtin_fma(mB, dpp_f64<0x143, 0xC>(Y), Y);
         Y = __builtin_fma(mlane, carry_y, Y);          // true state after this lane's last output
-        double yin = __shfl_up(Y, 1);
+        double yin = dpp_f64<0x138>(Y);                // the lane before (lane 0 receives 0)
         if (lane == 0) yin = carry_y;
         float res[E];
         double ylast = 0.0;
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
             if (!FULL && e0 + i == cnt - 1) ylast = yv;
         }
         // the lane that holds the tile's last output hands its state to the next tile
-        if constexpr (FULL) carry_y = __shfl(Y, 63);
+        if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
         else carry_y = __shfl(ylast, (cnt - 1) / E);
         carry_x = (double)xb[skew(cnt - 1)];
         if (FULL || e0 < cnt) {
@@ -262,7 +282,8 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     constexpr int T = 512;
     if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;   // exact (q, rem) inside a tile
     const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3);
-    const size_t lds = ((size_t)cap + T + T / 8 + 8) * 4;
+    const bool tabw = a->lazy_interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
+    const size_t lds = ((size_t)cap + T + T / 8 + 8 + (tabw ? 4 * (size_t)F.b : 0)) * 4;
     if (lds > 60 * 1024) return false;
     for (uint64_t l : a->lazy_row_len) if (l > 0x7FFFFFF0ull) return false;
     if ((*rc = audio_rowmax_ensure(a))) return true;
@@ -283,11 +304,22 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
     P.scale = (float)(1.0 / a->lazy_full);
     P.coef = coef;
+    if (tabw) {
+        std::vector<float> w(4 * (size_t)F.b);
+        for (unsigned r = 0; r < F.b; r++) {
+            const long double f = (long double)r / (long double)F.b, f2 = f * f, f3 = f2 * f;
+            w[4 * r] = (float)(-0.5L * f3 + f2 - 0.5L * f); w[4 * r + 1] = (float)(1.5L * f3 - 2.5L * f2 + 1.0L);
+            w[4 * r + 2] = (float)(-1.5L * f3 + 2.0L * f2 + 0.5L * f); w[4 * r + 3] = (float)(0.5L * f3 - 0.5L * f2);
+        }
+        if ((*rc = upload_table(ctx, ctx->tile_buf, w.data(), w.size() * 4))) return true;
+        P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
+    }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t ldsb = lds;
     const dim3 grid((unsigned)rows);
-    if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false>), grid, dim3(64), ldsb, ctx->stream, P); }
-    else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false>), grid, dim3(64), ldsb, ctx->stream, P); }
+    if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true, false>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false, false>), grid, dim3(64), ldsb, ctx->stream, P); }
+    else if (tabw) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, true>), grid, dim3(64), ldsb, ctx->stream, P); }
+    else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, false>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, false>), grid, dim3(64), ldsb, ctx->stream, P); }
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
     uint64_t in_elems = 0, out_elems = 0;
     for (uint64_t l : a->lazy_row_len) in_elems += l;
