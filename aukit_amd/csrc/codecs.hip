@@ -563,17 +563,26 @@ __global__ __launch_bounds__(256) void k_ima_stream(const ImaStreamParams P) {
     }
 }
 
+// a table entry of k_ima_stream_f32 — the f32 sample RN(p * (1 / 128 | RN(1 / 127))) — read back as the reference's double p / (p < 0 and 128 or 127)
+// (:2812): the predictor is recovered exactly (|p| < 2^15: the entry's relative error of 2^-23 moves p * 127 by less than 1/2)
+struct CvImaF32 {
+    static AUKIT_DEV double cv(double v) {
+        const double p = rint(v * (v < 0 ? 128.0 : 127.0));
+        return p < 0 ? p * (1.0 / 128) : div_rcp(p, 127.0, 1.0 / 127.0);
+    }
+};
+
 // ---- stream.adpcm, one channel, linear / cubic, integer rates with at most 512 output phases (22 050 → 48 000 Hz has 320): config 3a.
 // The block is kept in LDS as the int16 predictors themselves (exact floats, 4 bytes a sample) and every output is decided in up to
 // three tiers, each taken only when it is certain of the integer interval the reference's value falls into (the output is floor()ed,
 // :2823) — the argument of floor_wave.hip, with one more difficulty: the samples are p / 128 (p < 0) or p / 127 (:2812), not exact in
 // f32 and with two scales inside one interpolation window.
-//   1. f32, straight-line for the whole wave.  With pp = max(p, 0): sample = (p + pp / 127) / 128, so by linearity the interpolated
-//      value is (A + B / 127) / 128, A and B the same tap-weighted sums over p and pp.  Taps are exact integers below 2^15; the
-//      weights of the output's phase come from an LDS table (computed in fp64 on the host, rounded once: ≤ 2^-25 relative, the
-//      position itself is exact); four FMAs per sum round at magnitudes below 2^16 (half an ulp = 2^-9 each).  In units of the
-//      output: (4 · 2^-25 · 2^15 + 4 · 2^-9 + 2^-9) / 128 + the B branch at 1 / 127 of that < 1.2e-4.  Taken when the value lies more
-//      than 1e-3 away from an integer.
+//   1. f32, straight-line for the whole wave, on the samples themselves as f32 table entries (round 3; rounds 1-2 kept the integer predictors and
+//      evaluated two tap-weighted sums, over p and over max(p, 0), to keep both scales exact: eight FMAs, four v_med3 and a combine per output
+//      in a kernel that is bound by its VALU instructions).  An entry is within 2^-23 relative of the sample (3.1e-5 at the largest magnitude,
+//      258); the weights of the output's phase come from an LDS table (computed in fp64 on the host, rounded once; the position itself is
+//      exact); one multiply and three FMAs round at magnitudes below 512 (3e-5 each): < 2.5e-4 in all — the bound k_ms_wave's mono path
+//      lives by.  Taken when the value lies more than 1e-3 away from an integer.
 //   2. (about one output in 500) the polynomial in fp64 on exact doubles and the exact rational position, FMA Horner form, taken
 //      when more than 1e-6 away from an integer (the reference's x carries < 1024 · 2^-53 of rounding, times a slope below 1600).
 //   3. otherwise, and where the nil fall-backs of the block's ends apply: the reference-order code on the same table.
@@ -622,9 +631,9 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             if ((reinterpret_cast<uintptr_t>(blk) & 3) == 0) { const uint2 ww = *reinterpret_cast<const uint2 *>(wp); w0 = ww.x; w1 = ww.y; }  // wave-uniform
             else { w0 = (unsigned)wp[0] | (unsigned)wp[1] << 8 | (unsigned)wp[2] << 16 | (unsigned)wp[3] << 24; w1 = (unsigned)wp[4] | (unsigned)wp[5] << 8 | (unsigned)wp[6] << 16 | (unsigned)wp[7] << 24; }
             float *const mine = sm + 16 * lane;
-            ima_wave_chunk_full(w0, w1, steps, lane, pred, idx, [&](int k, int p) { mine[k] = (float)p; });
+            ima_wave_chunk_full(w0, w1, steps, lane, pred, idx, [&](int k, int p) { mine[k] = (float)p * (p < 0 ? 1.0f / 128.0f : c127); });
         } else {
-            for (unsigned long long q0 = 0; q0 < nb; q0 += 1024) ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { sm[q] = (float)p; });
+            for (unsigned long long q0 = 0; q0 < nb; q0 += 1024) ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { sm[q] = (float)p * (p < 0 ? 1.0f / 128.0f : c127); });
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -637,11 +646,11 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             bool ok = false;
             if (inside) {
                 const int s1 = k - 1;
-                const double p1 = CvIma8::cv((double)sm[s1]), p2 = CvIma8::cv((double)sm[s1 + 1]);
+                const double p1 = CvImaF32::cv((double)sm[s1]), p2 = CvImaF32::cv((double)sm[s1 + 1]);
                 const double fx = (double)rem * P.inv_fb;
                 if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
                 else {
-                    const double p0 = CvIma8::cv((double)sm[s1 - 1]), p3 = CvIma8::cv((double)sm[s1 + 2]);
+                    const double p0 = CvImaF32::cv((double)sm[s1 - 1]), p3 = CvImaF32::cv((double)sm[s1 + 2]);
                     const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
                     const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
                     const double c1 = 0.5 * (p2 - p0);
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
                 const double fr = v - floor(v);
                 ok = fr > 1e-6 && fr < 1 - 1e-6;
             }
-            if (!ok) { bool isint; v = eval_at<INTERP, false, float, CvIma8>(RP, sg, sm, 1, j, &isint); }
+            if (!ok) { bool isint; v = eval_at<INTERP, false, float, CvImaF32>(RP, sg, sm, 1, j, &isint); }
             return (float)lua_clamp(floor(v), -128, 127);
         };
         // floor(j fa / fb) and the remainder: by the reciprocal for the lane's first output (exact: (newlen * fa + fb) * fb < 2^32),
@@ -678,20 +687,13 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             const int s1 = inside ? k - 1 : 2;
             const float *tp = sm + s1;
             const float p1 = tp[0], p2 = tp[1];
-            auto pos = [](float p) { return __builtin_amdgcn_fmed3f(p, 0.0f, __builtin_inff()); };  // max(p, 0) as one v_med3_f32 (fmaxf costs a canonicalising v_max on top)
-            float A, Bv;
-            if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                const float fx = wt[rem];
-                A = __builtin_fmaf(p2 - p1, fx, p1);
-                const float q1 = pos(p1), q2 = pos(p2);
-                Bv = __builtin_fmaf(q2 - q1, fx, q1);
-            } else {
+            float v;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fmaf(p2 - p1, wt[rem], p1);
+            else {
                 const float4 w = *reinterpret_cast<const float4 *>(wt + 4 * rem);
                 const float p0 = tp[-1], p3 = tp[2];
-                A = __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
-                Bv = __builtin_fmaf(w.w, pos(p3), __builtin_fmaf(w.z, pos(p2), __builtin_fmaf(w.y, pos(p1), w.x * pos(p0))));
+                v = __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
             }
-            const float v = __builtin_fmaf(Bv, c127, A) * (1.0f / 128.0f);
             float fl = floorf(v);
             const float fr = v - fl;
             const bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
