@@ -172,11 +172,12 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
     auto finish = [&](double s, double prev) -> float {   // one output from its raw interpolated sample (EPI 1: and the raw sample before it)
         if constexpr (EPI == 0) return __builtin_amdgcn_fmed3f((float)s, -1.0f, 1.0f);   // :667-668
         else {
-            const double ns = prev + alpha * (s - prev);                                  // :2401
+            const double ns = __builtin_fma(alpha, s - prev, prev);                       // :2401 (fused: this kernel keeps the arithmetic type, not the operation order)
             // ns * (ns < 0 and 128 or 127): the factor is 127.5 - copysign(0.5, ns) (a bit operation and one add instead of a compare and two
-            // selects; -0 gets 128 instead of 127 and is -0 either way); clamp(…, -128, 127) as v_max_f64 / v_min_f64  :2402
+            // selects; -0 gets 128 instead of 127 and is -0 either way); clamp(…, -128, 127) AFTER the rounding to f32 — the bounds are f32
+            // numbers and rounding is monotone: the same value as clamping the double first, in one v_med3_f32 instead of v_max_f64 + v_min_f64  :2402
             const double v = ns * (127.5 - __builtin_copysign(0.5, ns));
-            return (float)__builtin_fmin(__builtin_fmax(v, -128.0), 127.0);
+            return __builtin_amdgcn_fmed3f((float)v, -128.0f, 127.0f);
         }
     };
     constexpr int ROWS = TILE / 64;
