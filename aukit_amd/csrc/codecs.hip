@@ -255,13 +255,26 @@ AUKIT_DEV Sat sat_then(const Sat &f, const Sat &g) { return Sat{f.a + g.a, clamp
 AUKIT_DEV int sat_apply(const Sat &f, int x) { return clampi(x + f.a, f.lo, f.hi); }
 AUKIT_DEV Sat sat_id() { return Sat{0, -(1 << 28), 1 << 28}; }
 AUKIT_DEV Sat sat_shfl_up(const Sat &v, int o) { return Sat{__shfl_up(v.a, o), __shfl_up(v.lo, o), __shfl_up(v.hi, o)}; }
-AUKIT_DEV Sat wave_scan_incl(Sat v, int lane) {
-    for (int o = 1; o < 64; o <<= 1) {
-        Sat p = sat_shfl_up(v, o);
-        if (lane >= o) v = sat_then(p, v);
-    }
+// The scan's moves as DPP (VALU latency, no LDS crossbar): a lane without a source lane — and the rows a row_bcast does not write — keep `old`,
+// which is the identity map here, so no step needs a select.  CTRL: row_shr:n = 0x110 + n, row_bcast15 = 0x142 (rows 1, 3), row_bcast31 = 0x143
+// (rows 2, 3), wave_shr:1 = 0x138.
+template <int CTRL, int ROW_MASK = 0xF>
+AUKIT_DEV Sat sat_dpp(const Sat &v) {
+    const Sat id = sat_id();
+    return Sat{__builtin_amdgcn_update_dpp(id.a, v.a, CTRL, ROW_MASK, 0xF, false), __builtin_amdgcn_update_dpp(id.lo, v.lo, CTRL, ROW_MASK, 0xF, false),
+               __builtin_amdgcn_update_dpp(id.hi, v.hi, CTRL, ROW_MASK, 0xF, false)};
+}
+AUKIT_DEV Sat wave_scan_incl(Sat v, int) {
+    v = sat_then(sat_dpp<0x111>(v), v);
+    v = sat_then(sat_dpp<0x112>(v), v);
+    v = sat_then(sat_dpp<0x114>(v), v);
+    v = sat_then(sat_dpp<0x118>(v), v);
+    v = sat_then(sat_dpp<0x142, 0xA>(v), v);
+    v = sat_then(sat_dpp<0x143, 0xC>(v), v);
     return v;
 }
+AUKIT_DEV Sat wave_excl_of(const Sat &inc) { return sat_dpp<0x138>(inc); }   // the lane before; lane 0: the identity
+AUKIT_DEV Sat wave_last_of(const Sat &inc) { return Sat{__builtin_amdgcn_readlane(inc.a, 63), __builtin_amdgcn_readlane(inc.lo, 63), __builtin_amdgcn_readlane(inc.hi, 63)}; }
 AUKIT_DEV int ima_index_delta(int nib) { return (nib & 4) ? ((nib & 3) + 1) * 2 : -1; }  // {-1,-1,-1,-1,2,4,6,8} :156-159
 
 // nibble q of one (block, channel) sequence
@@ -318,10 +331,9 @@ AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned
         f = sat_then(f, g);
     }
     const Sat inc = wave_scan_incl(f, lane);
-    Sat exc = sat_shfl_up(inc, 1);
-    if (lane == 0) exc = sat_id();
+    const Sat exc = wave_excl_of(inc);
     int si = sat_apply(exc, idx);
-    const int idx_end = sat_apply(Sat{__shfl(inc.a, 63), __shfl(inc.lo, 63), __shfl(inc.hi, 63)}, idx);
+    const int idx_end = sat_apply(wave_last_of(inc), idx);
     int delta[16];
     Sat g = sat_id();
 #pragma unroll
@@ -336,10 +348,9 @@ AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned
         g = sat_then(g, ok ? Sat{d, -32768, 32767} : sat_id());                       // :2810-2811
     }
     const Sat ginc = wave_scan_incl(g, lane);
-    Sat gexc = sat_shfl_up(ginc, 1);
-    if (lane == 0) gexc = sat_id();
+    const Sat gexc = wave_excl_of(ginc);
     int p = sat_apply(gexc, pred);
-    const int pred_end = sat_apply(Sat{__shfl(ginc.a, 63), __shfl(ginc.lo, 63), __shfl(ginc.hi, 63)}, pred);
+    const int pred_end = sat_apply(wave_last_of(ginc), pred);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         p = clampi(p + delta[k], -32768, 32767);
@@ -361,10 +372,9 @@ AUKIT_DEV void ima_wave_chunk_full(unsigned w0, unsigned w1, const int *steps, i
 #pragma unroll
     for (int k = 0; k < 16; k++) f = sat_then(f, Sat{ima_index_delta(nibs[k]), 0, 88});
     const Sat inc = wave_scan_incl(f, lane);
-    Sat exc = sat_shfl_up(inc, 1);
-    if (lane == 0) exc = sat_id();
+    const Sat exc = wave_excl_of(inc);
     int si = sat_apply(exc, idx);
-    const int idx_end = sat_apply(Sat{__shfl(inc.a, 63), __shfl(inc.lo, 63), __shfl(inc.hi, 63)}, idx);
+    const int idx_end = sat_apply(wave_last_of(inc), idx);
     int delta[16];
     Sat g = sat_id();
 #pragma unroll
@@ -376,10 +386,9 @@ AUKIT_DEV void ima_wave_chunk_full(unsigned w0, unsigned w1, const int *steps, i
         g = sat_then(g, Sat{delta[k], -32768, 32767});                                // :2810-2811
     }
     const Sat ginc = wave_scan_incl(g, lane);
-    Sat gexc = sat_shfl_up(ginc, 1);
-    if (lane == 0) gexc = sat_id();
+    const Sat gexc = wave_excl_of(ginc);
     int p = sat_apply(gexc, pred);
-    const int pred_end = sat_apply(Sat{__shfl(ginc.a, 63), __shfl(ginc.lo, 63), __shfl(ginc.hi, 63)}, pred);
+    const int pred_end = sat_apply(wave_last_of(ginc), pred);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         p = clampi(p + delta[k], -32768, 32767);
