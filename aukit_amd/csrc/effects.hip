@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256) void k_center(T *data, RowMeta m, unsigned lon
 // y_out = A * y_in + B composites; compose(f then g) = (gA * fA, gA * fB + gB)
 struct Aff { double A, B; };
 AUKIT_DEV Aff aff_then(const Aff &f, const Aff &g) { return Aff{g.A * f.A, __builtin_fma(g.A, f.B, g.B)}; }
+// an affine map moved between lanes by DPP: lanes without a source lane, and rows outside ROW_MASK, receive the identity {1, 0}
+// (row_shr:n = 0x110 + n, row_bcast15 = 0x142, row_bcast31 = 0x143, wave_shr:1 = 0x138)
+template <int CTRL, int ROW_MASK = 0xF>
+AUKIT_DEV Aff aff_dpp(const Aff &v) {
+    const long long a = __double_as_longlong(v.A), b = __double_as_longlong(v.B);
+    const int alo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)a, CTRL, ROW_MASK, 0xF, false);
+    const int ahi = __builtin_amdgcn_update_dpp(0x3FF00000, (int)(a >> 32), CTRL, ROW_MASK, 0xF, false);
+    const int blo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, false);
+    const int bhi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return Aff{__longlong_as_double(((long long)ahi << 32) | (unsigned)alo), __longlong_as_double(((long long)bhi << 32) | (unsigned)blo)};
+}
 
 // One workgroup per row, 64 bytes per thread and tile (rows start on 64-byte boundaries and are padded to 16 elements,
 // audio_prepare).  Per tile: every thread composes the affine maps of its own samples, a wave scan + one LDS exchange give the
@@ -276,19 +287,21 @@ __global__ __launch_bounds__(256) void k_onepole(T *data, RowMeta m, double a, u
             }
         }
         if (HIGHPASS && cnt && i0 + cnt - 1 == tile_last) carry_x[ph ^ 1] = xp;  // xp = this thread's last ORIGINAL sample
+        // the wave scan on DPP moves (round 3: VALU latency instead of four LDS crossbar trips per step; a lane without a source — and the rows
+        // a row_bcast does not write — receive the identity map, so no step needs a select): four steps inside rows of 16, then lane 15 / 31
         Aff inc = f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Aff p{__shfl_up(inc.A, o), __shfl_up(inc.B, o)};
-            if (lane >= o) inc = aff_then(p, inc);
-        }
+        inc = aff_then(aff_dpp<0x111>(inc), inc);
+        inc = aff_then(aff_dpp<0x112>(inc), inc);
+        inc = aff_then(aff_dpp<0x114>(inc), inc);
+        inc = aff_then(aff_dpp<0x118>(inc), inc);
+        inc = aff_then(aff_dpp<0x142, 0xA>(inc), inc);
+        inc = aff_then(aff_dpp<0x143, 0xC>(inc), inc);
         if (lane == 63) wave_tot[ph][wave] = inc;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the prefetched vectors stay in flight across the barrier
         __builtin_amdgcn_s_barrier();        // also publishes the carries written during the previous tile
         Aff pre{1.0, 0.0};
         for (int w = 0; w < wave; w++) pre = aff_then(pre, wave_tot[ph][w]);
-        Aff exc{__shfl_up(inc.A, 1), __shfl_up(inc.B, 1)};
-        if (lane > 0) pre = aff_then(pre, exc);
+        pre = aff_then(pre, aff_dpp<0x138>(inc));   // the lane before (lane 0: the identity)
         double y = __builtin_fma(pre.A, carry_y[ph], pre.B);  // value entering this thread's first sample
         xp = xprev;
         T out[PER];
