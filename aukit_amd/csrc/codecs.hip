@@ -472,6 +472,7 @@ struct ImaStreamParams {
     double inv_fb;
     unsigned fdq, fdr;                   // 64 fa = fdq fb + fdr
     unsigned long long bps;              // k_ima_stream_f32: blocks per stream when that is the same for every stream, else 0
+    unsigned mid_lo, mid_end_full;       // k_ima_stream_f32: the clean rows of a full block (host-made: two 64-bit divisions per block otherwise)
 };
 
 template <int INTERP, typename OUT_T>
@@ -678,9 +679,10 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
         // Rows of 64 outputs whose taps all lie inside the table and which are all wanted — every row of a block but its first and its last one
         // or two — run a copy of the loop body without the `inside` / `active` bookkeeping (round 3: the kernel is bound by its VALU instructions,
         // and those were six of a row's ~50): rows rb with rb fa >= 2 fb (floor(x) >= 3) and floor((rb + 63) fa / fb) + 3 <= nb, rb + 63 < newlen
-        const unsigned mid_lo = (unsigned)(((((3ull * P.fb + P.fa - 1) / P.fa) + 63) / 64) * 64);   // (3 fb: a margin of one sample)
-        unsigned mid_end = 0;   // rows rb with rb + 64 <= mid_end are clean
-        if (newlen >= 64 && nbi >= 4) {
+        const unsigned mid_lo = P.mid_lo;   // round_up64(ceil(3 fb / fa)) (3 fb: a margin of one sample)
+        unsigned mid_end = P.mid_end_full;  // rows rb with rb + 64 <= mid_end are clean
+        if (nb != 1024 || newlen != P.newlen_full) mid_end = 0;
+        if (mid_end == 0 && (nb != 1024 || newlen != P.newlen_full) && newlen >= 64 && nbi >= 4) {   // a stream's last, shorter block
             const unsigned long long jm = (((unsigned long long)(nbi - 3) * P.fb) / P.fa);       // outputs j <= jm - 1 have floor(j fa / fb) + 3 <= nb
             const unsigned long long lim = jm < newlen ? jm : newlen;
             mid_end = (unsigned)(lim & ~63ull);
@@ -964,6 +966,11 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             if (fb >= 2 && ((double)newlen_full * (double)fa + (double)fb) * (double)fb < 4294967296.0) {
                 P.fast = 1; P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb); P.inv_fb = 1.0 / (double)fb;
                 P.fdq = (unsigned)((64ull * fa) / fb); P.fdr = (unsigned)((64ull * fa) % fb);
+                P.mid_lo = (unsigned)(((((3ull * fb + fa - 1) / fa) + 63) / 64) * 64);
+                {   // a full block: 1024 table entries (the junk word included), newlen_full outputs
+                    const unsigned long long jm = ((1024ull - 3) * fb) / fa, lim = std::min<unsigned long long>(jm, P.newlen_full);
+                    P.mid_end_full = P.newlen_full >= 64 ? (unsigned)(lim & ~63ull) : 0u;
+                }
             }
         }
         // one channel, at most 512 phases: the three-tier kernel on an f32 table (k_ima_stream_f32)
