@@ -250,7 +250,9 @@ __constant__ int c_ima_step[89] = {
     15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767};  // aukit.lua:161-171
 
 struct Sat { int a, lo, hi; };  // x -> clamp(x + a, lo, hi)
-AUKIT_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// clamp(v, lo, hi) for lo <= hi as ONE v_med3_i32 (left to itself hipcc builds part of these out of compares and selects; the IMA kernels are bound
+// by their VALU instructions)
+AUKIT_DEV int clampi(int v, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi)); return r; }
 AUKIT_DEV Sat sat_then(const Sat &f, const Sat &g) { return Sat{f.a + g.a, clampi(f.lo + g.a, g.lo, g.hi), clampi(f.hi + g.a, g.lo, g.hi)}; }
 AUKIT_DEV int sat_apply(const Sat &f, int x) { return clampi(x + f.a, f.lo, f.hi); }
 AUKIT_DEV Sat sat_id() { return Sat{0, -(1 << 28), 1 << 28}; }
@@ -342,7 +344,7 @@ AUKIT_DEV void ima_wave_chunk(const NibSeq &seq, unsigned long long q0, unsigned
         const int step = c_ima_step[si];                                              // :2807 (si stays a valid index when !ok)
         const int nsi = clampi(si + ima_index_delta(nibs[k]), 0, 88);                 // :2808
         si = ok ? nsi : si;
-        const int diff = (int)(((nibs[k] & 7) * (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
+        const int diff = (int)(__umul24(nibs[k] & 7, (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
         const int d = (nibs[k] & 8) ? -diff : diff;
         delta[k] = ok ? d : 0;
         g = sat_then(g, ok ? Sat{d, -32768, 32767} : sat_id());                       // :2810-2811
@@ -381,7 +383,7 @@ AUKIT_DEV void ima_wave_chunk_full(unsigned w0, unsigned w1, const int *steps, i
     for (int k = 0; k < 16; k++) {
         const int step = steps[si];                                                   // :2807
         si = clampi(si + ima_index_delta(nibs[k]), 0, 88);                            // :2808
-        const int diff = (int)(((nibs[k] & 7) * (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
+        const int diff = (int)(__umul24(nibs[k] & 7, (unsigned)step) >> 2) + (step >> 3);  // :2809 (Q5)
         delta[k] = (nibs[k] & 8) ? -diff : diff;
         g = sat_then(g, Sat{delta[k], -32768, 32767});                                // :2810-2811
     }
