@@ -31,7 +31,7 @@ typedef unsigned long long u64;
 #endif
 
 struct SatMap { int a, lo, hi; };
-AUKIT_DEV int sm_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+AUKIT_DEV int sm_clamp(int v, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi)); return r; }   // lo <= hi everywhere: one v_med3_i32 (the ternaries became compares and selects)
 AUKIT_DEV SatMap sm_then(const SatMap &f, const SatMap &g) { return SatMap{f.a + g.a, sm_clamp(f.lo + g.a, g.lo, g.hi), sm_clamp(f.hi + g.a, g.lo, g.hi)}; }
 AUKIT_DEV int sm_apply(const SatMap &f, int x) { return sm_clamp(x + f.a, f.lo, f.hi); }
 
