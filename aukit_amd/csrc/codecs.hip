@@ -256,7 +256,6 @@ AUKIT_DEV int clampi(int v, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2,
 AUKIT_DEV Sat sat_then(const Sat &f, const Sat &g) { return Sat{f.a + g.a, clampi(f.lo + g.a, g.lo, g.hi), clampi(f.hi + g.a, g.lo, g.hi)}; }
 AUKIT_DEV int sat_apply(const Sat &f, int x) { return clampi(x + f.a, f.lo, f.hi); }
 AUKIT_DEV Sat sat_id() { return Sat{0, -(1 << 28), 1 << 28}; }
-AUKIT_DEV Sat sat_shfl_up(const Sat &v, int o) { return Sat{__shfl_up(v.a, o), __shfl_up(v.lo, o), __shfl_up(v.hi, o)}; }
 // The scan's moves as DPP (VALU latency, no LDS crossbar): a lane without a source lane — and the rows a row_bcast does not write — keep `old`,
 // which is the identity map here, so no step needs a select.  CTRL: row_shr:n = 0x110 + n, row_bcast15 = 0x142 (rows 1, 3), row_bcast31 = 0x143
 // (rows 2, 3), wave_shr:1 = 0x138.
