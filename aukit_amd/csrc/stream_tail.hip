@@ -266,11 +266,11 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
                     if (job.last_off != ~0ull) z0 = tail_row(rows, job.last_off + (unsigned long long)c * job.last_cstride, P.full);
                     ls = KIND == TAIL_FLAC ? z0 / (z0 < 0 ? 128 : 127) : z0;   // :3172 / :3316
                 }
-                for (int i = begin; i < start; i++) { const double s = ls + P.lp_alpha * ((double)xs[skew(i)] - ls); ls = s; }
+                for (int i = begin; i < start; i++) { ls = __builtin_fma(P.lp_alpha, (double)xs[skew(i)] - ls, ls); }
 #pragma unroll
                 for (int i = 0; i < E; i++) {
                     const double xv = e0 + i < cnt ? (double)xs[skew(start + i)] : 0.0;
-                    const double s = ls + P.lp_alpha * (xv - ls);   // :3324 / :3179
+                    const double s = __builtin_fma(P.lp_alpha, xv - ls, ls);   // :3324 / :3179 (fused: the tolerance path)
                     ls = s;
                     if constexpr (KIND == TAIL_QOA) acc[i] = c == 0 ? (float)s : acc[i] + (float)s;   // n = n + s  :3327
                     else { const float f = (float)s; acc[i] = __builtin_amdgcn_fmed3f(f * (f < 0 ? 128.0f : 127.0f), -128.0f, 127.0f); }   // :3181
