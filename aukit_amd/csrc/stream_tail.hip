@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
         // thread ↔ E consecutive outputs: warm-up, recurrence, epilogue, and E consecutive elements stored straight from registers — a wave's
         // 64 × E outputs are one contiguous run, so its two 16-byte stores per lane fill whole lines between them (no trip back through LDS)
         const int e0 = tid * E;
+        float acc[E];
+#pragma unroll
+        for (int i = 0; i < E; i++) acc[i] = 0.f;
         if (e0 < cnt) {
-            float acc[E];
             for (int c = 0; c < P.C; c++) {
                 const float *xs = xb + c * P.xbn;
                 const int start = wl + e0;
@@ -282,6 +284,19 @@ __global__ __launch_bounds__(256) void k_iir_tail_fast(const TailParams P) {
                     for (int i = 0; i < E; i++) acc[i] = acc[i] / (float)P.C;   // lines[1][i] = n / file_channels  :3329
                 }
             }
+        }
+        if (NT == 64 && cnt == T && true) {
+            // a full tile leaves through LDS once more (round 3): a lane's E consecutive results as they stand are E stores of 16 bytes at a stride of
+            // 4 E bytes — every store instruction touches all 64 lines of the tile; transposed back (the skewed layout of the way in, read the other
+            // way round) a store instruction writes 256 contiguous bytes
+            tile_sync();
+#pragma unroll
+            for (int i = 0; i < E; i++) xb[skew(e0 + i)] = acc[i];
+            tile_sync();
+            OUT_T *const ot = out + job.out_off + (unsigned long long)o0 + (unsigned)tid;
+#pragma unroll
+            for (int u = 0; u < E; u++) ot[64 * u] = xb[skew(tid + 64 * u)];
+        } else if (e0 < cnt) {
             OUT_T *const op = out + job.out_off + (unsigned long long)o0 + (unsigned)e0;
             if (e0 + E <= cnt) {
                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
