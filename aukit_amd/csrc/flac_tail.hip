@@ -197,9 +197,21 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
         else carry_y = __shfl(ylast, (cnt - 1) / E);
         carry_x = (double)xb[skew(cnt - 1)];
-        if (FULL || e0 < cnt) {
+        if constexpr (FULL) {
+            // a full tile leaves through LDS once more: a lane's eight consecutive results as they stand are two 16-byte stores at a stride of 32 bytes —
+            // each store instruction touches every line of the tile; transposed back (the skewed layout of the way in, read the other way round) a
+            // store instruction writes 256 contiguous bytes
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < E; i++) xb[skew(e0 + i)] = res[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float *ot = orow + o0 + (unsigned)lane;
+#pragma unroll
+            for (int u = 0; u < E; u++) ot[64 * u] = xb[skew(lane + 64 * u)];
+        } else if (e0 < cnt) {
             float *op = orow + o0 + (unsigned)e0;
-            if (FULL || e0 + E <= cnt) {
+            if (e0 + E <= cnt) {
                 reinterpret_cast<float4 *>(op)[0] = make_float4(res[0], res[1], res[2], res[3]);
                 reinterpret_cast<float4 *>(op)[1] = make_float4(res[4], res[5], res[6], res[7]);
             } else {
