@@ -231,7 +231,7 @@ int aukit_group_gather_audio(aukit_group *g, uint32_t root, aukit_audio *const *
     for (uint32_t r = 0; r < W; r++) {
         const aukit_audio *p = parts[r];
         if (!p) return fail(AUKIT_E_ARG, "part %u is null", r);
-        if (p->pend_norm) { int frc = audio_flush(g->ctx[r], p); if (frc) return frc; }
+        if (p->pend_norm || p->lazy_rs) { int frc = audio_flush(g->ctx[r], p); if (frc) return frc; }   // deferred work (a normalize, a FLAC resample) is done before the rows travel
         if (!first) first = p;
         else if (p->channels != first->channels || p->rate != first->rate || p->dtype != first->dtype) return fail(AUKIT_E_ARG, "parts differ in channels / rate / dtype");
         lens.insert(lens.end(), p->len.begin(), p->len.end());

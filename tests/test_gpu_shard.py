@@ -129,6 +129,42 @@ def test_group_scatter_compute_gather_through_the_c_abi(ctx, world, root):
         g.close()
 
 
+def test_group_gather_of_deferred_audios(ctx, oracle):
+    """A member's audio may still owe work when it is gathered — the resample `aukit_decode_resample` defers on FLAC (flac_tail.hip), a pending
+    normalize: aukit_group_gather_audio finishes it in the member's context before the rows travel (round 3: it looked at the pending normalize only)."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    rng = np.random.default_rng(5)
+    streams = []
+    for i, n in enumerate((9000, 4097, 12000, 300)):
+        x = np.stack([pcm16(n, 44100, 8, 2 * i + c) for c in range(2)], 1).ravel()
+        streams.append(oracle.gen_flac(x, 2, 16, 44100, 1024))
+    desc = B.make_desc(N.CODEC_FLAC, 2, 44100)
+    single = B.decode_resample(ctx, B.Batch.upload(ctx, streams), desc, 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0] == "(resample deferred)"
+    single = single.download()
+    g = B.Group([0, 0], dtype=N.F32)
+    try:
+        whole = B.Batch.upload(g.contexts[0], streams)
+        shards, cuts = g.scatter(whole, 0)
+        parts = [B.decode_resample(g.contexts[r], shards[r], desc, 48000, "cubic", dtype=N.F32) for r in range(2)]
+        assert all(g.contexts[r].last_kernel()[0] == "(resample deferred)" for r in range(2))
+        B.effect(g.contexts[1], parts[1], "normalize", 0.8)   # ... and a pending normalize on one member
+        got = g.gather_audio(parts, 0)
+        g.sync()
+        rows = got.download()
+        ref1 = B.decode_resample(ctx, B.Batch.upload(ctx, streams[cuts[1][0]:cuts[1][1]]), desc, 48000, "cubic", dtype=N.F32)
+        B.effect(ctx, ref1, "normalize", 0.8)
+        ref1 = ref1.download()
+        assert len(rows) == len(single)
+        for s in range(len(rows)):
+            want = single[s] if s < cuts[0][1] else ref1[s - cuts[1][0]]
+            for c in range(2):
+                assert np.array_equal(rows[s][c], want[c]), (s, c)
+    finally:
+        g.close()
+
+
 def test_group_rccl_transport_initialises(ctx, monkeypatch):
     """AUKIT_GROUP_TRANSPORT=rccl: librccl is dlopen'ed and ncclCommInitAll builds the group's communicators (distinct devices only — a one-GPU box
     has a group of one, whose scatter / gather move nothing: the messages between members cannot be exercised here, only the set-up and tear-down);
