@@ -62,6 +62,9 @@ constexpr int OSTR = 33;  // row stride of the value array
 #ifndef AUKIT_FLAC_TAKE_EAGER
 #define AUKIT_FLAC_TAKE_EAGER 0
 #endif
+#ifndef AUKIT_FLAC_SPLIT_TAPS
+#define AUKIT_FLAC_SPLIT_TAPS 0     // 1: k_flac_restore_fast always splits a tap into two 24-bit multiply-adds (A/B)
+#endif
 #ifndef AUKIT_FLAC_CAREFUL_LOOP
 #define AUKIT_FLAC_CAREFUL_LOOP 0   // 1: k_flac_extract uses its end-of-data-aware field loop in every round (A/B)
 #endif
@@ -965,6 +968,8 @@ struct FlacTail {
 // multiply-add: floor((2^S Sh + Sl) / 2^L) = (Sh + (Sl >> S)) >> (L - S), exact as long as every restored value stays below a bound hb chosen
 // per subframe so that neither partial sum can leave 32 bits.  A wave that cannot promise that (negative shift, many wasted bits) or meets a
 // value at or beyond the bound (24-bit audio, garbage) marks itself in `redo` and leaves; k_flac_restore does those waves with 64-bit sums.
+// ONE: a wave whose coefficients are small enough that the whole sum stays inside 32 bits for every value the bit depth allows
+// (sum |coef| * 2^depth < 2^31: 16-bit audio with up to 14 bits of coefficient magnitude in total) runs one multiply-add per tap.
 // Kept lean on purpose (no cross-round prefetch, no 64-bit state): at ~100 VGPRs five waves share a SIMD and cover each other's loads.
 __device__ __forceinline__ int mad24(int a, int b, int c) {   // named outright: from __mul24 hipcc derives sign extensions (v_bfe_i32) it does not need
     int d;
@@ -990,7 +995,7 @@ template <int ASG> __device__ __forceinline__ int flac_tail(int o, bool odd, int
 }
 
 // One wave's rounds (k_flac_restore_fast).  Returns false when a value reached the bound.
-template <int MAXO, int ASG>
+template <int MAXO, int ASG, bool ONE>
 __device__ __forceinline__ bool flac_fast_rounds(const int *scratch, int *rows, int *s_v, const u64 *s_src, const u64 *s_dst, const int *s_bs, int lane, int bs, int maxbs,
                                                  int order, int S, int sh8, int wasted, int hb, int asg, int depth, const int (&cl)[MAXO], const int (&chh)[MAXO]) {
     const bool odd = lane & 1;
@@ -1013,10 +1018,10 @@ __device__ __forceinline__ bool flac_fast_rounds(const int *scratch, int *rows, 
 #pragma unroll
             for (int q = 0; q < MAXO; q++) {
                 const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj];
-                sl = mad24(t, cl[q], sl);
+                if constexpr (!ONE) sl = mad24(t, cl[q], sl);
                 sh = mad24(t, chh[q], sh);
             }
-            int pr = (sh + (sl >> S)) >> sh8;
+            int pr = ONE ? sh >> sh8 : (sh + (sl >> S)) >> sh8;
             if constexpr (WARM) pr = i0 + jj >= order ? pr : 0;
             const int v = res[jj] + pr;
             badacc |= (unsigned)(v + hb);
@@ -1089,16 +1094,23 @@ __global__ __launch_bounds__(64) void k_flac_restore_fast(const SubJob *jobs, u6
     int cl[MAXO], chh[MAXO];
 #pragma unroll
     for (int q = 0; q < MAXO; q++) { cl[q] = 0; chh[q] = 0; }
-    int scl = 1, sch = 1;
+    int scl = 1, sch = 1, sabs = 1;
     if (j < njobs) {
         const SubDesc &d = sd[job.desc];
         order = d.order; lshift = d.lshift; wasted = d.wasted;
-        const int S = min(max(lshift, 0), 8);
+#pragma unroll
+        for (int q = 0; q < MAXO; q++) if (q < order) { const int c = (int)d.coef[q]; sabs += c < 0 ? -c : c; }
+    }
+    const int hb1 = 1 << min(23, __clz(sabs) - 1);   // hb1 * sum |coef| < 2^31
+    const bool one = __all(hb1 >= (1 << min(max(depth, 1), 23))) && !AUKIT_FLAC_SPLIT_TAPS;
+    if (j < njobs) {
+        const SubDesc &d = sd[job.desc];
+        const int S = one ? 0 : min(max(lshift, 0), 8);
 #pragma unroll
         for (int q = 0; q < MAXO; q++)
             if (q < order) { const int c = (int)d.coef[q]; cl[q] = c & ((1 << S) - 1); chh[q] = c >> S; scl += cl[q]; sch += chh[q] < 0 ? -chh[q] : chh[q]; }
     }
-    const int hb = min(1 << 23, 1 << (29 - (31 - __clz(max(scl, sch)))));   // a power of two; hb * max(sum cl, sum |ch|) < 2^30
+    const int hb = one ? hb1 : min(1 << 23, 1 << (29 - (31 - __clz(max(scl, sch)))));   // a power of two; hb * max(sum cl, sum |ch|) < 2^30
     // 16-byte accesses (block sizes are multiples of 4 but for a stream's last frame), 32-bit element offsets, 16-bit block sizes — else the general kernel
     const bool vec = __all((job.src & 3) == 0 && (job.dst & 3) == 0 && (job.bs & 3) == 0 && job.bs < 65536 && (job.src >> 32) == 0 && (job.dst >> 32) == 0);
     if (!__all(j >= njobs || (lshift >= 0 && wasted < 6)) || !vec || depth > 30 || depth < 1) { if (lane == 0) redo[blockIdx.x] = 1; return; }
@@ -1107,11 +1119,15 @@ __global__ __launch_bounds__(64) void k_flac_restore_fast(const SubJob *jobs, u6
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) maxbs = max(maxbs, __shfl_xor(maxbs, m));
     __syncthreads();
-    const int S = min(lshift, 8), sh8 = lshift - S;
+    const int S = one ? 0 : min(lshift, 8), sh8 = lshift - S;
     const int asg_u = __builtin_amdgcn_readfirstlane(job.asgn);
     const bool uniform = __all(j >= njobs || job.asgn == asg_u);   // jobs of one class are sorted by assignment: all but a few waves
     bool ok;
-#define AUKIT_ROUNDS(A) ok = flac_fast_rounds<MAXO, A>(scratch, rows, s_v, s_src, s_dst, s_bs, lane, job.bs, maxbs, order, S, sh8, wasted, hb, job.asgn, depth, cl, chh)
+#define AUKIT_ROUNDS(A)                                                                                                                                      \
+    do {                                                                                                                                                     \
+        if (one) ok = flac_fast_rounds<MAXO, A, true>(scratch, rows, s_v, s_src, s_dst, s_bs, lane, job.bs, maxbs, order, S, sh8, wasted, hb, job.asgn, depth, cl, chh); \
+        else ok = flac_fast_rounds<MAXO, A, false>(scratch, rows, s_v, s_src, s_dst, s_bs, lane, job.bs, maxbs, order, S, sh8, wasted, hb, job.asgn, depth, cl, chh);   \
+    } while (0)
     if (!uniform) AUKIT_ROUNDS(-1);
     else if (asg_u == 0) AUKIT_ROUNDS(0);
     else if (asg_u == 8) AUKIT_ROUNDS(8);

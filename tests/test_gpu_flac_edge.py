@@ -199,3 +199,33 @@ def test_flac_values_beyond_int32_fall_back_to_int64_rows(ctx, oracle):
     got = B.decode(ctx, B.Batch.upload(ctx, [s]), B.make_desc(N.CODEC_FLAC), dtype=N.F64).download()[0]
     assert np.array_equal(got[0], ref.data[0])
     assert abs(ref.data[0][3]) > 2 ** 16  # far outside [-1, 1): really the wide path
+
+
+def _lpc_stream(coefs, precision, shift, seed, nframes=8, bs=256):
+    """An encoder's view: the residuals of a given predictor on a 16-bit signal (lossless whatever the coefficients are)."""
+    x = pcm16(nframes * bs, 44100, 5, seed).astype(np.int64)
+    order = len(coefs)
+    frames = []
+    for f in range(nframes):
+        s = [int(v) for v in x[f * bs:(f + 1) * bs]]
+        res = [s[i] - (sum(int(coefs[j]) * s[i - 1 - j] for j in range(order)) >> shift) for i in range(order, bs)]
+        k = min(14, max(1, max(abs(r) for r in res).bit_length() - 1))
+        frames.append(frame(bs, [lpc_subframe(order, 16, s[:order], precision, shift, coefs, 1, bs, [k], res)], number=f))
+    return streaminfo(44100, 1, 16, nframes * bs) + b"".join(frames), x
+
+
+@pytest.mark.parametrize("coefs, precision, shift", [
+    ([900, -420, 30, -11, 7, -3, 2, -1], 12, 9),                       # sum |c| < 2^15: one multiply-add per tap (k_flac_restore_fast, ONE)
+    ([16000, -15800, 9000, -2000, 500, -300, 100, -50], 15, 14),       # sum |c| = 43750 > 2^15: a tap is two 24-bit multiply-adds
+    ([16383, 16383, -16384, 16383, -16384, 16383, 16383, -16384, 16383, 16383, -16384, 16383], 15, 14),   # the largest 15-bit taps
+    ([4, -2, 1], 5, 0),                                                 # shift 0
+])
+def test_flac_predictors_small_and_large(ctx, oracle, coefs, precision, shift):
+    """The int32 prediction kernel picks its arithmetic per wave from the size of the coefficients; every choice restores the encoder's samples."""
+    B, N = _B(), _N()
+    made = [_lpc_stream(coefs, precision, shift, seed) for seed in range(9)]
+    got = B.decode(ctx, B.Batch.upload(ctx, [m[0] for m in made]), B.make_desc(N.CODEC_FLAC), dtype=N.F64).download()
+    for (s, x), g in zip(made, got):
+        ref = oracle.flac(s)
+        assert np.array_equal(ref.data[0] * 65536.0, x.astype(np.float64))   # s / 2^sampleDepth (aukit.lua:505)
+        assert np.array_equal(g[0], ref.data[0])
