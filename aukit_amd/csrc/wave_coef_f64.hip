@@ -18,6 +18,13 @@ namespace aukit {
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
+typedef double cdbl2 __attribute__((ext_vector_type(2)));
+struct CoefRow {   // (c3, c2), (c1, p1) of one source sample, read from LDS by hand
+    cdbl2 a, b;
+    AUKIT_DEV void issue(unsigned addr) { asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(a), "=&v"(b) : "v"(addr)); }
+    template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(K)); }
+};
+
 template <int INTERP>
 __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, const FastParams F, const unsigned ccap, const double inv_b) {
     extern __shared__ double smd[];
@@ -106,14 +113,40 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
+            if constexpr (INTERP == AUKIT_INTERP_CUBIC) {
+                // a row's two table reads are issued one row ahead and waited for with a counted lgkmcnt (LDS returns in order), as in
+                // wave_f64.hip's Row: hipcc on its own waits lgkmcnt(0) right behind every row's reads (tools/isa_check.py replays the counters)
+                const unsigned cf0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)cf;
+                CoefRow nx;
+                nx.issue(cf0 + 32u * q);
 #pragma unroll
-            for (int r = 0; r < WT / 64; r++) {
-                orow[r * 64 + lane] = eval(q, rem);
-                rem += F.dr64;
-                q += F.dq64;
-                const bool wrap = rem >= F.b;
-                rem -= wrap ? F.b : 0u;
-                q += wrap ? 1u : 0u;
+                for (int r = 0; r < WT / 64; r++) {
+                    const double fx = (double)rem * inv_b;
+                    CoefRow c = nx;
+                    if (r + 1 < WT / 64) {
+                        rem += F.dr64;
+                        q += F.dq64;
+                        const bool wrap = rem >= F.b;
+                        rem -= wrap ? F.b : 0u;
+                        q += wrap ? 1u : 0u;
+                        nx.issue(cf0 + 32u * q);
+                        c.template wait<2>();
+                    } else {
+                        c.template wait<0>();
+                    }
+                    const double v = __builtin_fma(__builtin_fma(__builtin_fma(c.a.x, fx, c.a.y), fx, c.b.x), fx, c.b.y);
+                    orow[r * 64 + lane] = __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < WT / 64; r++) {
+                    orow[r * 64 + lane] = eval(q, rem);
+                    rem += F.dr64;
+                    q += F.dq64;
+                    const bool wrap = rem >= F.b;
+                    rem -= wrap ? F.b : 0u;
+                    q += wrap ? 1u : 0u;
+                }
             }
         } else {
             for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
@@ -156,7 +189,7 @@ bool wave_coef_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate
     const unsigned ccap = (unsigned)((win + 3) & ~3);
     const int cw = interp == AUKIT_INTERP_CUBIC ? 4 : 2;
     const size_t lds = ((size_t)F.cap / 2 + (size_t)ccap * cw) * 8 * 4;
-    unsigned per_cu = 16;
+    unsigned per_cu = 64;   // workgroups per CU in the grid (6 are resident); 6 / 12 / 16 / 24 / 32 / 64 / 128 measured 1.83 / 1.82 / 1.77 / 1.74 / 1.74 / 1.72 / 1.76 ms on config 2a
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;

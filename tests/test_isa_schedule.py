@@ -51,7 +51,7 @@ def test_checker_accepts_a_correct_schedule_and_catches_an_early_use():
 
 
 @pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
-@pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16)])
+@pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16), ("wave_coef_f64.hip", 32)])
 def test_hand_scheduled_kernels_keep_their_registers(src, at_least):
     asm = isa_check.compile_asm(os.path.join(ROOT, "aukit_amd", "csrc", src))
     v, n = isa_check.check(asm)

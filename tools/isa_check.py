@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check of the hand-scheduled memory pipelines (wave_f64.hip's Row::issue / wait, dfpwm_par.hip's AUKIT_DFF_ISSUE /
+"""Build-time check of the hand-scheduled memory pipelines (wave_f64.hip's Row::issue / wait, wave_coef_f64.hip's CoefRow, dfpwm_par.hip's AUKIT_DFF_ISSUE /
 WAIT, flac.hip / fast_wave_dev.h's "landed" statements are NOT covered: those pass through compiler-visible loads).
 
 The kernels issue `ds_read_*` / `global_load_*` in one inline-asm statement and wait for them in a LATER one (`s_waitcnt lgkmcnt(N)` /
