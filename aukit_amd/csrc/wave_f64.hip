@@ -330,6 +330,190 @@ __global__ __launch_bounds__(256) void k_wave_f64(const ResampleParams P, const 
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
+// ---- the phases in registers (round 3).  Lane l of row r evaluates output 64 r + l of its tile, at phase ((64 r + l) a) mod b.  When the
+// tile is a multiple of lcm(64, b) outputs, every tile of a segment starts at phase 0 and a lane meets only PH = b / gcd(b, 64) phases —
+// rows r and r + PH share one (44.1 → 48 kHz: b = 160, PH = 5, tiles of 640).  The lane then keeps the weights of its PH phases and the tap
+// offsets of its first PH rows in registers for the whole launch: a row reads its four taps from LDS (32 bytes where the phase-table kernel
+// reads 64 — its LDS reads are what bound that one) and needs no position arithmetic at all (one add for the tap address).  Same weights
+// (the host's table, read once per lane from HBM), same order of operations: bit-identical to k_wave_f64<…, TAB = true>.
+template <int INTERP> struct PhaseW;
+template <> struct PhaseW<AUKIT_INTERP_CUBIC> {
+    double w0, w1, w2, w3;
+    AUKIT_DEV void load(const double *wg, unsigned b, unsigned rem) { w0 = wg[2 * rem]; w1 = wg[2 * rem + 1]; w2 = wg[2 * b + 2 * rem]; w3 = wg[2 * b + 2 * rem + 1]; }
+    AUKIT_DEV double eval(const Row<AUKIT_INTERP_CUBIC, false> &t) const { return __builtin_fma(w3, t.p3, __builtin_fma(w2, t.p2, __builtin_fma(w1, t.p1, w0 * t.p0))); }
+};
+template <> struct PhaseW<AUKIT_INTERP_LINEAR> {
+    double fx;
+    AUKIT_DEV void load(const double *wg, unsigned, unsigned rem) { fx = wg[rem]; }
+    AUKIT_DEV double eval(const Row<AUKIT_INTERP_LINEAR, false> &t) const { return __builtin_fma(t.p2 - t.p1, fx, t.p1); }
+};
+
+#ifndef AUKIT_F64_REG_NQ
+#define AUKIT_F64_REG_NQ 6
+#endif
+constexpr int REG_NQ_MAX = AUKIT_F64_REG_NQ;  // conversion rounds of 128 samples a window can take
+#ifndef AUKIT_F64_REG_K5
+#define AUKIT_F64_REG_K5 2          // tiles of 64 · 5 · K5 outputs when a lane meets five phases (A/B)
+#endif
+#ifdef AUKIT_F64_REG_WAVES
+#define AUKIT_REG_OCC __attribute__((amdgpu_waves_per_eu(AUKIT_F64_REG_WAVES, 8)))
+#else
+#define AUKIT_REG_OCC
+#endif
+
+template <int INTERP, int PH, int K, int EPI>
+__global__ __launch_bounds__(256) AUKIT_REG_OCC void k_wave_f64_reg(const ResampleParams P, const FastParams F, const double *__restrict__ wg, const unsigned nq, const unsigned qstep8,
+                                                      const double inv_b, const double alpha) {
+    extern __shared__ double smd[];  // [4 × window of 128 nq doubles][4 × raw tile of 256 nq bytes]
+    constexpr int TILE = 64 * PH * K, ROWS = PH * K;
+    constexpr int HL = (INTERP == AUKIT_INTERP_CUBIC ? 1 : 0) + (EPI ? 1 : 0), HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
+    auto finish = [&](double s, double prev) -> float {   // as in k_wave_f64
+        if constexpr (EPI == 0) return __builtin_amdgcn_fmed3f((float)s, -1.0f, 1.0f);
+        else {
+            const double ns = __builtin_fma(alpha, s - prev, prev);
+            const double v = ns * (127.5 - __builtin_copysign(0.5, ns));
+            return __builtin_amdgcn_fmed3f((float)v, -128.0f, 127.0f);
+        }
+    };
+    using R = Row<INTERP, false>;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *const sm = smd + wave * (128u * nq);
+    unsigned char *const raw = reinterpret_cast<unsigned char *>(smd + 4u * 128u * nq) + wave * (256u * nq);
+    const unsigned nwaves = gridDim.x * 4u;
+
+    unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
+    if (t >= P.n_tiles) return;
+    // this lane's PH phases: weights and the byte offset of the first tap
+    PhaseW<INTERP> pw[PH];
+    unsigned qo[PH];
+#pragma unroll
+    for (int p = 0; p < PH; p++) {
+        const unsigned n = (unsigned)(64 * p + lane) * F.a;
+        const unsigned q = __umulhi(n, F.magic), rem = n - q * F.b;
+        qo[p] = 8u * q;
+        pw[p].load(wg, F.b, rem);
+    }
+    auto dma = [&](const WaveTile &w) {
+#pragma unroll
+        for (int i = 0; i < (REG_NQ_MAX + 3) / 4; i++) {
+            const int v = lane + 64 * i;
+            if (v < 16 * (int)nq) {   // the raw area is 16 nq vectors: lanes beyond it stay out of the LDS write
+                const unsigned char *p = w.al + 16 * (size_t)v;
+                const bool ok = v < w.nvec && p >= P.safe_lo && p + 16 <= P.safe_hi;
+                __builtin_amdgcn_global_load_lds((const AUKIT_GLOBAL_AS void *)(ok ? p : P.safe_lo), (AUKIT_LDS_AS void *)(raw + 1024 * i), 16, 0, 0);
+            }
+        }
+    };
+    WaveTile cur = describe_t<TILE, HL, HR>(P, F, t);
+    dma(cur);
+    __builtin_amdgcn_s_waitcnt(VMCNT0);
+    const double sc_pos = 1.0 / 32767.0, sc_neg = 1.0 / 32768.0;
+    for (;;) {
+        // ---- 1. raw → window as doubles (k_wave_f64's conflict-free mapping), nq rounds of 64 dwords
+        unsigned rw[REG_NQ_MAX];
+#pragma unroll
+        for (int j = 0; j < REG_NQ_MAX; j++) if (j < (int)nq) rw[j] = reinterpret_cast<const unsigned *>(raw)[64 * j + lane];
+#pragma unroll
+        for (int j = 0; j < REG_NQ_MAX; j++) {
+            if (j < (int)nq) {
+                const unsigned w = rw[j];
+                const int s0 = (int)(short)(w & 0xFFFF), s1 = (int)w >> 16;
+                reinterpret_cast<double2 *>(sm)[64 * j + lane] = make_double2((double)s0 * (s0 < 0 ? sc_neg : sc_pos), (double)s1 * (s1 < 0 ? sc_neg : sc_pos));  // :1081
+            }
+        }
+        {
+            const unsigned char *lo = cur.al, *hi = cur.al + 16 * (size_t)cur.nvec;
+            auto sample = [&](const unsigned char *q) { const short s = (short)(q[0] | q[1] << 8); return (double)s * (s < 0 ? sc_neg : sc_pos); };
+            if (lo < P.safe_lo || hi > P.safe_hi) {  // wave-uniform, rare: vectors that straddle the allocation
+                for (int idx = lane; idx < cur.nvec * 8; idx += 64) {
+                    const unsigned char *q = cur.al + (size_t)idx * 2;
+                    const unsigned char *vb = cur.al + 16 * (size_t)(idx / 8);
+                    if (!(vb >= P.safe_lo && vb + 16 <= P.safe_hi)) sm[idx] = (q >= P.safe_lo && q + 2 <= P.safe_hi) ? sample(q) : 0.0;
+                }
+            }
+            const int k_hi = cur.k_lo + cur.n_stage - 1;   // nil fall-backs of interpolate.{linear,cubic} (:259, :264) = replicated edge samples
+            if (cur.k_lo < cur.w_lo) {
+                const double e_lo = sample(cur.base + 2ll * cur.w_lo);
+                for (int idx = lane; idx < cur.w_lo - cur.k_lo; idx += 64) sm[cur.head + idx] = e_lo;
+            }
+            if (k_hi > cur.w_hi) {
+                const double e_hi = sample(cur.base + 2ll * cur.w_hi);
+                const int first = cur.w_hi + 1 - cur.k_lo;
+                for (int idx = lane; idx < k_hi - cur.w_hi; idx += 64) sm[cur.head + first + idx] = e_hi;
+            }
+        }
+        // ---- 2. the next tile's raw samples
+        const unsigned tn = t + nwaves;
+        const bool more = tn < P.n_tiles;
+        WaveTile nxt = cur;
+        if (more) {  // wave-uniform
+            nxt = describe_t<TILE, HL, HR>(P, F, tn);
+            dma(nxt);
+        }
+        const double *tab = sm + cur.head + HL;  // tab[q] = d[1 + kb + q]
+        float *orow = cur.orow;
+        const bool full = cur.cnt == (unsigned)TILE;  // wave-uniform
+        float res[ROWS];
+        [[maybe_unused]] double carry = 0.0;   // EPI 1: the raw sample before the tile's first output (0 at the start of a chunk)
+        if constexpr (EPI == 1) {
+            const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - as_const(P.seg_tile0)[as_const(P.tile_seg)[t]]) == 0;
+            if (!first) carry = eval_plain<INTERP, true>(tab - 1, wg, F.b, inv_b, 0u, F.b - F.a);   // a tile starts at phase 0: one table step back, phase b - a (a < b)
+        }
+        if (full) {
+            // ---- 3. the rows, into registers: row r = phase r mod PH, taps (r / PH) · qstep further
+            asm volatile("" ::: "memory");  // the staging stores above stay above
+            const unsigned tap0 = lds_addr(tab) - (INTERP == AUKIT_INTERP_CUBIC ? 8u : 0u);
+            R nx;
+            nx.issue(tap0 + qo[0], 0u, 0u);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                R c = nx;
+                if (r + 1 < ROWS) {
+                    nx.issue(tap0 + qo[(r + 1) % PH] + (unsigned)((r + 1) / PH) * qstep8, 0u, 0u);
+                    c.template wait<R::N>();
+                } else {
+                    c.template wait<0>();
+                }
+                const double sv = pw[r % PH].eval(c);
+                if constexpr (EPI == 0) res[r] = finish(sv, 0.0);
+                else { const double pv = prev_lane_d(sv, carry); carry = last_lane_d(sv); res[r] = finish(sv, pv); }
+            }
+            asm volatile("" ::: "memory");  // the next tile's staging stores stay below
+        }
+        // ---- 4. the next tile's samples have landed (k_wave_f64 explains why the wait is here, on the straight path)
+        __builtin_amdgcn_s_waitcnt(VMCNT0);
+        unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
+        asm volatile("" : "+s"(full2));
+        if (full2) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) orow[r * 64 + lane] = res[r];
+        } else {
+            for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
+                const unsigned j = rb + lane;
+                const unsigned n = cur.r0 + (j < cur.cnt ? j : cur.cnt - 1) * F.a;
+                const unsigned q = __umulhi(n, F.magic);
+                const unsigned rem = n - q * F.b;
+                const double v = eval_plain<INTERP, true>(tab, wg, F.b, inv_b, q, rem);
+                double pv = 0.0;
+                if constexpr (EPI == 1) { pv = prev_lane_d(v, carry); carry = last_lane_d(v); }
+                if (j < cur.cnt) orow[j] = finish(v, pv);
+            }
+        }
+        if (!more) break;
+        cur = nxt;
+        t = tn;
+    }
+}
+
+template <int INTERP, int EPI>
+static void launch_wf64_reg(int ph, const ResampleParams &P, const FastParams &F, const double *wg, unsigned nq, unsigned qstep8, double inv_b, double alpha, size_t lds,
+                            unsigned grid, hipStream_t st) {
+    if (ph == 1) hipLaunchKernelGGL((k_wave_f64_reg<INTERP, 1, 8, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, nq, qstep8, inv_b, alpha);
+    else if (ph == 3) hipLaunchKernelGGL((k_wave_f64_reg<INTERP, 3, 3, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, nq, qstep8, inv_b, alpha);
+    else hipLaunchKernelGGL((k_wave_f64_reg<INTERP, 5, AUKIT_F64_REG_K5, EPI>), dim3(grid), dim3(256), lds, st, P, F, wg, nq, qstep8, inv_b, alpha);
+}
+
 template <int INTERP, int TILE, bool TAB, int EPI>
 static void launch_wf64(int nv, const ResampleParams &P, const FastParams &F, const double *wg, unsigned wtd, double inv_b, double alpha, size_t lds, unsigned grid, hipStream_t st) {
     switch (nv) {
@@ -372,6 +556,57 @@ bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, dou
     if (!fast_eligible(SRC_PCM_S16LE_MONO, interp, old_rate, new_rate, F)) return false;
     for (const Seg &g : segs)
         if (g.w_hi < g.w_lo && g.n_out) return false;
+    {   // the phases in registers, when a lane meets at most five of them (k_wave_f64_reg): up-sampling with b = 2^i, 3 · 2^i or 5 · 2^i, i <= 6
+        const char *er = getenv("AUKIT_F64_REGS");
+        unsigned g = F.b, h = 64;
+        while (h) { const unsigned r = g % h; g = h; h = r; }
+        const unsigned ph = F.b / g;
+        if (!(er && atoi(er) == 0) && !getenv("AUKIT_F64_TILE") && !getenv("AUKIT_F64_HORNER") && F.a <= F.b && F.b <= 512 && (ph == 1 || ph == 3 || ph == 5)) {
+            const int tile = ph == 1 ? 512 : (ph == 3 ? 576 : 320 * AUKIT_F64_REG_K5);
+            const int hl = (interp == AUKIT_INTERP_CUBIC ? 1 : 0) + (epi ? 1 : 0), hr = interp == AUKIT_INTERP_CUBIC ? 2 : 1;
+            const int win = (int)(((unsigned long long)(tile - 1) * F.a) / F.b) + 2 + hl + hr;
+            const unsigned nq = (unsigned)(win + 16 + 127) / 128;   // + 16: the window starts at a 16-byte boundary (up to 7 samples early), as nv above
+            uint64_t max_tiles = 0;
+            for (const Seg &sg : segs) max_tiles = std::max<uint64_t>(max_tiles, (sg.n_out + tile - 1) / tile);
+            F.wc = (unsigned)(((unsigned long long)tile * F.a) / F.b);
+            F.wd = (unsigned)(((unsigned long long)tile * F.a) % F.b);
+            const bool fits = nq <= (unsigned)REG_NQ_MAX && F.wd == 0 && ((double)max_tiles + 1) * (double)F.wc < 2147483648.0 &&
+                              ((double)F.b + (double)tile * (double)F.a) * (double)F.b < 4294967296.0;
+            if (fits) {
+                F.cap = 128 * (int)nq;
+                F.dq64 = (unsigned)((64ull * F.a) / F.b);
+                F.dr64 = (unsigned)((64ull * F.a) % F.b);
+                if (ctx->wt_b != F.b || ctx->wt_interp != interp) {
+                    std::vector<double> w;
+                    phase_weights(F.b, interp, w);
+                    if ((*rc = upload_table(ctx, ctx->wt_buf, w.data(), w.size() * sizeof(double)))) return true;
+                    ctx->wt_b = F.b; ctx->wt_interp = interp; ctx->wt_doubles = (unsigned)w.size();
+                }
+                const size_t lds = (size_t)nq * (4 * 128 * 8 + 4 * 256);
+                if ((*rc = plan_tiles_sized(ctx, segs, tile, P))) return true;
+                if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
+                unsigned per_cu = 64;
+                if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
+                const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
+                if ((*rc = ctx_begin_kernel(ctx))) return true;
+                const double *wg = reinterpret_cast<const double *>(ctx->wt_buf.p);
+                const unsigned qstep8 = 8u * (unsigned)((64ull * ph * F.a) / F.b);   // lcm(64, b) outputs further: a whole number of source samples
+                const double inv_b = 1.0 / (double)F.b;
+                if (interp == AUKIT_INTERP_LINEAR) {
+                    if (epi) launch_wf64_reg<AUKIT_INTERP_LINEAR, 1>((int)ph, P, F, wg, nq, qstep8, inv_b, alpha, lds, grid, ctx->stream);
+                    else launch_wf64_reg<AUKIT_INTERP_LINEAR, 0>((int)ph, P, F, wg, nq, qstep8, inv_b, 0.0, lds, grid, ctx->stream);
+                } else {
+                    if (epi) launch_wf64_reg<AUKIT_INTERP_CUBIC, 1>((int)ph, P, F, wg, nq, qstep8, inv_b, alpha, lds, grid, ctx->stream);
+                    else launch_wf64_reg<AUKIT_INTERP_CUBIC, 0>((int)ph, P, F, wg, nq, qstep8, inv_b, 0.0, lds, grid, ctx->stream);
+                }
+                if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_wave_f64_reg launch failed"); return true; }
+                static thread_local char nmr[96];
+                snprintf(nmr, sizeof nmr, "k_wave_f64<pcm_s16le_mono,%s,tile%d,phase_regs%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", tile, epi ? ",stream_pcm" : "");
+                *rc = ctx_end_kernel(ctx, nmr, algorithmic_bytes);
+                return true;
+            }
+        }
+    }
     int tile = 512;  // outputs per wave tile: 512 keeps six workgroups (24 waves) per CU next to their windows; 1024 keeps three
     if (const char *e = getenv("AUKIT_F64_TILE")) tile = (atoi(e) == 1024 && !epi) ? 1024 : 512;
     const int spv = 8;

@@ -32,12 +32,13 @@ def _check(got, ref):
     return int(np.count_nonzero(g32 != r32)), len(ref)
 
 
-@pytest.mark.parametrize("tile", ["512", "1024"])
+@pytest.mark.parametrize("tile", ["512", "1024", "auto"])
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
-@pytest.mark.parametrize("rate,new_rate", [(44100, 48000), (8000, 48000), (22050, 48000), (48000, 44100), (32000, 48000), (11025, 48000), (47999, 48000)])
+@pytest.mark.parametrize("rate,new_rate", [(44100, 48000), (8000, 48000), (22050, 48000), (48000, 44100), (32000, 48000), (11025, 48000), (47999, 48000), (24000, 48000), (16000, 48000), (4800, 48000)])
 def test_wave_f64_rounds_the_oracles_double(ctx, oracle, monkeypatch, rate, new_rate, interp, tile):
     B, N = _mods()
-    monkeypatch.setenv("AUKIT_F64_TILE", tile)
+    if tile != "auto":
+        monkeypatch.setenv("AUKIT_F64_TILE", tile)
     ctx.set_option(N.OPT_EXACT_MATH, 1)
     try:
         lens = [rate * 2 + 11, 9000, 4097, 1, 2, 3, 5, 700, 941, 942, 1024, 1025]
@@ -50,6 +51,9 @@ def test_wave_f64_rounds_the_oracles_double(ctx, oracle, monkeypatch, rate, new_
             assert name.startswith(("k_resample<", "k_exact_wave<")), name
         elif rate == 48000 and tile == "1024":  # down-sampling: the window of a 1024-output tile + its raw samples do not fit 64 KiB of LDS next to three others
             assert name.startswith(("k_exact_wave<", "k_fast_wave_fmt<signed16,1ch")), name   # (round 3: the generic format kernel with fp64 tables and 512-output tiles fits)
+        elif tile == "auto":   # no tile asked for: the phases-in-registers kernel wherever a lane meets at most five phases (up-sampling, b = 2^i, 3 * 2^i, 5 * 2^i)
+            assert name.startswith("k_wave_f64<pcm_s16le_mono," + interp + ",tile"), name
+            assert ("phase_regs" in name) == (rate not in (48000, 11025)), name
         else:
             assert name.startswith("k_wave_f64<pcm_s16le_mono," + interp + ",tile" + tile), name
             assert ("horner" in name) == (rate == 11025), name  # 640 phases do not fit the table (b <= 512)
@@ -73,7 +77,12 @@ def test_wave_f64_horner_form_agrees(ctx, oracle, monkeypatch):
         bt = B.Batch.upload(ctx, [s, s[:5000]])
         desc = B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed")
         a = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32).download()
+        assert "phase_regs" in ctx.last_kernel()[0]
+        monkeypatch.setenv("AUKIT_F64_REGS", "0")
+        t = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32).download()
         assert "phase_table" in ctx.last_kernel()[0]
+        for x, y in zip(a, t):
+            assert np.array_equal(x[0], y[0])   # same weights, same order of operations: the two are bit-identical
         monkeypatch.setenv("AUKIT_F64_HORNER", "1")
         b = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32).download()
         assert "horner" in ctx.last_kernel()[0]
