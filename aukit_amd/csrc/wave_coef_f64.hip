@@ -46,10 +46,11 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
     auto load_window = [&](const WaveTile &w) {
         const unsigned char *vb = w.al + 16 * (size_t)(lane >> 2);  // a vector that straddles the allocation reads as zero (patched below)
         pre1 = 0;
-        if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *reinterpret_cast<const unsigned *>(w.al + 4 * (size_t)lane);
+        if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *(const __attribute__((address_space(1))) unsigned *)(w.al + 4 * (size_t)lane);   // global_load (a generic dereference is a flat_load, which also counts in lgkmcnt: the rows' counted waits would sit it out)
     };
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);
     load_window(cur);
+    asm volatile("" : "+v"(pre1));   // waited for on every edge into the loop (fast_wave_dev.h: or hipcc's vmcnt(0) lands at the top of the loop, behind the stores)
     for (;;) {
         if ((lane >> 2) < cur.nvec) {
             const float sc = (float)P.g711_scale;
@@ -109,7 +110,13 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
             }
             return __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);  // :667-668
         };
-        if (cur.cnt == (unsigned)WT) {
+        // A tile's rows wait in registers until the NEXT tile's window dword has been waited for, and only then are stored (the order of
+        // k_fast_wave / k_wave_f64: loads and stores share vmcnt, so a wait that stands right behind sixteen fresh stores — where hipcc puts it
+        // when the rows are stored as they are evaluated — sits out their write latency once per tile; here the only stores still counted
+        // are the tile-before's).
+        const bool full = cur.cnt == (unsigned)WT;  // wave-uniform
+        float res[WT / 64];
+        if (full) {
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
@@ -135,12 +142,12 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
                         c.template wait<0>();
                     }
                     const double v = __builtin_fma(__builtin_fma(__builtin_fma(c.a.x, fx, c.a.y), fx, c.b.x), fx, c.b.y);
-                    orow[r * 64 + lane] = __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);
+                    res[r] = __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < WT / 64; r++) {
-                    orow[r * 64 + lane] = eval(q, rem);
+                    res[r] = eval(q, rem);
                     rem += F.dr64;
                     q += F.dq64;
                     const bool wrap = rem >= F.b;
@@ -148,6 +155,18 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
                     q += wrap ? 1u : 0u;
                 }
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) res[r] = 0.f;
+        }
+        // ---- the next tile's dword has landed (on the straight path, as in k_wave_f64: inside the branches hipcc finds a way around it)
+        asm volatile("" : "+v"(pre1), "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]));
+        asm volatile("" : "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
+        unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
+        asm volatile("" : "+s"(full2));  // opaque: or jump threading fuses the two `if (full)` and the wait is back inside the branches
+        if (full2) {
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) orow[r * 64 + lane] = res[r];
         } else {
             for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
                 const unsigned j = rb + lane;

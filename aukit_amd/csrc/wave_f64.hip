@@ -585,7 +585,7 @@ bool wave_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, dou
                 const size_t lds = (size_t)nq * (4 * 128 * 8 + 4 * 256);
                 if ((*rc = plan_tiles_sized(ctx, segs, tile, P))) return true;
                 if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
-                unsigned per_cu = 64;
+                unsigned per_cu = 128;   // 4 / 8 / 16 / 32 / 64 / 128 / 256 measured 2.15 / 2.22 / 2.30 / 2.26 / 2.06 / 2.04 / 2.05 ms on config T (four workgroups are resident)
                 if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
                 const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
                 if ((*rc = ctx_begin_kernel(ctx))) return true;
