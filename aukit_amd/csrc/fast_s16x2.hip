@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_s16x2(const ResampleParams P,
     uint4 pre[NV];
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);
     issue_loads<NV>(P, cur, lane, pre);
+    pre_landed<NV>(pre);   // waited for on every edge into the loop (fast_wave_dev.h)
     for (;;) {
         // ---- window → two LDS tables
 #pragma unroll
@@ -83,20 +84,34 @@ __global__ __launch_bounds__(256) void k_fast_wave_s16x2(const ResampleParams P,
         }
         const float *tabL = smL + cur.head + HL, *tabR = smR + cur.head + HL;  // tab[q] = d[1 + kb + q]
         float *orowL = cur.orow, *orowR = cur.orow + ostride;
-        if (cur.cnt == (unsigned)WT) {
+        // the rows wait in registers until the next tile's loads have been waited for, then they are stored (fast_wave_dev.h, "Where the wave waits")
+        const bool full = cur.cnt == (unsigned)WT;  // wave-uniform
+        float res[2 * (WT / 64)];
+        if (full) {
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
-                orowL[r * 64 + lane] = interp_qr<SRC_PCM_S16LE_MONO, INTERP>(F, tabL, q, rem);
-                orowR[r * 64 + lane] = interp_qr<SRC_PCM_S16LE_MONO, INTERP>(F, tabR, q, rem);
+                res[2 * r] = interp_qr<SRC_PCM_S16LE_MONO, INTERP>(F, tabL, q, rem);
+                res[2 * r + 1] = interp_qr<SRC_PCM_S16LE_MONO, INTERP>(F, tabR, q, rem);
                 rem += F.dr64;
                 q += F.dq64;
                 const bool wrap = rem >= F.b;
                 rem -= wrap ? F.b : 0u;
                 q += wrap ? 1u : 0u;
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2 * (WT / 64); r++) res[r] = 0.f;
+        }
+        pre_landed<NV>(pre);
+        hold_results(res);
+        unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
+        asm volatile("" : "+s"(full2));  // opaque: or jump threading fuses the two `if (full)` and the wait is back inside the branches
+        if (full2) {
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) { orowL[r * 64 + lane] = res[2 * r]; orowR[r * 64 + lane] = res[2 * r + 1]; }
         } else {
             for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
                 const unsigned j = rb + lane;

@@ -132,6 +132,15 @@ AUKIT_DEV void loads_landed(uint4 (&pre)[NV], float (&res)[16]) {
     asm volatile("" : "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
 }
 
+// results that must not be stored before this point (the statement is ordered after every asm volatile in front of it, and the stores need its outputs)
+template <int N>
+AUKIT_DEV void hold_results(float (&res)[N]) {
+    static_assert(N % 8 == 0, "N");
+#pragma unroll
+    for (int i = 0; i < N; i += 8)
+        asm volatile("" : "+v"(res[i]), "+v"(res[i + 1]), "+v"(res[i + 2]), "+v"(res[i + 3]), "+v"(res[i + 4]), "+v"(res[i + 5]), "+v"(res[i + 6]), "+v"(res[i + 7]));
+}
+
 template <int SRC>
 AUKIT_DEV float sample_at(const ResampleParams &P, const FastParams &F, const unsigned char *q) {
     if constexpr (SRC == SRC_PCM_S16LE_MONO) {
