@@ -23,6 +23,9 @@
 // top of that changed nothing (771): what is left is per-tile work (describe, staging, the coefficient pass, LDS round trips).
 #include <algorithm>
 #include <type_traits>
+// Tiles of 960 outputs in this translation unit (15 rows): a multiple of lcm(64, b) for b = 2^i, 3 · 2^i and 5 · 2^i (i <= 6), so that a tile
+// starts at phase 0 and a lane meets at most five phases (the PH > 0 instantiations below), and an iterator call's 48000 outputs are 50 whole tiles.
+#define AUKIT_WT 960
 #include "fast_wave_dev.h"
 #include "resample_dev.h"
 
@@ -33,8 +36,12 @@ AUKIT_DEV void store_floor(double *p, float v) { *p = (double)v; }
 
 // DW: the window is at most 16 vectors (up-sampling by > ~4.6, e.g. 8 kHz -> 48 kHz): every lane stages one dword of it instead
 // of the first few lanes staging 16 bytes each, and the polynomial coefficients are tabulated per source sample (ccap entries).
-template <int INTERP, bool DW, typename OUT_T>
-__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F, const unsigned ccap) {
+// PH > 0 (round 3, with DW): the phases in registers.  Lane l of row r is output 64 r + l of its tile, at phase ((64 r + l) a) mod b; rows r and
+// r + PH share it (PH = b / gcd(b, 64)) and every tile starts at phase 0, so fx, the "rem == 0" answer and the coefficient entry's offset
+// are per-lane constants of the launch: a row is one table read, three FMAs and the guard — no position arithmetic, in a kernel bound by its VALU
+// instructions.  Same f32 operations on the same values as the generic rows: the same tier decisions, bit for bit.
+template <int INTERP, bool DW, typename OUT_T, int PH>
+__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F, const unsigned ccap, const unsigned qstep) {
     extern __shared__ float smf[];
     constexpr int SRC = SRC_G711_MONO;
     // one more tap to the left than the polynomial needs: at a mathematically integer position the reference's x may round to just
@@ -54,6 +61,23 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
 
     unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
     if (t >= P.n_tiles) return;
+    constexpr int NPH = PH > 0 ? PH : 1;
+    [[maybe_unused]] float fxp[NPH];
+    [[maybe_unused]] unsigned qo[NPH];
+    [[maybe_unused]] bool acc0[NPH];
+    if constexpr (PH > 0) {
+#pragma unroll
+        for (int p = 0; p < PH; p++) {
+            const unsigned n = (unsigned)(64 * p + lane) * F.a;
+            const unsigned q = __umulhi(n, F.magic), rem = n - q * F.b;
+            const float remf = (float)rem;
+            float fx = remf * inv_bf;
+            fx = __builtin_fmaf(__builtin_fmaf(-fx, bf, remf), inv_bf, fx);  // rem / b to one ulp, as in the generic rows
+            fxp[p] = fx;
+            qo[p] = q;
+            acc0[p] = int_ratio && rem == 0;
+        }
+    }
     constexpr int NV = 1;
     uint4 pre[NV];
     unsigned pre1 = 0;
@@ -200,7 +224,45 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             if (active) store_floor(orow + j, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));  // :2909 (one v_med3; fl is never a nan: the window holds finite samples)
         }
         };
-        if (cur.cnt == (unsigned)WT) rows(std::true_type{}); else rows(std::false_type{});
+        [[maybe_unused]] auto rows_reg = [&]() {   // a full tile with the phases in registers
+            // Every row stores its tier-1 answer and notes in a bit whether the guard turned it down; the (rare) turned-down outputs are redone
+            // behind the rows by ONE copy of tiers 2-3 and stored again (same lane, same address: in order).  Inline, fifteen copies of the slow
+            // path cost 137 VGPRs and measured slower than the generic rows.
+            unsigned need = 0;
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) {
+                const int p = r % NPH;
+                const unsigned qq = qo[p] + (unsigned)(r / NPH) * qstep;
+                const float fx = fxp[p];
+                float w;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                    const float2 c = *reinterpret_cast<const float2 *>(cf + 2 * qq);
+                    w = __builtin_fmaf(c.x, fx, c.y);
+                } else {
+                    const float4 c = *reinterpret_cast<const float4 *>(cf + 4 * qq);
+                    w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.x, fx, c.y), fx, c.z), fx, c.w);
+                }
+                const float fl = floorf(w);
+                const float fr = w - fl;
+                const bool guard = fr > 1e-3f && fr < 1 - 1e-3f;
+                const bool accept = guard || acc0[p];
+                need |= accept ? 0u : 1u << r;
+                store_floor(orow + r * 64 + lane, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));
+            }
+            if (__any(need != 0)) {
+                while (need) {
+                    const int r = __builtin_ctz(need);
+                    need &= need - 1;
+                    const unsigned j = (unsigned)(r * 64 + lane), n = j * F.a;
+                    const unsigned q2 = __umulhi(n, F.magic);
+                    const float fl = slow(q2, n - q2 * F.b, j);
+                    store_floor(orow + j, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));
+                }
+            }
+        };
+        if (cur.cnt == (unsigned)WT) {
+            if constexpr (PH > 0 && DW) rows_reg(); else rows(std::true_type{});
+        } else rows(std::false_type{});
         if (DW) __builtin_amdgcn_wave_barrier();  // the next tile's staging overwrites both tables
         if (!more) break;
         cur = nxt;
@@ -241,9 +303,19 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
     const size_t lds = ((size_t)F.cap + (size_t)ccap * (interp == AUKIT_INTERP_CUBIC ? 4 : 2)) * 4 * 4;  // per wave: window + coefficient table
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 8);
+    // the phases in registers: tiles start at phase 0 and a lane meets PH = b / gcd(b, 64) <= 5 phases
+    unsigned g64 = F.b, h64 = 64;
+    while (h64) { const unsigned r = g64 % h64; g64 = h64; h64 = r; }
+    unsigned ph = F.b / g64;
+    const char *er = getenv("AUKIT_FLOOR_REGS");
+    if (!dw || F.wd != 0 || (ph != 1 && ph != 3 && ph != 5) || (WT / 64) % (int)ph != 0 || (er && atoi(er) == 0)) ph = 0;
+    const unsigned qstep = ph ? (unsigned)((64ull * ph * F.a) / F.b) : 0u;
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-#define AUKIT_FW(I, T) do { if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap); \
-                            else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap); } while (0)
+#define AUKIT_FW(I, T) do { if (dw && ph == 1) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
+                            else if (dw && ph == 3) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 3>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
+                            else if (dw && ph == 5) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
+                            else if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
+                            else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); } while (0)
     if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, signed char); else AUKIT_FW(AUKIT_INTERP_CUBIC, signed char); }
     else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, double); else AUKIT_FW(AUKIT_INTERP_CUBIC, double); }
 #undef AUKIT_FW
