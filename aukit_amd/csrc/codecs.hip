@@ -474,6 +474,7 @@ struct ImaStreamParams {
     unsigned fdq, fdr;                   // 64 fa = fdq fb + fdr
     unsigned long long bps;              // k_ima_stream_f32: blocks per stream when that is the same for every stream, else 0
     unsigned mid_lo, mid_end_full;       // k_ima_stream_f32: the clean rows of a full block (host-made: two 64-bit divisions per block otherwise)
+    unsigned qstep;                      // k_ima_stream_f32<…, PH>: 64 PH fa / fb, the table entries that 64 PH outputs span (a whole number)
 };
 
 template <int INTERP, typename OUT_T>
@@ -598,7 +599,11 @@ struct CvImaF32 {
 //      when more than 1e-6 away from an integer (the reference's x carries < 1024 · 2^-53 of rounding, times a slope below 1600).
 //   3. otherwise, and where the nil fall-backs of the block's ends apply: the reference-order code on the same table.
 // Same-box A/B against the fp64-only short-cut of k_ima_stream (AUKIT_IMA_F64=1) in DESIGN.md §3.
-template <int INTERP, typename OUT_T>
+// PH > 0 (round 3): the phases in registers.  A block's outputs start at phase 0 and rows R and R + PH (PH = fb / gcd(fb, 64): 5 at 22 050 and 44 100 Hz)
+// share their phases, so a lane keeps the weights and the first-tap offsets of its PH phases for the whole launch; the clean rows of a block then run
+// in groups of PH rows without position arithmetic, the guard's turn-downs noted in a bit each and redone behind the group by one copy of tiers 2-3.
+// Same f32 operations on the same values as the generic rows: the same tier decisions, bit for bit.
+template <int INTERP, typename OUT_T, int PH>
 __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P, const float *__restrict__ wg) {
     extern __shared__ float smf[];
     constexpr int WF = INTERP == AUKIT_INTERP_CUBIC ? 4 : 1;  // floats per phase: w0..w3 / fx
@@ -615,6 +620,19 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
     ResampleParams RP;  // only the position fields are used by pos_of / eval_at
     RP.ratio = P.ratio; RP.rcp = P.rcp; RP.exact_rcp = P.exact_rcp; RP.sinc_w = 10;
     const float c127 = 1.0f / 127.0f;
+    constexpr int NPH = PH > 0 ? PH : 1;
+    [[maybe_unused]] float4 pw[NPH];     // cubic: w0..w3 of the phase; linear: .x = fx
+    [[maybe_unused]] unsigned qo[NPH];
+    if constexpr (PH > 0) {
+#pragma unroll
+        for (int i = 0; i < PH; i++) {
+            const unsigned n = (unsigned)(64 * i + lane) * P.fa;
+            const unsigned q = __umulhi(n, P.fmagic), r = n - q * P.fb;
+            qo[i] = q;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) pw[i] = make_float4(wt[r], 0.f, 0.f, 0.f);
+            else pw[i] = *reinterpret_cast<const float4 *>(wt + 4 * r);
+        }
+    }
     for (unsigned long long gb = (unsigned long long)blockIdx.x * 4 + wave; gb < P.nblocks; gb += (unsigned long long)gridDim.x * 4) {
         unsigned lo = 0, hi = P.nstreams;  // stream of this block (wave-uniform): a division when every stream has the same number of blocks, else a binary search in blk0
         if (P.bps) lo = (unsigned)(gb / P.bps);
@@ -712,8 +730,54 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             if (active && !accept) fl = slow(k, rem, j, inside);
             if (active) obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);  // :2824 (one v_med3; fl is finite)
         };
-        for (unsigned rb = 0; rb < newlen; rb += 64, q0 += P.fdq, rem += P.fdr) {
+        // (the turn-downs of a GROUP are redone behind the group; noting them per block — a bit per row — and redoing them behind all the rows
+        // measured 7 % more VALU instructions, not fewer: 1.81 G against 1.68 G per launch of config 3a)
+        [[maybe_unused]] auto group = [&](unsigned rb, unsigned gq) {   // PH clean rows from output rb (a multiple of 64 PH), table entries from gq on
+            unsigned need = 0;
+            OUT_T *const ob = obase + (rb + lane);      // one 64-bit address per group: the rows' stores are immediate offsets from it
+#pragma unroll
+            for (int i = 0; i < NPH; i++) {
+                const float *tp = sm + (qo[i] + gq);   // s1 = floor(x) - 1
+                const float p1 = tp[0], p2 = tp[1];
+                float v;
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fmaf(p2 - p1, pw[i].x, p1);
+                else {
+                    const float p0 = tp[-1], p3 = tp[2];
+                    v = __builtin_fmaf(pw[i].w, p3, __builtin_fmaf(pw[i].z, p2, __builtin_fmaf(pw[i].y, p1, pw[i].x * p0)));
+                }
+                asm volatile("" : "+v"(v));   // rows stay scalar: paired into v_pk_fma_f32 they cost a dozen v_mov per pair to line the operands up
+                const float fl = floorf(v);
+                const float fr = v - fl;
+                const bool accept = fr > 1e-3f && fr < 1 - 1e-3f;
+                need |= accept ? 0u : 1u << i;
+                ob[64 * i] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
+            }
+            if (__any(need != 0)) {
+                while (need) {
+                    const int i = __builtin_ctz(need);
+                    need &= need - 1;
+                    const unsigned j = rb + 64 * i + lane, n = j * P.fa;
+                    const unsigned q = __umulhi(n, P.fmagic);
+                    const float fl = slow((int)q + 1, n - q * P.fb, j, true);
+                    obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
+                }
+            }
+        };
+        unsigned gq = 0, gnext = 0;   // the next group boundary (output index) and its table offset
+        for (unsigned rb = 0; rb < newlen;) {
+            if constexpr (PH > 0) {
+                if (rb == gnext) {
+                    if (rb >= mid_lo && rb + 64 * PH <= mid_end) {
+                        group(rb, gq);
+                        rb += 64 * PH; q0 += P.qstep;          // 64 PH fa = qstep fb exactly: rem stays
+                        gnext = rb; gq += P.qstep;
+                        continue;
+                    }
+                    gnext += 64 * PH; gq += P.qstep;
+                }
+            }
             if (rb >= mid_lo && rb + 64 <= mid_end) row(rb, std::true_type{}); else row(rb, std::false_type{});
+            rb += 64; q0 += P.fdq; rem += P.fdr;
         }
         __builtin_amdgcn_wave_barrier();  // the next block's decode overwrites the table
     }
@@ -968,6 +1032,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 P.fast = 1; P.fa = (unsigned)fa; P.fb = (unsigned)fb; P.fmagic = (unsigned)((4294967296ull + fb - 1) / fb); P.inv_fb = 1.0 / (double)fb;
                 P.fdq = (unsigned)((64ull * fa) / fb); P.fdr = (unsigned)((64ull * fa) % fb);
                 P.mid_lo = (unsigned)(((((3ull * fb + fa - 1) / fa) + 63) / 64) * 64);
+                P.qstep = 0;
                 {   // a full block: 1024 table entries (the junk word included), newlen_full outputs
                     const unsigned long long jm = ((1024ull - 3) * fb) / fa, lim = std::min<unsigned long long>(jm, P.newlen_full);
                     P.mid_end_full = P.newlen_full >= 64 ? (unsigned)(lim & ~63ull) : 0u;
@@ -1003,8 +1068,19 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 lap("tables");
                 if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
                 const float *wgp = reinterpret_cast<const float *>(ctx->tmp_buf3.p);
-                if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_LINEAR, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); else hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_CUBIC, signed char>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); }
-                else { if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_LINEAR, double>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); else hipLaunchKernelGGL((k_ima_stream_f32<AUKIT_INTERP_CUBIC, double>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); }
+                // the phases in registers when a lane meets 3 or 5 of them (fb = 3 · 2^i or 5 · 2^i, i <= 6: 22 050 and 44 100 Hz have 5)
+                unsigned g64 = P.fb, h64 = 64;
+                while (h64) { const unsigned r = g64 % h64; g64 = h64; h64 = r; }
+                unsigned ph = P.fb / g64;
+                const char *er = getenv("AUKIT_IMA_REGS");
+                if ((ph != 3 && ph != 5) || (er && atoi(er) == 0)) ph = 0;
+                P.qstep = ph ? (unsigned)((64ull * ph * P.fa) / P.fb) : 0u;
+#define AUKIT_IMA_F32(I, T) do { if (ph == 5) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
+                                 else if (ph == 3) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 3>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
+                                 else hipLaunchKernelGGL((k_ima_stream_f32<I, T, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); } while (0)
+                if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_IMA_F32(AUKIT_INTERP_LINEAR, signed char); else AUKIT_IMA_F32(AUKIT_INTERP_CUBIC, signed char); }
+                else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_IMA_F32(AUKIT_INTERP_LINEAR, double); else AUKIT_IMA_F32(AUKIT_INTERP_CUBIC, double); }
+#undef AUKIT_IMA_F32
                 if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_ima_stream_f32 launch failed"); }
                 uint64_t out_elems = 0;
                 for (uint64_t l : lens) out_elems += l * nd;
