@@ -12,6 +12,9 @@
 //     after the rounding to f32 (monotone, representable bounds).
 // Against the oracle: ≤ one f32 ulp (tests/test_gpu_wave_f64.py).  Write-dominated: 4.17 B per output.
 #include <algorithm>
+// tiles of 960 outputs in this translation unit (15 rows): a multiple of lcm(64, b) for b = 2^i, 3 · 2^i, 5 · 2^i (i <= 6), so that a tile starts at phase 0
+// and a lane meets at most five phases (the PH > 0 instantiations: 8 → 48 kHz has b = 6, PH = 3)
+#define AUKIT_WT 960
 #include "fast_wave_dev.h"
 
 namespace aukit {
@@ -25,8 +28,10 @@ struct CoefRow {   // (c3, c2), (c1, p1) of one source sample, read from LDS by 
     template <int K> AUKIT_DEV void wait() { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(K)); }
 };
 
-template <int INTERP>
-__global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, const FastParams F, const unsigned ccap, const double inv_b) {
+// PH > 0: the phases in registers (as k_wave_f64_reg, wave_f64.hip) — fx and the coefficient entry's offset of rows r, r + PH, … are per-lane constants
+// of the launch; a row is its two table reads, three FMAs, the rounding and the clamp.  Same operations on the same values as the generic rows.
+template <int INTERP, int PH>
+__global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, const FastParams F, const unsigned ccap, const double inv_b, const unsigned qstep) {
     extern __shared__ double smd[];
     constexpr int SRC = SRC_G711_MONO;
     constexpr int HL = INTERP == AUKIT_INTERP_CUBIC ? 1 : 0, HR = INTERP == AUKIT_INTERP_CUBIC ? 2 : 1;
@@ -41,6 +46,18 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
 
     unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
     if (t >= P.n_tiles) return;
+    constexpr int NPH = PH > 0 ? PH : 1;
+    [[maybe_unused]] double fxp[NPH];
+    [[maybe_unused]] unsigned qo[NPH];
+    if constexpr (PH > 0) {
+#pragma unroll
+        for (int p = 0; p < PH; p++) {
+            const unsigned n = (unsigned)(64 * p + lane) * F.a;
+            const unsigned q = __umulhi(n, F.magic), rem = n - q * F.b;
+            fxp[p] = (double)rem * inv_b;
+            qo[p] = q;
+        }
+    }
     uint4 pre[1];
     unsigned pre1 = 0;
     auto load_window = [&](const WaveTile &w) {
@@ -116,7 +133,32 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
         // are the tile-before's).
         const bool full = cur.cnt == (unsigned)WT;  // wave-uniform
         float res[WT / 64];
-        if (full) {
+        if (full && PH > 0) {
+            if constexpr (INTERP == AUKIT_INTERP_CUBIC) {
+                const unsigned cf0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)cf;
+                CoefRow nx;
+                nx.issue(cf0 + 32u * qo[0]);
+#pragma unroll
+                for (int r = 0; r < WT / 64; r++) {
+                    CoefRow c = nx;
+                    if (r + 1 < WT / 64) {
+                        nx.issue(cf0 + 32u * (qo[(r + 1) % NPH] + (unsigned)((r + 1) / NPH) * qstep));
+                        c.template wait<2>();
+                    } else {
+                        c.template wait<0>();
+                    }
+                    const double fx = fxp[r % NPH];
+                    const double v = __builtin_fma(__builtin_fma(__builtin_fma(c.a.x, fx, c.a.y), fx, c.b.x), fx, c.b.y);
+                    res[r] = __builtin_amdgcn_fmed3f((float)v, -1.0f, 1.0f);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < WT / 64; r++) {
+                    const double2 c = *reinterpret_cast<const double2 *>(cf + 2 * (qo[r % NPH] + (unsigned)(r / NPH) * qstep));
+                    res[r] = __builtin_amdgcn_fmed3f((float)__builtin_fma(c.x, fxp[r % NPH], c.y), -1.0f, 1.0f);
+                }
+            }
+        } else if (full) {
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
@@ -160,8 +202,9 @@ __global__ __launch_bounds__(256) void k_wave_coef_f64(const ResampleParams P, c
             for (int r = 0; r < WT / 64; r++) res[r] = 0.f;
         }
         // ---- the next tile's dword has landed (on the straight path, as in k_wave_f64: inside the branches hipcc finds a way around it)
-        asm volatile("" : "+v"(pre1), "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]));
-        asm volatile("" : "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
+        asm volatile("" : "+v"(pre1));
+#pragma unroll
+        for (int r = 0; r < WT / 64; r++) asm volatile("" : "+v"(res[r]));
         unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
         asm volatile("" : "+s"(full2));  // opaque: or jump threading fuses the two `if (full)` and the wait is back inside the branches
         if (full2) {
@@ -208,13 +251,24 @@ bool wave_coef_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate
     const unsigned ccap = (unsigned)((win + 3) & ~3);
     const int cw = interp == AUKIT_INTERP_CUBIC ? 4 : 2;
     const size_t lds = ((size_t)F.cap / 2 + (size_t)ccap * cw) * 8 * 4;
+    // the phases in registers: a lane meets PH = b / gcd(b, 64) <= 5 phases and every tile starts at phase 0
+    unsigned g64 = F.b, h64 = 64;
+    while (h64) { const unsigned r = g64 % h64; g64 = h64; h64 = r; }
+    unsigned ph = F.b / g64;
+    const char *er = getenv("AUKIT_COEF_REGS");
+    if (F.wd != 0 || (ph != 1 && ph != 3 && ph != 5) || (WT / 64) % (int)ph != 0 || (er && atoi(er) == 0)) ph = 0;
+    const unsigned qstep = ph ? (unsigned)((64ull * ph * F.a) / F.b) : 0u;
     unsigned per_cu = 64;   // workgroups per CU in the grid (6 are resident); 6 / 12 / 16 / 24 / 32 / 64 / 128 measured 1.83 / 1.82 / 1.77 / 1.74 / 1.74 / 1.72 / 1.76 ms on config 2a
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const double inv_b = 1.0 / (double)F.b;
-    if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_wave_coef_f64<AUKIT_INTERP_LINEAR>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b);
-    else hipLaunchKernelGGL((k_wave_coef_f64<AUKIT_INTERP_CUBIC>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b);
+#define AUKIT_WC(I) do { if (ph == 1) hipLaunchKernelGGL((k_wave_coef_f64<I, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b, qstep); \
+                         else if (ph == 3) hipLaunchKernelGGL((k_wave_coef_f64<I, 3>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b, qstep); \
+                         else if (ph == 5) hipLaunchKernelGGL((k_wave_coef_f64<I, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b, qstep); \
+                         else hipLaunchKernelGGL((k_wave_coef_f64<I, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, inv_b, qstep); } while (0)
+    if (interp == AUKIT_INTERP_LINEAR) AUKIT_WC(AUKIT_INTERP_LINEAR); else AUKIT_WC(AUKIT_INTERP_CUBIC);
+#undef AUKIT_WC
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_wave_coef_f64 launch failed"); return true; }
     static thread_local char nm[96];
     snprintf(nm, sizeof nm, "k_wave_coef_f64<g711_mono,%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic");
