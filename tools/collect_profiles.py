@@ -16,9 +16,9 @@ for f in sorted(glob.glob(os.path.join(src, "r1_*.csv")) + glob.glob(os.path.joi
 shutil.copy(os.path.join(root, "gpurun_out", "bench_lines.jsonl"), os.path.join(dst, "r%s_bench_lines.jsonl" % rnd))
 
 # kernel name as bench.py reports it (ctx.last_kernel) -> (tag, substring of the rocprofv3 kernel name)
-DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table>", "wavef64", "k_wave_f64<", 4096),
+DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile640,phase_regs>", "wavef64", "k_wave_f64", 4096),
             ("k_fast_wave<pcm_s16le_mono,cubic,nv2>", "fastwave", "k_fast_wave<", 4096),
-            ("k_wave_f64<pcm_s16le_mono,cubic,tile512,nv1,phase_table,stream_pcm>", "pcmstream", "k_wave_f64<", 4096),
+            ("k_wave_f64<pcm_s16le_mono,cubic,tile640,phase_regs,stream_pcm>", "pcmstream", "k_wave_f64", 4096),
             ("k_wave_coef_f64<g711_mono,cubic>", "g711cubic", "k_wave_coef_f64<", 4096),
             ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<", 2048),
             ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<", 4096),
