@@ -303,7 +303,7 @@ def test_stream_adpcm_bit_exact(ctx, oracle, interp, ch, mono, ba):
 
 
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
-@pytest.mark.parametrize("rate", [48000, 24000, 16000, 44100])
+@pytest.mark.parametrize("rate", [48000, 24000, 16000, 44100, 32000, 8000])
 def test_stream_adpcm_other_rates_bit_exact(ctx, oracle, rate, interp):
     """stream.adpcm on mono files at 48 kHz (equal rates: every position an integer — the three-tier kernel runs them as 2a / 2), at
     integer ratios and at 44.1 kHz: floored outputs bit for bit the oracle's, random-byte blocks (saturated predictors) included."""

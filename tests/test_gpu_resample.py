@@ -501,7 +501,7 @@ def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):
 
 
 @pytest.mark.parametrize("alaw", [False, True])
-@pytest.mark.parametrize("rate", [8000, 11025, 16000, 22050, 44100])
+@pytest.mark.parametrize("rate", [8000, 11025, 16000, 22050, 44100, 6000, 9600, 7200])   # the last three: one and five phases per lane in registers (8000: three)
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
 def test_stream_g711_guarded_wave_kernel(ctx, oracle, interp, rate, alaw):
     """Mono stream.g711 takes the guarded short-cut kernel (floor_wave.hip): every output equal to the oracle's and to the
