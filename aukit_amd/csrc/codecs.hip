@@ -594,7 +594,7 @@ struct CvImaF32 {
 //      in a kernel that is bound by its VALU instructions).  An entry is within 2^-23 relative of the sample (3.1e-5 at the largest magnitude,
 //      258); the weights of the output's phase come from an LDS table (computed in fp64 on the host, rounded once; the position itself is
 //      exact); one multiply and three FMAs round at magnitudes below 512 (3e-5 each): < 2.5e-4 in all — the bound k_ms_wave's mono path
-//      lives by.  Taken when the value lies more than 1e-3 away from an integer.
+//      lives by.  Taken when the value lies more than 5e-4 (TIER1_GUARD; 1e-3 until late round 3) away from an integer.
 //   2. (about one output in 500) the polynomial in fp64 on exact doubles and the exact rational position, FMA Horner form, taken
 //      when more than 1e-6 away from an integer (the reference's x carries < 1024 · 2^-53 of rounding, times a slope below 1600).
 //   3. otherwise, and where the nil fall-backs of the block's ends apply: the reference-order code on the same table.
@@ -603,6 +603,13 @@ struct CvImaF32 {
 // share their phases, so a lane keeps the weights and the first-tap offsets of its PH phases for the whole launch; the clean rows of a block then run
 // in groups of PH rows without position arithmetic, the guard's turn-downs noted in a bit each and redone behind the group by one copy of tiers 2-3.
 // Same f32 operations on the same values as the generic rows: the same tier decisions, bit for bit.
+// tier 1's guard: its error is below 2.5e-4 (entries 5.3e-5, four roundings below 512: 9.3e-5 — 1.5e-4 by the count above, 2.5e-4 with slack); 1e-3 until late
+// round 3.  The turn-downs cost this kernel a sixth of its instructions; 5e-4 halves them and keeps a factor of two over the bound.
+#ifndef AUKIT_IMA_TIER1_GUARD
+#define AUKIT_IMA_TIER1_GUARD 5e-4f
+#endif
+constexpr float TIER1_GUARD = AUKIT_IMA_TIER1_GUARD;
+
 template <int INTERP, typename OUT_T, int PH>
 __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P, const float *__restrict__ wg) {
     extern __shared__ float smf[];
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             }
             float fl = floorf(v);
             const float fr = v - fl;
-            const bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
+            const bool accept = inside && fr > TIER1_GUARD && fr < 1 - TIER1_GUARD;
             if (active && !accept) fl = slow(k, rem, j, inside);
             if (active) obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);  // :2824 (one v_med3; fl is finite)
         };
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
                 asm volatile("" : "+v"(v));   // rows stay scalar: paired into v_pk_fma_f32 they cost a dozen v_mov per pair to line the operands up
                 const float fl = floorf(v);
                 const float fr = v - fl;
-                const bool accept = fr > 1e-3f && fr < 1 - 1e-3f;
+                const bool accept = fr > TIER1_GUARD && fr < 1 - TIER1_GUARD;
                 need |= accept ? 0u : 1u << i;
                 ob[64 * i] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
             }

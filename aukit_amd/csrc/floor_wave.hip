@@ -6,7 +6,8 @@
 //   1. f32, straight-line for the whole wave.  G.711 samples are multiples of 1/64 up to 126 in magnitude (m / 0x40, :2891), so
 //      they and the spline coefficients (multiples of 1/128 below 1400) are exact in f32; the three Horner FMAs round at
 //      magnitudes below 2048 (half an ulp = 6.1e-5 each) and the position fraction is good to one ulp (4.5e-5 after the slope of
-//      < 750): the f32 value is within 2.3e-4 of the exact one and is taken when it lies more than 1e-3 away from an integer.
+//      < 750): the f32 value is within 2.3e-4 of the exact one and is taken when it lies more than 5e-4 away from an integer
+//      (TIER1_GUARD below; 1e-3 until late round 3).
 //   2. (about one output in 500) the same polynomial in fp64 with exact rational positions and FMA Horner form, taken when more
 //      than 1e-6 away from an integer.  Margin: the reference's x = (i-1)/ratio + 1 carries at most 48000 * 2^-53 = 5.3e-12 of
 //      rounding error, the spline's slope is below 3 * 1004 (samples are < 512 in magnitude), so the two values differ by
@@ -30,6 +31,14 @@
 #include "resample_dev.h"
 
 namespace aukit {
+
+// How far from an integer tier 1's f32 value must lie to be taken.  Its error is below 2.3e-4 (header); 1e-3 was the guard of rounds 1-2 and early round 3.
+// The turned-down outputs are what a quarter of this kernel's instructions were spent on after the phases went into registers (one output in
+// 500 at 1e-3, and a tile of 960 outputs has one more often than not): 5e-4 halves them and keeps a factor of two over the bound.
+#ifndef AUKIT_TIER1_GUARD
+#define AUKIT_TIER1_GUARD 5e-4f
+#endif
+constexpr float TIER1_GUARD = AUKIT_TIER1_GUARD;
 
 AUKIT_DEV void store_floor(signed char *p, float v) { *p = (signed char)(int)v; }
 AUKIT_DEV void store_floor(double *p, float v) { *p = (double)v; }
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             // (as plain boolean algebra — the masks stay in scalar registers; written `rem == 0 ? int_ratio : guard` hipcc built the choice out
             // of six VALU instructions per row, in a kernel that is bound by exactly those.  At rem == 0 without an integer ratio the guard
             // may answer as well: the reference returns p1 itself or, where its x rounds just below the integer, a value within 1e-9 of it.)
-            const bool guard = fr > 1e-3f && fr < 1 - 1e-3f;
+            const bool guard = fr > TIER1_GUARD && fr < 1 - TIER1_GUARD;
             const bool accept = guard || (int_ratio && rem == 0);
             if (active && !accept) fl = slow(q, rem, j);  // about one wave row in eight has such a lane
             if (active) store_floor(orow + j, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));  // :2909 (one v_med3; fl is never a nan: the window holds finite samples)
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
                 }
                 const float fl = floorf(w);
                 const float fr = w - fl;
-                const bool guard = fr > 1e-3f && fr < 1 - 1e-3f;
+                const bool guard = fr > TIER1_GUARD && fr < 1 - TIER1_GUARD;
                 const bool accept = guard || acc0[p];
                 need |= accept ? 0u : 1u << r;
                 store_floor(orow + r * 64 + lane, __builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f));

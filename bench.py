@@ -610,9 +610,12 @@ def main(argv=None):
 
     # untimed pre-warm (half a second of steps) so that the timed region never starts on a GPU that is still leaving its idle
     # power state; then the W warm-up steps
+    # (steps queued eight at a time: with a sync behind every step the GPU idles between them and a short, instruction-bound step — stream.g711,
+    # 1.5 ms — started its timed region 10-25 % below the clocks it reaches under back-to-back launches; the later windows showed the difference)
     t_pre = time.perf_counter()
     while not selftest and time.perf_counter() - t_pre < args.prewarm:
-        wl.step()
+        for _ in range(8):
+            wl.step()
         sync()
     for _ in range(args.warmup):
         wl.step()
