@@ -32,11 +32,12 @@ __global__ __launch_bounds__(256) void k_fast_wave_coef(const ResampleParams P, 
         if constexpr (DW) {
             const unsigned char *vb = w.al + 16 * (size_t)(lane >> 2);  // same rule as issue_loads: a vector that straddles the allocation reads as zero
             pre1 = 0;
-            if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *reinterpret_cast<const unsigned *>(w.al + 4 * (size_t)lane);
+            if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *(const __attribute__((address_space(1))) unsigned *)(w.al + 4 * (size_t)lane);   // a global load (a generic dereference is a flat load)
         } else issue_loads<NV>(P, w, lane, pre);
     };
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);
     load_window(cur);
+    if constexpr (DW) asm volatile("" : "+v"(pre1)); else pre_landed<NV>(pre);   // waited for on every edge into the loop (fast_wave_dev.h)
     for (;;) {
         if constexpr (DW) {
             static_assert(!DW || SRC == SRC_G711_MONO, "dword staging is for one-byte samples");
@@ -99,19 +100,34 @@ __global__ __launch_bounds__(256) void k_fast_wave_coef(const ResampleParams P, 
             (void)p1;
             return __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);  // rem == 0 → fx == 0 → v == p1 exactly, and |p1| <= 1 for these sources (aukit.lua:666-668)
         };
-        if (cur.cnt == (unsigned)WT) {
+        // the rows wait in registers until the next tile's loads have been waited for, then they are stored (fast_wave_dev.h, "Where the wave waits";
+        // same-box A/B in DESIGN.md §3.7: k_wave_coef_f64, this kernel's fp64 sibling, gained 4 % from exactly this)
+        const bool full = cur.cnt == (unsigned)WT;  // wave-uniform
+        float res[WT / 64];
+        if (full) {
             const unsigned n0 = cur.r0 + lane_a;
             unsigned q = __umulhi(n0, F.magic);
             unsigned rem = n0 - q * F.b;
 #pragma unroll
             for (int r = 0; r < WT / 64; r++) {
-                orow[r * 64 + lane] = eval(q, rem);
+                res[r] = eval(q, rem);
                 rem += F.dr64;
                 q += F.dq64;
                 const bool wrap = rem >= F.b;
                 rem -= wrap ? F.b : 0u;
                 q += wrap ? 1u : 0u;
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) res[r] = 0.f;
+        }
+        if constexpr (DW) asm volatile("" : "+v"(pre1)); else pre_landed<NV>(pre);
+        hold_results(res);
+        unsigned full2 = __builtin_amdgcn_readfirstlane((unsigned)full);
+        asm volatile("" : "+s"(full2));  // opaque: or jump threading fuses the two `if (full)` and the wait is back inside the branches
+        if (full2) {
+#pragma unroll
+            for (int r = 0; r < WT / 64; r++) orow[r * 64 + lane] = res[r];
         } else {
             for (unsigned rb = 0; rb < cur.cnt; rb += 64) {
                 const unsigned j = rb + lane;
