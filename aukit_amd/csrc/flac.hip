@@ -384,8 +384,19 @@ template <typename R> struct ExtractArgs {
 };
 
 // decodeFrame (:510-557) without prediction: header, per-subframe warm-up / residual values → scratch, predictor → SubDesc.
+#ifdef AUKIT_FLAC_EXTRACT_WAVES
+#define AUKIT_EXTRACT_OCC __attribute__((amdgpu_waves_per_eu(AUKIT_FLAC_EXTRACT_WAVES, 8)))
+#else
+#define AUKIT_EXTRACT_OCC
+#endif
+#ifndef AUKIT_FLAC_EXTRACT_WGS
+#define AUKIT_FLAC_EXTRACT_WGS 8   // workgroups per CU in k_flac_extract's persistent grid
+#endif
+#ifndef AUKIT_FLAC_NOPF
+#define AUKIT_FLAC_NOPF 0   // 1: no register prefetch of the window lines (48 VGPRs less: A/B for a third wave per SIMD)
+#endif
 template <typename R>
-__global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
+__global__ __launch_bounds__(64) AUKIT_EXTRACT_OCC void k_flac_extract(const ExtractArgs<R> A) {
     __shared__ unsigned s_win[64 * WSTR];
     __shared__ R s_out[64 * OSTRX];
     __shared__ u64 s_ptr[64];
@@ -517,17 +528,19 @@ __global__ __launch_bounds__(64) void k_flac_extract(const ExtractArgs<R> A) {
                         // the line that follows a slot's line into the slot (eight lines on) was requested when that one arrived: a round ago or
                         // more, so it is here — unless the lane is new or jumped, then it is fetched now
                         uint4 v = pf[i];
-                        if (pf_line[i] != line) {
+                        if (AUKIT_FLAC_NOPF || pf_line[i] != line) {
                             v = make_uint4(0, 0, 0, 0);
                             if (2 * line < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
                         }
                         unsigned *wrow = s_win + s * WSTR + 4 * sub8;
                         wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
                         wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
-                        const u64 nl = line + LPW;
-                        pf_line[i] = nl;
-                        pf[i] = make_uint4(0, 0, 0, 0);
-                        if (2 * nl < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * nl);
+                        if (!AUKIT_FLAC_NOPF) {
+                            const u64 nl = line + LPW;
+                            pf_line[i] = nl;
+                            pf[i] = make_uint4(0, 0, 0, 0);
+                            if (2 * nl < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * nl);
+                        }
                     }
                 }
             }
@@ -1398,7 +1411,7 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             A.ticket = &d_cnt->ticket;
             AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->ticket, 0, 4, ctx->stream));
             // lanes pull candidates off the ticket counter: as many workgroups as the chip holds at once (17.6 KB of LDS each: 9 per CU)
-            const unsigned grid = std::min<unsigned>((count + 63) / 64, (unsigned)ctx->num_cus * 8u);
+            const unsigned grid = std::min<unsigned>((count + 63) / 64, (unsigned)ctx->num_cus * (unsigned)AUKIT_FLAC_EXTRACT_WGS);
             hipLaunchKernelGGL((k_flac_extract<R>), dim3(grid), dim3(64), 0, ctx->stream, A);
             AUKIT_HIP_CHECK(hipGetLastError());
             return AUKIT_OK;
