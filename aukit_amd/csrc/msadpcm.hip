@@ -26,6 +26,12 @@
 
 namespace aukit {
 
+// tier 1's guard (k_ms_wave): its error is below 3e-4 (see tier1 below); 1e-3 until late round 3, 6e-4 keeps a factor of two (cf. floor_wave.hip, codecs.hip)
+#ifndef AUKIT_MS_TIER1_GUARD
+#define AUKIT_MS_TIER1_GUARD 6e-4f
+#endif
+constexpr float MS_TIER1_GUARD = AUKIT_MS_TIER1_GUARD;
+
 int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len,
                         uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
                         double norm_neg, aukit_audio **out);
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                 auto put = [&](float v, float spread, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
                     float fl = floorf(v);
                     const float fr = v - fl;
-                    bool accept = inside && fr > 1e-3f && fr < 1 - 1e-3f;
+                    bool accept = inside && fr > MS_TIER1_GUARD && fr < 1 - MS_TIER1_GUARD;
                     if constexpr (FLOORED) { if (INTERP == AUKIT_INTERP_NONE || P.unit) accept = inside; }   // the entry itself (or l + r / 2 of two entries): exact
                     // Equal taps: the difference forms of tier 1 return the entry itself (or l + r / 2), and an f32 entry that is an integer IS the
                     // reference's value (an entry is the predictor times 1/128 — exact — or times RN(1/127): integral only for multiples of 127,

@@ -612,11 +612,17 @@ def main(argv=None):
     # power state; then the W warm-up steps
     # (steps queued eight at a time: with a sync behind every step the GPU idles between them and a short, instruction-bound step — stream.g711,
     # 1.5 ms — started its timed region 10-25 % below the clocks it reaches under back-to-back launches; the later windows showed the difference)
+    # ... and a batch of a small workload (1024 streams: a step of 2 ms that does not fill the chip) needed more than eight steps in the queue: the
+    # batches are sized to ~100 ms of queued work from the time of the first one.
     t_pre = time.perf_counter()
+    per_sync = 8
     while not selftest and time.perf_counter() - t_pre < args.prewarm:
-        for _ in range(8):
+        t_b = time.perf_counter()
+        for _ in range(per_sync):
             wl.step()
         sync()
+        dt_b = max(time.perf_counter() - t_b, 1e-6)
+        per_sync = int(min(256, max(8, per_sync * 0.1 / dt_b)))
     for _ in range(args.warmup):
         wl.step()
     dt, ev_ms, n_launch, alg_total = timed_window()  # THE measurement: exactly K steps
