@@ -121,7 +121,10 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     if (const char *e = getenv("AUKIT_NT_STORE")) P.nt_store = atoi(e);
     if (src_kind == SRC_I32) F.scale_pos = F.scale_neg = (float)(1.0 / P.norm_pos);  // a power of two (checked by fast_try)
     size_t lds = (size_t)F.cap * 4 * 4 + (P.nt_store == 2 ? 4 * 256 * 4 : 0);  // 4 wave windows (+ 4 × 1 KiB of store-transpose staging in the x4 experiment)
-    unsigned per_cu = 16;  // 2x the resident workgroups: measured +3.5 % over 8 (better tail balance across XCDs)
+    // workgroups per CU in the grid (a finer hand-out of the tiles than the resident count): 16 / 32 / 64 / 128 measured 2.010 / 1.958 / 1.891 / 1.868 ms on
+    // config T in f32 arithmetic, 1.605 / 1.601 / 1.579 / 1.508 on config 2a in f32, 2.195 / 2.154 / 2.125 / 2.112 on stream.pcm (f32); the interleaved-stereo
+    // kernels are best at 16 (2.03 against 2.10-2.19)
+    unsigned per_cu = src_kind == SRC_PCM_S16LE_STEREO ? 16 : 128;
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     unsigned nblk_needed = (P.n_tiles + 3) / 4;
     unsigned grid = std::min<unsigned>(nblk_needed, (unsigned)ctx->num_cus * std::max(per_cu, 1u));
@@ -158,7 +161,9 @@ int launch_fast_wave(aukit_ctx *ctx, int src_kind, int interp, const std::vector
     }
     if (F.b >= 2 * F.a && nv <= 2 && (src_kind == SRC_PCM_S16LE_MONO || src_kind == SRC_G711_MONO) && !getenv("AUKIT_FAST_NOCOEF")) {
         // up-sampling by 2x and more: per-source-sample coefficient table (fast_coef.hip)
-        if ((rc = launch_fast_wave_coef(ctx, src_kind, interp, nv, win, P, F, grid))) return rc;
+        // (the write-dominated coefficient-table kernel wants a finer hand-out still: 128 / 256 / 512 / 1024 workgroups per CU measured 1.52 / 1.46 / 1.36-1.38 / 1.42 ms on config 2a in f32)
+        const unsigned gridc = getenv("AUKIT_FAST_BLOCKS_PER_CU") ? grid : std::min<unsigned>(nblk_needed, (unsigned)ctx->num_cus * 512u);
+        if ((rc = launch_fast_wave_coef(ctx, src_kind, interp, nv, win, P, F, gridc))) return rc;
         static thread_local char nmc[96];
         snprintf(nmc, sizeof nmc, "k_fast_wave_coef<%s,%s,nv%d>", src_kind == SRC_PCM_S16LE_MONO ? "pcm_s16le_mono" : "g711_mono", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic", nv);
         return ctx_end_kernel(ctx, nmc, algorithmic_bytes);

@@ -311,7 +311,9 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     if ((*rc = plan_tiles_sized(ctx, segs, WT, P))) return true;
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
     const size_t lds = ((size_t)F.cap + (size_t)ccap * (interp == AUKIT_INTERP_CUBIC ? 4 : 2)) * 4 * 4;  // per wave: window + coefficient table
-    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 8);
+    unsigned per_cu = 64;   // workgroups per CU in the grid (five are resident): 4 / 5 / 8 / 16 / 32 / 64 / 128 measured 1.65 / 1.55 / 1.52 / 1.43 / 1.38 / 1.35 / 1.36 ms on config 2b
+    if (const char *e = getenv("AUKIT_FLOOR_PER_CU")) { const int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }   // tuning knob
+    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     // the phases in registers: tiles start at phase 0 and a lane meets PH = b / gcd(b, 64) <= 5 phases
     unsigned g64 = F.b, h64 = 64;
     while (h64) { const unsigned r = g64 % h64; g64 = h64; h64 = r; }

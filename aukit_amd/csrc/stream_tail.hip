@@ -403,7 +403,8 @@ bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows,
         P.fa = (unsigned)S.fa; P.fb = (unsigned)S.fb; P.fmagic = (unsigned)((4294967296ull + S.fb - 1) / S.fb);
         P.dq256 = (unsigned)((64ull * S.fa) / S.fb); P.dr256 = (unsigned)((64ull * S.fa) % S.fb);   // the step of one row of a wave tile (64 outputs)
     }
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / S.lds));
+    unsigned per_cu = 64;   // workgroups per CU in the grid (what the LDS lets stay resident is fewer: a finer hand-out of the tiles): 8 / 16 / 32 / 64 / 128 / 256 measured 3.51 / 3.42 / 3.40 / 3.37 / 3.46 / 3.55 ms on stream.qoa
+    if (const char *e = getenv("AUKIT_TAIL_PER_CU")) { const int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }   // tuning knob
     const unsigned grid = (unsigned)std::min<uint64_t>(S.fast ? (P.n_tiles + 3) / 4 : P.n_tiles, (uint64_t)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t lds = S.lds;

@@ -258,7 +258,7 @@ bool wave_coef_f64_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate
     const char *er = getenv("AUKIT_COEF_REGS");
     if (F.wd != 0 || (ph != 1 && ph != 3 && ph != 5) || (WT / 64) % (int)ph != 0 || (er && atoi(er) == 0)) ph = 0;
     const unsigned qstep = ph ? (unsigned)((64ull * ph * F.a) / F.b) : 0u;
-    unsigned per_cu = 64;   // workgroups per CU in the grid (6 are resident); 6 / 12 / 16 / 24 / 32 / 64 / 128 measured 1.83 / 1.82 / 1.77 / 1.74 / 1.74 / 1.72 / 1.76 ms on config 2a
+    unsigned per_cu = 512;   // workgroups per CU in the grid (six are resident): 64 / 128 / 256 / 512 / 1024 / 2048 measured 1.573 / 1.550 / 1.541 / 1.473 / 1.581 / 1.771 ms on config 2a (a wave then takes 3-4 tiles: the hardware's dispatcher balances better than the static tile stride)
     if (const char *e = getenv("AUKIT_FAST_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }
     const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
