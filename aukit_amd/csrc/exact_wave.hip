@@ -220,7 +220,9 @@ bool exact_wave_try(aukit_ctx *ctx, int src_kind, int interp, double old_rate, d
     P.halo_l = hl; P.halo_r = hr; P.sinc_w = ctx->sinc_w;
     if ((*rc = plan_tiles_sized(ctx, segs, WT, P))) return true;
     if (P.n_tiles == 0) { *rc = AUKIT_OK; return true; }
-    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * 16);
+    unsigned per_cu = 128;   // workgroups per CU in the grid: 16 / 32 / 64 / 128 / 256 measured 5.24 / 5.03 / 4.99 / 4.96 / 4.94 ms on config T with F64 storage
+    if (const char *e = getenv("AUKIT_EXACT_PER_CU")) { const int v = atoi(e); if (v >= 1) per_cu = (unsigned)v; }   // tuning knob
+    const unsigned grid = std::min<unsigned>((P.n_tiles + 3) / 4, (unsigned)ctx->num_cus * per_cu);
     if ((*rc = ctx_begin_kernel(ctx))) return true;
 #define AUKIT_EW(S, I) do { if (dtype == AUKIT_F64) launch_exact_nv<S, I, double>(nv, P, F, lds, grid, ctx->stream); else launch_exact_nv<S, I, float>(nv, P, F, lds, grid, ctx->stream); } while (0)
     if (epi) {
