@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "resample.h"
 #include "stream_tail.h"
+#include "flac_dev.h"
 
 namespace aukit {
 
@@ -31,24 +32,6 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         uint32_t n, int channels, double rate, double new_rate, int interp, bool do_resample, int dtype, double norm_pos,
                         double norm_neg, aukit_audio **out);
 
-typedef unsigned long long u64;
-
-enum FlacErr { FE_OK = 0, FE_EOF_START = 1 /* readByte() == nil at a frame start: clean end */, FE_NIL = 2, FE_SYNC = 3, FE_BLOCKSIZE = 4,
-               FE_CHAN = 5, FE_SUBTYPE = 6, FE_RESMETHOD = 7, FE_PARTITION = 8,
-               FE_LIMIT = 9 /* the candidate ran past its bit budget; extracted again without a budget if the chain needs it */ };
-static const char *flac_err_msg(int e) {
-    switch (e) {
-    case FE_NIL: return "attempt to perform arithmetic on a nil value";
-    case FE_SYNC: return "Sync code expected";
-    case FE_BLOCKSIZE: return "Reserved block size";
-    case FE_CHAN: return "Reserved channel assignment";
-    case FE_SUBTYPE: return "Reserved subframe type";
-    case FE_RESMETHOD: return "Reserved residual coding method";
-    case FE_PARTITION: return "Block size not divisible by number of Rice partitions";
-    }
-    return "FLAC decode error";
-}
-enum { FLAG_OVERFLOW = 1, FLAG_INTERNAL = 2 };
 
 #ifndef AUKIT_FLAC_WN
 #define AUKIT_FLAC_WN 16
@@ -74,16 +57,6 @@ constexpr int OSTR = 33;  // row stride of the value array
 constexpr int NCX = AUKIT_FLAC_NCX;  // values a lane extracts per round (k_flac_extract); a power of two <= 64
 constexpr int OSTRX = NCX + 1;
 
-struct FlacStreamInfo { u64 first_byte; double rate, nsamples; int channels, depth, status, pad; };
-
-struct FlacGlobals {
-    const unsigned char *src;  // batch data
-    const u64 *w0;             // 16-byte aligned base at or below src
-    u64 base_bit;              // bit offset of src relative to w0
-    u64 safe_words;            // even; 16-byte vectors [w0 + 2k, w0 + 2k + 2) with 2k < safe_words touch the batch (same page as a valid byte)
-    const u64 *off;
-    const FlacStreamInfo *info;
-};
 
 // MSB-first bit reader over [first, end) of the batch buffer.  Three big-endian 64-bit words are kept in registers
 // (current, next, next-but-one); they are refilled from the lane's LDS window, or from global memory when a field
@@ -235,29 +208,6 @@ AUKIT_DEV bool flac_header_plausible(const unsigned char *src, u64 p, u64 end, i
     return crc == src[idx];
 }
 
-struct Cand { unsigned stream; unsigned nolimit; u64 byte; };  // byte: absolute in the batch
-
-// byte position → candidate index (open addressing, linear probing; empty key = ~0)
-struct CandHash { u64 *keys; unsigned *vals; unsigned shift; u64 mask; };
-AUKIT_DEV u64 hash_slot(const CandHash &H, u64 key) { return (key * 0x9E3779B97F4A7C15ull) >> H.shift; }
-AUKIT_DEV void hash_insert(const CandHash &H, u64 key, unsigned val) {
-    u64 h = hash_slot(H, key);
-    for (;;) {
-        const u64 prev = atomicCAS(&H.keys[h], ~0ull, key);
-        if (prev == ~0ull) { H.vals[h] = val; return; }
-        if (prev == key) return;
-        h = (h + 1) & H.mask;
-    }
-}
-AUKIT_DEV unsigned hash_lookup(const CandHash &H, u64 key) {
-    u64 h = hash_slot(H, key);
-    for (;;) {
-        const u64 k = H.keys[h];
-        if (k == key) return H.vals[h];
-        if (k == ~0ull) return ~0u;
-        h = (h + 1) & H.mask;
-    }
-}
 
 // One 16-byte vector (+ the first byte of the next one) per thread and step: 16 byte positions are tested for the sync code
 // (round 1 read two bytes per thread and launched 4 M workgroups: 6 ms for 3.6 GB; this is one pass at HBM speed).
@@ -357,14 +307,6 @@ __global__ __launch_bounds__(64) void k_flac_hash_insert(const Cand *cands, unsi
     if (i < count) hash_insert(H, cands[first + i].byte, first + i);
 }
 
-struct CandInfo {
-    u64 end_byte;     // absolute byte after the frame's CRC-16
-    u64 scratch;      // element offset of subframe 0 in the scratch array; subframe c at + c * blocksize
-    u64 sample_off;   // chain: samples of the stream before this frame
-    int blocksize, chan_asgn, status, nsub;
-    unsigned seq, used;
-};
-struct SubDesc { int order, lshift, wasted, kind; short coef[32]; };  // kind: 0 = no prediction, 1/2/3 = order <= 4/12/32
 
 enum { ST_FRAME = 0, ST_SUB, ST_WARM, ST_CONST, ST_COEF, ST_PART, ST_CODES, ST_SUBEND, ST_FRAMEEND, ST_DIRECT_WAIT, ST_DONE };
 
@@ -846,7 +788,6 @@ __global__ __launch_bounds__(64) AUKIT_EXTRACT_OCC void k_flac_extract(const Ext
     }
 }
 
-struct ChainOut { u64 L, miss_at; unsigned nframes; int status; int miss_kind; unsigned miss_ci; };  // miss_kind: 1 = no candidate at miss_at, 2 = candidate miss_ci hit its bit budget
 
 // decodeFLAC's frame loop (:615): follow end → start links from the first frame
 __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned n, CandHash H, CandInfo *ci, const SubDesc *sd, int C, ChainOut *out, u64 *kind_count) {
@@ -869,7 +810,8 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
                 ci[k].sample_off = sp;
                 ci[k].seq = nf;
                 ci[k].used = 1;
-                if (C == 2) kc[4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0)] += 2;  // a stereo frame's two jobs share a wave (k_flac_jobs)
+                if (!sd) {}   // (the fused decoder, flac_fused.hip: no prediction jobs to count)
+                else if (C == 2) kc[4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0)] += 2;  // a stereo frame's two jobs share a wave (k_flac_jobs)
                 else for (int c = 0; c < f.nsub; c++) kc[4 * (sd[(size_t)k * C + c].kind & 3)]++;
                 sp += (u64)f.blocksize;
                 nf++;
@@ -889,8 +831,6 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
     for (int q = 0; q < 16; q++) if (kc[q]) atomicAdd(&kind_count[q], (u64)kc[q]);
 }
 
-struct SubJob { u64 src, dst; unsigned desc; int bs; int asgn, pad; };  // asgn: the frame's channel assignment when it decorrelates (8..10), else 0
-struct FrameRec { u64 sample_off; int bs, chan_asgn; unsigned stream, pad; };
 
 __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const CandInfo *ci, const SubDesc *sd, unsigned ncand, int C, const u64 *row_off,
                                                   const u64 *frame_base, const u64 *kind_base, u64 *kind_fill, SubJob *jobs, FrameRec *frames) {
@@ -1341,11 +1281,6 @@ struct FlacDecoded {
     uint64_t nfr = 0;
 };
 
-struct Carve {
-    size_t at = 0;
-    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
-};
-struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, ticket; };
 
 static bool g_flac_force_wide() { const char *e = getenv("AUKIT_FLAC_WIDE"); return e && atoi(e) != 0; }
 
@@ -1560,6 +1495,148 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
     }
 }
 
+// The fused decoder (flac_fused.hip): find → k_flac_decode (final integers into the scratch) → chain → k_flac_gather (scratch → rows).
+// Returns AUKIT_OK, an error, or 2 = "the chain needs a frame k_flac_decode declined": the caller runs the first design (flac_run).
+static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
+    const uint32_t n = in->n;
+    const int C = D.channels;
+    int rc;
+    const FlacStreamInfo *d_info = reinterpret_cast<const FlacStreamInfo *>(ctx->misc_buf.p);
+    const uintptr_t dptr = reinterpret_cast<uintptr_t>(in->data());
+    FlacGlobals G;
+    G.src = in->data();
+    G.w0 = reinterpret_cast<const u64 *>(dptr & ~(uintptr_t)15);
+    G.base_bit = 8 * (dptr & 15);
+    G.safe_words = (((dptr & 15) + in->total() + 15) / 16) * 2;
+    G.off = reinterpret_cast<const u64 *>(in->d_off);
+    G.info = d_info;
+    uint64_t capc = in->total() / 2048 + n + 4096;
+    uint64_t guess = 0;
+    for (uint32_t s = 0; s < n; s++) guess += (uint64_t)D.info[s].nsamples * C;
+    uint64_t scap = std::max<uint64_t>(guess + guess / 16 + 65536, ctx->tmp_buf3.cap > 256 ? (ctx->tmp_buf3.cap - 256) / 4 : 0);
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) return fail(AUKIT_E_HIP, "internal: FLAC candidate tables keep overflowing");
+        uint64_t hs = 1; unsigned hbits = 0;
+        while (hs < 2 * capc) { hs <<= 1; hbits++; }
+        Carve cv;
+        const size_t o_cnt = cv.take(sizeof(Counters)), o_chain = cv.take((size_t)n * sizeof(ChainOut)), o_cand = cv.take(capc * sizeof(Cand)),
+                     o_ci = cv.take(capc * sizeof(CandInfo)), o_keys = cv.take(hs * 8), o_vals = cv.take(hs * 4),
+                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8);
+        if ((rc = ctx->tmp_buf2.ensure(cv.at))) return rc;
+        char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+        Counters *d_cnt = reinterpret_cast<Counters *>(B + o_cnt);
+        ChainOut *d_chain = reinterpret_cast<ChainOut *>(B + o_chain);
+        Cand *d_cand = reinterpret_cast<Cand *>(B + o_cand);
+        CandInfo *d_ci = reinterpret_cast<CandInfo *>(B + o_ci);
+        CandHash H{reinterpret_cast<u64 *>(B + o_keys), reinterpret_cast<unsigned *>(B + o_vals), 64 - hbits, hs - 1};
+        u64 *d_rowoff = reinterpret_cast<u64 *>(B + o_rowoff), *d_fbase = reinterpret_cast<u64 *>(B + o_fbase);
+        AUKIT_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), ctx->stream));
+        AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, ctx->stream));
+        const uint64_t cand_room = capc - n - 64;
+        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 64)), dim3(256), 0, ctx->stream, G,
+                           (u64)in->total(), n, d_cand, cand_room, &d_cnt->ncand, H);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        Counters hc;
+        AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (hc.ncand > cand_room) { capc = hc.ncand + hc.ncand / 8 + n + 4096; continue; }
+        unsigned ncand = (unsigned)hc.ncand;
+        auto decode = [&](unsigned first, unsigned count, int limit_factor) -> int {
+            FusedArgs A;
+            A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.C = C; A.depth = D.depth;
+            A.scratch = reinterpret_cast<int *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
+            A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket;
+            return flac_fused_launch(ctx, A);
+        };
+        std::vector<ChainOut> chain(n);
+        bool restart = false;
+        for (int pass = 0;; pass++) {
+            if (pass == 0) {
+                if ((rc = ctx->tmp_buf3.ensure(scap * 4 + 256))) return rc;
+                AUKIT_HIP_CHECK(hipMemsetAsync(&d_cnt->scratch_cursor, 0, 8, ctx->stream));
+                if ((rc = ctx_begin_kernel(ctx))) return rc;
+                if ((rc = decode(0, ncand, 5))) return rc;
+                if ((rc = ctx_end_kernel(ctx, "k_flac_decode", in->total() + guess * 4))) return rc;
+            }
+            hipLaunchKernelGGL(k_flac_chain, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, G, n, H, d_ci, (const SubDesc *)nullptr, C, d_chain, d_cnt->kind_count);
+            AUKIT_HIP_CHECK(hipGetLastError());
+            AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipMemcpyAsync(chain.data(), d_chain, (size_t)n * sizeof(ChainOut), hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (getenv("AUKIT_FLAC_DEBUG")) {
+                std::vector<CandInfo> hci(ncand);
+                (void)hipMemcpy(hci.data(), d_ci, ncand * sizeof(CandInfo), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[flac fused] pass %d ncand %u cursor %llu scap %llu\n", pass, ncand, (u64)hc.scratch_cursor, (u64)scap);
+                for (unsigned k = 0; k < ncand && k < 16; k++)
+                    fprintf(stderr, "  cand %u end %llu bs %d asgn %d status %d nsub %d used %u seq %u\n", k, hci[k].end_byte, hci[k].blocksize, hci[k].chan_asgn, hci[k].status, hci[k].nsub, hci[k].used, hci[k].seq);
+                for (uint32_t s = 0; s < n && s < 4; s++)
+                    fprintf(stderr, "  chain %u L %llu nfr %u status %d miss %d at %llu ci %u\n", s, chain[s].L, chain[s].nframes, chain[s].status, chain[s].miss_kind, chain[s].miss_at, chain[s].miss_ci);
+            }
+            if (hc.scratch_cursor > scap) { scap = hc.scratch_cursor + hc.scratch_cursor / 16 + 65536; pass = -1; continue; }
+            std::vector<Cand> extra;
+            std::vector<unsigned> redo;
+            for (uint32_t s = 0; s < n; s++) {
+                if (chain[s].miss_kind == 1) extra.push_back(Cand{s, 1, chain[s].miss_at});
+                else if (chain[s].miss_kind == 2) redo.push_back(chain[s].miss_ci);
+            }
+            if (extra.empty() && redo.empty()) break;
+            if (pass > 1000000) return fail(AUKIT_E_HIP, "internal: FLAC chain does not converge");
+            if ((uint64_t)ncand + extra.size() > capc) { capc = (uint64_t)ncand + extra.size() * 2 + n + 4096; restart = true; break; }
+            if (!extra.empty()) {
+                AUKIT_HIP_CHECK(hipMemcpyAsync(d_cand + ncand, extra.data(), extra.size() * sizeof(Cand), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_flac_hash_insert, dim3((unsigned)((extra.size() + 63) / 64)), dim3(64), 0, ctx->stream, d_cand, ncand, (unsigned)extra.size(), H);
+                if ((rc = decode(ncand, (unsigned)extra.size(), 0))) return rc;
+                AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                ncand += (unsigned)extra.size();
+            }
+            for (unsigned k : redo) if ((rc = decode(k, 1, 0))) return rc;   // hit their bit budget and are needed after all: once more, without one
+        }
+        if (restart) continue;
+        for (uint32_t s = 0; s < n; s++) if (chain[s].status == FE_DECLINE) return 2;
+
+        D.status.assign(n, 0);
+        D.row_off.assign((size_t)n * C, 0);
+        D.row_len.assign((size_t)n * C, 0);
+        std::vector<uint64_t> fbase(n);
+        uint64_t tot = 0, nfr = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            const uint64_t L = chain[s].L, stride = round_up(std::max<uint64_t>(L, 1), 4);
+            for (int c = 0; c < C; c++) { D.row_off[(size_t)s * C + c] = tot + (uint64_t)c * stride; D.row_len[(size_t)s * C + c] = L; }
+            tot += stride * C;
+            fbase[s] = nfr;
+            nfr += chain[s].nframes;
+            D.status[s] = chain[s].status;
+        }
+        if ((rc = ctx->tmp_buf.ensure((size_t)tot * 4 + 256))) return rc;
+        if ((rc = ctx->seg_buf.ensure(nfr * sizeof(FrameRec) + 512))) return rc;
+        ctx->plan_key.clear();
+        FrameRec *d_frames = reinterpret_cast<FrameRec *>(ctx->seg_buf.p);
+        if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8))) return rc;
+        if (nfr) {
+            if ((rc = ctx_begin_kernel(ctx))) return rc;
+            if ((rc = flac_gather_launch(ctx, d_cand, d_ci, ncand, C, d_rowoff, d_fbase, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<int *>(ctx->tmp_buf.p), d_frames))) return rc;
+            if ((rc = ctx_end_kernel(ctx, "k_flac_gather", 2 * tot * 4))) return rc;
+        }
+        std::vector<FrameRec> hfr;
+        if (want_frames && nfr) {
+            hfr.resize(nfr);
+            AUKIT_HIP_CHECK(hipMemcpyAsync(hfr.data(), d_frames, nfr * sizeof(FrameRec), hipMemcpyDeviceToHost, ctx->stream));
+            AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        D.frames.assign(n, {});
+        D.d_frames = d_frames; D.d_fbase = d_fbase; D.d_rowoff = d_rowoff; D.fbase = fbase; D.nfr = nfr;
+        D.nframes.assign(n, 0);
+        for (uint32_t s = 0; s < n; s++) D.nframes[s] = chain[s].nframes;
+        if (want_frames)
+            for (uint32_t s = 0; s < n; s++) {
+                D.frames[s].reserve(chain[s].nframes);
+                for (unsigned f = 0; f < chain[s].nframes; f++) D.frames[s].push_back({hfr[fbase[s] + f].sample_off, hfr[fbase[s] + f].bs});
+            }
+        D.wide = false;
+        return AUKIT_OK;
+    }
+}
+
 static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
     const uint32_t n = in->n;
     if (n == 0) return fail(AUKIT_E_ARG, "empty batch");
@@ -1585,6 +1662,13 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
         else if (D.info[s].channels != D.channels || D.info[s].depth != D.depth || D.info[s].rate != D.rate)
             return fail(AUKIT_E_ARG, "all FLAC streams of a batch must share channel count, bit depth and sample rate");
     }
+    const bool no_fused = getenv("AUKIT_FLAC_NO_FUSED") != nullptr;   // A/B and the tests: the first design for every batch
+    if (D.depth <= 24 && !g_flac_force_wide() && !no_fused && !getenv("AUKIT_FLAC_SLOW_RESTORE")) {
+        rc = flac_run_fused(ctx, in, D, want_frames);
+        ctx->counters[AUKIT_COUNTER_FLAC_FUSED] = rc == AUKIT_OK ? 1 : 0;
+        if (rc != 2) return rc;
+        if (getenv("AUKIT_FLAC_DEBUG")) fprintf(stderr, "[flac] the fused decoder declined a frame of the chain: two-kernel decoder\n");
+    } else ctx->counters[AUKIT_COUNTER_FLAC_FUSED] = 0;
     if (D.depth <= 24 && !g_flac_force_wide()) {
         rc = flac_run<int>(ctx, in, D, want_frames);
         if (rc != 1) return rc;

@@ -1,0 +1,600 @@
+// flac_fused.hip — FLAC frames decoded to FINAL integers by the lane that reads their bits (round 4).
+//
+// flac.hip's first design splits decodeFrame (aukit.lua:510-567) in two: k_flac_extract turns bit fields into residuals (7.8 GB written for
+// BASELINE config 5), k_flac_restore_fast reads them back (9.8 GB), predicts, decorrelates, wraps and writes the samples (8.0 GB) — 13.4 of the
+// step's 20.4 ms.  Here one kernel does all of it:
+//   * a lane owns one candidate frame (k_flac_find's list, a ticket counter, a persistent grid — as before) and walks it like decodeFrame;
+//   * the hot loop is ONE loop over Rice codes and fixed-width fields (escape partitions, warm-up, VERBATIM): a value = alignbit, count-leading-
+//     zeros, two bit-field extracts, a select.  Everything else — frame / subframe / partition headers, LPC coefficients, codes longer than 32
+//     bits, the last bytes of a stream — is generic code outside it, entered a few times per subframe (the old loop folded the headers in as
+//     "fields": 105 instructions per field);
+//   * rounds of 32 values are aligned to the subframe, so Rice partitions (multiples of 32 values for every ordinary stream) end where rounds end;
+//   * after a round's values are in the lane's LDS row the SAME lane restores the prediction (:411-419) with its history in registers
+//     (v_mad_i32_i24 per tap while sum |coef| * |value| provably fits 32 bits, else 64-bit sums), shifts by the wasted bits (:467-469);
+//   * the round leaves through LDS as 16-byte stores: independent channels wrapped (:501-507) and final; the first subframe of a decorrelating
+//     stereo frame parked (raw) in the SECOND channel's place; the second subframe's rounds read that back, apply :482-497 and write both
+//     channels — final values are written once, no descriptor table, no residual array, no second kernel.
+// What this kernel does not serve it DECLINES (FE_DECLINE in the frame's CandInfo): predictor orders above 12, values beyond the ranges checked
+// below, the :400 quirk (a Rice partition shorter than the predictor order), sample depths of a subframe outside 1..31.  If the chain walk
+// (k_flac_chain) needs a declined frame the whole batch is decoded by the first design — so nothing here can change a result.
+#include <algorithm>
+#include <type_traits>
+#include "flac_dev.h"
+
+namespace aukit {
+
+constexpr int FWN = 16;             // 64-bit words of bit-stream window per lane (128 bytes, a ring of 32 dwords)
+constexpr int FLPW = FWN / 2;       // lanes that refill one window, 16 bytes each
+constexpr int FWS = 2 * FWN + 1;    // row stride of the window array in dwords (odd: lanes at one offset hit distinct banks)
+constexpr int FNC = 32;             // values per lane and round
+constexpr int FOS = FNC + 1;        // row stride of the value array
+constexpr int FMAXO = 12;           // predictor orders served
+constexpr unsigned FRING = 2 * FWN - 1;
+
+enum { S_FRAME = 0, S_SUB, S_RUN, S_CONST, S_COEF, S_PART, S_SUBEND, S_FRAMEEND, S_DONE };
+
+// MSB-first reader of the generic (rare) code: the lane's ring window in LDS, global memory outside it
+struct FRd {
+    const unsigned *lw;    // ring: lw[k & 31] = big-endian dword k of the batch (counted from G.w0) for the dwords [2 win_lo, 2 win_lo + 32)
+    const unsigned *g32;   // the batch as raw dwords from G.w0
+    u64 safe_dw, win_lo, pos, end;
+    int eof;
+};
+AUKIT_DEV unsigned rd_dword(const FRd &r, u64 k) {
+    if (k - 2 * r.win_lo < (u64)(2 * FWN)) return r.lw[(unsigned)k & FRING];
+    return k < r.safe_dw ? __builtin_bswap32(r.g32[k]) : 0u;
+}
+AUKIT_DEV unsigned rd_peek(const FRd &r) {   // the next 32 bits
+    const u64 d = r.pos >> 5;
+    const unsigned u = (unsigned)r.pos & 31u;
+    const unsigned a = rd_dword(r, d);
+    if (u == 0) return a;
+    return (a << u) | (rd_dword(r, d + 1) >> (32 - u));
+}
+AUKIT_DEV unsigned rd_get(FRd &r, int n) {   // BitInputStream.readUint(n), 0 <= n <= 31  (:351-364)
+    if (n == 0) return 0;
+    if (r.pos + (u64)n > r.end) { r.eof = 1; return 0; }
+    const unsigned v = rd_peek(r) >> (32 - n);
+    r.pos += (u64)n;
+    return v;
+}
+AUKIT_DEV int rd_sget(FRd &r, int n) {       // readSignedInt(n)  (:365-369)
+    const unsigned v = rd_get(r, n);
+    return n > 0 ? ((int)(v << (32 - n)) >> (32 - n)) : 0;
+}
+
+// the three combinations of :482-497 (first subframe a, second subframe b)
+AUKIT_DEV void flac_decor(int asg, int a, int b, int &c0, int &c1) {
+    const int right = a - (b >> 1);                                                           // mid / side: floor(side / 2)
+    c0 = asg == 8 ? a : (asg == 9 ? a + b : right + b);
+    c1 = asg == 8 ? a - b : (asg == 9 ? b : right);
+}
+
+__device__ __forceinline__ int fmad24(int a, int b, int c) {   // v_mad_i32_i24 named outright (cf. flac.hip)
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// readRiceSignedInt (:370-376) with every check: codes longer than 32 bits, the end of the data.  Returns FE_OK (value in v), FE_NIL, FE_DECLINE.
+AUKIT_DEV int flac_rice_slow(FRd &b, int k, int &v) {
+    u64 zeros = 0;
+    bool gz = true, dec = false;
+    while (gz) {   // (single-exit: see k_flac_chain)
+        if (b.pos >= b.end) { b.eof = 1; gz = false; }
+        else {
+            const unsigned hi = rd_peek(b);
+            const u64 avail = b.end - b.pos;
+            const int z = hi ? __builtin_clz(hi) : 32;
+            if ((u64)z >= avail) { b.eof = 1; gz = false; }   // ran off the end inside the unary prefix
+            else if (z < 32) { zeros += (u64)z; b.pos += (u64)z + 1; gz = false; }
+            else { zeros += 32; b.pos += 32; if (zeros > (1u << 26)) { dec = true; gz = false; } }
+        }
+    }
+    const unsigned lowb = rd_get(b, k);
+    const u64 u = (zeros << k) + lowb;
+    if (b.eof) return FE_NIL;
+    if (dec || (u >> 31)) return FE_DECLINE;   // beyond int32: the first design's overflow path knows what to do
+    v = (int)(unsigned)(u >> 1) ^ -(int)(unsigned)(u & 1);
+    return FE_OK;
+}
+
+// restoreLinearPrediction (:411-419) over the first `cnt` values of a lane's row, then result[i] * 2^shift (:467-469).  hist[q] = value i - 1 - q.
+// WARM: the row may hold warm-up samples (index below `order`: copied).  WIDE: 64-bit sums and range checks (any coefficients, any shift);
+// otherwise one 24-bit multiply-add per tap — exact while |value| < hb, a power of two with hb * sum |coef| < 2^31 (checked: `badacc`).
+template <int MAXO, bool WARM, bool WIDE>
+AUKIT_DEV void flac_predict(int *row, int cnt, int jpos0, int order, int lshift, int wasted, const int (&coef)[FMAXO], int (&hist)[FMAXO], int hb, unsigned &badacc) {
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        const int res[4] = {row[k], row[k + 1], row[k + 2], row[k + 3]};
+        int nv[4], out[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            int v, o;
+            if constexpr (WIDE) {
+                long long sum = 0;
+#pragma unroll
+                for (int q = 0; q < MAXO; q++) { const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj]; sum += (long long)t * (long long)coef[q]; }
+                long long pr = lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));   // floor(sum / 2^shift)
+                if (WARM && jpos0 + k + jj < order) pr = 0;
+                const long long vv = (long long)res[jj] + pr;
+                const long long oo = vv << wasted;
+                if ((unsigned long long)(oo + (1ll << 29)) >= (1ull << 30) || (unsigned long long)(vv + (1ll << 29)) >= (1ull << 30)) badacc |= 0x80000000u;
+                v = (int)vv; o = (int)oo;
+            } else {
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q < MAXO; q++) { const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj]; sum = fmad24(t, coef[q], sum); }
+                int pr = sum >> lshift;
+                if (WARM && jpos0 + k + jj < order) pr = 0;
+                v = res[jj] + pr;
+                badacc |= (unsigned)(v + hb);
+                o = (int)((unsigned)v << wasted);   // |v| < 2^23, wasted <= 6
+            }
+            nv[jj] = v;
+            out[jj] = o;
+        }
+        row[k] = out[0]; row[k + 1] = out[1]; row[k + 2] = out[2]; row[k + 3] = out[3];
+#pragma unroll
+        for (int q = MAXO - 1; q >= 4; q--) hist[q] = hist[q - 4];
+#pragma unroll
+        for (int q = 0; q < 4 && q < MAXO; q++) hist[q] = nv[3 - q];
+    }
+    for (; k < cnt; k++) {   // a short round's last one to three values
+        long long sum = 0;
+#pragma unroll
+        for (int q = 0; q < MAXO; q++) sum += (long long)hist[q] * (long long)coef[q];
+        long long pr = lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));
+        if (jpos0 + k < order) pr = 0;
+        const long long vv = (long long)row[k] + pr;
+        const long long oo = vv << wasted;
+        if constexpr (WIDE) { if ((unsigned long long)(oo + (1ll << 29)) >= (1ull << 30) || (unsigned long long)(vv + (1ll << 29)) >= (1ull << 30)) badacc |= 0x80000000u; }
+        else { if ((unsigned long long)(vv + (long long)hb) >= 2ull * (unsigned long long)hb) badacc |= 0x80000000u; }
+        row[k] = (int)oo;
+#pragma unroll
+        for (int q = MAXO - 1; q >= 1; q--) hist[q] = hist[q - 1];
+        hist[0] = (int)vv;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
+    __shared__ unsigned s_win[64 * FWS];
+    __shared__ int s_val[64 * FOS];
+    __shared__ u64 s_ptr[64];
+    __shared__ unsigned s_meta[64];   // values of the round | mode << 8 | channel assignment << 12   (mode 0: wrap and store, 1: park the first subframe, 2: decorrelate)
+    __shared__ int s_bs[64];
+    const int lane = threadIdx.x;
+    const int C = A.C, depth = A.depth;
+    const int wrap_half = 1 << (depth - 1), wrap_full = 1 << depth;   // 1 <= depth <= 24 (the host sends nothing else here)
+    auto wrap = [&](int v) -> int { return v >= wrap_half ? v - wrap_full : v; };   // :504
+
+    FRd b;
+    b.lw = s_win + lane * FWS;
+    b.g32 = reinterpret_cast<const unsigned *>(A.G.w0);
+    b.safe_dw = 2 * A.G.safe_words;
+    b.win_lo = 0; b.pos = 0; b.end = 0; b.eof = 0;
+    u64 limit = ~0ull;
+    bool have = false, fresh = true;
+    unsigned idx = 0, nolimit = 0;
+    int st = S_DONE, status = FE_OK;
+    int bs = 0, chan_asgn = 0, nsub = 0, ch = 0;
+    int order = 0, wasted = 0, sdepth = 0, lshift = 0, after = S_SUBEND;
+    int nparts = 0, psize = 0, pi = 0, param_bits = 4, remaining = 0, jpos = 0, rk = 0, cval = 0, hb = 1 << 23;
+    bool fixed = false, wide = false, store_ok = false, lpc = false;
+    u64 cand_scratch = 0, end_byte = 0;
+    int coef[FMAXO], hist[FMAXO];
+#pragma unroll
+    for (int q = 0; q < FMAXO; q++) { coef[q] = 0; hist[q] = 0; }
+    int *const orow = s_val + lane * FOS;
+
+    auto start = [&](unsigned rel) {
+        have = true;
+        idx = A.first + rel;
+        const Cand c = A.cands[idx];
+        const FlacStreamInfo si = A.G.info[c.stream];
+        (void)si;
+        b.end = A.G.base_bit + 8 * A.G.off[c.stream + 1];
+        b.pos = A.G.base_bit + 8 * c.byte;
+        b.eof = 0;
+        b.win_lo = 0;
+        limit = ~0ull;
+        nolimit = c.nolimit;
+        st = S_FRAME; status = FE_OK; fresh = true;
+        bs = 0; chan_asgn = 0; nsub = 0; ch = 0; jpos = 0; remaining = 0;
+        store_ok = false;
+        cand_scratch = 0; end_byte = 0;
+    };
+    auto finish = [&]() {
+        CandInfo f;
+        f.end_byte = end_byte; f.scratch = cand_scratch; f.sample_off = 0;
+        f.blocksize = bs; f.chan_asgn = chan_asgn; f.status = status; f.nsub = nsub;
+        f.seq = 0; f.used = 0;
+        A.ci[idx] = f;
+        have = false;
+    };
+    auto take = [&]() {   // every lane without a frame takes a ticket: one atomic per wave
+        const u64 m = __ballot(!have);
+        if (!m) return;
+        unsigned base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(A.ticket, (unsigned)__builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        const unsigned rel = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1));
+        if (!have && rel < A.count) start(rel);
+    };
+    take();
+
+    // ---- a round's values leave at the top of the NEXT round, behind the wait for that round's window lines (loads and stores share vmcnt: stores
+    // issued in front of that wait would be waited for as well)
+    bool have_flush = false, flush_fast = false;
+    uint4 tpre[8];   // mode 2: the parked first-subframe values of the eight rows this lane stores for, requested while the round is predicted
+#pragma unroll
+    for (int i = 0; i < 8; i++) tpre[i] = make_uint4(0, 0, 0, 0);
+    auto flush = [&]() {
+        if (flush_fast) {
+            const int grp = lane >> 3, q4 = 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int s = 8 * i + grp;
+                const unsigned m = s_meta[s];
+                const int cn = (int)(m & 0xFFu), mode = (int)((m >> 8) & 3u), asg = (int)(m >> 12);
+                if (q4 < cn) {
+                    const int *v = s_val + s * FOS + q4;
+                    const int a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                    int *dst = A.scratch + s_ptr[s] + q4;
+                    if (mode == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)wrap(a0), (unsigned)wrap(a1), (unsigned)wrap(a2), (unsigned)wrap(a3));
+                    else if (mode == 1) *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
+                    else {
+                        int l0, l1, l2, l3, r0, r1, r2, r3;
+                        flac_decor(asg, (int)tpre[i].x, a0, l0, r0); flac_decor(asg, (int)tpre[i].y, a1, l1, r1);
+                        flac_decor(asg, (int)tpre[i].z, a2, l2, r2); flac_decor(asg, (int)tpre[i].w, a3, l3, r3);
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)wrap(l0), (unsigned)wrap(l1), (unsigned)wrap(l2), (unsigned)wrap(l3));
+                        *reinterpret_cast<uint4 *>(dst + s_bs[s]) = make_uint4((unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
+                    }
+                }
+            }
+            return;
+        }
+        const int part = lane >> 5, k = lane & 31;   // any alignment, any count: two rows per instruction
+        for (int i = 0; i < 32; i++) {
+            const int s = 2 * i + part;
+            const unsigned m = s_meta[s];
+            const int cn = (int)(m & 0xFFu), mode = (int)((m >> 8) & 3u), asg = (int)(m >> 12);
+            if (k < cn) {
+                const int a = s_val[s * FOS + k];
+                int *dst = A.scratch + s_ptr[s] + k;
+                if (mode == 0) *dst = wrap(a);
+                else if (mode == 1) *dst = a;
+                else { int l, r; flac_decor(asg, dst[s_bs[s]], a, l, r); dst[0] = wrap(l); dst[s_bs[s]] = wrap(r); }
+            }
+        }
+    };
+    uint4 pf[FLPW];      // per window this lane loads for: the line that will replace its slot's line, already requested
+    u64 pf_line[FLPW];
+#pragma unroll
+    for (int i = 0; i < FLPW; i++) { pf[i] = make_uint4(0, 0, 0, 0); pf_line[i] = ~0ull; }
+
+    bool more = true;
+    while (more) {
+        // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per window, 8 windows per load
+        {
+            const u64 wi = b.pos >> 6;
+            const bool want = st != S_DONE && (fresh || (wi - b.win_lo) >= (u64)(FWN / 4));
+            const u64 new_lo = wi & ~1ull;
+            const u64 keep_from = fresh ? ~0ull : b.win_lo / 2 + FWN / 2;   // first 16-byte line the ring does not hold yet
+            if (want) b.win_lo = new_lo;
+            const int sub8 = lane % FLPW, grp = lane / FLPW;
+#pragma unroll
+            for (int i = 0; i < FLPW; i++) {
+                const int s = i * (64 / FLPW) + grp;
+                const int w = __shfl((int)want, s);
+                const u64 ws = __shfl(new_lo, s);
+                const u64 kf = __shfl(keep_from, s);
+                if (w) {
+                    const u64 l0 = ws / 2, line = l0 + (((u64)sub8 - l0) & (u64)(FLPW - 1));   // ring slot sub8 holds the line congruent to sub8
+                    if (kf == ~0ull || line >= kf || line < kf - FWN / 2) {
+                        uint4 v = pf[i];
+                        if (pf_line[i] != line) {
+                            v = make_uint4(0, 0, 0, 0);
+                            if (2 * line < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
+                        }
+                        unsigned *wrow = s_win + s * FWS + 4 * sub8;
+                        wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
+                        wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
+                        const u64 nl = line + FLPW;
+                        pf_line[i] = nl;
+                        pf[i] = make_uint4(0, 0, 0, 0);
+                        if (2 * nl < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * nl);
+                    }
+                }
+            }
+            __syncthreads();
+            if (have_flush) flush();
+            __syncthreads();
+            fresh = false;
+        }
+
+        // ---- phase 1: every lane advances its frame until it has 32 values of ONE subframe (or its window runs low, or the subframe ends)
+        int cnt = 0;
+        int lim = FNC - (jpos & (FNC - 1));   // rounds end at multiples of 32 values of the subframe: where Rice partitions end
+        bool rdone = st == S_DONE;
+        const unsigned dwbase = (unsigned)(2 * b.win_lo);
+        // a lane whose window reaches the end of its stream's data reads value by value with every check (a stream's last rounds)
+        const bool careful = b.end < ((b.win_lo + FWN) << 6) + 64;
+        bool go_on = __any(!rdone);
+        while (go_on) {
+            // -- the run loop: Rice codes (:370-376) or fields of `rk` bits (:405, :423, :457), one value per turn
+            const bool run = !rdone && st == S_RUN && remaining > 0 && !careful;
+            if (__any(run)) {
+                const u64 dfull = (b.pos - 1) >> 5;                     // the dword that holds the last bit read (frames start far beyond bit 0)
+                unsigned d = (unsigned)dfull;
+                int s = (int)((0u - (unsigned)b.pos) & 31u);            // bits of it not yet read
+                unsigned w0 = b.lw[d & FRING], w1 = b.lw[(d + 1) & FRING], wn = b.lw[(d + 2) & FRING];   // wn: one dword ahead, off the dependency chain
+                const int cnt0 = cnt;
+                bool slow = false;
+                bool go = run && cnt < lim && (d + 1 - dwbase) < 25u;
+                while (go) {
+                    const unsigned hi = __builtin_amdgcn_alignbit(w0, w1, (unsigned)s);
+                    const int z = hi ? __builtin_clz(hi) : 32;
+                    const int tot_r = z + 1 + rk;
+                    const unsigned low = __builtin_amdgcn_ubfe(hi, (unsigned)(31 - rk - z) & 31u, (unsigned)rk);
+                    const unsigned ur = ((unsigned)z << rk) | low;
+                    const int v_r = (int)(ur >> 1) ^ -(int)(ur & 1u);
+                    const int v_f = __builtin_amdgcn_sbfe((int)hi, (unsigned)(32 - rk) & 31u, (unsigned)rk);
+                    const int tot = fixed ? rk : tot_r;
+                    if (tot > 32) { slow = true; go = false; }   // a Rice code longer than 32 bits: the generic reader takes this one
+                    else {
+                        orow[cnt] = fixed ? v_f : v_r;
+                        s -= tot;
+                        const bool cross = s < 0;
+                        s &= 31;
+                        d += cross ? 1u : 0u;
+                        w0 = cross ? w1 : w0;
+                        w1 = cross ? wn : w1;
+                        wn = b.lw[(d + 2) & FRING];
+                        cnt++; remaining--;
+                        go = cnt < lim && remaining > 0 && (d + 1 - dwbase) < 25u;
+                    }
+                }
+                if (run) {
+                    b.pos = 32 * (dfull + (u64)(d - (unsigned)dfull) + 1) - (u64)s;
+                    jpos += cnt - cnt0;
+                    if (slow) {   // this one value by the generic reader
+                        int v1 = 0;
+                        const int r1 = flac_rice_slow(b, rk, v1);
+                        if (r1) { status = r1; st = S_DONE; rdone = true; }
+                        else { orow[cnt] = v1; cnt++; remaining--; jpos++; }
+                    }
+                    if (!rdone && remaining > 0 && (cnt >= lim || ((b.pos >> 5) - (u64)2 * b.win_lo) >= 24)) rdone = true;   // the round is full, or the window low
+                }
+            }
+            // -- everything else, one transition per turn (divergent, rare)
+            if (!rdone) {
+                if (st == S_RUN) {
+                    if (remaining == 0) { st = after; if (after == S_PART) { pi++; if (pi >= nparts) st = S_SUBEND; } }
+                    else if (cnt >= lim) rdone = true;
+                    else if (careful) {   // value by value near the end of the data
+                        int r1 = FE_OK, v1 = 0;
+                        if (fixed) { v1 = rd_sget(b, rk); if (b.eof) r1 = FE_NIL; }
+                        else r1 = flac_rice_slow(b, rk, v1);
+                        if (r1) { status = r1; st = S_DONE; rdone = true; }
+                        else { orow[cnt] = v1; cnt++; remaining--; jpos++; }
+                        if (!rdone && remaining > 0 && (cnt >= lim || ((b.pos >> 5) - (u64)2 * b.win_lo) >= 24)) rdone = true;
+                    }
+                } else if (st == S_CONST) {   // :453-454
+                    while (remaining > 0 && cnt < lim) { orow[cnt++] = cval; remaining--; jpos++; }
+                    if (remaining == 0) st = S_SUBEND; else rdone = true;
+                } else if (st == S_PART) {   // :394-406
+                    const int escape = param_bits == 4 ? 15 : 31;
+                    const int param = (int)rd_get(b, param_bits);
+                    const bool esc = param >= escape;
+                    int nbits = 0;
+                    if (esc) nbits = (int)rd_get(b, 5);
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (b.pos > limit) { status = FE_LIMIT; st = S_DONE; rdone = true; }
+                    else {
+                        const int start_i = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
+                        remaining = endd > start_i ? endd - start_i : 0;
+                        fixed = esc;
+                        rk = esc ? nbits : param;
+                        after = S_PART;
+                        st = S_RUN;   // (an empty partition leaves through S_RUN's remaining == 0)
+                    }
+                } else if (st == S_SUB) {   // decodeSubframe  :443-465
+                    rd_get(b, 1);
+                    const int type = (int)rd_get(b, 6);
+                    wasted = (int)rd_get(b, 1);
+                    if (wasted == 1) {   // unary wasted-bits count  :447-449
+                        bool gw = true;
+                        while (gw) { const unsigned bit = rd_get(b, 1); if (b.eof || bit) gw = false; else wasted++; }
+                    }
+                    sdepth = depth - wasted;
+                    if (chan_asgn >= 8) sdepth += ((chan_asgn == 9) == (ch == 0)) ? 1 : 0;   // the side channel has one more bit  :480-481
+                    order = 0; lshift = 0; jpos = 0; lim = FNC; lpc = false; wide = false; hb = 1 << 23;
+#pragma unroll
+                    for (int q = 0; q < FMAXO; q++) { coef[q] = 0; hist[q] = 0; }
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (sdepth < 1 || sdepth > 31 || wasted > 24) { status = FE_DECLINE; st = S_DONE; rdone = true; }
+                    else if (type == 0) {
+                        cval = rd_sget(b, sdepth);
+                        wide = sdepth > 24 || wasted > 6;
+                        if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                        else { remaining = bs; st = S_CONST; }
+                    } else if (type == 1) { wide = sdepth > 24 || wasted > 6; remaining = bs; fixed = true; rk = sdepth; after = S_SUBEND; st = S_RUN; }
+                    else if ((type >= 8 && type <= 12) || (type >= 32 && type <= 63)) {
+                        order = type <= 12 ? type - 8 : type - 31;
+                        lpc = type >= 32;
+                        if (order > FMAXO || order > bs) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // (order > bs: the Lua table grows past blockSize)
+                        else { remaining = order; fixed = true; rk = sdepth; after = S_COEF; st = S_RUN; }
+                    } else { status = FE_SUBTYPE; st = S_DONE; rdone = true; }
+                } else if (st == S_COEF) {   // :433-438 / FIXED_PREDICTION_COEFFICIENTS :334-340, then the residual header :381-391
+                    if (lpc) {
+                        const int precision = (int)rd_get(b, 4) + 1;
+                        lshift = rd_sget(b, 5);
+#pragma unroll
+                        for (int q = 0; q < FMAXO; q++) if (q < order) coef[q] = rd_sget(b, precision);
+                    } else {
+                        const int fc[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) coef[q] = q < order ? fc[order][q] : 0;
+                    }
+                    const int method = (int)rd_get(b, 2);
+                    param_bits = method == 0 ? 4 : 5;
+                    const int porder = (int)rd_get(b, 4);
+                    nparts = 1 << porder;
+                    int sabs = 1;
+#pragma unroll
+                    for (int q = 0; q < FMAXO; q++) sabs += coef[q] < 0 ? -coef[q] : coef[q];
+                    const int hbits = min(23, __builtin_clz((unsigned)sabs) - 1);   // 2^hbits * sum |coef| < 2^31
+                    hb = 1 << hbits;
+                    // values of this subframe have up to sdepth bits: the 24-bit multiply-adds serve it when those fit under hb; else 64-bit sums
+                    wide = sdepth - 1 > hbits || lshift < 0 || wasted > 6;
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (method >= 2) { status = FE_RESMETHOD; st = S_DONE; rdone = true; }
+                    else if (bs % nparts != 0) { status = FE_PARTITION; st = S_DONE; rdone = true; }
+                    else {
+                        psize = bs / nparts;
+                        pi = 0;
+                        if (nparts > 1 && psize < order) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // :400 — later partitions overwrite warm-up entries
+                        else st = S_PART;
+                    }
+                } else if (st == S_SUBEND) {
+                    if (cnt > 0) rdone = true;   // this subframe's last values are predicted and stored before the next header is read
+                    else { ch++; jpos = 0; lim = FNC; st = ch < nsub ? S_SUB : S_FRAMEEND; }
+                } else if (st == S_FRAME) {   // decodeFrame header  :510-553
+                    int fs = FE_OK;
+                    const unsigned t0 = rd_get(b, 8);
+                    if (b.eof) fs = FE_EOF_START;
+                    const unsigned sync = t0 * 64 + rd_get(b, 6);
+                    if (!fs && b.eof) fs = FE_NIL;
+                    if (!fs && sync != 0x3FFE) fs = FE_SYNC;
+                    rd_get(b, 2);
+                    const int bsc = (int)rd_get(b, 4), src_code = (int)rd_get(b, 4);
+                    chan_asgn = (int)rd_get(b, 4);
+                    rd_get(b, 4);
+                    const int t = (int)rd_get(b, 8);
+                    if (!fs && b.eof) fs = FE_NIL;
+                    int t2 = -1;
+                    for (int i = 7; i >= 0; i--) { if (!(t & (1 << i))) break; t2++; }
+                    for (int i = 1; i <= t2; i++) rd_get(b, 8);
+                    if (bsc == 1) bs = 192;
+                    else if (bsc >= 2 && bsc <= 5) bs = 576 << (bsc - 2);
+                    else if (bsc == 6) bs = (int)rd_get(b, 8) + 1;
+                    else if (bsc == 7) bs = (int)rd_get(b, 16) + 1;
+                    else if (bsc >= 8) bs = 256 << (bsc - 8);
+                    else { bs = 0; if (!fs) fs = FE_BLOCKSIZE; }
+                    if (src_code == 12) rd_get(b, 8);
+                    else if (src_code == 13 || src_code == 14) rd_get(b, 16);
+                    rd_get(b, 8);   // CRC-8, ignored :553
+                    if (!fs && b.eof) fs = FE_NIL;
+                    if (!fs) {
+                        if (chan_asgn <= 7) nsub = C;
+                        else if (chan_asgn <= 10) { nsub = 2; if (C != 2) fs = FE_NIL; }   // result[ch] of a missing / extra channel is nil (:482-507)
+                        else fs = FE_CHAN;
+                    }
+                    status = fs;
+                    if (fs != FE_OK) { st = S_DONE; rdone = true; }
+                    else {
+                        limit = (A.limit_factor > 0 && !nolimit) ? b.pos + (u64)A.limit_factor * (u64)bs * (u64)C * (u64)(depth + 2) / 4 + 4096 : ~0ull;
+                        const u64 need = (u64)nsub * (u64)bs;
+                        cand_scratch = atomicAdd(A.scratch_cursor, ((need + 3) & ~3ull) + 32);   // (+ 32: see k_flac_extract — frames must not all start at one offset within 16 KiB)
+                        store_ok = cand_scratch + need <= A.scratch_cap;
+                        ch = 0; jpos = 0; lim = FNC;
+                        st = S_SUB;
+                    }
+                } else if (st == S_FRAMEEND) {   // :555-557
+                    b.pos = (b.pos + 7) & ~7ull;                                  // alignToByte (frames start on byte boundaries of the batch buffer)
+                    b.pos = (b.pos + 16 <= b.end) ? b.pos + 16 : b.end;           // readUint(16): a nil here is discarded, the NEXT readByte returns nil
+                    end_byte = (b.pos - A.G.base_bit) >> 3;
+                    st = S_DONE; rdone = true;
+                }
+                // a generic step that ran the window low ends the round as well (the next step would read global memory)
+                if (!rdone && ((b.pos >> 5) - (u64)2 * b.win_lo) >= 26 && st != S_FRAMEEND && st != S_SUBEND) rdone = true;
+            }
+            go_on = __any(!rdone);
+        }
+        if (st != S_DONE && b.pos > limit) { status = FE_LIMIT; st = S_DONE; }
+
+        // ---- where the round's values go
+        const bool decor = C == 2 && chan_asgn >= 8 && chan_asgn <= 10;
+        const int mode = !decor ? 0 : (ch == 0 ? 1 : 2);
+        const int jpos0 = jpos - cnt;   // the subframe index of the row's first value (a round never mixes subframes)
+        const u64 gptr = cand_scratch + (u64)jpos0 + (mode == 0 ? (u64)ch * (u64)bs : (mode == 1 ? (u64)bs : 0ull));
+        const bool live = have && cnt > 0 && status == FE_OK;
+        const bool stores = live && store_ok;
+        s_meta[lane] = stores ? ((unsigned)cnt | ((unsigned)mode << 8) | ((unsigned)chan_asgn << 12)) : 0u;
+        s_ptr[lane] = gptr;
+        s_bs[lane] = bs;
+        // the 16-byte path needs whole vectors at aligned places (block sizes are multiples of 4 but for a stream's last frame)
+        flush_fast = __all(!stores || ((cnt & 3) == 0 && (gptr & 3) == 0 && (mode != 2 || (bs & 3) == 0)));
+        __syncthreads();
+        if (flush_fast) {   // the parked first-subframe values of the rounds that decorrelate: requested now, used by the flush at the top of the next round
+            const int grp = lane >> 3, q4 = 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int s = 8 * i + grp;
+                const unsigned m = s_meta[s];
+                if (((m >> 8) & 3u) == 2u && q4 < (int)(m & 0xFFu)) tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + s_ptr[s] + s_bs[s] + q4);
+            }
+        }
+        // ---- phase 2: the prediction, by the lane that decoded the values
+        if (__any(live)) {
+            unsigned badacc = 0;
+            const int pcnt = live ? cnt : 0;
+            const bool anywide = __any(live && wide);
+            const bool warm = __any(live && jpos0 < order);
+            const bool big = __any(live && order > 4);
+#define AUKIT_PRED(MO, W, WD) flac_predict<MO, W, WD>(orow, pcnt, jpos0, order, lshift, wasted, coef, hist, hb, badacc)
+            if (anywide) { if (big) { if (warm) AUKIT_PRED(12, true, true); else AUKIT_PRED(12, false, true); } else { if (warm) AUKIT_PRED(4, true, true); else AUKIT_PRED(4, false, true); } }
+            else { if (big) { if (warm) AUKIT_PRED(12, true, false); else AUKIT_PRED(12, false, false); } else { if (warm) AUKIT_PRED(4, true, false); else AUKIT_PRED(4, false, false); } }
+#undef AUKIT_PRED
+            const bool bad = anywide ? (badacc >> 31) != 0 : ((badacc & ~(2u * (unsigned)hb - 1u)) != 0);
+            if (live && bad) { status = FE_DECLINE; st = S_DONE; s_meta[lane] = 0u; }
+        }
+        have_flush = true;
+        if (have && st == S_DONE) finish();
+        if (__ballot(have) == 0) take();   // new frames when the whole wave is through with its old ones: the lanes then parse their headers in the same rounds
+        more = __ballot(st != S_DONE) != 0;
+    }
+    __syncthreads();
+    flush();
+}
+
+int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
+    if (!A.count) return AUKIT_OK;
+    AUKIT_HIP_CHECK(hipMemsetAsync(A.ticket, 0, 4, ctx->stream));
+    static const int wgs = getenv("AUKIT_FLAC_FUSED_WGS") ? atoi(getenv("AUKIT_FLAC_FUSED_WGS")) : 8;
+    const unsigned grid = std::min<unsigned>((A.count + 63) / 64, (unsigned)ctx->num_cus * (unsigned)std::max(wgs, 1));
+    hipLaunchKernelGGL(k_flac_decode, dim3(grid), dim3(64), 0, ctx->stream, A);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+
+// chained frames: scratch → rows.  One workgroup per candidate; 16 bytes per thread and turn where everything is aligned.
+__global__ __launch_bounds__(256) void k_flac_gather(const Cand *cands, const CandInfo *ci, unsigned ncand, int C, const u64 *row_off, const u64 *frame_base, const int *scratch,
+                                                    int *rows, FrameRec *frames) {
+    const unsigned k = blockIdx.x;
+    if (k >= ncand) return;
+    const CandInfo f = ci[k];
+    if (!f.used) return;
+    const unsigned s = cands[k].stream;
+    if (threadIdx.x == 0) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
+    for (int c = 0; c < f.nsub; c++) {
+        const int *src = scratch + f.scratch + (u64)c * (u64)f.blocksize;
+        int *dst = rows + row_off[(size_t)s * C + c] + f.sample_off;
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (f.blocksize & 3) == 0) {
+            for (int i = threadIdx.x; i < f.blocksize / 4; i += 256) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        } else {
+            for (int i = threadIdx.x; i < f.blocksize; i += 256) dst[i] = src[i];
+        }
+    }
+}
+
+int flac_gather_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, int C, const u64 *row_off, const u64 *frame_base, const int *scratch, int *rows,
+                       FrameRec *frames) {
+    if (!ncand) return AUKIT_OK;
+    hipLaunchKernelGGL(k_flac_gather, dim3(ncand), dim3(256), 0, ctx->stream, cands, ci, ncand, C, row_off, frame_base, scratch, rows, frames);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+
+}  // namespace aukit

@@ -142,7 +142,9 @@ int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 /* counters of the most recent call that produced them (AUKIT_OPT_COLLECT_STATS = 1) */
 typedef enum {
     AUKIT_COUNTER_DFPWM_CHUNKS = 0,        /* chunks the parallel DFPWM decoder cut the batch into (aukit.dfpwm, stream.dfpwm, the transcode) */
-    AUKIT_COUNTER_DFPWM_CHUNKS_REDONE = 1  /* of those, the ones whose warmed-up start state differed from the true one and were decoded again */
+    AUKIT_COUNTER_DFPWM_CHUNKS_REDONE = 1, /* of those, the ones whose warmed-up start state differed from the true one and were decoded again */
+    AUKIT_COUNTER_FLAC_FUSED = 2           /* 1: the most recent FLAC decode was served by the fused decoder (flac_fused.hip); 0: a frame it declines was on
+                                              the chain (or the batch is deeper than 24 bits) and the two-kernel decoder ran.  Set without COLLECT_STATS. */
 } aukit_counter;
 int aukit_ctx_get_counter(aukit_ctx *ctx, int counter, uint64_t *value);
 /* hipEvent pair on the ctx stream: begin(); ...launches...; end() → elapsed milliseconds */
