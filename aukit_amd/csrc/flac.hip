@@ -1546,6 +1546,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.C = C; A.depth = D.depth;
             A.scratch = reinterpret_cast<int *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
             A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket;
+            A.dbg = getenv("AUKIT_FLAC_FUSED_DBG") ? atoi(getenv("AUKIT_FLAC_FUSED_DBG")) : 0;
             return flac_fused_launch(ctx, A);
         };
         std::vector<ChainOut> chain(n);

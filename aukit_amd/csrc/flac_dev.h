@@ -88,6 +88,7 @@ struct FusedArgs {
     unsigned *flags;
     int limit_factor;
     unsigned *ticket;
+    int dbg;                 // ablation switches (AUKIT_FLAC_FUSED_DBG; wrong results): 1 no prediction, 2 no stores, 4 no read-back of parked values
 };
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A);
 // chained frames: scratch → rows (one workgroup per candidate; unused candidates leave at once), and the frame records in stream order

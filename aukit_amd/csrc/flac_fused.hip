@@ -33,18 +33,20 @@ constexpr unsigned FRING = 2 * FWN - 1;
 
 enum { S_FRAME = 0, S_SUB, S_RUN, S_CONST, S_COEF, S_PART, S_SUBEND, S_FRAMEEND, S_DONE };
 
-// MSB-first reader of the generic (rare) code: the lane's ring window in LDS, global memory outside it
+// MSB-first reader of the generic (rare) code, on the lane's ring window in LDS ONLY: a generic step starts with 32 bytes of window in front of it
+// (the round ends otherwise and the window slides), which covers every header of an ordinary stream; a read beyond it — a unary run of
+// hundreds of zero bits — raises `oow` and the frame is declined.  (With a global-memory path in here hipcc put `s_waitcnt vmcnt(0)` behind
+// every field read — a join — and each one waited for the window lines requested at the top of the round.)
 struct FRd {
     const unsigned *lw;    // ring: lw[k & 31] = big-endian dword k of the batch (counted from G.w0) for the dwords [2 win_lo, 2 win_lo + 32)
-    const unsigned *g32;   // the batch as raw dwords from G.w0
-    u64 safe_dw, win_lo, pos, end;
-    int eof;
+    u64 win_lo, pos, end;
+    int eof, oow;
 };
-AUKIT_DEV unsigned rd_dword(const FRd &r, u64 k) {
-    if (k - 2 * r.win_lo < (u64)(2 * FWN)) return r.lw[(unsigned)k & FRING];
-    return k < r.safe_dw ? __builtin_bswap32(r.g32[k]) : 0u;
+AUKIT_DEV unsigned rd_dword(FRd &r, u64 k) {
+    if (k - 2 * r.win_lo >= (u64)(2 * FWN)) r.oow = 1;
+    return r.lw[(unsigned)k & FRING];
 }
-AUKIT_DEV unsigned rd_peek(const FRd &r) {   // the next 32 bits
+AUKIT_DEV unsigned rd_peek(FRd &r) {   // the next 32 bits
     const u64 d = r.pos >> 5;
     const unsigned u = (unsigned)r.pos & 31u;
     const unsigned a = rd_dword(r, d);
@@ -170,9 +172,7 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
 
     FRd b;
     b.lw = s_win + lane * FWS;
-    b.g32 = reinterpret_cast<const unsigned *>(A.G.w0);
-    b.safe_dw = 2 * A.G.safe_words;
-    b.win_lo = 0; b.pos = 0; b.end = 0; b.eof = 0;
+    b.win_lo = 0; b.pos = 0; b.end = 0; b.eof = 0; b.oow = 0;
     u64 limit = ~0ull;
     bool have = false, fresh = true;
     unsigned idx = 0, nolimit = 0;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
         (void)si;
         b.end = A.G.base_bit + 8 * A.G.off[c.stream + 1];
         b.pos = A.G.base_bit + 8 * c.byte;
-        b.eof = 0;
+        b.eof = 0; b.oow = 0;
         b.win_lo = 0;
         limit = ~0ull;
         nolimit = c.nolimit;
@@ -231,6 +231,10 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
     for (int i = 0; i < 8; i++) tpre[i] = make_uint4(0, 0, 0, 0);
     auto flush = [&]() {
         if (flush_fast) {
+            // every requested value is awaited HERE, once, before the first store: hipcc cannot count loads across the branches below and would
+            // wait vmcnt(0) at each use — behind the stores of the iteration before it, i.e. for those stores (2.5 of the first version's 10 ms)
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" : "+v"(tpre[i].x), "+v"(tpre[i].y), "+v"(tpre[i].z), "+v"(tpre[i].w));
             const int grp = lane >> 3, q4 = 4 * (lane & 7);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -275,7 +279,10 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
 
     bool more = true;
     while (more) {
-        // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per window, 8 windows per load
+        // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per window, 8 windows per load.
+        // Three passes over the eight windows a lane loads for, so that ONE wait covers the round's loads: hipcc cannot count loads across the
+        // branches of a pass and waits vmcnt(0) at every use — with "use line i, request its successor" in one pass every iteration waited for
+        // the request of the iteration before it (eight memory latencies per round: half of the first version's 9.5 ms).
         {
             const u64 wi = b.pos >> 6;
             const bool want = st != S_DONE && (fresh || (wi - b.win_lo) >= (u64)(FWN / 4));
@@ -283,32 +290,48 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
             const u64 keep_from = fresh ? ~0ull : b.win_lo / 2 + FWN / 2;   // first 16-byte line the ring does not hold yet
             if (want) b.win_lo = new_lo;
             const int sub8 = lane % FLPW, grp = lane / FLPW;
+            unsigned act = 0;
+            // the lines requested a round ago are awaited here, once and unconditionally (see flush)
 #pragma unroll
-            for (int i = 0; i < FLPW; i++) {
-                const int s = i * (64 / FLPW) + grp;
-                const int w = __shfl((int)want, s);
-                const u64 ws = __shfl(new_lo, s);
-                const u64 kf = __shfl(keep_from, s);
-                if (w) {
+            for (int i = 0; i < FLPW; i++) asm volatile("" : "+v"(pf[i].x), "+v"(pf[i].y), "+v"(pf[i].z), "+v"(pf[i].w));
+            if (__any(want)) {
+#pragma unroll
+                for (int i = 0; i < FLPW; i++) {   // pass 1: which lines move in; the ones that were not requested a round ago (a new frame) are requested now
+                    const int s = i * (64 / FLPW) + grp;
+                    const int w = __shfl((int)want, s);
+                    const u64 ws = __shfl(new_lo, s);
+                    const u64 kf = __shfl(keep_from, s);
                     const u64 l0 = ws / 2, line = l0 + (((u64)sub8 - l0) & (u64)(FLPW - 1));   // ring slot sub8 holds the line congruent to sub8
-                    if (kf == ~0ull || line >= kf || line < kf - FWN / 2) {
-                        uint4 v = pf[i];
+                    if (w && (kf == ~0ull || line >= kf || line < kf - FWN / 2)) {
+                        act |= 1u << i;
                         if (pf_line[i] != line) {
-                            v = make_uint4(0, 0, 0, 0);
-                            if (2 * line < A.G.safe_words) v = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
+                            pf_line[i] = line;
+                            pf[i] = make_uint4(0, 0, 0, 0);
+                            if (2 * line < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
                         }
-                        unsigned *wrow = s_win + s * FWS + 4 * sub8;
-                        wrow[0] = __builtin_bswap32(v.x); wrow[1] = __builtin_bswap32(v.y);
-                        wrow[2] = __builtin_bswap32(v.z); wrow[3] = __builtin_bswap32(v.w);
-                        const u64 nl = line + FLPW;
-                        pf_line[i] = nl;
-                        pf[i] = make_uint4(0, 0, 0, 0);
-                        if (2 * nl < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * nl);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FLPW; i++) {   // pass 2: into the rings
+                    if (act & (1u << i)) {
+                        unsigned *wrow = s_win + (i * (64 / FLPW) + grp) * FWS + 4 * sub8;
+                        const bool inr = 2 * pf_line[i] < A.G.safe_words;   // (a line beyond the batch was requested at a dummy address: zeros)
+                        wrow[0] = inr ? __builtin_bswap32(pf[i].x) : 0u; wrow[1] = inr ? __builtin_bswap32(pf[i].y) : 0u;
+                        wrow[2] = inr ? __builtin_bswap32(pf[i].z) : 0u; wrow[3] = inr ? __builtin_bswap32(pf[i].w) : 0u;
                     }
                 }
             }
             __syncthreads();
-            if (have_flush) flush();
+            if (have_flush && !(A.dbg & 2)) flush();
+#pragma unroll
+            for (int i = 0; i < FLPW; i++) {       // pass 3: every slot's next line is requested now, a round or more before it is needed.  Straight-line:
+                // a slot that did not move asks for the line it already holds once more (a hit in L2) — a conditional load would be a branch, and
+                // behind a branch hipcc waits for everything in flight, the stores of the flush included
+                const u64 nl = pf_line[i] + ((act & (1u << i)) ? (u64)FLPW : 0ull);
+                pf_line[i] = nl;
+                const u64 la = (nl != ~0ull && 2 * nl < A.G.safe_words) ? 2 * nl : 0ull;
+                pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + la);
+            }
             __syncthreads();
             fresh = false;
         }
@@ -341,26 +364,26 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                     const int v_r = (int)(ur >> 1) ^ -(int)(ur & 1u);
                     const int v_f = __builtin_amdgcn_sbfe((int)hi, (unsigned)(32 - rk) & 31u, (unsigned)rk);
                     const int tot = fixed ? rk : tot_r;
-                    if (tot > 32) { slow = true; go = false; }   // a Rice code longer than 32 bits: the generic reader takes this one
-                    else {
-                        orow[cnt] = fixed ? v_f : v_r;
-                        s -= tot;
-                        const bool cross = s < 0;
-                        s &= 31;
-                        d += cross ? 1u : 0u;
-                        w0 = cross ? w1 : w0;
-                        w1 = cross ? wn : w1;
-                        wn = b.lw[(d + 2) & FRING];
-                        cnt++; remaining--;
-                        go = cnt < lim && remaining > 0 && (d + 1 - dwbase) < 25u;
-                    }
+                    const bool ok = tot <= 32;              // else a Rice code longer than 32 bits: the generic reader takes this one (nothing moves)
+                    orow[cnt] = fixed ? v_f : v_r;          // (a value that is not ok is overwritten by the generic reader's)
+                    s -= ok ? tot : 0;
+                    const bool cross = s < 0;
+                    s &= 31;
+                    d += cross ? 1u : 0u;
+                    w0 = cross ? w1 : w0;
+                    w1 = cross ? wn : w1;
+                    wn = b.lw[(d + 2) & FRING];
+                    cnt += ok ? 1 : 0; remaining -= ok ? 1 : 0;
+                    slow = !ok;
+                    go = ok && cnt < lim && remaining > 0 && (d + 1 - dwbase) < 25u;
                 }
                 if (run) {
                     b.pos = 32 * (dfull + (u64)(d - (unsigned)dfull) + 1) - (u64)s;
                     jpos += cnt - cnt0;
                     if (slow) {   // this one value by the generic reader
                         int v1 = 0;
-                        const int r1 = flac_rice_slow(b, rk, v1);
+                        int r1 = flac_rice_slow(b, rk, v1);
+                        if (!r1 && b.oow) r1 = FE_DECLINE;
                         if (r1) { status = r1; st = S_DONE; rdone = true; }
                         else { orow[cnt] = v1; cnt++; remaining--; jpos++; }
                     }
@@ -368,6 +391,7 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                 }
             }
             // -- everything else, one transition per turn (divergent, rare)
+            if (!rdone && ((b.pos >> 5) - (u64)2 * b.win_lo) >= 24 && st != S_SUBEND && st != S_FRAMEEND && !(st == S_RUN && remaining == 0)) rdone = true;   // a step that reads wants 32 bytes of window
             if (!rdone) {
                 if (st == S_RUN) {
                     if (remaining == 0) { st = after; if (after == S_PART) { pi++; if (pi >= nparts) st = S_SUBEND; } }
@@ -433,9 +457,12 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
 #pragma unroll
                         for (int q = 0; q < FMAXO; q++) if (q < order) coef[q] = rd_sget(b, precision);
                     } else {
-                        const int fc[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) coef[q] = q < order ? fc[order][q] : 0;
+                        // FIXED_PREDICTION_COEFFICIENTS[order + 1] = {}, {1}, {2, -1}, {3, -3, 1}, {4, -6, 4, -1}: binomials, by arithmetic (a table
+                        // would be a load from constant memory, and a vector-memory load in here puts a wait for the window prefetch behind it)
+                        coef[0] = order;
+                        coef[1] = order == 2 ? -1 : (order == 3 ? -3 : (order == 4 ? -6 : 0));
+                        coef[2] = order == 3 ? 1 : (order == 4 ? 4 : 0);
+                        coef[3] = order == 4 ? -1 : 0;
                     }
                     const int method = (int)rd_get(b, 2);
                     param_bits = method == 0 ? 4 : 5;
@@ -507,8 +534,7 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                     end_byte = (b.pos - A.G.base_bit) >> 3;
                     st = S_DONE; rdone = true;
                 }
-                // a generic step that ran the window low ends the round as well (the next step would read global memory)
-                if (!rdone && ((b.pos >> 5) - (u64)2 * b.win_lo) >= 26 && st != S_FRAMEEND && st != S_SUBEND) rdone = true;
+                if (b.oow && st != S_DONE) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // a field beyond the window: not an ordinary stream
             }
             go_on = __any(!rdone);
         }
@@ -527,17 +553,21 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
         // the 16-byte path needs whole vectors at aligned places (block sizes are multiples of 4 but for a stream's last frame)
         flush_fast = __all(!stores || ((cnt & 3) == 0 && (gptr & 3) == 0 && (mode != 2 || (bs & 3) == 0)));
         __syncthreads();
-        if (flush_fast) {   // the parked first-subframe values of the rounds that decorrelate: requested now, used by the flush at the top of the next round
+        {   // the parked first-subframe values of the rounds that decorrelate: requested now, used by the flush at the top of the next round.
+            // Straight-line and unconditional (a lane with nothing to fetch reads the scratch's first vector): inside an `if` hipcc merges the loaded
+            // registers with the old ones at the join — moves that wait for the loads right here
+            const bool ff = flush_fast && !(A.dbg & 4);
             const int grp = lane >> 3, q4 = 4 * (lane & 7);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int s = 8 * i + grp;
                 const unsigned m = s_meta[s];
-                if (((m >> 8) & 3u) == 2u && q4 < (int)(m & 0xFFu)) tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + s_ptr[s] + s_bs[s] + q4);
+                const bool need = ff && ((m >> 8) & 3u) == 2u && q4 < (int)(m & 0xFFu);
+                tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr[s] + (u64)s_bs[s] + (u64)q4 : 0ull));
             }
         }
         // ---- phase 2: the prediction, by the lane that decoded the values
-        if (__any(live)) {
+        if (__any(live) && !(A.dbg & 1)) {
             unsigned badacc = 0;
             const int pcnt = live ? cnt : 0;
             const bool anywide = __any(live && wide);
