@@ -137,6 +137,13 @@ struct aukit_audio {
     double lazy_rate = 0, lazy_full = 1;
     int lazy_interp = 0;
     aukit_ctx *lazy_ctx = nullptr;
+    // round 4: the rows may still lie frame by frame where the fused FLAC decoder left them (lazy_rows = its scratch) — lazy_tab then holds the
+    // frame records in stream order, each stream's first record, each stream's block size and the (stream, channel) offsets of the contiguous
+    // rows they would make; k_rs_onepole follows the records, every other consumer gathers the rows first (lazy_materialize)
+    bool lazy_indirect = false;
+    aukit::DevBuf lazy_tab;
+    uint64_t lazy_nfr = 0, lazy_tot = 0;
+    size_t lazy_o_fbase = 0, lazy_o_bs0 = 0, lazy_o_rowoff = 0;
 };
 
 struct aukit_chunks {
@@ -168,8 +175,11 @@ int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
 // the deferred resample of flac_tail.hip
 void lazy_drop(aukit_ctx *ctx, aukit_audio *a);
 int lazy_materialize(aukit_ctx *ctx, aukit_audio *a);
+struct LazyFrames {   // the fused FLAC decoder's frames (flac_dev.h), for a deferred resample that reads them in place
+    const void *d_frames; uint64_t nfr; const unsigned long long *d_fbase, *d_rowoff; const std::vector<int> *bs0; bool uniform; uint64_t tot_elems;
+};
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
-                       double full, aukit_audio **out, int *rc);
+                       double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr);
 bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc);
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 // the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time

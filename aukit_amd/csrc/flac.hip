@@ -798,6 +798,7 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
     const u64 endb = G.off[s + 1];
     u64 sp = 0;
     unsigned nf = 0;
+    int bs0 = 0, prev_bs = 0, uniform = 1;
     unsigned kc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // jobs per (order class, channel assignment): class * 4 + (0 = independent, 1..3 = 8..10)
     int stream_status = FE_OK;
     bool go = at < endb;  // readByte() → nil → decodeFrame returns false
@@ -813,6 +814,9 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
                 if (!sd) {}   // (the fused decoder, flac_fused.hip: no prediction jobs to count)
                 else if (C == 2) kc[4 * max(sd[(size_t)k * 2].kind & 3, sd[(size_t)k * 2 + 1].kind & 3) + (f.chan_asgn >= 8 ? f.chan_asgn - 7 : 0)] += 2;  // a stereo frame's two jobs share a wave (k_flac_jobs)
                 else for (int c = 0; c < f.nsub; c++) kc[4 * (sd[(size_t)k * C + c].kind & 3)]++;
+                if (nf == 0) bs0 = f.blocksize;
+                else if (prev_bs != bs0) uniform = 0;   // a frame that is not the last differs from the first
+                prev_bs = f.blocksize;
                 sp += (u64)f.blocksize;
                 nf++;
                 at = f.end_byte;
@@ -825,6 +829,8 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
         }
     }
     r.L = sp;
+    r.bs0 = bs0;
+    r.uniform = (uniform && prev_bs <= bs0) ? 1 : 0;
     r.nframes = nf;
     r.status = stream_status;
     out[s] = r;
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const Cand
             }
         }
     }
-    if (used) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
+    if (used) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, 0ull, f.blocksize, f.chan_asgn, s, 0};
 }
 
 // A value on its way out of the prediction (int32 rows): decorrelated against the partner lane's value of the same sample — lanes 2p / 2p+1
@@ -1279,6 +1285,13 @@ struct FlacDecoded {
     std::vector<uint64_t> fbase;
     std::vector<unsigned> nframes;
     uint64_t nfr = 0;
+    // the fused decoder (flac_fused.hip) leaves every frame's final integers where it decoded them — ctx->tmp_buf3, at FrameRec::scratch — and
+    // the consumers that can follow the frame records read them there (the loader's conversion, the deferred resample + one-pole pass,
+    // stream.flac's tail jobs); flac_rows_materialize() gathers contiguous rows into ctx->tmp_buf for the others
+    bool in_scratch = false;
+    uint64_t tot_elems = 0;          // elements of the contiguous rows (row_off / row_len describe them whether they exist yet or not)
+    std::vector<int> bs0;            // per stream: the first frame's block size
+    bool uniform = false;            // every stream: all frames but the last have bs0, the last no more
 };
 
 
@@ -1608,16 +1621,16 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             nfr += chain[s].nframes;
             D.status[s] = chain[s].status;
         }
-        if ((rc = ctx->tmp_buf.ensure((size_t)tot * 4 + 256))) return rc;
         if ((rc = ctx->seg_buf.ensure(nfr * sizeof(FrameRec) + 512))) return rc;
         ctx->plan_key.clear();
         FrameRec *d_frames = reinterpret_cast<FrameRec *>(ctx->seg_buf.p);
         if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8))) return rc;
-        if (nfr) {
-            if ((rc = ctx_begin_kernel(ctx))) return rc;
-            if ((rc = flac_gather_launch(ctx, d_cand, d_ci, ncand, C, d_rowoff, d_fbase, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<int *>(ctx->tmp_buf.p), d_frames))) return rc;
-            if ((rc = ctx_end_kernel(ctx, "k_flac_gather", 2 * tot * 4))) return rc;
-        }
+        if (nfr && (rc = flac_frames_launch(ctx, d_cand, d_ci, ncand, d_fbase, d_frames))) return rc;
+        D.in_scratch = true;
+        D.tot_elems = tot;
+        D.bs0.assign(n, 0);
+        D.uniform = true;
+        for (uint32_t s = 0; s < n; s++) { D.bs0[s] = chain[s].bs0; if (!chain[s].uniform) D.uniform = false; }
         std::vector<FrameRec> hfr;
         if (want_frames && nfr) {
             hfr.resize(nfr);
@@ -1636,6 +1649,20 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         D.wide = false;
         return AUKIT_OK;
     }
+}
+
+// contiguous int32 rows in ctx->tmp_buf from the frames the fused decoder left in ctx->tmp_buf3 (the consumers that want rows)
+static int flac_rows_materialize(aukit_ctx *ctx, FlacDecoded &D) {
+    if (!D.in_scratch) return AUKIT_OK;
+    int rc;
+    if ((rc = ctx->tmp_buf.ensure((size_t)D.tot_elems * 4 + 256))) return rc;
+    if (D.nfr) {
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        if ((rc = flac_gather_launch(ctx, D.d_frames, D.nfr, D.channels, D.d_rowoff, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<int *>(ctx->tmp_buf.p)))) return rc;
+        if ((rc = ctx_end_kernel(ctx, "k_flac_gather", 2 * D.tot_elems * 4))) return rc;
+    }
+    D.in_scratch = false;
+    return AUKIT_OK;
 }
 
 static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
@@ -1687,10 +1714,27 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     for (uint32_t s = 0; s < in->n; s++)
         if (D.status[s]) return fail(AUKIT_E_LUA, "%s", flac_err_msg(D.status[s]));  // decodeFLAC raises: the whole load fails
     const double full = std::ldexp(1.0, D.depth);  // :505
+    if (D.in_scratch && !do_resample && (dtype == AUKIT_F32 || dtype == AUKIT_F64)) {
+        // the loader without a resample: the frames go from where they were decoded straight into the audio's rows, converted on the way
+        std::vector<uint64_t> lens(in->n);
+        for (uint32_t s = 0; s < in->n; s++) {
+            lens[s] = D.row_len[(size_t)s * D.channels];
+            if (lens[s] > 0x7FFFFFF0ull) return fail(AUKIT_E_UNSUPPORTED, "stream too long");
+        }
+        aukit_audio *a = *out;
+        if ((rc = audio_prepare(ctx, &a, in->n, D.channels, D.rate, dtype, lens.data()))) return rc;
+        *out = a;
+        if (!D.nfr) return AUKIT_OK;
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        if ((rc = flac_gather_convert_launch(ctx, D.d_frames, D.nfr, D.channels, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<const u64 *>(a->d_meta), in->n, a->dev, dtype, full))) return rc;
+        return ctx_end_kernel(ctx, "k_flac_gather<convert>", D.tot_elems * 4 + D.tot_elems * dtype_size(dtype));
+    }
     if (!D.wide && do_resample && dtype == AUKIT_F32) {   // F32 pipelines: the resample is owed — a following effects.highpass / lowpass pays it in its own pass (flac_tail.hip)
         int lrc = AUKIT_OK;
-        if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc)) return lrc;
+        LazyFrames LF{D.d_frames, D.nfr, D.d_fbase, D.d_rowoff, &D.bs0, D.uniform, D.tot_elems};
+        if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc, D.in_scratch ? &LF : nullptr)) return lrc;
     }
+    if ((rc = flac_rows_materialize(ctx, D))) return rc;
     if (D.wide) return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, 1, 1, out);
     return audio_from_int_rows(ctx, SRC_I32, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, full, full, out);
 }
@@ -1823,7 +1867,7 @@ __global__ __launch_bounds__(64) void k_flac_stream_iir(const FsJob *jobs, const
 // the tail jobs of stream.flac (one per (frame, channel), in the order the reference walks them) from the frame records the decoder left on the
 // device: one lane per stream — `last = {src[#src-1], src[#src]}` is shared across channels and frames (Q14), so a stream's jobs chain
 __global__ __launch_bounds__(64) void k_flac_tail_jobs(const FrameRec *frames, const u64 *fbase, const unsigned *nframes, const u64 *rowoff, const u64 *a_meta, unsigned n, int C,
-                                                      double ratio, TailJob *jobs) {
+                                                      double ratio, TailJob *jobs, int in_scratch) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     const u64 *a_row_off = a_meta + n, *a_row_stride = a_meta + 2 * (size_t)n;
@@ -1834,7 +1878,7 @@ __global__ __launch_bounds__(64) void k_flac_tail_jobs(const FrameRec *frames, c
         const int nout = (int)floor((double)fr.bs * ratio);
         for (int c = 0; c < C; c++) {
             TailJob j;
-            j.src_off = rowoff[(size_t)s * C + c] + fr.sample_off;
+            j.src_off = in_scratch ? fr.scratch + (u64)c * (u64)fr.bs : rowoff[(size_t)s * C + c] + fr.sample_off;   // (the fused decoder's frames are read where they lie)
             j.last_off = l2; j.m1_off = l1;
             j.out_off = a_row_off[s] + (u64)c * a_row_stride[s] + op;
             j.src_cstride = j.last_cstride = j.out_cstride = 0;
@@ -1911,11 +1955,11 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             unsigned *dnf = reinterpret_cast<unsigned *>(dj + njobs);
             if ((rc = h2d_table(ctx, dnf, D.nframes.data(), (size_t)in->n * 4))) { delete ck; return rc; }
             hipLaunchKernelGGL(k_flac_tail_jobs, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, D.d_frames, D.d_fbase, dnf, D.d_rowoff, reinterpret_cast<const u64 *>(a->d_meta), in->n, C,
-                               ratio, dj);
+                               ratio, dj, D.in_scratch ? 1 : 0);
             if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_flac_tail_jobs launch failed"); }
             lap("plan + jobs");
             int trc = AUKIT_OK;
-            if (iir_tail_try_dev(ctx, TAIL_FLAC, rk, ctx->tmp_buf.p, fullv, dj, njobs, max_nout, sum_nout, 1, D.rate, interp, dtype, a->dev, in->total() + sum_nout * dtype_size(dtype),
+            if (iir_tail_try_dev(ctx, TAIL_FLAC, rk, D.in_scratch ? ctx->tmp_buf3.p : ctx->tmp_buf.p, fullv, dj, njobs, max_nout, sum_nout, 1, D.rate, interp, dtype, a->dev, in->total() + sum_nout * dtype_size(dtype),
                                  "k_iir_tail<flac>", &trc)) {
                 if (trc) { delete ck; return trc; }
                 lap("tail launch");
@@ -1924,6 +1968,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             }
         }
     }
+    if ((rc = flac_rows_materialize(ctx, D))) { delete ck; return rc; }
     std::vector<FsJob> jobs;
     uint64_t nouts = 0;
     for (uint32_t s = 0; s < in->n; s++) {

@@ -599,30 +599,62 @@ int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
     return AUKIT_OK;
 }
 
-// chained frames: scratch → rows.  One workgroup per candidate; 16 bytes per thread and turn where everything is aligned.
-__global__ __launch_bounds__(256) void k_flac_gather(const Cand *cands, const CandInfo *ci, unsigned ncand, int C, const u64 *row_off, const u64 *frame_base, const int *scratch,
-                                                    int *rows, FrameRec *frames) {
-    const unsigned k = blockIdx.x;
+__global__ __launch_bounds__(64) void k_flac_frames(const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames) {
+    const unsigned k = blockIdx.x * 64 + threadIdx.x;
     if (k >= ncand) return;
     const CandInfo f = ci[k];
     if (!f.used) return;
     const unsigned s = cands[k].stream;
-    if (threadIdx.x == 0) frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.blocksize, f.chan_asgn, s, 0};
-    for (int c = 0; c < f.nsub; c++) {
-        const int *src = scratch + f.scratch + (u64)c * (u64)f.blocksize;
-        int *dst = rows + row_off[(size_t)s * C + c] + f.sample_off;
-        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (f.blocksize & 3) == 0) {
-            for (int i = threadIdx.x; i < f.blocksize / 4; i += 256) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.scratch, f.blocksize, f.chan_asgn, s, 0};
+}
+int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames) {
+    if (!ncand) return AUKIT_OK;
+    hipLaunchKernelGGL(k_flac_frames, dim3((ncand + 63) / 64), dim3(64), 0, ctx->stream, cands, ci, ncand, frame_base, frames);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+
+// chained frames: scratch → rows.  One workgroup per frame; 16 bytes per thread and turn where everything is aligned.  OUT = int: the decoder's
+// integers as they are; float / double: the loader's `s / 2^depth` (:505; an exact scaling) straight into an audio's rows.
+template <typename OUT>
+__global__ __launch_bounds__(256) void k_flac_gather(const FrameRec *frames, int C, const u64 *row_off, const u64 *a_meta, unsigned n, const int *scratch, OUT *rows, double inv_full) {
+    const FrameRec f = frames[blockIdx.x];
+    const int nch = f.chan_asgn >= 8 ? 2 : C;
+    for (int c = 0; c < nch; c++) {
+        const int *src = scratch + f.scratch + (u64)c * (u64)f.bs;
+        OUT *dst = rows + (row_off ? row_off[(size_t)f.stream * C + c] : a_meta[n + f.stream] + (u64)c * a_meta[2 * (size_t)n + f.stream]) + f.sample_off;
+        if constexpr (std::is_same<OUT, int>::value) {
+            if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (f.bs & 3) == 0) {
+                for (int i = threadIdx.x; i < f.bs / 4; i += 256) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+            } else {
+                for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = src[i];
+            }
         } else {
-            for (int i = threadIdx.x; i < f.blocksize; i += 256) dst[i] = src[i];
+            if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (f.bs & 3) == 0) {
+                for (int i = threadIdx.x; i < f.bs / 4; i += 256) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(src)[i];
+                    typedef OUT ov4 __attribute__((ext_vector_type(4), aligned(16)));
+                    ov4 w;
+                    w[0] = (OUT)((double)(int)v.x * inv_full); w[1] = (OUT)((double)(int)v.y * inv_full);
+                    w[2] = (OUT)((double)(int)v.z * inv_full); w[3] = (OUT)((double)(int)v.w * inv_full);
+                    *reinterpret_cast<ov4 *>(dst + 4 * i) = w;
+                }
+            } else {
+                for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = (OUT)((double)src[i] * inv_full);
+            }
         }
     }
 }
-
-int flac_gather_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, int C, const u64 *row_off, const u64 *frame_base, const int *scratch, int *rows,
-                       FrameRec *frames) {
-    if (!ncand) return AUKIT_OK;
-    hipLaunchKernelGGL(k_flac_gather, dim3(ncand), dim3(256), 0, ctx->stream, cands, ci, ncand, C, row_off, frame_base, scratch, rows, frames);
+int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows) {
+    if (!nfr) return AUKIT_OK;
+    hipLaunchKernelGGL((k_flac_gather<int>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, row_off, (const u64 *)nullptr, 0u, scratch, rows, 1.0);
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return AUKIT_OK;
+}
+int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full) {
+    if (!nfr) return AUKIT_OK;
+    if (dtype == AUKIT_F32) hipLaunchKernelGGL((k_flac_gather<float>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<float *>(out), 1.0 / full);
+    else hipLaunchKernelGGL((k_flac_gather<double>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<double *>(out), 1.0 / full);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }

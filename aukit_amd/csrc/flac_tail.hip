@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "resample.h"
+#include "flac_dev.h"
 
 namespace aukit {
 
@@ -34,6 +35,11 @@ struct RsOnepoleParams {
     float inv_b, scale;
     double coef;
     const float *wg;   // cubic: the four tap weights of each of the fb output phases (null: the Horner form on fx = rem / fb)
+    // round 4: the rows frame by frame where the fused FLAC decoder left them (null: contiguous rows at row_off).  Every stream's frames but its
+    // last have bs0[stream] samples, and a tile's window is shorter than that: it lies in one frame or two consecutive ones
+    const FrameRec *frames;
+    const unsigned long long *fbase;
+    const int *bs0;
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
@@ -92,13 +98,37 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     // are the edge samples repeated.  Its first 512 entries travel through registers, loaded one tile AHEAD (a row is a serial chain of tiles:
     // a load waited for where it is issued costs its whole latency, eight times per tile in the first cut of this loop)
     auto tile_nst = [&](unsigned rr, int cn) { const unsigned nn = rr + ((unsigned)cn - 1) * P.fa; return (int)__umulhi(nn, P.fmagic) + 4; };
+    // frame-by-frame rows: sample i of the row lies at base0 + i (the frame that holds the window's first sample) or base1 + i (the frame after
+    // it).  The records are walked as the tiles advance, the one after next already loaded (base2): no look-up sits in front of a tile's loads
+    const int bsn = P.frames ? P.bs0[s] : 0;
+    const unsigned nfr_s = P.frames ? (unsigned)(P.fbase[s + 1] - P.fbase[s]) : 0u;
+    const FrameRec *const fr_s = P.frames ? P.frames + P.fbase[s] : nullptr;
+    long long base0 = 0, base1 = 0, base2 = 0;
+    int bound = 0x7FFFFFFF;
+    unsigned fcur = 0;
+    auto rec_base = [&](unsigned f) -> long long { const FrameRec a = fr_s[f]; return (long long)a.scratch + (long long)c * a.bs - (long long)f * bsn; };
+    if (P.frames && L > 0 && nfr_s > 0) {
+        base0 = rec_base(0);
+        bound = bsn;
+        base1 = nfr_s > 1 ? rec_base(1) : base0;
+        base2 = nfr_s > 2 ? rec_base(2) : base1;
+    }
     auto fetch = [&](unsigned kk, int nst, int (&pre)[8]) {
+        if (P.frames && L > 0) {
+            const unsigned k0 = kk < 1u ? 1u : (kk > (unsigned)L ? (unsigned)L : kk);
+            while ((int)(k0 - 1u) >= bound && fcur + 1u < nfr_s) {
+                fcur++;
+                base0 = base1; base1 = base2; bound += bsn;
+                if (fcur + 2u < nfr_s) base2 = rec_base(fcur + 2u);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int j = lane + 64 * u;
             const unsigned k = kk + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
-            pre[u] = (j < nst && L > 0) ? row[kc - 1] : 0;
+            const int *src = P.frames ? P.rows + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
+            pre[u] = (j < nst && L > 0) ? *src : 0;
         }
     };
     int pre[8];
@@ -113,10 +143,11 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 8; u++) win[lane + 64 * u] = (float)pre[u] * P.scale;   // (cap >= 512)
-        for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output
+        for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output (base0 / base1 / bound still describe THIS tile: the fetch below moves them on)
             const unsigned k = kb + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
-            win[j] = L > 0 ? (float)row[kc - 1] * P.scale : 0.f;
+            const int *src = P.frames ? P.rows + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
+            win[j] = L > 0 ? (float)*src * P.scale : 0.f;
         }
         unsigned kb_n = kb + wc, r0_n = r0 + wd;
         if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
@@ -231,10 +262,12 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
 void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
     a->lazy_rs = false;
     if (a->lazy_rows.p) {
-        if (ctx && ctx->tmp_buf.cap < a->lazy_rows.cap) { ctx->tmp_buf.release(); ctx->tmp_buf = a->lazy_rows; a->lazy_rows = DevBuf{}; }
+        DevBuf *home = ctx ? (a->lazy_indirect ? &ctx->tmp_buf3 : &ctx->tmp_buf) : nullptr;   // where the buffer came from
+        if (home && home->cap < a->lazy_rows.cap) { home->release(); *home = a->lazy_rows; a->lazy_rows = DevBuf{}; }
         else a->lazy_rows.release();
     }
     a->lazy_row_off.clear(); a->lazy_row_len.clear();
+    a->lazy_indirect = false;   // (lazy_tab keeps its allocation for the next call: freeing it here would wait for the kernel that reads it)
 }
 
 // the owed resample with the ordinary kernel, into the audio's own rows
@@ -243,10 +276,23 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
     if (!ctx) ctx = a->lazy_ctx;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred resample and no context to run it with");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
-    // the rows move back into the context's scratch: the wave kernels of audio_from_int_rows take them from there
-    ctx->tmp_buf.release();
-    ctx->tmp_buf = a->lazy_rows;
-    a->lazy_rows = DevBuf{};
+    if (a->lazy_indirect) {   // frame by frame in the fused decoder's scratch: contiguous rows first (k_flac_gather)
+        int grc;
+        if ((grc = ctx->tmp_buf.ensure((size_t)a->lazy_tot * 4 + 256))) return grc;
+        const char *T = reinterpret_cast<const char *>(a->lazy_tab.p);
+        if ((grc = ctx_begin_kernel(ctx))) return grc;
+        if ((grc = flac_gather_launch(ctx, reinterpret_cast<const FrameRec *>(T), a->lazy_nfr, a->channels, reinterpret_cast<const u64 *>(T + a->lazy_o_rowoff),
+                                      reinterpret_cast<const int *>(a->lazy_rows.p), reinterpret_cast<int *>(ctx->tmp_buf.p)))) return grc;
+        if ((grc = ctx_end_kernel(ctx, "k_flac_gather", 2 * a->lazy_tot * 4))) return grc;
+        if (ctx->tmp_buf3.cap < a->lazy_rows.cap) { ctx->tmp_buf3.release(); ctx->tmp_buf3 = a->lazy_rows; a->lazy_rows = DevBuf{}; }   // the scratch goes home
+        else a->lazy_rows.release();
+        a->lazy_indirect = false;
+    } else {
+        // the rows move back into the context's scratch: the wave kernels of audio_from_int_rows take them from there
+        ctx->tmp_buf.release();
+        ctx->tmp_buf = a->lazy_rows;
+        a->lazy_rows = DevBuf{};
+    }
     a->lazy_rs = false;
     const std::vector<uint64_t> ro = a->lazy_row_off, rl = a->lazy_row_len;
     aukit_audio *self = a;
@@ -255,7 +301,7 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
 
 // after the decoder has left int32 rows in ctx->tmp_buf: shape *out as the resampled audio and leave the resample owed.  false: not this shape
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
-                       double full, aukit_audio **out, int *rc) {
+                       double full, aukit_audio **out, int *rc, const LazyFrames *LF) {
     *rc = AUKIT_OK;
     if (getenv("AUKIT_NO_TAIL_FUSION") || ctx->exact_math || (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) || n == 0) return false;
     FastParams F;
@@ -272,12 +318,40 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
         if (Ls == 0 || lens[s] == 0) return false;                          // (the ordinary path has the reference's answers for empty rows)
         if (std::floor(((double)(lens[s] - 1)) / ratio + 1) > (double)Ls) return false;
     }
+    if (LF) {
+        // frame-by-frame rows are read in place only where a tile's window (k_rs_onepole: 512 outputs) spans at most two frames of its stream
+        if (!LF->uniform || !LF->nfr) return false;
+        const uint64_t capw = std::max<uint64_t>(512, (512ull * F.a) / F.b + 19);
+        for (uint32_t s = 0; s < n; s++) if ((uint64_t)(*LF->bs0)[s] < capw) return false;
+    }
     aukit_audio *a = *out;
     if ((*rc = audio_prepare(ctx, &a, n, C, new_rate, AUKIT_F32, lens.data()))) return true;
     *out = a;
     a->lazy_rows.release();
-    a->lazy_rows = ctx->tmp_buf;     // the rows leave the context's scratch with the audio: nothing can overwrite them
-    ctx->tmp_buf = DevBuf{};
+    a->lazy_indirect = false;
+    if (LF) {
+        // the scratch leaves the context with the audio, and so do the records that say where its frames lie
+        Carve cv;
+        const size_t o_fr = cv.take(LF->nfr * sizeof(FrameRec)), o_fb = cv.take(((size_t)n + 1) * 8), o_bs = cv.take((size_t)n * 4), o_ro = cv.take((size_t)n * C * 8);
+        (void)o_fr;
+        if ((*rc = a->lazy_tab.ensure(cv.at))) return true;
+        char *T = reinterpret_cast<char *>(a->lazy_tab.p);
+        std::vector<uint64_t> fb(n + 1, 0);
+        if (hipMemcpyAsync(T, LF->d_frames, LF->nfr * sizeof(FrameRec), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(T + o_fb, LF->d_fbase, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(T + o_ro, LF->d_rowoff, (size_t)n * C * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "copy of the frame records failed"); return true; }
+        const uint64_t nfr = LF->nfr;
+        if ((*rc = h2d_table(ctx, T + o_fb + (size_t)n * 8, &nfr, 8))) return true;          // fbase[n] = the number of records
+        if ((*rc = h2d_table(ctx, T + o_bs, LF->bs0->data(), (size_t)n * 4))) return true;
+        a->lazy_nfr = LF->nfr; a->lazy_tot = LF->tot_elems;
+        a->lazy_o_fbase = o_fb; a->lazy_o_bs0 = o_bs; a->lazy_o_rowoff = o_ro;
+        a->lazy_indirect = true;
+        a->lazy_rows = ctx->tmp_buf3;
+        ctx->tmp_buf3 = DevBuf{};
+    } else {
+        a->lazy_rows = ctx->tmp_buf;     // the rows leave the context's scratch with the audio: nothing can overwrite them
+        ctx->tmp_buf = DevBuf{};
+    }
     a->lazy_row_off = row_off; a->lazy_row_len = row_len;
     a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx;
     a->lazy_rs = true;
@@ -316,6 +390,12 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
     P.scale = (float)(1.0 / a->lazy_full);
     P.coef = coef;
+    if (a->lazy_indirect) {
+        const char *T = reinterpret_cast<const char *>(a->lazy_tab.p);
+        P.frames = reinterpret_cast<const FrameRec *>(T);
+        P.fbase = reinterpret_cast<const unsigned long long *>(T + a->lazy_o_fbase);
+        P.bs0 = reinterpret_cast<const int *>(T + a->lazy_o_bs0);
+    }
     if (tabw) {
         std::vector<float> w(4 * (size_t)F.b);
         for (unsigned r = 0; r < F.b; r++) {

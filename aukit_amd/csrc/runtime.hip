@@ -499,6 +499,7 @@ void aukit_audio_free(aukit_audio *a) {
     if (a->d_meta) (void)hipFree(a->d_meta);
     if (a->d_rowmax) (void)hipFree(a->d_rowmax);
     a->lazy_rows.release();
+    a->lazy_tab.release();
     delete a;
 }
 
