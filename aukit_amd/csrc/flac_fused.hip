@@ -351,11 +351,16 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                 const u64 dfull = (b.pos - 1) >> 5;                     // the dword that holds the last bit read (frames start far beyond bit 0)
                 unsigned d = (unsigned)dfull;
                 int s = (int)((0u - (unsigned)b.pos) & 31u);            // bits of it not yet read
-                unsigned w0 = b.lw[d & FRING], w1 = b.lw[(d + 1) & FRING], wn = b.lw[(d + 2) & FRING];   // wn: one dword ahead, off the dependency chain
+                unsigned w0 = b.lw[d & FRING], w1 = b.lw[(d + 1) & FRING];
+                asm volatile("" : "+v"(w0), "+v"(w1));   // awaited HERE: pending at the loop header they would put an lgkmcnt(0) there — which also waits for every turn's store
                 const int cnt0 = cnt;
                 bool slow = false;
-                bool go = run && cnt < lim && (d + 1 - dwbase) < 25u;
+                const unsigned dlim = dwbase + 24u;                     // the window is low beyond this dword
+                int n_it = min(lim - cnt, remaining);                   // values this lane may still take in this round
+                int *wp = orow + cnt;
+                bool go = run && n_it > 0 && (int)(d - dlim) < 0;
                 while (go) {
+                    const unsigned wn = b.lw[(d + 2) & FRING];          // for a crossing at the END of this turn: requested first, used last
                     const unsigned hi = __builtin_amdgcn_alignbit(w0, w1, (unsigned)s);
                     const int z = hi ? __builtin_clz(hi) : 32;
                     const int tot_r = z + 1 + rk;
@@ -365,18 +370,19 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                     const int v_f = __builtin_amdgcn_sbfe((int)hi, (unsigned)(32 - rk) & 31u, (unsigned)rk);
                     const int tot = fixed ? rk : tot_r;
                     const bool ok = tot <= 32;              // else a Rice code longer than 32 bits: the generic reader takes this one (nothing moves)
-                    orow[cnt] = fixed ? v_f : v_r;          // (a value that is not ok is overwritten by the generic reader's)
+                    *wp = fixed ? v_f : v_r;                // (a value that is not ok is overwritten by the generic reader's)
                     s -= ok ? tot : 0;
                     const bool cross = s < 0;
                     s &= 31;
                     d += cross ? 1u : 0u;
                     w0 = cross ? w1 : w0;
                     w1 = cross ? wn : w1;
-                    wn = b.lw[(d + 2) & FRING];
-                    cnt += ok ? 1 : 0; remaining -= ok ? 1 : 0;
+                    wp += ok ? 1 : 0; n_it -= ok ? 1 : 0;
                     slow = !ok;
-                    go = ok && cnt < lim && remaining > 0 && (d + 1 - dwbase) < 25u;
+                    go = ok && n_it > 0 && (int)(d - dlim) < 0;
                 }
+                if (run) { const int got = (int)(wp - orow) - cnt; cnt += got; remaining -= got; }
+                (void)cnt0;
                 if (run) {
                     b.pos = 32 * (dfull + (u64)(d - (unsigned)dfull) + 1) - (u64)s;
                     jpos += cnt - cnt0;

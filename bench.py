@@ -59,6 +59,37 @@ def _measured_traffic(kernel, args):
     return None
 
 
+def _cpu_pcm16(n_samples, channels, rate, seed_base, count):
+    """`count` distinct config-1 style s16 signals (0.5 sine(440 Hz) + uniform noise ±0.25) as byte strings, for the CPU leg"""
+    import numpy as np
+    t = np.arange(n_samples) / rate
+    sine = 0.5 * np.sin(2 * np.pi * 440 * t)
+    out = []
+    for i in range(count):
+        rng = np.random.Generator(np.random.PCG64(0xA0C17 + seed_base + i))
+        x = sine[:, None] + rng.uniform(-0.25, 0.25, (n_samples, channels))
+        out.append(np.round(x * 32767).astype(np.int16).tobytes())
+    return out
+
+
+def _cpu_random_bytes(n, seed_base, count):
+    import numpy as np
+    return [np.random.Generator(np.random.PCG64(0xA0C17 + seed_base + i)).integers(0, 256, n, dtype=np.uint8).tobytes() for i in range(count)]
+
+
+def _measured_traffic_step(workload, args):
+    """HBM bytes per STEP of a multi-launch workload: the sum over every kernel of the step of FETCH_SIZE x 2 + WRITE_SIZE from the committed PMC
+    passes of this same command (profiles/traffic.json, `steps` entries); None when no matching measurement is committed."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
+            for e in json.load(fh).get("steps", []):
+                if e["workload"] == workload and e["streams"] == args.streams and e["seconds"] == args.seconds:
+                    return e
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def _fixture(name):
     """an encoder-made input cached under bench_data/ (tools/make_bench_inputs.py wrote it with the oracle's generators — once, not at bench
     time: the bench itself needs the checker only for the cpu_baseline leg)"""
@@ -87,8 +118,35 @@ class Workload:
     name = unit = desc = ""
     distinct = None   # how many distinct streams the synthetic batch cycles through (None: every stream is its own)
 
-    def cpu_baseline(self, args):
+    def cpu_one(self, args):
+        """(one, sample): one(i) runs the oracle's entry points of this workload on the i-th of its distinct CPU inputs and returns the units it
+        produced (the metric's unit); sample describes the inputs.  None: no CPU leg (selftest)."""
         return None
+
+    def cpu_baseline(self, args):
+        """The C oracle (reference arithmetic, scalar fp64: `kind: port`) timed on this box's host cores on a BOUNDED sample of the workload:
+        one thread for about args.cpu_seconds, then every core (one stream per task) for about as long."""
+        got = self.cpu_one(args)
+        if not got:
+            return None
+        import concurrent.futures
+        one, sample = got
+        t0 = time.perf_counter()
+        done = one(0)
+        t_first = max(time.perf_counter() - t0, 1e-5)
+        n1 = int(max(1, min(args.cpu_streams, args.cpu_seconds / t_first)))
+        for i in range(1, n1):
+            done += one(i)
+        dt = time.perf_counter() - t0
+        cores = os.cpu_count() or 1
+        n_all = int(max(cores, min(args.cpu_streams, cores * (args.cpu_seconds / 2) / (dt / n1))))
+        t1 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL around the C calls
+            done_all = sum(ex.map(one, range(n_all)))
+        dt_all = time.perf_counter() - t1
+        return {"value": done / dt / 1e6, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"{n1} streams of the workload's shape ({sample}), scalar fp64 C oracle (reference arithmetic), {dt:.1f} s",
+                "all_cores": {"value": done_all / dt_all / 1e6, "unit": self.unit, "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
 
     def task_bytes(self):
         return None
@@ -105,6 +163,7 @@ class Pcm16Cubic(Workload):
         self.d = B.make_desc(N.CODEC_PCM, 1, SRC_RATE, 16, "signed")
         self.out = B.AudioBatch(ctx)
         self.dtype = N.F32 if args.dtype == "f32" else N.F64
+        self.interp = args.interp
         self.step = lambda: B.decode_resample(ctx, self.bt, self.d, DST_RATE, args.interp, dtype=self.dtype, out=self.out)
         self.desc = (f"{args.streams}x s16le 44.1kHz mono {args.seconds:g}s per GPU -> aukit.pcm:resample(48000,'cubic'), "
                      f"{args.dtype} store (SURVEY 8d config T)")
@@ -116,33 +175,13 @@ class Pcm16Cubic(Workload):
     def task_bytes(self):
         return int(self.x.numel()) * 2 + self.out_samples() * (4 if self.dtype == 1 else 8)
 
-    def cpu_baseline(self, args):
-        import numpy as np
+    def cpu_one(self, args):
         from oracle import oracle as O
         O.build()
-        # DISTINCT streams of the workload's shape (64 of them = 56 MB of input + a fresh 3.8 MB fp64 row per call: not cache-resident), cycled
-        t = np.arange(self.n_samples) / SRC_RATE
-        sine = 0.5 * np.sin(2 * np.pi * 440 * t)
-        distinct = []
-        for i in range(min(64, max(args.cpu_streams, 1))):
-            rng = np.random.Generator(np.random.PCG64(0xA0C17 + 1000 + i))
-            distinct.append(np.round((sine + rng.uniform(-0.25, 0.25, self.n_samples)) * 32767).astype(np.int16).tobytes())
-        one = lambda i: len(O.resample(O.pcm(distinct[i % len(distinct)], 16, O.SIGNED, 1, SRC_RATE), DST_RATE, O.CUBIC).data[0])
-        done, t0 = 0, time.perf_counter()
-        for i in range(args.cpu_streams):
-            done += one(i)
-        dt = time.perf_counter() - t0
-        # (ii) every host core, one stream per task; ctypes releases the GIL around the C calls
-        import concurrent.futures
-        cores = os.cpu_count() or 1
-        t1 = time.perf_counter()
-        with concurrent.futures.ThreadPoolExecutor(cores) as ex:
-            n_all = max(args.cpu_streams, min(args.streams, 16 * cores))
-            done_all = sum(ex.map(one, range(n_all)))
-        dt_all = time.perf_counter() - t1
-        return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                "sample": f"{args.cpu_streams} streams of the workload's shape ({self.n_samples} samples each, {len(distinct)} distinct ones cycled), scalar fp64 C oracle (reference arithmetic), {dt:.1f} s",
-                "all_cores": {"value": done_all / dt_all / 1e6, "unit": "Msamples/s", "cores": cores, "streams": n_all, "seconds": round(dt_all, 1)}}
+        distinct = _cpu_pcm16(self.n_samples, 1, SRC_RATE, 1000, 64)   # 64 distinct streams = 56 MB of input + a fresh 3.8 MB fp64 row per call: not cache-resident
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: len(O.resample(O.pcm(distinct[i % len(distinct)], 16, O.SIGNED, 1, SRC_RATE), DST_RATE, mode).data[0])
+        return one, f"{self.n_samples} samples each, {len(distinct)} distinct ones cycled"
 
 
 class Pcm16Stereo(Workload):
@@ -150,6 +189,7 @@ class Pcm16Stereo(Workload):
     name, unit = "pcm16_stereo", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.interp = args.interp
         self.n_samples = int(round(args.seconds * SRC_RATE))
         self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples * 2, SRC_RATE, 0xA0C17 + 6000 + rank)
         offs = [i * self.n_samples * 4 for i in range(args.streams + 1)]
@@ -161,6 +201,14 @@ class Pcm16Stereo(Workload):
         self.desc = f"{args.streams}x s16le 44.1kHz STEREO {args.seconds:g}s -> aukit.pcm:resample(48000,'{args.interp}'), {args.dtype} store; unit = out-samples of both channels"
         return self
 
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        distinct = _cpu_pcm16(self.n_samples, 2, SRC_RATE, 6000, 32)
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: 2 * len(O.resample(O.pcm(distinct[i % len(distinct)], 16, O.SIGNED, 2, SRC_RATE), DST_RATE, mode).data[0])
+        return one, f"{self.n_samples} stereo frames each, {len(distinct)} distinct ones cycled"
+
     def out_samples(self):
         return int(self.out.layout()[0].sum()) * 2
 
@@ -170,6 +218,7 @@ class Pcm16Stream(Workload):
     name, unit = "pcm16_stream", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.interp = args.interp
         self.n_samples = int(round(args.seconds * SRC_RATE))
         self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples, SRC_RATE, 0xA0C17 + 1000 + rank)
         offs = [i * self.n_samples * 2 for i in range(args.streams + 1)]
@@ -182,6 +231,14 @@ class Pcm16Stream(Workload):
                      f"{args.dtype} store (config T, stream path)")
         return self
 
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        distinct = _cpu_pcm16(self.n_samples, 1, SRC_RATE, 1000, 64)
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: len(O.stream_pcm(distinct[i % len(distinct)], 16, O.SIGNED, 1, SRC_RATE, False, False, mode).data[0])
+        return one, f"{self.n_samples} samples each, {len(distinct)} distinct ones cycled; every iterator call"
+
     def out_samples(self):
         return int(self.out.layout()[0].sum())
 
@@ -191,6 +248,7 @@ class Pcm16StereoStream(Workload):
     name, unit = "pcm16_stereo_stream", "Msamples/s"
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
+        self.interp = args.interp
         self.n_samples = int(round(args.seconds * SRC_RATE))
         self.x = _sine_noise_s16(torch, dev, args.streams, self.n_samples * 2, SRC_RATE, 0xA0C17 + 7000 + rank)
         offs = [i * self.n_samples * 4 for i in range(args.streams + 1)]
@@ -203,6 +261,14 @@ class Pcm16StereoStream(Workload):
                      f"{args.dtype} store; unit = out-samples of both channels")
         return self
 
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        distinct = _cpu_pcm16(self.n_samples, 2, SRC_RATE, 7000, 32)
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: 2 * len(O.stream_pcm(distinct[i % len(distinct)], 16, O.SIGNED, 2, SRC_RATE, False, False, mode).data[0])
+        return one, f"{self.n_samples} stereo frames each, {len(distinct)} distinct ones cycled; every iterator call"
+
     def out_samples(self):
         return int(self.out.layout()[0].sum()) * 2
 
@@ -212,6 +278,7 @@ class G711Cubic(Workload):
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
         n = int(round(args.seconds * 8000))
+        self.nbytes = n
         self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 2000 + rank)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
         self.d = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
@@ -219,6 +286,13 @@ class G711Cubic(Workload):
         self.step = lambda: B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=N.F32, out=self.out)
         self.desc = f"{args.streams}x G.711 u-law 8kHz {args.seconds:g}s -> aukit.g711:resample(48000,'cubic'), f32 store (config 2a)"
         return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        distinct = _cpu_random_bytes(self.nbytes, 2000, 64)
+        one = lambda i: len(O.resample(O.g711(distinct[i % len(distinct)], True, 1, 8000), DST_RATE, O.CUBIC).data[0])
+        return one, f"{self.nbytes} u-law bytes each, {len(distinct)} distinct ones cycled"
 
     def out_samples(self):
         return int(self.out.layout()[0].sum())
@@ -230,6 +304,8 @@ class G711Stream(Workload):
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
         n = int(round(args.seconds * 8000))
+        self.nbytes = n
+        self.interp = args.interp
         self.x = _random_bytes(torch, dev, args.streams * n, 0xA0C17 + 2000 + rank)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), [i * n for i in range(args.streams + 1)], keep=self.x)
         self.d = B.make_desc(N.CODEC_G711, 1, 8000, ulaw=True)
@@ -238,6 +314,15 @@ class G711Stream(Workload):
         self.arith = "int decode + f64 resample"
         self.desc = f"{args.streams}x G.711 u-law 8kHz {args.seconds:g}s -> aukit.stream.g711 ({args.interp}), all iterator calls, int8 out (config 2b)"
         return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        distinct = _cpu_random_bytes(self.nbytes, 2000, 64)
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        calls = -(-self.nbytes // 8000)   # one iterator call per second of input (with string input the iterator never returns nil: Q13)
+        one = lambda i: len(O.stream_g711(distinct[i % len(distinct)], True, 1, 8000, False, mode, max_calls=calls).data[0])
+        return one, f"{self.nbytes} u-law bytes each, {len(distinct)} distinct ones cycled; {calls} iterator calls"
 
     def out_samples(self):
         return int(self.out.layout()[0].sum())
@@ -251,6 +336,7 @@ class ImaStream(Workload):
         if abs(args.seconds - 10.0) > 1e-9:
             raise SystemExit("ima_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
         blobs = [_fixture(f"ima_22050_220x512_{i}.bin") for i in range(4)]
+        self.blobs, self.interp = blobs, args.interp
         self.distinct = len(blobs)
         self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
@@ -261,11 +347,59 @@ class ImaStream(Workload):
         self.desc = f"{args.streams}x IMA-ADPCM 22.05kHz mono {blocks}x512B ({self.distinct} distinct encoder-made streams, cycled) -> stream.adpcm cubic, int8 out (config 3a)"
         return self
 
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        blobs = self.blobs
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: len(O.stream_adpcm(blobs[i % len(blobs)], 512, 1, 22050, False, mode).data[0])
+        return one, f"220 blocks of 512 B each, the {len(blobs)} fixture streams cycled; every iterator call"
+
     def out_samples(self):
         return int(self.out.layout()[0].sum())
 
     def task_bytes(self):
         return int(self.x.numel()) + self.out_samples()
+
+
+class ImaPipeline(Workload):
+    """BASELINE config 3 as written: IMA-ADPCM in WAV blocks -> aukit.wav(d):resample(48000, "cubic") -> aukit.effects.lowpass(a, 11025)
+    (auplay.lua:11-34 for the call order).  Algorithmic bytes: 0.2316 B in + 4 B out per output sample."""
+    name, unit = "ima_pipeline", "Msamples/s"
+
+    def setup(self, torch, dev, ctx, args, rank, N, B):
+        if abs(args.seconds - 10.0) > 1e-9:
+            raise SystemExit("ima_pipeline: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
+        blobs = [_fixture(f"ima_22050_220x512_{i}.bin") for i in range(4)]
+        self.blobs = blobs
+        self.distinct = len(blobs)
+        self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
+        self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
+        self.d = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
+        self.out = B.AudioBatch(ctx)
+        self.dtype = N.F32 if args.dtype == "f32" else N.F64
+
+        def step():
+            B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=self.dtype, out=self.out)
+            B.effect(ctx, self.out, "lowpass", 11025.0)
+        self.step = step
+        self.arith = "i32 decode + " + ("f32 interpolation, f64 recurrence" if args.dtype == "f32" else "f64 reference-order resample and filter")
+        self.desc = (f"{args.streams}x IMA-ADPCM 22.05kHz mono 220x512B in WAV blocks ({self.distinct} distinct encoder-made streams, cycled) -> aukit.wav:resample(48000,'cubic') "
+                     f"-> effects.lowpass(11025), {args.dtype} store (config 3b)")
+        return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        blobs = self.blobs
+        one = lambda i: len(O.fx_lowpass(O.resample(O.wav_adpcm(blobs[i % len(blobs)], 512, 1, 22050), DST_RATE, O.CUBIC), 11025.0).data[0])
+        return one, f"220 blocks of 512 B each, the {len(blobs)} fixture streams cycled: aukit.wav -> resample -> lowpass"
+
+    def out_samples(self):
+        return int(self.out.layout()[0].sum())
+
+    def task_bytes(self):
+        return int(self.x.numel()) + self.out_samples() * (4 if self.dtype == 1 else 8)
 
 
 class MsadpcmStream(Workload):
@@ -276,6 +410,7 @@ class MsadpcmStream(Workload):
         if abs(args.seconds - 10.0) > 1e-9:
             raise SystemExit("msadpcm_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
         blobs = [_fixture(f"msadpcm_44100_mono_216x1024_{i}.bin") for i in range(2)]
+        self.blobs, self.interp = blobs, args.interp
         self.distinct = len(blobs)
         self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
@@ -285,6 +420,14 @@ class MsadpcmStream(Workload):
         self.arith = "i32 recurrence (fp64 per lane beyond the int32-safe range) + f32 resample with f64 / reference-order fallback under the floor (bit-exact)"
         self.desc = f"{args.streams}x MS-ADPCM 44.1kHz mono 216x1024B ({self.distinct} distinct encoder-made streams, cycled) -> stream.msadpcm {args.interp}, int8 out"
         return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        blobs = self.blobs
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: len(O.stream_msadpcm(blobs[i % len(blobs)], 1024, 1, 44100, False, None, mode).data[0])
+        return one, f"216 blocks of 1024 B each, the {len(blobs)} fixture streams cycled; every iterator call"
 
     def out_samples(self):
         return int(self.out.layout()[0].sum())
@@ -301,6 +444,7 @@ class QoaStream(Workload):
         if abs(args.seconds - 10.0) > 1e-9:
             raise SystemExit("qoa_stream: the cached fixtures are 10 s long (tools/make_bench_inputs.py)")
         blobs = [_fixture(f"qoa_44100_stereo_10s_{i}.bin") for i in range(2)]
+        self.blobs, self.interp = blobs, args.interp
         self.distinct = len(blobs)
         self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
@@ -312,6 +456,14 @@ class QoaStream(Workload):
         self.desc = (f"{args.streams}x QOA 44.1kHz stereo 10s ({self.distinct} distinct encoder-made files, cycled) -> stream.qoa {args.interp}, all iterator calls, "
                      f"{args.dtype} store; unit = out-samples of both channels")
         return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        blobs = self.blobs
+        mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
+        one = lambda i: 2 * len(O.stream_qoa(blobs[i % len(blobs)], False, mode).data[0])
+        return one, f"10 s stereo files, the {len(blobs)} fixture files cycled; every iterator call"
 
     def out_samples(self):
         return int(self.out.layout()[0].sum()) * 2
@@ -328,6 +480,7 @@ class DfpwmTranscode(Workload):
         # aukit.pcm → Audio:dfpwm on the device (sub-batches of 512 streams; every stream has its own noise).  The chunk-parallel decoder's
         # warm-up / verify / redo step depends on what the bytes are, so the timed input is what the config names, not random bytes.
         frames = int(round(args.seconds * 48000))
+        self.frames = frames
         nb = frames * 2 // 8
         self.x = torch.empty(args.streams * nb, dtype=torch.uint8, device=dev)
         pcm_desc = B.make_desc(N.CODEC_PCM, 2, 48000, 16, "signed")
@@ -354,6 +507,15 @@ class DfpwmTranscode(Workload):
                      f"style signal -> aukit.dfpwm:mono():dfpwm() fused (config 4); unit = mono samples")
         return self
 
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        frames = self.frames
+        # the same route as the GPU input: the config-1 style stereo signal through the (oracle's) DFPWM encoder, 4 distinct streams
+        enc = [O.audio_dfpwm(O.pcm(d, 16, O.SIGNED, 2, 48000), True) for d in _cpu_pcm16(frames, 2, 48000, 4000, 4)]
+        one = lambda i: 8 * len(O.audio_dfpwm(O.mono(O.dfpwm(enc[i % len(enc)], 2, 48000)), True))
+        return one, f"{len(enc[0])} DFPWM bytes each (stereo, {frames} frames), {len(enc)} distinct encoder-made streams cycled: aukit.dfpwm -> mono -> dfpwm"
+
     def out_samples(self):
         return int(self.outb.info()[1]) * 8
 
@@ -376,6 +538,7 @@ class FlacPipeline(Workload):
         if abs(args.seconds - 10.0) > 1e-9:
             raise SystemExit("flac_pipeline: the cached fixture is 10 s long (tools/make_bench_inputs.py)")
         one = _fixture("flac_44100_stereo_10s.bin")
+        self.blob = one
         self.distinct = 1  # copies of ONE stream back to back: a lane takes consecutive frames of a stream, so the divergence inside a wave is a real file's
         self.flac_bytes = len(one)
         self.x, offs = _tile_streams(torch, dev, [one], args.streams)
@@ -395,6 +558,17 @@ class FlacPipeline(Workload):
         self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each, copies of one encoder-made stream) -> aukit.flac:resample(48000,'cubic') "
                      f"-> highpass(20) -> normalize(0.8) -> mono, {args.dtype} store (config 5); unit = mono out-samples")
         return self
+
+    def cpu_one(self, args):
+        from oracle import oracle as O
+        O.build()
+        blob = self.blob
+
+        def one(i):
+            a = O.resample(O.flac(blob), DST_RATE, O.CUBIC)
+            a = O.fx_normalize(O.fx_highpass(a, 20.0), 0.8)
+            return len(O.mono(a).data[0])
+        return one, f"the fixture stream ({len(blob)} B, 10 s stereo): aukit.flac -> resample -> highpass -> normalize -> mono"
 
     def out_samples(self):
         return int(self.m.layout()[0].sum())
@@ -417,7 +591,7 @@ class SelftestNull(Workload):
         return 1000
 
 
-WORKLOADS = {w.name: w for w in (SelftestNull, Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, MsadpcmStream, QoaStream, DfpwmTranscode, FlacPipeline)}
+WORKLOADS = {w.name: w for w in (SelftestNull, Pcm16Cubic, Pcm16Stereo, Pcm16Stream, Pcm16StereoStream, G711Cubic, G711Stream, ImaStream, ImaPipeline, MsadpcmStream, QoaStream, DfpwmTranscode, FlacPipeline)}
 
 
 def _free_port():
@@ -525,7 +699,12 @@ def main(argv=None):
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default 4096; 16384 for dfpwm_transcode)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="STORAGE type of the output rows")
-    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams timed on the CPU oracle (0 disables)")
+    ap.add_argument("--cpu-streams", type=int, default=1024, help="most streams timed on the CPU oracle (0 disables the cpu_baseline leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="about how long the one-thread CPU leg runs (the all-cores leg runs about half as long again)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --streams per GPU whatever N; strong: --streams is the TOTAL, cut into N contiguous shares (aukit_partition's rule)")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="raise --steps so that the timed region lasts at least this long (keeps the device busy long enough for an external sampler); 0: exactly --steps")
     ap.add_argument("--store-x4", type=int, default=1, help="tuning: LDS-transposed 16-byte stores in the v1 fast kernel")
     ap.add_argument("--exact-math", type=int, default=None,
                     help="arithmetic behind f32 storage: 1 = fp64 (the reference computes in doubles; default for pcm16_cubic, the driver's line), "
@@ -539,7 +718,7 @@ def main(argv=None):
     ap.add_argument("--interp", default="cubic", choices=["linear", "cubic"], help="tuning only: the metric is defined on cubic")
     args = ap.parse_args(argv)
     if args.streams is None:
-        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048, "qoa_stream": 1024, "msadpcm_stream": 1024}.get(args.workload, 4096)
+        args.streams = {"dfpwm_transcode": 16384, "flac_pipeline": 2048, "pcm16_stereo": 2048, "pcm16_stereo_stream": 2048}.get(args.workload, 4096)
     if args.exact_math is None:
         args.exact_math = 1 if args.workload in ("pcm16_cubic", "g711_cubic", "pcm16_stream") else 0   # the workloads that have an fp64-arithmetic wave kernel
     selftest = args.workload == "selftest_null"
@@ -555,6 +734,12 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let `python bench.py --gpus N` start them)")
+    streams_total = args.streams * world
+    if args.scaling == "strong":   # a fixed job cut into contiguous shares: rank g takes streams [total g / N, total (g + 1) / N) (equal-sized synthetic streams: the byte-balanced cut)
+        streams_total = args.streams
+        args.streams = streams_total * (rank + 1) // world - streams_total * rank // world
+        if args.streams < 1:
+            raise SystemExit(f"bench.py: --scaling strong with {streams_total} streams leaves rank {rank} of {world} without any")
     if selftest:
         N = B = ctx = None
         dev = torch.device("cpu")
@@ -625,6 +810,17 @@ def main(argv=None):
         per_sync = int(min(256, max(8, per_sync * 0.1 / dt_b)))
     for _ in range(args.warmup):
         wl.step()
+    if args.min_seconds > 0:   # as many steps as fill the asked-for time (the same count on every rank: rank 0's estimate)
+        sync()
+        t_e = time.perf_counter()
+        wl.step()
+        sync()
+        want = int(args.min_seconds / max(time.perf_counter() - t_e, 1e-6)) + 1
+        if world > 1:
+            tw = torch.tensor([want], device=rdev, dtype=torch.int64)
+            dist.broadcast(tw, 0)
+            want = int(tw.item())
+        args.steps = max(args.steps, want)
     dt, ev_ms, n_launch, alg_total = timed_window()  # THE measurement: exactly K steps
     out_samples = wl.out_samples()
     name = ctx.last_kernel()[0] if ctx else "none"
@@ -670,7 +866,7 @@ def main(argv=None):
             arith = wl.arith
         elif name.startswith("k_fast"):
             arith = "f32"
-        elif "dfpwm" in name:
+        elif "dfpwm" in name or name.startswith("k_df"):
             arith = "i32"
         else:
             arith = "f64"
@@ -683,13 +879,13 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             # arithmetic type of the path: "f64" = every tap, weight, product and sum is an fp64 value (the reference computes in Lua
             # doubles), whatever the storage type of the rows; the f32-tap kernels report "f32"; DFPWM / ADPCM decode is int32
             "dtype": arith,
             "data": "synthetic",
-            "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "seconds_per_stream": args.seconds,
+            "config": {"workload": wl.desc, "streams_per_gpu": args.streams, "streams_total": streams_total, "seconds_per_stream": args.seconds,
                        "parallelism": f"shard{world}", "storage": args.dtype, "exact_math": args.exact_math,
                        "arithmetic": ("fp64 phase-weight table on exact rational positions (k_wave_f64): the reference's arithmetic TYPE, not its operation order — "
                                       "within one f32 ulp of the reference-order kernel" if (headline and args.exact_math == 1) else arith)},
@@ -704,12 +900,19 @@ def main(argv=None):
             roof_bytes = task if task else alg_bytes
             achieved = roof_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             tr = _measured_traffic(name, args) if launches == 1 else None
+            tstep = _measured_traffic_step(args.workload, args) if launches > 1 else None
+            if tstep:
+                tr = tstep["hbm_bytes_per_step"]
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": tr, "kernel": name, "kernel_ms": kernel_ms,
                                 "launches_per_step": launches, "algorithmic_bytes_per_launch": roof_bytes if launches == 1 else None,
                                 "algorithmic_bytes_per_step": roof_bytes,
                                 "bytes_per_out_sample": roof_bytes / max(out_samples, 1),
                                 "frac_median_window": roof_bytes / (statistics.median(kernel_windows) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if tr is not None:
+                line["roofline"]["traffic_ratio"] = tr / max(roof_bytes, 1)
+            if tstep:
+                line["roofline"]["traffic_by_kernel"] = tstep.get("kernels")
             if tr is not None:
                 line["roofline"]["traffic_source"] = "committed PMC pass of this command (profiles/traffic.json; FETCH_SIZE / WRITE_SIZE corrected as the guide prescribes), not collected in this run"
             if launches > 1:
