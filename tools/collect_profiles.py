@@ -23,7 +23,7 @@ DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile640,phase_regs>", "wavef64", "
             ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<", 2048),
             ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<", 4096),
             ("k_ima_stream_f32", "ima", "k_ima_stream_f32<", 4096),
-            ("k_ms_wave", "msadpcm", "k_ms_wave<", 1024)]
+            ("k_ms_wave", "msadpcm", "k_ms_wave<", 4096)]
 
 
 def first(tag, which, pat, col):
@@ -44,12 +44,47 @@ for kernel, tag, pat, nstreams in DOMINANT:
         continue
     entries.append({"kernel": kernel, "streams": nstreams, "seconds": 10.0, "tag": tag, "fetch_kb": fk, "write_kb": wk,
                     "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)})
+# multi-launch workloads: HBM bytes of ONE step = every aukit kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over the run, divided by the number of
+# steps the run made = the dispatches of a kernel that is launched once per step (the anchor)
+STEPS = [("flac_pipeline", "flac", "k_mono<", 2048), ("qoa_stream", "qoa", "k_iir_tail", 4096), ("dfpwm_transcode", "dfpwm", "k_df_fused", 16384),
+         ("ima_pipeline", "imapipe", "onepole", 4096)]
+
+
+def step_traffic(tag, anchor):
+    tot, per, n_anchor = 0.0, {}, 0
+    for which, col, mul in (("fetch", "FETCH_SIZE", 2048.0), ("write", "WRITE_SIZE", 1024.0)):
+        with open(os.path.join(dst, "r%s_%s_pmc_%s.csv" % (rnd, tag, which))) as fh:
+            na = 0
+            for row in csv.DictReader(fh):
+                if not row.get(col):
+                    continue
+                k = row["kernel"].replace("void ", "").replace("aukit::", "").split("(")[0][:60]
+                per[k] = per.get(k, 0.0) + float(row[col]) * mul
+                tot += float(row[col]) * mul
+                if anchor in row["kernel"]:
+                    na += 1
+            n_anchor = max(n_anchor, na)
+    if not n_anchor:
+        return None
+    return int(tot / n_anchor), {k: int(v / n_anchor) for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v / n_anchor >= 1e6}, n_anchor
+
+
+steps = []
+for workload, tag, anchor, nstreams in STEPS:
+    try:
+        got = step_traffic(tag, anchor)
+    except OSError:
+        continue
+    if got:
+        steps.append({"workload": workload, "streams": nstreams, "seconds": 10.0, "tag": tag, "anchor": anchor, "steps_in_run": got[2], "hbm_bytes_per_step": got[0], "kernels": got[1]})
 note = ("HBM bytes per launch from rocprofv3 PMC passes of `python3 bench.py --steps 5 --warmup 1 --cpu-streams 0 [--workload W]` "
         "(tools/profile_bench.sh, separate passes for FETCH_SIZE and WRITE_SIZE): FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports wide "
         "coalesced reads as 64-B requests: MI355X_MICROARCH.md, HBM/rocprofv3 section) + WRITE_SIZE [KB] x 1024. Source rows: "
         "profiles/r%s_<tag>_pmc_fetch.csv / _pmc_write.csv; rebuilt by tools/collect_profiles.py." % rnd)
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
-    json.dump({"note": note, "entries": entries}, fh, indent=1)
+    json.dump({"note": note, "entries": entries, "steps": steps}, fh, indent=1)
 print("copied %d csv files, %d traffic entries" % (n, len(entries)))
 for e in entries:
     print("  %-60s %.3f GB" % (e["kernel"], e["hbm_bytes_per_launch"] / 1e9))
+for e in steps:
+    print("  step %-55s %.3f GB over %d steps" % (e["workload"], e["hbm_bytes_per_step"] / 1e9, e["steps_in_run"]))
