@@ -702,6 +702,13 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         double norm_neg, aukit_audio **out) {
     const double ratio = do_resample ? new_rate / rate : 1.0;
     if (!(ratio > 0)) return fail(AUKIT_E_ARG, "bad sample rate");
+    // F32 pipelines (round 4): the resample of `loader(...):resample(r)` on the int16 / int8 rows of the IMA / MS-ADPCM / QOA / DFPWM loaders is
+    // left OWED exactly as FLAC's is (flac_tail.hip) — a following effects.lowpass / highpass pays it inside its own pass (BASELINE config 3:
+    // aukit.wav -> resample -> lowpass as decode + ONE launch), anything else materialises it first (audio_flush)
+    if (do_resample && dtype == AUKIT_F32 && rows_dev == ctx->tmp_buf.p && (src_kind == SRC_I16 || src_kind == SRC_I8)) {
+        int lrc = AUKIT_OK;
+        if (lazy_resample_try(ctx, row_off, row_len, n, channels, rate, new_rate, interp, 1.0, out, &lrc, nullptr, src_kind, norm_pos, norm_neg)) return lrc;
+    }
     std::vector<uint64_t> lens(n);
     uint64_t in_elems = 0, out_elems = 0;
     for (uint32_t s = 0; s < n; s++) {
@@ -810,6 +817,7 @@ int aukit_decode(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "dtype must be AUKIT_F64 or AUKIT_F32");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     if (desc->codec == AUKIT_CODEC_PCM || desc->codec == AUKIT_CODEC_G711) return decode_resample_flat(ctx, in, desc, desc->sample_rate, AUKIT_INTERP_NONE, false, dtype, out);
+    if (*out && ((*out)->lazy_rs || (*out)->lazy_rows.p)) lazy_drop(ctx, *out);   // the output's old rows (a deferred resample nobody paid) return to the scratch the decoder is about to use
     return decode_block_codec(ctx, in, desc, 0, 0, false, dtype, out);
 }
 
@@ -820,6 +828,7 @@ int aukit_decode_resample(aukit_ctx *ctx, const aukit_batch *in, const aukit_cod
     if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "bad argument #2 (invalid interpolation type)");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     if (desc->codec == AUKIT_CODEC_PCM || desc->codec == AUKIT_CODEC_G711) return decode_resample_flat(ctx, in, desc, new_rate, interp, true, dtype, out);
+    if (*out && ((*out)->lazy_rs || (*out)->lazy_rows.p)) lazy_drop(ctx, *out);
     return decode_block_codec(ctx, in, desc, new_rate, interp, true, dtype, out);
 }
 

@@ -76,6 +76,7 @@ struct aukit_ctx {
     int tab_cur = 0;
     bool tab_used[2] = {false, false};
     hipEvent_t tab_ev[2] = {};
+    bool lazy_suppress = false;   // set while an owed resample is being materialised: audio_from_int_rows must not defer it again
     std::string plan_key;   // non-empty: seg_buf / tile_buf still hold the tables of plan_segs (any other upload into them clears it)
     std::vector<unsigned char> plan_segs;   // the segment descriptors of that plan, byte for byte
     int plan_tile_out = 0;
@@ -134,7 +135,9 @@ struct aukit_audio {
     bool lazy_rs = false;
     aukit::DevBuf lazy_rows;                             // taken out of the context's scratch; handed back when the resample is paid
     std::vector<uint64_t> lazy_row_off, lazy_row_len;    // per (stream, channel): element offset / samples in lazy_rows
-    double lazy_rate = 0, lazy_full = 1;
+    double lazy_rate = 0, lazy_full = 1;                 // lazy_full: int32 rows, `v / full`
+    int lazy_src = 8;                                    // SrcKind of the rows: SRC_I32 (FLAC), SRC_I16 (IMA / MS-ADPCM / QOA), SRC_I8 (DFPWM) — round 4
+    double lazy_norm_pos = 1, lazy_norm_neg = 1;         // `v / (v < 0 and norm_neg or norm_pos)` of the loader the rows came from
     int lazy_interp = 0;
     aukit_ctx *lazy_ctx = nullptr;
     // round 4: the rows may still lie frame by frame where the fused FLAC decoder left them (lazy_rows = its scratch) — lazy_tab then holds the
@@ -177,9 +180,10 @@ void lazy_drop(aukit_ctx *ctx, aukit_audio *a);
 int lazy_materialize(aukit_ctx *ctx, aukit_audio *a);
 struct LazyFrames {   // the fused FLAC decoder's frames (flac_dev.h), for a deferred resample that reads them in place
     const void *d_frames; uint64_t nfr; const unsigned long long *d_fbase, *d_rowoff; const std::vector<int> *bs0; bool uniform; uint64_t tot_elems;
+    const std::vector<unsigned> *nframes;
 };
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
-                       double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr);
+                       double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr, int src_kind = 8 /* SRC_I32 */, double norm_pos = 0, double norm_neg = 0);
 bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc);
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 // the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time

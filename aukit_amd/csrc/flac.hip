@@ -1731,8 +1731,12 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     }
     if (!D.wide && do_resample && dtype == AUKIT_F32) {   // F32 pipelines: the resample is owed — a following effects.highpass / lowpass pays it in its own pass (flac_tail.hip)
         int lrc = AUKIT_OK;
-        LazyFrames LF{D.d_frames, D.nfr, D.d_fbase, D.d_rowoff, &D.bs0, D.uniform, D.tot_elems};
+        LazyFrames LF{D.d_frames, D.nfr, D.d_fbase, D.d_rowoff, &D.bs0, D.uniform, D.tot_elems, &D.nframes};
         if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc, D.in_scratch ? &LF : nullptr)) return lrc;
+        if (D.in_scratch) {   // frames too short (or of mixed sizes) to be followed in place: contiguous rows, and the resample is owed on those
+            if ((rc = flac_rows_materialize(ctx, D))) return rc;
+            if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc, nullptr)) return lrc;
+        }
     }
     if ((rc = flac_rows_materialize(ctx, D))) return rc;
     if (D.wide) return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, do_resample, dtype, 1, 1, out);

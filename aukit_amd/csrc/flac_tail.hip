@@ -24,7 +24,7 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
 struct RsOnepoleParams {
-    const int *rows;
+    const void *rows;                              // int32 (FLAC), int16 (IMA / MS-ADPCM / QOA) or int8 (DFPWM) rows: the template's S
     const unsigned long long *row_off, *row_len;   // per (stream, channel): element offset / samples of the decoded row
     const unsigned long long *a_meta;              // the audio's len[n], row_off[n], row_stride[n]
     float *out;
@@ -32,7 +32,7 @@ struct RsOnepoleParams {
     unsigned n;
     int C, cap;
     unsigned fa, fb, fmagic, dq256, dr256;
-    float inv_b, scale;
+    float inv_b, scale, scale_neg;                 // sample = (float)v * (v < 0 ? scale_neg : scale): the fast wave kernels' conversion (fast_wave_dev.h)
     double coef;
     const float *wg;   // cubic: the four tap weights of each of the fb output phases (null: the Horner form on fx = rem / fb)
     // round 4: the rows frame by frame where the fused FLAC decoder left them (null: contiguous rows at row_off).  Every stream's frames but its
@@ -40,6 +40,10 @@ struct RsOnepoleParams {
     const FrameRec *frames;
     const unsigned long long *fbase;
     const int *bs0;
+    // round 4: a row is cut into `segs` runs of tiles, a wave each.  A run starts `warm` tiles early from a zero state and stores nothing there: the
+    // recurrence forgets its state at m per output (m^(512 warm) < 2^-40), so the run's own outputs are those of the whole row's chain to far
+    // below an f32 ulp — and a row is no longer ONE serial chain of 938 tiles on a chip that can run four times as many chains as config 5 has rows
+    int segs, warm;
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
@@ -58,7 +62,7 @@ AUKIT_DEV double dpp_f64(double v) {
 
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
-template <int INTERP, bool HP, bool TAB>
+template <int INTERP, bool HP, bool TAB, typename S>
 __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     extern __shared__ float rsm[];
     constexpr int E = 8, T = 64 * E;
@@ -67,10 +71,11 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     [[maybe_unused]] float *const wt = xb + (T + T / E + 8);                 // TAB: 4 fb floats
     if constexpr (TAB) { for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64) wt[i] = P.wg[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     const int lane = threadIdx.x;
-    const unsigned r = blockIdx.x, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
+    const unsigned r = blockIdx.x / (unsigned)P.segs, seg = blockIdx.x - r * (unsigned)P.segs, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
     const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s];
     const int L = (int)P.row_len[r];
-    const int *row = P.rows + P.row_off[r];
+    const S *const rows_s = reinterpret_cast<const S *>(P.rows);
+    const S *row = rows_s + P.row_off[r];
     float *orow = P.out + obase;
     // the slope of the recurrence's affine map y -> m y + ...: a (high-pass, :3614), 1 - alpha (low-pass, :3594)
     const double m = HP ? P.coef : 1.0 - P.coef;
@@ -127,32 +132,54 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
             const int j = lane + 64 * u;
             const unsigned k = kk + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
-            const int *src = P.frames ? P.rows + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
-            pre[u] = (j < nst && L > 0) ? *src : 0;
+            const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
+            pre[u] = (j < nst && L > 0) ? (int)*src : 0;
         }
     };
     int pre[8];
+    // this wave's run of tiles [t_lo, t_hi) of the row's ntiles, entered `warm` tiles early
+    const unsigned long long ntiles = (nout + T - 1) / T;
+    const unsigned long long t_lo = ntiles * seg / (unsigned)P.segs, t_hi = ntiles * (seg + 1u) / (unsigned)P.segs;
+    const unsigned long long t_in = t_lo > (unsigned long long)P.warm ? t_lo - (unsigned long long)P.warm : 0ull;
+    const unsigned long long o_lo = t_lo * T, o_end = t_hi * T < nout ? t_hi * T : nout;
     {
-        const int cnt0 = (int)(nout < (unsigned long long)T ? nout : (unsigned long long)T);
-        if (nout) fetch(0u, tile_nst(0u, cnt0), pre);
+        const unsigned long long nn = t_in * (unsigned long long)T * P.fa;   // x - 1 of the run's first output = nn / fb exactly
+        kb = (unsigned)(nn / P.fb); r0 = (unsigned)(nn % P.fb);
+        const unsigned long long left0 = o_end > t_in * T ? o_end - t_in * T : 0ull;
+        const int cnt0 = (int)(left0 < (unsigned long long)T ? left0 : (unsigned long long)T);
+        if (left0) fetch(kb, tile_nst(r0, cnt0), pre);
     }
-    for (unsigned long long o0 = 0; o0 < nout; o0 += T) {
-        const int cnt = (int)((nout - o0) < (unsigned long long)T ? (nout - o0) : (unsigned long long)T);
+    // a full tile's results wait in registers (held[]) and are stored at the top of the NEXT turn, behind the wait for that tile's window: loads and
+    // stores share vmcnt and hipcc waits vmcnt(0) across this loop's branches — stores issued at the end of a turn were waited for at the top of
+    // the next one, a store latency per tile in a chain of 938 tiles (the late-store schedule of wave_f64.hip)
+    float held[E];
+    float *held_at = nullptr;
+#pragma unroll
+    for (int u = 0; u < E; u++) held[u] = 0.f;
+    for (unsigned long long o0 = t_in * T; o0 < o_end; o0 += T) {
+        const bool emit = o0 >= o_lo;   // (a warm-up tile: state only)
+        const int cnt = (int)((o_end - o0) < (unsigned long long)T ? (o_end - o0) : (unsigned long long)T);
         auto qr = [&](unsigned j, unsigned &q, unsigned &rem) { const unsigned nn = r0 + j * P.fa; q = __umulhi(nn, P.fmagic); rem = nn - q * P.fb; };   // q relative to kb
         const int nst = tile_nst(r0, cnt);   // table indices kb .. kb + ql + 3 (floor(x) = q + 1; taps q .. q + 3)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int u = 0; u < 8; u++) win[lane + 64 * u] = (float)pre[u] * P.scale;   // (cap >= 512)
+        for (int u = 0; u < 8; u++) win[lane + 64 * u] = (float)pre[u] * (pre[u] < 0 ? P.scale_neg : P.scale);   // (cap >= 512)
+        if (held_at) {   // (wave-uniform) the tile before this one
+#pragma unroll
+            for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
+            held_at = nullptr;
+        }
         for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output (base0 / base1 / bound still describe THIS tile: the fetch below moves them on)
             const unsigned k = kb + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
-            const int *src = P.frames ? P.rows + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
-            win[j] = L > 0 ? (float)*src * P.scale : 0.f;
+            const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
+            const int sv = L > 0 ? (int)*src : 0;
+            win[j] = (float)sv * (sv < 0 ? P.scale_neg : P.scale);
         }
         unsigned kb_n = kb + wc, r0_n = r0 + wd;
         if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
-        if (o0 + T < nout) {
-            const unsigned long long left = nout - o0 - T;
+        if (o0 + T < o_end) {
+            const unsigned long long left = o_end - o0 - T;
             fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -221,14 +248,15 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         for (int i = 0; i < E; i++) {
             const double yv = __builtin_fma(mp[i + 1], yin, z[i]);
             res[i] = (float)yv;
-            if (FULL || e0 + i < cnt) mxf = fmaxf(mxf, fabsf(res[i]));
+            if (emit && (FULL || e0 + i < cnt)) mxf = fmaxf(mxf, fabsf(res[i]));
             if (!FULL && e0 + i == cnt - 1) ylast = yv;
         }
         // the lane that holds the tile's last output hands its state to the next tile
         if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
         else carry_y = __shfl(ylast, (cnt - 1) / E);
         carry_x = (double)xb[skew(cnt - 1)];
-        if constexpr (FULL) {
+        if (!emit) {}
+        else if constexpr (FULL) {
             // a full tile leaves through LDS once more: a lane's eight consecutive results as they stand are two 16-byte stores at a stride of 32 bytes —
             // each store instruction touches every line of the tile; transposed back (the skewed layout of the way in, read the other way round) a
             // store instruction writes 256 contiguous bytes
@@ -237,9 +265,9 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
             for (int i = 0; i < E; i++) xb[skew(e0 + i)] = res[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            float *ot = orow + o0 + (unsigned)lane;
 #pragma unroll
-            for (int u = 0; u < E; u++) ot[64 * u] = xb[skew(lane + 64 * u)];
+            for (int u = 0; u < E; u++) held[u] = xb[skew(lane + 64 * u)];
+            held_at = orow + o0 + (unsigned)lane;
         } else if (e0 < cnt) {
             float *op = orow + o0 + (unsigned)e0;
             if (e0 + E <= cnt) {
@@ -253,8 +281,12 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         if (cnt == T) compute(std::true_type{}); else compute(std::false_type{});
         kb = kb_n; r0 = r0_n;
     }
+    if (held_at) {
+#pragma unroll
+        for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
+    }
     for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
-    if (lane == 0) P.rowmax[r] = (unsigned long long)__double_as_longlong((double)mxf);   // the largest |stored value|, as k_onepole reports it
+    if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
 }
 
 // ---------------------------------------------------------------- the lazy state
@@ -296,18 +328,25 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
     a->lazy_rs = false;
     const std::vector<uint64_t> ro = a->lazy_row_off, rl = a->lazy_row_len;
     aukit_audio *self = a;
-    return audio_from_int_rows(ctx, SRC_I32, ctx->tmp_buf.p, ro, rl, a->n, a->channels, a->lazy_rate, a->rate, a->lazy_interp, true, AUKIT_F32, a->lazy_full, a->lazy_full, &self);
+    ctx->lazy_suppress = true;
+    const int mrc = audio_from_int_rows(ctx, a->lazy_src, ctx->tmp_buf.p, ro, rl, a->n, a->channels, a->lazy_rate, a->rate, a->lazy_interp, true, AUKIT_F32, a->lazy_norm_pos, a->lazy_norm_neg, &self);
+    ctx->lazy_suppress = false;
+    return mrc;
 }
 
 // after the decoder has left int32 rows in ctx->tmp_buf: shape *out as the resampled audio and leave the resample owed.  false: not this shape
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
-                       double full, aukit_audio **out, int *rc, const LazyFrames *LF) {
+                       double full, aukit_audio **out, int *rc, const LazyFrames *LF, int src_kind, double norm_pos, double norm_neg) {
     *rc = AUKIT_OK;
-    if (getenv("AUKIT_NO_TAIL_FUSION") || ctx->exact_math || (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) || n == 0) return false;
+    if (getenv("AUKIT_NO_TAIL_FUSION") || ctx->exact_math || ctx->lazy_suppress || (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) || n == 0) return false;
     FastParams F;
-    if (!fast_eligible(SRC_I32, interp, rate, new_rate, F)) return false;
-    int e = 0;
-    if (std::frexp(full, &e) != 0.5 || full > 16777216.0) return false;   // v / full must be an exact f32 operation (as fast_try asks)
+    const int fsrc = src_kind == SRC_I16 ? SRC_PCM_S16LE_MONO : (src_kind == SRC_I8 ? SRC_PCM8_MONO : SRC_I32);   // the wave kernel that would run otherwise
+    if (!fast_eligible(fsrc, interp, rate, new_rate, F)) return false;
+    if (src_kind == SRC_I32) {
+        int e = 0;
+        if (std::frexp(full, &e) != 0.5 || full > 16777216.0) return false;   // v / full must be an exact f32 operation (as fast_try asks)
+        norm_pos = norm_neg = full;
+    } else if (!((src_kind == SRC_I16 && norm_pos == 32767 && norm_neg == 32768) || (src_kind == SRC_I8 && norm_pos == 127 && norm_neg == 128))) return false;
     const double ratio = new_rate / rate;
     std::vector<uint64_t> lens(n);
     for (uint32_t s = 0; s < n; s++) {
@@ -322,7 +361,7 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
         // frame-by-frame rows are read in place only where a tile's window (k_rs_onepole: 512 outputs) spans at most two frames of its stream
         if (!LF->uniform || !LF->nfr) return false;
         const uint64_t capw = std::max<uint64_t>(512, (512ull * F.a) / F.b + 19);
-        for (uint32_t s = 0; s < n; s++) if ((uint64_t)(*LF->bs0)[s] < capw) return false;
+        for (uint32_t s = 0; s < n; s++) if ((*LF->nframes)[s] > 1 && (uint64_t)(*LF->bs0)[s] < capw) return false;   // (a stream of one frame is one run of samples)
     }
     aukit_audio *a = *out;
     if ((*rc = audio_prepare(ctx, &a, n, C, new_rate, AUKIT_F32, lens.data()))) return true;
@@ -354,6 +393,7 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
     }
     a->lazy_row_off = row_off; a->lazy_row_len = row_len;
     a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx;
+    a->lazy_src = src_kind; a->lazy_norm_pos = norm_pos; a->lazy_norm_neg = norm_neg;
     a->lazy_rs = true;
     ctx->last_kernel = "(resample deferred)";
     return true;
@@ -364,7 +404,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     *rc = AUKIT_OK;
     if (!a->lazy_rs || a->dtype != AUKIT_F32) return false;
     FastParams F;
-    if (!fast_eligible(SRC_I32, a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
+    if (!fast_eligible(a->lazy_src == SRC_I16 ? SRC_PCM_S16LE_MONO : (a->lazy_src == SRC_I8 ? SRC_PCM8_MONO : SRC_I32), a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
     constexpr int T = 512;
     if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;   // exact (q, rem) inside a tile
     const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3);
@@ -379,7 +419,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     tab.insert(tab.end(), a->lazy_row_len.begin(), a->lazy_row_len.end());
     if ((*rc = upload_table(ctx, ctx->misc_buf, tab.data(), tab.size() * 8))) return true;
     RsOnepoleParams P{};
-    P.rows = reinterpret_cast<const int *>(a->lazy_rows.p);
+    P.rows = a->lazy_rows.p;
     P.row_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
     P.row_len = P.row_off + rows;
     P.a_meta = reinterpret_cast<const unsigned long long *>(a->d_meta);
@@ -388,7 +428,9 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     P.n = a->n; P.C = a->channels; P.cap = cap;
     P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
-    P.scale = (float)(1.0 / a->lazy_full);
+    // (1 / 32767 etc. rounded to f32 once: the constants of fast.hip / fast_wave_dev.h)
+    P.scale = a->lazy_src == SRC_I16 ? 1.0f / 32767.0f : (a->lazy_src == SRC_I8 ? 1.0f / 127.0f : (float)(1.0 / a->lazy_full));
+    P.scale_neg = a->lazy_src == SRC_I16 ? 1.0f / 32768.0f : (a->lazy_src == SRC_I8 ? 1.0f / 128.0f : P.scale);
     P.coef = coef;
     if (a->lazy_indirect) {
         const char *T = reinterpret_cast<const char *>(a->lazy_tab.p);
@@ -406,19 +448,39 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
         if ((*rc = upload_table(ctx, ctx->tile_buf, w.data(), w.size() * 4))) return true;
         P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
     }
+    {   // rows cut into runs of tiles (RsOnepoleParams::segs): as many as bring a SMALL launch to the ≈ 4 K waves the chip holds at once (measured: beyond that nothing is gained — 2.94 against 3.06 ms on config 3b, 3.63 against 3.46 on config 5), each at least 8 x its warm-up long
+        const double m = highpass ? coef : 1.0 - coef;
+        uint64_t min_tiles = ~0ull;
+        for (uint64_t l : a->len) min_tiles = std::min<uint64_t>(min_tiles, (l + T - 1) / T);
+        int warm = 0, segs = 1;
+        if (m > 0 && m < 1 && !getenv("AUKIT_RS_ONE_CHAIN")) {
+            warm = (int)std::ceil(40.0 * M_LN2 / -std::log(m) / T);
+            const uint64_t by_rows = std::max<uint64_t>(1, 4096 / std::max<size_t>(rows, 1))   /* (what the chip holds at once: more runs than that only add warm-up) */, by_len = min_tiles / (8ull * (uint64_t)std::max(warm, 1));
+            segs = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(by_rows, by_len), 16));
+        }
+        if (getenv("AUKIT_RS_SEGS")) segs = std::max(1, atoi(getenv("AUKIT_RS_SEGS")));
+        P.segs = segs; P.warm = segs > 1 ? warm : 0;
+        if (hipMemsetAsync(a->d_rowmax, 0, rows * 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
+    }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t ldsb = lds;
-    const dim3 grid((unsigned)rows);
-    if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true, false>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false, false>), grid, dim3(64), ldsb, ctx->stream, P); }
-    else if (tabw) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, true>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, true>), grid, dim3(64), ldsb, ctx->stream, P); }
-    else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, false>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, false>), grid, dim3(64), ldsb, ctx->stream, P); }
+    const dim3 grid((unsigned)(rows * (size_t)P.segs));
+#define AUKIT_RSO(S)                                                                                                                                         \
+    do {                                                                                                                                                     \
+        if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true, false, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false, false, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
+        else if (tabw) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, true, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, true, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
+        else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, false, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, false, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
+    } while (0)
+    if (a->lazy_src == SRC_I16) AUKIT_RSO(short); else if (a->lazy_src == SRC_I8) AUKIT_RSO(signed char); else AUKIT_RSO(int);
+#undef AUKIT_RSO
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
     uint64_t in_elems = 0, out_elems = 0;
     for (uint64_t l : a->lazy_row_len) in_elems += l;
     for (uint64_t l : a->len) out_elems += l * (uint64_t)a->channels;
     a->rowmax_valid = true;
     lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
-    *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_elems * 4 + out_elems * 4);
+    const uint64_t in_bytes = in_elems * (a->lazy_src == SRC_I16 ? 2 : (a->lazy_src == SRC_I8 ? 1 : 4));
+    *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_bytes + out_elems * 4);
     return true;
 }
 

@@ -1,0 +1,164 @@
+"""Deferred work on an audio (round 4): the resample that `loader(...):resample(r)` leaves owed on F32 pipelines for EVERY
+int-row loader (aukit.wav's IMA splitter aukit.lua:1509-1548, aukit.msadpcm :1283-1353, aukit.qoa :1706-1777, aukit.dfpwm :1392-1414,
+aukit.flac :1657-1660 — Audio:resample :653-673) and that effects.lowpass / highpass (:3586-3618) pay inside their own pass, and the
+deferred normalize (:3431-3459).  Every consumer of an audio's device rows must see the finished rows whatever is still owed."""
+import numpy as np
+import pytest
+
+from util import pcm16, rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _B():
+    from aukit_amd import batch as B
+    return B
+
+
+def _N():
+    from aukit_amd import _native as N
+    return N
+
+
+def _loader(oracle, kind, i, n):
+    """(stream bytes, descriptor factory, oracle loader) of loader `kind`, stream i, about n samples per channel"""
+    N, B = _N(), _B()
+    if kind == "ima":
+        nb = max(n // 1016, 1)
+        s = oracle.gen_ima(pcm16(1016 * nb, 22050, 3, i), 1, 512, 15)
+        return s, lambda: B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), lambda d: oracle.wav_adpcm(d, 512, 1, 22050)
+    if kind == "msadpcm":
+        nb = max(n // 2036, 1)
+        s = oracle.gen_msadpcm(pcm16(2036 * nb, 44100, 3, 10 + i), 1, 1024)
+        return s, lambda: B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=1024), lambda d: oracle.msadpcm(d, 1024, 1, 44100)
+    if kind == "qoa":
+        st = np.stack([pcm16(n, 44100, 3, 20 + 2 * i + c) for c in range(2)], 1).ravel()
+        s = oracle.gen_qoa(st, 2, 44100) + b"\0" * 8
+        return s, lambda: B.make_desc(N.CODEC_QOA, 2, 44100), lambda d: oracle.qoa(d)
+    if kind == "dfpwm":
+        a = oracle.pcm(pcm16(n, 32000, 3, 30 + i).tobytes(), 16, oracle.SIGNED, 1, 32000)
+        s = oracle.audio_dfpwm(a, True)
+        return s, lambda: B.make_desc(N.CODEC_DFPWM, 1, 32000), lambda d: oracle.dfpwm(d, 1, 32000)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["ima", "msadpcm", "qoa", "dfpwm"])
+@pytest.mark.parametrize("interp", ["cubic", "linear"])
+def test_resample_of_int_row_loaders_is_deferred_into_the_filter(ctx, oracle, monkeypatch, kind, interp):
+    """BASELINE config 3 as written (aukit.wav -> resample(48000, cubic) -> effects.lowpass) and its siblings: the loader's int16 / int8 rows
+    stay as they are, the resample is owed, the one-pole filter pays it in ONE launch (k_rs_onepole); any other consumer materialises it."""
+    B, N = _B(), _N()
+    made = [_loader(oracle, kind, i, n) for i, n in enumerate((12000, 5000, 2100))]
+    streams = [m[0] for m in made]
+    desc, load = made[0][1](), made[0][2]
+    bt = B.Batch.upload(ctx, streams)
+
+    def chain(which):
+        a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
+        n0 = ctx.last_kernel()[0]
+        if which == "download":
+            return a.download(), n0
+        B.effect(ctx, a, which, 11025.0 if which == "lowpass" else 20.0)
+        return a.download(), (n0, ctx.last_kernel()[0])
+
+    got, n0 = chain("download")
+    assert n0 == "(resample deferred)", n0
+    monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
+    plain, p0 = chain("download")
+    monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
+    assert p0 != "(resample deferred)"
+    for s in range(len(streams)):
+        for c in range(len(got[s])):
+            assert np.array_equal(got[s][c], plain[s][c]), (s, c)   # materialised by the same kernel the undeferred call runs
+    for which in ("lowpass", "highpass"):
+        rows, (n0, n1) = chain(which)
+        assert n0 == "(resample deferred)" and n1 == "k_rs_onepole<" + which + ">", (n0, n1)
+        for s_i, s in enumerate(streams):
+            ref = oracle.resample(load(s), 48000, oracle.INTERP[interp])
+            ref = oracle.fx_lowpass(ref, 11025.0) if which == "lowpass" else oracle.fx_highpass(ref, 20.0)
+            for c in range(len(ref.data)):
+                assert len(rows[s_i][c]) == len(ref.data[c])
+                assert rms(rows[s_i][c], ref.data[c]) <= 1e-6, (which, s_i, c)
+    # a step repeated on the same output audio hands the rows' buffer back and forth without growing anything
+    a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
+    for _ in range(3):
+        a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32, out=a)
+        B.effect(ctx, a, "lowpass", 11025.0)
+    ref = oracle.fx_lowpass(oracle.resample(load(streams[0]), 48000, oracle.INTERP[interp]), 11025.0)
+    assert rms(a.download()[0][0], ref.data[0]) <= 1e-6
+
+
+def _states(ctx, oracle):
+    """audios of the same content in every deferred state: (name, factory) — nothing owed, resample owed (contiguous int16 rows), resample owed
+    (FLAC frames where the fused decoder left them), normalize owed, resample owed then filtered + normalize owed"""
+    B, N = _B(), _N()
+    ima = [oracle.gen_ima(pcm16(1016 * nb, 22050, 3, 40 + i), 1, 512, 15) for i, nb in enumerate((9, 3))]
+    flac = [oracle.gen_flac(np.stack([pcm16(n, 44100, 5, 50 + 2 * i + c) for c in range(2)], 1).astype(np.int64).ravel(), 2, 16, 44100, 1152) for i, n in enumerate((9000, 3000))]
+    bi, bf = B.Batch.upload(ctx, ima), B.Batch.upload(ctx, flac)
+    di, df = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), B.make_desc(N.CODEC_FLAC)
+
+    def ima_rs():
+        return B.decode_resample(ctx, bi, di, 48000, "cubic", dtype=N.F32)
+
+    def flac_rs():
+        return B.decode_resample(ctx, bf, df, 48000, "cubic", dtype=N.F32)
+
+    def flac_norm():
+        a = flac_rs()
+        B.effect(ctx, a, "highpass", 20.0)
+        B.effect(ctx, a, "normalize", 0.8)
+        return a
+
+    def ima_norm():
+        a = ima_rs()
+        B.effect(ctx, a, "normalize", 0.5)
+        return a
+    return [("ima resample owed", ima_rs), ("flac resample owed", flac_rs), ("flac filtered, normalize owed", flac_norm), ("ima normalize owed", ima_norm)]
+
+
+def test_every_consumer_of_device_rows_sees_finished_rows(ctx, oracle, monkeypatch):
+    """One accessor for an audio's device rows (audio_flush behind AUKIT_FLUSH; aukit_audio_device_ptr, the group's gather and every entry point
+    that reads samples go through it): whatever is owed — a resample, a normalize, both — download, download_raw, device_ptr views, clone,
+    mono, mix, an effect, Audio:pcm, a second resample and the structural ops return what the same calls return
+    with nothing deferred (AUKIT_NO_TAIL_FUSION=1)."""
+    B, N = _B(), _N()
+    def consumers(a):
+        out = {}
+        out["download"] = a().download()
+        out["clone"] = a().clone().download()
+        out["mono"] = B.mono(ctx, a()).download()
+        x = a()
+        B.effect(ctx, x, "amplify", 0.5)
+        out["amplify"] = x.download()
+        out["mix"] = B.mix(ctx, [a(), a()], 0.5).download()
+        out["pcm"] = B.encode_pcm(ctx, a(), 8, "signed", True).download()
+        out["resample"] = B.resample(ctx, a(), 32000, "linear").download()
+        out["reverse"] = B.reverse(ctx, a()).download()
+        x = a()
+        ptr = x.device_ptr()          # a view (what shard.py and the Lua shim's device face hand to RCCL): the rows must be final when the pointer leaves
+        inf = x.info()
+        lens, offs, strides = x.layout()
+        import ctypes as C
+        total = int(inf["total_elems"])
+        ctx.sync()
+        hip = C.CDLL("libamdhip64.so")   # (the HIP runtime the library itself is linked against, already loaded)
+        host = np.zeros(max(total, 1), dtype=np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(total * 4), 2) == 0   # hipMemcpyDeviceToHost
+        t = host
+        out["device view"] = [[t[int(offs[s]) + c * int(strides[s]): int(offs[s]) + c * int(strides[s]) + int(lens[s])].astype(np.float64)
+                               for c in range(inf["channels"])] for s in range(inf["n"])]
+        return out
+
+    for name, make in _states(ctx, oracle):
+        got = consumers(make)
+        monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
+        plain = consumers(make)
+        monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
+        for k in plain:
+            for s in range(len(plain[k])):
+                for c in range(len(plain[k][s])):
+                    g, p = np.asarray(got[k][s][c]), np.asarray(plain[k][s][c])
+                    assert g.shape == p.shape, (name, k, s, c)
+                    # the deferred resample + filter pass interpolates with phase weights where the undeferred kernels use the Horner form: f32 ulps
+                    tol = 1.0 if k == "pcm" else 4e-7   # (8-bit PCM: a value an ulp from a rounding boundary may land on either side)
+                    assert np.max(np.abs(g - p), initial=0) <= tol, (name, k, s, c, float(np.max(np.abs(g - p), initial=0)))
