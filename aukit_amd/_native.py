@@ -44,7 +44,7 @@ EXPORTS = [
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
     "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_close",
     "aukit_partition", "aukit_group_create", "aukit_group_destroy", "aukit_group_info", "aukit_group_ctx", "aukit_group_sync", "aukit_group_scatter",
-    "aukit_group_gather_audio", "aukit_group_gather_batch",
+    "aukit_group_gather_audio", "aukit_group_gather_batch", "aukit_group_run", "aukit_group_last_run",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
 ]
 
@@ -54,6 +54,18 @@ class CodecDesc(C.Structure):
                 ("data_type", C.c_int32), ("big_endian", C.c_int32), ("interleaved", C.c_int32), ("ulaw", C.c_int32),
                 ("top_first", C.c_int32), ("block_align", C.c_int32), ("ncoef", C.c_int32), ("coef1", C.c_int16 * 32),
                 ("coef2", C.c_int16 * 32), ("predictor", C.c_int32 * MAX_CH), ("step_index", C.c_int32 * MAX_CH)]
+
+
+GOP = {"none": 0, "decode": 1, "decode_resample": 2, "stream_decode": 3, "resample": 4, "mono": 5, "effect": 6, "dfpwm_encode": 7, "dfpwm_transcode_mono": 8,
+       "encode_pcm": 9, "sync": 10}
+
+
+class GroupCall(C.Structure):
+    """aukit_group_call (include/aukit_hip.h): one entry-point call of a member's list in aukit_group_run"""
+    _fields_ = [("op", C.c_int32), ("dtype", C.c_int32), ("interp", C.c_int32), ("mono", C.c_int32), ("batch", C.c_void_p), ("desc", C.c_void_p),
+                ("audio", C.c_void_p), ("out_audio", C.c_void_p), ("out_batch", C.c_void_p), ("out_chunks", C.c_void_p), ("new_rate", C.c_double),
+                ("effect_id", C.c_int32), ("nargs", C.c_int32), ("args", C.c_double * 8), ("channels", C.c_int32), ("interleaved", C.c_int32),
+                ("bit_depth", C.c_int32), ("data_type", C.c_int32)]
 
 
 class Container(C.Structure):

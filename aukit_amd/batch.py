@@ -166,6 +166,58 @@ class Group:
         N.check(N.lib().aukit_group_gather_batch(self._h, C.c_uint32(root), hs, C.byref(out._h)))
         return out
 
+    def run(self, lists):
+        """aukit_group_run: lists[r] = member r's calls, each a dict {"op": name, ...} with the entry point's arguments:
+        decode / decode_resample / stream_decode: batch, desc, dtype, [new_rate, interp, mono], out (AudioBatch), [chunks_out];
+        resample / mono / encode_pcm: audio, out; effect: audio, name, args; dfpwm_encode: audio, interleaved, out (Batch);
+        dfpwm_transcode_mono: batch, channels, out (Batch).  The members' lists run side by side on the group's worker threads."""
+        W = len(self.devices)
+        n_per = max([len(l) for l in lists] + [0])
+        calls = (N.GroupCall * (W * max(n_per, 1)))()
+        keep = []
+        for r in range(W):
+            for k, c in enumerate(lists[r]):
+                g = calls[r * n_per + k]
+                g.op = N.GOP[c["op"]]
+                g.dtype = int(c.get("dtype", self.contexts[r].dtype))
+                it = c.get("interp", "linear")
+                g.interp = N.INTERP[it] if isinstance(it, str) else int(it)
+                g.mono = int(bool(c.get("mono", False)))
+                if "batch" in c:
+                    g.batch = c["batch"]._h.value
+                if "desc" in c:
+                    keep.append(c["desc"])
+                    g.desc = C.addressof(c["desc"])
+                if "audio" in c:
+                    g.audio = c["audio"]._h.value
+                out = c.get("out")
+                if isinstance(out, AudioBatch):
+                    g.out_audio = C.addressof(out._h)
+                elif isinstance(out, Batch):
+                    g.out_batch = C.addressof(out._h)
+                if c.get("chunks_out") is not None:
+                    g.out_chunks = C.addressof(c["chunks_out"])
+                g.new_rate = float(c.get("new_rate", 0.0))
+                if c["op"] == "effect":
+                    g.effect_id = N.FX[c["name"]]
+                    a = [float(x) for x in c.get("args", ())]
+                    g.nargs = len(a)
+                    for i, x in enumerate(a):
+                        g.args[i] = x
+                g.channels = int(c.get("channels", 1))
+                g.interleaved = int(bool(c.get("interleaved", True)))
+                g.bit_depth = int(c.get("bit_depth", 8))
+                dt = c.get("data_type", "signed")
+                g.data_type = N.PCM_TYPE[dt] if isinstance(dt, str) else int(dt)
+        N.check(N.lib().aukit_group_run(self._h, calls, C.c_uint32(n_per)))
+
+    def last_run(self):
+        """→ [(start_ms, end_ms) per member] of the last run()"""
+        W = len(self.devices)
+        a, b = (C.c_double * W)(), (C.c_double * W)()
+        N.check(N.lib().aukit_group_last_run(self._h, a, b))
+        return [(a[r], b[r]) for r in range(W)]
+
     def sync(self):
         N.check(N.lib().aukit_group_sync(self._h))
 

@@ -14,6 +14,10 @@
 // tests of a one-GPU box drive every line of the peer path.
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "common.h"
 
 struct aukit_group {
@@ -28,6 +32,19 @@ struct aukit_group {
     int (*p_send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*p_recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*p_destroy)(void *) = nullptr;
+    // aukit_group_run: one worker thread per member, parked on `cv` between runs
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    uint64_t run_id = 0;                 // bumped by every aukit_group_run
+    uint32_t pending = 0;                // members still working on the current run
+    bool quit = false;
+    const aukit_group_call *calls = nullptr;
+    uint32_t n_per = 0;
+    std::vector<int> status;
+    std::vector<std::string> message;
+    std::vector<double> t_start, t_end;  // ms since the run's epoch
+    std::chrono::steady_clock::time_point epoch;
 };
 
 namespace aukit {
@@ -83,11 +100,92 @@ static int group_move(aukit_group *g, const std::vector<GroupMsg> &msgs, bool on
     return AUKIT_OK;
 }
 
+static_assert(sizeof(aukit_group_call) == 160, "aukit_group_call layout (aukit_amd/_native.py GroupCall, aukit_amd/lua/aukit.lua)");
+// one call of a member's list: the single-GPU entry point it names, on the member's context
+static int group_call(aukit_ctx *ctx, const aukit_group_call &c) {
+    switch (c.op) {
+    case AUKIT_GOP_NONE: return AUKIT_OK;
+    case AUKIT_GOP_DECODE: return aukit_decode(ctx, c.batch, c.desc, c.dtype, c.out_audio);
+    case AUKIT_GOP_DECODE_RESAMPLE: return aukit_decode_resample(ctx, c.batch, c.desc, c.new_rate, c.interp, c.dtype, c.out_audio);
+    case AUKIT_GOP_STREAM_DECODE: return aukit_stream_decode(ctx, c.batch, c.desc, c.interp, c.mono, c.dtype, c.out_audio, c.out_chunks);
+    case AUKIT_GOP_RESAMPLE: return aukit_resample(ctx, c.audio, c.new_rate, c.interp, c.out_audio);
+    case AUKIT_GOP_MONO: return aukit_mono(ctx, c.audio, c.out_audio);
+    case AUKIT_GOP_EFFECT: return aukit_effect(ctx, c.audio, c.effect_id, c.args, c.nargs);
+    case AUKIT_GOP_DFPWM_ENCODE: return aukit_dfpwm_encode(ctx, c.audio, c.interleaved, c.out_batch);
+    case AUKIT_GOP_DFPWM_TRANSCODE_MONO: return aukit_dfpwm_transcode_mono(ctx, c.batch, c.channels, c.out_batch);
+    case AUKIT_GOP_ENCODE_PCM: return aukit_encode_pcm(ctx, c.audio, c.bit_depth, c.data_type, c.interleaved, c.out_audio);
+    case AUKIT_GOP_SYNC: return aukit_ctx_sync(ctx);
+    }
+    return fail(AUKIT_E_ARG, "aukit_group_run: unknown op %d", c.op);
+}
+
+static void group_worker(aukit_group *g, uint32_t r) {
+    (void)hipSetDevice(g->dev[r]);   // (the device is per-thread state of the HIP runtime)
+    uint64_t seen = 0;
+    for (;;) {
+        const aukit_group_call *calls;
+        uint32_t n_per;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv.wait(lk, [&] { return g->quit || g->run_id != seen; });
+            if (g->quit) return;
+            seen = g->run_id;
+            calls = g->calls; n_per = g->n_per;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = AUKIT_OK;
+        std::string msg;
+        for (uint32_t k = 0; k < n_per; k++) {
+            const int r1 = group_call(g->ctx[r], calls[(size_t)r * n_per + k]);
+            if (r1 && !rc) { rc = r1; msg = aukit_last_error(); }   // (the message is this thread's: carried to the caller below)
+            if (r1) break;   // a member's list is a pipeline: what follows a failed call would read its missing output
+        }
+        if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess && !rc) { rc = AUKIT_E_HIP; msg = "hipStreamSynchronize failed in a group member"; }
+        const auto t1 = std::chrono::steady_clock::now();
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->status[r] = rc; g->message[r] = msg;
+            g->t_start[r] = std::chrono::duration<double, std::milli>(t0 - g->epoch).count();
+            g->t_end[r] = std::chrono::duration<double, std::milli>(t1 - g->epoch).count();
+            if (--g->pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
 }  // namespace aukit
 
 using namespace aukit;
 
 extern "C" {
+
+int aukit_group_run(aukit_group *g, const aukit_group_call *calls, uint32_t n_per_member) {
+    if (!g || (!calls && n_per_member)) return fail(AUKIT_E_ARG, "null argument");
+    const uint32_t W = (uint32_t)g->ctx.size();
+    if (g->workers.empty()) {   // started with the first run: a group that only scatters and gathers has no threads
+        g->status.assign(W, 0); g->message.assign(W, ""); g->t_start.assign(W, 0); g->t_end.assign(W, 0);
+        for (uint32_t r = 0; r < W; r++) g->workers.emplace_back(group_worker, g, r);
+    }
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->calls = calls; g->n_per = n_per_member;
+        g->pending = W;
+        g->epoch = std::chrono::steady_clock::now();
+        g->run_id++;
+        g->cv.notify_all();
+        g->cv_done.wait(lk, [&] { return g->pending == 0; });
+    }
+    for (uint32_t r = 0; r < W; r++)
+        if (g->status[r]) return fail(g->status[r], "%s", g->message[r].c_str());
+    return AUKIT_OK;
+}
+
+int aukit_group_last_run(const aukit_group *g, double *start_ms, double *end_ms) {
+    if (!g || !start_ms || !end_ms) return fail(AUKIT_E_ARG, "null argument");
+    if (g->t_start.empty()) return fail(AUKIT_E_ARG, "no aukit_group_run yet");
+    const double t0 = *std::min_element(g->t_start.begin(), g->t_start.end());
+    for (size_t r = 0; r < g->ctx.size(); r++) { start_ms[r] = g->t_start[r] - t0; end_ms[r] = g->t_end[r] - t0; }
+    return AUKIT_OK;
+}
 
 // Contiguous stream ranges per rank, balanced by input bytes: rank g takes the streams whose cumulative byte midpoint falls in
 // [g / world, (g + 1) / world) of the total — contiguous (outputs concatenate in rank order) and within one stream of the ideal split.
@@ -163,6 +261,12 @@ int aukit_group_create(aukit_group **out, const int *devices, uint32_t n_devices
 
 void aukit_group_destroy(aukit_group *g) {
     if (!g) return;
+    if (!g->workers.empty()) {
+        { std::lock_guard<std::mutex> lk(g->mu); g->quit = true; }
+        g->cv.notify_all();
+        for (std::thread &t : g->workers) t.join();
+        g->workers.clear();
+    }
     for (size_t r = 0; r < g->ctx.size(); r++) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream); }
     if (g->p_destroy) for (void *c : g->comms) if (c) g->p_destroy(c);
     for (size_t r = 0; r < g->ev.size(); r++) { (void)hipSetDevice(g->dev[r]); if (g->ev[r]) (void)hipEventDestroy(g->ev[r]); }
@@ -197,6 +301,8 @@ int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole,
     int rc = aukit_partition(sizes.data(), whole->n, W, cuts);
     if (rc) return rc;
     std::vector<GroupMsg> msgs;
+    // a failure part-way must not leave the caller with a half-filled shards[]: what this call allocated is freed and nulled
+    auto undo = [&](int code) { for (uint32_t q = 0; q < W; q++) if (shards[q]) { aukit_batch_free(shards[q]); shards[q] = nullptr; } return code; };
     for (uint32_t r = 0; r < W; r++) {
         const uint32_t lo = cuts[r], hi = cuts[r + 1];
         std::vector<uint64_t> off((size_t)(hi - lo) + 1);
@@ -204,21 +310,22 @@ int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole,
         const uint64_t bytes = off.back();
         if (shards[r]) { aukit_batch_free(shards[r]); shards[r] = nullptr; }
         if (r == root) {
-            if ((rc = aukit_batch_wrap_device(g->ctx[r], &shards[r], whole->data() + whole->off[lo], off.data(), hi - lo))) return rc;
+            if ((rc = aukit_batch_wrap_device(g->ctx[r], &shards[r], whole->data() + whole->off[lo], off.data(), hi - lo))) return undo(rc);
             continue;
         }
         // an owned batch of member r's device with the same offsets
-        AUKIT_HIP_CHECK(hipSetDevice(g->dev[r]));
+        if (hipSetDevice(g->dev[r]) != hipSuccess) return undo(fail(AUKIT_E_HIP, "hipSetDevice failed"));
         aukit_batch *b = new aukit_batch();
         b->n = hi - lo; b->off = off; b->front_pad = 64; b->cap = (size_t)bytes + 128; b->own = true;
-        if (hipMalloc((void **)&b->base, b->cap) != hipSuccess) { delete b; return fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed", b->cap); }
-        if (hipMalloc((void **)&b->d_off, (off.size()) * 8) != hipSuccess) { (void)hipFree(b->base); delete b; return fail(AUKIT_E_NOMEM, "hipMalloc failed"); }
-        if ((rc = h2d_table(g->ctx[r], b->d_off, off.data(), off.size() * 8))) { aukit_batch_free(b); return rc; }
+        if (hipMalloc((void **)&b->base, b->cap) != hipSuccess) { delete b; return undo(fail(AUKIT_E_NOMEM, "hipMalloc(%zu) failed", b->cap)); }
+        if (hipMalloc((void **)&b->d_off, (off.size()) * 8) != hipSuccess) { (void)hipFree(b->base); delete b; return undo(fail(AUKIT_E_NOMEM, "hipMalloc failed")); }
+        if ((rc = h2d_table(g->ctx[r], b->d_off, off.data(), off.size() * 8))) { aukit_batch_free(b); return undo(rc); }
         b->version = 1;
         shards[r] = b;
         msgs.push_back(GroupMsg{whole->data() + whole->off[lo], b->data(), (size_t)bytes, root, r});
     }
-    return group_move(g, msgs, true, root);
+    rc = group_move(g, msgs, true, root);
+    return rc ? undo(rc) : AUKIT_OK;
 }
 
 // parts[r] is member r's result (same channel count, rate, dtype); *whole — on member `root` — gets every stream of every part in rank order.

@@ -50,6 +50,22 @@ aukit_ctx *aukit_group_ctx(aukit_group *g, uint32_t rank); int aukit_group_sync(
 int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole, aukit_batch **shards, uint32_t *cuts);
 int aukit_group_gather_audio(aukit_group *g, uint32_t root, aukit_audio *const *parts, aukit_audio **whole);
 int aukit_group_gather_batch(aukit_group *g, uint32_t root, aukit_batch *const *parts, aukit_batch **whole);
+typedef struct {
+    int32_t op;
+    int32_t dtype, interp, mono;
+    const aukit_batch *batch;
+    const aukit_codec_desc *desc;
+    aukit_audio *audio;
+    aukit_audio **out_audio;
+    aukit_batch **out_batch;
+    aukit_chunks **out_chunks;
+    double new_rate;
+    int32_t effect_id, nargs;
+    double args[8];
+    int32_t channels, interleaved;
+    int32_t bit_depth, data_type;
+} aukit_group_call;
+int aukit_group_run(aukit_group *g, const aukit_group_call *calls, uint32_t n_per_member);
 int aukit_decode_nibbles(aukit_ctx *, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out);
 int aukit_stream_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
@@ -682,6 +698,35 @@ function aukit.gpus(devices)
     check(C.aukit_group_create(g, devs, n))
     local group = {handle = ffi.gc(g[0], C.aukit_group_destroy), size = n}
     function group:ctx(rank) return C.aukit_group_ctx(self.handle, rank) end
+    -- group:run(lists): lists[r + 1] = member r's calls, each a table {op = "decode_resample", batch = b, desc = d, new_rate = 48000, interp = "cubic",
+    -- dtype = 1, out = ffi.new("aukit_audio*[1]")} / {op = "effect", audio = a, name = "highpass", args = {20}} / {op = "mono", audio = a, out = o} /
+    -- {op = "dfpwm_transcode_mono", batch = b, channels = 2, out = ffi.new("aukit_batch*[1]")} ...  The members' lists run SIDE BY SIDE on the
+    -- library's worker threads (aukit_group_run) — from this one Lua state, with no callback into it — where calling the entry points member
+    -- after member from here would run the shards of a codec that reads counts back (FLAC, DFPWM, the ADPCMs, QOA) one after another.
+    local GOP = {decode = 1, decode_resample = 2, stream_decode = 3, resample = 4, mono = 5, effect = 6, dfpwm_encode = 7, dfpwm_transcode_mono = 8, encode_pcm = 9, sync = 10}
+    function group:run(lists)
+        local per = 0
+        for r = 1, n do per = math.max(per, #(lists[r] or {})) end
+        local calls = ffi.new("aukit_group_call[?]", n * math.max(per, 1))
+        for r = 1, n do
+            for k, c in ipairs(lists[r] or {}) do
+                local g = calls[(r - 1) * per + k - 1]
+                g.op = GOP[c.op]
+                g.dtype = c.dtype or F64; g.interp = INTERP[c.interp or "linear"]; g.mono = c.mono and 1 or 0
+                g.batch = c.batch; g.desc = c.desc; g.audio = c.audio
+                if c.op == "dfpwm_encode" or c.op == "dfpwm_transcode_mono" then g.out_batch = c.out else g.out_audio = c.out end
+                g.out_chunks = c.chunks_out
+                g.new_rate = c.new_rate or 0
+                if c.op == "effect" then
+                    g.effect_id = FX[c.name]; g.nargs = #(c.args or {})
+                    for i, v in ipairs(c.args or {}) do g.args[i - 1] = v end
+                end
+                g.channels = c.channels or 1; g.interleaved = (c.interleaved == false) and 0 or 1
+                g.bit_depth = c.bit_depth or 8; g.data_type = DTYPE[c.data_type or "signed"]
+            end
+        end
+        check(C.aukit_group_run(self.handle, calls, per))
+    end
     function group:map(strings, fn, root)
         root = root or 0
         local total, offs = 0, ffi.new("uint64_t[?]", #strings + 1)

@@ -276,6 +276,38 @@ int aukit_group_sync(aukit_group *g);
 int aukit_group_scatter(aukit_group *g, uint32_t root, const aukit_batch *whole, aukit_batch **shards, uint32_t *cuts /* n_devices + 1 */);
 int aukit_group_gather_audio(aukit_group *g, uint32_t root, aukit_audio *const *parts /* n_devices */, aukit_audio **whole);
 int aukit_group_gather_batch(aukit_group *g, uint32_t root, aukit_batch *const *parts /* n_devices */, aukit_batch **whole);
+/* The members' work, side by side (round 4).  Calling the single-GPU entry points on aukit_group_ctx(g, r) one member after another from the
+ * host's one thread runs them one AFTER another wherever an entry point waits for its device (the block codecs read counts back: FLAC five
+ * times per call, DFPWM, MS-ADPCM, QOA, IMA) — eight shards of BASELINE configs 4 and 5 in sequence.  aukit_group_run hands every member a
+ * list of calls; the group's worker threads — one per member, each bound to its member's device and context — run the lists concurrently
+ * and the call returns when all are through ("one scatter, N independent runs, one gather": SURVEY.md §8e).  A call is one entry point:
+ * its `op` names it, the other fields are that entry point's arguments (unused ones ignored); a member's calls run in order, so a pipeline
+ * (decode_resample -> effect -> effect -> mono) is one list.  `calls` holds n_per_member entries per member, member-major; an entry with op
+ * AUKIT_GOP_NONE is skipped.  Returns the first failing member's status (its message in aukit_last_error()); the other members finish their
+ * lists regardless.  No callbacks into the host: a LuaJIT host calls this from its one Lua state. */
+typedef enum {
+    AUKIT_GOP_NONE = 0, AUKIT_GOP_DECODE = 1, AUKIT_GOP_DECODE_RESAMPLE = 2, AUKIT_GOP_STREAM_DECODE = 3, AUKIT_GOP_RESAMPLE = 4, AUKIT_GOP_MONO = 5,
+    AUKIT_GOP_EFFECT = 6, AUKIT_GOP_DFPWM_ENCODE = 7, AUKIT_GOP_DFPWM_TRANSCODE_MONO = 8, AUKIT_GOP_ENCODE_PCM = 9, AUKIT_GOP_SYNC = 10
+} aukit_group_op;
+typedef struct {
+    int32_t op;                     /* aukit_group_op */
+    int32_t dtype, interp, mono;    /* decode / decode_resample / stream_decode */
+    const aukit_batch *batch;       /* decode, decode_resample, stream_decode, dfpwm_transcode_mono: the member's shard */
+    const aukit_codec_desc *desc;
+    aukit_audio *audio;             /* resample, mono, dfpwm_encode, encode_pcm: the input; effect: the audio changed in place */
+    aukit_audio **out_audio;        /* decode*, stream_decode, resample, mono, encode_pcm */
+    aukit_batch **out_batch;        /* dfpwm_encode, dfpwm_transcode_mono */
+    aukit_chunks **out_chunks;      /* stream_decode (may be NULL) */
+    double new_rate;                /* decode_resample, resample */
+    int32_t effect_id, nargs;       /* effect */
+    double args[8];
+    int32_t channels, interleaved;  /* dfpwm_transcode_mono: channels; dfpwm_encode / encode_pcm: interleaved */
+    int32_t bit_depth, data_type;   /* encode_pcm */
+} aukit_group_call;
+int aukit_group_run(aukit_group *g, const aukit_group_call *calls /* n_devices * n_per_member */, uint32_t n_per_member);
+/* when the members of the last aukit_group_run started and ended, in milliseconds after the first of them started (host clock around each
+ * member's list, the member's stream drained at the end): evidence of the overlap */
+int aukit_group_last_run(const aukit_group *g, double *start_ms /* n_devices */, double *end_ms /* n_devices */);
 
 /* ---- aukit.stream.<codec>(fn, ...): the reader-FUNCTION input (aukit.lua:2776-2786 and siblings; austream.lua:19-64), as a resumable handle.
  * Bytes are fed in any pieces; the chunks handed out are exactly those aukit.stream.<codec>(s, ...) hands out for the string s = every

@@ -74,7 +74,7 @@ def _params(proto):
         words = [w for w in a.split() if w != "const"]
         # the last word is the parameter's name unless the declaration is unnamed (type only)
         base_types = {"int", "double", "uint32_t", "uint64_t", "int32_t", "uint8_t", "void", "float", "char", "aukit_ctx", "aukit_batch", "aukit_audio", "aukit_chunks",
-                      "aukit_codec_desc", "aukit_container"}
+                      "aukit_codec_desc", "aukit_container", "aukit_group", "aukit_group_call"}
         if len(words) > 1 and words[-1] not in base_types:
             words = words[:-1]
         out.append(" ".join(words) + "*" * stars)
@@ -109,11 +109,12 @@ def test_lua_shim_declarations_match_the_header():
             names.append(re.sub(r"\[.*?\]", "", first.split()[-1]).strip("*"))
             names += [re.sub(r"\[.*?\]", "", r.strip()) for r in rest]
         return names
-    for st in ("aukit_codec_desc", "aukit_container"):
+    for st in ("aukit_codec_desc", "aukit_container", "aukit_group_call"):
         assert fields(cdef, st) == fields(hdr, st), st
 
 
 def test_container_struct_layout():
     import ctypes as C
     from aukit_amd import _native as N
+    assert C.sizeof(N.GroupCall) == 160 and N.GroupCall.new_rate.offset == 64 and N.GroupCall.args.offset == 80   # static_assert in group.hip
     assert C.sizeof(N.Container) == 240 + 8 + 8 + 4 + 4 + 8 and N.Container.payload_off.offset == 240 and N.Container.length_seconds.offset == 264
