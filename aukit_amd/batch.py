@@ -146,6 +146,7 @@ class Group:
         W = len(self.devices)
         hs = (C.c_void_p * W)()
         cuts = np.zeros(W + 1, dtype=np.uint32)
+        # (on failure the library frees and nulls what it allocated in this call: nothing to release here — ADVICE r03)
         N.check(N.lib().aukit_group_scatter(self._h, C.c_uint32(root), whole._h, hs, cuts.ctypes.data_as(C.POINTER(C.c_uint32))))
         shards = []
         for r in range(W):

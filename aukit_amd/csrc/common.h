@@ -169,6 +169,10 @@ struct DfSliceHook {
     int slices = 1;
     std::function<int(unsigned, unsigned, unsigned long long, unsigned long long)> after_slice;
 };
+// contexts that exist (runtime.hip): an audio remembers the context its deferred work was queued on (pend_ctx, lazy_ctx) and must not touch it once
+// it is gone; owner_ready() makes `ctx` (the context about to pay the work) wait for what `owner` has queued when the two differ
+bool ctx_is_live(const aukit_ctx *c);
+int owner_ready(aukit_ctx *ctx, aukit_ctx *owner);
 // applies a deferred map (aukit_audio::pend_norm) in place; every entry point that reads an audio's samples calls it first
 int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
 #define AUKIT_FLUSH(ctx, a)                                                   \

@@ -530,8 +530,9 @@ int audio_flush(aukit_ctx *ctx, const aukit_audio *ca) {
     aukit_audio *a = const_cast<aukit_audio *>(ca);
     if (a && a->lazy_rs) { int lrc = lazy_materialize(ctx, a); if (lrc) return lrc; }   // an owed resample first (flac_tail.hip)
     if (!a || !a->pend_norm) return AUKIT_OK;
-    if (!ctx) ctx = a->pend_ctx;
+    if (!ctx) ctx = ctx_is_live(a->pend_ctx) ? a->pend_ctx : nullptr;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred map and no context to apply it with");
+    { int orc = owner_ready(ctx, a->pend_ctx); if (orc) return orc; }   // the pass that left the rows and their maxima ran on pend_ctx's stream
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     a->pend_norm = false;
     MapArgs A{};

@@ -6,7 +6,7 @@
 // buffer moves from the context's scratch into the audio, so no later call can overwrite it) and the resample is owed.  If the next call is
 // effects.highpass / lowpass, k_rs_onepole below pays it inside the filter pass: one workgroup walks one output row tile by tile —
 //   stage the tile's window of int32 samples as f32 (the `/ 2^depth` of :505 is an exact scaling) → interpolate exactly as
-//   k_fast_wave<i32> does (exact rational positions, f32 Horner form: the same f32 values) → run the one-pole recurrence over the tile in fp64,
+//   k_fast_wave<i32> does (exact rational positions; cubic through per-phase weights where the rate's denominator allows: within an f32 ulp or two of that kernel's Horner form, so `resample` then `highpass` may differ in the last bit from the unfused calls — tests: 4e-7) → run the one-pole recurrence over the tile in fp64,
 //   thread ↔ 8 consecutive outputs with an affine carry scan across the workgroup and the carry of the tile before (the high-pass at 20 Hz
 //   remembers thousands of samples: no truncation here, cf. stream_tail.hip) → store f32, record the row's |max| for effects.normalize.
 // Anything else that reads the samples first (download, another effect, Audio:mono ...) materialises the resample with the ordinary kernel
@@ -305,8 +305,9 @@ void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
 // the owed resample with the ordinary kernel, into the audio's own rows
 int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
     if (!a->lazy_rs) return AUKIT_OK;
-    if (!ctx) ctx = a->lazy_ctx;
+    if (!ctx) ctx = ctx_is_live(a->lazy_ctx) ? a->lazy_ctx : nullptr;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred resample and no context to run it with");
+    { int orc = owner_ready(ctx, a->lazy_ctx); if (orc) return orc; }   // the decoder wrote the rows on lazy_ctx's stream
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     if (a->lazy_indirect) {   // frame by frame in the fused decoder's scratch: contiguous rows first (k_flac_gather)
         int grc;
@@ -403,6 +404,7 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
 bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc) {
     *rc = AUKIT_OK;
     if (!a->lazy_rs || a->dtype != AUKIT_F32) return false;
+    if ((*rc = owner_ready(ctx, a->lazy_ctx))) return true;
     FastParams F;
     if (!fast_eligible(a->lazy_src == SRC_I16 ? SRC_PCM_S16LE_MONO : (a->lazy_src == SRC_I8 ? SRC_PCM8_MONO : SRC_I32), a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
     constexpr int T = 512;

@@ -1,5 +1,7 @@
 // runtime.hip — contexts, batches, audio objects, scratch tables, timers (host side of the C ABI).
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include "common.h"
 
 namespace aukit {
@@ -186,6 +188,23 @@ extern "C" {
 int aukit_abi_version(void) { return AUKIT_ABI_VERSION; }
 const char *aukit_last_error(void) { return g_err; }
 
+}  // extern "C"
+namespace aukit {
+static std::mutex g_live_mu;
+static std::set<const aukit_ctx *> g_live;
+bool ctx_is_live(const aukit_ctx *c) { std::lock_guard<std::mutex> lk(g_live_mu); return c && g_live.count(c) != 0; }
+// `ctx` is about to finish work that `owner` queued the inputs of (a decoder's rows behind a deferred resample, a filter pass behind a deferred
+// normalize): when they are different contexts, ctx's stream waits for owner's — if owner still exists; an audio outlives its context legally
+int owner_ready(aukit_ctx *ctx, aukit_ctx *owner) {
+    if (!owner || owner == ctx || !ctx_is_live(owner)) return AUKIT_OK;
+    AUKIT_HIP_CHECK(hipSetDevice(owner->device));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(owner->stream));   // (rare: a host wait is the simple, device-agnostic order)
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    return AUKIT_OK;
+}
+}  // namespace aukit
+extern "C" {
+
 int aukit_ctx_create(aukit_ctx **out, int device) {
     if (!out) return fail(AUKIT_E_ARG, "out is null");
     int count = 0;
@@ -205,12 +224,14 @@ int aukit_ctx_create(aukit_ctx **out, int device) {
     AUKIT_HIP_CHECK(hipEventCreate(&c->ev1));
     AUKIT_HIP_CHECK(hipEventCreate(&c->kev0));
     AUKIT_HIP_CHECK(hipEventCreate(&c->kev1));
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(c); }
     *out = c;
     return AUKIT_OK;
 }
 
 void aukit_ctx_destroy(aukit_ctx *c) {
     if (!c) return;
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.erase(c); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release();
@@ -409,7 +430,11 @@ int aukit_audio_layout(const aukit_audio *a, uint64_t *lens, uint64_t *row_off, 
 }
 void *aukit_audio_device_ptr(const aukit_audio *a) {
     if (!a) return nullptr;
-    if ((a->pend_norm || a->lazy_rs) && audio_flush(a->pend_norm ? a->pend_ctx : a->lazy_ctx, a)) return nullptr;  // the caller reads the samples: deferred work is done first
+    if (a->pend_norm || a->lazy_rs) {   // the caller reads the samples: deferred work is done first, on the context that queued it — if that still exists
+        aukit_ctx *owner = a->lazy_rs ? a->lazy_ctx : a->pend_ctx;
+        if (!ctx_is_live(owner)) { fail(AUKIT_E_ARG, "audio has deferred work and its context is gone: pass it through an entry point that takes a context first"); return nullptr; }
+        if (audio_flush(owner, a)) return nullptr;
+    }
     const_cast<aukit_audio *>(a)->rowmax_valid = false;              // ... and may write them
     return a->dev;
 }

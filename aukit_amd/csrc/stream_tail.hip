@@ -332,6 +332,7 @@ struct TailShape { bool ok = false, fast = false; int C = 1, E = 4, T = 1024, W 
 static TailShape tail_shape(aukit_ctx *ctx, int kind, int rows_kind, int mix_channels, double rate, double full, int interp, int dtype, uint64_t max_nout, uint64_t avg_nout) {
     TailShape S;
     if (interp < 0 || interp > 2 || (dtype != AUKIT_F64 && dtype != AUKIT_F32) || getenv("AUKIT_NO_IIR_TAIL")) return S;
+    if (ctx->exact_math == 2) return S;   // "always the reference-order kernels": the carried two-pass recurrence, not the warm-up tiles
     if (kind == TAIL_QOA && rows_kind != TAIL_ROWS_I8) return S;
     if (kind == TAIL_FLAC && (rows_kind == TAIL_ROWS_I8 || mix_channels > 1)) return S;
     S.C = std::max(1, mix_channels);

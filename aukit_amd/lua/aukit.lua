@@ -727,6 +727,32 @@ function aukit.gpus(devices)
         end
         check(C.aukit_group_run(self.handle, calls, per))
     end
+    -- group:scatter(strings, root) -> shards (aukit_batch*[n], 0-based), cuts; keep the returned `whole` alive while the shards are in use
+    function group:scatter(strings, root)
+        root = root or 0
+        local total, offs = 0, ffi.new("uint64_t[?]", #strings + 1)
+        for i, s in ipairs(strings) do offs[i - 1] = total; total = total + #s end
+        offs[#strings] = total
+        local whole = ffi.new("aukit_batch*[1]")
+        check(C.aukit_batch_upload(self:ctx(root), whole, ffi.cast("const uint8_t*", table.concat(strings)), offs, #strings))
+        local shards, cuts = ffi.new("aukit_batch*[?]", n), ffi.new("uint32_t[?]", n + 1)
+        check(C.aukit_group_scatter(self.handle, root, whole[0], shards, cuts))
+        return shards, cuts, whole
+    end
+    function group:gather_batches(outs, root)   -- outs[r] = aukit_batch*[1] of member r - 1
+        local parts, o = ffi.new("aukit_batch*[?]", n), ffi.new("aukit_batch*[1]")
+        for r = 1, n do parts[r - 1] = outs[r][0] end
+        check(C.aukit_group_gather_batch(self.handle, root or 0, parts, o))
+        check(C.aukit_group_sync(self.handle))
+        return o[0]
+    end
+    function group:gather_audios(outs, root)    -- outs[r] = aukit_audio*[1] of member r - 1
+        local parts, o = ffi.new("aukit_audio*[?]", n), ffi.new("aukit_audio*[1]")
+        for r = 1, n do parts[r - 1] = outs[r][0] end
+        check(C.aukit_group_gather_audio(self.handle, root or 0, parts, o))
+        check(C.aukit_group_sync(self.handle))
+        return o[0]
+    end
     function group:map(strings, fn, root)
         root = root or 0
         local total, offs = 0, ffi.new("uint64_t[?]", #strings + 1)

@@ -132,8 +132,11 @@ int aukit_ctx_set_sinc_window(aukit_ctx *ctx, int w);
 typedef enum {
     AUKIT_OPT_EXACT_MATH = 0, /* arithmetic behind AUKIT_F32 storage.  0 (default): f32 FMA taps on exact rational positions, ≤ 1e-6 RMS
                                  from the reference.  1: fp64 arithmetic, rounded to f32 once when stored (aukit.lua computes in
-                                 doubles, :261-266, :662-669): the fp64 phase-weight kernel where it applies (16-bit mono PCM),
-                                 else the reference-order kernels.  2: always the reference-order fp64 kernels. */
+                                 doubles, :261-266, :662-669) — fp64 values throughout, NOT the reference's operation order: the phase-weight
+                                 kernel (16-bit mono PCM, stream.pcm on it), the fp64 coefficient kernel (G.711 mono), fp64 tables with a
+                                 Horner form on the exact rational position (every other interleaved PCM format of one or two channels,
+                                 G.711 stereo); anything else runs the reference-order kernels.  Results may differ from value 2 by one
+                                 f32 ulp.  2: always the reference-order fp64 kernels (stream tails included). */
     AUKIT_OPT_STORE_X4 = 1,   /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
     AUKIT_OPT_COLLECT_STATS = 2 /* 1: calls that have counters (aukit_ctx_get_counter) read them back — one more device→host sync per call.
                                    0 (default): they do not. */

@@ -207,3 +207,15 @@ def test_partition_matches_the_numpy_statement():
             cuts = [int(np.searchsorted(owner, g, side="left")) for g in range(world)] + [n]
             want = [(cuts[g], cuts[g + 1]) for g in range(world)]
         assert B.partition(sizes.astype(np.uint64), world) == want, (trial, n, world)
+
+
+def test_partition_numpy_fallback_agrees_with_the_library():
+    """shard.partition falls back to numpy on a host without the built library: the two must cut alike"""
+    from aukit_amd import batch as B
+    from aukit_amd.shard import _partition_numpy
+    rng = np.random.Generator(np.random.PCG64(9))
+    for trial in range(300):
+        n = int(rng.integers(0, 60))
+        world = int(rng.integers(1, 10))
+        sizes = rng.integers(0, 9000, n) * (rng.integers(0, 2, n) if trial % 4 == 0 else 1)
+        assert _partition_numpy(sizes, world) == B.partition(sizes, world), (list(sizes), world)
