@@ -25,6 +25,7 @@
 #include "resample.h"
 #include "stream_tail.h"
 #include "flac_dev.h"
+#include "resample_dev.h"
 
 namespace aukit {
 
@@ -1758,7 +1759,7 @@ template <typename R> AUKIT_DEV double flac_row_value(const R *rows, u64 at, dou
 }
 template <int INTERP, typename OUT_T, typename R>
 __global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs, const R *rows, double full, OUT_T *out, double ratio, double rcp, int exact,
-                                                   double lp_alpha) {
+                                                   double lp_alpha, int sinc_w) {
     const u64 j = (u64)blockIdx.x * 64 + threadIdx.x;
     if (j >= njobs) return;
     const FsJob job = jobs[j];
@@ -1779,6 +1780,7 @@ __global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs
             const double fx = x - ffx;
             if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
             else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else if constexpr (INTERP == AUKIT_INTERP_SINC) s = sinc_at(tap, k, -1, n, fx, sinc_w);
             else {
                 const double p1 = tap(k), p0 = (k - 1 >= -1) ? tap(k - 1) : p1, p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2;
                 s = cubic_exact(p0, p1, p2, p3, fx);
@@ -1795,7 +1797,7 @@ __global__ __launch_bounds__(64) void k_flac_stream(const FsJob *jobs, u64 njobs
 // every output, all outputs in parallel, into a scratch of doubles; pass 2: the recursive low-pass (:3179) and the scaling, serially per job
 // over contiguous doubles, 32 per round with the next 32 in flight, 16-byte stores.  Same operations in the same order: same values.
 template <int INTERP, typename R>
-__global__ __launch_bounds__(256) void k_flac_stream_interp(const FsJob *jobs, const u64 *scr_off, const R *rows, double full, double *scr, double ratio, double rcp, int exact) {
+__global__ __launch_bounds__(256) void k_flac_stream_interp(const FsJob *jobs, const u64 *scr_off, const R *rows, double full, double *scr, double ratio, double rcp, int exact, int sinc_w) {
     const FsJob job = jobs[blockIdx.y];
     double m1 = 0, z0 = 0;
     if (job.last_off != ~0ull) z0 = flac_row_value(rows, job.last_off, full);
@@ -1814,6 +1816,7 @@ __global__ __launch_bounds__(256) void k_flac_stream_interp(const FsJob *jobs, c
             const double fx = x - ffx;
             if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
             else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else if constexpr (INTERP == AUKIT_INTERP_SINC) s = sinc_at(tap, k, -1, n, fx, sinc_w);
             else {
                 const double p1 = tap(k), p0 = (k - 1 >= -1) ? tap(k - 1) : p1, p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2;
                 s = cubic_exact(p0, p1, p2, p3, fx);
@@ -1897,7 +1900,7 @@ __global__ __launch_bounds__(64) void k_flac_tail_jobs(const FrameRec *frames, c
 }
 
 int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
-    if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.flac: interpolation must be none, linear or cubic");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "stream.flac: bad interpolation");   // (sinc: the reference-order kernels below — aukit.defaultInterpolation = "sinc" is legal at :3156)
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.flac output must be AUKIT_F64 or AUKIT_F32");
     FlacDecoded D;
     static const bool TT = getenv("AUKIT_HOST_TIMING") != nullptr;
@@ -2015,9 +2018,9 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             double *scr = reinterpret_cast<double *>(ctx->tmp_buf3.p);
             for (size_t first = 0; first < jobs.size(); first += 65535) {
                 const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)std::min<size_t>(65535, jobs.size() - first));
-#define AUKIT_FI2(I, R) hipLaunchKernelGGL((k_flac_stream_interp<I, R>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, reinterpret_cast<const R *>(ctx->tmp_buf.p), full, scr, ratio, 1.0 / ratio, exact)
+#define AUKIT_FI2(I, R) hipLaunchKernelGGL((k_flac_stream_interp<I, R>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, reinterpret_cast<const R *>(ctx->tmp_buf.p), full, scr, ratio, 1.0 / ratio, exact, ctx->sinc_w)
 #define AUKIT_FI(I) do { if (D.wide) AUKIT_FI2(I, double); else AUKIT_FI2(I, int); } while (0)
-                if (interp == 0) AUKIT_FI(0); else if (interp == 1) AUKIT_FI(1); else AUKIT_FI(2);
+                if (interp == 0) AUKIT_FI(0); else if (interp == 1) AUKIT_FI(1); else if (interp == 2) AUKIT_FI(2); else AUKIT_FI(3);
 #undef AUKIT_FI
 #undef AUKIT_FI2
             }
@@ -2026,10 +2029,10 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             else { if (D.wide) AUKIT_FR(float, double); else AUKIT_FR(float, int); }
 #undef AUKIT_FR
         } else {
-#define AUKIT_FS2(I, T, R) hipLaunchKernelGGL((k_flac_stream<I, T, R>), dim3(grid), dim3(64), 0, ctx->stream, dj, (u64)jobs.size(), reinterpret_cast<const R *>(ctx->tmp_buf.p), full, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
+#define AUKIT_FS2(I, T, R) hipLaunchKernelGGL((k_flac_stream<I, T, R>), dim3(grid), dim3(64), 0, ctx->stream, dj, (u64)jobs.size(), reinterpret_cast<const R *>(ctx->tmp_buf.p), full, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha, ctx->sinc_w)
 #define AUKIT_FS(I, T) do { if (D.wide) AUKIT_FS2(I, T, double); else AUKIT_FS2(I, T, int); } while (0)
-        if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_FS(0, double); else if (interp == 1) AUKIT_FS(1, double); else AUKIT_FS(2, double); }
-        else { if (interp == 0) AUKIT_FS(0, float); else if (interp == 1) AUKIT_FS(1, float); else AUKIT_FS(2, float); }
+        if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_FS(0, double); else if (interp == 1) AUKIT_FS(1, double); else if (interp == 2) AUKIT_FS(2, double); else AUKIT_FS(3, double); }
+        else { if (interp == 0) AUKIT_FS(0, float); else if (interp == 1) AUKIT_FS(1, float); else if (interp == 2) AUKIT_FS(2, float); else AUKIT_FS(3, float); }
 #undef AUKIT_FS
 #undef AUKIT_FS2
         }

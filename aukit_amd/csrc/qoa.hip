@@ -393,7 +393,8 @@ int decode_qoa_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_de
 // aukit.stream.qoa(data, mono)  aukit.lua:3202-3337
 int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
     if (getenv("AUKIT_QOA_HOST")) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
-    if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.qoa: interpolation must be none, linear or cubic");
+    if (interp == AUKIT_INTERP_SINC) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);   // aukit.defaultInterpolation = "sinc" (:3252): the reference-order kernels
+    if (interp < 0 || interp > 2) return fail(AUKIT_E_ARG, "stream.qoa: bad interpolation");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.qoa output must be AUKIT_F64 or AUKIT_F32");
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
     QoaLaps laps;

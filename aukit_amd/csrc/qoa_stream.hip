@@ -6,6 +6,7 @@
 // int16 rows (L2-resident), history of the previous call through two extra slots.  Not on a BASELINE config.
 #include <algorithm>
 #include "resample.h"
+#include "resample_dev.h"
 
 namespace aukit {
 
@@ -21,7 +22,7 @@ struct QsJob {
 
 template <int INTERP, typename OUT_T>
 __global__ __launch_bounds__(64) void k_qoa_stream(const QsJob *jobs, unsigned long long njobs, const short *rows, OUT_T *out, double ratio, double rcp, int exact,
-                                                  double lp_alpha) {
+                                                  double lp_alpha, int sinc_w) {
     const unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
     if (j >= njobs) return;
     const QsJob job = jobs[j];
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(64) void k_qoa_stream(const QsJob *jobs, unsigned l
             const double fx = x - ffx;
             if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
             else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else if constexpr (INTERP == AUKIT_INTERP_SINC) s = sinc_at(tap, k, -1, n, fx, sinc_w);
             else { const double p1 = tap(k), p0 = tap(k - 1), p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2; s = cubic_exact(p0, p1, p2, p3, fx); }
             s = lua_clamp(s, -128, 127);  // :3323
         }
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(64) void k_qoa_stream(const QsJob *jobs, unsigned l
 // (ls = filtered s, :3324-3325) serially per job over contiguous doubles, 32 per round with the next 32 in flight.
 template <int INTERP>
 __global__ __launch_bounds__(256) void k_qoa_stream_interp(const QsJob *jobs, const unsigned long long *scr_off, const short *rows, double *scr, double ratio, double rcp,
-                                                          int exact) {
+                                                          int exact, int sinc_w) {
     const QsJob job = jobs[blockIdx.y];
     const short *src = rows + job.src_off;
     double m1 = 0, z0 = 0;
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void k_qoa_stream_interp(const QsJob *jobs, co
             const double fx = x - ffx;
             if constexpr (INTERP == AUKIT_INTERP_NONE) s = tap(k);
             else if constexpr (INTERP == AUKIT_INTERP_LINEAR) { const double a = tap(k), b = (k + 1 <= n) ? tap(k + 1) : a; s = linear_exact(a, b, fx); }
+            else if constexpr (INTERP == AUKIT_INTERP_SINC) s = sinc_at(tap, k, -1, n, fx, sinc_w);
             else { const double p1 = tap(k), p0 = tap(k - 1), p2 = (k + 1 <= n) ? tap(k + 1) : p1, p3 = (k + 2 <= n) ? tap(k + 2) : p2; s = cubic_exact(p0, p1, p2, p3, fx); }
             s = lua_clamp(s, -128, 127);  // :3323
         }
@@ -137,7 +140,7 @@ struct QFrame { uint64_t off; int samples; };
 
 // round 2's aukit.stream.qoa: the fallback of qoa.hip (frames of more than 8192 samples, sample rates below ≈ 300 Hz)
 int stream_qoa_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks_out) {
-    if (interp < 0 || interp > 2) return fail(interp == AUKIT_INTERP_SINC ? AUKIT_E_UNSUPPORTED : AUKIT_E_ARG, "stream.qoa: interpolation must be none, linear or cubic");
+    if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "stream.qoa: bad interpolation");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.qoa output must be AUKIT_F64 or AUKIT_F32");
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
     // (through the context's pinned staging buffer: a fresh 360 MB std::vector — zero-filled, then page-faulted in by a pageable copy — was
@@ -283,16 +286,17 @@ int stream_qoa_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_des
             double *scr = reinterpret_cast<double *>(ctx->tmp_buf3.p);
             for (size_t first = 0; first < jobs.size(); first += 65535) {  // (grid.y holds 65535 jobs)
                 const dim3 g1((unsigned)std::min<uint64_t>((max_nout + 255) / 256, 1024), (unsigned)std::min<size_t>(65535, jobs.size() - first));
-                if (interp == 0) hipLaunchKernelGGL((k_qoa_stream_interp<0>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
-                else if (interp == 1) hipLaunchKernelGGL((k_qoa_stream_interp<1>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
-                else hipLaunchKernelGGL((k_qoa_stream_interp<2>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact);
+                if (interp == 0) hipLaunchKernelGGL((k_qoa_stream_interp<0>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact, ctx->sinc_w);
+                else if (interp == 1) hipLaunchKernelGGL((k_qoa_stream_interp<1>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact, ctx->sinc_w);
+                else if (interp == 2) hipLaunchKernelGGL((k_qoa_stream_interp<2>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact, ctx->sinc_w);
+                else hipLaunchKernelGGL((k_qoa_stream_interp<3>), g1, dim3(256), 0, ctx->stream, dj + first, dso + first, rows, scr, ratio, 1.0 / ratio, exact, ctx->sinc_w);
             }
             if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_qoa_stream_iir<double>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<double *>(a->dev), lp_alpha);
             else hipLaunchKernelGGL((k_qoa_stream_iir<float>), dim3(grid), dim3(64), 0, ctx->stream, dj, dso, (unsigned long long)jobs.size(), rows, scr, reinterpret_cast<float *>(a->dev), lp_alpha);
         } else {
-#define AUKIT_QS(I, T) hipLaunchKernelGGL((k_qoa_stream<I, T>), dim3(grid), dim3(64), 0, ctx->stream, dj, (unsigned long long)jobs.size(), rows, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha)
-        if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_QS(0, double); else if (interp == 1) AUKIT_QS(1, double); else AUKIT_QS(2, double); }
-        else { if (interp == 0) AUKIT_QS(0, float); else if (interp == 1) AUKIT_QS(1, float); else AUKIT_QS(2, float); }
+#define AUKIT_QS(I, T) hipLaunchKernelGGL((k_qoa_stream<I, T>), dim3(grid), dim3(64), 0, ctx->stream, dj, (unsigned long long)jobs.size(), rows, reinterpret_cast<T *>(a->dev), ratio, 1.0 / ratio, exact, lp_alpha, ctx->sinc_w)
+        if (dtype == AUKIT_F64) { if (interp == 0) AUKIT_QS(0, double); else if (interp == 1) AUKIT_QS(1, double); else if (interp == 2) AUKIT_QS(2, double); else AUKIT_QS(3, double); }
+        else { if (interp == 0) AUKIT_QS(0, float); else if (interp == 1) AUKIT_QS(1, float); else if (interp == 2) AUKIT_QS(2, float); else AUKIT_QS(3, float); }
 #undef AUKIT_QS
         }
         AUKIT_HIP_CHECK(hipGetLastError());

@@ -63,5 +63,21 @@ AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const TAB_T *ta
     }
 }
 
+// interpolate.sinc (:267-281) on a table whose indices lo .. hi hold numbers (everything else is nil and skipped): the block tables of stream.flac
+// and stream.qoa, indices -1 and 0 being the two samples kept from the block before (:3170-3171, :3312).  `tap(i)` reads entry i.
+template <class Tap> AUKIT_DEV double sinc_at(const Tap &tap, int k, int lo, int hi, double fx, int w) {
+    double sum = 0;
+    const double pi = 3.14159265358979323846;
+    for (int m = -w; m <= w; m++) {
+        const int idx = k + m;
+        if (idx >= lo && idx <= hi) {
+            const double d = tap(idx);
+            const double px = pi * (fx - m);
+            if (px == 0) sum = sum + d;
+            else sum = sum + d * sin(px) / px;
+        }
+    }
+    return sum;
+}
 
 }  // namespace aukit

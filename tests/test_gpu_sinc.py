@@ -43,3 +43,32 @@ def test_fused_and_stream_sinc(ctx, oracle):
     ref = oracle.stream_g711(g, True, 1, 8000, False, oracle.SINC)
     d = out.download()[0][0] - ref.data[0]
     assert np.max(np.abs(d)) <= 1 and np.count_nonzero(d) <= 2
+
+
+@pytest.mark.parametrize("dt", ["F64", "F32"])
+def test_stream_flac_and_qoa_sinc(ctx, oracle, dt):
+    """aukit.defaultInterpolation = "sinc" is legal for aukit.stream.flac (aukit.lua:3156) and aukit.stream.qoa (:3252): every block's table holds
+    numbers at indices -1 .. #block (the two samples kept from the block before at -1 and 0), nil elsewhere, and interpolate.sinc skips the
+    nils (:273).  Round 3 refused these with AUKIT_E_UNSUPPORTED (missing item 2)."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    dtype = getattr(N, dt)
+    tol = 1e-9 if dt == "F64" else 2e-5   # [-128, 127] scale: sin() comes from the device libm; f32 storage adds its rounding
+    pcms = [np.stack([pcm16(n, 44100, 6, 2 * i + c) for c in range(2)], 1) for i, n in enumerate((9000, 2500))]
+    fl = [oracle.gen_flac(p.astype(np.int64).ravel(), 2, 16, 44100, 1152) for p in pcms]
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, fl), B.make_desc(N.CODEC_FLAC), "sinc", dtype=dtype)
+    got = out.download()
+    for s, f in enumerate(fl):
+        ref = oracle.stream_flac(f, oracle.SINC)
+        for c in range(2):
+            assert len(got[s][c]) == len(ref.data[c])
+            assert np.max(np.abs(got[s][c] - ref.data[c]), initial=0) <= tol, (s, c)
+    qo = [oracle.gen_qoa(p.ravel(), 2, 44100) + b"\0" * 8 for p in pcms]
+    for mono in (False, True):
+        out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, qo), B.make_desc(N.CODEC_QOA, 2, 44100), "sinc", mono=mono, dtype=dtype)
+        got = out.download()
+        for s, q in enumerate(qo):
+            ref = oracle.stream_qoa(q, mono, oracle.SINC)
+            for c in range(1 if mono else 2):
+                assert len(got[s][c]) == len(ref.data[c])
+                assert np.max(np.abs(got[s][c] - ref.data[c]), initial=0) <= tol, (mono, s, c)
