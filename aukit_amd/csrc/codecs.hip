@@ -532,6 +532,7 @@ struct ImaStreamParams {
     unsigned long long bps;              // k_ima_stream_f32: blocks per stream when that is the same for every stream, else 0
     unsigned mid_lo, mid_end_full;       // k_ima_stream_f32: the clean rows of a full block (host-made: two 64-bit divisions per block otherwise)
     unsigned qstep;                      // k_ima_stream_f32<…, PH>: 64 PH fa / fb, the table entries that 64 PH outputs span (a whole number)
+    unsigned *audit;                     // k_ima_stream_f32<…, 0, true>: [0] bits of the largest |tier 1 - tier 2| (a non-negative float), [1] outputs compared
 };
 
 template <int INTERP, typename OUT_T>
@@ -667,8 +668,10 @@ struct CvImaF32 {
 #endif
 constexpr float TIER1_GUARD = AUKIT_IMA_TIER1_GUARD;
 
-template <int INTERP, typename OUT_T, int PH>
+template <int INTERP, typename OUT_T, int PH, bool AUDIT = false>
 __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P, const float *__restrict__ wg) {
+    [[maybe_unused]] float amax = 0.f;     // AUDIT (floor_wave.hip): what tier 1's f32 value really differs from tier 2's fp64 one by
+    [[maybe_unused]] unsigned acnt = 0;
     extern __shared__ float smf[];
     constexpr int WF = INTERP == AUKIT_INTERP_CUBIC ? 4 : 1;  // floats per phase: w0..w3 / fx
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -734,21 +737,24 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
         sg.w_lo = 1; sg.w_hi = (int)nb;
         OUT_T *obase = reinterpret_cast<OUT_T *>(P.out) + P.out_off[s] + bi * (unsigned long long)P.newlen_full;
         const int nbi = (int)nb;
+        auto exact_v = [&](int k, unsigned rem) -> double {   // tier 2's value (taps inside the table)
+            const int s1 = k - 1;
+            const double p1 = CvImaF32::cv((double)sm[s1]), p2 = CvImaF32::cv((double)sm[s1 + 1]);
+            const double fx = (double)rem * P.inv_fb;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) return __builtin_fma(p2 - p1, fx, p1);
+            else {
+                const double p0 = CvImaF32::cv((double)sm[s1 - 1]), p3 = CvImaF32::cv((double)sm[s1 + 2]);
+                const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                const double c1 = 0.5 * (p2 - p0);
+                return __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
+            }
+        };
         auto slow = [&](int k, unsigned rem, unsigned j, bool inside) -> float {  // tiers 2 and 3
             double v = 0;
             bool ok = false;
             if (inside) {
-                const int s1 = k - 1;
-                const double p1 = CvImaF32::cv((double)sm[s1]), p2 = CvImaF32::cv((double)sm[s1 + 1]);
-                const double fx = (double)rem * P.inv_fb;
-                if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fma(p2 - p1, fx, p1);
-                else {
-                    const double p0 = CvImaF32::cv((double)sm[s1 - 1]), p3 = CvImaF32::cv((double)sm[s1 + 2]);
-                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                    const double c1 = 0.5 * (p2 - p0);
-                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fx, c2), fx, c1), fx, p1);
-                }
+                v = exact_v(k, rem);
                 const double fr = v - floor(v);
                 ok = fr > 1e-6 && fr < 1 - 1e-6;
             }
@@ -788,6 +794,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
                 const float p0 = tp[-1], p3 = tp[2];
                 v = __builtin_fmaf(w.w, p3, __builtin_fmaf(w.z, p2, __builtin_fmaf(w.y, p1, w.x * p0)));
             }
+            if constexpr (AUDIT) { if (active && inside) { amax = fmaxf(amax, (float)fabs((double)v - exact_v(k, rem))); acnt++; } }
             float fl = floorf(v);
             const float fr = v - fl;
             const bool accept = inside && fr > TIER1_GUARD && fr < 1 - TIER1_GUARD;
@@ -844,6 +851,10 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             rb += 64; q0 += P.fdq; rem += P.fdr;
         }
         __builtin_amdgcn_wave_barrier();  // the next block's decode overwrites the table
+    }
+    if constexpr (AUDIT) {
+        for (int o = 32; o; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); acnt += __shfl_xor(acnt, o); }
+        if (lane == 0 && P.audit) { atomicMax(&P.audit[0], __float_as_uint(amax)); atomicAdd(&P.audit[1], acnt); }
     }
 }
 
@@ -1144,8 +1155,16 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 unsigned ph = P.fb / g64;
                 const char *er = getenv("AUKIT_IMA_REGS");
                 if ((ph != 3 && ph != 5) || (er && atoi(er) == 0)) ph = 0;
+                P.audit = nullptr;
+                if (ctx->collect_stats) {   // the audited instantiation (floor_wave.hip): tier 1's values against tier 2's, every output
+                    if ((rc = ctx->fmt_flag.ensure(64))) { delete ck; return rc; }
+                    P.audit = reinterpret_cast<unsigned *>(ctx->fmt_flag.p) + 8;
+                    AUKIT_HIP_CHECK(hipMemsetAsync(P.audit, 0, 8, ctx->stream));
+                    ph = 0;
+                }
                 P.qstep = ph ? (unsigned)((64ull * ph * P.fa) / P.fb) : 0u;
-#define AUKIT_IMA_F32(I, T) do { if (ph == 5) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
+#define AUKIT_IMA_F32(I, T) do { if (P.audit) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 0, true>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
+                                 else if (ph == 5) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
                                  else if (ph == 3) hipLaunchKernelGGL((k_ima_stream_f32<I, T, 3>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); \
                                  else hipLaunchKernelGGL((k_ima_stream_f32<I, T, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, wgp); } while (0)
                 if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_IMA_F32(AUKIT_INTERP_LINEAR, signed char); else AUKIT_IMA_F32(AUKIT_INTERP_CUBIC, signed char); }
@@ -1159,6 +1178,13 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 AUKIT_HIP_CHECK(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
                 AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 lap("kernel+sync");
+                if (P.audit) {
+                    unsigned h[2] = {0, 0};
+                    AUKIT_HIP_CHECK(hipMemcpy(h, P.audit, 8, hipMemcpyDeviceToHost));
+                    float e; memcpy(&e, &h[0], 4);
+                    ctx->counters[AUKIT_COUNTER_TIER1_ERR_NANO] = (uint64_t)std::llround((double)e * 1e9);
+                    ctx->counters[AUKIT_COUNTER_TIER1_OUTPUTS] = h[1];
+                }
                 if (herr) { delete ck; return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')"); }  // ima_step_table[idx > 88]
                 if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
                 lap("chunks out");

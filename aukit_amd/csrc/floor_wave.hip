@@ -49,8 +49,11 @@ AUKIT_DEV void store_floor(double *p, float v) { *p = (double)v; }
 // r + PH share it (PH = b / gcd(b, 64)) and every tile starts at phase 0, so fx, the "rem == 0" answer and the coefficient entry's offset
 // are per-lane constants of the launch: a row is one table read, three FMAs and the guard — no position arithmetic, in a kernel bound by its VALU
 // instructions.  Same f32 operations on the same values as the generic rows: the same tier decisions, bit for bit.
-template <int INTERP, bool DW, typename OUT_T, int PH>
-__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F, const unsigned ccap, const unsigned qstep) {
+// AUDIT (round 4): the same kernel, and next to every tier-1 answer the fp64 value of tier 2 — the largest |tier 1 - tier 2| of
+// the launch goes to audit[0] (bits of a non-negative float: they order like the value), the outputs compared to audit[1].  The error BOUND of the
+// header is a derivation; this is what the device actually produced (AUKIT_OPT_COLLECT_STATS: aukit_ctx_get_counter, tests/test_gpu_guard_band.py).
+template <int INTERP, bool DW, typename OUT_T, int PH, bool AUDIT = false>
+__global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P, const FastParams F, const unsigned ccap, const unsigned qstep, unsigned *audit = nullptr) {
     extern __shared__ float smf[];
     constexpr int SRC = SRC_G711_MONO;
     // one more tap to the left than the polynomial needs: at a mathematically integer position the reference's x may round to just
@@ -70,6 +73,8 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
 
     unsigned t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wave);
     if (t >= P.n_tiles) return;
+    [[maybe_unused]] float amax = 0.f;
+    [[maybe_unused]] unsigned acnt = 0;
     constexpr int NPH = PH > 0 ? PH : 1;
     [[maybe_unused]] float fxp[NPH];
     [[maybe_unused]] unsigned qo[NPH];
@@ -160,22 +165,26 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
             q = __umulhi(n0, F.magic);
             rem = n0 - q * F.b;
         }
+        // tier 2's value: the polynomial in fp64 on the exact rational position
+        auto exact_v = [&](unsigned q, unsigned rem) -> double {
+            const double p1 = (double)tab[q];  // the same samples (exact in f32, converted on read)
+            if (rem == 0) return p1;
+            const double fxd = (double)rem * inv_b;
+            if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
+                return __builtin_fma((double)tab[q + 1] - p1, fxd, p1);
+            } else {
+                const double p0 = (double)tab[(int)q - 1], p2 = (double)tab[q + 1], p3 = (double)tab[q + 2];
+                const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
+                const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
+                const double c1 = 0.5 * (p2 - p0);
+                return __builtin_fma(__builtin_fma(__builtin_fma(c3, fxd, c2), fxd, c1), fxd, p1);
+            }
+        };
         // tiers 2 and 3 for one output (rare): returns the floored, clamped value
         auto slow = [&](unsigned q, unsigned rem, unsigned j) -> float {
-            const double p1 = (double)tab[q];  // the same samples (exact in f32, converted on read)
-            double v = p1;
+            double v = exact_v(q, rem);
             bool ok = false;
             if (rem != 0) {
-                const double fxd = (double)rem * inv_b;
-                if constexpr (INTERP == AUKIT_INTERP_LINEAR) {
-                    v = __builtin_fma((double)tab[q + 1] - p1, fxd, p1);
-                } else {
-                    const double p0 = (double)tab[(int)q - 1], p2 = (double)tab[q + 1], p3 = (double)tab[q + 2];
-                    const double c3 = __builtin_fma(1.5, p1 - p2, 0.5 * (p3 - p0));
-                    const double c2 = __builtin_fma(-2.5, p1, p0) + __builtin_fma(2.0, p2, -0.5 * p3);
-                    const double c1 = 0.5 * (p2 - p0);
-                    v = __builtin_fma(__builtin_fma(__builtin_fma(c3, fxd, c2), fxd, c1), fxd, p1);
-                }
                 const double frd = v - floor(v);
                 ok = frd > 1e-6 && frd < 1 - 1e-6;
             }
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
                     w = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c3, fx, c2), fx, c1), fx, f1);
                 }
             }
+            if constexpr (AUDIT) { if (active) { amax = fmaxf(amax, (float)fabs((double)w - exact_v(q, rem))); acnt++; } }
             float fl = floorf(w);
             const float fr = w - fl;
             // (as plain boolean algebra — the masks stay in scalar registers; written `rem == 0 ? int_ratio : guard` hipcc built the choice out
@@ -277,6 +287,10 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
         cur = nxt;
         t = tn;
     }
+    if constexpr (AUDIT) {
+        for (int o = 32; o; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); acnt += __shfl_xor(acnt, o); }
+        if (lane == 0 && audit) { atomicMax(&audit[0], __float_as_uint(amax)); atomicAdd(&audit[1], acnt); }
+    }
 }
 
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
@@ -321,8 +335,16 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     const char *er = getenv("AUKIT_FLOOR_REGS");
     if (!dw || F.wd != 0 || (ph != 1 && ph != 3 && ph != 5) || (WT / 64) % (int)ph != 0 || (er && atoi(er) == 0)) ph = 0;
     const unsigned qstep = ph ? (unsigned)((64ull * ph * F.a) / F.b) : 0u;
+    unsigned *audit = nullptr;
+    if (ctx->collect_stats) {   // the audited instantiation (generic rows): every output's tier-1 value against tier 2's
+        if ((*rc = ctx->fmt_flag.ensure(64))) return true;
+        audit = reinterpret_cast<unsigned *>(ctx->fmt_flag.p) + 8;
+        if (hipMemsetAsync(audit, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
+    }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-#define AUKIT_FW(I, T) do { if (dw && ph == 1) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
+#define AUKIT_FWA(I, T) do { if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 0, true>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep, audit); \
+                             else hipLaunchKernelGGL((k_floor_wave_g711<I, false, T, 0, true>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep, audit); } while (0)
+#define AUKIT_FW(I, T) do { if (audit) AUKIT_FWA(I, T); else if (dw && ph == 1) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 1>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
                             else if (dw && ph == 3) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 3>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
                             else if (dw && ph == 5) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 5>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
                             else if (dw) hipLaunchKernelGGL((k_floor_wave_g711<I, true, T, 0>), dim3(grid), dim3(256), lds, ctx->stream, P, F, ccap, qstep); \
@@ -330,7 +352,15 @@ bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std:
     if (dtype == AUKIT_I8) { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, signed char); else AUKIT_FW(AUKIT_INTERP_CUBIC, signed char); }
     else { if (interp == AUKIT_INTERP_LINEAR) AUKIT_FW(AUKIT_INTERP_LINEAR, double); else AUKIT_FW(AUKIT_INTERP_CUBIC, double); }
 #undef AUKIT_FW
+#undef AUKIT_FWA
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_floor_wave_g711 launch failed"); return true; }
+    if (audit) {
+        unsigned h[2] = {0, 0};
+        if (hipMemcpyAsync(h, audit, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "audit read-back failed"); return true; }
+        float e; memcpy(&e, &h[0], 4);
+        ctx->counters[AUKIT_COUNTER_TIER1_ERR_NANO] = (uint64_t)std::llround((double)e * 1e9);
+        ctx->counters[AUKIT_COUNTER_TIER1_OUTPUTS] = h[1];
+    }
     static thread_local char nm[96];
     snprintf(nm, sizeof nm, "k_floor_wave_g711<%s>", interp == AUKIT_INTERP_LINEAR ? "linear" : "cubic");
     *rc = ctx_end_kernel(ctx, nm, algorithmic_bytes);

@@ -234,6 +234,7 @@ struct MsWaveParams {
     int exact_rcp;
     int unit;                                // sample rate 48000: every position is an integer, exactly (x = (i - 1) / 1 + 1)
     unsigned sst;                            // int8 stream output: bytes per block and output row in the LDS staging area (an odd number of dwords), 0: outputs go out pair by pair
+    unsigned *audit;                         // AUDIT instantiation: [0] bits of the largest |tier 1 - tier 2| (a non-negative float), [1] outputs compared (floor_wave.hip)
 };
 
 struct MsLane { int s1, s2, d, c1, c2; double ws1, ws2, wd; };
@@ -349,8 +350,10 @@ enum { MS_ROWS_I16 = 0, MS_ROWS_F32 = 1, MS_ROWS_F64 = 2, MS_STREAM = 3 };
 // C channels; RB bytes of a block per round; MODE one of the enums above; stream mode: INTERP, MIX (stereo: l + r / 2, :2672), OUT_T
 // FB bytes of a block per FETCH (the staging area holds them; FB / RB rounds consume it): the stream kernels fetch 64 bytes at a time and decode
 // them in four rounds of 16 — with 16-byte fetches every 128-byte line of the input came from HBM eight times (PMC FETCH_SIZE, profiles/)
-template <int C, int RB, int MODE, int INTERP, bool MIX, typename OUT_T, int FB = RB>
+template <int C, int RB, int MODE, int INTERP, bool MIX, typename OUT_T, int FB = RB, bool AUDIT = false>
 __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
+    [[maybe_unused]] float amax = 0.f;
+    [[maybe_unused]] unsigned acnt = 0;
     constexpr int R = RB * 2 / C;         // samples per channel and round
     constexpr int ROW = 4 + R + 1;        // floats per (block, channel) row: slots 0..3 = table indices R r - 1 .. R r + 2, slot(t) = t - R r + 1
                                           // (+ 1: an odd stride — a lane's row starts in its own bank; with 36 or 20 every 8th lane shared one)
@@ -601,6 +604,9 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     return lua_clamp(floor(d), -128, 127);   // :2673 / :2674 / :2727
                 };
                 auto put = [&](float v, float spread, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
+                    if constexpr (AUDIT) {
+                        if (active && inside) { double d2 = tier2(ta); if (tb) d2 = d2 + tier2(tb) / 2; amax = fmaxf(amax, (float)fabs((double)v - d2)); acnt++; }
+                    }
                     float fl = floorf(v);
                     const float fr = v - fl;
                     bool accept = inside && fr > MS_TIER1_GUARD && fr < 1 - MS_TIER1_GUARD;
@@ -691,6 +697,10 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (AUDIT) {
+        for (int o = 32; o; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); acnt += __shfl_xor(acnt, o); }
+        if (threadIdx.x == 0 && P.audit) { atomicMax(&P.audit[0], __float_as_uint(amax)); atomicAdd(&P.audit[1], acnt); }
+    }
 }
 
 // ----------------------------------------------------------------- host side of the wave kernel
@@ -719,6 +729,13 @@ constexpr int MS_FB_STREAM = 16;
 template <int C, int RB, bool MIX, typename OUT_T>
 static void ms_launch_stream(int interp, const MsWaveParams &P, unsigned grid, size_t lds, hipStream_t st) {
     constexpr int FB = RB < MS_FB_STREAM ? MS_FB_STREAM : RB;
+    if constexpr (RB == 16 && sizeof(OUT_T) == 1) {   // the audited instantiations (AUKIT_OPT_COLLECT_STATS)
+        if (P.audit) {
+            if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T, FB, true>), dim3(grid), dim3(64), lds, st, P);
+            else if (interp == AUKIT_INTERP_CUBIC) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_CUBIC, MIX, OUT_T, FB, true>), dim3(grid), dim3(64), lds, st, P);
+            if (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) return;
+        }
+    }
     if (interp == AUKIT_INTERP_NONE) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_NONE, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
     else if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
     else hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_CUBIC, MIX, OUT_T, FB>), dim3(grid), dim3(64), lds, st, P);
@@ -961,6 +978,12 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         P.exact_rcp = exact_div_verified(ctx, ratio, (uint64_t)newlen + 2) ? 1 : 0;
         P.unit = d->sample_rate == 48000 ? 1 : 0;
         P.sst = sst;
+        P.audit = nullptr;
+        if (ctx->collect_stats && dtype == AUKIT_I8 && MS_RB == 16 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {
+            if ((rc = ctx->fmt_flag.ensure(64))) { delete ck; return rc; }
+            P.audit = reinterpret_cast<unsigned *>(ctx->fmt_flag.p) + 8;
+            if (hipMemsetAsync(P.audit, 0, 8, ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "hipMemsetAsync failed"); }
+        }
         const unsigned grid = (unsigned)((nblocks + 63) / 64);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
 #define AUKIT_MS_STREAM(CC, RBB, MIXX)                                                                                                 \
@@ -976,6 +999,13 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         if ((rc = ctx_end_kernel(ctx, "k_ms_wave", in->total() + out_elems * dtype_size(dtype)))) { delete ck; return rc; }
         int herr = 0;
         if (hipMemcpyAsync(&herr, P.err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_ms_wave failed"); }
+        if (P.audit) {
+            unsigned h[2] = {0, 0};
+            if (hipMemcpy(h, P.audit, 8, hipMemcpyDeviceToHost) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "audit read-back failed"); }
+            float e; memcpy(&e, &h[0], 4);
+            ctx->counters[AUKIT_COUNTER_TIER1_ERR_NANO] = (uint64_t)std::llround((double)e * 1e9);
+            ctx->counters[AUKIT_COUNTER_TIER1_OUTPUTS] = h[1];
+        }
         if (herr) { delete ck; return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (local 'c1')"); }
         return done();
     }

@@ -146,6 +146,10 @@ int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 typedef enum {
     AUKIT_COUNTER_DFPWM_CHUNKS = 0,        /* chunks the parallel DFPWM decoder cut the batch into (aukit.dfpwm, stream.dfpwm, the transcode) */
     AUKIT_COUNTER_DFPWM_CHUNKS_REDONE = 1, /* of those, the ones whose warmed-up start state differed from the true one and were decoded again */
+    AUKIT_COUNTER_TIER1_ERR_NANO = 3,      /* the bit-exact floor()ed stream paths (stream.g711, stream.adpcm, stream.msadpcm) answer most outputs from an f32 evaluation
+                                              that is only taken when it lies further from an integer than a guard (5e-4 / 6e-4) set at twice its derived error
+                                              bound.  With COLLECT_STATS the call runs an audited instantiation: the largest |f32 value - fp64 value| it saw, in 1e-9 */
+    AUKIT_COUNTER_TIER1_OUTPUTS = 4,       /* ... and how many outputs it compared */
     AUKIT_COUNTER_FLAC_FUSED = 2           /* 1: the most recent FLAC decode was served by the fused decoder (flac_fused.hip); 0: a frame it declines was on
                                               the chain (or the batch is deeper than 24 bits) and the two-kernel decoder ran.  Set without COLLECT_STATS. */
 } aukit_counter;
