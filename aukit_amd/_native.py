@@ -42,7 +42,7 @@ EXPORTS = [
     "aukit_audio_download_raw", "aukit_audio_clone", "aukit_audio_free",
     "aukit_parse_container", "aukit_decode", "aukit_decode_table", "aukit_decode_nibbles", "aukit_stream_decode_table", "aukit_decode_resample", "aukit_resample", "aukit_mono", "aukit_mix", "aukit_effect", "aukit_dfpwm_encode", "aukit_dfpwm_transcode_mono",
     "aukit_encode_pcm", "aukit_stream_decode", "aukit_chunks_info", "aukit_chunks_get", "aukit_chunks_free",
-    "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_close",
+    "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_resident", "aukit_stream_close",
     "aukit_partition", "aukit_group_create", "aukit_group_destroy", "aukit_group_info", "aukit_group_ctx", "aukit_group_sync", "aukit_group_scatter",
     "aukit_group_gather_audio", "aukit_group_gather_batch", "aukit_group_run", "aukit_group_last_run",
     "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",

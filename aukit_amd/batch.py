@@ -601,6 +601,12 @@ class StreamHandle:
         N.check(N.lib().aukit_stream_length(self._h, C.byref(s)))
         return s.value
 
+    def resident(self):
+        """→ (bytes resident on the device, bytes dropped in front of them, input bytes of every decode so far summed)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(N.lib().aukit_stream_resident(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def close(self):
         if self._h:
             N.lib().aukit_stream_close(self._h)

@@ -355,6 +355,12 @@ static int build_chunk_plan(double sample_rate, int interp, ChunkPlan &cp) {
     return AUKIT_OK;
 }
 
+long stream_pcm_call_frames(double sample_rate, int interp) {
+    ChunkPlan cp;
+    build_chunk_plan(sample_rate, interp, cp);
+    return cp.K;
+}
+
 static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                       aukit_chunks **chunks_out, bool table = false) {
     int rc;
@@ -373,8 +379,8 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     char keyb[256];
     unsigned long long oh = 1469598103934665603ull;   // FNV-1a over the stream offsets (a freed batch's address can come back with another layout)
     for (uint64_t o : in->off) { oh ^= o; oh *= 1099511628211ull; }
-    snprintf(keyb, sizeof keyb, "%p/%llu/%u/%llx/%d/%d/%d/%d/%.17g/%d/%d/%d", (const void *)in, (unsigned long long)in->version, in->n, oh,
-             d->bit_depth + (table ? 1000 : 0), d->data_type, d->big_endian, C, d->sample_rate, interp, mono, nd);
+    snprintf(keyb, sizeof keyb, "%p/%llu/%u/%llx/%d/%d/%d/%d/%.17g/%d/%d/%d/%llu/%llu", (const void *)in, (unsigned long long)in->version, in->n, oh,
+             d->bit_depth + (table ? 1000 : 0), d->data_type, d->big_endian, C, d->sample_rate, interp, mono, nd, (unsigned long long)ctx->sb_bytes, (unsigned long long)ctx->sb_outputs);
     std::vector<Seg> segs;
     std::vector<uint64_t> lens(in->n, 0);
     uint64_t in_bytes = 0, out_elems = 0;
@@ -401,7 +407,7 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         uint64_t nb = in->off[s + 1] - in->off[s];
         if (nb % ((size_t)bd * C) != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream.pcm: data is not a whole number of frames (stream %u)", s); }
         const long long nframes = (long long)(nb / ((size_t)bd * C));
-        ck->length_seconds[s] = ((double)nb / bd) / C / d->sample_rate;  // :2245, :2423
+        ck->length_seconds[s] = ((double)(nb + ctx->sb_bytes) / bd) / C / d->sample_rate;  // :2245, :2423 (sb_bytes: what a stream handle has dropped already)
         in_bytes += nb;
         for (long c = 0;; c++) {
             const long long src_base = (long long)c * cp.K - istart[interp];  // frame of table index 0
@@ -435,7 +441,7 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     ck->lens.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
     ck->pos.assign((size_t)ck->n * std::max<uint32_t>(ck->max_chunks, 1), 0);
     for (uint32_t s = 0; s < in->n; s++) {
-        double nacc = 0;
+        double nacc = (double)ctx->sb_outputs;
         for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
             ck->lens[(size_t)s * ck->max_chunks + k] = clens[s][k];
             ck->pos[(size_t)s * ck->max_chunks + k] = nacc / 48000;  // (n - #chunk[1]) / 48000  :2422
@@ -599,7 +605,7 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t nb = in->off[s + 1] - in->off[s];
         if (nb % (uint64_t)C != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "G.711 data length is not a multiple of the channel count (stream %u)", s); }
-        ck->length_seconds[s] = (double)nb / d->sample_rate / C;
+        ck->length_seconds[s] = (double)(nb + ctx->sb_bytes) / d->sample_rate / C;
         in_bytes += nb;
         uint32_t calls = (uint32_t)((nb + per_call - 1) / per_call);  // calls that see data; the reference then returns {{}} forever (Q13)
         ck->nchunks[s] = calls;
@@ -625,7 +631,7 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
             g.pad = 0;
             segs.push_back(g);
             ck->lens[(size_t)s * ck->max_chunks + k] = n_out;
-            ck->pos[(size_t)s * ck->max_chunks + k] = ((double)(pos + 1) - 1) / d->sample_rate / C;  // (lp - 1) / sampleRate / channels
+            ck->pos[(size_t)s * ck->max_chunks + k] = ((double)(pos + ctx->sb_bytes + 1) - 1) / d->sample_rate / C;  // (lp - 1) / sampleRate / channels
             lens[s] += n_out;
         }
         out_elems += lens[s] * (uint64_t)nd;

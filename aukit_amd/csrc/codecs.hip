@@ -1030,7 +1030,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
             done += take;
             if (produced == 0) break;  // #retval[1] == 0 → nil
             pl.len.push_back((uint32_t)produced);
-            pl.pos.push_back(((double)(done * ba + 1)) / bytesPerSecond);  // (n + pos) / bytesPerSecond :2833
+            pl.pos.push_back(((double)(done * ba + ctx->sb_bytes + 1)) / bytesPerSecond);  // (n + pos) / bytesPerSecond :2833 (sb_bytes: what a stream handle dropped)
             pl.total += produced;
             if (done >= nblk) break;   // the next call sees n + 4C > #data and returns nil
         }
@@ -1053,7 +1053,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     lap("scan+plans");
     for (uint32_t s = 0; s < in->n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
-        ck->length_seconds[s] = (double)nb / (double)ba * spb / d->sample_rate;   // :2834
+        ck->length_seconds[s] = (double)(nb + ctx->sb_bytes) / (double)ba * spb / d->sample_rate;   // :2834
         if (first_bad[s] != 0xFFFFFFFFu) {
             // a bad header kills the iterator call that reaches it: only the calls before that one deliver
             const uint64_t calls_ok = (uint64_t)first_bad[s] / std::max<uint64_t>(ips, 1);

@@ -76,6 +76,10 @@ struct aukit_ctx {
     int tab_cur = 0;
     bool tab_used[2] = {false, false};
     hipEvent_t tab_ev[2] = {};
+    // a resumable stream handle (stream_handle.hip) that has dropped the bytes of delivered iterator calls decodes the REST of its stream: what it dropped
+    // — bytes, 48 kHz outputs per channel — enters the chunk positions and the length of the stream factories that support it (stream.pcm / g711 /
+    // adpcm / msadpcm), so that the rest's chunks carry the whole stream's numbers.  Zero everywhere else.
+    uint64_t sb_bytes = 0, sb_outputs = 0;
     bool lazy_suppress = false;   // set while an owed resample is being materialised: audio_from_int_rows must not defer it again
     std::string plan_key;   // non-empty: seg_buf / tile_buf still hold the tables of plan_segs (any other upload into them clears it)
     std::vector<unsigned char> plan_segs;   // the segment descriptors of that plan, byte for byte
@@ -189,6 +193,8 @@ struct LazyFrames {   // the fused FLAC decoder's frames (flac_dev.h), for a def
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
                        double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr, int src_kind = 8 /* SRC_I32 */, double norm_pos = 0, double norm_neg = 0);
 bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc);
+// the frames one full iterator call of aukit.stream.pcm moves its table on by (K of SURVEY Q1: aukit.lua:2417-2419), api_resample.hip
+long stream_pcm_call_frames(double sample_rate, int interp);
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 // the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time
 void *ctx_host_stage(aukit_ctx *ctx, size_t bytes);

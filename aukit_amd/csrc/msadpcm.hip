@@ -876,7 +876,7 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
     std::vector<uint64_t> lens(in->n, 0);
     for (uint32_t s = 0; s < in->n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s], nblk = B.blk0[s + 1] - B.blk0[s];
-        ck->length_seconds[s] = (double)nb / (double)ba * samplesPerBlock / d->sample_rate;
+        ck->length_seconds[s] = (double)(nb + ctx->sb_bytes) / (double)ba * samplesPerBlock / d->sample_rate;
         ck->nchunks[s] = newlen ? (uint32_t)((nblk + ips - 1) / ips) : 0;
         ck->max_chunks = std::max(ck->max_chunks, ck->nchunks[s]);
         lens[s] = nblk * newlen;
@@ -889,7 +889,7 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
             const uint64_t done = std::min<uint64_t>((uint64_t)(k + 1) * ips, nblk), first = (uint64_t)k * ips;
             ck->lens[(size_t)s * mc + k] = (uint32_t)((done - first) * newlen);
-            ck->pos[(size_t)s * mc + k] = ((double)(done * ba + 1)) / bytesPerSecond;  // (n + pos) / bytesPerSecond
+            ck->pos[(size_t)s * mc + k] = ((double)(done * ba + ctx->sb_bytes + 1)) / bytesPerSecond;  // (n + pos) / bytesPerSecond
         }
     }
     aukit_audio *a = *out;

@@ -10,6 +10,18 @@
 // exists — every iterator call of the reference consumes a fixed slice of its input, so a call that was followed by another one had all
 // the input it wanted (tests/test_gpu_stream_handle.py checks this against the string result for every codec at random split points) —
 // or once aukit_stream_finish has declared the input complete.  Only decided chunks are copied to the host, each once.
+//
+// Round 4: BOUNDED for the live sources austream.lua:19-64 feeds.  Re-decoding the whole prefix is O(n^2) work and keeps
+// every byte resident — fine for a file, not for an HTTP / websocket stream that runs for hours.  Where an iterator call's chunk depends on
+// nothing older than the call before it, the handle drops the bytes of the calls it has delivered and decodes the REST as a fresh stream:
+//   * stream.pcm (aukit.lua:2363-2424): a full call moves its table on by K frames and keeps d[-1], d[0] (Q1).  A fresh stream that starts K
+//     frames before call c reproduces call c exactly as ITS second call (its first one, which differs in its first taps, was delivered long
+//     ago and is skipped);
+//   * stream.g711 (:2850-2913), stream.adpcm (:2753-2835), stream.msadpcm (:2588-2736, not sinc): every call stands alone (Q6, Q13: the history
+//     copies write to the wrong table) — the rest starts at the next call's first byte.
+// The positions and the length the factories report are those of the whole stream: the handle tells them what it dropped (aukit_ctx::sb_bytes /
+// sb_outputs).  Device memory then stays at a call or two of input and decode work is linear in the stream; aukit_stream_resident reports both.
+// stream.dfpwm / mdfpwm (the decoder's state crosses calls), stream.qoa and stream.flac (file headers, `last` samples) keep the whole prefix.
 #include <algorithm>
 #include "common.h"
 
@@ -27,6 +39,10 @@ struct aukit_stream {
     uint32_t delivered = 0;
     uint64_t delivered_samples = 0;   // per channel
     uint64_t decoded_at = ~0ull;      // `fed` when the prefix was last decoded
+    // what has been dropped in front of dbuf: bytes, delivered chunks, 48 kHz outputs per channel before the first chunk of the current decode
+    uint64_t sb_bytes = 0, sb_outputs = 0, decoded_bytes_total = 0;
+    uint8_t head7[8] = {};            // stream.msadpcm mono reads EVERY block's header from the start of the string (Q9, aukit.lua:2706): the stream's first
+    bool have_head7 = false;          // seven bytes stay in front of whatever rest is decoded
 };
 
 namespace aukit {
@@ -58,15 +74,84 @@ static int redecode(aukit_stream *h) {
     int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
+    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs;   // the rest of a stream: the factories add what was dropped to their positions
     rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
+    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0;
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
+    h->decoded_bytes_total += usable;
     if (rc) { if (ck) aukit_chunks_free(ck); return rc; }
     std::swap(h->out, h->spare);
     if (h->ck) aukit_chunks_free(h->ck);
     h->ck = ck;
     h->decoded_at = h->fed;
     h->dirty = false;
+    return AUKIT_OK;
+}
+
+// Where the rest of the stream may start once chunk `j` (an index into the current decode) has been delivered: `lead` chunks of the fresh decode
+// repeat delivered ones and are skipped, the next call's chunk is fresh chunk `lead`.
+struct Restart { bool ok = false; int lead = 0; uint64_t call_bytes = 0; };
+static Restart restart_rule(const aukit_stream *h) {
+    Restart r;
+    const aukit_codec_desc &d = h->desc;
+    const uint64_t C = (uint64_t)std::max(d.channels, 1);
+    if (getenv("AUKIT_STREAM_UNBOUNDED")) return r;   // A/B and the tests: the whole prefix every time
+    switch (d.codec) {
+    case AUKIT_CODEC_PCM:
+        if (h->interp == AUKIT_INTERP_SINC || d.sample_rate > 48000 || d.sample_rate < 1) return r;
+        r.ok = true; r.lead = 1;
+        r.call_bytes = (uint64_t)stream_pcm_call_frames(d.sample_rate, h->interp) * C * (uint64_t)std::max(d.bit_depth / 8, 1);
+        return r;
+    case AUKIT_CODEC_G711:
+        if (d.sample_rate != std::floor(d.sample_rate) || d.sample_rate < 1) return r;
+        r.ok = true; r.call_bytes = (uint64_t)d.sample_rate * C;
+        return r;
+    case AUKIT_CODEC_ADPCM_WAV: {
+        if (d.block_align <= 4 * (int)C || d.sample_rate < 1) return r;
+        const double spb = (double)((uint64_t)d.block_align - 4 * C) * 2 / (double)C;        // :2765
+        r.ok = true; r.call_bytes = (uint64_t)std::ceil(d.sample_rate / spb) * (uint64_t)d.block_align;   // :2766-2767
+        return r;
+    }
+    case AUKIT_CODEC_MSADPCM: {
+        if (h->interp == AUKIT_INTERP_SINC || d.sample_rate < 1 || (C != 1 && C != 2) || d.block_align <= 14 || (C == 1 && !h->have_head7)) return r;
+        const double spb = C == 2 ? (double)(d.block_align - 14) : (double)(d.block_align - 7) * 2;      // :2617 / :2682
+        r.ok = true; r.call_bytes = (uint64_t)std::ceil(d.sample_rate / spb) * (uint64_t)d.block_align;
+        return r;
+    }
+    default: return r;
+    }
+}
+
+// after chunk h->delivered - 1 went out: drop what no later chunk depends on (see the header)
+static int compact(aukit_stream *h) {
+    const Restart R = restart_rule(h);
+    if (!R.ok || !R.call_bytes || !h->ck || h->delivered == 0) return AUKIT_OK;
+    const uint64_t j = h->delivered - 1;                       // the chunk just delivered
+    const uint64_t shift = R.lead ? j : j + 1;                  // fresh chunk 0 = current chunk `shift`
+    const uint64_t drop = shift * R.call_bytes;
+    if (shift == 0 || drop < (64u << 10) || drop > h->fed) return AUKIT_OK;   // (a few calls at a time: every drop costs one decode of the rest)
+    const uint32_t mc = std::max<uint32_t>(h->ck->max_chunks, 1);
+    (void)mc;
+    uint64_t outs = 0;
+    for (uint64_t m = 0; m < shift; m++) outs += h->ck->lens[m];
+    // the rest moves to the front of a buffer sized for it: memory follows the stream instead of growing with it
+    const size_t rest = (size_t)(h->fed - drop);
+    const size_t cap = std::max<size_t>(rest + rest / 2 + 4096, 1 << 16);
+    uint8_t *nb = nullptr;
+    if (hipMalloc((void **)&nb, cap + 64) != hipSuccess) { (void)hipGetLastError(); return AUKIT_OK; }   // no memory for the move: keep the prefix (correct, only bigger)
+    if (rest) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream));
+    if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.channels == 1 && rest >= 7)   // Q9: the header every mono block is read from is the STREAM's first (no block reads its own)
+        AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    (void)hipFree(h->dbuf);
+    h->dbuf = nb; h->dcap = cap;
+    h->fed -= drop;
+    h->sb_bytes += drop;
+    h->sb_outputs += outs;
+    h->delivered = (uint32_t)R.lead;
+    aukit_chunks_free(h->ck); h->ck = nullptr;     // the chunk table described the longer buffer
+    h->dirty = true; h->decoded_at = ~0ull;
     return AUKIT_OK;
 }
 }  // namespace aukit
@@ -93,6 +178,10 @@ int aukit_stream_feed(aukit_stream *h, const uint8_t *bytes, uint64_t n) {
     if (rc) return rc;
     AUKIT_HIP_CHECK(hipMemcpyAsync(h->dbuf + h->fed, bytes, n, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));  // the caller may reuse `bytes`
+    if (!h->have_head7 && h->sb_bytes == 0 && h->fed < 7) {   // (kept from the caller's bytes: no read-back)
+        for (uint64_t i = 0; i < n && h->fed + i < 7; i++) h->head7[h->fed + i] = bytes[i];
+        if (h->fed + n >= 7) h->have_head7 = true;
+    }
     h->fed += n;
     h->dirty = true;
     return AUKIT_OK;
@@ -143,9 +232,11 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     if (n > cap) { *len = n; return fail(AUKIT_E_ARG, "chunk of %u samples does not fit the %u offered", n, cap); }
     if (n && !dst) return fail(AUKIT_E_ARG, "null argument");
     const size_t esz = dtype_size(h->out->dtype);
+    uint64_t before = 0;   // samples per channel of this decode's chunks in front of chunk k
+    for (uint32_t m = 0; m < k; m++) before += h->ck->lens[m];
     std::vector<unsigned char> tmp((size_t)n * C * esz + 8);
     for (int c = 0; c < C && n; c++) {
-        const char *src = reinterpret_cast<const char *>(h->out->dev) + (h->out->row_off[0] + (uint64_t)c * h->out->row_stride[0] + h->delivered_samples) * esz;
+        const char *src = reinterpret_cast<const char *>(h->out->dev) + (h->out->row_off[0] + (uint64_t)c * h->out->row_stride[0] + before) * esz;
         AUKIT_HIP_CHECK(hipMemcpyAsync(tmp.data() + (size_t)c * n * esz, src, (size_t)n * esz, hipMemcpyDeviceToHost, h->ctx->stream));
     }
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
@@ -159,6 +250,17 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     *state = AUKIT_STREAM_CHUNK;
     h->delivered++;
     h->delivered_samples += n;
+    if (!h->finished) return compact(h);
+    return AUKIT_OK;
+}
+
+// bytes of the stream resident on the device right now, bytes dropped in front of them, and the bytes every decode so far was handed, summed
+// (linear in the stream where the handle is bounded, quadratic where it keeps the prefix)
+int aukit_stream_resident(const aukit_stream *h, uint64_t *resident, uint64_t *dropped, uint64_t *decoded_total) {
+    if (!h) return fail(AUKIT_E_ARG, "null argument");
+    if (resident) *resident = h->fed;
+    if (dropped) *dropped = h->sb_bytes;
+    if (decoded_total) *decoded_total = h->decoded_bytes_total;
     return AUKIT_OK;
 }
 

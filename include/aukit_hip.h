@@ -330,6 +330,9 @@ int aukit_stream_finish(aukit_stream *s);                                    /* 
  * except stream.flac / stream.qoa (one coded block resampled: at most 65535 * 48000 / sampleRate). */
 int aukit_stream_next(aukit_stream *s, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
 int aukit_stream_length(aukit_stream *s, double *seconds);                   /* the factory's second return value, for the bytes fed so far */
+/* stream bytes resident on the device, bytes dropped in front of them (stream.pcm / g711 / adpcm / msadpcm drop what delivered calls consumed:
+ * austream.lua:19-64 feeds live sources for hours), and the input bytes of every decode so far, summed */
+int aukit_stream_resident(const aukit_stream *s, uint64_t *resident, uint64_t *dropped, uint64_t *decoded_total);
 void aukit_stream_close(aukit_stream *s);
 
 #ifdef __cplusplus

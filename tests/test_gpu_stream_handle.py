@@ -230,3 +230,71 @@ def test_ignore_header_strips_later_headers_and_first_piece_quirks(ctx, oracle):
     h.finish()
     assert h.length() == 30000 / 44100
     h.close()
+
+
+@pytest.mark.parametrize("name", ["pcm16_mono_44k_cubic", "pcm8_48k_linear", "pcm16_stereo_mix", "g711_stereo", "ima_22k", "msadpcm_44k"])
+def test_long_live_stream_is_bounded(ctx, oracle, monkeypatch, name):
+    """VERDICT r03 item 8 (austream.lua:19-64: HTTP / websocket readers run for hours).  A long stream fed in 64 KiB pieces: the chunks equal the
+    string call's (samples, lengths, positions, the stream's length), the bytes resident on the device stay at a few calls' worth instead of growing
+    with the stream, and the input bytes of all decodes together stay linear in the stream — where the whole-prefix handle (AUKIT_STREAM_UNBOUNDED)
+    re-reads a quadratic amount."""
+    B, N = _mods()
+    rng = np.random.Generator(np.random.PCG64(123))
+    if name == "pcm16_mono_44k_cubic":
+        data, desc, interp, mono, dtype, call = pcm16(44100 * 150, 44100, 9, 5).tobytes(), B.make_desc(N.CODEC_PCM, 1, 44100, 16, "signed"), "cubic", False, N.F32, 44102 * 2
+    elif name == "pcm8_48k_linear":
+        data, desc, interp, mono, dtype, call = rng.integers(0, 256, 48000 * 200, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_PCM, 1, 48000, 8, "unsigned"), "linear", False, N.F32, 48000
+    elif name == "pcm16_stereo_mix":
+        st = np.stack([pcm16(44100 * 80, 44100, 9, 6), pcm16(44100 * 80, 44100, 9, 7)], 1)
+        data, desc, interp, mono, dtype, call = st.tobytes(), B.make_desc(N.CODEC_PCM, 2, 44100, 16, "signed"), "linear", True, N.F64, 44101 * 4
+    elif name == "g711_stereo":
+        data, desc, interp, mono, dtype, call = rng.integers(0, 256, 8000 * 2 * 400, dtype=np.uint8).tobytes(), B.make_desc(N.CODEC_G711, 2, 8000, ulaw=True), "cubic", False, N.I8, 16000
+    elif name == "ima_22k":
+        data = b"".join(oracle.gen_ima(pcm16(1016 * 500, 22050, 3, i), 1, 512, 88) for i in range(8))
+        desc, interp, mono, dtype, call = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", False, N.I8, 22 * 512
+    else:
+        data = b"".join(oracle.gen_msadpcm(pcm16(2036 * 300, 44100, 3, 20 + i), 1, 1024) for i in range(8))
+        desc, interp, mono, dtype, call = B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=1024), "linear", False, N.I8, 22 * 1024
+    want, st_w, len_w = _whole(ctx, B, data, desc, interp, mono, dtype)
+    assert len(want) >= 60
+    piece = 64 << 10
+    pieces = [data[a:a + piece] for a in range(0, len(data), piece)]
+
+    def run():
+        h = B.StreamHandle(ctx, desc, interp, mono, dtype)
+        got, peak, it, done, err = [], 0, iter(pieces), False, 0
+        try:
+            while True:
+                kind, chans, pos = h.next()
+                if kind == "chunk":
+                    got.append((chans, pos))
+                    peak = max(peak, h.resident()[0])
+                elif kind == "end":
+                    break
+                else:
+                    p = None if done else next(it, None)
+                    if p is None:
+                        done = True
+                        h.finish()
+                    else:
+                        h.feed(p)
+        except N.AukitError as e:   # where the reference's iterator raises at the end of the data (:2407), like the string call's status
+            err = e.code
+        res = h.resident()
+        length = h.length() if not err else None
+        h.close()
+        return got, peak, res, length, err
+
+    got, peak, (resident, dropped, decoded), length, err = run()
+    assert len(got) == len(want) and err == st_w and (err or length == len_w)
+    for (gc, gp), (wc, wp) in zip(got, want):
+        assert gp == wp and len(gc) == len(wc)
+        for a, b in zip(gc, wc):
+            assert np.array_equal(a, b)
+    assert dropped > 0.9 * len(data) - 8 * call
+    assert peak <= 8 * call + 3 * piece, (peak, call)               # a few calls and pieces, whatever the stream's length
+    assert decoded <= 12 * len(data), (decoded, len(data))          # linear: every byte is decoded a bounded number of times
+    monkeypatch.setenv("AUKIT_STREAM_UNBOUNDED", "1")
+    if name == "ima_22k":   # the whole-prefix handle on the same input: quadratic work, the whole stream resident
+        _, peak_u, (res_u, drop_u, dec_u), _, _ = run()
+        assert drop_u == 0 and peak_u >= 0.9 * len(data) and dec_u > 5 * decoded
