@@ -26,8 +26,6 @@ namespace aukit {
 constexpr int FWN = 16;             // 64-bit words of bit-stream window per lane (128 bytes, a ring of 32 dwords)
 constexpr int FLPW = FWN / 2;       // lanes that refill one window, 16 bytes each
 constexpr int FWS = 2 * FWN + 1;    // row stride of the window array in dwords (odd: lanes at one offset hit distinct banks)
-constexpr int FNC = 32;             // values per lane and round
-constexpr int FOS = FNC + 1;        // row stride of the value array
 constexpr int FMAXO = 12;           // predictor orders served
 constexpr unsigned FRING = 2 * FWN - 1;
 
@@ -159,12 +157,20 @@ AUKIT_DEV void flac_predict(int *row, int cnt, int jpos0, int order, int lshift,
     }
 }
 
-__global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
+// FNC values per lane and round.  PF: the window lines and the parked first-subframe values are requested a round ahead into registers (80 VGPRs).
+// <32, true> holds 237 VGPRs and 17.9 KB of LDS: two waves per SIMD, each issuing an instruction every 8.4 cycles (PMC: 54 % of a wave's cycles
+// active, a third parked at s_waitcnt) — a latency-bound instruction stream with too few waves to cover it.  <16, false> fits three (13.3 KB, no
+// prefetch registers, __launch_bounds__ tells hipcc so): more per-round overhead per value, and the loads it no longer prefetches are covered by the
+// third wave instead.
+template <int FNC, bool PF>
+__global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs A) {
+    constexpr int FOS = FNC + 1;        // row stride of the value array
+    constexpr int LPR = FNC / 4;        // lanes that store one row (16 bytes each)
+    constexpr int RPI = 64 / LPR;       // rows per store instruction
     __shared__ unsigned s_win[64 * FWS];
     __shared__ int s_val[64 * FOS];
     __shared__ u64 s_ptr[64];
-    __shared__ unsigned s_meta[64];   // values of the round | mode << 8 | channel assignment << 12   (mode 0: wrap and store, 1: park the first subframe, 2: decorrelate)
-    __shared__ int s_bs[64];
+    __shared__ unsigned s_meta[64];   // values of the round | mode << 6 | channel assignment << 8 | block size << 12   (mode 0: wrap and store, 1: park the first subframe, 2: decorrelate)
     const int lane = threadIdx.x;
     const int C = A.C, depth = A.depth;
     const int wrap_half = 1 << (depth - 1), wrap_full = 1 << depth;   // 1 <= depth <= 24 (the host sends nothing else here)
@@ -226,21 +232,23 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
     // ---- a round's values leave at the top of the NEXT round, behind the wait for that round's window lines (loads and stores share vmcnt: stores
     // issued in front of that wait would be waited for as well)
     bool have_flush = false, flush_fast = false;
-    uint4 tpre[8];   // mode 2: the parked first-subframe values of the eight rows this lane stores for, requested while the round is predicted
+    uint4 tpre[PF ? LPR : 1];   // mode 2: the parked first-subframe values of the rows this lane stores for, requested while the round is predicted
 #pragma unroll
-    for (int i = 0; i < 8; i++) tpre[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < (PF ? LPR : 1); i++) tpre[i] = make_uint4(0, 0, 0, 0);
     auto flush = [&]() {
         if (flush_fast) {
             // every requested value is awaited HERE, once, before the first store: hipcc cannot count loads across the branches below and would
             // wait vmcnt(0) at each use — behind the stores of the iteration before it, i.e. for those stores (2.5 of the first version's 10 ms)
+            if constexpr (PF) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("" : "+v"(tpre[i].x), "+v"(tpre[i].y), "+v"(tpre[i].z), "+v"(tpre[i].w));
-            const int grp = lane >> 3, q4 = 4 * (lane & 7);
+                for (int i = 0; i < LPR; i++) asm volatile("" : "+v"(tpre[i].x), "+v"(tpre[i].y), "+v"(tpre[i].z), "+v"(tpre[i].w));
+            }
+            const int grp = lane / LPR, q4 = 4 * (lane % LPR);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int s = 8 * i + grp;
+            for (int i = 0; i < LPR; i++) {
+                const int s = RPI * i + grp;
                 const unsigned m = s_meta[s];
-                const int cn = (int)(m & 0xFFu), mode = (int)((m >> 8) & 3u), asg = (int)(m >> 12);
+                const int cn = (int)(m & 0x3Fu), mode = (int)((m >> 6) & 3u), asg = (int)((m >> 8) & 15u), rbs = (int)(m >> 12);
                 if (q4 < cn) {
                     const int *v = s_val + s * FOS + q4;
                     const int a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
@@ -249,33 +257,35 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                     else if (mode == 1) *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
                     else {
                         int l0, l1, l2, l3, r0, r1, r2, r3;
-                        flac_decor(asg, (int)tpre[i].x, a0, l0, r0); flac_decor(asg, (int)tpre[i].y, a1, l1, r1);
-                        flac_decor(asg, (int)tpre[i].z, a2, l2, r2); flac_decor(asg, (int)tpre[i].w, a3, l3, r3);
+                        uint4 tp;
+                        if constexpr (PF) tp = tpre[i]; else tp = *reinterpret_cast<const uint4 *>(dst + rbs);   // (no prefetch: read where it is needed; the other waves cover it)
+                        flac_decor(asg, (int)tp.x, a0, l0, r0); flac_decor(asg, (int)tp.y, a1, l1, r1);
+                        flac_decor(asg, (int)tp.z, a2, l2, r2); flac_decor(asg, (int)tp.w, a3, l3, r3);
                         *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)wrap(l0), (unsigned)wrap(l1), (unsigned)wrap(l2), (unsigned)wrap(l3));
-                        *reinterpret_cast<uint4 *>(dst + s_bs[s]) = make_uint4((unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
+                        *reinterpret_cast<uint4 *>(dst + rbs) = make_uint4((unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
                     }
                 }
             }
             return;
         }
-        const int part = lane >> 5, k = lane & 31;   // any alignment, any count: two rows per instruction
-        for (int i = 0; i < 32; i++) {
-            const int s = 2 * i + part;
+        const int part = lane / FNC, k = lane % FNC;   // any alignment, any count: 64 / FNC rows per instruction
+        for (int i = 0; i < FNC; i++) {
+            const int s = (64 / FNC) * i + part;
             const unsigned m = s_meta[s];
-            const int cn = (int)(m & 0xFFu), mode = (int)((m >> 8) & 3u), asg = (int)(m >> 12);
+            const int cn = (int)(m & 0x3Fu), mode = (int)((m >> 6) & 3u), asg = (int)((m >> 8) & 15u), rbs = (int)(m >> 12);
             if (k < cn) {
                 const int a = s_val[s * FOS + k];
                 int *dst = A.scratch + s_ptr[s] + k;
                 if (mode == 0) *dst = wrap(a);
                 else if (mode == 1) *dst = a;
-                else { int l, r; flac_decor(asg, dst[s_bs[s]], a, l, r); dst[0] = wrap(l); dst[s_bs[s]] = wrap(r); }
+                else { int l, r; flac_decor(asg, dst[rbs], a, l, r); dst[0] = wrap(l); dst[rbs] = wrap(r); }
             }
         }
     };
-    uint4 pf[FLPW];      // per window this lane loads for: the line that will replace its slot's line, already requested
-    u64 pf_line[FLPW];
+    uint4 pf[PF ? FLPW : 1];      // per window this lane loads for: the line that will replace its slot's line, already requested
+    u64 pf_line[PF ? FLPW : 1];
 #pragma unroll
-    for (int i = 0; i < FLPW; i++) { pf[i] = make_uint4(0, 0, 0, 0); pf_line[i] = ~0ull; }
+    for (int i = 0; i < (PF ? FLPW : 1); i++) { pf[i] = make_uint4(0, 0, 0, 0); pf_line[i] = ~0ull; }
 
     bool more = true;
     while (more) {
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
             if (want) b.win_lo = new_lo;
             const int sub8 = lane % FLPW, grp = lane / FLPW;
             unsigned act = 0;
+            if constexpr (PF) {
             // the lines requested a round ago are awaited here, once and unconditionally (see flush)
 #pragma unroll
             for (int i = 0; i < FLPW; i++) asm volatile("" : "+v"(pf[i].x), "+v"(pf[i].y), "+v"(pf[i].z), "+v"(pf[i].w));
@@ -321,8 +332,37 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
                     }
                 }
             }
+            } else if (__any(want)) {
+                // no prefetch registers: every line that moves in is read now, all eight requests in flight before the first is used (straight-line:
+                // an inactive slot reads the batch's first vector) — the wait is covered by the SIMD's other waves
+                uint4 ld[FLPW];
+                unsigned actm = 0;
+#pragma unroll
+                for (int i = 0; i < FLPW; i++) {
+                    const int s = i * (64 / FLPW) + grp;
+                    const int w = __shfl((int)want, s);
+                    const u64 ws = __shfl(new_lo, s);
+                    const u64 kf = __shfl(keep_from, s);
+                    const u64 l0 = ws / 2, line = l0 + (((u64)sub8 - l0) & (u64)(FLPW - 1));
+                    const bool on = w && (kf == ~0ull || line >= kf || line < kf - FWN / 2);
+                    const bool inr = on && 2 * line < A.G.safe_words;
+                    actm |= (on ? 1u : 0u) << i;
+                    actm |= (inr ? 1u : 0u) << (8 + i);
+                    ld[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + (inr ? 2 * line : 0ull));
+                }
+#pragma unroll
+                for (int i = 0; i < FLPW; i++) {
+                    if (actm & (1u << i)) {
+                        unsigned *wrow = s_win + (i * (64 / FLPW) + grp) * FWS + 4 * sub8;
+                        const bool inr = (actm >> (8 + i)) & 1u;
+                        wrow[0] = inr ? __builtin_bswap32(ld[i].x) : 0u; wrow[1] = inr ? __builtin_bswap32(ld[i].y) : 0u;
+                        wrow[2] = inr ? __builtin_bswap32(ld[i].z) : 0u; wrow[3] = inr ? __builtin_bswap32(ld[i].w) : 0u;
+                    }
+                }
+            }
             __syncthreads();
             if (have_flush && !(A.dbg & 2)) flush();
+            if constexpr (PF)
 #pragma unroll
             for (int i = 0; i < FLPW; i++) {       // pass 3: every slot's next line is requested now, a round or more before it is needed.  Straight-line:
                 // a slot that did not move asks for the line it already holds once more (a hit in L2) — a conditional load would be a branch, and
@@ -553,23 +593,24 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
         const u64 gptr = cand_scratch + (u64)jpos0 + (mode == 0 ? (u64)ch * (u64)bs : (mode == 1 ? (u64)bs : 0ull));
         const bool live = have && cnt > 0 && status == FE_OK;
         const bool stores = live && store_ok;
-        s_meta[lane] = stores ? ((unsigned)cnt | ((unsigned)mode << 8) | ((unsigned)chan_asgn << 12)) : 0u;
+        s_meta[lane] = stores ? ((unsigned)cnt | ((unsigned)mode << 6) | ((unsigned)chan_asgn << 8) | ((unsigned)bs << 12)) : 0u;
         s_ptr[lane] = gptr;
-        s_bs[lane] = bs;
         // the 16-byte path needs whole vectors at aligned places (block sizes are multiples of 4 but for a stream's last frame)
         flush_fast = __all(!stores || ((cnt & 3) == 0 && (gptr & 3) == 0 && (mode != 2 || (bs & 3) == 0)));
         __syncthreads();
         {   // the parked first-subframe values of the rounds that decorrelate: requested now, used by the flush at the top of the next round.
             // Straight-line and unconditional (a lane with nothing to fetch reads the scratch's first vector): inside an `if` hipcc merges the loaded
             // registers with the old ones at the join — moves that wait for the loads right here
+            if constexpr (PF) {
             const bool ff = flush_fast && !(A.dbg & 4);
-            const int grp = lane >> 3, q4 = 4 * (lane & 7);
+            const int grp = lane / LPR, q4 = 4 * (lane % LPR);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int s = 8 * i + grp;
+            for (int i = 0; i < LPR; i++) {
+                const int s = RPI * i + grp;
                 const unsigned m = s_meta[s];
-                const bool need = ff && ((m >> 8) & 3u) == 2u && q4 < (int)(m & 0xFFu);
-                tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr[s] + (u64)s_bs[s] + (u64)q4 : 0ull));
+                const bool need = ff && ((m >> 6) & 3u) == 2u && q4 < (int)(m & 0x3Fu);
+                tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr[s] + (u64)(m >> 12) + (u64)q4 : 0ull));
+            }
             }
         }
         // ---- phase 2: the prediction, by the lane that decoded the values
@@ -598,9 +639,11 @@ __global__ __launch_bounds__(64) void k_flac_decode(const FusedArgs A) {
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
     if (!A.count) return AUKIT_OK;
     AUKIT_HIP_CHECK(hipMemsetAsync(A.ticket, 0, 4, ctx->stream));
-    static const int wgs = getenv("AUKIT_FLAC_FUSED_WGS") ? atoi(getenv("AUKIT_FLAC_FUSED_WGS")) : 8;
+    static const int variant = getenv("AUKIT_FLAC_FUSED_VARIANT") ? atoi(getenv("AUKIT_FLAC_FUSED_VARIANT")) : 0;   // 0: <32, prefetch> two waves per SIMD; 1: <16, none> three
+    static const int wgs = getenv("AUKIT_FLAC_FUSED_WGS") ? atoi(getenv("AUKIT_FLAC_FUSED_WGS")) : (variant == 1 ? 12 : 8);
     const unsigned grid = std::min<unsigned>((A.count + 63) / 64, (unsigned)ctx->num_cus * (unsigned)std::max(wgs, 1));
-    hipLaunchKernelGGL(k_flac_decode, dim3(grid), dim3(64), 0, ctx->stream, A);
+    if (variant == 1) hipLaunchKernelGGL((k_flac_decode<16, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_flac_decode<32, true>), dim3(grid), dim3(64), 0, ctx->stream, A);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }
