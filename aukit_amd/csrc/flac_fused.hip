@@ -70,6 +70,29 @@ AUKIT_DEV void flac_decor(int asg, int a, int b, int &c0, int &c1) {
     c1 = asg == 8 ? a - b : (asg == 9 ? b : right);
 }
 
+// A 16-byte load that only the lanes with `on` make, in straight-line code: hipcc has no such thing (a load under an `if` is a branch, and at the
+// join it waits for everything in flight).  The compiler does not know this load exists: the caller waits for it (`s_waitcnt vmcnt(0)`) before
+// it reads `dst`, and nothing else may touch `dst` in between (tests/test_isa_schedule.py checks the registers in the built code object).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// The rows leave with the non-temporal hint: a lane's two 128-byte store runs per round would otherwise push its bit-stream line out of the XCD's
+// L2 before the lane comes back for the line's next 16 bytes (PMC, config 5: 8.3 GB fetched for 3.1 GB of bit stream with plain stores, 4.8 GB
+// with these; -DAUKIT_FLAC_PLAIN_STORES for the A/B)
+__device__ __forceinline__ void st16(int *dst, unsigned x, unsigned y, unsigned z, unsigned w) {
+#ifdef AUKIT_FLAC_PLAIN_STORES
+    *reinterpret_cast<v4u *>(dst) = v4u{x, y, z, w};
+#else
+    __builtin_nontemporal_store(v4u{x, y, z, w}, reinterpret_cast<v4u *>(dst));
+#endif
+}
+__device__ __forceinline__ void masked_load16(v4u &dst, const void *addr, bool on) {
+    unsigned long long save;
+    asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\t"
+                 "s_and_saveexec_b64 %1, vcc\n\t"
+                 "global_load_dwordx4 %0, %3, off\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(save) : "v"((unsigned)on), "v"(addr) : "vcc", "memory");
+}
+
 __device__ __forceinline__ int fmad24(int a, int b, int c) {   // v_mad_i32_i24 named outright (cf. flac.hip)
     int d;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -253,16 +276,16 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                     const int *v = s_val + s * FOS + q4;
                     const int a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
                     int *dst = A.scratch + s_ptr[s] + q4;
-                    if (mode == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)wrap(a0), (unsigned)wrap(a1), (unsigned)wrap(a2), (unsigned)wrap(a3));
-                    else if (mode == 1) *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
+                    if (mode == 0) st16(dst, (unsigned)wrap(a0), (unsigned)wrap(a1), (unsigned)wrap(a2), (unsigned)wrap(a3));
+                    else if (mode == 1) st16(dst, (unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
                     else {
                         int l0, l1, l2, l3, r0, r1, r2, r3;
                         uint4 tp;
                         if constexpr (PF) tp = tpre[i]; else tp = *reinterpret_cast<const uint4 *>(dst + rbs);   // (no prefetch: read where it is needed; the other waves cover it)
                         flac_decor(asg, (int)tp.x, a0, l0, r0); flac_decor(asg, (int)tp.y, a1, l1, r1);
                         flac_decor(asg, (int)tp.z, a2, l2, r2); flac_decor(asg, (int)tp.w, a3, l3, r3);
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4((unsigned)wrap(l0), (unsigned)wrap(l1), (unsigned)wrap(l2), (unsigned)wrap(l3));
-                        *reinterpret_cast<uint4 *>(dst + rbs) = make_uint4((unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
+                        st16(dst, (unsigned)wrap(l0), (unsigned)wrap(l1), (unsigned)wrap(l2), (unsigned)wrap(l3));
+                        st16(dst + rbs, (unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
                     }
                 }
             }
@@ -282,10 +305,10 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
             }
         }
     };
-    uint4 pf[PF ? FLPW : 1];      // per window this lane loads for: the line that will replace its slot's line, already requested
+    v4u pf[PF ? FLPW : 1];        // per window this lane loads for: the line that will replace its slot's line, already requested
     u64 pf_line[PF ? FLPW : 1];
 #pragma unroll
-    for (int i = 0; i < (PF ? FLPW : 1); i++) { pf[i] = make_uint4(0, 0, 0, 0); pf_line[i] = ~0ull; }
+    for (int i = 0; i < (PF ? FLPW : 1); i++) { pf[i] = v4u{0, 0, 0, 0}; pf_line[i] = ~0ull; }
 
     bool more = true;
     while (more) {
@@ -302,9 +325,10 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
             const int sub8 = lane % FLPW, grp = lane / FLPW;
             unsigned act = 0;
             if constexpr (PF) {
-            // the lines requested a round ago are awaited here, once and unconditionally (see flush)
+            // the lines requested a round ago (masked_load16 in pass 3: loads hipcc does not see) are awaited here, once and unconditionally
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < FLPW; i++) asm volatile("" : "+v"(pf[i].x), "+v"(pf[i].y), "+v"(pf[i].z), "+v"(pf[i].w));
+            for (int i = 0; i < FLPW; i++) asm volatile("" : "+v"(pf[i]));
             if (__any(want)) {
 #pragma unroll
                 for (int i = 0; i < FLPW; i++) {   // pass 1: which lines move in; the ones that were not requested a round ago (a new frame) are requested now
@@ -317,8 +341,8 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                         act |= 1u << i;
                         if (pf_line[i] != line) {
                             pf_line[i] = line;
-                            pf[i] = make_uint4(0, 0, 0, 0);
-                            if (2 * line < A.G.safe_words) pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + 2 * line);
+                            pf[i] = v4u{0, 0, 0, 0};
+                            if (2 * line < A.G.safe_words) pf[i] = *reinterpret_cast<const v4u *>(A.G.w0 + 2 * line);
                         }
                     }
                 }
@@ -364,13 +388,14 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
             if (have_flush && !(A.dbg & 2)) flush();
             if constexpr (PF)
 #pragma unroll
-            for (int i = 0; i < FLPW; i++) {       // pass 3: every slot's next line is requested now, a round or more before it is needed.  Straight-line:
-                // a slot that did not move asks for the line it already holds once more (a hit in L2) — a conditional load would be a branch, and
-                // behind a branch hipcc waits for everything in flight, the stores of the flush included
-                const u64 nl = pf_line[i] + ((act & (1u << i)) ? (u64)FLPW : 0ull);
+            for (int i = 0; i < FLPW; i++) {       // pass 3: a slot that moved asks for its next line now, a round or more before it is needed.
+                // Only the slots that moved (masked_load16): until round 4's last pass every slot asked every round — "a hit in L2" for the ones
+                // that kept their line, it said here; PMC said 16.1 GB fetched for 3.1 GB of bit stream: with two 128-byte store runs per lane
+                // in flight the per-XCD L2 (4 MiB for 16 K lanes) does not keep a lane's line from one round to the next
+                const bool mv = (act >> i) & 1u;
+                const u64 nl = pf_line[i] + (mv ? (u64)FLPW : 0ull);
                 pf_line[i] = nl;
-                const u64 la = (nl != ~0ull && 2 * nl < A.G.safe_words) ? 2 * nl : 0ull;
-                pf[i] = *reinterpret_cast<const uint4 *>(A.G.w0 + la);
+                masked_load16(pf[i], A.G.w0 + 2 * nl, mv && 2 * nl < A.G.safe_words);
             }
             __syncthreads();
             fresh = false;

@@ -900,7 +900,7 @@ def main(argv=None):
             roof_bytes = task if task else alg_bytes
             achieved = roof_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             tr = _measured_traffic(name, args) if launches == 1 else None
-            tstep = _measured_traffic_step(args.workload, args) if launches > 1 else None
+            tstep = _measured_traffic_step(args.workload, args) if (launches > 1 or tr is None) else None   # (a one-launch step with helper kernels around it is recorded as a step too)
             if tstep:
                 tr = tstep["hbm_bytes_per_step"]
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

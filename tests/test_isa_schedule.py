@@ -1,5 +1,5 @@
 """the hand-scheduled LDS / global-load pipelines (wave_f64.hip's Row::issue / wait — the headline kernel — and
-dfpwm_par.hip's AUKIT_DFF_ISSUE / WAIT) are only correct if hipcc keeps its hands off the destination registers between the asm
+dfpwm_par.hip's AUKIT_DFF_ISSUE / WAIT, flac_fused.hip's masked window prefetch) are only correct if hipcc keeps its hands off the destination registers between the asm
 statement that issues the loads and the one that waits for them.  tools/isa_check.py disassembles the translation units (hipcc
 cross-compiles gfx950 without a GPU) and replays the hardware's counters over every kernel; this test runs it at every build."""
 import os
@@ -51,7 +51,7 @@ def test_checker_accepts_a_correct_schedule_and_catches_an_early_use():
 
 
 @pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
-@pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16), ("wave_coef_f64.hip", 32)])
+@pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16), ("wave_coef_f64.hip", 32), ("flac_fused.hip", 8)])
 def test_hand_scheduled_kernels_keep_their_registers(src, at_least):
     asm = isa_check.compile_asm(os.path.join(ROOT, "aukit_amd", "csrc", src))
     v, n = isa_check.check(asm)
