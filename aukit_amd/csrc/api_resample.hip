@@ -584,6 +584,24 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
 
 // ---------------------------------------------------------------- stream.g711  aukit.lua:2850-2913
 bool floor_wave_g711_try(aukit_ctx *ctx, int interp, double old_rate, const std::vector<Seg> &segs, ResampleParams &P, int dtype, uint64_t algorithmic_bytes, int *rc);
+
+// stream.g711 with several channels (round 4): the channels of `str_byte(data, pos, ...)` (:2878-2893) are interleaved bytes; every
+// channel is resampled on its own (:2897-2911), so C planar byte rows + the MONO three-tier floor kernel give the same chunks.  This pass writes the
+// planar rows (1 byte per sample: a sixth of what the 8 kHz -> 48 kHz outputs weigh); row r = stream r / C, channel r % C, padded to 16 bytes.
+__global__ __launch_bounds__(256) void k_deinterleave_bytes(const unsigned char *src, const unsigned long long *in_off, const unsigned long long *row_off, int C, unsigned char *dst) {
+    const unsigned r = blockIdx.y, s = r / (unsigned)C, c = r - s * (unsigned)C;
+    const unsigned long long frames = (in_off[s + 1] - in_off[s]) / (unsigned long long)C;
+    const unsigned char *p = src + in_off[s] + c;
+    unsigned char *o = dst + row_off[r];
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; 4 * g < frames; g += (unsigned long long)gridDim.x * 256) {
+        unsigned w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * g + j < frames) w |= (unsigned)p[(4 * g + j) * (unsigned long long)C] << (8 * j);
+        *reinterpret_cast<unsigned *>(o + 4 * g) = w;
+    }
+}
+
 static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                        aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -654,6 +672,44 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
     if (C == 1 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {  // guarded short-cut under the floor(), bit-exact (floor_wave.hip)
         int frc = AUKIT_OK;
         done = floor_wave_g711_try(ctx, interp, d->sample_rate, segs, P, dtype, in_bytes + out_elems * dtype_size(dtype), &frc);
+        if (done && frc) { delete ck; return frc; }
+    }
+    if (!done && C >= 2 && !mono && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC) && !ctx->exact_math && !getenv("AUKIT_G711_NO_PLANAR") && in->n) {
+        // planar byte rows, then the mono floor kernel on n * C rows (k_deinterleave_bytes above)
+        std::vector<uint64_t> roff((size_t)in->n * C);
+        uint64_t tot = 0;
+        for (uint32_t s = 0; s < in->n; s++) {
+            const uint64_t fr = (in->off[s + 1] - in->off[s]) / (uint64_t)C;
+            for (int c = 0; c < C; c++) { roff[(size_t)s * C + c] = tot; tot += (fr + 15) & ~15ull; }
+        }
+        const size_t tab_at = (size_t)((tot + 16 + 255) & ~255ull);
+        if ((rc = ctx->tmp_buf2.ensure(tab_at + roff.size() * 8))) { delete ck; return rc; }
+        unsigned char *pl = reinterpret_cast<unsigned char *>(ctx->tmp_buf2.p);
+        if ((rc = h2d_table(ctx, pl + tab_at, roff.data(), roff.size() * 8))) { delete ck; return rc; }
+        uint64_t maxfr = 0;
+        for (uint32_t s = 0; s < in->n; s++) maxfr = std::max<uint64_t>(maxfr, (in->off[s + 1] - in->off[s]) / (uint64_t)C);
+        const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((maxfr / 4 + 255) / 256, 1), 64);
+        hipLaunchKernelGGL(k_deinterleave_bytes, dim3(gx, in->n * (unsigned)C), dim3(256), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
+                           reinterpret_cast<const unsigned long long *>(pl + tab_at), C, pl);
+        if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_deinterleave_bytes launch failed"); }
+        std::vector<Seg> ps;
+        ps.reserve(segs.size() * C);
+        for (const Seg &g : segs)
+            for (int c = 0; c < C; c++) {
+                Seg q = g;
+                q.stream = g.stream * (unsigned)C + (unsigned)c;
+                q.out_off = g.out_off + (unsigned long long)c * g.out_stride;
+                q.out_stride = 0;
+                ps.push_back(q);
+            }
+        ResampleParams Q = P;
+        Q.src = pl;
+        Q.src_off = reinterpret_cast<const unsigned long long *>(pl + tab_at);
+        Q.safe_lo = pl;
+        Q.safe_hi = pl + tot + 16;
+        Q.channels = 1;
+        int frc = AUKIT_OK;
+        done = floor_wave_g711_try(ctx, interp, d->sample_rate, ps, Q, dtype, in_bytes + out_elems * dtype_size(dtype), &frc);
         if (done && frc) { delete ck; return frc; }
     }
     if (!done) {

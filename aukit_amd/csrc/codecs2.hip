@@ -366,6 +366,8 @@ __global__ __launch_bounds__(256) void k_dfpwm_stream_copy(const signed char *ro
         }
 }
 
+bool dfpwm_stream_wave_try(aukit_ctx *ctx, int interp, double sample_rate, int channels, int rows_out, int mono, const std::vector<Seg> &segs, ResampleParams &P,
+                           uint64_t algorithmic_bytes, int *rc);
 static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                         aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -461,12 +463,22 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
         P.mix_mono = mono ? 1 : 0;
         P.out_channels = C;
         P.out = a->dev;
-        size_t lds;
-        if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) { delete ck; return rc; }
+        P.safe_lo = P.src;
+        P.safe_hi = P.src + (size_t)tot + 64;
         uint64_t oe = 0;
         for (uint64_t l : lens) oe += l * nd;
-        rc = launch_resample(ctx, SRC_I8, interp, EPI_STREAM_DFPWM, dtype, P, lds, in->total() + oe * dtype_size(dtype), nullptr);
-        if (rc) { delete ck; return rc; }
+        bool took = false;
+        if (dtype == AUKIT_F32 && (interp == AUKIT_INTERP_LINEAR || interp == AUKIT_INTERP_CUBIC)) {   // the wave kernel (fast_stream_dfpwm.hip)
+            int wrc = AUKIT_OK;
+            took = dfpwm_stream_wave_try(ctx, interp, d->sample_rate, C, nd, mono, segs, P, in->total() + oe * dtype_size(dtype), &wrc);
+            if (took && wrc) { delete ck; return wrc; }
+        }
+        if (!took) {
+            size_t lds;
+            if ((rc = plan_tiles(ctx, segs, ratio, interp, 1, P, &lds))) { delete ck; return rc; }
+            rc = launch_resample(ctx, SRC_I8, interp, EPI_STREAM_DFPWM, dtype, P, lds, in->total() + oe * dtype_size(dtype), nullptr);
+            if (rc) { delete ck; return rc; }
+        }
     }
     if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
     return AUKIT_OK;

@@ -16,6 +16,7 @@ template <int SRC> struct SrcTraits;
 template <> struct SrcTraits<SRC_PCM_S16LE_MONO> { static constexpr int BYTES = 2, SPV = 8; };
 template <> struct SrcTraits<SRC_G711_MONO> { static constexpr int BYTES = 1, SPV = 16; };
 template <> struct SrcTraits<SRC_PCM8_MONO> { static constexpr int BYTES = 1, SPV = 16; };  // 8-bit PCM: s / (s < 0 and 128 or 127), or (s - 128) / (s < 128 and 128 or 127) for unsigned (Q4)
+template <> struct SrcTraits<SRC_I8> { static constexpr int BYTES = 1, SPV = 16; };         // raw int8 rows (the DFPWM decoder's samples, stream.dfpwm): the value itself
 template <> struct SrcTraits<SRC_AUDIO_F32> { static constexpr int BYTES = 4, SPV = 4; };
 template <> struct SrcTraits<SRC_I32> { static constexpr int BYTES = 4, SPV = 4; };  // integer rows (FLAC): v * 2^-depth, exact in f32 for |v| < 2^24
 
@@ -150,6 +151,8 @@ AUKIT_DEV float sample_at(const ResampleParams &P, const FastParams &F, const un
         return g711_f32b(*q, P.ulaw, (float)P.g711_scale);
     } else if constexpr (SRC == SRC_PCM8_MONO) {
         return pcm8_f32(*q, P.data_type == AUKIT_UNSIGNED);
+    } else if constexpr (SRC == SRC_I8) {
+        return (float)(signed char)*q;
     } else if constexpr (SRC == SRC_I32) {
         return (float)*reinterpret_cast<const int *>(q) * F.scale_pos;
     } else {
@@ -192,6 +195,12 @@ AUKIT_DEV void write_lds(const ResampleParams &P, const FastParams &F, const Wav
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 o[e] = make_float4(pcm8_f32(ww[e] & 0xFF, us), pcm8_f32((ww[e] >> 8) & 0xFF, us), pcm8_f32((ww[e] >> 16) & 0xFF, us), pcm8_f32(ww[e] >> 24, us));
+        } else if constexpr (SRC == SRC_I8) {
+            const unsigned ww[4] = {u.x, u.y, u.z, u.w};
+            float4 *o = reinterpret_cast<float4 *>(sm + 16 * v);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[e] = make_float4((float)(signed char)(ww[e] & 0xFF), (float)(signed char)((ww[e] >> 8) & 0xFF), (float)(signed char)((ww[e] >> 16) & 0xFF), (float)(signed char)(ww[e] >> 24));
         } else if constexpr (SRC == SRC_I32) {
             *reinterpret_cast<float4 *>(sm + 4 * v) = make_float4((float)(int)u.x * F.scale_pos, (float)(int)u.y * F.scale_pos, (float)(int)u.z * F.scale_pos, (float)(int)u.w * F.scale_pos);
         } else {

@@ -206,6 +206,35 @@ def test_stream_dfpwm(ctx, oracle, ch, mono, rate):
                 assert np.max(np.abs(got[i][c] - ref.data[c]), initial=0) <= 1e-13, (i, c)
 
 
+@pytest.mark.parametrize("ch,mono,rate", [(1, False, 24000), (1, False, 32000), (2, False, 32000), (2, True, 32000), (1, False, 44100), (2, False, 22050), (3, True, 8000), (2, False, 24000)])
+def test_stream_dfpwm_other_rates_on_the_wave_kernel(ctx, oracle, monkeypatch, ch, mono, rate):
+    """stream.dfpwm at rates other than 48 kHz with F32 storage (aukit.lua:2471-2491; round 4): k_fast_wave_dfpwm against the oracle (tolerance stage:
+    1e-6 RMS of the [-1, 1] scale = 1.28e-4 on these int8-range values) and against the reference-order kernel, chunk table unchanged."""
+    B, N = _B(), _N()
+    streams = [_dfpwm_bytes(oracle, 48000 * 2 + 16, 4, 3), _dfpwm_bytes(oracle, 6000 * 8 * ch, 4, 4), b"\xaa" * 13, _dfpwm_bytes(oracle, 6000 * 8 * ch + 8, 4, 5)]
+    bt = B.Batch.upload(ctx, streams)
+    for interp in ("linear", "cubic"):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, ch, rate), interp, mono=mono, dtype=N.F32)
+        assert ctx.last_kernel()[0].startswith("k_fast_wave_dfpwm"), ctx.last_kernel()
+        got = out.download()
+        monkeypatch.setenv("AUKIT_DFPWM_NO_WAVE", "1")
+        out2, ck2 = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, ch, rate), interp, mono=mono, dtype=N.F32)
+        monkeypatch.delenv("AUKIT_DFPWM_NO_WAVE")
+        assert ctx.last_kernel()[0].startswith("k_resample<"), ctx.last_kernel()
+        got2 = out2.download()
+        for i, s in enumerate(streams):
+            ref = oracle.stream_dfpwm(s, rate, ch, mono, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks
+            assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            assert np.array_equal(ck.pos[i][:ref.nchunks], ref.chunk_pos)
+            for c in range(ref.channels):
+                assert len(got[i][c]) == len(ref.data[c])
+                if len(ref.data[c]):
+                    assert np.sqrt(np.mean((got[i][c] - ref.data[c]) ** 2)) <= 1.28e-4, (i, c)
+                    assert np.max(np.abs(got[i][c] - ref.data[c])) <= 1e-3, (i, c)
+                    assert np.max(np.abs(got2[i][c] - ref.data[c])) <= 2e-5, (i, c)   # (the reference-order kernel, rounded to f32)
+
+
 def test_mdfpwm(ctx, oracle, monkeypatch):
     B, N = _B(), _N()
     e1, e2 = _dfpwm_bytes(oracle, 48000 * 3, 4, 5), _dfpwm_bytes(oracle, 48000 * 3, 4, 6)

@@ -500,6 +500,35 @@ def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):
             assert np.array_equal(got[i][c], ref.data[c]), (i, c)
 
 
+@pytest.mark.parametrize("ch", [2, 3])
+@pytest.mark.parametrize("rate,interp,alaw", [(8000, "cubic", False), (8000, "linear", True), (44100, "cubic", False), (22050, "linear", False), (11025, "cubic", True)])
+def test_stream_g711_several_channels_on_the_floor_kernel(ctx, oracle, monkeypatch, ch, rate, interp, alaw):
+    """stream.g711 with interleaved channels (aukit.lua:2878-2911; round 4): planar byte rows (k_deinterleave_bytes) + the mono three-tier floor
+    kernel on n * channels rows — bit for bit the oracle's chunks and the reference-order kernel's, ragged lengths, random bytes and plateaus."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(rate + ch))
+    flat = np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), 25 * ch)
+    streams = [oracle.gen_g711(pcm16(int(rate * 2.3) * ch, rate, 2, 5), not alaw), rng.integers(0, 256, (rate + 17) * ch, dtype=np.uint8).tobytes(), flat.tobytes()[:len(flat) // ch * ch],
+               (b"\x00\xff\x80" * 700)[:2100 // ch * ch], b"\x7f" * ch]
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_G711, ch, rate, ulaw=not alaw)
+    for dt in (N.I8, N.F64):
+        out, ck = B.stream_decode(ctx, bt, desc, interp, dtype=dt)
+        assert ctx.last_kernel()[0].startswith("k_floor_wave_g711"), ctx.last_kernel()
+        got = out.download()
+        monkeypatch.setenv("AUKIT_G711_NO_PLANAR", "1")
+        out2, _ = B.stream_decode(ctx, bt, desc, interp, dtype=dt)
+        monkeypatch.delenv("AUKIT_G711_NO_PLANAR")
+        assert ctx.last_kernel()[0].startswith("k_resample<"), ctx.last_kernel()
+        got2 = out2.download()
+        for i, s in enumerate(streams):
+            ref = oracle.stream_g711(s, not alaw, ch, rate, False, oracle.INTERP[interp])
+            assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+            for c in range(ch):
+                assert np.array_equal(got[i][c], ref.data[c]), (i, c, dt)
+                assert np.array_equal(got2[i][c], ref.data[c]), (i, c, dt)
+
+
 @pytest.mark.parametrize("alaw", [False, True])
 @pytest.mark.parametrize("rate", [8000, 11025, 16000, 22050, 44100, 6000, 9600, 7200])   # the last three: one and five phases per lane in registers (8000: three)
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
