@@ -360,7 +360,13 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     constexpr int SEGS = FB / 16;         // 16-byte vectors of a block per fetch
     constexpr int RSEG = RB / 16;         // ... per round
     constexpr int RPF = FB / RB;          // rounds per fetch
-    constexpr int INS = FB == 16 ? 4 : FB / 4 + 4;  // dwords between two blocks in the staging area (conflict-free ds_read_b128 per lane)
+    // REGS (FB == 128, round 4): no staging area at all — every lane reads ITS block's bytes itself, a whole 128-byte line at a time (eight aligned
+    // 16-byte loads into registers, one line ahead), and cuts a round's 16 bytes out of two neighbouring vectors (per-lane byte offset: blocks start
+    // 7 or 14 bytes into a line).  With 16 bytes per lane and round from 64 lines 1 KiB apart every line came from HBM eight times over (PMC: 6.5 GB
+    // fetched for 0.9 GB of blocks — the power-of-two stride also lands the wave's 64 lines in a few L2 sets)
+    constexpr bool REGS = FB == 128;
+    static_assert(!REGS || RB == 16, "the register window serves 16-byte rounds");
+    constexpr int INS = REGS ? 0 : (FB == 16 ? 4 : FB / 4 + 4);  // dwords between two blocks in the staging area (conflict-free ds_read_b128 per lane)
     constexpr int HB = 7 * C;
     constexpr bool STREAM = MODE == MS_STREAM;
     constexpr bool FLOORED = STREAM && C == 2;
@@ -428,6 +434,23 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     const int ndata = P.block_align - HB;                 // data bytes per block
     const int nr = (ndata + RB - 1) / RB;                  // rounds
     typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    // REGS: the lane's aligned 16-byte vectors, eight (a line) held and eight requested
+    [[maybe_unused]] const unsigned char *cb = nullptr;
+    [[maybe_unused]] unsigned sh = 0;
+    [[maybe_unused]] uint4 ra[REGS ? 8 : 1], rn[REGS ? 8 : 1];
+    [[maybe_unused]] auto ldc = [&](int j) -> uint4 {   // vector j of this lane's block data (zeros beyond the allocation / for a lane without a block)
+        const unsigned char *p = cb + 16 * (long long)j;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid && p + 16 <= P.safe_hi && p + 16 > P.src) {
+            const u32x4u t = *reinterpret_cast<const u32x4u *>(p);
+            v = make_uint4(t.x, t.y, t.z, t.w);
+        } else if (valid) {
+            unsigned t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) if (p + k >= P.src && p + k < P.safe_hi) t[k >> 2] |= (unsigned)p[k] << (8 * (k & 3));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        return v;
+    };
     // staging: vector i of this lane belongs to block i * (64 / SEGS) + lane / SEGS, bytes (lane % SEGS) * 16 .. + 16 of the round
     const int sblk0 = lane / SEGS, sseg = lane % SEGS;
     auto fetch = [&](int r, u32x4u (&pf)[SEGS]) {
@@ -446,12 +469,29 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
         }
     };
     u32x4u pf[SEGS];
-    fetch(0, pf);
+    if constexpr (!REGS) fetch(0, pf);
+    else {
+        const unsigned char *a0 = P.src + boff + HB;
+        cb = reinterpret_cast<const unsigned char *>((uintptr_t)a0 & ~(uintptr_t)15);
+        sh = (unsigned)(a0 - cb);
+#pragma unroll
+        for (int k = 0; k < 8; k++) rn[k] = ldc(k);
+    }
     [[maybe_unused]] ResampleParams RP;
     if constexpr (STREAM) { RP.ratio = P.ratio; RP.rcp = P.rcp; RP.exact_rcp = P.exact_rcp; RP.sinc_w = 10; RP.pos_mul = 0; }
     const int nf = (ndata + FB - 1) / FB;                  // fetches
     for (int r = 0; r < nr; r++) {
         const int sub = r % RPF;   // wave-uniform
+        if constexpr (REGS) {
+            if (sub == 0) {   // the requested line becomes the held one; the line after it is requested (round r needs vectors r and r + 1: up to vector nr)
+#pragma unroll
+                for (int k = 0; k < 8; k++) ra[k] = rn[k];
+                if (r + 8 <= nr) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rn[k] = ldc(r + 8 + k);
+                }
+            }
+        } else
         if (sub == 0) {
             // this fetch's bytes into the staging area, the next fetch's on their way
 #pragma unroll
@@ -465,7 +505,28 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
         for (int v = 0; v < RSEG; v++) {
             const int nb = nby - 16 * v;   // wave-uniform
             if (nb <= 0) break;
-            const uint4 q = *reinterpret_cast<const uint4 *>(inl + lane * INS + 4 * (sub * RSEG + v));
+            uint4 q;
+            if constexpr (REGS) {
+                uint4 c0, c1;
+                switch (sub) {   // wave-uniform
+                case 0: c0 = ra[0]; c1 = ra[1]; break;
+                case 1: c0 = ra[1]; c1 = ra[2]; break;
+                case 2: c0 = ra[2]; c1 = ra[3]; break;
+                case 3: c0 = ra[3]; c1 = ra[4]; break;
+                case 4: c0 = ra[4]; c1 = ra[5]; break;
+                case 5: c0 = ra[5]; c1 = ra[6]; break;
+                case 6: c0 = ra[6]; c1 = ra[7]; break;
+                default: c0 = ra[7]; c1 = rn[0]; break;
+                }
+                // bytes sh .. sh + 15 of the 32: a per-lane dword offset (selects) and byte offset (v_alignbyte)
+                const unsigned dsh = sh >> 2, bsh = sh & 3u;
+                const unsigned d8[9] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, 0u};
+                unsigned e[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) e[k] = dsh == 0 ? d8[k] : (dsh == 1 ? d8[k + 1] : (dsh == 2 ? d8[k + 2] : d8[k + 3]));
+                q = make_uint4(__builtin_amdgcn_alignbyte(e[1], e[0], bsh), __builtin_amdgcn_alignbyte(e[2], e[1], bsh), __builtin_amdgcn_alignbyte(e[3], e[2], bsh),
+                               __builtin_amdgcn_alignbyte(e[4], e[3], bsh));
+            } else q = *reinterpret_cast<const uint4 *>(inl + lane * INS + 4 * (sub * RSEG + v));
             const unsigned w[4] = {q.x, q.y, q.z, q.w};
             const int slot = 4 + v * (32 / C);
             const int s1s[2] = {L[0].s1, L[C - 1].s1}, s2s[2] = {L[0].s2, L[C - 1].s2}, ds[2] = {L[0].d, L[C - 1].d};
@@ -725,10 +786,15 @@ static void ms_launch_rows(const MsWaveParams &P, unsigned grid, size_t lds, hip
 // bytes of a block per fetch in the stream kernels.  Measured (1024 x 10 s mono, same box): fetching 64 bytes at a time and decoding them in four
 // rounds of 16 halves the input re-fetch (PMC FETCH x 2: 1.29 -> 0.60 GB for 0.23 GB of blocks — with 16-byte fetches every 128-byte line comes from
 // HBM several times) but costs 4 KB of LDS per wave, i.e. resident waves, and the kernel is bound by those: 2.52 -> 3.04 ms.  Time won: 16.
-constexpr int MS_FB_STREAM = 16;
+// Round 4: 128 = the register window (REGS in k_ms_wave): a line per lane at a time, no staging area — the re-fetch is gone (PMC FETCH x 2: 6.5 -> ?
+// GB per 4096 x 216 blocks) without the LDS that made 64 lose.  -DAUKIT_MS_FB=16 for the A/B.
+#ifndef AUKIT_MS_FB
+#define AUKIT_MS_FB 128
+#endif
+constexpr int MS_FB_STREAM = AUKIT_MS_FB;
 template <int C, int RB, bool MIX, typename OUT_T>
 static void ms_launch_stream(int interp, const MsWaveParams &P, unsigned grid, size_t lds, hipStream_t st) {
-    constexpr int FB = RB < MS_FB_STREAM ? MS_FB_STREAM : RB;
+    constexpr int FB = RB == 16 ? MS_FB_STREAM : RB;
     if constexpr (RB == 16 && sizeof(OUT_T) == 1) {   // the audited instantiations (AUKIT_OPT_COLLECT_STATS)
         if (P.audit) {
             if (interp == AUKIT_INTERP_LINEAR) hipLaunchKernelGGL((k_ms_wave<C, RB, MS_STREAM, AUKIT_INTERP_LINEAR, MIX, OUT_T, FB, true>), dim3(grid), dim3(64), lds, st, P);
@@ -742,7 +808,8 @@ static void ms_launch_stream(int interp, const MsWaveParams &P, unsigned grid, s
 }
 static size_t ms_lds_bytes(int C, int rb, unsigned wt_floats, int fb = 0, size_t stage_bytes = 0) {
     if (fb < rb) fb = rb;
-    const int R = rb * 2 / C, ROW = 4 + R + 1, INS = fb == 16 ? 4 : fb / 4 + 4;
+    if (rb != 16 && fb == 128) fb = rb;
+    const int R = rb * 2 / C, ROW = 4 + R + 1, INS = fb == 128 ? 0 : (fb == 16 ? 4 : fb / 4 + 4);
     return (size_t)64 * INS * 4 + (size_t)C * 64 * ROW * 4 + 3 * 64 * 8 + 16 * 4 + (((size_t)wt_floats + 3) & ~(size_t)3) * 4 + stage_bytes;
 }
 
