@@ -19,7 +19,7 @@ static int check_pcm_desc(const aukit_codec_desc *d) {
     if (d->data_type == AUKIT_FLOAT && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
     if (d->channels < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #5 (number outside of range)");
-    if (d->channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_CHANNELS);
+    if (d->channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_PLANAR_CHANNELS);
     return AUKIT_OK;
 }
 
@@ -118,7 +118,7 @@ static int decode_resample_flat(aukit_ctx *ctx, const aukit_batch *in, const auk
         if ((rc = check_pcm_desc(d))) return rc;
         planar = !(d->interleaved && C > 1) && C > 1;  // aukit.lua:1156-1169
     } else {
-        if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
+        if (C < 1 || C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
     }
     const size_t frame_bytes = d->codec == AUKIT_CODEC_PCM ? (size_t)(d->bit_depth / 8) * C : (size_t)C;
     const double ratio = do_resample ? new_rate / d->sample_rate : 1.0;  // :658
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_deinterleave_bytes(const unsigned char 
 static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                        aukit_chunks **chunks_out) {
     const int C = d->channels;
-    if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
+    if (C < 1 || C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
     if (d->sample_rate != std::floor(d->sample_rate) || d->sample_rate < 1) return fail(AUKIT_E_UNSUPPORTED, "stream.g711 needs an integer sample rate");
     if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
     if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.g711 output must be AUKIT_I8 or AUKIT_F64");

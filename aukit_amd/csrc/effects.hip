@@ -644,6 +644,7 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
     if (*out == in) return fail(AUKIT_E_ARG, "mono cannot run in place");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     if (in->lazy_rs) { int lrc = lazy_materialize(ctx, const_cast<aukit_audio *>(in)); if (lrc) return lrc; }
+    if (in->pend_norm && in->channels > AUKIT_MAX_CHANNELS) { int frc = audio_flush(ctx, in); if (frc) return frc; }   // (k_mono<NORM> keeps a multiplier per channel in registers: eight)
     aukit_audio *o = *out;
     int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, in->dtype, in->len.data());
     if (rc) return rc;

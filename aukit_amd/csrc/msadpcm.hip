@@ -923,7 +923,6 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
     const int C = d->channels;
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
     if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
-    if (interp == AUKIT_INTERP_SINC && C == 2) return fail(AUKIT_E_UNSUPPORTED, "stream.msadpcm stereo + sinc reads the previous block through a shifted history (not reproduced)");
     if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.msadpcm output must be AUKIT_I8 or AUKIT_F64");
     MsBlocks B;
     int rc = ms_count_blocks(in, d, B);
@@ -1087,6 +1086,9 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         for (uint64_t b = 0; b < nblk[s]; b++) {
             Seg g;
             g.src_base = -1; g.w_lo = 1; g.w_hi = (int)spb_dec; g.n_out = newlen;
+            // stereo keeps the block before at indices -N .. -1 (`left[i-#lastL-1] = lastL[i]`, :2640-2643; `lastL` outlives the iterator call): only
+            // sinc reaches below index 1 — the rows of a stream's blocks are consecutive, so those entries are the row's entries 1 - N .. 0
+            if (C == 2 && interp == AUKIT_INTERP_SINC && b > 0) g.w_lo = 1 - (int)spb_dec;
             g.stream = (unsigned)(blkrows.size() / C);
             g.out_off = a->row_off[s] + b * newlen;
             g.out_stride = (unsigned)a->row_stride[s];
@@ -1103,6 +1105,7 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         RP.src_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
         RP.channels = C;
         RP.mix_mono = (C == 2 && mono) ? 2 : 0;
+        RP.sinc_hole = (C == 2 && interp == AUKIT_INTERP_SINC) ? 1 : 0;
         RP.out = a->dev;
         size_t glds;
         if ((rc = plan_tiles(ctx, segs, ratio, interp, C, RP, &glds))) { delete ck; return rc; }

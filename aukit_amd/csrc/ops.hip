@@ -144,7 +144,7 @@ int aukit_combine(aukit_ctx *ctx, const aukit_audio *const *in, uint32_t count, 
     const uint32_t n = in[0]->n;
     int cn = 0;
     for (uint32_t a = 0; a < count; a++) cn += in[a]->channels;
-    if (cn > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
+    if (cn > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_PLANAR_CHANNELS);
     std::vector<uint64_t> lens(n, 0);
     for (uint32_t s = 0; s < n; s++)
         for (uint32_t a = 0; a < count; a++) lens[s] = std::max(lens[s], in[a]->len[s]);  // :757
@@ -174,7 +174,7 @@ int aukit_split(aukit_ctx *ctx, const aukit_audio *in, const int32_t *channels, 
     if (rc) return rc;
     AUKIT_FLUSH(ctx, in);
     if (count == 0) return fail(AUKIT_E_LUA, "bad argument #1 (cannot use empty table)");
-    if (count > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
+    if (count > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_PLANAR_CHANNELS);
     for (uint32_t k = 0; k < count; k++)
         if (channels[k] < 1 || channels[k] > in->channels) return fail(AUKIT_E_LUA, "channel %d (in argument 1) out of range", channels[k]);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -341,7 +341,7 @@ int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, do
         if (!(duty >= 0 && duty <= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %.14g to be within 0 and 1)", duty);
     }
     if (!(channels >= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %d to be within 1 and inf)", channels);
-    if (channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
+    if (channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_PLANAR_CHANNELS);
     if (!(sample_rate >= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %.14g to be within 1 and inf)", sample_rate);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     const double cnt = duration * sample_rate;  // for i = 1, duration * sampleRate
@@ -378,7 +378,7 @@ int aukit_decode_table(aukit_ctx *ctx, const double *values, const uint64_t *off
     if (d->data_type == AUKIT_FLOAT && d->bit_depth != 32) return fail(AUKIT_E_ARG, "bad argument #2 (float audio must have 32-bit depth)");
     if (d->channels < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
     if (!(d->sample_rate >= 1)) return fail(AUKIT_E_ARG, "bad argument #5 (number outside of range)");
-    if (d->channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_CHANNELS);
+    if (d->channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_PLANAR_CHANNELS);
     const int dtype = ctx->dtype == AUKIT_F32 ? AUKIT_F32 : AUKIT_F64;
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     std::vector<uint64_t> lens(n);

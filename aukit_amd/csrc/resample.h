@@ -48,6 +48,7 @@ struct ResampleParams {
     int exact_rcp;              // 1: RN((i-1)/ratio) via rcp + two fmas is verified exact for this launch
     int halo_l, halo_r;         // taps below / above floor(x)
     int sinc_w;
+    int sinc_hole;   // stream.msadpcm stereo (:2640-2643): table indices -N .. -1 are the block before (entry i of it at i - N - 1), index 0 is nil — sinc only reaches there
     // source
     const unsigned char *src;
     const unsigned long long *src_off;     // per stream: byte offset (batch) / element offset (audio rows)

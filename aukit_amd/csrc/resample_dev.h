@@ -52,8 +52,13 @@ AUKIT_DEV double eval_at(const ResampleParams &P, const Seg &sg, const TAB_T *ta
         const double pi = 3.14159265358979323846;
         for (int n = -P.sinc_w; n <= P.sinc_w; n++) {
             int w = k + n;
+            int sft = 0;
+            if (P.sinc_hole) {   // reference index w <= -1 is the row's entry w + 1 (the block before, shifted by the hole at 0)
+                if (w == 0) continue;
+                if (w < 0) { sft = 1; w++; }
+            }
             if (w >= sg.w_lo && w <= sg.w_hi) {
-                double d = tab[idx + n];
+                double d = tab[idx + n + sft];
                 double px = pi * (fx - n);
                 if (px == 0) sum = sum + d;
                 else sum = sum + d * sin(px) / px;

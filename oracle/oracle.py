@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libaukit_oracle.so")
-MAX_CH = 8
+MAX_CH = 64
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED = 0, -1, -2, -3, -4
 NONE, LINEAR, CUBIC, SINC = 0, 1, 2, 3

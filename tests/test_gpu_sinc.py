@@ -72,3 +72,29 @@ def test_stream_flac_and_qoa_sinc(ctx, oracle, dt):
             for c in range(1 if mono else 2):
                 assert len(got[s][c]) == len(ref.data[c])
                 assert np.max(np.abs(got[s][c] - ref.data[c]), initial=0) <= tol, (mono, s, c)
+
+
+@pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("rate", [44100, 22050])
+def test_stream_msadpcm_stereo_sinc(ctx, oracle, mono, rate):
+    """aukit.stream.msadpcm with two channels keeps the block before at table indices -N .. -1 and leaves index 0 nil (aukit.lua:2640-2643; `lastL`
+    outlives the iterator call): interpolate.sinc is the one interpolation that reaches there.  Floored int8 outputs: sin() is the device's libm,
+    so an output whose value lies within 1e-12 of an integer may land on the other side — counted, not tolerated in bulk."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    ba = 256
+    spb = (ba - 14) + 2   # frames a stereo block decodes to
+    streams = [oracle.gen_msadpcm(np.stack([pcm16(spb * nb, rate, 3, 60 + 2 * i + c) for c in range(2)], 1).ravel(), 2, ba) for i, nb in enumerate((40, 3, 1))]
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, streams), B.make_desc(N.CODEC_MSADPCM, 2, rate, block_align=ba), "sinc", mono=mono, dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_msadpcm(s, ba, 2, rate, mono, None, oracle.SINC)
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        for c in range(ref.channels):
+            d = got[i][c].astype(np.int64) - ref.data[c].astype(np.int64)
+            assert np.max(np.abs(d), initial=0) <= 1 and np.count_nonzero(d) <= 2, (i, c, int(np.count_nonzero(d)))
+    # the history matters: the second block decoded as a stream's first block (no `lastL`) gives different outputs near its start
+    two = oracle.stream_msadpcm(streams[0][:2 * ba], ba, 2, rate, mono, None, oracle.SINC)
+    alone = oracle.stream_msadpcm(streams[0][ba:2 * ba], ba, 2, rate, mono, None, oracle.SINC)
+    n1 = len(alone.data[0])
+    assert len(two.data[0]) == 2 * n1 and not np.array_equal(two.data[0][n1:], alone.data[0])
