@@ -44,6 +44,7 @@ struct RsOnepoleParams {
     // recurrence forgets its state at m per output (m^(512 warm) < 2^-40), so the run's own outputs are those of the whole row's chain to far
     // below an f32 ulp — and a row is no longer ONE serial chain of 938 tiles on a chip that can run four times as many chains as config 5 has rows
     int segs, warm;
+    int novec;   // AUKIT_RS_NOVEC=1: every window element by element (the first cut; A/B)
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
@@ -62,12 +63,14 @@ AUKIT_DEV double dpp_f64(double v) {
 
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 template <int INTERP, bool HP, bool TAB, typename S>
 __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     extern __shared__ float rsm[];
     constexpr int E = 8, T = 64 * E;
-    float *const win = rsm;                                  // P.cap floats
+    float *const win = rsm + 16;                             // P.cap floats in all: 16 of slack in front (a part's first vector may start EPV - 1 elements early), the window, 16 behind
     float *const xb = rsm + P.cap;                           // T + T / E + 8
+    constexpr int EPV = 16 / (int)sizeof(S), VPL = 2;        // elements per 16-byte vector; vectors per lane and tile
     [[maybe_unused]] float *const wt = xb + (T + T / E + 8);                 // TAB: 4 fb floats
     if constexpr (TAB) { for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64) wt[i] = P.wg[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     const int lane = threadIdx.x;
@@ -118,13 +121,49 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         base1 = nfr_s > 1 ? rec_base(1) : base0;
         base2 = nfr_s > 2 ? rec_base(2) : base1;
     }
-    auto fetch = [&](unsigned kk, int nst, int (&pre)[8]) {
+    // Round 4, late: the window as ALIGNED 16-BYTE VECTORS where it lies inside the row (every tile but a row's first and last).  One element per
+    // lane and load — a clamp, a frame select and a 64-bit address each — was 13 of the kernel's 45 VALU instructions per output, and PMC says the
+    // kernel is bound by those (VALU busy ~ 75 %).  A window is one run of elements (part A) or two (frame-by-frame rows: the rest in the frame
+    // after, part B); a part is read from the vector that holds its first element on, vector s of the tile by lane s % 64.  Part A's vectors are
+    // written to LDS as they stand — what they hold beyond the part falls into the slack around the window or onto part B's place — part B's
+    // behind them, its first vector guarded.
+    struct VecDesc { int on, nvA, nvB, dposA, dposB, loB; };
+    auto fetch = [&](unsigned kk, int nst, int (&pre)[8], VecDesc &vd) {
         if (P.frames && L > 0) {
             const unsigned k0 = kk < 1u ? 1u : (kk > (unsigned)L ? (unsigned)L : kk);
             while ((int)(k0 - 1u) >= bound && fcur + 1u < nfr_s) {
                 fcur++;
                 base0 = base1; base1 = base2; bound += bsn;
                 if (fcur + 2u < nfr_s) base2 = rec_base(fcur + 2u);
+            }
+        }
+        vd.on = 0; vd.nvA = vd.nvB = vd.dposA = vd.dposB = vd.loB = 0;
+        const int e0 = (int)kk - 1, e1 = e0 + nst;   // row elements [e0, e1)
+        if (L > 0 && e0 >= EPV && e1 + EPV <= L && !P.novec) {
+            const int xeA = P.frames ? (e1 < bound ? e1 : bound) : e1;
+            const S *const pA = P.frames ? rows_s + (base0 + (long long)e0) : row + e0;
+            const uintptr_t aA = (uintptr_t)pA, alA = aA & ~(uintptr_t)15;
+            const int hA = (int)((aA - alA) / sizeof(S));
+            const int nvA = (hA + (xeA - e0) + EPV - 1) / EPV;
+            uintptr_t alB = alA;
+            int nvB = 0, hB = 0;
+            if (e1 > xeA) {
+                const uintptr_t aB = (uintptr_t)(rows_s + (base1 + (long long)xeA));
+                alB = aB & ~(uintptr_t)15;
+                hB = (int)((aB - alB) / sizeof(S));
+                nvB = (hB + (e1 - xeA) + EPV - 1) / EPV;
+            }
+            if (nvA + nvB <= 64 * VPL) {
+                vd.on = 1; vd.nvA = nvA; vd.nvB = nvB; vd.dposA = -hA; vd.dposB = (xeA - e0) - hB; vd.loB = xeA - e0;
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    const int sl = lane + 64 * i, sb = sl - nvA;
+                    const bool inA = sl < nvA, inB = !inA && sb < nvB;
+                    const uintptr_t a = inB ? alB + 16u * (unsigned)sb : alA + (inA ? 16u * (unsigned)sl : 0u);   // (a slot without a vector reads the tile's first one: no branch around a load)
+                    const u32x4g v = *(const __attribute__((address_space(1))) u32x4g *)a;   // (global_load_dwordx4; through a generic pointer it would be a flat load, counted on lgkmcnt as well)
+                    pre[4 * i] = (int)v.x; pre[4 * i + 1] = (int)v.y; pre[4 * i + 2] = (int)v.z; pre[4 * i + 3] = (int)v.w;
+                }
+                return;
             }
         }
 #pragma unroll
@@ -137,6 +176,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         }
     };
     int pre[8];
+    VecDesc vcur{0, 0, 0, 0, 0, 0}, vnxt{0, 0, 0, 0, 0, 0};
     // this wave's run of tiles [t_lo, t_hi) of the row's ntiles, entered `warm` tiles early
     const unsigned long long ntiles = (nout + T - 1) / T;
     const unsigned long long t_lo = ntiles * seg / (unsigned)P.segs, t_hi = ntiles * (seg + 1u) / (unsigned)P.segs;
@@ -147,7 +187,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         kb = (unsigned)(nn / P.fb); r0 = (unsigned)(nn % P.fb);
         const unsigned long long left0 = o_end > t_in * T ? o_end - t_in * T : 0ull;
         const int cnt0 = (int)(left0 < (unsigned long long)T ? left0 : (unsigned long long)T);
-        if (left0) fetch(kb, tile_nst(r0, cnt0), pre);
+        if (left0) fetch(kb, tile_nst(r0, cnt0), pre, vcur);
     }
     // a full tile's results wait in registers (held[]) and are stored at the top of the NEXT turn, behind the wait for that tile's window: loads and
     // stores share vmcnt and hipcc waits vmcnt(0) across this loop's branches — stores issued at the end of a turn were waited for at the top of
@@ -162,13 +202,57 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         auto qr = [&](unsigned j, unsigned &q, unsigned &rem) { const unsigned nn = r0 + j * P.fa; q = __umulhi(nn, P.fmagic); rem = nn - q * P.fb; };   // q relative to kb
         const int nst = tile_nst(r0, cnt);   // table indices kb .. kb + ql + 3 (floor(x) = q + 1; taps q .. q + 3)
         __builtin_amdgcn_wave_barrier();
+        auto cvt = [&](int v) -> float { return (float)v * (v < 0 ? P.scale_neg : P.scale); };
+        if (vcur.on) {   // (wave-uniform)
 #pragma unroll
-        for (int u = 0; u < 8; u++) win[lane + 64 * u] = (float)pre[u] * (pre[u] < 0 ? P.scale_neg : P.scale);   // (cap >= 512)
+            for (int i = 0; i < VPL; i++) {
+                const int sl = lane + 64 * i;
+                if (sl < vcur.nvA) {
+                    float *d = win + (vcur.dposA + EPV * sl);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int x = pre[4 * i + w];
+                        if constexpr (sizeof(S) == 4) d[w] = cvt(x);
+                        else if constexpr (sizeof(S) == 2) { d[2 * w] = cvt((int)(short)(x & 0xFFFF)); d[2 * w + 1] = cvt(x >> 16); }
+                        else { d[4 * w] = cvt((int)(signed char)(x & 0xFF)); d[4 * w + 1] = cvt((int)(signed char)((x >> 8) & 0xFF)); d[4 * w + 2] = cvt((int)(signed char)((x >> 16) & 0xFF)); d[4 * w + 3] = cvt(x >> 24); }
+                    }
+                }
+            }
+            if (vcur.nvB) {   // (a window across two frames: one tile in eight or nine of config 5)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    const int sb = lane + 64 * i - vcur.nvA;
+                    if (sb >= 0 && sb < vcur.nvB) {
+                        const int di = vcur.dposB + EPV * sb;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const int x = pre[4 * i + w];
+                            if constexpr (sizeof(S) == 4) { if (di + w >= vcur.loB) win[di + w] = cvt(x); }
+                            else if constexpr (sizeof(S) == 2) {
+                                if (di + 2 * w >= vcur.loB) win[di + 2 * w] = cvt((int)(short)(x & 0xFFFF));
+                                if (di + 2 * w + 1 >= vcur.loB) win[di + 2 * w + 1] = cvt(x >> 16);
+                            } else {
+                                if (di + 4 * w >= vcur.loB) win[di + 4 * w] = cvt((int)(signed char)(x & 0xFF));
+                                if (di + 4 * w + 1 >= vcur.loB) win[di + 4 * w + 1] = cvt((int)(signed char)((x >> 8) & 0xFF));
+                                if (di + 4 * w + 2 >= vcur.loB) win[di + 4 * w + 2] = cvt((int)(signed char)((x >> 16) & 0xFF));
+                                if (di + 4 * w + 3 >= vcur.loB) win[di + 4 * w + 3] = cvt(x >> 24);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) win[lane + 64 * u] = cvt(pre[u]);   // (cap >= 512)
+        }
         if (held_at) {   // (wave-uniform) the tile before this one
 #pragma unroll
             for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
             held_at = nullptr;
         }
+        if (!vcur.on)
         for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output (base0 / base1 / bound still describe THIS tile: the fetch below moves them on)
             const unsigned k = kb + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
@@ -180,7 +264,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
         if (o0 + T < o_end) {
             const unsigned long long left = o_end - o0 - T;
-            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre);
+            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre, vnxt);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -279,7 +363,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         }
         };
         if (cnt == T) compute(std::true_type{}); else compute(std::false_type{});
-        kb = kb_n; r0 = r0_n;
+        kb = kb_n; r0 = r0_n; vcur = vnxt;
     }
     if (held_at) {
 #pragma unroll
@@ -409,7 +493,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     if (!fast_eligible(a->lazy_src == SRC_I16 ? SRC_PCM_S16LE_MONO : (a->lazy_src == SRC_I8 ? SRC_PCM8_MONO : SRC_I32), a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
     constexpr int T = 512;
     if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;   // exact (q, rem) inside a tile
-    const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3);
+    const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3) + 32;   // (+ 32: the slack around the window that whole vectors may spill into)
     const bool tabw = a->lazy_interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
     const size_t lds = ((size_t)cap + T + T / 8 + 8 + (tabw ? 4 * (size_t)F.b : 0)) * 4;
     if (lds > 60 * 1024) return false;
@@ -462,6 +546,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
         }
         if (getenv("AUKIT_RS_SEGS")) segs = std::max(1, atoi(getenv("AUKIT_RS_SEGS")));
         P.segs = segs; P.warm = segs > 1 ? warm : 0;
+        P.novec = getenv("AUKIT_RS_NOVEC") ? 1 : 0;
         if (hipMemsetAsync(a->d_rowmax, 0, rows * 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
