@@ -137,6 +137,11 @@ struct aukit_audio {
     // a deferred resample (flac_tail.hip): aukit_decode_resample on FLAC with F32 storage leaves the decoder's int32 rows here and the resample
     // owed; effects.highpass / lowpass pay it inside their own pass, anything else that reads the samples materialises it first (audio_flush)
     bool lazy_rs = false;
+    // round 4, late: effects.highpass / lowpass on a STEREO audio whose resample is owed is owed too (1: low-pass, 2: high-pass, coefficient kept) —
+    // if Audio:mono reads the audio next (BASELINE config 5: ... highpass -> normalize -> mono), resample + filter + channel mean run as one pass
+    // that never writes the stereo rows (k_rs_onepole<..., 2 waves>); anything else resolves what is owed in order (lazy_resolve)
+    int lazy_fx = 0;
+    double lazy_fx_coef = 0;
     aukit::DevBuf lazy_rows;                             // taken out of the context's scratch; handed back when the resample is paid
     std::vector<uint64_t> lazy_row_off, lazy_row_len;    // per (stream, channel): element offset / samples in lazy_rows
     double lazy_rate = 0, lazy_full = 1;                 // lazy_full: int32 rows, `v / full`
@@ -192,7 +197,8 @@ struct LazyFrames {   // the fused FLAC decoder's frames (flac_dev.h), for a def
 };
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
                        double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr, int src_kind = 8 /* SRC_I32 */, double norm_pos = 0, double norm_neg = 0);
-bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc);
+bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc, aukit_audio *mono_out = nullptr);
+int lazy_resolve(aukit_ctx *ctx, aukit_audio *a);   // everything owed on the rows themselves (resample, then a deferred filter), effects.hip
 // the frames one full iterator call of aukit.stream.pcm moves its table on by (K of SURVEY Q1: aukit.lua:2417-2419), api_resample.hip
 long stream_pcm_call_frames(double sample_rate, int interp);
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows

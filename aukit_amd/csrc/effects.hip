@@ -526,9 +526,30 @@ static int run_map(aukit_ctx *ctx, aukit_audio *a, const MapArgs &A, const char 
     return ctx_end_kernel(ctx, name, 2 * audio_bytes(a));
 }
 
+static int fx_onepole(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass);
+
+// everything owed on the rows themselves: a resample (flac_tail.hip), and behind it a deferred effects.highpass / lowpass (aukit_audio::lazy_fx) —
+// both in one pass where k_rs_onepole serves the shape, else the ordinary resample kernel and then the ordinary filter
+int lazy_resolve(aukit_ctx *ctx, aukit_audio *a) {
+    if (!a->lazy_rs) return AUKIT_OK;
+    if (a->lazy_fx) {
+        aukit_ctx *use = ctx ? ctx : (ctx_is_live(a->lazy_ctx) ? a->lazy_ctx : nullptr);
+        if (!use) return fail(AUKIT_E_ARG, "audio has a deferred filter and no context to run it with");
+        const int fx = a->lazy_fx;
+        const double coef = a->lazy_fx_coef;
+        int lrc = AUKIT_OK;
+        if (lazy_onepole_try(use, a, coef, fx == 2, &lrc)) return lrc;
+        a->lazy_fx = 0;
+        if ((lrc = lazy_materialize(use, a))) return lrc;
+        a->rowmax_valid = false;
+        return fx_onepole(use, a, coef, fx == 2);
+    }
+    return lazy_materialize(ctx, a);
+}
+
 int audio_flush(aukit_ctx *ctx, const aukit_audio *ca) {
     aukit_audio *a = const_cast<aukit_audio *>(ca);
-    if (a && a->lazy_rs) { int lrc = lazy_materialize(ctx, a); if (lrc) return lrc; }   // an owed resample first (flac_tail.hip)
+    if (a && a->lazy_rs) { int lrc = lazy_resolve(ctx, a); if (lrc) return lrc; }   // an owed resample (and filter) first (flac_tail.hip)
     if (!a || !a->pend_norm) return AUKIT_OK;
     if (!ctx) ctx = ctx_is_live(a->pend_ctx) ? a->pend_ctx : nullptr;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred map and no context to apply it with");
@@ -643,7 +664,24 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
     AUKIT_FLOAT_ONLY(in);
     if (*out == in) return fail(AUKIT_E_ARG, "mono cannot run in place");
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
-    if (in->lazy_rs) { int lrc = lazy_materialize(ctx, const_cast<aukit_audio *>(in)); if (lrc) return lrc; }
+    if (in->lazy_rs && in->lazy_fx && in->channels == 2 && in->dtype == AUKIT_F32 && !(in->pend_norm && in->pend_independent) && in->n && !getenv("AUKIT_NO_MONO_FUSION")) {
+        // resample -> highpass / lowpass [-> normalize] -> mono with everything before the mono still owed (BASELINE config 5's tail): one pass from the
+        // decoder's rows to the MEAN of the filtered channels — the stereo rows are never written.  A normalize in between (not `independent`: one
+        // multiplier per stream, :3439-3444) commutes with the mean up to rounding (mult * (l + r) / 2 for (mult l + mult r) / 2: the F32 tolerance
+        // path, 1e-7 of full scale) and stays owed on the RESULT, whose row maxima receive the channels' (k_rs_onepole<..., 2>, flac_tail.hip)
+        aukit_audio *o = *out;
+        int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, AUKIT_F32, in->len.data());
+        if (rc) return rc;
+        *out = o;
+        int lrc = AUKIT_OK;
+        if (lazy_onepole_try(ctx, const_cast<aukit_audio *>(in), in->lazy_fx_coef, in->lazy_fx == 2, &lrc, o)) {
+            if (lrc) return lrc;
+            o->pend_norm = false;
+            if (in->pend_norm) { o->pend_norm = true; o->pend_peak = in->pend_peak; o->pend_independent = 0; o->pend_ctx = ctx; }
+            return AUKIT_OK;
+        }
+    }
+    if (in->lazy_rs) { int lrc = lazy_resolve(ctx, const_cast<aukit_audio *>(in)); if (lrc) return lrc; }
     if (in->pend_norm && in->channels > AUKIT_MAX_CHANNELS) { int frc = audio_flush(ctx, in); if (frc) return frc; }   // (k_mono<NORM> keeps a multiplier per channel in registers: eight)
     aukit_audio *o = *out;
     int rc = audio_prepare(ctx, &o, in->n, 1, in->rate, in->dtype, in->len.data());
@@ -725,10 +763,29 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
     if (!ctx || !a) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_FLOAT_ONLY(a);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
-    if (a->lazy_rs && !a->pend_norm && nargs >= 1 && args && (id == AUKIT_FX_HIGHPASS || id == AUKIT_FX_LOWPASS)) {   // resample + filter in one pass (flac_tail.hip)
+    if (a->lazy_rs && !a->lazy_fx && !a->pend_norm && nargs >= 1 && args && (id == AUKIT_FX_HIGHPASS || id == AUKIT_FX_LOWPASS)) {   // resample + filter in one pass (flac_tail.hip)
         int lrc = AUKIT_OK;
         const double coef = id == AUKIT_FX_HIGHPASS ? 1 / (2 * M_PI * (args[0] / a->rate) + 1) : 1 - std::exp(-(args[0] / a->rate) * 2 * M_PI);   // :3607 / :3589
+        if (a->channels == 2 && a->dtype == AUKIT_F32 && a->n && !getenv("AUKIT_NO_MONO_FUSION")) {
+            // two channels: the filter is owed as well — Audio:mono may be the next reader (aukit_mono above); anyone else pays it first (lazy_resolve)
+            a->lazy_fx = id == AUKIT_FX_HIGHPASS ? 2 : 1;
+            a->lazy_fx_coef = coef;
+            ctx->last_kernel = "(filter deferred)";
+            return AUKIT_OK;
+        }
         if (lazy_onepole_try(ctx, a, coef, id == AUKIT_FX_HIGHPASS, &lrc)) return lrc;
+    }
+    if (id == AUKIT_FX_NORMALIZE && a->lazy_rs && a->lazy_fx && !a->pend_norm) {
+        // the peak search needs the FILTERED rows' maxima: the pass that pays the filter leaves them (k_rs_onepole), so the normalize is owed behind it
+        int nrc = audio_rowmax_ensure(a);
+        if (nrc) return nrc;
+        auto argn = [&](int i, double def) { return (args && i < nargs) ? args[i] : def; };
+        a->pend_norm = true;
+        a->pend_peak = argn(0, 1.0);
+        a->pend_independent = argn(1, 0.0) != 0;
+        a->pend_ctx = ctx;
+        ctx->last_kernel = "(normalize deferred)";
+        return AUKIT_OK;
     }
     AUKIT_FLUSH(ctx, a);  // every effect reads the samples
     const bool had_rowmax = a->rowmax_valid;

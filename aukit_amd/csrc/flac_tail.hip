@@ -45,6 +45,11 @@ struct RsOnepoleParams {
     // below an f32 ulp — and a row is no longer ONE serial chain of 938 tiles on a chip that can run four times as many chains as config 5 has rows
     int segs, warm;
     int novec;   // AUKIT_RS_NOVEC=1: every window element by element (the first cut; A/B)
+    // NW = 2 (round 4, late): a workgroup = the two channels of one stream, a wave each; what leaves is their MEAN (`Audio:mono` :682-687 behind
+    // the filter), `out` / `a_meta` describe the MONO audio, rowmax2[stream] receives the larger of the two channels' maxima (what a
+    // non-independent effects.normalize in between divides by, :3439-3444); wave_lds = floats of LDS per wave
+    unsigned long long *rowmax2;
+    int wave_lds;
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
@@ -64,18 +69,26 @@ AUKIT_DEV double dpp_f64(double v) {
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
-template <int INTERP, bool HP, bool TAB, typename S>
-__global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
-    extern __shared__ float rsm[];
+template <int INTERP, bool HP, bool TAB, typename S, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void k_rs_onepole(const RsOnepoleParams P) {
+    extern __shared__ float rsm_all[];
     constexpr int E = 8, T = 64 * E;
+    const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
+    float *const rsm = rsm_all + (NW > 1 ? wv * (unsigned)P.wave_lds : 0u);
     float *const win = rsm + 16;                             // P.cap floats in all: 16 of slack in front (a part's first vector may start EPV - 1 elements early), the window, 16 behind
     float *const xb = rsm + P.cap;                           // T + T / E + 8
     constexpr int EPV = 16 / (int)sizeof(S), VPL = 2;        // elements per 16-byte vector; vectors per lane and tile
-    [[maybe_unused]] float *const wt = xb + (T + T / E + 8);                 // TAB: 4 fb floats
-    if constexpr (TAB) { for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64) wt[i] = P.wg[i]; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    const int lane = threadIdx.x;
-    const unsigned r = blockIdx.x / (unsigned)P.segs, seg = blockIdx.x - r * (unsigned)P.segs, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
-    const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s];
+    [[maybe_unused]] float *const wt = NW > 1 ? rsm_all + NW * P.wave_lds : xb + (T + T / E + 8);   // TAB: 4 fb floats (one table per workgroup)
+    constexpr int MIXN = T + T / E + 8;                                      // NW > 1: a wave's tile of results, skewed like xb
+    [[maybe_unused]] float *const mix = rsm_all + NW * P.wave_lds + (TAB ? (4 * (int)P.fb + 3 & ~3) : 0);   // [parity][wave][MIXN]
+    if constexpr (TAB) {
+        for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64 * NW) wt[i] = P.wg[i];
+        if constexpr (NW > 1) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned r = NW > 1 ? (blockIdx.x / (unsigned)P.segs) * (unsigned)NW + wv : blockIdx.x / (unsigned)P.segs;
+    const unsigned seg = blockIdx.x % (unsigned)P.segs, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
+    const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
     const int L = (int)P.row_len[r];
     const S *const rows_s = reinterpret_cast<const S *>(P.rows);
     const S *row = rows_s + P.row_off[r];
@@ -196,6 +209,24 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
     float *held_at = nullptr;
 #pragma unroll
     for (int u = 0; u < E; u++) held[u] = 0.f;
+    // NW > 1: a tile's results wait in LDS (mix[parity][wave]) for the other channel's; behind the workgroup barrier at the top of the next turn
+    // every wave reads both, averages and stores ITS share of the tile's outputs (T / NW consecutive ones)
+    [[maybe_unused]] int mix_cnt = 0, mix_par = 0, mix_par_next = 0;
+    [[maybe_unused]] unsigned long long mix_o0 = 0;
+    [[maybe_unused]] auto mix_out = [&]() {
+        __syncthreads();
+        const float *const mp0 = mix + (size_t)(mix_par * NW) * MIXN;
+        constexpr int SH = T / NW;   // outputs per wave
+#pragma unroll
+        for (int u = 0; u < SH / 64; u++) {
+            const int idx = (int)wv * SH + lane + 64 * u;
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) acc = acc + mp0[w * MIXN + skew(idx)];       // s = 0 + c1 + c2  :685
+            if (idx < mix_cnt) orow[mix_o0 + (unsigned)idx] = acc / (float)NW;       // s / cn  :686
+        }
+        mix_cnt = 0;
+    };
     for (unsigned long long o0 = t_in * T; o0 < o_end; o0 += T) {
         const bool emit = o0 >= o_lo;   // (a warm-up tile: state only)
         const int cnt = (int)((o_end - o0) < (unsigned long long)T ? (o_end - o0) : (unsigned long long)T);
@@ -252,6 +283,7 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
             for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
             held_at = nullptr;
         }
+        if constexpr (NW > 1) { if (mix_cnt) mix_out(); }   // (the same turn of both waves: the condition is the stream's, not the channel's)
         if (!vcur.on)
         for (int j = lane + 512; j < nst; j += 64) {   // ratios above one source sample per output (base0 / base1 / bound still describe THIS tile: the fetch below moves them on)
             const unsigned k = kb + (unsigned)j;
@@ -339,6 +371,13 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
         else carry_y = __shfl(ylast, (cnt - 1) / E);
         carry_x = (double)xb[skew(cnt - 1)];
+        if constexpr (NW > 1) {
+            if (emit) {
+                float *const mw = mix + (size_t)(mix_par_next * NW + (int)wv) * MIXN;
+#pragma unroll
+                for (int i = 0; i < E; i++) mw[skew(e0 + i)] = res[i];
+            }
+        } else
         if (!emit) {}
         else if constexpr (FULL) {
             // a full tile leaves through LDS once more: a lane's eight consecutive results as they stand are two 16-byte stores at a stride of 32 bytes —
@@ -363,20 +402,24 @@ __global__ __launch_bounds__(64) void k_rs_onepole(const RsOnepoleParams P) {
         }
         };
         if (cnt == T) compute(std::true_type{}); else compute(std::false_type{});
+        if constexpr (NW > 1) { if (emit) { mix_cnt = cnt; mix_o0 = o0; mix_par = mix_par_next; mix_par_next ^= 1; } }
         kb = kb_n; r0 = r0_n; vcur = vnxt;
     }
     if (held_at) {
 #pragma unroll
         for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
     }
+    if constexpr (NW > 1) { if (mix_cnt) mix_out(); }
     for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
-    if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
+    if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));
+    if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
 }
 
 // ---------------------------------------------------------------- the lazy state
 // gives the rows' buffer back to the context (when its own scratch is empty or smaller) or frees it; clears the state
 void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
     a->lazy_rs = false;
+    a->lazy_fx = 0;
     if (a->lazy_rows.p) {
         DevBuf *home = ctx ? (a->lazy_indirect ? &ctx->tmp_buf3 : &ctx->tmp_buf) : nullptr;   // where the buffer came from
         if (home && home->cap < a->lazy_rows.cap) { home->release(); *home = a->lazy_rows; a->lazy_rows = DevBuf{}; }
@@ -485,9 +528,12 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
 }
 
 // effects.highpass / lowpass on an audio whose resample is owed: both in one pass.  false: not taken (the caller materialises and filters)
-bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc) {
+// mono_out (round 4, late): the two channels' mean goes to that (prepared, F32, one channel) audio instead of `a`'s own rows, `a` stays as it is —
+// rows still owed — and mono_out's row maxima receive the larger channel maximum of every stream (k_rs_onepole<..., 2>)
+bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass, int *rc, aukit_audio *mono_out) {
     *rc = AUKIT_OK;
     if (!a->lazy_rs || a->dtype != AUKIT_F32) return false;
+    if (mono_out && (a->channels != 2 || mono_out->dtype != AUKIT_F32 || mono_out->channels != 1 || mono_out->n != a->n)) return false;
     if ((*rc = owner_ready(ctx, a->lazy_ctx))) return true;
     FastParams F;
     if (!fast_eligible(a->lazy_src == SRC_I16 ? SRC_PCM_S16LE_MONO : (a->lazy_src == SRC_I8 ? SRC_PCM8_MONO : SRC_I32), a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
@@ -495,10 +541,13 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;   // exact (q, rem) inside a tile
     const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3) + 32;   // (+ 32: the slack around the window that whole vectors may spill into)
     const bool tabw = a->lazy_interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
-    const size_t lds = ((size_t)cap + T + T / 8 + 8 + (tabw ? 4 * (size_t)F.b : 0)) * 4;
+    const int NWh = mono_out ? 2 : 1;
+    const size_t wave_lds = (size_t)cap + T + T / 8 + 8;
+    const size_t lds = ((size_t)NWh * wave_lds + (tabw ? ((4 * (size_t)F.b + 3) & ~(size_t)3) : 0) + (mono_out ? 2 * (size_t)NWh * (T + T / 8 + 8) : 0)) * 4;
     if (lds > 60 * 1024) return false;
     for (uint64_t l : a->lazy_row_len) if (l > 0x7FFFFFF0ull) return false;
     if ((*rc = audio_rowmax_ensure(a))) return true;
+    if (mono_out && (*rc = audio_rowmax_ensure(mono_out))) return true;
     if (hipSetDevice(ctx->device) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipSetDevice failed"); return true; }
     const size_t rows = (size_t)a->n * a->channels;
     std::vector<uint64_t> tab(a->lazy_row_off);
@@ -508,9 +557,11 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     P.rows = a->lazy_rows.p;
     P.row_off = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
     P.row_len = P.row_off + rows;
-    P.a_meta = reinterpret_cast<const unsigned long long *>(a->d_meta);
-    P.out = reinterpret_cast<float *>(a->dev);
+    P.a_meta = reinterpret_cast<const unsigned long long *>(mono_out ? mono_out->d_meta : a->d_meta);
+    P.out = reinterpret_cast<float *>(mono_out ? mono_out->dev : a->dev);
     P.rowmax = reinterpret_cast<unsigned long long *>(a->d_rowmax);
+    P.rowmax2 = mono_out ? reinterpret_cast<unsigned long long *>(mono_out->d_rowmax) : nullptr;
+    P.wave_lds = (int)wave_lds;
     P.n = a->n; P.C = a->channels; P.cap = cap;
     P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
@@ -548,25 +599,38 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
         P.segs = segs; P.warm = segs > 1 ? warm : 0;
         P.novec = getenv("AUKIT_RS_NOVEC") ? 1 : 0;
         if (hipMemsetAsync(a->d_rowmax, 0, rows * 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
+        if (mono_out && hipMemsetAsync(mono_out->d_rowmax, 0, (size_t)a->n * 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t ldsb = lds;
-    const dim3 grid((unsigned)(rows * (size_t)P.segs));
+ const dim3 grid((unsigned)((rows / (size_t)NWh) * (size_t)P.segs));
+#define AUKIT_RSO1(I, H, Tb, S)                                                                                                                            \
+    do {                                                                                                                                                     \
+        if (mono_out) hipLaunchKernelGGL((k_rs_onepole<I, H, Tb, S, 2>), grid, dim3(128), ldsb, ctx->stream, P);                                          \
+        else hipLaunchKernelGGL((k_rs_onepole<I, H, Tb, S, 1>), grid, dim3(64), ldsb, ctx->stream, P);                                                     \
+    } while (0)
 #define AUKIT_RSO(S)                                                                                                                                         \
     do {                                                                                                                                                     \
-        if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, true, false, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_LINEAR, false, false, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
-        else if (tabw) { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, true, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, true, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
-        else { if (highpass) hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, true, false, S>), grid, dim3(64), ldsb, ctx->stream, P); else hipLaunchKernelGGL((k_rs_onepole<AUKIT_INTERP_CUBIC, false, false, S>), grid, dim3(64), ldsb, ctx->stream, P); } \
+        if (a->lazy_interp == AUKIT_INTERP_LINEAR) { if (highpass) AUKIT_RSO1(AUKIT_INTERP_LINEAR, true, false, S); else AUKIT_RSO1(AUKIT_INTERP_LINEAR, false, false, S); } \
+        else if (tabw) { if (highpass) AUKIT_RSO1(AUKIT_INTERP_CUBIC, true, true, S); else AUKIT_RSO1(AUKIT_INTERP_CUBIC, false, true, S); }              \
+        else { if (highpass) AUKIT_RSO1(AUKIT_INTERP_CUBIC, true, false, S); else AUKIT_RSO1(AUKIT_INTERP_CUBIC, false, false, S); }                      \
     } while (0)
     if (a->lazy_src == SRC_I16) AUKIT_RSO(short); else if (a->lazy_src == SRC_I8) AUKIT_RSO(signed char); else AUKIT_RSO(int);
+#undef AUKIT_RSO1
 #undef AUKIT_RSO
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
     uint64_t in_elems = 0, out_elems = 0;
     for (uint64_t l : a->lazy_row_len) in_elems += l;
     for (uint64_t l : a->len) out_elems += l * (uint64_t)a->channels;
-    a->rowmax_valid = true;
-    lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
     const uint64_t in_bytes = in_elems * (a->lazy_src == SRC_I16 ? 2 : (a->lazy_src == SRC_I8 ? 1 : 4));
+    if (mono_out) {   // `a` keeps everything it owes (its own rows were not written); the mean's maxima are not known (rowmax2 holds the channels')
+        mono_out->rowmax_valid = false;
+        *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass,mono>" : "k_rs_onepole<lowpass,mono>", in_bytes + out_elems * 4 / (uint64_t)a->channels);
+        return true;
+    }
+    a->rowmax_valid = true;
+    a->lazy_fx = 0;
+    lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
     *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_bytes + out_elems * 4);
     return true;
 }

@@ -382,6 +382,7 @@ class ImaPipeline(Workload):
         def step():
             B.decode_resample(ctx, self.bt, self.d, DST_RATE, "cubic", dtype=self.dtype, out=self.out)
             B.effect(ctx, self.out, "lowpass", 11025.0)
+            self.out.device_ptr()   # (nothing may stay owed on the rows when the step ends: a no-op for one channel, the filter is paid by the call above)
         self.step = step
         self.arith = "i32 decode + " + ("f32 interpolation, f64 recurrence" if args.dtype == "f32" else "f64 reference-order resample and filter")
         self.desc = (f"{args.streams}x IMA-ADPCM 22.05kHz mono 220x512B in WAV blocks ({self.distinct} distinct encoder-made streams, cycled) -> aukit.wav:resample(48000,'cubic') "
@@ -554,6 +555,7 @@ class FlacPipeline(Workload):
             B.effect(ctx, self.a, "highpass", 20.0)
             B.effect(ctx, self.a, "normalize", 0.8)
             B.mono(ctx, self.a, out=self.m)
+            self.m.device_ptr()   # the step ends with the mono rows FINAL in HBM: whatever the calls above left owed on them (a deferred normalize) is paid here
         self.step = step
         self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each, copies of one encoder-made stream) -> aukit.flac:resample(48000,'cubic') "
                      f"-> highpass(20) -> normalize(0.8) -> mono, {args.dtype} store (config 5); unit = mono out-samples")

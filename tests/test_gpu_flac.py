@@ -187,7 +187,10 @@ def test_deferred_resample_fused_into_the_filter_pass(ctx, oracle, monkeypatch, 
         B.effect(ctx, a, which, 300.0 if which == "lowpass" else 20.0)
         name1 = ctx.last_kernel()[0]
         B.effect(ctx, a, "normalize", 0.8)
-        return (a.download(), B.mono(ctx, a).download()), (name0, name1)
+        m_first = B.mono(ctx, a)   # two channels: resample + filter + mean in one pass, the normalize owed on the result; `a` keeps what it owes
+        name2 = ctx.last_kernel()[0]
+        m_first = m_first.download()
+        return (a.download(), B.mono(ctx, a).download(), m_first), (name0, name1, name2)
 
     for which in ("download", "mono", "amplify"):
         got, name = chain(which)
@@ -200,10 +203,17 @@ def test_deferred_resample_fused_into_the_filter_pass(ctx, oracle, monkeypatch, 
             for c in range(len(got[s])):
                 assert np.array_equal(got[s][c], plain[s][c]), (which, s, c)
     for which in ("highpass", "lowpass"):
-        (rows, mono), (n0, n1) = chain(which)
-        assert n0 == "(resample deferred)" and n1 == "k_rs_onepole<" + which + ">", (n0, n1)
+        (rows, mono, mono1), (n0, n1, n2) = chain(which)
+        if ch == 2:   # round 4, late: the filter of a stereo audio is owed too, Audio:mono pays resample + filter + mean at once
+            assert n0 == "(resample deferred)" and n1 == "(filter deferred)" and n2 == "k_rs_onepole<" + which + ",mono>", (n0, n1, n2)
+        else:
+            assert n0 == "(resample deferred)" and n1 == "k_rs_onepole<" + which + ">" and n2.startswith("k_mono"), (n0, n1, n2)
+        monkeypatch.setenv("AUKIT_NO_MONO_FUSION", "1")
+        (rows_q, mono_q, mono1_q), (q0, q1, q2) = chain(which)
+        monkeypatch.delenv("AUKIT_NO_MONO_FUSION")
+        assert q1 == "k_rs_onepole<" + which + ">" and q2.startswith("k_mono"), (q1, q2)
         monkeypatch.setenv("AUKIT_NO_TAIL_FUSION", "1")
-        (rows_p, mono_p), (p0, p1) = chain(which)
+        (rows_p, mono_p, mono1_p), (p0, p1, p2) = chain(which)
         monkeypatch.delenv("AUKIT_NO_TAIL_FUSION")
         assert p1.startswith("k_onepole<"), p1
         for s_i, s in enumerate(streams):
@@ -216,6 +226,11 @@ def test_deferred_resample_fused_into_the_filter_pass(ctx, oracle, monkeypatch, 
                 assert rms(rows[s_i][c], ref.data[c]) <= 1e-6, (which, s_i, c)
             assert np.max(np.abs(mono[s_i][0] - mono_p[s_i][0]), initial=0) <= 4e-7
             assert rms(mono[s_i][0], oracle.mono(ref).data[0]) <= 1e-6
+            for c in range(ch):
+                assert np.array_equal(rows[s_i][c], rows_q[s_i][c]), (which, s_i, c)   # (paid by the same kernel whether the filter was owed or run at once)
+            assert len(mono1[s_i][0]) == len(mono_p[s_i][0])
+            assert np.max(np.abs(mono1[s_i][0] - mono_p[s_i][0]), initial=0) <= 6e-7, (which, s_i)
+            assert rms(mono1[s_i][0], oracle.mono(ref).data[0]) <= 1e-6
     # the output audio reused for the next decode gives the rows' buffer back (no growth), and a deferred audio can be cloned / freed
     a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
     a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32, out=a)
