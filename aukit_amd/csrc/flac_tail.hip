@@ -70,7 +70,7 @@ AUKIT_DEV double dpp_f64(double v) {
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 template <int INTERP, bool HP, bool TAB, typename S, int NW = 1>
-__global__ __launch_bounds__(64 * NW) void k_rs_onepole(const RsOnepoleParams P) {
+__global__ __launch_bounds__(64 * NW, NW > 1 ? 4 : 1) void k_rs_onepole(const RsOnepoleParams P) {   // (NW = 2: four waves per SIMD asked for — 128 VGPRs instead of the 133 hipcc takes otherwise; the launch is sized for that residency)
     extern __shared__ float rsm_all[];
     constexpr int E = 8, T = 64 * E;
     const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) void k_rs_onepole(const RsOnepoleParams P)
     constexpr int EPV = 16 / (int)sizeof(S), VPL = 2;        // elements per 16-byte vector; vectors per lane and tile
     [[maybe_unused]] float *const wt = NW > 1 ? rsm_all + NW * P.wave_lds : xb + (T + T / E + 8);   // TAB: 4 fb floats (one table per workgroup)
     constexpr int MIXN = T + T / E + 8;                                      // NW > 1: a wave's tile of results, skewed like xb
-    [[maybe_unused]] float *const mix = rsm_all + NW * P.wave_lds + (TAB ? (4 * (int)P.fb + 3 & ~3) : 0);   // [parity][wave][MIXN]
+    [[maybe_unused]] float *const mix = rsm_all + NW * P.wave_lds + (TAB ? (4 * (int)P.fb + 3 & ~3) : 0);   // [wave][MIXN]
     if constexpr (TAB) {
         for (unsigned i = threadIdx.x; i < 4 * P.fb; i += 64 * NW) wt[i] = P.wg[i];
         if constexpr (NW > 1) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(64 * NW) void k_rs_onepole(const RsOnepoleParams P)
     [[maybe_unused]] int mix_cnt = 0, mix_par = 0, mix_par_next = 0;
     [[maybe_unused]] unsigned long long mix_o0 = 0;
     [[maybe_unused]] auto mix_out = [&]() {
-        __syncthreads();
-        const float *const mp0 = mix + (size_t)(mix_par * NW) * MIXN;
+        __syncthreads();   // (both channels' results of the tile before are in `mix`)
+        const float *const mp0 = mix;
         constexpr int SH = T / NW;   // outputs per wave
 #pragma unroll
         for (int u = 0; u < SH / 64; u++) {
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(64 * NW) void k_rs_onepole(const RsOnepoleParams P)
         carry_x = (double)xb[skew(cnt - 1)];
         if constexpr (NW > 1) {
             if (emit) {
-                float *const mw = mix + (size_t)(mix_par_next * NW + (int)wv) * MIXN;
+                __syncthreads();   // (every wave has read the tile before out of `mix`: one buffer, two barriers a tile, and the workgroup's LDS lets every wave of config 5 be resident at once — with two buffers 14 of the 16 waves per CU were)
+                float *const mw = mix + (size_t)wv * MIXN;
 #pragma unroll
                 for (int i = 0; i < E; i++) mw[skew(e0 + i)] = res[i];
             }
@@ -543,7 +544,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     const bool tabw = a->lazy_interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
     const int NWh = mono_out ? 2 : 1;
     const size_t wave_lds = (size_t)cap + T + T / 8 + 8;
-    const size_t lds = ((size_t)NWh * wave_lds + (tabw ? ((4 * (size_t)F.b + 3) & ~(size_t)3) : 0) + (mono_out ? 2 * (size_t)NWh * (T + T / 8 + 8) : 0)) * 4;
+    const size_t lds = ((size_t)NWh * wave_lds + (tabw ? ((4 * (size_t)F.b + 3) & ~(size_t)3) : 0) + (mono_out ? (size_t)NWh * (T + T / 8 + 8) : 0)) * 4;
     if (lds > 60 * 1024) return false;
     for (uint64_t l : a->lazy_row_len) if (l > 0x7FFFFFF0ull) return false;
     if ((*rc = audio_rowmax_ensure(a))) return true;
