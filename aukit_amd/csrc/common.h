@@ -153,6 +153,7 @@ struct aukit_audio {
     // frame records in stream order, each stream's first record, each stream's block size and the (stream, channel) offsets of the contiguous
     // rows they would make; k_rs_onepole follows the records, every other consumer gathers the rows first (lazy_materialize)
     bool lazy_indirect = false;
+    bool lazy_scratch16 = false;                         // ... as int16 (LazyFrames::scratch16)
     aukit::DevBuf lazy_tab;
     uint64_t lazy_nfr = 0, lazy_tot = 0;
     size_t lazy_o_fbase = 0, lazy_o_bs0 = 0, lazy_o_rowoff = 0;
@@ -194,6 +195,7 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a);
 struct LazyFrames {   // the fused FLAC decoder's frames (flac_dev.h), for a deferred resample that reads them in place
     const void *d_frames; uint64_t nfr; const unsigned long long *d_fbase, *d_rowoff; const std::vector<int> *bs0; bool uniform; uint64_t tot_elems;
     const std::vector<unsigned> *nframes;
+    bool scratch16 = false;   // the frames hold int16 finals (k_flac_decode<..., O16>): [channel 0][channel 1] from twice the record's offset
 };
 bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, const std::vector<uint64_t> &row_len, uint32_t n, int C, double rate, double new_rate, int interp,
                        double full, aukit_audio **out, int *rc, const LazyFrames *frames = nullptr, int src_kind = 8 /* SRC_I32 */, double norm_pos = 0, double norm_neg = 0);

@@ -1290,6 +1290,8 @@ struct FlacDecoded {
     // the consumers that can follow the frame records read them there (the loader's conversion, the deferred resample + one-pole pass,
     // stream.flac's tail jobs); flac_rows_materialize() gathers contiguous rows into ctx->tmp_buf for the others
     bool in_scratch = false;
+    bool scratch16 = false;   // ... as int16 (FusedArgs::out16: asked for by the loader's F32 resample path, depths <= 16)
+    bool want16 = false;
     uint64_t tot_elems = 0;          // elements of the contiguous rows (row_off / row_len describe them whether they exist yet or not)
     std::vector<int> bs0;            // per stream: the first frame's block size
     bool uniform = false;            // every stream: all frames but the last have bs0, the last no more
@@ -1515,6 +1517,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
     const uint32_t n = in->n;
     const int C = D.channels;
     int rc;
+    const bool o16 = D.want16 && D.depth <= 16 && !getenv("AUKIT_FLAC_NO_I16");   // finals as int16 (flac_fused.hip, O16)
     const FlacStreamInfo *d_info = reinterpret_cast<const FlacStreamInfo *>(ctx->misc_buf.p);
     const uintptr_t dptr = reinterpret_cast<uintptr_t>(in->data());
     FlacGlobals G;
@@ -1560,6 +1563,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.C = C; A.depth = D.depth;
             A.scratch = reinterpret_cast<int *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
             A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket;
+            A.out16 = o16 ? 1 : 0;
             A.dbg = getenv("AUKIT_FLAC_FUSED_DBG") ? atoi(getenv("AUKIT_FLAC_FUSED_DBG")) : 0;
             return flac_fused_launch(ctx, A);
         };
@@ -1608,6 +1612,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         }
         if (restart) continue;
         for (uint32_t s = 0; s < n; s++) if (chain[s].status == FE_DECLINE) return 2;
+        if (o16 && (hc.flags & 0x100u)) return 3;   // a final value beyond int16 (not an ordinary stream): once more with int32 finals
 
         D.status.assign(n, 0);
         D.row_off.assign((size_t)n * C, 0);
@@ -1628,6 +1633,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8))) return rc;
         if (nfr && (rc = flac_frames_launch(ctx, d_cand, d_ci, ncand, d_fbase, d_frames))) return rc;
         D.in_scratch = true;
+        D.scratch16 = o16;
         D.tot_elems = tot;
         D.bs0.assign(n, 0);
         D.uniform = true;
@@ -1659,10 +1665,11 @@ static int flac_rows_materialize(aukit_ctx *ctx, FlacDecoded &D) {
     if ((rc = ctx->tmp_buf.ensure((size_t)D.tot_elems * 4 + 256))) return rc;
     if (D.nfr) {
         if ((rc = ctx_begin_kernel(ctx))) return rc;
-        if ((rc = flac_gather_launch(ctx, D.d_frames, D.nfr, D.channels, D.d_rowoff, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<int *>(ctx->tmp_buf.p)))) return rc;
+        if ((rc = flac_gather_launch(ctx, D.d_frames, D.nfr, D.channels, D.d_rowoff, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<int *>(ctx->tmp_buf.p), D.scratch16))) return rc;
         if ((rc = ctx_end_kernel(ctx, "k_flac_gather", 2 * D.tot_elems * 4))) return rc;
     }
     D.in_scratch = false;
+    D.scratch16 = false;
     return AUKIT_OK;
 }
 
@@ -1694,6 +1701,7 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     const bool no_fused = getenv("AUKIT_FLAC_NO_FUSED") != nullptr;   // A/B and the tests: the first design for every batch
     if (D.depth <= 24 && !g_flac_force_wide() && !no_fused && !getenv("AUKIT_FLAC_SLOW_RESTORE")) {
         rc = flac_run_fused(ctx, in, D, want_frames);
+        if (rc == 3) { D.want16 = false; rc = flac_run_fused(ctx, in, D, want_frames); }
         ctx->counters[AUKIT_COUNTER_FLAC_FUSED] = rc == AUKIT_OK ? 1 : 0;
         if (rc != 2) return rc;
         if (getenv("AUKIT_FLAC_DEBUG")) fprintf(stderr, "[flac] the fused decoder declined a frame of the chain: two-kernel decoder\n");
@@ -1710,6 +1718,7 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                       aukit_audio **out) {
     FlacDecoded D;
     if (*out && ((*out)->lazy_rs || (*out)->lazy_rows.p)) lazy_drop(ctx, *out);   // the output's old rows (a deferred resample nobody asked for) return to the scratch the decoder is about to use
+    D.want16 = do_resample && dtype == AUKIT_F32;   // the F32 resample path reads the frames in place (k_rs_onepole<..., short>) or gathers them: int16 finals halve both
     int rc = flac_decode_rows(ctx, in, D, false);
     if (rc) return rc;
     for (uint32_t s = 0; s < in->n; s++)
@@ -1732,7 +1741,7 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     }
     if (!D.wide && do_resample && dtype == AUKIT_F32) {   // F32 pipelines: the resample is owed — a following effects.highpass / lowpass pays it in its own pass (flac_tail.hip)
         int lrc = AUKIT_OK;
-        LazyFrames LF{D.d_frames, D.nfr, D.d_fbase, D.d_rowoff, &D.bs0, D.uniform, D.tot_elems, &D.nframes};
+        LazyFrames LF{D.d_frames, D.nfr, D.d_fbase, D.d_rowoff, &D.bs0, D.uniform, D.tot_elems, &D.nframes, D.scratch16};
         if (lazy_resample_try(ctx, D.row_off, D.row_len, in->n, D.channels, D.rate, new_rate, interp, full, out, &lrc, D.in_scratch ? &LF : nullptr)) return lrc;
         if (D.in_scratch) {   // frames too short (or of mixed sizes) to be followed in place: contiguous rows, and the resample is owed on those
             if ((rc = flac_rows_materialize(ctx, D))) return rc;

@@ -88,13 +88,14 @@ struct FusedArgs {
     unsigned *flags;
     int limit_factor;
     unsigned *ticket;
+    int out16;               // finals as int16 (k_flac_decode<..., O16>; depths <= 16)
     int dbg;                 // ablation switches (AUKIT_FLAC_FUSED_DBG; wrong results): 1 no prediction, 2 no stores, 4 no read-back of parked values
 };
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A);
 // the chained frames' records in stream order (one lane per candidate)
 int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames);
 // chained frames: scratch → contiguous int32 rows (one workgroup per frame record)
-int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows);
+int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows, bool scratch16 = false);   // scratch16: the frames hold int16 finals (FusedArgs::out16)
 // the same with the loader's conversion `s / 2^depth` (:505) into the rows of an audio (dtype AUKIT_F32 / AUKIT_F64; a_meta = len[n], row_off[n], row_stride[n])
 int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full);
 

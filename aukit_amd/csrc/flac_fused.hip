@@ -84,6 +84,14 @@ __device__ __forceinline__ void st16(int *dst, unsigned x, unsigned y, unsigned 
     __builtin_nontemporal_store(v4u{x, y, z, w}, reinterpret_cast<v4u *>(dst));
 #endif
 }
+// O16: two int16 finals per dword (the values were range-checked by the caller)
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st8(short *dst, int a, int b, int c, int d) {
+    __builtin_nontemporal_store(v2u{((unsigned)a & 0xFFFFu) | ((unsigned)b << 16), ((unsigned)c & 0xFFFFu) | ((unsigned)d << 16)}, reinterpret_cast<v2u *>(dst));
+}
+__device__ __forceinline__ unsigned out16(int a, int b, int c, int d) {   // nonzero: a value that does not fit int16
+    return (((unsigned)(a + 32768) | (unsigned)(b + 32768) | (unsigned)(c + 32768) | (unsigned)(d + 32768)) >> 16);
+}
 __device__ __forceinline__ void masked_load16(v4u &dst, const void *addr, bool on) {
     unsigned long long save;
     asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\t"
@@ -185,14 +193,19 @@ AUKIT_DEV void flac_predict(int *row, int cnt, int jpos0, int order, int lshift,
 // active, a third parked at s_waitcnt) — a latency-bound instruction stream with too few waves to cover it.  <16, false> fits three (13.3 KB, no
 // prefetch registers, __launch_bounds__ tells hipcc so): more per-round overhead per value, and the loads it no longer prefetches are covered by the
 // third wave instead.
-template <int FNC, bool PF>
+// O16 (round 4, late; depths <= 16, the loader's resample path): the FINAL values leave as int16 — a frame's region of nsub * bs int32 slots holds
+// [channel 0: bs int16][channel 1: bs int16] in its first half and, for decorrelated stereo frames, the parked first subframe (17 bits: int32) in
+// its second half.  7.2 + 7.1 GB of config 5's int32 rows become 3.6 + 3.6.  A final that does not fit int16 (garbage input: the reference
+// carries whatever the arithmetic gives) raises a flag and the batch is decoded again without O16.
+template <int FNC, bool PF, bool O16>
 __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs A) {
     constexpr int FOS = FNC + 1;        // row stride of the value array
     constexpr int LPR = FNC / 4;        // lanes that store one row (16 bytes each)
     constexpr int RPI = 64 / LPR;       // rows per store instruction
     __shared__ unsigned s_win[64 * FWS];
     __shared__ int s_val[64 * FOS];
-    __shared__ u64 s_ptr[64];
+    __shared__ u64 s_ptr[64];                              // where the round's finals go (O16: in int16 units)
+    __shared__ u64 s_ptr2[O16 ? 64 : 1];                   // O16: where the parked first subframe lies (int32 units)
     __shared__ unsigned s_meta[64];   // values of the round | mode << 6 | channel assignment << 8 | block size << 12   (mode 0: wrap and store, 1: park the first subframe, 2: decorrelate)
     const int lane = threadIdx.x;
     const int C = A.C, depth = A.depth;
@@ -259,6 +272,7 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < (PF ? LPR : 1); i++) tpre[i] = make_uint4(0, 0, 0, 0);
     auto flush = [&]() {
+        [[maybe_unused]] unsigned bad16 = 0;
         if (flush_fast) {
             // every requested value is awaited HERE, once, before the first store: hipcc cannot count loads across the branches below and would
             // wait vmcnt(0) at each use — behind the stores of the iteration before it, i.e. for those stores (2.5 of the first version's 10 ms)
@@ -275,6 +289,23 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                 if (q4 < cn) {
                     const int *v = s_val + s * FOS + q4;
                     const int a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                    if constexpr (O16) {
+                        short *dst = reinterpret_cast<short *>(A.scratch) + s_ptr[s] + q4;
+                        int *park = A.scratch + s_ptr2[s] + q4;
+                        if (mode == 0) { const int w0 = wrap(a0), w1 = wrap(a1), w2 = wrap(a2), w3 = wrap(a3); bad16 |= out16(w0, w1, w2, w3); st8(dst, w0, w1, w2, w3); }
+                        else if (mode == 1) st16(park, (unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
+                        else {
+                            int l0, l1, l2, l3, r0, r1, r2, r3;
+                            uint4 tp;
+                            if constexpr (PF) tp = tpre[i]; else tp = *reinterpret_cast<const uint4 *>(park);
+                            flac_decor(asg, (int)tp.x, a0, l0, r0); flac_decor(asg, (int)tp.y, a1, l1, r1);
+                            flac_decor(asg, (int)tp.z, a2, l2, r2); flac_decor(asg, (int)tp.w, a3, l3, r3);
+                            l0 = wrap(l0); l1 = wrap(l1); l2 = wrap(l2); l3 = wrap(l3); r0 = wrap(r0); r1 = wrap(r1); r2 = wrap(r2); r3 = wrap(r3);
+                            bad16 |= out16(l0, l1, l2, l3) | out16(r0, r1, r2, r3);
+                            st8(dst, l0, l1, l2, l3);
+                            st8(dst + rbs, r0, r1, r2, r3);
+                        }
+                    } else {
                     int *dst = A.scratch + s_ptr[s] + q4;
                     if (mode == 0) st16(dst, (unsigned)wrap(a0), (unsigned)wrap(a1), (unsigned)wrap(a2), (unsigned)wrap(a3));
                     else if (mode == 1) st16(dst, (unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3);
@@ -287,8 +318,10 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                         st16(dst, (unsigned)wrap(l0), (unsigned)wrap(l1), (unsigned)wrap(l2), (unsigned)wrap(l3));
                         st16(dst + rbs, (unsigned)wrap(r0), (unsigned)wrap(r1), (unsigned)wrap(r2), (unsigned)wrap(r3));
                     }
+                    }
                 }
             }
+            if constexpr (O16) { if (__any(bad16 != 0u) && lane == 0) atomicOr(A.flags, 0x100u); }
             return;
         }
         const int part = lane / FNC, k = lane % FNC;   // any alignment, any count: 64 / FNC rows per instruction
@@ -298,12 +331,21 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
             const int cn = (int)(m & 0x3Fu), mode = (int)((m >> 6) & 3u), asg = (int)((m >> 8) & 15u), rbs = (int)(m >> 12);
             if (k < cn) {
                 const int a = s_val[s * FOS + k];
+                if constexpr (O16) {
+                    short *dst = reinterpret_cast<short *>(A.scratch) + s_ptr[s] + k;
+                    int *park = A.scratch + s_ptr2[s] + k;
+                    if (mode == 0) { const int w = wrap(a); bad16 |= out16(w, 0, 0, 0); *dst = (short)w; }
+                    else if (mode == 1) *park = a;
+                    else { int l, r; flac_decor(asg, *park, a, l, r); l = wrap(l); r = wrap(r); bad16 |= out16(l, r, 0, 0); dst[0] = (short)l; dst[rbs] = (short)r; }
+                } else {
                 int *dst = A.scratch + s_ptr[s] + k;
                 if (mode == 0) *dst = wrap(a);
                 else if (mode == 1) *dst = a;
                 else { int l, r; flac_decor(asg, dst[rbs], a, l, r); dst[0] = wrap(l); dst[rbs] = wrap(r); }
+                }
             }
         }
+        if constexpr (O16) { if (__any(bad16 != 0u) && lane == 0) atomicOr(A.flags, 0x100u); }
     };
     v4u pf[PF ? FLPW : 1];        // per window this lane loads for: the line that will replace its slot's line, already requested
     u64 pf_line[PF ? FLPW : 1];
@@ -615,13 +657,16 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
         const bool decor = C == 2 && chan_asgn >= 8 && chan_asgn <= 10;
         const int mode = !decor ? 0 : (ch == 0 ? 1 : 2);
         const int jpos0 = jpos - cnt;   // the subframe index of the row's first value (a round never mixes subframes)
-        const u64 gptr = cand_scratch + (u64)jpos0 + (mode == 0 ? (u64)ch * (u64)bs : (mode == 1 ? (u64)bs : 0ull));
+        // (O16: finals in int16 units from twice the region's int32 offset; the parking area is the region's second half, in int32 units)
+        const u64 gptr = O16 ? 2 * cand_scratch + (u64)jpos0 + (mode == 0 ? (u64)ch * (u64)bs : 0ull)
+                             : cand_scratch + (u64)jpos0 + (mode == 0 ? (u64)ch * (u64)bs : (mode == 1 ? (u64)bs : 0ull));
+        if constexpr (O16) s_ptr2[lane] = cand_scratch + (u64)bs + (u64)jpos0;
         const bool live = have && cnt > 0 && status == FE_OK;
         const bool stores = live && store_ok;
         s_meta[lane] = stores ? ((unsigned)cnt | ((unsigned)mode << 6) | ((unsigned)chan_asgn << 8) | ((unsigned)bs << 12)) : 0u;
         s_ptr[lane] = gptr;
         // the 16-byte path needs whole vectors at aligned places (block sizes are multiples of 4 but for a stream's last frame)
-        flush_fast = __all(!stores || ((cnt & 3) == 0 && (gptr & 3) == 0 && (mode != 2 || (bs & 3) == 0)));
+        flush_fast = __all(!stores || ((cnt & 3) == 0 && (gptr & 3) == 0 && ((mode != 2 && !(O16 && mode == 1)) || (bs & 3) == 0)));
         __syncthreads();
         {   // the parked first-subframe values of the rounds that decorrelate: requested now, used by the flush at the top of the next round.
             // Straight-line and unconditional (a lane with nothing to fetch reads the scratch's first vector): inside an `if` hipcc merges the loaded
@@ -634,7 +679,8 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                 const int s = RPI * i + grp;
                 const unsigned m = s_meta[s];
                 const bool need = ff && ((m >> 6) & 3u) == 2u && q4 < (int)(m & 0x3Fu);
-                tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr[s] + (u64)(m >> 12) + (u64)q4 : 0ull));
+                if constexpr (O16) tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr2[s] + (u64)q4 : 0ull));
+                else tpre[i] = *reinterpret_cast<const uint4 *>(A.scratch + (need ? s_ptr[s] + (u64)(m >> 12) + (u64)q4 : 0ull));
             }
             }
         }
@@ -667,8 +713,9 @@ int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
     static const int variant = getenv("AUKIT_FLAC_FUSED_VARIANT") ? atoi(getenv("AUKIT_FLAC_FUSED_VARIANT")) : 0;   // 0: <32, prefetch> two waves per SIMD; 1: <16, none> three
     static const int wgs = getenv("AUKIT_FLAC_FUSED_WGS") ? atoi(getenv("AUKIT_FLAC_FUSED_WGS")) : (variant == 1 ? 12 : 8);
     const unsigned grid = std::min<unsigned>((A.count + 63) / 64, (unsigned)ctx->num_cus * (unsigned)std::max(wgs, 1));
-    if (variant == 1) hipLaunchKernelGGL((k_flac_decode<16, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
-    else hipLaunchKernelGGL((k_flac_decode<32, true>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    if (A.out16) hipLaunchKernelGGL((k_flac_decode<32, true, true>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else if (variant == 1) hipLaunchKernelGGL((k_flac_decode<16, false, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_flac_decode<32, true, false>), dim3(grid), dim3(64), 0, ctx->stream, A);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }
@@ -690,10 +737,19 @@ int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, un
 
 // chained frames: scratch → rows.  One workgroup per frame; 16 bytes per thread and turn where everything is aligned.  OUT = int: the decoder's
 // integers as they are; float / double: the loader's `s / 2^depth` (:505; an exact scaling) straight into an audio's rows.
-template <typename OUT>
+template <typename OUT, bool S16 = false>
 __global__ __launch_bounds__(256) void k_flac_gather(const FrameRec *frames, int C, const u64 *row_off, const u64 *a_meta, unsigned n, const int *scratch, OUT *rows, double inv_full) {
     const FrameRec f = frames[blockIdx.x];
     const int nch = f.chan_asgn >= 8 ? 2 : C;
+    if constexpr (S16) {   // int16 finals (k_flac_decode<..., O16>) to int32 rows: the consumers that want rows want them as before
+        const short *base = reinterpret_cast<const short *>(scratch) + 2 * f.scratch;
+        for (int c = 0; c < nch; c++) {
+            const short *src = base + (u64)c * (u64)f.bs;
+            OUT *dst = rows + row_off[(size_t)f.stream * C + c] + f.sample_off;
+            for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = (OUT)src[i];
+        }
+        return;
+    }
     for (int c = 0; c < nch; c++) {
         const int *src = scratch + f.scratch + (u64)c * (u64)f.bs;
         OUT *dst = rows + (row_off ? row_off[(size_t)f.stream * C + c] : a_meta[n + f.stream] + (u64)c * a_meta[2 * (size_t)n + f.stream]) + f.sample_off;
@@ -719,9 +775,10 @@ __global__ __launch_bounds__(256) void k_flac_gather(const FrameRec *frames, int
         }
     }
 }
-int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows) {
+int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows, bool scratch16) {
     if (!nfr) return AUKIT_OK;
-    hipLaunchKernelGGL((k_flac_gather<int>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, row_off, (const u64 *)nullptr, 0u, scratch, rows, 1.0);
+    if (scratch16) hipLaunchKernelGGL((k_flac_gather<int, true>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, row_off, (const u64 *)nullptr, 0u, scratch, rows, 1.0);
+    else hipLaunchKernelGGL((k_flac_gather<int>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, row_off, (const u64 *)nullptr, 0u, scratch, rows, 1.0);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }

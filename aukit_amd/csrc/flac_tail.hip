@@ -45,6 +45,7 @@ struct RsOnepoleParams {
     // below an f32 ulp — and a row is no longer ONE serial chain of 938 tiles on a chip that can run four times as many chains as config 5 has rows
     int segs, warm;
     int novec;   // AUKIT_RS_NOVEC=1: every window element by element (the first cut; A/B)
+    int fr_mul;  // frame-by-frame rows: a record's offset counts int32 slots — 2 when the frames hold int16 finals (k_flac_decode<..., O16>), else 1
     // NW = 2 (round 4, late): a workgroup = the two channels of one stream, a wave each; what leaves is their MEAN (`Audio:mono` :682-687 behind
     // the filter), `out` / `a_meta` describe the MONO audio, rowmax2[stream] receives the larger of the two channels' maxima (what a
     // non-independent effects.normalize in between divides by, :3439-3444); wave_lds = floats of LDS per wave
@@ -70,14 +71,14 @@ AUKIT_DEV double dpp_f64(double v) {
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 template <int INTERP, bool HP, bool TAB, typename S, int NW = 1>
-__global__ __launch_bounds__(64 * NW, NW > 1 ? 4 : 1) void k_rs_onepole(const RsOnepoleParams P) {   // (NW = 2: four waves per SIMD asked for — 128 VGPRs instead of the 133 hipcc takes otherwise; the launch is sized for that residency)
+__global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
     extern __shared__ float rsm_all[];
     constexpr int E = 8, T = 64 * E;
     const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
     float *const rsm = rsm_all + (NW > 1 ? wv * (unsigned)P.wave_lds : 0u);
     float *const win = rsm + 16;                             // P.cap floats in all: 16 of slack in front (a part's first vector may start EPV - 1 elements early), the window, 16 behind
     float *const xb = rsm + P.cap;                           // T + T / E + 8
-    constexpr int EPV = 16 / (int)sizeof(S), VPL = 2;        // elements per 16-byte vector; vectors per lane and tile
+    constexpr int EPV = 16 / (int)sizeof(S), VPL = sizeof(S) == 4 ? 2 : 1;   // elements per 16-byte vector; vectors per lane and tile (512 elements either way: a second slot of 8 or 16 would sit idle in every tile and cost its instructions)
     [[maybe_unused]] float *const wt = NW > 1 ? rsm_all + NW * P.wave_lds : xb + (T + T / E + 8);   // TAB: 4 fb floats (one table per workgroup)
     constexpr int MIXN = T + T / E + 8;                                      // NW > 1: a wave's tile of results, skewed like xb
     [[maybe_unused]] float *const mix = rsm_all + NW * P.wave_lds + (TAB ? (4 * (int)P.fb + 3 & ~3) : 0);   // [wave][MIXN]
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, NW > 1 ? 4 : 1) void k_rs_onepole(const Rs
     long long base0 = 0, base1 = 0, base2 = 0;
     int bound = 0x7FFFFFFF;
     unsigned fcur = 0;
-    auto rec_base = [&](unsigned f) -> long long { const FrameRec a = fr_s[f]; return (long long)a.scratch + (long long)c * a.bs - (long long)f * bsn; };
+    auto rec_base = [&](unsigned f) -> long long { const FrameRec a = fr_s[f]; return (long long)P.fr_mul * (long long)a.scratch + (long long)c * a.bs - (long long)f * bsn; };
     if (P.frames && L > 0 && nfr_s > 0) {
         base0 = rec_base(0);
         bound = bsn;
@@ -233,7 +234,11 @@ __global__ __launch_bounds__(64 * NW, NW > 1 ? 4 : 1) void k_rs_onepole(const Rs
         auto qr = [&](unsigned j, unsigned &q, unsigned &rem) { const unsigned nn = r0 + j * P.fa; q = __umulhi(nn, P.fmagic); rem = nn - q * P.fb; };   // q relative to kb
         const int nst = tile_nst(r0, cnt);   // table indices kb .. kb + ql + 3 (floor(x) = q + 1; taps q .. q + 3)
         __builtin_amdgcn_wave_barrier();
-        auto cvt = [&](int v) -> float { return (float)v * (v < 0 ? P.scale_neg : P.scale); };
+        // (FLAC rows — every int32 row, and int16 ones whose two scales agree — need no sign select: a wave-uniform fork, two copies of the loops below)
+        const bool sym = sizeof(S) == 4 || P.scale == P.scale_neg;
+        auto cvt_a = [&](int v) -> float { return (float)v * (v < 0 ? P.scale_neg : P.scale); };
+        auto cvt_s = [&](int v) -> float { return (float)v * P.scale; };
+        auto stage = [&](auto cvt) {
         if (vcur.on) {   // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
@@ -278,6 +283,9 @@ __global__ __launch_bounds__(64 * NW, NW > 1 ? 4 : 1) void k_rs_onepole(const Rs
 #pragma unroll
         for (int u = 0; u < 8; u++) win[lane + 64 * u] = cvt(pre[u]);   // (cap >= 512)
         }
+        };
+        if (sym) stage(cvt_s); else stage(cvt_a);
+        [[maybe_unused]] auto cvt = cvt_a;   // (the element-by-element rest of wide windows)
         if (held_at) {   // (wave-uniform) the tile before this one
 #pragma unroll
             for (int u = 0; u < E; u++) held_at[64 * u] = held[u];
@@ -428,6 +436,7 @@ void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
     }
     a->lazy_row_off.clear(); a->lazy_row_len.clear();
     a->lazy_indirect = false;   // (lazy_tab keeps its allocation for the next call: freeing it here would wait for the kernel that reads it)
+    a->lazy_scratch16 = false;
 }
 
 // the owed resample with the ordinary kernel, into the audio's own rows
@@ -443,7 +452,8 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
         const char *T = reinterpret_cast<const char *>(a->lazy_tab.p);
         if ((grc = ctx_begin_kernel(ctx))) return grc;
         if ((grc = flac_gather_launch(ctx, reinterpret_cast<const FrameRec *>(T), a->lazy_nfr, a->channels, reinterpret_cast<const u64 *>(T + a->lazy_o_rowoff),
-                                      reinterpret_cast<const int *>(a->lazy_rows.p), reinterpret_cast<int *>(ctx->tmp_buf.p)))) return grc;
+                                      reinterpret_cast<const int *>(a->lazy_rows.p), reinterpret_cast<int *>(ctx->tmp_buf.p), a->lazy_scratch16))) return grc;
+        if (a->lazy_scratch16) { a->lazy_scratch16 = false; a->lazy_src = SRC_I32; a->lazy_norm_pos = a->lazy_norm_neg = a->lazy_full; }   // (gathered to int32 rows: the ordinary kernels take those)
         if ((grc = ctx_end_kernel(ctx, "k_flac_gather", 2 * a->lazy_tot * 4))) return grc;
         if (ctx->tmp_buf3.cap < a->lazy_rows.cap) { ctx->tmp_buf3.release(); ctx->tmp_buf3 = a->lazy_rows; a->lazy_rows = DevBuf{}; }   // the scratch goes home
         else a->lazy_rows.release();
@@ -523,6 +533,8 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
     a->lazy_row_off = row_off; a->lazy_row_len = row_len;
     a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx;
     a->lazy_src = src_kind; a->lazy_norm_pos = norm_pos; a->lazy_norm_neg = norm_neg;
+    a->lazy_scratch16 = LF && LF->scratch16;
+    if (a->lazy_scratch16) a->lazy_src = SRC_I16;   // (k_rs_onepole<..., short> on the frames; v / full as for int32 rows)
     a->lazy_rs = true;
     ctx->last_kernel = "(resample deferred)";
     return true;
@@ -567,8 +579,9 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);   // the step of 64 outputs (one row of lanes)
     // (1 / 32767 etc. rounded to f32 once: the constants of fast.hip / fast_wave_dev.h)
-    P.scale = a->lazy_src == SRC_I16 ? 1.0f / 32767.0f : (a->lazy_src == SRC_I8 ? 1.0f / 127.0f : (float)(1.0 / a->lazy_full));
-    P.scale_neg = a->lazy_src == SRC_I16 ? 1.0f / 32768.0f : (a->lazy_src == SRC_I8 ? 1.0f / 128.0f : P.scale);
+    P.scale = a->lazy_scratch16 ? (float)(1.0 / a->lazy_full) : (a->lazy_src == SRC_I16 ? 1.0f / 32767.0f : (a->lazy_src == SRC_I8 ? 1.0f / 127.0f : (float)(1.0 / a->lazy_full)));
+    P.scale_neg = a->lazy_scratch16 ? P.scale : (a->lazy_src == SRC_I16 ? 1.0f / 32768.0f : (a->lazy_src == SRC_I8 ? 1.0f / 128.0f : P.scale));
+    P.fr_mul = a->lazy_scratch16 ? 2 : 1;
     P.coef = coef;
     if (a->lazy_indirect) {
         const char *T = reinterpret_cast<const char *>(a->lazy_tab.p);
