@@ -157,12 +157,18 @@ AUKIT_DEV void flac_predict(int *row, int cnt, int jpos0, int order, int lshift,
                 // sums overlap), the taps on the samples just restored last — as one chain of twelve dependent multiply-adds from the newest
                 // tap down, every sample waited for the one before it through all twelve (hipcc even pads that chain with s_nop).  Integer
                 // sums: any order gives the same bits
+#ifdef AUKIT_FLAC_OLD_PRED
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q < MAXO; q++) { const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj]; sum = fmad24(t, coef[q], sum); }
+#else
                 int sa = 0, sb = 0;
 #pragma unroll
                 for (int q = MAXO - 1; q >= jj; q--) { if ((q - jj) & 1) sb = fmad24(hist[q - jj], coef[q], sb); else sa = fmad24(hist[q - jj], coef[q], sa); }
                 int sum = sa + sb;
 #pragma unroll
                 for (int q = jj - 1; q >= 0; q--) sum = fmad24(nv[jj - 1 - q], coef[q], sum);
+#endif
                 int pr = sum >> lshift;
                 if (WARM && jpos0 + k + jj < order) pr = 0;
                 v = res[jj] + pr;
@@ -473,47 +479,29 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                 int n_it = min(lim - cnt, remaining);                   // values this lane may still take in this round
                 int *wp = orow + cnt;
                 bool go = run && n_it > 0 && (int)(d - dlim) < 0;
-                // MIXED: some lane of the wave reads fixed-width fields (warm-up samples, escaped partitions, VERBATIM) — else every running lane is in a
-                // Rice run and the field arithmetic and its selects drop out of the loop (round 4, late: 36 -> 31 VALU instructions per value).
-                // A Rice code longer than 32 bits ends the lane's loop with NOTHING committed: the turn's bookkeeping runs unconditionally and is
-                // taken back behind the loop (one lane in thousands; selects on `ok` in every turn were three instructions of every value)
-                int tot_last = 0;
-                bool cross_last = false;
-                auto inner = [&](auto mixedc) {
-                    constexpr bool MIXED = decltype(mixedc)::value;
-                    while (go) {
-                        const unsigned wn = b.lw[(d + 2) & FRING];          // for a crossing at the END of this turn: requested first, used last
-                        const unsigned hi = __builtin_amdgcn_alignbit(w0, w1, (unsigned)s);
-                        const int z = hi ? __builtin_clz(hi) : 32;
-                        const int tot_r = z + 1 + rk;
-                        const unsigned low = __builtin_amdgcn_ubfe(hi, (unsigned)(31 - rk - z) & 31u, (unsigned)rk);
-                        const unsigned ur = ((unsigned)z << rk) | low;
-                        const int v_r = (int)(ur >> 1) ^ -(int)(ur & 1u);
-                        int tot = tot_r, val = v_r;
-                        if constexpr (MIXED) {
-                            const int v_f = __builtin_amdgcn_sbfe((int)hi, (unsigned)(32 - rk) & 31u, (unsigned)rk);
-                            tot = fixed ? rk : tot_r;
-                            val = fixed ? v_f : v_r;
-                        }
-                        const bool ok = tot <= 32;              // else a Rice code longer than 32 bits: the generic reader takes this one
-                        *wp = val;                              // (a value that is not ok is overwritten by the generic reader's)
-                        s -= tot;
-                        const bool cross = s < 0;
-                        s &= 31;
-                        d += cross ? 1u : 0u;
-                        w0 = cross ? w1 : w0;
-                        w1 = cross ? wn : w1;
-                        wp++; n_it--;
-                        tot_last = tot; cross_last = cross;
-                        slow = !ok;
-                        go = ok && n_it > 0 && (int)(d - dlim) < 0;
-                    }
-                };
-                if (__any(run && fixed)) inner(std::true_type{}); else inner(std::false_type{});
-                if (slow) {   // the last turn did not happen
-                    wp--;
-                    d -= cross_last ? 1u : 0u;
-                    s = (s + tot_last) & 31;   // (s was in 0 .. 31 before the turn)
+                // (tried, round 4 late: a second copy of this loop without the field arithmetic for Rice-only rounds, and a turn that commits
+                // unconditionally with the last one taken back — 36 -> 31 VALU instructions per value on paper, 8.0 -> 8.4 / 8.5 ms measured)
+                while (go) {
+                    const unsigned wn = b.lw[(d + 2) & FRING];          // for a crossing at the END of this turn: requested first, used last
+                    const unsigned hi = __builtin_amdgcn_alignbit(w0, w1, (unsigned)s);
+                    const int z = hi ? __builtin_clz(hi) : 32;
+                    const int tot_r = z + 1 + rk;
+                    const unsigned low = __builtin_amdgcn_ubfe(hi, (unsigned)(31 - rk - z) & 31u, (unsigned)rk);
+                    const unsigned ur = ((unsigned)z << rk) | low;
+                    const int v_r = (int)(ur >> 1) ^ -(int)(ur & 1u);
+                    const int v_f = __builtin_amdgcn_sbfe((int)hi, (unsigned)(32 - rk) & 31u, (unsigned)rk);
+                    const int tot = fixed ? rk : tot_r;
+                    const bool ok = tot <= 32;              // else a Rice code longer than 32 bits: the generic reader takes this one (nothing moves)
+                    *wp = fixed ? v_f : v_r;                // (a value that is not ok is overwritten by the generic reader's)
+                    s -= ok ? tot : 0;
+                    const bool cross = s < 0;
+                    s &= 31;
+                    d += cross ? 1u : 0u;
+                    w0 = cross ? w1 : w0;
+                    w1 = cross ? wn : w1;
+                    wp += ok ? 1 : 0; n_it -= ok ? 1 : 0;
+                    slow = !ok;
+                    go = ok && n_it > 0 && (int)(d - dlim) < 0;
                 }
                 if (run) { const int got = (int)(wp - orow) - cnt; cnt += got; remaining -= got; }
                 (void)cnt0;
