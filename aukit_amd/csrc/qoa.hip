@@ -441,7 +441,7 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d,
     ck->lens.assign((size_t)ck->n * mc, 0);
     ck->pos.assign((size_t)ck->n * mc, 0);
     for (uint32_t s = 0; s < in->n; s++) {
-        double file_pos = 0;
+        double file_pos = (double)ctx->sb_samples;   // (the rest of a stream behind a bounded reader-function handle: what was dropped counts)
         for (unsigned k = 0; k < S[s].ncalls; k++) {
             ck->lens[(size_t)s * mc + k] = (uint32_t)nouts[S[s].call_first + k];
             ck->pos[(size_t)s * mc + k] = file_pos / rate;                                         // :3332

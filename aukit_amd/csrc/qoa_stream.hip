@@ -180,7 +180,7 @@ int stream_qoa_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_des
         else if (fc != C || fr != rate) { delete ck; return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate"); }
         ck->length_seconds[s] = file_samples / fr;
         uint64_t pos = 8;
-        double file_pos = 0;
+        double file_pos = (double)ctx->sb_samples;
         for (;;) {  // one iterator call
             std::vector<QFrame> frames;
             double sample_pos = 0;

@@ -21,7 +21,9 @@
 //     copies write to the wrong table) — the rest starts at the next call's first byte.
 // The positions and the length the factories report are those of the whole stream: the handle tells them what it dropped (aukit_ctx::sb_bytes /
 // sb_outputs).  Device memory then stays at a call or two of input and decode work is linear in the stream; aukit_stream_resident reports both.
-// stream.dfpwm / mdfpwm (the decoder's state crosses calls), stream.qoa and stream.flac (file headers, `last` samples) keep the whole prefix.
+//   * stream.qoa (:3202-3337): frames carry their LMS state and a call takes whole frames; the two `last` samples of a chunk are all that reaches
+//     the next call — the rest starts one call earlier (as stream.pcm), behind the file's 8-byte header, which stays in front.
+// stream.dfpwm / mdfpwm (the decoder's state crosses calls) and stream.flac (frame boundaries are only known once decoded) keep the whole prefix.
 #include <algorithm>
 #include "common.h"
 
@@ -43,6 +45,9 @@ struct aukit_stream {
     uint64_t sb_bytes = 0, sb_outputs = 0, decoded_bytes_total = 0;
     uint8_t head7[8] = {};            // stream.msadpcm mono reads EVERY block's header from the start of the string (Q9, aukit.lua:2706): the stream's first
     bool have_head7 = false;          // seven bytes stay in front of whatever rest is decoded
+    uint8_t head16[16] = {};          // stream.qoa: the 8-byte file header stays in front of the rest too; bytes 8 .. 15 = the first frame's header (channels, rate)
+    bool have_head16 = false;
+    uint64_t sb_samples = 0;          // stream.qoa: decoded samples per channel dropped in front (file_pos, aukit.lua:3332)
 };
 
 namespace aukit {
@@ -74,9 +79,9 @@ static int redecode(aukit_stream *h) {
     int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
-    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs;   // the rest of a stream: the factories add what was dropped to their positions
+    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples;   // the rest of a stream: the factories add what was dropped to their positions
     rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
-    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0;
+    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0;
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
     h->decoded_bytes_total += usable;
@@ -91,7 +96,7 @@ static int redecode(aukit_stream *h) {
 
 // Where the rest of the stream may start once chunk `j` (an index into the current decode) has been delivered: `lead` chunks of the fresh decode
 // repeat delivered ones and are skipped, the next call's chunk is fresh chunk `lead`.
-struct Restart { bool ok = false; int lead = 0; uint64_t call_bytes = 0; };
+struct Restart { bool ok = false; int lead = 0; uint64_t call_bytes = 0; uint64_t hdr = 0, call_outputs = 0, call_samples = 0; };   // hdr: bytes of a file header kept in front; call_outputs: what a dropped call must have delivered (0: not checked)
 static Restart restart_rule(const aukit_stream *h) {
     Restart r;
     const aukit_codec_desc &d = h->desc;
@@ -119,6 +124,21 @@ static Restart restart_rule(const aukit_stream *h) {
         r.ok = true; r.call_bytes = (uint64_t)std::ceil(d.sample_rate / spb) * (uint64_t)d.block_align;
         return r;
     }
+    case AUKIT_CODEC_QOA: {
+        // stream.qoa (aukit.lua:3202-3337): frames carry their own LMS state, an iterator call takes whole frames until it has a second of samples,
+        // and all that reaches the next call are the last two samples of the chunk (`last`, :3334) — the rest starts one call EARLIER (lead 1: its
+        // first chunk repeats a delivered one and is skipped, its second has the right `last`).  A full frame is 5120 samples in
+        // 8 + channels * (16 + 2048) bytes; calls of anything else (a short frame in mid-stream) are not dropped (call_outputs is checked)
+        if (!h->have_head16 || h->interp == AUKIT_INTERP_SINC) return r;
+        const uint64_t fc = h->head16[8], fr = ((uint64_t)h->head16[9] << 16) | ((uint64_t)h->head16[10] << 8) | h->head16[11];
+        if (fc < 1 || fc > 8 || fr < 1) return r;
+        const uint64_t fpc = (fr + 5119) / 5120;
+        r.ok = true; r.lead = 1; r.hdr = 8;
+        r.call_bytes = fpc * (8 + fc * (16 + 2048));
+        r.call_samples = fpc * 5120;
+        r.call_outputs = (uint64_t)std::floor((double)(fpc * 5120) * (48000.0 / (double)fr));
+        return r;
+    }
     default: return r;
     }
 }
@@ -130,7 +150,9 @@ static int compact(aukit_stream *h) {
     const uint64_t j = h->delivered - 1;                       // the chunk just delivered
     const uint64_t shift = R.lead ? j : j + 1;                  // fresh chunk 0 = current chunk `shift`
     const uint64_t drop = shift * R.call_bytes;
-    if (shift == 0 || drop < (64u << 10) || drop > h->fed) return AUKIT_OK;   // (a few calls at a time: every drop costs one decode of the rest)
+    if (shift == 0 || drop < (64u << 10) || drop + R.hdr > h->fed) return AUKIT_OK;   // (a few calls at a time: every drop costs one decode of the rest)
+    if (R.call_outputs)
+        for (uint64_t m = 0; m < shift; m++) if (h->ck->lens[m] != R.call_outputs) return AUKIT_OK;   // a call of other than whole full frames: the byte arithmetic above does not hold
     const uint32_t mc = std::max<uint32_t>(h->ck->max_chunks, 1);
     (void)mc;
     uint64_t outs = 0;
@@ -143,12 +165,15 @@ static int compact(aukit_stream *h) {
     if (rest) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream));
     if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.channels == 1 && rest >= 7)   // Q9: the header every mono block is read from is the STREAM's first (no block reads its own)
         AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream));
+    if (R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
+        AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head16, R.hdr, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
     (void)hipFree(h->dbuf);
     h->dbuf = nb; h->dcap = cap;
     h->fed -= drop;
     h->sb_bytes += drop;
     h->sb_outputs += outs;
+    h->sb_samples += shift * R.call_samples;
     h->delivered = (uint32_t)R.lead;
     aukit_chunks_free(h->ck); h->ck = nullptr;     // the chunk table described the longer buffer
     h->dirty = true; h->decoded_at = ~0ull;
@@ -178,6 +203,10 @@ int aukit_stream_feed(aukit_stream *h, const uint8_t *bytes, uint64_t n) {
     if (rc) return rc;
     AUKIT_HIP_CHECK(hipMemcpyAsync(h->dbuf + h->fed, bytes, n, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));  // the caller may reuse `bytes`
+    if (!h->have_head16 && h->sb_bytes == 0 && h->fed < 16) {
+        for (uint64_t i = 0; i < n && h->fed + i < 16; i++) h->head16[h->fed + i] = bytes[i];
+        if (h->fed + n >= 16) h->have_head16 = true;
+    }
     if (!h->have_head7 && h->sb_bytes == 0 && h->fed < 7) {   // (kept from the caller's bytes: no read-back)
         for (uint64_t i = 0; i < n && h->fed + i < 7; i++) h->head7[h->fed + i] = bytes[i];
         if (h->fed + n >= 7) h->have_head7 = true;

@@ -232,7 +232,7 @@ def test_ignore_header_strips_later_headers_and_first_piece_quirks(ctx, oracle):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["pcm16_mono_44k_cubic", "pcm8_48k_linear", "pcm16_stereo_mix", "g711_stereo", "ima_22k", "msadpcm_44k"])
+@pytest.mark.parametrize("name", ["pcm16_mono_44k_cubic", "pcm8_48k_linear", "pcm16_stereo_mix", "g711_stereo", "ima_22k", "msadpcm_44k", "qoa_44k_stereo", "qoa_22k_mono_mix"])
 def test_long_live_stream_is_bounded(ctx, oracle, monkeypatch, name):
     """VERDICT r03 item 8 (austream.lua:19-64: HTTP / websocket readers run for hours).  A long stream fed in 64 KiB pieces: the chunks equal the
     string call's (samples, lengths, positions, the stream's length), the bytes resident on the device stay at a few calls' worth instead of growing
@@ -252,6 +252,14 @@ def test_long_live_stream_is_bounded(ctx, oracle, monkeypatch, name):
     elif name == "ima_22k":
         data = b"".join(oracle.gen_ima(pcm16(1016 * 500, 22050, 3, i), 1, 512, 88) for i in range(8))
         desc, interp, mono, dtype, call = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), "cubic", False, N.I8, 22 * 512
+    elif name == "qoa_44k_stereo":   # frames carry their LMS state; the rest starts one call early for the two `last` samples (aukit.lua:3334)
+        st = np.stack([pcm16(44100 * 75, 44100, 9, 31), pcm16(44100 * 75, 44100, 9, 32)], 1)
+        data = oracle.gen_qoa(st.ravel(), 2, 44100) + b"\0" * 8
+        desc, interp, mono, dtype, call = B.make_desc(N.CODEC_QOA, 2, 44100), "cubic", False, N.F32, 9 * (8 + 2 * 2064)
+    elif name == "qoa_22k_mono_mix":
+        st = np.stack([pcm16(22050 * 160, 22050, 9, 33), pcm16(22050 * 160, 22050, 9, 34)], 1)
+        data = oracle.gen_qoa(st.ravel(), 2, 22050) + b"\0" * 8
+        desc, interp, mono, dtype, call = B.make_desc(N.CODEC_QOA, 2, 22050), "linear", True, N.F64, 5 * (8 + 2 * 2064)
     else:
         data = b"".join(oracle.gen_msadpcm(pcm16(2036 * 300, 44100, 3, 20 + i), 1, 1024) for i in range(8))
         desc, interp, mono, dtype, call = B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=1024), "linear", False, N.I8, 22 * 1024
