@@ -79,6 +79,7 @@ struct aukit_ctx {
     // a resumable stream handle (stream_handle.hip) that has dropped the bytes of delivered iterator calls decodes the REST of its stream: what it dropped
     // — bytes, 48 kHz outputs per channel — enters the chunk positions and the length of the stream factories that support it (stream.pcm / g711 /
     // adpcm / msadpcm), so that the rest's chunks carry the whole stream's numbers.  Zero everywhere else.
+    double sb_pos = 0;   // stream.flac: the accumulated position (aukit.lua:3188) at the cut, exactly as the sums before it left it
     uint64_t sb_bytes = 0, sb_outputs = 0, sb_samples = 0;   // (sb_samples: decoded samples per channel in front — stream.qoa's file_pos)
     bool lazy_suppress = false;   // set while an owed resample is being materialised: audio_from_int_rows must not defer it again
     std::string plan_key;   // non-empty: seg_buf / tile_buf still hold the tables of plan_segs (any other upload into them clears it)
@@ -164,6 +165,10 @@ struct aukit_chunks {
     std::vector<uint32_t> nchunks, lens;
     std::vector<double> pos, length_seconds;
     std::vector<int32_t> status;
+    // stream.flac (fused decoder): the byte, relative to the stream's start, behind the last frame of every chunk, and where the first frame starts —
+    // what a bounded reader-function handle cuts at (stream_handle.hip); empty where it is not known
+    std::vector<uint64_t> in_end;
+    std::vector<uint64_t> in_first;
 };
 
 namespace aukit {

@@ -1290,6 +1290,8 @@ struct FlacDecoded {
     // the consumers that can follow the frame records read them there (the loader's conversion, the deferred resample + one-pole pass,
     // stream.flac's tail jobs); flac_rows_materialize() gathers contiguous rows into ctx->tmp_buf for the others
     bool in_scratch = false;
+    std::vector<std::vector<uint32_t>> frame_end;   // fused decoder, want_frames: the byte behind every frame, relative to its stream's start (0: unknown)
+    std::vector<uint64_t> first_frame;             // ... and where the stream's first frame starts (behind the metadata blocks)
     bool scratch16 = false;   // ... as int16 (FusedArgs::out16: asked for by the loader's F32 resample path, depths <= 16)
     bool want16 = false;
     uint64_t tot_elems = 0;          // elements of the contiguous rows (row_off / row_len describe them whether they exist yet or not)
@@ -1631,7 +1633,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         ctx->plan_key.clear();
         FrameRec *d_frames = reinterpret_cast<FrameRec *>(ctx->seg_buf.p);
         if ((rc = h2d_table(ctx, d_rowoff, D.row_off.data(), (size_t)n * C * 8)) || (rc = h2d_table(ctx, d_fbase, fbase.data(), (size_t)n * 8))) return rc;
-        if (nfr && (rc = flac_frames_launch(ctx, d_cand, d_ci, ncand, d_fbase, d_frames))) return rc;
+        if (nfr && (rc = flac_frames_launch(ctx, d_cand, d_ci, ncand, d_fbase, d_frames, G.off))) return rc;
         D.in_scratch = true;
         D.scratch16 = o16;
         D.tot_elems = tot;
@@ -1648,11 +1650,19 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         D.d_frames = d_frames; D.d_fbase = d_fbase; D.d_rowoff = d_rowoff; D.fbase = fbase; D.nfr = nfr;
         D.nframes.assign(n, 0);
         for (uint32_t s = 0; s < n; s++) D.nframes[s] = chain[s].nframes;
-        if (want_frames)
+        if (want_frames) {
+            D.frame_end.assign(n, {});
+            D.first_frame.assign(n, 0);
             for (uint32_t s = 0; s < n; s++) {
                 D.frames[s].reserve(chain[s].nframes);
-                for (unsigned f = 0; f < chain[s].nframes; f++) D.frames[s].push_back({hfr[fbase[s] + f].sample_off, hfr[fbase[s] + f].bs});
+                D.frame_end[s].reserve(chain[s].nframes);
+                D.first_frame[s] = D.info[s].first_byte;
+                for (unsigned f = 0; f < chain[s].nframes; f++) {
+                    D.frames[s].push_back({hfr[fbase[s] + f].sample_off, hfr[fbase[s] + f].bs});
+                    D.frame_end[s].push_back(hfr[fbase[s] + f].end_rel);
+                }
             }
+        }
         D.wide = false;
         return AUKIT_OK;
     }
@@ -1942,13 +1952,14 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     auto build_chunks = [&]() {
         std::vector<uint32_t> clen;
         std::vector<double> cpos;
+        std::vector<uint64_t> cend;
         std::vector<uint32_t> first(in->n + 1, 0);
         for (uint32_t s = 0; s < in->n; s++) {
             ck->length_seconds[s] = D.info[s].nsamples / D.rate;
             // iterator calls: frames accumulate while #chunk[1] < sampleRate; an error or the end of data kills the coroutine (errors are swallowed)
             size_t f = 0;
             bool dead = false;
-            double pos = 0;
+            double pos = ctx->sb_pos;   // (the rest of a stream behind a bounded reader-function handle: the position the dropped calls had summed up)
             first[s] = (uint32_t)clen.size();
             while (!dead) {
                 uint64_t got = 0;
@@ -1960,6 +1971,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
                 pos = pos + (double)got / 48000;                                  // :3188
                 clen.push_back((uint32_t)got);
                 cpos.push_back(pos);
+                cend.push_back(f > 0 && s < D.frame_end.size() && f - 1 < D.frame_end[s].size() ? (uint64_t)D.frame_end[s][f - 1] : 0ull);
             }
             ck->nchunks[s] = (uint32_t)clen.size() - first[s];
             ck->max_chunks = std::max(ck->max_chunks, ck->nchunks[s]);
@@ -1970,6 +1982,14 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
         ck->pos.assign((size_t)ck->n * mc, 0);
         for (uint32_t s = 0; s < in->n; s++)
             for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = clen[first[s] + k]; ck->pos[(size_t)s * mc + k] = cpos[first[s] + k]; }
+        if (!D.frame_end.empty()) {   // where a bounded handle may cut (stream_handle.hip)
+            ck->in_end.assign((size_t)ck->n * mc, 0);
+            ck->in_first.assign(ck->n, 0);
+            for (uint32_t s = 0; s < in->n; s++) {
+                ck->in_first[s] = D.first_frame[s];
+                for (uint32_t k = 0; k < ck->nchunks[s]; k++) ck->in_end[(size_t)s * mc + k] = cend[first[s] + k];
+            }
+        }
     };
     aukit_audio *a = *out;
     if ((rc = audio_prepare(ctx, &a, in->n, C, 48000, dtype, lens.data()))) { delete ck; return rc; }

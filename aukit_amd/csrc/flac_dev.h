@@ -67,7 +67,7 @@ struct CandInfo {
 struct SubDesc { int order, lshift, wasted, kind; short coef[32]; };  // kind: 0 = no prediction, 1/2/3 = order <= 4/12/32
 struct ChainOut { u64 L, miss_at; unsigned nframes; int status; int miss_kind; unsigned miss_ci; int bs0, uniform; };   // bs0: the first frame's block size; uniform: every frame but the last has it, the last is no longer  // miss_kind: 1 = no candidate at miss_at, 2 = candidate miss_ci hit its bit budget
 struct SubJob { u64 src, dst; unsigned desc; int bs; int asgn, pad; };  // asgn: the frame's channel assignment when it decorrelates (8..10), else 0
-struct FrameRec { u64 sample_off; u64 scratch; int bs, chan_asgn; unsigned stream, pad; };   // scratch: where k_flac_decode left the frame's final values (channel c at + c * bs); 0 for the first design
+struct FrameRec { u64 sample_off; u64 scratch; int bs, chan_asgn; unsigned stream, end_rel; };   // end_rel: the byte behind the frame, relative to its stream's start (streams below 4 GiB; 0: not recorded)   // scratch: where k_flac_decode left the frame's final values (channel c at + c * bs); 0 for the first design
 struct Carve {
     size_t at = 0;
     size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
@@ -93,7 +93,7 @@ struct FusedArgs {
 };
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A);
 // the chained frames' records in stream order (one lane per candidate)
-int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames);
+int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames, const u64 *stream_off);
 // chained frames: scratch → contiguous int32 rows (one workgroup per frame record)
 int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows, bool scratch16 = false);   // scratch16: the frames hold int16 finals (FusedArgs::out16)
 // the same with the loader's conversion `s / 2^depth` (:505) into the rows of an audio (dtype AUKIT_F32 / AUKIT_F64; a_meta = len[n], row_off[n], row_stride[n])

@@ -735,17 +735,18 @@ int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
     return AUKIT_OK;
 }
 
-__global__ __launch_bounds__(64) void k_flac_frames(const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames) {
+__global__ __launch_bounds__(64) void k_flac_frames(const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames, const u64 *stream_off) {
     const unsigned k = blockIdx.x * 64 + threadIdx.x;
     if (k >= ncand) return;
     const CandInfo f = ci[k];
     if (!f.used) return;
     const unsigned s = cands[k].stream;
-    frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.scratch, f.blocksize, f.chan_asgn, s, 0};
+    const u64 rel = f.end_byte - stream_off[s];
+    frames[frame_base[s] + f.seq] = FrameRec{f.sample_off, f.scratch, f.blocksize, f.chan_asgn, s, rel < 0xFFFFFFFFull ? (unsigned)rel : 0u};
 }
-int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames) {
+int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames, const u64 *stream_off) {
     if (!ncand) return AUKIT_OK;
-    hipLaunchKernelGGL(k_flac_frames, dim3((ncand + 63) / 64), dim3(64), 0, ctx->stream, cands, ci, ncand, frame_base, frames);
+    hipLaunchKernelGGL(k_flac_frames, dim3((ncand + 63) / 64), dim3(64), 0, ctx->stream, cands, ci, ncand, frame_base, frames, stream_off);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }

@@ -23,7 +23,10 @@
 // sb_outputs).  Device memory then stays at a call or two of input and decode work is linear in the stream; aukit_stream_resident reports both.
 //   * stream.qoa (:3202-3337): frames carry their LMS state and a call takes whole frames; the two `last` samples of a chunk are all that reaches
 //     the next call — the rest starts one call earlier (as stream.pcm), behind the file's 8-byte header, which stays in front.
-// stream.dfpwm / mdfpwm (the decoder's state crosses calls) and stream.flac (frame boundaries are only known once decoded) keep the whole prefix.
+//   * stream.flac (:3124-3191): as stream.qoa — whole frames per call, the two `last` samples of the block before — but where frames end is only known
+//     once they are decoded: the fused decoder's chunk table carries the byte behind every call's last frame (aukit_chunks::in_end), the rest
+//     starts there, one call early, behind the metadata blocks; the position carries on from the exact double the dropped calls had summed up.
+// stream.dfpwm / mdfpwm (the decoder's state crosses calls) keep the whole prefix.
 #include <algorithm>
 #include "common.h"
 
@@ -48,6 +51,7 @@ struct aukit_stream {
     uint8_t head16[16] = {};          // stream.qoa: the 8-byte file header stays in front of the rest too; bytes 8 .. 15 = the first frame's header (channels, rate)
     bool have_head16 = false;
     uint64_t sb_samples = 0;          // stream.qoa: decoded samples per channel dropped in front (file_pos, aukit.lua:3332)
+    double sb_pos = 0;                // stream.flac: the position summed up by the dropped calls (:3188)
 };
 
 namespace aukit {
@@ -79,9 +83,9 @@ static int redecode(aukit_stream *h) {
     int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
-    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples;   // the rest of a stream: the factories add what was dropped to their positions
+    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples; h->ctx->sb_pos = h->sb_pos;   // the rest of a stream: the factories add what was dropped to their positions
     rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
-    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0;
+    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0; h->ctx->sb_pos = 0;
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
     h->decoded_bytes_total += usable;
@@ -139,6 +143,13 @@ static Restart restart_rule(const aukit_stream *h) {
         r.call_outputs = (uint64_t)std::floor((double)(fpc * 5120) * (48000.0 / (double)fr));
         return r;
     }
+    case AUKIT_CODEC_FLAC:
+        // stream.flac (aukit.lua:3124-3191): an iterator call takes whole frames; all that reaches the next frame are the two `last` samples of the
+        // block before it — the rest starts one call EARLIER (lead 1), behind the metadata blocks, which stay in front.  Where frames end is only
+        // known once they are decoded: the chunk table of the fused decoder carries it (aukit_chunks::in_end); `call_bytes` is not a constant here
+        if (h->interp == AUKIT_INTERP_SINC || !h->ck || h->ck->in_end.empty() || h->ck->in_first.empty()) return r;
+        r.ok = true; r.lead = 1; r.call_bytes = 0; r.hdr = h->ck->in_first[0];
+        return r;
     default: return r;
     }
 }
@@ -146,10 +157,17 @@ static Restart restart_rule(const aukit_stream *h) {
 // after chunk h->delivered - 1 went out: drop what no later chunk depends on (see the header)
 static int compact(aukit_stream *h) {
     const Restart R = restart_rule(h);
-    if (!R.ok || !R.call_bytes || !h->ck || h->delivered == 0) return AUKIT_OK;
+    const bool by_table = R.ok && h->desc.codec == AUKIT_CODEC_FLAC;   // the cut comes from the chunk table, not from a constant call size
+    if (!R.ok || (!R.call_bytes && !by_table) || !h->ck || h->delivered == 0) return AUKIT_OK;
     const uint64_t j = h->delivered - 1;                       // the chunk just delivered
     const uint64_t shift = R.lead ? j : j + 1;                  // fresh chunk 0 = current chunk `shift`
-    const uint64_t drop = shift * R.call_bytes;
+    uint64_t drop = shift * R.call_bytes;
+    if (by_table) {
+        if (shift == 0 || shift - 1 >= h->ck->in_end.size()) return AUKIT_OK;
+        const uint64_t cut = h->ck->in_end[shift - 1];          // the byte behind the last dropped call's last frame
+        if (cut <= R.hdr || cut > h->fed) return AUKIT_OK;
+        drop = cut - R.hdr;
+    }
     if (shift == 0 || drop < (64u << 10) || drop + R.hdr > h->fed) return AUKIT_OK;   // (a few calls at a time: every drop costs one decode of the rest)
     if (R.call_outputs)
         for (uint64_t m = 0; m < shift; m++) if (h->ck->lens[m] != R.call_outputs) return AUKIT_OK;   // a call of other than whole full frames: the byte arithmetic above does not hold
@@ -163,9 +181,10 @@ static int compact(aukit_stream *h) {
     uint8_t *nb = nullptr;
     if (hipMalloc((void **)&nb, cap + 64) != hipSuccess) { (void)hipGetLastError(); return AUKIT_OK; }   // no memory for the move: keep the prefix (correct, only bigger)
     if (rest) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream));
+    if (by_table && R.hdr) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf, (size_t)R.hdr, hipMemcpyDeviceToDevice, h->ctx->stream));   // the metadata blocks stay in front (the bytes just copied there are dropped frames')
     if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.channels == 1 && rest >= 7)   // Q9: the header every mono block is read from is the STREAM's first (no block reads its own)
         AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream));
-    if (R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
+    if (!by_table && R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
         AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head16, R.hdr, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
     (void)hipFree(h->dbuf);
@@ -174,6 +193,7 @@ static int compact(aukit_stream *h) {
     h->sb_bytes += drop;
     h->sb_outputs += outs;
     h->sb_samples += shift * R.call_samples;
+    if (by_table) h->sb_pos = h->ck->pos[shift - 1];   // (chunk k's position is the sum behind it, :3188: the next call starts from exactly that double)
     h->delivered = (uint32_t)R.lead;
     aukit_chunks_free(h->ck); h->ck = nullptr;     // the chunk table described the longer buffer
     h->dirty = true; h->decoded_at = ~0ull;
