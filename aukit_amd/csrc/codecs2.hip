@@ -315,16 +315,18 @@ int decode_mdfpwm_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
 }
 
 // ================================================================= stream.dfpwm  aukit.lua:2439-2496
+struct DfInit { int on; int st[6]; };   // the state a decoder starts from (a bounded reader-function handle's rest of a stream; aukit_ctx::sb_dfpwm)
 __global__ __launch_bounds__(64) void k_dfpwm_stream_rows(const unsigned char *src, const unsigned long long *off, unsigned n, unsigned long long adv,
-                                                         signed char *out, const unsigned long long *row_off) {
+                                                         signed char *out, const unsigned long long *row_off, const DfInit init) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     const unsigned char *p = src + off[s];
     const unsigned long long nb = off[s + 1] - off[s];
     signed char *o = out + row_off[s];
     DfDec d{};
+    if (init.on) { d.p.n = init.st[0]; d.p.strength = init.st[1]; d.p.pb = init.st[2]; d.lpf = init.st[3]; d.pn = init.st[4]; }
     unsigned long long w = 0;
-    o[w++] = 0;  // audio[0] of the first chunk = `last` = 0
+    o[w++] = init.on ? (signed char)init.st[3] : 0;  // audio[0] of the first chunk = `last` = 0 — or the last sample before the rest of a stream (the decoder's low-pass state IS its last output)
     for (unsigned long long pos = 0; pos < nb; pos += adv) {  // str_sub(data, pos, pos + 6000 * channels): one byte of overlap
         const unsigned long long cnt = nb - pos < adv + 1 ? nb - pos : adv + 1;
         for (unsigned long long b = 0; b < cnt; b++) {
@@ -337,9 +339,34 @@ __global__ __launch_bounds__(64) void k_dfpwm_stream_rows(const unsigned char *s
 
 bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int C, signed char *out, const unsigned long long *d_out_off,
                            const unsigned long long *d_out_stride, int *rc, uint64_t adv, uint64_t lead, const DfSliceHook *hook = nullptr);
-__global__ __launch_bounds__(256) void k_row_heads_zero(signed char *out, const unsigned long long *row_off, unsigned n) {
+__global__ __launch_bounds__(256) void k_row_heads_zero(signed char *out, const unsigned long long *row_off, unsigned n, int head = 0) {
     const unsigned s = blockIdx.x * 256 + threadIdx.x;
-    if (s < n) out[row_off[s]] = 0;
+    if (s < n) out[row_off[s]] = (signed char)head;
+}
+// the decoder's state after `calls` iterator calls of stream.dfpwm (each feeds adv + 1 bytes and moves on by adv, :2456-2467) from `init`: what a
+// bounded reader-function handle carries over the bytes it drops (stream_handle.hip).  One lane: 27 ns per sample, a few milliseconds per drop
+__global__ void k_dfpwm_state_at(const unsigned char *p, unsigned long long calls, unsigned long long adv, const DfInit init, int *out6) {
+    if (threadIdx.x || blockIdx.x) return;
+    DfDec d{};
+    if (init.on) { d.p.n = init.st[0]; d.p.strength = init.st[1]; d.p.pb = init.st[2]; d.lpf = init.st[3]; d.pn = init.st[4]; }
+    for (unsigned long long k = 0; k < calls; k++)
+        for (unsigned long long b = 0; b <= adv; b++) {
+            unsigned byte = p[k * adv + b];
+            for (int i = 0; i < 8; i++) { (void)df_decode_bit(d, byte & 1); byte >>= 1; }
+        }
+    out6[0] = d.p.n; out6[1] = d.p.strength; out6[2] = d.p.pb; out6[3] = d.lpf; out6[4] = d.pn; out6[5] = 0;
+}
+int dfpwm_state_after(aukit_ctx *ctx, const unsigned char *dev_bytes, uint64_t calls, uint64_t adv, const int *in6, bool in_on, int *out6) {
+    DfInit I{};
+    I.on = in_on ? 1 : 0;
+    if (in_on) for (int i = 0; i < 6; i++) I.st[i] = in6[i];
+    int rc = ctx->fmt_flag.ensure(128);
+    if (rc) return rc;
+    int *d6 = reinterpret_cast<int *>(ctx->fmt_flag.p) + 16;
+    hipLaunchKernelGGL(k_dfpwm_state_at, dim3(1), dim3(64), 0, ctx->stream, dev_bytes, (unsigned long long)calls, (unsigned long long)adv, I, d6);
+    if (hipGetLastError() != hipSuccess) return fail(AUKIT_E_HIP, "k_dfpwm_state_at launch failed");
+    if (hipMemcpyAsync(out6, d6, 24, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "reading the DFPWM state back failed");
+    return AUKIT_OK;
 }
 
 // stream.dfpwm on a 48 kHz file — what nearly every ComputerCraft DFPWM file is: ratio 1, every position x is an integer, `s = audio[x]`
@@ -388,7 +415,7 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
     uint64_t tot = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         const uint64_t nb = in->off[s + 1] - in->off[s];
-        ck->length_seconds[s] = (double)nb * 8 / d->sample_rate / C;
+        ck->length_seconds[s] = (double)(nb + ctx->sb_bytes) * 8 / d->sample_rate / C;
         rowo[s] = tot;
         uint64_t fed = 0;
         for (uint64_t pos = 0; pos < nb; pos += adv) {
@@ -414,7 +441,7 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
     for (uint32_t s = 0; s < in->n; s++)
         for (uint32_t k = 0; k < ck->nchunks[s]; k++) {
             ck->lens[(size_t)s * mc + k] = clen[s][k];
-            ck->pos[(size_t)s * mc + k] = (double)(k * adv + 1) * 8 / d->sample_rate / C;  // p * 8 / sampleRate / channels :2494
+            ck->pos[(size_t)s * mc + k] = (double)(ctx->sb_bytes + k * adv + 1) * 8 / d->sample_rate / C;  // p * 8 / sampleRate / channels :2494
         }
     int rc;
     aukit_audio *a = *out;
@@ -428,10 +455,15 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
         const unsigned long long *d_rowo = reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p);
         if (dfpwm_decode_parallel(ctx, in, 0, 1, reinterpret_cast<signed char *>(ctx->tmp_buf.p), d_rowo, nullptr, &prc, (uint64_t)adv, 1)) {  // chunk-parallel, exact (dfpwm_par.hip)
             if (prc) { delete ck; return prc; }
-            hipLaunchKernelGGL(k_row_heads_zero, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<signed char *>(ctx->tmp_buf.p), d_rowo, in->n);  // audio[0] of the first chunk = `last` = 0
-        } else
+            hipLaunchKernelGGL(k_row_heads_zero, dim3((in->n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<signed char *>(ctx->tmp_buf.p), d_rowo, in->n,
+                               ctx->sb_dfpwm_on ? ctx->sb_dfpwm[3] : 0);  // audio[0] of the first chunk = `last` = 0 (or the last sample in front of the rest of a stream)
+        } else {
+        DfInit I{};
+        I.on = ctx->sb_dfpwm_on ? 1 : 0;
+        for (int i = 0; i < 6; i++) I.st[i] = ctx->sb_dfpwm[i];
         hipLaunchKernelGGL(k_dfpwm_stream_rows, dim3((in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
-                           in->n, (unsigned long long)adv, reinterpret_cast<signed char *>(ctx->tmp_buf.p), reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p));
+                           in->n, (unsigned long long)adv, reinterpret_cast<signed char *>(ctx->tmp_buf.p), reinterpret_cast<const unsigned long long *>(ctx->misc_buf.p), I);
+        }
         AUKIT_HIP_CHECK(hipGetLastError());
         if (d->sample_rate == 48000 && !getenv("AUKIT_NO_FAST_CONVERT")) {  // ratio 1: a strided copy (k_dfpwm_stream_copy)
             if ((rc = upload_table(ctx, ctx->seg_buf, segs.data(), segs.size() * sizeof(Seg)))) { delete ck; return rc; }

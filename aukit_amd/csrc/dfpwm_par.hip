@@ -92,6 +92,7 @@ struct DfParParams {
     unsigned bpc;       // blocks per chunk
     unsigned nchunk;    // chunks per stream
     u64 W;              // block size in fed bytes
+    const int *init;    // [6]: the state every stream's decoder starts from (a bounded reader-function handle's rest of a stream); null: the reset state
     u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
     SatMap *maps;       // [n][nblk]
     int *s_start;       // [n][nblk + 1] strength at block starts
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
 __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
-    int st = 0;
+    int st = P.init ? P.init[1] : 0;
     int *o = P.s_start + (size_t)s * (P.nblk + 1);
-    o[0] = 0;
+    o[0] = st;
     for (unsigned b = 0; b < P.nblk; b++) { st = sm_apply(P.maps[(size_t)s * P.nblk + b], st); o[b + 1] = st; }
 }
 
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
     const DfOut O = dfp_out(P, s, lut);
     DfDec d{};
+    if (c == 0 && P.init) dfp_unpack(P.init, d);
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
@@ -566,7 +568,7 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     if (n == 0 || nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
     // scratch: stream table, maps, strengths, states, stats
     const size_t b_tab = (size_t)n * 16, b_maps = (size_t)n * nchunk * sizeof(SatMap), b_ss = (size_t)n * (nchunk + 1) * 4, b_st = (size_t)n * nchunk * 6 * 4;
-    if ((*rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + 2 * b_st + 256))) return true;
+    if ((*rc = ctx->tmp_buf2.ensure(b_tab + b_maps + b_ss + 2 * b_st + 256 + 64))) return true;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((*rc = h2d_table(ctx, B, h_off.data(), (size_t)n * 8)) || (*rc = h2d_table(ctx, B + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return true;
     DfParParams P{};
@@ -575,6 +577,12 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     P.maps = reinterpret_cast<SatMap *>(B + b_tab); P.s_start = reinterpret_cast<int *>(B + b_tab + b_maps);
     P.st_start = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss); P.st_end = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss + b_st);
     P.stats = reinterpret_cast<unsigned *>(B + b_tab + b_maps + b_ss + 2 * b_st);
+    P.init = nullptr;
+    if (ctx->sb_dfpwm_on && !hook) {
+        int *di = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss + 2 * b_st + 256);
+        if ((*rc = h2d_table(ctx, di, ctx->sb_dfpwm, 6 * sizeof(int)))) return true;
+        P.init = di;
+    }
     P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
     hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);

@@ -26,7 +26,9 @@
 //   * stream.flac (:3124-3191): as stream.qoa — whole frames per call, the two `last` samples of the block before — but where frames end is only known
 //     once they are decoded: the fused decoder's chunk table carries the byte behind every call's last frame (aukit_chunks::in_end), the rest
 //     starts there, one call early, behind the metadata blocks; the position carries on from the exact double the dropped calls had summed up.
-// stream.dfpwm / mdfpwm (the decoder's state crosses calls) keep the whole prefix.
+//   * stream.dfpwm (:2439-2496): one decoder runs through the whole stream; the rest starts at the next call with the decoder's state behind the
+//     dropped calls (one lane walks them: k_dfpwm_state_at) and its last output as `last`.
+// stream.mdfpwm keeps the whole prefix.
 #include <algorithm>
 #include "common.h"
 
@@ -52,6 +54,7 @@ struct aukit_stream {
     bool have_head16 = false;
     uint64_t sb_samples = 0;          // stream.qoa: decoded samples per channel dropped in front (file_pos, aukit.lua:3332)
     double sb_pos = 0;                // stream.flac: the position summed up by the dropped calls (:3188)
+    int df_state[6] = {0, 0, 0, 0, 0, 0};   // stream.dfpwm: the decoder's state behind the dropped calls (valid once sb_bytes > 0)
 };
 
 namespace aukit {
@@ -83,9 +86,11 @@ static int redecode(aukit_stream *h) {
     int rc = aukit_batch_wrap_device(h->ctx, &b, h->dbuf, off, 1);
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
-    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples; h->ctx->sb_pos = h->sb_pos;   // the rest of a stream: the factories add what was dropped to their positions
+    h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples; h->ctx->sb_pos = h->sb_pos;
+    h->ctx->sb_dfpwm_on = h->desc.codec == AUKIT_CODEC_DFPWM && h->sb_bytes > 0;
+    for (int i = 0; i < 6; i++) h->ctx->sb_dfpwm[i] = h->df_state[i];   // the rest of a stream: the factories add what was dropped to their positions
     rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
-    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0; h->ctx->sb_pos = 0;
+    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0; h->ctx->sb_pos = 0; h->ctx->sb_dfpwm_on = false;
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
     h->decoded_bytes_total += usable;
@@ -143,6 +148,13 @@ static Restart restart_rule(const aukit_stream *h) {
         r.call_outputs = (uint64_t)std::floor((double)(fpc * 5120) * (48000.0 / (double)fr));
         return r;
     }
+    case AUKIT_CODEC_DFPWM:
+        // stream.dfpwm (aukit.lua:2439-2496): ONE decoder runs through the whole stream (every call feeds it 6000 * channels + 1 bytes and moves on
+        // by 6000 * channels), and `last` is its last output — the rest of the stream starts at the next call with the decoder's STATE behind the
+        // dropped calls, computed by one lane over those bytes (k_dfpwm_state_at: 27 ns a sample, milliseconds per drop) and handed to the decode
+        if (d.sample_rate < 1 || C < 1) return r;
+        r.ok = true; r.call_bytes = 6000 * C;
+        return r;
     case AUKIT_CODEC_FLAC:
         // stream.flac (aukit.lua:3124-3191): an iterator call takes whole frames; all that reaches the next frame are the two `last` samples of the
         // block before it — the rest starts one call EARLIER (lead 1), behind the metadata blocks, which stay in front.  Where frames end is only
@@ -175,6 +187,12 @@ static int compact(aukit_stream *h) {
     (void)mc;
     uint64_t outs = 0;
     for (uint64_t m = 0; m < shift; m++) outs += h->ck->lens[m];
+    if (h->desc.codec == AUKIT_CODEC_DFPWM) {   // the decoder's state behind the `shift` dropped calls, from the state in front of this buffer
+        int st[6];
+        const int src = dfpwm_state_after(h->ctx, h->dbuf, shift, R.call_bytes, h->df_state, h->sb_bytes > 0, st);
+        if (src) return src;
+        for (int i = 0; i < 6; i++) h->df_state[i] = st[i];
+    }
     // the rest moves to the front of a buffer sized for it: memory follows the stream instead of growing with it
     const size_t rest = (size_t)(h->fed - drop);
     const size_t cap = std::max<size_t>(rest + rest / 2 + 4096, 1 << 16);
