@@ -1292,6 +1292,7 @@ struct FlacDecoded {
     bool in_scratch = false;
     std::vector<std::vector<uint32_t>> frame_end;   // fused decoder, want_frames: the byte behind every frame, relative to its stream's start (0: unknown)
     std::vector<uint64_t> first_frame;             // ... and where the stream's first frame starts (behind the metadata blocks)
+    std::vector<uint2> brief;                      // fused decoder, want_frames: (block size, end offset) of every frame in stream order — `frames` / `frame_end` are made of it on demand (frames_from_brief)
     bool scratch16 = false;   // ... as int16 (FusedArgs::out16: asked for by the loader's F32 resample path, depths <= 16)
     bool want16 = false;
     uint64_t tot_elems = 0;          // elements of the contiguous rows (row_off / row_len describe them whether they exist yet or not)
@@ -1513,6 +1514,11 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
     }
 }
 
+__global__ __launch_bounds__(256) void k_flac_frames_brief(const FrameRec *frames, u64 nfr, uint2 *out) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < nfr) out[i] = make_uint2((unsigned)frames[i].bs, frames[i].end_rel);
+}
+
 // The fused decoder (flac_fused.hip): find → k_flac_decode (final integers into the scratch) → chain → k_flac_gather (scratch → rows).
 // Returns AUKIT_OK, an error, or 2 = "the chain needs a frame k_flac_decode declined": the caller runs the first design (flac_run).
 static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool want_frames) {
@@ -1640,28 +1646,28 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         D.bs0.assign(n, 0);
         D.uniform = true;
         for (uint32_t s = 0; s < n; s++) { D.bs0[s] = chain[s].bs0; if (!chain[s].uniform) D.uniform = false; }
-        std::vector<FrameRec> hfr;
+        // what the host needs of the frame records (stream.flac's chunk table): block size and end offset — 8 of a record's 32 bytes come down
+        // (110 K records of a 1024-stream call: 3.5 MB and 0.15 ms of a call that is measured against 8 ms)
+        std::vector<uint2> hfr;
         if (want_frames && nfr) {
             hfr.resize(nfr);
-            AUKIT_HIP_CHECK(hipMemcpyAsync(hfr.data(), d_frames, nfr * sizeof(FrameRec), hipMemcpyDeviceToHost, ctx->stream));
+            if ((rc = ctx->tile_buf.ensure(nfr * sizeof(uint2) + 64))) return rc;
+            ctx->plan_key.clear();
+            hipLaunchKernelGGL(k_flac_frames_brief, dim3((unsigned)((nfr + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, nfr, reinterpret_cast<uint2 *>(ctx->tile_buf.p));
+            AUKIT_HIP_CHECK(hipGetLastError());
+            void *stage = ctx_host_stage(ctx, nfr * sizeof(uint2));   // (pinned: a pageable destination costs the copy a staging pass of its own)
+            AUKIT_HIP_CHECK(hipMemcpyAsync(stage ? stage : (void *)hfr.data(), ctx->tile_buf.p, nfr * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (stage) memcpy(hfr.data(), stage, nfr * sizeof(uint2));
         }
         D.frames.assign(n, {});
         D.d_frames = d_frames; D.d_fbase = d_fbase; D.d_rowoff = d_rowoff; D.fbase = fbase; D.nfr = nfr;
         D.nframes.assign(n, 0);
         for (uint32_t s = 0; s < n; s++) D.nframes[s] = chain[s].nframes;
-        if (want_frames) {
-            D.frame_end.assign(n, {});
+        if (want_frames) {   // (the per-stream vectors are host work the device does not wait for: stream.flac makes them after its tail kernel is launched)
+            D.brief = std::move(hfr);
             D.first_frame.assign(n, 0);
-            for (uint32_t s = 0; s < n; s++) {
-                D.frames[s].reserve(chain[s].nframes);
-                D.frame_end[s].reserve(chain[s].nframes);
-                D.first_frame[s] = D.info[s].first_byte;
-                for (unsigned f = 0; f < chain[s].nframes; f++) {
-                    D.frames[s].push_back({hfr[fbase[s] + f].sample_off, hfr[fbase[s] + f].bs});
-                    D.frame_end[s].push_back(hfr[fbase[s] + f].end_rel);
-                }
-            }
+            for (uint32_t s = 0; s < n; s++) D.first_frame[s] = D.info[s].first_byte;
         }
         D.wide = false;
         return AUKIT_OK;
@@ -1723,12 +1729,31 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     return flac_run<double>(ctx, in, D, want_frames);
 }
 
+static void frames_from_brief(FlacDecoded &D) {
+    if (D.brief.empty()) return;
+    const size_t n = D.nframes.size();
+    D.frames.assign(n, {});
+    D.frame_end.assign(n, {});
+    for (size_t s = 0; s < n; s++) {
+        D.frames[s].reserve(D.nframes[s]);
+        D.frame_end[s].reserve(D.nframes[s]);
+        uint64_t at = 0;   // (a frame's sample offset is the block sizes before it: the chain walk numbers them in order)
+        for (unsigned f = 0; f < D.nframes[s]; f++) {
+            const uint2 b = D.brief[D.fbase[s] + f];
+            D.frames[s].push_back({at, (int)b.x});
+            D.frame_end[s].push_back(b.y);
+            at += b.x;
+        }
+    }
+    D.brief.clear();
+}
+
 // aukit.flac(data)  aukit.lua:1657-1660
 int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *, double new_rate, int interp, bool do_resample, int dtype,
                       aukit_audio **out) {
     FlacDecoded D;
     if (*out && ((*out)->lazy_rs || (*out)->lazy_rows.p)) lazy_drop(ctx, *out);   // the output's old rows (a deferred resample nobody asked for) return to the scratch the decoder is about to use
-    D.want16 = do_resample && dtype == AUKIT_F32;   // the F32 resample path reads the frames in place (k_rs_onepole<..., short>) or gathers them: int16 finals halve both
+    D.want16 = true;   // every reader behind the loader takes int16 finals: the F32 resample path in place (k_rs_onepole<..., short>), the others through k_flac_gather
     int rc = flac_decode_rows(ctx, in, D, false);
     if (rc) return rc;
     for (uint32_t s = 0; s < in->n; s++)
@@ -1746,8 +1771,8 @@ int decode_flac_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         *out = a;
         if (!D.nfr) return AUKIT_OK;
         if ((rc = ctx_begin_kernel(ctx))) return rc;
-        if ((rc = flac_gather_convert_launch(ctx, D.d_frames, D.nfr, D.channels, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<const u64 *>(a->d_meta), in->n, a->dev, dtype, full))) return rc;
-        return ctx_end_kernel(ctx, "k_flac_gather<convert>", D.tot_elems * 4 + D.tot_elems * dtype_size(dtype));
+        if ((rc = flac_gather_convert_launch(ctx, D.d_frames, D.nfr, D.channels, reinterpret_cast<const int *>(ctx->tmp_buf3.p), reinterpret_cast<const u64 *>(a->d_meta), in->n, a->dev, dtype, full, D.scratch16))) return rc;
+        return ctx_end_kernel(ctx, "k_flac_gather<convert>", D.tot_elems * (D.scratch16 ? 2 : 4) + D.tot_elems * dtype_size(dtype));
     }
     if (!D.wide && do_resample && dtype == AUKIT_F32) {   // F32 pipelines: the resample is owed — a following effects.highpass / lowpass pays it in its own pass (flac_tail.hip)
         int lrc = AUKIT_OK;
@@ -1936,15 +1961,18 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
     ck->nchunks.assign(in->n, 0); ck->status.assign(in->n, 0); ck->length_seconds.assign(in->n, 0);
     std::vector<uint64_t> lens(in->n, 0);
     uint64_t max_nout = 0, sum_nout = 0, njobs = 0;
+    const bool brief = !D.brief.empty();
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t l = 0;
-        for (auto &fr : D.frames[s]) {
-            const uint64_t no = (uint64_t)std::floor((double)fr.second * ratio);   // every frame ends up in some call's chunk
+        const size_t nf = brief ? D.nframes[s] : D.frames[s].size();
+        for (size_t f = 0; f < nf; f++) {
+            const int bsz = brief ? (int)D.brief[D.fbase[s] + f].x : D.frames[s][f].second;
+            const uint64_t no = (uint64_t)std::floor((double)bsz * ratio);   // every frame ends up in some call's chunk
             l += no;
             max_nout = std::max(max_nout, no);
         }
         lens[s] = l;
-        sum_nout += l * (uint64_t)C; njobs += (uint64_t)C * D.frames[s].size();
+        sum_nout += l * (uint64_t)C; njobs += (uint64_t)C * nf;
     }
     lap("lens");
     // the chunk table (which frames an iterator call returns) is host work nothing on the device waits for: it is built AFTER the tail kernel has been
@@ -2012,6 +2040,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
                                  "k_iir_tail<flac>", &trc)) {
                 if (trc) { delete ck; return trc; }
                 lap("tail launch");
+                if (brief) frames_from_brief(D);
                 build_chunks();
                 lap("chunk table");
                 if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
@@ -2019,6 +2048,7 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             }
         }
     }
+    if (brief) frames_from_brief(D);
     build_chunks();
     if ((rc = flac_rows_materialize(ctx, D))) { delete ck; return rc; }
     std::vector<FsJob> jobs;

@@ -97,6 +97,6 @@ int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, un
 // chained frames: scratch → contiguous int32 rows (one workgroup per frame record)
 int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const u64 *row_off, const int *scratch, int *rows, bool scratch16 = false);   // scratch16: the frames hold int16 finals (FusedArgs::out16)
 // the same with the loader's conversion `s / 2^depth` (:505) into the rows of an audio (dtype AUKIT_F32 / AUKIT_F64; a_meta = len[n], row_off[n], row_stride[n])
-int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full);
+int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full, bool scratch16 = false);
 
 }  // namespace aukit

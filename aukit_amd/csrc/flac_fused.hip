@@ -761,8 +761,18 @@ __global__ __launch_bounds__(256) void k_flac_gather(const FrameRec *frames, int
         const short *base = reinterpret_cast<const short *>(scratch) + 2 * f.scratch;
         for (int c = 0; c < nch; c++) {
             const short *src = base + (u64)c * (u64)f.bs;
-            OUT *dst = rows + row_off[(size_t)f.stream * C + c] + f.sample_off;
-            for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = (OUT)src[i];
+            OUT *dst = rows + (row_off ? row_off[(size_t)f.stream * C + c] : a_meta[n + f.stream] + (u64)c * a_meta[2 * (size_t)n + f.stream]) + f.sample_off;
+            if constexpr (std::is_same<OUT, int>::value) { for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = (OUT)src[i]; }
+            else if ((((uintptr_t)src) & 7) == 0 && (((uintptr_t)dst) & 15) == 0 && (f.bs & 3) == 0) {   // four samples a turn: 8 bytes in, 16 / 32 out
+                for (int i = threadIdx.x; i < f.bs / 4; i += 256) {
+                    const uint2 v = reinterpret_cast<const uint2 *>(src)[i];
+                    typedef OUT ov4 __attribute__((ext_vector_type(4), aligned(16)));
+                    ov4 w;
+                    w[0] = (OUT)((double)(short)(v.x & 0xFFFF) * inv_full); w[1] = (OUT)((double)((int)v.x >> 16) * inv_full);
+                    w[2] = (OUT)((double)(short)(v.y & 0xFFFF) * inv_full); w[3] = (OUT)((double)((int)v.y >> 16) * inv_full);
+                    *reinterpret_cast<ov4 *>(dst + 4 * i) = w;
+                }
+            } else { for (int i = threadIdx.x; i < f.bs; i += 256) dst[i] = (OUT)((double)src[i] * inv_full); }
         }
         return;
     }
@@ -798,8 +808,14 @@ int flac_gather_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, c
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
 }
-int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full) {
+int flac_gather_convert_launch(aukit_ctx *ctx, const FrameRec *frames, u64 nfr, int C, const int *scratch, const u64 *a_meta, unsigned n, void *out, int dtype, double full, bool scratch16) {
     if (!nfr) return AUKIT_OK;
+    if (scratch16) {
+        if (dtype == AUKIT_F32) hipLaunchKernelGGL((k_flac_gather<float, true>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<float *>(out), 1.0 / full);
+        else hipLaunchKernelGGL((k_flac_gather<double, true>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<double *>(out), 1.0 / full);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        return AUKIT_OK;
+    }
     if (dtype == AUKIT_F32) hipLaunchKernelGGL((k_flac_gather<float>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<float *>(out), 1.0 / full);
     else hipLaunchKernelGGL((k_flac_gather<double>), dim3((unsigned)nfr), dim3(256), 0, ctx->stream, frames, C, (const u64 *)nullptr, a_meta, n, scratch, reinterpret_cast<double *>(out), 1.0 / full);
     AUKIT_HIP_CHECK(hipGetLastError());
