@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "resample.h"
 #include "flac_dev.h"
+#include "stream_tail.h"
 
 namespace aukit {
 
@@ -51,6 +52,11 @@ struct RsOnepoleParams {
     // non-independent effects.normalize in between divides by, :3439-3444); wave_lds = floats of LDS per wave
     unsigned long long *rowmax2;
     int wave_lds;
+    // JOBS (round 4, last): a workgroup's work item is not a row of an audio but a JOB of stream.qoa's tail (stream_tail.h: one iterator call's chunk of one
+    // channel — or of all its channels, NW = 2, whose mean is stored): its own table (n samples at src_off, the history sample `last[2]` as table index 0,
+    // :3255), its own outputs, the low-pass seeded with the history sample (:3316), interpolated samples clamped to [clo, chi] (:3323)
+    const TailJob *jobs;
+    float clo, chi;
 };
 
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
@@ -70,7 +76,7 @@ AUKIT_DEV double dpp_f64(double v) {
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
-template <int INTERP, bool HP, bool TAB, typename S, int NW = 1>
+template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
     extern __shared__ float rsm_all[];
     constexpr int E = 8, T = 64 * E;
@@ -87,12 +93,24 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
         if constexpr (NW > 1) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     }
     const int lane = (int)(threadIdx.x & 63u);
-    const unsigned r = NW > 1 ? (blockIdx.x / (unsigned)P.segs) * (unsigned)NW + wv : blockIdx.x / (unsigned)P.segs;
-    const unsigned seg = blockIdx.x % (unsigned)P.segs, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
-    const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
-    const int L = (int)P.row_len[r];
     const S *const rows_s = reinterpret_cast<const S *>(P.rows);
-    const S *row = rows_s + P.row_off[r];
+    unsigned r = 0, seg = 0, s = 0, c = 0;
+    unsigned long long nout = 0, obase = 0;
+    int L = 0, hist = 0;
+    const S *row = rows_s;
+    if constexpr (JOBS) {
+        const TailJob jb = P.jobs[blockIdx.x];
+        c = wv;
+        nout = (unsigned long long)jb.nout; obase = jb.out_off; L = jb.n;
+        row = rows_s + jb.src_off + (unsigned long long)c * jb.src_cstride;
+        if (jb.last_off != ~0ull) hist = (int)rows_s[jb.last_off + (unsigned long long)c * jb.last_cstride];
+    } else {
+        r = NW > 1 ? (blockIdx.x / (unsigned)P.segs) * (unsigned)NW + wv : blockIdx.x / (unsigned)P.segs;
+        seg = blockIdx.x % (unsigned)P.segs; s = r / (unsigned)P.C; c = r - s * (unsigned)P.C;
+        nout = P.a_meta[s]; obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
+        L = (int)P.row_len[r];
+        row = rows_s + P.row_off[r];
+    }
     float *orow = P.out + obase;
     // the slope of the recurrence's affine map y -> m y + ...: a (high-pass, :3614), 1 - alpha (low-pass, :3594)
     const double m = HP ? P.coef : 1.0 - P.coef;
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
     auto skew = [](int i) { return i + i / E; };
     float mxf = 0.f;
-    double carry_y = 0.0, carry_x = 0.0;   // state and raw sample of the output before the tile (wave-uniform)
+    double carry_y = JOBS ? (double)((float)hist * (hist < 0 ? P.scale_neg : P.scale)) : 0.0, carry_x = 0.0;   // state and raw sample of the output before the tile (wave-uniform); JOBS: ls = last[2]  (:3316)
     // x - 1 = o fa / fb exactly.  The tile's first output: (kb, r0) advanced by additions from tile to tile (T fa = wc fb + wd); the outputs inside it
     // from there (n < fb + T fa: the magic division is exact, as in the wave kernels)
     const unsigned wc = (unsigned)(((unsigned long long)T * P.fa) / P.fb), wd = (unsigned)(((unsigned long long)T * P.fa) % P.fb);
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
             const unsigned k = kk + (unsigned)j;
             const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
             const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
-            pre[u] = (j < nst && L > 0) ? (int)*src : 0;
+            pre[u] = (j < nst && L > 0) ? ((JOBS && k == 0u) ? hist : (int)*src) : 0;   // (JOBS: table index 0 is the history sample, not the edge)
         }
     };
     int pre[8];
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
                         const float c1 = 0.5f * (p2 - p0);
                         v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
                     }
-                    xb[skew(idx)] = __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);   // :667-668 (rem == 0: v is p1 itself)
+                    xb[skew(idx)] = JOBS ? __builtin_amdgcn_fmed3f(v, P.clo, P.chi) : __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);   // :667-668 (rem == 0: v is p1 itself); JOBS: :3323
                 }
             }
         }
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
         double z[E];
         {
             double xp = (e0 == 0) ? carry_x : ((FULL || e0 <= cnt) ? (double)xb[skew(e0 - 1)] : 0.0);
-            const bool first = o0 == 0 && lane == 0;
+            const bool first = !JOBS && o0 == 0 && lane == 0;
             double y = 0.0;
 #pragma unroll
             for (int i = 0; i < E; i++) {
@@ -420,8 +438,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     }
     if constexpr (NW > 1) { if (mix_cnt) mix_out(); }
     for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
+    if constexpr (!JOBS) {
     if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));
-    if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
+    if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }
+    }   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
 }
 
 // ---------------------------------------------------------------- the lazy state
@@ -646,6 +666,68 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     a->lazy_fx = 0;
     lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
     *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_bytes + out_elems * 4);
+    return true;
+}
+
+// stream.qoa's tail (aukit.lua:3312-3330) on k_rs_onepole<..., JOBS>: interpolate -> clamp -> low-pass seeded with the history sample -> chunk sample
+// (or the channels' mean), one workgroup per job, from the decoder's int8-range rows.  The kernel k_iir_tail_fast (stream_tail.hip) does the same
+// with self-contained tiles that warm up (≈ 44 instructions per output, 2.4 ps per output on 4096 streams); this one carries the state from tile
+// to tile (1.5 ps).  false: not this shape (the caller keeps k_iir_tail)
+bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<TailJob> &jobs, int mix_channels, double rate, int interp, double lp_alpha, float *out,
+                         uint64_t algorithmic_bytes, const char *name, int *rc) {
+    *rc = AUKIT_OK;
+    if (getenv("AUKIT_NO_RS_JOBS") || ctx->exact_math || jobs.empty()) return false;
+    if (mix_channels != 1 && mix_channels != 2) return false;
+    if (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) return false;
+    FastParams F;
+    if (!fast_eligible(SRC_PCM8_MONO, interp, rate, 48000, F)) return false;
+    constexpr int T = 512;
+    if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;
+    if (!(lp_alpha > 0 && lp_alpha < 1)) return false;
+    for (const TailJob &j : jobs) if (j.n <= 0 || j.nout < 0 || (uint64_t)j.n > 0x7FFFFFF0ull) return false;
+    const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3) + 32;
+    const bool tabw = interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
+    const int NWh = mix_channels;
+    const size_t wave_lds = (size_t)cap + T + T / 8 + 8;
+    const size_t lds = ((size_t)NWh * wave_lds + (tabw ? ((4 * (size_t)F.b + 3) & ~(size_t)3) : 0) + (NWh > 1 ? (size_t)NWh * (T + T / 8 + 8) : 0)) * 4;
+    if (lds > 60 * 1024) return false;
+    if (hipSetDevice(ctx->device) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipSetDevice failed"); return true; }
+    if ((*rc = upload_table(ctx, ctx->misc_buf, jobs.data(), jobs.size() * sizeof(TailJob)))) return true;
+    RsOnepoleParams P{};
+    P.rows = rows_i8;
+    P.jobs = reinterpret_cast<const TailJob *>(ctx->misc_buf.p);
+    P.out = out;
+    P.n = 0; P.C = 1; P.cap = cap;
+    P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
+    P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);
+    P.scale = P.scale_neg = 1.0f;
+    P.coef = lp_alpha;
+    P.segs = 1; P.warm = 0; P.novec = getenv("AUKIT_RS_NOVEC") ? 1 : 0; P.fr_mul = 1;
+    P.wave_lds = (int)wave_lds;
+    P.clo = -128.0f; P.chi = 127.0f;
+    if (tabw) {
+        std::vector<float> w(4 * (size_t)F.b);
+        for (unsigned r = 0; r < F.b; r++) {
+            const long double f = (long double)r / (long double)F.b, f2 = f * f, f3 = f2 * f;
+            w[4 * r] = (float)(-0.5L * f3 + f2 - 0.5L * f); w[4 * r + 1] = (float)(1.5L * f3 - 2.5L * f2 + 1.0L);
+            w[4 * r + 2] = (float)(-1.5L * f3 + 2.0L * f2 + 0.5L * f); w[4 * r + 3] = (float)(0.5L * f3 - 0.5L * f2);
+        }
+        if ((*rc = upload_table(ctx, ctx->tile_buf, w.data(), w.size() * 4))) return true;
+        P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
+    }
+    if ((*rc = ctx_begin_kernel(ctx))) return true;
+    const dim3 grid((unsigned)jobs.size());
+#define AUKIT_RSJ(I, Tb)                                                                                                                              \
+    do {                                                                                                                                              \
+        if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, signed char, 2, true>), grid, dim3(128), lds, ctx->stream, P);                   \
+        else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, signed char, 1, true>), grid, dim3(64), lds, ctx->stream, P);                             \
+    } while (0)
+    if (interp == AUKIT_INTERP_LINEAR) AUKIT_RSJ(AUKIT_INTERP_LINEAR, false);
+    else if (tabw) AUKIT_RSJ(AUKIT_INTERP_CUBIC, true);
+    else AUKIT_RSJ(AUKIT_INTERP_CUBIC, false);
+#undef AUKIT_RSJ
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole<jobs> launch failed"); return true; }
+    *rc = ctx_end_kernel(ctx, name, algorithmic_bytes);
     return true;
 }
 

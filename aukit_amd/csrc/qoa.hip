@@ -484,6 +484,11 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d,
             }
         }
         int trc = AUKIT_OK;
+        const double lp_alpha = 1 - std::exp(-(rate / 96000) * 2 * M_PI);   // :3250
+        if (dtype == AUKIT_F32 && (!mix || C == 2) &&
+            rs_onepole_jobs_try(ctx, ctx->tmp_buf.p, jobs, mix ? C : 1, rate, interp, lp_alpha, reinterpret_cast<float *>(a->dev), tot + total_out * dtype_size(dtype), "k_rs_onepole<qoa>", &trc)) {
+            // (the tile chain of flac_tail.hip: the state carried, not warmed up)
+        } else
         if (!iir_tail_try(ctx, TAIL_QOA, TAIL_ROWS_I8, ctx->tmp_buf.p, 1.0, jobs, mix ? C : 1, rate, interp, dtype, a->dev, tot + total_out * dtype_size(dtype), "k_iir_tail<qoa>", &trc)) {
             delete ck;
             return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);   // very low sample rates: the filter's memory outlasts a tile's warm-up

@@ -33,4 +33,8 @@ bool iir_tail_served(aukit_ctx *ctx, int kind, int rows_kind, int mix_channels, 
 bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows, double full, const TailJob *d_jobs, size_t njobs, uint64_t max_nout, uint64_t sum_nout,
                       int mix_channels, double rate, int interp, int dtype, void *out, uint64_t algorithmic_bytes, const char *name, int *rc);
 
+// the same tail for stream.qoa with F32 storage on the tile chain of k_rs_onepole (flac_tail.hip): state carried from tile to tile instead of warmed up per tile
+bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<TailJob> &jobs, int mix_channels, double rate, int interp, double lp_alpha, float *out,
+                         uint64_t algorithmic_bytes, const char *name, int *rc);
+
 }  // namespace aukit
