@@ -465,7 +465,7 @@ def test_stream_qoa(ctx, oracle, ch, mono, interp):
 
 @pytest.mark.parametrize("rate", [44100, 22050, 8000, 48000, 32000])
 @pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
-def test_stream_qoa_f32_tail(ctx, oracle, ch, mono, rate):
+def test_stream_qoa_f32_tail(ctx, oracle, monkeypatch, ch, mono, rate):
     """F32 storage: stream.qoa's tail (interpolation, clamp, recursive low-pass, channel mean) runs in ONE launch from the int8 rows with the
     interpolation in f32 (k_iir_tail_fast, stream_tail.hip).  Tolerance path: 1e-6 RMS of the [-128, 127] scale, and no single
     sample off by more than 1e-4 of it; the chunk plan is the exact path's."""
@@ -474,8 +474,18 @@ def test_stream_qoa_f32_tail(ctx, oracle, ch, mono, rate):
     bt = B.Batch.upload(ctx, streams)
     for interp in ("none", "linear", "cubic"):
         out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F32)
-        assert ctx.last_kernel()[0].startswith("k_iir_tail"), ctx.last_kernel()
+        # linear / cubic: the tile chain of k_rs_onepole (state carried from tile to tile: round 4); "none": the warm-up tiles of k_iir_tail_fast
+        assert ctx.last_kernel()[0] == ("k_iir_tail<qoa>" if interp == "none" else "k_rs_onepole<qoa>"), ctx.last_kernel()
         got = out.download()
+        if interp != "none":
+            monkeypatch.setenv("AUKIT_NO_RS_JOBS", "1")
+            out2, _ = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F32)
+            monkeypatch.delenv("AUKIT_NO_RS_JOBS")
+            assert ctx.last_kernel()[0] == "k_iir_tail<qoa>", ctx.last_kernel()
+            got2 = out2.download()
+            for i in range(len(streams)):
+                for c in range(len(got[i])):
+                    assert np.max(np.abs(got[i][c] - got2[i][c]), initial=0) <= 1e-4, (interp, i, c)   # (two f32 evaluations of the same taps; [-128, 127] scale)
         for i, s in enumerate(streams):
             ref = oracle.stream_qoa(s, mono, oracle.INTERP[interp])
             assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
