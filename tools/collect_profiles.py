@@ -46,7 +46,7 @@ for kernel, tag, pat, nstreams in DOMINANT:
                     "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)})
 # multi-launch workloads: HBM bytes of ONE step = every aukit kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over the run, divided by the number of
 # steps the run made = the dispatches of a kernel that is launched once per step (the anchor)
-STEPS = [("flac_pipeline", "flac", "k_flac_find", 2048), ("qoa_stream", "qoa", "k_iir_tail", 4096), ("dfpwm_transcode", "dfpwm", "k_df_fused", 16384),
+STEPS = [("flac_pipeline", "flac", "k_flac_find", 2048), ("qoa_stream", "qoa", "k_qoa_wave", 4096), ("dfpwm_transcode", "dfpwm", "k_df_fused", 16384),
          ("ima_pipeline", "imapipe", "onepole", 4096)]
 
 
