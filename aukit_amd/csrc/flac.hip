@@ -2036,6 +2036,17 @@ int stream_flac(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *,
             if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_flac_tail_jobs launch failed"); }
             lap("plan + jobs");
             int trc = AUKIT_OK;
+            if (rk == TAIL_ROWS_I32 && dtype == AUKIT_F32 &&
+                rs_onepole_jobs_try_dev(ctx, D.in_scratch ? ctx->tmp_buf3.p : ctx->tmp_buf.p, fullv, dj, njobs, D.rate, interp, lp_alpha, reinterpret_cast<float *>(a->dev),
+                                        in->total() + sum_nout * dtype_size(dtype), "k_rs_onepole<flac>", &trc)) {   // the tile chain of flac_tail.hip (state carried from tile to tile, a workgroup takes frame after frame)
+                if (trc) { delete ck; return trc; }
+                lap("tail launch");
+                if (brief) frames_from_brief(D);
+                build_chunks();
+                lap("chunk table");
+                if (chunks_out) { if (*chunks_out) aukit_chunks_free(*chunks_out); *chunks_out = ck; } else delete ck;
+                return AUKIT_OK;
+            }
             if (iir_tail_try_dev(ctx, TAIL_FLAC, rk, D.in_scratch ? ctx->tmp_buf3.p : ctx->tmp_buf.p, fullv, dj, njobs, max_nout, sum_nout, 1, D.rate, interp, dtype, a->dev, in->total() + sum_nout * dtype_size(dtype),
                                  "k_iir_tail<flac>", &trc)) {
                 if (trc) { delete ck; return trc; }

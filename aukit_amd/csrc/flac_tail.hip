@@ -56,6 +56,8 @@ struct RsOnepoleParams {
     // channel — or of all its channels, NW = 2, whose mean is stored): its own table (n samples at src_off, the history sample `last[2]` as table index 0,
     // :3255), its own outputs, the low-pass seeded with the history sample (:3316), interpolated samples clamped to [clo, chi] (:3323)
     const TailJob *jobs;
+    unsigned njobs;
+    int epi;   // 1: stream.flac's seed and store scaling (above)
     float clo, chi;
 };
 
@@ -76,7 +78,7 @@ AUKIT_DEV double dpp_f64(double v) {
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
-template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false>
+template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false, bool LOOPJ = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
     extern __shared__ float rsm_all[];
     constexpr int E = 8, T = 64 * E;
@@ -94,24 +96,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     }
     const int lane = (int)(threadIdx.x & 63u);
     const S *const rows_s = reinterpret_cast<const S *>(P.rows);
-    unsigned r = 0, seg = 0, s = 0, c = 0;
-    unsigned long long nout = 0, obase = 0;
-    int L = 0, hist = 0;
-    const S *row = rows_s;
-    if constexpr (JOBS) {
-        const TailJob jb = P.jobs[blockIdx.x];
-        c = wv;
-        nout = (unsigned long long)jb.nout; obase = jb.out_off; L = jb.n;
-        row = rows_s + jb.src_off + (unsigned long long)c * jb.src_cstride;
-        if (jb.last_off != ~0ull) hist = (int)rows_s[jb.last_off + (unsigned long long)c * jb.last_cstride];
-    } else {
-        r = NW > 1 ? (blockIdx.x / (unsigned)P.segs) * (unsigned)NW + wv : blockIdx.x / (unsigned)P.segs;
-        seg = blockIdx.x % (unsigned)P.segs; s = r / (unsigned)P.C; c = r - s * (unsigned)P.C;
-        nout = P.a_meta[s]; obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
-        L = (int)P.row_len[r];
-        row = rows_s + P.row_off[r];
-    }
-    float *orow = P.out + obase;
     // the slope of the recurrence's affine map y -> m y + ...: a (high-pass, :3614), 1 - alpha (low-pass, :3594)
     const double m = HP ? P.coef : 1.0 - P.coef;
     double mp[E + 1];   // m^1 .. m^E (mp[0] = 1)
@@ -128,11 +112,35 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     const double mB = lane >= 32 ? pow(mp[E], (double)(lane - 31)) : 0.0;
     const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
     auto skew = [](int i) { return i + i / E; };
+    const unsigned wc = (unsigned)(((unsigned long long)T * P.fa) / P.fb), wd = (unsigned)(((unsigned long long)T * P.fa) % P.fb);
+    // JOBS: a workgroup takes job after job (short jobs — a FLAC frame is nine tiles — would otherwise pay the set-up above once each)
+    auto run_item = [&](const unsigned item) {
+    unsigned r = 0, seg = 0, s = 0, c = 0;
+    unsigned long long nout = 0, obase = 0;
+    int L = 0, hist = 0;
+    const S *row = rows_s;
+    if constexpr (JOBS) {
+        const TailJob jb = P.jobs[item];
+        c = wv;
+        nout = (unsigned long long)jb.nout; obase = jb.out_off; L = jb.n;
+        row = rows_s + jb.src_off + (unsigned long long)c * jb.src_cstride;
+        if (jb.last_off != ~0ull) hist = (int)rows_s[jb.last_off + (unsigned long long)c * jb.last_cstride];
+    } else {
+        r = NW > 1 ? (item / (unsigned)P.segs) * (unsigned)NW + wv : item / (unsigned)P.segs;
+        seg = item % (unsigned)P.segs; s = r / (unsigned)P.C; c = r - s * (unsigned)P.C;
+        nout = P.a_meta[s]; obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
+        L = (int)P.row_len[r];
+        row = rows_s + P.row_off[r];
+    }
+    float *orow = P.out + obase;
     float mxf = 0.f;
-    double carry_y = JOBS ? (double)((float)hist * (hist < 0 ? P.scale_neg : P.scale)) : 0.0, carry_x = 0.0;   // state and raw sample of the output before the tile (wave-uniform); JOBS: ls = last[2]  (:3316)
+    double carry_y = 0.0, carry_x = 0.0;
+    if constexpr (JOBS) {   // ls = last[2] (stream.qoa :3316), or last[2] / (last[2] < 0 and 128 or 127) (stream.flac :3172)
+        const double z0 = (double)((float)hist * (hist < 0 ? P.scale_neg : P.scale));
+        carry_y = P.epi ? z0 / (z0 < 0 ? 128.0 : 127.0) : z0;
+    }
     // x - 1 = o fa / fb exactly.  The tile's first output: (kb, r0) advanced by additions from tile to tile (T fa = wc fb + wd); the outputs inside it
     // from there (n < fb + T fa: the magic division is exact, as in the wave kernels)
-    const unsigned wc = (unsigned)(((unsigned long long)T * P.fa) / P.fb), wd = (unsigned)(((unsigned long long)T * P.fa) % P.fb);
     unsigned kb = 0, r0 = 0;   // (row lengths stay below 2^31: checked by the host)
     // the window of a tile: table indices kb .. kb + nst - 1, clamped into 1 .. #data — the nil fall-backs of interpolate.{linear,cubic} (:259, :264)
     // are the edge samples repeated.  Its first 512 entries travel through registers, loaded one tile AHEAD (a row is a serial chain of tiles:
@@ -393,6 +401,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
             if (emit && (FULL || e0 + i < cnt)) mxf = fmaxf(mxf, fabsf(res[i]));
             if (!FULL && e0 + i == cnt - 1) ylast = yv;
         }
+        if constexpr (JOBS) {
+            if (P.epi) {   // stream.flac: dest[d] = clamp(s * (s < 0 and 128 or 127), -128, 127)  (:3181; the recurrence itself carries s)
+#pragma unroll
+                for (int i = 0; i < E; i++) res[i] = __builtin_amdgcn_fmed3f(res[i] * (res[i] < 0.f ? 128.f : 127.f), -128.f, 127.f);
+            }
+        }
         // the lane that holds the tile's last output hands its state to the next tile
         if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
         else carry_y = __shfl(ylast, (cnt - 1) / E);
@@ -442,6 +456,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));
     if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }
     }   // the largest |stored value|, as k_onepole reports it (bit patterns of non-negative doubles order like the values; zeroed by the host)
+    };   // run_item
+    if constexpr (LOOPJ) { for (unsigned item = blockIdx.x; item < P.njobs; item += gridDim.x) run_item(item); }   // (short jobs: several per workgroup)
+    else run_item(blockIdx.x);   // (not a loop that runs once: as one hipcc spilled 15 - 18 registers of the audio kernels and 7 of the long-job ones)
 }
 
 // ---------------------------------------------------------------- the lazy state
@@ -669,22 +686,22 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     return true;
 }
 
-// stream.qoa's tail (aukit.lua:3312-3330) on k_rs_onepole<..., JOBS>: interpolate -> clamp -> low-pass seeded with the history sample -> chunk sample
-// (or the channels' mean), one workgroup per job, from the decoder's int8-range rows.  The kernel k_iir_tail_fast (stream_tail.hip) does the same
-// with self-contained tiles that warm up (≈ 44 instructions per output, 2.4 ps per output on 4096 streams); this one carries the state from tile
-// to tile (1.5 ps).  false: not this shape (the caller keeps k_iir_tail)
-bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<TailJob> &jobs, int mix_channels, double rate, int interp, double lp_alpha, float *out,
-                         uint64_t algorithmic_bytes, const char *name, int *rc) {
+// stream.qoa's / stream.flac's tail (aukit.lua:3312-3330, :3166-3183) on k_rs_onepole<..., JOBS>: interpolate [-> clamp] -> low-pass seeded with the
+// history sample -> chunk sample (or the channels' mean), from the decoder's integer rows.  The kernel k_iir_tail_fast (stream_tail.hip) does
+// the same with self-contained tiles that warm up (≈ 44 instructions per output, 2.4 ps per output on 4096 QOA streams); this one carries the
+// state from tile to tile (1.7 ps).  false: not this shape (the caller keeps k_iir_tail)
+static bool rs_onepole_jobs_launch(aukit_ctx *ctx, const void *rows, bool rows_i32, double full, int epi, const TailJob *d_jobs, size_t njobs, bool long_jobs, int mix_channels, double rate,
+                                   int interp, double lp_alpha, float *out, uint64_t algorithmic_bytes, const char *name, int *rc) {
     *rc = AUKIT_OK;
-    if (getenv("AUKIT_NO_RS_JOBS") || ctx->exact_math || jobs.empty()) return false;
+    if (getenv("AUKIT_NO_RS_JOBS") || ctx->exact_math || !njobs) return false;
     if (mix_channels != 1 && mix_channels != 2) return false;
     if (interp != AUKIT_INTERP_LINEAR && interp != AUKIT_INTERP_CUBIC) return false;
     FastParams F;
-    if (!fast_eligible(SRC_PCM8_MONO, interp, rate, 48000, F)) return false;
+    if (!fast_eligible(rows_i32 ? SRC_I32 : SRC_PCM8_MONO, interp, rate, 48000, F)) return false;
+    if (rows_i32) { int e = 0; if (std::frexp(full, &e) != 0.5 || full > 16777216.0) return false; }   // v / full must be an exact f32 operation
     constexpr int T = 512;
     if (((double)F.b + (double)T * (double)F.a) * (double)F.b >= 4294967296.0) return false;
     if (!(lp_alpha > 0 && lp_alpha < 1)) return false;
-    for (const TailJob &j : jobs) if (j.n <= 0 || j.nout < 0 || (uint64_t)j.n > 0x7FFFFFF0ull) return false;
     const int cap = std::max(512, ((int)(((unsigned long long)T * F.a) / F.b) + 16 + 3) & ~3) + 32;
     const bool tabw = interp == AUKIT_INTERP_CUBIC && F.b <= 512 && !getenv("AUKIT_RS_HORNER");
     const int NWh = mix_channels;
@@ -692,19 +709,20 @@ bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<
     const size_t lds = ((size_t)NWh * wave_lds + (tabw ? ((4 * (size_t)F.b + 3) & ~(size_t)3) : 0) + (NWh > 1 ? (size_t)NWh * (T + T / 8 + 8) : 0)) * 4;
     if (lds > 60 * 1024) return false;
     if (hipSetDevice(ctx->device) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipSetDevice failed"); return true; }
-    if ((*rc = upload_table(ctx, ctx->misc_buf, jobs.data(), jobs.size() * sizeof(TailJob)))) return true;
     RsOnepoleParams P{};
-    P.rows = rows_i8;
-    P.jobs = reinterpret_cast<const TailJob *>(ctx->misc_buf.p);
+    P.rows = rows;
+    P.jobs = d_jobs;
+    P.njobs = (unsigned)njobs;
     P.out = out;
     P.n = 0; P.C = 1; P.cap = cap;
     P.fa = F.a; P.fb = F.b; P.fmagic = F.magic; P.inv_b = F.inv_b;
     P.dq256 = (unsigned)((64ull * F.a) / F.b); P.dr256 = (unsigned)((64ull * F.a) % F.b);
-    P.scale = P.scale_neg = 1.0f;
+    P.scale = P.scale_neg = rows_i32 ? (float)(1.0 / full) : 1.0f;
     P.coef = lp_alpha;
     P.segs = 1; P.warm = 0; P.novec = getenv("AUKIT_RS_NOVEC") ? 1 : 0; P.fr_mul = 1;
     P.wave_lds = (int)wave_lds;
-    P.clo = -128.0f; P.chi = 127.0f;
+    P.epi = epi;
+    P.clo = epi ? -3.0e38f : -128.0f; P.chi = epi ? 3.0e38f : 127.0f;   // (stream.flac does not clamp the interpolated sample, :3177-3178)
     if (tabw) {
         std::vector<float> w(4 * (size_t)F.b);
         for (unsigned r = 0; r < F.b; r++) {
@@ -716,19 +734,43 @@ bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<
         P.wg = reinterpret_cast<const float *>(ctx->tile_buf.p);
     }
     if ((*rc = ctx_begin_kernel(ctx))) return true;
-    const dim3 grid((unsigned)jobs.size());
-#define AUKIT_RSJ(I, Tb)                                                                                                                              \
+    // long jobs (an iterator call of stream.qoa: ~ 100 tiles): a workgroup each — measured 6.8 ms against 7.6 for workgroups that take five in turn;
+    // short ones (a FLAC frame: nine tiles): a workgroup takes several in turn and pays the set-up in front of its tile loop once
+    const dim3 grid((unsigned)((long_jobs || NWh > 1) ? njobs : std::min<size_t>(njobs, (size_t)ctx->num_cus * 64)));
+#define AUKIT_RSJ(I, Tb, S)                                                                                                                           \
     do {                                                                                                                                              \
-        if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, signed char, 2, true>), grid, dim3(128), lds, ctx->stream, P);                   \
-        else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, signed char, 1, true>), grid, dim3(64), lds, ctx->stream, P);                             \
+        if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 2, true, false>), grid, dim3(128), lds, ctx->stream, P);                      \
+        else if (long_jobs) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, false>), grid, dim3(64), lds, ctx->stream, P);                 \
+        else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, true>), grid, dim3(64), lds, ctx->stream, P);                                 \
     } while (0)
-    if (interp == AUKIT_INTERP_LINEAR) AUKIT_RSJ(AUKIT_INTERP_LINEAR, false);
-    else if (tabw) AUKIT_RSJ(AUKIT_INTERP_CUBIC, true);
-    else AUKIT_RSJ(AUKIT_INTERP_CUBIC, false);
+#define AUKIT_RSJS(S)                                                                                                                                 \
+    do {                                                                                                                                              \
+        if (interp == AUKIT_INTERP_LINEAR) AUKIT_RSJ(AUKIT_INTERP_LINEAR, false, S);                                                                  \
+        else if (tabw) AUKIT_RSJ(AUKIT_INTERP_CUBIC, true, S);                                                                                        \
+        else AUKIT_RSJ(AUKIT_INTERP_CUBIC, false, S);                                                                                                 \
+    } while (0)
+    if (rows_i32) AUKIT_RSJS(int); else AUKIT_RSJS(signed char);
+#undef AUKIT_RSJS
 #undef AUKIT_RSJ
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole<jobs> launch failed"); return true; }
     *rc = ctx_end_kernel(ctx, name, algorithmic_bytes);
     return true;
+}
+
+bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<TailJob> &jobs, int mix_channels, double rate, int interp, double lp_alpha, float *out,
+                         uint64_t algorithmic_bytes, const char *name, int *rc) {
+    *rc = AUKIT_OK;
+    if (getenv("AUKIT_NO_RS_JOBS") || ctx->exact_math || jobs.empty()) return false;
+    for (const TailJob &j : jobs) if (j.n <= 0 || j.nout < 0) return false;
+    if ((*rc = upload_table(ctx, ctx->misc_buf, jobs.data(), jobs.size() * sizeof(TailJob)))) return true;
+    uint64_t sum_out = 0;
+    for (const TailJob &j : jobs) sum_out += (uint64_t)j.nout;
+    return rs_onepole_jobs_launch(ctx, rows_i8, false, 1.0, 0, reinterpret_cast<const TailJob *>(ctx->misc_buf.p), jobs.size(), sum_out / jobs.size() >= 32 * 512, mix_channels, rate, interp, lp_alpha, out, algorithmic_bytes, name, rc);
+}
+// stream.flac: int32 rows (v / full), the jobs already on the device (k_flac_tail_jobs)
+bool rs_onepole_jobs_try_dev(aukit_ctx *ctx, const void *rows_i32, double full, const TailJob *d_jobs, size_t njobs, double rate, int interp, double lp_alpha, float *out,
+                             uint64_t algorithmic_bytes, const char *name, int *rc) {
+    return rs_onepole_jobs_launch(ctx, rows_i32, true, full, 1, d_jobs, njobs, false, 1, rate, interp, lp_alpha, out, algorithmic_bytes, name, rc);
 }
 
 }  // namespace aukit

@@ -36,5 +36,7 @@ bool iir_tail_try_dev(aukit_ctx *ctx, int kind, int rows_kind, const void *rows,
 // the same tail for stream.qoa with F32 storage on the tile chain of k_rs_onepole (flac_tail.hip): state carried from tile to tile instead of warmed up per tile
 bool rs_onepole_jobs_try(aukit_ctx *ctx, const void *rows_i8, const std::vector<TailJob> &jobs, int mix_channels, double rate, int interp, double lp_alpha, float *out,
                          uint64_t algorithmic_bytes, const char *name, int *rc);
+bool rs_onepole_jobs_try_dev(aukit_ctx *ctx, const void *rows_i32, double full, const TailJob *d_jobs, size_t njobs, double rate, int interp, double lp_alpha, float *out,
+                             uint64_t algorithmic_bytes, const char *name, int *rc);
 
 }  // namespace aukit

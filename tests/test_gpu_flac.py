@@ -136,7 +136,7 @@ def test_stream_flac(ctx, oracle, interp):
 
 
 @pytest.mark.parametrize("rate,bs", [(44100, 4096), (22050, 1152), (8000, 576), (48000, 4096)])
-def test_stream_flac_f32_tail(ctx, oracle, rate, bs):
+def test_stream_flac_f32_tail(ctx, oracle, monkeypatch, rate, bs):
     """F32 storage: stream.flac's per-block resample + recursive low-pass + scaling in one launch from the int32 rows, f32 interpolation
     (k_iir_tail_fast).  Tolerance path: 1e-6 RMS of the [-128, 127] scale."""
     B, N = _B(), _N()
@@ -148,8 +148,17 @@ def test_stream_flac_f32_tail(ctx, oracle, rate, bs):
         bt = B.Batch.upload(ctx, [s])
         for interp in ("none", "linear", "cubic"):
             out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_FLAC), interp, dtype=N.F32)
-            assert ctx.last_kernel()[0].startswith("k_iir_tail"), ctx.last_kernel()
+            # linear / cubic: the tile chain of k_rs_onepole (JOBS: a job per frame and channel, state carried from tile to tile; round 4) — "none": k_iir_tail_fast
+            assert ctx.last_kernel()[0] == ("k_iir_tail<flac>" if interp == "none" else "k_rs_onepole<flac>"), ctx.last_kernel()
             got = out.download()[0]
+            if interp != "none":
+                monkeypatch.setenv("AUKIT_NO_RS_JOBS", "1")
+                out2, _ = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_FLAC), interp, dtype=N.F32)
+                monkeypatch.delenv("AUKIT_NO_RS_JOBS")
+                assert ctx.last_kernel()[0] == "k_iir_tail<flac>", ctx.last_kernel()
+                got2 = out2.download()[0]
+                for c in range(len(got)):
+                    assert np.max(np.abs(got[c] - got2[c]), initial=0) <= 1e-4, (interp, c)
             ref = oracle.stream_flac(s, oracle.INTERP[interp])
             assert ck.nchunks[0] == ref.nchunks and list(ck.lens[0][:ref.nchunks]) == list(ref.chunk_len[:, 0])
             for c in range(ref.channels):
