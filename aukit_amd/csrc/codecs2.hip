@@ -93,7 +93,7 @@ static int qoa_scan(const uint8_t *hdr, uint64_t nb, bool audio_mode, int *file_
     if (nb < 12) return fail(AUKIT_E_LUA, nb == 8 && !audio_mode ? "Not a QOA file" : "data string too short");
     *file_channels = hdr[8];
     *file_rate = (double)((uint32_t)hdr[9] << 16 | (uint32_t)hdr[10] << 8 | hdr[11]);
-    if (*file_channels < 1 || *file_channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", *file_channels);
+    if (*file_channels < 1 || *file_channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", *file_channels);
     uint64_t pos = 8;
     double sample_pos = 0;
     for (;;) {
@@ -175,8 +175,9 @@ int decode_qoa_audio_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_cod
 }
 
 // ================================================================= MDFPWM  aukit.lua:1420-1448
+struct DfInit2 { int on; int st[2][6]; };   // decoderL's / decoderR's state where the rest of a stream starts (aukit_ctx::sb_dfpwm / sb_dfpwm2)
 __global__ __launch_bounds__(64) void k_mdfpwm_decode(const unsigned char *src, const unsigned long long *payload_off, const unsigned long long *payload_len,
-                                                     unsigned n, signed char *out, const unsigned long long *row_off) {
+                                                     unsigned n, signed char *out, const unsigned long long *row_off, const DfInit2 init) {
     const unsigned r = blockIdx.x * 64 + threadIdx.x;  // row = stream * 2 + channel: decoderL / decoderR are independent
     if (r >= 2 * n) return;
     const unsigned s = r >> 1, c = r & 1;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(64) void k_mdfpwm_decode(const unsigned char *src, 
     const unsigned long long nb = payload_len[s];
     signed char *o = out + row_off[r];
     DfDec d{};
+    if (init.on) { d.p.n = init.st[c][0]; d.p.strength = init.st[c][1]; d.p.pb = init.st[c][2]; d.lpf = init.st[c][3]; d.pn = init.st[c][4]; }
     unsigned long long w = 0;
     for (unsigned long long pos = 6000ull * c; pos < nb; pos += 12000) {
         const unsigned long long cnt = nb - pos < 6000 ? nb - pos : 6000;
@@ -292,8 +294,11 @@ static int mdfpwm_rows(aukit_ctx *ctx, const aukit_batch *in, const char *badmsg
             lap("par decode");
             return ctx_end_kernel(ctx, "k_df_chunks", in->total() + tot);
         }
+        DfInit2 I2{};
+        I2.on = ctx->sb_dfpwm_on ? 1 : 0;
+        for (int i = 0; i < 6; i++) { I2.st[0][i] = ctx->sb_dfpwm[i]; I2.st[1][i] = ctx->sb_dfpwm2[i]; }
         hipLaunchKernelGGL(k_mdfpwm_decode, dim3((2 * in->n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), t, t + in->n, in->n,
-                           reinterpret_cast<signed char *>(ctx->tmp_buf.p), t + 2 * (size_t)in->n);
+                           reinterpret_cast<signed char *>(ctx->tmp_buf.p), t + 2 * (size_t)in->n, I2);
         AUKIT_HIP_CHECK(hipGetLastError());
         if ((rc = ctx_end_kernel(ctx, "k_mdfpwm_decode", in->total() + tot))) return rc;
     }
@@ -355,6 +360,32 @@ __global__ void k_dfpwm_state_at(const unsigned char *p, unsigned long long call
             for (int i = 0; i < 8; i++) { (void)df_decode_bit(d, byte & 1); byte >>= 1; }
         }
     out6[0] = d.p.n; out6[1] = d.p.strength; out6[2] = d.p.pb; out6[3] = d.lpf; out6[4] = d.pn; out6[5] = 0;
+}
+// stream.mdfpwm: decoderL / decoderR after `calls` block pairs (6000 bytes each, alternating; no overlap byte), lanes 0 and 1
+__global__ void k_mdfpwm_state_at(const unsigned char *p, unsigned long long calls, const DfInit2 init, int *out12) {
+    const int c = threadIdx.x;
+    if (c > 1 || blockIdx.x) return;
+    DfDec d{};
+    if (init.on) { d.p.n = init.st[c][0]; d.p.strength = init.st[c][1]; d.p.pb = init.st[c][2]; d.lpf = init.st[c][3]; d.pn = init.st[c][4]; }
+    for (unsigned long long k = 0; k < calls; k++)
+        for (unsigned long long b = 0; b < 6000; b++) {
+            unsigned byte = p[k * 12000 + 6000ull * c + b];
+            for (int i = 0; i < 8; i++) { (void)df_decode_bit(d, byte & 1); byte >>= 1; }
+        }
+    int *o = out12 + 6 * c;
+    o[0] = d.p.n; o[1] = d.p.strength; o[2] = d.p.pb; o[3] = d.lpf; o[4] = d.pn; o[5] = 0;
+}
+int mdfpwm_state_after(aukit_ctx *ctx, const unsigned char *dev_payload, uint64_t calls, const int *in12, bool in_on, int *out12) {
+    DfInit2 I{};
+    I.on = in_on ? 1 : 0;
+    if (in_on) for (int i = 0; i < 12; i++) I.st[i / 6][i % 6] = in12[i];
+    int rc = ctx->fmt_flag.ensure(256);
+    if (rc) return rc;
+    int *d12 = reinterpret_cast<int *>(ctx->fmt_flag.p) + 32;
+    hipLaunchKernelGGL(k_mdfpwm_state_at, dim3(1), dim3(64), 0, ctx->stream, dev_payload, (unsigned long long)calls, I, d12);
+    if (hipGetLastError() != hipSuccess) return fail(AUKIT_E_HIP, "k_mdfpwm_state_at launch failed");
+    if (hipMemcpyAsync(out12, d12, 48, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "reading the DFPWM states back failed");
+    return AUKIT_OK;
 }
 int dfpwm_state_after(aukit_ctx *ctx, const unsigned char *dev_bytes, uint64_t calls, uint64_t adv, const int *in6, bool in_on, int *out6) {
     DfInit I{};
@@ -582,7 +613,7 @@ static int stream_mdfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_code
         uint32_t good = 0;
         for (uint64_t pos = 0; pos < pl; pos += 12000) {
             const bool full = pos + 12000 <= pl;
-            const bool trimmed = (double)(pos + 1) + 12000 > (double)hdrs[s].length;
+            const bool trimmed = (double)(ctx->sb_bytes + pos + 1) + 12000 > (double)hdrs[s].length;   // (pos - headerSize counts from the stream's first payload byte: what a bounded handle dropped included)
             if (!full || trimmed) { ck->status[s] = mono ? AUKIT_E_LUA : AUKIT_E_UNSUPPORTED; break; }
             good++;
         }
@@ -594,7 +625,7 @@ static int stream_mdfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_code
     ck->lens.assign((size_t)ck->n * mc, 0);
     ck->pos.assign((size_t)ck->n * mc, 0);
     for (uint32_t s = 0; s < in->n; s++)
-        for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = 48000; ck->pos[(size_t)s * mc + k] = (double)(12000ull * k + 1) / 12000; }
+        for (uint32_t k = 0; k < ck->nchunks[s]; k++) { ck->lens[(size_t)s * mc + k] = 48000; ck->pos[(size_t)s * mc + k] = (double)(ctx->sb_bytes + 12000ull * k + 1) / 12000; }
     lap("chunk plan");
     aukit_audio *a = *out;
     if ((rc = audio_prepare(ctx, &a, in->n, mono ? 1 : 2, 48000, AUKIT_I8, lens.data()))) { delete ck; return rc; }

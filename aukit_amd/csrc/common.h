@@ -80,6 +80,8 @@ struct aukit_ctx {
     // — bytes, 48 kHz outputs per channel — enters the chunk positions and the length of the stream factories that support it (stream.pcm / g711 /
     // adpcm / msadpcm), so that the rest's chunks carry the whole stream's numbers.  Zero everywhere else.
     int sb_dfpwm[6] = {0, 0, 0, 0, 0, 0};   // stream.dfpwm: the decoder's state (dfpwm_dev.h: n, strength, pb, lpf, pn) where the rest of the stream starts; sb_dfpwm_on: use it
+    int sb_dfpwm2[6] = {0, 0, 0, 0, 0, 0};  // stream.mdfpwm: decoderR's (sb_dfpwm is decoderL's)
+    int sb_dfpwm_n = 1;                      // states in use: 1 (stream.dfpwm), 2 (stream.mdfpwm: even pseudo-streams L, odd ones R)
     bool sb_dfpwm_on = false;
     double sb_pos = 0;   // stream.flac: the accumulated position (aukit.lua:3188) at the cut, exactly as the sums before it left it
     uint64_t sb_bytes = 0, sb_outputs = 0, sb_samples = 0;   // (sb_samples: decoded samples per channel in front — stream.qoa's file_pos)
@@ -210,6 +212,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
 int lazy_resolve(aukit_ctx *ctx, aukit_audio *a);   // everything owed on the rows themselves (resample, then a deferred filter), effects.hip
 // the frames one full iterator call of aukit.stream.pcm moves its table on by (K of SURVEY Q1: aukit.lua:2417-2419), api_resample.hip
 long stream_pcm_call_frames(double sample_rate, int interp);
+int mdfpwm_state_after(aukit_ctx *ctx, const unsigned char *dev_payload, uint64_t calls, const int *in12, bool in_on, int *out12);   // codecs2.hip
 int dfpwm_state_after(aukit_ctx *ctx, const unsigned char *dev_bytes, uint64_t calls, uint64_t adv, const int *in6, bool in_on, int *out6);   // codecs2.hip
 int audio_rowmax_ensure(aukit_audio *a);  // allocates a->d_rowmax for n × channels rows
 // the context's pinned host staging buffer, grown to `bytes` (nullptr beyond 1 GiB or when pinning fails: use pageable memory then); one user at a time

@@ -92,7 +92,8 @@ struct DfParParams {
     unsigned bpc;       // blocks per chunk
     unsigned nchunk;    // chunks per stream
     u64 W;              // block size in fed bytes
-    const int *init;    // [6]: the state every stream's decoder starts from (a bounded reader-function handle's rest of a stream); null: the reset state
+    int init_n;         // states at `init`: stream s starts from state s % init_n (stream.mdfpwm: decoderL / decoderR alternate)
+    const int *init;    // [init_n][6]: the state a stream's decoder starts from (a bounded reader-function handle's rest of a stream); null: the reset state
     u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
     SatMap *maps;       // [n][nblk]
     int *s_start;       // [n][nblk + 1] strength at block starts
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
 __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
-    int st = P.init ? P.init[1] : 0;
+    int st = P.init ? P.init[(s % (unsigned)P.init_n) * 6 + 1] : 0;
     int *o = P.s_start + (size_t)s * (P.nblk + 1);
     o[0] = st;
     for (unsigned b = 0; b < P.nblk; b++) { st = sm_apply(P.maps[(size_t)s * P.nblk + b], st); o[b + 1] = st; }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     if (f0 >= fed && c > 0) { ss[1] = -1; se[1] = -1; return; }
     const DfOut O = dfp_out(P, s, lut);
     DfDec d{};
-    if (c == 0 && P.init) dfp_unpack(P.init, d);
+    if (c == 0 && P.init) dfp_unpack(P.init + (s % (unsigned)P.init_n) * 6, d);
     if (c > 0) {  // warm-up over the block before the chunk: exact strength and previous bit, everything else from zero
         const u64 fw = f0 - P.W;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
@@ -580,8 +581,11 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     P.init = nullptr;
     if (ctx->sb_dfpwm_on && !hook) {
         int *di = reinterpret_cast<int *>(B + b_tab + b_maps + b_ss + 2 * b_st + 256);
-        if ((*rc = h2d_table(ctx, di, ctx->sb_dfpwm, 6 * sizeof(int)))) return true;
+        int both[12];
+        for (int i = 0; i < 6; i++) { both[i] = ctx->sb_dfpwm[i]; both[6 + i] = ctx->sb_dfpwm2[i]; }
+        if ((*rc = h2d_table(ctx, di, both, sizeof both))) return true;
         P.init = di;
+        P.init_n = ctx->sb_dfpwm_n == 2 ? 2 : 1;
     }
     P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_qoa_walk(const unsigned char *src, const
         const double file_samples = (double)((unsigned)h[4] << 24 | (unsigned)h[5] << 16 | (unsigned)h[6] << 8 | h[7]);
         const int fc = h[8];
         const unsigned fr = (unsigned)h[9] << 16 | (unsigned)h[10] << 8 | h[11];
-        if (fc >= 1 && fc <= AUKIT_MAX_CHANNELS) {
+        if (fc >= 1 && fc <= AUKIT_MAX_PLANAR_CHANNELS) {
             unsigned long long pos = 8, jat = 0, rat = 0;
             if (FILL) { jat = fin[s].job_first; rat = fin[s].row_base; }
             for (;;) {   // mode 1: one iterator call per turn
@@ -314,7 +314,7 @@ static int qoa_walk_count(aukit_ctx *ctx, const aukit_batch *in, int mode, std::
         q.file_samples = (double)((uint32_t)h[4] << 24 | (uint32_t)h[5] << 16 | (uint32_t)h[6] << 8 | h[7]);
         q.channels = h[8];
         q.rate = (double)((uint32_t)h[9] << 16 | (uint32_t)h[10] << 8 | h[11]);
-        if (q.channels < 1 || q.channels > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", q.channels);
+        if (q.channels < 1 || q.channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", q.channels);
         q.raised = wo[s].raised != 0; q.big = wo[s].big != 0; q.ncalls = wo[s].ncalls;
         q.njobs = wo[s].njobs; q.L = wo[s].L;
         q.stride = mode == 0 ? round_up(std::max<uint64_t>(q.L, 1), 8) : 0;

@@ -175,7 +175,7 @@ int stream_qoa_host(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_des
         if (nb < 12) { delete ck; return fail(AUKIT_E_LUA, "data string too short"); }
         const int fc = h[8];
         const double fr = (double)((uint32_t)h[9] << 16 | (uint32_t)h[10] << 8 | h[11]);
-        if (fc < 1 || fc > AUKIT_MAX_CHANNELS) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", fc); }
+        if (fc < 1 || fc > AUKIT_MAX_PLANAR_CHANNELS) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "QOA channel count %d", fc); }
         if (s == 0) { C = fc; rate = fr; ratio = 48000 / rate; }
         else if (fc != C || fr != rate) { delete ck; return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate"); }
         ck->length_seconds[s] = file_samples / fr;

@@ -28,8 +28,9 @@
 //     starts there, one call early, behind the metadata blocks; the position carries on from the exact double the dropped calls had summed up.
 //   * stream.dfpwm (:2439-2496): one decoder runs through the whole stream; the rest starts at the next call with the decoder's state behind the
 //     dropped calls (one lane walks them: k_dfpwm_state_at) and its last output as `last`.
-// stream.mdfpwm keeps the whole prefix.
+//   * stream.mdfpwm (:2507-2572): the same with two decoders on alternating blocks and the container header in front.
 #include <algorithm>
+#include <cstring>
 #include "common.h"
 
 struct aukit_stream {
@@ -54,7 +55,9 @@ struct aukit_stream {
     bool have_head16 = false;
     uint64_t sb_samples = 0;          // stream.qoa: decoded samples per channel dropped in front (file_pos, aukit.lua:3332)
     double sb_pos = 0;                // stream.flac: the position summed up by the dropped calls (:3188)
-    int df_state[6] = {0, 0, 0, 0, 0, 0};   // stream.dfpwm: the decoder's state behind the dropped calls (valid once sb_bytes > 0)
+    int df_state[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // stream.dfpwm: the decoder's state behind the dropped calls (valid once sb_bytes > 0); stream.mdfpwm: decoderL's, then decoderR's
+    uint8_t head_md[800] = {};        // stream.mdfpwm: the container header (magic, length, three short strings) as fed, to find where the payload starts
+    uint32_t head_md_n = 0;
 };
 
 namespace aukit {
@@ -80,6 +83,12 @@ static int redecode(aukit_stream *h) {
         if (h->desc.codec == AUKIT_CODEC_PCM) usable -= usable % (C * (uint64_t)std::max(h->desc.bit_depth / 8, 1));
         else if (h->desc.codec == AUKIT_CODEC_G711 || h->desc.codec == AUKIT_CODEC_DFPWM) usable -= usable % C;
         else if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.block_align > 0) usable -= usable % (uint64_t)h->desc.block_align;  // a partial block raises (:2640)
+        else if (h->desc.codec == AUKIT_CODEC_MDFPWM && h->head_md_n >= 14) {   // whole L/R block pairs behind the container header (an odd rest makes a table with holes: refused)
+            uint64_t at = 11;
+            bool ok = true;
+            for (int k = 0; k < 3 && ok; k++) { if (at >= h->head_md_n) ok = false; else at += 1 + (uint64_t)h->head_md[at]; }
+            if (ok && at <= h->head_md_n && usable > at) usable = at + (usable - at) / 12000 * 12000;
+        }
     }
     const uint64_t off[2] = {0, usable};
     aukit_batch *b = nullptr;
@@ -87,10 +96,11 @@ static int redecode(aukit_stream *h) {
     if (rc) return rc;
     aukit_chunks *ck = nullptr;
     h->ctx->sb_bytes = h->sb_bytes; h->ctx->sb_outputs = h->sb_outputs; h->ctx->sb_samples = h->sb_samples; h->ctx->sb_pos = h->sb_pos;
-    h->ctx->sb_dfpwm_on = h->desc.codec == AUKIT_CODEC_DFPWM && h->sb_bytes > 0;
-    for (int i = 0; i < 6; i++) h->ctx->sb_dfpwm[i] = h->df_state[i];   // the rest of a stream: the factories add what was dropped to their positions
+    h->ctx->sb_dfpwm_on = (h->desc.codec == AUKIT_CODEC_DFPWM || h->desc.codec == AUKIT_CODEC_MDFPWM) && h->sb_bytes > 0;
+    h->ctx->sb_dfpwm_n = h->desc.codec == AUKIT_CODEC_MDFPWM ? 2 : 1;
+    for (int i = 0; i < 6; i++) { h->ctx->sb_dfpwm[i] = h->df_state[i]; h->ctx->sb_dfpwm2[i] = h->df_state[6 + i]; }   // the rest of a stream: the factories add what was dropped to their positions
     rc = aukit_stream_decode(h->ctx, b, &h->desc, h->interp, h->mono, h->dtype, &h->spare, &ck);
-    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0; h->ctx->sb_pos = 0; h->ctx->sb_dfpwm_on = false;
+    h->ctx->sb_bytes = 0; h->ctx->sb_outputs = 0; h->ctx->sb_samples = 0; h->ctx->sb_pos = 0; h->ctx->sb_dfpwm_on = false; h->ctx->sb_dfpwm_n = 1;
     if (!rc) rc = aukit_ctx_sync(h->ctx);
     aukit_batch_free(b);
     h->decoded_bytes_total += usable;
@@ -155,6 +165,16 @@ static Restart restart_rule(const aukit_stream *h) {
         if (d.sample_rate < 1 || C < 1) return r;
         r.ok = true; r.call_bytes = 6000 * C;
         return r;
+    case AUKIT_CODEC_MDFPWM: {
+        // stream.mdfpwm (aukit.lua:2507-2572): two decoders run through the whole stream on alternating 6000-byte blocks; a call takes a pair.  The
+        // rest starts at the next pair with both decoders' states behind the dropped pairs (k_mdfpwm_state_at), the container header stays in front
+        if (h->head_md_n < 14 || memcmp(h->head_md, "MDFPWM\3", 7) != 0) return r;
+        uint64_t at = 11;
+        for (int k = 0; k < 3; k++) { if (at >= h->head_md_n) return r; at += 1 + (uint64_t)h->head_md[at]; }
+        if (at > h->head_md_n) return r;
+        r.ok = true; r.call_bytes = 12000; r.hdr = at;
+        return r;
+    }
     case AUKIT_CODEC_FLAC:
         // stream.flac (aukit.lua:3124-3191): an iterator call takes whole frames; all that reaches the next frame are the two `last` samples of the
         // block before it — the rest starts one call EARLIER (lead 1), behind the metadata blocks, which stay in front.  Where frames end is only
@@ -170,6 +190,7 @@ static Restart restart_rule(const aukit_stream *h) {
 static int compact(aukit_stream *h) {
     const Restart R = restart_rule(h);
     const bool by_table = R.ok && h->desc.codec == AUKIT_CODEC_FLAC;   // the cut comes from the chunk table, not from a constant call size
+    const bool dev_hdr = by_table || h->desc.codec == AUKIT_CODEC_MDFPWM;   // a header of any length stays in front: copied from the old buffer
     if (!R.ok || (!R.call_bytes && !by_table) || !h->ck || h->delivered == 0) return AUKIT_OK;
     const uint64_t j = h->delivered - 1;                       // the chunk just delivered
     const uint64_t shift = R.lead ? j : j + 1;                  // fresh chunk 0 = current chunk `shift`
@@ -187,6 +208,12 @@ static int compact(aukit_stream *h) {
     (void)mc;
     uint64_t outs = 0;
     for (uint64_t m = 0; m < shift; m++) outs += h->ck->lens[m];
+    if (h->desc.codec == AUKIT_CODEC_MDFPWM) {
+        int st[12];
+        const int src = mdfpwm_state_after(h->ctx, h->dbuf + R.hdr, shift, h->df_state, h->sb_bytes > 0, st);
+        if (src) return src;
+        for (int i = 0; i < 12; i++) h->df_state[i] = st[i];
+    }
     if (h->desc.codec == AUKIT_CODEC_DFPWM) {   // the decoder's state behind the `shift` dropped calls, from the state in front of this buffer
         int st[6];
         const int src = dfpwm_state_after(h->ctx, h->dbuf, shift, R.call_bytes, h->df_state, h->sb_bytes > 0, st);
@@ -199,10 +226,10 @@ static int compact(aukit_stream *h) {
     uint8_t *nb = nullptr;
     if (hipMalloc((void **)&nb, cap + 64) != hipSuccess) { (void)hipGetLastError(); return AUKIT_OK; }   // no memory for the move: keep the prefix (correct, only bigger)
     if (rest) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream));
-    if (by_table && R.hdr) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf, (size_t)R.hdr, hipMemcpyDeviceToDevice, h->ctx->stream));   // the metadata blocks stay in front (the bytes just copied there are dropped frames')
+    if (dev_hdr && R.hdr) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf, (size_t)R.hdr, hipMemcpyDeviceToDevice, h->ctx->stream));   // the metadata blocks stay in front (the bytes just copied there are dropped frames')
     if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.channels == 1 && rest >= 7)   // Q9: the header every mono block is read from is the STREAM's first (no block reads its own)
         AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream));
-    if (!by_table && R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
+    if (!dev_hdr && R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
         AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head16, R.hdr, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
     (void)hipFree(h->dbuf);
@@ -241,6 +268,10 @@ int aukit_stream_feed(aukit_stream *h, const uint8_t *bytes, uint64_t n) {
     if (rc) return rc;
     AUKIT_HIP_CHECK(hipMemcpyAsync(h->dbuf + h->fed, bytes, n, hipMemcpyHostToDevice, h->ctx->stream));
     AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));  // the caller may reuse `bytes`
+    if (h->desc.codec == AUKIT_CODEC_MDFPWM && h->sb_bytes == 0 && h->fed < sizeof h->head_md) {
+        for (uint64_t i = 0; i < n && h->fed + i < sizeof h->head_md; i++) h->head_md[h->fed + i] = bytes[i];
+        h->head_md_n = (uint32_t)std::min<uint64_t>(h->fed + n, sizeof h->head_md);
+    }
     if (!h->have_head16 && h->sb_bytes == 0 && h->fed < 16) {
         for (uint64_t i = 0; i < n && h->fed + i < 16; i++) h->head16[h->fed + i] = bytes[i];
         if (h->fed + n >= 16) h->have_head16 = true;
@@ -288,6 +319,7 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     if (h->delivered >= avail) {
         if (!h->finished) { *state = AUKIT_STREAM_NEED_INPUT; return AUKIT_OK; }
         if (h->ck && !h->ck->status.empty() && h->ck->status[0] == AUKIT_E_LUA) return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (field '?')");
+        if (h->ck && !h->ck->status.empty() && h->ck->status[0] == AUKIT_E_UNSUPPORTED) return fail(AUKIT_E_UNSUPPORTED, "the stream's last chunk is one the reference returns with holes (aukit.lua:2552-2556): not delivered");   // (the string call's status for these bytes)
         *state = AUKIT_STREAM_END;
         return AUKIT_OK;
     }

@@ -34,7 +34,7 @@ extern "C" {
 
 #define AUKIT_ABI_VERSION 1
 #define AUKIT_MAX_CHANNELS 8          /* block codecs with per-channel state in the descriptor (ADPCM predictors), FLAC, QOA, DFPWM loaders */
-#define AUKIT_MAX_PLANAR_CHANNELS 64  /* PCM and G.711 (loaders and streams), the Audio methods and effects: planar rows of any count up to this
+#define AUKIT_MAX_PLANAR_CHANNELS 64  /* PCM, G.711 and QOA (loaders and streams), the Audio methods and effects: planar rows of any count up to this
                                          (the reference takes any channel count, aukit.lua:1049-1171, :2228; round 4) */
 
 typedef struct aukit_ctx aukit_ctx;

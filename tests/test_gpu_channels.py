@@ -89,3 +89,25 @@ def test_channel_caps_are_refusals_by_name(ctx):
     with pytest.raises(N.AukitError) as e:
         B.decode(ctx, B.Batch.upload(ctx, [b"\0" * 90]), B.make_desc(N.CODEC_DFPWM, 9, 48000))
     assert "at most 8 channels" in str(e.value)
+
+
+@pytest.mark.parametrize("ch", [3, 9, 12])
+def test_qoa_with_many_channels(ctx, oracle, ch):
+    """QOA files carry their channel count in every frame header (aukit.lua:1706-1777, :3202-3337): the loader and the stream take what the planar rows
+    take.  (The corrupted-header sweeps of tests/test_gpu_fuzz.py meet such counts by accident: product and checker must agree on them.)"""
+    N, B = _mods()
+    x = _frames(5120 * 3 + 777, ch, 44100, 11).ravel()
+    f = oracle.gen_qoa(x, ch, 44100) + b"\0" * 8
+    bt = B.Batch.upload(ctx, [f])
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_QOA), dtype=N.F64).download()[0]
+    ref = oracle.qoa(f)
+    assert len(got) == ref.channels == ch
+    for c in range(ch):
+        assert np.array_equal(got[c], ref.data[c]), c
+    for mono in (False, True):
+        out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), "cubic", mono=mono, dtype=N.F64)
+        rs = oracle.stream_qoa(f, mono, oracle.CUBIC)
+        assert ck.nchunks[0] == rs.nchunks
+        a = out.download()[0]
+        for c in range(rs.channels):
+            assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (mono, c)

@@ -232,7 +232,7 @@ def test_ignore_header_strips_later_headers_and_first_piece_quirks(ctx, oracle):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["pcm16_mono_44k_cubic", "pcm8_48k_linear", "pcm16_stereo_mix", "g711_stereo", "ima_22k", "msadpcm_44k", "qoa_44k_stereo", "qoa_22k_mono_mix", "flac_44k_stereo", "dfpwm_48k_stereo", "dfpwm_32k_mono", "dfpwm_48k_mix_f64"])
+@pytest.mark.parametrize("name", ["pcm16_mono_44k_cubic", "pcm8_48k_linear", "pcm16_stereo_mix", "g711_stereo", "ima_22k", "msadpcm_44k", "qoa_44k_stereo", "qoa_22k_mono_mix", "flac_44k_stereo", "dfpwm_48k_stereo", "dfpwm_32k_mono", "dfpwm_48k_mix_f64", "mdfpwm", "mdfpwm_mono"])
 def test_long_live_stream_is_bounded(ctx, oracle, monkeypatch, name):
     """VERDICT r03 item 8 (austream.lua:19-64: HTTP / websocket readers run for hours).  A long stream fed in 64 KiB pieces: the chunks equal the
     string call's (samples, lengths, positions, the stream's length), the bytes resident on the device stay at a few calls' worth instead of growing
@@ -260,6 +260,10 @@ def test_long_live_stream_is_bounded(ctx, oracle, monkeypatch, name):
         st = np.stack([pcm16(44100 * 66, 44100, 9, 41), pcm16(44100 * 66, 44100, 9, 42)], 1).astype(np.int64)
         data = oracle.gen_flac(st.ravel(), 2, 16, 44100, 4096)
         desc, interp, mono, dtype, call = B.make_desc(N.CODEC_FLAC), "cubic", False, N.F32, len(data) // 60
+    elif name.startswith("mdfpwm"):   # two decoders on alternating 6000-byte blocks, the container header in front
+        lr = [oracle.audio_dfpwm(oracle.pcm(pcm16(6000 * 8 * 75, 48000, 9, 61 + c).tobytes(), 16, oracle.SIGNED, 1, 48000), True) for c in range(2)]
+        data = oracle.gen_mdfpwm(lr[0], lr[1], b"an artist", b"a title", b"an album")
+        desc, interp, mono, dtype, call = B.make_desc(N.CODEC_MDFPWM), "linear", name == "mdfpwm_mono", N.I8, 12000
     elif name.startswith("dfpwm"):   # one decoder runs through the whole stream: its state behind the dropped calls is carried (k_dfpwm_state_at)
         ch = 1 if name == "dfpwm_32k_mono" else 2
         rate = 32000 if name == "dfpwm_32k_mono" else 48000
