@@ -77,16 +77,26 @@ AUKIT_DEV double dpp_f64(double v) {
 
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
+#ifndef AUKIT_RS_WAVES
+#define AUKIT_RS_WAVES 4
+#endif
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
 template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false, bool LOOPJ = false>
-__global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
-    extern __shared__ float rsm_all[];
+__global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
+    extern __shared__ __attribute__((aligned(16))) float rsm_all[];
     constexpr int E = 8, T = 64 * E;
     const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
     float *const rsm = rsm_all + (NW > 1 ? wv * (unsigned)P.wave_lds : 0u);
-    float *const win = rsm + 16;                             // P.cap floats in all: 16 of slack in front (a part's first vector may start EPV - 1 elements early), the window, 16 behind
+    float *const win = rsm + 16;                             // P.cap floats in all: 16 of slack in front, the window, 16 behind (whole vectors spill up to EPV - 1 elements either way, and the window starts hA <= 7 floats in)
     float *const xb = rsm + P.cap;                           // T + T / E + 8
-    constexpr int EPV = 16 / (int)sizeof(S), VPL = sizeof(S) == 4 ? 2 : 1;   // elements per 16-byte vector; vectors per lane and tile (512 elements either way: a second slot of 8 or 16 would sit idle in every tile and cost its instructions)
+    // a lane's vector = EIGHT elements (8, 16 or 32 bytes of the row, aligned to that), one per lane and tile: their floats leave as two aligned
+    // ds_write_b128 at a lane stride of 32 bytes.  (Until late round 4 a vector was 16 BYTES: 8 or 16 elements written float by float to wherever the
+    // window's first element put them, at a lane stride of 8 or 16 dwords — an 8- or 16-way bank conflict on every one of those writes.  PMC on
+    // stream.qoa's tail: SQ_LDS_BANK_CONFLICT 57 % of SQ_LDS_IDX_ACTIVE, waves waiting on the LDS 27 % of their time.)
+    constexpr int EPV = 8, VB = EPV * (int)sizeof(S), DPV = VB / 4, VPL = 1;
+    struct V32 { u32x4g lo, hi; };
+    using VT = std::conditional_t<DPV == 8, V32, std::conditional_t<DPV == 4, u32x4g, u32x2g>>;
     [[maybe_unused]] float *const wt = NW > 1 ? rsm_all + NW * P.wave_lds : xb + (T + T / E + 8);   // TAB: 4 fb floats (one table per workgroup)
     constexpr int MIXN = T + T / E + 8;                                      // NW > 1: a wave's tile of results, skewed like xb
     [[maybe_unused]] float *const mix = rsm_all + NW * P.wave_lds + (TAB ? (4 * (int)P.fb + 3 & ~3) : 0);   // [wave][MIXN]
@@ -106,6 +116,16 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     Md[0] = mp[E];
 #pragma unroll
     for (int k = 1; k < 6; k++) Md[k] = Md[k - 1] * Md[k - 1];
+    // (the same in every lane, but made by vector multiplies: said so, these 14 doubles live in scalar registers — 28 VGPRs of a kernel that is held to
+    // 128 and spilled into its tile loop without them; an FMA takes one of them as its scalar operand)
+    auto uni = [](double v) {
+        const long long b = __double_as_longlong(v);
+        return __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b));
+    };
+#pragma unroll
+    for (int i = 1; i <= E; i++) mp[i] = uni(mp[i]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) Md[k] = uni(Md[k]);
     // the scan runs on DPP moves: four steps inside rows of 16 lanes (a lane without a source receives 0), then lane 15 / lane 31 of the row(s)
     // before — with what the receiving lane's distance makes of them
     const double mA = (lane & 16) ? pow(mp[E], (double)((lane & 15) + 1)) : 0.0;
@@ -167,8 +187,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
     // after, part B); a part is read from the vector that holds its first element on, vector s of the tile by lane s % 64.  Part A's vectors are
     // written to LDS as they stand — what they hold beyond the part falls into the slack around the window or onto part B's place — part B's
     // behind them, its first vector guarded.
-    struct VecDesc { int on, nvA, nvB, dposA, dposB, loB; };
-    auto fetch = [&](unsigned kk, int nst, int (&pre)[8], VecDesc &vd) {
+    struct VecDesc { int on, nvA, nvB, hA, dposB, loB; };   // hA: the window's first element sits hA floats behind `win` (part A's vectors are written where their alignment puts them)
+    auto fetch = [&](unsigned kk, int nst, int (&pre)[8], VT &pva, VecDesc &vd) {
         if (P.frames && L > 0) {
             const unsigned k0 = kk < 1u ? 1u : (kk > (unsigned)L ? (unsigned)L : kk);
             while ((int)(k0 - 1u) >= bound && fcur + 1u < nfr_s) {
@@ -177,32 +197,33 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
                 if (fcur + 2u < nfr_s) base2 = rec_base(fcur + 2u);
             }
         }
-        vd.on = 0; vd.nvA = vd.nvB = vd.dposA = vd.dposB = vd.loB = 0;
+        vd.on = 0; vd.nvA = vd.nvB = vd.hA = vd.dposB = vd.loB = 0;
         const int e0 = (int)kk - 1, e1 = e0 + nst;   // row elements [e0, e1)
         if (L > 0 && e0 >= EPV && e1 + EPV <= L && !P.novec) {
             const int xeA = P.frames ? (e1 < bound ? e1 : bound) : e1;
             const S *const pA = P.frames ? rows_s + (base0 + (long long)e0) : row + e0;
-            const uintptr_t aA = (uintptr_t)pA, alA = aA & ~(uintptr_t)15;
+            const uintptr_t aA = (uintptr_t)pA, alA = aA & ~(uintptr_t)(VB - 1);
             const int hA = (int)((aA - alA) / sizeof(S));
             const int nvA = (hA + (xeA - e0) + EPV - 1) / EPV;
             uintptr_t alB = alA;
             int nvB = 0, hB = 0;
             if (e1 > xeA) {
                 const uintptr_t aB = (uintptr_t)(rows_s + (base1 + (long long)xeA));
-                alB = aB & ~(uintptr_t)15;
+                alB = aB & ~(uintptr_t)(VB - 1);
                 hB = (int)((aB - alB) / sizeof(S));
                 nvB = (hB + (e1 - xeA) + EPV - 1) / EPV;
             }
             if (nvA + nvB <= 64 * VPL) {
-                vd.on = 1; vd.nvA = nvA; vd.nvB = nvB; vd.dposA = -hA; vd.dposB = (xeA - e0) - hB; vd.loB = xeA - e0;
-#pragma unroll
-                for (int i = 0; i < VPL; i++) {
+                vd.on = 1; vd.nvA = nvA; vd.nvB = nvB; vd.hA = hA; vd.dposB = (xeA - e0) - hB; vd.loB = xeA - e0;
+                auto ldv = [&](const int i, VT &dst) {
                     const int sl = lane + 64 * i, sb = sl - nvA;
                     const bool inA = sl < nvA, inB = !inA && sb < nvB;
-                    const uintptr_t a = inB ? alB + 16u * (unsigned)sb : alA + (inA ? 16u * (unsigned)sl : 0u);   // (a slot without a vector reads the tile's first one: no branch around a load)
-                    const u32x4g v = *(const __attribute__((address_space(1))) u32x4g *)a;   // (global_load_dwordx4; through a generic pointer it would be a flat load, counted on lgkmcnt as well)
-                    pre[4 * i] = (int)v.x; pre[4 * i + 1] = (int)v.y; pre[4 * i + 2] = (int)v.z; pre[4 * i + 3] = (int)v.w;
-                }
+                    const uintptr_t a = inB ? alB + (unsigned)VB * (unsigned)sb : alA + (inA ? (unsigned)VB * (unsigned)sl : 0u);   // (a slot without a vector reads the tile's first one: no branch around a load)
+                    // (global_load_dwordx2 / x4; through a generic pointer it would be a flat load, counted on lgkmcnt as well)
+                    if constexpr (DPV == 8) { dst.lo = *(const __attribute__((address_space(1))) u32x4g *)a; dst.hi = *(const __attribute__((address_space(1))) u32x4g *)(a + 16); }
+                    else dst = *(const __attribute__((address_space(1))) VT *)a;
+                };
+                ldv(0, pva);
                 return;
             }
         }
@@ -215,7 +236,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
             pre[u] = (j < nst && L > 0) ? ((JOBS && k == 0u) ? hist : (int)*src) : 0;   // (JOBS: table index 0 is the history sample, not the edge)
         }
     };
-    int pre[8];
+    // (the vectors are VALUES, not elements of an array: with int pre[8] serving both ways of fetch(), hipcc merged the last store of either path
+    // into ONE store at a variable index — and an array indexed by a variable lives in scratch memory: loads and stores behind vmcnt(0) in the middle
+    // of the tile loop, + 6 ... 20 % on the kernel)
+    int pre[8];                // a window element by element (a row's first and last tiles)
+    VT pva{};                  // ... as vectors: this lane's
     VecDesc vcur{0, 0, 0, 0, 0, 0}, vnxt{0, 0, 0, 0, 0, 0};
     // this wave's run of tiles [t_lo, t_hi) of the row's ntiles, entered `warm` tiles early
     const unsigned long long ntiles = (nout + T - 1) / T;
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
         kb = (unsigned)(nn / P.fb); r0 = (unsigned)(nn % P.fb);
         const unsigned long long left0 = o_end > t_in * T ? o_end - t_in * T : 0ull;
         const int cnt0 = (int)(left0 < (unsigned long long)T ? left0 : (unsigned long long)T);
-        if (left0) fetch(kb, tile_nst(r0, cnt0), pre, vcur);
+        if (left0) fetch(kb, tile_nst(r0, cnt0), pre, pva, vcur);
     }
     // a full tile's results wait in registers (held[]) and are stored at the top of the NEXT turn, behind the wait for that tile's window: loads and
     // stores share vmcnt and hipcc waits vmcnt(0) across this loop's branches — stores issued at the end of a turn were waited for at the top of
@@ -264,45 +289,38 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
         const bool sym = sizeof(S) == 4 || P.scale == P.scale_neg;
         auto cvt_a = [&](int v) -> float { return (float)v * (v < 0 ? P.scale_neg : P.scale); };
         auto cvt_s = [&](int v) -> float { return (float)v * P.scale; };
+        float *const wb = win + vcur.hA;   // the window's first element (table index kb)
         auto stage = [&](auto cvt) {
         if (vcur.on) {   // (wave-uniform)
-#pragma unroll
-            for (int i = 0; i < VPL; i++) {
-                const int sl = lane + 64 * i;
-                if (sl < vcur.nvA) {
-                    float *d = win + (vcur.dposA + EPV * sl);
-#pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        const int x = pre[4 * i + w];
-                        if constexpr (sizeof(S) == 4) d[w] = cvt(x);
-                        else if constexpr (sizeof(S) == 2) { d[2 * w] = cvt((int)(short)(x & 0xFFFF)); d[2 * w + 1] = cvt(x >> 16); }
-                        else { d[4 * w] = cvt((int)(signed char)(x & 0xFF)); d[4 * w + 1] = cvt((int)(signed char)((x >> 8) & 0xFF)); d[4 * w + 2] = cvt((int)(signed char)((x >> 16) & 0xFF)); d[4 * w + 3] = cvt(x >> 24); }
-                    }
-                }
+            auto cv8 = [&](const VT &x, float4 &f0, float4 &f1) {
+                auto s16 = [&](unsigned w, float &a, float &b) { a = cvt((int)(short)(w & 0xFFFFu)); b = cvt((int)w >> 16); };
+                auto s8 = [&](unsigned w, float4 &f) { f = make_float4(cvt((int)(signed char)(w & 0xFFu)), cvt((int)(signed char)((w >> 8) & 0xFFu)), cvt((int)(signed char)((w >> 16) & 0xFFu)), cvt((int)w >> 24)); };
+                if constexpr (DPV == 8) {
+                    f0 = make_float4(cvt((int)x.lo.x), cvt((int)x.lo.y), cvt((int)x.lo.z), cvt((int)x.lo.w));
+                    f1 = make_float4(cvt((int)x.hi.x), cvt((int)x.hi.y), cvt((int)x.hi.z), cvt((int)x.hi.w));
+                } else if constexpr (DPV == 4) { s16(x.x, f0.x, f0.y); s16(x.y, f0.z, f0.w); s16(x.z, f1.x, f1.y); s16(x.w, f1.z, f1.w); }
+                else { s8(x.x, f0); s8(x.y, f1); }
+            };
+            float4 f0, f1;
+            cv8(pva, f0, f1);
+            if (lane < vcur.nvA) {   // (aligned: two ds_write_b128)
+                *reinterpret_cast<float4 *>(win + EPV * lane) = f0;
+                *reinterpret_cast<float4 *>(win + EPV * lane + 4) = f1;
             }
             if (vcur.nvB) {   // (a window across two frames: one tile in eight or nine of config 5)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < VPL; i++) {
-                    const int sb = lane + 64 * i - vcur.nvA;
-                    if (sb >= 0 && sb < vcur.nvB) {
-                        const int di = vcur.dposB + EPV * sb;
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            const int x = pre[4 * i + w];
-                            if constexpr (sizeof(S) == 4) { if (di + w >= vcur.loB) win[di + w] = cvt(x); }
-                            else if constexpr (sizeof(S) == 2) {
-                                if (di + 2 * w >= vcur.loB) win[di + 2 * w] = cvt((int)(short)(x & 0xFFFF));
-                                if (di + 2 * w + 1 >= vcur.loB) win[di + 2 * w + 1] = cvt(x >> 16);
-                            } else {
-                                if (di + 4 * w >= vcur.loB) win[di + 4 * w] = cvt((int)(signed char)(x & 0xFF));
-                                if (di + 4 * w + 1 >= vcur.loB) win[di + 4 * w + 1] = cvt((int)(signed char)((x >> 8) & 0xFF));
-                                if (di + 4 * w + 2 >= vcur.loB) win[di + 4 * w + 2] = cvt((int)(signed char)((x >> 16) & 0xFF));
-                                if (di + 4 * w + 3 >= vcur.loB) win[di + 4 * w + 3] = cvt(x >> 24);
-                            }
-                        }
-                    }
+                const int sb = lane - vcur.nvA;
+                if (sb >= 0 && sb < vcur.nvB) {
+                    const int di = vcur.dposB + EPV * sb;
+                    if (di >= vcur.loB) wb[di] = f0.x;
+                    if (di + 1 >= vcur.loB) wb[di + 1] = f0.y;
+                    if (di + 2 >= vcur.loB) wb[di + 2] = f0.z;
+                    if (di + 3 >= vcur.loB) wb[di + 3] = f0.w;
+                    if (di + 4 >= vcur.loB) wb[di + 4] = f1.x;
+                    if (di + 5 >= vcur.loB) wb[di + 5] = f1.y;
+                    if (di + 6 >= vcur.loB) wb[di + 6] = f1.z;
+                    if (di + 7 >= vcur.loB) wb[di + 7] = f1.w;
                 }
             }
         } else {
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
         if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
         if (o0 + T < o_end) {
             const unsigned long long left = o_end - o0 - T;
-            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre, vnxt);
+            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre, pva, vnxt);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rs_onepole(const RsOnepoleParams
                 const int idx = lane + 64 * u;
                 if (rem >= P.fb) { rem -= P.fb; q++; }
                 if (FULL || idx < cnt) {
-                    const float *tp = win + q;   // tp[0] = p0 (index kb + q), tp[1] = p1 = data[floor(x)]
+                    const float *tp = wb + q;   // tp[0] = p0 (index kb + q), tp[1] = p1 = data[floor(x)]
                     const float fx = (float)rem * P.inv_b;
                     float v;
                     if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = fmaf(tp[2] - tp[1], fx, tp[1]);

@@ -159,13 +159,16 @@ static AUKIT_DEV int qoa_mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1,
 static AUKIT_DEV int qoa_mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 static AUKIT_DEV int qoa_med3(int a, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi)); return r; }
 
+#ifndef AUKIT_QOA_K
+#define AUKIT_QOA_K 4
+#endif
 // S8: stream.qoa's math_floor(reconstructed / 256) as int8 rows (:3299); else the reconstructed int16 (aukit.qoa, :1765 divides later)
 template <bool S8>
 __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const QoaJob *jobs, unsigned long long njobs, void *out) {
-    constexpr int K = 4;                          // slices per job and round
+    constexpr int K = AUKIT_QOA_K;                // slices per job and round
     constexpr int OB = S8 ? 1 : 2;                // bytes per stored sample
-    constexpr int OSTR = 80 * OB + 8;             // bytes between two jobs' output areas
-    constexpr int UPJ = 80 * OB / 8;              // 8-byte units per job and round
+    constexpr int OSTR = K * 20 * OB + 8;         // bytes between two jobs' output areas
+    constexpr int UPJ = K * 20 * OB / 8;          // 8-byte units per job and round
     __shared__ unsigned long long sl_in[64 * (K + 1)];
     __shared__ unsigned long long j_src[64], j_out[64];
     __shared__ unsigned j_step[64], j_ns[64];
@@ -251,12 +254,12 @@ __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // the round's 80 samples of every job, 8 bytes per lane along each job's row
+        // the round's K * 20 samples of every job, 8 bytes per lane along each job's row
 #pragma unroll 2
         for (int i = 0; i < UPJ; i++) {
             const unsigned u = (unsigned)i * 64 + lane, jb = u / UPJ, v = u % UPJ;
             constexpr int SPU = 8 / OB;   // samples per unit
-            const int sb = (int)(r * 80) + (int)v * SPU, em = j_emit[jb];
+            const int sb = (int)(r * (K * 20)) + (int)v * SPU, em = j_emit[jb];
             if (sb < em) {
                 const unsigned long long bits = *reinterpret_cast<const unsigned long long *>(obuf + jb * OSTR + v * 8);
                 unsigned char *dstp = reinterpret_cast<unsigned char *>(out) + (j_out[jb] + (unsigned long long)sb) * OB;
