@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
     // written to LDS as they stand — what they hold beyond the part falls into the slack around the window or onto part B's place — part B's
     // behind them, its first vector guarded.
     struct VecDesc { int on, nvA, nvB, hA, dposB, loB; };   // hA: the window's first element sits hA floats behind `win` (part A's vectors are written where their alignment puts them)
-    auto fetch = [&](unsigned kk, int nst, int (&pre)[8], VT &pva, VecDesc &vd) {
+    auto fetch = [&](unsigned kk, int nst, VT &pva, VecDesc &vd) {
         if (P.frames && L > 0) {
             const unsigned k0 = kk < 1u ? 1u : (kk > (unsigned)L ? (unsigned)L : kk);
             while ((int)(k0 - 1u) >= bound && fcur + 1u < nfr_s) {
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         }
         vd.on = 0; vd.nvA = vd.nvB = vd.hA = vd.dposB = vd.loB = 0;
         const int e0 = (int)kk - 1, e1 = e0 + nst;   // row elements [e0, e1)
+        uintptr_t va = 0;   // this lane's vector
         if (L > 0 && e0 >= EPV && e1 + EPV <= L && !P.novec) {
             const int xeA = P.frames ? (e1 < bound ? e1 : bound) : e1;
             const S *const pA = P.frames ? rows_s + (base0 + (long long)e0) : row + e0;
@@ -215,32 +216,39 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
             }
             if (nvA + nvB <= 64 * VPL) {
                 vd.on = 1; vd.nvA = nvA; vd.nvB = nvB; vd.hA = hA; vd.dposB = (xeA - e0) - hB; vd.loB = xeA - e0;
-                auto ldv = [&](const int i, VT &dst) {
-                    const int sl = lane + 64 * i, sb = sl - nvA;
-                    const bool inA = sl < nvA, inB = !inA && sb < nvB;
-                    const uintptr_t a = inB ? alB + (unsigned)VB * (unsigned)sb : alA + (inA ? (unsigned)VB * (unsigned)sl : 0u);   // (a slot without a vector reads the tile's first one: no branch around a load)
-                    // (global_load_dwordx2 / x4; through a generic pointer it would be a flat load, counted on lgkmcnt as well)
-                    if constexpr (DPV == 8) { dst.lo = *(const __attribute__((address_space(1))) u32x4g *)a; dst.hi = *(const __attribute__((address_space(1))) u32x4g *)(a + 16); }
-                    else dst = *(const __attribute__((address_space(1))) VT *)a;
-                };
-                ldv(0, pva);
-                return;
+                const int sb = lane - nvA;
+                const bool inA = lane < nvA, inB = !inA && sb < nvB;
+                va = inB ? alB + (unsigned)VB * (unsigned)sb : alA + (inA ? (unsigned)VB * (unsigned)lane : 0u);   // (a lane without a vector reads the tile's first one)
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int j = lane + 64 * u;
-            const unsigned k = kk + (unsigned)j;
-            const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
-            const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
-            pre[u] = (j < nst && L > 0) ? ((JOBS && k == 0u) ? hist : (int)*src) : 0;   // (JOBS: table index 0 is the history sample, not the edge)
+        // (a window that cannot come as vectors — a row's first and last tiles — is loaded element by element where it is staged, at the top of its own
+        // tile: C++ loads in here put a `vmcnt(0)` at this function's join, on every tile's path, behind the stores of the tile before)
+        // A load hipcc does not see, in NO arm of a fork.  As a C++ load it sat in the vector arm above, its value met the other arm's at the join, and
+        // hipcc waited `vmcnt(0)` for it right there — six instructions behind the load: the "tile ahead" was never ahead, every tile stood a whole HBM
+        // latency (PMC: waves at an s_waitcnt 60 % of their time).  Now the request is inline asm into the register(s) the value keeps (a read-write
+        // operand: no copy anywhere), issued for every tile with the lanes masked off when the window goes element by element, the tile's END waits
+        // vmcnt(0) by hand (`landed` below), and tools/isa_check.py --cfg walks the built code's control-flow graph to prove that nothing touches those
+        // registers in between (tests/test_isa_schedule.py).
+        {
+            unsigned long long save;
+            const unsigned on = (unsigned)vd.on;
+            if constexpr (DPV == 8)
+                asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %2, vcc\n\tglobal_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\ts_mov_b64 exec, %2"
+                             : "+v"(pva.lo), "+v"(pva.hi), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
+            else if constexpr (DPV == 4)
+                asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\ts_and_saveexec_b64 %1, vcc\n\tglobal_load_dwordx4 %0, %3, off\n\ts_mov_b64 exec, %1" : "+v"(pva), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
+            else
+                asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\ts_and_saveexec_b64 %1, vcc\n\tglobal_load_dwordx2 %0, %3, off\n\ts_mov_b64 exec, %1" : "+v"(pva), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
         }
     };
-    // (the vectors are VALUES, not elements of an array: with int pre[8] serving both ways of fetch(), hipcc merged the last store of either path
+    // (the vector is a VALUE, not elements of an array: with an int pre[8] serving both ways of fetch(), hipcc merged the last store of either path
     // into ONE store at a variable index — and an array indexed by a variable lives in scratch memory: loads and stores behind vmcnt(0) in the middle
-    // of the tile loop, + 6 ... 20 % on the kernel)
-    int pre[8];                // a window element by element (a row's first and last tiles)
-    VT pva{};                  // ... as vectors: this lane's
+    // of the tile loop)
+    VT pva{};   // this lane's vector of the window
+    auto landed = [](VT &v) {   // the hand-issued request (fetch) has arrived — and with it every store of the tile
+        if constexpr (DPV == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v.lo), "+v"(v.hi) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+    };
     VecDesc vcur{0, 0, 0, 0, 0, 0}, vnxt{0, 0, 0, 0, 0, 0};
     // this wave's run of tiles [t_lo, t_hi) of the row's ntiles, entered `warm` tiles early
     const unsigned long long ntiles = (nout + T - 1) / T;
@@ -252,8 +260,9 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         kb = (unsigned)(nn / P.fb); r0 = (unsigned)(nn % P.fb);
         const unsigned long long left0 = o_end > t_in * T ? o_end - t_in * T : 0ull;
         const int cnt0 = (int)(left0 < (unsigned long long)T ? left0 : (unsigned long long)T);
-        if (left0) fetch(kb, tile_nst(r0, cnt0), pre, pva, vcur);
+        if (left0) fetch(kb, tile_nst(r0, cnt0), pva, vcur);
     }
+    landed(pva);
     // a full tile's results wait in registers (held[]) and are stored at the top of the NEXT turn, behind the wait for that tile's window: loads and
     // stores share vmcnt and hipcc waits vmcnt(0) across this loop's branches — stores issued at the end of a turn were waited for at the top of
     // the next one, a store latency per tile in a chain of 938 tiles (the late-store schedule of wave_f64.hip)
@@ -325,7 +334,13 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
             }
         } else {
 #pragma unroll
-        for (int u = 0; u < 8; u++) win[lane + 64 * u] = cvt(pre[u]);   // (cap >= 512)
+        for (int u = 0; u < 8; u++) {   // (cap >= 512; base0 / base1 / bound still describe THIS tile: the fetch below moves them on)
+            const int j = lane + 64 * u;
+            const unsigned k = kb + (unsigned)j;
+            const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);
+            const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
+            win[j] = cvt((j < nst && L > 0) ? ((JOBS && k == 0u) ? hist : (int)*src) : 0);   // (JOBS: table index 0 is the history sample, not the edge)
+        }
         }
         };
         if (sym) stage(cvt_s); else stage(cvt_a);
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         if (r0_n >= P.fb) { r0_n -= P.fb; kb_n++; }
         if (o0 + T < o_end) {
             const unsigned long long left = o_end - o0 - T;
-            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pre, pva, vnxt);
+            fetch(kb_n, tile_nst(r0_n, (int)(left < (unsigned long long)T ? left : (unsigned long long)T)), pva, vnxt);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         };
         if (cnt == T) compute(std::true_type{}); else compute(std::false_type{});
         if constexpr (NW > 1) { if (emit) { mix_cnt = cnt; mix_o0 = o0; mix_par = mix_par_next; mix_par_next ^= 1; } }
+        landed(pva);   // (requested before this tile's arithmetic)
         kb = kb_n; r0 = r0_n; vcur = vnxt;
     }
     if (held_at) {

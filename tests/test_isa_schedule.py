@@ -50,6 +50,31 @@ def test_checker_accepts_a_correct_schedule_and_catches_an_early_use():
     assert n == 1 and len(v) == 1 and v[0][3] == [0]
 
 
+def test_cfg_checker_follows_branches():
+    """check_vm_cfg: a hand-issued global load in one arm of a fork; the other arm may reuse the register, the join may not before vmcnt(0)."""
+    base = ("_Z1hv: ; @_Z1hv\n\ts_cbranch_scc1 .LBB0_2\n; %bb.1:\n\t;;#ASMSTART\n\tglobal_load_dwordx2 v[2:3], v[8:9], off\n\t;;#ASMEND\n\ts_branch .LBB0_3\n"
+            ".LBB0_2:\n\tv_mov_b32_e32 v2, 0\n.LBB0_3:\n\tv_add_u32_e32 v5, v6, v7\n{USE}\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v4, v3\n\ts_endpgm\n")
+    v, n = isa_check.check_vm_cfg(base.replace("{USE}", ""))
+    assert n == 1 and v == []          # (text order would flag the v_mov in the other arm)
+    assert len(isa_check.check(base.replace("{USE}", ""))[0]) == 1
+    v, _ = isa_check.check_vm_cfg(base.replace("{USE}", "\tv_mov_b32_e32 v4, v2\n"))
+    assert len(v) == 1 and v[0][3] == [2]
+    # a loop whose body requests at its end and waits at its top: the back edge carries the request to the instructions before the wait
+    loop = ("_Z1iv: ; @_Z1iv\n.LBB1_1:\n\tv_mov_b32_e32 v10, v2\n\ts_waitcnt vmcnt(0)\n\t;;#ASMSTART\n\tglobal_load_dwordx2 v[2:3], v[8:9], off\n\t;;#ASMEND\n"
+            "\ts_cbranch_scc1 .LBB1_1\n; %bb.2:\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")
+    v, _ = isa_check.check_vm_cfg(loop)
+    assert len(v) == 1 and v[0][3] == [2]
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
+def test_rs_onepole_keeps_its_prefetch_registers():
+    """flac_tail.hip: k_rs_onepole requests the next tile's window in inline asm and waits at the tile's end (every instantiation, on the control-flow graph)."""
+    asm = isa_check.compile_asm(os.path.join(ROOT, "aukit_amd", "csrc", "flac_tail.hip"))
+    v, n = isa_check.check_vm_cfg(asm)
+    assert n >= 100, f"only {n} hand-issued loads found"
+    assert not v, "\n".join(f"{k[:70]} line {ln}: `{s}` touches in-flight v{r}" for k, ln, s, r in v[:10])
+
+
 @pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
 @pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16), ("wave_coef_f64.hip", 32), ("flac_fused.hip", 8)])
 def test_hand_scheduled_kernels_keep_their_registers(src, at_least):

@@ -16,7 +16,7 @@ disassembles the translation unit and walks every kernel in text order with the 
 Straight-line approximation: labels and branches do not reset the queues (a loop's back edge is checked as if it fell through), which
 is the conservative direction for the loops in question — their bodies end in a full wait.
 
-usage: python tools/isa_check.py file.hip [more.hip ...]     (exit code 1 on a violation)
+usage: python tools/isa_check.py [--cfg] file.hip [more.hip ...]     (exit code 1 on a violation; --cfg: check_vm_cfg, see there)
 """
 import os, re, subprocess, sys, tempfile
 
@@ -105,10 +105,94 @@ def check(asm):
     return viol, issued
 
 
+def check_vm_cfg(asm):
+    """The vector-memory half of check() on the kernel's control-flow graph instead of in text order, for kernels whose hand-issued
+    `global_load` sits in one arm of a fork (k_rs_onepole, flac_tail.hip): in text order the OTHER arm's instructions follow the load and
+    every register they reuse looks like a violation.  Per basic block: IN = union of the predecessors' OUT (registers of hand-issued
+    loads still in flight on SOME path), `s_waitcnt vmcnt(0)` empties the set, a hand-issued load adds its destination; iterated to the
+    fixed point, then every instruction that touches a register of its IN-flight set is a violation.  -> (violations, loads)."""
+    viol, issued = [], 0
+    kernels, cur = [], None
+    for ln, raw in enumerate(asm.splitlines(), 1):
+        if raw.startswith("_Z") and ":" in raw and not raw[0].isspace():
+            cur = (raw.split(":")[0], [])
+            kernels.append(cur)
+            continue
+        if cur is not None:
+            cur[1].append((ln, raw))
+    for name, lines in kernels:
+        # instructions and labels
+        ins, labels, in_asm = [], {}, False
+        for ln, raw in lines:
+            if ";;#ASMSTART" in raw: in_asm = True; continue
+            if ";;#ASMEND" in raw: in_asm = False; continue
+            line = raw.split(";")[0].rstrip()
+            t = line.strip()
+            if not t: continue
+            if t.endswith(":") and not raw[0].isspace():
+                labels[t[:-1]] = len(ins)
+                continue
+            if t.startswith("."): continue
+            parts = t.split(None, 1)
+            ins.append((ln, parts[0], parts[1] if len(parts) > 1 else "", in_asm, t))
+            if parts[0] == "s_endpgm": break
+        if not ins: continue
+        # basic blocks
+        leaders = {0} | set(labels.values())
+        for i, (_, op, args, _, _) in enumerate(ins):
+            if op.startswith(("s_branch", "s_cbranch", "s_endpgm")) and i + 1 < len(ins): leaders.add(i + 1)
+        starts = sorted(x for x in leaders if x < len(ins))
+        bidx = {st: k for k, st in enumerate(starts)}
+        blocks = [(st, (starts[k + 1] if k + 1 < len(starts) else len(ins))) for k, st in enumerate(starts)]
+        succ = []
+        for st, en in blocks:
+            _, op, args, _, _ = ins[en - 1]
+            out = []
+            if op.startswith("s_branch") or op.startswith("s_cbranch"):
+                tgt = labels.get(args.strip())
+                if tgt is not None and tgt in bidx: out.append(bidx[tgt])
+            if not op.startswith("s_branch") and op != "s_endpgm" and en < len(ins): out.append(bidx[en])
+            succ.append(out)
+
+        def run(k, state, report):
+            nonlocal issued
+            st, en = blocks[k]
+            fl = set(state)
+            for i in range(st, en):
+                ln, op, args, ia, text = ins[i]
+                if op == "s_waitcnt":
+                    m = VM.search(args)
+                    if m and int(m.group(1)) == 0: fl = set()
+                    continue
+                touched = regs_of(args)
+                hand = ia and op.startswith(("global_load", "buffer_load"))
+                dest = regs_of(args.split(",")[0]) if hand else set()
+                hit = touched & fl
+                if report and hit and not (hand and not (dest & fl)):
+                    viol.append((name, ln, text, sorted(hit)))
+                if hand:
+                    fl |= dest
+                    if report: issued += 1
+            return fl
+
+        IN = [set() for _ in blocks]
+        work = list(range(len(blocks)))
+        while work:
+            k = work.pop()
+            out = run(k, IN[k], False)
+            for j in succ[k]:
+                if not out <= IN[j]:
+                    IN[j] |= out
+                    if j not in work: work.append(j)
+        for k in range(len(blocks)): run(k, IN[k], True)
+    return viol, issued
+
+
 def main(argv):
     bad = 0
-    for src in argv:
-        v, n = check(compile_asm(src))
+    cfg = "--cfg" in argv
+    for src in [a for a in argv if a != "--cfg"]:
+        v, n = (check_vm_cfg if cfg else check)(compile_asm(src))
         print(f"{os.path.basename(src)}: {n} hand-issued loads, {len(v)} violations")
         for k, ln, s, regs in v[:20]:
             print(f"  {k[:60]} line {ln}: `{s}` touches in-flight v{regs}")
