@@ -372,6 +372,12 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         {
             unsigned q, rem;
             qr((unsigned)lane, q, rem);
+            // (the eight values first, their LDS writes behind them: with a write to xb between two outputs' reads of the window and the weight table hipcc
+            // kept the order — it cannot tell the arrays apart — and waited for each output's reads before it asked for the next one's: eight LDS round
+            // trips in a row per tile)
+            float vo[E];
+#pragma unroll
+            for (int u = 0; u < E; u++) vo[u] = 0.f;
 #pragma unroll
             for (int u = 0; u < E; u++, q += P.dq256, rem += P.dr256) {   // (dq256 / dr256 hold the step of 64 outputs here)
                 const int idx = lane + 64 * u;
@@ -391,9 +397,12 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
                         const float c1 = 0.5f * (p2 - p0);
                         v = fmaf(fmaf(fmaf(c3, fx, c2), fx, c1), fx, p1);
                     }
-                    xb[skew(idx)] = JOBS ? __builtin_amdgcn_fmed3f(v, P.clo, P.chi) : __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);   // :667-668 (rem == 0: v is p1 itself); JOBS: :3323
+                    vo[u] = JOBS ? __builtin_amdgcn_fmed3f(v, P.clo, P.chi) : __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);   // :667-668 (rem == 0: v is p1 itself); JOBS: :3323
                 }
             }
+#pragma unroll
+            for (int u = 0; u < E; u++)
+                if (FULL || lane + 64 * u < cnt) xb[skew(lane + 64 * u)] = vo[u];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
