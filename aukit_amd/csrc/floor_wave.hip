@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
         if constexpr (DW) {
             const unsigned char *vb = w.al + 16 * (size_t)(lane >> 2);  // same rule as issue_loads: a vector that straddles the allocation reads as zero
             pre1 = 0;
-            if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *reinterpret_cast<const unsigned *>(w.al + 4 * (size_t)lane);
+            if ((lane >> 2) < w.nvec && vb >= P.safe_lo && vb + 16 <= P.safe_hi) pre1 = *(const __attribute__((address_space(1))) unsigned *)(uintptr_t)(w.al + 4 * (size_t)lane);   // (global_load: through the generic pointer it was a FLAT load, counted on lgkmcnt too — every LDS wait of the tile waited for the prefetch)
         } else issue_loads<NV>(P, w, lane, pre);
     };
     WaveTile cur = describe<SRC, HL, HR>(P, F, t);

@@ -442,7 +442,8 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
         const unsigned char *p = cb + 16 * (long long)j;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (valid && p + 16 <= P.safe_hi && p + 16 > P.src) {
-            const u32x4u t = *reinterpret_cast<const u32x4u *>(p);
+            typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+            const u32x4a t = *(const __attribute__((address_space(1))) u32x4a *)(uintptr_t)p;   // (aligned by construction; global_load_dwordx4 — as a generic pointer's FLAT load it sat on lgkmcnt as well, and every LDS wait of the round waited for the line requested for eight rounds later)
             v = make_uint4(t.x, t.y, t.z, t.w);
         } else if (valid) {
             unsigned t[4] = {0, 0, 0, 0};
