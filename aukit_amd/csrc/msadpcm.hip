@@ -21,6 +21,7 @@
 // Anything the wave kernel does not take (sinc, non-integer sample rates, > 512 output phases, coefficient tables whose products
 // could leave 32 bits) runs the lane-per-block fp64 kernel of round 1/2 (k_msadpcm) and the generic resampler behind it.
 #include <algorithm>
+#include <type_traits>
 #include "resample.h"
 #include "resample_dev.h"
 
@@ -346,6 +347,9 @@ static AUKIT_DEV void ms_vec_int(const unsigned (&w)[4], int nbytes, MsLane (&L)
 }
 
 enum { MS_ROWS_I16 = 0, MS_ROWS_F32 = 1, MS_ROWS_F64 = 2, MS_STREAM = 3 };
+// the stream kernels' list of deferred output lines (flushed when the next lines would not fit; a call of defer() adds at most 64).  With the register
+// window (REGS) the list lies where the staged fetch keeps its 64 block offsets: the kernel's LDS — what bounds its resident waves — does not grow
+constexpr unsigned MS_DL_CAP = 64;
 
 // C channels; RB bytes of a block per round; MODE one of the enums above; stream mode: INTERP, MIX (stereo: l + r / 2, :2672), OUT_T
 // FB bytes of a block per FETCH (the staging area holds them; FB / RB rounds consume it): the stream kernels fetch 64 bytes at a time and decode
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
     float *const wt = reinterpret_cast<float *>(adl + 16);                         // fb × WF (stream mode)
     constexpr bool LANEOUT = MODE == MS_STREAM && sizeof(OUT_T) == 1;               // int8 chunks: every lane makes its own block's outputs (below)
     [[maybe_unused]] signed char *const stage = reinterpret_cast<signed char *>(wt + ((MODE == MS_STREAM ? P.fb * WF : 0u) + 3u & ~3u));   // (C == 2 && !MIX ? 2 : 1) × 64 × P.sst bytes
+    [[maybe_unused]] unsigned *const dl = REGS ? reinterpret_cast<unsigned *>(bp) : reinterpret_cast<unsigned *>(stage + (((STREAM ? (size_t)(C == 2 && !MIX ? 2 : 1) * 64 * P.sst : 0) + 7) & ~(size_t)7));   // MS_DL_CAP entries of two dwords: the deferred lines (stream mode)
     if (lane < 16) adl[lane] = c_ms_adapt[lane];
     if constexpr (STREAM) for (unsigned i = lane; i < P.fb * WF; i += 64) wt[i] = P.wg[i];
     const unsigned long long ba = (unsigned long long)P.block_align;
@@ -601,7 +606,10 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
             Seg sg; sg.w_lo = 1; sg.w_hi = w_hi;
             const unsigned total = nvalid * nj;
             // one output: block-relative index j at position (q0, remc) [x - 1 = q0 + remc / fb], from the block's table rows t0 (t1: the second channel)
-            auto one_output = [&](unsigned j, unsigned q0, unsigned remc, const float *t0, const float *t1, bool active, OUT_T &v0, OUT_T &v1) {
+            // SEL 0: tier 1 for every line of the output; what it does not vouch for is NOT computed here — `fails` says which lines (bit 0, bit 1) and
+            // the caller puts them on the wave's list (defer / flush below).  SEL 1 / 2: tiers 2 and 3 for line 0 / 1 of an output from that list.
+            auto one_output = [&](auto selc, unsigned j, unsigned q0, unsigned remc, const float *t0, const float *t1, bool active, OUT_T &v0, OUT_T &v1, unsigned &fails) {
+                constexpr int SEL = decltype(selc)::value;
                 const int k = (int)q0 + 1;  // floor(x), exact
                 const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && remc != 0));
                 const int s1 = inside ? k - kbase + 1 : 3;   // slot of table index k
@@ -665,7 +673,14 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     if (!ok) { d = tier3(ta); if (tb) d = d + tier3(tb) / 2; }
                     return lua_clamp(floor(d), -128, 127);   // :2673 / :2674 / :2727
                 };
-                auto put = [&](float v, float spread, const float *ta, const float *tb) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
+                auto slow_value = [&](const float *ta, const float *tb) -> OUT_T {
+                    const double d = slow(ta, tb);
+                    if constexpr (sizeof(OUT_T) == 8) return (OUT_T)d;
+                    else return (OUT_T)(int)__builtin_amdgcn_fmed3f((float)d, -128.0f, 127.0f);
+                };
+                if constexpr (SEL == 1) { v0 = (C == 2 && MIX) ? slow_value(t0, t1) : slow_value(t0, nullptr); return; }
+                if constexpr (SEL == 2) { v1 = slow_value(t1, nullptr); return; }
+                auto put = [&](float v, float spread, const float *ta, const float *tb, unsigned failbit) -> OUT_T {   // the value (the caller stores it: a pointer that may be LDS or HBM would make every store a flat one)
                     if constexpr (AUDIT) {
                         if (active && inside) { double d2 = tier2(ta); if (tb) d2 = d2 + tier2(tb) / 2; amax = fmaxf(amax, (float)fabs((double)v - d2)); acnt++; }
                     }
@@ -679,18 +694,57 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     // streams: 5 % of the outputs sit in such stretches (the encoder clips) and went through tier 2 one or two lanes at a time —
                     // half of the wave's turns, 1.2 of the kernel's 2.6 ms.
                     if constexpr (INTERP != AUKIT_INTERP_NONE && C == 1) accept = accept || (inside && fr == 0.0f && spread == 0.0f && remc != 0);
-                    if (active && !accept) {
-                        const double d = slow(ta, tb);
-                        if constexpr (sizeof(OUT_T) == 8) return (OUT_T)d;
-                        fl = (float)d;
-                    }
+                    // (not vouched for: tiers 2 and 3 LATER, for the wave's failures together — computed here, under a branch the whole wave takes when
+                    // one lane in 64 needs it (one output in ~400 does: one turn in seven), they were a sixth of the kernel's instructions)
+                    if (active && !accept) fails |= failbit;
                     if constexpr (sizeof(OUT_T) == 8) return (OUT_T)fminf(fmaxf(fl, -128.0f), 127.0f);   // (a nan — garbage input on the fp64 path — stays what fmin / fmax make of it)
                     else return (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
                 };
                 float sa = 1.0f, sb = 1.0f;
-                if constexpr (C == 1) { const float a = tier1(t0, sa); v0 = put(a, sa, t0, nullptr); }
-                else if constexpr (MIX) { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(__builtin_fmaf(b2, 0.5f, a), fmaxf(sa, sb), t0, t1); }   // l + r / 2
-                else { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(a, sa, t0, nullptr); v1 = put(b2, sb, t1, nullptr); }
+                if constexpr (C == 1) { const float a = tier1(t0, sa); v0 = put(a, sa, t0, nullptr, 1u); }
+                else if constexpr (MIX) { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(__builtin_fmaf(b2, 0.5f, a), fmaxf(sa, sb), t0, t1, 1u); }   // l + r / 2
+                else { const float a = tier1(t0, sa), b2 = tier1(t1, sb); v0 = put(a, sa, t0, nullptr, 1u); v1 = put(b2, sb, t1, nullptr, 2u); }
+            };
+            // the wave's list of output lines tier 1 did not vouch for: (block, line, j, q0, rem) in two dwords; flushed — tiers 2 / 3 with a lane per
+            // entry — when the next lines would not fit and before the round's table rows move on.  `to_stage`: the value goes to the LDS row it was left
+            // out of (the int8 chunk rows), else to the audio
+            unsigned dcnt = 0;
+            auto flush = [&](bool to_stage) {
+                if (!dcnt) return;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (unsigned i0 = 0; i0 < dcnt; i0 += 64) {
+                    const bool on = i0 + lane < dcnt;
+                    const unsigned e0 = on ? dl[2 * (i0 + lane)] : 0u, e1 = on ? dl[2 * (i0 + lane) + 1] : 0u;
+                    const unsigned j = e0 & 0x3FFFFFFu, bb = e0 >> 26, q0 = e1 & 0x1FFFFu, remc = (e1 >> 17) & 0x1FFu, lines = e1 >> 26;
+                    const float *t0 = tab + __umul24(bb, ROW), *t1 = t0 + 64 * ROW;
+                    OUT_T v0 = 0, v1 = 0;
+                    unsigned dummy = 0;
+                    if (lines & 1u) {
+                        one_output(std::integral_constant<int, 1>{}, j, q0, remc, t0, t1, true, v0, v1, dummy);
+                        if (to_stage) { if constexpr (sizeof(OUT_T) == 1) stage[bb * P.sst + (j - rd.jl)] = (signed char)v0; }
+                        else reinterpret_cast<OUT_T *>(P.out)[ob[bb] + j] = v0;
+                    }
+                    if constexpr (C == 2 && !MIX) {
+                        if (lines & 2u) {
+                            one_output(std::integral_constant<int, 2>{}, j, q0, remc, t0, t1, true, v0, v1, dummy);
+                            if (to_stage) { if constexpr (sizeof(OUT_T) == 1) stage[(64u + bb) * P.sst + (j - rd.jl)] = (signed char)v1; }
+                            else reinterpret_cast<OUT_T *>(P.out)[ob[bb] + os[bb] + j] = v1;
+                        }
+                    }
+                }
+                dcnt = 0;
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto defer = [&](bool to_stage, unsigned lines, unsigned bb, unsigned j, unsigned q0, unsigned remc) {   // lines: bit 0 / bit 1 = the output's first / second line
+                const bool need = lines != 0;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+                if (m) {   // (wave-uniform)
+                    if (dcnt + (unsigned)__builtin_popcountll(m) > MS_DL_CAP) flush(to_stage);
+                    const unsigned pos = dcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (need) { dl[2 * pos] = j | bb << 26; dl[2 * pos + 1] = q0 | remc << 17 | lines << 26; }   // (j < 2^26, q0 < 2^17, rem < 2^9: checked by the host)
+                    dcnt += (unsigned)__builtin_popcountll(m);
+                }
             };
             if (nj && LANEOUT && P.sst) {
                 // int8 chunks (round 3).  Every block of the wave has the same geometry, so output j of the round sits at the same (q, rem) in all
@@ -708,12 +762,15 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                 const unsigned dq1 = P.fa / P.fb, dr1 = P.fa - dq1 * P.fb;
                 for (unsigned jj = 0; jj < nj_s; jj++) {
                     OUT_T v0 = 0, v1 = 0;
-                    one_output(jl_s + jj, q0, rem, t0, t1, valid, v0, v1);
+                    unsigned fm = 0;
+                    one_output(std::integral_constant<int, 0>{}, jl_s + jj, q0, rem, t0, t1, valid, v0, v1, fm);
                     st0[jj] = (signed char)v0;
                     if constexpr (C == 2 && !MIX) st1[jj] = (signed char)v1;
+                    defer(true, fm, (unsigned)lane, jl_s + jj, q0, rem);
                     q0 += dq1; rem += dr1;
                     if (rem >= P.fb) { rem -= P.fb; q0++; }
                 }
+                flush(true);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 unsigned b = rd.b0q ? (unsigned)lane / nj : 0, jj = rd.b0q ? (unsigned)lane % nj : (unsigned)lane;
@@ -745,9 +802,12 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     if (jj >= nj) { jj -= nj; b++; q0 -= rd.nq; if (rem < rd.nrm) { rem += P.fb; q0--; } rem -= rd.nrm; }
                     OUT_T *const o0 = reinterpret_cast<OUT_T *>(P.out) + ob[bb] + j;
                     OUT_T v0 = 0, v1 = 0;
-                    one_output(j, q0c, remc, t0, t1, active, v0, v1);
-                    if (active) { *o0 = v0; if constexpr (C == 2 && !MIX) o0[os[bb]] = v1; }
+                    unsigned fm = 0;
+                    one_output(std::integral_constant<int, 0>{}, j, q0c, remc, t0, t1, active, v0, v1, fm);
+                    if (active) { if (!(fm & 1u)) *o0 = v0; if constexpr (C == 2 && !MIX) { if (!(fm & 2u)) o0[os[bb]] = v1; } }
+                    defer(false, fm, bb, j, q0c, remc);
                 }
+                flush(false);
             }
         }
         // the round's last four samples are the next round's slots 0..3
@@ -993,7 +1053,8 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         sst = (unsigned)((((njmax + 3) / 4) | 1) * 4);
         if ((size_t)nd * 64 * sst > 24 * 1024) sst = 0;                // strong up-sampling: the pair-mapped loop
     }
-    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM, (size_t)nd * 64 * sst) : 0;
+    wave = wave && spb_dec < (1u << 17) && newlen < (1u << 26);   // (the deferred-line records of k_ms_wave pack q0 and j into 17 and 26 bits)
+    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM, (((size_t)nd * 64 * sst + 7) & ~(size_t)7) + ((MS_RB == 16 && MS_FB_STREAM == 128) ? 0 : (size_t)MS_DL_CAP * 8)) : 0;
     if (wave && lds <= 64 * 1024) {
         const int R = MS_RB * 2 / C, ndata = d->block_align - 7 * C, nr = (ndata + MS_RB - 1) / MS_RB;
         // tables: blk0 (n + 1) | out_off (n) | out_stride (n) | err | rounds (nr) | weights (fb * wf, f32)
