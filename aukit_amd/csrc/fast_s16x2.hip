@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_s16x2(const ResampleParams P,
         }
         // the tile's segment: the right channel's row is out_stride elements after the left one
         unsigned sidx;
-        if (P.tiles_per_seg) sidx = t / P.tiles_per_seg; else sidx = P.tile_seg[t];
-        const unsigned ostride = P.segs[sidx].out_stride;
+        if (P.tiles_per_seg) sidx = t / P.tiles_per_seg; else sidx = as_const(P.tile_seg)[t];
+        const unsigned ostride = load_seg(P.segs, sidx).out_stride;   // (scalar loads: cf. floor_wave.hip)
         const unsigned tn = t + nwaves;
         const bool more = tn < P.n_tiles;
         WaveTile nxt = cur;

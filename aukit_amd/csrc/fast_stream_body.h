@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream(const ResampleParams P
     issue_loads<NV>(P, cur, lane, pre);
     for (;;) {
         write_lds<SRC, NV>(P, F, cur, lane, pre, sm);
-        const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - P.seg_tile0[P.tile_seg[t]]) == 0;  // first tile of its iterator call
+        const bool first = (P.tiles_per_seg ? t % P.tiles_per_seg : t - as_const(P.seg_tile0)[as_const(P.tile_seg)[t]]) == 0;  // first tile of its iterator call
         const unsigned tn = t + nwaves;
         const bool more = tn < P.n_tiles;
         WaveTile nxt = cur;

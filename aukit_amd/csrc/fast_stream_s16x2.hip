@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void k_fast_wave_stream_s16x2(const ResamplePa
         }
         unsigned sidx, tin;
         if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
-        else { sidx = P.tile_seg[t]; tin = t - P.seg_tile0[sidx]; }
-        const unsigned ostride = P.segs[sidx].out_stride;
+        else { sidx = as_const(P.tile_seg)[t]; tin = t - as_const(P.seg_tile0)[sidx]; }
+        const unsigned ostride = load_seg(P.segs, sidx).out_stride;   // (scalar loads: cf. floor_wave.hip)
         const bool first = tin == 0;  // first tile of its iterator call: ls = 0
         const unsigned tn = t + nwaves;
         const bool more = tn < P.n_tiles;

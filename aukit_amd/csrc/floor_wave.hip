@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void k_floor_wave_g711(const ResampleParams P,
         // the tile's segment, for the reference-order fallback
         unsigned sidx, tin;
         if (P.tiles_per_seg) { sidx = t / P.tiles_per_seg; tin = t - sidx * P.tiles_per_seg; }
-        else { sidx = P.tile_seg[t]; tin = t - P.seg_tile0[sidx]; }
-        const Seg sg = P.segs[sidx];
+        else { sidx = as_const(P.tile_seg)[t]; tin = t - as_const(P.seg_tile0)[sidx]; }
+        const Seg sg = load_seg(P.segs, sidx);   // (scalar loads: as vector loads they sat on vmcnt in front of the next tile's window request, and the wait for THEM — vmcnt(0), the request is in a fork — was the wait for the request: no prefetch)
         const unsigned tn = t + nwaves;
         const bool more = tn < P.n_tiles;
         WaveTile nxt = cur;
