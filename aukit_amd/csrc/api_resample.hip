@@ -602,6 +602,28 @@ __global__ __launch_bounds__(256) void k_deinterleave_bytes(const unsigned char 
     }
 }
 
+// two channels: a thread takes eight frames as one 16-byte load and leaves eight bytes in either row (the general kernel above reads every line of
+// the input once per channel, a byte per load: 0.19 of stream.g711 stereo's 0.53 ms per 1024 five-second streams went there)
+__global__ __launch_bounds__(256) void k_deinterleave_bytes2(const unsigned char *src, const unsigned long long *in_off, const unsigned long long *row_off, unsigned char *dst) {
+    const unsigned s = blockIdx.y;
+    const unsigned long long frames = (in_off[s + 1] - in_off[s]) / 2ull;
+    const unsigned char *p = src + in_off[s];
+    unsigned char *o0 = dst + row_off[2 * (size_t)s], *o1 = dst + row_off[2 * (size_t)s + 1];
+    typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; 8 * g < frames; g += (unsigned long long)gridDim.x * 256) {
+        if (8 * g + 8 <= frames) {
+            const u32x4u w = *reinterpret_cast<const u32x4u *>(p + 16 * g);
+            uint2 a, b;
+            a.x = __builtin_amdgcn_perm(w.y, w.x, 0x06040200u); a.y = __builtin_amdgcn_perm(w.w, w.z, 0x06040200u);
+            b.x = __builtin_amdgcn_perm(w.y, w.x, 0x07050301u); b.y = __builtin_amdgcn_perm(w.w, w.z, 0x07050301u);
+            *reinterpret_cast<uint2 *>(o0 + 8 * g) = a;    // (rows start at multiples of 16 bytes)
+            *reinterpret_cast<uint2 *>(o1 + 8 * g) = b;
+        } else {
+            for (unsigned long long f = 8 * g; f < frames; f++) { o0[f] = p[2 * f]; o1[f] = p[2 * f + 1]; }
+        }
+    }
+}
+
 static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                        aukit_chunks **chunks_out) {
     const int C = d->channels;
@@ -689,6 +711,10 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
         uint64_t maxfr = 0;
         for (uint32_t s = 0; s < in->n; s++) maxfr = std::max<uint64_t>(maxfr, (in->off[s + 1] - in->off[s]) / (uint64_t)C);
         const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((maxfr / 4 + 255) / 256, 1), 64);
+        if (C == 2)
+            hipLaunchKernelGGL(k_deinterleave_bytes2, dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>((maxfr / 8 + 255) / 256, 1), 64), in->n), dim3(256), 0, ctx->stream, in->data(),
+                               reinterpret_cast<const unsigned long long *>(in->d_off), reinterpret_cast<const unsigned long long *>(pl + tab_at), pl);
+        else
         hipLaunchKernelGGL(k_deinterleave_bytes, dim3(gx, in->n * (unsigned)C), dim3(256), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off),
                            reinterpret_cast<const unsigned long long *>(pl + tab_at), C, pl);
         if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_deinterleave_bytes launch failed"); }
