@@ -173,10 +173,18 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
 #pragma unroll
                     for (int q = 0; q < NQ; q++) nxt[q] = reinterpret_cast<const uint4 *>(a + 16 * NQ)[q];
                 }
+#ifdef AUKIT_DF_MAPS_ROLLED
 #pragma unroll 1
-                for (int q = 0; q < NQ; q++) {
+#else
+#pragma unroll
+#endif
+                for (int q = 0; q < NQ; q++) {   // (unrolled: as a loop, cur[q] is an array indexed by a variable — scratch memory, whose loads wait vmcnt(0): for the prefetch too)
                     const unsigned w4[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#ifdef AUKIT_DF_MAPS_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
                     for (int w = 0; w < 4; w++) {
                         const unsigned word = w4[w];
 #pragma unroll
