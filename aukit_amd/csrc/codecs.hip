@@ -667,6 +667,7 @@ struct CvImaF32 {
 #define AUKIT_IMA_TIER1_GUARD 5e-4f
 #endif
 constexpr float TIER1_GUARD = AUKIT_IMA_TIER1_GUARD;
+constexpr unsigned IMA_DL_CAP = 32;   // k_ima_stream_f32's list of deferred outputs (entries; at most 64 lanes: one per lane when flushed)
 
 template <int INTERP, typename OUT_T, int PH, bool AUDIT = false>
 __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P, const float *__restrict__ wg) {
@@ -776,6 +777,21 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             const unsigned long long lim = jm < newlen ? jm : newlen;
             mid_end = (unsigned)(lim & ~63ull);
         }
+        unsigned *const dl = reinterpret_cast<unsigned *>(sm + (P.cap - (int)IMA_DL_CAP));   // the table's last IMA_DL_CAP slots (the host's capf leaves them free)
+        unsigned dcnt = 0;
+        auto flush_deferred = [&]() {
+            if (!dcnt) return;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((unsigned)lane < dcnt) {
+                const unsigned j = dl[lane], n = j * P.fa;
+                const unsigned q = __umulhi(n, P.fmagic);
+                const float fl = slow((int)q + 1, n - q * P.fb, j, true);
+                obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
+            }
+            dcnt = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
         auto row = [&](unsigned rb, auto cleanc) {
             constexpr bool CLEAN = decltype(cleanc)::value;
             const unsigned j = rb + lane;
@@ -824,13 +840,28 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
                 ob[64 * i] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
             }
             if (__any(need != 0)) {
-                while (need) {
-                    const int i = __builtin_ctz(need);
-                    need &= need - 1;
-                    const unsigned j = rb + 64 * i + lane, n = j * P.fa;
-                    const unsigned q = __umulhi(n, P.fmagic);
-                    const float fl = slow((int)q + 1, n - q * P.fb, j, true);
-                    obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
+                // (round 4, late) the turned-down outputs go on the wave's list (their index j, in the table's spare slots) and tiers 2 - 3 take them
+                // together, a lane each, when the list is full and behind the block's rows: redone here — one pass per row with a turn-down, one or
+                // two lanes alive in it — they were a twelfth of the kernel's instructions for a five-hundredth of its outputs
+#pragma unroll
+                for (int i = 0; i < NPH; i++) {
+                    const bool nd = (need >> i) & 1u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(nd);
+                    if (m) {   // (wave-uniform)
+                        const unsigned c = (unsigned)__builtin_popcountll(m);
+                        if (dcnt + c > IMA_DL_CAP) flush_deferred();
+                        if (c > IMA_DL_CAP) {   // (more than the list holds in one row — silence, garbage: in place)
+                            if (nd) {
+                                const unsigned j = rb + 64 * i + lane, n = j * P.fa;
+                                const unsigned q = __umulhi(n, P.fmagic);
+                                const float fl = slow((int)q + 1, n - q * P.fb, j, true);
+                                obase[j] = (OUT_T)(int)__builtin_amdgcn_fmed3f(fl, -128.0f, 127.0f);
+                            }
+                        } else {
+                            if (nd) dl[dcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = rb + 64 * i + lane;
+                            dcnt += c;
+                        }
+                    }
                 }
             }
         };
@@ -850,6 +881,7 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
             if (rb >= mid_lo && rb + 64 <= mid_end) row(rb, std::true_type{}); else row(rb, std::false_type{});
             rb += 64; q0 += P.fdq; rem += P.fdr;
         }
+        flush_deferred();
         __builtin_amdgcn_wave_barrier();  // the next block's decode overwrites the table
     }
     if constexpr (AUDIT) {
@@ -1138,7 +1170,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                 for (uint32_t s = 1; s < in->n && uni; s++) uni = blk0[s + 1] - blk0[s] == b1;
                 if (uni) P.bps = b1;
             }
-            const int capf = (int)((ba - 4ull) * 2 + 8 + 8 + 15) & ~15;  // floats per wave: the block's nibbles + the junk word's + slack, unskewed
+            const int capf = ((int)((ba - 4ull) * 2 + 8 + 8 + 15) & ~15) + (int)IMA_DL_CAP;  // floats per wave: the block's nibbles + the junk word's + slack, unskewed, + the deferred-output list
             const size_t lds = ((((size_t)P.fb * wf + 3) & ~(size_t)3) + 96) * 4 + (size_t)capf * 4 * 4;
             if (lds <= 64 * 1024) {
                 P.cap = capf;
