@@ -197,6 +197,7 @@ __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const
         h0 = be16(q.x, 1); h1 = be16(q.x, 0); h2 = be16(q.y, 1); h3 = be16(q.y, 0);
         w0 = be16(q.z, 1); w1 = be16(q.z, 0); w2 = be16(q.w, 1); w3 = be16(q.w, 0);
     }
+    int g0 = (h0 >> 31) | 1, g1 = (h1 >> 31) | 1, g2 = (h2 >> 31) | 1, g3 = (h3 >> 31) | 1;   // the history samples' signs
     unsigned nrmax = (ns + K - 1) / K;
     for (int o = 32; o > 0; o >>= 1) nrmax = max(nrmax, (unsigned)__shfl_xor((int)nrmax, o));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -226,27 +227,34 @@ __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const
 #pragma unroll
         for (int sj = 0; sj < K; sj++) {
             const unsigned long long raw = sl_in[lane * (K + 1) + sj];
-            unsigned hi = __builtin_bswap32((unsigned)raw), lo = __builtin_bswap32((unsigned)(raw >> 32));   // (">I4I4"):unpack
+            const unsigned hi = __builtin_bswap32((unsigned)raw), lo = __builtin_bswap32((unsigned)(raw >> 32));   // (">I4I4"):unpack
             const int *dq = deq + (hi >> 28) * 8;   // scalefactor = bit32_extract(sliceH, 28, 4)
             unsigned pk[S8 ? 5 : 10];
 #pragma unroll
             for (int k = 0; k < 20; k++) {
                 const int sum = qoa_mad24(w3, h3, qoa_mad24(w2, h2, qoa_mad24(w1, h1, qoa_mul24(w0, h0))));   // the low 32 bits of the Lua's double sum
                 const int predicted = sum >> 13;                                                              // signed_rshift(..., 13)  :1686-1689
-                const int d = dq[(hi >> 25) & 7];
+                // quantized = bit32_extract(sliceH, 25, 3), then the slice moves three bits up (:1752-1760): residual k sits at bits 57 - 3 k .. 59 - 3 k of
+                // the 64, a constant once the loop is unrolled — one v_bfe_u32 instead of a shift, a mask and the two-word shift (k = 9 straddles the words)
+                const int bp = 57 - 3 * k;
+                unsigned qi;
+                if (bp >= 32) qi = __builtin_amdgcn_ubfe(hi, (unsigned)(bp - 32), 3u);
+                else if (bp + 3 <= 32) qi = __builtin_amdgcn_ubfe(lo, (unsigned)bp, 3u);
+                else qi = __builtin_amdgcn_alignbit(hi, lo, (unsigned)bp) & 7u;
+                const int d = dq[qi];
                 const int rec = qoa_med3(predicted + d, lo16, hi16);                                         // :1763
-                if constexpr (S8) {
-                    const unsigned v8 = (unsigned)(rec >> 8) & 0xFFu;                                        // math_floor(reconstructed / 256)  :3299
-                    if ((k & 3) == 0) pk[k >> 2] = v8; else pk[k >> 2] |= v8 << (8 * (k & 3));
+                if constexpr (S8) {   // math_floor(reconstructed / 256) = byte 1 of the int32  (:3299): one v_perm_b32 drops it into its place
+                    constexpr unsigned SEL[4] = {0x0c0c0c05u, 0x0c0c0500u, 0x0c050100u, 0x05020100u};
+                    pk[k >> 2] = __builtin_amdgcn_perm((unsigned)rec, (k & 3) ? pk[k >> 2] : 0u, SEL[k & 3]);
                 } else {
-                    const unsigned v16 = (unsigned)rec & 0xFFFFu;
-                    if (k & 1) pk[k >> 1] |= v16 << 16; else pk[k >> 1] = v16;
+                    if (k & 1) pk[k >> 1] = __builtin_amdgcn_perm((unsigned)rec, pk[k >> 1], 0x05040100u); else pk[k >> 1] = (unsigned)rec;   // (the upper half: overwritten by the odd sample)
                 }
-                hi = (hi << 3) | (lo >> 29);
-                lo <<= 3;
                 const int delta = d >> 4;                                                                     // signed_rshift(residual, 4)
-                w0 += h0 < 0 ? -delta : delta; w1 += h1 < 0 ? -delta : delta; w2 += h2 < 0 ? -delta : delta; w3 += h3 < 0 ? -delta : delta;   // :1694-1699
+                // weights[i] += history[i] < 0 and -delta or delta  (:1694-1699) as ONE v_mad_i32_i24 each: the history sample's sign (+-1, made once when
+                // the sample is, two instructions) times delta (|delta| < 2^11) — a compare, four selects and four adds otherwise: 10 of the 21 per sample
+                w0 = qoa_mad24(g0, delta, w0); w1 = qoa_mad24(g1, delta, w1); w2 = qoa_mad24(g2, delta, w2); w3 = qoa_mad24(g3, delta, w3);
                 h0 = h1; h1 = h2; h2 = h3; h3 = rec;
+                g0 = g1; g1 = g2; g2 = g3; g3 = (rec >> 31) | 1;
             }
             unsigned *ow = reinterpret_cast<unsigned *>(obuf + lane * OSTR + sj * 20 * OB);
 #pragma unroll
