@@ -21,6 +21,7 @@ DOMINANT = [("k_wave_f64<pcm_s16le_mono,cubic,tile640,phase_regs>", "wavef64", "
             ("k_wave_f64<pcm_s16le_mono,cubic,tile640,phase_regs,stream_pcm>", "pcmstream", "k_wave_f64", 4096),
             ("k_wave_coef_f64<g711_mono,cubic>", "g711cubic", "k_wave_coef_f64<", 4096),
             ("k_fast_wave_s16x2<cubic,nv4>", "stereo", "k_fast_wave_s16x2<", 2048),
+            ("k_fast_wave_stream_s16x2<cubic,nv4,stereo>", "stereostream", "k_fast_wave_stream_s16x2<", 2048),
             ("k_floor_wave_g711<cubic>", "g711stream", "k_floor_wave_g711<", 4096),
             ("k_ima_stream_f32", "ima", "k_ima_stream_f32<", 4096),
             ("k_ms_wave", "msadpcm", "k_ms_wave<", 4096)]
