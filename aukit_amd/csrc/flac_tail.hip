@@ -174,7 +174,13 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
     long long base0 = 0, base1 = 0, base2 = 0;
     int bound = 0x7FFFFFFF;
     unsigned fcur = 0;
-    auto rec_base = [&](unsigned f) -> long long { const FrameRec a = fr_s[f]; return (long long)P.fr_mul * (long long)a.scratch + (long long)c * a.bs - (long long)f * bsn; };
+    // (the record by SCALAR loads — the frame index is the wave's: as vector loads they waited vmcnt(0), behind the tile's stores)
+    auto rec_base = [&](unsigned f) -> long long {
+        const __attribute__((address_space(4))) unsigned long long *q = (const __attribute__((address_space(4))) unsigned long long *)(fr_s + f);
+        const unsigned long long scratch = q[1];
+        const int bs = (int)(unsigned)q[2];
+        return (long long)P.fr_mul * (long long)scratch + (long long)c * bs - (long long)f * bsn;
+    };
     if (P.frames && L > 0 && nfr_s > 0) {
         base0 = rec_base(0);
         bound = bsn;
