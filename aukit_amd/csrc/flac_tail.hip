@@ -187,12 +187,12 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         base1 = nfr_s > 1 ? rec_base(1) : base0;
         base2 = nfr_s > 2 ? rec_base(2) : base1;
     }
-    // Round 4, late: the window as ALIGNED 16-BYTE VECTORS where it lies inside the row (every tile but a row's first and last).  One element per
-    // lane and load — a clamp, a frame select and a 64-bit address each — was 13 of the kernel's 45 VALU instructions per output, and PMC says the
-    // kernel is bound by those (VALU busy ~ 75 %).  A window is one run of elements (part A) or two (frame-by-frame rows: the rest in the frame
-    // after, part B); a part is read from the vector that holds its first element on, vector s of the tile by lane s % 64.  Part A's vectors are
-    // written to LDS as they stand — what they hold beyond the part falls into the slack around the window or onto part B's place — part B's
-    // behind them, its first vector guarded.
+    // Round 4, late: the window as ALIGNED VECTORS of eight elements where it lies inside the row (every tile but a row's first and last).  One
+    // element per lane and load — a clamp, a frame select and a 64-bit address each — was 13 of the kernel's 45 VALU instructions per output.  A
+    // window is one run of elements (part A) or two (frame-by-frame rows: the rest in the frame after, part B); a part is read from the vector that
+    // holds its first element on, vector s of the tile by lane s (at most 64 of them: else the element-by-element way).  Part A's vectors are written
+    // to LDS as they stand, where their alignment puts them (`win + 8 s`: the window's first element is `win[hA]`) — what they hold beyond the part
+    // falls into the slack around the window or onto part B's place — part B's behind them, element by element, its first vector guarded.
     struct VecDesc { int on, nvA, nvB, hA, dposB, loB; };   // hA: the window's first element sits hA floats behind `win` (part A's vectors are written where their alignment puts them)
     auto fetch = [&](unsigned kk, int nst, VT &pva, VecDesc &vd) {
         if (P.frames && L > 0) {
