@@ -819,18 +819,23 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
         };
         // (the turn-downs of a GROUP are redone behind the group; noting them per block — a bit per row — and redoing them behind all the rows
         // measured 7 % more VALU instructions, not fewer: 1.81 G against 1.68 G per launch of config 3a)
-        [[maybe_unused]] auto group = [&](unsigned rb, unsigned gq) {   // PH clean rows from output rb (a multiple of 64 PH), table entries from gq on
+        // ROT (round 4, last): the group starts ROT rows behind a multiple of PH rows — its row i has phase (i + ROT) mod PH, one cycle of table entries
+        // (qstep) further on where that wraps.  With ROT = 1 the groups begin right behind a block's first (unclean) row: six groups instead of five
+        // in a 2229-output block, five rows instead of ten left to the row-by-row code
+        [[maybe_unused]] auto group = [&](unsigned rb, unsigned gq, auto rotc) {   // PH clean rows from output rb (64 (PH g + ROT)), table entries from gq on
+            constexpr int ROT = decltype(rotc)::value;
             unsigned need = 0;
             OUT_T *const ob = obase + (rb + lane);      // one 64-bit address per group: the rows' stores are immediate offsets from it
 #pragma unroll
             for (int i = 0; i < NPH; i++) {
-                const float *tp = sm + (qo[i] + gq);   // s1 = floor(x) - 1
+                const int p = (i + ROT) % NPH;   // (a constant once the loop is unrolled)
+                const float *tp = sm + (qo[p] + gq + ((i + ROT) >= NPH ? P.qstep : 0u));   // s1 = floor(x) - 1
                 const float p1 = tp[0], p2 = tp[1];
                 float v;
-                if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fmaf(p2 - p1, pw[i].x, p1);
+                if constexpr (INTERP == AUKIT_INTERP_LINEAR) v = __builtin_fmaf(p2 - p1, pw[p].x, p1);
                 else {
                     const float p0 = tp[-1], p3 = tp[2];
-                    v = __builtin_fmaf(pw[i].w, p3, __builtin_fmaf(pw[i].z, p2, __builtin_fmaf(pw[i].y, p1, pw[i].x * p0)));
+                    v = __builtin_fmaf(pw[p].w, p3, __builtin_fmaf(pw[p].z, p2, __builtin_fmaf(pw[p].y, p1, pw[p].x * p0)));
                 }
                 asm volatile("" : "+v"(v));   // rows stay scalar: paired into v_pk_fma_f32 they cost a dozen v_mov per pair to line the operands up
                 const float fl = floorf(v);
@@ -865,12 +870,13 @@ __global__ __launch_bounds__(256) void k_ima_stream_f32(const ImaStreamParams P,
                 }
             }
         };
-        unsigned gq = 0, gnext = 0;   // the next group boundary (output index) and its table offset
+        const bool rot1 = PH > 1 && mid_lo == 64;   // (wave-uniform) the groups begin at the block's second row
+        unsigned gq = 0, gnext = rot1 ? 64u : 0u;   // the next group boundary (output index) and its table offset
         for (unsigned rb = 0; rb < newlen;) {
             if constexpr (PH > 0) {
                 if (rb == gnext) {
                     if (rb >= mid_lo && rb + 64 * PH <= mid_end) {
-                        group(rb, gq);
+                        if (rot1) group(rb, gq, std::integral_constant<int, 1>{}); else group(rb, gq, std::integral_constant<int, 0>{});
                         rb += 64 * PH; q0 += P.qstep;          // 64 PH fa = qstep fb exactly: rem stays
                         gnext = rb; gq += P.qstep;
                         continue;
