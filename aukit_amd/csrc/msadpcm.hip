@@ -605,13 +605,17 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
             const int w_hi = (int)P.spb_dec;    // #left
             Seg sg; sg.w_lo = 1; sg.w_hi = w_hi;
             const unsigned total = nvalid * nj;
+            // (wave-uniform) every output of the round has floor(x) = k in kbase + 1 .. kbase + R: are all their taps inside the table?
+            const bool clean_round = INTERP == AUKIT_INTERP_CUBIC ? (kbase + 1 >= 3 && kbase + R + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (kbase + 1 >= 2 && kbase + R + 1 <= w_hi) : false);
             // one output: block-relative index j at position (q0, remc) [x - 1 = q0 + remc / fb], from the block's table rows t0 (t1: the second channel)
             // SEL 0: tier 1 for every line of the output; what it does not vouch for is NOT computed here — `fails` says which lines (bit 0, bit 1) and
             // the caller puts them on the wave's list (defer / flush below).  SEL 1 / 2: tiers 2 and 3 for line 0 / 1 of an output from that list.
             auto one_output = [&](auto selc, unsigned j, unsigned q0, unsigned remc, const float *t0, const float *t1, bool active, OUT_T &v0, OUT_T &v1, unsigned &fails) {
                 constexpr int SEL = decltype(selc)::value;
                 const int k = (int)q0 + 1;  // floor(x), exact
-                const bool inside = INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && remc != 0));
+                // (SEL 3 = SEL 0 in a round all of whose outputs have their taps inside the table — every round of a block but its first and its last one or
+                // two: `inside` is a constant there, five instructions per output less)
+                const bool inside = SEL == 3 || (INTERP == AUKIT_INTERP_CUBIC ? (k >= 3 && k + 2 <= w_hi) : (INTERP == AUKIT_INTERP_LINEAR ? (k >= 2 && k + 1 <= w_hi) : (k >= 2 && remc != 0)));
                 const int s1 = inside ? k - kbase + 1 : 3;   // slot of table index k
                 // tier 1: the interpolated value in f32 — taps of magnitude < 259 with <= 2^-23 of relative rounding, weights rounded once, four
                 // roundings below 1024: < 3e-4 in all (cf. k_ima_stream_f32).  Written around p1 (the weights sum to 1): equal taps — silence, a
@@ -760,16 +764,19 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                 const unsigned jl_s = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.jl), nj_s = (unsigned)__builtin_amdgcn_readfirstlane((int)nj);
                 unsigned q0 = (unsigned)(((unsigned long long)jl_s * P.fa) / P.fb), rem = jl_s * P.fa - q0 * P.fb;   // scalar arithmetic (jl fa < 2^32: checked by the host)
                 const unsigned dq1 = P.fa / P.fb, dr1 = P.fa - dq1 * P.fb;
+                auto fill = [&](auto fastc) {
                 for (unsigned jj = 0; jj < nj_s; jj++) {
                     OUT_T v0 = 0, v1 = 0;
                     unsigned fm = 0;
-                    one_output(std::integral_constant<int, 0>{}, jl_s + jj, q0, rem, t0, t1, valid, v0, v1, fm);
+                    one_output(fastc, jl_s + jj, q0, rem, t0, t1, valid, v0, v1, fm);
                     st0[jj] = (signed char)v0;
                     if constexpr (C == 2 && !MIX) st1[jj] = (signed char)v1;
                     defer(true, fm, (unsigned)lane, jl_s + jj, q0, rem);
                     q0 += dq1; rem += dr1;
                     if (rem >= P.fb) { rem -= P.fb; q0++; }
                 }
+                };
+                if (clean_round) fill(std::integral_constant<int, 3>{}); else fill(std::integral_constant<int, 0>{});
                 flush(true);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -791,6 +798,7 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                 unsigned b = rd.b0q ? (unsigned)lane / nj : 0, jj = rd.b0q ? (unsigned)lane % nj : (unsigned)lane;
                 unsigned q0, rem;
                 { const unsigned j = rd.jl + jj; q0 = __umulhi(j * P.fa, P.fmagic); rem = j * P.fa - q0 * P.fb; }
+                auto pairs = [&](auto fastc) {
                 for (unsigned base = 0; base < total; base += 64) {
                     const bool active = base + lane < total;
                     const unsigned bb = active ? b : 0;
@@ -803,10 +811,12 @@ __global__ __launch_bounds__(64) void k_ms_wave(const MsWaveParams P) {
                     OUT_T *const o0 = reinterpret_cast<OUT_T *>(P.out) + ob[bb] + j;
                     OUT_T v0 = 0, v1 = 0;
                     unsigned fm = 0;
-                    one_output(std::integral_constant<int, 0>{}, j, q0c, remc, t0, t1, active, v0, v1, fm);
+                    one_output(fastc, j, q0c, remc, t0, t1, active, v0, v1, fm);
                     if (active) { if (!(fm & 1u)) *o0 = v0; if constexpr (C == 2 && !MIX) { if (!(fm & 2u)) o0[os[bb]] = v1; } }
                     defer(false, fm, bb, j, q0c, remc);
                 }
+                };
+                if (clean_round) pairs(std::integral_constant<int, 3>{}); else pairs(std::integral_constant<int, 0>{});
                 flush(false);
             }
         }
