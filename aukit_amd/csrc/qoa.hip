@@ -169,12 +169,16 @@ __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const
     constexpr int OB = S8 ? 1 : 2;                // bytes per stored sample
     constexpr int OSTR = K * 20 * OB + 8;         // bytes between two jobs' output areas
     constexpr int UPJ = K * 20 * OB / 8;          // 8-byte units per job and round
-    __shared__ unsigned long long sl_in[64 * (K + 1)];
+    // (the fetched slices and the decoded samples share their LDS: a lane takes its K slices into registers before the first sample is written — 2.6 KB
+    // less per wave, and what bounds this kernel's resident waves is its LDS: PMC had its waves waiting to issue 41 % of their time, VALU 69 % busy)
+    constexpr int OBYTES = 64 * (K * 20 * OB + 8), SBYTES = 64 * (K + 1) * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char io_buf[OBYTES > SBYTES ? OBYTES : SBYTES];
+    unsigned long long *const sl_in = reinterpret_cast<unsigned long long *>(io_buf);
     __shared__ unsigned long long j_src[64], j_out[64];
     __shared__ unsigned j_step[64], j_ns[64];
     __shared__ int j_emit[64];
     __shared__ int deq[128];
-    __shared__ __attribute__((aligned(16))) unsigned char obuf[64 * OSTR];
+    unsigned char *const obuf = io_buf;
     const int lane = threadIdx.x;
     const unsigned long long j = (unsigned long long)blockIdx.x * 64 + lane;
     QoaJob job;
@@ -224,9 +228,14 @@ __global__ __launch_bounds__(64) void k_qoa_wave(const unsigned char *src, const
         if (r + 1 < nrmax) fetch(r + 1, pf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        unsigned long long raws[K];
+#pragma unroll
+        for (int sj = 0; sj < K; sj++) raws[sj] = sl_in[lane * (K + 1) + sj];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (every lane has its slices: the samples may overwrite them)
 #pragma unroll
         for (int sj = 0; sj < K; sj++) {
-            const unsigned long long raw = sl_in[lane * (K + 1) + sj];
+            const unsigned long long raw = raws[sj];
             const unsigned hi = __builtin_bswap32((unsigned)raw), lo = __builtin_bswap32((unsigned)(raw >> 32));   // (">I4I4"):unpack
             const int *dq = deq + (hi >> 28) * 8;   // scalefactor = bit32_extract(sliceH, 28, 4)
             unsigned pk[S8 ? 5 : 10];
