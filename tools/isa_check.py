@@ -137,6 +137,8 @@ def check_vm_cfg(asm):
             ins.append((ln, parts[0], parts[1] if len(parts) > 1 else "", in_asm, t))
             if parts[0] == "s_endpgm": break
         if not ins: continue
+        if any(i[1].startswith(("s_setpc", "s_swappc", "s_call")) for i in ins) and any(i[3] and i[1].startswith(("global_load", "buffer_load")) for i in ins):
+            viol.append((name, ins[0][0], "indirect branch in a kernel with hand-issued loads: the graph is incomplete", []))   # (sound, not clever)
         # basic blocks
         leaders = {0} | set(labels.values())
         for i, (_, op, args, _, _) in enumerate(ins):
