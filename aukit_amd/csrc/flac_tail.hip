@@ -80,10 +80,16 @@ AUKIT_DEV double dpp_f64(double v) {
 #ifndef AUKIT_RS_WAVES
 #define AUKIT_RS_WAVES 4
 #endif
+template <int CTRL, int ROW_MASK = 0xF> AUKIT_DEV double dpp_rt(double v) { return dpp_f64<CTRL, ROW_MASK>(v); }
+template <int CTRL, int ROW_MASK = 0xF> AUKIT_DEV float dpp_rt(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true)); }
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
-template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false, bool LOOPJ = false>
-__global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const RsOnepoleParams P) {   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
+// R32 (round 4, last): the recurrence and its scan in f32 — for slopes m <= 1/2 only (a low-pass well above the band: stream.qoa's and stream.flac's,
+// effects.lowpass at a quarter of the rate), where a step's rounding (2^-24 of the state) is worth at most twice itself in the end: ~1e-7 of the
+// scale, inside the f32 stages' 1e-6.  Saves the two conversions per output and half of the scan's moves in a kernel bound by its instruction count.
+template <int INTERP, bool HP, bool TAB, typename S, int NW = 1, bool JOBS = false, bool LOOPJ = false, bool R32 = false>
+__global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const RsOnepoleParams P) {
+    using RT = std::conditional_t<R32, float, double>;   // (four waves per SIMD asked for: 128 VGPRs — hipcc takes 130 - 133 for some instantiations otherwise, three waves per SIMD, and the launches are sized for four: config 3b ran in 1.33 rounds, 2.8 -> 3.8 ms)
     extern __shared__ __attribute__((aligned(16))) float rsm_all[];
     constexpr int E = 8, T = 64 * E;
     const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
@@ -108,29 +114,36 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
     const S *const rows_s = reinterpret_cast<const S *>(P.rows);
     // the slope of the recurrence's affine map y -> m y + ...: a (high-pass, :3614), 1 - alpha (low-pass, :3594)
     const double m = HP ? P.coef : 1.0 - P.coef;
-    double mp[E + 1];   // m^1 .. m^E (mp[0] = 1)
-    mp[0] = 1.0;
+    double mpd[E + 1];   // m^1 .. m^E (mpd[0] = 1)
+    mpd[0] = 1.0;
 #pragma unroll
-    for (int i = 1; i <= E; i++) mp[i] = mp[i - 1] * m;
-    double Md[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan
-    Md[0] = mp[E];
+    for (int i = 1; i <= E; i++) mpd[i] = mpd[i - 1] * m;
+    double Mdd[6];       // M^1, M^2, M^4 ... M^32 with M = m^E: the steps of the wave scan
+    Mdd[0] = mpd[E];
 #pragma unroll
-    for (int k = 1; k < 6; k++) Md[k] = Md[k - 1] * Md[k - 1];
+    for (int k = 1; k < 6; k++) Mdd[k] = Mdd[k - 1] * Mdd[k - 1];
     // (the same in every lane, but made by vector multiplies: said so, these 14 doubles live in scalar registers — 28 VGPRs of a kernel that is held to
     // 128 and spilled into its tile loop without them; an FMA takes one of them as its scalar operand)
-    auto uni = [](double v) {
-        const long long b = __double_as_longlong(v);
-        return __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b));
+    auto uni = [](double v) -> RT {
+        if constexpr (R32) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v)));
+        else {
+            const long long b = __double_as_longlong(v);
+            return __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b));
+        }
     };
+    RT mp[E + 1], Md[6];
+    mp[0] = (RT)1;
 #pragma unroll
-    for (int i = 1; i <= E; i++) mp[i] = uni(mp[i]);
+    for (int i = 1; i <= E; i++) mp[i] = uni(mpd[i]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) Md[k] = uni(Md[k]);
+    for (int k = 0; k < 6; k++) Md[k] = uni(Mdd[k]);
+    const RT coef_r = (RT)P.coef;
+    auto fmaR = [](RT a, RT b, RT c) -> RT { if constexpr (R32) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c); };
     // the scan runs on DPP moves: four steps inside rows of 16 lanes (a lane without a source receives 0), then lane 15 / lane 31 of the row(s)
     // before — with what the receiving lane's distance makes of them
-    const double mA = (lane & 16) ? pow(mp[E], (double)((lane & 15) + 1)) : 0.0;
-    const double mB = lane >= 32 ? pow(mp[E], (double)(lane - 31)) : 0.0;
-    const double mlane = pow(mp[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
+    const RT mA = (RT)((lane & 16) ? pow(mpd[E], (double)((lane & 15) + 1)) : 0.0);
+    const RT mB = (RT)(lane >= 32 ? pow(mpd[E], (double)(lane - 31)) : 0.0);
+    const RT mlane = (RT)pow(mpd[E], (double)(lane + 1));   // M^(lane + 1): what the tile's carry is worth after this lane's outputs
     auto skew = [](int i) { return i + i / E; };
     const unsigned wc = (unsigned)(((unsigned long long)T * P.fa) / P.fb), wd = (unsigned)(((unsigned long long)T * P.fa) % P.fb);
     // JOBS: a workgroup takes job after job (short jobs — a FLAC frame is nine tiles — would otherwise pay the set-up above once each)
@@ -154,10 +167,10 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
     }
     float *orow = P.out + obase;
     float mxf = 0.f;
-    double carry_y = 0.0, carry_x = 0.0;
+    RT carry_y = 0, carry_x = 0;
     if constexpr (JOBS) {   // ls = last[2] (stream.qoa :3316), or last[2] / (last[2] < 0 and 128 or 127) (stream.flac :3172)
         const double z0 = (double)((float)hist * (hist < 0 ? P.scale_neg : P.scale));
-        carry_y = P.epi ? z0 / (z0 < 0 ? 128.0 : 127.0) : z0;
+        carry_y = (RT)(P.epi ? z0 / (z0 < 0 ? 128.0 : 127.0) : z0);
     }
     // x - 1 = o fa / fb exactly.  The tile's first output: (kb, r0) advanced by additions from tile to tile (T fa = wc fb + wd); the outputs inside it
     // from there (n < fb + T fa: the magic division is exact, as in the wave kernels)
@@ -414,37 +427,37 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
         __builtin_amdgcn_wave_barrier();
         // lane ↔ E consecutive outputs: the recurrence from a zero state, then the state it really started from
         const int e0 = lane * E;
-        double z[E];
+        RT z[E];
         {
-            double xp = (e0 == 0) ? carry_x : ((FULL || e0 <= cnt) ? (double)xb[skew(e0 - 1)] : 0.0);
+            RT xp = (e0 == 0) ? carry_x : ((FULL || e0 <= cnt) ? (RT)xb[skew(e0 - 1)] : (RT)0);
             const bool first = !JOBS && o0 == 0 && lane == 0;
-            double y = 0.0;
+            RT y = 0;
 #pragma unroll
             for (int i = 0; i < E; i++) {
-                const double xv = (FULL || e0 + i < cnt) ? (double)xb[skew(e0 + i)] : xp;
+                const RT xv = (FULL || e0 + i < cnt) ? (RT)xb[skew(e0 + i)] : xp;
                 if (i == 0 && first) y = xv;                               // y[1] = x[1]: the first sample passes  (:3592, :3612)
-                else if constexpr (HP) y = P.coef * (y + xv - xp);              // :3614
-                else y = __builtin_fma(P.coef, xv - y, y);                      // :3594 (fused: the tolerance path)
+                else if constexpr (HP) y = coef_r * (y + xv - xp);              // :3614
+                else y = fmaR(coef_r, xv - y, y);                      // :3594 (fused: the tolerance path)
                 xp = xv;
                 z[i] = y;
             }
         }
         // Y_t = z_t[E - 1] + M Y_(t-1): inclusive scan over the wave, Y_(-1) = the tile's carry
-        double Y = z[E - 1];
-        Y = __builtin_fma(Md[0], dpp_f64<0x111>(Y), Y);
-        Y = __builtin_fma(Md[1], dpp_f64<0x112>(Y), Y);
-        Y = __builtin_fma(Md[2], dpp_f64<0x114>(Y), Y);
-        Y = __builtin_fma(Md[3], dpp_f64<0x118>(Y), Y);
-        Y = __builtin_fma(mA, dpp_f64<0x142, 0xA>(Y), Y);
-        Y = __builtin_fma(mB, dpp_f64<0x143, 0xC>(Y), Y);
-        Y = __builtin_fma(mlane, carry_y, Y);          // true state after this lane's last output
-        double yin = dpp_f64<0x138>(Y);                // the lane before (lane 0 receives 0)
+        RT Y = z[E - 1];
+        Y = fmaR(Md[0], dpp_rt<0x111>(Y), Y);
+        Y = fmaR(Md[1], dpp_rt<0x112>(Y), Y);
+        Y = fmaR(Md[2], dpp_rt<0x114>(Y), Y);
+        Y = fmaR(Md[3], dpp_rt<0x118>(Y), Y);
+        Y = fmaR(mA, dpp_rt<0x142, 0xA>(Y), Y);
+        Y = fmaR(mB, dpp_rt<0x143, 0xC>(Y), Y);
+        Y = fmaR(mlane, carry_y, Y);          // true state after this lane's last output
+        RT yin = dpp_rt<0x138>(Y);                     // the lane before (lane 0 receives 0)
         if (lane == 0) yin = carry_y;
         float res[E];
-        double ylast = 0.0;
+        RT ylast = 0;
 #pragma unroll
         for (int i = 0; i < E; i++) {
-            const double yv = __builtin_fma(mp[i + 1], yin, z[i]);
+            const RT yv = fmaR(mp[i + 1], yin, z[i]);
             res[i] = (float)yv;
             if (emit && (FULL || e0 + i < cnt)) mxf = fmaxf(mxf, fabsf(res[i]));
             if (!FULL && e0 + i == cnt - 1) ylast = yv;
@@ -456,9 +469,12 @@ __global__ __launch_bounds__(64 * NW, AUKIT_RS_WAVES) void k_rs_onepole(const Rs
             }
         }
         // the lane that holds the tile's last output hands its state to the next tile
-        if constexpr (FULL) carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
+        if constexpr (FULL) {
+            if constexpr (R32) carry_y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Y), 63));
+            else carry_y = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(Y) >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(Y), 63));
+        }
         else carry_y = __shfl(ylast, (cnt - 1) / E);
-        carry_x = (double)xb[skew(cnt - 1)];
+        carry_x = (RT)xb[skew(cnt - 1)];
         if constexpr (NW > 1) {
             if (emit) {
                 __syncthreads();   // (every wave has read the tile before out of `mix`: one buffer, two barriers a tile, and the workgroup's LDS lets every wave of config 5 be resident at once — with two buffers 14 of the 16 waves per CU were)
@@ -704,9 +720,13 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     if ((*rc = ctx_begin_kernel(ctx))) return true;
     const size_t ldsb = lds;
  const dim3 grid((unsigned)((rows / (size_t)NWh) * (size_t)P.segs));
+    const bool r32 = !highpass && (1.0 - coef) <= 0.5 && (1.0 - coef) >= 0 && !getenv("AUKIT_RS_F64");   // the recurrence in f32 (k_rs_onepole<..., R32>)
 #define AUKIT_RSO1(I, H, Tb, S)                                                                                                                            \
     do {                                                                                                                                                     \
-        if (mono_out) hipLaunchKernelGGL((k_rs_onepole<I, H, Tb, S, 2>), grid, dim3(128), ldsb, ctx->stream, P);                                          \
+        if (!H && r32) {                                                                                                                                     \
+            if (mono_out) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 2, false, false, true>), grid, dim3(128), ldsb, ctx->stream, P);              \
+            else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, false, false, true>), grid, dim3(64), ldsb, ctx->stream, P);                         \
+        } else if (mono_out) hipLaunchKernelGGL((k_rs_onepole<I, H, Tb, S, 2>), grid, dim3(128), ldsb, ctx->stream, P);                                   \
         else hipLaunchKernelGGL((k_rs_onepole<I, H, Tb, S, 1>), grid, dim3(64), ldsb, ctx->stream, P);                                                     \
     } while (0)
 #define AUKIT_RSO(S)                                                                                                                                         \
@@ -786,9 +806,14 @@ static bool rs_onepole_jobs_launch(aukit_ctx *ctx, const void *rows, bool rows_i
     // long jobs (an iterator call of stream.qoa: ~ 100 tiles): a workgroup each — measured 6.8 ms against 7.6 for workgroups that take five in turn;
     // short ones (a FLAC frame: nine tiles): a workgroup takes several in turn and pays the set-up in front of its tile loop once
     const dim3 grid((unsigned)((long_jobs || NWh > 1) ? njobs : std::min<size_t>(njobs, (size_t)ctx->num_cus * 64)));
+    const bool r32 = (1.0 - lp_alpha) <= 0.5 && (1.0 - lp_alpha) >= 0 && !getenv("AUKIT_RS_F64");   // the recurrence in f32 (k_rs_onepole<..., R32>)
 #define AUKIT_RSJ(I, Tb, S)                                                                                                                           \
     do {                                                                                                                                              \
-        if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 2, true, false>), grid, dim3(128), lds, ctx->stream, P);                      \
+        if (r32) {                                                                                                                                    \
+            if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 2, true, false, true>), grid, dim3(128), lds, ctx->stream, P);            \
+            else if (long_jobs) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, false, true>), grid, dim3(64), lds, ctx->stream, P);       \
+            else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, true, true>), grid, dim3(64), lds, ctx->stream, P);                       \
+        } else if (NWh == 2) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 2, true, false>), grid, dim3(128), lds, ctx->stream, P);               \
         else if (long_jobs) hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, false>), grid, dim3(64), lds, ctx->stream, P);                 \
         else hipLaunchKernelGGL((k_rs_onepole<I, false, Tb, S, 1, true, true>), grid, dim3(64), lds, ctx->stream, P);                                 \
     } while (0)
