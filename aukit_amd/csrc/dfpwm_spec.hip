@@ -1,0 +1,470 @@
+// dfpwm_spec.hip — the chunk-speculative DFPWM transcoder: aukit.dfpwm(d, 2, rate):mono():dfpwm() (aukit.lua:1392-1414, :677-689,
+// :1005-1018; BASELINE config 4) with ONE lane per (stream, time chunk) that decodes its chunk's stereo samples, mixes them down and
+// ENCODES them on the spot — the mono samples never leave the lane's registers, and a batch of any size fills the chip
+// (the lane-per-stream encoder of dfpwm_par.hip has a serial floor of 27 ns per sample whatever the batch: 13 ms for ten seconds).
+//
+// The decoder side is dfpwm_par.hip's: exact strength at the warm-up start from the clamp-add scan, charge and filter from zero,
+// verified afterwards.  The ENCODER's bits depend on its own state, so nothing about it is scannable; what makes it speculable:
+//   * its charge is a contraction towards the samples, its strength a ±1 counter driven by its own bits — warmed up over a few
+//     thousand samples two encoders end in the same state IF they sit in the same class of the invariant
+//         I = (strength - 2 [previous bit = 0] - t) mod 4      (t = index of the next sample)
+//     which every step preserves unless the strength is clamped at 8 or 1023 (strength' = strength + b b', and
+//     b b' = 1 - 2 (q xor q') ≡ 1 + 2 q + 2 q' mod 4 with q = [bit = 0]).  Measured on the config-4 signal (CPU experiment,
+//     DESIGN.md §3.10): started from all 2032 (strength, previous bit) pairs, 2048 samples leave 4 distinct states — one per class;
+//     with the true class a single guess is right in 99.4 % (2048 samples) / 99.8 % (2560) / 99.99 % (4096) of the chunks;
+//   * the true encoder only ever clamps in its first samples on such input (strength starts at the floor), so the class it is in after
+//     512 samples (k_dfx_prologue, a lane per stream) is its class for good — or until a passage at the floor (silence), which
+//     the verify pass notices: it re-speculates the rest of that stream with the class it now knows (a "round").
+// Exactness never rests on any of this: k_dfx_verify walks every stream's chunks in order, compares each chunk's recorded start
+// state (decoder and encoder) with the true end state of the chunk before it and, where they differ, runs the chunk again from the
+// true state — block by block, against the states the chunk lane left at every block boundary, until the two runs have merged.
+#include <algorithm>
+#include "common.h"
+#include "dfpwm_dev.h"
+#include "dfpwm_par_dev.h"
+
+namespace aukit {
+
+int dfpwm_strength_scan(aukit_ctx *ctx, const DfParParams &P);  // k_df_blockmaps + k_df_blockscan (dfpwm_par.hip)
+
+AUKIT_DEV unsigned dfs_class(const DfEnc &e, u64 t) { return ((unsigned)e.strength - (e.pb < 0 ? 2u : 0u) - (unsigned)t) & 3u; }
+AUKIT_DEV int dfs_pack(const DfEnc &e) { return (int)((unsigned)e.cu | (unsigned)e.strength << 8 | (e.pb > 0 ? 1u << 18 : 0u)); }
+AUKIT_DEV DfEnc dfs_unpack(int v) { DfEnc e; e.cu = v & 255; e.strength = (v >> 8) & 1023; e.pb = (v >> 18) & 1 ? 1 : -1; return e; }
+
+constexpr unsigned DFX_X0 = 128;  // fed bytes (512 mono samples) the prologue runs from the reset state to learn the encoder's class
+
+struct DfxParams {
+    DfParParams P;          // src, off, fed, feed, n, nblk = nchunk, bpc, W (= the block: Wd + We), s_start
+    unsigned Wd;            // fed bytes at the start of a warm-up block that only the decoder runs (its charge and filter settle)
+    unsigned npad;          // n rounded up to 64
+    unsigned round, rounds; // this launch's round; rounds in all (the last verify redoes whatever is left)
+    int *st;                // [nchunk][12][npad] start state (decoder n, strength, pb, lpf, pn; encoder packed), end state (same six)
+    unsigned G, nck;        // checkpoints: the state every G fed bytes inside a chunk (G divides W), nck = bpc W / G - 1 of them
+    int *ck;                // [nchunk][nck][6][npad]
+    int *fx;                // [nchunk][13][npad] k_dfx_fix's record per chunk: 0 none, else intervals it wrote << 1 | merged with the chunk lane's run (0: ran to the chunk's end),
+                            //   the state it started from (6), the end state it reached (6, status 2)
+    int *ctl;               // [8][npad]: first chunk not final yet; encoder class; the true state (5 + 1) where that chunk starts
+    unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [12] by k_dfx_verify
+    const unsigned char *lut;  // [65536] mono + 128 for (l + 128) * 256 + (r + 128): the reference's fp64 mix (dfp_mix), in global memory
+    unsigned char *enc_out; // the packed result
+    const u64 *ooff;        // [n + 1]
+};
+
+// ---- output bits: 4 per fed byte, 16 per source dword; whole 8-byte rounds leave as one store
+struct DfsAcc { u64 bits = 0; unsigned pos = 0; unsigned char *o = nullptr; };
+typedef unsigned dfs_u32x2u __attribute__((ext_vector_type(2), aligned(1)));  // (unaligned global stores are single instructions on gfx950)
+AUKIT_DEV void dfs_put(DfsAcc &a, unsigned v, unsigned nbits) {
+    a.bits |= (u64)v << a.pos;
+    a.pos += nbits;
+    if (a.pos >= 64) {
+        dfs_u32x2u w; w.x = (unsigned)a.bits; w.y = (unsigned)(a.bits >> 32);
+        *reinterpret_cast<dfs_u32x2u *>(a.o) = w;
+        a.o += 8;
+        a.pos -= 64;
+        a.bits = a.pos ? (u64)(v >> (nbits - a.pos)) : 0;
+    }
+}
+
+// one fed byte: eight decoder steps, four mixes, four encoder steps → four bits
+template <typename LUT>
+AUKIT_DEV unsigned dfx_byte(DfDec &d, DfEnc &e, unsigned byte, LUT lutc) {
+    const unsigned nb = ~byte;
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+        out |= df_encode_u(e, (unsigned)lutc[l * 256 + r]) & (1u << k);
+    }
+    return out;
+}
+
+// fed bytes [f0, f1) of one stream through decoder, mix and encoder; EMIT: the bits go to `acc`
+template <bool EMIT, typename LUT>
+AUKIT_DEV void dfx_span(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, DfDec &d, DfEnc &e, LUT lutc, DfsAcc &acc) {
+    fed_for_each(p, f0, f1, fd,
+                 [&](unsigned byte) {
+                     const unsigned b4 = dfx_byte(d, e, byte, lutc);
+                     if (EMIT) dfs_put(acc, b4, 4);
+                 },
+                 [&](unsigned word) {
+                     unsigned b16 = 0;
+#pragma unroll
+                     for (int j = 0; j < 4; j++) b16 |= dfx_byte(d, e, (word >> (8 * j)) & 0xFF, lutc) << (4 * j);
+                     if (EMIT) dfs_put(acc, b16, 16);
+                 });
+}
+
+// the stream's last bits: the last byte is padded with samples of value 0 (aukit.lua:1011-1016 hands the encoder whole bytes)
+AUKIT_DEV void dfx_tail(DfsAcc &acc, DfEnc &e) {
+    if (acc.pos & 4) {
+        unsigned b4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) b4 |= df_encode_u(e, 128u) & (1u << k);
+        acc.bits |= (u64)b4 << acc.pos;
+        acc.pos += 4;
+    }
+    for (unsigned k = 0; k < acc.pos; k += 8) *acc.o++ = (unsigned char)(acc.bits >> k);
+    acc.pos = 0; acc.bits = 0;
+}
+
+AUKIT_DEV void dfx_store6(int *st, unsigned npad, const DfDec &d, const DfEnc &e) {
+    int v[6];
+    dfp_pack(d, v);
+#pragma unroll
+    for (int i = 0; i < 5; i++) st[(size_t)i * npad] = v[i];
+    st[(size_t)5 * npad] = dfs_pack(e);
+}
+AUKIT_DEV void dfx_load6(const int *st, unsigned npad, int *v) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = st[(size_t)i * npad];
+}
+AUKIT_DEV bool dfx_same6(const int *a, const int *b) {
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) same = same && a[i] == b[i];
+    return same;
+}
+
+// the 64 KiB mix table, once per context (k_dfx_chunks copies it into LDS: 256 bytes per thread instead of 256 fp64 mixes)
+__global__ __launch_bounds__(256) void k_dfx_lut(unsigned char *lut) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    lut[i] = (unsigned char)(dfp_mix((int)(i >> 8) - 128, (int)(i & 255) - 128) + 128);
+}
+
+// a lane per stream: the encoder's class after the first DFX_X0 fed bytes; the control block of round 0
+__global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
+    const DfParParams &P = X.P;
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= P.n) return;
+    const unsigned char *p = P.src + P.off[s];
+    const u64 fed = P.fed[s], f1 = fed < DFX_X0 ? fed : (u64)DFX_X0;
+    DfDec d{};
+    DfEnc e{};
+    DfsAcc acc;
+    dfx_span<false>(p, 0, f1, P.feed, d, e, X.lut + 128 * 257, acc);
+    X.ctl[s] = 0;
+    X.ctl[(size_t)X.npad + s] = (int)dfs_class(e, 4 * f1);
+}
+
+// copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
+AUKIT_DEV void dfx_lut_to_lds(const unsigned char *g, unsigned char *l, unsigned nthreads) {
+    const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+    uint4 *lv = reinterpret_cast<uint4 *>(l);
+    for (unsigned i = threadIdx.x; i < 4096; i += nthreads) lv[i] = gv[i];
+}
+
+AUKIT_DEV int *dfx_ck(const DfxParams &X, unsigned c, unsigned j, unsigned s) { return X.ck + (((size_t)c * X.nck + j) * 6) * X.npad + s; }
+
+// Runs chunk c of stream s again from (d, e), checkpoint interval by interval, writing its bytes, until its state equals the one the chunk
+// lane left at a checkpoint — from there on the chunk lane's bytes and end state are the true ones (returns true) — or to the chunk's end
+// (returns false; (d, e) = the end state, the stream's tail written when the stream ends here).
+// `min_iv` / `may_merge`: k_dfx_fix may have run this chunk before from a state that was not the true one — its bytes lie over the
+// chunk lane's in the first `min_iv` intervals (no merge counts before those are rewritten), or in all of them (`may_merge` false).
+template <typename LUT>
+AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsigned char *p, u64 fed, DfDec &d, DfEnc &e, LUT lutc, unsigned &intervals,
+                         unsigned min_iv = 0, bool may_merge = true) {
+    const DfParParams &P = X.P;
+    const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
+    DfsAcc acc;
+    acc.o = X.enc_out + X.ooff[s] + f0 / 2;
+    u64 b0 = f0;
+    for (unsigned j = 0; j < X.nck; j++) {
+        const u64 b1 = b0 + X.G;
+        if (b1 >= f1) break;
+        dfx_span<true>(p, b0, b1, P.feed, d, e, lutc, acc);
+        intervals++;
+        b0 = b1;
+        int t[6], w[6];
+        dfp_pack(d, t);
+        t[5] = dfs_pack(e);
+        dfx_load6(dfx_ck(X, c, j, s), X.npad, w);
+        if (may_merge && j + 1 >= min_iv && dfx_same6(t, w)) return true;
+    }
+    dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
+    intervals++;
+    if (f1 == fed) dfx_tail(acc, e);
+    return false;
+}
+
+// a lane per (stream, chunk)
+__global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
+    extern __shared__ unsigned char lutu[];
+    const DfParParams &P = X.P;
+    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the round before left nothing
+    dfx_lut_to_lds(X.lut, lutu, 256);
+    __syncthreads();
+    const unsigned char *lutc = lutu + 128 * 257;  // indexed by signed (l, r)
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
+    if (c >= P.nchunk) return;
+    const unsigned c_from = X.round ? (unsigned)X.ctl[s] : 0u;
+    if (c < c_from) return;  // final already (a stream that is done has c_from = nchunk)
+    const unsigned char *p = P.src + P.off[s];
+    const u64 fed = P.fed[s];
+    const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
+    int *st = X.st + (size_t)c * 12 * X.npad + s;
+    if (f0 >= fed && c > 0) { st[(size_t)X.npad] = -1; return; }  // strength -1: no such chunk
+    DfDec d{};
+    DfEnc e{};
+    DfsAcc acc;
+    if (c == c_from) {
+        if (c > 0) {  // the true state, left by the verify pass of the round before
+            int v[6];
+            dfx_load6(X.ctl + (size_t)2 * X.npad + s, X.npad, v);
+            dfp_unpack(v, d);
+            e = dfs_unpack(v[5]);
+        }
+    } else {
+        // warm-up over the block before the chunk: the decoder with its exact strength and previous bit, charge and filter from zero;
+        // after Wd bytes the encoder joins in, charge on its first sample, strength near the usual one in the stream's class
+        const u64 fw = f0 - P.W, fe = fw + X.Wd;
+        d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
+        d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
+        DfOut O{};
+        O.feed = P.feed;
+        dfp_run<false>(p, fw, fe, d, O);
+        {   // the first byte of the encoder's warm-up by hand: its first mono sample is where the charge starts
+            const unsigned nb = ~(unsigned)p[dfp_src_index(fe, P.feed)];
+            unsigned u[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+                u[k] = (unsigned)lutc[l * 256 + r];
+            }
+            const unsigned cls = (unsigned)X.ctl[(size_t)X.npad + s] & 3u;
+            e.cu = (int)u[0];
+            e.pb = -1;
+            e.strength = 40;
+            e.strength += (int)((cls - dfs_class(e, 4 * fe)) & 3u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
+        }
+        dfx_span<false>(p, fe + 1, f0, P.feed, d, e, lutc, acc);
+    }
+    dfx_store6(st, X.npad, d, e);
+    acc.o = X.enc_out + X.ooff[s] + f0 / 2;  // four mono samples per fed byte, eight per output byte
+    u64 b0 = f0;
+    for (unsigned j = 0; j < X.nck; j++) {
+        const u64 b1 = b0 + X.G;
+        if (b1 >= f1) break;
+        dfx_span<true>(p, b0, b1, P.feed, d, e, lutc, acc);
+        dfx_store6(dfx_ck(X, c, j, s), X.npad, d, e);
+        b0 = b1;
+    }
+    dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
+    if (f1 == fed) dfx_tail(acc, e);
+    dfx_store6(st + (size_t)6 * X.npad, X.npad, d, e);
+}
+
+// a lane per (stream, chunk) again: a chunk whose recorded start state is not the recorded end state of the chunk before it runs again
+// from that end state until the two runs merge — every mismatch of the batch at once, a few checkpoint intervals each, instead of one
+// after the other in the stream's verify lane.  (The end state of the chunk before is the true one unless that chunk failed itself and
+// did not merge: k_dfx_verify checks what this lane started from.)
+__global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
+    extern __shared__ unsigned char lutu[];
+    const DfParParams &P = X.P;
+    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);
+    const bool last_round = X.round + 1 >= X.rounds;
+    bool need = false;
+    int from[6] = {0, 0, 0, 0, 0, 0};
+    if (c >= 1 && c < P.nchunk && c > (X.round ? (unsigned)X.ctl[s] : 0u)) {
+        int v[6];
+        dfx_load6(X.st + (size_t)c * 12 * X.npad + s, X.npad, v);
+        if (v[1] >= 0) {
+            dfx_load6(X.st + ((size_t)(c - 1) * 12 + 6) * X.npad + s, X.npad, from);
+            const u64 t0 = 4 * dfp_chunk_start(P, c);
+            // (an encoder in another class never merges: left to the verify lane, which speculates the rest of the stream again — in the
+            // last round there is no again, and running the whole chunk here is still better than running it there)
+            need = !dfx_same6(v, from) && (last_round || dfs_class(dfs_unpack(from[5]), t0) == dfs_class(dfs_unpack(v[5]), t0));
+        }
+        if (!need) X.fx[(size_t)c * 13 * X.npad + s] = 0;
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) return;
+    dfx_lut_to_lds(X.lut, lutu, 256);
+    __syncthreads();
+    if (!need) return;
+    const unsigned char *lutc = lutu + 128 * 257;
+    DfDec d;
+    dfp_unpack(from, d);
+    DfEnc e = dfs_unpack(from[5]);
+    unsigned iv = 0;
+    const bool merged = dfx_rerun(X, s, c, P.src + P.off[s], P.fed[s], d, e, lutc, iv);
+    int *fx = X.fx + (size_t)c * 13 * X.npad + s;
+    fx[0] = (int)(iv << 1 | (merged ? 1u : 0u));  // (iv >= 1)
+#pragma unroll
+    for (int i = 0; i < 6; i++) fx[(size_t)(1 + i) * X.npad] = from[i];
+    if (!merged) dfx_store6(fx + (size_t)7 * X.npad, X.npad, d, e);
+    atomicAdd(&X.flags[9], iv);
+    atomicAdd(&X.flags[11], 1u);
+}
+
+// a lane per stream: the chain of true states
+__global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
+    extern __shared__ unsigned char lutu[];
+    const DfParParams &P = X.P;
+    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    const bool act = s < P.n;
+    unsigned c = act ? (X.round ? (unsigned)X.ctl[s] : 0u) : P.nchunk;
+    const bool last_round = X.round + 1 >= X.rounds;
+    const unsigned char *p = P.src + (act ? P.off[s] : 0);
+    const u64 fed = act ? P.fed[s] : 0;
+    int truth[6] = {0, 0, 0, 0, 0, 0};
+    unsigned chunks = 0, intervals = 0, rerun = 0;
+    enum { WALK, NEED_TABLE, DONE, AGAIN } state = c < P.nchunk ? WALK : DONE;
+    if (state == WALK) {
+        dfx_load6(X.st + ((size_t)c * 12 + 6) * X.npad + s, X.npad, truth);  // chunk c ran from the true state
+        chunks = 1;
+        c++;
+    }
+    bool table = false;
+    // walks the chain until the stream is done, handed back for another round, or (without the table) needs a chunk run again here
+    auto walk = [&]() {
+        for (; c < P.nchunk; c++) {
+            const int *st = X.st + (size_t)c * 12 * X.npad + s;
+            int v[6];
+            dfx_load6(st, X.npad, v);
+            if (v[1] < 0) break;  // the stream ended before this chunk
+            if (dfx_same6(v, truth)) { chunks++; dfx_load6(st + (size_t)6 * X.npad, X.npad, truth); continue; }
+            const int *fx = X.fx + (size_t)c * 13 * X.npad + s;
+            const int fst = fx[0];
+            if (fst) {  // k_dfx_fix ran this chunk again: from the true state?
+                int w[6];
+                dfx_load6(fx + (size_t)X.npad, X.npad, w);
+                if (dfx_same6(w, truth)) { chunks++; dfx_load6(fst & 1 ? st + (size_t)6 * X.npad : fx + (size_t)7 * X.npad, X.npad, truth); continue; }
+            }
+            const u64 t0 = 4 * dfp_chunk_start(P, c);
+            DfDec d;
+            dfp_unpack(truth, d);
+            DfEnc e = dfs_unpack(truth[5]);
+            if (!last_round && dfs_class(e, t0) != dfs_class(dfs_unpack(v[5]), t0)) {
+                // the true encoder has changed its class (it was clamped on the way): this and the later chunks are speculated again
+                X.ctl[s] = (int)c;
+                X.ctl[(size_t)X.npad + s] = (int)dfs_class(e, t0);
+#pragma unroll
+                for (int i = 0; i < 6; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = truth[i];
+                __hip_atomic_store(&X.flags[X.round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&X.flags[10], 1u);
+                state = AGAIN;
+                return;
+            }
+            // nobody has run this chunk from the true state yet: here and now (the mix table has to be in LDS first)
+            if (!table) { state = NEED_TABLE; return; }
+            chunks++;
+            rerun++;
+            if (dfx_rerun(X, s, c, p, fed, d, e, lutu + 128 * 257, intervals, (unsigned)fst >> 1, fst == 0 || (fst & 1))) dfx_load6(st + (size_t)6 * X.npad, X.npad, truth);
+            else { dfp_pack(d, truth); truth[5] = dfs_pack(e); }
+        }
+        state = DONE;
+    };
+    if (state == WALK) walk();
+    if (__syncthreads_or(state == NEED_TABLE ? 1 : 0)) {
+        dfx_lut_to_lds(X.lut, lutu, 64);
+        __syncthreads();
+        table = true;
+        if (state == NEED_TABLE) walk();
+    }
+    if (!act || !chunks) return;
+    if (state == DONE) X.ctl[s] = (int)P.nchunk;
+    atomicAdd(&X.flags[8], chunks);
+    if (intervals) atomicAdd(&X.flags[9], intervals);
+    if (rerun) atomicAdd(&X.flags[12], rerun);
+}
+
+// host side; *taken = false (nothing launched) when the batch is too short to be cut
+int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const u64 *d_ooff, bool *taken) {
+    *taken = false;
+    const uint32_t n = in->n;
+    // (the environment switches of the older schedules — tests and A/B runs — name those schedules: not this one)
+    if (n == 0 || getenv("AUKIT_DFPWM_SERIAL") || getenv("AUKIT_DFPWM_NOSPEC") || getenv("AUKIT_DFPWM_FUSED") || getenv("AUKIT_DFPWM_SLICES") || getenv("AUKIT_DFPWM_BLOCK") ||
+        getenv("AUKIT_DFPWM_CHUNKS"))
+        return AUKIT_OK;
+    std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + n), h_fed(n);
+    uint64_t fed_max = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        h_fed[s] = nb ? nb + (nb + 6000 - 1) / 6000 - 1 : 0;  // 6001-byte slices advanced by 6000 (Q10)
+        fed_max = std::max(fed_max, h_fed[s]);
+    }
+    unsigned We = 640, Wd = 64;  // fed bytes: 2560 mono samples of encoder warm-up behind 64 bytes of decoder-only warm-up
+    if (const char *e = getenv("AUKIT_DFX_WE")) We = (unsigned)std::max(64, atoi(e)) & ~63u;
+    if (const char *e = getenv("AUKIT_DFX_WD")) Wd = (unsigned)std::max(64, atoi(e)) & ~63u;
+    const uint64_t W = (uint64_t)We + Wd;  // a multiple of 64: checkpoint intervals of W / 4 are whole 8-byte output rounds
+    const unsigned nblk_all = (unsigned)((fed_max + W - 1) / W);
+    // chunks per stream: enough lanes for `wps` waves on every SIMD, at least three blocks each (the warm-up block is then 1/4 of a lane's work)
+    unsigned wps = 2;
+    if (const char *e = getenv("AUKIT_DFX_WPS")) wps = (unsigned)std::max(1, atoi(e));
+    const uint64_t lanes = (uint64_t)ctx->num_cus * 4 * 64 * wps;
+    unsigned want = (unsigned)std::max<uint64_t>(1, (lanes + n - 1) / n);
+    if (const char *e = getenv("AUKIT_DFX_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
+    unsigned min_bpc = 3;
+    if (const char *e = getenv("AUKIT_DFX_MIN_BPC")) min_bpc = (unsigned)std::max(1, atoi(e));
+    const unsigned bpc = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, min_bpc);
+    const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
+    if (nchunk < 2) return AUKIT_OK;
+    unsigned rounds = 4;
+    if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
+    const unsigned npad = (unsigned)round_up(n, 64);
+    // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~80 MB of them
+    unsigned G = (unsigned)W / 4;
+    while (G < W && (uint64_t)nchunk * (bpc * (W / G) - 1) * 24 * npad > (80ull << 20)) G *= 2;
+    if (const char *e = getenv("AUKIT_DFX_G")) { const unsigned k = (unsigned)std::max(1, atoi(e)); if (k <= 4 && (k & (k - 1)) == 0) G = (unsigned)W / k; }
+    const unsigned nck = bpc * (unsigned)(W / G) - 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_tab = take((size_t)n * 16), o_maps = take((size_t)n * nchunk * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
+                 o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
+                 o_ctl = take((size_t)8 * npad * 4), o_fl = take(64);
+    int rc = ctx->tmp_buf2.ensure(o + 256);
+    if (rc) return rc;
+    char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+    if ((rc = h2d_table(ctx, B + o_tab, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + o_tab + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
+    if (!ctx->dfx_lut.p) {
+        if ((rc = ctx->dfx_lut.ensure(65536))) return rc;
+        hipLaunchKernelGGL(k_dfx_lut, dim3(256), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned char *>(ctx->dfx_lut.p));
+        AUKIT_HIP_CHECK(hipGetLastError());
+    }
+    DfxParams X{};
+    DfParParams &P = X.P;
+    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B + o_tab); P.fed = P.off + n; P.feed = Feed{6001, 6000};
+    P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
+    P.maps = reinterpret_cast<SatMap *>(B + o_maps); P.s_start = reinterpret_cast<int *>(B + o_ss);
+    P.init = nullptr; P.mode = 1; P.C = 2;
+    X.Wd = Wd; X.npad = npad; X.rounds = rounds; X.G = G; X.nck = nck;
+    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl);
+    X.flags = reinterpret_cast<unsigned *>(B + o_fl);
+    X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);
+    X.enc_out = out; X.ooff = d_ooff;
+    if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_dfx_prologue, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
+    if ((rc = dfpwm_strength_scan(ctx, P))) return rc;
+    if (!ctx->dfx_attr_set) {
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_verify), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        ctx->dfx_attr_set = true;
+    }
+    const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256));
+    for (unsigned r = 0; r < rounds; r++) {
+        X.round = r;
+        hipLaunchKernelGGL(k_dfx_chunks, grid, dim3(256), 65536, ctx->stream, X);
+        hipLaunchKernelGGL(k_dfx_fix, grid, dim3(256), 65536, ctx->stream, X);
+        hipLaunchKernelGGL(k_dfx_verify, dim3((n + 63) / 64), dim3(64), 65536, ctx->stream, X);
+    }
+    AUKIT_HIP_CHECK(hipGetLastError());
+    if (getenv("AUKIT_DFPWM_STATS") || ctx->collect_stats) {
+        unsigned h[16] = {};
+        (void)hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[8]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[11] + h[12]; ctx->counters[AUKIT_COUNTER_DFPWM_RESPECULATED] = h[10];
+        if (getenv("AUKIT_DFPWM_STATS"))
+            fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u): %u chunks verified; run again: %u chunks by their own lanes, %u by the verify lanes, %u checkpoint intervals in all; %u stream rounds re-speculated (flags %u %u %u %u)\n",
+                    n, nchunk, bpc, (unsigned long long)W, Wd, G, h[8], h[11], h[12], h[9], h[10], h[0], h[1], h[2], h[3]);
+    }
+    *taken = true;
+    return AUKIT_OK;
+}
+
+}  // namespace aukit

@@ -234,7 +234,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     { std::lock_guard<std::mutex> lk(g_live_mu); g_live.erase(c); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release();
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release(); c->dfx_lut.release();
     if (c->aux_stream) {
         (void)hipStreamSynchronize(c->aux_stream);
         if (c->dec_stream) { (void)hipStreamSynchronize(c->dec_stream); (void)hipStreamDestroy(c->dec_stream); }

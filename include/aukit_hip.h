@@ -152,6 +152,8 @@ typedef enum {
                                               that is only taken when it lies further from an integer than a guard (5e-4 / 6e-4) set at twice its derived error
                                               bound.  With COLLECT_STATS the call runs an audited instantiation: the largest |f32 value - fp64 value| it saw, in 1e-9 */
     AUKIT_COUNTER_TIER1_OUTPUTS = 4,       /* ... and how many outputs it compared */
+    AUKIT_COUNTER_DFPWM_RESPECULATED = 5,  /* the chunk-speculative transcoder / encoder (dfpwm_spec.hip): how many times a stream's remaining chunks were speculated
+                                              again because its true encoder had changed its class (a clamp of the strength on the way) */
     AUKIT_COUNTER_FLAC_FUSED = 2           /* 1: the most recent FLAC decode was served by the fused decoder (flac_fused.hip); 0: a frame it declines was on
                                               the chain (or the batch is deeper than 24 bits) and the two-kernel decoder ran.  Set without COLLECT_STATS. */
 } aukit_counter;

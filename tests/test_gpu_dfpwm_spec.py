@@ -1,0 +1,116 @@
+"""The chunk-speculative DFPWM transcoder (aukit_amd/csrc/dfpwm_spec.hip): aukit.dfpwm(d, 2, rate):mono():dfpwm()
+(aukit.lua:1392-1414, :677-689, :1005-1018) with a lane per (stream, time chunk).  Whatever the speculation does — right guesses,
+wrong classes, warm-ups too short to converge, chunk boundaries anywhere — the bytes are the oracle's and the serial kernel's."""
+import numpy as np
+import pytest
+
+from util import signal
+
+pytestmark = pytest.mark.gpu
+
+
+def _B():
+    from aukit_amd import batch
+    return batch
+
+
+def _N():
+    from aukit_amd import _native
+    return _native
+
+
+def _enc_stereo(oracle, l, r):
+    return oracle.dfpwm_encode(np.stack([np.round(l), np.round(r)], 1).ravel())
+
+
+def _ref(oracle, s):
+    return oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(s, 2, 48000)), True) if s else b""
+
+
+ENVS = ({}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_G": "1"}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_ROUNDS": "1", "AUKIT_DFX_G": "2"}, {"AUKIT_DFX_CHUNKS": "1000", "AUKIT_DFX_MIN_BPC": "1"}, {"AUKIT_DFX_ROUNDS": "1"},
+        {"AUKIT_DFX_WE": "128", "AUKIT_DFX_CHUNKS": "7", "AUKIT_DFX_ROUNDS": "2"}, {"AUKIT_DFX_WPS": "1", "AUKIT_DFX_WE": "1008"})
+
+
+def _all_schedules(ctx, monkeypatch, bt, want):
+    B = _B()
+    for env in ENVS:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        name = ctx.last_kernel()[0]
+        for k in env:
+            monkeypatch.delenv(k)
+        assert name == "k_dfx_chunks", (env, name)
+        assert got == want, env
+
+
+def test_spec_transcode_config4_signal(ctx, oracle, monkeypatch):
+    """the config-4 signal, streams of six lengths (a Q10 slice boundary inside, an exact multiple of the block, short ones)"""
+    B = _B()
+    streams = []
+    for i, n in enumerate((120000, 24000, 6000, 6002, 45056, 30001)):
+        streams.append(_enc_stereo(oracle, signal(n * 4, 48000, 4, 2 * i) * 100, signal(n * 4, 48000, 4, 2 * i + 1) * 90))
+    bt = B.Batch.upload(ctx, streams)
+    want = [_ref(oracle, s) for s in streams]
+    assert len(want[0]) == 60010
+    monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
+    assert B.dfpwm_transcode_mono(ctx, bt, 2).download() == want
+    monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
+    _all_schedules(ctx, monkeypatch, bt, want)
+
+
+def test_spec_transcode_ragged_batch(ctx, oracle, monkeypatch):
+    """150 streams of six lengths (an empty one, one of a single slice, odd byte counts), unaligned starts: lanes of one wave at different
+    places of their streams"""
+    B = _B()
+    base = []
+    for i, n in enumerate((30000, 0, 6000, 18016, 6001, 12345 * 2 + 1)):
+        base.append(_enc_stereo(oracle, signal(n * 4, 48000, 4, 60 + 2 * i) * 100, signal(n * 4, 48000, 4, 61 + 2 * i) * 90) if n else b"")
+    order = [(i * 5 + i // 7) % 6 for i in range(150)]
+    bt = B.Batch.upload(ctx, [base[c] for c in order])
+    refs = [_ref(oracle, b) for b in base]
+    want = [refs[c] for c in order]
+    _all_schedules(ctx, monkeypatch, bt, want)
+
+
+def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
+    """inputs on which the single guess is wrong: silence in front of and inside the signal (the true encoder sits at its strength floor and
+    leaves it in another class: the verify pass re-speculates the rest), random bytes (noise: the class changes all the time; the verify
+    lanes run most blocks again), saturating patterns"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(7))
+    n = 60000 * 4
+    sig = [signal(n, 48000, 4, 90 + k) * 100 for k in range(4)]
+    gate = np.ones(n)
+    gate[: n // 5] = 0
+    gate[n // 2: n // 2 + n // 8] = 0
+    streams = [_enc_stereo(oracle, sig[0] * gate, sig[1] * gate), _enc_stereo(oracle, sig[2], sig[3] * gate),
+               bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), b"\xaa" * 30000 + bytes(rng.integers(0, 256, 30000, dtype=np.uint8)),
+               b"\xff" * 20000 + b"\x00" * 20000 + b"\x0f" * 20000]
+    bt = B.Batch.upload(ctx, streams)
+    want = [_ref(oracle, s) for s in streams]
+    _all_schedules(ctx, monkeypatch, bt, want)
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    B.dfpwm_transcode_mono(ctx, bt, 2)
+    ctx.sync()
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    assert ctx.counter(N.COUNTER_DFPWM_CHUNKS) > 0
+    assert ctx.counter(N.COUNTER_DFPWM_RESPECULATED) >= 1   # the gated streams left the floor in a class the prologue could not know
+
+
+def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):
+    """2048 streams (the shard one GPU of eight gets of BASELINE config 4), 2 s each, 8 distinct signals: the oracle's bytes, and the single
+    guess is right for nearly every chunk (what the speed rests on)"""
+    B, N = _B(), _N()
+    K = 8
+    base = [_enc_stereo(oracle, signal(96000, 48000, 4, 2 * i) * 100, signal(96000, 48000, 4, 2 * i + 1) * 90) for i in range(K)]
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(2048)])
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    assert ctx.last_kernel()[0] == "k_dfx_chunks"
+    chunks, redone, respec = (ctx.counter(c) for c in (N.COUNTER_DFPWM_CHUNKS, N.COUNTER_DFPWM_CHUNKS_REDONE, N.COUNTER_DFPWM_RESPECULATED))
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    for c in range(K):
+        assert all(g == got[c] for g in got[c::K])
+        assert got[c] == _ref(oracle, base[c])
+    assert respec == 0 and redone <= chunks // 50, (chunks, redone, respec)
