@@ -189,7 +189,7 @@ bool dfpwm_decode_parallel(aukit_ctx *ctx, const aukit_batch *in, int mode, int 
                            const unsigned long long *d_out_stride, int *rc, uint64_t adv = 6000, uint64_t lead = 0, const DfSliceHook *hook = nullptr);
 int dfpwm_transcode_sliced(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const unsigned long long *d_moff, const unsigned long long *d_mcount, unsigned char *out,
                            const unsigned long long *d_ooff, const uint64_t *h_ooff, int slices, bool *taken);
-int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const unsigned long long *d_ooff, bool *taken);  // dfpwm_spec.hip
+int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const unsigned long long *d_ooff, const uint64_t *h_ooff, bool *taken);  // dfpwm_spec.hip
 int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mono, const unsigned long long *d_moff, const unsigned long long *d_mcount, unsigned char *out,
                           const unsigned long long *d_ooff, const uint64_t *h_ooff, bool *taken);
 bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff,
@@ -1424,7 +1424,7 @@ int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channe
     if (channels == 2) {
         // every lane decodes, mixes and encodes its own time chunk of a stream; verified and patched afterwards (dfpwm_spec.hip)
         bool spec = false;
-        if ((rc = dfpwm_transcode_spec(ctx, in, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), &spec))) return rc;
+        if ((rc = dfpwm_transcode_spec(ctx, in, b->data(), reinterpret_cast<const unsigned long long *>(b->d_off), off.data(), &spec))) return rc;
         if (spec) return ctx_end_kernel(ctx, "k_dfx_chunks", in->total() + off[in->n]);
     }
     if (channels == 2) {  // decode + mono mix in parallel chunks (exact), then one encoder lane per stream (dfpwm_par.hip)

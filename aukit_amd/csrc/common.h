@@ -63,6 +63,10 @@ struct aukit_ctx {
     bool fused_attr_set = false;
     aukit::DevBuf dfx_lut;        // the 64 KiB stereo → mono mix table of the chunk-speculative transcoder (dfpwm_spec.hip), built once
     bool dfx_attr_set = false;
+    bool dfx_off = false;         // AUKIT_OPT_DFPWM_SPECULATE = 0
+    bool dfx_disable = false;     // set while that transcoder hands its hard streams to the older schedules (a nested aukit_dfpwm_transcode_mono)
+    aukit::DevBuf dfx_gather;     // ... their bytes, gathered
+    aukit_batch *dfx_sub_out = nullptr;  // ... and their result before it is scattered
     aukit_audio *stream_full = nullptr;  // stream.qoa with `mono`: the per-channel chunks before the mix, kept between calls (3.9 GB allocated and freed per call otherwise)  // k_df_fused's dynamic LDS size was announced on this context's device
     aukit::DevBuf fmt_flag;     // fast_fmt.hip: "a sample beyond ±1 was staged" (the launch condition of the reference-order redo)
     aukit::DevBuf wt_buf;       // phase-weight table of wave_f64.hip, cached per (b, interpolation)

@@ -26,6 +26,11 @@
 namespace aukit {
 
 int dfpwm_strength_scan(aukit_ctx *ctx, const DfParParams &P);  // k_df_blockmaps + k_df_blockscan (dfpwm_par.hip)
+}
+extern "C" int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channels, aukit_batch **out);
+extern "C" int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_bytes, const uint64_t *offsets, uint32_t n);
+extern "C" void aukit_batch_free(aukit_batch *b);
+namespace aukit {
 
 AUKIT_DEV unsigned dfs_class(const DfEnc &e, u64 t) { return ((unsigned)e.strength - (e.pb < 0 ? 2u : 0u) - (unsigned)t) & 3u; }
 AUKIT_DEV int dfs_pack(const DfEnc &e) { return (int)((unsigned)e.cu | (unsigned)e.strength << 8 | (e.pb > 0 ? 1u << 18 : 0u)); }
@@ -39,12 +44,15 @@ struct DfxParams {
     unsigned npad;          // n rounded up to 64
     unsigned round, rounds; // this launch's round; rounds in all (the last verify redoes whatever is left)
     int *st;                // [nchunk][12][npad] start state (decoder n, strength, pb, lpf, pn; encoder packed), end state (same six)
+    unsigned fix_iv;        // intervals k_dfx_fix runs a chunk again before it gives up (rounds before the last)
     unsigned G, nck;        // checkpoints: the state every G fed bytes inside a chunk (G divides W), nck = bpc W / G - 1 of them
     int *ck;                // [nchunk][nck][6][npad]
     int *fx;                // [nchunk][13][npad] k_dfx_fix's record per chunk: 0 none, else intervals it wrote << 1 | merged with the chunk lane's run (0: ran to the chunk's end),
                             //   the state it started from (6), the end state it reached (6, status 2)
-    int *ctl;               // [8][npad]: first chunk not final yet; encoder class; the true state (5 + 1) where that chunk starts
-    unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [12] by k_dfx_verify
+    int *ctl;               // [9][npad]: first chunk not final yet (nchunk: done, nchunk + 1: given up — a "hard" stream); the reference encoder state the
+                            //   chunk lanes model their guess on (packed); the true state (5 + 1) where that chunk starts; strikes
+    unsigned *hard;         // [npad] the hard streams (flags[13] of them): left to the lane-per-stream encoder (host side)
+    unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [13] hard streams
     const unsigned char *lut;  // [65536] mono + 128 for (l + 128) * 256 + (r + 128): the reference's fp64 mix (dfp_mix), in global memory
     unsigned char *enc_out; // the packed result
     const u64 *ooff;        // [n + 1]
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void k_dfx_lut(unsigned char *lut) {
     lut[i] = (unsigned char)(dfp_mix((int)(i >> 8) - 128, (int)(i & 255) - 128) + 128);
 }
 
-// a lane per stream: the encoder's class after the first DFX_X0 fed bytes; the control block of round 0
+// a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
 __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     const DfParParams &P = X.P;
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
@@ -143,7 +151,14 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     DfsAcc acc;
     dfx_span<false>(p, 0, f1, P.feed, d, e, X.lut + 128 * 257, acc);
     X.ctl[s] = 0;
-    X.ctl[(size_t)X.npad + s] = (int)dfs_class(e, 4 * f1);
+    X.ctl[(size_t)X.npad + s] = dfs_pack(e);   // (at sample 4 f1: a multiple of 4, like every warm-up start — see k_dfx_chunks)
+    {
+        int v[6];
+        dfp_pack(d, v);
+#pragma unroll
+        for (int i = 0; i < 5; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = v[i];   // the decoder's side of the reference
+    }
+    X.ctl[(size_t)8 * X.npad + s] = 0;
 }
 
 // copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
@@ -162,7 +177,7 @@ AUKIT_DEV int *dfx_ck(const DfxParams &X, unsigned c, unsigned j, unsigned s) { 
 // chunk lane's in the first `min_iv` intervals (no merge counts before those are rewritten), or in all of them (`may_merge` false).
 template <typename LUT>
 AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsigned char *p, u64 fed, DfDec &d, DfEnc &e, LUT lutc, unsigned &intervals,
-                         unsigned min_iv = 0, bool may_merge = true) {
+                         unsigned min_iv = 0, bool may_merge = true, unsigned max_iv = 0xFFFFFFFFu, bool *gave_up = nullptr) {
     const DfParParams &P = X.P;
     const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
     DfsAcc acc;
@@ -179,6 +194,7 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
         t[5] = dfs_pack(e);
         dfx_load6(dfx_ck(X, c, j, s), X.npad, w);
         if (may_merge && j + 1 >= min_iv && dfx_same6(t, w)) return true;
+        if (j + 1 >= max_iv) { *gave_up = true; return false; }  // (k_dfx_fix before the last round: two runs that have not merged by now are not going to)
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
     intervals++;
@@ -216,10 +232,20 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
         }
     } else {
         // warm-up over the block before the chunk: the decoder with its exact strength and previous bit, charge and filter from zero;
-        // after Wd bytes the encoder joins in, charge on its first sample, strength near the usual one in the stream's class
+        // after Wd bytes the encoder joins in
         const u64 fw = f0 - P.W, fe = fw + X.Wd;
         d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
         d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
+        {   // At the strength floor the decoder's charge step is ±1 whatever the charge: an integrator of the bits, which forgets nothing
+            // — a warm-up from zero never arrives (digital silence: the bits alternate, the charge is off by its phase for good).  If the
+            // reference decoder sat at the floor too, its charge, filter and previous charge are the better start: the same 2-cycle.
+            const int rs = X.ctl[(size_t)3 * X.npad + s];
+            if (d.p.strength <= 9 && rs >= 0 && rs <= 9) {
+                d.p.n = X.ctl[(size_t)2 * X.npad + s];
+                d.lpf = X.ctl[(size_t)5 * X.npad + s];
+                d.pn = X.ctl[(size_t)6 * X.npad + s];
+            }
+        }
         DfOut O{};
         O.feed = P.feed;
         dfp_run<false>(p, fw, fe, d, O);
@@ -231,11 +257,20 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
                 const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
                 u[k] = (unsigned)lutc[l * 256 + r];
             }
-            const unsigned cls = (unsigned)X.ctl[(size_t)X.npad + s] & 3u;
-            e.cu = (int)u[0];
-            e.pb = -1;
-            e.strength = 40;
-            e.strength += (int)((cls - dfs_class(e, 4 * fe)) & 3u);
+            // The guess is modelled on a true state of this stream (the reference: after the first samples, or where the verify pass
+            // last found the guesses failing): its strength and previous bit — the reference and every warm-up start sit at sample
+            // indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and the
+            // charge on the first sample.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at
+            // every step, and which of its two phases it is in is not a matter of class) is copied whole, charge included.
+            const DfEnc ref = dfs_unpack(X.ctl[(size_t)X.npad + s]);
+            const int du = ref.cu - (int)u[0];
+            if (ref.strength > 9) { e.strength = ref.strength; e.pb = ref.pb; e.cu = (int)u[0]; }
+            else if (du >= -2 && du <= 2) e = ref;   // the same silence, by the look of the first sample
+            else {
+                // a floor reference says nothing about a passage with signal: any strength away from the floor, in the reference's class
+                // all the same — the lanes of the stream then agree with each other, which is what tells a change of class from noise
+                e.cu = (int)u[0]; e.pb = ref.pb; e.strength = 40 + ((ref.strength - 40) & 3);
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
         }
@@ -266,7 +301,6 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);
-    const bool last_round = X.round + 1 >= X.rounds;
     bool need = false;
     int from[6] = {0, 0, 0, 0, 0, 0};
     if (c >= 1 && c < P.nchunk && c > (X.round ? (unsigned)X.ctl[s] : 0u)) {
@@ -274,10 +308,7 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
         dfx_load6(X.st + (size_t)c * 12 * X.npad + s, X.npad, v);
         if (v[1] >= 0) {
             dfx_load6(X.st + ((size_t)(c - 1) * 12 + 6) * X.npad + s, X.npad, from);
-            const u64 t0 = 4 * dfp_chunk_start(P, c);
-            // (an encoder in another class never merges: left to the verify lane, which speculates the rest of the stream again — in the
-            // last round there is no again, and running the whole chunk here is still better than running it there)
-            need = !dfx_same6(v, from) && (last_round || dfs_class(dfs_unpack(from[5]), t0) == dfs_class(dfs_unpack(v[5]), t0));
+            need = !dfx_same6(v, from);
         }
         if (!need) X.fx[(size_t)c * 13 * X.npad + s] = 0;
     }
@@ -289,10 +320,13 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     DfDec d;
     dfp_unpack(from, d);
     DfEnc e = dfs_unpack(from[5]);
+    // A run that has not merged after a few intervals is given up: the true encoder is not where the chunk lane guessed it for good
+    // (another class: it never merges), and the verify lane has the rest of the stream speculated again.
     unsigned iv = 0;
-    const bool merged = dfx_rerun(X, s, c, P.src + P.off[s], P.fed[s], d, e, lutc, iv);
+    bool gave_up = false;
+    const bool merged = dfx_rerun(X, s, c, P.src + P.off[s], P.fed[s], d, e, lutc, iv, 0, true, X.fix_iv, &gave_up);
     int *fx = X.fx + (size_t)c * 13 * X.npad + s;
-    fx[0] = (int)(iv << 1 | (merged ? 1u : 0u));  // (iv >= 1)
+    fx[0] = gave_up ? -(int)iv : (int)(iv << 1 | (merged ? 1u : 0u));  // (iv >= 1)
 #pragma unroll
     for (int i = 0; i < 6; i++) fx[(size_t)(1 + i) * X.npad] = from[i];
     if (!merged) dfx_store6(fx + (size_t)7 * X.npad, X.npad, d, e);
@@ -300,83 +334,77 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     atomicAdd(&X.flags[11], 1u);
 }
 
-// a lane per stream: the chain of true states
+// a lane per stream: the chain of true states.  A chunk whose recorded start state is the true end state of the chunk before it is final;
+// so is one that k_dfx_fix ran again FROM that true state until it merged (or to its end).  Anything else ends the walk: the stream's
+// later chunks are speculated again in the next round, modelled on the true state here — unless the rounds are used up or the stream keeps
+// failing every few chunks (noise: its encoder touches the strength floor and changes class all the time), in which case it is handed
+// to the host as "hard".
 __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
-    extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
     if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
-    const bool act = s < P.n;
-    unsigned c = act ? (X.round ? (unsigned)X.ctl[s] : 0u) : P.nchunk;
-    const bool last_round = X.round + 1 >= X.rounds;
-    const unsigned char *p = P.src + (act ? P.off[s] : 0);
-    const u64 fed = act ? P.fed[s] : 0;
-    int truth[6] = {0, 0, 0, 0, 0, 0};
-    unsigned chunks = 0, intervals = 0, rerun = 0;
-    enum { WALK, NEED_TABLE, DONE, AGAIN } state = c < P.nchunk ? WALK : DONE;
-    if (state == WALK) {
-        dfx_load6(X.st + ((size_t)c * 12 + 6) * X.npad + s, X.npad, truth);  // chunk c ran from the true state
-        chunks = 1;
-        c++;
-    }
-    bool table = false;
-    // walks the chain until the stream is done, handed back for another round, or (without the table) needs a chunk run again here
-    auto walk = [&]() {
-        for (; c < P.nchunk; c++) {
-            const int *st = X.st + (size_t)c * 12 * X.npad + s;
-            int v[6];
-            dfx_load6(st, X.npad, v);
-            if (v[1] < 0) break;  // the stream ended before this chunk
-            if (dfx_same6(v, truth)) { chunks++; dfx_load6(st + (size_t)6 * X.npad, X.npad, truth); continue; }
-            const int *fx = X.fx + (size_t)c * 13 * X.npad + s;
-            const int fst = fx[0];
-            if (fst) {  // k_dfx_fix ran this chunk again: from the true state?
-                int w[6];
-                dfx_load6(fx + (size_t)X.npad, X.npad, w);
-                if (dfx_same6(w, truth)) { chunks++; dfx_load6(fst & 1 ? st + (size_t)6 * X.npad : fx + (size_t)7 * X.npad, X.npad, truth); continue; }
-            }
-            const u64 t0 = 4 * dfp_chunk_start(P, c);
-            DfDec d;
-            dfp_unpack(truth, d);
-            DfEnc e = dfs_unpack(truth[5]);
-            if (!last_round && dfs_class(e, t0) != dfs_class(dfs_unpack(v[5]), t0)) {
-                // the true encoder has changed its class (it was clamped on the way): this and the later chunks are speculated again
-                X.ctl[s] = (int)c;
-                X.ctl[(size_t)X.npad + s] = (int)dfs_class(e, t0);
-#pragma unroll
-                for (int i = 0; i < 6; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = truth[i];
-                __hip_atomic_store(&X.flags[X.round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&X.flags[10], 1u);
-                state = AGAIN;
-                return;
-            }
-            // nobody has run this chunk from the true state yet: here and now (the mix table has to be in LDS first)
-            if (!table) { state = NEED_TABLE; return; }
-            chunks++;
-            rerun++;
-            if (dfx_rerun(X, s, c, p, fed, d, e, lutu + 128 * 257, intervals, (unsigned)fst >> 1, fst == 0 || (fst & 1))) dfx_load6(st + (size_t)6 * X.npad, X.npad, truth);
-            else { dfp_pack(d, truth); truth[5] = dfs_pack(e); }
+    if (s >= P.n) return;
+    const unsigned c_from = X.round ? (unsigned)X.ctl[s] : 0u;
+    if (c_from >= P.nchunk) return;
+    unsigned c = c_from;
+    int truth[6];
+    dfx_load6(X.st + ((size_t)c * 12 + 6) * X.npad + s, X.npad, truth);  // chunk c ran from the true state
+    unsigned chunks = 1;
+    for (c++; c < P.nchunk; c++) {
+        const int *st = X.st + (size_t)c * 12 * X.npad + s;
+        int v[6];
+        dfx_load6(st, X.npad, v);
+        if (v[1] < 0) break;  // the stream ended before this chunk
+        if (dfx_same6(v, truth)) { chunks++; dfx_load6(st + (size_t)6 * X.npad, X.npad, truth); continue; }
+        const int *fx = X.fx + (size_t)c * 13 * X.npad + s;
+        const int fst = fx[0];   // 0: k_dfx_fix did not run; < 0: it gave up after -fst intervals; else intervals << 1 | merged
+        if (fst > 0) {
+            int w[6];
+            dfx_load6(fx + (size_t)X.npad, X.npad, w);
+            if (dfx_same6(w, truth)) { chunks++; dfx_load6(fst & 1 ? st + (size_t)6 * X.npad : fx + (size_t)7 * X.npad, X.npad, truth); continue; }
         }
-        state = DONE;
-    };
-    if (state == WALK) walk();
-    if (__syncthreads_or(state == NEED_TABLE ? 1 : 0)) {
-        dfx_lut_to_lds(X.lut, lutu, 64);
-        __syncthreads();
-        table = true;
-        if (state == NEED_TABLE) walk();
+        // the guesses do not lead to the true state from here on
+        const unsigned progress = c - c_from, few = P.nchunk / 16 > 2 ? P.nchunk / 16 : 2;
+        const int strikes = progress < few ? X.ctl[(size_t)8 * X.npad + s] + 1 : 0;
+        atomicAdd(&X.flags[8], chunks);
+        // how the later chunks look: after a change of class the guesses still agree with each other (they converge to the same wrong run),
+        // on noise they do not — every boundary is a mismatch, and another round would fail at the next one
+        unsigned later = 0, bad = 0;
+        for (unsigned k = c + 1; k < P.nchunk; k++) {
+            if (X.st[((size_t)k * 12 + 1) * X.npad + s] < 0) break;
+            later++;
+            bad += X.fx[(size_t)k * 13 * X.npad + s] != 0 ? 1u : 0u;
+        }
+        if (X.round + 1 >= X.rounds || strikes >= 2 || (later >= 4 && bad * 4 > later)) {
+            X.ctl[s] = (int)P.nchunk + 1;
+            X.hard[atomicAdd(&X.flags[13], 1u)] = s;
+            return;
+        }
+        X.ctl[s] = (int)c;
+        X.ctl[(size_t)X.npad + s] = truth[5];   // (at sample 4 x chunk start: a multiple of 4)
+#pragma unroll
+        for (int i = 0; i < 6; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = truth[i];
+        X.ctl[(size_t)8 * X.npad + s] = strikes;
+        __hip_atomic_store(&X.flags[X.round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&X.flags[10], 1u);
+        return;
     }
-    if (!act || !chunks) return;
-    if (state == DONE) X.ctl[s] = (int)P.nchunk;
+    X.ctl[s] = (int)P.nchunk;  // done
     atomicAdd(&X.flags[8], chunks);
-    if (intervals) atomicAdd(&X.flags[9], intervals);
-    if (rerun) atomicAdd(&X.flags[12], rerun);
+}
+
+// bytes [src_off[i], + len[i]) of `src` to dst + dst_off[i]: the hard streams to and from the lane-per-stream schedule
+__global__ __launch_bounds__(256) void k_dfx_move(const unsigned char *src, unsigned char *dst, const u64 *tab, unsigned m) {
+    const unsigned i = blockIdx.y;
+    const u64 so = tab[i], d0 = tab[m + i], len = tab[2 * (size_t)m + i];
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < len; k += (u64)gridDim.x * 256) dst[d0 + k] = src[so + k];
 }
 
 // host side; *taken = false (nothing launched) when the batch is too short to be cut
-int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const u64 *d_ooff, bool *taken) {
+int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const u64 *d_ooff, const uint64_t *h_ooff, bool *taken) {
     *taken = false;
     const uint32_t n = in->n;
+    if (ctx->dfx_disable || ctx->dfx_off) return AUKIT_OK;
     // (the environment switches of the older schedules — tests and A/B runs — name those schedules: not this one)
     if (n == 0 || getenv("AUKIT_DFPWM_SERIAL") || getenv("AUKIT_DFPWM_NOSPEC") || getenv("AUKIT_DFPWM_FUSED") || getenv("AUKIT_DFPWM_SLICES") || getenv("AUKIT_DFPWM_BLOCK") ||
         getenv("AUKIT_DFPWM_CHUNKS"))
@@ -404,7 +432,10 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     const unsigned bpc = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, min_bpc);
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
-    unsigned rounds = 4;
+    // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
+    // into many chunks per stream, all of it again when it is cut into few (a large batch: none there).  One re-speculation covers the
+    // usual case (silence in front of the signal); streams that need more are "hard" and go to the lane-per-stream encoder.
+    unsigned rounds = nchunk >= 16 ? 2 : 1;
     if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
     const unsigned npad = (unsigned)round_up(n, 64);
     // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~80 MB of them
@@ -416,7 +447,7 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_tab = take((size_t)n * 16), o_maps = take((size_t)n * nchunk * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
-                 o_ctl = take((size_t)8 * npad * 4), o_fl = take(64);
+                 o_ctl = take((size_t)9 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
     int rc = ctx->tmp_buf2.ensure(o + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
@@ -433,7 +464,8 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     P.maps = reinterpret_cast<SatMap *>(B + o_maps); P.s_start = reinterpret_cast<int *>(B + o_ss);
     P.init = nullptr; P.mode = 1; P.C = 2;
     X.Wd = Wd; X.npad = npad; X.rounds = rounds; X.G = G; X.nck = nck;
-    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl);
+    X.fix_iv = std::max<unsigned>(2, (unsigned)(W / G));  // a warm-up length
+    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.hard = reinterpret_cast<unsigned *>(B + o_hard);
     X.flags = reinterpret_cast<unsigned *>(B + o_fl);
     X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);
     X.enc_out = out; X.ooff = d_ooff;
@@ -443,7 +475,6 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     if (!ctx->dfx_attr_set) {
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_verify), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         ctx->dfx_attr_set = true;
     }
     const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256));
@@ -451,17 +482,64 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
         X.round = r;
         hipLaunchKernelGGL(k_dfx_chunks, grid, dim3(256), 65536, ctx->stream, X);
         hipLaunchKernelGGL(k_dfx_fix, grid, dim3(256), 65536, ctx->stream, X);
-        hipLaunchKernelGGL(k_dfx_verify, dim3((n + 63) / 64), dim3(64), 65536, ctx->stream, X);
+        hipLaunchKernelGGL(k_dfx_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
+        if (getenv("AUKIT_DFX_TRACE")) {  // (debugging: where the first streams stand after every round)
+            int h[16] = {};
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, X.ctl, sizeof(int) * std::min<unsigned>(8, npad), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h + 8, X.ctl + npad, sizeof(int) * std::min<unsigned>(8, npad), hipMemcpyDeviceToHost);
+            unsigned fl[16] = {};
+            (void)hipMemcpy(fl, X.flags, 64, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[dfpwm spec] round %u: %u hard streams so far, %u re-speculations so far, %u chunks run again by k_dfx_fix\n", r, fl[13], fl[10], fl[11]);
+            fprintf(stderr, "[dfpwm spec] round %u: first not-final chunk of streams 0..7: %d %d %d %d %d %d %d %d; classes %d %d %d %d %d %d %d %d\n", r, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7],
+                    h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+        }
     }
     AUKIT_HIP_CHECK(hipGetLastError());
-    if (getenv("AUKIT_DFPWM_STATS") || ctx->collect_stats) {
-        unsigned h[16] = {};
-        (void)hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-        ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[8]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[11] + h[12]; ctx->counters[AUKIT_COUNTER_DFPWM_RESPECULATED] = h[10];
-        if (getenv("AUKIT_DFPWM_STATS"))
-            fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u): %u chunks verified; run again: %u chunks by their own lanes, %u by the verify lanes, %u checkpoint intervals in all; %u stream rounds re-speculated (flags %u %u %u %u)\n",
-                    n, nchunk, bpc, (unsigned long long)W, Wd, G, h[8], h[11], h[12], h[9], h[10], h[0], h[1], h[2], h[3]);
+    // what the rounds have left: one look at the counters (the only host synchronisation of the call)
+    unsigned h[16] = {};
+    AUKIT_HIP_CHECK(hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[8]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[11]; ctx->counters[AUKIT_COUNTER_DFPWM_RESPECULATED] = h[10];
+    ctx->counters[AUKIT_COUNTER_DFPWM_HARD] = h[13];
+    if (getenv("AUKIT_DFPWM_STATS"))
+        fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u, %u rounds): %u chunks verified; %u chunks run again by k_dfx_fix (%u checkpoint intervals); %u stream rounds re-speculated (flags %u %u %u %u %u %u); %u hard streams\n",
+                n, nchunk, bpc, (unsigned long long)W, Wd, G, rounds, h[8], h[11], h[9], h[10], h[0], h[1], h[2], h[3], h[4], h[5], h[13]);
+    const unsigned m = h[13];
+    if (m) {
+        // Hard streams — the encoder changes its class every few chunks (noise) or more often than there are rounds: the schedule with one
+        // encoder lane per stream does not care.  Their bytes are gathered into a batch of their own, transcoded by
+        // aukit_dfpwm_transcode_mono with this schedule switched off, and scattered to their places.
+        std::vector<unsigned> hs(m);
+        AUKIT_HIP_CHECK(hipMemcpy(hs.data(), X.hard, (size_t)m * 4, hipMemcpyDeviceToHost));
+        std::sort(hs.begin(), hs.end());
+        std::vector<uint64_t> sub_off(m + 1, 0), tab(3 * (size_t)m);
+        for (unsigned i = 0; i < m; i++) {
+            const uint64_t len = in->off[hs[i] + 1] - in->off[hs[i]];
+            tab[i] = in->off[hs[i]]; tab[m + i] = sub_off[i]; tab[2 * (size_t)m + i] = len;
+            sub_off[i + 1] = sub_off[i] + len;
+        }
+        if ((rc = ctx->dfx_gather.ensure((size_t)sub_off[m] + 64 + tab.size() * 8))) return rc;
+        unsigned char *gbuf = reinterpret_cast<unsigned char *>(ctx->dfx_gather.p);
+        u64 *dtab = reinterpret_cast<u64 *>(gbuf + round_up(sub_off[m] + 16, 64));
+        uint64_t maxlen = 1;
+        for (unsigned i = 0; i < m; i++) maxlen = std::max(maxlen, tab[2 * (size_t)m + i]);
+        if ((rc = h2d_table(ctx, dtab, tab.data(), tab.size() * 8))) return rc;
+        for (unsigned i0 = 0; i0 < m; i0 += 65535)  // (gridDim.y limit; the table is indexed from i0 by pointer offset: src | dst | len planes of m)
+            hipLaunchKernelGGL(k_dfx_move, dim3((unsigned)std::min<uint64_t>((maxlen + 4095) / 4096, 64), std::min<unsigned>(65535, m - i0)), dim3(256), 0, ctx->stream, in->data(), gbuf, dtab + i0, m);
+        aukit_batch *sub_in = nullptr;
+        if ((rc = aukit_batch_wrap_device(ctx, &sub_in, gbuf, sub_off.data(), m))) return rc;
+        ctx->dfx_disable = true;
+        rc = aukit_dfpwm_transcode_mono(ctx, sub_in, 2, &ctx->dfx_sub_out);
+        ctx->dfx_disable = false;
+        aukit_batch_free(sub_in);
+        if (rc) return rc;
+        const aukit_batch *so = ctx->dfx_sub_out;
+        for (unsigned i = 0; i < m; i++) { tab[i] = so->off[i]; tab[m + i] = h_ooff[hs[i]]; tab[2 * (size_t)m + i] = so->off[i + 1] - so->off[i]; }
+        if ((rc = h2d_table(ctx, dtab, tab.data(), tab.size() * 8))) return rc;
+        for (unsigned i0 = 0; i0 < m; i0 += 65535)
+            hipLaunchKernelGGL(k_dfx_move, dim3((unsigned)std::min<uint64_t>((maxlen / 2 + 4095) / 4096 + 1, 64), std::min<unsigned>(65535, m - i0)), dim3(256), 0, ctx->stream, so->data(), out, dtab + i0, m);
+        AUKIT_HIP_CHECK(hipGetLastError());
     }
     *taken = true;
     return AUKIT_OK;

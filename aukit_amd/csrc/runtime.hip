@@ -234,7 +234,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     { std::lock_guard<std::mutex> lk(g_live_mu); g_live.erase(c); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release(); c->dfx_lut.release();
+    c->seg_buf.release(); c->tile_buf.release(); c->misc_buf.release(); c->tmp_buf.release(); c->tmp_buf2.release(); c->tmp_buf3.release(); c->wt_buf.release(); c->enc_state_buf.release(); c->dfx_lut.release(); c->dfx_gather.release(); if (c->dfx_sub_out) { aukit_batch_free(c->dfx_sub_out); c->dfx_sub_out = nullptr; }
     if (c->aux_stream) {
         (void)hipStreamSynchronize(c->aux_stream);
         if (c->dec_stream) { (void)hipStreamSynchronize(c->dec_stream); (void)hipStreamDestroy(c->dec_stream); }
@@ -284,6 +284,7 @@ int aukit_ctx_set_option(aukit_ctx *c, int option, int value) {
     if (option == AUKIT_OPT_EXACT_MATH) c->exact_math = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (option == AUKIT_OPT_STORE_X4) c->fast_store_x4 = value != 0;
     else if (option == AUKIT_OPT_COLLECT_STATS) c->collect_stats = value != 0;
+    else if (option == AUKIT_OPT_DFPWM_SPECULATE) c->dfx_off = value == 0;
     else return fail(AUKIT_E_ARG, "unknown option %d", option);
     return AUKIT_OK;
 }

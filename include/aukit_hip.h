@@ -140,8 +140,12 @@ typedef enum {
                                  G.711 stereo); anything else runs the reference-order kernels.  Results may differ from value 2 by one
                                  f32 ulp.  2: always the reference-order fp64 kernels (stream tails included). */
     AUKIT_OPT_STORE_X4 = 1,   /* 1 (default): fast kernels transpose results through LDS and store 16 B per lane */
-    AUKIT_OPT_COLLECT_STATS = 2 /* 1: calls that have counters (aukit_ctx_get_counter) read them back — one more device→host sync per call.
+    AUKIT_OPT_COLLECT_STATS = 2, /* 1: calls that have counters (aukit_ctx_get_counter) read them back — one more device→host sync per call.
                                    0 (default): they do not. */
+    AUKIT_OPT_DFPWM_SPECULATE = 3 /* 1 (default): aukit_dfpwm_transcode_mono cuts every stream into time chunks that are decoded, mixed and ENCODED
+                                   by a lane each from a guessed encoder state, verified afterwards (dfpwm_spec.hip) — several times faster
+                                   on signal, same bytes always; up to ~1.9x slower than 0 where the guesses fail (the encoder at its strength
+                                   floor: long digital silence, noise).  0: one encoder lane per stream behind the chunk-parallel decoder. */
 } aukit_option;
 int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 /* counters of the most recent call that produced them (AUKIT_OPT_COLLECT_STATS = 1) */
@@ -154,6 +158,7 @@ typedef enum {
     AUKIT_COUNTER_TIER1_OUTPUTS = 4,       /* ... and how many outputs it compared */
     AUKIT_COUNTER_DFPWM_RESPECULATED = 5,  /* the chunk-speculative transcoder / encoder (dfpwm_spec.hip): how many times a stream's remaining chunks were speculated
                                               again because its true encoder had changed its class (a clamp of the strength on the way) */
+    AUKIT_COUNTER_DFPWM_HARD = 6,          /* ... and how many streams it gave up on and left to the schedule with one encoder lane per stream (noise-like input) */
     AUKIT_COUNTER_FLAC_FUSED = 2           /* 1: the most recent FLAC decode was served by the fused decoder (flac_fused.hip); 0: a frame it declines was on
                                               the chain (or the batch is deeper than 24 bits) and the two-kernel decoder ran.  Set without COLLECT_STATS. */
 } aukit_counter;

@@ -96,6 +96,7 @@ def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
     ctx.set_option(N.OPT_COLLECT_STATS, 0)
     assert ctx.counter(N.COUNTER_DFPWM_CHUNKS) > 0
     assert ctx.counter(N.COUNTER_DFPWM_RESPECULATED) >= 1   # the gated streams left the floor in a class the prologue could not know
+    assert ctx.counter(N.COUNTER_DFPWM_HARD) >= 1           # the noise is given up on and goes to the lane-per-stream encoder
 
 
 def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):

@@ -212,7 +212,8 @@ def test_one_long_dfpwm_stream(ctx, oracle):
     ref = oracle.dfpwm(s, 2, 48000)
     assert np.array_equal(got[0], ref.data[0]) and np.array_equal(got[1], ref.data[1])
     fused = B.dfpwm_transcode_mono(ctx, bt, 2).download()[0]
-    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfe_*"  # one stream: the exact parallel encoder
+    assert ctx.last_kernel()[0] == "k_dfx_chunks"  # a lane per time chunk decodes, mixes and encodes (random bytes: noise — most of the guesses fail, the stream
+    # is given up on as "hard" and goes through the older schedule, a nested call: the exact parallel encoder for a batch of one)
     assert fused == oracle.audio_dfpwm(oracle.mono(ref), True)
 
 
