@@ -588,10 +588,19 @@ class StreamHandle:
     def next(self):
         """→ ("chunk", [per-channel float64 arrays], pos) | ("need_input", None, None) | ("end", None, None)"""
         if getattr(self, "_buf", None) is None:  # one buffer per handle (a fresh zero-filled 64 MB array per chunk was most of a chunk's cost)
-            self._buf = np.empty(self._cap * AUKIT_MAX_CH, dtype=np.float64)
-        buf = self._buf
+            self._buf_ch = 2
+            self._buf = np.empty(self._cap * self._buf_ch, dtype=np.float64)
         ln, ch, st, pos = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_double()
-        N.check(N.lib().aukit_stream_next(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint32(self._cap), C.byref(ln), C.byref(ch), C.byref(pos), C.byref(st)))
+        while True:
+            buf = self._buf
+            rc = N.lib().aukit_stream_next(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(buf.size), C.c_uint32(self._cap), C.byref(ln), C.byref(ch), C.byref(pos),
+                                           C.byref(st))
+            if rc == N.E_ARG and ch.value > self._buf_ch and ln.value <= self._cap:  # more channels than the buffer was sized for: the chunk is still there
+                self._buf_ch = ch.value
+                self._buf = np.empty(self._cap * self._buf_ch, dtype=np.float64)
+                continue
+            N.check(rc)
+            break
         if st.value == N.STREAM_CHUNK:
             return "chunk", [buf[c * self._cap: c * self._cap + ln.value].copy() for c in range(ch.value)], pos.value
         return ("need_input" if st.value == N.STREAM_NEED_INPUT else "end"), None, None

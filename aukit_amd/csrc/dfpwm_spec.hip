@@ -36,6 +36,8 @@ AUKIT_DEV unsigned dfs_class(const DfEnc &e, u64 t) { return ((unsigned)e.streng
 AUKIT_DEV int dfs_pack(const DfEnc &e) { return (int)((unsigned)e.cu | (unsigned)e.strength << 8 | (e.pb > 0 ? 1u << 18 : 0u)); }
 AUKIT_DEV DfEnc dfs_unpack(int v) { DfEnc e; e.cu = v & 255; e.strength = (v >> 8) & 1023; e.pb = (v >> 18) & 1 ? 1 : -1; return e; }
 
+constexpr unsigned DFX_PROBE_FROM = 256, DFX_PROBE_END = 768;  // fed bytes: the probe's guess warms up over 512 of them (2048 mono samples: on the config-4
+                                                                 // signal 0.6 % of such guesses miss; the batch is declined at 6 %)
 constexpr unsigned DFX_X0 = 128;  // fed bytes (512 mono samples) the prologue runs from the reset state to learn the encoder's class
 
 struct DfxParams {
@@ -44,6 +46,7 @@ struct DfxParams {
     unsigned npad;          // n rounded up to 64
     unsigned round, rounds; // this launch's round; rounds in all (the last verify redoes whatever is left)
     int *st;                // [nchunk][12][npad] start state (decoder n, strength, pb, lpf, pn; encoder packed), end state (same six)
+    unsigned probe;         // k_dfx_prologue also tries one guess per stream (flags[14]: it missed, [15]: the stream starts in silence)
     unsigned fix_iv;        // intervals k_dfx_fix runs a chunk again before it gives up (rounds before the last)
     unsigned G, nck;        // checkpoints: the state every G fed bytes inside a chunk (G divides W), nck = bpc W / G - 1 of them
     int *ck;                // [nchunk][nck][6][npad]
@@ -133,10 +136,36 @@ AUKIT_DEV bool dfx_same6(const int *a, const int *b) {
     return same;
 }
 
+// The encoder a chunk lane starts its warm-up with, modelled on a true state of the stream (the reference: after the stream's first samples,
+// or where the verify pass last found the guesses failing): the reference's strength and previous bit — the reference and every warm-up
+// start sit at sample indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and
+// the charge on the first sample `u0`.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at every
+// step, and which of its two phases it is in is not a matter of class) is copied whole where the first sample looks like the same silence.
+AUKIT_DEV DfEnc dfx_guess(const DfEnc &ref, unsigned u0) {
+    DfEnc e;
+    const int du = ref.cu - (int)u0;
+    if (ref.strength > 9) { e.strength = ref.strength; e.pb = ref.pb; e.cu = (int)u0; }
+    else if (du >= -2 && du <= 2) e = ref;
+    else {
+        // a floor reference says nothing about a passage with signal: any strength away from the floor, in the reference's class all the
+        // same — the lanes of the stream then agree with each other, which is what tells a change of class from noise
+        e.cu = (int)u0; e.pb = ref.pb; e.strength = 40 + ((ref.strength - 40) & 3);
+    }
+    return e;
+}
+
 // the 64 KiB mix table, once per context (k_dfx_chunks copies it into LDS: 256 bytes per thread instead of 256 fp64 mixes)
 __global__ __launch_bounds__(256) void k_dfx_lut(unsigned char *lut) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     lut[i] = (unsigned char)(dfp_mix((int)(i >> 8) - 128, (int)(i & 255) - 128) + 128);
+}
+
+// A round after the first runs only if the round before left streams to speculate again — and not at all once most of the batch has been
+// given up on: the input is noise-like then, the lucky rest would fail a few chunks further on, and every round costs the time of a whole
+// chunk lane however few streams it is for.  (Streams left unfinished this way are hard streams to the host.)
+AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
+    return !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+           2 * __hip_atomic_load(&X.flags[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > X.P.n;
 }
 
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
@@ -149,7 +178,8 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     DfDec d{};
     DfEnc e{};
     DfsAcc acc;
-    dfx_span<false>(p, 0, f1, P.feed, d, e, X.lut + 128 * 257, acc);
+    const unsigned char *lutc = X.lut + 128 * 257;
+    dfx_span<false>(p, 0, f1, P.feed, d, e, lutc, acc);
     X.ctl[s] = 0;
     X.ctl[(size_t)X.npad + s] = dfs_pack(e);   // (at sample 4 f1: a multiple of 4, like every warm-up start — see k_dfx_chunks)
     {
@@ -157,6 +187,27 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
         dfp_pack(d, v);
 #pragma unroll
         for (int i = 0; i < 5; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = v[i];   // the decoder's side of the reference
+    }
+    if (X.probe && fed >= DFX_PROBE_END) {
+        // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on to DFX_PROBE_END, and from
+        // DFX_PROBE_FROM a guess modelled on the reference runs beside it, the way the chunk lanes' guesses will — do they meet?
+        const DfEnc ref = e;
+        dfx_span<false>(p, f1, DFX_PROBE_FROM, P.feed, d, e, lutc, acc);
+        DfEnc g;
+        bool first = true;
+        fed_for_each(p, DFX_PROBE_FROM, DFX_PROBE_END, P.feed, [&](unsigned byte) {
+            const unsigned nb = ~byte;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+                const unsigned u = (unsigned)lutc[l * 256 + r];
+                if (first) { g = dfx_guess(ref, u); first = false; }
+                df_encode_u(e, u);
+                df_encode_u(g, u);
+            }
+        });
+        if (dfs_pack(g) != dfs_pack(e)) atomicAdd(&X.flags[14], 1u);
+        else if (ref.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
     }
     X.ctl[(size_t)8 * X.npad + s] = 0;
 }
@@ -206,7 +257,7 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
 __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
-    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the round before left nothing
+    if (X.round > 0 && dfx_round_off(X)) return;
     dfx_lut_to_lds(X.lut, lutu, 256);
     __syncthreads();
     const unsigned char *lutc = lutu + 128 * 257;  // indexed by signed (l, r)
@@ -262,15 +313,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
             // indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and the
             // charge on the first sample.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at
             // every step, and which of its two phases it is in is not a matter of class) is copied whole, charge included.
-            const DfEnc ref = dfs_unpack(X.ctl[(size_t)X.npad + s]);
-            const int du = ref.cu - (int)u[0];
-            if (ref.strength > 9) { e.strength = ref.strength; e.pb = ref.pb; e.cu = (int)u[0]; }
-            else if (du >= -2 && du <= 2) e = ref;   // the same silence, by the look of the first sample
-            else {
-                // a floor reference says nothing about a passage with signal: any strength away from the floor, in the reference's class
-                // all the same — the lanes of the stream then agree with each other, which is what tells a change of class from noise
-                e.cu = (int)u[0]; e.pb = ref.pb; e.strength = 40 + ((ref.strength - 40) & 3);
-            }
+            e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), u[0]);
 #pragma unroll
             for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
         }
@@ -298,7 +341,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
 __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
-    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (X.round > 0 && dfx_round_off(X)) return;
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);
     bool need = false;
@@ -341,7 +384,7 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
 // to the host as "hard".
 __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
     const DfParParams &P = X.P;
-    if (X.round > 0 && !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (X.round > 0 && dfx_round_off(X)) return;
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned c_from = X.round ? (unsigned)X.ctl[s] : 0u;
@@ -355,10 +398,13 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
         int v[6];
         dfx_load6(st, X.npad, v);
         if (v[1] < 0) break;  // the stream ended before this chunk
-        if (dfx_same6(v, truth)) { chunks++; dfx_load6(st + (size_t)6 * X.npad, X.npad, truth); continue; }
         const int *fx = X.fx + (size_t)c * 13 * X.npad + s;
         const int fst = fx[0];   // 0: k_dfx_fix did not run; < 0: it gave up after -fst intervals; else intervals << 1 | merged
-        if (fst > 0) {
+        // (a chunk that started from the true state but that k_dfx_fix ran all the same — the chunk before it was run again to its end without
+        // merging, so its RECORDED end state, where k_dfx_fix started this one from, was not the true one — has the bytes of that run over
+        // its first intervals: not final)
+        if (dfx_same6(v, truth) && fst == 0) { chunks++; dfx_load6(st + (size_t)6 * X.npad, X.npad, truth); continue; }
+        if (fst > 0 && !dfx_same6(v, truth)) {
             int w[6];
             dfx_load6(fx + (size_t)X.npad, X.npad, w);
             if (dfx_same6(w, truth)) { chunks++; dfx_load6(fst & 1 ? st + (size_t)6 * X.npad : fx + (size_t)7 * X.npad, X.npad, truth); continue; }
@@ -433,9 +479,9 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
     // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
-    // into many chunks per stream, all of it again when it is cut into few (a large batch: none there).  One re-speculation covers the
-    // usual case (silence in front of the signal); streams that need more are "hard" and go to the lane-per-stream encoder.
-    unsigned rounds = nchunk >= 16 ? 2 : 1;
+    // into many chunks per stream, all of it again when it is cut into few (a large batch: none there).  Every passage of silence can cost
+    // two (into it, out of it); streams that need more, or fail every few chunks, are "hard" and go to the lane-per-stream encoder.
+    unsigned rounds = nchunk >= 16 ? 4 : 1;
     if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
     const unsigned npad = (unsigned)round_up(n, 64);
     // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~80 MB of them
@@ -470,7 +516,21 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);
     X.enc_out = out; X.ooff = d_ooff;
     if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    // The probe: one guess per stream is tried first, at the stream's start (0.3 ms of a lane per stream, one look at the outcome).  Where
+    // more than one in sixteen misses, or the streams start in silence (whatever follows it will be in another class), the batch is declined
+    // and runs the older schedule: a failed speculation costs rounds of a whole chunk lane's time each (and a large batch, cut into few chunks
+    // per stream, a whole step for a gain of a quarter).  What the probe cannot see — silence or noise later in the streams — costs rounds.
+    X.probe = getenv("AUKIT_DFX_NOPROBE") ? 0u : 1u;
     hipLaunchKernelGGL(k_dfx_prologue, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
+    if (X.probe) {
+        unsigned h[16] = {};
+        AUKIT_HIP_CHECK(hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (getenv("AUKIT_DFPWM_STATS")) fprintf(stderr, "[dfpwm spec] probe: of %u streams, %u guesses missed, %u start in silence\n", n, h[14], h[15]);
+        if ((uint64_t)(h[14] + h[15]) * 16 > n) return AUKIT_OK;   // not taken: the caller runs the older schedule (on the config-4 signal one guess
+                                                                      // in a thousand misses; on noise one in five at a stream's start, three in four later)
+        if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    }
     if ((rc = dfpwm_strength_scan(ctx, P))) return rc;
     if (!ctx->dfx_attr_set) {
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -505,14 +565,18 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     if (getenv("AUKIT_DFPWM_STATS"))
         fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u, %u rounds): %u chunks verified; %u chunks run again by k_dfx_fix (%u checkpoint intervals); %u stream rounds re-speculated (flags %u %u %u %u %u %u); %u hard streams\n",
                 n, nchunk, bpc, (unsigned long long)W, Wd, G, rounds, h[8], h[11], h[9], h[10], h[0], h[1], h[2], h[3], h[4], h[5], h[13]);
-    const unsigned m = h[13];
+    std::vector<unsigned> hs;
+    if (h[13] || h[10]) {   // something was given up on or speculated again: who is not done?
+        std::vector<int> cf(n);
+        AUKIT_HIP_CHECK(hipMemcpy(cf.data(), X.ctl, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < n; s++) if (cf[s] != (int)nchunk) hs.push_back(s);
+        ctx->counters[AUKIT_COUNTER_DFPWM_HARD] = hs.size();
+    }
+    const unsigned m = (unsigned)hs.size();
     if (m) {
         // Hard streams — the encoder changes its class every few chunks (noise) or more often than there are rounds: the schedule with one
         // encoder lane per stream does not care.  Their bytes are gathered into a batch of their own, transcoded by
         // aukit_dfpwm_transcode_mono with this schedule switched off, and scattered to their places.
-        std::vector<unsigned> hs(m);
-        AUKIT_HIP_CHECK(hipMemcpy(hs.data(), X.hard, (size_t)m * 4, hipMemcpyDeviceToHost));
-        std::sort(hs.begin(), hs.end());
         std::vector<uint64_t> sub_off(m + 1, 0), tab(3 * (size_t)m);
         for (unsigned i = 0; i < m; i++) {
             const uint64_t len = in->off[hs[i] + 1] - in->off[hs[i]];

@@ -208,30 +208,29 @@ static int compact(aukit_stream *h) {
     (void)mc;
     uint64_t outs = 0;
     for (uint64_t m = 0; m < shift; m++) outs += h->ck->lens[m];
-    if (h->desc.codec == AUKIT_CODEC_MDFPWM) {
-        int st[12];
-        const int src = mdfpwm_state_after(h->ctx, h->dbuf + R.hdr, shift, h->df_state, h->sb_bytes > 0, st);
-        if (src) return src;
-        for (int i = 0; i < 12; i++) h->df_state[i] = st[i];
-    }
-    if (h->desc.codec == AUKIT_CODEC_DFPWM) {   // the decoder's state behind the `shift` dropped calls, from the state in front of this buffer
-        int st[6];
-        const int src = dfpwm_state_after(h->ctx, h->dbuf, shift, R.call_bytes, h->df_state, h->sb_bytes > 0, st);
-        if (src) return src;
-        for (int i = 0; i < 6; i++) h->df_state[i] = st[i];
-    }
+    // Nothing below may fail the iterator call: the chunk it is part of HAS been delivered.  Whatever goes wrong — the state walk, the
+    // allocation, a copy — the handle keeps its prefix (correct, only bigger) and tries again behind a later chunk; the state in front
+    // of the buffer and the buffer itself change together, at the end.
+    int st_md[12] = {}, st_df[6] = {};
+    if (h->desc.codec == AUKIT_CODEC_MDFPWM && mdfpwm_state_after(h->ctx, h->dbuf + R.hdr, shift, h->df_state, h->sb_bytes > 0, st_md)) return AUKIT_OK;
+    // (DFPWM: the decoder's state behind the `shift` dropped calls, from the state in front of this buffer)
+    if (h->desc.codec == AUKIT_CODEC_DFPWM && dfpwm_state_after(h->ctx, h->dbuf, shift, R.call_bytes, h->df_state, h->sb_bytes > 0, st_df)) return AUKIT_OK;
     // the rest moves to the front of a buffer sized for it: memory follows the stream instead of growing with it
     const size_t rest = (size_t)(h->fed - drop);
     const size_t cap = std::max<size_t>(rest + rest / 2 + 4096, 1 << 16);
     uint8_t *nb = nullptr;
-    if (hipMalloc((void **)&nb, cap + 64) != hipSuccess) { (void)hipGetLastError(); return AUKIT_OK; }   // no memory for the move: keep the prefix (correct, only bigger)
-    if (rest) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream));
-    if (dev_hdr && R.hdr) AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->dbuf, (size_t)R.hdr, hipMemcpyDeviceToDevice, h->ctx->stream));   // the metadata blocks stay in front (the bytes just copied there are dropped frames')
+    if (hipMalloc((void **)&nb, cap + 64) != hipSuccess) { (void)hipGetLastError(); return AUKIT_OK; }
+    bool ok = true;
+    if (rest) ok = ok && hipMemcpyAsync(nb, h->dbuf + drop, rest, hipMemcpyDeviceToDevice, h->ctx->stream) == hipSuccess;
+    if (dev_hdr && R.hdr) ok = ok && hipMemcpyAsync(nb, h->dbuf, (size_t)R.hdr, hipMemcpyDeviceToDevice, h->ctx->stream) == hipSuccess;   // the metadata blocks stay in front (the bytes just copied there are dropped frames')
     if (h->desc.codec == AUKIT_CODEC_MSADPCM && h->desc.channels == 1 && rest >= 7)   // Q9: the header every mono block is read from is the STREAM's first (no block reads its own)
-        AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream));
+        ok = ok && hipMemcpyAsync(nb, h->head7, 7, hipMemcpyHostToDevice, h->ctx->stream) == hipSuccess;
     if (!dev_hdr && R.hdr && rest >= R.hdr)   // (the bytes copied to the front are the last of the dropped frames: the file header takes their place)
-        AUKIT_HIP_CHECK(hipMemcpyAsync(nb, h->head16, R.hdr, hipMemcpyHostToDevice, h->ctx->stream));
-    AUKIT_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+        ok = ok && hipMemcpyAsync(nb, h->head16, R.hdr, hipMemcpyHostToDevice, h->ctx->stream) == hipSuccess;
+    ok = hipStreamSynchronize(h->ctx->stream) == hipSuccess && ok;
+    if (!ok) { (void)hipGetLastError(); (void)hipFree(nb); return AUKIT_OK; }
+    if (h->desc.codec == AUKIT_CODEC_MDFPWM) for (int i = 0; i < 12; i++) h->df_state[i] = st_md[i];
+    if (h->desc.codec == AUKIT_CODEC_DFPWM) for (int i = 0; i < 6; i++) h->df_state[i] = st_df[i];
     (void)hipFree(h->dbuf);
     h->dbuf = nb; h->dcap = cap;
     h->fed -= drop;
@@ -297,7 +296,7 @@ int aukit_stream_finish(aukit_stream *h) {
 // AUKIT_STREAM_NEED_INPUT — nothing is decided yet: feed more or finish; AUKIT_STREAM_END — the iterator has returned nil.  Where the
 // reference's iterator RAISES instead of returning nil (end of data inside a prefill, a malformed block) the call that would have raised
 // returns AUKIT_E_LUA with the reference's message.
-int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state) {
+int aukit_stream_next(aukit_stream *h, double *dst, uint64_t dst_elems, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state) {
     if (!h || !len || !state) return fail(AUKIT_E_ARG, "null argument");
     AUKIT_HIP_CHECK(hipSetDevice(h->ctx->device));
     *len = 0;
@@ -329,6 +328,10 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     if (channels) *channels = C;
     if (pos) *pos = h->ck->pos[k];
     if (n > cap) { *len = n; return fail(AUKIT_E_ARG, "chunk of %u samples does not fit the %u offered", n, cap); }
+    if ((uint64_t)C * cap > dst_elems) {   // channel c goes to dst + c * cap: a stream of more channels than the caller sized its buffer for is refused, not written past it
+        *len = n;
+        return fail(AUKIT_E_ARG, "%d channels of %u samples need %llu elements at dst, %llu offered", C, cap, (unsigned long long)C * cap, (unsigned long long)dst_elems);
+    }
     if (n && !dst) return fail(AUKIT_E_ARG, "null argument");
     const size_t esz = dtype_size(h->out->dtype);
     uint64_t before = 0;   // samples per channel of this decode's chunks in front of chunk k
@@ -349,7 +352,7 @@ int aukit_stream_next(aukit_stream *h, double *dst, uint32_t cap, uint32_t *len,
     *state = AUKIT_STREAM_CHUNK;
     h->delivered++;
     h->delivered_samples += n;
-    if (!h->finished) return compact(h);
+    if (!h->finished) (void)compact(h);   // (never the call's status: the chunk is out)
     return AUKIT_OK;
 }
 

@@ -76,7 +76,7 @@ int aukit_chunks_get(const aukit_chunks *, uint32_t *nchunks, uint32_t *lens, do
 typedef struct aukit_stream aukit_stream;
 int aukit_stream_open(aukit_ctx *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_stream **out);
 int aukit_stream_feed(aukit_stream *, const uint8_t *bytes, uint64_t n); int aukit_stream_finish(aukit_stream *);
-int aukit_stream_next(aukit_stream *, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
+int aukit_stream_next(aukit_stream *, double *dst, uint64_t dst_elems, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
 int aukit_stream_length(aukit_stream *, double *seconds); void aukit_stream_close(aukit_stream *);
 ]]
 
@@ -552,14 +552,22 @@ local function streamer_fn(d, fn, first, mono, dtype)
     local h = ffi.gc(hp[0], C.aukit_stream_close)
     local function feed(s) check(C.aukit_stream_feed(h, ffi.cast("const uint8_t*", s), #s)) end
     feed(first)
-    local buf = ffi.new("double[?]", CHUNK_CAP * 8)
+    local buf_ch = 2
+    local buf = ffi.new("double[?]", CHUNK_CAP * buf_ch)
     local len, ch, st, pos = ffi.new("uint32_t[1]"), ffi.new("int32_t[1]"), ffi.new("int32_t[1]"), ffi.new("double[1]")
     local done, ended = false, false
     local length = ffi.new("double[1]")
     check(C.aukit_stream_length(h, length))
     return function()
         while not ended do
-            check(C.aukit_stream_next(h, buf, CHUNK_CAP, len, ch, pos, st))
+            local rc = C.aukit_stream_next(h, buf, CHUNK_CAP * buf_ch, CHUNK_CAP, len, ch, pos, st)
+            if rc == -1 and ch[0] > buf_ch and len[0] <= CHUNK_CAP then
+                -- more channels than the buffer was sized for (the library refuses before it writes; the chunk is still there): grow, ask again
+                buf_ch = ch[0]
+                buf = ffi.new("double[?]", CHUNK_CAP * buf_ch)
+                rc = C.aukit_stream_next(h, buf, CHUNK_CAP * buf_ch, CHUNK_CAP, len, ch, pos, st)
+            end
+            check(rc)
             if st[0] == 0 then      -- AUKIT_STREAM_CHUNK
                 local chunk = {}
                 for c = 1, ch[0] do

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AUKIT_ABI_VERSION 1
+#define AUKIT_ABI_VERSION 2   /* 2: aukit_stream_next takes the capacity of dst */
 #define AUKIT_MAX_CHANNELS 8          /* block codecs with per-channel state in the descriptor (ADPCM predictors), FLAC, QOA, DFPWM loaders */
 #define AUKIT_MAX_PLANAR_CHANNELS 64  /* PCM, G.711 and QOA (loaders and streams), the Audio methods and effects: planar rows of any count up to this
                                          (the reference takes any channel count, aukit.lua:1049-1171, :2228; round 4) */
@@ -335,9 +335,11 @@ int aukit_stream_open(aukit_ctx *ctx, const aukit_codec_desc *desc, int interp, 
 int aukit_stream_feed(aukit_stream *s, const uint8_t *bytes, uint64_t n);   /* fn() returned a string */
 int aukit_stream_finish(aukit_stream *s);                                    /* fn() returned nil */
 /* the iterator call: state = CHUNK (`*len` samples per channel at dst + c * cap, `*pos` = its second return value), NEED_INPUT, or END (nil).
+ * `dst_elems` = doubles available at dst: a chunk of `*channels` channels needs channels * cap of them — a call that offers fewer is refused
+ * with AUKIT_E_ARG before anything is written (`*len`, `*channels` say what the chunk needs; it stays undelivered: offer more and call again).
  * Where the reference's iterator raises instead of ending, the call returns AUKIT_E_LUA.  A chunk never exceeds 48000 samples per channel
  * except stream.flac / stream.qoa (one coded block resampled: at most 65535 * 48000 / sampleRate). */
-int aukit_stream_next(aukit_stream *s, double *dst, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
+int aukit_stream_next(aukit_stream *s, double *dst, uint64_t dst_elems, uint32_t cap, uint32_t *len, int32_t *channels, double *pos, int32_t *state);
 int aukit_stream_length(aukit_stream *s, double *seconds);                   /* the factory's second return value, for the bytes fed so far */
 /* stream bytes resident on the device, bytes dropped in front of them (stream.pcm / g711 / adpcm / msadpcm drop what delivered calls consumed:
  * austream.lua:19-64 feeds live sources for hours), and the input bytes of every decode so far, summed */

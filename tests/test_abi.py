@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = N.lib()
     missing = [s for s in _declared() if not hasattr(L, s)]
     assert not missing, missing
-    assert L.aukit_abi_version() == 1
+    assert L.aukit_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -111,3 +111,38 @@ def test_qoa_with_many_channels(ctx, oracle, ch):
         a = out.download()[0]
         for c in range(rs.channels):
             assert np.max(np.abs(a[c] - rs.data[c]), initial=0) <= 1e-12, (mono, c)
+
+
+@pytest.mark.parametrize("ch", [10, 16])
+def test_stream_handle_with_many_channels(ctx, oracle, ch):
+    """the reader-function handle (aukit_stream_open / feed / next) on a stream of more channels than a caller would size its buffer
+    for: the library refuses a dst that is too small BEFORE it writes (it used to write channels * cap doubles into a
+    buffer of 8 * cap), the mirror grows its buffer and asks again, and the chunks are the string version's"""
+    import ctypes as C
+    N, B = _mods()
+    raw = _frames(44100 + 500, ch, 44100, 3).astype("<i2").tobytes()
+    desc = B.make_desc(N.CODEC_PCM, ch, 44100, 16, "signed")
+    ref = oracle.stream_pcm(raw, 16, oracle.SIGNED, ch, 44100, False, False, oracle.CUBIC)
+    # the C ABI itself: a buffer for 2 channels is refused, nothing is written, the chunk stays
+    h = B.StreamHandle(ctx, desc, "cubic", False, N.F64, cap=48000)
+    h.feed(raw)
+    h.finish()
+    small = np.full(2 * 48000 + 16, -7.0)
+    ln, nch, st, pos = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_double()
+    rc = N.lib().aukit_stream_next(h._h, small.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(2 * 48000), C.c_uint32(48000), C.byref(ln), C.byref(nch), C.byref(pos), C.byref(st))
+    assert rc == N.E_ARG and nch.value == ch and np.all(small == -7.0)
+    got = []
+    while True:
+        kind, chans, p = h.next()
+        if kind != "chunk":
+            assert kind == "end"
+            break
+        got.append(chans)
+    h.close()
+    assert len(got) == ref.nchunks and all(len(g) == ch for g in got)
+    at = 0
+    for k, g in enumerate(got):
+        n = int(ref.chunk_len[k, 0])
+        for c in range(ch):
+            assert len(g[c]) == n and np.max(np.abs(g[c] - ref.data[c][at:at + n])) <= 1e-12, (k, c)
+        at += n

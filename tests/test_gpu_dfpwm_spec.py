@@ -28,12 +28,13 @@ def _ref(oracle, s):
 
 
 ENVS = ({}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_G": "1"}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_ROUNDS": "1", "AUKIT_DFX_G": "2"}, {"AUKIT_DFX_CHUNKS": "1000", "AUKIT_DFX_MIN_BPC": "1"}, {"AUKIT_DFX_ROUNDS": "1"},
-        {"AUKIT_DFX_WE": "128", "AUKIT_DFX_CHUNKS": "7", "AUKIT_DFX_ROUNDS": "2"}, {"AUKIT_DFX_WPS": "1", "AUKIT_DFX_WE": "1008"})
+        {"AUKIT_DFX_WE": "128", "AUKIT_DFX_CHUNKS": "7", "AUKIT_DFX_ROUNDS": "2", "AUKIT_DFX_NOPROBE": "1"}, {"AUKIT_DFX_WPS": "1", "AUKIT_DFX_WE": "1008"})
 
 
 def _all_schedules(ctx, monkeypatch, bt, want):
     B = _B()
     for env in ENVS:
+        env = dict(env, AUKIT_DFX_NOPROBE="1")   # (the probe would decline the batches with silence and noise in them: here the schedule itself is under test)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
@@ -91,12 +92,17 @@ def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
     want = [_ref(oracle, s) for s in streams]
     _all_schedules(ctx, monkeypatch, bt, want)
     ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    monkeypatch.setenv("AUKIT_DFX_NOPROBE", "1")
     B.dfpwm_transcode_mono(ctx, bt, 2)
+    monkeypatch.delenv("AUKIT_DFX_NOPROBE")
     ctx.sync()
     ctx.set_option(N.OPT_COLLECT_STATS, 0)
     assert ctx.counter(N.COUNTER_DFPWM_CHUNKS) > 0
     assert ctx.counter(N.COUNTER_DFPWM_RESPECULATED) >= 1   # the gated streams left the floor in a class the prologue could not know
     assert ctx.counter(N.COUNTER_DFPWM_HARD) >= 1           # the noise is given up on and goes to the lane-per-stream encoder
+    # by default one guess per stream is tried first (the probe), and on this input the batch is declined: the older schedule, the same bytes
+    got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    assert ctx.last_kernel()[0] != "k_dfx_chunks" and got == want
 
 
 def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):
