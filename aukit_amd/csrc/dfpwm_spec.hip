@@ -164,8 +164,15 @@ __global__ __launch_bounds__(256) void k_dfx_lut(unsigned char *lut) {
 // given up on: the input is noise-like then, the lucky rest would fail a few chunks further on, and every round costs the time of a whole
 // chunk lane however few streams it is for.  (Streams left unfinished this way are hard streams to the host.)
 AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
+    if (__hip_atomic_load(&X.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;   // the probe declined the batch
+    if (X.round == 0) return false;
     return !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
            2 * __hip_atomic_load(&X.flags[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > X.P.n;
+}
+
+// the probe's verdict, on the device (the host hears of it at the end of the call: nothing in between waits for the host)
+__global__ void k_dfx_decide(unsigned *flags, unsigned n) {
+    if ((unsigned long long)(flags[14] + flags[15]) * 16 > n) flags[6] = 1;
 }
 
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
@@ -257,7 +264,7 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
 __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
-    if (X.round > 0 && dfx_round_off(X)) return;
+    if (dfx_round_off(X)) return;
     dfx_lut_to_lds(X.lut, lutu, 256);
     __syncthreads();
     const unsigned char *lutc = lutu + 128 * 257;  // indexed by signed (l, r)
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
 __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
-    if (X.round > 0 && dfx_round_off(X)) return;
+    if (dfx_round_off(X)) return;
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);
     bool need = false;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
 // to the host as "hard".
 __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
     const DfParParams &P = X.P;
-    if (X.round > 0 && dfx_round_off(X)) return;
+    if (dfx_round_off(X)) return;
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned c_from = X.round ? (unsigned)X.ctl[s] : 0u;
@@ -521,17 +528,13 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     // and runs the older schedule: a failed speculation costs rounds of a whole chunk lane's time each (and a large batch, cut into few chunks
     // per stream, a whole step for a gain of a quarter).  What the probe cannot see — silence or noise later in the streams — costs rounds.
     X.probe = getenv("AUKIT_DFX_NOPROBE") ? 0u : 1u;
-    hipLaunchKernelGGL(k_dfx_prologue, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
-    if (X.probe) {
-        unsigned h[16] = {};
-        AUKIT_HIP_CHECK(hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream));
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (getenv("AUKIT_DFPWM_STATS")) fprintf(stderr, "[dfpwm spec] probe: of %u streams, %u guesses missed, %u start in silence\n", n, h[14], h[15]);
-        if ((uint64_t)(h[14] + h[15]) * 16 > n) return AUKIT_OK;   // not taken: the caller runs the older schedule (on the config-4 signal one guess
-                                                                      // in a thousand misses; on noise one in five at a stream's start, three in four later)
-        if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
-    }
+    // (the prologue's 256 lone waves run on the side stream, beside the strength scan: the probe hides behind k_df_blockmaps)
+    hipStream_t side = nullptr;
+    if ((rc = ctx_side_fork(ctx, &side))) return rc;
+    hipLaunchKernelGGL(k_dfx_prologue, dim3((n + 63) / 64), dim3(64), 0, side, X);
+    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n);
     if ((rc = dfpwm_strength_scan(ctx, P))) return rc;
+    if ((rc = ctx_side_join(ctx))) return rc;
     if (!ctx->dfx_attr_set) {
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -563,8 +566,11 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[8]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[11]; ctx->counters[AUKIT_COUNTER_DFPWM_RESPECULATED] = h[10];
     ctx->counters[AUKIT_COUNTER_DFPWM_HARD] = h[13];
     if (getenv("AUKIT_DFPWM_STATS"))
+        fprintf(stderr, "[dfpwm spec] probe: of %u streams, %u guesses missed, %u start in silence%s\n", n, h[14], h[15], h[6] ? ": declined" : "");
+    if (getenv("AUKIT_DFPWM_STATS") && !h[6])
         fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u, %u rounds): %u chunks verified; %u chunks run again by k_dfx_fix (%u checkpoint intervals); %u stream rounds re-speculated (flags %u %u %u %u %u %u); %u hard streams\n",
                 n, nchunk, bpc, (unsigned long long)W, Wd, G, rounds, h[8], h[11], h[9], h[10], h[0], h[1], h[2], h[3], h[4], h[5], h[13]);
+    if (h[6]) return AUKIT_OK;   // declined by the probe (nothing was written): not taken, the caller runs the older schedule
     std::vector<unsigned> hs;
     if (h[13] || h[10]) {   // something was given up on or speculated again: who is not done?
         std::vector<int> cf(n);
