@@ -62,15 +62,31 @@ struct DfxParams {
 };
 
 // ---- output bits: 4 per fed byte, 16 per source dword; whole 8-byte rounds leave as one store
-struct DfsAcc { u64 bits = 0; unsigned pos = 0; unsigned char *o = nullptr; };
+struct DfsAcc { u64 bits = 0, lo = 0; unsigned pos = 0; bool half = false; unsigned char *o = nullptr; };
 typedef unsigned dfs_u32x2u __attribute__((ext_vector_type(2), aligned(1)));  // (unaligned global stores are single instructions on gfx950)
+typedef unsigned dfs_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+// a full round of 64 bits: every second one leaves, with the one before it, as ONE 16-byte store (8-byte stores from 131 072 lanes at their own
+// addresses left the L2 as partial sectors: 6.5 GB written for 1 GB of result, profiles/r05_dfpwm_pmc_write.csv)
+AUKIT_DEV void dfs_round(DfsAcc &a, u64 r) {
+    if (!a.half) { a.lo = r; a.half = true; return; }
+    dfs_u32x4u w; w.x = (unsigned)a.lo; w.y = (unsigned)(a.lo >> 32); w.z = (unsigned)r; w.w = (unsigned)(r >> 32);
+    *reinterpret_cast<dfs_u32x4u *>(a.o) = w;
+    a.o += 16;
+    a.half = false;
+}
+// whatever whole round is held back goes out (chunk ends, checkpoints a run may stop at)
+AUKIT_DEV void dfs_flush(DfsAcc &a) {
+    if (!a.half) return;
+    dfs_u32x2u w; w.x = (unsigned)a.lo; w.y = (unsigned)(a.lo >> 32);
+    *reinterpret_cast<dfs_u32x2u *>(a.o) = w;
+    a.o += 8;
+    a.half = false;
+}
 AUKIT_DEV void dfs_put(DfsAcc &a, unsigned v, unsigned nbits) {
     a.bits |= (u64)v << a.pos;
     a.pos += nbits;
     if (a.pos >= 64) {
-        dfs_u32x2u w; w.x = (unsigned)a.bits; w.y = (unsigned)(a.bits >> 32);
-        *reinterpret_cast<dfs_u32x2u *>(a.o) = w;
-        a.o += 8;
+        dfs_round(a, a.bits);
         a.pos -= 64;
         a.bits = a.pos ? (u64)(v >> (nbits - a.pos)) : 0;
     }
@@ -107,6 +123,7 @@ AUKIT_DEV void dfx_span(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, 
 
 // the stream's last bits: the last byte is padded with samples of value 0 (aukit.lua:1011-1016 hands the encoder whole bytes)
 AUKIT_DEV void dfx_tail(DfsAcc &acc, DfEnc &e) {
+    dfs_flush(acc);
     if (acc.pos & 4) {
         unsigned b4 = 0;
 #pragma unroll
@@ -251,12 +268,13 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
         dfp_pack(d, t);
         t[5] = dfs_pack(e);
         dfx_load6(dfx_ck(X, c, j, s), X.npad, w);
-        if (may_merge && j + 1 >= min_iv && dfx_same6(t, w)) return true;
-        if (j + 1 >= max_iv) { *gave_up = true; return false; }  // (k_dfx_fix before the last round: two runs that have not merged by now are not going to)
+        if (may_merge && j + 1 >= min_iv && dfx_same6(t, w)) { dfs_flush(acc); return true; }
+        if (j + 1 >= max_iv) { dfs_flush(acc); *gave_up = true; return false; }  // (k_dfx_fix before the last round: two runs that have not merged by now are not going to)
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
     intervals++;
     if (f1 == fed) dfx_tail(acc, e);
+    dfs_flush(acc);
     return false;
 }
 
@@ -338,6 +356,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
     if (f1 == fed) dfx_tail(acc, e);
+    dfs_flush(acc);
     dfx_store6(st + (size_t)6 * X.npad, X.npad, d, e);
 }
 
@@ -472,8 +491,6 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     unsigned We = 640, Wd = 64;  // fed bytes: 2560 mono samples of encoder warm-up behind 64 bytes of decoder-only warm-up
     if (const char *e = getenv("AUKIT_DFX_WE")) We = (unsigned)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("AUKIT_DFX_WD")) Wd = (unsigned)std::max(64, atoi(e)) & ~63u;
-    const uint64_t W = (uint64_t)We + Wd;  // a multiple of 64: checkpoint intervals of W / 4 are whole 8-byte output rounds
-    const unsigned nblk_all = (unsigned)((fed_max + W - 1) / W);
     // chunks per stream: enough lanes for `wps` waves on every SIMD, at least three blocks each (the warm-up block is then 1/4 of a lane's work)
     unsigned wps = 2;
     if (const char *e = getenv("AUKIT_DFX_WPS")) wps = (unsigned)std::max(1, atoi(e));
@@ -482,6 +499,11 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     if (const char *e = getenv("AUKIT_DFX_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     unsigned min_bpc = 3;
     if (const char *e = getenv("AUKIT_DFX_MIN_BPC")) min_bpc = (unsigned)std::max(1, atoi(e));
+    // long chunks (a large batch) can afford a longer encoder warm-up: 3840 mono samples, one guess in ~5000 misses instead of one in 500 —
+    // and every miss costs the step the time of a checkpoint interval in k_dfx_fix
+    if (!getenv("AUKIT_DFX_WE") && (fed_max + 703) / 704 >= 16 * (uint64_t)want) We = 960;
+    const uint64_t W = (uint64_t)We + Wd;  // a multiple of 64: checkpoint intervals of W / 4 are whole 8-byte output rounds
+    const unsigned nblk_all = (unsigned)((fed_max + W - 1) / W);
     const unsigned bpc = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, min_bpc);
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
@@ -491,9 +513,9 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     unsigned rounds = nchunk >= 16 ? 4 : 1;
     if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
     const unsigned npad = (unsigned)round_up(n, 64);
-    // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~80 MB of them
+    // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~320 MB of them
     unsigned G = (unsigned)W / 4;
-    while (G < W && (uint64_t)nchunk * (bpc * (W / G) - 1) * 24 * npad > (80ull << 20)) G *= 2;
+    while (G < W && (uint64_t)nchunk * (bpc * (W / G) - 1) * 24 * npad > (320ull << 20)) G *= 2;
     if (const char *e = getenv("AUKIT_DFX_G")) { const unsigned k = (unsigned)std::max(1, atoi(e)); if (k <= 4 && (k & (k - 1)) == 0) G = (unsigned)W / k; }
     const unsigned nck = bpc * (unsigned)(W / G) - 1;
     size_t o = 0;
