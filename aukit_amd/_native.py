@@ -27,7 +27,7 @@ FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center"
 MAX_CH = 8
 OPT_EXACT_MATH, OPT_STORE_X4, OPT_COLLECT_STATS, OPT_DFPWM_SPECULATE = 0, 1, 2, 3
 COUNTER_DFPWM_CHUNKS, COUNTER_DFPWM_CHUNKS_REDONE, COUNTER_FLAC_FUSED, COUNTER_TIER1_ERR_NANO, COUNTER_TIER1_OUTPUTS = 0, 1, 2, 3, 4
-COUNTER_DFPWM_RESPECULATED, COUNTER_DFPWM_HARD = 5, 6
+COUNTER_DFPWM_RESPECULATED, COUNTER_DFPWM_HARD, COUNTER_RECURRENCE_F32 = 5, 6, 7
 WAVE_NONE, WAVE_SINE, WAVE_TRIANGLE, WAVE_SAWTOOTH, WAVE_SQUARE = 0, 1, 2, 3, 4
 PACK_TRUNC, PACK_FLOOR, PACK_STRICT = 0, 1, 2
 STREAM_CHUNK, STREAM_NEED_INPUT, STREAM_END = 0, 1, 2

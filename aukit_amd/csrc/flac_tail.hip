@@ -721,6 +721,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     const size_t ldsb = lds;
  const dim3 grid((unsigned)((rows / (size_t)NWh) * (size_t)P.segs));
     const bool r32 = !highpass && (1.0 - coef) <= 0.5 && (1.0 - coef) >= 0 && !getenv("AUKIT_RS_F64");   // the recurrence in f32 (k_rs_onepole<..., R32>)
+    ctx->counters[AUKIT_COUNTER_RECURRENCE_F32] = r32 ? 1 : 0;
 #define AUKIT_RSO1(I, H, Tb, S)                                                                                                                            \
     do {                                                                                                                                                     \
         if (!H && r32) {                                                                                                                                     \
@@ -807,6 +808,7 @@ static bool rs_onepole_jobs_launch(aukit_ctx *ctx, const void *rows, bool rows_i
     // short ones (a FLAC frame: nine tiles): a workgroup takes several in turn and pays the set-up in front of its tile loop once
     const dim3 grid((unsigned)((long_jobs || NWh > 1) ? njobs : std::min<size_t>(njobs, (size_t)ctx->num_cus * 64)));
     const bool r32 = (1.0 - lp_alpha) <= 0.5 && (1.0 - lp_alpha) >= 0 && !getenv("AUKIT_RS_F64");   // the recurrence in f32 (k_rs_onepole<..., R32>)
+    ctx->counters[AUKIT_COUNTER_RECURRENCE_F32] = r32 ? 1 : 0;
 #define AUKIT_RSJ(I, Tb, S)                                                                                                                           \
     do {                                                                                                                                              \
         if (r32) {                                                                                                                                    \

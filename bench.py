@@ -384,7 +384,10 @@ class ImaPipeline(Workload):
             B.effect(ctx, self.out, "lowpass", 11025.0)
             self.out.device_ptr()   # (nothing may stay owed on the rows when the step ends: a no-op for one channel, the filter is paid by the call above)
         self.step = step
-        self.arith = "i32 decode + " + ("f32 interpolation, f64 recurrence" if args.dtype == "f32" else "f64 reference-order resample and filter")
+        # (the recurrence's arithmetic is what the library reports of the launch it made — AUKIT_COUNTER_RECURRENCE_F32 — not a literal: round 4's last
+        # commit moved it to f32 for slopes <= 1/2 and these labels went on saying f64)
+        self.arith = (lambda ctx, N: "i32 decode + f32 interpolation, " + ("f32" if ctx.counter(N.COUNTER_RECURRENCE_F32) else "f64") + " recurrence and scan") if args.dtype == "f32" \
+            else "i32 decode + f64 reference-order resample and filter"
         self.desc = (f"{args.streams}x IMA-ADPCM 22.05kHz mono 220x512B in WAV blocks ({self.distinct} distinct encoder-made streams, cycled) -> aukit.wav:resample(48000,'cubic') "
                      f"-> effects.lowpass(11025), {args.dtype} store (config 3b)")
         return self
@@ -453,7 +456,8 @@ class QoaStream(Workload):
         self.out = B.AudioBatch(ctx)
         self.dtype = N.F32 if args.dtype == "f32" else N.F64
         self.step = lambda: B.stream_decode(ctx, self.bt, self.d, args.interp, dtype=self.dtype, out=self.out)
-        self.arith = "i32 LMS decode + " + ("f32 interpolation, f64 recurrence" if args.dtype == "f32" else "f64 reference-order tail")
+        self.arith = (lambda ctx, N: "i32 LMS decode + f32 interpolation, " + ("f32" if ctx.counter(N.COUNTER_RECURRENCE_F32) else "f64") + " recurrence and scan") if args.dtype == "f32" \
+            else "i32 LMS decode + f64 reference-order tail"
         self.desc = (f"{args.streams}x QOA 44.1kHz stereo 10s ({self.distinct} distinct encoder-made files, cycled) -> stream.qoa {args.interp}, all iterator calls, "
                      f"{args.dtype} store; unit = out-samples of both channels")
         return self
@@ -865,7 +869,7 @@ def main(argv=None):
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         headline = args.workload == "pcm16_cubic"
         if getattr(wl, "arith", None):
-            arith = wl.arith
+            arith = wl.arith(ctx, N) if callable(wl.arith) else wl.arith
         elif name.startswith("k_fast"):
             arith = "f32"
         elif "dfpwm" in name or name.startswith("k_df"):

@@ -158,6 +158,8 @@ typedef enum {
     AUKIT_COUNTER_TIER1_OUTPUTS = 4,       /* ... and how many outputs it compared */
     AUKIT_COUNTER_DFPWM_RESPECULATED = 5,  /* the chunk-speculative transcoder / encoder (dfpwm_spec.hip): how many times a stream's remaining chunks were speculated
                                               again because its true encoder had changed its class (a clamp of the strength on the way) */
+    AUKIT_COUNTER_RECURRENCE_F32 = 7,      /* the most recent one-pole filter launch (effects.lowpass / highpass with an owed resample, the stream.qoa / stream.flac tails:
+                                              k_rs_onepole) ran its recurrence and scan in f32 (1) or in fp64 (0) — set with or without AUKIT_OPT_COLLECT_STATS */
     AUKIT_COUNTER_DFPWM_HARD = 6,          /* ... and how many streams it gave up on and left to the schedule with one encoder lane per stream (noise-like input) */
     AUKIT_COUNTER_FLAC_FUSED = 2           /* 1: the most recent FLAC decode was served by the fused decoder (flac_fused.hip); 0: a frame it declines was on
                                               the chain (or the batch is deeper than 24 bits) and the two-kernel decoder ran.  Set without COLLECT_STATS. */

@@ -123,6 +123,28 @@ def test_config_3_full_batch(ctx, oracle):
         assert np.array_equal(rows[c], oracle.stream_adpcm(base[c], 512, 1, 22050, False, oracle.CUBIC).data[0])
 
 
+@pytest.mark.parametrize("max_index", [15, 88])
+def test_config_3b_full_batch(ctx, oracle, max_index):
+    """BASELINE config 3 as it is worded — 4096 x 220 IMA blocks in WAV -> aukit.wav -> :resample(48000, "cubic") -> effects.lowpass(a, 11025)
+    (aukit.lua:1509-1548, :653-675, :3586-3598) — at full size: the loader's int16 rows with the resample owed, paid inside the filter's one launch
+    (k_rs_onepole, whose recurrence and scan run in f32 at this slope since round 4's last commit).  8 classes of identical rows, every class
+    against the oracle: <= 1e-6 RMS on the [-1, 1] scale and a bound on the LARGEST error too.  Both corpora of SURVEY 8d: header
+    step indices <= 15 (aukit.wav's masked index agrees with stream.adpcm's) and the full range (Q8: the loader masks with 0x0F by design)."""
+    B, N = _B(), _N()
+    n = max(K, int(4096 * SCALE) // K * K)
+    base = [oracle.gen_ima(pcm16(1016 * 220, 22050, 3, i), 1, 512, max_index) for i in range(K)]
+    bt = B.Batch.upload(ctx, [base[i % K] for i in range(n)])
+    a = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), 48000, "cubic", dtype=N.F32)
+    assert ctx.last_kernel()[0] == "(resample deferred)"
+    B.effect(ctx, a, "lowpass", 11025.0)
+    assert ctx.last_kernel()[0] == "k_rs_onepole<lowpass>" and ctx.counter(N.COUNTER_RECURRENCE_F32) == 1
+    rows = _row_classes(a, n, 486574, K)   # floor(223520 * 48000 / 22050)
+    for c in range(K):
+        ref = oracle.fx_lowpass(oracle.resample(oracle.wav_adpcm(base[c], 512, 1, 22050), 48000, oracle.CUBIC), 11025.0).data[0]
+        err = rows[c].astype(np.float64) - ref
+        assert np.sqrt(np.mean(err * err)) <= 1e-6 and np.max(np.abs(err)) <= 1e-6, (c, np.sqrt(np.mean(err * err)), np.max(np.abs(err)))
+
+
 def test_config_4_full_batch(ctx, oracle):
     B, N = _B(), _N()
     n = max(K, int(16384 * SCALE) // K * K)
