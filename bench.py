@@ -151,6 +151,21 @@ class Workload:
     def task_bytes(self):
         return None
 
+    # ---- the distribution leg (--distribute 1, SURVEY 8e's second curve): workloads that have one define
+    #   dist_whole(torch, ctx, B, args, world) -> the Batch of EVERY rank's shard, resident on rank 0 (the same synthetic content `world` times);
+    #   dist_pass(ctx, B, N, args, mine)       -> runs one pass on this rank's scattered shard; returns ("audio" | "batch", the output object);
+    #   dist_units(kind, got)                  -> the metric's units in what rank 0 gathered.
+    dist_whole = None
+
+
+def _repeat_batch(torch, ctx, B, x, offs, world):
+    """the byte tensor `x` (streams at offsets `offs`) `world` times back to back as one Batch on this rank"""
+    x = x.view(torch.uint8)
+    big = x.repeat(world) if world > 1 else x
+    total = int(offs[-1])
+    all_offs = [k * total + int(o) for k in range(world) for o in offs[:-1]] + [world * total]
+    return B.Batch.wrap(ctx, big.data_ptr(), all_offs, keep=big)
+
 
 class Pcm16Cubic(Workload):
     name, unit = "pcm16_cubic", "Msamples/s"
@@ -182,6 +197,15 @@ class Pcm16Cubic(Workload):
         mode = O.CUBIC if self.interp == "cubic" else O.LINEAR
         one = lambda i: len(O.resample(O.pcm(distinct[i % len(distinct)], 16, O.SIGNED, 1, SRC_RATE), DST_RATE, mode).data[0])
         return one, f"{self.n_samples} samples each, {len(distinct)} distinct ones cycled"
+
+
+    def dist_whole(self, torch, ctx, B, args, world):
+        return _repeat_batch(torch, ctx, B, self.x, [i * self.n_samples * 2 for i in range(args.streams + 1)], world)
+
+    def dist_pass(self, ctx, B, N, args, mine):
+        self._dist_out = getattr(self, "_dist_out", None) or B.AudioBatch(ctx)
+        B.decode_resample(ctx, mine, self.d, DST_RATE, args.interp, dtype=self.dtype, out=self._dist_out)
+        return "audio", self._dist_out
 
 
 class Pcm16Stereo(Workload):
@@ -536,6 +560,16 @@ class DfpwmTranscode(Workload):
         return {"dfpwm_chunks": ctx.counter(N.COUNTER_DFPWM_CHUNKS), "dfpwm_chunks_redone": ctx.counter(N.COUNTER_DFPWM_CHUNKS_REDONE)}
 
 
+    def dist_whole(self, torch, ctx, B, args, world):
+        nb = self.frames * 2 // 8
+        return _repeat_batch(torch, ctx, B, self.x, [i * nb for i in range(args.streams + 1)], world)
+
+    def dist_pass(self, ctx, B, N, args, mine):
+        self._dist_out = getattr(self, "_dist_out", None) or B.Batch(ctx, __import__("ctypes").c_void_p())
+        B.dfpwm_transcode_mono(ctx, mine, 2, out=self._dist_out)
+        return "batch", self._dist_out   # the re-encoded DFPWM bytes travel back (shard.gather_batch)
+
+
 class FlacPipeline(Workload):
     name, unit = "flac_pipeline", "Msamples/s"
 
@@ -581,6 +615,19 @@ class FlacPipeline(Workload):
 
     def task_bytes(self):
         return int(self.x.numel()) + self.out_samples() * (4 if self.dtype == 1 else 8)
+
+
+    def dist_whole(self, torch, ctx, B, args, world):
+        return _repeat_batch(torch, ctx, B, self.x, [i * self.flac_bytes for i in range(args.streams + 1)], world)
+
+    def dist_pass(self, ctx, B, N, args, mine):
+        if getattr(self, "_dist_a", None) is None:
+            self._dist_a, self._dist_m = B.AudioBatch(ctx), B.AudioBatch(ctx)
+        B.decode_resample(ctx, mine, self.d, DST_RATE, "cubic", dtype=self.dtype, out=self._dist_a)
+        B.effect(ctx, self._dist_a, "highpass", 20.0)
+        B.effect(ctx, self._dist_a, "normalize", 0.8)
+        B.mono(ctx, self._dist_a, out=self._dist_m)
+        return "audio", self._dist_m   # the mono rows travel back (shard.gather_audio pays whatever is still owed on them)
 
 
 class SelftestNull(Workload):
@@ -634,21 +681,16 @@ XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (the brief's figure): ever
 def time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync):
     """SURVEY 8e's second curve: the job's input starts on rank 0 (all `world` shards back to back in its HBM), is scattered device to device
     (aukit_amd.shard.scatter_batch: RCCL point-to-point, each peer's share over its own xGMI link, received straight into the tensor
-    the library then wraps with aukit_batch_wrap_device), every rank runs ONE pass, and the output rows are gathered to rank 0
-    (shard.gather_audio: sent straight from aukit_audio_device_ptr).  Returns the three times (max over ranks) and the inclusive rate."""
+    the library then wraps with aukit_batch_wrap_device), every rank runs ONE pass of the workload's chain (Workload.dist_pass), and the outputs
+    are gathered to rank 0 — rows (shard.gather_audio: sent straight from aukit_audio_device_ptr; config T, config 5's mono rows) or
+    re-encoded bytes (shard.gather_batch; config 4).  Returns the three times (max over ranks) and the inclusive rate."""
     from aukit_amd import shard
     own_group = False
     if not dist.is_initialized():  # N = 1: a one-rank group, so that the same code runs (its scatter / gather are views, nothing moves)
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
         own_group = True
     try:
-        whole = None
-        if rank == 0:
-            x = wl.x.view(torch.uint8)
-            big = x.repeat(world) if world > 1 else x  # every rank's shard (the same synthetic content), resident on rank 0
-            n = args.streams * world
-            whole = B.Batch.wrap(ctx, big.data_ptr(), [i * wl.n_samples * 2 for i in range(n + 1)], keep=big)
-        out = B.AudioBatch(ctx)
+        whole = wl.dist_whole(torch, ctx, B, args, world) if rank == 0 else None
         times = []
         def agreed(err):
             # every rank learns whether ANY rank failed its local stage before the next collective is entered: a rank that raised on its own
@@ -657,37 +699,39 @@ def time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
                 raise RuntimeError(f"distribution pass failed on rank {rank}: {err}" if err is not None else "distribution pass failed on another rank")
+        share_in = nbytes_out = nunits = 0
         for it in range(2):  # the first round pays RCCL's connection set-up: report the second
             sync(); dist.barrier(); sync()
             t0 = time.perf_counter()
             mine, (lo, hi) = shard.scatter_batch(ctx, whole, src=0, device=dev)
             sync(); t1 = time.perf_counter()
-            err = None
+            err, kind, out = None, "audio", None
             try:
-                B.decode_resample(ctx, mine, wl.d, DST_RATE, args.interp, dtype=wl.dtype, out=out)
+                kind, out = wl.dist_pass(ctx, B, N, args, mine)
                 ctx.sync()
             except Exception as e:  # noqa: BLE001 — reported through agreed()
                 err = f"{type(e).__name__}: {e}"
             sync(); t2 = time.perf_counter()
             agreed(err)   # (outside the timed stages' meaning: a 4-byte all-reduce, counted in the gather time)
-            got = shard.gather_audio(out, dst=0, device=dev)
+            got = shard.gather_audio(out, dst=0, device=dev) if kind == "audio" else shard.gather_batch(out, dst=0, device=dev)
             sync(); dist.barrier(); sync()
             t3 = time.perf_counter()
             times.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
-            nbytes_out = sum(int(t.numel()) for t, _ in got) if got is not None else 0
-            nsamp = sum(int(m["lens"].sum()) for _, m in got) if got is not None else 0
+            share_in = int(mine.info()[1])
+            if got is not None:
+                nbytes_out = sum(int(t.numel()) for t, _ in got)
+                nunits = sum(int(m["lens"].sum()) * int(m.get("channels", 1)) for _, m in got) if kind == "audio" else 8 * sum(int(sum(sz)) for _, sz in got)
             del got, mine
         tt = torch.tensor(times[-1], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sc, co, ga, tot = [float(v) for v in tt.tolist()]
         if rank != 0:
             return None
-        share_in = args.streams * wl.n_samples * 2
         share_out = nbytes_out / max(world, 1)
-        return {"scatter_s": sc, "compute_s": co, "gather_s": ga, "total_s": tot, "value_inclusive": nsamp / tot / 1e6, "unit": "Msamples/s",
+        return {"scatter_s": sc, "compute_s": co, "gather_s": ga, "total_s": tot, "value_inclusive": nunits / tot / 1e6, "unit": "Msamples/s",
                 "bytes_scattered_per_peer": share_in, "bytes_gathered_per_peer": int(share_out), "peers": world - 1,
                 "xgmi_link_GBs": XGMI_LINK_GBS, "link_bound_s": ((share_in + share_out) / (XGMI_LINK_GBS * 1e9)) if world > 1 else 0.0,
-                "note": "input on rank 0 -> RCCL scatter (HBM to HBM) -> one pass per rank -> gather of the output rows to rank 0; max over ranks; "
+                "note": "input on rank 0 -> RCCL scatter (HBM to HBM) -> one pass per rank -> gather of the outputs (rows, or re-encoded bytes) to rank 0; max over ranks; "
                         "xGMI-bound by construction (SURVEY 8e), reported beside `value`, never as it"}
     finally:
         if own_group:
@@ -854,7 +898,7 @@ def main(argv=None):
         ctx.set_option(N.OPT_EXACT_MATH, args.exact_math)
 
     distribute = None
-    if args.distribute and not selftest and args.workload == "pcm16_cubic":
+    if args.distribute and not selftest and wl.dist_whole is not None:
         try:
             distribute = time_distribution(torch, dist, dev, ctx, wl, args, world, rank, N, B, sync)
         except Exception as e:  # the distribution figure is optional: never lose the line to it

@@ -219,3 +219,62 @@ def test_partition_numpy_fallback_agrees_with_the_library():
         world = int(rng.integers(1, 10))
         sizes = rng.integers(0, 9000, n) * (rng.integers(0, 2, n) if trial % 4 == 0 else 1)
         assert _partition_numpy(sizes, world) == B.partition(sizes, world), (list(sizes), world)
+
+
+def _worker_flows(rank, world, port, q):
+    """BASELINE configs 4 and 5 as 8-GPU jobs: rank 0 holds the byte batch, shard.scatter_streams cuts it by input bytes, every rank
+    runs the whole chain on its shard (stand-in for the GPU: the oracle), the outputs — re-encoded DFPWM bytes (shard.gather_batch's transport:
+    sizes travel as a table) and mono f32 rows — come back in stream order.  gather(process(scatter(batch))) == process(batch), also with a rank
+    whose shard is empty (world 3, two streams)."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aukit_amd import shard
+    from oracle import oracle as O
+    from tests.util import pcm16, signal
+    nst = 5 if world < 3 else 2
+
+    def transcode(s):   # config 4: a = aukit.dfpwm(d, 2, 48000); m = a:mono(); out = m:dfpwm()
+        return O.audio_dfpwm(O.mono(O.dfpwm(s, 2, 48000)), True)
+
+    def pipeline(s):    # config 5: aukit.flac(d):resample(48000, "cubic") -> highpass(20) -> normalize(0.8) -> mono
+        a = O.fx_normalize(O.fx_highpass(O.resample(O.flac(s), 48000, O.CUBIC), 20.0), 0.8)
+        return O.mono(a).data[0].astype(np.float32).tobytes()
+
+    ok = True
+    for make, work in ((lambda i: O.dfpwm_encode(np.round(signal(16 * (700 + 310 * i), 48000, 4, i) * 100)), transcode),
+                       (lambda i: O.gen_flac(np.stack([pcm16(3000 + 900 * i, 44100, 5, 2 * i + c) for c in range(2)], 1).astype(np.int64).ravel(), 2, 16, 44100, 1152), pipeline)):
+        streams = [make(i) for i in range(nst)] if rank == 0 else None
+        mine, (lo, hi) = shard.scatter_streams(streams, src=0)
+        if world == 3:
+            ok = ok and (hi - lo) in (0, 1)
+        gathered = shard.gather_streams([work(s) for s in mine], dst=0)
+        if rank == 0:
+            ok = ok and gathered == [work(s) for s in streams]
+            ok = ok and [(a, b) for a, b in shard.partition([len(s) for s in streams], world)][0] == (lo, hi)
+        else:
+            ok = ok and gathered is None
+    if rank == 0:
+        q.put(bool(ok))
+    else:
+        assert ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config4_and_config5_flows_scatter_process_gather_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_worker_flows, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
