@@ -46,7 +46,7 @@ EXPORTS = [
     "aukit_stream_open", "aukit_stream_feed", "aukit_stream_finish", "aukit_stream_next", "aukit_stream_length", "aukit_stream_resident", "aukit_stream_close",
     "aukit_partition", "aukit_group_create", "aukit_group_destroy", "aukit_group_info", "aukit_group_ctx", "aukit_group_sync", "aukit_group_scatter",
     "aukit_group_gather_audio", "aukit_group_gather_batch", "aukit_group_run", "aukit_group_last_run",
-    "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_pack_pcm",
+    "aukit_concat", "aukit_sub", "aukit_combine", "aukit_split", "aukit_rep", "aukit_reverse", "aukit_tone", "aukit_noise", "aukit_pack_pcm",
 ]
 
 

@@ -14,6 +14,7 @@ checks arguments the way cc.expect does, and moves handles around.  Lua `data` s
 Batch use (N streams per call) goes through `aukit_amd.batch` directly.
 """
 import math
+import os
 import re
 import struct
 
@@ -200,25 +201,61 @@ class Audio:
     def reverse(self):  # :856
         return Audio(_wrap(B.reverse, context(), self._h), self.metadata, self.info)
 
-    def wav(self, bitDepth=None, int_mode=N.PACK_TRUNC):  # :947 (metadata LIST chunk not written: self.metadata must be empty)
+    def _wav_list(self):
+        """the "LIST" chunk Audio:wav writes for self.metadata (:946-956, :980-990): str_pack("!2<c4" .. ("c4s4Xh"):rep(k), "INFO", tag, tostring(value), ...)
+        — every entry its four-letter tag, the value's length as a little-endian u32, the value, padded to an even offset — then "LIST" .. u32(#list) .. list.
+        The reference walks `pairs(self.metadata)` (and `pairs(wavMetadata)` for the tag: trackNumber has two, IPRT and ITRK), whose order a Lua VM
+        does not define: here the metadata's own order, and the first tag in the reference's table.  Keys without a tag are left out, as there."""
+        if not self.metadata:
+            return b""
+        entries = b""
+        for k, v in self.metadata.items():
+            tag = _WAV_TAG.get(k)
+            if tag is None:
+                continue
+            val = _lua_tostring(v).encode("latin-1", "replace") if not isinstance(v, (bytes, bytearray)) else bytes(v)
+            entries += tag + struct.pack("<I", len(val)) + val
+            if len(entries) % 2:
+                entries += b"\0"   # Xh: align to 2 (the chunk starts at an even offset: "INFO" is four bytes)
+        lst = b"INFO" + entries
+        return b"LIST" + struct.pack("<I", len(lst)) + lst
+
+    def wav(self, bitDepth=None, int_mode=N.PACK_TRUNC):  # :940-997
         bitDepth = 16 if bitDepth is None else _expect(1, bitDepth, "number")
         nc, rate, n = self.channels(), self.sampleRate, int(self._h.layout()[0][0])
-        if self.metadata:
-            raise LuaError("Audio:wav with metadata is not supported by this mirror")
+        lst = self._wav_list()   # (the RIFF size field does not count it: `#str + 72` / `#str + 36` with or without, as the reference writes it)
         if bitDepth == 1:  # DFPWM in WAVE_FORMAT_EXTENSIBLE  :952-961, :981-985
             body = self.dfpwm(True)
             guid = bytes([0x3A, 0xC1, 0xFA, 0x38, 0x81, 0x1D, 0x43, 0x61, 0xA4, 0x0D, 0xCE, 0x53, 0xCA, 0x60, 0x7C, 0xD1])  # wavExtensible.dfpwm  :137
             chmask = {1: 0x04, 2: 0x03, 3: 0x07, 4: 0x33, 5: 0x37, 6: 0x3F, 7: 0x637, 8: 0x63F}.get(nc, 0)  # wavExtensibleChannels  :141-149
-            return (struct.pack("<4sI4s4sIHHIIHHHHI16s4sII4sI", b"RIFF", len(body) + 72, b"WAVE", b"fmt ", 40, 0xFFFE, nc, int(rate), int(rate * nc / 8),
-                                int(math.ceil(nc / 8)), 1, 22, 1, chmask, guid, b"fact", 4, n, b"data", len(body)) + body)
+            return (struct.pack("<4sI4s4sIHHIIHHHHI16s4sII", b"RIFF", len(body) + 72, b"WAVE", b"fmt ", 40, 0xFFFE, nc, int(rate), int(rate * nc / 8),
+                                int(math.ceil(nc / 8)), 1, 22, 1, chmask, guid, b"fact", 4, n) + lst + struct.pack("<4sI", b"data", len(body)) + body)
         if bitDepth not in (8, 16, 24, 32):
             raise LuaError("bad argument #2 (invalid bit depth)")
         body = _wrap(B.pack_pcm, context(), self._h, bitDepth, "unsigned" if bitDepth == 8 else "signed", False, True, int_mode).download()[0]
-        return struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", len(body) + 36, b"WAVE", b"fmt ", 16, 1, nc, int(rate), int(rate * nc * bitDepth / 8),
-                           int(nc * bitDepth / 8), bitDepth, b"data", len(body)) + body
+        return struct.pack("<4sI4s4sIHHIIHH", b"RIFF", len(body) + 36, b"WAVE", b"fmt ", 16, 1, nc, int(rate), int(rate * nc * bitDepth / 8),
+                           int(nc * bitDepth / 8), bitDepth) + lst + struct.pack("<4sI", b"data", len(body)) + body
 
     def __str__(self):
         return f"Audio: {self.sampleRate} Hz, {self.channels()} channels, {self.len()} seconds"
+
+
+# wavMetadata (aukit.lua:198-216), inverted: metadata key -> the tag Audio:wav writes (the first of the reference's table where a key has two)
+_WAV_TAG = {"album": b"IPRD", "title": b"INAM", "artist": b"IART", "author": b"IWRI", "composer": b"IMUS", "producer": b"IPRO", "trackNumber": b"IPRT",
+            "trackCount": b"IFRM", "partNumber": b"PRT1", "partCount": b"PRT2", "length": b"TLEN", "rating": b"IRTD", "date": b"ICRD", "encodedBy": b"ITCH",
+            "encoder": b"ISFT", "media": b"ISRF", "genre": b"IGNR", "comment": b"ICMT", "copyright": b"ICOP", "language": b"ILNG"}
+
+
+def _lua_tostring(v):
+    """tostring(v) for the values metadata holds: strings as they are, integral numbers without a fraction (CC: Tweaked's VM prints 5, not 5.0),
+    other numbers as %.14g"""
+    if isinstance(v, str):
+        return v
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (int, float)):
+        return str(int(v)) if float(v).is_integer() else "%.14g" % v
+    return str(v)
 
 
 def _load(desc, data, dtype=None):
@@ -248,8 +285,21 @@ def tone(frequency, duration, amplitude=None, waveType=None, duty=None, channels
     return Audio(_wrap(B.tone, context(), 1, float(frequency), float(duration), float(amplitude), waveType, float(duty), int(channels), float(sampleRate), N.F64))
 
 
-def noise(duration, amplitude=None, channels=None, sampleRate=None):  # :1840 draws from the host VM's math.random: not reproducible
-    raise LuaError("aukit.noise depends on the host VM's math.random and has no reproducible counterpart here")
+_noise_calls = [0]
+
+
+def noise(duration, amplitude=None, channels=None, sampleRate=None, seed=None):  # :1840
+    """White noise, (random() * 2 - 1) * amplitude per sample.  The reference draws from its VM's math.random — not reproducible by anyone;
+    here the device draws (Philox4x32-10, aukit_noise): `seed` names the audio (the same seed, the same samples); without one every call
+    draws a fresh audio, as the reference's calls do."""
+    _expect(1, duration, "number")
+    amplitude = 1 if amplitude is None else _expect(2, amplitude, "number")
+    channels = 1 if channels is None else _expect(3, channels, "number")
+    sampleRate = 48000 if sampleRate is None else _expect(4, sampleRate, "number")
+    if seed is None:
+        _noise_calls[0] += 1
+        seed = (int.from_bytes(os.urandom(8), "little") ^ _noise_calls[0])
+    return Audio(_wrap(B.noise, context(), 1, float(duration), float(amplitude), int(channels), float(sampleRate), int(seed), N.F64))
 
 
 def pack(data, bitDepth=None, dataType=None, bigEndian=None, int_mode=N.PACK_TRUNC):  # :1861 on a table of numbers

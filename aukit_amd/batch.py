@@ -552,6 +552,14 @@ def tone(ctx, n, frequency, duration, amplitude=1.0, wave="sine", duty=0.5, chan
     return out
 
 
+def noise(ctx, n, duration, amplitude=1.0, channels=1, sample_rate=48000.0, seed=0, dtype=None, out=None):
+    """aukit.noise (aukit.lua:1840) on the device: Philox4x32-10 keyed by `seed` — the reference's math.random stream is not reproducible."""
+    out = out if out is not None else AudioBatch(ctx)
+    N.check(N.lib().aukit_noise(ctx._h, int(n), C.c_double(duration), C.c_double(amplitude), int(channels), C.c_double(sample_rate), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                ctx.dtype if dtype is None else dtype, C.byref(out._h)))
+    return out
+
+
 def pack_pcm(ctx, audio, bit_depth=8, data_type="signed", big_endian=False, interleaved=True, int_mode=N.PACK_TRUNC, out=None):
     """aukit.pack(audio:pcm(...), ...) (aukit.lua:901, :1861) → Batch of byte strings."""
     out = out if out is not None else Batch(ctx, C.c_void_p())

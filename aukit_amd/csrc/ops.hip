@@ -272,6 +272,28 @@ __global__ __launch_bounds__(256) void k_tone(T *out, const u64 *row_off, u64 le
     }
 }
 
+// aukit.noise  aukit.lua:1840-1853: l[i] = (random() * 2 - 1) * amplitude.  Philox4x32-10 (Salmon et al., SC'11), one block of four words per
+// sample pair index: counter = (i, channel, stream, 0), key = the seed's halves; words 0-1 make the double of sample 2 i, words 2-3 of 2 i + 1
+AUKIT_DEV void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_noise(T *out, const u64 *row_off, u64 len, double amp, unsigned k0, unsigned k1, int channels, unsigned stream0) {
+    T *row = out + row_off[blockIdx.y];
+    const unsigned stream = stream0 + blockIdx.y / (unsigned)channels, ch = blockIdx.y % (unsigned)channels;
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; 2 * q < len; q += (u64)gridDim.x * 256) {
+        unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32) ^ (ch << 8), c2 = stream, c3 = 0x4155u;  // ("AU")
+        unsigned a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) { philox_round(c0, c1, c2, c3, a, b); a += 0x9E3779B9u; b += 0xBB67AE85u; }
+        const double u0 = (double)(((u64)(c0 >> 5) << 26) | (c1 >> 6)) * 0x1.0p-53, u1 = (double)(((u64)(c2 >> 5) << 26) | (c3 >> 6)) * 0x1.0p-53;
+        row[2 * q] = (T)((u0 * 2 - 1) * amp);
+        if (2 * q + 1 < len) row[2 * q + 1] = (T)((u1 * 2 - 1) * amp);
+    }
+}
+
 // string.pack of one sample (aukit.pack :1861-1878; Audio:wav :966-971).  `mode` says what the host VM does with a number
 // that has no integer representation — the reference leaves that to string.pack, which is not part of aukit.lua.
 // Four output elements per thread, 4 * BYTES contiguous bytes per store (the packed strings start anywhere: unaligned vector stores) —
@@ -366,6 +388,42 @@ int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, do
     }
     AUKIT_HIP_CHECK(hipGetLastError());
     return ctx_end_kernel(ctx, "k_tone", (uint64_t)n * channels * len * dtype_size(dtype));
+}
+
+// aukit.noise  aukit.lua:1840-1853
+int aukit_noise(aukit_ctx *ctx, uint32_t n, double duration, double amplitude, int channels, double sample_rate, uint64_t seed, int dtype, aukit_audio **out) {
+    if (!ctx || !out) return fail(AUKIT_E_ARG, "null argument");
+    if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "dtype must be AUKIT_F64 or AUKIT_F32");
+    if (!(amplitude >= 0 && amplitude <= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %.14g to be within 0 and 1)", amplitude);
+    if (!(channels >= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %d to be within 1 and inf)", channels);
+    if (channels > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "more than %d channels", AUKIT_MAX_PLANAR_CHANNELS);
+    if (!(sample_rate >= 1)) return fail(AUKIT_E_LUA, "number outside of range (expected %.14g to be within 1 and inf)", sample_rate);
+    AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
+    const double cnt = duration * sample_rate;  // for i = 1, duration * sampleRate
+    const uint64_t len = cnt >= 1 ? (uint64_t)std::floor(cnt) : 0;
+    std::vector<uint64_t> lens(n, len);
+    aukit_audio *o = *out;
+    int rc = audio_prepare(ctx, &o, n, channels, sample_rate, dtype, lens.data());
+    if (rc) return rc;
+    *out = o;
+    if (!n || !len) return AUKIT_OK;
+    std::vector<uint64_t> rows((size_t)n * channels);
+    for (uint32_t s = 0; s < n; s++)
+        for (int c = 0; c < channels; c++) rows[(size_t)s * channels + c] = o->row_off[s] + (uint64_t)c * o->row_stride[s];
+    if ((rc = upload_table(ctx, ctx->misc_buf, rows.data(), rows.size() * 8))) return rc;
+    if ((rc = ctx_begin_kernel(ctx))) return rc;
+    const unsigned gx = (unsigned)std::min<uint64_t>((len / 2 + 1024) / 1024, 1024);
+    // (rows beyond gridDim.y's limit: the stream / channel of a row come from blockIdx.y, so a launch starts at a multiple of `channels`)
+    const size_t per = (size_t)(65535 / channels) * channels;
+    for (size_t first = 0; first < rows.size(); first += per) {
+        const unsigned gy = (unsigned)std::min<size_t>(per, rows.size() - first);
+        const u64 *ro = reinterpret_cast<const u64 *>(ctx->misc_buf.p) + first;
+        const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32), stream0 = (unsigned)(first / channels);
+        if (dtype == AUKIT_F64) hipLaunchKernelGGL((k_noise<double>), dim3(gx, gy), dim3(256), 0, ctx->stream, reinterpret_cast<double *>(o->dev), ro, (u64)len, amplitude, k0, k1, channels, stream0);
+        else hipLaunchKernelGGL((k_noise<float>), dim3(gx, gy), dim3(256), 0, ctx->stream, reinterpret_cast<float *>(o->dev), ro, (u64)len, amplitude, k0, k1, channels, stream0);
+    }
+    AUKIT_HIP_CHECK(hipGetLastError());
+    return ctx_end_kernel(ctx, "k_noise", (uint64_t)n * channels * len * dtype_size(dtype));
 }
 
 // aukit.pcm(data, bitDepth, dataType, channels, sampleRate, interleaved) with `data` a TABLE of numbers (aukit.lua:1077-1096): `n` tables

@@ -11,8 +11,8 @@
 --- .mdfpwm :1420, .wav :1456, .aiff :1580, .au :1639, .flac :1657, .qoa :1706; aukit.new :1783, .tone :1808, .pack :1861;
 --- Audio:len / :channels / :resample :653 / :mono :677 / :concat :695 / :sub :725 / :combine :751 / :split :781 / :mix :804 /
 --- :rep :839 / :reverse :856 / :pcm :901 / :stream :921 / :wav :954 / :dfpwm :1005; aukit.stream.* :2228-3337; aukit.effects.* :3356-3618.
---- Left to the reference's own Lua (not on the path: SURVEY.md §8): aukit.play / Player, aukit.noise (draws from the VM's math.random),
---- aukit.detect, metadata (LIST / ID3) reading and writing.
+--- aukit.noise :1840 (the device draws: Philox keyed by a seed — the reference's math.random stream is not reproducible), aukit.detect :2156 (host-side
+--- bytes), Audio:wav's LIST / INFO chunk :946-956.  Left to the reference's own Lua (not on the path: SURVEY.md §8): aukit.play / Player, ID3 / LIST READING.
 local ffi = require "ffi"
 
 ffi.cdef [[
@@ -69,6 +69,7 @@ int aukit_group_run(aukit_group *g, const aukit_group_call *calls, uint32_t n_pe
 int aukit_decode_nibbles(aukit_ctx *, const uint8_t *nibbles, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int dtype, aukit_audio **out);
 int aukit_stream_decode_table(aukit_ctx *, const double *values, const uint64_t *offsets, uint32_t n, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_tone(aukit_ctx *, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels, double sample_rate, int dtype, aukit_audio **out);
+int aukit_noise(aukit_ctx *, uint32_t n, double duration, double amplitude, int channels, double sample_rate, uint64_t seed, int dtype, aukit_audio **out);
 int aukit_pack_pcm(aukit_ctx *, const aukit_audio *, int bit_depth, int data_type, int big_endian, int interleaved, int int_mode, aukit_batch **out);
 int aukit_stream_decode(aukit_ctx *, const aukit_batch *, const aukit_codec_desc *, int interp, int mono, int dtype, aukit_audio **out, aukit_chunks **chunks);
 int aukit_chunks_info(const aukit_chunks *, uint32_t *n, uint32_t *max_chunks);
@@ -350,19 +351,42 @@ local function packed(self, bitDepth, dataType, bigEndian, interleaved)
 end
 local wavExtensibleChannels = {0x04, 0x03, 0x07, 0x33, 0x37, 0x3F, 0x637, 0x63F, 0x50F7, 0x50FF, 0x56F7, 0x56FF}  -- :141-154 (by channel count)
 local dfpwmGUID = "\x3a\xc1\xfa\x38\x81\x1d\x43\x61\xa4\x0d\xce\x53\xca\x60\x7c\xd1"                          -- :138
-function Audio:wav(bitDepth)                                           -- :954 (metadata / LIST chunk not written: out of scope)
+-- wavMetadata :198-220 inverted: the tag Audio:wav writes for a metadata key (the reference finds it by walking pairs(wavMetadata), whose order a
+-- Lua VM does not define — trackNumber has two tags, IPRT and ITRK: the first of the table here)
+local wavTag = {album = "IPRD", title = "INAM", artist = "IART", author = "IWRI", composer = "IMUS", producer = "IPRO", trackNumber = "IPRT",
+    trackCount = "IFRM", partNumber = "PRT1", partCount = "PRT2", length = "TLEN", rating = "IRTD", date = "ICRD", encodedBy = "ITCH",
+    encoder = "ISFT", media = "ISRF", genre = "IGNR", comment = "ICMT", copyright = "ICOP", language = "ILNG"}
+--- "LIST" .. s4("INFO" .. (tag .. s4(tostring(value)) .. pad to even)...) for self.metadata (:946-956): str_pack("!2<c4" .. ("c4s4Xh"):rep(n), "INFO", ...)
+local function wav_list(self)
+    if not self.metadata or not next(self.metadata) then return "" end
+    local parts = {"INFO"}
+    local at = 4
+    for k, v in pairs(self.metadata) do
+        local tag = wavTag[k]
+        if tag then
+            local val = tostring(v)
+            parts[#parts + 1] = tag .. u32(#val) .. val
+            at = at + 8 + #val
+            if at % 2 == 1 then parts[#parts + 1] = "\0" at = at + 1 end  -- Xh
+        end
+    end
+    local list = table.concat(parts)
+    return "LIST" .. u32(#list) .. list
+end
+function Audio:wav(bitDepth)                                           -- :940-997
     bitDepth = expect(1, bitDepth, "number", "nil") or 16
     local ch, rate, len = geom(self)
+    local list = wav_list(self)  -- (the RIFF size field does not count it, with or without: `#str + 72` / `#str + 36`, as the reference writes it)
     if bitDepth == 1 then
         local str = self:dfpwm(true)
-        -- "<c4Ic4c4IHHIIHHHHIc16c4IIc4I" (:983-988)
+        -- "<c4Ic4c4IHHIIHHHHIc16c4II[c4s4]c4I" (:957-967, :969-975)
         return "RIFF" .. u32(#str + 72) .. "WAVE" .. "fmt " .. u32(40) .. u16(0xFFFE) .. u16(ch) .. u32(rate) .. u32(rate * ch / 8) .. u16(math.ceil(ch / 8)) .. u16(1) ..
-            u16(22) .. u16(1) .. u32(wavExtensibleChannels[ch] or 0) .. dfpwmGUID .. "fact" .. u32(4) .. u32(len) .. "data" .. u32(#str) .. str
+            u16(22) .. u16(1) .. u32(wavExtensibleChannels[ch] or 0) .. dfpwmGUID .. "fact" .. u32(4) .. u32(len) .. list .. "data" .. u32(#str) .. str
     elseif bitDepth ~= 8 and bitDepth ~= 16 and bitDepth ~= 24 and bitDepth ~= 32 then error("bad argument #2 (invalid bit depth)", 2) end
     local str = packed(self, bitDepth, bitDepth == 8 and "unsigned" or "signed", false, true)
-    -- "<c4Ic4c4IHHIIHHc4I" (:996)
+    -- "<c4Ic4c4IHHIIHH[c4s4]c4I" (:991-995)
     return "RIFF" .. u32(#str + 36) .. "WAVE" .. "fmt " .. u32(16) .. u16(1) .. u16(ch) .. u32(rate) .. u32(rate * ch * bitDepth / 8) .. u16(ch * bitDepth / 8) .. u16(bitDepth) ..
-        "data" .. u32(#str) .. str
+        list .. "data" .. u32(#str) .. str
 end
 
 -- ---------------------------------------------------------------- generators, packing
@@ -387,6 +411,23 @@ function aukit.tone(frequency, duration, amplitude, waveType, duty, channels, sa
     if not w then error("bad argument #4 (invalid wave type)", 2) end
     local o = ffi.new("aukit_audio*[1]")
     check(C.aukit_tone(ctx(), 1, frequency, duration, amplitude, w, duty, channels, sampleRate, F64, o))
+    return wrap(o[0], {}, {})
+end
+--- aukit.noise(duration, amplitude, channels, sampleRate) :1840.  The reference draws from math.random; here the device draws (Philox4x32-10,
+--- aukit_noise) from a seed: a fifth argument names it (the same seed, the same audio), otherwise every call draws a fresh one from math.random.
+local noise_calls = 0
+function aukit.noise(duration, amplitude, channels, sampleRate, seed)
+    expect(1, duration, "number")
+    amplitude = expect(2, amplitude, "number", "nil") or 1
+    channels = expect(3, channels, "number", "nil") or 1
+    sampleRate = expect(4, sampleRate, "number", "nil") or 48000
+    range(2, amplitude, 0, 1) range(3, channels, 1) range(4, sampleRate, 1)
+    if seed == nil then
+        noise_calls = noise_calls + 1
+        seed = math.floor(math.random() * 4294967296) * 4294967296 + math.floor(math.random() * 4294967296) + noise_calls
+    end
+    local o = ffi.new("aukit_audio*[1]")
+    check(C.aukit_noise(ctx(), 1, duration, amplitude, channels, sampleRate, ffi.cast("uint64_t", seed), F64, o))
     return wrap(o[0], {}, {})
 end
 --- aukit.pack(data, bitDepth, dataType, bigEndian) :1861 takes the number table Audio:pcm returns; with an Audio as first argument the
@@ -795,6 +836,60 @@ function aukit.gpus(devices)
         return out
     end
     return group
+end
+
+-- ---------------------------------------------------------------- aukit.detect  :2136-2195 (host-side bytes; LuaJIT has no string.unpack: eight numbers by hand)
+local datafmts = {{1, 8, "signed"}, {1, 8, "unsigned"}, {2, 16, "signed"}, {4, 32, "signed"}, {4, 32, "float"}, {3, 24, "signed"}, {4, 32, "unsigned"},
+    {3, 24, "unsigned"}, {2, 16, "unsigned"}}
+--- pcall(str_unpack, fmt, data, init) for eight little-endian values of `size` bytes → the numbers, or nil where string.unpack raises
+--- ("initial position out of string", "data string too short")
+local function unpack8(data, size, kind, init)
+    local n = #data
+    if init < 0 then init = (-init > n) and 0 or n + init + 1 end
+    if init < 1 or init - 1 > n then return nil end
+    if init - 1 + 8 * size > n then return nil end
+    local out = {}
+    for k = 0, 7 do
+        local p = init + k * size
+        if kind == "float" then
+            out[k + 1] = ffi.cast("const float*", ffi.cast("const uint8_t*", data) + (p - 1))[0]   -- (unaligned loads are fine on the hosts LuaJIT runs on)
+        else
+            local v = 0
+            for b = size - 1, 0, -1 do v = v * 256 + data:byte(p + b) end
+            if kind == "signed" and v >= 2 ^ (8 * size - 1) then v = v - 2 ^ (8 * size) end
+            out[k + 1] = v
+        end
+    end
+    return out
+end
+function aukit.detect(data)
+    expect(1, data, "string")
+    if data:match "^RIFF....WAVE" then return "wav"
+    elseif data:match "^FORM....AIF[FC]" then return "aiff"
+    elseif data:match "^%.snd" then return "au"
+    elseif data:match "^fLaC" then return "flac"
+    elseif data:match "^MDFPWM\3" then return "mdfpwm"
+    elseif data:match "^qoaf" then return "qoa"
+    end
+    -- the start or the end of the audio is expected to be (near) silence
+    for _, f in ipairs(datafmts) do
+        local size, bits, kind = f[1], f[2], f[3]
+        local mid = kind == "unsigned" and 2 ^ (bits - 1) or 0
+        local gap = kind == "float" and 0.001 or 8 * 2 ^ (bits - 8)
+        for _, init in ipairs {1, #data - bits} do   -- (:2183 subtracts the bit depth, not the byte count)
+            local nums = unpack8(data, size, kind, init)
+            if nums then
+                local allzero, ok = true, true
+                for _, v in ipairs(nums) do
+                    if v ~= mid then allzero = false end
+                    if v < mid - gap or v > mid + gap then ok = false break end
+                end
+                if ok and not allzero then return "pcm", bits, kind end
+            end
+        end
+    end
+    if data:find(("\x55"):rep(12), 1, true) or data:find(("\xAA"):rep(12), 1, true) then return "dfpwm" end
+    return nil
 end
 
 return aukit

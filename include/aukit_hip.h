@@ -246,6 +246,11 @@ typedef enum { AUKIT_WAVE_NONE = 0 /* aukit.new: silence */, AUKIT_WAVE_SINE = 1
  * :1808 — `n` identical audios (aukit.noise draws from the host VM's math.random and cannot be reproduced) */
 int aukit_tone(aukit_ctx *ctx, uint32_t n, double frequency, double duration, double amplitude, int wave, double duty, int channels,
                double sample_rate, int dtype, aukit_audio **out);
+/* aukit.noise(duration, amplitude, channels, sampleRate) :1840-1853 — `n` audios of white noise, (random() * 2 - 1) * amplitude per sample.  The
+ * reference draws from its VM's math.random: NOT reproducible, by anyone.  Here: Philox4x32-10 on the device, keyed by `seed`, counter =
+ * (sample index, channel, stream) — every sample of every channel of every stream its own draw, 53 random bits to a double in [0, 1), the
+ * same audio for the same seed.  Same argument checks and error strings as the reference's. */
+int aukit_noise(aukit_ctx *ctx, uint32_t n, double duration, double amplitude, int channels, double sample_rate, uint64_t seed, int dtype, aukit_audio **out);
 /* What string.pack does with a sample that has no integer representation is the host VM's business, not aukit.lua's
  * (Audio:pcm hands it unfloored numbers, :875): truncate like a Java (long) cast (CC: Tweaked's VM), floor, or raise like PUC Lua 5.3. */
 typedef enum { AUKIT_PACK_TRUNC = 0, AUKIT_PACK_FLOOR = 1, AUKIT_PACK_STRICT = 2,
