@@ -24,7 +24,8 @@ PCM_TYPE = {"signed": 0, "unsigned": 1, "float": 2}
 CODEC_PCM, CODEC_G711, CODEC_ADPCM, CODEC_ADPCM_WAV, CODEC_MSADPCM, CODEC_DFPWM, CODEC_MDFPWM, CODEC_QOA, CODEC_FLAC = range(9)
 FX = {"amplify": 0, "speed": 1, "fade": 2, "invert": 3, "normalize": 4, "center": 5, "trim": 6, "delay": 7, "echo": 8, "reverb": 9,
       "lowpass": 10, "highpass": 11}
-MAX_CH = 8
+MAX_CH = 8            # AUKIT_MAX_CHANNELS
+MAX_PLANAR_CH = 64    # AUKIT_MAX_PLANAR_CHANNELS (the descriptor's predictor / step_index arrays)
 OPT_EXACT_MATH, OPT_STORE_X4, OPT_COLLECT_STATS, OPT_DFPWM_SPECULATE = 0, 1, 2, 3
 COUNTER_DFPWM_CHUNKS, COUNTER_DFPWM_CHUNKS_REDONE, COUNTER_FLAC_FUSED, COUNTER_TIER1_ERR_NANO, COUNTER_TIER1_OUTPUTS = 0, 1, 2, 3, 4
 COUNTER_DFPWM_RESPECULATED, COUNTER_DFPWM_HARD, COUNTER_RECURRENCE_F32 = 5, 6, 7
@@ -54,7 +55,7 @@ class CodecDesc(C.Structure):
     _fields_ = [("codec", C.c_int32), ("channels", C.c_int32), ("sample_rate", C.c_double), ("bit_depth", C.c_int32),
                 ("data_type", C.c_int32), ("big_endian", C.c_int32), ("interleaved", C.c_int32), ("ulaw", C.c_int32),
                 ("top_first", C.c_int32), ("block_align", C.c_int32), ("ncoef", C.c_int32), ("coef1", C.c_int16 * 32),
-                ("coef2", C.c_int16 * 32), ("predictor", C.c_int32 * MAX_CH), ("step_index", C.c_int32 * MAX_CH)]
+                ("coef2", C.c_int16 * 32), ("predictor", C.c_int32 * MAX_PLANAR_CH), ("step_index", C.c_int32 * MAX_PLANAR_CH)]
 
 
 GOP = {"none": 0, "decode": 1, "decode_resample": 2, "stream_decode": 3, "resample": 4, "mono": 5, "effect": 6, "dfpwm_encode": 7, "dfpwm_transcode_mono": 8,

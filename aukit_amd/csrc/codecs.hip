@@ -209,7 +209,7 @@ static int dfpwm_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit
     const int C = d->channels;
     if (C < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #3 (number outside of range)");
-    if (C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_CHANNELS);
+    if (C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_PLANAR_CHANNELS);
     std::vector<uint64_t> row_off((size_t)in->n * C), row_len((size_t)in->n * C), soff(in->n), sstride(in->n);
     uint64_t tot = 0;
     for (uint32_t s = 0; s < in->n; s++) {
@@ -414,7 +414,7 @@ struct ImaParams {
     const ImaRowJob *jobs;
     unsigned njobs;
     int C, block_align, mode, top_first, interleaved;
-    int init_pred[AUKIT_MAX_CHANNELS], init_idx[AUKIT_MAX_CHANNELS];
+    int init_pred[AUKIT_MAX_PLANAR_CHANNELS], init_idx[AUKIT_MAX_PLANAR_CHANNELS];
     int mask_mono_index;          // aukit.wav masks the mono header step index with 0x0F (Q8)
     short *out;
     int *err;
@@ -903,7 +903,7 @@ static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_c
     const bool wav = d->codec == AUKIT_CODEC_ADPCM_WAV;
     if (C < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #3 (number outside of range)");
-    if (C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_CHANNELS);
+    if (C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_UNSUPPORTED, "at most %d channels are supported", AUKIT_MAX_PLANAR_CHANNELS);
     if (wav) {
         if (C > 2) return fail(AUKIT_E_UNSUPPORTED, "the WAV IMA splitter handles 1 or 2 channels (aukit.lua:1512-1546)");
         if (d->block_align <= 4 * C || (d->block_align - 4 * C) % (4 * C) != 0) return fail(AUKIT_E_ARG, "bad blockAlign");
@@ -1008,7 +1008,7 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
                       aukit_chunks **chunks_out) {
     const int C = d->channels;
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #4 (number outside of range)");
-    if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
+    if (C < 1 || C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_ARG, "channels out of range");
     if (d->block_align <= 4 * C || (d->block_align - 4 * C) % (4 * C) != 0) return fail(AUKIT_E_UNSUPPORTED, "blockAlign must be 4*channels*(k+1)");
     if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
     if (dtype != AUKIT_I8 && dtype != AUKIT_F64) return fail(AUKIT_E_ARG, "stream.adpcm output must be AUKIT_I8 or AUKIT_F64");

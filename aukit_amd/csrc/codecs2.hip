@@ -430,7 +430,7 @@ static int stream_dfpwm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec
                         aukit_chunks **chunks_out) {
     const int C = d->channels;
     if (d->sample_rate < 1) return fail(AUKIT_E_ARG, "bad argument #2 (number outside of range)");
-    if (C < 1 || C > AUKIT_MAX_CHANNELS) return fail(AUKIT_E_ARG, "bad argument #3 (number outside of range)");
+    if (C < 1 || C > AUKIT_MAX_PLANAR_CHANNELS) return fail(AUKIT_E_ARG, "bad argument #3 (number outside of range)");
     if (interp < 0 || interp > 3) return fail(AUKIT_E_ARG, "invalid interpolation");
     if (dtype != AUKIT_F64 && dtype != AUKIT_F32) return fail(AUKIT_E_ARG, "stream.dfpwm output must be AUKIT_F64 or AUKIT_F32");
     if (C == 1) mono = 0;

@@ -18,7 +18,7 @@ local ffi = require "ffi"
 ffi.cdef [[
 typedef struct aukit_ctx aukit_ctx; typedef struct aukit_batch aukit_batch; typedef struct aukit_audio aukit_audio; typedef struct aukit_chunks aukit_chunks;
 typedef struct { int32_t codec, channels; double sample_rate; int32_t bit_depth, data_type, big_endian, interleaved, ulaw, top_first, block_align, ncoef;
-                 int16_t coef1[32], coef2[32]; int32_t predictor[8], step_index[8]; } aukit_codec_desc;
+                 int16_t coef1[32], coef2[32]; int32_t predictor[64], step_index[64]; } aukit_codec_desc;
 typedef struct { aukit_codec_desc desc; uint64_t payload_off, payload_len; int32_t wav_data_type, bit_depth; double length_seconds; } aukit_container;
 const char *aukit_last_error(void);
 int aukit_ctx_create(aukit_ctx **out, int device); void aukit_ctx_destroy(aukit_ctx *ctx);
@@ -146,7 +146,7 @@ local function desc(t)
         d.ncoef = n
         for i = 1, n do d.coef1[i - 1] = t.coefficients[1][i]; d.coef2[i - 1] = t.coefficients[2][i] end
     end
-    for c = 1, 8 do  -- aukit.adpcm's predictor / step_index: a number or one per channel (:1190-1215)
+    for c = 1, 64 do  -- aukit.adpcm's predictor / step_index: a number or one per channel (:1190-1215)
         local p, s = t.predictor, t.step_index
         if type(p) == "table" then p = p[c] end
         if type(s) == "table" then s = s[c] end

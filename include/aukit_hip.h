@@ -32,9 +32,9 @@
 extern "C" {
 #endif
 
-#define AUKIT_ABI_VERSION 2   /* 2: aukit_stream_next takes the capacity of dst */
-#define AUKIT_MAX_CHANNELS 8          /* block codecs with per-channel state in the descriptor (ADPCM predictors), FLAC, QOA, DFPWM loaders */
-#define AUKIT_MAX_PLANAR_CHANNELS 64  /* PCM, G.711 and QOA (loaders and streams), the Audio methods and effects: planar rows of any count up to this
+#define AUKIT_ABI_VERSION 2   /* 2: aukit_stream_next takes the capacity of dst; aukit_codec_desc carries AUKIT_MAX_PLANAR_CHANNELS predictors / step indices */
+#define AUKIT_MAX_CHANNELS 8          /* FLAC (its format's own limit), the WAV IMA splitter and MS-ADPCM take the reference's 1 or 2 */
+#define AUKIT_MAX_PLANAR_CHANNELS 64  /* PCM, G.711, QOA, IMA ADPCM and DFPWM (loaders and streams), the Audio methods and effects: planar rows of any count up to this
                                          (the reference takes any channel count, aukit.lua:1049-1171, :2228; round 4) */
 
 typedef struct aukit_ctx aukit_ctx;
@@ -74,8 +74,8 @@ typedef struct {
     int32_t ncoef;         /* MSADPCM: number of coefficient pairs (0 → the 7 defaults :1304) */
     int16_t coef1[32];     /* MSADPCM `coefficients[1]`                                      */
     int16_t coef2[32];     /* MSADPCM `coefficients[2]`                                      */
-    int32_t predictor[AUKIT_MAX_CHANNELS];  /* ADPCM: initial predictor(s)                   */
-    int32_t step_index[AUKIT_MAX_CHANNELS]; /* ADPCM: initial step index(es)                 */
+    int32_t predictor[AUKIT_MAX_PLANAR_CHANNELS];  /* ADPCM: initial predictor(s)            */
+    int32_t step_index[AUKIT_MAX_PLANAR_CHANNELS]; /* ADPCM: initial step index(es)          */
 } aukit_codec_desc;
 
 /* ---- container front-ends (host-side byte parsing, no GPU): aukit.wav / aukit.aiff / aukit.au (aukit.lua:1456-1651) and the header

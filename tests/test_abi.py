@@ -48,10 +48,11 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_codec_desc_layout_matches_header():
-    """ctypes mirror of aukit_codec_desc: field order / sizes as in the header (4+4+8+7*4+4+64+64+32+32 = 240 bytes)."""
+    """ctypes mirror of aukit_codec_desc: field order / sizes as in the header (4+4+8+7*4+4+64+64+256+256 = 688 bytes; ABI 2: the predictor /
+    step-index arrays hold AUKIT_MAX_PLANAR_CHANNELS entries)."""
     import ctypes as C
     from aukit_amd import _native as N
-    assert C.sizeof(N.CodecDesc) == 240
+    assert C.sizeof(N.CodecDesc) == 688
     assert N.CodecDesc.sample_rate.offset == 8 and N.CodecDesc.coef1.offset == 48 and N.CodecDesc.predictor.offset == 176
 
 
@@ -117,4 +118,4 @@ def test_container_struct_layout():
     import ctypes as C
     from aukit_amd import _native as N
     assert C.sizeof(N.GroupCall) == 160 and N.GroupCall.new_rate.offset == 64 and N.GroupCall.args.offset == 80   # static_assert in group.hip
-    assert C.sizeof(N.Container) == 240 + 8 + 8 + 4 + 4 + 8 and N.Container.payload_off.offset == 240 and N.Container.length_seconds.offset == 264
+    assert C.sizeof(N.Container) == 688 + 8 + 8 + 4 + 4 + 8 and N.Container.payload_off.offset == 688 and N.Container.length_seconds.offset == 712
