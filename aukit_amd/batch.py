@@ -173,6 +173,8 @@ class Group:
         resample / mono / encode_pcm: audio, out; effect: audio, name, args; dfpwm_encode: audio, interleaved, out (Batch);
         dfpwm_transcode_mono: batch, channels, out (Batch).  The members' lists run side by side on the group's worker threads."""
         W = len(self.devices)
+        if len(lists) != W:
+            raise ValueError(f"Group.run: {len(lists)} call lists for a group of {W} members (one list per member, empty lists allowed)")
         n_per = max([len(l) for l in lists] + [0])
         calls = (N.GroupCall * (W * max(n_per, 1)))()
         keep = []

@@ -36,6 +36,7 @@ struct DevBuf {
 
 // ---------------------------------------------------------------- opaque handle bodies
 struct aukit_ctx {
+    uint64_t id = 0;            // unique over the process's life (runtime.hip): what an audio remembers of the context it owes work to, beside its address
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -145,6 +146,7 @@ struct aukit_audio {
     double pend_peak = 1;
     int pend_independent = 0;
     aukit_ctx *pend_ctx = nullptr;
+    uint64_t pend_ctx_id = 0;   // ... and that context's id: an address can come back with a later aukit_ctx_create
     // a deferred resample (flac_tail.hip): aukit_decode_resample on FLAC with F32 storage leaves the decoder's int32 rows here and the resample
     // owed; effects.highpass / lowpass pay it inside their own pass, anything else that reads the samples materialises it first (audio_flush)
     bool lazy_rs = false;
@@ -160,6 +162,7 @@ struct aukit_audio {
     double lazy_norm_pos = 1, lazy_norm_neg = 1;         // `v / (v < 0 and norm_neg or norm_pos)` of the loader the rows came from
     int lazy_interp = 0;
     aukit_ctx *lazy_ctx = nullptr;
+    uint64_t lazy_ctx_id = 0;
     // round 4: the rows may still lie frame by frame where the fused FLAC decoder left them (lazy_rows = its scratch) — lazy_tab then holds the
     // frame records in stream order, each stream's first record, each stream's block size and the (stream, channel) offsets of the contiguous
     // rows they would make; k_rs_onepole follows the records, every other consumer gathers the rows first (lazy_materialize)
@@ -196,8 +199,8 @@ struct DfSliceHook {
 };
 // contexts that exist (runtime.hip): an audio remembers the context its deferred work was queued on (pend_ctx, lazy_ctx) and must not touch it once
 // it is gone; owner_ready() makes `ctx` (the context about to pay the work) wait for what `owner` has queued when the two differ
-bool ctx_is_live(const aukit_ctx *c);
-int owner_ready(aukit_ctx *ctx, aukit_ctx *owner);
+bool ctx_is_live(const aukit_ctx *c, uint64_t id);   // the context at this address is still the one with this id (ids are never reused)
+int owner_ready(aukit_ctx *ctx, aukit_ctx *owner, uint64_t owner_id);
 // applies a deferred map (aukit_audio::pend_norm) in place; every entry point that reads an audio's samples calls it first
 int audio_flush(aukit_ctx *ctx, const aukit_audio *a);
 #define AUKIT_FLUSH(ctx, a)                                                   \

@@ -533,7 +533,7 @@ static int fx_onepole(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
 int lazy_resolve(aukit_ctx *ctx, aukit_audio *a) {
     if (!a->lazy_rs) return AUKIT_OK;
     if (a->lazy_fx) {
-        aukit_ctx *use = ctx ? ctx : (ctx_is_live(a->lazy_ctx) ? a->lazy_ctx : nullptr);
+        aukit_ctx *use = ctx ? ctx : (ctx_is_live(a->lazy_ctx, a->lazy_ctx_id) ? a->lazy_ctx : nullptr);
         if (!use) return fail(AUKIT_E_ARG, "audio has a deferred filter and no context to run it with");
         const int fx = a->lazy_fx;
         const double coef = a->lazy_fx_coef;
@@ -551,9 +551,9 @@ int audio_flush(aukit_ctx *ctx, const aukit_audio *ca) {
     aukit_audio *a = const_cast<aukit_audio *>(ca);
     if (a && a->lazy_rs) { int lrc = lazy_resolve(ctx, a); if (lrc) return lrc; }   // an owed resample (and filter) first (flac_tail.hip)
     if (!a || !a->pend_norm) return AUKIT_OK;
-    if (!ctx) ctx = ctx_is_live(a->pend_ctx) ? a->pend_ctx : nullptr;
+    if (!ctx) ctx = ctx_is_live(a->pend_ctx, a->pend_ctx_id) ? a->pend_ctx : nullptr;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred map and no context to apply it with");
-    { int orc = owner_ready(ctx, a->pend_ctx); if (orc) return orc; }   // the pass that left the rows and their maxima ran on pend_ctx's stream
+    { int orc = owner_ready(ctx, a->pend_ctx, a->pend_ctx_id); if (orc) return orc; }   // the pass that left the rows and their maxima ran on pend_ctx's stream
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     a->pend_norm = false;
     MapArgs A{};
@@ -584,7 +584,7 @@ static int fx_normalize(aukit_ctx *ctx, aukit_audio *a, double peak, int indepen
     a->pend_norm = true;
     a->pend_peak = peak;
     a->pend_independent = independent;
-    a->pend_ctx = ctx;
+    a->pend_ctx = ctx; a->pend_ctx_id = ctx->id;
     if (getenv("AUKIT_NO_TAIL_FUSION")) return audio_flush(ctx, a);  // A/B: five passes
     return AUKIT_OK;
 }
@@ -677,7 +677,7 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
         if (lazy_onepole_try(ctx, const_cast<aukit_audio *>(in), in->lazy_fx_coef, in->lazy_fx == 2, &lrc, o)) {
             if (lrc) return lrc;
             o->pend_norm = false;
-            if (in->pend_norm) { o->pend_norm = true; o->pend_peak = in->pend_peak; o->pend_independent = 0; o->pend_ctx = ctx; }
+            if (in->pend_norm) { o->pend_norm = true; o->pend_peak = in->pend_peak; o->pend_independent = 0; o->pend_ctx = ctx; o->pend_ctx_id = ctx->id; }
             return AUKIT_OK;
         }
     }
@@ -783,7 +783,7 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
         a->pend_norm = true;
         a->pend_peak = argn(0, 1.0);
         a->pend_independent = argn(1, 0.0) != 0;
-        a->pend_ctx = ctx;
+        a->pend_ctx = ctx; a->pend_ctx_id = ctx->id; a->pend_ctx_id = ctx->id;
         ctx->last_kernel = "(normalize deferred)";
         return AUKIT_OK;
     }

@@ -544,9 +544,9 @@ void lazy_drop(aukit_ctx *ctx, aukit_audio *a) {
 // the owed resample with the ordinary kernel, into the audio's own rows
 int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
     if (!a->lazy_rs) return AUKIT_OK;
-    if (!ctx) ctx = ctx_is_live(a->lazy_ctx) ? a->lazy_ctx : nullptr;
+    if (!ctx) ctx = ctx_is_live(a->lazy_ctx, a->lazy_ctx_id) ? a->lazy_ctx : nullptr;
     if (!ctx) return fail(AUKIT_E_ARG, "audio has a deferred resample and no context to run it with");
-    { int orc = owner_ready(ctx, a->lazy_ctx); if (orc) return orc; }   // the decoder wrote the rows on lazy_ctx's stream
+    { int orc = owner_ready(ctx, a->lazy_ctx, a->lazy_ctx_id); if (orc) return orc; }   // the decoder wrote the rows on lazy_ctx's stream
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
     if (a->lazy_indirect) {   // frame by frame in the fused decoder's scratch: contiguous rows first (k_flac_gather)
         int grc;
@@ -633,7 +633,7 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
         ctx->tmp_buf = DevBuf{};
     }
     a->lazy_row_off = row_off; a->lazy_row_len = row_len;
-    a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx;
+    a->lazy_rate = rate; a->lazy_full = full; a->lazy_interp = interp; a->lazy_ctx = ctx; a->lazy_ctx_id = ctx->id;
     a->lazy_src = src_kind; a->lazy_norm_pos = norm_pos; a->lazy_norm_neg = norm_neg;
     a->lazy_scratch16 = LF && LF->scratch16;
     if (a->lazy_scratch16) a->lazy_src = SRC_I16;   // (k_rs_onepole<..., short> on the frames; v / full as for int32 rows)
@@ -649,7 +649,7 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     *rc = AUKIT_OK;
     if (!a->lazy_rs || a->dtype != AUKIT_F32) return false;
     if (mono_out && (a->channels != 2 || mono_out->dtype != AUKIT_F32 || mono_out->channels != 1 || mono_out->n != a->n)) return false;
-    if ((*rc = owner_ready(ctx, a->lazy_ctx))) return true;
+    if ((*rc = owner_ready(ctx, a->lazy_ctx, a->lazy_ctx_id))) return true;
     FastParams F;
     if (!fast_eligible(a->lazy_src == SRC_I16 ? SRC_PCM_S16LE_MONO : (a->lazy_src == SRC_I8 ? SRC_PCM8_MONO : SRC_I32), a->lazy_interp, a->lazy_rate, a->rate, F)) return false;
     constexpr int T = 512;

@@ -135,10 +135,16 @@ static void group_worker(aukit_group *g, uint32_t r) {
         const auto t0 = std::chrono::steady_clock::now();
         int rc = AUKIT_OK;
         std::string msg;
-        for (uint32_t k = 0; k < n_per; k++) {
-            const int r1 = group_call(g->ctx[r], calls[(size_t)r * n_per + k]);
-            if (r1 && !rc) { rc = r1; msg = aukit_last_error(); }   // (the message is this thread's: carried to the caller below)
-            if (r1) break;   // a member's list is a pipeline: what follows a failed call would read its missing output
+        try {   // (an exception must not leave this thread — std::terminate would take the host process with it: ADVICE r04)
+            for (uint32_t k = 0; k < n_per; k++) {
+                const int r1 = group_call(g->ctx[r], calls[(size_t)r * n_per + k]);
+                if (r1 && !rc) { rc = r1; msg = aukit_last_error(); }   // (the message is this thread's: carried to the caller below)
+                if (r1) break;   // a member's list is a pipeline: what follows a failed call would read its missing output
+            }
+        } catch (const std::bad_alloc &) {
+            if (!rc) { rc = AUKIT_E_NOMEM; msg = "out of host memory in a group member's call list"; }
+        } catch (const std::exception &e) {
+            if (!rc) { rc = AUKIT_E_HIP; msg = std::string("exception in a group member's call list: ") + e.what(); }
         }
         if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess && !rc) { rc = AUKIT_E_HIP; msg = "hipStreamSynchronize failed in a group member"; }
         const auto t1 = std::chrono::steady_clock::now();

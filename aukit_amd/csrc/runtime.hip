@@ -192,11 +192,13 @@ const char *aukit_last_error(void) { return g_err; }
 namespace aukit {
 static std::mutex g_live_mu;
 static std::set<const aukit_ctx *> g_live;
-bool ctx_is_live(const aukit_ctx *c) { std::lock_guard<std::mutex> lk(g_live_mu); return c && g_live.count(c) != 0; }
+static uint64_t g_next_ctx_id = 1;
+// (the id is read under the registry's lock, after the address was found in it: a destroyed context is never dereferenced)
+bool ctx_is_live(const aukit_ctx *c, uint64_t id) { std::lock_guard<std::mutex> lk(g_live_mu); return c && g_live.count(c) != 0 && c->id == id; }
 // `ctx` is about to finish work that `owner` queued the inputs of (a decoder's rows behind a deferred resample, a filter pass behind a deferred
 // normalize): when they are different contexts, ctx's stream waits for owner's — if owner still exists; an audio outlives its context legally
-int owner_ready(aukit_ctx *ctx, aukit_ctx *owner) {
-    if (!owner || owner == ctx || !ctx_is_live(owner)) return AUKIT_OK;
+int owner_ready(aukit_ctx *ctx, aukit_ctx *owner, uint64_t owner_id) {
+    if (!owner || (owner == ctx && ctx->id == owner_id) || !ctx_is_live(owner, owner_id)) return AUKIT_OK;
     AUKIT_HIP_CHECK(hipSetDevice(owner->device));
     AUKIT_HIP_CHECK(hipStreamSynchronize(owner->stream));   // (rare: a host wait is the simple, device-agnostic order)
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -224,7 +226,7 @@ int aukit_ctx_create(aukit_ctx **out, int device) {
     AUKIT_HIP_CHECK(hipEventCreate(&c->ev1));
     AUKIT_HIP_CHECK(hipEventCreate(&c->kev0));
     AUKIT_HIP_CHECK(hipEventCreate(&c->kev1));
-    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(c); }
+    { std::lock_guard<std::mutex> lk(g_live_mu); c->id = g_next_ctx_id++; g_live.insert(c); }
     *out = c;
     return AUKIT_OK;
 }
@@ -433,7 +435,7 @@ void *aukit_audio_device_ptr(const aukit_audio *a) {
     if (!a) return nullptr;
     if (a->pend_norm || a->lazy_rs) {   // the caller reads the samples: deferred work is done first, on the context that queued it — if that still exists
         aukit_ctx *owner = a->lazy_rs ? a->lazy_ctx : a->pend_ctx;
-        if (!ctx_is_live(owner)) { fail(AUKIT_E_ARG, "audio has deferred work and its context is gone: pass it through an entry point that takes a context first"); return nullptr; }
+        if (!ctx_is_live(owner, a->lazy_rs ? a->lazy_ctx_id : a->pend_ctx_id)) { fail(AUKIT_E_ARG, "audio has deferred work and its context is gone: pass it through an entry point that takes a context first"); return nullptr; }
         if (audio_flush(owner, a)) return nullptr;
     }
     const_cast<aukit_audio *>(a)->rowmax_valid = false;              // ... and may write them

@@ -27,11 +27,14 @@ def partition(sizes, world):
     """
     if world < 1:
         raise ValueError("world must be >= 1")
-    try:
-        from . import batch as B
-        return B.partition(sizes, world)
-    except (ImportError, OSError, AttributeError):   # a launcher host without the built library: the same arithmetic in numpy (tests assert they agree)
+    import os
+    from . import _native
+    if not os.path.exists(_native.LIB_PATH):   # a launcher host without the built library: the same arithmetic in numpy (tests assert they agree)
+        import warnings
+        warnings.warn(f"{_native.LIB_PATH} is missing: aukit_amd.shard.partition uses its numpy statement", RuntimeWarning, stacklevel=2)
         return _partition_numpy(sizes, world)
+    from . import batch as B   # (a library that is there but broken — a failed dlopen, a missing symbol — must surface, not be papered over: ADVICE r04)
+    return B.partition(sizes, world)
 
 
 def _partition_numpy(sizes, world):
