@@ -57,6 +57,7 @@ struct DfxParams {
     unsigned *hard;         // [npad] the hard streams (flags[13] of them): left to the lane-per-stream encoder (host side)
     unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [13] hard streams
     const unsigned char *lut;  // [65536] mono + 128 for (l + 128) * 256 + (r + 128): the reference's fp64 mix (dfp_mix), in global memory
+    const u64 *count;       // rows kind (Audio:dfpwm on int8 samples): samples per stream — P.fed counts whole UNITS of four of them, the rest is the tail's
     unsigned char *enc_out; // the packed result
     const u64 *ooff;        // [n + 1]
 };
@@ -121,18 +122,49 @@ AUKIT_DEV void dfx_span(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, 
                  });
 }
 
-// the stream's last bits: the last byte is padded with samples of value 0 (aukit.lua:1011-1016 hands the encoder whole bytes)
-AUKIT_DEV void dfx_tail(DfsAcc &acc, DfEnc &e) {
-    dfs_flush(acc);
-    if (acc.pos & 4) {
-        unsigned b4 = 0;
+// ---- the same engine on int8 SAMPLES (Audio:dfpwm, aukit.lua:1005-1018, behind k_dfpwm_quantize): no decoder, no table — `p` is the stream's row
+// of samples and the index unit is four samples (what a fed byte of the stereo transcode makes: every index computation stays as it is).
+// Kernels and helpers take the row kind as their "table" argument.
+struct DfeRows {};
+template <bool EMIT>
+AUKIT_DEV void dfx_span(const unsigned char *p, u64 f0, u64 f1, const Feed &, DfDec &, DfEnc &e, DfeRows, DfsAcc &acc) {
+    auto unit = [&](unsigned w) -> unsigned {   // four samples, first lowest
+        w ^= 0x80808080u;                         // u = v + 128
+        unsigned out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) b4 |= df_encode_u(e, 128u) & (1u << k);
-        acc.bits |= (u64)b4 << acc.pos;
-        acc.pos += 4;
+        for (int k = 0; k < 4; k++) out |= df_encode_u(e, (w >> (8 * k)) & 0xFF) & (1u << k);
+        return out;
+    };
+    u64 f = f0;
+    const unsigned char *a = p + 4 * f0;   // (rows are 16-byte aligned, chunk and checkpoint starts multiples of 16 units)
+    while (f < f1 && ((uintptr_t)a & 15)) { const unsigned b4 = unit(*reinterpret_cast<const unsigned *>(a)); if (EMIT) dfs_put(acc, b4, 4); a += 4; f++; }
+    if (f + 4 <= f1) {
+        uint4 cur = *reinterpret_cast<const uint4 *>(a);
+        while (f + 4 <= f1) {
+            uint4 nxt = cur;
+            if (f + 8 <= f1) nxt = *reinterpret_cast<const uint4 *>(a + 16);   // in flight while `cur` is encoded
+            const unsigned b16 = unit(cur.x) | unit(cur.y) << 4 | unit(cur.z) << 8 | unit(cur.w) << 12;
+            if (EMIT) dfs_put(acc, b16, 16);
+            cur = nxt; a += 16; f += 4;
+        }
     }
+    while (f < f1) { const unsigned b4 = unit(*reinterpret_cast<const unsigned *>(a)); if (EMIT) dfs_put(acc, b4, 4); a += 4; f++; }
+}
+
+// the stream's last bits: the last byte is padded with samples of value 0 (aukit.lua:1011-1016 hands the encoder whole bytes)
+AUKIT_DEV void dfx_tail(DfsAcc &acc, DfEnc &e, const unsigned char *rest = nullptr, unsigned nrest = 0) {
+    dfs_flush(acc);
+    // (rows kind: the `nrest` < 4 samples behind the last whole unit first)
+    for (unsigned k = 0; k < nrest; k++) { acc.bits |= (u64)(df_encode_u(e, (unsigned)rest[k] ^ 0x80u) & 1u) << acc.pos; acc.pos++; }
+    while (acc.pos & 7) { acc.bits |= (u64)(df_encode_u(e, 128u) & 1u) << acc.pos; acc.pos++; }
     for (unsigned k = 0; k < acc.pos; k += 8) *acc.o++ = (unsigned char)(acc.bits >> k);
     acc.pos = 0; acc.bits = 0;
+}
+// the tail of stream s where the stream ends at unit `fed` (transcode: nothing behind the last fed byte; rows: count % 4 samples)
+template <int KIND>
+AUKIT_DEV void dfx_stream_tail(const DfxParams &X, unsigned s, const unsigned char *p, u64 fed, DfsAcc &acc, DfEnc &e) {
+    if constexpr (KIND == 0) dfx_tail(acc, e);
+    else dfx_tail(acc, e, p + 4 * fed, (unsigned)(X.count[s] - 4 * fed));
 }
 
 AUKIT_DEV void dfx_store6(int *st, unsigned npad, const DfDec &d, const DfEnc &e) {
@@ -193,6 +225,7 @@ __global__ void k_dfx_decide(unsigned *flags, unsigned n) {
 }
 
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
+template <int KIND>
 __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     const DfParParams &P = X.P;
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
@@ -202,7 +235,7 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     DfDec d{};
     DfEnc e{};
     DfsAcc acc;
-    const unsigned char *lutc = X.lut + 128 * 257;
+    auto lutc = [&]() { if constexpr (KIND == 0) return X.lut + 128 * 257; else return DfeRows{}; }();
     dfx_span<false>(p, 0, f1, P.feed, d, e, lutc, acc);
     X.ctl[s] = 0;
     X.ctl[(size_t)X.npad + s] = dfs_pack(e);   // (at sample 4 f1: a multiple of 4, like every warm-up start — see k_dfx_chunks)
@@ -219,17 +252,26 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
         dfx_span<false>(p, f1, DFX_PROBE_FROM, P.feed, d, e, lutc, acc);
         DfEnc g;
         bool first = true;
-        fed_for_each(p, DFX_PROBE_FROM, DFX_PROBE_END, P.feed, [&](unsigned byte) {
-            const unsigned nb = ~byte;
+        if constexpr (KIND == 0) {
+            fed_for_each(p, DFX_PROBE_FROM, DFX_PROBE_END, P.feed, [&](unsigned byte) {
+                const unsigned nb = ~byte;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
-                const unsigned u = (unsigned)lutc[l * 256 + r];
+                for (int k = 0; k < 4; k++) {
+                    const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+                    const unsigned u = (unsigned)lutc[l * 256 + r];
+                    if (first) { g = dfx_guess(ref, u); first = false; }
+                    df_encode_u(e, u);
+                    df_encode_u(g, u);
+                }
+            });
+        } else {
+            for (u64 i = 4ull * DFX_PROBE_FROM; i < 4ull * DFX_PROBE_END; i++) {
+                const unsigned u = (unsigned)p[i] ^ 0x80u;
                 if (first) { g = dfx_guess(ref, u); first = false; }
                 df_encode_u(e, u);
                 df_encode_u(g, u);
             }
-        });
+        }
         if (dfs_pack(g) != dfs_pack(e)) atomicAdd(&X.flags[14], 1u);
         else if (ref.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
     }
@@ -250,7 +292,7 @@ AUKIT_DEV int *dfx_ck(const DfxParams &X, unsigned c, unsigned j, unsigned s) { 
 // (returns false; (d, e) = the end state, the stream's tail written when the stream ends here).
 // `min_iv` / `may_merge`: k_dfx_fix may have run this chunk before from a state that was not the true one — its bytes lie over the
 // chunk lane's in the first `min_iv` intervals (no merge counts before those are rewritten), or in all of them (`may_merge` false).
-template <typename LUT>
+template <int KIND, typename LUT>
 AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsigned char *p, u64 fed, DfDec &d, DfEnc &e, LUT lutc, unsigned &intervals,
                          unsigned min_iv = 0, bool may_merge = true, unsigned max_iv = 0xFFFFFFFFu, bool *gave_up = nullptr) {
     const DfParParams &P = X.P;
@@ -273,19 +315,22 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
     intervals++;
-    if (f1 == fed) dfx_tail(acc, e);
+    if (f1 == fed) dfx_stream_tail<KIND>(X, s, p, fed, acc, e);
     dfs_flush(acc);
     return false;
 }
 
 // a lane per (stream, chunk)
+template <int KIND>
 __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
     if (dfx_round_off(X)) return;
-    dfx_lut_to_lds(X.lut, lutu, 256);
-    __syncthreads();
-    const unsigned char *lutc = lutu + 128 * 257;  // indexed by signed (l, r)
+    if constexpr (KIND == 0) {
+        dfx_lut_to_lds(X.lut, lutu, 256);
+        __syncthreads();
+    }
+    auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)(lutu + 128 * 257); /* indexed by signed (l, r) */ else return DfeRows{}; }();
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
     if (c >= P.nchunk) return;
@@ -307,42 +352,49 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
             e = dfs_unpack(v[5]);
         }
     } else {
-        // warm-up over the block before the chunk: the decoder with its exact strength and previous bit, charge and filter from zero;
-        // after Wd bytes the encoder joins in
-        const u64 fw = f0 - P.W, fe = fw + X.Wd;
-        d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
-        d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
-        {   // At the strength floor the decoder's charge step is ±1 whatever the charge: an integrator of the bits, which forgets nothing
-            // — a warm-up from zero never arrives (digital silence: the bits alternate, the charge is off by its phase for good).  If the
-            // reference decoder sat at the floor too, its charge, filter and previous charge are the better start: the same 2-cycle.
-            const int rs = X.ctl[(size_t)3 * X.npad + s];
-            if (d.p.strength <= 9 && rs >= 0 && rs <= 9) {
-                d.p.n = X.ctl[(size_t)2 * X.npad + s];
-                d.lpf = X.ctl[(size_t)5 * X.npad + s];
-                d.pn = X.ctl[(size_t)6 * X.npad + s];
+        if constexpr (KIND == 1) {
+            // warm-up over the block before the chunk: a guess modelled on the reference (dfx_guess), charge on the block's first sample
+            const u64 fw = f0 - P.W;
+            e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), (unsigned)p[4 * fw] ^ 0x80u);
+            dfx_span<false>(p, fw, f0, P.feed, d, e, lutc, acc);
+        } else {
+            // warm-up over the block before the chunk: the decoder with its exact strength and previous bit, charge and filter from zero;
+            // after Wd bytes the encoder joins in
+            const u64 fw = f0 - P.W, fe = fw + X.Wd;
+            d.p.strength = P.s_start[(size_t)s * (P.nblk + 1) + c];
+            d.p.pb = fw ? (int)((p[dfp_src_index(fw - 1, P.feed)] >> 6) & 2) - 1 : -1;
+            {   // At the strength floor the decoder's charge step is ±1 whatever the charge: an integrator of the bits, which forgets nothing
+                // — a warm-up from zero never arrives (digital silence: the bits alternate, the charge is off by its phase for good).  If the
+                // reference decoder sat at the floor too, its charge, filter and previous charge are the better start: the same 2-cycle.
+                const int rs = X.ctl[(size_t)3 * X.npad + s];
+                if (d.p.strength <= 9 && rs >= 0 && rs <= 9) {
+                    d.p.n = X.ctl[(size_t)2 * X.npad + s];
+                    d.lpf = X.ctl[(size_t)5 * X.npad + s];
+                    d.pn = X.ctl[(size_t)6 * X.npad + s];
+                }
             }
-        }
-        DfOut O{};
-        O.feed = P.feed;
-        dfp_run<false>(p, fw, fe, d, O);
-        {   // the first byte of the encoder's warm-up by hand: its first mono sample is where the charge starts
-            const unsigned nb = ~(unsigned)p[dfp_src_index(fe, P.feed)];
-            unsigned u[4];
+            DfOut O{};
+            O.feed = P.feed;
+            dfp_run<false>(p, fw, fe, d, O);
+            {   // the first byte of the encoder's warm-up by hand: its first mono sample is where the charge starts
+                const unsigned nb = ~(unsigned)p[dfp_src_index(fe, P.feed)];
+                unsigned u[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
-                u[k] = (unsigned)lutc[l * 256 + r];
+                for (int k = 0; k < 4; k++) {
+                    const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
+                    u[k] = (unsigned)lutc[l * 256 + r];
+                }
+                // The guess is modelled on a true state of this stream (the reference: after the first samples, or where the verify pass
+                // last found the guesses failing): its strength and previous bit — the reference and every warm-up start sit at sample
+                // indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and the
+                // charge on the first sample.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at
+                // every step, and which of its two phases it is in is not a matter of class) is copied whole, charge included.
+                e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), u[0]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
             }
-            // The guess is modelled on a true state of this stream (the reference: after the first samples, or where the verify pass
-            // last found the guesses failing): its strength and previous bit — the reference and every warm-up start sit at sample
-            // indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and the
-            // charge on the first sample.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at
-            // every step, and which of its two phases it is in is not a matter of class) is copied whole, charge included.
-            e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), u[0]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
+            dfx_span<false>(p, fe + 1, f0, P.feed, d, e, lutc, acc);
         }
-        dfx_span<false>(p, fe + 1, f0, P.feed, d, e, lutc, acc);
     }
     dfx_store6(st, X.npad, d, e);
     acc.o = X.enc_out + X.ooff[s] + f0 / 2;  // four mono samples per fed byte, eight per output byte
@@ -355,7 +407,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
         b0 = b1;
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
-    if (f1 == fed) dfx_tail(acc, e);
+    if (f1 == fed) dfx_stream_tail<KIND>(X, s, p, fed, acc, e);
     dfs_flush(acc);
     dfx_store6(st + (size_t)6 * X.npad, X.npad, d, e);
 }
@@ -364,6 +416,7 @@ __global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
 // from that end state until the two runs merge — every mismatch of the batch at once, a few checkpoint intervals each, instead of one
 // after the other in the stream's verify lane.  (The end state of the chunk before is the true one unless that chunk failed itself and
 // did not merge: k_dfx_verify checks what this lane started from.)
+template <int KIND>
 __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
@@ -382,10 +435,12 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
         if (!need) X.fx[(size_t)c * 13 * X.npad + s] = 0;
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;
-    dfx_lut_to_lds(X.lut, lutu, 256);
-    __syncthreads();
+    if constexpr (KIND == 0) {
+        dfx_lut_to_lds(X.lut, lutu, 256);
+        __syncthreads();
+    }
     if (!need) return;
-    const unsigned char *lutc = lutu + 128 * 257;
+    auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)(lutu + 128 * 257); else return DfeRows{}; }();
     DfDec d;
     dfp_unpack(from, d);
     DfEnc e = dfs_unpack(from[5]);
@@ -393,7 +448,7 @@ __global__ __launch_bounds__(256) void k_dfx_fix(const DfxParams X) {
     // (another class: it never merges), and the verify lane has the rest of the stream speculated again.
     unsigned iv = 0;
     bool gave_up = false;
-    const bool merged = dfx_rerun(X, s, c, P.src + P.off[s], P.fed[s], d, e, lutc, iv, 0, true, X.fix_iv, &gave_up);
+    const bool merged = dfx_rerun<KIND>(X, s, c, P.src + P.off[s], P.fed[s], d, e, lutc, iv, 0, true, X.fix_iv, &gave_up);
     int *fx = X.fx + (size_t)c * 13 * X.npad + s;
     fx[0] = gave_up ? -(int)iv : (int)(iv << 1 | (merged ? 1u : 0u));  // (iv >= 1)
 #pragma unroll
@@ -472,22 +527,29 @@ __global__ __launch_bounds__(256) void k_dfx_move(const unsigned char *src, unsi
     for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < len; k += (u64)gridDim.x * 256) dst[d0 + k] = src[so + k];
 }
 
-// host side; *taken = false (nothing launched) when the batch is too short to be cut
-int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const u64 *d_ooff, const uint64_t *h_ooff, bool *taken) {
+// what the two front ends hand the planner
+struct DfxJob {
+    int kind;                          // 0: aukit.dfpwm(d, 2, rate):mono():dfpwm() on DFPWM bytes; 1: Audio:dfpwm on int8 samples
+    const unsigned char *src;          // the batch's bytes / the rows' buffer
+    std::vector<uint64_t> off, fed;    // [n] first byte of every stream; fed bytes / whole units of four samples
+    std::vector<uint64_t> count;       // kind 1: samples per stream
+    const aukit_batch *in = nullptr;   // kind 0: the batch (hard streams are gathered from it)
+    const u64 *d_in_off = nullptr, *d_count = nullptr;   // kind 1: the device tables the lane-per-stream encoder takes
+};
+int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const u64 *d_in_off, const u64 *d_count, uint32_t n, unsigned char *out, const u64 *d_ooff);  // dfpwm_par.hip
+
+// host side; *taken = false (nothing launched, or the probe declined: nothing written) when the batch is left to the older schedules
+static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u64 *d_ooff, const uint64_t *h_ooff, bool *taken) {
     *taken = false;
-    const uint32_t n = in->n;
+    const uint32_t n = (uint32_t)J.off.size();
     if (ctx->dfx_disable || ctx->dfx_off) return AUKIT_OK;
     // (the environment switches of the older schedules — tests and A/B runs — name those schedules: not this one)
     if (n == 0 || getenv("AUKIT_DFPWM_SERIAL") || getenv("AUKIT_DFPWM_NOSPEC") || getenv("AUKIT_DFPWM_FUSED") || getenv("AUKIT_DFPWM_SLICES") || getenv("AUKIT_DFPWM_BLOCK") ||
-        getenv("AUKIT_DFPWM_CHUNKS"))
+        getenv("AUKIT_DFPWM_CHUNKS") || getenv("AUKIT_DFPWM_ENC_SERIAL"))
         return AUKIT_OK;
-    std::vector<uint64_t> h_off(in->off.begin(), in->off.begin() + n), h_fed(n);
+    const std::vector<uint64_t> &h_off = J.off, &h_fed = J.fed;
     uint64_t fed_max = 0;
-    for (uint32_t s = 0; s < n; s++) {
-        const uint64_t nb = in->off[s + 1] - in->off[s];
-        h_fed[s] = nb ? nb + (nb + 6000 - 1) / 6000 - 1 : 0;  // 6001-byte slices advanced by 6000 (Q10)
-        fed_max = std::max(fed_max, h_fed[s]);
-    }
+    for (uint32_t s = 0; s < n; s++) fed_max = std::max(fed_max, h_fed[s]);
     unsigned We = 640, Wd = 64;  // fed bytes: 2560 mono samples of encoder warm-up behind 64 bytes of decoder-only warm-up
     if (const char *e = getenv("AUKIT_DFX_WE")) We = (unsigned)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("AUKIT_DFX_WD")) Wd = (unsigned)std::max(64, atoi(e)) & ~63u;
@@ -520,21 +582,23 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     const unsigned nck = bpc * (unsigned)(W / G) - 1;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_tab = take((size_t)n * 16), o_maps = take((size_t)n * nchunk * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
+    const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
                  o_ctl = take((size_t)9 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
     int rc = ctx->tmp_buf2.ensure(o + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
     if ((rc = h2d_table(ctx, B + o_tab, h_off.data(), (size_t)n * 8)) || (rc = h2d_table(ctx, B + o_tab + (size_t)n * 8, h_fed.data(), (size_t)n * 8))) return rc;
-    if (!ctx->dfx_lut.p) {
+    if (J.kind == 1 && (rc = h2d_table(ctx, B + o_tab + (size_t)n * 16, J.count.data(), (size_t)n * 8))) return rc;
+    if (J.kind == 0 && !ctx->dfx_lut.p) {
         if ((rc = ctx->dfx_lut.ensure(65536))) return rc;
         hipLaunchKernelGGL(k_dfx_lut, dim3(256), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned char *>(ctx->dfx_lut.p));
         AUKIT_HIP_CHECK(hipGetLastError());
     }
     DfxParams X{};
     DfParParams &P = X.P;
-    P.src = in->data(); P.off = reinterpret_cast<const u64 *>(B + o_tab); P.fed = P.off + n; P.feed = Feed{6001, 6000};
+    P.src = J.src; P.off = reinterpret_cast<const u64 *>(B + o_tab); P.fed = P.off + n; P.feed = Feed{6001, 6000};
+    X.count = P.off + 2 * (size_t)n;
     P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
     P.maps = reinterpret_cast<SatMap *>(B + o_maps); P.s_start = reinterpret_cast<int *>(B + o_ss);
     P.init = nullptr; P.mode = 1; P.C = 2;
@@ -542,7 +606,7 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     X.fix_iv = std::max<unsigned>(2, (unsigned)(W / G));  // a warm-up length
     X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.hard = reinterpret_cast<unsigned *>(B + o_hard);
     X.flags = reinterpret_cast<unsigned *>(B + o_fl);
-    X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);
+    X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);   // (kind 1: never read)
     X.enc_out = out; X.ooff = d_ooff;
     if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
     // The probe: one guess per stream is tried first, at the stream's start (0.3 ms of a lane per stream, one look at the outcome).  Where
@@ -553,20 +617,26 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     // (the prologue's 256 lone waves run on the side stream, beside the strength scan: the probe hides behind k_df_blockmaps)
     hipStream_t side = nullptr;
     if ((rc = ctx_side_fork(ctx, &side))) return rc;
-    hipLaunchKernelGGL(k_dfx_prologue, dim3((n + 63) / 64), dim3(64), 0, side, X);
+    if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 63) / 64), dim3(64), 0, side, X);
+    else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 63) / 64), dim3(64), 0, side, X);
     if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n);
-    if ((rc = dfpwm_strength_scan(ctx, P))) return rc;
+    if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
     if ((rc = ctx_side_join(ctx))) return rc;
     if (!ctx->dfx_attr_set) {
-        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         ctx->dfx_attr_set = true;
     }
     const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256));
     for (unsigned r = 0; r < rounds; r++) {
         X.round = r;
-        hipLaunchKernelGGL(k_dfx_chunks, grid, dim3(256), 65536, ctx->stream, X);
-        hipLaunchKernelGGL(k_dfx_fix, grid, dim3(256), 65536, ctx->stream, X);
+        if (J.kind == 0) {
+            hipLaunchKernelGGL(k_dfx_chunks<0>, grid, dim3(256), 65536, ctx->stream, X);
+            hipLaunchKernelGGL(k_dfx_fix<0>, grid, dim3(256), 65536, ctx->stream, X);
+        } else {
+            hipLaunchKernelGGL(k_dfx_chunks<1>, grid, dim3(256), 0, ctx->stream, X);
+            hipLaunchKernelGGL(k_dfx_fix<1>, grid, dim3(256), 0, ctx->stream, X);
+        }
         hipLaunchKernelGGL(k_dfx_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
         if (getenv("AUKIT_DFX_TRACE")) {  // (debugging: where the first streams stand after every round)
             int h[16] = {};
@@ -601,7 +671,16 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
         ctx->counters[AUKIT_COUNTER_DFPWM_HARD] = hs.size();
     }
     const unsigned m = (unsigned)hs.size();
-    if (m) {
+    if (m && J.kind == 1) {
+        // Hard streams of Audio:dfpwm: the lane-per-stream encoder takes any offsets — their table entries, gathered
+        std::vector<uint64_t> tab(3 * (size_t)m);
+        for (unsigned i = 0; i < m; i++) { tab[i] = J.off[hs[i]]; tab[m + i] = J.count[hs[i]]; tab[2 * (size_t)m + i] = h_ooff[hs[i]]; }
+        if ((rc = ctx->dfx_gather.ensure(tab.size() * 8 + 64))) return rc;
+        u64 *dtab = reinterpret_cast<u64 *>(ctx->dfx_gather.p);
+        if ((rc = h2d_table(ctx, dtab, tab.data(), tab.size() * 8))) return rc;
+        if ((rc = dfpwm_encode_i8(ctx, reinterpret_cast<const signed char *>(J.src), dtab, dtab + m, m, out, dtab + 2 * (size_t)m))) return rc;
+    } else if (m) {
+        const aukit_batch *in = J.in;
         // Hard streams — the encoder changes its class every few chunks (noise) or more often than there are rounds: the schedule with one
         // encoder lane per stream does not care.  Their bytes are gathered into a batch of their own, transcoded by
         // aukit_dfpwm_transcode_mono with this schedule switched off, and scattered to their places.
@@ -635,6 +714,31 @@ int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *o
     }
     *taken = true;
     return AUKIT_OK;
+}
+
+// aukit.dfpwm(d, 2, rate):mono():dfpwm() on a batch of DFPWM bytes (aukit_dfpwm_transcode_mono)
+int dfpwm_transcode_spec(aukit_ctx *ctx, const aukit_batch *in, unsigned char *out, const u64 *d_ooff, const uint64_t *h_ooff, bool *taken) {
+    DfxJob J;
+    J.kind = 0; J.src = in->data(); J.in = in;
+    J.off.assign(in->off.begin(), in->off.begin() + in->n);
+    J.fed.resize(in->n);
+    for (uint32_t s = 0; s < in->n; s++) {
+        const uint64_t nb = in->off[s + 1] - in->off[s];
+        J.fed[s] = nb ? nb + (nb + 6000 - 1) / 6000 - 1 : 0;  // 6001-byte slices advanced by 6000 (Q10)
+    }
+    return dfx_run(ctx, J, out, d_ooff, h_ooff, taken);
+}
+
+// Audio:dfpwm on int8 samples (aukit_dfpwm_encode behind k_dfpwm_quantize): rows at h_in_off (16-byte aligned), h_count samples each
+int dfpwm_encode_spec(aukit_ctx *ctx, const signed char *rows, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const u64 *d_ooff,
+                      const uint64_t *h_ooff, bool *taken) {
+    DfxJob J;
+    J.kind = 1; J.src = reinterpret_cast<const unsigned char *>(rows);
+    J.off.assign(h_in_off, h_in_off + n);
+    J.count.assign(h_count, h_count + n);
+    J.fed.resize(n);
+    for (uint32_t s = 0; s < n; s++) J.fed[s] = h_count[s] / 4;
+    return dfx_run(ctx, J, out, d_ooff, h_ooff, taken);
 }
 
 }  // namespace aukit

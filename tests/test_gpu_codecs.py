@@ -511,6 +511,7 @@ def test_dfpwm_parallel_encoder_small_batches(ctx, oracle, monkeypatch):
     sigs.append(sigs[0][:65536])
     sigs.append(sigs[3][:70003])
     ab = B.AudioBatch.upload(ctx, [[x] for x in sigs], 48000, dtype=N.F64)
+    monkeypatch.setenv("AUKIT_DFPWM_NOSPEC", "1")   # (the candidate search of round 3: since round 5 the chunk-speculative encoder comes first, tests/test_gpu_dfpwm_spec.py)
     got = B.dfpwm_encode(ctx, ab, True).download()
     assert ctx.last_kernel()[0] == "k_dfpwm_quantize+k_dfe_*", ctx.last_kernel()
     for x, g in zip(sigs, got):
@@ -522,6 +523,8 @@ def test_dfpwm_parallel_encoder_small_batches(ctx, oracle, monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         assert again == got, env
+    monkeypatch.delenv("AUKIT_DFPWM_NOSPEC")
+    assert B.dfpwm_encode(ctx, ab, True).download() == got   # the default schedule (probe, speculation or not): the same bytes
     # stereo, interleaved and channel after channel, through the same encoder
     st = [[sigs[0][:100000], sigs[3][:100000]]]
     ab2 = B.AudioBatch.upload(ctx, st, 48000, dtype=N.F64)

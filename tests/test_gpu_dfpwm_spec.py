@@ -121,3 +121,63 @@ def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):
         assert all(g == got[c] for g in got[c::K])
         assert got[c] == _ref(oracle, base[c])
     assert respec == 0 and redone <= chunks // 50, (chunks, redone, respec)
+
+
+ENC_ENVS = ({}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_G": "1"}, {"AUKIT_DFX_CHUNKS": "1000", "AUKIT_DFX_MIN_BPC": "1"}, {"AUKIT_DFX_ROUNDS": "1"},
+            {"AUKIT_DFX_WE": "128", "AUKIT_DFX_CHUNKS": "7", "AUKIT_DFX_ROUNDS": "2"}, {"AUKIT_DFX_WPS": "1", "AUKIT_DFX_WE": "1008"})
+
+
+def test_spec_encoder_audio_dfpwm(ctx, oracle, monkeypatch):
+    """Audio:dfpwm (aukit.lua:1005-1018) through the same engine on the quantized samples (k_dfx_chunks<rows>): signal, silence in front and inside,
+    noise, rails, lengths that are no multiple of 4 or 8 (the padded last byte), stereo interleaved and channel after channel — the oracle's bytes
+    under every schedule, and with the probe deciding"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(23))
+    n = 150001
+    t = np.arange(n) / 48000
+    gate = np.ones(n); gate[:30000] = 0; gate[80000:95000] = 0
+    sigs = [0.6 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.1, 0.1, n), (0.5 * np.sin(2 * np.pi * 330 * t) + rng.uniform(-0.2, 0.2, n)) * gate,
+            rng.uniform(-1, 1, n), np.where((np.arange(n) // 300) % 2 == 0, 1.0, -1.0), np.zeros(n), signal(n, 48000, 4, 3)[:n - 3], signal(70006, 48000, 4, 4), signal(37, 48000, 4, 5)]
+    ab = B.AudioBatch.upload(ctx, [[x] for x in sigs], 48000, dtype=N.F64)
+    want = [oracle.audio_dfpwm(oracle.Audio([x], 48000), True) for x in sigs]
+    monkeypatch.setenv("AUKIT_DFPWM_SERIAL", "1")
+    assert B.dfpwm_encode(ctx, ab, True).download() == want
+    monkeypatch.delenv("AUKIT_DFPWM_SERIAL")
+    for env in ENC_ENVS:
+        env = dict(env, AUKIT_DFX_NOPROBE="1")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = B.dfpwm_encode(ctx, ab, True).download()
+        name = ctx.last_kernel()[0]
+        for k in env:
+            monkeypatch.delenv(k)
+        assert name == "k_dfpwm_quantize+k_dfx_chunks<rows>", (env, name)
+        assert got == want, env
+    assert B.dfpwm_encode(ctx, ab, True).download() == want   # the probe's decision, whatever it is
+    st = [[sigs[0][:100003], sigs[1][:100003]], [sigs[5][:60000], sigs[0][:60000]]]
+    ab2 = B.AudioBatch.upload(ctx, st, 48000, dtype=N.F64)
+    for inter in (True, False):
+        monkeypatch.setenv("AUKIT_DFX_NOPROBE", "1")
+        got = B.dfpwm_encode(ctx, ab2, inter).download()
+        monkeypatch.delenv("AUKIT_DFX_NOPROBE")
+        assert ctx.last_kernel()[0] == "k_dfpwm_quantize+k_dfx_chunks<rows>"
+        for s in range(2):
+            assert got[s] == oracle.audio_dfpwm(oracle.Audio(st[s], 48000), inter), (inter, s)
+
+
+def test_spec_encoder_mid_batch(ctx, oracle):
+    """the regime between "a few streams" and "a group of 64 per CU" (Audio:dfpwm on a mid-size batch): 512 mono streams of 2 s, 8 distinct
+    signals — the oracle's bytes, class identity, and nearly every guess right"""
+    B, N = _B(), _N()
+    K = 8
+    base = [np.round(signal(96000, 48000, 4, 20 + i) * 100) / 127 for i in range(K)]
+    ab = B.AudioBatch.upload(ctx, [[base[i % K]] for i in range(512)], 48000, dtype=N.F64)
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    got = B.dfpwm_encode(ctx, ab, True).download()
+    assert ctx.last_kernel()[0] == "k_dfpwm_quantize+k_dfx_chunks<rows>"
+    chunks, redone, hard = (ctx.counter(c) for c in (N.COUNTER_DFPWM_CHUNKS, N.COUNTER_DFPWM_CHUNKS_REDONE, N.COUNTER_DFPWM_HARD))
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    for c in range(K):
+        assert all(g == got[c] for g in got[c::K])
+        assert got[c] == oracle.audio_dfpwm(oracle.Audio([base[c]], 48000), True)
+    assert hard == 0 and redone <= chunks // 50, (chunks, redone, hard)
