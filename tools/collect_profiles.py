@@ -47,8 +47,8 @@ for kernel, tag, pat, nstreams in DOMINANT:
                     "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)})
 # multi-launch workloads: HBM bytes of ONE step = every aukit kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over the run, divided by the number of
 # steps the run made = the dispatches of a kernel that is launched once per step (the anchor)
-STEPS = [("flac_pipeline", "flac", "k_flac_find", 2048), ("qoa_stream", "qoa", "k_qoa_wave", 4096), ("dfpwm_transcode", "dfpwm", "k_df_fused", 16384),
-         ("ima_pipeline", "imapipe", "onepole", 4096)]
+STEPS = [("flac_pipeline", "flac", "k_flac_find", 2048), ("flac_pipeline", "flac256", "k_flac_find", 256), ("qoa_stream", "qoa", "k_qoa_wave", 4096),
+         ("dfpwm_transcode", "dfpwm", "k_dfx_prologue<0>", 16384), ("dfpwm_transcode", "dfpwm2048", "k_dfx_prologue<0>", 2048), ("ima_pipeline", "imapipe", "onepole", 4096)]
 
 
 def step_traffic(tag, anchor):
@@ -60,6 +60,8 @@ def step_traffic(tag, anchor):
                 if not row.get(col):
                     continue
                 k = row["kernel"].replace("void ", "").replace("aukit::", "").split("(")[0][:60]
+                if tag.startswith("dfpwm") and any(x in k for x in ("k_pcm_unpack", "k_dfpwm_quantize", "k_dfpwm_encode_i8", "<1>", "k_dfx_lut")):
+                    continue   # the input is MADE by the product's encoder (bench.py DfpwmTranscode.setup): not part of a step
                 per[k] = per.get(k, 0.0) + float(row[col]) * mul
                 tot += float(row[col]) * mul
                 if anchor in row["kernel"]:
