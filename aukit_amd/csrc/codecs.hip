@@ -482,8 +482,83 @@ __global__ __launch_bounds__(64) void k_ima_rows(const ImaParams P) {
 // aukit.wav's IMA blocks (mode 0), one wave per (stream, channel, BLOCK) — round 4.  k_ima_rows walks a stream's blocks one after another: 4096
 // streams are 4096 waves for a chip that holds 8192 and wants far more to hide a wave's scan latencies (PMC: 18 % of the wave cycles active),
 // although every block starts from its own header (:1513-1545) and 220 blocks per stream wait to run side by side.
+#ifndef AUKIT_IMA_BPW
+#define AUKIT_IMA_BPW 8   // blocks a one-channel wave takes in turn (a wave per block — 901 120 workgroups for config 3b, each with its own table set-up — ran
+#endif                    // at the dispatcher's pace: 1.11 ms for 2.25 GB)
 __global__ __launch_bounds__(64) void k_ima_rows_blocks(const ImaParams P, unsigned max_blocks) {
     const int lane = threadIdx.x;
+    if (P.C == 1) {
+        // one channel (the shape of nearly every IMA WAV file): the lean chunk of stream.adpcm — two words per lane, the step table in LDS (indexed
+        // per lane a __constant__ array is a global load per nibble), no predicates; words past the block's end are zeros, and what they leave in
+        // (pred, idx) is never used: every block starts from its own header.  A lane's sixteen predictors leave as two 16-byte stores
+        // (rows start on 16-byte boundaries and a block of 512 B is 1016 samples = 127 x 16 bytes).  A wave takes AUKIT_IMA_BPW blocks of its
+        // stream in turn, the next block's words requested before this one's scans.
+        const unsigned per = (max_blocks + AUKIT_IMA_BPW - 1) / AUKIT_IMA_BPW;
+        const unsigned ji = blockIdx.x / per, bg = blockIdx.x - ji * per;
+        const ImaRowJob job = P.jobs[ji];
+        const unsigned long long ba = (unsigned long long)P.block_align;
+        const unsigned long long spb_full = (ba - 4ull) * 2;
+        __shared__ int steps[89];
+        for (int i = lane; i < 89; i += 64) steps[i] = c_ima_step[i];
+        __syncthreads();
+        typedef unsigned u32u __attribute__((aligned(1)));
+        struct Blk { unsigned w0, w1, hdr; unsigned long long nb; bool on; };
+        auto load = [&](unsigned bi) -> Blk {
+            Blk k{0u, 0u, 0u, 0ull, false};
+            const unsigned long long b0 = (unsigned long long)bi * ba;
+            if (bi >= max_blocks || b0 >= job.nbytes) return k;
+            const unsigned char *blk = P.src + job.src_off + b0;
+            const unsigned long long rem = job.nbytes - b0;
+            k.nb = rem < ba ? (rem > 4ull ? (rem - 4ull) * 2 : 0) : spb_full;   // str_sub is simply shorter (:1545)
+            k.on = true;
+            k.hdr = (unsigned)blk[0] | (unsigned)blk[1] << 8 | (unsigned)blk[2] << 16;
+            if (k.nb <= 1024) {   // (the usual block: one chunk — its words in flight while the block before is decoded)
+                const unsigned long long nw = (k.nb + 7) / 8;
+                k.w0 = 2ull * lane < nw ? *reinterpret_cast<const u32u *>(blk + 4 + 8 * lane) : 0u;
+                k.w1 = 2ull * lane + 1 < nw ? *reinterpret_cast<const u32u *>(blk + 4 + 8 * lane + 4) : 0u;
+            }
+            return k;
+        };
+        Blk cur = load(bg * AUKIT_IMA_BPW);
+        for (unsigned t = 0; t < AUKIT_IMA_BPW; t++) {
+            const unsigned bi = bg * AUKIT_IMA_BPW + t;
+            const Blk nxt = t + 1 < AUKIT_IMA_BPW ? load(bi + 1) : Blk{0u, 0u, 0u, 0ull, false};
+            if (!cur.on) break;
+            int pred = (short)(cur.hdr & 0xFFFFu);
+            int idx = (int)(cur.hdr >> 16);
+            if (P.mask_mono_index) idx &= 0x0F;              // :1544
+            if (idx > 88) { if (lane == 0) atomicCAS(P.err, 0, 2); cur = nxt; continue; }  // expect.range(step_index, 0, 88)
+            short *orow = P.out + job.out_off + (unsigned long long)bi * spb_full;
+            const unsigned char *wbase = P.src + job.src_off + (unsigned long long)bi * ba + 4;
+            const unsigned long long nb = cur.nb;
+            for (unsigned long long q0 = 0; q0 < nb; q0 += 1024) {
+                unsigned w0 = cur.w0, w1 = cur.w1;
+                if (nb > 1024) {   // (block sizes beyond 516 bytes: chunk by chunk, loaded where they are used)
+                    const unsigned long long nw = (nb - q0 + 7) / 8, wi = q0 / 8 + 2ull * lane;
+                    w0 = 2ull * lane < nw ? *reinterpret_cast<const u32u *>(wbase + 4 * wi) : 0u;
+                    w1 = 2ull * lane + 1 < nw ? *reinterpret_cast<const u32u *>(wbase + 4 * wi + 4) : 0u;
+                }
+                int pv[16];
+                ima_wave_chunk_full(w0, w1, steps, lane, pred, idx, [&](int k, int p) { pv[k] = p; });
+                const unsigned long long qa = q0 + 16ull * lane;
+                short *o = orow + qa;
+                if (qa + 16 <= nb && ((uintptr_t)o & 15) == 0) {
+                    uint4 a, b;
+                    a.x = (unsigned)(pv[0] & 0xFFFF) | (unsigned)pv[1] << 16; a.y = (unsigned)(pv[2] & 0xFFFF) | (unsigned)pv[3] << 16;
+                    a.z = (unsigned)(pv[4] & 0xFFFF) | (unsigned)pv[5] << 16; a.w = (unsigned)(pv[6] & 0xFFFF) | (unsigned)pv[7] << 16;
+                    b.x = (unsigned)(pv[8] & 0xFFFF) | (unsigned)pv[9] << 16; b.y = (unsigned)(pv[10] & 0xFFFF) | (unsigned)pv[11] << 16;
+                    b.z = (unsigned)(pv[12] & 0xFFFF) | (unsigned)pv[13] << 16; b.w = (unsigned)(pv[14] & 0xFFFF) | (unsigned)pv[15] << 16;
+                    reinterpret_cast<uint4 *>(o)[0] = a;
+                    reinterpret_cast<uint4 *>(o)[1] = b;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) if (qa + k < nb) o[k] = (short)pv[k];
+                }
+            }
+            cur = nxt;
+        }
+        return;
+    }
     const unsigned ji = blockIdx.x / max_blocks, bi = blockIdx.x - ji * max_blocks;
     const ImaRowJob job = P.jobs[ji];
     const unsigned long long ba = (unsigned long long)P.block_align, b0 = (unsigned long long)bi * ba;
@@ -493,44 +568,10 @@ __global__ __launch_bounds__(64) void k_ima_rows_blocks(const ImaParams P, unsig
     const unsigned char *blk = P.src + job.src_off + b0;
     const unsigned long long rem = job.nbytes - b0;
     unsigned long long nb = spb_full;
-    if (rem < ba) nb = rem > 4ull * P.C ? (rem - 4ull * P.C) * 2 / P.C : 0;  // mono: str_sub is simply shorter (:1545); stereo validated on the host
+    if (rem < ba) nb = rem > 4ull * P.C ? (rem - 4ull * P.C) * 2 / P.C : 0;  // stereo validated on the host
     int pred = (short)(blk[4 * job.c] | blk[4 * job.c + 1] << 8);
     int idx = blk[4 * job.c + 2];
-    if (P.C == 1 && P.mask_mono_index) idx &= 0x0F;              // :1544
     if (idx > 88) { if (lane == 0) atomicCAS(P.err, 0, 2); return; }  // expect.range(step_index, 0, 88)
-    if (P.C == 1) {
-        // one channel (the shape of nearly every IMA WAV file): the lean chunk of stream.adpcm — two words per lane, the step table in LDS (indexed
-        // per lane a __constant__ array is a global load per nibble), no predicates; words past the block's end are zeros, and what they leave in
-        // (pred, idx) is never used: every block starts from its own header.  A lane's sixteen predictors leave as two 16-byte stores
-        // (rows start on 16-byte boundaries and a block of 512 B is 1016 samples = 127 x 16 bytes).
-        __shared__ int steps[89];
-        for (int i = lane; i < 89; i += 64) steps[i] = c_ima_step[i];
-        __syncthreads();
-        typedef unsigned u32u __attribute__((aligned(1)));
-        const unsigned char *wbase = blk + 4;
-        for (unsigned long long q0 = 0; q0 < nb; q0 += 1024) {
-            const unsigned long long nw = (nb - q0 + 7) / 8, wi = q0 / 8 + 2ull * lane;   // words of this chunk that exist; this lane's first word
-            const unsigned w0 = 2ull * lane < nw ? *reinterpret_cast<const u32u *>(wbase + 4 * wi) : 0u;
-            const unsigned w1 = 2ull * lane + 1 < nw ? *reinterpret_cast<const u32u *>(wbase + 4 * wi + 4) : 0u;
-            int pv[16];
-            ima_wave_chunk_full(w0, w1, steps, lane, pred, idx, [&](int k, int p) { pv[k] = p; });
-            const unsigned long long qa = q0 + 16ull * lane;
-            short *o = orow + qa;
-            if (qa + 16 <= nb && ((uintptr_t)o & 15) == 0) {
-                uint4 a, b;
-                a.x = (unsigned)(pv[0] & 0xFFFF) | (unsigned)pv[1] << 16; a.y = (unsigned)(pv[2] & 0xFFFF) | (unsigned)pv[3] << 16;
-                a.z = (unsigned)(pv[4] & 0xFFFF) | (unsigned)pv[5] << 16; a.w = (unsigned)(pv[6] & 0xFFFF) | (unsigned)pv[7] << 16;
-                b.x = (unsigned)(pv[8] & 0xFFFF) | (unsigned)pv[9] << 16; b.y = (unsigned)(pv[10] & 0xFFFF) | (unsigned)pv[11] << 16;
-                b.z = (unsigned)(pv[12] & 0xFFFF) | (unsigned)pv[13] << 16; b.w = (unsigned)(pv[14] & 0xFFFF) | (unsigned)pv[15] << 16;
-                reinterpret_cast<uint4 *>(o)[0] = a;
-                reinterpret_cast<uint4 *>(o)[1] = b;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) if (qa + k < nb) o[k] = (short)pv[k];
-            }
-        }
-        return;
-    }
     NibSeq seq{blk + 4 * P.C, 0, P.C, job.c, 0, 1, 0};
     for (unsigned long long q0 = 0; q0 < nb; q0 += 1024)
         ima_wave_chunk(seq, q0, nb, lane, pred, idx, [&](unsigned long long q, int p) { orow[q] = (short)p; });
@@ -984,7 +1025,7 @@ static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_c
         uint64_t max_blocks = 0;
         if (wav) for (uint32_t s = 0; s < in->n; s++) max_blocks = std::max<uint64_t>(max_blocks, (in->off[s + 1] - in->off[s] + (uint64_t)d->block_align - 1) / (uint64_t)d->block_align);
         if (wav && max_blocks > 1 && (uint64_t)jobs.size() * max_blocks < (1ull << 31) && !getenv("AUKIT_IMA_ROWS_SERIAL"))
-            hipLaunchKernelGGL(k_ima_rows_blocks, dim3((unsigned)(jobs.size() * max_blocks)), dim3(64), 0, ctx->stream, P, (unsigned)max_blocks);
+            hipLaunchKernelGGL(k_ima_rows_blocks, dim3((unsigned)(jobs.size() * (C == 1 ? (max_blocks + AUKIT_IMA_BPW - 1) / AUKIT_IMA_BPW : max_blocks))), dim3(64), 0, ctx->stream, P, (unsigned)max_blocks);
         else hipLaunchKernelGGL(k_ima_rows, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, P);
         AUKIT_HIP_CHECK(hipGetLastError());
         if ((rc = ctx_end_kernel(ctx, "k_ima_rows", in->total() + tot * 2))) return rc;
