@@ -220,8 +220,8 @@ AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
 }
 
 // the probe's verdict, on the device (the host hears of it at the end of the call: nothing in between waits for the host)
-__global__ void k_dfx_decide(unsigned *flags, unsigned n) {
-    if ((unsigned long long)(flags[14] + flags[15]) * 16 > n) flags[6] = 1;
+__global__ void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_counts) {
+    if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n) flags[6] = 1;
 }
 
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
             later++;
             bad += X.fx[(size_t)k * 13 * X.npad + s] != 0 ? 1u : 0u;
         }
-        if (X.round + 1 >= X.rounds || strikes >= 2 || (later >= 4 && bad * 4 > later)) {
+        if (X.round + 1 >= X.rounds || strikes >= 3 || (later >= 12 && bad * 2 > later)) {
             X.ctl[s] = (int)P.nchunk + 1;
             X.hard[atomicAdd(&X.flags[13], 1u)] = s;
             return;
@@ -572,7 +572,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
     // into many chunks per stream, all of it again when it is cut into few (a large batch: none there).  Every passage of silence can cost
     // two (into it, out of it); streams that need more, or fail every few chunks, are "hard" and go to the lane-per-stream encoder.
-    unsigned rounds = nchunk >= 16 ? 4 : 1;
+    unsigned rounds = nchunk >= 24 ? 6 : (nchunk >= 16 ? 2 : 1);
     if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
     const unsigned npad = (unsigned)round_up(n, 64);
     // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~320 MB of them
@@ -619,7 +619,9 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     if ((rc = ctx_side_fork(ctx, &side))) return rc;
     if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 63) / 64), dim3(64), 0, side, X);
     else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 63) / 64), dim3(64), 0, side, X);
-    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n);
+    // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
+    // is cut into many chunks per stream; a batch with few chunks per stream declines them)
+    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
     if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
     if ((rc = ctx_side_join(ctx))) return rc;
     if (!ctx->dfx_attr_set) {

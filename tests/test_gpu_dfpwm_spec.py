@@ -99,7 +99,14 @@ def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
     ctx.set_option(N.OPT_COLLECT_STATS, 0)
     assert ctx.counter(N.COUNTER_DFPWM_CHUNKS) > 0
     assert ctx.counter(N.COUNTER_DFPWM_RESPECULATED) >= 1   # the gated streams left the floor in a class the prologue could not know
-    assert ctx.counter(N.COUNTER_DFPWM_HARD) >= 1           # the noise is given up on and goes to the lane-per-stream encoder
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    monkeypatch.setenv("AUKIT_DFX_NOPROBE", "1")
+    monkeypatch.setenv("AUKIT_DFX_ROUNDS", "1")   # no re-speculation: whatever the one round leaves is given up on and goes to the lane-per-stream encoder
+    assert B.dfpwm_transcode_mono(ctx, bt, 2).download() == want
+    monkeypatch.delenv("AUKIT_DFX_NOPROBE")
+    monkeypatch.delenv("AUKIT_DFX_ROUNDS")
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    assert ctx.counter(N.COUNTER_DFPWM_HARD) >= 1
     # by default one guess per stream is tried first (the probe), and on this input the batch is declined: the older schedule, the same bytes
     got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
     assert ctx.last_kernel()[0] != "k_dfx_chunks" and got == want

@@ -19,6 +19,8 @@ else:
         if kind == "gated":
             pcm[:, : 2 * 96000] = 0
             pcm[:, 2 * 240000: 2 * 288000] = 0
+        if kind == "lead":   # half a second of digital silence in front of the signal, and nothing else
+            pcm[:, : 2 * 24000] = 0
         pcm = pcm.reshape(-1).contiguous()
         torch.cuda.synchronize()
         bt = B.Batch.wrap(ctx, pcm.data_ptr(), [i * frames * 4 for i in range(k + 1)], keep=pcm)
