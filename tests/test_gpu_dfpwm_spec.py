@@ -107,8 +107,12 @@ def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
     monkeypatch.delenv("AUKIT_DFX_ROUNDS")
     ctx.set_option(N.OPT_COLLECT_STATS, 0)
     assert ctx.counter(N.COUNTER_DFPWM_HARD) >= 1
-    # by default one guess per stream is tried first (the probe), and on this input the batch is declined: the older schedule, the same bytes
+    # by default one guess per stream is tried first (the probe): whatever it decides, the same bytes; cut into few chunks per stream (what a large
+    # batch gets: a failed speculation would cost it a whole step) streams that start in silence count against the batch, and this one is declined
+    assert B.dfpwm_transcode_mono(ctx, bt, 2).download() == want
+    monkeypatch.setenv("AUKIT_DFX_CHUNKS", "7")
     got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    monkeypatch.delenv("AUKIT_DFX_CHUNKS")
     assert ctx.last_kernel()[0] != "k_dfx_chunks" and got == want
 
 
