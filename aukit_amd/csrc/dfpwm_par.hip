@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
     const unsigned blk = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)blk * P.n);
     if (blk >= P.nblk) return;
+    if (P.skip_last && blk + 1 == P.nblk) { P.maps[(size_t)s * P.nblk + blk] = SatMap{0, -(1 << 28), 1 << 28}; return; }
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
     const u64 e1 = dfp_chunk_start(P, blk + 1) - P.W;

@@ -85,6 +85,7 @@ struct DfParParams {
     signed char *out;
     const u64 *out_off, *out_stride;  // rows: element offset of channel 0 / channel stride per stream; mix: element offset per stream
     unsigned *stats;
+    unsigned skip_last;   // k_df_blockmaps: the last block's map is not wanted (nothing starts behind it): identity, its bytes are not read
     unsigned c_lo, c_hi;  // k_df_chunks / k_df_verify: the chunk indices [c_lo, c_hi) of every stream (a time slice of the batch)
 };
 
