@@ -854,3 +854,56 @@ def test_fuzz_dfpwm_parallel_encoder(ctx, oracle, seed, monkeypatch):
     print("encoder:", name)
     for s in range(nstreams):
         assert got[s] == oracle.audio_dfpwm(oracle.Audio(a[s], 48000), inter), (ch, nstreams, s, inter)
+
+
+def _fuzz_signal(rng, n):
+    """one channel of one of the characters the DFPWM encoder behaves differently on: tone + noise, silence with clicks, rail-to-rail squares, slow ramps,
+    noise bursts between digital silence, full-scale noise, signal behind / around stretches of digital silence"""
+    t = np.arange(n) / 48000
+    kind = int(rng.integers(0, 8))
+    if kind == 0:
+        x = rng.uniform(0.05, 0.9) * np.sin(2 * np.pi * rng.uniform(30, 9000) * t) + rng.uniform(-1, 1, n) * rng.uniform(0, 0.1)
+    elif kind == 1:
+        x = np.where(rng.uniform(0, 1, n) < 0.001, rng.uniform(-1, 1, n), 0.0)
+    elif kind == 2:
+        x = np.where((np.arange(n) // int(rng.integers(2, 5000))) % 2 == 0, 1.0, -1.0) * rng.choice([1.0, 0.5])
+    elif kind == 3:
+        x = np.linspace(-1, 1, n) * rng.choice([1.0, -1.0])
+    elif kind == 4:
+        x = (np.sin(2 * np.pi * rng.uniform(0.5, 5) * t) > 0.3).astype(np.float64) * rng.uniform(-1, 1, n) * rng.uniform(0.1, 1.0)
+    elif kind == 5:
+        x = rng.uniform(-1, 1, n) * rng.uniform(0.3, 1.0)
+    else:
+        x = 0.5 * np.sin(2 * np.pi * 440 * t) + rng.uniform(-0.25, 0.25, n)   # the config signal ...
+        for _ in range(int(rng.integers(1, 4))):                               # ... with stretches of digital silence
+            a = int(rng.integers(0, n)); x[a:a + int(rng.integers(100, n // 3 + 101))] = 0
+        if kind == 7:
+            x[: int(rng.integers(1, n // 2))] = 0
+    return np.clip(x, -1, 1)
+
+
+@pytest.mark.parametrize("seed", _seeds(10))
+def test_fuzz_dfpwm_speculation(ctx, oracle, seed, monkeypatch):
+    """the chunk-speculative engine (dfpwm_spec.hip) with the probe switched off — every batch is speculated on, whatever it holds — under random
+    schedules (warm-up length, chunks per stream, checkpoint spacing, rounds): Audio:dfpwm on 1 - 2 channels and the stereo -> mono -> DFPWM transcode of
+    what it made, bytes equal to the oracle's"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(15000 + seed))
+    env = {"AUKIT_DFX_NOPROBE": "1", "AUKIT_DFX_WE": str(int(rng.choice([64, 128, 384, 640, 960]))), "AUKIT_DFX_G": str(int(rng.choice([1, 2, 4]))),
+           "AUKIT_DFX_ROUNDS": str(int(rng.integers(1, 7))), "AUKIT_DFX_MIN_BPC": str(int(rng.integers(1, 5)))}
+    if rng.integers(0, 2):
+        env["AUKIT_DFX_CHUNKS"] = str(int(rng.choice([2, 5, 13, 40, 200, 1000])))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nstreams = int(rng.integers(1, 6))
+    ch = int(rng.integers(1, 3))
+    a = [[_fuzz_signal(rng, n) for _ in range(ch)] for n in (int(rng.choice([12000, 48001, 70003, int(rng.integers(20000, 200000))])) for _ in range(nstreams))]
+    inter = bool(rng.integers(0, 2))
+    enc = B.dfpwm_encode(ctx, B.AudioBatch.upload(ctx, a, 48000, dtype=N.F64), inter).download()
+    for s in range(nstreams):
+        assert enc[s] == oracle.audio_dfpwm(oracle.Audio(a[s], 48000), inter), ("encode", env, ch, nstreams, s, inter)
+    # the transcode of stereo DFPWM made from two such channels (byte counts whose samples divide by two: always)
+    st = [oracle.audio_dfpwm(oracle.Audio([_fuzz_signal(rng, n), _fuzz_signal(rng, n)], 48000), True) for n in (int(rng.integers(6000, 90000)) for _ in range(nstreams))]
+    got = B.dfpwm_transcode_mono(ctx, B.Batch.upload(ctx, st), 2).download()
+    for s in range(nstreams):
+        assert got[s] == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(st[s], 2, 48000)), True), ("transcode", env, s, len(st[s]))
