@@ -9,7 +9,7 @@
 //     thousand samples two encoders end in the same state IF they sit in the same class of the invariant
 //         I = (strength - 2 [previous bit = 0] - t) mod 4      (t = index of the next sample)
 //     which every step preserves unless the strength is clamped at 8 or 1023 (strength' = strength + b b', and
-//     b b' = 1 - 2 (q xor q') ≡ 1 + 2 q + 2 q' mod 4 with q = [bit = 0]).  Measured on the config-4 signal (CPU experiment,
+//     b b' = 1 - 2 (q xor q') ≡ 1 + 2 q + 2 q' mod 4 with q = [bit = 0]).  Measured on the config-4 signal (tools/experiments/,
 //     DESIGN.md §3.10): started from all 2032 (strength, previous bit) pairs, 2048 samples leave 4 distinct states — one per class;
 //     with the true class a single guess is right in 99.4 % (2048 samples) / 99.8 % (2560) / 99.99 % (4096) of the chunks;
 //   * the true encoder only ever clamps in its first samples on such input (strength starts at the floor), so the class it is in after

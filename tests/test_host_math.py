@@ -278,3 +278,39 @@ def test_config4_and_config5_flows_scatter_process_gather_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_dfpwm_encoder_class_invariant():
+    """what dfpwm_spec.hip's guesses rest on (its header): the DFPWM1a encoder's I = (strength - 2 [previous bit = 0] - t) mod 4 survives every step
+    that does not clamp the strength.  A Python restatement of the encoder step (checked against the oracle's bytes first) run over noise, a tone and
+    silence: the invariant holds on every unclamped step, and changes only where the strength was clamped at 8 or 1023."""
+    from oracle import oracle as O
+    rng = np.random.Generator(np.random.PCG64(42))
+    n = 6000
+    t = np.arange(n)
+    for x in (rng.integers(-128, 128, n), np.round(100 * np.sin(t * 0.05)).astype(np.int64), np.zeros(n, dtype=np.int64),
+              np.where((t // 700) % 2 == 0, np.round(90 * np.sin(t * 0.3)), 0).astype(np.int64)):
+        charge, strength, prev = 0, 0, False
+        bits, unclamped, kept, clamped, changed = [], 0, 0, 0, 0
+        for i, v in enumerate(x):
+            v = int(v)
+            inv_before = (strength - (0 if prev else 2) - i) % 4
+            bit = v > charge or (v == charge and v == 127)
+            target = 127 if bit else -128
+            nxt = charge + (strength * (target - charge) + 512) // 1024
+            if nxt == charge and nxt != target:
+                nxt += 1 if bit else -1
+            raw = strength + (1 if bit == prev else -1)
+            ns = min(max(raw, 8), 1023)
+            charge, strength, prev = nxt, ns, bit
+            bits.append(bit)
+            inv_after = (strength - (0 if prev else 2) - (i + 1)) % 4
+            if raw == ns:
+                unclamped += 1
+                kept += inv_after == inv_before
+            else:
+                clamped += 1
+                changed += inv_after != inv_before
+        by = bytes(sum(int(b) << k for k, b in enumerate(bits[j:j + 8])) for j in range(0, n, 8))
+        assert by == O.dfpwm_encode(x.astype(np.float64))   # the restatement is the oracle's encoder
+        assert kept == unclamped and changed == clamped, (unclamped, kept, clamped, changed)
