@@ -530,3 +530,27 @@ def test_dfpwm_parallel_encoder_small_batches(ctx, oracle, monkeypatch):
     ab2 = B.AudioBatch.upload(ctx, st, 48000, dtype=N.F64)
     for inter in (True, False):
         assert B.dfpwm_encode(ctx, ab2, inter).download()[0] == oracle.audio_dfpwm(oracle.Audio(st[0], 48000), inter)
+
+
+def test_dfpwm_chunk_decoder_in_digital_silence(ctx, oracle):
+    """DFPWM made from audio with stretches of digital silence (the idle pattern aukit.detect looks for, aukit.lua:2193 — 0x55 or 0xAA bytes, depending on
+    where the silence starts): the chunk-parallel decoder's warm-ups converge there as they do on signal (measured: one chunk per stream decoded again,
+    at a transition), the samples are the oracle's."""
+    B, N = _B(), _N()
+    n = 800000
+    streams = []
+    for k in range(6):   # silence from the first sample, from the second (the idle bytes are 0xAA in one case, 0x55 in the other), and inside the signal
+        x = np.round(signal(n, 48000, 4, 70 + k) * 100)
+        x[k % 2: n // 4 + k] = 0
+        x[n // 2 + 3 * k: n // 2 + n // 5] = 0
+        streams.append(oracle.dfpwm_encode(x))
+    assert any(b"\x55" * 64 in s for s in streams) and any(b"\xaa" * 64 in s for s in streams)
+    bt = B.Batch.upload(ctx, streams)
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    got = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F64).download()
+    chunks, redone = ctx.counter(N.COUNTER_DFPWM_CHUNKS), ctx.counter(N.COUNTER_DFPWM_CHUNKS_REDONE)
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    for i, d in enumerate(streams):
+        ref = oracle.dfpwm(d, 2, 48000)
+        assert np.array_equal(got[i][0], ref.data[0]) and np.array_equal(got[i][1], ref.data[1])
+    assert chunks > 10 and redone * 10 <= chunks, (chunks, redone)
