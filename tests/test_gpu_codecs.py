@@ -544,7 +544,7 @@ def test_dfpwm_chunk_decoder_in_digital_silence(ctx, oracle):
         x[k % 2: n // 4 + k] = 0
         x[n // 2 + 3 * k: n // 2 + n // 5] = 0
         streams.append(oracle.dfpwm_encode(x))
-    assert any(b"\x55" * 64 in s for s in streams) and any(b"\xaa" * 64 in s for s in streams)
+    assert all(b"\x55" * 64 in s or b"\xaa" * 64 in s for s in streams)
     bt = B.Batch.upload(ctx, streams)
     ctx.set_option(N.OPT_COLLECT_STATS, 1)
     got = B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F64).download()
