@@ -262,3 +262,60 @@ def _timed(fn):
     t0 = time.perf_counter()
     fn()
     return time.perf_counter() - t0
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_config4_and_config5_sharded_equal_single(ctx, oracle, world):
+    """BASELINE configs 4 and 5 are worded as 8-GPU jobs: cut by input bytes (shard.partition), every shard through its own context, outputs back in
+    rank order — the re-encoded DFPWM bytes (config 4: whatever the speculative transcoder's probe and rounds decide per shard, the bytes are the same) and
+    the mono rows of the FLAC chain (config 5) equal the unsharded call's, and the oracle's."""
+    from aukit_amd import _native as N
+    from aukit_amd import batch as B
+    from aukit_amd import shard
+    from tests.util import signal
+    # config 4: eleven stereo DFPWM streams of six lengths (one with digital silence in front)
+    st = []
+    for i, n in enumerate((30000, 6000, 18016, 6001, 24690, 30000, 12000, 45000, 6002, 9000, 30001)):
+        x = np.round(signal(8 * n, 48000, 4, 200 + i) * 100)
+        if i == 5:
+            x[: 8 * n // 3] = 0
+        st.append(oracle.dfpwm_encode(x))
+    whole = B.Batch.upload(ctx, st)
+    starts = whole.offsets().astype(np.int64)
+    single = B.dfpwm_transcode_mono(ctx, whole, 2).download()
+    for s, g in zip(st, single):
+        assert g == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(s, 2, 48000)), True)
+    got = []
+    for lo, hi in shard.partition([len(s) for s in st], world):
+        c2 = B.Context(0)
+        try:
+            bt = B.Batch.wrap(c2, whole.device_ptr() + int(starts[lo]), (starts[lo:hi + 1] - starts[lo]).astype(np.uint64), keep=whole)
+            got += B.dfpwm_transcode_mono(c2, bt, 2).download()
+        finally:
+            c2.close()
+    assert got == single
+    # config 5: five FLAC files through resample -> highpass -> normalize -> mono
+    fl = [oracle.gen_flac(np.stack([pcm16(n, 44100, 5, 300 + 2 * i + c) for c in range(2)], 1).astype(np.int64).ravel(), 2, 16, 44100, 1152) for i, n in enumerate((9000, 3000, 12001, 4608, 7000))]
+    whole = B.Batch.upload(ctx, fl)
+    starts = whole.offsets().astype(np.int64)
+
+    def chain(c, bt):
+        a = B.decode_resample(c, bt, B.make_desc(N.CODEC_FLAC), 48000, "cubic", dtype=N.F32)
+        B.effect(c, a, "highpass", 20.0)
+        B.effect(c, a, "normalize", 0.8)
+        return B.mono(c, a).download()
+
+    single = chain(ctx, whole)
+    for s, g in zip(fl, single):
+        ref = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(s), 48000, oracle.CUBIC), 20.0), 0.8)).data[0]
+        assert len(g[0]) == len(ref) and np.sqrt(np.mean((g[0] - ref) ** 2)) <= 1e-6
+    got = []
+    for lo, hi in shard.partition([len(s) for s in fl], world):
+        c2 = B.Context(0)
+        try:
+            if hi > lo:
+                bt = B.Batch.wrap(c2, whole.device_ptr() + int(starts[lo]), (starts[lo:hi + 1] - starts[lo]).astype(np.uint64), keep=whole)
+                got += chain(c2, bt)
+        finally:
+            c2.close()
+    assert len(got) == len(single) and all(np.array_equal(a[0], b[0]) for a, b in zip(got, single))
