@@ -578,7 +578,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~320 MB of them
     unsigned G = (unsigned)W / 4;
     while (G < W && (uint64_t)nchunk * (bpc * (W / G) - 1) * 24 * npad > (320ull << 20)) G *= 2;
-    if (const char *e = getenv("AUKIT_DFX_G")) { const unsigned k = (unsigned)std::max(1, atoi(e)); if (k <= 4 && (k & (k - 1)) == 0) G = (unsigned)W / k; }
+    if (const char *e = getenv("AUKIT_DFX_G")) { const unsigned k = (unsigned)std::max(1, atoi(e)); if (W % k == 0 && (W / k) % 16 == 0) G = (unsigned)W / k; }   // (whole 8-byte output rounds)
     const unsigned nck = bpc * (unsigned)(W / G) - 1;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };

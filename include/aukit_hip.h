@@ -214,10 +214,13 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out);       
 int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, double amplifier, aukit_audio **out);
 /* aukit.effects.<name>(audio, ...) in place :3356-3618 */
 int aukit_effect(aukit_ctx *ctx, aukit_audio *inout, int effect_id, const double *args, int nargs);
-/* Audio:dfpwm(interleaved) :1005 → one byte string per stream */
+/* Audio:dfpwm(interleaved) :1005-1018 → one byte string per stream.  Every stream is cut into time chunks that a lane each encodes from a guessed encoder
+ * state; a verify pass keeps only what follows from the true state and the rest is encoded again (dfpwm_spec.hip): the reference's bytes, whatever the
+ * batch size.  Raises (AUKIT_E_LUA) for an amplitude outside -128..127 like the cc.audio.dfpwm encoder.  Synchronises with the host before it returns. */
 int aukit_dfpwm_encode(aukit_ctx *ctx, const aukit_audio *in, int interleaved, aukit_batch **out);
-/* fused pipeline  aukit.dfpwm(data, channels, sr):mono():dfpwm()  (:1392, :677, :1005) — one lane per stream, the decoded
- * samples never leave registers.  Same bytes as aukit_decode(DFPWM) → aukit_mono → aukit_dfpwm_encode with AUKIT_F64. */
+/* fused pipeline  aukit.dfpwm(data, channels, sr):mono():dfpwm()  (:1392-1414, :677-689, :1005-1018; BASELINE config 4) — the decoded samples never
+ * leave the lane that decodes them.  Same bytes as aukit_decode(DFPWM) → aukit_mono → aukit_dfpwm_encode with AUKIT_F64.  channels == 2: a lane per
+ * (stream, time chunk) decodes, mixes and encodes (AUKIT_OPT_DFPWM_SPECULATE; one host synchronisation per call); other channel counts: a lane per stream. */
 int aukit_dfpwm_transcode_mono(aukit_ctx *ctx, const aukit_batch *in, int channels, aukit_batch **out);
 /* Audio:pcm(bitDepth, dataType, interleaved) :901 → unfloored numbers, packed per stream */
 int aukit_encode_pcm(aukit_ctx *ctx, const aukit_audio *in, int bit_depth, int data_type, int interleaved, aukit_audio **out);
