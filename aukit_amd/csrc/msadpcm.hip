@@ -1064,7 +1064,10 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         if ((size_t)nd * 64 * sst > 24 * 1024) sst = 0;                // strong up-sampling: the pair-mapped loop
     }
     wave = wave && spb_dec < (1u << 17) && newlen < (1u << 26);   // (the deferred-line records of k_ms_wave pack q0 and j into 17 and 26 bits)
-    const size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM, (((size_t)nd * 64 * sst + 7) & ~(size_t)7) + ((MS_RB == 16 && MS_FB_STREAM == 128) ? 0 : (size_t)MS_DL_CAP * 8)) : 0;
+    size_t lds = wave ? ms_lds_bytes(C, MS_RB, (unsigned)fb * wf, MS_FB_STREAM, (((size_t)nd * 64 * sst + 7) & ~(size_t)7) + ((MS_RB == 16 && MS_FB_STREAM == 128) ? 0 : (size_t)MS_DL_CAP * 8)) : 0;
+    // (A/B only: what a per-block staging row for whole output lines would cost in resident waves — unused bytes of LDS per workgroup,
+    // profiles/r05_msadpcm_lds_ab.txt)
+    if (const char *e = getenv("AUKIT_MS_EXTRA_LDS")) lds += (size_t)std::max(0, atoi(e));
     if (wave && lds <= 64 * 1024) {
         const int R = MS_RB * 2 / C, ndata = d->block_align - 7 * C, nr = (ndata + MS_RB - 1) / MS_RB;
         // tables: blk0 (n + 1) | out_off (n) | out_stride (n) | err | rounds (nr) | weights (fb * wf, f32)
