@@ -32,9 +32,9 @@ namespace aukit {
 // look-ups of a wave spent 70 % of their LDS cycles in bank conflicts — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02_dfpwm_pmc_lds.csv)
 __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     __shared__ unsigned bm[512];
-    for (int e = threadIdx.x; e < 512; e += 256) {
-        unsigned byte = e & 255;
-        int prev = e >> 8;
+    for (int e = threadIdx.x; e < 512; e += 256) {   // entry (byte << 1) | previous bit: nine consecutive bits of the stream
+        unsigned byte = (unsigned)e >> 1;
+        int prev = e & 1;
         SatMap f{0, -(1 << 28), 1 << 28};
         for (int k = 0; k < 8; k++) {
             const int bit = byte & 1;
@@ -42,17 +42,27 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             f = sm_then(f, SatMap{bit == prev ? 1 : -1, 8, 1023});
             prev = bit;
         }
-        bm[e] = (unsigned)(f.a + 8) | ((unsigned)(f.lo - 8) << 8) | ((unsigned)(1023 - f.hi) << 16);
+        bm[e] = (unsigned)f.lo | ((unsigned)f.hi << 12) | ((unsigned)f.a << 24);   // a field each, unbiased: lo & 0xFFF, bits 12..23, the top byte signed — three instructions a look-up (six with biased 5 / 4 / 4-bit fields)
     }
     __syncthreads();
     const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-    const unsigned blk = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)blk * P.n);
+    // a lane per (block, piece, stream): a large batch is cut into few chunks per stream — eight at 16 384 streams, two waves per SIMD if a block
+    // were one lane's, each walking 15 000 bytes behind its LDS look-ups
+    const unsigned F = P.msub ? P.msub : 1;
+    const unsigned bp = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)bp * P.n);
+    const unsigned blk = bp / F, sub = bp - blk * F;
     if (blk >= P.nblk) return;
-    if (P.skip_last && blk + 1 == P.nblk) { P.maps[(size_t)s * P.nblk + blk] = SatMap{0, -(1 << 28), 1 << 28}; return; }
+    SatMap *const dst = P.maps + ((size_t)s * P.nblk + blk) * F + sub;
+    if (P.skip_last && blk + 1 == P.nblk) { *dst = SatMap{0, -(1 << 28), 1 << 28}; return; }
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
     const u64 e1 = dfp_chunk_start(P, blk + 1) - P.W;
-    const u64 f0 = blk ? dfp_chunk_start(P, blk) - P.W : 0, f1 = e1 < fed ? e1 : fed;
+    u64 f0 = blk ? dfp_chunk_start(P, blk) - P.W : 0, f1 = e1 < fed ? e1 : fed;
+    if (F > 1 && f0 < f1) {   // pieces of whole 16-byte vectors
+        const u64 piece = (((f1 - f0 + F - 1) / F) + 15) & ~15ull;
+        f0 = f0 + sub * piece < f1 ? f0 + sub * piece : f1;
+        f1 = f0 + piece < f1 ? f0 + piece : f1;
+    }
     SatMap f{0, -(1 << 28), 1 << 28};
     if (f0 < f1) {
         int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
@@ -67,10 +77,21 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             }
             b = 1;
         }
+        auto look = [&](unsigned at4) {   // at4 = 4 * entry: the LDS byte address
+            const unsigned e = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(bm) + at4);
+            f = sm_then(f, SatMap{(int)e >> 24, (int)(e & 0xFFFu), (int)((e >> 12) & 0xFFFu)});
+        };
         auto step = [&](unsigned byte) {
-            const unsigned e = bm[(prev << 8) | byte];
-            f = sm_then(f, SatMap{(int)(e & 31u) - 8, 8 + (int)((e >> 8) & 15u), 1023 - (int)((e >> 16) & 15u)});
+            look((byte << 3) | ((unsigned)prev << 2));
             prev = byte >> 7;
+        };
+        // four bytes: the entries are nine-bit windows of the word (the first one borrows the bit before it), a shift and a mask each
+        auto step4 = [&](unsigned word) {
+            look(((word << 3) | ((unsigned)prev << 2)) & 0x7FCu);
+            look((word >> 5) & 0x7FCu);
+            look((word >> 13) & 0x7FCu);
+            look((word >> 21) & 0x7FCu);
+            prev = word >> 31;
         };
         // The usual block lies inside one run of the feed: 64 bytes per turn with the next 64 requested before these are looked at.  With one
         // 16-byte vector ahead (fed_for_each) a lane had 16 bytes in flight and the kernel moved 0.8 TB/s, waiting 66 % of its time.
@@ -104,9 +125,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
 #pragma unroll
 #endif
                     for (int w = 0; w < 4; w++) {
-                        const unsigned word = w4[w];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) step((word >> (8 * j)) & 0xFF);
+                        step4(w4[w]);
                     }
                 }
                 if (more) {
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             while (rem) { step((unsigned)*a); a++; rem--; }
         } else fed_for_each(p, b, f1, P.feed, step);
     }
-    P.maps[(size_t)s * P.nblk + blk] = f;
+    *dst = f;
 }
 
 __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
@@ -127,7 +146,12 @@ __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {
     int st = P.init ? P.init[(s % (unsigned)P.init_n) * 6 + 1] : 0;
     int *o = P.s_start + (size_t)s * (P.nblk + 1);
     o[0] = st;
-    for (unsigned b = 0; b < P.nblk; b++) { st = sm_apply(P.maps[(size_t)s * P.nblk + b], st); o[b + 1] = st; }
+    const unsigned F = P.msub ? P.msub : 1;
+    const SatMap *m = P.maps + (size_t)s * P.nblk * F;
+    for (unsigned b = 0; b < P.nblk; b++) {
+        for (unsigned j = 0; j < F; j++) st = sm_apply(m[(size_t)b * F + j], st);
+        o[b + 1] = st;
+    }
 }
 
 
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
 
 // the exact strength at every chunk's warm-up start (P.s_start), for planners outside this file (dfpwm_spec.hip)
 int dfpwm_strength_scan(aukit_ctx *ctx, const DfParParams &P) {
-    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)P.n * P.nblk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)P.n * P.nblk * (P.msub ? P.msub : 1) + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((P.n + 63) / 64), dim3(64), 0, ctx->stream, P);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;

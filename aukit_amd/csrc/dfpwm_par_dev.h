@@ -76,7 +76,7 @@ struct DfParParams {
     int init_n;         // states at `init`: stream s starts from state s % init_n (stream.mdfpwm: decoderL / decoderR alternate)
     const int *init;    // [init_n][6]: the state a stream's decoder starts from (a bounded reader-function handle's rest of a stream); null: the reset state
     u64 lead;           // rows mode, C == 1: elements to skip at the start of each row (stream.dfpwm's leading 0)
-    SatMap *maps;       // [n][nblk]
+    SatMap *maps;       // [n][nblk][msub]
     int *s_start;       // [n][nblk + 1] strength at block starts
     int *st_start, *st_end;  // [n][nchunk][6] decoder state after warm-up / at chunk end (n, strength, pb, lpf, pn, -: dfpwm_dev.h); strength -1 = no such chunk
     // output
@@ -86,6 +86,7 @@ struct DfParParams {
     const u64 *out_off, *out_stride;  // rows: element offset of channel 0 / channel stride per stream; mix: element offset per stream
     unsigned *stats;
     unsigned skip_last;   // k_df_blockmaps: the last block's map is not wanted (nothing starts behind it): identity, its bytes are not read
+    unsigned msub;        // k_df_blockmaps / k_df_blockscan: lanes per map block (0 = 1): `maps` is [n][nblk][msub], a block's bytes cut into msub pieces
     unsigned c_lo, c_hi;  // k_df_chunks / k_df_verify: the chunk indices [c_lo, c_hi) of every stream (a time slice of the batch)
 };
 

@@ -38,6 +38,9 @@ AUKIT_DEV DfEnc dfs_unpack(int v) { DfEnc e; e.cu = v & 255; e.strength = (v >> 
 
 constexpr unsigned DFX_PROBE_FROM = 256, DFX_PROBE_END = 768;  // fed bytes: the probe's guess warms up over 512 of them (2048 mono samples: on the config-4
                                                                  // signal 0.6 % of such guesses miss; the batch is declined at 6 %)
+#ifndef AUKIT_DFX_WG
+#define AUKIT_DFX_WG 256   // threads of a chunk-lane workgroup (one 64 KiB mix table each: two workgroups per CU)
+#endif
 constexpr unsigned DFX_X0 = 128;  // fed bytes (512 mono samples) the prologue runs from the reset state to learn the encoder's class
 
 struct DfxParams {
@@ -322,16 +325,16 @@ AUKIT_DEV bool dfx_rerun(const DfxParams &X, unsigned s, unsigned c, const unsig
 
 // a lane per (stream, chunk)
 template <int KIND>
-__global__ __launch_bounds__(256) void k_dfx_chunks(const DfxParams X) {
+__global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
     if (dfx_round_off(X)) return;
     if constexpr (KIND == 0) {
-        dfx_lut_to_lds(X.lut, lutu, 256);
+        dfx_lut_to_lds(X.lut, lutu, AUKIT_DFX_WG);
         __syncthreads();
     }
     auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)(lutu + 128 * 257); /* indexed by signed (l, r) */ else return DfeRows{}; }();
-    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * AUKIT_DFX_WG + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
     if (c >= P.nchunk) return;
     const unsigned c_from = X.round ? (unsigned)X.ctl[s] : 0u;
@@ -582,7 +585,11 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     const unsigned nck = bpc * (unsigned)(W / G) - 1;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
+    // the strength scan's lanes: a map block (the bytes between two chunks' warm-up starts) cut into pieces until four waves per SIMD walk them
+    unsigned msub = 1;
+    while (msub < 16 && (uint64_t)n * nchunk * msub < (uint64_t)ctx->num_cus * 4 * 64 * 4 && (uint64_t)bpc * W / (2 * msub) >= 1024) msub *= 2;
+    if (const char *e = getenv("AUKIT_DFX_MSUB")) msub = (unsigned)std::max(1, std::min(atoi(e), 64));
+    const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * msub * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
                  o_ctl = take((size_t)9 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
     int rc = ctx->tmp_buf2.ensure(o + 256);
@@ -602,6 +609,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     P.n = n; P.nblk = nchunk; P.bpc = bpc; P.nchunk = nchunk; P.W = W;
     P.maps = reinterpret_cast<SatMap *>(B + o_maps); P.s_start = reinterpret_cast<int *>(B + o_ss);
     P.init = nullptr; P.mode = 1; P.C = 2;
+    P.msub = msub;
     P.skip_last = 1;   // (the strength behind the last chunk's start is nobody's warm-up: an eighth of the scan's bytes for a batch cut into eight chunks)
     X.Wd = Wd; X.npad = npad; X.rounds = rounds; X.G = G; X.nck = nck;
     X.fix_iv = std::max<unsigned>(2, (unsigned)(W / G));  // a warm-up length
@@ -630,7 +638,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         ctx->dfx_attr_set = true;
     }
-    const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256));
+    const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256)), cgrid((unsigned)(((size_t)n * nchunk + AUKIT_DFX_WG - 1) / AUKIT_DFX_WG));
     // Rounds are queued two at a time with a look at the counters behind each pair (the first look is the call's one host synchronisation on signal:
     // the later rounds of a finely cut batch exist for streams with passages of silence, and queued blind they cost a batch of plain signal a dozen
     // empty launches, 0.12 ms of a 2.8 ms step)
@@ -639,10 +647,10 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
         for (unsigned r = r0; r < std::min(rounds, r0 + 2); r++) {
             X.round = r;
             if (J.kind == 0) {
-                hipLaunchKernelGGL(k_dfx_chunks<0>, grid, dim3(256), 65536, ctx->stream, X);
+                hipLaunchKernelGGL(k_dfx_chunks<0>, cgrid, dim3(AUKIT_DFX_WG), 65536, ctx->stream, X);
                 hipLaunchKernelGGL(k_dfx_fix<0>, grid, dim3(256), 65536, ctx->stream, X);
             } else {
-                hipLaunchKernelGGL(k_dfx_chunks<1>, grid, dim3(256), 0, ctx->stream, X);
+                hipLaunchKernelGGL(k_dfx_chunks<1>, cgrid, dim3(AUKIT_DFX_WG), 0, ctx->stream, X);
                 hipLaunchKernelGGL(k_dfx_fix<1>, grid, dim3(256), 0, ctx->stream, X);
             }
             hipLaunchKernelGGL(k_dfx_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, X);
