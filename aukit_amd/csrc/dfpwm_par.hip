@@ -387,6 +387,12 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     if (sliced) want *= (unsigned)hook->slices;
     if (const char *e = getenv("AUKIT_DFPWM_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
     unsigned bpc = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, getenv("AUKIT_DFPWM_CHUNKS") ? 1u : 6u);  // warm-up (1 block) <= 1/6 of a chunk
+    // ... for a batch that fills the chip.  A few streams leave most SIMDs idle and the launch takes the time of ONE lane: short chunks then,
+    // whatever their warm-up share (one stream of ten seconds: 40 lanes of 7 blocks, 1.24 ms; 235 lanes of 2 blocks, a third of it) — the
+    // shortest that keeps the lanes under 3/4 of a wave per SIMD
+    if (!getenv("AUKIT_DFPWM_CHUNKS") && !getenv("AUKIT_DFPWM_BPC_MIN6"))
+        for (unsigned b = std::max<unsigned>(nblk ? (nblk + want - 1) / want : 1, 1); b < 6; b++)
+            if ((uint64_t)n * ((nblk + b - 1) / b) * 4 <= (uint64_t)ctx->num_cus * 4 * 64 * 3) { bpc = b; break; }
     const unsigned nchunk = nblk ? (nblk + bpc - 1) / bpc : 0;
     if (n == 0 || nchunk < 2 || getenv("AUKIT_DFPWM_SERIAL")) return false;
     // scratch: stream table, maps, strengths, states, stats

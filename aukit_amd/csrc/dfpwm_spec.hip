@@ -57,6 +57,8 @@ struct DfxParams {
                             //   the state it started from (6), the end state it reached (6, status 2)
     int *ctl;               // [9][npad]: first chunk not final yet (nchunk: done, nchunk + 1: given up — a "hard" stream); the reference encoder state the
                             //   chunk lanes model their guess on (packed); the true state (5 + 1) where that chunk starts; strikes
+    int *pst;               // [6][npad] k_dfx_prologue, `phase` 1 -> 2: the true state at DFX_X0 (the decoder's five words, the encoder's one)
+    unsigned phase;         // k_dfx_prologue: 0 reference and probe in one launch; 1 the reference only; 2 the probe, from `pst`
     unsigned *hard;         // [npad] the hard streams (flags[13] of them): left to the lane-per-stream encoder (host side)
     unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [13] hard streams
     const unsigned char *lut;  // [65536] mono + 128 for (l + 128) * 256 + (r + 128): the reference's fp64 mix (dfp_mix), in global memory
@@ -218,8 +220,11 @@ __global__ __launch_bounds__(256) void k_dfx_lut(unsigned char *lut) {
 AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
     if (__hip_atomic_load(&X.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;   // the probe declined the batch
     if (X.round == 0) return false;
-    return !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-           2 * __hip_atomic_load(&X.flags[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > X.P.n;
+    // ... nor once more streams are hard than the exact parallel encoder takes (16): the lane-per-stream schedule will run then, and it takes
+    // its 12 ms for one stream or for all that are left — every further round is time on top (64 noise-like streams that got past the probe:
+    // six rounds and a fallback for the half of them given up on, 28 ms; 15 with this)
+    const unsigned hard = __hip_atomic_load(&X.flags[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return !__hip_atomic_load(&X.flags[X.round - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || 2 * hard > X.P.n || hard > 16;
 }
 
 // the probe's verdict, on the device (the host hears of it at the end of the call: nothing in between waits for the host)
@@ -227,10 +232,24 @@ __global__ void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_count
     if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n) flags[6] = 1;
 }
 
+// copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
+AUKIT_DEV void dfx_lut_to_lds(const unsigned char *g, unsigned char *l, unsigned nthreads) {
+    const uint4 *gv = reinterpret_cast<const uint4 *>(g);
+    uint4 *lv = reinterpret_cast<uint4 *>(l);
+    for (unsigned i = threadIdx.x; i < 4096; i += nthreads) lv[i] = gv[i];
+}
+
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
 template <int KIND>
 __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
+    extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
+    // (the mix table in LDS here too: a lone lane per stream waits for every look-up, and one in global memory is an L2 round trip —
+    // 0.39 ms of prologue and probe for ONE stream, most of it those)
+    if constexpr (KIND == 0) {
+        dfx_lut_to_lds(X.lut, lutu, 64);
+        __syncthreads();
+    }
     const unsigned s = blockIdx.x * 64 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
@@ -238,15 +257,28 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     DfDec d{};
     DfEnc e{};
     DfsAcc acc;
-    auto lutc = [&]() { if constexpr (KIND == 0) return X.lut + 128 * 257; else return DfeRows{}; }();
-    dfx_span<false>(p, 0, f1, P.feed, d, e, lutc, acc);
-    X.ctl[s] = 0;
-    X.ctl[(size_t)X.npad + s] = dfs_pack(e);   // (at sample 4 f1: a multiple of 4, like every warm-up start — see k_dfx_chunks)
-    {
+    auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)lutu + 128 * 257; else return DfeRows{}; }();
+    if (X.phase != 2) {
+        dfx_span<false>(p, 0, f1, P.feed, d, e, lutc, acc);
+        X.ctl[s] = 0;
+        X.ctl[(size_t)X.npad + s] = dfs_pack(e);   // (at sample 4 f1: a multiple of 4, like every warm-up start — see k_dfx_chunks)
         int v[6];
         dfp_pack(d, v);
 #pragma unroll
         for (int i = 0; i < 5; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = v[i];   // the decoder's side of the reference
+        X.ctl[(size_t)8 * X.npad + s] = 0;
+        if (X.phase == 1) {   // (the control block is the verify pass's from here on: the probe continues from a copy)
+#pragma unroll
+            for (int i = 0; i < 5; i++) X.pst[(size_t)i * X.npad + s] = v[i];
+            X.pst[(size_t)5 * X.npad + s] = dfs_pack(e);
+            return;
+        }
+    } else {
+        int v[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = X.pst[(size_t)i * X.npad + s];
+        dfp_unpack(v, d);
+        e = dfs_unpack(v[5]);
     }
     if (X.probe && fed >= DFX_PROBE_END) {
         // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on to DFX_PROBE_END, and from
@@ -278,14 +310,6 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
         if (dfs_pack(g) != dfs_pack(e)) atomicAdd(&X.flags[14], 1u);
         else if (ref.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
     }
-    X.ctl[(size_t)8 * X.npad + s] = 0;
-}
-
-// copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
-AUKIT_DEV void dfx_lut_to_lds(const unsigned char *g, unsigned char *l, unsigned nthreads) {
-    const uint4 *gv = reinterpret_cast<const uint4 *>(g);
-    uint4 *lv = reinterpret_cast<uint4 *>(l);
-    for (unsigned i = threadIdx.x; i < 4096; i += nthreads) lv[i] = gv[i];
 }
 
 AUKIT_DEV int *dfx_ck(const DfxParams &X, unsigned c, unsigned j, unsigned s) { return X.ck + (((size_t)c * X.nck + j) * 6) * X.npad + s; }
@@ -540,6 +564,7 @@ struct DfxJob {
     const u64 *d_in_off = nullptr, *d_count = nullptr;   // kind 1: the device tables the lane-per-stream encoder takes
 };
 int dfpwm_encode_i8(aukit_ctx *ctx, const signed char *in, const u64 *d_in_off, const u64 *d_count, uint32_t n, unsigned char *out, const u64 *d_ooff);  // dfpwm_par.hip
+bool dfpwm_encode_i8_small(aukit_ctx *ctx, const signed char *in, const uint64_t *h_in_off, const uint64_t *h_count, uint32_t n, unsigned char *out, const uint64_t *h_ooff, int *rc);  // dfpwm_par.hip: k_dfe_*, up to 16 streams
 
 // host side; *taken = false (nothing launched, or the probe declined: nothing written) when the batch is left to the older schedules
 static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u64 *d_ooff, const uint64_t *h_ooff, bool *taken) {
@@ -551,8 +576,16 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
         getenv("AUKIT_DFPWM_CHUNKS") || getenv("AUKIT_DFPWM_ENC_SERIAL"))
         return AUKIT_OK;
     const std::vector<uint64_t> &h_off = J.off, &h_fed = J.fed;
-    uint64_t fed_max = 0;
-    for (uint32_t s = 0; s < n; s++) fed_max = std::max(fed_max, h_fed[s]);
+    uint64_t fed_max = 0, fed_sum = 0;
+    for (uint32_t s = 0; s < n; s++) { fed_max = std::max(fed_max, h_fed[s]); fed_sum += h_fed[s]; }
+    // A FEW SHORT streams (the reference's own use: one song) stay with the exact parallel encoder k_dfe_* (dfpwm_par.hip): it takes the same
+    // 0.7 ms (Audio:dfpwm) / 1.3 ms (transcode) for ten seconds of anything, where a round of this schedule costs a lone lane's time — 0.4 / 1.3 ms
+    // for clean signal, but one more round for silence in front, four for two passages of it, six and a fallback for noise
+    // (profiles/r05_small_batches.txt: one stream 0.35 - 1.3 / 2.2 - 10 ms; four 0.85 - 2.0 / 1.2 - 12.9).  From about forty stream-seconds on
+    // the candidate search's 500-fold work costs more than the rounds do.
+    uint64_t few = 500000;   // fed bytes of the batch (stereo transcode; units of four samples for Audio:dfpwm): four ten-second streams
+    if (const char *e = getenv("AUKIT_DFX_FEW")) few = strtoull(e, nullptr, 10);
+    if (n <= 16 && fed_sum <= few) return AUKIT_OK;
     unsigned We = 640, Wd = 64;  // fed bytes: 2560 mono samples of encoder warm-up behind 64 bytes of decoder-only warm-up
     if (const char *e = getenv("AUKIT_DFX_WE")) We = (unsigned)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("AUKIT_DFX_WD")) Wd = (unsigned)std::max(64, atoi(e)) & ~63u;
@@ -562,14 +595,24 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     const uint64_t lanes = (uint64_t)ctx->num_cus * 4 * 64 * wps;
     unsigned want = (unsigned)std::max<uint64_t>(1, (lanes + n - 1) / n);
     if (const char *e = getenv("AUKIT_DFX_CHUNKS")) want = (unsigned)std::max(1, atoi(e));
-    unsigned min_bpc = 3;
+    unsigned min_bpc = 0;   // 0: chosen below
     if (const char *e = getenv("AUKIT_DFX_MIN_BPC")) min_bpc = (unsigned)std::max(1, atoi(e));
     // long chunks (a large batch) can afford a longer encoder warm-up: 3840 mono samples, one guess in ~5000 misses instead of one in 500 —
     // and every miss costs the step the time of a checkpoint interval in k_dfx_fix
     if (!getenv("AUKIT_DFX_WE") && (fed_max + 703) / 704 >= 16 * (uint64_t)want) We = 960;
     const uint64_t W = (uint64_t)We + Wd;  // a multiple of 64: checkpoint intervals of W / 4 are whole 8-byte output rounds
     const unsigned nblk_all = (unsigned)((fed_max + W - 1) / W);
-    const unsigned bpc = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, min_bpc);
+    // blocks per chunk: a lane walks bpc + 1 blocks, one of them warm-up.  A batch that fills the chip wants the warm-up small (three blocks: a
+    // quarter of a lane's work); a small one is better off with short chunks on SIMDs that would idle — the step takes the time of one lane, and
+    // so does every further round.  Measured (profiles/r05_small_batches.txt): one block per chunk while the lanes stay under 3/4 of a wave per
+    // SIMD, two likewise, else three.
+    const unsigned b0 = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, 1);
+    unsigned bpc = std::max(b0, min_bpc ? min_bpc : 3u);
+    bool small = false;   // most SIMDs idle: one pass of the chunk lanes is a small fraction of what the older schedules take
+    if (!min_bpc)
+        for (unsigned b = b0; b < 3; b++)
+            if ((uint64_t)n * ((nblk_all + b - 1) / b) * 4 <= (uint64_t)ctx->num_cus * 4 * 64 * 3) { bpc = b; small = true; break; }
+    if (const char *e = getenv("AUKIT_DFX_PROBE_ASIDE")) small = atoi(e) != 0;
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
     // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
@@ -591,7 +634,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     if (const char *e = getenv("AUKIT_DFX_MSUB")) msub = (unsigned)std::max(1, std::min(atoi(e), 64));
     const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * msub * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
-                 o_ctl = take((size_t)9 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
+                 o_ctl = take((size_t)9 * npad * 4), o_pst = take((size_t)6 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
     int rc = ctx->tmp_buf2.ensure(o + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
@@ -613,7 +656,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     P.skip_last = 1;   // (the strength behind the last chunk's start is nobody's warm-up: an eighth of the scan's bytes for a batch cut into eight chunks)
     X.Wd = Wd; X.npad = npad; X.rounds = rounds; X.G = G; X.nck = nck;
     X.fix_iv = std::max<unsigned>(2, (unsigned)(W / G));  // a warm-up length
-    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.hard = reinterpret_cast<unsigned *>(B + o_hard);
+    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.pst = reinterpret_cast<int *>(B + o_pst); X.hard = reinterpret_cast<unsigned *>(B + o_hard);
     X.flags = reinterpret_cast<unsigned *>(B + o_fl);
     X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);   // (kind 1: never read)
     X.enc_out = out; X.ooff = d_ooff;
@@ -624,19 +667,32 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // per stream, a whole step for a gain of a quarter).  What the probe cannot see — silence or noise later in the streams — costs rounds.
     X.probe = getenv("AUKIT_DFX_NOPROBE") ? 0u : 1u;
     // (the prologue's 256 lone waves run on the side stream, beside the strength scan: the probe hides behind k_df_blockmaps)
-    hipStream_t side = nullptr;
-    if ((rc = ctx_side_fork(ctx, &side))) return rc;
-    if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 63) / 64), dim3(64), 0, side, X);
-    else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 63) / 64), dim3(64), 0, side, X);
-    // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
-    // is cut into many chunks per stream; a batch with few chunks per stream declines them)
-    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
-    if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
-    if ((rc = ctx_side_join(ctx))) return rc;
     if (!ctx->dfx_attr_set) {
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_fix<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_prologue<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         ctx->dfx_attr_set = true;
+    }
+    hipStream_t side = nullptr;
+    if ((rc = ctx_side_fork(ctx, &side))) return rc;
+    // A small batch does not wait for the probe: the chunk lanes need the reference only (512 samples of a lone lane, not 3072), the probe runs
+    // beside them, and a batch it declines has lost one pass of chunk lanes — 0.3 ms and more off every call on signal, under a tenth on
+    // top of what a declined batch costs in the older schedules.  A large batch (a pass there is most of a step) asks first.
+    const bool aside = small && X.probe;
+    auto prologue = [&](unsigned phase) {
+        X.phase = phase;
+        if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 63) / 64), dim3(64), 65536, side, X);
+        else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 63) / 64), dim3(64), 0, side, X);
+    };
+    prologue(aside ? 1u : 0u);
+    // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
+    // is cut into many chunks per stream; a batch with few chunks per stream declines them)
+    if (X.probe && !aside) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
+    if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
+    if ((rc = ctx_side_join(ctx))) return rc;
+    if (aside) {   // (the side stream again, behind the reference; joined before the host's first look at the flags)
+        prologue(2u);
+        hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
     }
     const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256)), cgrid((unsigned)(((size_t)n * nchunk + AUKIT_DFX_WG - 1) / AUKIT_DFX_WG));
     // Rounds are queued two at a time with a look at the counters behind each pair (the first look is the call's one host synchronisation on signal:
@@ -667,6 +723,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
             }
         }
         AUKIT_HIP_CHECK(hipGetLastError());
+        if (aside && r0 == 0 && (rc = ctx_side_join(ctx))) return rc;
         AUKIT_HIP_CHECK(hipMemcpyAsync(h, X.flags, 64, hipMemcpyDeviceToHost, ctx->stream));
         AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const unsigned last = std::min(rounds, r0 + 2) - 1;
@@ -695,7 +752,10 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
         if ((rc = ctx->dfx_gather.ensure(tab.size() * 8 + 64))) return rc;
         u64 *dtab = reinterpret_cast<u64 *>(ctx->dfx_gather.p);
         if ((rc = h2d_table(ctx, dtab, tab.data(), tab.size() * 8))) return rc;
-        if ((rc = dfpwm_encode_i8(ctx, reinterpret_cast<const signed char *>(J.src), dtab, dtab + m, m, out, dtab + 2 * (size_t)m))) return rc;
+        // (a few of them: the exact parallel encoder, as a batch of that size would get on its own — 16 noise streams 5 ms instead of 11.5)
+        int src = AUKIT_OK;
+        if (dfpwm_encode_i8_small(ctx, reinterpret_cast<const signed char *>(J.src), tab.data(), tab.data() + m, m, out, tab.data() + 2 * (size_t)m, &src)) { if (src) return src; }
+        else if ((rc = dfpwm_encode_i8(ctx, reinterpret_cast<const signed char *>(J.src), dtab, dtab + m, m, out, dtab + 2 * (size_t)m))) return rc;
     } else if (m) {
         const aukit_batch *in = J.in;
         // Hard streams — the encoder changes its class every few chunks (noise) or more often than there are rounds: the schedule with one

@@ -112,10 +112,15 @@ def test_config4_pipeline_and_fused_transcode(ctx, oracle, monkeypatch):
         assert u == ref
         assert f == ref
     assert len(fused[0]) == 60010  # Q10: 120 000 B → 960 152 samples → 480 076 mono samples → 60 010 B
-    assert ctx.last_kernel()[0] == "k_dfx_chunks"  # a lane per (stream, chunk) decodes, mixes and encodes (dfpwm_spec.hip; tests/test_gpu_dfpwm_spec.py)
+    # four short streams (16 seconds together): chunk-parallel exact decode + the exact parallel encoder — a few short streams are theirs (dfx_run)
+    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfe_*"
+    monkeypatch.setenv("AUKIT_DFX_FEW", "0")   # ... unless told otherwise: a lane per (stream, chunk) decodes, mixes and encodes (dfpwm_spec.hip; tests/test_gpu_dfpwm_spec.py)
+    assert B.dfpwm_transcode_mono(ctx, bt, 2).download() == fused
+    assert ctx.last_kernel()[0] == "k_dfx_chunks"
+    monkeypatch.delenv("AUKIT_DFX_FEW")
     monkeypatch.setenv("AUKIT_DFPWM_NOSPEC", "1")
     assert B.dfpwm_transcode_mono(ctx, bt, 2).download() == fused
-    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfe_*"  # chunk-parallel exact decode + (four streams: a small batch) the exact parallel encoder
+    assert ctx.last_kernel()[0] == "k_df_chunks+k_dfe_*"
     monkeypatch.delenv("AUKIT_DFPWM_NOSPEC")
     # the same bytes through every schedule: one lane per stream; 2-byte blocks (a warm-up of 16 steps: most recorded start states
     # are wrong and the verify pass redoes the chunks); chunk and Q10 slice boundaries in odd positions

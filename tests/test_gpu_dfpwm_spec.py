@@ -9,6 +9,13 @@ from util import signal
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _speculate_on_small_batches(monkeypatch):
+    """by default a few short streams (<= 16 of <= 40 stream-seconds together) stay with the exact parallel encoder k_dfe_* (dfx_run): the
+    schedule under test here takes them all the same"""
+    monkeypatch.setenv("AUKIT_DFX_FEW", "0")
+
+
 def _B():
     from aukit_amd import batch
     return batch

@@ -884,12 +884,13 @@ def _fuzz_signal(rng, n):
 
 @pytest.mark.parametrize("seed", _seeds(10))
 def test_fuzz_dfpwm_speculation(ctx, oracle, seed, monkeypatch):
-    """the chunk-speculative engine (dfpwm_spec.hip) with the probe switched off — every batch is speculated on, whatever it holds — under random
+    """the chunk-speculative engine (dfpwm_spec.hip) with the probe and the few-short-streams rule switched off — every batch is speculated on, whatever
+    it holds — under random
     schedules (warm-up length, chunks per stream, checkpoint spacing, rounds): Audio:dfpwm on 1 - 2 channels and the stereo -> mono -> DFPWM transcode of
     what it made, bytes equal to the oracle's"""
     B, N = _B(), _N()
     rng = np.random.Generator(np.random.PCG64(15000 + seed))
-    env = {"AUKIT_DFX_NOPROBE": "1", "AUKIT_DFX_WE": str(int(rng.choice([64, 128, 384, 640, 960]))), "AUKIT_DFX_G": str(int(rng.choice([1, 2, 4]))),
+    env = {"AUKIT_DFX_FEW": "0", "AUKIT_DFX_NOPROBE": "1", "AUKIT_DFX_WE": str(int(rng.choice([64, 128, 384, 640, 960]))), "AUKIT_DFX_G": str(int(rng.choice([1, 2, 4]))),
            "AUKIT_DFX_ROUNDS": str(int(rng.integers(1, 7))), "AUKIT_DFX_MIN_BPC": str(int(rng.integers(1, 5)))}
     if rng.integers(0, 2):
         env["AUKIT_DFX_CHUNKS"] = str(int(rng.choice([2, 5, 13, 40, 200, 1000])))

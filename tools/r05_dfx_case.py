@@ -1,10 +1,12 @@
-"""one input class of the DFPWM transcode, a few steps (for rocprofv3): python tools/r05_dfx_case.py noise|gated 2048"""
+"""one input class of the DFPWM transcode, a few steps (for rocprofv3): python tools/r05_dfx_case.py noise|gated|lead|signal 2048 [enc]
+(enc: Audio:dfpwm on the mono mix of the same input instead of the transcode)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from aukit_amd import _native as N, batch as B, shard
 kind, n = sys.argv[1], int(sys.argv[2])
+enc_only = len(sys.argv) > 3 and sys.argv[3] == "enc"
 dev = torch.device("cuda:0"); ctx = B.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 nb, frames, sub = 120000, 480000, 512
@@ -31,6 +33,13 @@ else:
         torch.cuda.synchronize()
 bt = B.Batch.wrap(ctx, x.data_ptr(), [i * nb for i in range(n + 1)], keep=x)
 out = B.Batch(ctx, __import__("ctypes").c_void_p())
+if enc_only:
+    mono = B.mono(ctx, B.decode(ctx, bt, B.make_desc(N.CODEC_DFPWM, 2, 48000), dtype=N.F32))
+    for _ in range(2): B.dfpwm_encode(ctx, mono, True, out=out)
+    ctx.sync(); t0 = time.perf_counter()
+    for _ in range(10): B.dfpwm_encode(ctx, mono, True, out=out)
+    ctx.sync(); print(kind, n, "enc ms/step", (time.perf_counter() - t0) / 10 * 1e3)
+    sys.exit(0)
 for _ in range(2): B.dfpwm_transcode_mono(ctx, bt, 2, out=out)
 ctx.sync(); t0 = time.perf_counter()
 for _ in range(5): B.dfpwm_transcode_mono(ctx, bt, 2, out=out)

@@ -19,7 +19,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1, 16, 64, 512, 2048, 4096]:
         os.environ.update(env)
         for _ in range(2): B.dfpwm_encode(ctx, a, True, out=out)
         ctx.sync(); t0 = time.perf_counter()
-        for _ in range(5): B.dfpwm_encode(ctx, a, True, out=out)
-        ctx.sync(); res[tag] = (time.perf_counter() - t0) / 5 * 1e3, ctx.last_kernel()[0]
+        for _ in range(20): B.dfpwm_encode(ctx, a, True, out=out)
+        ctx.sync(); res[tag] = (time.perf_counter() - t0) / 20 * 1e3, ctx.last_kernel()[0]
         for k in env: del os.environ[k]
     print(f"{n:5d} streams x 10 s: spec {res['spec'][0]:8.3f} ms ({res['spec'][1]})   older {res['older'][0]:8.3f} ms ({res['older'][1]})   {n * frames / res['spec'][0] / 1e6:8.1f} G samples/s", flush=True)
