@@ -12,7 +12,7 @@
 //                       filter state zero — the charge update is a contraction towards the target ((1 - s/1024) per step, plus
 //                       a nudge) and the low-pass forgets at 116/256 per step, so after the 8192 warm-up steps the state is the
 //                       true one in practice — records the state it reached, decodes its chunk, records the end state;
-//   4. k_df_verify      lane per stream: where a chunk's recorded start state differs from the true end state of the chunk
+//   4. k_df_verify      wave per stream: where a chunk's recorded start state differs from the true end state of the chunk
 //                       before it, that chunk is decoded again serially from the true state.  Exactness therefore never rests
 //                       on the convergence argument; only the speed does (AUKIT_DFPWM_STATS=1 prints the redo count).
 // Output: de-interleaved int8 rows (the loader), or the stereo → mono mix of aukit.pcm ∘ Audio:mono ∘ encodePCM as int8 (transcode).
@@ -184,45 +184,106 @@ __global__ __launch_bounds__(256) void k_df_chunks(const DfParParams P) {
     dfp_pack(d, se);
 }
 
+// A WAVE per stream (a lane per stream walked the chunks one dependent load after the other — 235 chunks of a short-chunk batch 0.15 ms, more
+// than the chunk lanes took beside 63 idle SIMDs): 64 chunks' recorded start states are compared at once with the recorded end states before
+// them; a mismatch is decoded again from the true state by lane 0, and its new end state decides about the chunk behind it.
 __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
-    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    const unsigned s = blockIdx.x, lane = threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s];
     const DfOut O = dfp_out(P, s, nullptr);
-    int truth[6];
     const unsigned c_first = P.c_lo > 1 ? P.c_lo : 1;  // the chunk before it was verified by the slice before this one (chunk 0 starts from the reset state: always true)
-    for (int i = 0; i < 6; i++) truth[i] = P.st_end[((size_t)s * P.nchunk + c_first - 1) * 6 + i];
-    if (truth[1] < 0) return;  // the stream ended before this slice
+    const int *SS = P.st_start + (size_t)s * P.nchunk * 6;
+    int *SE = P.st_end + (size_t)s * P.nchunk * 6;
+    if (SE[(size_t)(c_first - 1) * 6 + 1] < 0) return;  // the stream ended before this slice
     unsigned redone = 0, chunks = P.c_lo == 0 ? 1 : 0;
-    for (unsigned c = c_first; c < P.c_hi; c++) {
-        const int *ss = P.st_start + ((size_t)s * P.nchunk + c) * 6;
-        int *se = P.st_end + ((size_t)s * P.nchunk + c) * 6;
-        if (ss[1] < 0) break;
-        chunks++;
+    bool carry = false;   // the last chunk of the group before was decoded again: `ce` is its true end state
+    int ce[6] = {0, 0, 0, 0, 0, 0};
+    for (unsigned c0 = c_first; c0 < P.c_hi; c0 += 64) {
+        const unsigned c = c0 + lane;
+        const bool valid = c < P.c_hi;
+        int ss[6], pe[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { ss[i] = valid ? SS[(size_t)c * 6 + i] : -1; pe[i] = valid ? SE[(size_t)(c - 1) * 6 + i] : 0; }
+        if (carry && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) pe[i] = ce[i];
+        }
+        carry = false;
+        const u64 none = __ballot(!valid || ss[1] < 0);          // the walk ends at the stream's first missing chunk
+        const unsigned jx = none ? (unsigned)__builtin_ctzll(none) : 64u;
+        const bool exists = lane < jx;
+        chunks += jx;
         bool same = true;
-        for (int i = 0; i < 6; i++) same = same && ss[i] == truth[i];
-        if (same) { for (int i = 0; i < 6; i++) truth[i] = se[i]; continue; }
-        DfDec d;
-        dfp_unpack(truth, d);
-        const u64 f0 = dfp_chunk_start(P, c), e1 = dfp_chunk_start(P, c + 1), f1 = e1 < fed ? e1 : fed;
-        if (P.mode == 1) {  // no table in this kernel: mix computed on the spot
-            u64 i = 4 * f0;
-            for (u64 b = f0; b < f1; b++) {
-                unsigned byte = p[dfp_src_index(b, P.feed)];
-                for (int k = 0; k < 4; k++) {
-                    const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
-                    byte >>= 2;
-                    O.base[i++] = (signed char)dfp_mix(l, r);
-                }
+#pragma unroll
+        for (int i = 0; i < 6; i++) same = same && ss[i] == pe[i];
+        u64 mask = __ballot(exists && !same);
+        while (mask) {
+            const unsigned j = (unsigned)__builtin_ctzll(mask);
+            mask &= mask - 1;
+            int truth[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) truth[i] = __shfl(pe[i], (int)j);
+            const unsigned cc = c0 + j;
+            if (lane == 0) {
+                DfDec d;
+                dfp_unpack(truth, d);
+                const u64 f0 = dfp_chunk_start(P, cc), e1 = dfp_chunk_start(P, cc + 1), f1 = e1 < fed ? e1 : fed;
+                if (P.mode == 1) {  // no table in this kernel: mix computed on the spot (and repeated dwords skipped: DfRepeat)
+                    u64 i = 4 * f0;
+                    auto four = [&](unsigned byte) -> unsigned {
+                        unsigned packed = 0;
+                        for (int k = 0; k < 4; k++) {
+                            const int l = df_decode_bit(d, byte & 1), r = df_decode_bit(d, (byte >> 1) & 1);
+                            byte >>= 2;
+                            packed |= ((unsigned)(unsigned char)dfp_mix(l, r)) << (8 * k);
+                        }
+                        return packed;
+                    };
+                    DfRepeat rp;
+                    fed_for_each<true>(p, f0, f1, P.feed,
+                                 [&](unsigned byte) { *reinterpret_cast<unsigned *>(O.base + i) = four(byte); i += 4; rp.fixed = false; },
+                                 [&](unsigned word) {
+                                     dfp_u32x4a v;
+                                     if (rp.hit(word)) v = rp.va;
+                                     else {
+                                         rp.before(d);
+                                         v.x = four(word & 0xFF); v.y = four((word >> 8) & 0xFF); v.z = four((word >> 16) & 0xFF); v.w = four(word >> 24);
+                                         rp.after(word, d);
+                                         rp.va = v;
+                                     }
+                                     *reinterpret_cast<dfp_u32x4a *>(O.base + i) = v;
+                                     i += 16;
+                                 });
+                } else dfp_run<true, true>(p, f0, f1, d, O);
+                dfp_pack(d, truth);
+                for (int i = 0; i < 6; i++) SE[(size_t)cc * 6 + i] = truth[i];
             }
-        } else dfp_run<true>(p, f0, f1, d, O);
-        dfp_pack(d, truth);
-        for (int i = 0; i < 6; i++) se[i] = truth[i];
-        redone++;
+            redone++;
+#pragma unroll
+            for (int i = 0; i < 6; i++) truth[i] = __shfl(truth[i], 0);   // the chunk's true end state
+            if (j + 1 < 64) {   // the chunk behind it is judged by that, not by the end state the chunk lane had recorded
+                bool again = false;
+                if (lane == j + 1 && exists) {
+                    bool sm = true;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { pe[i] = truth[i]; sm = sm && ss[i] == truth[i]; }
+                    again = !sm;
+                }
+                mask = (mask & ~(1ull << (j + 1))) | __ballot(again);
+            } else {
+                carry = true;
+#pragma unroll
+                for (int i = 0; i < 6; i++) ce[i] = truth[i];
+            }
+        }
+        if (jx < 64) break;
     }
-    if (redone) atomicAdd(&P.stats[0], redone);
-    atomicAdd(&P.stats[1], chunks);
+    if (lane == 0) {
+        if (redone) atomicAdd(&P.stats[0], redone);
+        atomicAdd(&P.stats[1], chunks);
+    }
 }
 
 // the exact strength at every chunk's warm-up start (P.s_start), for planners outside this file (dfpwm_spec.hip)
@@ -425,7 +486,7 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
         P.c_lo = (unsigned)((u64)nchunk * k / nsl);
         P.c_hi = (unsigned)((u64)nchunk * (k + 1) / nsl);
         hipLaunchKernelGGL(k_df_chunks, dim3((unsigned)(((size_t)n * (P.c_hi - P.c_lo) + cb - 1) / cb)), dim3(cb), mode == 1 ? 65536 : 0, ctx->stream, P);
-        hipLaunchKernelGGL(k_df_verify, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_df_verify, dim3(n), dim3(64), 0, ctx->stream, P);
         if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "parallel DFPWM decode launch failed"); return true; }
         if (sliced && (*rc = hook->after_slice(k, nsl, (u64)P.c_lo * bpc * W, (u64)P.c_hi * bpc * W))) return true;  // fed bytes [lo, hi) of every stream are final
     }
@@ -658,13 +719,13 @@ AUKIT_DEV void dff_encoder(const DfFusedParams &F, unsigned j, const signed char
                 if (same) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) truth[k] = st[(size_t)(5 + k) * F.npad];
-                } else {  // (never on real data: the warm-up converges) decode the chunk again from the true state
+                } else {  // (rare on signal: the warm-up converges) decode the chunk again from the true state
                     DfDec d;
                     dfp_unpack(truth, d);
                     const u64 e1 = dfp_chunk_start(P, cc + 1), f1 = e1 < fed ? e1 : fed;
                     DfOut O = dfp_out(P, s, lut);
                     O.mode = 1; O.C = 2;
-                    dfp_run<true>(src, f0, f1, d, O);
+                    dfp_run<true, true>(src, f0, f1, d, O);   // (digital silence does not converge: DfRepeat)
                     dfp_pack(d, truth);
                     redone++;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the samples just stored are read back below

@@ -27,7 +27,9 @@ AUKIT_DEV u64 dfp_src_index(u64 f, const Feed &fd) { const u64 k = f / fd.run; r
 // Calls fn(byte) for the fed bytes [f0, f1) in order.  Inside a run the source is contiguous: aligned 16-byte loads (the next one
 // in flight while the current one is consumed), single bytes up to the first aligned address and around the end of a run.
 // fn4(word) takes four fed bytes at once (the dwords of the aligned vectors: little-endian, first byte lowest).
-template <typename F, typename F4>
+// DEEP: four vectors in flight (a lone lane — the serial passes — waits a microsecond or two for every load it has not asked for early:
+// 64 bytes per turn, the next 64 requested before these are looked at)
+template <bool DEEP = false, typename F, typename F4>
 AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn, F4 &&fn4) {
     if (f0 >= f1) return;
     const u64 k0 = f0 / fd.run, o0 = f0 - k0 * fd.run;
@@ -38,6 +40,36 @@ AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &
     u64 rem = f1 - f0;
     uint4 pre = make_uint4(0, 0, 0, 0);
     bool have = false;
+    if constexpr (DEEP) {
+        uint4 cur[4], nxt[4];
+        bool have4 = false;
+        while (rem) {
+            if (((uintptr_t)a & 15) == 0 && left >= 64 && rem >= 64) {
+                if (!have4) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cur[q] = reinterpret_cast<const uint4 *>(a)[q];
+                }
+                have4 = left >= 128 && rem >= 128;
+                if (have4) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) nxt[q] = reinterpret_cast<const uint4 *>(a + 64)[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { fn4(cur[q].x); fn4(cur[q].y); fn4(cur[q].z); fn4(cur[q].w); }
+                if (have4) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+                }
+                a += 64; left -= 64; rem -= 64;
+            } else {
+                fn((unsigned)*a);
+                a++; left--; rem--;
+                have4 = false;
+            }
+            if (left == 0) { a += skip; left = run; have4 = false; }
+        }
+        return;
+    }
     while (rem) {
         if (((uintptr_t)a & 15) == 0 && left >= 16 && rem >= 16) {
             const uint4 q = have ? pre : *reinterpret_cast<const uint4 *>(a);
@@ -56,7 +88,7 @@ AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &
 }
 template <typename F>
 AUKIT_DEV void fed_for_each(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, F &&fn) {
-    fed_for_each(p, f0, f1, fd, fn, [&](unsigned word) {
+    fed_for_each<false>(p, f0, f1, fd, fn, [&](unsigned word) {
 #pragma unroll
         for (int j = 0; j < 4; j++) fn((word >> (8 * j)) & 0xFF);
     });
@@ -101,10 +133,30 @@ struct DfOut {  // where decoded samples go
     const signed char *lut;
 };
 
+// Fast-forward through repeated source dwords (FF, the serial redo of k_df_verify): the decoder is a function of (state, bits), so when a dword
+// left the state where it found it, the same dword again leaves it there again and makes the same 32 samples — digital silence (0x55 / 0xAA
+// bytes at the strength floor, the charge stepping +-1 around wherever it stood when the silence began: the one thing a chunk lane's warm-up
+// never finds out, every chunk of the passage is redone) and rails reach such a cycle within a few dwords.  A compare and the stores instead
+// of 512 instructions: one second of silence inside 64 streams cost the loader 3.5 of its 4.2 ms.
+typedef unsigned dfp_u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+struct DfRepeat {
+    unsigned pw = 0;
+    bool fixed = false;
+    int s[5] = {0, 0, 0, 0, 0};
+    dfp_u32x4a va, vb;
+    AUKIT_DEV bool hit(unsigned word) const { return fixed && word == pw; }
+    AUKIT_DEV void before(const DfDec &d) { s[0] = d.p.n; s[1] = d.p.strength; s[2] = d.p.pb; s[3] = d.lpf; s[4] = d.pn; }
+    AUKIT_DEV void after(unsigned word, const DfDec &d) {
+        fixed = s[0] == d.p.n && s[1] == d.p.strength && s[2] == d.p.pb && s[3] == d.lpf && s[4] == d.pn;
+        pw = word;
+    }
+};
+
 // decode fed bytes [f0, f1) of one stream; EMIT = false: state only
-template <bool EMIT>
+template <bool EMIT, bool FF = false>
 AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const DfOut &O) {
     u64 i = 8 * f0;  // index of the next decoded sample in the fed order
+    [[maybe_unused]] DfRepeat rp;
     if (EMIT && O.mode == 1) {
         // stereo frames → one mono int8 each: 4 per fed byte (one dword store), 16 per aligned source dword (one 16-byte store — a
         // quarter of the store instructions, each of which visits 64 cache lines for the 64 streams of a wave)
@@ -120,11 +172,16 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
             return packed;
         };
         typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));
-        fed_for_each(p, f0, f1, O.feed,
-                     [&](unsigned byte) { *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = four(byte); i += 8; },
+        fed_for_each<FF>(p, f0, f1, O.feed,
+                     [&](unsigned byte) { *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = four(byte); i += 8; if (FF) rp.fixed = false; },
                      [&](unsigned word) {
                          u32x4a v;
-                         v.x = four(word & 0xFF); v.y = four((word >> 8) & 0xFF); v.z = four((word >> 16) & 0xFF); v.w = four(word >> 24);
+                         if (FF && rp.hit(word)) v = rp.va;
+                         else {
+                             if (FF) rp.before(d);
+                             v.x = four(word & 0xFF); v.y = four((word >> 8) & 0xFF); v.z = four((word >> 16) & 0xFF); v.w = four(word >> 24);
+                             if (FF) { rp.after(word, d); rp.va = v; }
+                         }
                          *reinterpret_cast<u32x4a *>(O.base + (i >> 1)) = v;
                          i += 32;
                      });
@@ -143,19 +200,25 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
                     c1 |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 2 * k + 1))) << (8 * k);
                 }
             };
-            fed_for_each(p, f0, f1, O.feed,
+            fed_for_each<FF>(p, f0, f1, O.feed,
                          [&](unsigned byte) {
                              unsigned c0, c1;
                              pair(byte, c0, c1);
                              *reinterpret_cast<unsigned *>(O.base + (i >> 1)) = c0;
                              *reinterpret_cast<unsigned *>(O.base + O.stride + (i >> 1)) = c1;
                              i += 8;
+                             if (FF) rp.fixed = false;
                          },
                          [&](unsigned word) {
-                             unsigned a[4], b[4];
-                             pair(word & 0xFF, a[0], b[0]); pair((word >> 8) & 0xFF, a[1], b[1]); pair((word >> 16) & 0xFF, a[2], b[2]); pair(word >> 24, a[3], b[3]);
                              u32x4a va, vb;
-                             va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = b[0]; vb.y = b[1]; vb.z = b[2]; vb.w = b[3];
+                             if (FF && rp.hit(word)) { va = rp.va; vb = rp.vb; }
+                             else {
+                                 if (FF) rp.before(d);
+                                 unsigned a[4], b[4];
+                                 pair(word & 0xFF, a[0], b[0]); pair((word >> 8) & 0xFF, a[1], b[1]); pair((word >> 16) & 0xFF, a[2], b[2]); pair(word >> 24, a[3], b[3]);
+                                 va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = b[0]; vb.y = b[1]; vb.z = b[2]; vb.w = b[3];
+                                 if (FF) { rp.after(word, d); rp.va = va; rp.vb = vb; }
+                             }
                              *reinterpret_cast<u32x4a *>(O.base + (i >> 1)) = va;
                              *reinterpret_cast<u32x4a *>(O.base + O.stride + (i >> 1)) = vb;
                              i += 32;
@@ -169,18 +232,24 @@ AUKIT_DEV void dfp_run(const unsigned char *p, u64 f0, u64 f1, DfDec &d, const D
 #pragma unroll
                 for (int k = 0; k < 4; k++) hi |= ((unsigned)(unsigned char)df_decode_b(d, df_pm1(nb, 4 + k))) << (8 * k);
             };
-            fed_for_each(p, f0, f1, O.feed,
+            fed_for_each<FF>(p, f0, f1, O.feed,
                          [&](unsigned byte) {
                              unsigned lo, hi;
                              eight(byte, lo, hi);
                              *reinterpret_cast<uint2 *>(O.base + i) = make_uint2(lo, hi);
                              i += 8;
+                             if (FF) rp.fixed = false;
                          },
                          [&](unsigned word) {
-                             unsigned a[8];
-                             eight(word & 0xFF, a[0], a[1]); eight((word >> 8) & 0xFF, a[2], a[3]); eight((word >> 16) & 0xFF, a[4], a[5]); eight(word >> 24, a[6], a[7]);
                              u32x4a va, vb;
-                             va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = a[4]; vb.y = a[5]; vb.z = a[6]; vb.w = a[7];
+                             if (FF && rp.hit(word)) { va = rp.va; vb = rp.vb; }
+                             else {
+                                 if (FF) rp.before(d);
+                                 unsigned a[8];
+                                 eight(word & 0xFF, a[0], a[1]); eight((word >> 8) & 0xFF, a[2], a[3]); eight((word >> 16) & 0xFF, a[4], a[5]); eight(word >> 24, a[6], a[7]);
+                                 va.x = a[0]; va.y = a[1]; va.z = a[2]; va.w = a[3]; vb.x = a[4]; vb.y = a[5]; vb.z = a[6]; vb.w = a[7];
+                                 if (FF) { rp.after(word, d); rp.va = va; rp.vb = vb; }
+                             }
                              *reinterpret_cast<u32x4a *>(O.base + i) = va;
                              *reinterpret_cast<u32x4a *>(O.base + i + 16) = vb;
                              i += 32;
