@@ -30,6 +30,12 @@ namespace aukit {
 // The eight clamp-add steps of one byte, given the bit before it, compose to one clamp-add map: 512 table entries per workgroup.
 // (one dword per entry: eight unit steps inside [8, 1023] give a in [-8, 8], lo in [8, 16], hi in [1015, 1023]; as three ints the random
 // look-ups of a wave spent 70 % of their LDS cycles in bank conflicts — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02_dfpwm_pmc_lds.csv)
+// <NQ, SINGLE>: 16-byte vectors per turn, and whether the turn's loads are asked for at its top (no second buffer) or a turn ahead.
+//   <4, false>  64 bytes per turn, the next 64 in flight: the short runs of a finely cut batch (their first loads are most of their latency)
+//   <8, true>   a whole 128-byte line per turn, fetched ONCE: with four vectors the two halves of a line are two turns apart, and the lines of
+//               262 144 lanes are more than the L2s hold — 4.1 GB fetched for 2.0 of input at 16 384 streams (profiles/r05_dfpwm_pmc_fetch.csv
+//               before / after); with eight vectors AND a second buffer the kernel holds 145 VGPRs, three waves per SIMD, 1.25 ms for 0.97
+template <int NQ, bool SINGLE>
 __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
     __shared__ unsigned bm[512];
     for (int e = threadIdx.x; e < 512; e += 256) {   // entry (byte << 1) | previous bit: nine consecutive bits of the stream
@@ -100,14 +106,25 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             const unsigned char *a = p + k0 * P.feed.stride + (b - k0 * P.feed.run);
             u64 rem = f1 - b;
             while (rem && ((uintptr_t)a & 15)) { step((unsigned)*a); a++; rem--; }
-            constexpr int NQ = AUKIT_DF_MAPS_NQ;   // 16-byte vectors per turn
+            // (whole turns start on a multiple of their size: with eight vectors a turn is one 128-byte line, fetched once — with four, the two
+            // halves of a line are two turns apart, and 262 144 lanes' lines are more than the L2s hold: 4.1 GB fetched for 2.0 of input)
+            while (rem >= 16 && ((uintptr_t)a & (16 * NQ - 1))) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(a);
+                step4(q.x); step4(q.y); step4(q.z); step4(q.w);
+                a += 16; rem -= 16;
+            }
             uint4 cur[NQ], nxt[NQ];
+            [[maybe_unused]] const unsigned char *const a0 = a;
             if (rem >= 16 * NQ) {
 #pragma unroll
                 for (int q = 0; q < NQ; q++) cur[q] = reinterpret_cast<const uint4 *>(a)[q];
             }
             while (rem >= 16 * NQ) {
-                const bool more = rem >= 32 * NQ;
+                const bool more = !SINGLE && rem >= 32 * NQ;
+                if (SINGLE && a != a0) {   // (the turn's own loads, asked for at its top: the other waves cover them)
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) cur[q] = reinterpret_cast<const uint4 *>(a)[q];
+                }
                 if (more) {
 #pragma unroll
                     for (int q = 0; q < NQ; q++) nxt[q] = reinterpret_cast<const uint4 *>(a + 16 * NQ)[q];
@@ -288,7 +305,10 @@ __global__ __launch_bounds__(64) void k_df_verify(const DfParParams P) {
 
 // the exact strength at every chunk's warm-up start (P.s_start), for planners outside this file (dfpwm_spec.hip)
 int dfpwm_strength_scan(aukit_ctx *ctx, const DfParParams &P) {
-    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)P.n * P.nblk * (P.msub ? P.msub : 1) + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    const unsigned F = P.msub ? P.msub : 1;
+    const dim3 grid((unsigned)(((size_t)P.n * P.nblk * F + 255) / 256));
+    if ((uint64_t)P.bpc * P.W / F >= 4096) hipLaunchKernelGGL((k_df_blockmaps<8, true>), grid, dim3(256), 0, ctx->stream, P);   // long runs per lane: whole lines
+    else hipLaunchKernelGGL((k_df_blockmaps<4, false>), grid, dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((P.n + 63) / 64), dim3(64), 0, ctx->stream, P);
     AUKIT_HIP_CHECK(hipGetLastError());
     return AUKIT_OK;
@@ -478,7 +498,7 @@ bool dfpwm_decode_parallel_feed(aukit_ctx *ctx, const unsigned char *src, const 
     }
     P.mode = mode; P.C = C; P.out = out; P.out_off = d_out_off; P.out_stride = d_out_stride; P.lead = lead;
     if (hipMemsetAsync(P.stats, 0, 8, ctx->stream) != hipSuccess) { *rc = fail(AUKIT_E_HIP, "hipMemsetAsync failed"); return true; }
-    hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL((k_df_blockmaps<4, false>), dim3((unsigned)(((size_t)n * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
     hipLaunchKernelGGL(k_df_blockscan, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, P);
     const unsigned cb = 256;  // (1024 lanes sharing one table, 8 waves per SIMD instead of 2: 7 % slower — the kernel is issue-bound)
     const unsigned nsl = sliced ? std::min<unsigned>((unsigned)hook->slices, nchunk) : 1u;
@@ -907,7 +927,7 @@ int dfpwm_transcode_fused(aukit_ctx *ctx, const aukit_batch *in, signed char *mo
         F.G = G; F.npad = npad; F.total = nchunk * G; F.mcount = d_mcount + s0;
         F.enc_out = out; F.ooff = d_ooff + s0;
         if (hipMemsetAsync(F.flags, 0, b_fl + 8, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
-        hipLaunchKernelGGL(k_df_blockmaps, dim3((unsigned)(((size_t)ns * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
+        hipLaunchKernelGGL((k_df_blockmaps<4, false>), dim3((unsigned)(((size_t)ns * nchunk + 255) / 256)), dim3(256), 0, ctx->stream, P);
         hipLaunchKernelGGL(k_df_blockscan, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, P);
         hipLaunchKernelGGL(k_df_fused, dim3((unsigned)std::max<int>(ctx->num_cus, (int)G)), dim3(448), lds, ctx->stream, F);
         AUKIT_HIP_CHECK(hipGetLastError());

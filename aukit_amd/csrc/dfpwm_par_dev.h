@@ -7,9 +7,6 @@
 namespace aukit {
 
 typedef unsigned long long u64;
-#ifndef AUKIT_DF_MAPS_NQ
-#define AUKIT_DF_MAPS_NQ 4
-#endif
 
 struct SatMap { int a, lo, hi; };
 AUKIT_DEV int sm_clamp(int v, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi)); return r; }   // lo <= hi everywhere: one v_med3_i32 (the ternaries became compares and selects)
