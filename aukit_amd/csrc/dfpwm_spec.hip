@@ -68,25 +68,45 @@ struct DfxParams {
 };
 
 // ---- output bits: 4 per fed byte, 16 per source dword; whole 8-byte rounds leave as one store
-struct DfsAcc { u64 bits = 0, lo = 0; unsigned pos = 0; bool half = false; unsigned char *o = nullptr; };
+struct DfsAcc {
+    u64 bits = 0;            // the round being filled
+    u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0;   // whole rounds held back, h0 the newest
+    unsigned pos = 0, nh = 0;
+    unsigned char *o = nullptr;
+};
 typedef unsigned dfs_u32x2u __attribute__((ext_vector_type(2), aligned(1)));  // (unaligned global stores are single instructions on gfx950)
 typedef unsigned dfs_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
-// a full round of 64 bits: every second one leaves, with the one before it, as ONE 16-byte store (8-byte stores from 131 072 lanes at their own
-// addresses left the L2 as partial sectors: 6.5 GB written for 1 GB of result, profiles/r05_dfpwm_pmc_write.csv)
-AUKIT_DEV void dfs_round(DfsAcc &a, u64 r) {
-    if (!a.half) { a.lo = r; a.half = true; return; }
-    dfs_u32x4u w; w.x = (unsigned)a.lo; w.y = (unsigned)(a.lo >> 32); w.z = (unsigned)r; w.w = (unsigned)(r >> 32);
-    *reinterpret_cast<dfs_u32x4u *>(a.o) = w;
-    a.o += 16;
-    a.half = false;
+AUKIT_DEV void dfs_store16(unsigned char *o, u64 a, u64 b) {
+    dfs_u32x4u w; w.x = (unsigned)a; w.y = (unsigned)(a >> 32); w.z = (unsigned)b; w.w = (unsigned)(b >> 32);
+    *reinterpret_cast<dfs_u32x4u *>(o) = w;
 }
-// whatever whole round is held back goes out (chunk ends, checkpoints a run may stop at)
+AUKIT_DEV void dfs_store8(unsigned char *o, u64 a) {
+    dfs_u32x2u w; w.x = (unsigned)a; w.y = (unsigned)(a >> 32);
+    *reinterpret_cast<dfs_u32x2u *>(o) = w;
+}
+// a full round of 64 bits: every eighth one leaves, with the seven before it, as FOUR 16-byte stores in a row — 64 bytes of one or two lines that
+// the L2 sees together.  (8-byte stores from 131 072 lanes at their own addresses left the L2 as partial sectors, 6.5 GB written for 1 GB of
+// result; 16-byte stores 3.6 GB: the lane's next one came thousands of instructions later, its line long evicted — profiles/r05_dfpwm_pmc_write.csv)
+AUKIT_DEV void dfs_round(DfsAcc &a, u64 r) {
+#ifdef AUKIT_DFS_PAIRS   // (A/B: 16-byte stores, every second round)
+    if (a.nh == 1) { dfs_store16(a.o, a.h0, r); a.o += 16; a.nh = 0; return; }
+#endif
+    if (a.nh == 7) {
+        dfs_store16(a.o, a.h6, a.h5); dfs_store16(a.o + 16, a.h4, a.h3); dfs_store16(a.o + 32, a.h2, a.h1); dfs_store16(a.o + 48, a.h0, r);
+        a.o += 64;
+        a.nh = 0;
+        return;
+    }
+    a.h6 = a.h5; a.h5 = a.h4; a.h4 = a.h3; a.h3 = a.h2; a.h2 = a.h1; a.h1 = a.h0; a.h0 = r;
+    a.nh++;
+}
+// whatever whole rounds are held back go out, oldest first (chunk ends, checkpoints a run may stop at)
 AUKIT_DEV void dfs_flush(DfsAcc &a) {
-    if (!a.half) return;
-    dfs_u32x2u w; w.x = (unsigned)a.lo; w.y = (unsigned)(a.lo >> 32);
-    *reinterpret_cast<dfs_u32x2u *>(a.o) = w;
-    a.o += 8;
-    a.half = false;
+    const u64 h[7] = {a.h0, a.h1, a.h2, a.h3, a.h4, a.h5, a.h6};
+#pragma unroll
+    for (int k = 6; k >= 0; k--)
+        if ((unsigned)k < a.nh) { dfs_store8(a.o, h[k]); a.o += 8; }
+    a.nh = 0;
 }
 AUKIT_DEV void dfs_put(DfsAcc &a, unsigned v, unsigned nbits) {
     a.bits |= (u64)v << a.pos;
@@ -114,7 +134,12 @@ AUKIT_DEV unsigned dfx_byte(DfDec &d, DfEnc &e, unsigned byte, LUT lutc) {
 // fed bytes [f0, f1) of one stream through decoder, mix and encoder; EMIT: the bits go to `acc`
 template <bool EMIT, typename LUT>
 AUKIT_DEV void dfx_span(const unsigned char *p, u64 f0, u64 f1, const Feed &fd, DfDec &d, DfEnc &e, LUT lutc, DfsAcc &acc) {
-    fed_for_each(p, f0, f1, fd,
+    // (64-byte turns of the source — fed_for_each<true> — would fetch 2.5 GB instead of 3.8 at 16 384 streams and cost 0.4 ms of 12.9: the kernel is
+    // bound by its instructions, not by its bytes; profiles/r05_dfx_burst_ab.txt)
+#ifndef AUKIT_DFX_LOADS_DEEP
+#define AUKIT_DFX_LOADS_DEEP false
+#endif
+    fed_for_each<AUKIT_DFX_LOADS_DEEP>(p, f0, f1, fd,
                  [&](unsigned byte) {
                      const unsigned b4 = dfx_byte(d, e, byte, lutc);
                      if (EMIT) dfs_put(acc, b4, 4);
