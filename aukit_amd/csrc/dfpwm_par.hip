@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
         f1 = f0 + piece < f1 ? f0 + piece : f1;
     }
     SatMap f{0, -(1 << 28), 1 << 28};
+    bool anyflat = false;
     if (f0 < f1) {
         int prev = f0 ? (p[dfp_src_index(f0 - 1, P.feed)] >> 7) & 1 : 0;
         u64 b = f0;
@@ -99,12 +100,14 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
             look((word >> 21) & 0x7FCu);
             prev = word >> 31;
         };
-        // The usual block lies inside one run of the feed: 64 bytes per turn with the next 64 requested before these are looked at.  With one
-        // 16-byte vector ahead (fed_for_each) a lane had 16 bytes in flight and the kernel moved 0.8 TB/s, waiting 66 % of its time.
-        const u64 k0 = b / P.feed.run;
-        if (f1 > b && (f1 - 1) / P.feed.run == k0) {
+        // Run by run of the feed (inside a run the source is contiguous; a piece of a large batch's map block is longer than a run — and went
+        // through fed_for_each byte by byte until this was a loop): 64 or 128 bytes per turn.  With one 16-byte vector ahead (fed_for_each) a lane
+        // had 16 bytes in flight and the kernel moved 0.8 TB/s, waiting 66 % of its time.
+        for (u64 k0 = b / P.feed.run; b < f1; k0++) {
+            const u64 seg_end = (k0 + 1) * P.feed.run < f1 ? (k0 + 1) * P.feed.run : f1;
             const unsigned char *a = p + k0 * P.feed.stride + (b - k0 * P.feed.run);
-            u64 rem = f1 - b;
+            u64 rem = seg_end - b;
+            b = seg_end;
             while (rem && ((uintptr_t)a & 15)) { step((unsigned)*a); a++; rem--; }
             // (whole turns start on a multiple of their size: with eight vectors a turn is one 128-byte line, fetched once — with four, the two
             // halves of a line are two turns apart, and 262 144 lanes' lines are more than the L2s hold: 4.1 GB fetched for 2.0 of input)
@@ -129,6 +132,13 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
 #pragma unroll
                     for (int q = 0; q < NQ; q++) nxt[q] = reinterpret_cast<const uint4 *>(a + 16 * NQ)[q];
                 }
+                if (P.inner) {   // (a turn of one byte repeated: digital silence)
+                    const unsigned x = cur[0].x;
+                    bool flat = x == (x & 0xFFu) * 0x01010101u;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) flat = flat && cur[q].x == x && cur[q].y == x && cur[q].z == x && cur[q].w == x;
+                    anyflat = anyflat || flat;
+                }
 #ifdef AUKIT_DF_MAPS_ROLLED
 #pragma unroll 1
 #else
@@ -152,9 +162,10 @@ __global__ __launch_bounds__(256) void k_df_blockmaps(const DfParParams P) {
                 a += 16 * NQ; rem -= 16 * NQ;
             }
             while (rem) { step((unsigned)*a); a++; rem--; }
-        } else fed_for_each(p, b, f1, P.feed, step);
+        }
     }
     *dst = f;
+    if (P.inner && anyflat && f0 >= (P.lead_on ? (u64)P.lead_on[s] : 0ull)) P.inner[s] = 1;
 }
 
 __global__ __launch_bounds__(64) void k_df_blockscan(const DfParParams P) {

@@ -114,6 +114,9 @@ struct DfParParams {
     const u64 *out_off, *out_stride;  // rows: element offset of channel 0 / channel stride per stream; mix: element offset per stream
     unsigned *stats;
     unsigned skip_last;   // k_df_blockmaps: the last block's map is not wanted (nothing starts behind it): identity, its bytes are not read
+    const unsigned *lead_on;  // k_df_blockmaps (may be null): [n] the fed unit at which the silence a stream starts with ends (0: none) ...
+    unsigned char *inner;     // ... and (may be null) [n] set to 1 where a stream holds digital silence BEHIND that: a whole turn of the scan (64 or 128
+                              // source bytes) that is one byte repeated — dfpwm_spec.hip declines large batches of such streams
     unsigned msub;        // k_df_blockmaps / k_df_blockscan: lanes per map block (0 = 1): `maps` is [n][nblk][msub], a block's bytes cut into msub pieces
     unsigned c_lo, c_hi;  // k_df_chunks / k_df_verify: the chunk indices [c_lo, c_hi) of every stream (a time slice of the batch)
 };

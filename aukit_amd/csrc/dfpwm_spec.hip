@@ -41,6 +41,7 @@ constexpr unsigned DFX_PROBE_FROM = 256, DFX_PROBE_END = 768;  // fed bytes: the
 #ifndef AUKIT_DFX_WG
 #define AUKIT_DFX_WG 256   // threads of a chunk-lane workgroup (one 64 KiB mix table each: two workgroups per CU)
 #endif
+constexpr unsigned DFX_LEAD_MAX = 60000;   // fed units (5 s of a 48 kHz stream) of leading silence the prologue walks through for the second reference
 constexpr unsigned DFX_X0 = 128;  // fed bytes (512 mono samples) the prologue runs from the reset state to learn the encoder's class
 
 struct DfxParams {
@@ -57,7 +58,9 @@ struct DfxParams {
                             //   the state it started from (6), the end state it reached (6, status 2)
     int *ctl;               // [9][npad]: first chunk not final yet (nchunk: done, nchunk + 1: given up — a "hard" stream); the reference encoder state the
                             //   chunk lanes model their guess on (packed); the true state (5 + 1) where that chunk starts; strikes
-    int *pst;               // [6][npad] k_dfx_prologue, `phase` 1 -> 2: the true state at DFX_X0 (the decoder's five words, the encoder's one)
+    int *pst;               // [7][npad] k_dfx_prologue, `phase` 1 -> 2: the true state where the references end (the decoder's five words, the encoder's one, the fed position)
+    unsigned *onset;        // [npad] k_dfx_onset: the fed unit at which the silence a stream starts with ends (0: none)
+    int *ref2;              // [npad] the SECOND reference of round 0: the true encoder behind the silence a stream starts with (dfs_pack; 0: none)
     unsigned phase;         // k_dfx_prologue: 0 reference and probe in one launch; 1 the reference only; 2 the probe, from `pst`
     unsigned *hard;         // [npad] the hard streams (flags[13] of them): left to the lane-per-stream encoder (host side)
     unsigned *flags;        // [r] = round r's verify left something to re-speculate;  [8] chunks, [9] checkpoint intervals run again, [10] streams re-speculated, [11] chunks run again by k_dfx_fix, [13] hard streams
@@ -220,12 +223,20 @@ AUKIT_DEV bool dfx_same6(const int *a, const int *b) {
 // start sit at sample indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and
 // the charge on the first sample `u0`.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at every
 // step, and which of its two phases it is in is not a matter of class) is copied whole where the first sample looks like the same silence.
-AUKIT_DEV DfEnc dfx_guess(const DfEnc &ref, unsigned u0) {
+// `flat`: the lane's first source dword is one byte four times (digital silence: 0x55 / 0xAA in DFPWM, one sample value in the rows) — a
+// signal that merely crosses the reference's level where the lane starts is no silence (one chunk in forty did, and took its stream to a
+// second round)
+AUKIT_DEV DfEnc dfx_guess(const DfEnc &ref, unsigned u0, int ref2 = 0, bool flat = true) {
     DfEnc e;
     const int du = ref.cu - (int)u0;
     if (ref.strength > 9) { e.strength = ref.strength; e.pb = ref.pb; e.cu = (int)u0; }
-    else if (du >= -2 && du <= 2) e = ref;
-    else {
+    else if (du >= -2 && du <= 2 && flat) e = ref;
+    else if (ref2) {
+        // the stream STARTS in silence (the reference sits at the floor) and this lane does not: the prologue walked on to where the signal
+        // sets in and left the true state there — its class is the one the signal keeps until the next clamp
+        const DfEnc r2 = dfs_unpack(ref2);
+        e.strength = r2.strength; e.pb = r2.pb; e.cu = (int)u0;
+    } else {
         // a floor reference says nothing about a passage with signal: any strength away from the floor, in the reference's class all the
         // same — the lanes of the stream then agree with each other, which is what tells a change of class from noise
         e.cu = (int)u0; e.pb = ref.pb; e.strength = 40 + ((ref.strength - 40) & 3);
@@ -253,8 +264,22 @@ AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
 }
 
 // the probe's verdict, on the device (the host hears of it at the end of the call: nothing in between waits for the host)
-__global__ void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_counts) {
-    if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n) flags[6] = 1;
+// (`inner`, large batches: streams with digital silence behind the one they start with — every such passage ends the speculation of its
+// stream for this round, and a batch cut into few chunks has no second one: more than eight of them and the lane-per-stream schedule, which
+// then has to run for them, may as well run for all)
+__global__ __launch_bounds__(256) void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_counts, const unsigned char *inner) {
+    __shared__ unsigned cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if (inner && silence_counts) {
+        unsigned c = 0;
+        for (unsigned i = threadIdx.x; i < n; i += 256) c += inner[i];
+        if (c) atomicAdd(&cnt, c);
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    flags[12] = cnt;
+    if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n || cnt > 8) flags[6] = 1;
 }
 
 // copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
@@ -264,13 +289,46 @@ AUKIT_DEV void dfx_lut_to_lds(const unsigned char *g, unsigned char *l, unsigned
     for (unsigned i = threadIdx.x; i < 4096; i += nthreads) lv[i] = gv[i];
 }
 
+// Where the silence a stream STARTS with ends: a wave per stream compares the source bytes behind unit DFX_X0 with the byte there, 1 KiB a turn
+// (X.onset[s] = the first fed unit that holds another byte; 0: the stream does not go on with its byte at DFX_X0 for at least 64 units — no
+// silence worth the name — or all of the DFX_LEAD_MAX units looked at are silent).  Digital silence is ONE byte repeated: 0x55 or 0xAA in
+// DFPWM, one sample value in the rows.
+template <int KIND>
+__global__ __launch_bounds__(64) void k_dfx_onset(const DfxParams X) {
+    const DfParParams &P = X.P;
+    const unsigned s = blockIdx.x, lane = threadIdx.x;
+    const u64 fed = P.fed[s];
+    unsigned res = 0;
+    if (fed > 3 * (u64)DFX_X0) {
+        const unsigned char *p = P.src + P.off[s];
+        // source bytes [i0, i1): fed units [DFX_X0, lim) — rows: four bytes a unit; transcode: the feed's runs overlap by one byte (6001 / 6000),
+        // a source byte index i is fed unit i + i / stride
+        const u64 lim = fed - DFX_X0 < (u64)DFX_X0 + DFX_LEAD_MAX ? fed - DFX_X0 : (u64)DFX_X0 + DFX_LEAD_MAX;
+        const u64 i0 = KIND == 1 ? 4ull * DFX_X0 : dfp_src_index(DFX_X0, P.feed), i1 = KIND == 1 ? 4 * lim : dfp_src_index(lim, P.feed);
+        const unsigned v = p[i0];
+        u64 first = i1;
+        for (u64 i = i0; i < i1 && first == i1; i += 1024) {
+            const u64 at = i + 16ull * lane;
+            unsigned bad = 16;
+            for (unsigned k = 0; k < 16; k++) if (at + k < i1 && p[at + k] != v && bad == 16) bad = k;
+            const u64 m = __ballot(bad < 16);
+            if (m) first = i + 16ull * (unsigned)__builtin_ctzll(m) + (unsigned)__shfl((int)bad, __builtin_ctzll(m));
+        }
+        if (first < i1) {
+            const u64 f = KIND == 1 ? first / 4 : (first / P.feed.stride) * P.feed.run + first % P.feed.stride;
+            if (f >= (u64)DFX_X0 + 64) res = (unsigned)f;
+        }
+    }
+    if (lane == 0) X.onset[s] = res;
+}
+
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
 template <int KIND>
 __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
     // (the mix table in LDS here too: a lone lane per stream waits for every look-up, and one in global memory is an L2 round trip —
-    // 0.39 ms of prologue and probe for ONE stream, most of it those)
+    // 0.91 ms of prologue and probe at 16 384 streams, 0.41 with this)
     if constexpr (KIND == 0) {
         dfx_lut_to_lds(X.lut, lutu, 64);
         __syncthreads();
@@ -283,6 +341,8 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
     DfEnc e{};
     DfsAcc acc;
     auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)lutu + 128 * 257; else return DfeRows{}; }();
+    u64 pos = f1;        // where the references end and the probe sets out
+    int ref2 = 0;
     if (X.phase != 2) {
         dfx_span<false>(p, 0, f1, P.feed, d, e, lutc, acc);
         X.ctl[s] = 0;
@@ -292,10 +352,42 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
 #pragma unroll
         for (int i = 0; i < 5; i++) X.ctl[(size_t)(2 + i) * X.npad + s] = v[i];   // the decoder's side of the reference
         X.ctl[(size_t)8 * X.npad + s] = 0;
+        // A stream that STARTS in digital silence (every other CD rip): the reference sits at the strength floor and says nothing about the
+        // class the encoder will be in once the signal sets in — every lane behind the onset would guess one class in four, all of them the
+        // same, and the whole batch would pay a second round.  The lane walks on through the silence (dfx_walk_silence: a compare per dword),
+        // DFX_X0 units into the signal, and leaves the state there as the lanes' second model.
+        const u64 on = X.onset[s];
+        if (e.strength <= 9 && on) {
+            // (1) a few dwords until the pair of states repeats: decoder and encoder are functions of (state, bits), so a dword that left them
+            // where it found them does so again — every further dword of the silence can be skipped; (2) on from the last whole dword before the
+            // onset, through it, until the strength leaves the floor; (3) DFX_X0 units into the signal: the second reference
+            u64 f = f1;
+            bool fixed = false;
+            for (int k = 0; k < 16 && !fixed && f + 4 < on; k++) {
+                const int s0[8] = {d.p.n, d.p.strength, d.p.pb, d.lpf, d.pn, e.cu, e.strength, e.pb};
+                dfx_span<false>(p, f, f + 4, P.feed, d, e, lutc, acc);
+                f += 4;
+                fixed = s0[0] == d.p.n && s0[1] == d.p.strength && s0[2] == d.p.pb && s0[3] == d.lpf && s0[4] == d.pn && s0[5] == e.cu && s0[6] == e.strength && s0[7] == e.pb;
+            }
+            if (fixed || f + 4 >= on) {
+                if (fixed && on > f + 8) f += (on - 8 - f) / 4 * 4;   // (8 short: a feed run's doubled byte maps to the later of its two units)
+                u64 g = f;
+                while (g < on + 256 && g + DFX_X0 < fed && e.strength <= 9) { dfx_span<false>(p, g, g + 4, P.feed, d, e, lutc, acc); g += 4; }
+                if (e.strength > 9 && g + DFX_X0 <= fed) {
+                    dfx_span<false>(p, g, g + DFX_X0, P.feed, d, e, lutc, acc);
+                    g += DFX_X0;
+                    if (e.strength > 9) ref2 = dfs_pack(e);
+                }
+                pos = g;
+            } else pos = f;
+        }
+        X.ref2[s] = ref2;
         if (X.phase == 1) {   // (the control block is the verify pass's from here on: the probe continues from a copy)
+            dfp_pack(d, v);
 #pragma unroll
             for (int i = 0; i < 5; i++) X.pst[(size_t)i * X.npad + s] = v[i];
             X.pst[(size_t)5 * X.npad + s] = dfs_pack(e);
+            X.pst[(size_t)6 * X.npad + s] = (int)pos;
             return;
         }
     } else {
@@ -304,36 +396,46 @@ __global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
         for (int i = 0; i < 6; i++) v[i] = X.pst[(size_t)i * X.npad + s];
         dfp_unpack(v, d);
         e = dfs_unpack(v[5]);
+        pos = (u64)X.pst[(size_t)6 * X.npad + s];
+        ref2 = X.ref2[s];
     }
-    if (X.probe && fed >= DFX_PROBE_END) {
-        // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on to DFX_PROBE_END, and from
-        // DFX_PROBE_FROM a guess modelled on the reference runs beside it, the way the chunk lanes' guesses will — do they meet?
-        const DfEnc ref = e;
-        dfx_span<false>(p, f1, DFX_PROBE_FROM, P.feed, d, e, lutc, acc);
+    const u64 pf = pos + (DFX_PROBE_FROM - DFX_X0), pe = pos + (DFX_PROBE_END - DFX_X0);
+    if (X.probe && fed >= pe) {
+        // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on for DFX_PROBE_END - DFX_X0 units, and
+        // from DFX_PROBE_FROM - DFX_X0 on a guess modelled on the references runs beside it, the way the chunk lanes' guesses will — do they meet?
+        const DfEnc ref = dfs_unpack(X.ctl[(size_t)X.npad + s]);
+        dfx_span<false>(p, pos, pf, P.feed, d, e, lutc, acc);
         DfEnc g;
-        bool first = true;
+        bool first = true, flat;
         if constexpr (KIND == 0) {
-            fed_for_each(p, DFX_PROBE_FROM, DFX_PROBE_END, P.feed, [&](unsigned byte) {
+            const unsigned b0 = p[dfp_src_index(pf, P.feed)], b1 = p[dfp_src_index(pf + 1, P.feed)], b2 = p[dfp_src_index(pf + 2, P.feed)], b3 = p[dfp_src_index(pf + 3, P.feed)];
+            flat = b0 == b1 && b1 == b2 && b2 == b3;
+        } else {
+            const unsigned w0 = *reinterpret_cast<const unsigned *>(p + 4 * pf);
+            flat = w0 == (w0 & 0xFFu) * 0x01010101u;
+        }
+        if constexpr (KIND == 0) {
+            fed_for_each(p, pf, pe, P.feed, [&](unsigned byte) {
                 const unsigned nb = ~byte;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int l = df_decode_b(d, df_pm1(nb, 2 * k)), r = df_decode_b(d, df_pm1(nb, 2 * k + 1));
                     const unsigned u = (unsigned)lutc[l * 256 + r];
-                    if (first) { g = dfx_guess(ref, u); first = false; }
+                    if (first) { g = dfx_guess(ref, u, ref2, flat); first = false; }
                     df_encode_u(e, u);
                     df_encode_u(g, u);
                 }
             });
         } else {
-            for (u64 i = 4ull * DFX_PROBE_FROM; i < 4ull * DFX_PROBE_END; i++) {
+            for (u64 i = 4ull * pf; i < 4ull * pe; i++) {
                 const unsigned u = (unsigned)p[i] ^ 0x80u;
-                if (first) { g = dfx_guess(ref, u); first = false; }
+                if (first) { g = dfx_guess(ref, u, ref2, flat); first = false; }
                 df_encode_u(e, u);
                 df_encode_u(g, u);
             }
         }
         if (dfs_pack(g) != dfs_pack(e)) atomicAdd(&X.flags[14], 1u);
-        else if (ref.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
+        else if (e.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
     }
 }
 
@@ -407,7 +509,8 @@ __global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) 
         if constexpr (KIND == 1) {
             // warm-up over the block before the chunk: a guess modelled on the reference (dfx_guess), charge on the block's first sample
             const u64 fw = f0 - P.W;
-            e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), (unsigned)p[4 * fw] ^ 0x80u);
+            const unsigned w0 = *reinterpret_cast<const unsigned *>(p + 4 * fw);
+            e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), (w0 & 0xFFu) ^ 0x80u, X.round ? 0 : X.ref2[s], w0 == (w0 & 0xFFu) * 0x01010101u);
             dfx_span<false>(p, fw, f0, P.feed, d, e, lutc, acc);
         } else {
             // warm-up over the block before the chunk: the decoder with its exact strength and previous bit, charge and filter from zero;
@@ -441,7 +544,8 @@ __global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) 
                 // indices that are multiples of 4, so the copy is in the reference's class of the invariant without further ado — and the
                 // charge on the first sample.  A reference AT the strength floor (silence: the encoder runs a 2-cycle there, clamped at
                 // every step, and which of its two phases it is in is not a matter of class) is copied whole, charge included.
-                e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), u[0]);
+                const unsigned b0 = p[dfp_src_index(fe, P.feed)], b1 = p[dfp_src_index(fe + 1, P.feed)], b2 = p[dfp_src_index(fe + 2, P.feed)], b3 = p[dfp_src_index(fe + 3, P.feed)];
+                e = dfx_guess(dfs_unpack(X.ctl[(size_t)X.npad + s]), u[0], X.round ? 0 : X.ref2[s], b0 == b1 && b1 == b2 && b2 == b3);
 #pragma unroll
                 for (int k = 0; k < 4; k++) df_encode_u(e, u[k]);
             }
@@ -659,7 +763,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     if (const char *e = getenv("AUKIT_DFX_MSUB")) msub = (unsigned)std::max(1, std::min(atoi(e), 64));
     const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * msub * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
-                 o_ctl = take((size_t)9 * npad * 4), o_pst = take((size_t)6 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64);
+                 o_ctl = take((size_t)9 * npad * 4), o_pst = take((size_t)7 * npad * 4), o_on = take((size_t)2 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64 + (size_t)npad);
     int rc = ctx->tmp_buf2.ensure(o + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
@@ -681,11 +785,12 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     P.skip_last = 1;   // (the strength behind the last chunk's start is nobody's warm-up: an eighth of the scan's bytes for a batch cut into eight chunks)
     X.Wd = Wd; X.npad = npad; X.rounds = rounds; X.G = G; X.nck = nck;
     X.fix_iv = std::max<unsigned>(2, (unsigned)(W / G));  // a warm-up length
-    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.pst = reinterpret_cast<int *>(B + o_pst); X.hard = reinterpret_cast<unsigned *>(B + o_hard);
+    X.st = reinterpret_cast<int *>(B + o_st); X.ck = reinterpret_cast<int *>(B + o_ck); X.fx = reinterpret_cast<int *>(B + o_fx); X.ctl = reinterpret_cast<int *>(B + o_ctl); X.pst = reinterpret_cast<int *>(B + o_pst); X.onset = reinterpret_cast<unsigned *>(B + o_on); X.ref2 = reinterpret_cast<int *>(B + o_on) + npad; X.hard = reinterpret_cast<unsigned *>(B + o_hard);
     X.flags = reinterpret_cast<unsigned *>(B + o_fl);
     X.lut = reinterpret_cast<const unsigned char *>(ctx->dfx_lut.p);   // (kind 1: never read)
     X.enc_out = out; X.ooff = d_ooff;
-    if (hipMemsetAsync(X.flags, 0, 64, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    if (hipMemsetAsync(X.flags, 0, 64 + (size_t)npad, ctx->stream) != hipSuccess) return fail(AUKIT_E_HIP, "hipMemsetAsync failed");
+    P.lead_on = X.onset; P.inner = reinterpret_cast<unsigned char *>(X.flags) + 64;
     // The probe: one guess per stream is tried first, at the stream's start (0.3 ms of a lane per stream, one look at the outcome).  Where
     // more than one in sixteen misses, or the streams start in silence (whatever follows it will be in another class), the batch is declined
     // and runs the older schedule: a failed speculation costs rounds of a whole chunk lane's time each (and a large batch, cut into few chunks
@@ -698,6 +803,9 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_prologue<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         ctx->dfx_attr_set = true;
     }
+    // (where each stream's leading silence ends: the prologue's second reference and the strength scan's look-out for silence behind it)
+    if (J.kind == 0) hipLaunchKernelGGL(k_dfx_onset<0>, dim3(n), dim3(64), 0, ctx->stream, X);
+    else hipLaunchKernelGGL(k_dfx_onset<1>, dim3(n), dim3(64), 0, ctx->stream, X);
     hipStream_t side = nullptr;
     if ((rc = ctx_side_fork(ctx, &side))) return rc;
     // A small batch does not wait for the probe: the chunk lanes need the reference only (512 samples of a lone lane, not 3072), the probe runs
@@ -712,12 +820,12 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     prologue(aside ? 1u : 0u);
     // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
     // is cut into many chunks per stream; a batch with few chunks per stream declines them)
-    if (X.probe && !aside) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
     if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
     if ((rc = ctx_side_join(ctx))) return rc;
+    if (X.probe && !aside) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, ctx->stream, X.flags, n, nchunk < 24 ? 1u : 0u, J.kind == 0 ? P.inner : nullptr);
     if (aside) {   // (the side stream again, behind the reference; joined before the host's first look at the flags)
         prologue(2u);
-        hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(1), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u);
+        hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u, (const unsigned char *)nullptr);
     }
     const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256)), cgrid((unsigned)(((size_t)n * nchunk + AUKIT_DFX_WG - 1) / AUKIT_DFX_WG));
     // Rounds are queued two at a time with a look at the counters behind each pair (the first look is the call's one host synchronisation on signal:
@@ -757,7 +865,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS] = h[8]; ctx->counters[AUKIT_COUNTER_DFPWM_CHUNKS_REDONE] = h[11]; ctx->counters[AUKIT_COUNTER_DFPWM_RESPECULATED] = h[10];
     ctx->counters[AUKIT_COUNTER_DFPWM_HARD] = h[13];
     if (getenv("AUKIT_DFPWM_STATS"))
-        fprintf(stderr, "[dfpwm spec] probe: of %u streams, %u guesses missed, %u start in silence%s\n", n, h[14], h[15], h[6] ? ": declined" : "");
+        fprintf(stderr, "[dfpwm spec] probe: of %u streams, %u guesses missed, %u silent where the probe ends, %u with silence behind the one they start with%s\n", n, h[14], h[15], h[12], h[6] ? ": declined" : "");
     if (getenv("AUKIT_DFPWM_STATS") && !h[6])
         fprintf(stderr, "[dfpwm spec] %u streams x %u chunks of %u blocks of %llu fed bytes (decoder-only warm-up %u, checkpoints every %u, %u rounds): %u chunks verified; %u chunks run again by k_dfx_fix (%u checkpoint intervals); %u stream rounds re-speculated (flags %u %u %u %u %u %u); %u hard streams\n",
                 n, nchunk, bpc, (unsigned long long)W, Wd, G, rounds, h[8], h[11], h[9], h[10], h[0], h[1], h[2], h[3], h[4], h[5], h[13]);
