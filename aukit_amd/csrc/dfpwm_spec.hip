@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_dfx_decide(unsigned *flags, unsigned n,
     }
     __syncthreads();
     if (threadIdx.x) return;
-    flags[12] = cnt;
+    if (inner) flags[12] = cnt;
     if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n || cnt > 8) flags[6] = 1;
 }
 
@@ -348,16 +348,16 @@ __global__ __launch_bounds__(64) void k_dfx_onset(const DfxParams X) {
 
 // a lane per stream: the true encoder's state after the first DFX_X0 fed bytes (the reference of round 0); the control block
 template <int KIND>
-__global__ __launch_bounds__(64) void k_dfx_prologue(const DfxParams X) {
+__global__ __launch_bounds__(256) void k_dfx_prologue(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     const DfParParams &P = X.P;
     // (the mix table in LDS here too: a lone lane per stream waits for every look-up, and one in global memory is an L2 round trip —
     // 0.91 ms of prologue and probe at 16 384 streams, 0.41 with this)
-    if constexpr (KIND == 0) {
-        dfx_lut_to_lds(X.lut, lutu, 64);
+    if constexpr (KIND == 0) {   // (four waves to a workgroup: they share the copy)
+        dfx_lut_to_lds(X.lut, lutu, 256);
         __syncthreads();
     }
-    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
     if (s >= P.n) return;
     const unsigned char *p = P.src + P.off[s];
     const u64 fed = P.fed[s], f1 = fed < DFX_X0 ? fed : (u64)DFX_X0;
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) 
         dfx_span<true>(p, b0, b1, P.feed, d, e, lutc, acc);
         dfx_store6(dfx_ck(X, c, j, s), X.npad, d, e);
         b0 = b1;
+        if (__hip_atomic_load(&X.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the probe, running beside this pass, declined the batch
     }
     dfx_span<true>(p, b0, f1, P.feed, d, e, lutc, acc);
     if (f1 == fed) dfx_stream_tail<KIND>(X, s, p, fed, acc, e);
@@ -771,7 +772,9 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     if (!min_bpc)
         for (unsigned b = b0; b < 3; b++)
             if ((uint64_t)n * ((nblk_all + b - 1) / b) * 4 <= (uint64_t)ctx->num_cus * 4 * 64 * 3) { bpc = b; small = true; break; }
-    if (const char *e = getenv("AUKIT_DFX_PROBE_ASIDE")) small = atoi(e) != 0;
+    bool probe_aside = true;
+    if (const char *e = getenv("AUKIT_DFX_PROBE_ASIDE")) probe_aside = atoi(e) != 0;
+    (void)small;
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
     // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
@@ -838,21 +841,22 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     else hipLaunchKernelGGL(k_dfx_onset<1>, dim3(n), dim3(64), 0, ctx->stream, X);
     hipStream_t side = nullptr;
     if ((rc = ctx_side_fork(ctx, &side))) return rc;
-    // A small batch does not wait for the probe: the chunk lanes need the reference only (512 samples of a lone lane, not 3072), the probe runs
-    // beside them, and a batch it declines has lost one pass of chunk lanes — 0.3 ms and more off every call on signal, under a tenth on
-    // top of what a declined batch costs in the older schedules.  A large batch (a pass there is most of a step) asks first.
-    const bool aside = small && X.probe;
+    // The chunk lanes do not wait for the probe: they need the reference only (512 samples of a lone lane, not 3072) — the probe runs beside
+    // them, and when it declines the batch they hear of it at their next checkpoint (k_dfx_chunks looks at the flag there): a declined batch
+    // has lost the 0.3 - 0.4 ms the probe ran on, every other batch starts that much earlier (2048 streams: 0.43 -> 0.19 ms into the step).
+    const bool aside = probe_aside && X.probe;
     auto prologue = [&](unsigned phase) {
         X.phase = phase;
-        if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 63) / 64), dim3(64), 65536, side, X);
-        else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 63) / 64), dim3(64), 0, side, X);
+        if (J.kind == 0) hipLaunchKernelGGL(k_dfx_prologue<0>, dim3((n + 255) / 256), dim3(256), 65536, side, X);
+        else hipLaunchKernelGGL(k_dfx_prologue<1>, dim3((n + 255) / 256), dim3(256), 0, side, X);
     };
     prologue(aside ? 1u : 0u);
     // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
     // is cut into many chunks per stream; a batch with few chunks per stream declines them)
     if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
     if ((rc = ctx_side_join(ctx))) return rc;
-    if (X.probe && !aside) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, ctx->stream, X.flags, n, nchunk < 24 ? 1u : 0u, J.kind == 0 ? P.inner : nullptr);
+    // (the verdict on silence behind the leading one needs the scan: here; the probe's verdict follows the probe, on the side stream when it runs aside)
+    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, ctx->stream, X.flags, n, nchunk < 24 ? 1u : 0u, J.kind == 0 ? P.inner : nullptr);
     if (aside) {   // (the side stream again, behind the reference; joined before the host's first look at the flags)
         prologue(2u);
         hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u, (const unsigned char *)nullptr);
