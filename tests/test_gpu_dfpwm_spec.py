@@ -123,6 +123,49 @@ def test_spec_transcode_class_changes_and_noise(ctx, oracle, monkeypatch):
     assert ctx.last_kernel()[0] != "k_dfx_chunks" and got == want
 
 
+def test_spec_transcode_leading_silence_takes_one_round(ctx, oracle, monkeypatch):
+    """streams that START in digital silence (0.1 - 0.8 s of it, from the first or the second sample: 0x55 or 0xAA bytes): k_dfx_onset finds where it
+    ends, the prologue walks there and leaves a second reference behind the onset — the lanes in the signal model their guess on that one and the
+    batch is through in ONE round, also cut the way a large batch is (few chunks per stream: no second round to be had).  Silence BEHIND the
+    leading one is found by the strength scan: more than eight such streams in a batch cut that way and it is declined."""
+    B, N = _B(), _N()
+    n = 60000 * 4
+    streams = []
+    for k, lead in enumerate((4800, 9601, 20000, 38400, 12000, 7000, 30001, 16000, 5000, 26000)):
+        l, r = signal(n, 48000, 4, 120 + 2 * k) * 100, signal(n, 48000, 4, 121 + 2 * k) * 90
+        l[k % 2: lead] = 0
+        r[k % 2: lead] = 0
+        streams.append(_enc_stereo(oracle, l, r))
+    assert all(b"\x55" * 64 in s[:600] or b"\xaa" * 64 in s[:600] for s in streams)
+    bt = B.Batch.upload(ctx, streams)
+    want = [_ref(oracle, s) for s in streams]
+    for env in ({}, {"AUKIT_DFX_CHUNKS": "7"}, {"AUKIT_DFX_PROBE_ASIDE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx.set_option(N.OPT_COLLECT_STATS, 1)
+        got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        name, respec, hard = ctx.last_kernel()[0], ctx.counter(N.COUNTER_DFPWM_RESPECULATED), ctx.counter(N.COUNTER_DFPWM_HARD)
+        ctx.set_option(N.OPT_COLLECT_STATS, 0)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got == want, env
+        assert name == "k_dfx_chunks" and respec == 0 and hard == 0, (env, name, respec, hard)
+    # a second passage of silence inside every stream: rounds where they are to be had, declined where they are not
+    inner = []
+    for k in range(10):
+        l, r = signal(n, 48000, 4, 150 + 2 * k) * 100, signal(n, 48000, 4, 151 + 2 * k) * 90
+        l[: 9000] = 0; r[: 9000] = 0
+        l[n // 2: n // 2 + 12000] = 0; r[n // 2: n // 2 + 12000] = 0
+        inner.append(_enc_stereo(oracle, l, r))
+    bt2 = B.Batch.upload(ctx, inner)
+    want2 = [_ref(oracle, s) for s in inner]
+    assert B.dfpwm_transcode_mono(ctx, bt2, 2).download() == want2 and ctx.last_kernel()[0] == "k_dfx_chunks"
+    monkeypatch.setenv("AUKIT_DFX_CHUNKS", "7")
+    got2 = B.dfpwm_transcode_mono(ctx, bt2, 2).download()
+    monkeypatch.delenv("AUKIT_DFX_CHUNKS")
+    assert got2 == want2 and ctx.last_kernel()[0] != "k_dfx_chunks"
+
+
 def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):
     """2048 streams (the shard one GPU of eight gets of BASELINE config 4), 2 s each, 8 distinct signals: the oracle's bytes, and the single
     guess is right for nearly every chunk (what the speed rests on)"""
