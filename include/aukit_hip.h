@@ -144,8 +144,11 @@ typedef enum {
                                    0 (default): they do not. */
     AUKIT_OPT_DFPWM_SPECULATE = 3 /* 1 (default): aukit_dfpwm_transcode_mono cuts every stream into time chunks that are decoded, mixed and ENCODED
                                    by a lane each from a guessed encoder state, verified afterwards (dfpwm_spec.hip) — several times faster
-                                   on signal, same bytes always; up to ~1.9x slower than 0 where the guesses fail (the encoder at its strength
-                                   floor: long digital silence, noise).  0: one encoder lane per stream behind the chunk-parallel decoder. */
+                                   on signal (silence a stream STARTS with included), same bytes always; a few short streams (up to 16 of
+                                   up to 40 stream-seconds together) stay with the exact parallel encoder either way; up to ~1.6x slower than
+                                   0 where the guesses fail and the probe does not notice (noise-like streams; silence INSIDE the streams of a
+                                   batch too large for a second round is noticed and declined).  0: one encoder lane per stream behind the
+                                   chunk-parallel decoder. */
 } aukit_option;
 int aukit_ctx_set_option(aukit_ctx *ctx, int option, int value);
 /* counters of the most recent call that produced them (AUKIT_OPT_COLLECT_STATS = 1) */
