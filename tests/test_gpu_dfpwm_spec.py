@@ -150,6 +150,20 @@ def test_spec_transcode_leading_silence_takes_one_round(ctx, oracle, monkeypatch
             monkeypatch.delenv(k)
         assert got == want, env
         assert name == "k_dfx_chunks" and respec == 0 and hard == 0, (env, name, respec, hard)
+    # Audio:dfpwm on samples that start with zeros (a PCM source's digital silence: one sample value repeated): the same second reference
+    t = np.arange(n) / 48000
+    pcm = []
+    for k, lead in enumerate((4801, 12000, 26003, 9000, 40000, 7001, 15000, 20000, 5003, 33000)):
+        x = 0.6 * np.sin(2 * np.pi * (220 + 35 * k) * t) + 0.15 * np.sin(2 * np.pi * (1900 + 111 * k) * t)
+        x[:lead] = 0
+        pcm.append(x)
+    ab = B.AudioBatch.upload(ctx, [[x] for x in pcm], 48000, dtype=N.F64)
+    ctx.set_option(N.OPT_COLLECT_STATS, 1)
+    enc = B.dfpwm_encode(ctx, ab, True).download()
+    name, respec = ctx.last_kernel()[0], ctx.counter(N.COUNTER_DFPWM_RESPECULATED)
+    ctx.set_option(N.OPT_COLLECT_STATS, 0)
+    assert enc == [oracle.audio_dfpwm(oracle.Audio([x], 48000), True) for x in pcm]
+    assert name == "k_dfpwm_quantize+k_dfx_chunks<rows>" and respec == 0, (name, respec)
     # a second passage of silence inside every stream: rounds where they are to be had, declined where they are not
     inner = []
     for k in range(10):
