@@ -897,6 +897,9 @@ def test_fuzz_dfpwm_speculation(ctx, oracle, seed, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     nstreams = int(rng.integers(1, 6))
+    if seed % 3 == 2:   # (a third of the cases with the probe: beside the first pass or in front of it; whatever it decides, the oracle's bytes)
+        monkeypatch.delenv("AUKIT_DFX_NOPROBE")
+        monkeypatch.setenv("AUKIT_DFX_PROBE_ASIDE", str(seed // 3 % 2))
     ch = int(rng.integers(1, 3))
     a = [[_fuzz_signal(rng, n) for _ in range(ch)] for n in (int(rng.choice([12000, 48001, 70003, int(rng.integers(20000, 200000))])) for _ in range(nstreams))]
     inter = bool(rng.integers(0, 2))
