@@ -127,8 +127,24 @@ AUKIT_DEV void dfs_put(DfsAcc &a, unsigned v, unsigned nbits) {
 struct DfxLds {
     const unsigned char *mix;
     const unsigned *bits;
+    const int *lp;   // 128 - 140 q for q = -128 .. 128, addressed from its middle: the low-pass step's first multiply-add as a look-up (-DAUKIT_DFX_LP_TABLE, an
+                     // A/B that lost: 12.3 -> 12.8 ms at 16 384 streams, profiles/r05_dfx_lp_table_ab.txt — the LDS pipe has no room for eight more per byte)
     AUKIT_DEV unsigned char operator[](int i) const { return mix[i]; }
 };
+// df_decode_b (dfpwm_dev.h) with the low-pass's `128 - 140 q` from a table: q = (n + x + 3) >> 2 is only ever multiplied by -140 and biased, so
+// the lane keeps 4 q — the same sum with its two low bits cleared, one AND for the shift — as the table's byte offset, and one multiply-add is left
+AUKIT_DEV int dfx_decode_bt(DfDec &d, int b, const int *lp) {
+    const bool same = b == d.p.pb;
+    const int pn = d.pn;
+    const int n = df_predict(d.p, b);
+    const int q4 = (n + (same ? n : pn) + 3) & ~3;
+    d.pn = n;
+    const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(lp) + q4);
+    int u;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(u) : "v"(d.lpf), "s"(116), "v"(t));
+    d.lpf = u >> 8;
+    return d.lpf;
+}
 AUKIT_DEV void dfx_bits_to_lds(unsigned *bt, unsigned nthreads) {
     for (unsigned i = threadIdx.x; i < 256; i += nthreads) {
         unsigned t = 0;
@@ -144,7 +160,11 @@ AUKIT_DEV unsigned dfx_byte(DfDec &d, DfEnc &e, unsigned byte, LUT lutc) {
         const unsigned tb = lutc.bits[byte];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+#ifdef AUKIT_DFX_LP_TABLE
+            const int l = dfx_decode_bt(d, (int)(tb << (28 - 8 * k)) >> 28, lutc.lp), r = dfx_decode_bt(d, (int)(tb << (24 - 8 * k)) >> 28, lutc.lp);
+#else
             const int l = df_decode_b(d, (int)(tb << (28 - 8 * k)) >> 28), r = df_decode_b(d, (int)(tb << (24 - 8 * k)) >> 28);
+#endif
             out |= df_encode_u(e, (unsigned)lutc[l * 256 + r]) & (1u << k);
         }
     } else {
@@ -503,17 +523,19 @@ template <int KIND>
 __global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     [[maybe_unused]] __shared__ unsigned bits_lds[KIND == 0 ? 256 : 1];
+    [[maybe_unused]] __shared__ int lp_lds[KIND == 0 ? 260 : 1];
     const DfParParams &P = X.P;
     if (dfx_round_off(X)) return;
     if constexpr (KIND == 0) {
         dfx_lut_to_lds(X.lut, lutu, AUKIT_DFX_WG);
         dfx_bits_to_lds(bits_lds, AUKIT_DFX_WG);
+        for (int i = threadIdx.x; i < 257; i += AUKIT_DFX_WG) lp_lds[i] = 128 - 140 * (i - 128);
         __syncthreads();
     }
 #ifdef AUKIT_DFX_NO_BITS_TABLE   // (A/B)
     auto lutc = [&]() { if constexpr (KIND == 0) return (const unsigned char *)(lutu + 128 * 257); /* indexed by signed (l, r) */ else return DfeRows{}; }();
 #else
-    auto lutc = [&]() { if constexpr (KIND == 0) return DfxLds{(const unsigned char *)(lutu + 128 * 257), bits_lds}; else return DfeRows{}; }();
+    auto lutc = [&]() { if constexpr (KIND == 0) return DfxLds{(const unsigned char *)(lutu + 128 * 257), bits_lds, lp_lds + 128}; else return DfeRows{}; }();
 #endif
     const u64 gid = (u64)blockIdx.x * AUKIT_DFX_WG + threadIdx.x;
     const unsigned c = (unsigned)(gid / P.n), s = (unsigned)(gid - (u64)c * P.n);  // a wave = one chunk index of 64 streams
