@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_dfx_prologue(const DfxParams X) {
         X.ctl[(size_t)8 * X.npad + s] = 0;
         // A stream that STARTS in digital silence (every other CD rip): the reference sits at the strength floor and says nothing about the
         // class the encoder will be in once the signal sets in — every lane behind the onset would guess one class in four, all of them the
-        // same, and the whole batch would pay a second round.  The lane walks on through the silence (dfx_walk_silence: a compare per dword),
+        // same, and the whole batch would pay a second round.  The lane walks on through the silence (k_dfx_onset found where it ends),
         // DFX_X0 units into the signal, and leaves the state there as the lanes' second model.
         const u64 on = X.onset[s];
         if (e.strength <= 9 && on) {
@@ -790,13 +790,11 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // SIMD, two likewise, else three.
     const unsigned b0 = std::max<unsigned>(nblk_all ? (nblk_all + want - 1) / want : 1, 1);
     unsigned bpc = std::max(b0, min_bpc ? min_bpc : 3u);
-    bool small = false;   // most SIMDs idle: one pass of the chunk lanes is a small fraction of what the older schedules take
     if (!min_bpc)
         for (unsigned b = b0; b < 3; b++)
-            if ((uint64_t)n * ((nblk_all + b - 1) / b) * 4 <= (uint64_t)ctx->num_cus * 4 * 64 * 3) { bpc = b; small = true; break; }
+            if ((uint64_t)n * ((nblk_all + b - 1) / b) * 4 <= (uint64_t)ctx->num_cus * 4 * 64 * 3) { bpc = b; break; }
     bool probe_aside = true;
     if (const char *e = getenv("AUKIT_DFX_PROBE_ASIDE")) probe_aside = atoi(e) != 0;
-    (void)small;
     const unsigned nchunk = nblk_all ? (nblk_all + bpc - 1) / bpc : 0;
     if (nchunk < 2) return AUKIT_OK;
     // rounds: a re-speculation costs the time of one chunk lane however few streams need it — a fraction of the step when the batch is cut
