@@ -523,13 +523,19 @@ template <int KIND>
 __global__ __launch_bounds__(AUKIT_DFX_WG) void k_dfx_chunks(const DfxParams X) {
     extern __shared__ unsigned char lutu[];
     [[maybe_unused]] __shared__ unsigned bits_lds[KIND == 0 ? 256 : 1];
+#ifdef AUKIT_DFX_LP_TABLE
     [[maybe_unused]] __shared__ int lp_lds[KIND == 0 ? 260 : 1];
+#else
+    int *const lp_lds = nullptr;
+#endif
     const DfParParams &P = X.P;
     if (dfx_round_off(X)) return;
     if constexpr (KIND == 0) {
         dfx_lut_to_lds(X.lut, lutu, AUKIT_DFX_WG);
         dfx_bits_to_lds(bits_lds, AUKIT_DFX_WG);
+#ifdef AUKIT_DFX_LP_TABLE
         for (int i = threadIdx.x; i < 257; i += AUKIT_DFX_WG) lp_lds[i] = 128 - 140 * (i - 128);
+#endif
         __syncthreads();
     }
 #ifdef AUKIT_DFX_NO_BITS_TABLE   // (A/B)
