@@ -503,6 +503,7 @@ class QoaStream(Workload):
 
 class DfpwmTranscode(Workload):
     name, unit = "dfpwm_transcode", "Msamples/s"
+    valu_per_unit = (731 / 16, "k_dfx_chunks<0>'s hot block: 731 VALU instructions per source dword = 16 mono samples (2 x 15 decoder steps, mix index, 12 encoder steps, bookkeeping)")
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
         # "produced by the build's DFPWM encoder" — the config-1 style signal, two channels, 48 kHz, through the product's own
@@ -969,6 +970,14 @@ def main(argv=None):
                 line["roofline"]["launch_bytes_sum"] = alg_bytes
                 line["roofline"]["note"] = ("several launches per step: frac = (input bytes + final output bytes) / the step's kernel time; launch_bytes_sum adds every "
                                             "launch's own input + output, intermediates included, and is not a roofline fraction of the task")
+            if hasattr(wl, "valu_per_unit"):
+                # a step bound by VALU issue, not by bytes (the HBM fraction above says so: it is tiny): the USEFUL instructions — the hot loop's
+                # count per unit from the built code object, warm-ups, scans and repairs not counted — over the whole step's kernel
+                # time, against what 1024 SIMDs of 16 lanes issue at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+                per, what = wl.valu_per_unit
+                peak = 1024 * 16 * 2.4e9 / 1e12
+                ach = out_samples * per / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+                line["issue"] = {"bound": "valu", "achieved": ach, "peak": peak, "unit": "T lane-instructions/s", "frac": ach / peak, "per_unit": per, "counted": what}
             if wl.distinct:
                 line["config"]["distinct_streams"] = wl.distinct
             if hasattr(wl, "extra"):
