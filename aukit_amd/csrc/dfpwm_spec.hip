@@ -41,6 +41,10 @@ constexpr unsigned DFX_PROBE_FROM = 256, DFX_PROBE_END = 768;  // fed bytes: the
 #ifndef AUKIT_DFX_WG
 #define AUKIT_DFX_WG 256   // threads of a chunk-lane workgroup (one 64 KiB mix table each: two workgroups per CU)
 #endif
+#ifndef AUKIT_DFX_STRIKES
+#define AUKIT_DFX_STRIKES 3
+#endif
+constexpr int DFX_STRIKES = AUKIT_DFX_STRIKES;   // rounds in a row in which a stream got less than a sixteenth of itself further: hard
 constexpr unsigned DFX_LEAD_MAX = 60000;   // fed units (5 s of a 48 kHz stream) of leading silence the prologue walks through for the second reference
 constexpr unsigned DFX_X0 = 128;  // fed bytes (512 mono samples) the prologue runs from the reset state to learn the encoder's class
 
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
             later++;
             bad += X.fx[(size_t)k * 13 * X.npad + s] != 0 ? 1u : 0u;
         }
-        if (X.round + 1 >= X.rounds || strikes >= 3 || (later >= 12 && bad * 2 > later)) {
+        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 2 > later)) {
             X.ctl[s] = (int)P.nchunk + 1;
             X.hard[atomicAdd(&X.flags[13], 1u)] = s;
             return;

@@ -198,6 +198,37 @@ def test_spec_transcode_mid_batch_speculation_holds(ctx, oracle):
     assert respec == 0 and redone <= chunks // 50, (chunks, redone, respec)
 
 
+def test_spec_transcode_many_short_and_few_long_streams(ctx, oracle):
+    """the two ends of the planner: 40 000 one-second streams (more streams than the chip has lanes for two chunks each: the cut degenerates to
+    two chunks per stream, one round) with a fifth of a second of leading silence on every other class, and three two-minute streams (thousands of chunks each, the
+    verify lane's long walk) — the oracle's bytes for every class"""
+    B, N = _B(), _N()
+    K = 8
+    short = []
+    for i in range(K):
+        l, r = signal(48000, 48000, 4, 40 + 2 * i) * 100, signal(48000, 48000, 4, 41 + 2 * i) * 90
+        if i % 2:
+            l[:9600] = 0; r[:9600] = 0
+        short.append(_enc_stereo(oracle, l, r))
+    bt = B.Batch.upload(ctx, [short[i % K] for i in range(40000)])
+    got = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+    assert ctx.last_kernel()[0] == "k_dfx_chunks"
+    for c in range(K):
+        assert got[c] == _ref(oracle, short[c])
+        assert all(g == got[c] for g in got[c::K])
+    del bt, got
+    n = 48000 * 120
+    long_ = []
+    for i in range(3):
+        l, r = signal(n, 48000, 4, 60 + 2 * i) * 100, signal(n, 48000, 4, 61 + 2 * i) * 90
+        if i == 1:
+            l[:96000] = 0; r[:96000] = 0
+        long_.append(_enc_stereo(oracle, l, r))
+    got = B.dfpwm_transcode_mono(ctx, B.Batch.upload(ctx, long_), 2).download()
+    assert ctx.last_kernel()[0] == "k_dfx_chunks"
+    assert got == [_ref(oracle, s) for s in long_]
+
+
 ENC_ENVS = ({}, {"AUKIT_DFX_WE": "64", "AUKIT_DFX_G": "1"}, {"AUKIT_DFX_CHUNKS": "1000", "AUKIT_DFX_MIN_BPC": "1"}, {"AUKIT_DFX_ROUNDS": "1"},
             {"AUKIT_DFX_WE": "128", "AUKIT_DFX_CHUNKS": "7", "AUKIT_DFX_ROUNDS": "2"}, {"AUKIT_DFX_WPS": "1", "AUKIT_DFX_WE": "1008"})
 
