@@ -2,9 +2,8 @@
 
 The fused decoder gives a frame to ONE lane, which reads its bits code by code: 3.4 ms for a frame of 2 x 4096 samples however small the batch.
 Inside a Rice partition with parameter k the start of the code after the one at bit p is next(p) = p + zeros(p) + 1 + k — a function of the BIT
-POSITION alone, so a wave can fill next[] for every position of the partition at once (each lane a stretch of positions: count-leading-zeros on
-its window) and only the walk p -> next[p] along the chain of code starts stays serial: one dependent LDS read per sample instead of a
-code's whole decode.  This script parses frames of the bench fixture, checks that the walk over next[] lands on exactly the code starts the
+POSITION alone, so next[] can be filled for every position of the partition with independent instructions (count-leading-zeros on a
+sliding window) and only the walk p -> next[p] along the chain of code starts stays serial: one dependent LDS read per sample.  This script parses frames of the bench fixture, checks that the walk over next[] lands on exactly the code starts the
 sequential reader finds (remainder bits that look like unary runs and all), and counts what a wave would have to do:
 
     python tools/experiments/flac_rice_jump.py [frames=12]
@@ -130,7 +129,6 @@ print("walk over next[] == the sequential reader's code starts in %d of %d parti
     tot["walk_ok"], tot["walk_ok"] + tot["walk_bad"], tot["max_part_bits"], 2 * tot["max_part_bits"], tot["max_zeros"]))
 spf = tot["rice_samples"] / max(tot["frames"], 1)
 bpf = tot["rice_bits"] / max(tot["frames"], 1)
-print("per frame: %.0f coded samples, %.0f bit positions -> a wave fills next[] with %.0f positions per lane (clz on a sliding window: ~3 instructions each, %.0f wave-instructions)," % (spf, bpf, bpf / 64, 3 * bpf / 64))
-print("           then ONE lane walks %.0f dependent LDS reads (~100 cycles each: %.2f ms at 2.3 GHz) where the fused decoder's lane spends %.0f x 88 instructions x ~8 cycles = %.2f ms;" % (
-    spf, spf * 100 / 2.3e6, spf, spf * 88 * 8 / 2.3e6))
-print("           the values (k remainder bits + the run) are then 64 at a time, and the prediction a lane per channel (~4 dependent instructions per sample: %.2f ms)." % (spf / 2 * 4 * 7 / 2.3e6))
+print("per frame: %.0f coded samples, %.0f bit positions: filling next[] is ~3 instructions per position = %.0f per coded sample (the sequential reader: ~25, dependent);" % (spf, bpf, 3 * bpf / max(spf, 1)))
+print("           the walk is one dependent LDS read per code (~100 cycles) where the reader's own chain (align, count zeros, add) is ~50 - 80: no shorter.")
+print("           k_flac_decode spends 88 instructions per sample, most of them NOT on that chain — the idea does not pay as it stands (DESIGN.md, gap 1).")
