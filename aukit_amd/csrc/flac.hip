@@ -1387,6 +1387,8 @@ static int flac_run(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D, bool 
             AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipMemcpyAsync(chain.data(), d_chain, (size_t)n * sizeof(ChainOut), hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (getenv("AUKIT_FLAC_STATS"))
+                fprintf(stderr, "[flac stats] rounds %llu outer %llu turns %llu values|singles %llu lane_turns %llu live|single_turns %llu\n", hc.stats[0], hc.stats[1], hc.stats[2], hc.stats[3], hc.stats[4], hc.stats[5]);
             if (getenv("AUKIT_FLAC_DEBUG")) {
                 std::vector<CandInfo> hci(ncand);
                 (void)hipMemcpy(hci.data(), d_ci, ncand * sizeof(CandInfo), hipMemcpyDeviceToHost);
@@ -1570,10 +1572,11 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             FusedArgs A;
             A.G = G; A.cands = d_cand; A.first = first; A.count = count; A.ci = d_ci; A.C = C; A.depth = D.depth;
             A.scratch = reinterpret_cast<int *>(ctx->tmp_buf3.p); A.scratch_cap = scap; A.scratch_cursor = &d_cnt->scratch_cursor; A.flags = &d_cnt->flags;
-            A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket;
+            A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket; A.stats = d_cnt->stats;
             A.out16 = o16 ? 1 : 0;
             A.dbg = getenv("AUKIT_FLAC_FUSED_DBG") ? atoi(getenv("AUKIT_FLAC_FUSED_DBG")) : 0;
-            return flac_fused_launch(ctx, A);
+            static const bool round4 = getenv("AUKIT_FLAC_DECODER") && !strcmp(getenv("AUKIT_FLAC_DECODER"), "fused");   // A/B: k_flac_decode (flac_fused.hip)
+            return round4 ? flac_fused_launch(ctx, A) : flac_stream_launch(ctx, A);
         };
         std::vector<ChainOut> chain(n);
         bool restart = false;
@@ -1590,6 +1593,8 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipMemcpyAsync(chain.data(), d_chain, (size_t)n * sizeof(ChainOut), hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (getenv("AUKIT_FLAC_STATS"))
+                fprintf(stderr, "[flac stats] rounds %llu outer %llu turns %llu values|singles %llu lane_turns %llu live|single_turns %llu\n", hc.stats[0], hc.stats[1], hc.stats[2], hc.stats[3], hc.stats[4], hc.stats[5]);
             if (getenv("AUKIT_FLAC_DEBUG")) {
                 std::vector<CandInfo> hci(ncand);
                 (void)hipMemcpy(hci.data(), d_ci, ncand * sizeof(CandInfo), hipMemcpyDeviceToHost);

@@ -72,7 +72,7 @@ struct Carve {
     size_t at = 0;
     size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; }
 };
-struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, ticket; };
+struct Counters { u64 ncand, scratch_cursor, kind_count[16], kind_fill[16]; unsigned flags, ticket; u64 stats[8]; };   // stats: -DAUKIT_FLAC_STATS builds of k_flac_decode count their rounds and turns here (tools/r06_flac_stats.sh)
 
 // ---- flac_fused.hip: decodeFrame (:510-567) with the prediction (:411-419), the wasted-bits shift (:467-469), the stereo decorrelation and the
 // wrap (:482-507) done by the lane that reads the frame's bits — final integers leave the kernel once (k_flac_decode)
@@ -89,9 +89,12 @@ struct FusedArgs {
     int limit_factor;
     unsigned *ticket;
     int out16;               // finals as int16 (k_flac_decode<..., O16>; depths <= 16)
+    u64 *stats;              // Counters::stats
     int dbg;                 // ablation switches (AUKIT_FLAC_FUSED_DBG; wrong results): 1 no prediction, 2 no stores, 4 no read-back of parked values
 };
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A);
+// flac_stream.hip (round 6): the same contract, values in registers from the bit stream to the store
+int flac_stream_launch(aukit_ctx *ctx, const FusedArgs &A);
 // the chained frames' records in stream order (one lane per candidate)
 int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames, const u64 *stream_off);
 // chained frames: scratch → contiguous int32 rows (one workgroup per frame record)

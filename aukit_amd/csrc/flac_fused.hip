@@ -365,6 +365,9 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
 #pragma unroll
     for (int i = 0; i < (PF ? FLPW : 1); i++) { pf[i] = v4u{0, 0, 0, 0}; pf_line[i] = ~0ull; }
 
+#ifdef AUKIT_FLAC_STATS
+    u64 st_rounds = 0, st_outer = 0, st_turns = 0, st_values = 0, st_lane_turns = 0, st_live = 0;
+#endif
     bool more = true;
     while (more) {
         // ---- slide the LDS windows of the lanes that have used a quarter of theirs: 8 lanes × 16 bytes per window, 8 windows per load.
@@ -464,7 +467,13 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
         // a lane whose window reaches the end of its stream's data reads value by value with every check (a stream's last rounds)
         const bool careful = b.end < ((b.win_lo + FWN) << 6) + 64;
         bool go_on = __any(!rdone);
+#ifdef AUKIT_FLAC_STATS
+        st_rounds++; st_live += (u64)__builtin_popcountll(__ballot(have && st != S_DONE));
+#endif
         while (go_on) {
+#ifdef AUKIT_FLAC_STATS
+            st_outer++;
+#endif
             // -- the run loop: Rice codes (:370-376) or fields of `rk` bits (:405, :423, :457), one value per turn
             const bool run = !rdone && st == S_RUN && remaining > 0 && !careful;
             if (__any(run)) {
@@ -482,6 +491,9 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
                 // (tried, round 4 late: a second copy of this loop without the field arithmetic for Rice-only rounds, and a turn that commits
                 // unconditionally with the last one taken back — 36 -> 31 VALU instructions per value on paper, 8.0 -> 8.4 / 8.5 ms measured)
                 while (go) {
+#ifdef AUKIT_FLAC_STATS
+                    st_turns++; st_lane_turns += (u64)__builtin_popcountll(__ballot(true));
+#endif
                     const unsigned wn = b.lw[(d + 2) & FRING];          // for a crossing at the END of this turn: requested first, used last
                     const unsigned hi = __builtin_amdgcn_alignbit(w0, w1, (unsigned)s);
                     const int z = hi ? __builtin_clz(hi) : 32;
@@ -668,6 +680,9 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
         }
         if (st != S_DONE && b.pos > limit) { status = FE_LIMIT; st = S_DONE; }
 
+#ifdef AUKIT_FLAC_STATS
+        { int sv = cnt; for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o); st_values += (u64)sv; }
+#endif
         // ---- where the round's values go
         const bool decor = C == 2 && chan_asgn >= 8 && chan_asgn <= 10;
         const int mode = !decor ? 0 : (ch == 0 ? 1 : 2);
@@ -720,6 +735,9 @@ __global__ __launch_bounds__(64, PF ? 2 : 3) void k_flac_decode(const FusedArgs 
     }
     __syncthreads();
     flush();
+#ifdef AUKIT_FLAC_STATS
+    if (lane == 0) { atomicAdd(A.stats + 0, st_rounds); atomicAdd(A.stats + 1, st_outer); atomicAdd(A.stats + 2, st_turns); atomicAdd(A.stats + 3, st_values); atomicAdd(A.stats + 4, st_lane_turns); atomicAdd(A.stats + 5, st_live); }
+#endif
 }
 
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A) {
