@@ -291,7 +291,22 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         const unsigned own = s_rng[lane];
-        if (__any(own != 0u)) {
+        // the usual round: every row's halves are whole (eight pieces at a multiple of 16) or empty — a lane stores its 16 bytes or nothing
+        const unsigned pa_ = own & 0xFFu, pb_ = (own >> 8) & 0xFFu;
+        const bool usual = !((own >> 18) & 1u) && (pa_ == 0u || (pa_ == 0xFFu && ((own >> 16) & 1u))) && (pb_ == 0u || (pb_ == 0xFFu && ((own >> 17) & 1u)));
+        if (__all(usual)) {
+            if (__any(own != 0u)) {
+                const int part = lane & 7, half = part >> 2, c = part & 3;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int r = 8 * i + (lane >> 3);
+                    if (((s_rng[r] >> (8 * half)) & 0xFFu) != 0u) {
+                        const u64 dst = s_dst[2 * r + half];
+                        sstore(*reinterpret_cast<const v4u *>(s_out + r * SOS + 16 * half + 4 * c), reinterpret_cast<v4u *>(reinterpret_cast<char *>(A.scratch) + dst + (u64)(16 * c)));
+                    }
+                }
+            }
+        } else if (__any(own != 0u)) {
             const int part = lane & 7, half = part >> 2, c = part & 3;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -403,10 +418,9 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
             if (ok) {
                 d = d_; s = s_; w0 = w0_; w1 = w1_;
                 int nv[4], out[4];
+                if constexpr (WIDE) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    int v, o;
-                    if constexpr (WIDE) {
+                    for (int jj = 0; jj < 4; jj++) {
                         long long sum = 0;
 #pragma unroll
                         for (int q = 0; q < MAXO; q++) { const int t = q < jj ? nv[jj - 1 - q] : hist[q - jj]; sum += (long long)t * (long long)coef[q]; }
@@ -414,22 +428,28 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
                         const long long vv = (long long)res[jj] + pr;
                         const long long oo = vv << wasted;
                         if ((unsigned long long)(oo + (1ll << 29)) >= (1ull << 30) || (unsigned long long)(vv + (1ll << 29)) >= (1ull << 30)) badacc |= 0x80000000u;
-                        v = (int)vv; o = (int)oo;
-                    } else {
-                        // the taps on values of BEFORE these four first, in two chains (they depend on nothing computed here), the taps on the samples just
-                        // restored last.  Integer sums: any order gives the same bits
-                        int sa = 0, sb = 0;
+                        nv[jj] = (int)vv; out[jj] = (int)oo;
+                    }
+                } else {
+                    // the taps on values of BEFORE these four first — four sums that depend on nothing computed here, their multiply-adds interleaved
+                    // (one chain per sample: hipcc pads a chain of dependent v_mad_i32_i24 with s_nop) — the taps on the samples just restored last.
+                    // Integer sums: any order gives the same bits
+                    int sm[4] = {0, 0, 0, 0};
 #pragma unroll
-                        for (int q = MAXO - 1; q >= jj; q--) { if ((q - jj) & 1) sb = smad24(hist[q - jj], coef[q], sb); else sa = smad24(hist[q - jj], coef[q], sa); }
-                        int sum = sa + sb;
+                    for (int q = MAXO - 1; q >= 0; q--) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) if (q >= jj) sm[jj] = smad24(hist[q - jj], coef[q], sm[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        int sum = sm[jj];
 #pragma unroll
                         for (int q = jj - 1; q >= 0; q--) sum = smad24(nv[jj - 1 - q], coef[q], sum);
-                        v = res[jj] + (sum >> lshift);
+                        const int v = res[jj] + (sum >> lshift);
                         badacc |= (unsigned)(v + hb);
-                        o = (int)((unsigned)v << wasted);   // |v| < 2^23, wasted <= 6
+                        nv[jj] = v;
+                        out[jj] = (int)((unsigned)v << wasted);   // |v| < 2^23, wasted <= 6
                     }
-                    nv[jj] = v;
-                    out[jj] = o;
                 }
 #pragma unroll
                 for (int q = MAXO - 1; q >= 4; q--) hist[q] = hist[q - 4];
@@ -501,13 +521,12 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
                 // what the ring has room for NOW (a granule's slot is free once the dword the reader stands on has left it); the rest is asked for again
                 const long long fit = ((long long)(((b.pos - 1) >> 5) + SWD) - (long long)b.whi) >> 2;
                 const int nw = (int)max(0ll, min((long long)pf_n, fit));
+                const unsigned k0 = (unsigned)(4 * pf_g0);
 #pragma unroll
                 for (int i = 0; i < SPF; i++) {
                     if (i < nw) {
-                        const unsigned k = (unsigned)(4 * (pf_g0 + (u64)i));
-                        const bool inr = (pf_inr >> i) & 1u;
-                        lw[(k + 0) & SRING] = inr ? __builtin_bswap32(pf[i].x) : 0u; lw[(k + 1) & SRING] = inr ? __builtin_bswap32(pf[i].y) : 0u;
-                        lw[(k + 2) & SRING] = inr ? __builtin_bswap32(pf[i].z) : 0u; lw[(k + 3) & SRING] = inr ? __builtin_bswap32(pf[i].w) : 0u;
+                        const unsigned zm = ((pf_inr >> i) & 1u) ? 0xFFFFFFFFu : 0u;   // (a granule beyond the batch was read at a dummy address: zeros)
+                        *reinterpret_cast<v4u *>(lw + ((k0 + 4u * i) & SRING)) = v4u{__builtin_bswap32(pf[i].x) & zm, __builtin_bswap32(pf[i].y) & zm, __builtin_bswap32(pf[i].z) & zm, __builtin_bswap32(pf[i].w) & zm};
                     }
                 }
                 if (nw > 0) { b.whi = 4 * (pf_g0 + (u64)nw); if (b.whi > b.wlo + SWD) b.wlo = b.whi - SWD; }
@@ -525,11 +544,8 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
                 }
                 if (fresh) {
 #pragma unroll
-                    for (int i = 0; i < SPF; i++) {
-                        const unsigned k = (unsigned)(4 * (cg + (u64)i));
-                        lw[(k + 0) & SRING] = __builtin_bswap32(t[i].x); lw[(k + 1) & SRING] = __builtin_bswap32(t[i].y);
-                        lw[(k + 2) & SRING] = __builtin_bswap32(t[i].z); lw[(k + 3) & SRING] = __builtin_bswap32(t[i].w);
-                    }
+                    for (int i = 0; i < SPF; i++)
+                        *reinterpret_cast<v4u *>(lw + ((unsigned)(4 * (cg + (u64)i)) & SRING)) = v4u{__builtin_bswap32(t[i].x), __builtin_bswap32(t[i].y), __builtin_bswap32(t[i].z), __builtin_bswap32(t[i].w)};
                     b.wlo = 4 * cg; b.whi = 4 * (cg + SPF);
                 }
                 fresh = false;
@@ -537,12 +553,20 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
             {
                 const u64 g0 = b.whi >> 2;
                 const int n = (have && st != S_DONE) ? SPF : 0;   // (what of it fits is decided when it has arrived: the round in between makes the room)
-                pf_g0 = g0; pf_n = n; pf_inr = 0;
+                pf_g0 = g0; pf_n = n;
+                const bool allin = n > 0 && 2 * (g0 + SPF) <= A.G.safe_words;
+                const v4u *src = reinterpret_cast<const v4u *>(A.G.w0) + (allin ? g0 : 0ull);   // (a lane with nothing to fetch reads the batch's first vectors)
+                pf_inr = allin ? (1u << SPF) - 1u : 0u;
+                if (A.G.safe_words >= 2 * SPF) {
 #pragma unroll
-                for (int i = 0; i < SPF; i++) {
-                    const bool inr = i < n && 2 * (g0 + (u64)i) < A.G.safe_words;
-                    pf_inr |= (inr ? 1u : 0u) << i;
-                    pf[i] = *reinterpret_cast<const v4u *>(A.G.w0 + (inr ? 2 * (g0 + (u64)i) : 0ull));
+                    for (int i = 0; i < SPF; i++) pf[i] = src[i];
+                }
+                if (__any(n > 0 && !allin)) {   // the batch's last granules: one by one, the ones beyond it not at all
+#pragma unroll
+                    for (int i = 0; i < SPF; i++) {
+                        const bool inr = n > 0 && !allin && 2 * (g0 + (u64)i) < A.G.safe_words;
+                        if (inr) { pf_inr |= 1u << i; pf[i] = *(reinterpret_cast<const v4u *>(A.G.w0) + g0 + (u64)i); }
+                    }
                 }
             }
         }
