@@ -577,11 +577,13 @@ class FlacPipeline(Workload):
     def setup(self, torch, dev, ctx, args, rank, N, B):
         if abs(args.seconds - 10.0) > 1e-9:
             raise SystemExit("flac_pipeline: the cached fixture is 10 s long (tools/make_bench_inputs.py)")
-        one = _fixture("flac_44100_stereo_10s.bin")
-        self.blob = one
-        self.distinct = 1  # copies of ONE stream back to back: a lane takes consecutive frames of a stream, so the divergence inside a wave is a real file's
-        self.flac_bytes = len(one)
-        self.x, offs = _tile_streams(torch, dev, [one], args.streams)
+        # sixteen distinct encoder-made streams, cycled (round 6; the earlier rounds ran copies of ONE file): own seeds, own tones, own mix of
+        # subframe types / predictor orders / partition orders / stereo modes per frame (tools/make_bench_inputs.py)
+        blobs = [_fixture(f"flac_44100_stereo_10s_{i}.bin") for i in range(16)]
+        self.blobs = blobs
+        self.distinct = len(blobs)
+        self.flac_bytes = sum(len(b) for b in blobs) // len(blobs)
+        self.x, offs = _tile_streams(torch, dev, blobs, args.streams)
         self.bt = B.Batch.wrap(ctx, self.x.data_ptr(), offs, keep=self.x)
         self.d = B.make_desc(N.CODEC_FLAC)
         self.a = B.AudioBatch(ctx)
@@ -596,20 +598,20 @@ class FlacPipeline(Workload):
             B.mono(ctx, self.a, out=self.m)
             self.m.device_ptr()   # the step ends with the mono rows FINAL in HBM: whatever the calls above left owed on them (a deferred normalize) is paid here
         self.step = step
-        self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s ({self.flac_bytes} B each, copies of one encoder-made stream) -> aukit.flac:resample(48000,'cubic') "
+        self.desc = (f"{args.streams}x FLAC 44.1kHz stereo 16-bit {args.seconds:g}s (about {self.flac_bytes} B each, {self.distinct} distinct encoder-made streams cycled) -> aukit.flac:resample(48000,'cubic') "
                      f"-> highpass(20) -> normalize(0.8) -> mono, {args.dtype} store (config 5); unit = mono out-samples")
         return self
 
     def cpu_one(self, args):
         from oracle import oracle as O
         O.build()
-        blob = self.blob
+        blobs = self.blobs
 
         def one(i):
-            a = O.resample(O.flac(blob), DST_RATE, O.CUBIC)
+            a = O.resample(O.flac(blobs[i % len(blobs)]), DST_RATE, O.CUBIC)
             a = O.fx_normalize(O.fx_highpass(a, 20.0), 0.8)
             return len(O.mono(a).data[0])
-        return one, f"the fixture stream ({len(blob)} B, 10 s stereo): aukit.flac -> resample -> highpass -> normalize -> mono"
+        return one, f"the {len(blobs)} fixture streams cycled (about {self.flac_bytes} B each, 10 s stereo): aukit.flac -> resample -> highpass -> normalize -> mono"
 
     def out_samples(self):
         return int(self.m.layout()[0].sum())

@@ -459,13 +459,14 @@ def gen_qoa(pcm16_interleaved, channels=1, sample_rate=44100):
     return bytes(out[:n])
 
 
-def gen_flac(pcm_interleaved, channels=2, depth=16, sample_rate=44100, blocksize=4096):
+def gen_flac(pcm_interleaved, channels=2, depth=16, sample_rate=44100, blocksize=4096, salt=0):
+    """salt: which subframe type / predictor order / partition order / stereo mode each frame gets (0: as the golden fixtures know it)"""
     p = np.ascontiguousarray(pcm_interleaved, dtype=np.int32)
     frames = len(p) // channels
-    f = lib().ork_gen_flac
+    f = lib().ork_gen_flac_salt
     f.restype = C.POINTER(C.c_uint8)
     n = C.c_size_t()
-    ptr = f(p.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(frames), channels, depth, C.c_uint(sample_rate), blocksize, C.byref(n))
+    ptr = f(p.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(frames), channels, depth, C.c_uint(sample_rate), blocksize, C.c_uint(salt), C.byref(n))
     out = bytes(np.ctypeslib.as_array(ptr, shape=(max(n.value, 1),))[: n.value])
     lib().ork_free(ptr)
     return out

@@ -354,7 +354,8 @@ static void write_subframe(bitw *b, const int64_t *s_in, int n, int depth, int v
 }
 
 /* pcm interleaved (int32 container), depth 8/16/24.  Returns malloc'd FLAC stream. */
-uint8_t *ork_gen_flac(const int32_t *pcm, size_t frames, int channels, int depth, unsigned sample_rate, int blocksize, size_t *out_len) {
+/* salt: shifts which subframe type / predictor order / partition order / stereo mode each frame gets (0: the generator as the golden fixtures know it) */
+uint8_t *ork_gen_flac_salt(const int32_t *pcm, size_t frames, int channels, int depth, unsigned sample_rate, int blocksize, unsigned salt, size_t *out_len) {
     bitw b;
     memset(&b, 0, sizeof b);
     bw_bits(&b, 0x664C6143, 32);
@@ -380,7 +381,7 @@ uint8_t *ork_gen_flac(const int32_t *pcm, size_t frames, int channels, int depth
         else if (n <= 256) { bscode = 6; bsextra = 1; }
         else { bscode = 7; bsextra = 2; }
         int asgn = channels - 1;
-        if (channels == 2) { int m = (int)(fno % 4); asgn = m == 0 ? 1 : 7 + m; } /* 1, 8, 9, 10 */
+        if (channels == 2) { int m = (int)((fno + salt) % 4); asgn = m == 0 ? 1 : 7 + m; } /* 1, 8, 9, 10 */
         bw_bits(&b, 0x3FFE, 14); bw_bits(&b, 0, 1); bw_bits(&b, 0, 1);
         bw_bits(&b, (uint64_t)bscode, 4);
         int srcode = sample_rate == 44100 ? 9 : sample_rate == 48000 ? 10 : sample_rate == 8000 ? 4 : sample_rate == 22050 ? 6 : 0;
@@ -407,7 +408,7 @@ uint8_t *ork_gen_flac(const int32_t *pcm, size_t frames, int channels, int depth
             d1 = depth + 1;
         }
         for (int c = 0; c < channels; c++) {
-            int variant = (int)((fno * 3 + (size_t)c * 5) % 11);
+            int variant = (int)((fno * 3 + (size_t)c * 5 + (size_t)salt * 7) % 11);
             write_subframe(&b, ch[c], n, c == 0 ? d0 : (c == 1 ? d1 : depth), variant);
         }
         bw_align(&b);
@@ -416,4 +417,7 @@ uint8_t *ork_gen_flac(const int32_t *pcm, size_t frames, int channels, int depth
     for (int c = 0; c < channels; c++) free(ch[c]);
     *out_len = b.n;
     return b.p;
+}
+uint8_t *ork_gen_flac(const int32_t *pcm, size_t frames, int channels, int depth, unsigned sample_rate, int blocksize, size_t *out_len) {
+    return ork_gen_flac_salt(pcm, frames, channels, depth, sample_rate, blocksize, 0, out_len);
 }

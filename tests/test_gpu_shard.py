@@ -203,7 +203,7 @@ def test_group_run_members_side_by_side(ctx, oracle):
     import os, time
     from aukit_amd import _native as N
     from aukit_amd import batch as B
-    fx = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s.bin")
+    fx = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s_0.bin")
     one = open(fx, "rb").read()
     W, per = 4, 24
     desc = B.make_desc(N.CODEC_FLAC)

@@ -12,7 +12,7 @@ Nothing here is built or run by the tests."""
 import os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-data = open(os.path.join(ROOT, "bench_data", "flac_44100_stereo_10s.bin"), "rb").read()
+data = open(os.path.join(ROOT, "bench_data", "flac_44100_stereo_10s_0.bin"), "rb").read()
 bits = bin(int.from_bytes(data, "big"))[2:].zfill(8 * len(data))
 NFR = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 

@@ -6,7 +6,7 @@ import numpy as np
 from aukit_amd import batch as B, _native as N
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ctx = B.Context(0, dtype=N.F32)
-one = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s.bin"), "rb").read()
+one = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s_0.bin"), "rb").read()
 bt = B.Batch.upload(ctx, [one] * n)
 desc = B.make_desc(N.CODEC_FLAC, 2, 44100)
 out = None

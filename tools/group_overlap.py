@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aukit_amd import _native as N, batch as B
 
-one = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s.bin"), "rb").read()
+one = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "flac_44100_stereo_10s_0.bin"), "rb").read()
 desc = B.make_desc(N.CODEC_FLAC)
 for W, per in ((4, 24), (4, 128), (8, 32), (2, 256)):
     g = B.Group([0] * W, dtype=N.F32)

@@ -28,10 +28,14 @@ O.build()
 # config 3a: 220 blocks of 512 B, IMA mono 22 050 Hz (the AUKit-variant encoder), 4 distinct streams
 for i in range(4):
     put(f"ima_22050_220x512_{i}.bin", O.gen_ima(sig(1016 * 220, 22050, 0xA0C17 + 3000 + i), 1, 512, 88))
-# config 5: one FLAC stream, 44.1 kHz stereo 16-bit, 10 s, blocks of 4096 (every subframe type / stereo mode of the generator)
+# config 5: FLAC streams, 44.1 kHz stereo 16-bit, 10 s, blocks of 4096.  SIXTEEN distinct ones since round 6 (the bench ran 2048 copies
+# of one file): stream i has its own seed (0xA0C17 + 5000 + i), its own pair of tones, and the generator's `salt` i — which frame
+# gets which subframe type, predictor order, Rice partition order and stereo mode differs from file to file.  _0 is the round-5 fixture.
 n = 441000
-ch = [sig(n, 44100, 0xA0C17 + 5000, f, 0.9).astype(np.int32) for f in (440.0, 330.0)]
-put("flac_44100_stereo_10s.bin", O.gen_flac(np.stack(ch, 1).ravel(), 2, 16, 44100, 4096))
+for i in range(16):
+    fl, fr = 440.0 * (1 + 0.07 * i), 330.0 * (1 + 0.05 * i)
+    ch = [sig(n, 44100, 0xA0C17 + 5000 + i, f, 0.9 - 0.03 * (i % 5)).astype(np.int32) for f in (fl, fr)]
+    put(f"flac_44100_stereo_10s_{i}.bin", O.gen_flac(np.stack(ch, 1).ravel(), 2, 16, 44100, 4096, salt=i))
 # MS-ADPCM mono 44.1 kHz, blocks of 1024 B (2036 samples), 216 blocks ≈ 10 s, 2 distinct streams
 for i in range(2):
     put(f"msadpcm_44100_mono_216x1024_{i}.bin", O.gen_msadpcm(sig(2036 * 216, 44100, 0xA0C17 + 6000 + i), 1, 1024))
