@@ -169,6 +169,24 @@ __global__ __launch_bounds__(256) void k_mix(MixSrc S, T *out, RowMeta mo, doubl
     }
 }
 
+// the same for any number of audios (the reference sums whatever `...` holds, :804-835): the sources' table lies in device memory
+struct MixEnt { const void *data; RowMeta m; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_mix_many(const MixEnt *ents, int count, T *out, RowMeta mo, double amplifier) {
+    const unsigned r = blockIdx.y;
+    const unsigned s = r / (unsigned)mo.channels, c = r - s * (unsigned)mo.channels;
+    const unsigned long long len = mo.len[s], ob = mo.off[s] + (unsigned long long)c * mo.stride[s];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (unsigned long long)gridDim.x * 256) {
+        double acc = 0;
+        for (int a = 0; a < count; a++) {   // (in the order of the argument list: the sum is the reference's, term by term)
+            const MixEnt e = ents[a];
+            if ((int)c < e.m.channels)
+                acc = acc + (i < e.m.len[s] ? (double)reinterpret_cast<const T *>(e.data)[e.m.off[s] + (unsigned long long)c * e.m.stride[s] + i] : 0.0);
+        }
+        out[ob + i] = (T)lua_clamp(acc * amplifier, -1, 1);
+    }
+}
+
 // encodePCM  :874-892 : d * (d < 0 and maxValue or maxValue-1) + add, laid out interleaved or channel-after-channel
 template <typename T>
 __global__ __launch_bounds__(256) void k_encode_pcm(const T *in, RowMeta mi, double *out, RowMeta mo, double maxValue, double add, int is_float, int interleaved) {
@@ -702,7 +720,6 @@ int aukit_mono(aukit_ctx *ctx, const aukit_audio *in, aukit_audio **out) {
 
 int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, double amplifier, aukit_audio **out) {
     if (!ctx || !audios || !out || count < 1 || !audios[0]) return fail(AUKIT_E_ARG, "null argument");
-    if (count > 8) return fail(AUKIT_E_UNSUPPORTED, "at most 8 audios per mix call");
     const aukit_audio *self = audios[0];
     AUKIT_FLOAT_ONLY(self);
     AUKIT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -723,12 +740,21 @@ int aukit_mix(aukit_ctx *ctx, const aukit_audio *const *audios, int count, doubl
     if (rc) return rc;
     *out = o;
     if (self->n == 0) return AUKIT_OK;
+    uint64_t bytes = audio_bytes(o);
+    dim3 grid(xblocks(o), o->n * o->channels);
+    if (count > 8) {   // the sources' table in device memory (up to eight travel as kernel arguments)
+        std::vector<MixEnt> ents((size_t)count);
+        for (int a = 0; a < count; a++) { ents[a].data = audios[a]->dev; ents[a].m = meta_of(audios[a]); bytes += audio_bytes(audios[a]); }
+        if ((rc = upload_table(ctx, ctx->misc_buf, ents.data(), ents.size() * sizeof(MixEnt)))) return rc;
+        if ((rc = ctx_begin_kernel(ctx))) return rc;
+        AUKIT_DISPATCH_T(o, hipLaunchKernelGGL((k_mix_many<T>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const MixEnt *>(ctx->misc_buf.p), count, reinterpret_cast<T *>(o->dev), meta_of(o), amplifier));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        return ctx_end_kernel(ctx, "k_mix_many", bytes);
+    }
     MixSrc S;
     S.count = count;
-    uint64_t bytes = audio_bytes(o);
     for (int a = 0; a < count; a++) { S.data[a] = audios[a]->dev; S.m[a] = meta_of(audios[a]); bytes += audio_bytes(audios[a]); }
     if ((rc = ctx_begin_kernel(ctx))) return rc;
-    dim3 grid(xblocks(o), o->n * o->channels);
     AUKIT_DISPATCH_T(o, hipLaunchKernelGGL((k_mix<T>), grid, dim3(256), 0, ctx->stream, S, reinterpret_cast<T *>(o->dev), meta_of(o), amplifier));
     AUKIT_HIP_CHECK(hipGetLastError());
     return ctx_end_kernel(ctx, "k_mix", bytes);
@@ -783,7 +809,7 @@ int aukit_effect(aukit_ctx *ctx, aukit_audio *a, int id, const double *args, int
         a->pend_norm = true;
         a->pend_peak = argn(0, 1.0);
         a->pend_independent = argn(1, 0.0) != 0;
-        a->pend_ctx = ctx; a->pend_ctx_id = ctx->id; a->pend_ctx_id = ctx->id;
+        a->pend_ctx = ctx; a->pend_ctx_id = ctx->id;
         ctx->last_kernel = "(normalize deferred)";
         return AUKIT_OK;
     }

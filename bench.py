@@ -111,6 +111,48 @@ def _tile_streams(torch, dev, blobs, streams):
     return x, offs
 
 
+def _gpu_clocks(dev_index=0):
+    """engine / memory clocks of the GPU as the kernel driver reports them right now (sysfs pp_dpm_sclk / pp_dpm_mclk: the level marked `*`),
+    MHz — read before and after the timed windows so that a line from a box that ran below its clocks says so.  None where the files cannot be read."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    base = os.path.dirname(cards[min(dev_index, len(cards) - 1)])
+    for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        try:
+            with open(os.path.join(base, fn)) as fh:
+                cur = [l for l in fh.read().splitlines() if l.strip().endswith("*")]
+            out[key] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
+        except (OSError, ValueError, IndexError):
+            out[key] = None
+    return out if any(v is not None for v in out.values()) else None
+
+
+def _copy_ceiling(torch, nbytes_traffic, reps=12):
+    """what THIS box moves when nothing is computed: a device-to-device copy (torch's vectorised elementwise copy kernel: 16 bytes per lane and access)
+    whose read + write traffic equals `nbytes_traffic`, timed with events on the current stream — the same process, the same moment, as the line it
+    calibrates.  GB/s of traffic (median of `reps`)."""
+    n = max(int(nbytes_traffic) // 2 // 16 * 4, 1 << 20)   # float32 elements: n * 4 bytes read + n * 4 bytes written
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ms.sort()
+    del src, dst
+    return 2 * n * 4 / (ms[len(ms) // 2] * 1e-3) / 1e9
+
+
 class Workload:
     """setup(torch, dev, ctx, args, rank) → self; step() runs one pass; out_samples = units per pass on this rank.
     task_bytes(): END-TO-END algorithmic bytes of one step — the input read once + the final output written once (what the roofline
@@ -764,6 +806,7 @@ def main(argv=None):
                          "2 = fp64 in the reference's operation order, 0 = f32 taps (default for the other workloads)")
     ap.add_argument("--extra-windows", type=int, default=4, help="further K-step windows timed after the contractual one (spread of the measurement)")
     ap.add_argument("--fast-line", type=int, default=1, help="pcm16_cubic: also time the f32-tap kernel and report it as roofline_fast")
+    ap.add_argument("--copy-line", type=int, default=1, help="pcm16_cubic: also time a device copy of the same traffic on this box (roofline.copy_ceiling_GBs, frac_of_copy)")
     ap.add_argument("--distribute", type=int, default=0,
                     help="1: after the measurement, ALSO time the distribution variant (rank 0 holds every rank's input in its HBM: device-to-device "
                          "scatter over RCCL, one pass, gather of the output rows to rank 0) and report it as `distribute` — a second number, never `value`")
@@ -874,6 +917,7 @@ def main(argv=None):
             dist.broadcast(tw, 0)
             want = int(tw.item())
         args.steps = max(args.steps, want)
+    clocks_before = _gpu_clocks(local_rank) if not selftest else None
     dt, ev_ms, n_launch, alg_total = timed_window()  # THE measurement: exactly K steps
     out_samples = wl.out_samples()
     name = ctx.last_kernel()[0] if ctx else "none"
@@ -890,6 +934,31 @@ def main(argv=None):
             d2, _ = reduce_over_ranks(dist, torch, rdev, d2, out_samples)
         windows.append(d2 / args.steps * 1e3)
         kernel_windows.append(e2 / args.steps)
+
+    clocks_after = _gpu_clocks(local_rank) if not selftest else None
+    # every rank says who it is (device, what it sees of the job, its RCCL): the first run on N GPUs verifies itself from its own line
+    ranks_info = None
+    if not selftest:
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                  "uuid": str(getattr(props, "uuid", "")) or None, "cus": props.multi_processor_count,
+                  "world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
+                  "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                  "streams": args.streams, "out_samples": int(out_samples)}
+        except Exception as e:  # never lose the line to the census
+            me = {"rank": rank, "error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, me)
+        else:
+            ranks_info = [me]
+    copy_gbs = None
+    if not selftest and world == 1 and args.copy_line and args.workload == "pcm16_cubic":
+        try:
+            copy_gbs = _copy_ceiling(torch, wl.task_bytes() if hasattr(wl, "task_bytes") and wl.task_bytes() else 11476992000)
+        except Exception as e:
+            copy_gbs = None
 
     fast = None
     if not selftest and args.workload == "pcm16_cubic" and args.exact_math != 0 and args.fast_line and args.dtype == "f32":
@@ -962,6 +1031,13 @@ def main(argv=None):
                                 "algorithmic_bytes_per_step": roof_bytes,
                                 "bytes_per_out_sample": roof_bytes / max(out_samples, 1),
                                 "frac_median_window": roof_bytes / (statistics.median(kernel_windows) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if copy_gbs:
+                # the same box, the same process, minutes apart: a slow box shows in BOTH numbers, a regression of the kernel only in the first
+                line["roofline"]["copy_ceiling_GBs"] = copy_gbs
+                line["roofline"]["frac_of_copy"] = achieved / copy_gbs
+                line["roofline"]["copy_note"] = "device-to-device copy (torch elementwise copy kernel, 16 B per lane) of the same read + write traffic, median of 12, same process"
+            if clocks_before or clocks_after:
+                line["roofline"]["clocks"] = {"before": clocks_before, "after": clocks_after, "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (active level), MHz"}
             if tr is not None:
                 line["roofline"]["traffic_ratio"] = tr / max(roof_bytes, 1)
             if tstep:
@@ -989,6 +1065,8 @@ def main(argv=None):
             line["roofline_fast"] = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "kernel": fast[0],
                                      "kernel_ms": fast[1], "dtype": "f32", "traffic": _measured_traffic(fast[0], args),
                                      "note": "same batch through the f32-tap kernel (AUKIT_OPT_EXACT_MATH = 0): secondary figure"}
+        if ranks_info:
+            line["ranks"] = ranks_info
         if distribute:
             line["distribute"] = distribute
         if world == 1 and args.cpu_streams > 0:

@@ -154,6 +154,23 @@ def test_fade_error_cases_match_reference(ctx):
     B.effect(ctx, ab, "fade", 0.01, 1.0, 0.02, 1.0)  # both amplitudes 1: no-op, no error
 
 
+@pytest.mark.parametrize("count", [9, 33])
+def test_mix_any_number_of_audios(ctx, oracle, count):
+    """Audio:mix sums whatever `...` holds (aukit.lua:804-835): beyond eight audios the sources' table travels in device memory (k_mix_many);
+    the sum runs in the argument list's order, term by term, like the reference's — bit-exact in F64"""
+    B, N = _B(), _N()
+    lens = [(3000 + 37 * k, 200 - k) for k in range(count)]
+    chans = [1 + (k % 3) for k in range(count)]
+    data = [[[signal(n, 22050, 8, 11 * k + 3 * i + c) * (0.2 + 0.01 * k) for c in range(chans[k])] for i, n in enumerate(lens[k])] for k in range(count)]
+    abs_ = [B.AudioBatch.upload(ctx, d, 22050, dtype=N.F64) for d in data]
+    mixed = B.mix(ctx, abs_, 0.31).download()
+    for s in range(2):
+        ref = oracle.mix([oracle.Audio(data[k][s], 22050) for k in range(count)], 0.31)
+        assert len(mixed[s]) == max(chans)
+        for c in range(max(chans)):
+            assert np.array_equal(mixed[s][c], ref.data[c])
+
+
 def test_mono_mix_encode_pcm(ctx, oracle):
     B, N = _B(), _N()
     a = _audios(lens=(5000, 123), ch=3)
