@@ -111,15 +111,25 @@ def _tile_streams(torch, dev, blobs, streams):
     return x, offs
 
 
-def _gpu_clocks(dev_index=0):
+def _gpu_clocks(pci_bus=None):
     """engine / memory clocks of the GPU as the kernel driver reports them right now (sysfs pp_dpm_sclk / pp_dpm_mclk: the level marked `*`),
-    MHz — read before and after the timed windows so that a line from a box that ran below its clocks says so.  None where the files cannot be read."""
+    MHz — sampled while steps run, before and after the timed windows, so that a line from a box that ran below its clocks says so.  The card is
+    the one whose PCI bus number is the device's (a box shows every card of its host); None where nothing can be read."""
     import glob
     out = {}
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-    if not cards:
+    base = None
+    for f in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk")):
+        d = os.path.dirname(f)
+        addr = os.path.basename(os.path.realpath(d))   # 0000:5a:00.0
+        try:
+            bus = int(addr.split(":")[1], 16)
+        except (IndexError, ValueError):
+            bus = None
+        if pci_bus is None or bus == pci_bus:
+            base = d
+            break
+    if base is None:
         return None
-    base = os.path.dirname(cards[min(dev_index, len(cards) - 1)])
     for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
         try:
             with open(os.path.join(base, fn)) as fh:
@@ -127,30 +137,55 @@ def _gpu_clocks(dev_index=0):
             out[key] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
         except (OSError, ValueError, IndexError):
             out[key] = None
-    return out if any(v is not None for v in out.values()) else None
+    out["card"] = os.path.basename(os.path.dirname(base))
+    return out if any(out.get(k) is not None for k in ("sclk_mhz", "mclk_mhz")) else None
 
 
 def _copy_ceiling(torch, nbytes_traffic, reps=12):
-    """what THIS box moves when nothing is computed: a device-to-device copy (torch's vectorised elementwise copy kernel: 16 bytes per lane and access)
-    whose read + write traffic equals `nbytes_traffic`, timed with events on the current stream — the same process, the same moment, as the line it
-    calibrates.  GB/s of traffic (median of `reps`)."""
+    """what THIS box moves when nothing is computed: a float4 device-to-device copy (tools/bench_copy.hip: 16 bytes per lane and access, non-temporal,
+    persistent grid) whose read + write traffic equals `nbytes_traffic`, timed with events on the current stream — the same process, the same
+    moment, as the line it calibrates.  Returns (GB/s of traffic: median of `reps`, what copied)."""
+    import ctypes
     n = max(int(nbytes_traffic) // 2 // 16 * 4, 1 << 20)   # float32 elements: n * 4 bytes read + n * 4 bytes written
     src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
-    for _ in range(3):
-        dst.copy_(src)
-    torch.cuda.synchronize()
-    ms = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dst.copy_(src)
-        e1.record()
-        e1.synchronize()
-        ms.append(e0.elapsed_time(e1))
-    ms.sort()
+    lib = None
+    path = os.path.join(ROOT, "tools", "libbench_copy.so")
+    if os.path.exists(path):
+        lib = ctypes.CDLL(path)
+        lib.bench_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    cus = torch.cuda.get_device_properties(src.device).multi_processor_count
+    shapes = [("plain, one float4 per lane and turn, 4 workgroups per CU", 0, 4), ("non-temporal, four float4 in flight per lane, 8 workgroups per CU", 1, 8),
+              ("non-temporal, four float4 in flight per lane, 32 workgroups per CU", 1, 32)] if lib else [("torch copy_ (hipMemcpy device-to-device)", -1, 0)]
+    best, how = 0.0, ""
+    for name, shape, wgs in shapes:
+        def once():
+            if lib:
+                rc = lib.bench_copy(dst.data_ptr(), src.data_ptr(), n * 4, torch.cuda.current_stream().cuda_stream, cus, shape, wgs)
+                if rc:
+                    raise RuntimeError(f"bench_copy: HIP error {rc}")
+            else:
+                dst.copy_(src)
+        for _ in range(2):
+            once()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            once()
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        ms.sort()
+        g = 2 * n * 4 / (ms[len(ms) // 2] * 1e-3) / 1e9
+        if g > best:
+            best, how = g, ("k_bench_copy (tools/bench_copy.hip), best of %d shapes: %s" % (len(shapes), name)) if lib else name
+    ok = bool(torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:]))
     del src, dst
-    return 2 * n * 4 / (ms[len(ms) // 2] * 1e-3) / 1e9
+    if not ok:
+        raise RuntimeError("bench_copy: the copy does not match its source")
+    return best, how
 
 
 class Workload:
@@ -917,7 +952,16 @@ def main(argv=None):
             dist.broadcast(tw, 0)
             want = int(tw.item())
         args.steps = max(args.steps, want)
-    clocks_before = _gpu_clocks(local_rank) if not selftest else None
+    def clocks_under_load():
+        """the clocks while steps are running (an idle GPU drops to its lowest level at once: sampled behind a sync they say nothing)"""
+        if selftest:
+            return None
+        for _ in range(max(4, min(64, per_sync))):
+            wl.step()
+        c = _gpu_clocks(getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
+        sync()
+        return c
+    clocks_before = clocks_under_load()
     dt, ev_ms, n_launch, alg_total = timed_window()  # THE measurement: exactly K steps
     out_samples = wl.out_samples()
     name = ctx.last_kernel()[0] if ctx else "none"
@@ -935,7 +979,7 @@ def main(argv=None):
         windows.append(d2 / args.steps * 1e3)
         kernel_windows.append(e2 / args.steps)
 
-    clocks_after = _gpu_clocks(local_rank) if not selftest else None
+    clocks_after = clocks_under_load()
     # every rank says who it is (device, what it sees of the job, its RCCL): the first run on N GPUs verifies itself from its own line
     ranks_info = None
     if not selftest:
@@ -953,12 +997,12 @@ def main(argv=None):
             dist.all_gather_object(ranks_info, me)
         else:
             ranks_info = [me]
-    copy_gbs = None
+    copy_gbs, copy_how = None, None
     if not selftest and world == 1 and args.copy_line and args.workload == "pcm16_cubic":
         try:
-            copy_gbs = _copy_ceiling(torch, wl.task_bytes() if hasattr(wl, "task_bytes") and wl.task_bytes() else 11476992000)
+            copy_gbs, copy_how = _copy_ceiling(torch, wl.task_bytes() if hasattr(wl, "task_bytes") and wl.task_bytes() else 11476992000)
         except Exception as e:
-            copy_gbs = None
+            copy_gbs, copy_how = None, f"{type(e).__name__}: {e}"
 
     fast = None
     if not selftest and args.workload == "pcm16_cubic" and args.exact_math != 0 and args.fast_line and args.dtype == "f32":
@@ -1035,9 +1079,9 @@ def main(argv=None):
                 # the same box, the same process, minutes apart: a slow box shows in BOTH numbers, a regression of the kernel only in the first
                 line["roofline"]["copy_ceiling_GBs"] = copy_gbs
                 line["roofline"]["frac_of_copy"] = achieved / copy_gbs
-                line["roofline"]["copy_note"] = "device-to-device copy (torch elementwise copy kernel, 16 B per lane) of the same read + write traffic, median of 12, same process"
+                line["roofline"]["copy_note"] = copy_how + "; the same read + write traffic as the kernel's algorithmic bytes, median of 12, same process"
             if clocks_before or clocks_after:
-                line["roofline"]["clocks"] = {"before": clocks_before, "after": clocks_after, "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (active level), MHz"}
+                line["roofline"]["clocks"] = {"before": clocks_before, "after": clocks_after, "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (active level) sampled while untimed steps of the workload run, MHz"}
             if tr is not None:
                 line["roofline"]["traffic_ratio"] = tr / max(roof_bytes, 1)
             if tstep:
