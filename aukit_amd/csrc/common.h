@@ -45,6 +45,7 @@ struct aukit_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // user timer
     hipEvent_t kev0 = nullptr, kev1 = nullptr;  // per-kernel timing
     bool ktiming = false;
+    int ktiming_nested = 0;     // > 0: an entry point running inside another one (dfpwm_spec.hip's hard streams): ctx_begin_kernel / ctx_end_kernel leave the outer call's events alone
     int exact_math = 0;         // AUKIT_OPT_EXACT_MATH: 1 = F32 storage is computed in fp64 (wave_f64.hip; reference-order kernels where that
                                 //   one does not apply), 2 = always the reference-order kernels; 0 = f32 taps
     bool fast_store_x4 = true;  // AUKIT_OPT_STORE_X4: LDS-transposed 16-byte stores in the fast kernels

@@ -54,7 +54,7 @@ struct DfxParams {
     unsigned npad;          // n rounded up to 64
     unsigned round, rounds; // this launch's round; rounds in all (the last verify redoes whatever is left)
     int *st;                // [nchunk][12][npad] start state (decoder n, strength, pb, lpf, pn; encoder packed), end state (same six)
-    unsigned probe;         // k_dfx_prologue also tries one guess per stream (flags[14]: it missed, [15]: the stream starts in silence)
+    unsigned probe;         // k_dfx_prologue also tries this many guesses per stream, window behind window (flags[14]: guesses that missed, [15]: that met in silence); 0: no probe
     unsigned fix_iv;        // intervals k_dfx_fix runs a chunk again before it gives up (rounds before the last)
     unsigned G, nck;        // checkpoints: the state every G fed bytes inside a chunk (G divides W), nck = bpc W / G - 1 of them
     int *ck;                // [nchunk][nck][6][npad]
@@ -62,7 +62,7 @@ struct DfxParams {
                             //   the state it started from (6), the end state it reached (6, status 2)
     int *ctl;               // [9][npad]: first chunk not final yet (nchunk: done, nchunk + 1: given up — a "hard" stream); the reference encoder state the
                             //   chunk lanes model their guess on (packed); the true state (5 + 1) where that chunk starts; strikes
-    int *pst;               // [7][npad] k_dfx_prologue, `phase` 1 -> 2: the true state where the references end (the decoder's five words, the encoder's one, the fed position)
+    int *pst;               // [8][npad] k_dfx_prologue, `phase` 1 -> 2: the true state where the references end (the decoder's five words, the encoder's one, the fed position)
     unsigned *onset;        // [npad] k_dfx_onset: the fed unit at which the silence a stream starts with ends (0: none)
     int *ref2;              // [npad] the SECOND reference of round 0: the true encoder behind the silence a stream starts with (dfs_pack; 0: none)
     unsigned phase;         // k_dfx_prologue: 0 reference and probe in one launch; 1 the reference only; 2 the probe, from `pst`
@@ -315,7 +315,7 @@ AUKIT_DEV bool dfx_round_off(const DfxParams &X) {
 // (`inner`, large batches: streams with digital silence behind the one they start with — every such passage ends the speculation of its
 // stream for this round, and a batch cut into few chunks has no second one: more than eight of them and the lane-per-stream schedule, which
 // then has to run for them, may as well run for all)
-__global__ __launch_bounds__(256) void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_counts, const unsigned char *inner) {
+__global__ __launch_bounds__(256) void k_dfx_decide(unsigned *flags, unsigned n, unsigned silence_counts, const unsigned char *inner, unsigned windows) {
     __shared__ unsigned cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_dfx_decide(unsigned *flags, unsigned n,
     __syncthreads();
     if (threadIdx.x) return;
     if (inner) flags[12] = cnt;
-    if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > n || cnt > 8) flags[6] = 1;
+    if ((unsigned long long)(flags[14] + (silence_counts ? flags[15] : 0u)) * 16 > (unsigned long long)n * windows || cnt > 8) flags[6] = 1;   // (one guess in sixteen)
 }
 
 // copies the mix table into LDS (64 KiB: 4096 16-byte vectors)
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256) void k_dfx_prologue(const DfxParams X) {
             for (int i = 0; i < 5; i++) X.pst[(size_t)i * X.npad + s] = v[i];
             X.pst[(size_t)5 * X.npad + s] = dfs_pack(e);
             X.pst[(size_t)6 * X.npad + s] = (int)pos;
+            X.pst[(size_t)7 * X.npad + s] = X.ctl[(size_t)X.npad + s];   // the reference as THIS pass left it: round 0's verify may rewrite ctl while the probe runs beside it
             return;
         }
     } else {
@@ -447,11 +448,16 @@ __global__ __launch_bounds__(256) void k_dfx_prologue(const DfxParams X) {
         pos = (u64)X.pst[(size_t)6 * X.npad + s];
         ref2 = X.ref2[s];
     }
-    const u64 pf = pos + (DFX_PROBE_FROM - DFX_X0), pe = pos + (DFX_PROBE_END - DFX_X0);
-    if (X.probe && fed >= pe) {
-        // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on for DFX_PROBE_END - DFX_X0 units, and
-        // from DFX_PROBE_FROM - DFX_X0 on a guess modelled on the references runs beside it, the way the chunk lanes' guesses will — do they meet?
-        const DfEnc ref = dfs_unpack(X.ctl[(size_t)X.npad + s]);
+    // The probe (large batches: a failed speculation costs them a whole step): the true encoder runs on for DFX_PROBE_END - DFX_X0 units, and
+    // from DFX_PROBE_FROM - DFX_X0 on a guess modelled on the references runs beside it, the way the chunk lanes' guesses will — do they meet?
+    // A small batch gets several such windows per stream, one behind the other (X.probe = their number; round 6): ONE guess per stream said "go"
+    // to sixteen streams of noise one time in twenty (a noise stream's guess meets by chance five times in six) and the batch then paid six
+    // rounds and a fallback — 15.6 ms against the older schedule's 6.8 (profiles/r06_dfx_grid_before.txt)
+    const DfEnc ref = dfs_unpack(X.phase == 2 ? X.pst[(size_t)7 * X.npad + s] : X.ctl[(size_t)X.npad + s]);
+    unsigned missed = 0, silent = 0;
+    for (unsigned w = 0; w < X.probe; w++) {
+        const u64 pf = pos + (DFX_PROBE_FROM - DFX_X0), pe = pos + (DFX_PROBE_END - DFX_X0);
+        if (fed < pe) break;
         dfx_span<false>(p, pos, pf, P.feed, d, e, lutc, acc);
         DfEnc g;
         bool first = true, flat;
@@ -482,9 +488,12 @@ __global__ __launch_bounds__(256) void k_dfx_prologue(const DfxParams X) {
                 df_encode_u(g, u);
             }
         }
-        if (dfs_pack(g) != dfs_pack(e)) atomicAdd(&X.flags[14], 1u);
-        else if (e.strength <= 9) atomicAdd(&X.flags[15], 1u);   // (met, but in silence: what follows the silence will be in another class)
+        if (dfs_pack(g) != dfs_pack(e)) missed++;
+        else if (e.strength <= 9) silent++;   // (met, but in silence: what follows the silence will be in another class)
+        pos = pe;
     }
+    if (missed) atomicAdd(&X.flags[14], missed);
+    if (silent) atomicAdd(&X.flags[15], silent);
 }
 
 AUKIT_DEV int *dfx_ck(const DfxParams &X, unsigned c, unsigned j, unsigned s) { return X.ck + (((size_t)c * X.nck + j) * 6) * X.npad + s; }
@@ -721,7 +730,9 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
             later++;
             bad += X.fx[(size_t)k * 13 * X.npad + s] != 0 ? 1u : 0u;
         }
-        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 2 > later)) {
+        // (round 6: one boundary in ten — signal misses one in 200 - 500, noise one in six; the threshold was one in two, which noise never reached:
+        // sixteen streams of it went through six rounds and THEN to the fallback, 15.6 ms for the older schedule's 6.8)
+        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 10 > later)) {
             X.ctl[s] = (int)P.nchunk + 1;
             X.hard[atomicAdd(&X.flags[13], 1u)] = s;
             return;
@@ -811,7 +822,8 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // into many chunks per stream, all of it again when it is cut into few (a large batch: none there).  Every passage of silence can cost
     // two (into it, out of it); streams that need more, or fail every few chunks, are "hard" and go to the lane-per-stream encoder.
     unsigned rounds = nchunk >= 24 ? 6 : (nchunk >= 16 ? 2 : 1);
-    if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 8));
+    if (const char *e = getenv("AUKIT_DFX_ROUNDS")) rounds = (unsigned)std::max(1, std::min(atoi(e), 6));   // (flags[round] for rounds 0 .. 5; flags[6] is the probe's "declined": ADVICE r05)
+    static_assert(true, "flags: [0, 6) per round, 6 declined, 8 .. 15 counters");
     const unsigned npad = (unsigned)round_up(n, 64);
     // checkpoints: the finer, the less a mismatching chunk runs again before it merges; 24 bytes each, at most ~320 MB of them
     unsigned G = (unsigned)W / 4;
@@ -826,7 +838,7 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     if (const char *e = getenv("AUKIT_DFX_MSUB")) msub = (unsigned)std::max(1, std::min(atoi(e), 64));
     const size_t o_tab = take((size_t)n * 24), o_maps = take((size_t)n * nchunk * msub * sizeof(SatMap)), o_ss = take((size_t)n * (nchunk + 1) * 4),
                  o_st = take((size_t)nchunk * 12 * npad * 4), o_ck = take((size_t)nchunk * nck * 6 * npad * 4 + 4), o_fx = take((size_t)nchunk * 13 * npad * 4),
-                 o_ctl = take((size_t)9 * npad * 4), o_pst = take((size_t)7 * npad * 4), o_on = take((size_t)2 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64 + (size_t)npad);
+                 o_ctl = take((size_t)9 * npad * 4), o_pst = take((size_t)8 * npad * 4), o_on = take((size_t)2 * npad * 4), o_hard = take((size_t)npad * 4), o_fl = take(64 + (size_t)npad);
     int rc = ctx->tmp_buf2.ensure(o + 256);
     if (rc) return rc;
     char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
@@ -858,7 +870,11 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     // more than one in sixteen misses, or the streams start in silence (whatever follows it will be in another class), the batch is declined
     // and runs the older schedule: a failed speculation costs rounds of a whole chunk lane's time each (and a large batch, cut into few chunks
     // per stream, a whole step for a gain of a quarter).  What the probe cannot see — silence or noise later in the streams — costs rounds.
+    // windows of the probe per stream: one.  (More of them — 64 guesses per batch whatever its size — were tried for small batches, round 6: eight
+    // windows are 1.5 ms of a lone lane in front of the host's first look, 8 streams of signal 1.0 -> 2.6 ms; what tells noise from signal at
+    // any batch size is round 0 itself: k_dfx_verify below counts the chunk boundaries where the guesses missed.  AUKIT_DFX_PROBE_WINDOWS for the A/B)
     X.probe = getenv("AUKIT_DFX_NOPROBE") ? 0u : 1u;
+    if (const char *e = getenv("AUKIT_DFX_PROBE_WINDOWS")) X.probe = (unsigned)std::max(1, std::min(atoi(e), 16));
     // (the prologue's 256 lone waves run on the side stream, beside the strength scan: the probe hides behind k_df_blockmaps)
     if (!ctx->dfx_attr_set) {
         AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dfx_chunks<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -883,13 +899,13 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
     prologue(aside ? 1u : 0u);
     // (streams that START in silence cost one round of re-speculation where the signal sets in — worth it where rounds are cheap, i.e. the batch
     // is cut into many chunks per stream; a batch with few chunks per stream declines them)
-    if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) return rc;
+    if (J.kind == 0 && (rc = dfpwm_strength_scan(ctx, P))) { (void)ctx_side_join(ctx); return rc; }   // (never leave the side stream forked)
     if ((rc = ctx_side_join(ctx))) return rc;
     // (the verdict on silence behind the leading one needs the scan: here; the probe's verdict follows the probe, on the side stream when it runs aside)
-    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, ctx->stream, X.flags, n, nchunk < 24 ? 1u : 0u, J.kind == 0 ? P.inner : nullptr);
+    if (X.probe) hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, ctx->stream, X.flags, n, nchunk < 24 ? 1u : 0u, J.kind == 0 ? P.inner : nullptr, X.probe);
     if (aside) {   // (the side stream again, behind the reference; joined before the host's first look at the flags)
         prologue(2u);
-        hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u, (const unsigned char *)nullptr);
+        hipLaunchKernelGGL(k_dfx_decide, dim3(1), dim3(256), 0, side, X.flags, n, nchunk < 24 ? 1u : 0u, (const unsigned char *)nullptr, X.probe);
     }
     const dim3 grid((unsigned)(((size_t)n * nchunk + 255) / 256)), cgrid((unsigned)(((size_t)n * nchunk + AUKIT_DFX_WG - 1) / AUKIT_DFX_WG));
     // Rounds are queued two at a time with a look at the counters behind each pair (the first look is the call's one host synchronisation on signal:
@@ -974,9 +990,15 @@ static int dfx_run(aukit_ctx *ctx, const DfxJob &J, unsigned char *out, const u6
             hipLaunchKernelGGL(k_dfx_move, dim3((unsigned)std::min<uint64_t>((maxlen + 4095) / 4096, 64), std::min<unsigned>(65535, m - i0)), dim3(256), 0, ctx->stream, in->data(), gbuf, dtab + i0, m);
         aukit_batch *sub_in = nullptr;
         if ((rc = aukit_batch_wrap_device(ctx, &sub_in, gbuf, sub_off.data(), m))) return rc;
+        // (the nested call is an ordinary entry point: it must neither move the outer call's timing origin nor overwrite its counters — ADVICE r05)
+        uint64_t keep[8];
+        std::copy(ctx->counters, ctx->counters + 8, keep);
         ctx->dfx_disable = true;
+        ctx->ktiming_nested++;
         rc = aukit_dfpwm_transcode_mono(ctx, sub_in, 2, &ctx->dfx_sub_out);
+        ctx->ktiming_nested--;
         ctx->dfx_disable = false;
+        std::copy(keep, keep + 8, ctx->counters);
         aukit_batch_free(sub_in);
         if (rc) return rc;
         const aukit_batch *so = ctx->dfx_sub_out;

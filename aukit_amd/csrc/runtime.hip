@@ -105,10 +105,11 @@ bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count) {
 }
 
 int ctx_begin_kernel(aukit_ctx *ctx) {
-    if (ctx->ktiming) AUKIT_HIP_CHECK(hipEventRecord(ctx->kev0, ctx->stream));
+    if (ctx->ktiming && !ctx->ktiming_nested) AUKIT_HIP_CHECK(hipEventRecord(ctx->kev0, ctx->stream));
     return AUKIT_OK;
 }
 int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes) {
+    if (ctx->ktiming_nested) return AUKIT_OK;   // (the outer call reports: its name, its bytes, its interval)
     ctx->last_kernel = name ? name : "";
     ctx->last_bytes = algorithmic_bytes;
     ctx->timer_launches++;

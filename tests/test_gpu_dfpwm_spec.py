@@ -287,3 +287,48 @@ def test_spec_encoder_mid_batch(ctx, oracle):
         assert all(g == got[c] for g in got[c::K])
         assert got[c] == oracle.audio_dfpwm(oracle.Audio([base[c]], 48000), True)
     assert hard == 0 and redone <= chunks // 50, (chunks, redone, hard)
+
+
+def _class_pcm(kind, n, seed, rng):
+    """n stereo frames (int8-valued floats) of one input class of tools/r06_dfx_grid.py: signal / lead (silence in front) / gated (silence in front
+    and inside) / None for noise (random DFPWM bytes)"""
+    l, r = signal(n, 48000, 4, seed) * 100, signal(n, 48000, 4, seed + 1) * 90
+    if kind == "lead":
+        l[: n // 20] = 0; r[: n // 20] = 0
+    if kind == "gated":
+        l[: n // 5] = 0; r[: n // 5] = 0
+        l[n // 2: n // 2 + n // 10] = 0; r[n // 2: n // 2 + n // 10] = 0
+    return l, r
+
+
+@pytest.mark.parametrize("n", [1, 5, 8, 17, 64])
+@pytest.mark.parametrize("kind", ["signal", "lead", "gated", "noise"])
+def test_grid_cells_bytes(ctx, oracle, monkeypatch, n, kind):
+    """every cell of tools/r06_dfx_grid.py at reduced length: batch size x input class x entry point — the default engine's
+    bytes are the older schedule's (AUKIT_DFPWM_NOSPEC=1) and, on the first streams, the oracle's.  (The grid's times: profiles/r06_dfx_grid.txt.)"""
+    B, N = _B(), _N()
+    monkeypatch.delenv("AUKIT_DFX_FEW")   # the DEFAULT routing is under test here: few short streams stay with the exact parallel encoder
+    rng = np.random.default_rng(1000 * n + len(kind))
+    nb = 36000   # stereo DFPWM bytes per stream: 144 000 frames, three seconds
+    if kind == "noise":
+        streams = [rng.integers(0, 256, nb, dtype=np.uint8).tobytes() for _ in range(n)]
+    else:
+        distinct = [_enc_stereo(oracle, *_class_pcm(kind, nb * 4, 900 + 2 * i, rng)) for i in range(min(n, 3))]
+        streams = [distinct[i % len(distinct)] for i in range(n)]
+    bt = B.Batch.upload(ctx, streams)
+    d = B.make_desc(N.CODEC_DFPWM, 2, 48000)
+
+    def run():
+        t = B.dfpwm_transcode_mono(ctx, bt, 2).download()
+        mono = B.mono(ctx, B.decode(ctx, bt, d, dtype=N.F32))
+        e = B.dfpwm_encode(ctx, mono, True).download()
+        a = [x[0].copy() for x in B.decode(ctx, bt, d, dtype=N.F32).download()]
+        return t, e, a
+    t1, e1, a1 = run()
+    monkeypatch.setenv("AUKIT_DFPWM_NOSPEC", "1")
+    t0, e0, a0 = run()
+    monkeypatch.delenv("AUKIT_DFPWM_NOSPEC")
+    assert t1 == t0 and e1 == e0
+    assert all(np.array_equal(x, y) for x, y in zip(a1, a0))
+    for s in range(min(n, 2)):
+        assert t1[s] == _ref(oracle, streams[s])   # (Audio:dfpwm runs on the F32 rows of the mono mix here: its bytes are held to the older schedule's above)
