@@ -732,7 +732,9 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
         }
         // (round 6: one boundary in ten — signal misses one in 200 - 500, noise one in six; the threshold was one in two, which noise never reached:
         // sixteen streams of it went through six rounds and THEN to the fallback, 15.6 ms for the older schedule's 6.8)
-        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 10 > later)) {
+        // ... AND the round got the stream no further than a strike's worth: a passage of silence inside a stream leaves one boundary in five to
+        // two re-run as well (4096 gated streams went to the fallback on the count alone: 8.8 -> 20 ms), but the run up to it is long
+        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 2 > later) || (later >= 12 && bad * 10 > later && progress < few)) {
             X.ctl[s] = (int)P.nchunk + 1;
             X.hard[atomicAdd(&X.flags[13], 1u)] = s;
             return;

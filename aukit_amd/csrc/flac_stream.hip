@@ -363,6 +363,7 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
 #define SSTATW(c)
 #endif
     int rend = 0;        // the round's values of the running subframe end at this index (a multiple of RV)
+    bool slow_lane = false;   // the groups met a code longer than 32 bits: the lane's next value is the generic reader's
     bool rdone = false;
     auto groups_loop = [&](auto MO, auto WD, bool elig) {
         constexpr int MAXO = decltype(MO)::value;
@@ -588,131 +589,30 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
                     bool slow;
                     if (anywide) slow = big ? groups_loop(std::integral_constant<int, 12>(), std::true_type(), elig) : groups_loop(std::integral_constant<int, 4>(), std::true_type(), elig);
                     else slow = big ? groups_loop(std::integral_constant<int, 12>(), std::false_type(), elig) : groups_loop(std::integral_constant<int, 4>(), std::false_type(), elig);
-                    (void)slow;
+                    if (elig) slow_lane = slow;   // (a code longer than 32 bits: the generic reader's — this value and the ones that bring the run back to a multiple of four)
                 }
             }
-            // -- everything else, one transition (or one value) per turn
-            if (!rdone && (b.pos >> 5) + SLOOK > b.whi && st != S_SUBEND && st != S_FRAMEEND && st != S_CONST && !(st == S_RUN && remaining == 0)) rdone = true;   // a step that reads wants 32 bytes of window
-            if (!rdone) {
-                if (st == S_RUN) {
-                    if (remaining == 0) { st = after; if (after == S_PART) { pi++; if (pi >= nparts) st = S_SUBEND; } }
-                    else if (jpos >= rend) rdone = true;
-                    else {
-                        // one value by the generic reader: warm-up samples, the values that bring a run to a multiple of four, a code longer than 32 bits,
-                        // a stream's last bytes; 64-bit sums (:411-419)
-                        int r1 = FE_OK, v1 = 0;
-                        if (fixed) { v1 = srd_sget(b, rk); if (b.eof) r1 = FE_NIL; }
-                        else r1 = srd_rice(b, rk, v1);
-                        if (!r1 && b.oow) r1 = FE_DECLINE;
-                        if (r1) { status = r1; st = S_DONE; rdone = true; }
-                        else {
-                            long long sum = 0;
-#pragma unroll
-                            for (int q = 0; q < SMAXO; q++) sum += (long long)hist[q] * (long long)coef[q];
-                            long long pr = lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));
-                            if (jpos < order) pr = 0;
-                            const long long vv = (long long)v1 + pr;
-                            const long long oo = vv << wasted;
-                            if (wide) { if ((unsigned long long)(oo + (1ll << 29)) >= (1ull << 30) || (unsigned long long)(vv + (1ll << 29)) >= (1ull << 30)) badacc |= 0x80000000u; }
-                            else { if ((unsigned long long)(vv + (long long)hb) >= 2ull * (unsigned long long)hb) badacc |= 0x80000000u; }
-#pragma unroll
-                            for (int q = SMAXO - 1; q >= 1; q--) hist[q] = hist[q - 1];
-                            hist[0] = (int)vv;
-                            emit1((int)oo);
-                            SSTAT(st_singles++;) SSTATW(st_single_turns)
-                            remaining--; jpos++;
-                        }
-                    }
-                } else if (st == S_CONST) {   // :453-454
-                    const int o = (int)((unsigned)cval << wasted);
-                    while (remaining > 0 && jpos < rend) { emit1(o); remaining--; jpos++; }
-                    if (remaining == 0) st = S_SUBEND; else rdone = true;
-                } else if (st == S_PART) {   // :394-406
-                    const int escape = param_bits == 4 ? 15 : 31;
-                    const int param = (int)srd_get(b, param_bits);
-                    const bool esc = param >= escape;
-                    int nbits = 0;
-                    if (esc) nbits = (int)srd_get(b, 5);
-                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
-                    else if (b.pos > limit) { status = FE_LIMIT; st = S_DONE; rdone = true; }
-                    else {
-                        const int start_i = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
-                        remaining = endd > start_i ? endd - start_i : 0;
-                        fixed = esc;
-                        rk = esc ? nbits : param;
-                        after = S_PART;
-                        st = S_RUN;   // (an empty partition leaves through S_RUN's remaining == 0)
-                    }
-                } else if (st == S_SUB) {   // decodeSubframe  :443-465
-                    srd_get(b, 1);
-                    const int type = (int)srd_get(b, 6);
-                    wasted = (int)srd_get(b, 1);
-                    if (wasted == 1) {   // unary wasted-bits count  :447-449
-                        bool gw = true;
-                        while (gw) { const unsigned bit = srd_get(b, 1); if (b.eof || bit) gw = false; else wasted++; }
-                    }
-                    sdepth = depth - wasted;
-                    if (chan_asgn >= 8) sdepth += ((chan_asgn == 9) == (ch == 0)) ? 1 : 0;   // the side channel has one more bit  :480-481
-                    order = 0; lshift = 0; jpos = 0; rend = RV; lpc = false; hb = 1 << 23;
-                    wide = sdepth > 24 || wasted > 6;   // (until S_COEF knows the taps: the bound the warm-up samples are held to)
-#pragma unroll
-                    for (int q = 0; q < SMAXO; q++) { coef[q] = 0; hist[q] = 0; }
-                    set_outputs();
-                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
-                    else if (sdepth < 1 || sdepth > 31 || wasted > 24) { status = FE_DECLINE; st = S_DONE; rdone = true; }
-                    else if (type == 0) {
-                        cval = srd_sget(b, sdepth);
-                        if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
-                        else if (sdepth > 24 || wasted > 6) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // (a constant beyond the ranges of this kernel: not an ordinary stream)
-                        else { remaining = bs; st = S_CONST; }
-                    } else if (type == 1) { remaining = bs; fixed = true; rk = sdepth; after = S_SUBEND; st = S_RUN; }
-                    else if ((type >= 8 && type <= 12) || (type >= 32 && type <= 63)) {
-                        order = type <= 12 ? type - 8 : type - 31;
-                        lpc = type >= 32;
-                        if (order > SMAXO || order > bs) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // (order > bs: the Lua table grows past blockSize)
-                        else { remaining = order; fixed = true; rk = sdepth; after = S_COEF; st = S_RUN; }
-                    } else { status = FE_SUBTYPE; st = S_DONE; rdone = true; }
-                } else if (st == S_COEF) {   // :433-438 / FIXED_PREDICTION_COEFFICIENTS :334-340, then the residual header :381-391
-                    if (lpc) {
-                        const int precision = (int)srd_get(b, 4) + 1;
-                        lshift = srd_sget(b, 5);
-#pragma unroll
-                        for (int q = 0; q < SMAXO; q++) if (q < order) coef[q] = srd_sget(b, precision);
-                    } else {
-                        // FIXED_PREDICTION_COEFFICIENTS[order + 1] = {}, {1}, {2, -1}, {3, -3, 1}, {4, -6, 4, -1}: binomials, by arithmetic
-                        coef[0] = order;
-                        coef[1] = order == 2 ? -1 : (order == 3 ? -3 : (order == 4 ? -6 : 0));
-                        coef[2] = order == 3 ? 1 : (order == 4 ? 4 : 0);
-                        coef[3] = order == 4 ? -1 : 0;
-                    }
-                    const int method = (int)srd_get(b, 2);
-                    param_bits = method == 0 ? 4 : 5;
-                    const int porder = (int)srd_get(b, 4);
-                    nparts = 1 << porder;
-                    int sabs = 1;
-#pragma unroll
-                    for (int q = 0; q < SMAXO; q++) sabs += coef[q] < 0 ? -coef[q] : coef[q];
-                    const int hbits = min(23, __builtin_clz((unsigned)sabs) - 1);   // 2^hbits * sum |coef| < 2^31
-                    hb = 1 << hbits;
-                    // values of this subframe have up to sdepth bits: the 24-bit multiply-adds serve it when those fit under hb; else 64-bit sums
-                    wide = sdepth - 1 > hbits || lshift < 0 || wasted > 6;   // (the warm-up samples, sdepth-bit fields, fit under hb whenever this says narrow)
-                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
-                    else if (method >= 2) { status = FE_RESMETHOD; st = S_DONE; rdone = true; }
-                    else if (bs % nparts != 0) { status = FE_PARTITION; st = S_DONE; rdone = true; }
-                    else {
-                        psize = bs / nparts;
-                        pi = 0;
-                        if (nparts > 1 && psize < order) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // :400 — later partitions overwrite warm-up entries
-                        else st = S_PART;
-                    }
-                } else if (st == S_SUBEND) {
-                    if (sv_lo >= 0) rdone = true;   // this subframe's last values leave (with this round) before the next header is read: a row has one destination
-                    else {
-                        check_bad();
-                        if (st != S_DONE) { ch++; jpos = 0; rend = RV; st = ch < nsub ? S_SUB : S_FRAMEEND; }
-                        else rdone = true;
-                    }
-                } else if (st == S_FRAME) {   // decodeFrame header  :510-553
+            // -- everything else.  A lane passes through as many of these steps as follow from each other in one turn (a run's end, the partition
+            // header behind it; a subframe's end, the next one's header; a frame header and its first subframe's): the wave's other lanes wait for
+            // every turn.  A step that reads wants SLOOK dwords of window in front of it, or the lane's round is over.
+            auto window = [&]() -> bool { if ((b.pos >> 5) + SLOOK > b.whi) { rdone = true; return false; } return true; };
+            // what reads nothing: a run that ended -> the next partition or the subframe's end; a subframe's end -> the next subframe or the frame's end
+            if (!rdone && st == S_RUN && remaining == 0) { st = after; if (after == S_PART) { pi++; if (pi >= nparts) st = S_SUBEND; } }
+            if (!rdone && st == S_SUBEND) {
+                if (sv_lo >= 0) rdone = true;   // this subframe's last values leave (with this round) before the next header is read: a row has one destination
+                else {
+                    check_bad();
+                    if (st != S_DONE) { ch++; jpos = 0; rend = RV; st = ch < nsub ? S_SUB : S_FRAMEEND; }
+                    else rdone = true;
+                }
+            }
+            if (!rdone && st == S_FRAMEEND) {   // :555-557
+                    b.pos = (b.pos + 7) & ~7ull;                                  // alignToByte (frames start on byte boundaries of the batch buffer)
+                    b.pos = (b.pos + 16 <= b.end) ? b.pos + 16 : b.end;           // readUint(16): a nil here is discarded, the NEXT readByte returns nil
+                    end_byte = (b.pos - A.G.base_bit) >> 3;
+                    st = S_DONE; rdone = true;
+            }
+            if (!rdone && st == S_FRAME && window()) {   // decodeFrame header  :510-553
                     int fs = FE_OK;
                     const unsigned t0 = srd_get(b, 8);
                     if (b.eof) fs = FE_EOF_START;
@@ -753,14 +653,124 @@ __global__ __launch_bounds__(64, AUKIT_FS_LB) void k_flac_stream(const FusedArgs
                         ch = 0; jpos = 0;
                         st = S_SUB;
                     }
-                } else if (st == S_FRAMEEND) {   // :555-557
-                    b.pos = (b.pos + 7) & ~7ull;                                  // alignToByte (frames start on byte boundaries of the batch buffer)
-                    b.pos = (b.pos + 16 <= b.end) ? b.pos + 16 : b.end;           // readUint(16): a nil here is discarded, the NEXT readByte returns nil
-                    end_byte = (b.pos - A.G.base_bit) >> 3;
-                    st = S_DONE; rdone = true;
-                }
-                if (b.oow && st != S_DONE) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // a field beyond the window: not an ordinary stream
             }
+            if (!rdone && st == S_SUB && window()) {   // decodeSubframe  :443-465
+                    srd_get(b, 1);
+                    const int type = (int)srd_get(b, 6);
+                    wasted = (int)srd_get(b, 1);
+                    if (wasted == 1) {   // unary wasted-bits count  :447-449
+                        bool gw = true;
+                        while (gw) { const unsigned bit = srd_get(b, 1); if (b.eof || bit) gw = false; else wasted++; }
+                    }
+                    sdepth = depth - wasted;
+                    if (chan_asgn >= 8) sdepth += ((chan_asgn == 9) == (ch == 0)) ? 1 : 0;   // the side channel has one more bit  :480-481
+                    order = 0; lshift = 0; jpos = 0; rend = RV; lpc = false; hb = 1 << 23;
+                    wide = sdepth > 24 || wasted > 6;   // (until S_COEF knows the taps: the bound the warm-up samples are held to)
+#pragma unroll
+                    for (int q = 0; q < SMAXO; q++) { coef[q] = 0; hist[q] = 0; }
+                    set_outputs();
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (sdepth < 1 || sdepth > 31 || wasted > 24) { status = FE_DECLINE; st = S_DONE; rdone = true; }
+                    else if (type == 0) {
+                        cval = srd_sget(b, sdepth);
+                        if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                        else if (sdepth > 24 || wasted > 6) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // (a constant beyond the ranges of this kernel: not an ordinary stream)
+                        else { remaining = bs; st = S_CONST; }
+                    } else if (type == 1) { remaining = bs; fixed = true; rk = sdepth; after = S_SUBEND; st = S_RUN; }
+                    else if ((type >= 8 && type <= 12) || (type >= 32 && type <= 63)) {
+                        order = type <= 12 ? type - 8 : type - 31;
+                        lpc = type >= 32;
+                        if (order > SMAXO || order > bs) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // (order > bs: the Lua table grows past blockSize)
+                        else { remaining = order; fixed = true; rk = sdepth; after = S_COEF; st = S_RUN; }
+                    } else { status = FE_SUBTYPE; st = S_DONE; rdone = true; }
+            }
+            if (!rdone && st == S_COEF && window()) {   // :433-438 / FIXED_PREDICTION_COEFFICIENTS :334-340, then the residual header :381-391
+                    if (lpc) {
+                        const int precision = (int)srd_get(b, 4) + 1;
+                        lshift = srd_sget(b, 5);
+#pragma unroll
+                        for (int q = 0; q < SMAXO; q++) if (q < order) coef[q] = srd_sget(b, precision);
+                    } else {
+                        // FIXED_PREDICTION_COEFFICIENTS[order + 1] = {}, {1}, {2, -1}, {3, -3, 1}, {4, -6, 4, -1}: binomials, by arithmetic
+                        coef[0] = order;
+                        coef[1] = order == 2 ? -1 : (order == 3 ? -3 : (order == 4 ? -6 : 0));
+                        coef[2] = order == 3 ? 1 : (order == 4 ? 4 : 0);
+                        coef[3] = order == 4 ? -1 : 0;
+                    }
+                    const int method = (int)srd_get(b, 2);
+                    param_bits = method == 0 ? 4 : 5;
+                    const int porder = (int)srd_get(b, 4);
+                    nparts = 1 << porder;
+                    int sabs = 1;
+#pragma unroll
+                    for (int q = 0; q < SMAXO; q++) sabs += coef[q] < 0 ? -coef[q] : coef[q];
+                    const int hbits = min(23, __builtin_clz((unsigned)sabs) - 1);   // 2^hbits * sum |coef| < 2^31
+                    hb = 1 << hbits;
+                    // values of this subframe have up to sdepth bits: the 24-bit multiply-adds serve it when those fit under hb; else 64-bit sums
+                    wide = sdepth - 1 > hbits || lshift < 0 || wasted > 6;   // (the warm-up samples, sdepth-bit fields, fit under hb whenever this says narrow)
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (method >= 2) { status = FE_RESMETHOD; st = S_DONE; rdone = true; }
+                    else if (bs % nparts != 0) { status = FE_PARTITION; st = S_DONE; rdone = true; }
+                    else {
+                        psize = bs / nparts;
+                        pi = 0;
+                        if (nparts > 1 && psize < order) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // :400 — later partitions overwrite warm-up entries
+                        else st = S_PART;
+                    }
+            }
+            if (!rdone && st == S_PART && window()) {   // :394-406
+                    const int escape = param_bits == 4 ? 15 : 31;
+                    const int param = (int)srd_get(b, param_bits);
+                    const bool esc = param >= escape;
+                    int nbits = 0;
+                    if (esc) nbits = (int)srd_get(b, 5);
+                    if (b.eof) { status = FE_NIL; st = S_DONE; rdone = true; }
+                    else if (b.pos > limit) { status = FE_LIMIT; st = S_DONE; rdone = true; }
+                    else {
+                        const int start_i = pi * psize + (pi == 0 ? order : 0), endd = (pi + 1) * psize;
+                        remaining = endd > start_i ? endd - start_i : 0;
+                        fixed = esc;
+                        rk = esc ? nbits : param;
+                        after = S_PART;
+                        st = S_RUN;   // (an empty partition leaves through S_RUN's remaining == 0)
+                    }
+            }
+            if (!rdone && st == S_CONST) {   // :453-454
+                    const int o = (int)((unsigned)cval << wasted);
+                    while (remaining > 0 && jpos < rend) { emit1(o); remaining--; jpos++; }
+                    if (remaining == 0) st = S_SUBEND; else rdone = true;
+            }
+            if (!rdone && st == S_RUN && remaining > 0) {
+                if (jpos >= rend) rdone = true;
+                else if ((slow_lane || !(remaining >= 4 && (jpos & 3) == 0 && jpos >= order && !careful && !(mode == 2 && (bs & 3) != 0))) && window()) {   // (what the groups take is theirs: next turn)
+                        slow_lane = false;
+                        // one value by the generic reader: warm-up samples, the values that bring a run to a multiple of four, a code longer than 32 bits,
+                        // a stream's last bytes; 64-bit sums (:411-419)
+                        int r1 = FE_OK, v1 = 0;
+                        if (fixed) { v1 = srd_sget(b, rk); if (b.eof) r1 = FE_NIL; }
+                        else r1 = srd_rice(b, rk, v1);
+                        if (!r1 && b.oow) r1 = FE_DECLINE;
+                        if (r1) { status = r1; st = S_DONE; rdone = true; }
+                        else {
+                            long long sum = 0;
+#pragma unroll
+                            for (int q = 0; q < SMAXO; q++) sum += (long long)hist[q] * (long long)coef[q];
+                            long long pr = lshift >= 0 ? (sum >> lshift) : (sum << (-lshift));
+                            if (jpos < order) pr = 0;
+                            const long long vv = (long long)v1 + pr;
+                            const long long oo = vv << wasted;
+                            if (wide) { if ((unsigned long long)(oo + (1ll << 29)) >= (1ull << 30) || (unsigned long long)(vv + (1ll << 29)) >= (1ull << 30)) badacc |= 0x80000000u; }
+                            else { if ((unsigned long long)(vv + (long long)hb) >= 2ull * (unsigned long long)hb) badacc |= 0x80000000u; }
+#pragma unroll
+                            for (int q = SMAXO - 1; q >= 1; q--) hist[q] = hist[q - 1];
+                            hist[0] = (int)vv;
+                            emit1((int)oo);
+                            SSTAT(st_singles++;) SSTATW(st_single_turns)
+                            remaining--; jpos++;
+                        }
+                }
+            }
+            if (b.oow && st != S_DONE) { status = FE_DECLINE; st = S_DONE; rdone = true; }   // a field beyond the window: not an ordinary stream
             go_on = __any(!rdone);
         }
         if (st != S_DONE && b.pos > limit) { status = FE_LIMIT; st = S_DONE; }
