@@ -644,10 +644,16 @@ static int stream_g711(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_
     uint64_t in_bytes = 0, out_elems = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t nb = in->off[s + 1] - in->off[s];
-        if (nb % (uint64_t)C != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "G.711 data length is not a multiple of the channel count (stream %u)", s); }
+        // A byte count that is not a multiple of the channel count (round 6: refused until now): the LAST call's table has one sample more in its
+        // first channels than in the others, `newlen` follows the first (:2897), and the first output whose position reaches that sample reads
+        // nil in the shorter channels — "attempt to perform arithmetic on a nil value" out of the iterator itself (nothing catches it, :2898-2909):
+        // the calls before it deliver their chunks, that call raises.  (Above 48 kHz the last outputs stop short of the last sample: not modelled.)
+        const bool ragged = nb % (uint64_t)C != 0;
+        if (ragged && ratio < 1) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "G.711 data length is not a multiple of the channel count at a rate above 48 kHz (stream %u)", s); }
         ck->length_seconds[s] = (double)(nb + ctx->sb_bytes) / d->sample_rate / C;
         in_bytes += nb;
         uint32_t calls = (uint32_t)((nb + per_call - 1) / per_call);  // calls that see data; the reference then returns {{}} forever (Q13)
+        if (ragged) { calls--; ck->status[s] = AUKIT_E_LUA; }
         ck->nchunks[s] = calls;
         ck->max_chunks = std::max(ck->max_chunks, calls);
     }

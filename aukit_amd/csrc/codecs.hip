@@ -1039,14 +1039,19 @@ static int ima_decode_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_c
 
 template <typename OUT_T>
 static int launch_ima_stream(aukit_ctx *ctx, int interp, const ImaStreamParams &P, unsigned grid, size_t lds, unsigned threads) {
+    // (blocks beyond 64 KiB of decoded samples — blockAlign x channels above ~4 KiB — take the CU's whole LDS: the kernel is told so, round 6)
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) AUKIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, P);
+        AUKIT_HIP_CHECK(hipGetLastError());
+        return AUKIT_OK;
+    };
     switch (interp) {
-    case AUKIT_INTERP_NONE: hipLaunchKernelGGL((k_ima_stream<AUKIT_INTERP_NONE, OUT_T>), dim3(grid), dim3(threads), lds, ctx->stream, P); break;
-    case AUKIT_INTERP_LINEAR: hipLaunchKernelGGL((k_ima_stream<AUKIT_INTERP_LINEAR, OUT_T>), dim3(grid), dim3(threads), lds, ctx->stream, P); break;
-    case AUKIT_INTERP_CUBIC: hipLaunchKernelGGL((k_ima_stream<AUKIT_INTERP_CUBIC, OUT_T>), dim3(grid), dim3(threads), lds, ctx->stream, P); break;
-    default: hipLaunchKernelGGL((k_ima_stream<AUKIT_INTERP_SINC, OUT_T>), dim3(grid), dim3(threads), lds, ctx->stream, P); break;
+    case AUKIT_INTERP_NONE: return go(k_ima_stream<AUKIT_INTERP_NONE, OUT_T>);
+    case AUKIT_INTERP_LINEAR: return go(k_ima_stream<AUKIT_INTERP_LINEAR, OUT_T>);
+    case AUKIT_INTERP_CUBIC: return go(k_ima_stream<AUKIT_INTERP_CUBIC, OUT_T>);
+    default: return go(k_ima_stream<AUKIT_INTERP_SINC, OUT_T>);
     }
-    AUKIT_HIP_CHECK(hipGetLastError());
-    return AUKIT_OK;
 }
 
 // aukit.stream.adpcm(input, blockAlign, channels, sampleRate, mono)  aukit.lua:2753-2835
@@ -1302,7 +1307,9 @@ static int ima_stream(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
         unsigned nwv = 4;
         while (nwv > 1 && (size_t)P.cap * C * 8 * nwv > 64 * 1024) nwv >>= 1;
         const size_t lds = (size_t)P.cap * C * 8 * nwv;
-        if (lds > 64 * 1024) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "blockAlign %d with %d channels needs more than 64 KiB of LDS", d->block_align, C); }
+        // one wave per block and the CU's whole 160 KiB (less what the kernel declares itself): blockAlign x channels up to ~10 KiB — every WAV
+        // encoder's blocks; the reference has no limit at all, a block-at-a-time path for more than that does not exist here
+        if (lds > 156 * 1024) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "blockAlign %d with %d channels needs more than 156 KiB of LDS", d->block_align, C); }
         unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(32 / nwv, (160 * 1024) / lds));
         unsigned grid = (unsigned)std::min<uint64_t>((nblocks + nwv - 1) / nwv, (uint64_t)ctx->num_cus * per_cu * 2);
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }

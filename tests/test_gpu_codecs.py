@@ -559,3 +559,22 @@ def test_dfpwm_chunk_decoder_in_digital_silence(ctx, oracle):
         ref = oracle.dfpwm(d, 2, 48000)
         assert np.array_equal(got[i][0], ref.data[0]) and np.array_equal(got[i][1], ref.data[1])
     assert chunks > 10 and redone * 10 <= chunks, (chunks, redone)
+
+
+@pytest.mark.parametrize("ch,ba", [(2, 4096), (2, 8192), (4, 4096)])
+def test_stream_adpcm_large_blocks(ctx, oracle, ch, ba):
+    """stream.adpcm on blocks whose decoded samples do not fit 64 KiB (blockAlign x channels from ~4 KiB on: refused until round 6) — the kernel takes
+    the CU's whole LDS for a block; chunk for chunk the oracle's"""
+    B, N = _B(), _N()
+    spb = (ba - 4 * ch) * 2 // ch
+    streams = [oracle.gen_ima(np.stack([pcm16(spb * nb, 22050, 3, 4 * i + c) for c in range(ch)], 1).ravel(), ch, ba, 88) for i, nb in enumerate((5, 1, 3))]
+    streams.append(streams[0][: ba * 2 + 40])  # short final block
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, ch, 22050, block_align=ba), "cubic", dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_adpcm(s, ba, ch, 22050, False, oracle.CUBIC)
+        assert ck.nchunks[i] == ref.nchunks, (i, ck.nchunks[i], ref.nchunks)
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        for c in range(ref.channels):
+            assert np.array_equal(got[i][c], ref.data[c]), (i, c)

@@ -501,6 +501,28 @@ def test_stream_g711_bit_exact(ctx, oracle, interp, ch, mono):
 
 
 @pytest.mark.parametrize("ch", [2, 3])
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_stream_g711_ragged_byte_count(ctx, oracle, ch, interp):
+    """a byte count that is not a multiple of the channel count (aukit.lua:2878-2911; refused until round 6): the calls before the last deliver
+    their chunks, the last one — whose shorter channels read nil at the end — raises: chunk for chunk the oracle's, and its final status"""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(77 + ch))
+    streams = [rng.integers(0, 256, 8000 * ch * 2 + 1, dtype=np.uint8).tobytes(), rng.integers(0, 256, 8000 * ch + ch - 1, dtype=np.uint8).tobytes(),
+               rng.integers(0, 256, ch + 1, dtype=np.uint8).tobytes(), rng.integers(0, 256, 8000 * ch * 2, dtype=np.uint8).tobytes()]
+    bt = B.Batch.upload(ctx, streams)
+    out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_G711, ch, 8000, ulaw=True), interp, dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(streams):
+        ref = oracle.stream_g711(s, True, ch, 8000, False, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks, i
+        assert (ck.status[i] != 0) == (ref.final_status != 0), i
+        assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0])
+        for c in range(ch):
+            assert np.array_equal(got[i][c], ref.data[c]), (i, c)
+    assert [int(x != 0) for x in ck.status] == [1, 1, 1, 0]
+
+
+@pytest.mark.parametrize("ch", [2, 3])
 @pytest.mark.parametrize("rate,interp,alaw", [(8000, "cubic", False), (8000, "linear", True), (44100, "cubic", False), (22050, "linear", False), (11025, "cubic", True)])
 def test_stream_g711_several_channels_on_the_floor_kernel(ctx, oracle, monkeypatch, ch, rate, interp, alaw):
     """stream.g711 with interleaved channels (aukit.lua:2878-2911; round 4): planar byte rows (k_deinterleave_bytes) + the mono three-tier floor
