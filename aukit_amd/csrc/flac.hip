@@ -1575,8 +1575,13 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             A.limit_factor = limit_factor; A.ticket = &d_cnt->ticket; A.stats = d_cnt->stats;
             A.out16 = o16 ? 1 : 0;
             A.dbg = getenv("AUKIT_FLAC_FUSED_DBG") ? atoi(getenv("AUKIT_FLAC_FUSED_DBG")) : 0;
-            static const bool round4 = getenv("AUKIT_FLAC_DECODER") && !strcmp(getenv("AUKIT_FLAC_DECODER"), "fused");   // A/B: k_flac_decode (flac_fused.hip)
-            return round4 ? flac_fused_launch(ctx, A) : flac_stream_launch(ctx, A);
+            // k_flac_stream (a wave per 64 frames) when the batch fills the chip; k_flac_pq (a parser and a predictor wave per 64 frames: the lane's chain
+            // cut in two) when it does not — fewer frames than three of its workgroups per CU hold at once.  AUKIT_FLAC_DECODER = stream | pq | fused for the A/B
+            // (fused: k_flac_decode, flac_fused.hip, round 4)
+            const char *which = getenv("AUKIT_FLAC_DECODER");
+            if (which && !strcmp(which, "fused")) return flac_fused_launch(ctx, A);
+            const bool pq = which ? !strcmp(which, "pq") : (uint64_t)A.count <= (uint64_t)ctx->num_cus * 3ull * 64ull;
+            return pq ? flac_pq_launch(ctx, A) : flac_stream_launch(ctx, A);
         };
         std::vector<ChainOut> chain(n);
         bool restart = false;

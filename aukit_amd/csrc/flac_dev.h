@@ -95,6 +95,8 @@ struct FusedArgs {
 int flac_fused_launch(aukit_ctx *ctx, const FusedArgs &A);
 // flac_stream.hip (round 6): the same contract, values in registers from the bit stream to the store
 int flac_stream_launch(aukit_ctx *ctx, const FusedArgs &A);
+// flac_pq.hip (round 6): the same contract, a parser wave and a predictor wave per 64 frames — small batches
+int flac_pq_launch(aukit_ctx *ctx, const FusedArgs &A);
 // the chained frames' records in stream order (one lane per candidate)
 int flac_frames_launch(aukit_ctx *ctx, const Cand *cands, const CandInfo *ci, unsigned ncand, const u64 *frame_base, FrameRec *frames, const u64 *stream_off);
 // chained frames: scratch → contiguous int32 rows (one workgroup per frame record)
