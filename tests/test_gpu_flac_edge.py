@@ -9,6 +9,15 @@ from tests.util import pcm16
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "stream"])
+def _both_register_decoders(request, monkeypatch):
+    """round 6: small batches decode with k_flac_pq (a parser and a predictor wave per 64 frames), batches that fill the chip with k_flac_stream
+    (one wave) — every case of this module runs through both (AUKIT_FLAC_DECODER, read per call; the round-4 kernel stays behind "fused")"""
+    if request.param != "auto":
+        monkeypatch.setenv("AUKIT_FLAC_DECODER", request.param)
+
+
+
 def _B():
     from aukit_amd import batch as B
     return B

@@ -176,9 +176,12 @@ def test_fuzz_ima_stream(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds(24))
-def test_fuzz_flac(ctx, oracle, seed):
+@pytest.mark.parametrize("decoder", ["auto", "stream"])
+def test_fuzz_flac(ctx, oracle, seed, decoder, monkeypatch):
     """FLAC files of random depth / channels / block size / length (the oracle's encoder picks predictor orders and Rice parameters
     per block) through the loader (lossless), the resampled f32 pipeline and stream.flac"""
+    if decoder != "auto":   # (round 6: k_flac_pq takes small batches by default — the one-wave kernel sees the same cases)
+        monkeypatch.setenv("AUKIT_FLAC_DECODER", decoder)
     B, N = _B(), _N()
     rng = np.random.Generator(np.random.PCG64(5000 + seed))
     depth = int(rng.choice([8, 16, 24]))
@@ -556,10 +559,13 @@ def test_fuzz_mix_encode_dfpwm(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds(48))
-def test_fuzz_flac_corrupted(ctx, oracle, seed):
+@pytest.mark.parametrize("decoder", ["auto", "stream"])
+def test_fuzz_flac_corrupted(ctx, oracle, seed, decoder, monkeypatch):
     """FLAC files with a few random bytes overwritten or cut short after the metadata: whatever decodeFLAC does with them — decode
     garbage, lose sync, raise — the stream (errors swallowed, it just ends) must deliver the same chunks as the oracle, and the
     loader must raise exactly when the oracle does, with the same samples otherwise"""
+    if decoder != "auto":   # (round 6: k_flac_pq takes small batches by default — the one-wave kernel sees the same cases)
+        monkeypatch.setenv("AUKIT_FLAC_DECODER", decoder)
     B, N = _B(), _N()
     rng = np.random.Generator(np.random.PCG64(9950 + seed))
     ch = int(rng.integers(1, 3))
