@@ -839,6 +839,64 @@ __global__ __launch_bounds__(64) void k_flac_chain(const FlacGlobals G, unsigned
 }
 
 
+// The same walk for the register decoders (round 6), one dependent load per frame instead of three: k_flac_links (a lane per candidate, all at once)
+// looks every candidate's successor up — the candidate that starts where it ends — and puts what the walk wants of a frame into 16 bytes; the walk
+// follows those.  (k_flac_chain waits for the hash slot, the slot's value and the frame's record, one after the other, 108 times per ten-second
+// stream: 0.23 ms whatever the batch — a thirteenth of config 5's step at 256 streams.)
+struct ChainLink { unsigned next; int blocksize; int status; unsigned more; };   // more: the frame ends inside its stream's data (the walk goes on)
+__global__ __launch_bounds__(256) void k_flac_links(const FlacGlobals G, const Cand *cands, const CandInfo *ci, unsigned ncand, CandHash H, ChainLink *links) {
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ncand) return;
+    const CandInfo f = ci[k];
+    ChainLink l;
+    l.blocksize = f.blocksize; l.status = f.status;
+    l.more = (f.status == FE_OK && f.end_byte < G.off[cands[k].stream + 1]) ? 1u : 0u;
+    l.next = l.more ? hash_lookup(H, f.end_byte) : ~0u;
+    links[k] = l;
+}
+__global__ __launch_bounds__(64) void k_flac_chain_links(const FlacGlobals G, unsigned n, CandHash H, CandInfo *ci, const ChainLink *links, ChainOut *out) {
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n) return;
+    ChainOut r{};
+    const u64 at0 = G.off[s] + G.info[s].first_byte;
+    u64 sp = 0;
+    unsigned nf = 0;
+    int bs0 = 0, prev_bs = 0, uniform = 1;
+    int stream_status = FE_OK;
+    bool go = at0 < G.off[s + 1];  // readByte() -> nil -> decodeFrame returns false
+    unsigned k = go ? hash_lookup(H, at0) : ~0u, kprev = ~0u;
+    while (go) {   // (single-exit loop, as k_flac_chain)
+        if (k == ~0u) { r.miss_kind = 1; r.miss_at = kprev == ~0u ? at0 : ci[kprev].end_byte; go = false; }
+        else {
+            const ChainLink l = links[k];
+            if (l.status == FE_OK) {
+                ci[k].sample_off = sp;
+                ci[k].seq = nf;
+                ci[k].used = 1;
+                if (nf == 0) bs0 = l.blocksize;
+                else if (prev_bs != bs0) uniform = 0;
+                prev_bs = l.blocksize;
+                sp += (u64)l.blocksize;
+                nf++;
+                kprev = k;
+                k = l.next;
+                go = l.more != 0;
+            } else {
+                if (l.status == FE_LIMIT) { r.miss_kind = 2; r.miss_ci = k; }
+                else if (l.status != FE_EOF_START) stream_status = l.status;
+                go = false;
+            }
+        }
+    }
+    r.L = sp;
+    r.bs0 = bs0;
+    r.uniform = (uniform && prev_bs <= bs0) ? 1 : 0;
+    r.nframes = nf;
+    r.status = stream_status;
+    out[s] = r;
+}
+
+
 __global__ __launch_bounds__(256) void k_flac_jobs(const Cand *cands, const CandInfo *ci, const SubDesc *sd, unsigned ncand, int C, const u64 *row_off,
                                                   const u64 *frame_base, const u64 *kind_base, u64 *kind_fill, SubJob *jobs, FrameRec *frames) {
     // thread t takes candidate (t mod 64) * (threads / 64) + t / 64: the 64 candidates of a wave lie far apart (other streams), and since a wave's
@@ -1548,10 +1606,11 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         Carve cv;
         const size_t o_cnt = cv.take(sizeof(Counters)), o_chain = cv.take((size_t)n * sizeof(ChainOut)), o_cand = cv.take(capc * sizeof(Cand)),
                      o_ci = cv.take(capc * sizeof(CandInfo)), o_keys = cv.take(hs * 8), o_vals = cv.take(hs * 4),
-                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8);
+                     o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8), o_links = cv.take(capc * sizeof(ChainLink));
         if ((rc = ctx->tmp_buf2.ensure(cv.at))) return rc;
         char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
         Counters *d_cnt = reinterpret_cast<Counters *>(B + o_cnt);
+        ChainLink *d_links = reinterpret_cast<ChainLink *>(B + o_links);
         ChainOut *d_chain = reinterpret_cast<ChainOut *>(B + o_chain);
         Cand *d_cand = reinterpret_cast<Cand *>(B + o_cand);
         CandInfo *d_ci = reinterpret_cast<CandInfo *>(B + o_ci);
@@ -1593,7 +1652,11 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
                 if ((rc = decode(0, ncand, 5))) return rc;
                 if ((rc = ctx_end_kernel(ctx, "k_flac_decode", in->total() + guess * 4))) return rc;
             }
-            hipLaunchKernelGGL(k_flac_chain, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, G, n, H, d_ci, (const SubDesc *)nullptr, C, d_chain, d_cnt->kind_count);
+            if (getenv("AUKIT_FLAC_CHAIN_OLD")) hipLaunchKernelGGL(k_flac_chain, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, G, n, H, d_ci, (const SubDesc *)nullptr, C, d_chain, d_cnt->kind_count);
+            else {
+                hipLaunchKernelGGL(k_flac_links, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, G, d_cand, d_ci, ncand, H, d_links);
+                hipLaunchKernelGGL(k_flac_chain_links, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, G, n, H, d_ci, d_links, d_chain);
+            }
             AUKIT_HIP_CHECK(hipGetLastError());
             AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
             AUKIT_HIP_CHECK(hipMemcpyAsync(chain.data(), d_chain, (size_t)n * sizeof(ChainOut), hipMemcpyDeviceToHost, ctx->stream));
