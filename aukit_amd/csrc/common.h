@@ -60,6 +60,13 @@ struct aukit_ctx {
     hipStream_t aux_stream = nullptr, dec_stream = nullptr;  // aux_stream: the sliced transcode's encoder runs here (dec_stream: unused, kept for the CU-mask experiment)
     hipEvent_t aux_ev[10] = {};
     hipStream_t side_stream = nullptr;   // independent kernels of one call run next to each other (FLAC's order classes): ctx_side_stream()
+    // round 6: the FLAC loader's first stages (stream headers, the sync search) read nothing but the input batch: they run on a stream of their own, into one of
+    // two alternating sets of tables, so that call k + 1's search overlaps what call k still has queued on ctx->stream (its filter and normalize passes);
+    // the decoder waits for them by event.  AUKIT_FLAC_NO_LOOKAHEAD=1: everything on ctx->stream as before
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t pre_ev = nullptr;
+    aukit::DevBuf flac_set[2];
+    int flac_par = 0;
     hipEvent_t side_ev[2] = {};
     int aux_enc_cus = -1;
     bool fused_attr_set = false;
@@ -120,6 +127,7 @@ struct aukit_batch {
     bool own = true;
     uint64_t *d_off = nullptr;  // device copy of off (n+1)
     uint64_t version = 0;       // bumped whenever contents/layout change (plan cache key)
+    hipEvent_t ready = nullptr; // wrapped batches: recorded on the wrapping context's stream when the batch was wrapped — what the caller queued there before (the bytes' producer, the offsets' upload) is ordered in front of a reader on another stream that waits for it (null: complete)
     uint8_t *data() const { return base + front_pad; }
     uint64_t total() const { return off.empty() ? 0 : off.back(); }
 };
@@ -233,7 +241,8 @@ int ctx_end_kernel(aukit_ctx *ctx, const char *name, uint64_t algorithmic_bytes)
 int upload_table(aukit_ctx *ctx, DevBuf &buf, const void *src, size_t bytes);
 int h2d_table(aukit_ctx *ctx, void *dst, const void *src, size_t bytes);
 int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side);  // side stream that starts after everything queued on ctx->stream so far (runtime.hip)
-int ctx_side_join(aukit_ctx *ctx);                     // ctx->stream continues after everything queued on the side stream  // pinned-ring H2D on ctx->stream (runtime.hip)
+int ctx_side_join(aukit_ctx *ctx);
+int ctx_pre_stream(aukit_ctx *ctx, hipStream_t *s);   // the look-ahead stream of the FLAC loader's first stages (created on first use)                     // ctx->stream continues after everything queued on the side stream  // pinned-ring H2D on ctx->stream (runtime.hip)
 // q = RN(n / d) computed as fma(fma(-d, n*r, n), r, n*r) with r = RN(1/d) is exact for the integers
 // n in [0, count): verified on the host once per (d, count) and cached in ctx->div_ok.
 bool exact_div_verified(aukit_ctx *ctx, double d, uint64_t count);

@@ -1330,6 +1330,8 @@ __global__ __launch_bounds__(256) void k_flac_finish(const FrameRec *frames, con
 }
 
 struct FlacDecoded {
+    DevBuf *set = nullptr;      // round 6: the call's set of tables (aukit_ctx::flac_set) when its first stages run on the look-ahead stream `pre`; null: tmp_buf2, ctx->stream
+    hipStream_t pre = nullptr;
     std::vector<FlacStreamInfo> info;
     std::vector<std::vector<std::pair<uint64_t, int>>> frames;  // per stream: (sample offset, blocksize) of every decoded frame, in order
     std::vector<int> status;                                     // per stream: 0 = clean end, else FlacErr of the frame that failed
@@ -1586,7 +1588,6 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
     const int C = D.channels;
     int rc;
     const bool o16 = D.want16 && D.depth <= 16 && !getenv("AUKIT_FLAC_NO_I16");   // finals as int16 (flac_fused.hip, O16)
-    const FlacStreamInfo *d_info = reinterpret_cast<const FlacStreamInfo *>(ctx->misc_buf.p);
     const uintptr_t dptr = reinterpret_cast<uintptr_t>(in->data());
     FlacGlobals G;
     G.src = in->data();
@@ -1594,7 +1595,11 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
     G.base_bit = 8 * (dptr & 15);
     G.safe_words = (((dptr & 15) + in->total() + 15) / 16) * 2;
     G.off = reinterpret_cast<const u64 *>(in->d_off);
-    G.info = d_info;
+    G.info = reinterpret_cast<const FlacStreamInfo *>(ctx->misc_buf.p);
+    // the call's tables: its set of the two (flac_decode_rows; the stream infos lie at its front), or tmp_buf2 with everything on ctx->stream
+    DevBuf &TB = D.set ? *D.set : ctx->tmp_buf2;
+    hipStream_t pre = D.set ? D.pre : ctx->stream;
+    const size_t info_bytes = D.set ? (((size_t)n * sizeof(FlacStreamInfo) + 255) & ~(size_t)255) : 0;
     uint64_t capc = in->total() / 2048 + n + 4096;
     uint64_t guess = 0;
     for (uint32_t s = 0; s < n; s++) guess += (uint64_t)D.info[s].nsamples * C;
@@ -1604,11 +1609,18 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         uint64_t hs = 1; unsigned hbits = 0;
         while (hs < 2 * capc) { hs <<= 1; hbits++; }
         Carve cv;
+        cv.at = info_bytes;
         const size_t o_cnt = cv.take(sizeof(Counters)), o_chain = cv.take((size_t)n * sizeof(ChainOut)), o_cand = cv.take(capc * sizeof(Cand)),
                      o_ci = cv.take(capc * sizeof(CandInfo)), o_keys = cv.take(hs * 8), o_vals = cv.take(hs * 4),
                      o_rowoff = cv.take((size_t)n * C * 8), o_fbase = cv.take((size_t)n * 8), o_links = cv.take(capc * sizeof(ChainLink));
-        if ((rc = ctx->tmp_buf2.ensure(cv.at))) return rc;
-        char *B = reinterpret_cast<char *>(ctx->tmp_buf2.p);
+        if (TB.cap < cv.at) {   // (grows: the stream infos at the set's front move with it)
+            std::vector<char> keep(info_bytes);
+            if (info_bytes) { AUKIT_HIP_CHECK(hipStreamSynchronize(pre)); AUKIT_HIP_CHECK(hipMemcpy(keep.data(), TB.p, info_bytes, hipMemcpyDeviceToHost)); }
+            if ((rc = TB.ensure(cv.at + cv.at / 4))) return rc;
+            if (info_bytes) AUKIT_HIP_CHECK(hipMemcpy(TB.p, keep.data(), info_bytes, hipMemcpyHostToDevice));
+        }
+        char *B = reinterpret_cast<char *>(TB.p);
+        if (D.set) G.info = reinterpret_cast<const FlacStreamInfo *>(B);
         Counters *d_cnt = reinterpret_cast<Counters *>(B + o_cnt);
         ChainLink *d_links = reinterpret_cast<ChainLink *>(B + o_links);
         ChainOut *d_chain = reinterpret_cast<ChainOut *>(B + o_chain);
@@ -1616,16 +1628,18 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         CandInfo *d_ci = reinterpret_cast<CandInfo *>(B + o_ci);
         CandHash H{reinterpret_cast<u64 *>(B + o_keys), reinterpret_cast<unsigned *>(B + o_vals), 64 - hbits, hs - 1};
         u64 *d_rowoff = reinterpret_cast<u64 *>(B + o_rowoff), *d_fbase = reinterpret_cast<u64 *>(B + o_fbase);
-        AUKIT_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), ctx->stream));
-        AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, ctx->stream));
+        AUKIT_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), pre));
+        AUKIT_HIP_CHECK(hipMemsetAsync(H.keys, 0xFF, hs * 8, pre));
         const uint64_t cand_room = capc - n - 64;
-        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 64)), dim3(256), 0, ctx->stream, G,
+        hipLaunchKernelGGL(k_flac_find, dim3((unsigned)std::min<uint64_t>((G.safe_words / 2 + 255) / 256, (uint64_t)ctx->num_cus * 64)), dim3(256), 0, pre, G,
                            (u64)in->total(), n, d_cand, cand_room, &d_cnt->ncand, H);
         AUKIT_HIP_CHECK(hipGetLastError());
         Counters hc;
-        AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-        AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        AUKIT_HIP_CHECK(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, pre));
+        if (D.set) AUKIT_HIP_CHECK(hipEventRecord(ctx->pre_ev, pre));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(pre));
         if (hc.ncand > cand_room) { capc = hc.ncand + hc.ncand / 8 + n + 4096; continue; }
+        if (D.set) AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));   // the decoder (ctx->stream) behind the search
         unsigned ncand = (unsigned)hc.ncand;
         auto decode = [&](unsigned first, unsigned count, int limit_factor) -> int {
             FusedArgs A;
@@ -1766,15 +1780,33 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     const uint32_t n = in->n;
     if (n == 0) return fail(AUKIT_E_ARG, "empty batch");
     int rc;
-    // -- 1. stream headers
+    // -- 1. stream headers.  Round 6: on the look-ahead stream (common.h: pre_stream) — this stage and the sync search read the input batch and
+    // nothing else, and their host waits used to be waits for everything the call BEFORE had left on ctx->stream (config 5: its filter and
+    // normalize passes, 4.5 ms): back-to-back calls now search while the one before still filters.  The tables of a call lie in one of two
+    // alternating sets (the call before may still be read by its last kernels); ctx->stream sees the stream infos as a copy in misc_buf, in
+    // stream order, for the first design's kernels.
+    hipStream_t pre = ctx->stream;
+    D.set = nullptr;
+    if (!getenv("AUKIT_FLAC_NO_LOOKAHEAD")) {
+        if ((rc = ctx_pre_stream(ctx, &pre))) return rc;
+        if (in->ready) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, in->ready, 0));
+        ctx->flac_par ^= 1;
+        D.set = &ctx->flac_set[ctx->flac_par];
+    }
+    D.pre = pre;
     DevBuf &hb = ctx->misc_buf;
     if ((rc = hb.ensure((size_t)n * sizeof(FlacStreamInfo)))) return rc;
-    hipLaunchKernelGGL(k_flac_header, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const u64 *>(in->d_off), n,
-                       reinterpret_cast<FlacStreamInfo *>(hb.p));
+    FlacStreamInfo *d_info_pre = reinterpret_cast<FlacStreamInfo *>(hb.p);
+    if (D.set) {
+        if ((rc = D.set->ensure(((size_t)n * sizeof(FlacStreamInfo) + 255) & ~(size_t)255))) return rc;
+        d_info_pre = reinterpret_cast<FlacStreamInfo *>(D.set->p);
+    }
+    hipLaunchKernelGGL(k_flac_header, dim3((n + 63) / 64), dim3(64), 0, pre, in->data(), reinterpret_cast<const u64 *>(in->d_off), n, d_info_pre);
     AUKIT_HIP_CHECK(hipGetLastError());
     D.info.resize(n);
-    AUKIT_HIP_CHECK(hipMemcpyAsync(D.info.data(), hb.p, (size_t)n * sizeof(FlacStreamInfo), hipMemcpyDeviceToHost, ctx->stream));
-    AUKIT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    AUKIT_HIP_CHECK(hipMemcpyAsync(D.info.data(), d_info_pre, (size_t)n * sizeof(FlacStreamInfo), hipMemcpyDeviceToHost, pre));
+    AUKIT_HIP_CHECK(hipStreamSynchronize(pre));
+    if (D.set) AUKIT_HIP_CHECK(hipMemcpyAsync(hb.p, D.info.data(), (size_t)n * sizeof(FlacStreamInfo), hipMemcpyHostToDevice, ctx->stream));   // (pageable: the copy is staged before this returns)
     for (uint32_t s = 0; s < n; s++) {
         switch (D.info[s].status) {
         case 0: break;

@@ -72,6 +72,14 @@ int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side) {
     *side = ctx->side_stream;
     return AUKIT_OK;
 }
+int ctx_pre_stream(aukit_ctx *ctx, hipStream_t *s) {
+    if (!ctx->pre_stream) {
+        AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));
+        AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->pre_ev, hipEventDisableTiming));
+    }
+    *s = ctx->pre_stream;
+    return AUKIT_OK;
+}
 int ctx_side_join(aukit_ctx *ctx) {
     AUKIT_HIP_CHECK(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
     AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
@@ -247,6 +255,8 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     if (c->stream_full) { aukit_audio_free(c->stream_full); c->stream_full = nullptr; }
     delete c->spcm_ck;
     if (c->host_stage) (void)hipHostFree(c->host_stage);
+    if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->pre_ev); c->pre_stream = nullptr; }
+    c->flac_set[0].release(); c->flac_set[1].release();
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -384,6 +394,8 @@ int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_b
     b->own = false;
     int rc = batch_set_offsets(ctx, b, offsets, n);
     if (rc) { aukit_batch_free(b); return rc; }
+    // (what the caller queued on this stream before the wrap — the bytes' producer, the offsets' upload above — in front of readers on other streams)
+    if (hipEventCreateWithFlags(&b->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(b->ready, ctx->stream) != hipSuccess) { aukit_batch_free(b); return fail(AUKIT_E_HIP, "hipEventRecord failed"); }
     *out = b;
     return AUKIT_OK;
 }
@@ -412,6 +424,7 @@ void aukit_batch_free(aukit_batch *b) {
     if (!b) return;
     if (b->own && b->base) (void)hipFree(b->base);
     if (b->d_off) (void)hipFree(b->d_off);
+    if (b->ready) (void)hipEventDestroy(b->ready);
     delete b;
 }
 
