@@ -580,7 +580,17 @@ class QoaStream(Workload):
 
 class DfpwmTranscode(Workload):
     name, unit = "dfpwm_transcode", "Msamples/s"
-    valu_per_unit = (731 / 16, "k_dfx_chunks<0>'s hot block: 731 VALU instructions per source dword = 16 mono samples (2 x 15 decoder steps, mix index, 12 encoder steps, bookkeeping)")
+    @property
+    def valu_per_unit(self):
+        """the hot block's VALU instructions per mono sample, from the code this library was built from (tools/isa_count.py writes aukit_amd/isa_counts.json at
+        build time: ADVICE r05 — the literal 731 of round 5 belonged to one build); None (no `issue` object in the line) where that file is missing"""
+        try:
+            with open(os.path.join(ROOT, "aukit_amd", "isa_counts.json")) as fh:
+                c = json.load(fh)["dfx_chunks0_hot_valu"]
+            return (c["value"] / 16, f"k_dfx_chunks<0>'s hot block: {c['value']} VALU instructions per source dword = 16 mono samples (2 x 15 decoder steps, mix index, 12 encoder "
+                                     f"steps, bookkeeping); {c['definition']}, sources {c['src_sha16']}")
+        except (OSError, KeyError, ValueError, TypeError):
+            return None
 
     def setup(self, torch, dev, ctx, args, rank, N, B):
         # SURVEY 8d config 4: "produced by the build's DFPWM encoder" — the config-1 style signal, two channels, 48 kHz, through the product's own
@@ -1092,7 +1102,7 @@ def main(argv=None):
                 line["roofline"]["launch_bytes_sum"] = alg_bytes
                 line["roofline"]["note"] = ("several launches per step: frac = (input bytes + final output bytes) / the step's kernel time; launch_bytes_sum adds every "
                                             "launch's own input + output, intermediates included, and is not a roofline fraction of the task")
-            if hasattr(wl, "valu_per_unit"):
+            if getattr(wl, "valu_per_unit", None):
                 # a step bound by VALU issue, not by bytes (the HBM fraction above says so: it is tiny): the USEFUL instructions — the hot loop's
                 # count per unit from the built code object, warm-ups, scans and repairs not counted — over the whole step's kernel
                 # time, against what 1024 SIMDs of 16 lanes issue at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
