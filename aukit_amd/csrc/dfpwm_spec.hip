@@ -724,17 +724,22 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
         atomicAdd(&X.flags[8], chunks);
         // how the later chunks look: after a change of class the guesses still agree with each other (they converge to the same wrong run),
         // on noise they do not — every boundary is a mismatch, and another round would fail at the next one
-        unsigned later = 0, bad = 0;
+        unsigned later = 0, bad = 0, flips = 0;
+        bool was = true;   // (chunk c itself missed)
         for (unsigned k = c + 1; k < P.nchunk; k++) {
             if (X.st[((size_t)k * 12 + 1) * X.npad + s] < 0) break;
             later++;
-            bad += X.fx[(size_t)k * 13 * X.npad + s] != 0 ? 1u : 0u;
+            const bool b = X.fx[(size_t)k * 13 * X.npad + s] != 0;
+            bad += b ? 1u : 0u;
+            flips += b != was ? 1u : 0u;
+            was = b;
         }
-        // (round 6: one boundary in ten — signal misses one in 200 - 500, noise one in six; the threshold was one in two, which noise never reached:
-        // sixteen streams of it went through six rounds and THEN to the fallback, 15.6 ms for the older schedule's 6.8)
-        // ... AND the round got the stream no further than a strike's worth: a passage of silence inside a stream leaves one boundary in five to
-        // two re-run as well (4096 gated streams went to the fallback on the count alone: 8.8 -> 20 ms), but the run up to it is long
-        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 2 > later) || (later >= 12 && bad * 10 > later && progress < few)) {
+        // Round 6: noise is told from a passage of silence by how the missed boundaries LIE, not by how many there are.  Noise misses one boundary in
+        // six, anywhere: hits and misses alternate all along the stream (flips ≈ 0.28 per chunk).  Silence inside a stream leaves one boundary in five
+        // to two re-run as well, but in ONE run (two flips a passage).  (The count alone — one in ten — sent 4096 gated streams to the fallback,
+        // 8.8 -> 20 ms; one in two, round 5's threshold, noise never reached: sixteen streams of it went through six rounds and THEN to the fallback,
+        // 15.6 ms for the older schedule's 6.8: profiles/r06_dfx_grid_before.txt.)
+        if (X.round + 1 >= X.rounds || strikes >= DFX_STRIKES || (later >= 12 && bad * 2 > later) || (later >= 12 && flips >= 6 && flips * 8 > later)) {   // (six flips: more than two passages of silence make — a batch cut into few chunks per stream has few boundaries to count)
             X.ctl[s] = (int)P.nchunk + 1;
             X.hard[atomicAdd(&X.flags[13], 1u)] = s;
             return;

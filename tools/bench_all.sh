@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 : > gpurun_out/bench_lines.jsonl
 python bench.py --cpu-seconds ${CPU_SECONDS:-4} 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
 for w in pcm16_stream pcm16_stereo pcm16_stereo_stream g711_cubic g711_stream ima_stream ima_pipeline msadpcm_stream qoa_stream dfpwm_transcode flac_pipeline; do
-  python bench.py --workload $w --steps ${STEPS:-5} --warmup 1 --cpu-seconds ${CPU_SECONDS:-4} 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
+  python bench.py --workload $w --steps ${STEPS:-5} --warmup 3 --cpu-seconds ${CPU_SECONDS:-4} 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
 done
 python - <<'PY'
 import json
