@@ -405,7 +405,15 @@ static int stream_pcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_d
     std::vector<std::vector<uint32_t>> clens(in->n);
     for (uint32_t s = 0; s < in->n; s++) {
         uint64_t nb = in->off[s + 1] - in->off[s];
-        if (nb % ((size_t)bd * C) != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream.pcm: data is not a whole number of frames (stream %u)", s); }
+        // Data that ends inside a frame (round 6).  With the mono mix-down every index is read for ALL channels (`self[i] = (rawget(self, i) or 0) + read()`,
+        // :2368): the frame a channel is missing from raises where a frame missing altogether would — inside the pcall (the chunk ends there, :2389-2407) or,
+        // in the prefill, as `if not c then return nil end` (:2377-2384): the partial frame counts for nothing.  WITHOUT the mix-down the channels in front
+        // of the gap get one output more than the others in the last chunk (`for i ... for y`: they are written before the missing one raises) — chunk
+        // lengths per channel, which this ABI does not have: refused, as is data that ends inside a SAMPLE (`string.rep` with a fractional count is the VM's business).
+        if (nb % ((size_t)bd * C) != 0) {
+            if (nb % (size_t)bd != 0) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream.pcm: data ends inside a sample (stream %u)", s); }
+            if (!mono) { delete ck; return fail(AUKIT_E_UNSUPPORTED, "stream.pcm: data ends inside a frame and the channels are not mixed down: the reference's last chunk is longer in its first channels (stream %u)", s); }
+        }
         const long long nframes = (long long)(nb / ((size_t)bd * C));
         ck->length_seconds[s] = ((double)(nb + ctx->sb_bytes) / bd) / C / d->sample_rate;  // :2245, :2423 (sb_bytes: what a stream handle has dropped already)
         in_bytes += nb;

@@ -916,6 +916,12 @@ def main(argv=None):
 
     def timed_window():
         """K steps bracketed by barrier + synchronize on both sides; returns (wall seconds, HIP-event ms, launches, algorithmic bytes)"""
+        # (the host's garbage collector out of the timed region: a full collection — 30 ms with the chunk tables of the stream workloads alive — once in
+        # fifty-odd steps landed in one window of five and read as a step of 5.8 ms among steps of 2.4: profiles/r05_bench_lines.jsonl, r06)
+        import gc
+        gc.collect()
+        if not os.environ.get("AUKIT_BENCH_KEEP_GC"):
+            gc.disable()
         sync()
         if world > 1:
             dist.barrier()
@@ -931,6 +937,7 @@ def main(argv=None):
             dist.barrier()
         sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         nl, nb = ctx.timer_stats() if ctx else (0, 0)
         return dt, ev_ms, nl, nb
 

@@ -448,6 +448,31 @@ def test_stream_pcm_stereo_and_mono_mix(ctx, oracle):
             assert np.max(np.abs(got[c] - ref.data[c])) <= 1e-13
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("ch,extra", [(2, 1), (3, 1), (3, 2)])
+def test_stream_pcm_data_ends_inside_a_frame(ctx, oracle, interp, ch, extra):
+    """stream.pcm on whole samples but not whole frames (aukit.lua:2367-2407; refused until round 6): with the mono mix-down every index is read for all
+    channels, so the partial frame counts for nothing — chunk for chunk the oracle's (which reads sample by sample like the Lua); without the
+    mix-down the reference's last chunk is longer in its first channels, which the ABI cannot say: refused by name"""
+    B, N = _B(), _N()
+    frames = 22050 * 2 + 777
+    x = np.stack([pcm16(frames, 22050, 1, 40 + c) for c in range(ch)], 1).astype("<i2").tobytes()
+    ragged = x + pcm16(extra, 22050, 1, 99).astype("<i2").tobytes()
+    bt = B.Batch.upload(ctx, [ragged, x])
+    desc = B.make_desc(N.CODEC_PCM, ch, 22050, 16, "signed")
+    out, ck = B.stream_decode(ctx, bt, desc, interp, mono=True, dtype=N.F64)
+    got = out.download()
+    for i, s in enumerate((ragged, x)):
+        ref = oracle.stream_pcm(s, 16, oracle.SIGNED, ch, 22050, False, True, oracle.INTERP[interp])
+        assert ck.nchunks[i] == ref.nchunks and list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
+        assert (ck.status[i] != 0) == (ref.final_status != 0), i
+        assert np.max(np.abs(got[i][0] - ref.data[0]), initial=0) <= 1e-13
+    with pytest.raises(N.AukitError, match="ends inside a frame"):
+        B.stream_decode(ctx, bt, desc, interp, mono=False, dtype=N.F64)
+    with pytest.raises(N.AukitError, match="ends inside a sample"):
+        B.stream_decode(ctx, B.Batch.upload(ctx, [x + b"\x01"]), desc, interp, mono=True, dtype=N.F64)
+
+
 def test_stream_pcm_f32_tolerance_and_float_input(ctx, oracle):
     B, N = _B(), _N()
     s = pcm16(44100 * 2, 44100, 1, 9).tobytes()
