@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libaukit_hip.so")
 if os.environ.get("AUKIT_LIB"):  # A/B of library builds on one box (tools/build_variant.sh): never set in tests or by the driver
     LIB_PATH = os.path.abspath(os.environ["AUKIT_LIB"])
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_f32.hip", "fast_stream_u8.hip", "fast_stream_dfpwm.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "fast_fmt.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "wave_coef_f64.hip", "container.hip", "stream_handle.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "msadpcm.hip", "qoa_stream.hip", "qoa.hip", "stream_tail.hip", "effects.hip", "flac.hip", "flac_fused.hip", "flac_stream.hip", "flac_pq.hip", "flac_tail.hip", "ops.hip", "dfpwm_par.hip", "dfpwm_spec.hip", "group.hip"]
-HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "fast_stream_body.h", "resample_dev.h", "dfpwm_dev.h", "dfpwm_par_dev.h", "stream_tail.h", "flac_dev.h", "flac_stream_dev.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
+SOURCES = ["runtime.hip", "resample.hip", "fast.hip", "fast2.hip", "fast_stream.hip", "fast_stream_f32.hip", "fast_stream_u8.hip", "fast_stream_dfpwm.hip", "fast_stream_s16x2.hip", "fast_coef.hip", "fast_s16x2.hip", "fast_fmt.hip", "floor_wave.hip", "exact_wave.hip", "wave_f64.hip", "wave_coef_f64.hip", "container.hip", "stream_handle.hip", "api_resample.hip", "codecs.hip", "codecs2.hip", "msadpcm.hip", "qoa_stream.hip", "qoa.hip", "stream_tail.hip", "effects.hip", "flac.hip", "flac_fused.hip", "flac_stream.hip", "flac_pq.hip", "flac_tail.hip", "rs_periodic.hip", "ops.hip", "dfpwm_par.hip", "dfpwm_spec.hip", "group.hip"]
+HEADERS = ["common.h", "resample.h", "fast_wave_dev.h", "fast_stream_body.h", "resample_dev.h", "dfpwm_dev.h", "dfpwm_par_dev.h", "stream_tail.h", "flac_dev.h", "flac_stream_dev.h", "rs_onepole_dev.h", os.path.join(_ROOT, "include", "aukit_hip.h")]
 
 OK, E_ARG, E_LUA, E_NOMEM, E_UNSUPPORTED, E_HIP = 0, -1, -2, -3, -4, -5
 F64, F32, I8 = 0, 1, 2

@@ -179,6 +179,7 @@ struct aukit_audio {
     bool lazy_scratch16 = false;                         // ... as int16 (LazyFrames::scratch16)
     aukit::DevBuf lazy_tab;
     uint64_t lazy_nfr = 0, lazy_tot = 0;
+    int lazy_min_bs = 0;                                 // the shortest full-size frame of any stream with more than one (k_rsp's window must fit two)
     size_t lazy_o_fbase = 0, lazy_o_bs0 = 0, lazy_o_rowoff = 0;
 };
 

@@ -1787,7 +1787,13 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     // stream order, for the first design's kernels.
     hipStream_t pre = ctx->stream;
     D.set = nullptr;
-    if (!getenv("AUKIT_FLAC_NO_LOOKAHEAD")) {
+    // ... where the call before leaves the chip room: measured on config 5 with k_rsp behind the decoder (profiles/r06_flac_lookahead.txt) the search beside the
+    // filter and normalize passes takes 0.13 - 0.25 ms off a step of 256 - 1024 ten-second streams and ADDS 0.22 ms to one of 2048 (what the search
+    // takes from the kernels it runs beside is more than its own 0.6 ms there).  AUKIT_FLAC_LOOKAHEAD=0 / 1 decides it by hand
+    bool ahead = in->total() < (2ull << 30);
+    if (const char *e = getenv("AUKIT_FLAC_LOOKAHEAD")) ahead = atoi(e) != 0;
+    if (getenv("AUKIT_FLAC_NO_LOOKAHEAD")) ahead = false;
+    if (ahead) {
         if ((rc = ctx_pre_stream(ctx, &pre))) return rc;
         if (in->ready) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, in->ready, 0));
         ctx->flac_par ^= 1;

@@ -16,6 +16,7 @@
 #include "resample.h"
 #include "flac_dev.h"
 #include "stream_tail.h"
+#include "rs_onepole_dev.h"
 
 namespace aukit {
 
@@ -24,66 +25,15 @@ int audio_from_int_rows(aukit_ctx *ctx, int src_kind, const void *rows_dev, cons
                         double norm_neg, aukit_audio **out);
 bool fast_eligible(int src_kind, int interp, double old_rate, double new_rate, FastParams &F);
 
-struct RsOnepoleParams {
-    const void *rows;                              // int32 (FLAC), int16 (IMA / MS-ADPCM / QOA) or int8 (DFPWM) rows: the template's S
-    const unsigned long long *row_off, *row_len;   // per (stream, channel): element offset / samples of the decoded row
-    const unsigned long long *a_meta;              // the audio's len[n], row_off[n], row_stride[n]
-    float *out;
-    unsigned long long *rowmax;
-    unsigned n;
-    int C, cap;
-    unsigned fa, fb, fmagic, dq256, dr256;
-    float inv_b, scale, scale_neg;                 // sample = (float)v * (v < 0 ? scale_neg : scale): the fast wave kernels' conversion (fast_wave_dev.h)
-    double coef;
-    const float *wg;   // cubic: the four tap weights of each of the fb output phases (null: the Horner form on fx = rem / fb)
-    // round 4: the rows frame by frame where the fused FLAC decoder left them (null: contiguous rows at row_off).  Every stream's frames but its
-    // last have bs0[stream] samples, and a tile's window is shorter than that: it lies in one frame or two consecutive ones
-    const FrameRec *frames;
-    const unsigned long long *fbase;
-    const int *bs0;
-    // round 4: a row is cut into `segs` runs of tiles, a wave each.  A run starts `warm` tiles early from a zero state and stores nothing there: the
-    // recurrence forgets its state at m per output (m^(512 warm) < 2^-40), so the run's own outputs are those of the whole row's chain to far
-    // below an f32 ulp — and a row is no longer ONE serial chain of 938 tiles on a chip that can run four times as many chains as config 5 has rows
-    int segs, warm;
-    int novec;   // AUKIT_RS_NOVEC=1: every window element by element (the first cut; A/B)
-    int fr_mul;  // frame-by-frame rows: a record's offset counts int32 slots — 2 when the frames hold int16 finals (k_flac_decode<..., O16>), else 1
-    // NW = 2 (round 4, late): a workgroup = the two channels of one stream, a wave each; what leaves is their MEAN (`Audio:mono` :682-687 behind
-    // the filter), `out` / `a_meta` describe the MONO audio, rowmax2[stream] receives the larger of the two channels' maxima (what a
-    // non-independent effects.normalize in between divides by, :3439-3444); wave_lds = floats of LDS per wave
-    unsigned long long *rowmax2;
-    int wave_lds;
-    // JOBS (round 4, last): a workgroup's work item is not a row of an audio but a JOB of stream.qoa's tail (stream_tail.h: one iterator call's chunk of one
-    // channel — or of all its channels, NW = 2, whose mean is stored): its own table (n samples at src_off, the history sample `last[2]` as table index 0,
-    // :3255), its own outputs, the low-pass seeded with the history sample (:3316), interpolated samples clamped to [clo, chi] (:3323)
-    const TailJob *jobs;
-    unsigned njobs;
-    int epi;   // 1: stream.flac's seed and store scaling (above)
-    float clo, chi;
-};
-
 // One WAVE per output row (4096 rows of config 5 = four waves per SIMD, all resident at once: no tail, no block barrier anywhere), tiles of 512
 // outputs, the tile's carry in registers.  (The first version — a 256-thread workgroup per row, tiles of 2048, five block barriers per tile —
 // ran at 7.3 ms on config 5 against 6.7 ms for the two kernels it replaces: a row is a serial chain of tiles, and what a tile costs is its
 // latency, not its work.)
-// A double moved between lanes by DPP (two v_mov_b32 with a DPP modifier: VALU latency) instead of ds_bpermute (two LDS round trips): lanes without a
-// source lane — and rows outside ROW_MASK — get 0.  CTRL: row_shr:n = 0x110 + n, row_bcast15 = 0x142, row_bcast31 = 0x143, wave_shr:1 = 0x138.
-template <int CTRL, int ROW_MASK = 0xF>
-AUKIT_DEV double dpp_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
 // TAB: the cubic as w0 p0 + w1 p1 + w2 p2 + w3 p3 with the weights of the output's phase from an LDS table (fb <= 512 phases; one multiply and
 // three FMAs per output instead of the twelve operations of the coefficient + Horner form: the kernel is bound by its instruction count)
 #ifndef AUKIT_RS_WAVES
 #define AUKIT_RS_WAVES 4
 #endif
-template <int CTRL, int ROW_MASK = 0xF> AUKIT_DEV double dpp_rt(double v) { return dpp_f64<CTRL, ROW_MASK>(v); }
-template <int CTRL, int ROW_MASK = 0xF> AUKIT_DEV float dpp_rt(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true)); }
-typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
 // R32 (round 4, last): the recurrence and its scan in f32 — for slopes m <= 1/2 only (a low-pass well above the band: stream.qoa's and stream.flac's,
 // effects.lowpass at a quarter of the rate), where a step's rounding (2^-24 of the state) is worth at most twice itself in the end: ~1e-7 of the
 // scale, inside the f32 stages' 1e-6.  Saves the two conversions per output and half of the scan's moves in a kernel bound by its instruction count.
@@ -624,6 +574,8 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
         if ((*rc = h2d_table(ctx, T + o_fb + (size_t)n * 8, &nfr, 8))) return true;          // fbase[n] = the number of records
         if ((*rc = h2d_table(ctx, T + o_bs, LF->bs0->data(), (size_t)n * 4))) return true;
         a->lazy_nfr = LF->nfr; a->lazy_tot = LF->tot_elems;
+        a->lazy_min_bs = 0x7FFFFFFF;
+        for (uint32_t s = 0; s < n; s++) if ((*LF->nframes)[s] > 1) a->lazy_min_bs = std::min(a->lazy_min_bs, (*LF->bs0)[s]);   // (k_rsp's window is wider than k_rs_onepole's)
         a->lazy_o_fbase = o_fb; a->lazy_o_bs0 = o_bs; a->lazy_o_rowoff = o_ro;
         a->lazy_indirect = true;
         a->lazy_rows = ctx->tmp_buf3;
@@ -736,7 +688,13 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
         else if (tabw) { if (highpass) AUKIT_RSO1(AUKIT_INTERP_CUBIC, true, true, S); else AUKIT_RSO1(AUKIT_INTERP_CUBIC, false, true, S); }              \
         else { if (highpass) AUKIT_RSO1(AUKIT_INTERP_CUBIC, true, false, S); else AUKIT_RSO1(AUKIT_INTERP_CUBIC, false, false, S); }                      \
     } while (0)
-    if (a->lazy_src == SRC_I16) AUKIT_RSO(short); else if (a->lazy_src == SRC_I8) AUKIT_RSO(signed char); else AUKIT_RSO(int);
+    // int16 rows at a ratio whose phases repeat every 320 outputs (44.1 / 22.05 kHz -> 48 kHz): k_rsp (rs_periodic.hip), weights and tap offsets in registers
+    uint64_t min_out = ~0ull;
+    for (uint64_t l : a->len) min_out = std::min<uint64_t>(min_out, l);
+    bool periodic = false;
+    if (a->lazy_src == SRC_I16 && tabw) { periodic = rsp_try(ctx, P, highpass, r32, NWh, rows, min_out, a->lazy_indirect ? a->lazy_min_bs : 0, rc); if (periodic && *rc) return true; }
+    if (periodic) {}
+    else if (a->lazy_src == SRC_I16) AUKIT_RSO(short); else if (a->lazy_src == SRC_I8) AUKIT_RSO(signed char); else AUKIT_RSO(int);
 #undef AUKIT_RSO1
 #undef AUKIT_RSO
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
@@ -746,13 +704,13 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
     const uint64_t in_bytes = in_elems * (a->lazy_src == SRC_I16 ? 2 : (a->lazy_src == SRC_I8 ? 1 : 4));
     if (mono_out) {   // `a` keeps everything it owes (its own rows were not written); the mean's maxima are not known (rowmax2 holds the channels')
         mono_out->rowmax_valid = false;
-        *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass,mono>" : "k_rs_onepole<lowpass,mono>", in_bytes + out_elems * 4 / (uint64_t)a->channels);
+        *rc = ctx_end_kernel(ctx, periodic ? (highpass ? "k_rsp<highpass,mono>" : "k_rsp<lowpass,mono>") : (highpass ? "k_rs_onepole<highpass,mono>" : "k_rs_onepole<lowpass,mono>"), in_bytes + out_elems * 4 / (uint64_t)a->channels);
         return true;
     }
     a->rowmax_valid = true;
     a->lazy_fx = 0;
     lazy_drop(ctx, a);   // the resample is paid; the rows' buffer goes back to the context
-    *rc = ctx_end_kernel(ctx, highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>", in_bytes + out_elems * 4);
+    *rc = ctx_end_kernel(ctx, periodic ? (highpass ? "k_rsp<highpass>" : "k_rsp<lowpass>") : (highpass ? "k_rs_onepole<highpass>" : "k_rs_onepole<lowpass>"), in_bytes + out_elems * 4);
     return true;
 }
 

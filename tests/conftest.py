@@ -29,3 +29,12 @@ def ctx():
     c = B.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=["default", "generic"])
+def rs_kernel(request, monkeypatch):
+    """the tile-chain kernel behind `resample owed -> effects.lowpass / highpass`: k_rsp (rs_periodic.hip) where the rate and the rows allow it — int16 rows,
+    cubic, 44.1 / 22.05 kHz -> 48 kHz — else k_rs_onepole (flac_tail.hip); "generic" switches k_rsp off so that k_rs_onepole keeps its tests at those rates"""
+    if request.param == "generic":
+        monkeypatch.setenv("AUKIT_RS_GENERIC", "1")
+    return request.param

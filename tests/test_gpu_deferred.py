@@ -5,7 +5,7 @@ deferred normalize (:3431-3459).  Every consumer of an audio's device rows must 
 import numpy as np
 import pytest
 
-from util import pcm16, rms
+from util import pcm16, rms, tail_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def _loader(oracle, kind, i, n):
 
 @pytest.mark.parametrize("kind", ["ima", "msadpcm", "qoa", "dfpwm"])
 @pytest.mark.parametrize("interp", ["cubic", "linear"])
-def test_resample_of_int_row_loaders_is_deferred_into_the_filter(ctx, oracle, monkeypatch, kind, interp):
+def test_resample_of_int_row_loaders_is_deferred_into_the_filter(ctx, oracle, monkeypatch, rs_kernel, kind, interp):
     """BASELINE config 3 as written (aukit.wav -> resample(48000, cubic) -> effects.lowpass) and its siblings: the loader's int16 / int8 rows
     stay as they are, the resample is owed, the one-pole filter pays it in ONE launch (k_rs_onepole); any other consumer materialises it."""
     B, N = _B(), _N()
@@ -72,7 +72,7 @@ def test_resample_of_int_row_loaders_is_deferred_into_the_filter(ctx, oracle, mo
             assert np.array_equal(got[s][c], plain[s][c]), (s, c)   # materialised by the same kernel the undeferred call runs
     for which in ("lowpass", "highpass"):
         rows, (n0, n1) = chain(which)
-        assert n0 == "(resample deferred)" and n1 == "k_rs_onepole<" + which + ">", (n0, n1)
+        assert n0 == "(resample deferred)" and n1 == tail_kernel(which, rs_kernel, interp == "cubic" and kind != "dfpwm"), (n0, n1)   # (int16 rows at 22.05 / 44.1 kHz; DFPWM: int8 at 32 kHz)
         for s_i, s in enumerate(streams):
             ref = oracle.resample(load(s), 48000, oracle.INTERP[interp])
             ref = oracle.fx_lowpass(ref, 11025.0) if which == "lowpass" else oracle.fx_highpass(ref, 20.0)

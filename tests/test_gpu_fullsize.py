@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import pcm16, rms, signal
+from tests.util import pcm16, rms, signal, tail_kernel
 
 pytestmark = pytest.mark.gpu
 SCALE = float(os.environ.get("AUKIT_FULLSIZE_SCALE", "1.0"))
@@ -124,7 +124,7 @@ def test_config_3_full_batch(ctx, oracle):
 
 
 @pytest.mark.parametrize("max_index", [15, 88])
-def test_config_3b_full_batch(ctx, oracle, max_index):
+def test_config_3b_full_batch(ctx, oracle, rs_kernel, max_index):
     """BASELINE config 3 as it is worded — 4096 x 220 IMA blocks in WAV -> aukit.wav -> :resample(48000, "cubic") -> effects.lowpass(a, 11025)
     (aukit.lua:1509-1548, :653-675, :3586-3598) — at full size: the loader's int16 rows with the resample owed, paid inside the filter's one launch
     (k_rs_onepole, whose recurrence and scan run in f32 at this slope since round 4's last commit).  8 classes of identical rows, every class
@@ -137,7 +137,7 @@ def test_config_3b_full_batch(ctx, oracle, max_index):
     a = B.decode_resample(ctx, bt, B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), 48000, "cubic", dtype=N.F32)
     assert ctx.last_kernel()[0] == "(resample deferred)"
     B.effect(ctx, a, "lowpass", 11025.0)
-    assert ctx.last_kernel()[0] == "k_rs_onepole<lowpass>" and ctx.counter(N.COUNTER_RECURRENCE_F32) == 1
+    assert ctx.last_kernel()[0] == tail_kernel("lowpass", rs_kernel, True) and ctx.counter(N.COUNTER_RECURRENCE_F32) == 1
     rows = _row_classes(a, n, 486574, K)   # floor(223520 * 48000 / 22050)
     for c in range(K):
         ref = oracle.fx_lowpass(oracle.resample(oracle.wav_adpcm(base[c], 512, 1, 22050), 48000, oracle.CUBIC), 11025.0).data[0]

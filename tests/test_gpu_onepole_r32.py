@@ -6,7 +6,7 @@ Asserted: which arithmetic ran (AUKIT_COUNTER_RECURRENCE_F32), the RMS bar of SU
 import numpy as np
 import pytest
 
-from util import pcm16, rms
+from util import pcm16, rms, tail_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +29,7 @@ EDGE = 48000 * np.log(2) / (2 * np.pi)   # the cut-off at which the slope exp(-2
 
 
 @pytest.mark.parametrize("freq,f32", [(EDGE + 0.5, True), (EDGE - 0.5, False), (11025.0, True), (20000.0, True), (23999.0, True), (3000.0, False)])
-def test_r32_recurrence_directed(ctx, oracle, freq, f32):
+def test_r32_recurrence_directed(ctx, oracle, rs_kernel, freq, f32):
     N, B = _mods()
     streams = [oracle.gen_ima(r, 1, 512, 88) for r in _rows(1016 * 40)]
     bt = B.Batch.upload(ctx, streams)
@@ -38,7 +38,7 @@ def test_r32_recurrence_directed(ctx, oracle, freq, f32):
         a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
         assert ctx.last_kernel()[0] == "(resample deferred)"
         B.effect(ctx, a, "lowpass", float(freq))
-        assert ctx.last_kernel()[0] == "k_rs_onepole<lowpass>"
+        assert ctx.last_kernel()[0] == tail_kernel("lowpass", rs_kernel, interp == "cubic")
         assert ctx.counter(N.COUNTER_RECURRENCE_F32) == (1 if f32 else 0), freq
         got = a.download()
         for i, s in enumerate(streams):
@@ -50,7 +50,7 @@ def test_r32_recurrence_directed(ctx, oracle, freq, f32):
             assert rms(got[i][0], ref) <= 1e-6 and np.max(np.abs(err)) <= 6e-7, (freq, interp, i, rms(got[i][0], ref), np.max(np.abs(err)))
 
 
-def test_r32_recurrence_thirty_minute_row(ctx, oracle):
+def test_r32_recurrence_thirty_minute_row(ctx, oracle, rs_kernel):
     """one row of 30 minutes (86.4 M outputs, 84 375 tiles chained through the carried state): the error at the end of the row is what it is at its
     start — the recurrence forgets (slope <= 1/2), nothing piles up along the chain"""
     N, B = _mods()
@@ -61,7 +61,7 @@ def test_r32_recurrence_thirty_minute_row(ctx, oracle):
     s = oracle.gen_ima(x, 1, 512, 88)
     a = B.decode_resample(ctx, B.Batch.upload(ctx, [s]), B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512), 48000, "cubic", dtype=N.F32)
     B.effect(ctx, a, "lowpass", 11025.0)
-    assert ctx.last_kernel()[0] == "k_rs_onepole<lowpass>" and ctx.counter(N.COUNTER_RECURRENCE_F32) == 1
+    assert ctx.last_kernel()[0] == tail_kernel("lowpass", rs_kernel, True) and ctx.counter(N.COUNTER_RECURRENCE_F32) == 1
     got = a.download()[0][0]
     ref = oracle.fx_lowpass(oracle.resample(oracle.wav_adpcm(s, 512, 1, 22050), 48000, oracle.CUBIC), 11025.0).data[0]
     assert len(got) == len(ref) == int(n * 48000 // 22050)

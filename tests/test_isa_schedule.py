@@ -76,6 +76,15 @@ def test_rs_onepole_keeps_its_prefetch_registers():
 
 
 @pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
+def test_rsp_keeps_its_prefetch_registers():
+    """rs_periodic.hip: k_rsp requests the next tile's window the same way (two dwordx4 per lane), twelve instantiations."""
+    asm = isa_check.compile_asm(os.path.join(ROOT, "aukit_amd", "csrc", "rs_periodic.hip"))
+    v, n = isa_check.check_vm_cfg(asm)
+    assert n >= 48, f"only {n} hand-issued loads found"
+    assert not v, "\n".join(f"{k[:70]} line {ln}: `{s}` touches in-flight v{r}" for k, ln, s, r in v[:10])
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
 @pytest.mark.parametrize("src,at_least", [("wave_f64.hip", 1000), ("dfpwm_par.hip", 16), ("wave_coef_f64.hip", 32), ("flac_fused.hip", 8)])
 def test_hand_scheduled_kernels_keep_their_registers(src, at_least):
     asm = isa_check.compile_asm(os.path.join(ROOT, "aukit_amd", "csrc", src))

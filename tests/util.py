@@ -22,3 +22,9 @@ def rms(a, b):
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.sqrt(np.mean((a - b) ** 2))) if a.size else 0.0
+
+
+def tail_kernel(which, rs_kernel, periodic_shape, mono=False):
+    """the name `effects.<which>` leaves in ctx.last_kernel() when it pays an owed resample in its own pass (conftest.rs_kernel)"""
+    k = "k_rsp" if (rs_kernel == "default" and periodic_shape) else "k_rs_onepole"
+    return k + "<" + which + (",mono" if mono else "") + ">"
