@@ -703,6 +703,9 @@ __global__ __launch_bounds__(64) void k_dfx_verify(const DfxParams X) {
     dfx_load6(X.st + ((size_t)c * 12 + 6) * X.npad + s, X.npad, truth);  // chunk c ran from the true state
     unsigned chunks = 1;
     for (c++; c < P.nchunk; c++) {
+        // (the probe's verdict may arrive while this lane walks its stream: a batch of a few hundred streams is through its chunk pass in 0.1 ms, the
+        // probe runs 0.25 ms beside it — a declined batch then paid this walk in full, 0.5 ms of the 1.5 ms a declined call cost: profiles/r06_dfx_grid.txt)
+        if ((c & 7u) == 0u && __hip_atomic_load(&X.flags[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         const int *st = X.st + (size_t)c * 12 * X.npad + s;
         int v[6];
         dfx_load6(st, X.npad, v);

@@ -305,6 +305,34 @@ def test_ima_wav_mono_masks_header_index_and_partial_block(ctx, oracle):
     assert np.array_equal(got[1][0], oracle.wav_adpcm(s2, 512, 1, 22050).data[0])
 
 
+@pytest.mark.parametrize("ba", [8, 12, 36, 260, 512, 516, 1028])
+def test_ima_wav_a_lane_per_block(ctx, oracle, monkeypatch, ba):
+    """k_ima_lanes (codecs.hip, round 6): one-channel aukit.wav blocks (aukit.lua:1509-1548) decoded a lane each.  150 streams of 1 .. 5 blocks (a wave of
+    64 blocks spans dozens of streams; rows start at every multiple of 16 bytes within a line), short last blocks of every length (a part word of 1 .. 3
+    bytes, :1545 `str_sub` is simply shorter), against the oracle and against the wave-per-block kernel it replaces (AUKIT_IMA_ROWS_WAVE=1)."""
+    B, N = _B(), _N()
+    spb = (ba - 4) * 2
+    rng = np.random.Generator(np.random.PCG64(100 + ba))
+    streams = []
+    for i in range(150):
+        nb = 1 + i % 5
+        s = oracle.gen_ima(pcm16(spb * nb, 22050, 3, i), 1, ba, 88)[:ba * nb]
+        cut = int(rng.integers(0, ba - 3)) if i % 3 else 0      # (what is left of the last block: at least its 3 header bytes + ... the loader wants > 2)
+        if cut and len(s) - cut > 3 and (len(s) - cut) % ba >= 3:
+            s = s[:len(s) - cut]
+        streams.append(s)
+    bt = B.Batch.upload(ctx, streams)
+    desc = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=ba)
+    got = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    monkeypatch.setenv("AUKIT_IMA_ROWS_WAVE", "1")
+    old = B.decode(ctx, bt, desc, dtype=N.F64).download()
+    monkeypatch.delenv("AUKIT_IMA_ROWS_WAVE")
+    for i, s in enumerate(streams):
+        ref = oracle.wav_adpcm(s, ba, 1, 22050).data[0]
+        assert np.array_equal(got[i][0], ref), (i, len(s))
+        assert np.array_equal(old[i][0], ref), (i, len(s))
+
+
 @pytest.mark.parametrize("ch,interleaved,top_first", [(1, True, True), (1, True, False), (2, True, True), (2, False, False), (3, True, True)])
 def test_ima_raw_adpcm(ctx, oracle, ch, interleaved, top_first):
     B, N = _B(), _N()
