@@ -783,11 +783,14 @@ static bool rs_onepole_jobs_launch(aukit_ctx *ctx, const void *rows, bool rows_i
         else if (tabw) AUKIT_RSJ(AUKIT_INTERP_CUBIC, true, S);                                                                                        \
         else AUKIT_RSJ(AUKIT_INTERP_CUBIC, false, S);                                                                                                 \
     } while (0)
-    if (rows_i32) AUKIT_RSJS(int); else AUKIT_RSJS(signed char);
+    bool periodic = false;
+    if (!rows_i32 && tabw && (long_jobs || NWh > 1)) { periodic = rsp_jobs_try(ctx, P, r32, NWh, grid.x, rc); if (periodic && *rc) return true; }   // (rs_periodic.hip)
+    if (periodic) {}
+    else if (rows_i32) AUKIT_RSJS(int); else AUKIT_RSJS(signed char);
 #undef AUKIT_RSJS
 #undef AUKIT_RSJ
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole<jobs> launch failed"); return true; }
-    *rc = ctx_end_kernel(ctx, name, algorithmic_bytes);
+    *rc = ctx_end_kernel(ctx, periodic ? (std::string(name) == "k_rs_onepole<qoa>" ? "k_rsp<qoa>" : "k_rsp<jobs>") : name, algorithmic_bytes);
     return true;
 }
 

@@ -63,5 +63,6 @@ typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
 // rs_periodic.hip: the same pass for S = int16 rows, cubic, a ratio a / b < 1 with 320 a = 0 (mod b) whose tap pattern is one of the built ones.
 // false: not this shape (the caller launches k_rs_onepole).  `P` as lazy_onepole_try fills it (cap, wave_lds, segs, warm are set here)
 bool rsp_try(aukit_ctx *ctx, RsOnepoleParams &P, bool highpass, bool r32, int NW, size_t rows, uint64_t min_out_len, int min_frame, int *rc);
+bool rsp_jobs_try(aukit_ctx *ctx, const RsOnepoleParams &P, bool r32, int NW, unsigned grid, int *rc);   // stream.qoa's tail (long jobs of int8 rows at 44.1 kHz)
 
 }  // namespace aukit

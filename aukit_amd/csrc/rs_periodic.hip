@@ -43,10 +43,12 @@ template <int PAT> AUKIT_DEV constexpr int rsp_dm(int i) {
 }
 template <int PAT> constexpr int rsp_nt() { return PAT == 1 ? 8 : 6; }
 
-template <bool HP, bool R32, int NW, int PAT>
+// S: int16 rows (the loaders' audios), or int8 (JOBS: stream.qoa's decoded chunks).  JOBS: a workgroup's item is a job of stream.qoa's tail (stream_tail.h,
+// aukit.lua:3312-3330: interpolate -> clamp -> low-pass seeded with the history sample -> chunk sample) instead of a row of an audio — its own table behind
+// the history sample (table index 0), its own outputs, no row maxima: k_rs_onepole<..., JOBS>'s contract.
+template <bool HP, bool R32, int NW, int PAT, typename S = short, bool JOBS = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
     using RT = std::conditional_t<R32, float, double>;
-    using S = short;
     extern __shared__ __attribute__((aligned(16))) float rsm_all[];
     constexpr int E = 5, T = 64 * E, NSUB = PAT == 1 ? 2 : 4, TT = NSUB * T, NT = rsp_nt<PAT>();   // NSUB sub-tiles from one window of about 590 source samples
     const unsigned wv = NW > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;   // the wave = the channel
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
     float *const ob = rsm_all + NW * P.wave_lds;             // [sub-tile parity][wave][T]: the results on their way out
     const int lane = (int)(threadIdx.x & 63u);
     const S *const rows_s = reinterpret_cast<const S *>(P.rows);
-    constexpr int EPV = 16, VB = EPV * (int)sizeof(S);       // a lane's vector: 16 elements = 32 bytes, aligned to that
+    constexpr int EPV = 16, VB = EPV * (int)sizeof(S);       // a lane's vector: 16 elements = 32 (int16) or 16 (int8) bytes, aligned to that
     struct VT { u32x4g lo, hi; };
     // ---- the recurrence's constants: as k_rs_onepole's (slope m, its powers in scalar registers, the scan's factors)
     const double m = HP ? P.coef : 1.0 - P.coef;
@@ -105,15 +107,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
     const int e0 = lane * E;
     // ---- this workgroup's row(s) and run of tiles
     const unsigned item = blockIdx.x;
-    const unsigned r = NW > 1 ? (item / (unsigned)P.segs) * (unsigned)NW + wv : item / (unsigned)P.segs;
-    const unsigned seg = item % (unsigned)P.segs, s = r / (unsigned)P.C, c = r - s * (unsigned)P.C;
-    const unsigned long long nout = P.a_meta[s], obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
-    const int L = (int)P.row_len[r];
-    const S *const row = rows_s + P.row_off[r];
+    unsigned r = 0, seg = 0, s = 0, c = 0;
+    unsigned long long nout = 0, obase = 0;
+    int L = 0, hist = 0;
+    const S *row = rows_s;
+    if constexpr (JOBS) {
+        const TailJob jb = P.jobs[item];
+        c = wv;
+        nout = (unsigned long long)jb.nout; obase = jb.out_off; L = jb.n;
+        row = rows_s + jb.src_off + (unsigned long long)c * jb.src_cstride;
+        if (jb.last_off != ~0ull) hist = (int)rows_s[jb.last_off + (unsigned long long)c * jb.last_cstride];
+    } else {
+        r = NW > 1 ? (item / (unsigned)P.segs) * (unsigned)NW + wv : item / (unsigned)P.segs;
+        seg = item % (unsigned)P.segs; s = r / (unsigned)P.C; c = r - s * (unsigned)P.C;
+        nout = P.a_meta[s]; obase = P.a_meta[P.n + s] + (NW > 1 ? 0ull : (unsigned long long)c * P.a_meta[2 * (size_t)P.n + s]);
+        L = (int)P.row_len[r];
+        row = rows_s + P.row_off[r];
+    }
     float *const orow = P.out + obase;
     float mxf = 0.f;
     RT carry_y = 0;
     float carry_x = 0.f;
+    if constexpr (JOBS) carry_y = (RT)(double)((float)hist * (hist < 0 ? P.scale_neg : P.scale));   // ls = last[2]  (:3316)
     // frame-by-frame rows: as k_rs_onepole (flac_tail.hip)
     const int bsn = P.frames ? P.bs0[s] : 0;
     const unsigned nfr_s = P.frames ? (unsigned)(P.fbase[s + 1] - P.fbase[s]) : 0u;
@@ -171,16 +186,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
         {   // the request: in no arm of a fork, into the registers the value keeps (flac_tail.hip has the story)
             unsigned long long save;
             const unsigned on = (unsigned)vd.on;
-            asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %2, vcc\n\tglobal_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\ts_mov_b64 exec, %2"
-                         : "+v"(pva.lo), "+v"(pva.hi), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
+            if constexpr (sizeof(S) == 2)
+                asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %2, vcc\n\tglobal_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\ts_mov_b64 exec, %2"
+                             : "+v"(pva.lo), "+v"(pva.hi), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
+            else
+                asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\ts_and_saveexec_b64 %1, vcc\n\tglobal_load_dwordx4 %0, %3, off\n\ts_mov_b64 exec, %1"
+                             : "+v"(pva.lo), "=&s"(save) : "v"(on), "v"(va) : "vcc", "memory");
         }
     };
     VT pva{};
     auto landed = [](VT &v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v.lo), "+v"(v.hi) : : "memory"); };
     VecDesc vcur{0, 0, 0, 0, 0, 0}, vnxt{0, 0, 0, 0, 0, 0};
+    const unsigned nsegs = JOBS ? 1u : (unsigned)P.segs;
     const unsigned long long ntiles = (nout + TT - 1) / TT;
-    const unsigned long long t_lo = ntiles * seg / (unsigned)P.segs, t_hi = ntiles * (seg + 1u) / (unsigned)P.segs;
-    const unsigned long long t_in = t_lo > (unsigned long long)P.warm ? t_lo - (unsigned long long)P.warm : 0ull;
+    const unsigned long long t_lo = ntiles * seg / nsegs, t_hi = ntiles * (seg + 1u) / nsegs;
+    const unsigned long long t_in = (!JOBS && t_lo > (unsigned long long)P.warm) ? t_lo - (unsigned long long)P.warm : 0ull;
     const unsigned long long o_lo = t_lo * TT, o_end = t_hi * TT < nout ? t_hi * TT : nout;
     unsigned kb = (unsigned)(t_in * ((unsigned long long)NSUB * half_adv));   // the tile's first table index (its first output sits on phase 0)
     {
@@ -251,10 +271,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
         auto cvt_s = [&](int va, int vb, float &a, float &b) { const f32x2 f = (f32x2){(float)va, (float)vb} * (f32x2){P.scale, P.scale}; a = f.x; b = f.y; };
         auto stage = [&](auto cvt) {
             if (vcur.on) {   // (wave-uniform)
-                auto s16 = [&](unsigned w, float &a, float &b) { cvt((int)(short)(w & 0xFFFFu), (int)w >> 16, a, b); };
                 float4 f0, f1, f2, f3;
-                s16(pva.lo.x, f0.x, f0.y); s16(pva.lo.y, f0.z, f0.w); s16(pva.lo.z, f1.x, f1.y); s16(pva.lo.w, f1.z, f1.w);
-                s16(pva.hi.x, f2.x, f2.y); s16(pva.hi.y, f2.z, f2.w); s16(pva.hi.z, f3.x, f3.y); s16(pva.hi.w, f3.z, f3.w);
+                if constexpr (sizeof(S) == 2) {
+                    auto s16 = [&](unsigned w, float &a, float &b) { cvt((int)(short)(w & 0xFFFFu), (int)w >> 16, a, b); };
+                    s16(pva.lo.x, f0.x, f0.y); s16(pva.lo.y, f0.z, f0.w); s16(pva.lo.z, f1.x, f1.y); s16(pva.lo.w, f1.z, f1.w);
+                    s16(pva.hi.x, f2.x, f2.y); s16(pva.hi.y, f2.z, f2.w); s16(pva.hi.z, f3.x, f3.y); s16(pva.hi.w, f3.z, f3.w);
+                } else {
+                    auto s8 = [&](unsigned w, float4 &f) {
+                        cvt((int)(signed char)(w & 0xFFu), (int)(signed char)((w >> 8) & 0xFFu), f.x, f.y);
+                        cvt((int)(signed char)((w >> 16) & 0xFFu), (int)w >> 24, f.z, f.w);
+                    };
+                    s8(pva.lo.x, f0); s8(pva.lo.y, f1); s8(pva.lo.z, f2); s8(pva.lo.w, f3);
+                }
                 if (lane < vcur.nvA) {
                     float4 *const d = reinterpret_cast<float4 *>(win + EPV * lane);
                     d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
@@ -276,12 +304,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
                     const int kc = k < 1u ? 1 : (k > (unsigned)L ? L : (int)k);   // the nil fall-backs of interpolate.cubic (:264): the edge samples repeated
                     const S *src = P.frames ? rows_s + ((kc - 1 < bound ? base0 : base1) + (long long)(kc - 1)) : row + (kc - 1);
                     float fa, fb2;
-                    cvt(L > 0 ? (int)*src : 0, 0, fa, fb2);
+                    cvt(L > 0 ? ((JOBS && k == 0u) ? hist : (int)*src) : 0, 0, fa, fb2);   // (JOBS: table index 0 is the history sample, not the edge)
                     win[j] = fa;
                 }
             }
         };
-        if (sym) stage(cvt_s); else stage(cvt_a);
+        auto cvt_u = [&](int va, int vb, float &a, float &b) { a = (float)va; b = (float)vb; };   // (stream.qoa's int8 rows: the samples as they are)
+        if (P.scale == 1.0f && P.scale_neg == 1.0f) stage(cvt_u); else if (sym) stage(cvt_s); else stage(cvt_a);
         if (pend_c1) drain(1);   // (wave- and workgroup-uniform) the last sub-tile of the tile before
         const unsigned kb_n = kb + (unsigned)NSUB * half_adv;
         if (o0 + TT < o_end) {
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
                 acc = fmaf(W[i][2], t[d + 2], acc);
                 acc = fmaf(W[i][3], t[d + 3], acc);
                 if (i > 0) acc = fmaf(W[i][4], t[d + 4], acc);   // (the lane's first output starts its taps: never shifted)
-                v[i] = __builtin_amdgcn_fmed3f(acc, -1.0f, 1.0f);   // :667-668
+                v[i] = JOBS ? __builtin_amdgcn_fmed3f(acc, P.clo, P.chi) : __builtin_amdgcn_fmed3f(acc, -1.0f, 1.0f);   // :667-668; JOBS: :3323
             }
             // x[n - 1] of the lane's first output: the lane before's last, the sub-tile before's for lane 0
             float xprev = 0.f;
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
             RT z[E];
             {
                 RT xp = (RT)xprev;
-                const bool first = o0 == 0 && h == 0 && lane == 0;
+                const bool first = !JOBS && o0 == 0 && h == 0 && lane == 0;
                 RT y = 0;
 #pragma unroll
                 for (int i = 0; i < E; i++) {
@@ -389,9 +418,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_rsp(const RsOnepoleParams P) {
     }
     if (pend_c0) drain(0);
     if (pend_c1) drain(1);
-    for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
-    if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));
-    if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }
+    if constexpr (!JOBS) {
+        for (int o = 32; o; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o));
+        if (lane == 0) atomicMax(&P.rowmax[r], (unsigned long long)__double_as_longlong((double)mxf));
+        if constexpr (NW > 1) { if (lane == 0) atomicMax(&P.rowmax2[s], (unsigned long long)__double_as_longlong((double)mxf)); }
+    }
 }
 
 // the host's side: which ratios, how much LDS, how many runs per row
@@ -437,6 +468,28 @@ bool rsp_try(aukit_ctx *ctx, RsOnepoleParams &P, bool highpass, bool r32, int NW
     else { if (highpass) AUKIT_RSP(true, false, 1); else if (r32) AUKIT_RSP(false, true, 1); else AUKIT_RSP(false, false, 1); }
 #undef AUKIT_RSP
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rsp launch failed"); return true; }
+    return true;
+}
+
+// stream.qoa's tail on k_rsp: long jobs of int8 rows, a low-pass (rs_onepole_jobs_launch, flac_tail.hip, fills P and the grid).  false: not this shape
+bool rsp_jobs_try(aukit_ctx *ctx, const RsOnepoleParams &P, bool r32, int NW, unsigned grid, int *rc) {
+    *rc = AUKIT_OK;
+    constexpr int E = 5, T = 64 * E;
+    if (getenv("AUKIT_RS_GENERIC") || !P.wg || P.epi || P.fa >= P.fb || ((unsigned long long)T * P.fa) % P.fb) return false;
+    int dm[E];
+    for (int i = 0; i < E; i++) dm[i] = (int)(((unsigned long long)i * P.fa) / P.fb);
+    if (!(dm[1] == 0 && dm[2] == 1 && dm[3] == 2 && dm[4] == 3)) return false;   // (44.1 kHz: the one pattern built for jobs)
+    const int TT = 2 * T;
+    const unsigned adv = (unsigned)(((unsigned long long)TT * P.fa) / P.fb);
+    if (((double)P.fb + (double)TT * (double)P.fa) * (double)P.fb >= 4294967296.0) return false;
+    RsOnepoleParams Q = P;
+    Q.cap = (((int)adv + 24 + 3) & ~3) + 32;
+    Q.wave_lds = Q.cap;
+    Q.segs = 1; Q.warm = 0; Q.frames = nullptr;
+    const size_t lds = ((size_t)NW * Q.wave_lds + 2 * (size_t)NW * T) * 4;
+    if (NW == 2) { if (r32) hipLaunchKernelGGL((k_rsp<false, true, 2, 1, signed char, true>), dim3(grid), dim3(128), lds, ctx->stream, Q); else hipLaunchKernelGGL((k_rsp<false, false, 2, 1, signed char, true>), dim3(grid), dim3(128), lds, ctx->stream, Q); }
+    else { if (r32) hipLaunchKernelGGL((k_rsp<false, true, 1, 1, signed char, true>), dim3(grid), dim3(64), lds, ctx->stream, Q); else hipLaunchKernelGGL((k_rsp<false, false, 1, 1, signed char, true>), dim3(grid), dim3(64), lds, ctx->stream, Q); }
+    if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rsp<jobs> launch failed"); return true; }
     return true;
 }
 

@@ -502,7 +502,7 @@ def test_stream_qoa(ctx, oracle, ch, mono, interp):
 
 @pytest.mark.parametrize("rate", [44100, 22050, 8000, 48000, 32000])
 @pytest.mark.parametrize("ch,mono", [(1, False), (2, False), (2, True)])
-def test_stream_qoa_f32_tail(ctx, oracle, monkeypatch, ch, mono, rate):
+def test_stream_qoa_f32_tail(ctx, oracle, monkeypatch, rs_kernel, ch, mono, rate):
     """F32 storage: stream.qoa's tail (interpolation, clamp, recursive low-pass, channel mean) runs in ONE launch from the int8 rows with the
     interpolation in f32 (k_iir_tail_fast, stream_tail.hip).  Tolerance path: 1e-6 RMS of the [-128, 127] scale, and no single
     sample off by more than 1e-4 of it; the chunk plan is the exact path's."""
@@ -512,7 +512,11 @@ def test_stream_qoa_f32_tail(ctx, oracle, monkeypatch, ch, mono, rate):
     for interp in ("none", "linear", "cubic"):
         out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), interp, mono=mono, dtype=N.F32)
         # linear / cubic: the tile chain of k_rs_onepole (state carried from tile to tile: round 4); "none": the warm-up tiles of k_iir_tail_fast
-        assert ctx.last_kernel()[0] == ("k_iir_tail<qoa>" if interp == "none" else "k_rs_onepole<qoa>"), ctx.last_kernel()
+        # (round 6: at 44.1 kHz, cubic, the same chain with weights and tap offsets in registers — k_rsp<..., JOBS>, rs_periodic.hip — for long jobs and for the channels' mean)
+        name = ctx.last_kernel()[0]
+        assert name in (("k_iir_tail<qoa>",) if interp == "none" else ("k_rs_onepole<qoa>", "k_rsp<qoa>")), ctx.last_kernel()
+        if interp != "none":
+            assert (name == "k_rsp<qoa>") == (rs_kernel == "default" and interp == "cubic" and rate == 44100 and (ch == 2 and mono or name == "k_rsp<qoa>")), (name, rs_kernel)
         got = out.download()
         if interp != "none":
             monkeypatch.setenv("AUKIT_NO_RS_JOBS", "1")
