@@ -917,3 +917,73 @@ def test_fuzz_dfpwm_speculation(ctx, oracle, seed, monkeypatch):
     got = B.dfpwm_transcode_mono(ctx, B.Batch.upload(ctx, st), 2).download()
     for s in range(nstreams):
         assert got[s] == oracle.audio_dfpwm(oracle.mono(oracle.dfpwm(st[s], 2, 48000)), True), ("transcode", env, s, len(st[s]))
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
+def test_fuzz_deferred_resample_into_the_filter(ctx, oracle, seed, monkeypatch):
+    """`loader(...):resample(48000, interp)` then `effects.lowpass / highpass` [then `Audio:mono`] with F32 storage: ONE pass over the decoder's integer rows
+    (aukit.lua:648-680, :3586-3618, :682-687) — k_rsp (rs_periodic.hip) where the shape is its (int16 rows, cubic, 44.1 / 22.05 kHz), k_rs_onepole
+    (flac_tail.hip) else and under AUKIT_RS_GENERIC=1.  Random loader, lengths around the tile sizes, cut-off, forced runs of tiles: the oracle within 1e-6
+    RMS and 1e-6 at the worst sample, the two kernels within a few f32 ulps of each other."""
+    B, N = _B(), _N()
+    rng = np.random.Generator(np.random.PCG64(15000 + seed))
+    kind = ["ima", "msadpcm", "qoa", "flac", "flac"][int(rng.integers(0, 5))]
+    rate = int(rng.choice([44100, 22050])) if kind != "msadpcm" else 44100
+    ch = 1 if kind == "ima" else int(rng.integers(1, 3))
+    lens = [int(rng.choice([1, 7, 319, 320, 321, 639, 640, 1281, 2048, int(rng.integers(3000, 30000)), int(rng.integers(30000, 140000))])) for _ in range(4)]
+
+    def sig(n, k):
+        t = np.arange(n) / rate
+        x = rng.uniform(0.1, 0.9) * np.sin(2 * np.pi * rng.uniform(20, 9000) * t + k) + rng.uniform(-1, 1, n) * rng.uniform(0, 0.1)
+        return np.clip(x * 32767, -32768, 32767).astype(np.int16)
+
+    streams = []
+    for i, n in enumerate(lens):
+        x = np.stack([sig(n, i + c) for c in range(ch)], 1)
+        if kind == "ima":
+            nb = max(-(-n // 1016), 1)
+            streams.append(oracle.gen_ima(sig(1016 * nb, i), 1, 512, int(rng.integers(0, 89))))
+        elif kind == "msadpcm":
+            spb = (1024 - 7 * ch) * 2 // ch + 2
+            nb = max(-(-n // spb), 1)
+            streams.append(oracle.gen_msadpcm(np.stack([sig(spb * nb, i + c) for c in range(ch)], 1).ravel(), ch, 1024))
+        elif kind == "qoa":
+            streams.append(oracle.gen_qoa(x.ravel(), ch, rate) + b"\0" * 8)
+        else:
+            streams.append(oracle.gen_flac(x.astype(np.int64).ravel(), ch, 16, rate, int(rng.choice([4096, 1152, 2304, 700]))))
+    if kind == "ima":
+        desc, load = B.make_desc(N.CODEC_ADPCM_WAV, 1, rate, block_align=512), (lambda d: oracle.wav_adpcm(d, 512, 1, rate))
+    elif kind == "msadpcm":
+        desc, load = B.make_desc(N.CODEC_MSADPCM, ch, rate, block_align=1024), (lambda d: oracle.msadpcm(d, 1024, ch, rate))
+    elif kind == "qoa":
+        desc, load = B.make_desc(N.CODEC_QOA, ch, rate), oracle.qoa
+    else:
+        desc, load = B.make_desc(N.CODEC_FLAC), oracle.flac
+    interp = "cubic" if rng.integers(0, 4) else "linear"
+    which = ["lowpass", "highpass"][int(rng.integers(0, 2))]
+    freq = float(rng.choice([20.0, 300.0, 3000.0, 11025.0, float(rng.uniform(10, 20000))]))
+    mono = ch == 2 and bool(rng.integers(0, 2))
+    segs = int(rng.choice([0, 0, 2, 5]))
+    bt = B.Batch.upload(ctx, streams)
+    got = {}
+    for kern in ("default", "generic"):
+        if kern == "generic":
+            monkeypatch.setenv("AUKIT_RS_GENERIC", "1")
+        if segs:
+            monkeypatch.setenv("AUKIT_RS_SEGS", str(segs))
+        a = B.decode_resample(ctx, bt, desc, 48000, interp, dtype=N.F32)
+        B.effect(ctx, a, which, freq)
+        got[kern] = (B.mono(ctx, a) if mono else a).download()
+    monkeypatch.delenv("AUKIT_RS_GENERIC")
+    for i, s in enumerate(streams):
+        ref = oracle.resample(load(s), 48000, oracle.INTERP[interp])
+        ref = (oracle.fx_lowpass if which == "lowpass" else oracle.fx_highpass)(ref, freq)
+        if mono:
+            ref = oracle.mono(ref)
+        for c in range(len(ref.data)):
+            g, h = got["default"][i][c], got["generic"][i][c]
+            assert len(g) == len(ref.data[c]) == len(h), (kind, i, c)
+            if len(g):
+                # (a forced run of tiles warms up over the tiles before it: 1e-12 of full scale; the recurrence in f32 where the slope allows it: 6e-7)
+                assert rms(g, ref.data[c]) <= 1e-6 and np.max(np.abs(g.astype(np.float64) - ref.data[c])) <= 1e-6, (kind, rate, ch, interp, which, freq, mono, segs, i, c, len(g))
+                assert np.max(np.abs(g - h)) <= 4e-7, (kind, rate, ch, interp, which, freq, mono, segs, i, c)
