@@ -67,6 +67,16 @@ struct aukit_ctx {
     hipEvent_t pre_ev = nullptr;
     aukit::DevBuf flac_set[2];
     int flac_par = 0;
+    // round 6, late: the WHOLE decode of a FLAC call (search, decoder, chain) on the look-ahead stream — the call before's last passes (its normalize: no LDS,
+    // HBM-bound) run beside the decoder (VALU-bound, the CU's whole LDS).  What orders the two streams: entry_ev[k & 1], recorded on ctx->stream when call k
+    // begins (the look-ahead stream waits for the one of call k - 1 before it writes call k's table set: everything that read that set — call k - 2's — was
+    // queued before it); scratch_ev, recorded on ctx->stream whenever a frame scratch goes back to tmp_buf3 (its last reader was queued just before); pre_ev
+    // as before (ctx->stream behind the look-ahead stream)
+    hipEvent_t entry_ev[2] = {nullptr, nullptr};
+    hipEvent_t scratch_ev = nullptr;
+    bool scratch_ev_set = false;
+    bool scratch_dirty = false;   // tmp_buf3 holds a call's frames and nothing tracks who reads them (the call's own gather / stream tail on ctx->stream): the next decoder waits for all of ctx->stream
+    uint64_t flac_calls = 0;
     hipEvent_t side_ev[2] = {};
     int aux_enc_cus = -1;
     bool fused_attr_set = false;

@@ -1330,6 +1330,7 @@ __global__ __launch_bounds__(256) void k_flac_finish(const FrameRec *frames, con
 }
 
 struct FlacDecoded {
+    hipEvent_t entry = nullptr; // ctx->stream as it stood when the call began (flac_decode_rows)
     DevBuf *set = nullptr;      // round 6: the call's set of tables (aukit_ctx::flac_set) when its first stages run on the look-ahead stream `pre`; null: tmp_buf2, ctx->stream
     hipStream_t pre = nullptr;
     std::vector<FlacStreamInfo> info;
@@ -1639,7 +1640,19 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         if (D.set) AUKIT_HIP_CHECK(hipEventRecord(ctx->pre_ev, pre));
         AUKIT_HIP_CHECK(hipStreamSynchronize(pre));
         if (hc.ncand > cand_room) { capc = hc.ncand + hc.ncand / 8 + n + 4096; continue; }
-        if (D.set) AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));   // the decoder (ctx->stream) behind the search
+        // Round 6, late: the decoder and the chain walk stay on the look-ahead stream too (AUKIT_FLAC_DECODE_AHEAD=0: behind the search on ctx->stream as
+        // before).  The call before's last passes — its normalize: HBM-bound, no LDS — then run BESIDE this call's decoder (VALU-bound, the CU's whole LDS)
+        // instead of in front of it.  The frame scratch is the one buffer both streams touch: the decoder waits for its last reader (scratch_ev: the tile
+        // chain of the call before), or for all of ctx->stream when nothing tracked the readers.  Every nested launch goes where ctx->stream points: it
+        // points at the look-ahead stream until the chain has converged.
+        const bool dahead = D.set && !(getenv("AUKIT_FLAC_DECODE_AHEAD") && atoi(getenv("AUKIT_FLAC_DECODE_AHEAD")) == 0);
+        struct StreamSwap { aukit_ctx *c; hipStream_t saved; bool on; void back() { if (on) { c->stream = saved; on = false; } } ~StreamSwap() { back(); } } sw{ctx, ctx->stream, false};
+        if (dahead) {
+            if (getenv("AUKIT_DEBUG_NO_SCRATCH_WAIT")) {}   // (the race test's negative control: tests/test_gpu_flac.py must FAIL with this)
+            else if (ctx->scratch_dirty && D.entry) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, D.entry, 0));
+            else if (ctx->scratch_ev_set) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, ctx->scratch_ev, 0));
+            ctx->stream = pre; sw.on = true;
+        } else if (D.set) AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));   // the decoder (ctx->stream) behind the search
         unsigned ncand = (unsigned)hc.ncand;
         auto decode = [&](unsigned first, unsigned count, int limit_factor) -> int {
             FusedArgs A;
@@ -1705,6 +1718,12 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
             }
             for (unsigned k : redo) if ((rc = decode(k, 1, 0))) return rc;   // hit their bit budget and are needed after all: once more, without one
         }
+        if (dahead) {   // ctx->stream behind everything the look-ahead stream did for this call
+            sw.back();
+            AUKIT_HIP_CHECK(hipEventRecord(ctx->pre_ev, pre));
+            AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));
+        }
+        ctx->scratch_dirty = true;   // (until a deferred resample takes the buffer: lazy_resample_try)
         if (restart) continue;
         for (uint32_t s = 0; s < n; s++) if (chain[s].status == FE_DECLINE) return 2;
         if (o16 && (hc.flags & 0x100u)) return 3;   // a final value beyond int16 (not an ordinary stream): once more with int32 finals
@@ -1790,12 +1809,19 @@ static int flac_decode_rows(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &
     // ... where the call before leaves the chip room: measured on config 5 with k_rsp behind the decoder (profiles/r06_flac_lookahead.txt) the search beside the
     // filter and normalize passes takes 0.13 - 0.25 ms off a step of 256 - 1024 ten-second streams and ADDS 0.22 ms to one of 2048 (what the search
     // takes from the kernels it runs beside is more than its own 0.6 ms there).  AUKIT_FLAC_LOOKAHEAD=0 / 1 decides it by hand
-    bool ahead = in->total() < (2ull << 30);
+    // (with the decoder on the look-ahead stream as well — flac_run_fused — it pays at every size again: 2048 streams 11.0 ms against 11.35 with the search alone
+    // there and 11.5 with everything on ctx->stream, one box)
+    bool ahead = true;
     if (const char *e = getenv("AUKIT_FLAC_LOOKAHEAD")) ahead = atoi(e) != 0;
     if (getenv("AUKIT_FLAC_NO_LOOKAHEAD")) ahead = false;
     if (ahead) {
         if ((rc = ctx_pre_stream(ctx, &pre))) return rc;
         if (in->ready) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, in->ready, 0));
+        // (call k writes the table set call k - 2 used: whatever read that one on ctx->stream was queued before call k - 1 began)
+        const uint64_t k = ctx->flac_calls++;
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->entry_ev[k & 1], ctx->stream));
+        if (k >= 1) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, ctx->entry_ev[(k - 1) & 1], 0));
+        D.entry = ctx->entry_ev[k & 1];
         ctx->flac_par ^= 1;
         D.set = &ctx->flac_set[ctx->flac_par];
     }

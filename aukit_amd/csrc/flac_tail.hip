@@ -507,7 +507,10 @@ int lazy_materialize(aukit_ctx *ctx, aukit_audio *a) {
                                       reinterpret_cast<const int *>(a->lazy_rows.p), reinterpret_cast<int *>(ctx->tmp_buf.p), a->lazy_scratch16))) return grc;
         if (a->lazy_scratch16) { a->lazy_scratch16 = false; a->lazy_src = SRC_I32; a->lazy_norm_pos = a->lazy_norm_neg = a->lazy_full; }   // (gathered to int32 rows: the ordinary kernels take those)
         if ((grc = ctx_end_kernel(ctx, "k_flac_gather", 2 * a->lazy_tot * 4))) return grc;
-        if (ctx->tmp_buf3.cap < a->lazy_rows.cap) { ctx->tmp_buf3.release(); ctx->tmp_buf3 = a->lazy_rows; a->lazy_rows = DevBuf{}; }   // the scratch goes home
+        if (ctx->tmp_buf3.cap < a->lazy_rows.cap) {   // the scratch goes home
+            ctx->tmp_buf3.release(); ctx->tmp_buf3 = a->lazy_rows; a->lazy_rows = DevBuf{};
+            if (ctx->scratch_ev && hipEventRecord(ctx->scratch_ev, ctx->stream) == hipSuccess) ctx->scratch_ev_set = true;   // (behind the gather above)
+        }
         else a->lazy_rows.release();
         a->lazy_indirect = false;
     } else {
@@ -580,6 +583,7 @@ bool lazy_resample_try(aukit_ctx *ctx, const std::vector<uint64_t> &row_off, con
         a->lazy_indirect = true;
         a->lazy_rows = ctx->tmp_buf3;
         ctx->tmp_buf3 = DevBuf{};
+        ctx->scratch_dirty = false;   // (its readers from here on record scratch_ev: lazy_onepole_try, lazy_materialize)
     } else {
         a->lazy_rows = ctx->tmp_buf;     // the rows leave the context's scratch with the audio: nothing can overwrite them
         ctx->tmp_buf = DevBuf{};
@@ -698,6 +702,8 @@ bool lazy_onepole_try(aukit_ctx *ctx, aukit_audio *a, double coef, bool highpass
 #undef AUKIT_RSO1
 #undef AUKIT_RSO
     if (hipGetLastError() != hipSuccess) { *rc = fail(AUKIT_E_HIP, "k_rs_onepole launch failed"); return true; }
+    // (a frame scratch was read: the FLAC decoder of the NEXT call, on the look-ahead stream, writes such a buffer behind this point of ctx->stream — common.h)
+    if (a->lazy_indirect && ctx->scratch_ev && hipEventRecord(ctx->scratch_ev, ctx->stream) == hipSuccess) ctx->scratch_ev_set = true;
     uint64_t in_elems = 0, out_elems = 0;
     for (uint64_t l : a->lazy_row_len) in_elems += l;
     for (uint64_t l : a->len) out_elems += l * (uint64_t)a->channels;

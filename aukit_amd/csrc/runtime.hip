@@ -74,8 +74,15 @@ int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side) {
 }
 int ctx_pre_stream(aukit_ctx *ctx, hipStream_t *s) {
     if (!ctx->pre_stream) {
-        AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));
+        {   // (AUKIT_PRE_PRIORITY=1: the look-ahead stream above ctx->stream in the queues' priorities — A/B)
+            int lo = 0, hi = 0;
+            if (getenv("AUKIT_PRE_PRIORITY") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) AUKIT_HIP_CHECK(hipStreamCreateWithPriority(&ctx->pre_stream, hipStreamNonBlocking, atoi(getenv("AUKIT_PRE_PRIORITY")) > 0 ? hi : lo));
+            else AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));
+        }
         AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->pre_ev, hipEventDisableTiming));
+        AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->entry_ev[0], hipEventDisableTiming));
+        AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->entry_ev[1], hipEventDisableTiming));
+        AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->scratch_ev, hipEventDisableTiming));
     }
     *s = ctx->pre_stream;
     return AUKIT_OK;
@@ -255,7 +262,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     if (c->stream_full) { aukit_audio_free(c->stream_full); c->stream_full = nullptr; }
     delete c->spcm_ck;
     if (c->host_stage) (void)hipHostFree(c->host_stage);
-    if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->pre_ev); c->pre_stream = nullptr; }
+    if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->pre_ev); (void)hipEventDestroy(c->entry_ev[0]); (void)hipEventDestroy(c->entry_ev[1]); (void)hipEventDestroy(c->scratch_ev); c->pre_stream = nullptr; }
     c->flac_set[0].release(); c->flac_set[1].release();
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }

@@ -259,3 +259,59 @@ def test_deferred_resample_fused_into_the_filter_pass(ctx, oracle, monkeypatch, 
         for c in range(ch):
             assert rms(b.download()[s][c], want[s][c]) <= 1e-6
     a.free()
+
+
+def test_back_to_back_calls_share_the_look_ahead_stream(ctx, oracle, monkeypatch):
+    """Round 6: a FLAC call's search, decoder and chain walk run on the look-ahead stream while ctx->stream still works on the call BEFORE (its tile chain, its
+    normalize); the frame scratch, the two table sets and the audios' deferred work are what the two streams share.  Calls issued back to back with nothing
+    waited for in between — different batches, outputs kept, every way a scratch is consumed (the fused tail with and without the channels' mean, a
+    download that gathers, a loader call without a resample) — must give what the same calls give one at a time."""
+    B, N = _B(), _N()
+    monkeypatch.setenv("AUKIT_FLAC_LOOKAHEAD", "1")
+    rng = np.random.Generator(np.random.PCG64(77))
+    batches = []
+    for b in range(3):
+        distinct = []
+        for i in range(6):
+            n = int(rng.integers(60000, 120000))
+            p = np.stack([pcm16(n, 44100, 5, 10 * b + 2 * i + c) for c in range(2)], 1).astype(np.int64)
+            distinct.append(oracle.gen_flac(p.ravel(), 2, 16, 44100, 4096, salt=b))
+        streams = [distinct[i % 6] for i in range(256)]   # (kernels of a good part of a millisecond: the streams have something to overlap)
+        batches.append((streams, B.Batch.upload(ctx, streams)))
+    desc = B.make_desc(N.CODEC_FLAC)
+
+    def run(order, sync_each):
+        outs = []
+        for k, (b, how) in enumerate(order):
+            bt = batches[b][1]
+            if how == "mono":
+                a = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+                B.effect(ctx, a, "highpass", 20.0)
+                B.effect(ctx, a, "normalize", 0.8)
+                outs.append(B.mono(ctx, a))
+            elif how == "tail":
+                a = B.decode_resample(ctx, bt, desc, 48000, "cubic", dtype=N.F32)
+                B.effect(ctx, a, "lowpass", 3000.0)
+                outs.append(a)
+            elif how == "rows":
+                outs.append(B.decode_resample(ctx, bt, desc, 48000, "linear", dtype=N.F32))   # (materialised at the download: the gather)
+            else:
+                outs.append(B.decode(ctx, bt, desc, dtype=N.F32))
+            if sync_each:
+                ctx.sync()
+        return [o.download() for o in outs]
+
+    order = [(0, "mono"), (1, "tail"), (2, "mono"), (0, "rows"), (1, "plain"), (2, "tail"), (0, "mono"), (1, "mono"), (2, "rows"), (0, "tail")]
+    ref = run(order, True)
+    for rep in range(3):
+        got = run(order, False)
+        for k in range(len(order)):
+            for s in range(len(ref[k])):
+                for c in range(len(ref[k][s])):
+                    assert np.array_equal(got[k][s][c], ref[k][s][c]), (rep, k, order[k], s, c)
+                    if s >= 6:
+                        assert np.array_equal(got[k][s][c], got[k][s % 6][c]), (rep, k, s, c)   # (copies of a file: the same samples)
+    # ... and the first of them against the oracle
+    s0 = batches[0][0][0]
+    r0 = oracle.mono(oracle.fx_normalize(oracle.fx_highpass(oracle.resample(oracle.flac(s0), 48000, oracle.CUBIC), 20.0), 0.8)).data[0]
+    assert rms(ref[0][0][0], r0) <= 1e-6
