@@ -48,7 +48,7 @@ for kernel, tag, pat, nstreams in DOMINANT:
 # multi-launch workloads: HBM bytes of ONE step = every aukit kernel's FETCH_SIZE x 2 + WRITE_SIZE summed over the run, divided by the number of
 # steps the run made = the dispatches of a kernel that is launched once per step (the anchor)
 STEPS = [("flac_pipeline", "flac", "k_flac_find", 2048), ("flac_pipeline", "flac256", "k_flac_find", 256), ("qoa_stream", "qoa", "k_qoa_wave", 4096),
-         ("dfpwm_transcode", "dfpwm", "k_dfx_onset<0>", 16384), ("dfpwm_transcode", "dfpwm2048", "k_dfx_onset<0>", 2048), ("ima_pipeline", "imapipe", "onepole", 4096)]
+         ("dfpwm_transcode", "dfpwm", "k_dfx_onset<0>", 16384), ("dfpwm_transcode", "dfpwm2048", "k_dfx_onset<0>", 2048), ("ima_pipeline", "imapipe", "k_ima_lanes", 4096)]
 
 
 def step_traffic(tag, anchor):
