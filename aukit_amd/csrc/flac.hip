@@ -1648,8 +1648,7 @@ static int flac_run_fused(aukit_ctx *ctx, const aukit_batch *in, FlacDecoded &D,
         const bool dahead = D.set && !(getenv("AUKIT_FLAC_DECODE_AHEAD") && atoi(getenv("AUKIT_FLAC_DECODE_AHEAD")) == 0);
         struct StreamSwap { aukit_ctx *c; hipStream_t saved; bool on; void back() { if (on) { c->stream = saved; on = false; } } ~StreamSwap() { back(); } } sw{ctx, ctx->stream, false};
         if (dahead) {
-            if (getenv("AUKIT_DEBUG_NO_SCRATCH_WAIT")) {}   // (the race test's negative control: tests/test_gpu_flac.py must FAIL with this)
-            else if (ctx->scratch_dirty && D.entry) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, D.entry, 0));
+            if (ctx->scratch_dirty && D.entry) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, D.entry, 0));
             else if (ctx->scratch_ev_set) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, ctx->scratch_ev, 0));
             ctx->stream = pre; sw.on = true;
         } else if (D.set) AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));   // the decoder (ctx->stream) behind the search

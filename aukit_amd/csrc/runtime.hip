@@ -74,11 +74,7 @@ int ctx_side_fork(aukit_ctx *ctx, hipStream_t *side) {
 }
 int ctx_pre_stream(aukit_ctx *ctx, hipStream_t *s) {
     if (!ctx->pre_stream) {
-        {   // (AUKIT_PRE_PRIORITY=1: the look-ahead stream above ctx->stream in the queues' priorities — A/B)
-            int lo = 0, hi = 0;
-            if (getenv("AUKIT_PRE_PRIORITY") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) AUKIT_HIP_CHECK(hipStreamCreateWithPriority(&ctx->pre_stream, hipStreamNonBlocking, atoi(getenv("AUKIT_PRE_PRIORITY")) > 0 ? hi : lo));
-            else AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));
-        }
+        AUKIT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking));   // (a higher queue priority changes nothing: profiles/r06_flac_lookahead.txt)
         AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->pre_ev, hipEventDisableTiming));
         AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->entry_ev[0], hipEventDisableTiming));
         AUKIT_HIP_CHECK(hipEventCreateWithFlags(&ctx->entry_ev[1], hipEventDisableTiming));
