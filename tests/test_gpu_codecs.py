@@ -610,3 +610,38 @@ def test_stream_adpcm_large_blocks(ctx, oracle, ch, ba):
         assert list(ck.lens[i][:ref.nchunks]) == list(ref.chunk_len[:, 0]), i
         for c in range(ref.channels):
             assert np.array_equal(got[i][c], ref.data[c]), (i, c)
+
+
+def test_stream_adpcm_back_to_back_calls(ctx, oracle):
+    """stream.adpcm's header scan runs on the look-ahead stream and nothing waits for the kernel's own (unreachable) error flag: calls issued one behind the
+    other on different batches — one with a stream whose third block carries a step index above 88 — give what they give one at a time, and that is the oracle's"""
+    B, N = _B(), _N()
+    batches = []
+    for b in range(3):
+        streams = [oracle.gen_ima(pcm16(1016 * (20 + 7 * i + b), 22050, 3, 10 * b + i), 1, 512, 88) for i in range(24)]
+        if b == 1:
+            bad = bytearray(streams[5]); bad[2 * 512 + 2] = 120; streams[5] = bytes(bad)
+        batches.append((streams, B.Batch.upload(ctx, streams)))
+    desc = B.make_desc(N.CODEC_ADPCM_WAV, 1, 22050, block_align=512)
+
+    def run(sync_each):
+        res = []
+        for k in range(9):
+            out, ck = B.stream_decode(ctx, batches[k % 3][1], desc, "cubic", dtype=N.I8)
+            res.append((out, ck))
+            if sync_each:
+                ctx.sync()
+        return [(o.download(), list(c.nchunks), list(c.status)) for o, c in res]
+
+    ref = run(True)
+    for rep in range(3):
+        got = run(False)
+        for k in range(9):
+            assert got[k][1] == ref[k][1] and got[k][2] == ref[k][2], (rep, k)
+            for s in range(24):
+                assert np.array_equal(got[k][0][s][0], ref[k][0][s][0]), (rep, k, s)
+    for k in (0, 1):
+        for s in (0, 5):
+            r = oracle.stream_adpcm(batches[k][0][s], 512, 1, 22050, False, oracle.CUBIC)
+            assert ref[k][1][s] == r.nchunks and (ref[k][2][s] != 0) == (r.final_status != 0)
+            assert np.array_equal(ref[k][0][s][0], r.data[0])
