@@ -72,6 +72,8 @@ struct aukit_ctx {
     // begins (the look-ahead stream waits for the one of call k - 1 before it writes call k's table set: everything that read that set — call k - 2's — was
     // queued before it); scratch_ev, recorded on ctx->stream whenever a frame scratch goes back to tmp_buf3 (its last reader was queued just before); pre_ev
     // as before (ctx->stream behind the look-ahead stream)
+    aukit::DevBuf qoa_set[2][3];   // stream.qoa's two walks on the look-ahead stream: their words ([0] walk records + fill table, [1] call records, [2] decode jobs), two sets alternating like flac_set
+    int qoa_par = 0;
     aukit::DevBuf scan_buf;   // stream.adpcm's header scan (k_ima_scan_headers) on the look-ahead stream: its own words, not misc_buf (ctx->stream's kernels may still read that)
     hipEvent_t entry_ev[2] = {nullptr, nullptr};
     hipEvent_t scratch_ev = nullptr;

@@ -302,13 +302,15 @@ struct QoaLaps {   // AUKIT_HOST_TIMING=1: host laps on stderr
 struct QoaStreamInfo { int channels; double rate, file_samples; bool raised, big; unsigned ncalls; uint64_t njobs, rows_total, L, job_first, call_first, row_base, stride; };
 
 // pass 1 of the device walk; validates the file headers like the reference (errors with its strings)
-static int qoa_walk_count(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector<QoaStreamInfo> &S) {
+// (wb: where the walks keep their words — tmp_buf3, or the call's set of ctx->qoa_set when they run on the look-ahead stream: stream_qoa)
+static int qoa_walk_count(aukit_ctx *ctx, const aukit_batch *in, int mode, std::vector<QoaStreamInfo> &S, DevBuf *wb = nullptr) {
     const uint32_t n = in->n;
     S.assign(n, QoaStreamInfo{});
     if (!n) return AUKIT_OK;
-    int rc = ctx->tmp_buf3.ensure((size_t)n * (sizeof(QoaWalkOut) + sizeof(QoaFillIn)) + 64);
+    DevBuf &W = wb ? *wb : ctx->tmp_buf3;
+    int rc = W.ensure((size_t)n * (sizeof(QoaWalkOut) + sizeof(QoaFillIn)) + 64);
     if (rc) return rc;
-    QoaWalkOut *dwo = reinterpret_cast<QoaWalkOut *>(ctx->tmp_buf3.p);
+    QoaWalkOut *dwo = reinterpret_cast<QoaWalkOut *>(W.p);
     const unsigned long long *doff = reinterpret_cast<const unsigned long long *>(in->d_off);
     hipLaunchKernelGGL((k_qoa_walk<false>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), doff, n, mode, dwo, static_cast<const QoaFillIn *>(nullptr),
                        static_cast<QoaJob *>(nullptr), static_cast<QoaCallRec *>(nullptr));
@@ -346,15 +348,16 @@ static int qoa_walk_count(aukit_ctx *ctx, const aukit_batch *in, int mode, std::
 }
 
 // pass 2: the decode jobs into `djobs` (device), the call records to the host (stream mode: want_calls)
-static int qoa_walk_fill(aukit_ctx *ctx, const aukit_batch *in, int mode, const std::vector<QoaStreamInfo> &S, QoaJob *djobs, uint64_t ncalls, std::vector<QoaCallRec> *calls) {
+static int qoa_walk_fill(aukit_ctx *ctx, const aukit_batch *in, int mode, const std::vector<QoaStreamInfo> &S, QoaJob *djobs, uint64_t ncalls, std::vector<QoaCallRec> *calls, DevBuf *wb = nullptr, DevBuf *cb = nullptr) {
     const uint32_t n = in->n;
     std::vector<QoaFillIn> fin(n);
     for (uint32_t s = 0; s < n; s++) fin[s] = QoaFillIn{S[s].job_first, S[s].call_first, S[s].row_base, S[s].stride};
-    QoaFillIn *dfin = reinterpret_cast<QoaFillIn *>(reinterpret_cast<QoaWalkOut *>(ctx->tmp_buf3.p) + n);
+    QoaFillIn *dfin = reinterpret_cast<QoaFillIn *>(reinterpret_cast<QoaWalkOut *>((wb ? *wb : ctx->tmp_buf3).p) + n);
     { int hrc = h2d_table(ctx, dfin, fin.data(), (size_t)n * sizeof(QoaFillIn)); if (hrc) return hrc; }
-    int rc = ctx->misc_buf.ensure((size_t)std::max<uint64_t>(ncalls, 1) * sizeof(QoaCallRec) + 64);
+    DevBuf &CB = cb ? *cb : ctx->misc_buf;
+    int rc = CB.ensure((size_t)std::max<uint64_t>(ncalls, 1) * sizeof(QoaCallRec) + 64);
     if (rc) return rc;
-    QoaCallRec *dcalls = reinterpret_cast<QoaCallRec *>(ctx->misc_buf.p);
+    QoaCallRec *dcalls = reinterpret_cast<QoaCallRec *>(CB.p);
     hipLaunchKernelGGL((k_qoa_walk<true>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), n, mode,
                        static_cast<QoaWalkOut *>(nullptr), dfin, djobs, dcalls);
     AUKIT_HIP_CHECK(hipGetLastError());
@@ -419,24 +422,48 @@ int stream_qoa(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d,
     if (in->n == 0) return fail(AUKIT_E_ARG, "empty batch");
     QoaLaps laps;
     std::vector<QoaStreamInfo> S;
-    int rc = qoa_walk_count(ctx, in, 1, S);
+    // Round 6, late: the two walks (they read the input batch and nothing else) run on the look-ahead stream, into words of their own (ctx->qoa_set, alternating):
+    // their host waits were waits for everything the call BEFORE had left on ctx->stream — a host that issues call after call now counts, plans and
+    // builds the tail's job table while that call's decoder and tail still run.  entry_ev orders a set's next writer behind its last readers (common.h).
+    // AUKIT_QOA_WALK_MAIN=1: everything on ctx->stream, as before.
+    struct StreamSwap { aukit_ctx *c; hipStream_t saved; bool on; void back() { if (on) { c->stream = saved; on = false; } } ~StreamSwap() { back(); } } sw{ctx, ctx->stream, false};
+    DevBuf *qs = nullptr;   // the call's set: [0] walk words, [1] call records, [2] decode jobs
+    hipStream_t pre = nullptr;
+    if (!getenv("AUKIT_QOA_WALK_MAIN")) {
+        int prc = ctx_pre_stream(ctx, &pre);
+        if (prc) return prc;
+        if (in->ready) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, in->ready, 0));
+        const uint64_t k = ctx->flac_calls++;
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->entry_ev[k & 1], ctx->stream));
+        if (k >= 1) AUKIT_HIP_CHECK(hipStreamWaitEvent(pre, ctx->entry_ev[(k - 1) & 1], 0));
+        ctx->qoa_par ^= 1;
+        qs = ctx->qoa_set[ctx->qoa_par];
+        ctx->stream = pre; sw.on = true;
+    }
+    int rc = qoa_walk_count(ctx, in, 1, S, qs ? &qs[0] : nullptr);
     if (rc) return rc;
     laps.lap("walk 1");
     const int C = S[0].channels;
     const double rate = S[0].rate;
-    if (!(rate > 0)) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
+    if (!(rate > 0)) { sw.back(); return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out); }
     const double ratio = 48000 / rate;
     uint64_t tot = 0, njobs = 0, ncalls = 0;
     for (uint32_t s = 0; s < in->n; s++) {
         if (S[s].channels != C || S[s].rate != rate) return fail(AUKIT_E_ARG, "all QOA streams of a batch must share channel count and sample rate");
-        if (S[s].big) return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out);
+        if (S[s].big) { sw.back(); return stream_qoa_host(ctx, in, d, interp, mono, dtype, out, chunks_out); }
         tot += S[s].rows_total; njobs += S[s].njobs; ncalls += S[s].ncalls;
     }
     std::vector<QoaCallRec> calls;
     if ((rc = ctx->tmp_buf.ensure((size_t)tot + 64))) return rc;
-    if ((rc = ctx->tmp_buf2.ensure((size_t)std::max<uint64_t>(njobs, 1) * sizeof(QoaJob) + 64))) return rc;
-    QoaJob *djobs = reinterpret_cast<QoaJob *>(ctx->tmp_buf2.p);
-    if ((rc = qoa_walk_fill(ctx, in, 1, S, djobs, ncalls, &calls))) return rc;
+    DevBuf &JB = qs ? qs[2] : ctx->tmp_buf2;
+    if ((rc = JB.ensure((size_t)std::max<uint64_t>(njobs, 1) * sizeof(QoaJob) + 64))) return rc;
+    QoaJob *djobs = reinterpret_cast<QoaJob *>(JB.p);
+    if ((rc = qoa_walk_fill(ctx, in, 1, S, djobs, ncalls, &calls, qs ? &qs[0] : nullptr, qs ? &qs[1] : nullptr))) return rc;
+    if (sw.on) {   // ctx->stream behind the walks (the decoder reads their jobs)
+        sw.back();
+        AUKIT_HIP_CHECK(hipEventRecord(ctx->pre_ev, pre));
+        AUKIT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->pre_ev, 0));
+    }
     laps.lap("walk 2");
     aukit_chunks *ck = new aukit_chunks();
     ck->n = in->n;

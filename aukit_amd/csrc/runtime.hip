@@ -259,7 +259,7 @@ void aukit_ctx_destroy(aukit_ctx *c) {
     delete c->spcm_ck;
     if (c->host_stage) (void)hipHostFree(c->host_stage);
     if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); (void)hipEventDestroy(c->pre_ev); (void)hipEventDestroy(c->entry_ev[0]); (void)hipEventDestroy(c->entry_ev[1]); (void)hipEventDestroy(c->scratch_ev); c->pre_stream = nullptr; }
-    c->flac_set[0].release(); c->flac_set[1].release(); c->scan_buf.release();
+    c->flac_set[0].release(); c->flac_set[1].release(); c->scan_buf.release(); for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) c->qoa_set[i][j].release();
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); (void)hipEventDestroy(c->side_ev[0]); (void)hipEventDestroy(c->side_ev[1]); }
     if (c->tab_ring) { (void)hipHostFree(c->tab_ring); (void)hipEventDestroy(c->tab_ev[0]); (void)hipEventDestroy(c->tab_ev[1]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -645,3 +645,37 @@ def test_stream_adpcm_back_to_back_calls(ctx, oracle):
             r = oracle.stream_adpcm(batches[k][0][s], 512, 1, 22050, False, oracle.CUBIC)
             assert ref[k][1][s] == r.nchunks and (ref[k][2][s] != 0) == (r.final_status != 0)
             assert np.array_equal(ref[k][0][s][0], r.data[0])
+
+
+def test_stream_qoa_back_to_back_calls(ctx, oracle):
+    """stream.qoa's two walks run on the look-ahead stream into alternating sets of words: calls issued one behind the other on different batches (stereo, the
+    channels' mean, one channel) give what they give one at a time, and that is the oracle's"""
+    B, N = _B(), _N()
+    batches = []
+    for b in range(3):
+        ch = 2 if b < 2 else 1
+        streams = [oracle.gen_qoa(np.stack([pcm16(30000 + 4000 * i + 777 * b, 44100, 8, 40 * b + 2 * i + c) for c in range(ch)], 1).ravel(), ch, 44100) + b"\0" * 8 for i in range(12)]
+        batches.append((streams, B.Batch.upload(ctx, streams), ch))
+
+    def run(sync_each):
+        res = []
+        for k in range(9):
+            streams, bt, ch = batches[k % 3]
+            out, ck = B.stream_decode(ctx, bt, B.make_desc(N.CODEC_QOA), "cubic", mono=(k % 3 == 1), dtype=N.F32)
+            res.append((out, ck))
+            if sync_each:
+                ctx.sync()
+        return [(o.download(), list(c.nchunks)) for o, c in res]
+
+    ref = run(True)
+    for rep in range(3):
+        got = run(False)
+        for k in range(9):
+            assert got[k][1] == ref[k][1], (rep, k)
+            for s in range(12):
+                for c in range(len(ref[k][0][s])):
+                    assert np.array_equal(got[k][0][s][c], ref[k][0][s][c]), (rep, k, s, c)
+    for k in range(3):
+        r = oracle.stream_qoa(batches[k][0][3], k == 1, oracle.CUBIC)
+        for c in range(r.channels):
+            assert rms(ref[k][0][3][c] / 128, r.data[c] / 128) <= 1e-6, (k, c)
