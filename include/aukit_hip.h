@@ -181,8 +181,8 @@ int aukit_ctx_last_kernel(aukit_ctx *ctx, const char **name, float *ms, uint64_t
 /* ---- batches of byte strings ---- */
 int aukit_batch_upload(aukit_ctx *ctx, aukit_batch **out, const uint8_t *bytes, const uint64_t *offsets /* n+1 */, uint32_t n);
 /* zero-copy: bytes already on this device (e.g. received by RCCL); the caller keeps ownership.  Ordering: whatever was queued on the context's
- * stream BEFORE this call (the bytes' producer, if it ran there) is in front of every reader of the batch — also of the FLAC loader's decode,
- * which since round 6 reads it on a stream of its own (an event recorded here orders them).  The bytes must be complete, or on their way on
+ * stream BEFORE this call (the bytes' producer, if it ran there) is in front of every reader of the batch — also of the FLAC loader's decode, of stream.adpcm's header scan and of stream.qoa's frame walks,
+ * which since round 6 read it on a stream of the library's own (an event recorded here orders them).  The bytes must be complete, or on their way on
  * that stream, when the batch is wrapped, and must not change while the batch is in use: wrap again after rewriting them. */
 int aukit_batch_wrap_device(aukit_ctx *ctx, aukit_batch **out, const void *dev_bytes, const uint64_t *offsets /* host, n+1 */, uint32_t n);
 int aukit_batch_info(const aukit_batch *b, uint32_t *n, uint64_t *total_bytes);
