@@ -988,6 +988,14 @@ int decode_msadpcm_audio(aukit_ctx *ctx, const aukit_batch *in, const aukit_code
     return audio_from_int_rows(ctx, SRC_AUDIO_F64, ctx->tmp_buf.p, row_off, row_len, in->n, d->channels, d->sample_rate, new_rate, interp, do_resample, dtype, 1, 1, out);
 }
 
+// One channel: every block of a stream decodes with the predictor index of the stream's FIRST block (Q9), so "is an index beyond the coefficient table" is one
+// byte per stream.  The stream's first byte, to the host — on the look-ahead stream (round 6, late): the call then need not wait for k_ms_wave's own flag, and
+// a host that issues call after call plans while the kernel of the call before runs.
+__global__ __launch_bounds__(256) void k_ms_first_bytes(const unsigned char *src, const unsigned long long *off, unsigned n, unsigned char *out) {
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) out[s] = off[s + 1] > off[s] ? src[off[s]] : (unsigned char)0;
+}
+
 // aukit.stream.msadpcm  aukit.lua:2588-2736
 int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc *d, int interp, int mono, int dtype, aukit_audio **out,
                    aukit_chunks **chunks_out) {
@@ -998,6 +1006,19 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
     MsBlocks B;
     int rc = ms_count_blocks(in, d, B);
     if (rc) return rc;
+    std::vector<unsigned char> first_byte;
+    hipStream_t scan_stream = nullptr;
+    if (C == 1 && in->n && !getenv("AUKIT_MS_SCAN_OFF")) {
+        if ((rc = ctx_pre_stream(ctx, &scan_stream))) return rc;
+        if (in->ready) AUKIT_HIP_CHECK(hipStreamWaitEvent(scan_stream, in->ready, 0));
+        if ((rc = ctx->scan_buf.ensure((size_t)in->n + 64))) return rc;
+        first_byte.resize(in->n);
+        hipLaunchKernelGGL(k_ms_first_bytes, dim3((in->n + 255) / 256), dim3(256), 0, scan_stream, in->data(), reinterpret_cast<const unsigned long long *>(in->d_off), in->n,
+                           reinterpret_cast<unsigned char *>(ctx->scan_buf.p));
+        AUKIT_HIP_CHECK(hipGetLastError());
+        AUKIT_HIP_CHECK(hipMemcpyAsync(first_byte.data(), ctx->scan_buf.p, in->n, hipMemcpyDeviceToHost, scan_stream));
+        AUKIT_HIP_CHECK(hipStreamSynchronize(scan_stream));   // (the look-ahead stream: not a wait for what the call before left on ctx->stream)
+    }
     const uint64_t ba = (uint64_t)d->block_align;
     const uint64_t spb_dec = C == 2 ? (ba - 14) + 2 : (ba - 7) * 2 + 2;
     const double ratio = 48000 / d->sample_rate;
@@ -1126,6 +1147,12 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
             if (hipMemsetAsync(P.audit, 0, 8, ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "hipMemsetAsync failed"); }
         }
         const unsigned grid = (unsigned)((nblocks + 63) / 64);
+        bool scanned = false;
+        if (scan_stream) {   // the predictor indices of the streams that have a block at all: the reference's error, before anything is decoded
+            for (uint32_t s2 = 0; s2 < in->n; s2++)
+                if (B.blk0[s2 + 1] > B.blk0[s2] && (int)first_byte[s2] >= P.ncoef) { delete ck; return fail(AUKIT_E_LUA, "attempt to perform arithmetic on a nil value (local 'c1')"); }
+            scanned = true;
+        }
         if ((rc = ctx_begin_kernel(ctx))) { delete ck; return rc; }
 #define AUKIT_MS_STREAM(CC, RBB, MIXX)                                                                                                 \
         do {                                                                                                                            \
@@ -1139,6 +1166,8 @@ int stream_msadpcm(aukit_ctx *ctx, const aukit_batch *in, const aukit_codec_desc
         if (hipGetLastError() != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_ms_wave launch failed"); }
         if ((rc = ctx_end_kernel(ctx, "k_ms_wave", in->total() + out_elems * dtype_size(dtype)))) { delete ck; return rc; }
         int herr = 0;
+        // (scanned: no planned block can raise the kernel's flag — the host looked at every index it will meet; AUKIT_MS_ASSERT=1 waits and looks all the same)
+        if (!scanned || P.audit || getenv("AUKIT_MS_ASSERT"))
         if (hipMemcpyAsync(&herr, P.err, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { delete ck; return fail(AUKIT_E_HIP, "k_ms_wave failed"); }
         if (P.audit) {
             unsigned h[2] = {0, 0};

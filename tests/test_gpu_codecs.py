@@ -679,3 +679,27 @@ def test_stream_qoa_back_to_back_calls(ctx, oracle):
         r = oracle.stream_qoa(batches[k][0][3], k == 1, oracle.CUBIC)
         for c in range(r.channels):
             assert rms(ref[k][0][3][c] / 128, r.data[c] / 128) <= 1e-6, (k, c)
+
+
+@pytest.mark.parametrize("scan", ["look-ahead scan", "kernel flag"])
+def test_stream_msadpcm_predictor_index_beyond_the_table(ctx, oracle, monkeypatch, scan):
+    """aukit.stream.msadpcm (aukit.lua:2588-2736): a block header's predictor index selects a coefficient pair; beyond the table `c1` is nil and the
+    arithmetic raises.  One channel: every block uses the FIRST block's index (Q9) — the host looks at one byte per stream on the look-ahead stream
+    (round 6) instead of waiting for the kernel's flag; both ways raise the reference's error, and a clean batch decodes to the oracle's bytes either way."""
+    B, N = _B(), _N()
+    if scan == "kernel flag":
+        monkeypatch.setenv("AUKIT_MS_SCAN_OFF", "1")
+    good = [oracle.gen_msadpcm(pcm16(2036 * (3 + i), 44100, 3, 70 + i), 1, 1024) for i in range(5)]
+    desc = B.make_desc(N.CODEC_MSADPCM, 1, 44100, block_align=1024)
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, good), desc, "cubic", dtype=N.I8)
+    got = out.download()
+    for i, s in enumerate(good):
+        r = oracle.stream_msadpcm(s, 1024, 1, 44100, False, None, oracle.CUBIC)
+        assert ck.nchunks[i] == r.nchunks and np.array_equal(got[i][0], r.data[0]), i
+    bad = bytearray(good[2]); bad[0] = 7          # the default table has seven pairs: 0 .. 6
+    with pytest.raises(N.AukitError, match="local 'c1'"):
+        B.stream_decode(ctx, B.Batch.upload(ctx, good[:2] + [bytes(bad)] + good[3:]), desc, "cubic", dtype=N.I8)
+    later = bytearray(good[2]); later[1024] = 200  # a LATER block's index is never read (one channel: Q9)
+    out, ck = B.stream_decode(ctx, B.Batch.upload(ctx, [bytes(later)]), desc, "cubic", dtype=N.I8)
+    r = oracle.stream_msadpcm(bytes(later), 1024, 1, 44100, False, None, oracle.CUBIC)
+    assert np.array_equal(out.download()[0][0], r.data[0])
